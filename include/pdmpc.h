@@ -1,0 +1,204 @@
+/* pdmpc.h — C ABI of libpdmpc_hip.so: the MI355X (gfx950) backend for p-dmpc's
+ * per-vehicle graph-search trajectory optimizer.
+ *
+ * Drop-in boundary.  The reference selects its optimizer in
+ * hlc/optimizer/OptimizerInterface.m:19-34 (`get_optimizer`) and calls it through
+ *     info = run_optimizer(obj, veh_index, iter, mpa, options, time_step)   (OptimizerInterface.m:14)
+ * from hlc/controller/prioritized/PrioritizedController.m:335-341.  A MATLAB MEX shim (or a
+ * ctypes binding) marshals the 1-vehicle `iter` slice, the `mpa` tables and
+ * `options` into the plain structs below and calls pdmpc_plan_batch(); one vehicle per call is the
+ * literal `run_optimizer`, n vehicles per call is one computation level of
+ * hlc/controller/prioritized/PrioritizedSequentialController.m:83-91.
+ *
+ * Conventions
+ *  - every entry point returns an int status (PDMPC_OK == 0); no exceptions cross the ABI;
+ *  - all floating point is IEEE double, all indices that mirror MATLAB values are 1-based
+ *    (trim indices, tree node ids, tree_path) exactly as the reference stores them;
+ *  - the caller owns every host buffer; the library owns all device memory inside the handle;
+ *  - a handle is bound to one GPU and is not re-entrant (one call in flight per handle), which is
+ *    the reference's threading model (one blocking optimizer per controller process, main.m:43-60).
+ *  - polygons are stored as the reference stores them: 2 x V column lists [x; y] whose last column
+ *    repeats the first (closed), see generate_maneuver.m:46 and vectorize_all_obstacles.m:68-75.
+ */
+#ifndef PDMPC_H
+#define PDMPC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDMPC_HP_MAX 16 /* largest prediction horizon Hp accepted (BASELINE configs use 5..10) */
+#define PDMPC_VMAX 8    /* columns reserved per maneuver area (reference: 5, 6 or 7; generate_maneuver.m:74-101) */
+
+/* status codes (function results and pdmpc_vehicle_out.status) */
+enum {
+    PDMPC_OK = 0,
+    PDMPC_EXHAUSTED = 1,        /* per vehicle: open list ran empty == info.is_exhausted (GraphSearch.m:57-61) */
+    PDMPC_ARENA_OVERFLOW = 2,   /* per vehicle: search tree outgrew config.max_nodes (the reference tree is unbounded, Tree.m:54-70) */
+    PDMPC_ERR_INVALID = -1,     /* bad argument / inconsistent sizes */
+    PDMPC_ERR_NO_DEVICE = -2,   /* no gfx950 device, or the HIP code object failed to load */
+    PDMPC_ERR_HIP = -3,         /* a HIP runtime call failed; see pdmpc_last_error() */
+    PDMPC_ERR_CAPACITY = -4,    /* problem does not fit the per-vehicle LDS/HBM budget of this handle */
+    PDMPC_ERR_NO_MPA = -5       /* pdmpc_plan_* before pdmpc_upload_mpa */
+};
+
+/* constraint checker, chosen by OptimizerInterface.set_constraint_checker (OptimizerInterface.m:36-46)
+ * from Config.are_any_obstacles_non_convex (config/Config.m:71-87) */
+enum {
+    PDMPC_CHECK_SAT = 0,   /* are_constraints_satisfied_sat.m  (circle scenario / convex areas) */
+    PDMPC_CHECK_INTERX = 1 /* are_constraints_satisfied_interx.m + vectorize_all_obstacles.m (road networks) */
+};
+
+typedef struct pdmpc_handle pdmpc_handle;
+
+/* options.* fields read on the hot path (config/Config.m:32-33,47) plus backend sizing */
+typedef struct {
+    int32_t Hp;           /* options.Hp */
+    int32_t checker;      /* PDMPC_CHECK_* */
+    double dt_seconds;    /* options.dt_seconds (expand_node.m:70) */
+    int32_t device;       /* HIP device ordinal */
+    int32_t max_nodes;    /* per-vehicle tree capacity in HBM (0 = default 32768) */
+    int32_t max_vehicles; /* largest batch this handle will see (0 = default 256) */
+    int32_t trace_pops;   /* per-vehicle capacity of the debug pop trace (0 = off) */
+} pdmpc_config;
+
+/* One maneuver mpa.maneuvers{i,j} (generate_maneuver.m:25-66).  area* are [2][PDMPC_VMAX]
+ * row-major (row 0 = x, row 1 = y), the first n_cols columns valid. */
+typedef struct {
+    double dx, dy, dyaw;
+    int32_t n_cols;
+    int32_t _pad;
+    double area[2][PDMPC_VMAX];
+    double area_without_offset[2][PDMPC_VMAX];
+    double area_large_offset[2][PDMPC_VMAX];
+} pdmpc_maneuver;
+
+/* The MPA tables the search reads (MotionPrimitiveAutomaton.m:5-9). */
+typedef struct {
+    int32_t n_trims;               /* length(mpa.trims) */
+    int32_t Hp;                    /* size(transition_matrix_single, 3) */
+    const uint8_t* transition;     /* [Hp][n_trims][n_trims]: transition[k][i][j] = transition_matrix_single(i+1, j+1, k+1) */
+    const int32_t* maneuver_index; /* [n_trims][n_trims]: index into maneuvers[] or -1 where maneuvers{i,j} is empty */
+    int32_t n_maneuvers;
+    const pdmpc_maneuver* maneuvers;
+} pdmpc_mpa;
+
+/* A list of polygons/polylines: polygon p = columns offset[p] .. offset[p+1]-1 of (x, y). */
+typedef struct {
+    int32_t n_polygons;
+    const int32_t* offset; /* [n_polygons + 1] */
+    const double* x;
+    const double* y;
+} pdmpc_polygon_set;
+
+/* The 1-vehicle IterationData slice (hlc/controller/common/IterationData.m:4-33, filter :95-114)
+ * as PrioritizedController.plan hands it to run_optimizer (PrioritizedController.m:297-341). */
+typedef struct {
+    double x0, y0, yaw0;  /* iter.x0(1, 1:3) */
+    int32_t trim0;        /* iter.trim_indices (1-based) */
+    int32_t n_left;       /* columns of predicted_lanelet_boundary{1,1} (0 = empty, circle scenario) */
+    int32_t n_right;      /* columns of predicted_lanelet_boundary{1,2} */
+    int32_t _pad;
+    const double* ref_x;  /* [Hp] iter.reference_trajectory_points(1, :, 1) */
+    const double* ref_y;  /* [Hp] iter.reference_trajectory_points(1, :, 2) */
+    const double* v_ref;  /* [Hp] iter.v_ref(1, :) */
+    const double* left_x; /* left boundary polyline */
+    const double* left_y;
+    const double* right_x;
+    const double* right_y;
+    pdmpc_polygon_set obstacles;          /* iter.obstacles: n_s polygons */
+    pdmpc_polygon_set dynamic_obstacles;  /* iter.dynamic_obstacle_area: n_d x Hp cell, polygon index = i*Hp + (k-1) */
+    pdmpc_polygon_set hdv_reachable_sets; /* iter.hdv_reachable_sets(adjacent, :): n_h x Hp, same indexing (InterX only) */
+} pdmpc_vehicle_in;
+
+/* ControlResultsInfo for one vehicle (hlc/controller/common/ControlResultsInfo.m:5-17) in the
+ * fixed-stride form create_control_results_info_from_mex expects (OptimizerInterface.m:63-101). */
+typedef struct {
+    int32_t status;      /* PDMPC_OK / PDMPC_EXHAUSTED / PDMPC_ARENA_OVERFLOW */
+    int32_t n_expanded;  /* info.n_expanded == tree size (GraphSearch.m:58,89) */
+    int32_t n_popped;    /* nodes taken from the open list, incl. rejected ones */
+    int32_t n_hp;        /* Hp this record was written for */
+    int32_t tree_path[PDMPC_HP_MAX + 1];   /* info.tree_path, 1-based node ids (GraphSearch.m:84) */
+    int32_t predicted_trims[PDMPC_HP_MAX]; /* info.predicted_trims (GraphSearch.m:86) */
+    int32_t shape_cols[PDMPC_HP_MAX];      /* columns of info.shapes{1,k} */
+    int32_t _pad;
+    double y_predicted[PDMPC_HP_MAX][3];   /* info.y_predicted(:, k, 1) = [x; y; yaw] (return_path_to.m:14-23); NaN if exhausted */
+    double shapes[PDMPC_HP_MAX][2][PDMPC_VMAX]; /* info.shapes{1,k} (return_path_area.m:1-8) */
+    double path_nodes[PDMPC_HP_MAX + 1][8]; /* rows in NodeInfo order x,y,yaw,trim,g,h,k,exactEval (NodeInfo.m:4-13) */
+} pdmpc_vehicle_out;
+
+/* counters of the last pdmpc_plan_* call, summed over the batch (feeds the roofline formula) */
+typedef struct {
+    int64_t n_vehicles;
+    int64_t nodes_popped;
+    int64_t nodes_generated;  /* children created (tree size minus roots) */
+    int64_t obstacle_columns; /* sum over plans and steps of the obstacle-soup columns + boundary columns */
+    int64_t algorithmic_bytes;/* SURVEY.md 8(d) formula evaluated for the call */
+    double kernel_ms;         /* duration of the search kernel measured with HIP events on the launch stream */
+    int64_t lds_bytes;        /* dynamic LDS per workgroup used by the launch */
+    int64_t lds_nodes;        /* tree nodes resident in LDS per vehicle */
+    int64_t n_launches;       /* kernel launches since the last pdmpc_pack_* (kernel_ms is their sum) */
+} pdmpc_stats;
+
+/* ---- life cycle (replaces GraphSearch() construction in OptimizerInterface.get_optimizer, :26-27,
+ *      and the MEX instance table of priority_queue_interface_mex.cpp:48-53,111) ---- */
+int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle);
+int pdmpc_destroy(pdmpc_handle* handle);
+
+/* uploads mpa.maneuvers / mpa.transition_matrix_single once (MotionPrimitiveAutomaton.m:5-9) */
+int pdmpc_upload_mpa(pdmpc_handle* handle, const pdmpc_mpa* mpa);
+
+/* Plans n independent vehicles (one computation level).  Blocking.  With n == 1 this is
+ * GraphSearch.run_optimizer (GraphSearch.m:14-17). */
+int pdmpc_plan_batch(pdmpc_handle* handle, int32_t n_vehicles, const pdmpc_vehicle_in* in,
+                     pdmpc_vehicle_out* out);
+
+/* ---- device-resident path used by the batched host driver and bench.py ----
+ * pdmpc_pack_batch flattens host inputs into the handle's device blob (H2D copy, async on the
+ * handle's stream); pdmpc_launch_packed runs the search kernel on whatever is packed (no copies);
+ * pdmpc_fetch_results copies the result records back.  pdmpc_plan_batch == pack + launch + fetch. */
+int pdmpc_pack_batch(pdmpc_handle* handle, int32_t n_vehicles, const pdmpc_vehicle_in* in);
+int pdmpc_launch_packed(pdmpc_handle* handle);
+/* launches only slots [first, first + count) of the packed batch: one computation level, or one GPU's shard of it */
+int pdmpc_launch_range(pdmpc_handle* handle, int32_t first, int32_t count);
+int pdmpc_fetch_results(pdmpc_handle* handle, int32_t n_vehicles, pdmpc_vehicle_out* out);
+int pdmpc_synchronize(pdmpc_handle* handle);
+
+/* Step-level planning (PrioritizedSequentialController.controller, :77-94): all vehicles of a
+ * time step in ONE launch.  pred_offset/pred_index (CSR over vehicles, 0-based vehicle indices of
+ * this batch) list each vehicle's sequential predecessors; their solved info.shapes(1,:) are appended
+ * on the device to the vehicle's dynamic obstacles (PrioritizedController.m:476-491) before it plans.
+ * fallback_shapes (may be NULL) gives, per vehicle, the Hp areas published when its search is
+ * exhausted (PrioritizedController.m:568-616,678-718): [n][Hp] pdmpc_polygon_set-style via offsets. */
+int pdmpc_pack_step(pdmpc_handle* handle, int32_t n_vehicles, const pdmpc_vehicle_in* in,
+                    const int32_t* pred_offset, const int32_t* pred_index,
+                    const pdmpc_polygon_set* fallback_shapes);
+
+/* raw device pointer + byte size of the packed result records (pdmpc_vehicle_out[n]) for exchange
+ * between GPUs (RCCL all-gather of solved areas) */
+int pdmpc_result_device_buffer(pdmpc_handle* handle, void** dev_ptr, size_t* nbytes);
+/* make result records produced elsewhere (e.g. gathered from another GPU into dev_ptr) visible as
+ * predecessor outputs: copies n records into slots [first, first+n) of the handle's result buffer */
+int pdmpc_import_results(pdmpc_handle* handle, int32_t first, int32_t n, const void* dev_records);
+
+int pdmpc_get_last_stats(pdmpc_handle* handle, pdmpc_stats* stats);
+
+/* ---- debug / parity instrumentation (no reference counterpart: the reference keeps the whole
+ *      Tree in info.tree, Tree.m:3-13; these calls read it back from HBM) ---- */
+/* node ids popped by vehicle v in order (needs config.trace_pops > 0); returns count in *n */
+int pdmpc_debug_pop_trace(pdmpc_handle* handle, int32_t vehicle, int32_t capacity, int32_t* ids, int32_t* n);
+/* the search tree of vehicle v: arrays of length capacity, *n receives tree size */
+int pdmpc_debug_tree(pdmpc_handle* handle, int32_t vehicle, int32_t capacity, double* x, double* y,
+                     double* yaw, double* g, double* h, int32_t* trim, int32_t* k, int32_t* parent,
+                     int32_t* n);
+
+const char* pdmpc_last_error(void);
+const char* pdmpc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDMPC_H */

@@ -1,0 +1,202 @@
+"""ctypes binding of the CPU oracle (oracle/pdmpc_oracle.cpp).  TEST INFRASTRUCTURE ONLY.
+
+Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.  It reuses the
+struct definitions of the product's ABI mirror (pdmpc.abi) so both sides receive byte-identical inputs;
+the product never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+if os.path.join(_ROOT, "p-dmpc_amd") not in sys.path:
+    sys.path.insert(0, os.path.join(_ROOT, "p-dmpc_amd"))
+
+from pdmpc import abi  # noqa: E402
+from pdmpc.iteration_data import info_from_record  # noqa: E402
+
+_LIB = None
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+
+
+class TraceOut(C.Structure):
+    _fields_ = [
+        ("pop_capacity", C.c_int32),
+        ("n_pops", C.c_int32),
+        ("pops", abi.c_int32_p),
+        ("tree_capacity", C.c_int32),
+        ("n_nodes", C.c_int32),
+        ("x", abi.c_double_p),
+        ("y", abi.c_double_p),
+        ("yaw", abi.c_double_p),
+        ("g", abi.c_double_p),
+        ("h", abi.c_double_p),
+        ("trim", abi.c_int32_p),
+        ("k", abi.c_int32_p),
+        ("parent", abi.c_int32_p),
+    ]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libpdmpc_oracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        dp, ip = abi.c_double_p, abi.c_int32_p
+        L.oracle_intersect_sat.argtypes = [dp, dp, C.c_int, dp, dp, C.c_int]
+        L.oracle_intersect_lanelet_boundary.argtypes = [dp, dp, C.c_int, dp, dp, C.c_int, dp, dp, C.c_int]
+        L.oracle_intersect_lanelets.argtypes = [dp, dp, C.c_int, dp, C.c_int]
+        L.oracle_interx.argtypes = [dp, dp, C.c_int, dp, dp, C.c_int]
+        L.oracle_pq_script.argtypes = [ip, ip, dp, C.c_int, ip]
+        L.oracle_sincos.argtypes = [dp, C.c_int, dp, dp]
+        L.oracle_sincos.restype = None
+        L.oracle_plan_batch.argtypes = [
+            C.POINTER(abi.Config),
+            C.POINTER(abi.Mpa),
+            C.c_int,
+            C.POINTER(abi.VehicleIn),
+            C.POINTER(abi.VehicleOut),
+            C.POINTER(TraceOut),
+            C.c_int,
+            C.POINTER(C.c_double),
+        ]
+        _LIB = L
+    return _LIB
+
+
+def _xy(p):
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    x = np.ascontiguousarray(p[0])
+    y = np.ascontiguousarray(p[1])
+    return x, y, x.ctypes.data_as(abi.c_double_p), y.ctypes.data_as(abi.c_double_p), p.shape[1]
+
+
+def intersect_sat(s1, s2):
+    x1, y1, px1, py1, n1 = _xy(s1)
+    x2, y2, px2, py2, n2 = _xy(s2)
+    return bool(lib().oracle_intersect_sat(px1, py1, n1, px2, py2, n2))
+
+
+def intersect_lanelet_boundary(shape, left, right):
+    xs, ys, pxs, pys, n = _xy(shape)
+    xl, yl, pxl, pyl, nl = _xy(left) if np.size(left) else (None, None, None, None, 0)
+    xr, yr, pxr, pyr, nr = _xy(right) if np.size(right) else (None, None, None, None, 0)
+    return bool(lib().oracle_intersect_lanelet_boundary(pxs, pys, n, pxl, pyl, nl, pxr, pyr, nr))
+
+
+def intersect_lanelets(shape, lanelet_rows):
+    xs, ys, pxs, pys, n = _xy(shape)
+    rows = np.ascontiguousarray(lanelet_rows, dtype=np.float64)
+    assert rows.shape[1] == 6
+    return bool(lib().oracle_intersect_lanelets(pxs, pys, n, rows.ctypes.data_as(abi.c_double_p), rows.shape[0]))
+
+
+def interx(L1, L2):
+    x1, y1, px1, py1, n1 = _xy(L1)
+    x2, y2, px2, py2, n2 = _xy(L2)
+    return bool(lib().oracle_interx(px1, py1, n1, px2, py2, n2))
+
+
+def pq_script(ops, ids, keys):
+    ops = np.ascontiguousarray(ops, dtype=np.int32)
+    ids = np.ascontiguousarray(ids, dtype=np.int32)
+    keys = np.ascontiguousarray(keys, dtype=np.float64)
+    out = np.zeros(max(int((ops == 1).sum()), 1), dtype=np.int32)
+    n = lib().oracle_pq_script(
+        ops.ctypes.data_as(abi.c_int32_p),
+        ids.ctypes.data_as(abi.c_int32_p),
+        keys.ctypes.data_as(abi.c_double_p),
+        len(ops),
+        out.ctypes.data_as(abi.c_int32_p),
+    )
+    return out[:n]
+
+
+def sincos(x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    s = np.zeros_like(x)
+    c = np.zeros_like(x)
+    lib().oracle_sincos(x.ctypes.data_as(abi.c_double_p), x.size, s.ctypes.data_as(abi.c_double_p), c.ctypes.data_as(abi.c_double_p))
+    return s, c
+
+
+class Trace:
+    def __init__(self, pops, tree):
+        self.pops = pops
+        self.tree = tree  # dict of arrays x,y,yaw,g,h,trim,k,parent
+
+
+def make_abi_config(options, checker=None):
+    return abi.Config(
+        Hp=options.Hp,
+        checker=(abi.CHECK_INTERX if options.are_any_obstacles_non_convex else abi.CHECK_SAT) if checker is None else checker,
+        dt_seconds=options.dt_seconds,
+        device=options.device,
+        max_nodes=options.max_nodes,
+        max_vehicles=options.max_vehicles,
+        trace_pops=options.trace_pops,
+    )
+
+
+def plan_batch_raw(options, mpa_struct, veh_arr, n, n_threads=1, trace=False, trace_capacity=1 << 16):
+    """Low-level: returns (records, traces or None, elapsed_ms)."""
+    cfg = make_abi_config(options)
+    out = abi.out_array(n)
+    tr_arr = None
+    bufs = []
+    if trace:
+        tr_arr = (TraceOut * max(n, 1))()
+        for i in range(n):
+            b = {
+                "pops": np.zeros(trace_capacity, dtype=np.int32),
+                "x": np.zeros(trace_capacity),
+                "y": np.zeros(trace_capacity),
+                "yaw": np.zeros(trace_capacity),
+                "g": np.zeros(trace_capacity),
+                "h": np.zeros(trace_capacity),
+                "trim": np.zeros(trace_capacity, dtype=np.int32),
+                "k": np.zeros(trace_capacity, dtype=np.int32),
+                "parent": np.zeros(trace_capacity, dtype=np.int32),
+            }
+            bufs.append(b)
+            t = tr_arr[i]
+            t.pop_capacity = trace_capacity
+            t.tree_capacity = trace_capacity
+            t.pops = b["pops"].ctypes.data_as(abi.c_int32_p)
+            for name in ("x", "y", "yaw", "g", "h"):
+                setattr(t, name, b[name].ctypes.data_as(abi.c_double_p))
+            for name in ("trim", "k", "parent"):
+                setattr(t, name, b[name].ctypes.data_as(abi.c_int32_p))
+    elapsed = C.c_double(0.0)
+    rc = lib().oracle_plan_batch(C.byref(cfg), C.byref(mpa_struct), n, veh_arr, abi.out_ptr(out), tr_arr, n_threads, C.byref(elapsed))
+    if rc != 0:
+        raise RuntimeError("oracle_plan_batch failed: %d" % rc)
+    traces = None
+    if trace:
+        traces = []
+        for i in range(n):
+            t = tr_arr[i]
+            npop = min(t.n_pops, trace_capacity)
+            nn = min(t.n_nodes, trace_capacity)
+            b = bufs[i]
+            traces.append(Trace(b["pops"][:npop].copy(), {k: b[k][:nn].copy() for k in ("x", "y", "yaw", "g", "h", "trim", "k", "parent")}))
+    return out[:n], traces, elapsed.value
+
+
+def plan_batch(options, mpa, iters, n_threads=1, trace=False):
+    """Plan a list of VehicleIter with the oracle -> (list[ControlResultsInfo], records, traces)."""
+    mpa_struct, keep_m = abi.pack_mpa(mpa)
+    arr, keep_v = abi.pack_vehicles(iters, options.Hp)
+    recs, traces, _ = plan_batch_raw(options, mpa_struct, arr, len(iters), n_threads=n_threads, trace=trace)
+    infos = [info_from_record(recs[i], options.Hp) for i in range(len(iters))]
+    del keep_m, keep_v
+    return infos, recs, traces

@@ -1,0 +1,696 @@
+// api.cpp — host side of libpdmpc_hip.so: the C ABI declared in include/pdmpc.h.
+//
+// Responsibilities: own all device memory of a handle, flatten the caller's IterationData slices into
+// the pointer-free HBM blob of pdmpc_device.h (this is where vectorize_all_obstacles.m:36-62's
+// "[polygon, NaN]" concatenation happens for literal obstacles), size the LDS regions, launch the search
+// kernel on the handle's stream and time it with HIP events, copy results back.
+// There is no CPU implementation of the search in this library: without a gfx950 device every planning
+// entry point fails with PDMPC_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/pdmpc.h"
+#include "pdmpc_device.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                 \
+    do {                                                                                             \
+        hipError_t e__ = (expr);                                                                     \
+        if (e__ != hipSuccess) {                                                                     \
+            char buf__[512];                                                                         \
+            snprintf(buf__, sizeof buf__, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return fail(PDMPC_ERR_HIP, buf__);                                                       \
+        }                                                                                            \
+    } while (0)
+
+inline uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;  // elements
+    int ensure(size_t n) {
+        if (n <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = std::max(n, (size_t)64);
+        want += want / 2;
+        hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+        if (e != hipSuccess) return (int)e;
+        cap = want;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+template <class T>
+struct PinnedBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return 0;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = std::max(n, (size_t)64);
+        want += want / 2;
+        hipError_t e = hipHostMalloc((void**)&p, want * sizeof(T), hipHostMallocDefault);
+        if (e != hipSuccess) return (int)e;
+        cap = want;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+const size_t kLdsMax = 160 * 1024;  // gfx950: 160 KiB per CU (MI355X_MICROARCH.md)
+
+}  // namespace
+
+struct pdmpc_handle {
+    pdmpc_config cfg{};
+    hipStream_t stream = nullptr;
+    int n_cu = 256;
+    // MPA
+    bool has_mpa = false;
+    int n_trims = 0, n_words = 0, n_man = 0;
+    DevBuf<uint64_t> d_mask;
+    DevBuf<int16_t> d_mi;
+    DevBuf<DevManPose> d_pose;
+    DevBuf<double> d_area;
+    size_t mask_bytes = 0, mi_bytes = 0;
+    int64_t mpa_alg_bytes = 0;
+    // arenas
+    uint32_t max_nodes = 0;
+    int max_vehicles = 0;
+    DevBuf<double> ax, ay, ayaw, ag, ah, acs, asn, ahk;
+    DevBuf<uint32_t> aparent, ahid;
+    DevBuf<uint16_t> atk;
+    DevBuf<pdmpc_vehicle_out> d_out;
+    DevBuf<uint32_t> d_flag;
+    DevBuf<int32_t> d_tree_size;
+    DevBuf<int32_t> d_trace;
+    // batch blob
+    PinnedBuf<DevVehicle> h_veh;
+    PinnedBuf<double> h_pts;
+    PinnedBuf<int32_t> h_pred;
+    DevBuf<DevVehicle> d_veh;
+    DevBuf<double> d_pts;
+    DevBuf<int32_t> d_pred;
+    int n_packed = 0;
+    int soup_cap = 0;
+    uint32_t epoch = 0;
+    std::vector<int64_t> lit_cols;  // per vehicle: literal soup + boundary columns (for the bytes formula)
+    // launches
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t events_used = 0;
+    LdsLayout lds{};
+    int HL = 0, NL = 0, areas_in_lds = 0;
+    pdmpc_stats stats{};
+};
+
+namespace {
+
+int compute_lds(pdmpc_handle* h, int n_launch) {
+    const int Hp = h->cfg.Hp;
+    const size_t budget = (n_launch > h->n_cu) ? kLdsMax / 2 : kLdsMax;
+    LdsLayout L{};
+    uint32_t off = 0;
+    L.mask = off;
+    off = align16(off + (uint32_t)h->mask_bytes);
+    L.man_index = off;
+    off = align16(off + (uint32_t)h->mi_bytes);
+    L.pose = off;
+    off = align16(off + (uint32_t)(h->n_man * sizeof(DevManPose)));
+    const uint32_t area_bytes = (uint32_t)(h->n_man * 3 * PDMPC_VMAX * 16);
+    // fixed part after the tables
+    const uint32_t ref_bytes = 3 * PDMPC_HP_MAX * 8;
+    const uint32_t shape_bytes = 2 * PDMPC_VMAX * 16;
+    const uint32_t path_bytes = align16((PDMPC_HP_MAX + 2) * 4 + 2 * (PDMPC_HP_MAX + 1) * 4);
+    const uint32_t soup_bytes = (uint32_t)std::max(h->soup_cap, 1) * 16;
+    const uint32_t fixed_rest = ref_bytes + shape_bytes + path_bytes + soup_bytes;
+    const uint32_t per_entry = 8 + 4 + 7 * 8 + 4 + 2;  // heap key+id, node doubles, parent, tk
+    const uint32_t min_entries = 64;
+    int areas = 1;
+    if ((size_t)off + area_bytes + fixed_rest + (size_t)min_entries * per_entry + 256 > budget) areas = 0;
+    L.area = off;
+    if (areas) off = align16(off + area_bytes);
+    L.ref = off;
+    off += ref_bytes;
+    L.shape = off;
+    off += shape_bytes;
+    L.path = off;
+    off += path_bytes;
+    L.soup = off;
+    off = align16(off + soup_bytes);
+    if ((size_t)off + (size_t)min_entries * per_entry + 256 > budget) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "obstacle soup (%d columns) + MPA tables need %u B of LDS, budget %zu B", h->soup_cap, off, budget);
+        return fail(PDMPC_ERR_CAPACITY, buf);
+    }
+    uint32_t entries = (uint32_t)((budget - off - 256) / per_entry);
+    entries = std::min(entries, (uint32_t)4096);
+    entries = std::min(entries, h->max_nodes);
+    entries &= ~1u;  // keep every region 16-byte aligned
+    const uint32_t e8 = align16(entries * 8), e4 = align16(entries * 4), e2 = align16(entries * 2);
+    L.heap_key = off;
+    off += e8;
+    L.heap_id = off;
+    off += e4;
+    L.nx = off;
+    off += e8;
+    L.ny = off;
+    off += e8;
+    L.nyaw = off;
+    off += e8;
+    L.ng = off;
+    off += e8;
+    L.nh = off;
+    off += e8;
+    L.ncs = off;
+    off += e8;
+    L.nsn = off;
+    off += e8;
+    L.nparent = off;
+    off += e4;
+    L.ntk = off;
+    off += e2;
+    L.total = align16(off);
+    if (L.total > budget) return fail(PDMPC_ERR_CAPACITY, "internal: LDS layout exceeds budget");
+    h->lds = L;
+    h->HL = (int)entries;
+    h->NL = (int)entries;
+    h->areas_in_lds = areas;
+    (void)Hp;
+    return PDMPC_OK;
+}
+
+inline void push_pt(std::vector<double>& pts, double x, double y) {
+    pts.push_back(x);
+    pts.push_back(y);
+}
+
+int check_set(const pdmpc_polygon_set& s, const char* what) {
+    if (s.n_polygons < 0) return fail(PDMPC_ERR_INVALID, std::string(what) + ": negative polygon count");
+    if (s.n_polygons > 0 && (!s.offset || !s.x || !s.y)) return fail(PDMPC_ERR_INVALID, std::string(what) + ": null pointer");
+    for (int i = 0; i < s.n_polygons; ++i)
+        if (s.offset[i + 1] < s.offset[i]) return fail(PDMPC_ERR_INVALID, std::string(what) + ": offsets not monotone");
+    return PDMPC_OK;
+}
+
+int pack_common(pdmpc_handle* h, int n, const pdmpc_vehicle_in* in, const int32_t* pred_offset, const int32_t* pred_index,
+                const pdmpc_polygon_set* fallback) {
+    if (!h) return fail(PDMPC_ERR_INVALID, "null handle");
+    if (!h->has_mpa) return fail(PDMPC_ERR_NO_MPA, "pdmpc_upload_mpa has not been called");
+    if (n < 0 || (n > 0 && !in)) return fail(PDMPC_ERR_INVALID, "bad vehicle array");
+    if (n > h->max_vehicles) return fail(PDMPC_ERR_CAPACITY, "batch larger than config.max_vehicles");
+    const int Hp = h->cfg.Hp;
+    const double qnan = std::numeric_limits<double>::quiet_NaN();
+    std::vector<double> pts;
+    pts.reserve((size_t)n * 256);
+    std::vector<int32_t> pred;
+    if (h->h_veh.ensure((size_t)std::max(n, 1))) return fail(PDMPC_ERR_HIP, "hipHostMalloc failed");
+    h->lit_cols.assign((size_t)n, 0);
+    int soup_cap = 0;
+    for (int i = 0; i < n; ++i) {
+        const pdmpc_vehicle_in& v = in[i];
+        DevVehicle& d = h->h_veh.p[i];
+        std::memset(&d, 0, sizeof d);
+        if (!v.ref_x || !v.ref_y || !v.v_ref) return fail(PDMPC_ERR_INVALID, "reference trajectory missing");
+        if (v.trim0 < 1 || v.trim0 > h->n_trims) return fail(PDMPC_ERR_INVALID, "trim0 out of range");
+        int rc;
+        if ((rc = check_set(v.obstacles, "obstacles"))) return rc;
+        if ((rc = check_set(v.dynamic_obstacles, "dynamic_obstacles"))) return rc;
+        if ((rc = check_set(v.hdv_reachable_sets, "hdv_reachable_sets"))) return rc;
+        if (v.dynamic_obstacles.n_polygons % Hp) return fail(PDMPC_ERR_INVALID, "dynamic_obstacles must hold n_d * Hp polygons");
+        if (v.hdv_reachable_sets.n_polygons % Hp) return fail(PDMPC_ERR_INVALID, "hdv_reachable_sets must hold n_h * Hp polygons");
+        if (v.n_left < 0 || v.n_right < 0 || v.n_left == 1 || v.n_right == 1)
+            return fail(PDMPC_ERR_INVALID, "lanelet boundary needs 0 or >= 2 points per side");
+        d.x0 = v.x0;
+        d.y0 = v.y0;
+        d.yaw0 = v.yaw0;
+        d.trim0 = v.trim0;
+        for (int k = 0; k < Hp; ++k) {
+            d.ref_x[k] = v.ref_x[k];
+            d.ref_y[k] = v.ref_y[k];
+            d.v_ref[k] = v.v_ref[k];
+        }
+        const int n_pred = pred_offset ? pred_offset[i + 1] - pred_offset[i] : 0;
+        d.n_pred = n_pred;
+        d.pred_off = (int32_t)pred.size();
+        for (int q = 0; q < n_pred; ++q) {
+            const int ps = pred_index[pred_offset[i] + q];
+            if (ps < 0 || ps >= h->max_vehicles) return fail(PDMPC_ERR_INVALID, "predecessor slot out of range");
+            pred.push_back(ps);
+        }
+        const int n_dyn = v.dynamic_obstacles.n_polygons / Hp;
+        const int n_hdv = v.hdv_reachable_sets.n_polygons / Hp;
+        auto append_poly = [&](const pdmpc_polygon_set& s, int p, bool sep) {
+            for (int q = s.offset[p]; q < s.offset[p + 1]; ++q) push_pt(pts, s.x[q], s.y[q]);
+            if (sep) push_pt(pts, qnan, qnan);
+        };
+        int need = 0;
+        // vehicle_obstacles{k} = [static..., dynamic(:, k)...], each followed by [NaN; NaN]   vectorize_all_obstacles.m:36-62
+        for (int k = 0; k < Hp; ++k) {
+            d.lit_off[k] = (int32_t)(pts.size() / 2);
+            for (int p = 0; p < v.obstacles.n_polygons; ++p) append_poly(v.obstacles, p, true);
+            for (int r = 0; r < n_dyn; ++r) append_poly(v.dynamic_obstacles, r * Hp + k, true);
+            need += (int)(pts.size() / 2) - d.lit_off[k] + n_pred * PDMPC_VMAX;
+        }
+        d.lit_off[Hp] = (int32_t)(pts.size() / 2);
+        h->lit_cols[i] = d.lit_off[Hp] - d.lit_off[0];
+        for (int k = 0; k < Hp; ++k) {
+            d.hdv_off[k] = (int32_t)(pts.size() / 2);
+            for (int r = 0; r < n_hdv; ++r) append_poly(v.hdv_reachable_sets, r * Hp + k, true);
+        }
+        d.hdv_off[Hp] = (int32_t)(pts.size() / 2);
+        need += d.hdv_off[Hp] - d.hdv_off[0];
+        // lanelet_boundary = [left, NaN, right, NaN]                                          vectorize_all_obstacles.m:27-30
+        d.ll_off = (int32_t)(pts.size() / 2);
+        for (int q = 0; q < v.n_left; ++q) push_pt(pts, v.left_x[q], v.left_y[q]);
+        push_pt(pts, qnan, qnan);
+        for (int q = 0; q < v.n_right; ++q) push_pt(pts, v.right_x[q], v.right_y[q]);
+        push_pt(pts, qnan, qnan);
+        d.ll_len = (int32_t)(pts.size() / 2) - d.ll_off;
+        need += d.ll_len;
+        h->lit_cols[i] += d.ll_len;
+        if (fallback && fallback[i].n_polygons > 0) {
+            if (fallback[i].n_polygons != Hp) return fail(PDMPC_ERR_INVALID, "fallback_shapes must hold Hp polygons per vehicle");
+            int rc2;
+            if ((rc2 = check_set(fallback[i], "fallback_shapes"))) return rc2;
+            for (int k = 0; k < Hp; ++k) {
+                d.fb_off[k] = (int32_t)(pts.size() / 2);
+                if (fallback[i].offset[k + 1] - fallback[i].offset[k] > PDMPC_VMAX)
+                    return fail(PDMPC_ERR_INVALID, "fallback area has more than PDMPC_VMAX columns");
+                append_poly(fallback[i], k, false);
+            }
+            d.fb_off[Hp] = (int32_t)(pts.size() / 2);
+        } else {
+            for (int k = 0; k <= Hp; ++k) d.fb_off[k] = -1;
+        }
+        soup_cap = std::max(soup_cap, need);
+    }
+    // a trailing pad so 16-byte staged copies never run past the allocation
+    push_pt(pts, qnan, qnan);
+    pred.push_back(0);
+    h->soup_cap = soup_cap + 2;
+    if (h->h_pts.ensure(pts.size()) || h->h_pred.ensure(pred.size())) return fail(PDMPC_ERR_HIP, "hipHostMalloc failed");
+    std::memcpy(h->h_pts.p, pts.data(), pts.size() * sizeof(double));
+    std::memcpy(h->h_pred.p, pred.data(), pred.size() * sizeof(int32_t));
+    if (h->d_veh.ensure((size_t)std::max(n, 1)) || h->d_pts.ensure(pts.size()) || h->d_pred.ensure(pred.size()))
+        return fail(PDMPC_ERR_HIP, "hipMalloc failed for the batch blob");
+    if (n > 0) HIPCHK(hipMemcpyAsync(h->d_veh.p, h->h_veh.p, (size_t)n * sizeof(DevVehicle), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_pts.p, h->h_pts.p, pts.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_pred.p, h->h_pred.p, pred.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    // the pinned staging buffers are reused by the next pack: finish the copies first
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->n_packed = n;
+    h->epoch += 1;
+    h->events_used = 0;
+    std::memset(&h->stats, 0, sizeof h->stats);
+    return PDMPC_OK;
+}
+
+int launch_range(pdmpc_handle* h, int first, int count) {
+    if (!h) return fail(PDMPC_ERR_INVALID, "null handle");
+    if (first < 0 || count < 0 || first + count > h->n_packed) return fail(PDMPC_ERR_INVALID, "launch range outside the packed batch");
+    if (count == 0) return PDMPC_OK;
+    int rc = compute_lds(h, count);
+    if (rc) return rc;
+    KernelArgs a{};
+    a.succ_mask = h->d_mask.p;
+    a.man_index = h->d_mi.p;
+    a.man_pose = h->d_pose.p;
+    a.man_area = h->d_area.p;
+    a.n_trims = h->n_trims;
+    a.n_words = h->n_words;
+    a.n_man = h->n_man;
+    a.Hp = h->cfg.Hp;
+    a.checker = h->cfg.checker;
+    a.areas_in_lds = h->areas_in_lds;
+    a.dt = h->cfg.dt_seconds;
+    a.veh = h->d_veh.p;
+    a.points = h->d_pts.p;
+    a.pred = h->d_pred.p;
+    a.out = h->d_out.p;
+    a.done_flag = h->d_flag.p;
+    a.epoch = h->epoch;
+    a.first = first;
+    a.arena.x = h->ax.p;
+    a.arena.y = h->ay.p;
+    a.arena.yaw = h->ayaw.p;
+    a.arena.g = h->ag.p;
+    a.arena.h = h->ah.p;
+    a.arena.cs = h->acs.p;
+    a.arena.sn = h->asn.p;
+    a.arena.parent = h->aparent.p;
+    a.arena.tk = h->atk.p;
+    a.arena.heap_key = h->ahk.p;
+    a.arena.heap_id = h->ahid.p;
+    a.max_nodes = h->max_nodes;
+    a.pop_trace = h->d_trace.p;
+    a.trace_cap = h->cfg.trace_pops;
+    a.tree_size = h->d_tree_size.p;
+    a.lds = h->lds;
+    a.HL = h->HL;
+    a.NL = h->NL;
+    a.soup_cap = h->soup_cap;
+    a.spin_limit = 1u << 22;
+    if (h->events_used == h->events.size()) {
+        hipEvent_t e0, e1;
+        HIPCHK(hipEventCreate(&e0));
+        HIPCHK(hipEventCreate(&e1));
+        h->events.emplace_back(e0, e1);
+    }
+    auto& ev = h->events[h->events_used++];
+    HIPCHK(hipEventRecord(ev.first, h->stream));
+    int lrc = pdmpc_launch_search(&a, count, (void*)h->stream);
+    if (lrc != 0) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "kernel launch failed: %s (LDS %u B)", hipGetErrorString((hipError_t)lrc), h->lds.total);
+        return fail(PDMPC_ERR_HIP, buf);
+    }
+    HIPCHK(hipEventRecord(ev.second, h->stream));
+    h->stats.lds_bytes = h->lds.total;
+    h->stats.lds_nodes = h->NL;
+    return PDMPC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pdmpc_last_error(void) { return g_err.c_str(); }
+const char* pdmpc_version(void) { return "pdmpc-hip 0.1 (gfx950)"; }
+
+int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
+    if (!config || !out_handle) return fail(PDMPC_ERR_INVALID, "null argument");
+    if (config->Hp < 1 || config->Hp > PDMPC_HP_MAX) return fail(PDMPC_ERR_INVALID, "Hp must be in 1..PDMPC_HP_MAX");
+    if (config->checker != PDMPC_CHECK_SAT && config->checker != PDMPC_CHECK_INTERX) return fail(PDMPC_ERR_INVALID, "unknown checker");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(PDMPC_ERR_NO_DEVICE, "no HIP device visible: this backend has no CPU fallback");
+    if (config->device < 0 || config->device >= ndev) return fail(PDMPC_ERR_NO_DEVICE, "device ordinal out of range");
+    HIPCHK(hipSetDevice(config->device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, config->device));
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+        return fail(PDMPC_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    pdmpc_handle* h = new pdmpc_handle();
+    h->cfg = *config;
+    h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    h->max_nodes = config->max_nodes > 0 ? (uint32_t)config->max_nodes : 32768u;  // default arena: 256 x 32768 nodes, about 0.6 GB
+    h->max_nodes = (h->max_nodes + 1u) & ~1u;
+    h->max_vehicles = config->max_vehicles > 0 ? config->max_vehicles : 256;
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete h;
+        return fail(PDMPC_ERR_HIP, "hipStreamCreate failed");
+    }
+    const size_t tot = (size_t)h->max_vehicles * h->max_nodes;
+    int bad = 0;
+    bad |= h->ax.ensure(tot) | h->ay.ensure(tot) | h->ayaw.ensure(tot) | h->ag.ensure(tot) | h->ah.ensure(tot);
+    bad |= h->acs.ensure(tot) | h->asn.ensure(tot) | h->ahk.ensure(tot);
+    bad |= h->aparent.ensure(tot) | h->ahid.ensure(tot) | h->atk.ensure(tot);
+    bad |= h->d_out.ensure((size_t)h->max_vehicles) | h->d_flag.ensure((size_t)h->max_vehicles) | h->d_tree_size.ensure((size_t)h->max_vehicles);
+    bad |= h->d_trace.ensure((size_t)h->max_vehicles * (size_t)std::max(config->trace_pops, 1));
+    if (bad) {
+        pdmpc_destroy(h);
+        return fail(PDMPC_ERR_HIP, "hipMalloc failed for the per-vehicle arenas (lower max_nodes / max_vehicles)");
+    }
+    (void)hipMemsetAsync(h->d_flag.p, 0, h->d_flag.cap * sizeof(uint32_t), h->stream);
+    (void)hipMemsetAsync(h->d_tree_size.p, 0, h->d_tree_size.cap * sizeof(int32_t), h->stream);
+    (void)hipMemsetAsync(h->d_out.p, 0, h->d_out.cap * sizeof(pdmpc_vehicle_out), h->stream);
+    (void)hipStreamSynchronize(h->stream);
+    *out_handle = h;
+    return PDMPC_OK;
+}
+
+int pdmpc_destroy(pdmpc_handle* h) {
+    if (!h) return PDMPC_OK;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto& ev : h->events) {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    h->d_mask.release();
+    h->d_mi.release();
+    h->d_pose.release();
+    h->d_area.release();
+    h->ax.release();
+    h->ay.release();
+    h->ayaw.release();
+    h->ag.release();
+    h->ah.release();
+    h->acs.release();
+    h->asn.release();
+    h->ahk.release();
+    h->aparent.release();
+    h->ahid.release();
+    h->atk.release();
+    h->d_out.release();
+    h->d_flag.release();
+    h->d_tree_size.release();
+    h->d_trace.release();
+    h->h_veh.release();
+    h->h_pts.release();
+    h->h_pred.release();
+    h->d_veh.release();
+    h->d_pts.release();
+    h->d_pred.release();
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return PDMPC_OK;
+}
+
+int pdmpc_upload_mpa(pdmpc_handle* h, const pdmpc_mpa* mpa) {
+    if (!h || !mpa) return fail(PDMPC_ERR_INVALID, "null argument");
+    if (mpa->n_trims < 1 || mpa->n_trims > 1023) return fail(PDMPC_ERR_INVALID, "n_trims must be in 1..1023");
+    if (mpa->Hp < h->cfg.Hp) return fail(PDMPC_ERR_INVALID, "mpa.Hp smaller than config.Hp");
+    if (!mpa->transition || !mpa->maneuver_index || (mpa->n_maneuvers > 0 && !mpa->maneuvers)) return fail(PDMPC_ERR_INVALID, "null table");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const int n = mpa->n_trims, Hp = h->cfg.Hp;
+    const int nw = (n + 63) / 64;
+    std::vector<uint64_t> mask((size_t)Hp * n * nw + 2, 0);
+    for (int k = 0; k < Hp; ++k)
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j)
+                if (mpa->transition[((size_t)k * n + i) * n + j]) {
+                    const int mi = mpa->maneuver_index[i * n + j];
+                    if (mi < 0 || mi >= mpa->n_maneuvers) return fail(PDMPC_ERR_INVALID, "transition allowed but maneuver missing");
+                    mask[((size_t)k * n + i) * nw + j / 64] |= 1ull << (j % 64);
+                }
+    std::vector<int16_t> mi((size_t)n * n + 8, -1);
+    for (int i = 0; i < n * n; ++i) mi[i] = (int16_t)mpa->maneuver_index[i];
+    const int T = mpa->n_maneuvers;
+    std::vector<DevManPose> pose((size_t)std::max(T, 1));
+    std::vector<double> area((size_t)std::max(T, 1) * 3 * PDMPC_VMAX * 2, 0.0);
+    for (int t = 0; t < T; ++t) {
+        const pdmpc_maneuver& m = mpa->maneuvers[t];
+        if (m.n_cols < 2 || m.n_cols > PDMPC_VMAX) return fail(PDMPC_ERR_INVALID, "maneuver area column count out of range");
+        pose[t].dx = m.dx;
+        pose[t].dy = m.dy;
+        pose[t].dyaw = m.dyaw;
+        pose[t].n_cols = m.n_cols;
+        pose[t].pad = 0;
+        const double(*src[3])[PDMPC_VMAX] = {m.area, m.area_without_offset, m.area_large_offset};
+        for (int a = 0; a < 3; ++a)
+            for (int v = 0; v < m.n_cols; ++v) {
+                area[(((size_t)t * 3 + a) * PDMPC_VMAX + v) * 2 + 0] = src[a][0][v];
+                area[(((size_t)t * 3 + a) * PDMPC_VMAX + v) * 2 + 1] = src[a][1][v];
+            }
+    }
+    if (h->d_mask.ensure(mask.size()) || h->d_mi.ensure(mi.size()) || h->d_pose.ensure(pose.size()) || h->d_area.ensure(area.size()))
+        return fail(PDMPC_ERR_HIP, "hipMalloc failed for the MPA tables");
+    HIPCHK(hipMemcpy(h->d_mask.p, mask.data(), mask.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_mi.p, mi.data(), mi.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_pose.p, pose.data(), pose.size() * sizeof(DevManPose), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_area.p, area.data(), area.size() * 8, hipMemcpyHostToDevice));
+    h->n_trims = n;
+    h->n_words = nw;
+    h->n_man = T;
+    h->mask_bytes = (size_t)Hp * n * nw * 8;
+    h->mi_bytes = (size_t)n * n * 2;
+    // B_mpa = 8*T*(3 + 6*VMAX) + n*n*Hp/8
+    h->mpa_alg_bytes = (int64_t)8 * T * (3 + 6 * PDMPC_VMAX) + (int64_t)n * n * Hp / 8;
+    h->has_mpa = true;
+    return PDMPC_OK;
+}
+
+int pdmpc_pack_batch(pdmpc_handle* h, int32_t n, const pdmpc_vehicle_in* in) {
+    if (h) HIPCHK(hipSetDevice(h->cfg.device));
+    return pack_common(h, n, in, nullptr, nullptr, nullptr);
+}
+
+int pdmpc_pack_step(pdmpc_handle* h, int32_t n, const pdmpc_vehicle_in* in, const int32_t* pred_offset, const int32_t* pred_index,
+                    const pdmpc_polygon_set* fallback_shapes) {
+    if (h) HIPCHK(hipSetDevice(h->cfg.device));
+    if (pred_offset && !pred_index) return fail(PDMPC_ERR_INVALID, "pred_index missing");
+    return pack_common(h, n, in, pred_offset, pred_index, fallback_shapes);
+}
+
+int pdmpc_launch_packed(pdmpc_handle* h) {
+    if (!h) return fail(PDMPC_ERR_INVALID, "null handle");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    return launch_range(h, 0, h->n_packed);
+}
+
+int pdmpc_launch_range(pdmpc_handle* h, int32_t first, int32_t count) {
+    if (!h) return fail(PDMPC_ERR_INVALID, "null handle");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    return launch_range(h, first, count);
+}
+
+int pdmpc_synchronize(pdmpc_handle* h) {
+    if (!h) return fail(PDMPC_ERR_INVALID, "null handle");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return PDMPC_OK;
+}
+
+int pdmpc_fetch_results(pdmpc_handle* h, int32_t n, pdmpc_vehicle_out* out) {
+    if (!h || (n > 0 && !out)) return fail(PDMPC_ERR_INVALID, "null argument");
+    if (n < 0 || n > h->max_vehicles) return fail(PDMPC_ERR_INVALID, "bad record count");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if (n > 0) HIPCHK(hipMemcpyAsync(out, h->d_out.p, (size_t)n * sizeof(pdmpc_vehicle_out), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    // counters + SURVEY.md 8(d) algorithmic bytes of one pass over the packed batch
+    pdmpc_stats& s = h->stats;
+    const int Hp = h->cfg.Hp;
+    const int m = std::min(n, h->n_packed);
+    s.n_vehicles = m;
+    s.nodes_popped = s.nodes_generated = s.obstacle_columns = 0;
+    int64_t bytes = h->mpa_alg_bytes;
+    for (int i = 0; i < m; ++i) {
+        const pdmpc_vehicle_out& o = out[i];
+        const DevVehicle& d = h->h_veh.p[i];
+        int64_t cols = h->lit_cols[i];
+        for (int q = 0; q < d.n_pred; ++q) {
+            const int ps = h->h_pred.p[d.pred_off + q];
+            if (ps < n)
+                for (int k = 0; k < Hp; ++k) cols += out[ps].shape_cols[k] + 1;
+        }
+        const int64_t P = o.n_popped, C = std::max(o.n_expanded - 1, 0);
+        s.nodes_popped += P;
+        s.nodes_generated += C;
+        s.obstacle_columns += cols;
+        bytes += 8 * (4 + 3 * Hp) + 16 * cols;                             // B_in
+        bytes += P * (60 + 16);                                            // B_pop
+        bytes += C * (60 + 16);                                            // B_child
+        bytes += 8 * (3 * Hp + Hp + (Hp + 1)) + 16 * PDMPC_VMAX * Hp;      // B_out
+    }
+    s.algorithmic_bytes = bytes;
+    return PDMPC_OK;
+}
+
+int pdmpc_plan_batch(pdmpc_handle* h, int32_t n, const pdmpc_vehicle_in* in, pdmpc_vehicle_out* out) {
+    int rc = pdmpc_pack_batch(h, n, in);
+    if (rc) return rc;
+    rc = pdmpc_launch_packed(h);
+    if (rc) return rc;
+    return pdmpc_fetch_results(h, n, out);
+}
+
+int pdmpc_result_device_buffer(pdmpc_handle* h, void** dev_ptr, size_t* nbytes) {
+    if (!h || !dev_ptr || !nbytes) return fail(PDMPC_ERR_INVALID, "null argument");
+    *dev_ptr = h->d_out.p;
+    *nbytes = (size_t)h->max_vehicles * sizeof(pdmpc_vehicle_out);
+    return PDMPC_OK;
+}
+
+int pdmpc_import_results(pdmpc_handle* h, int32_t first, int32_t n, const void* dev_records) {
+    if (!h || (n > 0 && !dev_records)) return fail(PDMPC_ERR_INVALID, "null argument");
+    if (first < 0 || n < 0 || first + n > h->max_vehicles) return fail(PDMPC_ERR_INVALID, "slot range out of bounds");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if (n == 0) return PDMPC_OK;
+    const void* dst = (const void*)(h->d_out.p + first);
+    if (dev_records != dst)
+        HIPCHK(hipMemcpyAsync(h->d_out.p + first, dev_records, (size_t)n * sizeof(pdmpc_vehicle_out), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(h->d_flag.p + first), (int)h->epoch, (size_t)n, h->stream));
+    return PDMPC_OK;
+}
+
+int pdmpc_get_last_stats(pdmpc_handle* h, pdmpc_stats* stats) {
+    if (!h || !stats) return fail(PDMPC_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    double ms = 0.0;
+    for (size_t i = 0; i < h->events_used; ++i) {
+        float t = 0.f;
+        HIPCHK(hipEventElapsedTime(&t, h->events[i].first, h->events[i].second));
+        ms += t;
+    }
+    h->stats.kernel_ms = ms;
+    h->stats.n_launches = (int64_t)h->events_used;
+    *stats = h->stats;
+    return PDMPC_OK;
+}
+
+int pdmpc_debug_pop_trace(pdmpc_handle* h, int32_t vehicle, int32_t capacity, int32_t* ids, int32_t* n) {
+    if (!h || !ids || !n) return fail(PDMPC_ERR_INVALID, "null argument");
+    if (h->cfg.trace_pops <= 0) return fail(PDMPC_ERR_INVALID, "handle was created with trace_pops == 0");
+    if (vehicle < 0 || vehicle >= h->max_vehicles) return fail(PDMPC_ERR_INVALID, "vehicle slot out of range");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    pdmpc_vehicle_out rec;
+    HIPCHK(hipMemcpy(&rec, h->d_out.p + vehicle, sizeof rec, hipMemcpyDeviceToHost));
+    const int cnt = std::min(rec.n_popped, h->cfg.trace_pops);
+    *n = cnt;
+    const int m = std::min(cnt, capacity);
+    if (m > 0) HIPCHK(hipMemcpy(ids, h->d_trace.p + (size_t)vehicle * h->cfg.trace_pops, (size_t)m * 4, hipMemcpyDeviceToHost));
+    return PDMPC_OK;
+}
+
+int pdmpc_debug_tree(pdmpc_handle* h, int32_t vehicle, int32_t capacity, double* x, double* y, double* yaw, double* g, double* hh,
+                     int32_t* trim, int32_t* k, int32_t* parent, int32_t* n) {
+    if (!h || !n) return fail(PDMPC_ERR_INVALID, "null argument");
+    if (vehicle < 0 || vehicle >= h->max_vehicles) return fail(PDMPC_ERR_INVALID, "vehicle slot out of range");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    int32_t sz = 0;
+    HIPCHK(hipMemcpy(&sz, h->d_tree_size.p + vehicle, 4, hipMemcpyDeviceToHost));
+    *n = sz;
+    const size_t m = (size_t)std::max(std::min(sz, capacity), 0);
+    if (m == 0) return PDMPC_OK;
+    const size_t off = (size_t)vehicle * h->max_nodes;
+    if (x) HIPCHK(hipMemcpy(x, h->ax.p + off, m * 8, hipMemcpyDeviceToHost));
+    if (y) HIPCHK(hipMemcpy(y, h->ay.p + off, m * 8, hipMemcpyDeviceToHost));
+    if (yaw) HIPCHK(hipMemcpy(yaw, h->ayaw.p + off, m * 8, hipMemcpyDeviceToHost));
+    if (g) HIPCHK(hipMemcpy(g, h->ag.p + off, m * 8, hipMemcpyDeviceToHost));
+    if (hh) HIPCHK(hipMemcpy(hh, h->ah.p + off, m * 8, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> par(m);
+    std::vector<uint16_t> tk(m);
+    HIPCHK(hipMemcpy(par.data(), h->aparent.p + off, m * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(tk.data(), h->atk.p + off, m * 2, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < m; ++i) {
+        if (parent) parent[i] = (int32_t)par[i];
+        if (trim) trim[i] = (int32_t)(tk[i] & 1023u);
+        if (k) k[i] = (int32_t)(tk[i] >> 10);
+    }
+    return PDMPC_OK;
+}
+
+}  // extern "C"

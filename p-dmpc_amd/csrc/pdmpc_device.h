@@ -1,0 +1,106 @@
+// pdmpc_device.h — HBM data layout shared by the host packer (api.cpp) and the search kernel.
+//
+// Everything the kernel reads is a flat, pointer-free blob so one hipMemcpyAsync moves a whole batch:
+//
+//   DevVehicle veh[n]      fixed-stride record per vehicle (pose, reference, offsets into the pools)
+//   double2    points[]    every literal polygon vertex of the batch, already in the "NaN-separated
+//                          soup" order of vectorize_all_obstacles.m:36-62 (step-major per vehicle), so a
+//                          workgroup stages its obstacles with one coalesced, fully pipelined copy
+//   int32      pred[]      CSR list of predecessor slots (their solved areas are appended on the device)
+//
+// MPA tables (uploaded once):
+//   uint64  succ_mask[Hp][n][n_words]   bit j of word w set <=> transition_matrix_single(i, 64w+j, k) ~= 0
+//   int16   man_index[n][n]            index into the maneuver arrays or -1
+//   DevManPose man_pose[T]             dx, dy, dyaw, n_cols
+//   double2 man_area[T][3][VMAX]       area, area_without_offset, area_large_offset as (x, y) pairs
+#ifndef PDMPC_DEVICE_H
+#define PDMPC_DEVICE_H
+
+#include <stdint.h>
+
+#include "../../include/pdmpc.h"
+
+#define PDMPC_WAVE 64
+
+struct DevManPose {
+    double dx, dy, dyaw;
+    int32_t n_cols;
+    int32_t pad;
+};
+
+struct DevVehicle {
+    double x0, y0, yaw0;
+    double ref_x[PDMPC_HP_MAX];
+    double ref_y[PDMPC_HP_MAX];
+    double v_ref[PDMPC_HP_MAX];
+    int32_t trim0;                      // 1-based
+    int32_t n_pred;                     // predecessors whose solved areas become dynamic obstacles
+    int32_t pred_off;                   // into pred[]
+    int32_t ll_off, ll_len;             // lanelet soup [left, NaN, right, NaN] in points[]
+    int32_t lit_off[PDMPC_HP_MAX + 1];  // literal vehicle-obstacle soup of step k: points[lit_off[k] .. lit_off[k+1])
+    int32_t hdv_off[PDMPC_HP_MAX + 1];  // literal HDV soup of step k
+    int32_t fb_off[PDMPC_HP_MAX + 1];   // fallback areas (one polygon per step, no separators); fb_off[0] < 0: none
+    int32_t pad;
+};
+
+// byte offsets of the regions of the dynamic LDS allocation (all multiples of 16)
+struct LdsLayout {
+    uint32_t mask, man_index, pose, area;     // MPA tables
+    uint32_t ref;                             // ref_x[16], ref_y[16], dtv[16]
+    uint32_t shape;                           // shape A [8], shape B [8] (double2)
+    uint32_t path;                            // uint32 path[HP_MAX+1] + misc scratch
+    uint32_t soup;                            // double2[soup_cap]
+    uint32_t heap_key, heap_id;               // double[HL], uint32[HL]
+    uint32_t nx, ny, nyaw, ng, nh, ncs, nsn;  // double[NL] each
+    uint32_t nparent, ntk;                    // uint32[NL], uint16[NL]
+    uint32_t total;
+};
+
+struct NodeArena {  // per-vehicle slices of HBM arrays (stride = max_nodes entries)
+    double *x, *y, *yaw, *g, *h, *cs, *sn;
+    uint32_t* parent;
+    uint16_t* tk;  // trim (low byte.. 10 bits) | k << 10
+    double* heap_key;
+    uint32_t* heap_id;
+};
+
+struct KernelArgs {
+    // MPA
+    const uint64_t* succ_mask;
+    const int16_t* man_index;
+    const DevManPose* man_pose;
+    const double* man_area;  // double2 pairs
+    int32_t n_trims, n_words, n_man, Hp;
+    int32_t checker;
+    int32_t areas_in_lds;
+    double dt;
+    // batch
+    const DevVehicle* veh;
+    const double* points;  // double2 pairs
+    const int32_t* pred;
+    pdmpc_vehicle_out* out;
+    uint32_t* done_flag;
+    uint32_t epoch;
+    int32_t first;  // slot of blockIdx.x == 0
+    // arenas
+    NodeArena arena;
+    uint32_t max_nodes;
+    int32_t* pop_trace;
+    int32_t trace_cap;
+    int32_t* tree_size;  // per slot: nodes in the tree after the search (debug read-back)
+    // LDS
+    LdsLayout lds;
+    int32_t HL, NL, soup_cap;
+    uint32_t spin_limit;
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+// defined in search_kernel.hip; launches `count` workgroups of 64 threads on `stream`
+int pdmpc_launch_search(const KernelArgs* args, int count, void* stream);
+#ifdef __cplusplus
+}
+#endif
+
+#endif

@@ -1,0 +1,204 @@
+"""Loader and thin object wrapper for libpdmpc_hip.so (the C ABI of include/pdmpc.h).
+
+There is deliberately NO CPU fallback: if the shared library is missing or no gfx950 device is
+present, construction raises.  The library is built in-tree by `__graft_entry__.build()` /
+`make -C p-dmpc_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libpdmpc_hip.so")
+
+_LIB = None
+
+EXPORTS = [
+    "pdmpc_create",
+    "pdmpc_destroy",
+    "pdmpc_upload_mpa",
+    "pdmpc_plan_batch",
+    "pdmpc_pack_batch",
+    "pdmpc_launch_packed",
+    "pdmpc_launch_range",
+    "pdmpc_fetch_results",
+    "pdmpc_synchronize",
+    "pdmpc_pack_step",
+    "pdmpc_result_device_buffer",
+    "pdmpc_import_results",
+    "pdmpc_get_last_stats",
+    "pdmpc_debug_pop_trace",
+    "pdmpc_debug_tree",
+    "pdmpc_last_error",
+    "pdmpc_version",
+]
+
+
+class BackendError(RuntimeError):
+    pass
+
+
+def load_library(path=None):
+    """dlopen the HIP backend and declare every prototype of include/pdmpc.h."""
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise BackendError(
+            "HIP backend %s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback)" % p
+        )
+    L = C.CDLL(p)
+    H = C.c_void_p
+    L.pdmpc_create.argtypes = [C.POINTER(abi.Config), C.POINTER(H)]
+    L.pdmpc_destroy.argtypes = [H]
+    L.pdmpc_upload_mpa.argtypes = [H, C.POINTER(abi.Mpa)]
+    L.pdmpc_plan_batch.argtypes = [H, C.c_int32, C.POINTER(abi.VehicleIn), C.POINTER(abi.VehicleOut)]
+    L.pdmpc_pack_batch.argtypes = [H, C.c_int32, C.POINTER(abi.VehicleIn)]
+    L.pdmpc_launch_packed.argtypes = [H]
+    L.pdmpc_launch_range.argtypes = [H, C.c_int32, C.c_int32]
+    L.pdmpc_fetch_results.argtypes = [H, C.c_int32, C.POINTER(abi.VehicleOut)]
+    L.pdmpc_synchronize.argtypes = [H]
+    L.pdmpc_pack_step.argtypes = [H, C.c_int32, C.POINTER(abi.VehicleIn), abi.c_int32_p, abi.c_int32_p, C.POINTER(abi.PolygonSet)]
+    L.pdmpc_result_device_buffer.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.pdmpc_import_results.argtypes = [H, C.c_int32, C.c_int32, C.c_void_p]
+    L.pdmpc_get_last_stats.argtypes = [H, C.POINTER(abi.Stats)]
+    L.pdmpc_debug_pop_trace.argtypes = [H, C.c_int32, C.c_int32, abi.c_int32_p, abi.c_int32_p]
+    L.pdmpc_debug_tree.argtypes = [H, C.c_int32, C.c_int32] + [abi.c_double_p] * 5 + [abi.c_int32_p] * 4
+    L.pdmpc_last_error.restype = C.c_char_p
+    L.pdmpc_version.restype = C.c_char_p
+    for name in EXPORTS:
+        if name not in ("pdmpc_last_error", "pdmpc_version"):
+            getattr(L, name).restype = C.c_int
+    if path is None:
+        _LIB = L
+    return L
+
+
+def _check(L, rc, what):
+    if rc != 0:
+        msg = L.pdmpc_last_error()
+        raise BackendError("%s failed with status %d: %s" % (what, rc, msg.decode() if msg else ""))
+
+
+class Handle:
+    """One pdmpc_handle: bound to one GPU, owns the uploaded MPA and all device buffers."""
+
+    def __init__(self, options, checker=None):
+        self.L = load_library()
+        self.options = options
+        self.Hp = options.Hp
+        if checker is None:
+            checker = abi.CHECK_INTERX if options.are_any_obstacles_non_convex else abi.CHECK_SAT
+        self.cfg = abi.Config(
+            Hp=options.Hp,
+            checker=checker,
+            dt_seconds=options.dt_seconds,
+            device=options.device,
+            max_nodes=options.max_nodes,
+            max_vehicles=options.max_vehicles,
+            trace_pops=options.trace_pops,
+        )
+        self.h = C.c_void_p()
+        _check(self.L, self.L.pdmpc_create(C.byref(self.cfg), C.byref(self.h)), "pdmpc_create")
+        self._mpa_keep = None
+
+    def close(self):
+        if self.h:
+            self.L.pdmpc_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload_mpa(self, mpa):
+        s, keep = abi.pack_mpa(mpa)
+        _check(self.L, self.L.pdmpc_upload_mpa(self.h, C.byref(s)), "pdmpc_upload_mpa")
+        self._mpa_keep = keep
+
+    def plan_batch(self, iters):
+        """list[VehicleIter] -> numpy records (abi.VEHICLE_OUT_DTYPE)."""
+        n = len(iters)
+        arr, keep = abi.pack_vehicles(iters, self.Hp)
+        out = abi.out_array(n)
+        _check(self.L, self.L.pdmpc_plan_batch(self.h, n, arr, abi.out_ptr(out)), "pdmpc_plan_batch")
+        del keep
+        return out[:n]
+
+    # ---- device-resident path ----
+    def pack_batch(self, iters):
+        arr, keep = abi.pack_vehicles(iters, self.Hp)
+        _check(self.L, self.L.pdmpc_pack_batch(self.h, len(iters), arr), "pdmpc_pack_batch")
+        del keep
+
+    def pack_step(self, iters, predecessors, fallback_shapes=None):
+        """predecessors: list (per vehicle) of lists of 0-based vehicle indices in this batch."""
+        n = len(iters)
+        arr, keep = abi.pack_vehicles(iters, self.Hp)
+        off = np.zeros(n + 1, dtype=np.int32)
+        for i, p in enumerate(predecessors):
+            off[i + 1] = off[i] + len(p)
+        idx = np.array([j for p in predecessors for j in p] + [0], dtype=np.int32)
+        fb = None
+        if fallback_shapes is not None:
+            fb = (abi.PolygonSet * n)()
+            for i, shapes in enumerate(fallback_shapes):
+                fb[i] = abi.pack_polygon_set(list(shapes), keep)
+        _check(
+            self.L,
+            self.L.pdmpc_pack_step(self.h, n, arr, off.ctypes.data_as(abi.c_int32_p), idx.ctypes.data_as(abi.c_int32_p), fb),
+            "pdmpc_pack_step",
+        )
+        del keep
+
+    def launch(self):
+        _check(self.L, self.L.pdmpc_launch_packed(self.h), "pdmpc_launch_packed")
+
+    def launch_range(self, first, count):
+        _check(self.L, self.L.pdmpc_launch_range(self.h, first, count), "pdmpc_launch_range")
+
+    def synchronize(self):
+        _check(self.L, self.L.pdmpc_synchronize(self.h), "pdmpc_synchronize")
+
+    def fetch(self, n):
+        out = abi.out_array(n)
+        _check(self.L, self.L.pdmpc_fetch_results(self.h, n, abi.out_ptr(out)), "pdmpc_fetch_results")
+        return out[:n]
+
+    def result_device_buffer(self):
+        p = C.c_void_p()
+        nb = C.c_size_t()
+        _check(self.L, self.L.pdmpc_result_device_buffer(self.h, C.byref(p), C.byref(nb)), "pdmpc_result_device_buffer")
+        return p.value, nb.value
+
+    def import_results(self, first, n, dev_ptr):
+        _check(self.L, self.L.pdmpc_import_results(self.h, first, n, C.c_void_p(dev_ptr)), "pdmpc_import_results")
+
+    def stats(self):
+        s = abi.Stats()
+        _check(self.L, self.L.pdmpc_get_last_stats(self.h, C.byref(s)), "pdmpc_get_last_stats")
+        return {name: getattr(s, name) for name, _ in abi.Stats._fields_}
+
+    def pop_trace(self, vehicle, capacity=1 << 16):
+        ids = np.zeros(capacity, dtype=np.int32)
+        n = C.c_int32()
+        _check(self.L, self.L.pdmpc_debug_pop_trace(self.h, vehicle, capacity, ids.ctypes.data_as(abi.c_int32_p), C.byref(n)), "pdmpc_debug_pop_trace")
+        return ids[: min(n.value, capacity)].copy()
+
+    def tree(self, vehicle, capacity=1 << 16):
+        f = {k: np.zeros(capacity) for k in ("x", "y", "yaw", "g", "h")}
+        i = {k: np.zeros(capacity, dtype=np.int32) for k in ("trim", "k", "parent")}
+        n = C.c_int32()
+        args = [f[k].ctypes.data_as(abi.c_double_p) for k in ("x", "y", "yaw", "g", "h")] + [i[k].ctypes.data_as(abi.c_int32_p) for k in ("trim", "k", "parent")]
+        _check(self.L, self.L.pdmpc_debug_tree(self.h, vehicle, capacity, *args, C.byref(n)), "pdmpc_debug_tree")
+        nn = min(n.value, capacity)
+        d = {k: v[:nn].copy() for k, v in f.items()}
+        d.update({k: v[:nn].copy() for k, v in i.items()})
+        return d

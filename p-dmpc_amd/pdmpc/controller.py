@@ -1,0 +1,244 @@
+"""Host-side step driver: the caller of the optimizer boundary.
+
+Restates what the reference does around `run_optimizer` for prioritized planning so whole MPC steps can
+be produced and timed without MATLAB:
+
+    traffic info per step        HighLevelController.update_controlled_vehicles_traffic_info (HighLevelController.m:167-270)
+    coupling                     Coupler (full_coupling: Coupler.m:31-32; distance: DistanceCoupler.m:15-50)
+    priorities -> DAG            ConstantPrioritizer.m:14-20, Prioritizer.directed_coupling_from_priorities (Prioritizer.m:64-77)
+    computation levels           utility/kahn.m:1-24
+    level loop                   PrioritizedSequentialController.controller (PrioritizedSequentialController.m:77-94)
+    obstacle assembly            PrioritizedController.plan / consider_predecessors / consider_successors
+                                 (PrioritizedController.m:297-324, 449-566)
+    exhaustion handling          handle_graph_search_exhaustion / plan_fallback (PrioritizedController.m:568-616, 678-718)
+    plant                        Simulation.apply (plant/Simulation.m:86-100)
+
+The planner is injected (`plan_level`: list[VehicleIter] -> list[ControlResultsInfo]) — the product passes
+GraphSearchHip.run_optimizer_batch; tests may pass the CPU oracle to obtain the expected closed loop.
+ROS 2 messaging is replaced by in-memory hand-off of `info.shapes`.
+"""
+import math
+from dataclasses import dataclass
+from typing import Callable, List, Optional
+
+import numpy as np
+
+from .config import Config, ConstraintFromSuccessor, ScenarioType
+from .iteration_data import ControlResultsInfo, Tree, VehicleIter
+from .reference_trajectory import get_occupied_areas, get_reference_trajectory
+
+
+def kahn(A: np.ndarray) -> np.ndarray:
+    """utility/kahn.m:1-24: computation level (1-based) of every vertex of the DAG A (A[i,j]=1: i before j)."""
+    A = np.array(A, dtype=np.int64)
+    n = A.shape[0]
+    L = np.zeros(n, dtype=np.int64)
+    in_d = A.sum(axis=0)
+    done = np.zeros(n, dtype=bool)
+    level = 1
+    while not done.all():
+        src = in_d == 0
+        if not src.any():
+            raise ValueError("coupling graph has a cycle")
+        L[src] = level
+        A[src, :] = 0
+        done[src] = True
+        in_d = A.sum(axis=0)
+        in_d[done] = 1
+        level += 1
+    return L
+
+
+def directed_coupling_from_priorities(adjacency, priorities):
+    """Prioritizer.m:64-77: keep edge i->j only if priority(i) <= priority(j) (lower number plans first)."""
+    p = np.asarray(priorities)
+    removed = p[None, :] < p[:, None]
+    d = np.array(adjacency, dtype=np.int64)
+    d[removed] = 0
+    return d
+
+
+def del_first_rpt_last(seq, n=1):
+    """utility del_first_rpt_last: drop the first n entries, repeat the last one n times."""
+    seq = list(seq)
+    n = min(n, len(seq))
+    return seq[n:] + [seq[-1]] * n
+
+
+@dataclass
+class Measurement:  # plant PlantMeasurement
+    x: float
+    y: float
+    yaw: float
+    speed: float
+    steering: float
+
+
+class PrioritizedSequentialController:
+    def __init__(
+        self,
+        options: Config,
+        scenario,
+        mpa,
+        plan_level: Callable[[List[VehicleIter]], List[ControlResultsInfo]],
+        coupling: str = "full",
+        priorities: Optional[List[int]] = None,
+        boundary_provider=None,
+    ):
+        self.options = options
+        self.scenario = scenario
+        self.mpa = mpa
+        self.plan_level = plan_level
+        self.coupling = coupling
+        self.n = options.amount
+        self.priorities = list(priorities) if priorities is not None else list(range(1, self.n + 1))
+        self.boundary_provider = boundary_provider  # road networks: (vehicle, path, points_index, cpi) -> (left, right)
+        # Simulation.setup: initial speed = steering = 0 (Simulation.m:52-65)
+        self.meas = [Measurement(v.x_start, v.y_start, v.yaw_start, 0.0, 0.0) for v in scenario.vehicles]
+        self.k = 0
+        self.info_old: List[Optional[ControlResultsInfo]] = [None] * self.n
+        self.infos: List[Optional[ControlResultsInfo]] = [None] * self.n
+        self.last_iters: List[Optional[VehicleIter]] = [None] * self.n
+        self.last_levels = None
+
+    # ---- HighLevelController.update_controlled_vehicles_traffic_info (HighLevelController.m:167-270)
+    def _traffic_info(self):
+        o = self.options
+        n = self.n
+        self.x0 = np.zeros((n, 4))
+        self.trims = np.zeros(n, dtype=np.int64)
+        self.occupied = [None] * n
+        self.ref_points = [None] * n
+        self.v_ref = [None] * n
+        self.boundary = [(None, None)] * n
+        for i, m in enumerate(self.meas):
+            veh = self.scenario.vehicles[i]
+            self.x0[i] = [m.x, m.y, m.yaw, m.speed]
+            self.trims[i] = self.mpa.trim_from_values(m.speed, m.steering)
+            self.occupied[i] = get_occupied_areas(m.x, m.y, m.yaw, veh.Length, veh.Width, o.offset)
+            path, points_index, v_ref, cpi = get_reference_trajectory(
+                self.mpa, veh.reference_path, veh.reference_speed, m.x, m.y, int(self.trims[i]), o.dt_seconds
+            )
+            self.ref_points[i] = path
+            self.v_ref[i] = v_ref
+            if o.scenario_type != ScenarioType.circle and self.boundary_provider is not None:
+                self.boundary[i] = self.boundary_provider(i, veh, points_index, cpi)
+
+    def _couple(self):
+        n = self.n
+        if self.coupling == "full":  # Coupler.m:31-32
+            return np.ones((n, n), dtype=np.int64) - np.eye(n, dtype=np.int64)
+        if self.coupling == "none":
+            return np.zeros((n, n), dtype=np.int64)
+        if self.coupling == "distance":  # DistanceCoupler.m:15-50 (without the lanelet-adjacency pre-filter)
+            adj = np.zeros((n, n), dtype=np.int64)
+            max_distance = 2 * self.mpa.get_max_speed_of_mpa() * self.options.dt_seconds * self.options.Hp
+            for a in range(n):
+                for b in range(a + 1, n):
+                    d = math.hypot(self.x0[a, 0] - self.x0[b, 0], self.x0[a, 1] - self.x0[b, 1])
+                    adj[a, b] = adj[b, a] = int(d <= max_distance)
+            return adj
+        raise ValueError(self.coupling)
+
+    # ---- PrioritizedController.plan: obstacle assembly (PrioritizedController.m:297-324)
+    def _iter_for(self, i, directed, directed_seq):
+        o = self.options
+        Hp = o.Hp
+        predecessors = [j for j in range(self.n) if directed[j, i] == 1]
+        predecessors_seq = [j for j in range(self.n) if directed_seq[j, i]]
+        successors = [j for j in range(self.n) if directed[i, j] == 1]
+        dyn = []
+        for j in predecessors:  # consider_predecessors :449-506
+            if j in predecessors_seq:
+                dyn.append(list(self.infos[j].shapes))  # this step's /vehicle_prediction :476-491
+            else:
+                old = self.info_old[j]  # parallel_coupling_previous_trajectory :409-447
+                if old is not None and self.k > 1:
+                    dyn.append(del_first_rpt_last(old.shapes, 1))
+        obstacles = list(self.scenario.obstacles)
+        for j in successors:  # consider_successors :508-566
+            if o.constraint_from_successor == ConstraintFromSuccessor.area_of_standstill:
+                if abs(self.x0[j, 3]) < 0.01:  # :536-540
+                    obstacles.append(self.occupied[j][0])
+            elif o.constraint_from_successor == ConstraintFromSuccessor.area_of_previous_trajectory:
+                old = self.info_old[j]
+                if old is not None:  # :542-557 (message of the previous step, shifted once)
+                    dyn.append(del_first_rpt_last(old.shapes, 1))
+        scen_dyn = [list(r) for r in self.scenario.dynamic_obstacle_area]
+        return VehicleIter(
+            x0=self.x0[i].copy(),
+            trim_index=int(self.trims[i]),
+            reference_trajectory_points=self.ref_points[i],
+            v_ref=self.v_ref[i],
+            predicted_lanelet_boundary=self.boundary[i],
+            obstacles=obstacles,
+            dynamic_obstacle_area=scen_dyn + dyn,
+        )
+
+    # ---- handle_graph_search_exhaustion (PrioritizedController.m:568-616)
+    def _standstill_info(self, i, it: VehicleIter, info: ControlResultsInfo) -> ControlResultsInfo:
+        o = self.options
+        Hp = o.Hp
+        x, y, yaw = it.x0[0], it.x0[1], it.x0[2]
+        cost = 0.0
+        g = [0.0]
+        for s in range(Hp):
+            r = self.ref_points[i][s]
+            cost = cost + math.hypot(r[0] - x, r[1] - y) ** 2
+            g.append(cost)
+        _, rect = get_occupied_areas(x, y, yaw, self.scenario.vehicles[0].Length, self.scenario.vehicles[0].Width, o.offset)
+        tree = Tree(
+            x=np.full(Hp + 1, x), y=np.full(Hp + 1, y), yaw=np.full(Hp + 1, yaw),
+            trim=np.full(Hp + 1, it.trim_index, dtype=np.int64), k=np.arange(Hp + 1), g=np.array(g),
+            h=np.full(Hp + 1, -1.0), parent=np.arange(Hp + 1, dtype=np.uint32),
+        )
+        info.tree = tree
+        info.tree_path = np.arange(1, Hp + 2)
+        info.y_predicted = np.tile(np.array([[x], [y], [yaw]]), (1, Hp))
+        info.shapes = [rect.copy() for _ in range(Hp)]  # transformed_rectangle closed, no offset :602-611
+        info.predicted_trims = np.full(Hp, it.trim_index, dtype=np.int64)
+        info.needs_fallback = False
+        return info
+
+    # ---- plan_fallback (PrioritizedController.m:678-718): shifted previous plan
+    def _fallback_info(self, i, info: ControlResultsInfo) -> ControlResultsInfo:
+        old = self.info_old[i]
+        if old is None:
+            raise RuntimeError("vehicle %d needs a fallback in the first step" % (i + 1))
+        info.shapes = del_first_rpt_last(old.shapes)
+        info.predicted_trims = np.array(del_first_rpt_last(list(old.predicted_trims)))
+        info.y_predicted = np.array(del_first_rpt_last(list(old.y_predicted.T))).T
+        info.tree = old.tree
+        info.tree_path = old.tree_path
+        info.needs_fallback = True
+        return info
+
+    def step(self):
+        """One pass of HighLevelController.main_control_loop (HighLevelController.m:334-373) in simulation."""
+        self.k += 1
+        self._traffic_info()
+        adjacency = self._couple()
+        directed = directed_coupling_from_priorities(adjacency, self.priorities)
+        directed_seq = directed  # no cutting: every coupled pair plans sequentially (max_num_CLs >= depth)
+        levels = kahn(directed_seq)
+        self.last_levels = levels
+        self.infos = [None] * self.n
+        for lvl in range(1, int(levels.max()) + 1):  # PrioritizedSequentialController.m:83-91
+            members = [i for i in range(self.n) if levels[i] == lvl]
+            iters = [self._iter_for(i, directed, directed_seq) for i in members]
+            results = self.plan_level(iters)
+            for i, it, info in zip(members, iters, results):
+                self.last_iters[i] = it
+                if info.is_exhausted:  # PrioritizedController.m:344-352
+                    standstill = self.mpa.trims[it.trim_index - 1].speed == 0
+                    if standstill and self.options.constraint_from_successor != ConstraintFromSuccessor.none:
+                        info = self._standstill_info(i, it, info)
+                    else:
+                        info = self._fallback_info(i, info)
+                self.infos[i] = info
+        # Simulation.apply (Simulation.m:86-100)
+        for i, info in enumerate(self.infos):
+            t = self.mpa.trims[int(info.predicted_trims[0]) - 1]
+            self.meas[i] = Measurement(float(info.y_predicted[0, 0]), float(info.y_predicted[1, 0]), float(info.y_predicted[2, 0]), t.speed, t.steering)
+        self.info_old = list(self.infos)
+        return self.infos

@@ -1,0 +1,157 @@
+"""GPU parity tests proper: HIP backend (through the C ABI) vs the CPU oracle on identical inputs.
+
+The bar is bit-exactness: result records byte-identical, node-pop sequence identical, whole search tree
+identical (x, y, yaw, g, h as raw IEEE bits; trim, k, parent as integers).
+"""
+import numpy as np
+import pytest
+
+from pdmpc import abi
+from pdmpc.backend import Handle
+from pdmpc.config import MpaType
+
+import problems
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle():
+    from oracle import oracle
+
+    return oracle
+
+
+def assert_records_equal(gpu, ref, ctx=""):
+    assert gpu.dtype == ref.dtype
+    for name in gpu.dtype.names:
+        a, b = gpu[name], ref[name]
+        if a.dtype.kind == "f":
+            same = a.view(np.uint64) == b.view(np.uint64)
+        else:
+            same = a == b
+        assert np.all(same), "%s field %s differs at %s" % (ctx, name, np.argwhere(~same)[:5])
+
+
+def check_batch(options, mpa, iters, full_tree=True):
+    oracle = _oracle()
+    options.trace_pops = 1 << 15
+    options.max_nodes = 1 << 15
+    options.max_vehicles = max(len(iters), 1)
+    h = Handle(options)
+    h.upload_mpa(mpa)
+    gpu = h.plan_batch(iters)
+    _, ref, traces = oracle.plan_batch(options, mpa, iters, trace=True)
+    assert_records_equal(gpu, ref, "batch")
+    if full_tree:
+        for v in range(len(iters)):
+            pops = h.pop_trace(v)
+            assert np.array_equal(pops, traces[v].pops[: len(pops)]), "pop sequence of vehicle %d" % v
+            assert len(pops) == min(len(traces[v].pops), options.trace_pops)
+            tree = h.tree(v)
+            for key in ("x", "y", "yaw", "g", "h"):
+                assert np.array_equal(tree[key].view(np.uint64), traces[v].tree[key].view(np.uint64)), (v, key)
+            for key in ("trim", "k", "parent"):
+                assert np.array_equal(tree[key], traces[v].tree[key]), (v, key)
+    stats = h.stats()
+    h.close()
+    return gpu, stats
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_interx_random_road(seed):
+    options, mpa, iters = problems.problem_set("interx", seed, 24, Hp=6)
+    gpu, stats = check_batch(options, mpa, iters)
+    assert stats["nodes_popped"] == int(gpu["n_popped"].sum())
+    assert stats["kernel_ms"] > 0
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_sat_random_road(seed):
+    options, mpa, iters = problems.problem_set("sat", seed, 24, Hp=5)
+    check_batch(options, mpa, iters)
+
+
+def test_interx_triple_speed_hp8():
+    options, mpa, iters = problems.problem_set("interx", 5, 20, Hp=8, mpa_type=MpaType.triple_speed)
+    check_batch(options, mpa, iters)
+
+
+def test_single_vehicle_is_run_optimizer():
+    """n == 1 is the literal GraphSearch.run_optimizer call (GraphSearch.m:14-17)."""
+    from pdmpc.optimizer import OptimizerInterface
+
+    options, mpa, iters = problems.problem_set("interx", 7, 1, Hp=6)
+    options.max_vehicles = 4
+    opt = OptimizerInterface.get_optimizer(options)
+    info = opt.run_optimizer(1, iters[0], mpa, options, 1)
+    ref, _, _ = _oracle().plan_batch(options, mpa, iters)
+    assert info.is_exhausted == ref[0].is_exhausted
+    assert np.array_equal(info.tree_path, ref[0].tree_path)
+    assert np.array_equal(info.y_predicted, ref[0].y_predicted, equal_nan=True)
+    for a, b in zip(info.shapes, ref[0].shapes):
+        assert np.array_equal(a, b)
+
+
+def test_circle_closed_loop_c1():
+    """BASELINE config 0: 3-vehicle circle, Hp 5, sequential prioritized, 20 steps; GPU plans, oracle checks each level."""
+    from pdmpc.config import Config, ScenarioType
+    from pdmpc.controller import PrioritizedSequentialController
+    from pdmpc.iteration_data import info_from_record
+    from pdmpc.mpa import get_mpa
+    from pdmpc.scenario import circle_scenario
+
+    oracle = _oracle()
+    options = Config(scenario_type=ScenarioType.circle, amount=3, Hp=5, T_end=4, max_vehicles=4, max_nodes=1 << 15)
+    mpa = get_mpa(options)
+    h = Handle(options)
+    h.upload_mpa(mpa)
+    n_levels = [0]
+
+    def plan(iters):
+        gpu = h.plan_batch(iters)
+        _, ref, _ = oracle.plan_batch(options, mpa, iters)
+        assert_records_equal(gpu, ref, "step level %d" % n_levels[0])
+        n_levels[0] += 1
+        return [info_from_record(gpu[i], options.Hp) for i in range(len(iters))]
+
+    ctl = PrioritizedSequentialController(options, circle_scenario(options), mpa, plan)
+    for _ in range(options.k_end):
+        ctl.step()
+    assert n_levels[0] == 3 * options.k_end
+    h.close()
+
+
+def test_exhaustion_and_overflow_status():
+    """A vehicle boxed in by static obstacles exhausts its open list (GraphSearch.m:57-61); a tiny arena overflows."""
+    options, mpa, iters = problems.problem_set("interx", 21, 4, Hp=6)
+    for it in iters:
+        x, y = it.x0[0], it.x0[1]
+        it.obstacles = [problems.rect(x + 0.3, y, np.pi / 2, 1.2, 0.05), problems.rect(x - 0.25, y, np.pi / 2, 1.2, 0.05)]
+    gpu, _ = check_batch(options, mpa, iters)
+    assert (gpu["status"] == abi.EXHAUSTED).any()
+    options2, mpa2, iters2 = problems.problem_set("interx", 22, 4, Hp=6)
+    oracle = _oracle()
+    options2.max_nodes = 64
+    options2.max_vehicles = 4
+    h = Handle(options2)
+    h.upload_mpa(mpa2)
+    gpu2 = h.plan_batch(iters2)
+    _, ref2, _ = oracle.plan_batch(options2, mpa2, iters2)
+    assert_records_equal(gpu2, ref2, "overflow")
+    assert (gpu2["status"] == abi.ARENA_OVERFLOW).any()
+    h.close()
+
+
+def test_empty_batch_and_errors():
+    from pdmpc.backend import BackendError
+
+    options, mpa, iters = problems.problem_set("interx", 3, 2, Hp=6)
+    options.max_vehicles = 2
+    h = Handle(options)
+    with pytest.raises(BackendError):
+        h.plan_batch(iters)  # no MPA uploaded yet
+    h.upload_mpa(mpa)
+    assert len(h.plan_batch([])) == 0
+    with pytest.raises(BackendError):
+        h.plan_batch(iters * 2)  # larger than max_vehicles
+    h.close()
