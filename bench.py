@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py — MPC steps/s of the HIP graph-search backend on BASELINE config 1 (C2).
+
+Workload (N = 1): 20 vehicles on the CPM-lab road network, horizon 8, InterX constraint checker,
+constant priorities, distance coupling; one "step" = every vehicle plans once, all computation levels,
+with hand-off of solved areas to successors (one kernel launch per step, dependencies resolved on
+the device).  Inputs are recorded from the framework's own closed-loop simulation (the first 20 steps are
+dropped, as the reference's evaluation does, eval/eval_phd/eval_phd.m:41-49), packed into HBM before the
+timed region, and replayed: the planner is deterministic, so a replayed step does exactly the work of the
+closed-loop step.
+
+N > 1 (`--gpus N`, launched by torch.distributed.run): weak scaling — every rank plans its own independent
+20-vehicle road network (vehicles of different networks are not coupled, so the data path has no collective);
+value = network-steps per second summed over ranks.  The level-sharded mode with an RCCL all-gather per level
+(BASELINE configs 2/3) is `--workload sharded`, see DESIGN.md.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "p-dmpc_amd")]
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, MI355X_MICROARCH.md
+
+
+def build_world(args, rank):
+    from pdmpc.config import Config, MpaType, ScenarioType
+    from pdmpc.controller import PrioritizedSequentialController
+    from pdmpc.mpa import get_mpa
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    tiles = max(1, (args.vehicles + 19) // 20)
+    options = Config(
+        scenario_type=ScenarioType.commonroad,
+        amount=args.vehicles,
+        Hp=args.hp,
+        mpa_type=MpaType[args.mpa],
+        max_vehicles=max(args.vehicles, 32),
+        max_nodes=args.max_nodes,
+    )
+    mpa = get_mpa(options)
+    scenario = commonroad_scenario(options, seed=args.seed + rank, tiles=tiles)
+    ctl = PrioritizedSequentialController(options, scenario, mpa, None, coupling="distance", boundary_provider=boundary_provider(scenario))
+    return options, mpa, ctl
+
+
+def record_steps(options, mpa, ctl, optimizer, n_skip, n_record):
+    """Closed loop with the GPU planner (untimed); returns the recorded step problems."""
+    problems = []
+
+    def plan_step(prob):
+        problems.append(prob)
+        return optimizer.run_optimizer_step(prob, mpa)
+
+    for _ in range(n_skip + n_record):
+        ctl.step(plan_step=plan_step)
+    return problems[n_skip:]
+
+
+def cpu_baseline(options, mpa, problems, budget_s):
+    """The CPU oracle on the same recorded steps: all vehicles of a level concurrently on min(level, cores) threads
+    (the stand-in for ComputationMode.parallel_threads).  Bounded by `budget_s`."""
+    from oracle import oracle
+    from pdmpc import abi
+
+    cores = os.cpu_count() or 1
+    mpa_struct, keep = abi.pack_mpa(mpa)
+    ms_total, n_done = 0.0, 0
+    t0 = time.time()
+    for prob in problems:
+        _, ms = oracle.plan_step(options, mpa, prob, n_threads=cores, mpa_struct=mpa_struct)
+        ms_total += ms
+        n_done += 1
+        if time.time() - t0 > budget_s:
+            break
+    del keep
+    return {
+        "value": n_done / (ms_total / 1e3) if ms_total > 0 else None,
+        "unit": "MPC steps/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "%d recorded steps of the same workload, C++ oracle, levels in kahn order, min(level size, %d) threads per level, planning time only" % (n_done, cores),
+        "ms_per_step": ms_total / max(n_done, 1),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--vehicles", type=int, default=20)
+    ap.add_argument("--hp", type=int, default=8)
+    ap.add_argument("--mpa", default="single_speed", choices=["single_speed", "triple_speed", "realistic"])
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--record", type=int, default=20, help="distinct recorded time steps kept resident in HBM")
+    ap.add_argument("--skip", type=int, default=20, help="closed-loop steps dropped before recording")
+    ap.add_argument("--max-nodes", type=int, default=1 << 17)
+    ap.add_argument("--cpu-budget-s", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP backend has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from pdmpc.optimizer import GraphSearchHip
+
+    options, mpa, ctl = build_world(args, rank)
+    options.device = local_rank
+    optimizer = GraphSearchHip(options)
+    optimizer._ensure_mpa(mpa)
+    h = optimizer.handle
+    problems = record_steps(options, mpa, ctl, optimizer, args.skip, args.record)
+    S = len(problems)
+    # keep every recorded step resident in HBM (one bank each) and collect its algorithmic bytes
+    bytes_per_bank, pops_per_bank, nodes_per_bank = [], [], []
+    for b, prob in enumerate(problems):
+        h.select_bank(b)
+        fb = [f if f is not None else [] for f in prob["fallback"]]
+        h.pack_step(prob["iters"], prob["preds"], fb)
+        h.launch()
+        h.fetch(len(prob["iters"]))
+        st = h.stats()
+        bytes_per_bank.append(st["algorithmic_bytes"])
+        pops_per_bank.append(st["nodes_popped"])
+        nodes_per_bank.append(st["nodes_generated"])
+    lds_bytes = h.stats()["lds_bytes"]
+
+    def one_step(i):
+        h.select_bank(i % S)
+        h.launch()
+        h.synchronize()
+
+    for i in range(args.warmup):
+        one_step(i)
+    h.reset_stats()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    lat = []
+    t_begin = time.perf_counter()
+    for i in range(args.steps):
+        t0 = time.perf_counter()
+        one_step(i)
+        lat.append(time.perf_counter() - t0)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_begin
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        elapsed = float(t.item())
+    st = h.stats()
+    kernel_ms = st["kernel_ms"]
+    n_launch = st["n_launches"]
+    alg_bytes = sum(bytes_per_bank[i % S] for i in range(args.steps))
+    pops = sum(pops_per_bank[i % S] for i in range(args.steps))
+    nodes = sum(nodes_per_bank[i % S] for i in range(args.steps))
+    achieved = (alg_bytes / max(n_launch, 1)) / ((kernel_ms / max(n_launch, 1)) * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+
+    if rank == 0:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "MPC steps/sec (whole node) + p50 per-step plan latency, N vehicles H=8",
+            "value": world * args.steps / elapsed,
+            "unit": "MPC steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "p50_latency_ms": 1e3 * statistics.median(lat),
+            "p99_latency_ms": 1e3 * sorted(lat)[min(len(lat) - 1, int(0.99 * len(lat)))],
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "C2: %d vehicles on the CPM-lab road network (labmap fixture), Hp %d, InterX checker, %s MPA, "
+                "distance coupling, constant priorities, one launch per step; %d recorded closed-loop steps replayed from HBM; "
+                "per GPU one independent network" % (args.vehicles, args.hp, args.mpa, S),
+                "vehicles": args.vehicles,
+                "Hp": args.hp,
+                "mpa": args.mpa,
+                "levels_per_step": statistics.mean(len(p["level_sizes"]) for p in problems),
+                "seed": args.seed,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "kernel": "pdmpc_search_kernel",
+                "kernel_ms_avg": kernel_ms / max(n_launch, 1),
+                "algorithmic_bytes_per_launch": alg_bytes / max(n_launch, 1),
+                "launches": n_launch,
+                "lds_bytes_per_workgroup": lds_bytes,
+            },
+            "counters": {
+                "nodes_popped_per_s": pops / elapsed,
+                "nodes_generated_per_s": nodes / elapsed,
+                "nodes_popped_per_step": pops / args.steps,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(options, mpa, problems, args.cpu_budget_s)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

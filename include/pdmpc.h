@@ -166,6 +166,14 @@ int pdmpc_launch_packed(pdmpc_handle* handle);
 int pdmpc_launch_range(pdmpc_handle* handle, int32_t first, int32_t count);
 int pdmpc_fetch_results(pdmpc_handle* handle, int32_t n_vehicles, pdmpc_vehicle_out* out);
 int pdmpc_synchronize(pdmpc_handle* handle);
+/* starts a new time step for launches issued with pdmpc_launch_range: results of earlier steps stop
+ * satisfying predecessor waits (pdmpc_launch_packed does this implicitly) */
+int pdmpc_begin_step(pdmpc_handle* handle);
+/* several packed batches can stay resident in HBM side by side; pack/launch/fetch act on the selected
+ * bank (default 0).  bench.py keeps one bank per recorded time step so the timed region has no copies. */
+int pdmpc_select_bank(pdmpc_handle* handle, int32_t bank);
+/* forget the kernel timings accumulated so far (pdmpc_get_last_stats sums launches since the last reset/pack) */
+int pdmpc_reset_stats(pdmpc_handle* handle);
 
 /* Step-level planning (PrioritizedSequentialController.controller, :77-94): all vehicles of a
  * time step in ONE launch.  pred_offset/pred_index (CSR over vehicles, 0-based vehicle indices of

@@ -200,3 +200,52 @@ def plan_batch(options, mpa, iters, n_threads=1, trace=False):
     infos = [info_from_record(recs[i], options.Hp) for i in range(len(iters))]
     del keep_m, keep_v
     return infos, recs, traces
+
+
+def plan_step(options, mpa, problem, n_threads=1, mpa_struct=None):
+    """Oracle replay of one whole time step given in single-launch form (controller.build_step_problem):
+    the level loop of PrioritizedSequentialController.m:77-94 on the host, predecessors' solved areas handed over
+    as dynamic obstacles (PrioritizedController.m:476-491), published fallback areas on exhaustion.
+    Returns (records in slot order, planning milliseconds measured inside the C++ loop)."""
+    import copy
+
+    Hp = options.Hp
+    keep_m = None
+    if mpa_struct is None:
+        mpa_struct, keep_m = abi.pack_mpa(mpa)
+    n = len(problem["iters"])
+    recs = abi.out_array(n)
+    total_ms = 0.0
+    first = 0
+    for size in problem["level_sizes"]:
+        slots = list(range(first, first + size))
+        iters = []
+        for s in slots:
+            it = copy.copy(problem["iters"][s])
+            dyn = list(it.dynamic_obstacle_area)
+            for p in problem["preds"][s]:
+                if int(recs[p]["status"]) == 0:
+                    dyn.append([np.array(recs[p]["shapes"][k][:, : int(recs[p]["shape_cols"][k])]) for k in range(Hp)])
+                else:
+                    fb = problem["fallback"][p]
+                    if fb is not None and len(fb):
+                        dyn.append([np.asarray(a, dtype=np.float64) for a in fb])
+            it.dynamic_obstacle_area = dyn
+            iters.append(it)
+        arr, keep_v = abi.pack_vehicles(iters, Hp)
+        out, _, ms = plan_batch_raw(options, mpa_struct, arr, size, n_threads=min(n_threads, size))
+        total_ms += ms
+        for q, s in enumerate(slots):
+            recs[s] = out[q]
+            # the device publishes the fallback areas of an exhausted vehicle in its record
+            if int(out[q]["status"]) != 0:
+                fb = problem["fallback"][s]
+                if fb is not None and len(fb):
+                    for k in range(Hp):
+                        a = np.asarray(fb[k], dtype=np.float64)
+                        recs[s]["shape_cols"][k] = a.shape[1]
+                        recs[s]["shapes"][k][:, : a.shape[1]] = a
+        del keep_v
+        first += size
+    del keep_m
+    return recs, total_ms

@@ -90,6 +90,27 @@ const size_t kLdsMax = 160 * 1024;  // gfx950: 160 KiB per CU (MI355X_MICROARCH.
 
 }  // namespace
 
+// one packed batch: host mirror (pinned) + device copy
+struct PackedStep {
+    PinnedBuf<DevVehicle> h_veh;
+    PinnedBuf<double> h_pts;
+    PinnedBuf<int32_t> h_pred;
+    DevBuf<DevVehicle> d_veh;
+    DevBuf<double> d_pts;
+    DevBuf<int32_t> d_pred;
+    int n_packed = 0;
+    int soup_cap = 0;
+    std::vector<int64_t> lit_cols;  // per vehicle: literal soup + boundary columns (for the bytes formula)
+    void release() {
+        h_veh.release();
+        h_pts.release();
+        h_pred.release();
+        d_veh.release();
+        d_pts.release();
+        d_pred.release();
+    }
+};
+
 struct pdmpc_handle {
     pdmpc_config cfg{};
     hipStream_t stream = nullptr;
@@ -113,17 +134,10 @@ struct pdmpc_handle {
     DevBuf<uint32_t> d_flag;
     DevBuf<int32_t> d_tree_size;
     DevBuf<int32_t> d_trace;
-    // batch blob
-    PinnedBuf<DevVehicle> h_veh;
-    PinnedBuf<double> h_pts;
-    PinnedBuf<int32_t> h_pred;
-    DevBuf<DevVehicle> d_veh;
-    DevBuf<double> d_pts;
-    DevBuf<int32_t> d_pred;
-    int n_packed = 0;
-    int soup_cap = 0;
-    uint32_t epoch = 0;
-    std::vector<int64_t> lit_cols;  // per vehicle: literal soup + boundary columns (for the bytes formula)
+    // batch blobs: several packed steps can stay resident side by side ("banks", pdmpc_select_bank)
+    std::vector<PackedStep> banks;
+    int bank = 0;
+    uint32_t epoch = 1;  // done flags start at 0, so no slot looks solved before its first launch
     // launches
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
@@ -134,8 +148,9 @@ struct pdmpc_handle {
 
 namespace {
 
-int compute_lds(pdmpc_handle* h, int n_launch) {
+int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in) {
     const int Hp = h->cfg.Hp;
+    struct { int soup_cap; } hb{soup_cap_in};
     const size_t budget = (n_launch > h->n_cu) ? kLdsMax / 2 : kLdsMax;
     LdsLayout L{};
     uint32_t off = 0;
@@ -150,7 +165,7 @@ int compute_lds(pdmpc_handle* h, int n_launch) {
     const uint32_t ref_bytes = 3 * PDMPC_HP_MAX * 8;
     const uint32_t shape_bytes = 2 * PDMPC_VMAX * 16;
     const uint32_t path_bytes = align16((PDMPC_HP_MAX + 2) * 4 + 2 * (PDMPC_HP_MAX + 1) * 4);
-    const uint32_t soup_bytes = (uint32_t)std::max(h->soup_cap, 1) * 16;
+    const uint32_t soup_bytes = (uint32_t)std::max(hb.soup_cap, 1) * 16;
     const uint32_t fixed_rest = ref_bytes + shape_bytes + path_bytes + soup_bytes;
     const uint32_t per_entry = 8 + 4 + 7 * 8 + 4 + 2;  // heap key+id, node doubles, parent, tk
     const uint32_t min_entries = 64;
@@ -168,7 +183,7 @@ int compute_lds(pdmpc_handle* h, int n_launch) {
     off = align16(off + soup_bytes);
     if ((size_t)off + (size_t)min_entries * per_entry + 256 > budget) {
         char buf[256];
-        snprintf(buf, sizeof buf, "obstacle soup (%d columns) + MPA tables need %u B of LDS, budget %zu B", h->soup_cap, off, budget);
+        snprintf(buf, sizeof buf, "obstacle soup (%d columns) + MPA tables need %u B of LDS, budget %zu B", hb.soup_cap, off, budget);
         return fail(PDMPC_ERR_CAPACITY, buf);
     }
     uint32_t entries = (uint32_t)((budget - off - 256) / per_entry);
@@ -228,16 +243,17 @@ int pack_common(pdmpc_handle* h, int n, const pdmpc_vehicle_in* in, const int32_
     if (n < 0 || (n > 0 && !in)) return fail(PDMPC_ERR_INVALID, "bad vehicle array");
     if (n > h->max_vehicles) return fail(PDMPC_ERR_CAPACITY, "batch larger than config.max_vehicles");
     const int Hp = h->cfg.Hp;
+    PackedStep& B = h->banks[h->bank];
     const double qnan = std::numeric_limits<double>::quiet_NaN();
     std::vector<double> pts;
     pts.reserve((size_t)n * 256);
     std::vector<int32_t> pred;
-    if (h->h_veh.ensure((size_t)std::max(n, 1))) return fail(PDMPC_ERR_HIP, "hipHostMalloc failed");
-    h->lit_cols.assign((size_t)n, 0);
+    if (B.h_veh.ensure((size_t)std::max(n, 1))) return fail(PDMPC_ERR_HIP, "hipHostMalloc failed");
+    B.lit_cols.assign((size_t)n, 0);
     int soup_cap = 0;
     for (int i = 0; i < n; ++i) {
         const pdmpc_vehicle_in& v = in[i];
-        DevVehicle& d = h->h_veh.p[i];
+        DevVehicle& d = B.h_veh.p[i];
         std::memset(&d, 0, sizeof d);
         if (!v.ref_x || !v.ref_y || !v.v_ref) return fail(PDMPC_ERR_INVALID, "reference trajectory missing");
         if (v.trim0 < 1 || v.trim0 > h->n_trims) return fail(PDMPC_ERR_INVALID, "trim0 out of range");
@@ -281,7 +297,7 @@ int pack_common(pdmpc_handle* h, int n, const pdmpc_vehicle_in* in, const int32_
             need += (int)(pts.size() / 2) - d.lit_off[k] + n_pred * PDMPC_VMAX;
         }
         d.lit_off[Hp] = (int32_t)(pts.size() / 2);
-        h->lit_cols[i] = d.lit_off[Hp] - d.lit_off[0];
+        B.lit_cols[i] = d.lit_off[Hp] - d.lit_off[0];
         for (int k = 0; k < Hp; ++k) {
             d.hdv_off[k] = (int32_t)(pts.size() / 2);
             for (int r = 0; r < n_hdv; ++r) append_poly(v.hdv_reachable_sets, r * Hp + k, true);
@@ -296,7 +312,7 @@ int pack_common(pdmpc_handle* h, int n, const pdmpc_vehicle_in* in, const int32_
         push_pt(pts, qnan, qnan);
         d.ll_len = (int32_t)(pts.size() / 2) - d.ll_off;
         need += d.ll_len;
-        h->lit_cols[i] += d.ll_len;
+        B.lit_cols[i] += d.ll_len;
         if (fallback && fallback[i].n_polygons > 0) {
             if (fallback[i].n_polygons != Hp) return fail(PDMPC_ERR_INVALID, "fallback_shapes must hold Hp polygons per vehicle");
             int rc2;
@@ -316,19 +332,18 @@ int pack_common(pdmpc_handle* h, int n, const pdmpc_vehicle_in* in, const int32_
     // a trailing pad so 16-byte staged copies never run past the allocation
     push_pt(pts, qnan, qnan);
     pred.push_back(0);
-    h->soup_cap = soup_cap + 2;
-    if (h->h_pts.ensure(pts.size()) || h->h_pred.ensure(pred.size())) return fail(PDMPC_ERR_HIP, "hipHostMalloc failed");
-    std::memcpy(h->h_pts.p, pts.data(), pts.size() * sizeof(double));
-    std::memcpy(h->h_pred.p, pred.data(), pred.size() * sizeof(int32_t));
-    if (h->d_veh.ensure((size_t)std::max(n, 1)) || h->d_pts.ensure(pts.size()) || h->d_pred.ensure(pred.size()))
+    B.soup_cap = soup_cap + 2;
+    if (B.h_pts.ensure(pts.size()) || B.h_pred.ensure(pred.size())) return fail(PDMPC_ERR_HIP, "hipHostMalloc failed");
+    std::memcpy(B.h_pts.p, pts.data(), pts.size() * sizeof(double));
+    std::memcpy(B.h_pred.p, pred.data(), pred.size() * sizeof(int32_t));
+    if (B.d_veh.ensure((size_t)std::max(n, 1)) || B.d_pts.ensure(pts.size()) || B.d_pred.ensure(pred.size()))
         return fail(PDMPC_ERR_HIP, "hipMalloc failed for the batch blob");
-    if (n > 0) HIPCHK(hipMemcpyAsync(h->d_veh.p, h->h_veh.p, (size_t)n * sizeof(DevVehicle), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->d_pts.p, h->h_pts.p, pts.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->d_pred.p, h->h_pred.p, pred.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    if (n > 0) HIPCHK(hipMemcpyAsync(B.d_veh.p, B.h_veh.p, (size_t)n * sizeof(DevVehicle), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(B.d_pts.p, B.h_pts.p, pts.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(B.d_pred.p, B.h_pred.p, pred.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
     // the pinned staging buffers are reused by the next pack: finish the copies first
     HIPCHK(hipStreamSynchronize(h->stream));
-    h->n_packed = n;
-    h->epoch += 1;
+    B.n_packed = n;
     h->events_used = 0;
     std::memset(&h->stats, 0, sizeof h->stats);
     return PDMPC_OK;
@@ -336,9 +351,10 @@ int pack_common(pdmpc_handle* h, int n, const pdmpc_vehicle_in* in, const int32_
 
 int launch_range(pdmpc_handle* h, int first, int count) {
     if (!h) return fail(PDMPC_ERR_INVALID, "null handle");
-    if (first < 0 || count < 0 || first + count > h->n_packed) return fail(PDMPC_ERR_INVALID, "launch range outside the packed batch");
+    PackedStep& B = h->banks[h->bank];
+    if (first < 0 || count < 0 || first + count > B.n_packed) return fail(PDMPC_ERR_INVALID, "launch range outside the packed batch");
     if (count == 0) return PDMPC_OK;
-    int rc = compute_lds(h, count);
+    int rc = compute_lds(h, count, B.soup_cap);
     if (rc) return rc;
     KernelArgs a{};
     a.succ_mask = h->d_mask.p;
@@ -352,9 +368,9 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.checker = h->cfg.checker;
     a.areas_in_lds = h->areas_in_lds;
     a.dt = h->cfg.dt_seconds;
-    a.veh = h->d_veh.p;
-    a.points = h->d_pts.p;
-    a.pred = h->d_pred.p;
+    a.veh = B.d_veh.p;
+    a.points = B.d_pts.p;
+    a.pred = B.d_pred.p;
     a.out = h->d_out.p;
     a.done_flag = h->d_flag.p;
     a.epoch = h->epoch;
@@ -377,7 +393,7 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.lds = h->lds;
     a.HL = h->HL;
     a.NL = h->NL;
-    a.soup_cap = h->soup_cap;
+    a.soup_cap = B.soup_cap;
     a.spin_limit = 1u << 22;
     if (h->events_used == h->events.size()) {
         hipEvent_t e0, e1;
@@ -421,6 +437,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
         return fail(PDMPC_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
     pdmpc_handle* h = new pdmpc_handle();
     h->cfg = *config;
+    h->banks.resize(1);
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     h->max_nodes = config->max_nodes > 0 ? (uint32_t)config->max_nodes : 32768u;  // default arena: 256 x 32768 nodes, about 0.6 GB
     h->max_nodes = (h->max_nodes + 1u) & ~1u;
@@ -476,12 +493,7 @@ int pdmpc_destroy(pdmpc_handle* h) {
     h->d_flag.release();
     h->d_tree_size.release();
     h->d_trace.release();
-    h->h_veh.release();
-    h->h_pts.release();
-    h->h_pred.release();
-    h->d_veh.release();
-    h->d_pts.release();
-    h->d_pred.release();
+    for (auto& b : h->banks) b.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return PDMPC_OK;
@@ -556,7 +568,29 @@ int pdmpc_pack_step(pdmpc_handle* h, int32_t n, const pdmpc_vehicle_in* in, cons
 int pdmpc_launch_packed(pdmpc_handle* h) {
     if (!h) return fail(PDMPC_ERR_INVALID, "null handle");
     HIPCHK(hipSetDevice(h->cfg.device));
-    return launch_range(h, 0, h->n_packed);
+    h->epoch += 1;  // a new step: results of earlier launches no longer satisfy predecessor waits
+    return launch_range(h, 0, h->banks[h->bank].n_packed);
+}
+
+int pdmpc_begin_step(pdmpc_handle* h) {
+    if (!h) return fail(PDMPC_ERR_INVALID, "null handle");
+    h->epoch += 1;
+    return PDMPC_OK;
+}
+
+int pdmpc_select_bank(pdmpc_handle* h, int32_t bank) {
+    if (!h) return fail(PDMPC_ERR_INVALID, "null handle");
+    if (bank < 0 || bank >= 4096) return fail(PDMPC_ERR_INVALID, "bank out of range");
+    if ((size_t)bank >= h->banks.size()) h->banks.resize((size_t)bank + 1);
+    h->bank = bank;
+    return PDMPC_OK;
+}
+
+int pdmpc_reset_stats(pdmpc_handle* h) {
+    if (!h) return fail(PDMPC_ERR_INVALID, "null handle");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->events_used = 0;
+    return PDMPC_OK;
 }
 
 int pdmpc_launch_range(pdmpc_handle* h, int32_t first, int32_t count) {
@@ -580,16 +614,17 @@ int pdmpc_fetch_results(pdmpc_handle* h, int32_t n, pdmpc_vehicle_out* out) {
     // counters + SURVEY.md 8(d) algorithmic bytes of one pass over the packed batch
     pdmpc_stats& s = h->stats;
     const int Hp = h->cfg.Hp;
-    const int m = std::min(n, h->n_packed);
+    PackedStep& B = h->banks[h->bank];
+    const int m = std::min(n, B.n_packed);
     s.n_vehicles = m;
     s.nodes_popped = s.nodes_generated = s.obstacle_columns = 0;
     int64_t bytes = h->mpa_alg_bytes;
     for (int i = 0; i < m; ++i) {
         const pdmpc_vehicle_out& o = out[i];
-        const DevVehicle& d = h->h_veh.p[i];
-        int64_t cols = h->lit_cols[i];
+        const DevVehicle& d = B.h_veh.p[i];
+        int64_t cols = B.lit_cols[i];
         for (int q = 0; q < d.n_pred; ++q) {
-            const int ps = h->h_pred.p[d.pred_off + q];
+            const int ps = B.h_pred.p[d.pred_off + q];
             if (ps < n)
                 for (int k = 0; k < Hp; ++k) cols += out[ps].shape_cols[k] + 1;
         }

@@ -24,6 +24,9 @@ EXPORTS = [
     "pdmpc_pack_batch",
     "pdmpc_launch_packed",
     "pdmpc_launch_range",
+    "pdmpc_begin_step",
+    "pdmpc_select_bank",
+    "pdmpc_reset_stats",
     "pdmpc_fetch_results",
     "pdmpc_synchronize",
     "pdmpc_pack_step",
@@ -61,6 +64,9 @@ def load_library(path=None):
     L.pdmpc_pack_batch.argtypes = [H, C.c_int32, C.POINTER(abi.VehicleIn)]
     L.pdmpc_launch_packed.argtypes = [H]
     L.pdmpc_launch_range.argtypes = [H, C.c_int32, C.c_int32]
+    L.pdmpc_begin_step.argtypes = [H]
+    L.pdmpc_select_bank.argtypes = [H, C.c_int32]
+    L.pdmpc_reset_stats.argtypes = [H]
     L.pdmpc_fetch_results.argtypes = [H, C.c_int32, C.POINTER(abi.VehicleOut)]
     L.pdmpc_synchronize.argtypes = [H]
     L.pdmpc_pack_step.argtypes = [H, C.c_int32, C.POINTER(abi.VehicleIn), abi.c_int32_p, abi.c_int32_p, C.POINTER(abi.PolygonSet)]
@@ -163,6 +169,15 @@ class Handle:
 
     def launch_range(self, first, count):
         _check(self.L, self.L.pdmpc_launch_range(self.h, first, count), "pdmpc_launch_range")
+
+    def begin_step(self):
+        _check(self.L, self.L.pdmpc_begin_step(self.h), "pdmpc_begin_step")
+
+    def select_bank(self, bank):
+        _check(self.L, self.L.pdmpc_select_bank(self.h, bank), "pdmpc_select_bank")
+
+    def reset_stats(self):
+        _check(self.L, self.L.pdmpc_reset_stats(self.h), "pdmpc_reset_stats")
 
     def synchronize(self):
         _check(self.L, self.L.pdmpc_synchronize(self.h), "pdmpc_synchronize")

@@ -141,7 +141,9 @@ class PrioritizedSequentialController:
         raise ValueError(self.coupling)
 
     # ---- PrioritizedController.plan: obstacle assembly (PrioritizedController.m:297-324)
-    def _iter_for(self, i, directed, directed_seq):
+    def _iter_for(self, i, directed, directed_seq, device_handoff=False):
+        """device_handoff: sequential predecessors are NOT expanded into polygons here; the kernel appends their
+        solved areas on the device (pdmpc_pack_step), so the whole step is one launch."""
         o = self.options
         Hp = o.Hp
         predecessors = [j for j in range(self.n) if directed[j, i] == 1]
@@ -150,6 +152,8 @@ class PrioritizedSequentialController:
         dyn = []
         for j in predecessors:  # consider_predecessors :449-506
             if j in predecessors_seq:
+                if device_handoff:
+                    continue
                 dyn.append(list(self.infos[j].shapes))  # this step's /vehicle_prediction :476-491
             else:
                 old = self.info_old[j]  # parallel_coupling_previous_trajectory :409-447
@@ -213,29 +217,69 @@ class PrioritizedSequentialController:
         info.needs_fallback = True
         return info
 
-    def step(self):
-        """One pass of HighLevelController.main_control_loop (HighLevelController.m:334-373) in simulation."""
-        self.k += 1
+    def _post_plan(self, i, it, info):
+        self.last_iters[i] = it
+        if info.is_exhausted:  # PrioritizedController.m:344-352
+            standstill = self.mpa.trims[it.trim_index - 1].speed == 0
+            if standstill and self.options.constraint_from_successor != ConstraintFromSuccessor.none:
+                info = self._standstill_info(i, it, info)
+            else:
+                info = self._fallback_info(i, info)
+        self.infos[i] = info
+
+    def _published_on_exhaustion(self, i):
+        """The Hp areas vehicle i publishes if its search is exhausted: its standstill rectangle
+        (PrioritizedController.m:602-611) or the previous plan shifted by one step (:678-718)."""
+        o = self.options
+        standstill = self.mpa.trims[int(self.trims[i]) - 1].speed == 0
+        if standstill and o.constraint_from_successor != ConstraintFromSuccessor.none:
+            return [self.occupied[i][1].copy() for _ in range(o.Hp)]
+        if self.info_old[i] is not None:
+            return del_first_rpt_last(self.info_old[i].shapes)
+        return None
+
+    def build_step_problem(self):
+        """Everything one launch needs to plan the whole time step: vehicles in level order (slot = position),
+        per-slot predecessor slots, per-slot areas to publish on exhaustion."""
         self._traffic_info()
         adjacency = self._couple()
         directed = directed_coupling_from_priorities(adjacency, self.priorities)
-        directed_seq = directed  # no cutting: every coupled pair plans sequentially (max_num_CLs >= depth)
+        directed_seq = directed
         levels = kahn(directed_seq)
         self.last_levels = levels
+        order = sorted(range(self.n), key=lambda i: (int(levels[i]), i))
+        slot_of = {v: s for s, v in enumerate(order)}
+        iters = [self._iter_for(i, directed, directed_seq, device_handoff=True) for i in order]
+        preds = [[slot_of[j] for j in range(self.n) if directed_seq[j, i]] for i in order]
+        fallback = [self._published_on_exhaustion(i) for i in order]
+        level_sizes = [int(np.sum(levels == l)) for l in range(1, int(levels.max()) + 1)]
+        return {"order": order, "iters": iters, "preds": preds, "fallback": fallback, "level_sizes": level_sizes}
+
+    def step(self, plan_step=None):
+        """One pass of HighLevelController.main_control_loop (HighLevelController.m:334-373) in simulation.
+        With `plan_step(problem) -> list[ControlResultsInfo]` (slot order) the whole step is planned by one call
+        (one kernel launch, hand-off of solved areas on the device); otherwise levels are planned one by one."""
+        self.k += 1
         self.infos = [None] * self.n
-        for lvl in range(1, int(levels.max()) + 1):  # PrioritizedSequentialController.m:83-91
-            members = [i for i in range(self.n) if levels[i] == lvl]
-            iters = [self._iter_for(i, directed, directed_seq) for i in members]
-            results = self.plan_level(iters)
-            for i, it, info in zip(members, iters, results):
-                self.last_iters[i] = it
-                if info.is_exhausted:  # PrioritizedController.m:344-352
-                    standstill = self.mpa.trims[it.trim_index - 1].speed == 0
-                    if standstill and self.options.constraint_from_successor != ConstraintFromSuccessor.none:
-                        info = self._standstill_info(i, it, info)
-                    else:
-                        info = self._fallback_info(i, info)
-                self.infos[i] = info
+        if plan_step is not None:
+            prob = self.build_step_problem()
+            self.last_problem = prob
+            results = plan_step(prob)
+            for s, i in enumerate(prob["order"]):
+                self._post_plan(i, prob["iters"][s], results[s])
+        else:
+            self._traffic_info()
+            adjacency = self._couple()
+            directed = directed_coupling_from_priorities(adjacency, self.priorities)
+            directed_seq = directed  # no cutting: every coupled pair plans sequentially (max_num_CLs >= depth)
+            levels = kahn(directed_seq)
+            self.last_levels = levels
+            for lvl in range(1, int(levels.max()) + 1):  # PrioritizedSequentialController.m:83-91
+                members = [i for i in range(self.n) if levels[i] == lvl]
+                iters = [self._iter_for(i, directed, directed_seq) for i in members]
+                results = self.plan_level(iters)
+                for i, it, info in zip(members, iters, results):
+                    self._post_plan(i, it, info)
         # Simulation.apply (Simulation.m:86-100)
         for i, info in enumerate(self.infos):
             t = self.mpa.trims[int(info.predicted_trims[0]) - 1]

@@ -53,3 +53,15 @@ class GraphSearchHip(OptimizerInterface):
         self._ensure_mpa(mpa)
         recs = self.handle.plan_batch(iters)
         return [info_from_record(recs[i], self.options.Hp) for i in range(len(iters))]
+
+    def run_optimizer_step(self, problem, mpa) -> List[ControlResultsInfo]:
+        """A whole time step (all computation levels) in one launch: PrioritizedSequentialController.controller
+        (PrioritizedSequentialController.m:77-94) with the level loop replaced by per-vehicle dependency waits on
+        the device.  `problem` comes from pdmpc.controller.PrioritizedSequentialController.build_step_problem."""
+        self._ensure_mpa(mpa)
+        n = len(problem["iters"])
+        fb = [f if f is not None else [] for f in problem["fallback"]]
+        self.handle.pack_step(problem["iters"], problem["preds"], fb)
+        self.handle.launch()
+        recs = self.handle.fetch(n)
+        return [info_from_record(recs[i], self.options.Hp) for i in range(n)]

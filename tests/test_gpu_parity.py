@@ -122,11 +122,11 @@ def test_circle_closed_loop_c1():
 
 
 def test_exhaustion_and_overflow_status():
-    """A vehicle boxed in by static obstacles exhausts its open list (GraphSearch.m:57-61); a tiny arena overflows."""
+    """A vehicle cut by a static obstacle exhausts its open list (GraphSearch.m:57-61); a tiny arena overflows."""
     options, mpa, iters = problems.problem_set("interx", 21, 4, Hp=6)
     for it in iters:
         x, y = it.x0[0], it.x0[1]
-        it.obstacles = [problems.rect(x + 0.3, y, np.pi / 2, 1.2, 0.05), problems.rect(x - 0.25, y, np.pi / 2, 1.2, 0.05)]
+        it.obstacles = [problems.rect(x, y, np.pi / 2, 1.2, 0.05)]  # a wall through the vehicle itself: every edge crosses it
     gpu, _ = check_batch(options, mpa, iters)
     assert (gpu["status"] == abi.EXHAUSTED).any()
     options2, mpa2, iters2 = problems.problem_set("interx", 22, 4, Hp=6)

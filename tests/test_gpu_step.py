@@ -1,0 +1,70 @@
+"""Whole-step planning in one launch (device-side hand-off of solved areas) vs the oracle's host level loop."""
+import numpy as np
+import pytest
+
+from pdmpc.config import Config, MpaType, ScenarioType
+from pdmpc.controller import PrioritizedSequentialController
+from pdmpc.iteration_data import info_from_record
+from pdmpc.mpa import get_mpa
+
+from test_gpu_parity import assert_records_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def run_closed_loop(options, scenario, coupling, boundary, n_steps):
+    from oracle import oracle
+    from pdmpc.optimizer import GraphSearchHip
+
+    mpa = get_mpa(options)
+    opt = GraphSearchHip(options)
+    opt._ensure_mpa(mpa)
+    ctl = PrioritizedSequentialController(options, scenario, mpa, None, coupling=coupling, boundary_provider=boundary)
+    n_checked = [0]
+
+    def plan_step(prob):
+        n = len(prob["iters"])
+        fb = [f if f is not None else [] for f in prob["fallback"]]
+        opt.handle.pack_step(prob["iters"], prob["preds"], fb)
+        opt.handle.launch()
+        gpu = opt.handle.fetch(n)
+        ref, _ = oracle.plan_step(options, mpa, prob)
+        assert_records_equal(gpu, ref, "step %d" % n_checked[0])
+        n_checked[0] += 1
+        return [info_from_record(gpu[i], options.Hp) for i in range(n)]
+
+    for _ in range(n_steps):
+        ctl.step(plan_step=plan_step)
+    opt.handle.close()
+    return ctl
+
+
+def test_circle_step_in_one_launch():
+    from pdmpc.scenario import circle_scenario
+
+    options = Config(scenario_type=ScenarioType.circle, amount=3, Hp=5, T_end=4, max_vehicles=4, max_nodes=1 << 15)
+    run_closed_loop(options, circle_scenario(options), "full", None, options.k_end)
+
+
+def test_circle_8_vehicles_step():
+    from pdmpc.scenario import circle_scenario
+
+    options = Config(scenario_type=ScenarioType.circle, amount=8, Hp=6, max_vehicles=8, max_nodes=1 << 16)
+    run_closed_loop(options, circle_scenario(options), "full", None, 12)
+
+
+def test_road_network_20_vehicles_step():
+    """BASELINE config 1 (C2): 20 vehicles on the lab map, Hp 8, InterX."""
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    options = Config(scenario_type=ScenarioType.commonroad, amount=20, Hp=8, max_vehicles=32, max_nodes=1 << 17)
+    sc = commonroad_scenario(options, seed=1)
+    run_closed_loop(options, sc, "distance", boundary_provider(sc), 12)
+
+
+def test_road_network_triple_speed_step():
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    options = Config(scenario_type=ScenarioType.commonroad, amount=10, Hp=6, mpa_type=MpaType.triple_speed, max_vehicles=16, max_nodes=1 << 17)
+    sc = commonroad_scenario(options, seed=3)
+    run_closed_loop(options, sc, "distance", boundary_provider(sc), 8)
