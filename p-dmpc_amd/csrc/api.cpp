@@ -127,9 +127,9 @@ struct pdmpc_handle {
     // arenas
     uint32_t max_nodes = 0;
     int max_vehicles = 0;
-    DevBuf<double> ax, ay, ayaw, ag, ah, acs, asn, ahk;
-    DevBuf<uint32_t> aparent, ahid;
-    DevBuf<uint16_t> atk;
+    DevBuf<NodeRec> anodes;
+    DevBuf<double> ahk;
+    DevBuf<uint32_t> ahid;
     DevBuf<pdmpc_vehicle_out> d_out;
     DevBuf<uint32_t> d_flag;
     DevBuf<int32_t> d_tree_size;
@@ -167,10 +167,10 @@ int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in) {
     const uint32_t path_bytes = align16((PDMPC_HP_MAX + 2) * 4 + 2 * (PDMPC_HP_MAX + 1) * 4);
     const uint32_t soup_bytes = (uint32_t)std::max(hb.soup_cap, 1) * 16;
     const uint32_t fixed_rest = ref_bytes + shape_bytes + path_bytes + soup_bytes;
-    const uint32_t per_entry = 8 + 4 + 7 * 8 + 4 + 2;  // heap key+id, node doubles, parent, tk
-    const uint32_t min_entries = 64;
+    const uint32_t cand_bytes = align16((uint32_t)std::max(hb.soup_cap, 1) * 4);
+    const uint32_t min_bytes = 64 * 12 + 64 * (uint32_t)sizeof(NodeRec);
     int areas = 1;
-    if ((size_t)off + area_bytes + fixed_rest + (size_t)min_entries * per_entry + 256 > budget) areas = 0;
+    if ((size_t)off + area_bytes + fixed_rest + cand_bytes + min_bytes + 256 > budget) areas = 0;
     L.area = off;
     if (areas) off = align16(off + area_bytes);
     L.ref = off;
@@ -181,43 +181,31 @@ int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in) {
     off += path_bytes;
     L.soup = off;
     off = align16(off + soup_bytes);
-    if ((size_t)off + (size_t)min_entries * per_entry + 256 > budget) {
+    L.cand = off;
+    off += cand_bytes;
+    if ((size_t)off + min_bytes + 256 > budget) {
         char buf[256];
         snprintf(buf, sizeof buf, "obstacle soup (%d columns) + MPA tables need %u B of LDS, budget %zu B", hb.soup_cap, off, budget);
         return fail(PDMPC_ERR_CAPACITY, buf);
     }
-    uint32_t entries = (uint32_t)((budget - off - 256) / per_entry);
-    entries = std::min(entries, (uint32_t)4096);
-    entries = std::min(entries, h->max_nodes);
-    entries &= ~1u;  // keep every region 16-byte aligned
-    const uint32_t e8 = align16(entries * 8), e4 = align16(entries * 4), e2 = align16(entries * 2);
+    // the open list is touched several times per pop, a node twice: give the heap up to 4096 entries
+    // (12 levels) first, the rest of the budget to 64-byte node records
+    const uint32_t rest = (uint32_t)(budget - off - 256);
+    uint32_t hl = std::min((uint32_t)4096, rest / 2 / 12);
+    hl = std::min(hl, h->max_nodes) & ~3u;
+    uint32_t nl = (rest - hl * 12) / (uint32_t)sizeof(NodeRec);
+    nl = std::min(nl, h->max_nodes);
     L.heap_key = off;
-    off += e8;
+    off += align16(hl * 8);
     L.heap_id = off;
-    off += e4;
-    L.nx = off;
-    off += e8;
-    L.ny = off;
-    off += e8;
-    L.nyaw = off;
-    off += e8;
-    L.ng = off;
-    off += e8;
-    L.nh = off;
-    off += e8;
-    L.ncs = off;
-    off += e8;
-    L.nsn = off;
-    off += e8;
-    L.nparent = off;
-    off += e4;
-    L.ntk = off;
-    off += e2;
+    off += align16(hl * 4);
+    L.nodes = off;
+    off += nl * (uint32_t)sizeof(NodeRec);
     L.total = align16(off);
     if (L.total > budget) return fail(PDMPC_ERR_CAPACITY, "internal: LDS layout exceeds budget");
     h->lds = L;
-    h->HL = (int)entries;
-    h->NL = (int)entries;
+    h->HL = (int)hl;
+    h->NL = (int)nl;
     h->areas_in_lds = areas;
     (void)Hp;
     return PDMPC_OK;
@@ -375,15 +363,7 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.done_flag = h->d_flag.p;
     a.epoch = h->epoch;
     a.first = first;
-    a.arena.x = h->ax.p;
-    a.arena.y = h->ay.p;
-    a.arena.yaw = h->ayaw.p;
-    a.arena.g = h->ag.p;
-    a.arena.h = h->ah.p;
-    a.arena.cs = h->acs.p;
-    a.arena.sn = h->asn.p;
-    a.arena.parent = h->aparent.p;
-    a.arena.tk = h->atk.p;
+    a.arena.nodes = h->anodes.p;
     a.arena.heap_key = h->ahk.p;
     a.arena.heap_id = h->ahid.p;
     a.max_nodes = h->max_nodes;
@@ -449,9 +429,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
     }
     const size_t tot = (size_t)h->max_vehicles * h->max_nodes;
     int bad = 0;
-    bad |= h->ax.ensure(tot) | h->ay.ensure(tot) | h->ayaw.ensure(tot) | h->ag.ensure(tot) | h->ah.ensure(tot);
-    bad |= h->acs.ensure(tot) | h->asn.ensure(tot) | h->ahk.ensure(tot);
-    bad |= h->aparent.ensure(tot) | h->ahid.ensure(tot) | h->atk.ensure(tot);
+    bad |= h->anodes.ensure(tot) | h->ahk.ensure(tot) | h->ahid.ensure(tot);
     bad |= h->d_out.ensure((size_t)h->max_vehicles) | h->d_flag.ensure((size_t)h->max_vehicles) | h->d_tree_size.ensure((size_t)h->max_vehicles);
     bad |= h->d_trace.ensure((size_t)h->max_vehicles * (size_t)std::max(config->trace_pops, 1));
     if (bad) {
@@ -478,17 +456,9 @@ int pdmpc_destroy(pdmpc_handle* h) {
     h->d_mi.release();
     h->d_pose.release();
     h->d_area.release();
-    h->ax.release();
-    h->ay.release();
-    h->ayaw.release();
-    h->ag.release();
-    h->ah.release();
-    h->acs.release();
-    h->asn.release();
+    h->anodes.release();
     h->ahk.release();
-    h->aparent.release();
     h->ahid.release();
-    h->atk.release();
     h->d_out.release();
     h->d_flag.release();
     h->d_tree_size.release();
@@ -711,19 +681,17 @@ int pdmpc_debug_tree(pdmpc_handle* h, int32_t vehicle, int32_t capacity, double*
     const size_t m = (size_t)std::max(std::min(sz, capacity), 0);
     if (m == 0) return PDMPC_OK;
     const size_t off = (size_t)vehicle * h->max_nodes;
-    if (x) HIPCHK(hipMemcpy(x, h->ax.p + off, m * 8, hipMemcpyDeviceToHost));
-    if (y) HIPCHK(hipMemcpy(y, h->ay.p + off, m * 8, hipMemcpyDeviceToHost));
-    if (yaw) HIPCHK(hipMemcpy(yaw, h->ayaw.p + off, m * 8, hipMemcpyDeviceToHost));
-    if (g) HIPCHK(hipMemcpy(g, h->ag.p + off, m * 8, hipMemcpyDeviceToHost));
-    if (hh) HIPCHK(hipMemcpy(hh, h->ah.p + off, m * 8, hipMemcpyDeviceToHost));
-    std::vector<uint32_t> par(m);
-    std::vector<uint16_t> tk(m);
-    HIPCHK(hipMemcpy(par.data(), h->aparent.p + off, m * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(tk.data(), h->atk.p + off, m * 2, hipMemcpyDeviceToHost));
+    std::vector<NodeRec> rec(m);
+    HIPCHK(hipMemcpy(rec.data(), h->anodes.p + off, m * sizeof(NodeRec), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < m; ++i) {
-        if (parent) parent[i] = (int32_t)par[i];
-        if (trim) trim[i] = (int32_t)(tk[i] & 1023u);
-        if (k) k[i] = (int32_t)(tk[i] >> 10);
+        if (x) x[i] = rec[i].x;
+        if (y) y[i] = rec[i].y;
+        if (yaw) yaw[i] = rec[i].yaw;
+        if (g) g[i] = rec[i].g;
+        if (hh) hh[i] = rec[i].h;
+        if (parent) parent[i] = (int32_t)rec[i].parent;
+        if (trim) trim[i] = NODE_TRIM(rec[i].packed);
+        if (k) k[i] = NODE_K(rec[i].packed);
     }
     return PDMPC_OK;
 }

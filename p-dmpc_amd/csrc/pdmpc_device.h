@@ -43,23 +43,36 @@ struct DevVehicle {
     int32_t pad;
 };
 
+// One search-tree node (Tree.m:3-13 row + what the pop of this node needs), 64 bytes so a node is four
+// 16-byte accesses and the children of an expansion form one contiguous, coalesced store.
+struct NodeRec {
+    double x, y, yaw, g;  // Tree.x/y/yaw/g
+    double cs, sn;        // cos/sin(yaw), filled when the node is expanded (expand_node.m:50-51); its children's
+                          // edge checks read them (GraphSearch.m:155-156)
+    double h;             // Tree.h
+    uint32_t parent;      // Tree.parent (1-based id, 0 for the root)
+    uint32_t packed;      // trim (10 bit, 1-based) | k << 10 (5 bit) | maneuver index << 15 (12 bit) | area columns << 27
+};
+#define NODE_TRIM(p) ((int)((p) & 1023u))
+#define NODE_K(p) ((int)(((p) >> 10) & 31u))
+#define NODE_MAN(p) ((int)(((p) >> 15) & 4095u))
+#define NODE_COLS(p) ((int)((p) >> 27))
+
 // byte offsets of the regions of the dynamic LDS allocation (all multiples of 16)
 struct LdsLayout {
-    uint32_t mask, man_index, pose, area;     // MPA tables
-    uint32_t ref;                             // ref_x[16], ref_y[16], dtv[16]
-    uint32_t shape;                           // shape A [8], shape B [8] (double2)
-    uint32_t path;                            // uint32 path[HP_MAX+1] + misc scratch
-    uint32_t soup;                            // double2[soup_cap]
-    uint32_t heap_key, heap_id;               // double[HL], uint32[HL]
-    uint32_t nx, ny, nyaw, ng, nh, ncs, nsn;  // double[NL] each
-    uint32_t nparent, ntk;                    // uint32[NL], uint16[NL]
+    uint32_t mask, man_index, pose, area;  // MPA tables
+    uint32_t ref;                          // ref_x[16], ref_y[16], dtv[16]
+    uint32_t shape;                        // shape A [8], shape B [8] (double2)
+    uint32_t path;                         // uint32 path[HP_MAX+1] + misc scratch
+    uint32_t soup;                         // double2[soup_cap]
+    uint32_t cand;                         // uint32[soup_cap]: compacted candidate segments of one edge check
+    uint32_t heap_key, heap_id;            // double[HL], uint32[HL]
+    uint32_t nodes;                        // NodeRec[NL]
     uint32_t total;
 };
 
-struct NodeArena {  // per-vehicle slices of HBM arrays (stride = max_nodes entries)
-    double *x, *y, *yaw, *g, *h, *cs, *sn;
-    uint32_t* parent;
-    uint16_t* tk;  // trim (low byte.. 10 bits) | k << 10
+struct NodeArena {  // HBM arrays, per-vehicle stride = max_nodes entries
+    NodeRec* nodes;
     double* heap_key;
     uint32_t* heap_id;
 };

@@ -11,20 +11,47 @@
 //   return_path_to / return_path_area / Tree.path_to_root
 //
 // Mapping to the hardware (DESIGN.md has the full picture):
-//   * MPA tables, the vehicle's obstacle "soup", the open list (binary heap) and the first NL tree nodes
-//     live in LDS; nodes are written through to HBM (SoA, coalesced across the children of an expansion),
-//     heap entries beyond HL and nodes beyond NL spill to HBM.
-//   * lanes parallelise the inner loops: one lane per obstacle segment (InterX) / per separating axis
-//     (SAT), one lane per successor trim (expansion), one lane per polygon vertex (area transform);
-//     wave votes (ballot) reduce the collision predicates.
-//   * the sequential part (heap sift, pop -> check -> expand) runs wave-uniform with scalar branches.
-//   * floating point: every expression keeps the reference's operation order; the file is compiled with
-//     -ffp-contract=off so no FMA is formed, sqrt and division are IEEE-correct, sin/cos come from
-//     include/pdmpc_math.h.  Results are bit-identical to the CPU oracle.
+//   * MPA tables, the vehicle's obstacle "soup", the open list (binary heap, first HL entries) and the first
+//     NL tree nodes live in LDS; every node is also written through to HBM as one 64-byte record (the children
+//     of an expansion are one contiguous coalesced store); heap entries beyond HL spill to HBM.
+//   * the search is a dependent chain (pop -> check -> expand -> push), so the design minimises the number of
+//     LDS/HBM round trips on that chain rather than bytes:
+//       - pop: libstdc++'s sift-down is replayed on a 5-level sub-tree fetched by 62 lanes in ONE round trip
+//         (3 round trips for a 32k-entry heap instead of 15 dependent ones);
+//       - push: all ancestors of the new leaf are fetched by one lane each, a ballot finds where the value
+//         stops, the shift is one parallel store;
+//       - node fetch: one 64-byte broadcast read;
+//       - edge check (InterX): pass 1 evaluates C2 (which obstacle-segment lines cut the vehicle's area) one
+//         lane per obstacle segment and compacts the few survivors; pass 2 evaluates C1 only for those.
+//         Skipping C1 where C2 is false changes no result: the reference tests C1 & C2 (InterX.m:72-76).
+//   * floating point: every evaluated expression keeps the reference's operation order; compiled with
+//     -ffp-contract=off (no FMA), IEEE sqrt/div, sin/cos from include/pdmpc_math.h: bit-identical to the oracle.
 #include <hip/hip_runtime.h>
 
 #include "../../include/pdmpc_math.h"
 #include "pdmpc_device.h"
+
+#ifdef PDMPC_PROFILE
+#define PROF_N 16
+#define PROF_MEMBERS unsigned long long prof_t0, prof_acc[PROF_N];
+#define PROF_DECL \
+    S.prof_t0 = 0; \
+    for (int i__ = 0; i__ < PROF_N; ++i__) S.prof_acc[i__] = 0;
+#define PROF_START S.prof_t0 = __builtin_readcyclecounter();
+#define PROF_STOP(i)                                            \
+    {                                                           \
+        unsigned long long t1__ = __builtin_readcyclecounter(); \
+        S.prof_acc[i] += t1__ - S.prof_t0;                      \
+        S.prof_t0 = t1__;                                       \
+    }
+#define PROF_COUNT(i, v) S.prof_acc[i] += (v);
+#else
+#define PROF_MEMBERS
+#define PROF_DECL
+#define PROF_START
+#define PROF_STOP(i)
+#define PROF_COUNT(i, v)
+#endif
 
 namespace {
 
@@ -44,126 +71,240 @@ __device__ __forceinline__ double lane_d(double v, int lane_uniform) {
     uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), lane_uniform);
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
+__device__ __forceinline__ uint32_t lane_u(uint32_t v, int lane_uniform) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane_uniform); }
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 __device__ __forceinline__ bool is_nan(double v) { return v != v; }
 
 // ---------------------------------------------------------------------------------------------------
-// Per-vehicle search state.  Pointers named l* point into LDS, g* into this vehicle's HBM slices.
+// Per-vehicle search state.  l* point into LDS, g* into this vehicle's HBM slices.
 struct Search {
-    // tree nodes
-    double *lx, *ly, *lyaw, *lg, *lh, *lcs, *lsn;
-    uint32_t* lparent;
-    uint16_t* ltk;
-    NodeArena g;
+    NodeRec* ln;
+    NodeRec* gn;
     uint32_t NL, max_nodes;
-    // open list
     double* lkey;
     uint32_t* lid;
+    double* gkey;
+    uint32_t* gid;
     uint32_t HL;
     uint32_t heap_len;
     int lane;
+    PROF_MEMBERS
 };
 
-#define NODE_RD(S, field, i) (((i) < (S).NL) ? (S).l##field[(i)] : (S).g.field[(i)])
+__device__ __forceinline__ NodeRec node_load(const Search& S, uint32_t i0) {
+    if (i0 < S.NL) return S.ln[i0];
+    return S.gn[i0];
+}
+__device__ __forceinline__ uint32_t node_parent(const Search& S, uint32_t i0) {
+    if (i0 < S.NL) return S.ln[i0].parent;
+    return S.gn[i0].parent;
+}
 
-__device__ __forceinline__ double heap_key_at(const Search& S, uint32_t i) { return i < S.HL ? S.lkey[i] : S.g.heap_key[i]; }
-__device__ __forceinline__ uint32_t heap_id_at(const Search& S, uint32_t i) { return i < S.HL ? S.lid[i] : S.g.heap_id[i]; }
-__device__ __forceinline__ void heap_set(Search& S, uint32_t i, double key, uint32_t id) {
-    if (S.lane == 0) {
-        if (i < S.HL) {
-            S.lkey[i] = key;
-            S.lid[i] = id;
+// per-lane heap access (index may differ per lane).  LDSONLY: the caller knows every index is < HL.
+template <bool LDSONLY>
+__device__ __forceinline__ void heap_load(const Search& S, uint32_t idx, bool valid, double& k, uint32_t& id) {
+    k = 0.0;
+    id = 0;
+    if (valid) {
+        if (LDSONLY || idx < S.HL) {
+            k = S.lkey[idx];
+            id = S.lid[idx];
         } else {
-            S.g.heap_key[i] = key;
-            S.g.heap_id[i] = id;
+            k = S.gkey[idx];
+            id = S.gid[idx];
         }
     }
 }
-// make lane 0's heap writes visible to the whole wave (LDS: in-order DS queue; HBM spill: same-CU L1)
-__device__ __forceinline__ void heap_fence(const Search& S) {
-    if (S.heap_len > S.HL) __threadfence_block();
+template <bool LDSONLY>
+__device__ __forceinline__ void heap_store(const Search& S, uint32_t idx, double k, uint32_t id) {
+    if (LDSONLY || idx < S.HL) {
+        S.lkey[idx] = k;
+        S.lid[idx] = id;
+    } else {
+        S.gkey[idx] = k;
+        S.gid[idx] = id;
+    }
+}
+// order one phase's heap writes before the next phase's reads (LDS: in-order DS queue per wave; HBM spill:
+// same-CU L1, needs the stores drained)
+template <bool LDSONLY>
+__device__ __forceinline__ void heap_fence() {
+    if (!LDSONLY) __threadfence_block();
     __builtin_amdgcn_wave_barrier();
 }
 
-// std::push_heap: libstdc++ __push_heap(first, hole, top = 0, value) with comp(a, b) = a.key > b.key
-// (priority_queue_interface_mex.cpp:23-29).  All indices are wave-uniform.
-__device__ void heap_sift_up(Search& S, uint32_t hole, double key, uint32_t id) {
-    while (hole > 0) {
-        const uint32_t parent = (hole - 1) >> 1;
-        const double pk = uni_d(heap_key_at(S, parent));
-        if (!(pk > key)) break;  // strict: equal keys do not move up
-        const uint32_t pid = uni_u(heap_id_at(S, parent));
-        heap_set(S, hole, pk, pid);
-        hole = parent;
-    }
-    heap_set(S, hole, key, id);
+// neighbour lane's value (lane ^ 1) through DPP quad_perm [1,0,3,2]: no LDS round trip
+__device__ __forceinline__ double swap_pair_d(double v) {
+    const uint64_t u = (uint64_t)__double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, 0xB1, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), 0xB1, 0xf, 0xf, true);
+    return __longlong_as_double((long long)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo));
 }
 
-__device__ void heap_push(Search& S, uint32_t id, double key) {
+// libstdc++ __push_heap(first, hole, top = 0, value) with comp(a, b) = a.key > b.key
+// (priority_queue_interface_mex.cpp:23-29): the value climbs while the parent's key is
+// STRICTLY greater.  Lane t fetches ancestor t of the hole; a ballot finds the first ancestor that stays.
+template <bool LDSONLY>
+__device__ __forceinline__ void heap_sift_up(Search& S, uint32_t hole, double key, uint32_t id) {
+    const uint32_t h1 = hole + 1;
+    const int nlev = 31 - __builtin_clz(h1);  // number of ancestors, <= 17 for a 128k heap
+    const int lane = S.lane;
+    const bool valid = lane < nlev;
+    const uint32_t anc = valid ? ((h1 >> (lane + 1)) - 1u) : 0u;
+    double k;
+    uint32_t i;
+    heap_load<LDSONLY>(S, anc, valid, k, i);
+    const bool gt = valid && (k > key);
+    const unsigned long long b = __ballot(gt);
+    const int cnt = (~b == 0ull) ? 64 : (int)__builtin_ctzll(~b);  // ancestors that move down one level
+    if (lane < cnt) heap_store<LDSONLY>(S, (h1 >> lane) - 1u, k, i);
+    if (lane == 0) heap_store<LDSONLY>(S, (h1 >> cnt) - 1u, key, id);
+}
+
+__device__ __forceinline__ void heap_push(Search& S, uint32_t id, double key) {
     const uint32_t hole = S.heap_len;
     S.heap_len = hole + 1;
-    heap_sift_up(S, hole, key, id);
-    heap_fence(S);
+    if (hole < S.HL) {
+        heap_sift_up<true>(S, hole, key, id);
+        heap_fence<true>();
+    } else {
+        heap_sift_up<false>(S, hole, key, id);
+        heap_fence<false>();
+    }
 }
 
-// std::pop_heap + pop_back: libstdc++ __pop_heap -> __adjust_heap(first, 0, len, value) -> __push_heap
-__device__ void heap_pop(Search& S) {
+// std::pop_heap + pop_back: libstdc++ __pop_heap -> __adjust_heap(first, 0, len, value) -> __push_heap.
+// The hole always sinks to a leaf, choosing the right child unless key[right] > key[left].  Each round fetches the
+// five levels below the hole (2 + 4 + 8 + 16 + 32 = 62 entries, lane l holds sub-tree node l + 2 in heap order, so
+// siblings are lanes l ^ 1 and the children of lane l are lanes 2l + 2, 2l + 3).  Every lane decides whether it is
+// the child its parent would step to; a ballot + five scalar steps follow the chain from the hole; the lanes on
+// the chain store their entry one level up in one instruction.
+template <bool LDSONLY>
+__device__ __forceinline__ void heap_pop_impl(Search& S, uint32_t len) {
+    const int lane = S.lane;
+    double vkey;
+    uint32_t vid;
+    heap_load<LDSONLY>(S, len, true, vkey, vid);
+    vkey = uni_d(vkey);
+    vid = uni_u(vid);
+    const uint32_t half = (len - 1) >> 1;
+    uint32_t hole = 0;
+    const int d = 31 - __builtin_clz((uint32_t)lane + 2u);  // level below the hole: 1..5 (6 for lanes 62, 63)
+    const uint32_t q = (uint32_t)lane + 2u - (1u << d);
+    while (hole < half) {
+        const uint32_t idx = ((hole + 1u) << d) - 1u + q;
+        const uint32_t pidx = (idx - 1u) >> 1;
+        const bool step_ok = (lane < 62) && (pidx < half);  // the parent has two children (adjust_heap loop condition)
+        double k;
+        uint32_t i;
+        heap_load<LDSONLY>(S, idx, step_ok, k, i);
+        const double ks = swap_pair_d(k);
+        // odd lane = right child: taken unless key[right] > key[left]; even lane = left child: taken iff key[right] > key[left]
+        const bool pref = (lane & 1) ? !(k > ks) : (ks > k);
+        const unsigned long long P = __ballot(pref && step_ok);
+        int a = -1;
+        unsigned long long pathmask = 0;
+#pragma unroll
+        for (int dd = 0; dd < 5; ++dd) {
+            const int c = 2 * a + 2;
+            const unsigned long long two = (P >> c) & 3ull;
+            if (two == 0) break;
+            a = c + ((two & 1ull) ? 0 : 1);
+            pathmask |= 1ull << a;
+        }
+        if ((pathmask >> lane) & 1ull) heap_store<LDSONLY>(S, pidx, k, i);
+        hole = lane_u(idx, a);
+    }
+    if ((len & 1u) == 0 && hole == ((len - 2u) >> 1)) {  // lone left child at the bottom
+        const uint32_t child = 2u * (hole + 1u);
+        double ck;
+        uint32_t cid;
+        heap_load<LDSONLY>(S, child - 1u, true, ck, cid);
+        if (lane == 0) heap_store<LDSONLY>(S, hole, ck, cid);
+        hole = child - 1u;
+    }
+    heap_fence<LDSONLY>();
+    heap_sift_up<LDSONLY>(S, hole, vkey, vid);
+    heap_fence<LDSONLY>();
+}
+
+__device__ __forceinline__ void heap_pop(Search& S) {
     const uint32_t len = S.heap_len - 1;  // length after the pop
     S.heap_len = len;
     if (len == 0) return;
-    const double vkey = uni_d(heap_key_at(S, len));
-    const uint32_t vid = uni_u(heap_id_at(S, len));
-    uint32_t hole = 0, child = 0;
-    const uint32_t half = (len - 1) >> 1;
-    while (child < half) {
-        child = 2 * (child + 1);  // right child
-        double ck = uni_d(heap_key_at(S, child));
-        const double lk = uni_d(heap_key_at(S, child - 1));
-        if (ck > lk) {  // comp(right, left): right is worse -> take left
-            child--;
-            ck = lk;
-        }
-        const uint32_t cid = uni_u(heap_id_at(S, child));
-        heap_set(S, hole, ck, cid);
-        hole = child;
-    }
-    if ((len & 1u) == 0 && child == ((len - 2) >> 1)) {  // lone left child at the bottom
-        child = 2 * (child + 1);
-        const double ck = uni_d(heap_key_at(S, child - 1));
-        const uint32_t cid = uni_u(heap_id_at(S, child - 1));
-        heap_set(S, hole, ck, cid);
-        hole = child - 1;
-    }
-    heap_fence(S);
-    heap_sift_up(S, hole, vkey, vid);
-    heap_fence(S);
+    if (len < S.HL)
+        heap_pop_impl<true>(S, len);
+    else
+        heap_pop_impl<false>(S, len);
 }
 
 // ---------------------------------------------------------------------------------------------------
-// InterX.m:63-76,108-110 for one curve pair: L1 = shape (V points, LDS), L2 = soup (M points, LDS).
-// One lane per L2 segment; strict "< 0" products; NaN separators make every comparison false.
-__device__ bool interx_wave(const d2* sh, int V, const d2* L2, int M, int lane) {
-    if (M < 2 || V < 2) return false;
+// are_constraints_satisfied_interx.m:17-37 + InterX.m:63-76,108-110.
+// The three soups (vehicle obstacles of step k -> shape A, HDV sets of step k -> shape A, lanelet boundary ->
+// boundary-check shape B) are processed together.  hit(i, j) = C1(i, j) & C2(i, j) with
+//   C1 = (dx1_i*y2_j - dy1_i*x2_j - S1_i) * (dx1_i*y2_{j+1} - dy1_i*x2_{j+1} - S1_i) < 0
+//   C2 = (y1_i*dx2_j - x1_i*dy2_j - S2_j) * (y1_{i+1}*dx2_j - x1_{i+1}*dy2_j - S2_j) < 0     (strict; NaN -> false)
+// Pass 1 (one lane per obstacle segment j) evaluates C2 for every shape segment i and keeps a 7-bit mask; lanes with
+// a non-zero mask append (j, mask, shape) to a compact list.  Pass 2 evaluates C1 for the listed pairs only.
+// Pass 1 over one soup range: sh2 holds shape A in [0, VMAX) and shape B in [VMAX, 2*VMAX).
+__device__ __forceinline__ int interx_pass1(const d2* sh2, int shapeB, int V, const d2* soup, int start, int M, uint32_t* cand, int count, int lane) {
+    if (M < 2) return count;
+    const d2* L2 = soup + start;
+    const d2* sh = sh2 + shapeB * PDMPC_VMAX;
     for (int base = 0; base < M - 1; base += PDMPC_WAVE) {
         const int j = base + lane;
-        bool hit = false;
+        uint32_t bits = 0;
         if (j < M - 1) {
             const d2 q0 = L2[j], q1 = L2[j + 1];
             const double dx2 = q1.x - q0.x, dy2 = q1.y - q0.y;
             const double S2 = dx2 * q0.y - dy2 * q0.x;
-            d2 p0 = sh[0];
+            d2 p = sh[0];
+            double e0 = (p.y * dx2 - p.x * dy2) - S2;
             for (int i = 0; i < V - 1; ++i) {
-                const d2 p1 = sh[i + 1];
-                const double dx1 = p1.x - p0.x, dy1 = p1.y - p0.y;
-                const double S1 = dx1 * p0.y - dy1 * p0.x;
-                const double a0 = dx1 * q0.y - dy1 * q0.x;
-                const double a1 = dx1 * q1.y - dy1 * q1.x;
-                const bool c1 = (a0 - S1) * (a1 - S1) < 0;
-                const double b0 = p0.y * dx2 - p0.x * dy2;
-                const double b1 = p1.y * dx2 - p1.x * dy2;
-                const bool c2 = (b0 - S2) * (b1 - S2) < 0;
-                hit = hit || (c1 && c2);
-                p0 = p1;
+                p = sh[i + 1];
+                const double e1 = (p.y * dx2 - p.x * dy2) - S2;
+                if (e0 * e1 < 0) bits |= 1u << i;
+                e0 = e1;
+            }
+        }
+        const unsigned long long b = __ballot(bits != 0);
+        if (b) {
+            if (bits) {
+                const int pos = count + (int)__builtin_popcountll(b & ((1ull << lane) - 1ull));
+                cand[pos] = (uint32_t)(start + j) | (bits << 16) | ((uint32_t)shapeB << 24);
+            }
+            count += (int)__builtin_popcountll(b);
+        }
+    }
+    return count;
+}
+
+__device__ bool interx_check(const d2* sh2, int V, const d2* soup, int so, int M_k, int ho, int Hk, int lo, int Ml, uint32_t* cand, int lane) {
+    if (V < 2) return false;
+    int count = 0;
+    count = interx_pass1(sh2, 0, V, soup, so, M_k, cand, count, lane);
+    if (Hk > 0) count = interx_pass1(sh2, 0, V, soup, ho, Hk, cand, count, lane);
+    count = interx_pass1(sh2, 1, V, soup, lo, Ml, cand, count, lane);
+    if (count == 0) return false;
+    __builtin_amdgcn_wave_barrier();
+    for (int base = 0; base < count; base += PDMPC_WAVE) {
+        const int t = base + lane;
+        bool hit = false;
+        if (t < count) {
+            const uint32_t e = cand[t];
+            const int j = (int)(e & 0xffffu);
+            const uint32_t bits = (e >> 16) & 0xffu;
+            const d2* sh = sh2 + (e >> 24) * PDMPC_VMAX;
+            const d2 q0 = soup[j], q1 = soup[j + 1];
+            for (int i = 0; i < V - 1; ++i) {
+                if ((bits >> i) & 1u) {
+                    const d2 p0 = sh[i], p1 = sh[i + 1];
+                    const double dx1 = p1.x - p0.x, dy1 = p1.y - p0.y;
+                    const double S1 = dx1 * p0.y - dy1 * p0.x;
+                    const double a0 = dx1 * q0.y - dy1 * q0.x;
+                    const double a1 = dx1 * q1.y - dy1 * q1.x;
+                    hit = hit || ((a0 - S1) * (a1 - S1) < 0);
+                }
             }
         }
         if (wave_any(hit)) return true;
@@ -227,8 +368,7 @@ __device__ bool sat_pair_wave(const d2* sh, int V1, const d2* o, int V2, int lan
 __device__ bool sat_soup_wave(const d2* sh, int V1, const d2* soup, int M, int lane) {
     int pos = 0;
     while (pos < M) {
-        // next NaN separator at or after pos
-        int end = M;
+        int end = M;  // next NaN separator at or after pos
         for (int base = pos; base < M; base += PDMPC_WAVE) {
             const int j = base + lane;
             const bool sepr = (j < M) && is_nan(soup[j].x);
@@ -332,7 +472,6 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_search_kernel(con
     uint64_t* l_mask = (uint64_t*)(smem + A.lds.mask);
     int16_t* l_mi = (int16_t*)(smem + A.lds.man_index);
     DevManPose* l_pose = (DevManPose*)(smem + A.lds.pose);
-    const d2* area_tab = A.areas_in_lds ? (const d2*)(smem + A.lds.area) : (const d2*)A.man_area;
     double* l_rx = (double*)(smem + A.lds.ref);
     double* l_ry = l_rx + PDMPC_HP_MAX;
     double* l_dtv = l_ry + PDMPC_HP_MAX;
@@ -342,17 +481,12 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_search_kernel(con
     int32_t* l_soff = (int32_t*)(l_path + PDMPC_HP_MAX + 2);  // soup offsets [Hp+1], hdv offsets [Hp+1]
     int32_t* l_hoff = l_soff + PDMPC_HP_MAX + 1;
     d2* l_soup = (d2*)(smem + A.lds.soup);
+    uint32_t* l_cand = (uint32_t*)(smem + A.lds.cand);
+    const d2* l_area = (const d2*)(smem + A.lds.area);
+    const d2* g_area = (const d2*)A.man_area;
 
     Search S;
-    S.lx = (double*)(smem + A.lds.nx);
-    S.ly = (double*)(smem + A.lds.ny);
-    S.lyaw = (double*)(smem + A.lds.nyaw);
-    S.lg = (double*)(smem + A.lds.ng);
-    S.lh = (double*)(smem + A.lds.nh);
-    S.lcs = (double*)(smem + A.lds.ncs);
-    S.lsn = (double*)(smem + A.lds.nsn);
-    S.lparent = (uint32_t*)(smem + A.lds.nparent);
-    S.ltk = (uint16_t*)(smem + A.lds.ntk);
+    S.ln = (NodeRec*)(smem + A.lds.nodes);
     S.lkey = (double*)(smem + A.lds.heap_key);
     S.lid = (uint32_t*)(smem + A.lds.heap_id);
     S.NL = (uint32_t)A.NL;
@@ -360,21 +494,13 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_search_kernel(con
     S.max_nodes = A.max_nodes;
     S.lane = lane;
     const size_t voff = (size_t)slot * A.max_nodes;
-    S.g.x = A.arena.x + voff;
-    S.g.y = A.arena.y + voff;
-    S.g.yaw = A.arena.yaw + voff;
-    S.g.g = A.arena.g + voff;
-    S.g.h = A.arena.h + voff;
-    S.g.cs = A.arena.cs + voff;
-    S.g.sn = A.arena.sn + voff;
-    S.g.parent = A.arena.parent + voff;
-    S.g.tk = A.arena.tk + voff;
-    S.g.heap_key = A.arena.heap_key + voff;
-    S.g.heap_id = A.arena.heap_id + voff;
+    S.gn = A.arena.nodes + voff;
+    S.gkey = A.arena.heap_key + voff;
+    S.gid = A.arena.heap_id + voff;
 
     pdmpc_vehicle_out* __restrict__ O = A.out + slot;
 
-    // ---- prologue 1: stage MPA tables (coalesced 16-byte copies; sizes are padded to 16 B by the host)
+    // ---- prologue 1: stage MPA tables (coalesced 16-byte copies; the host pads every table to 16 B)
     {
         const int mask_bytes = Hp * n * nw * 8;
         stage16(l_mask, A.succ_mask, (mask_bytes + 15) / 16, lane);
@@ -423,8 +549,8 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_search_kernel(con
         if (lane == 0) l_path[PDMPC_HP_MAX + 1] = (uint32_t)off;
     }
     __syncthreads();
-    const int ll_base = (int)l_path[PDMPC_HP_MAX + 1];
-    const int ll_len = V->ll_len;
+    const int ll_base = uni_i((int)l_path[PDMPC_HP_MAX + 1]);
+    const int ll_len = uni_i(V->ll_len);
 
     // ---- prologue 4: wait for sequential predecessors and append their solved areas (PrioritizedController.m:476-491)
     bool dep_timeout = false;
@@ -469,21 +595,18 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_search_kernel(con
     uint32_t nnodes = 1;
     {
         if (lane == 0) {
-            const uint16_t tk = (uint16_t)V->trim0;
-            S.g.x[0] = V->x0;
-            S.g.y[0] = V->y0;
-            S.g.yaw[0] = V->yaw0;
-            S.g.g[0] = 0.0;
-            S.g.h[0] = 0.0;
-            S.g.parent[0] = 0;
-            S.g.tk[0] = tk;
-            S.lx[0] = V->x0;
-            S.ly[0] = V->y0;
-            S.lyaw[0] = V->yaw0;
-            S.lg[0] = 0.0;
-            S.lh[0] = 0.0;
-            S.lparent[0] = 0;
-            S.ltk[0] = tk;
+            NodeRec r;
+            r.x = V->x0;
+            r.y = V->y0;
+            r.yaw = V->yaw0;
+            r.g = 0.0;
+            r.cs = 0.0;
+            r.sn = 0.0;
+            r.h = 0.0;
+            r.parent = 0;
+            r.packed = (uint32_t)V->trim0;
+            S.gn[0] = r;
+            S.ln[0] = r;
             S.lkey[0] = 0.0;
             S.lid[0] = 1;
         }
@@ -494,6 +617,8 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_search_kernel(con
     int status = PDMPC_OK;
     int n_popped = 0;
     uint32_t goal = 0;
+    PROF_DECL
+    PROF_START
 
     // ---- main loop (GraphSearch.m:53-107)
     for (;;) {
@@ -501,31 +626,38 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_search_kernel(con
             status = PDMPC_EXHAUSTED;
             break;
         }
-        const uint32_t cur = uni_u(heap_id_at(S, 0));  // 1-based node id
+        PROF_STOP(7)
+        const uint32_t cur = uni_u(S.lid[0]);  // 1-based node id (HL >= 1: the top is always in LDS)
         heap_pop(S);
+        PROF_STOP(0)
         if (A.trace_cap > 0 && n_popped < A.trace_cap && lane == 0) A.pop_trace[(size_t)slot * A.trace_cap + n_popped] = (int32_t)cur;
         ++n_popped;
         const uint32_t c0 = cur - 1;
-        const uint32_t par = uni_u(NODE_RD(S, parent, c0));
-        const uint32_t ctk = uni_u((uint32_t)NODE_RD(S, tk, c0));
-        const int cTrim = (int)(ctk & 1023u);  // 1-based
-        const int cK = (int)(ctk >> 10);
+        const NodeRec cn = node_load(S, c0);  // same record in every lane
+        const uint32_t par = uni_u(cn.parent);
+        const uint32_t cpk = uni_u(cn.packed);
+        const int cTrim = NODE_TRIM(cpk);  // 1-based
+        const int cK = NODE_K(cpk);
 
         // ---- eval_edge_exact (GraphSearch.m:111-196)
         bool valid = true;
         if (par) {
-            const uint32_t p0 = par - 1;
-            const double pX = uni_d(NODE_RD(S, x, p0));
-            const double pY = uni_d(NODE_RD(S, y, p0));
-            const double c = uni_d(NODE_RD(S, cs, p0));  // cos/sin(pYaw), cached when the parent was expanded
-            const double s = uni_d(NODE_RD(S, sn, p0));
-            const int pTrim = (int)(uni_u((uint32_t)NODE_RD(S, tk, p0)) & 1023u);
-            const int m = uni_i((int)l_mi[(pTrim - 1) * n + (cTrim - 1)]);
-            const int ncols = uni_i(l_pose[m].n_cols);
+            const NodeRec pn = node_load(S, par - 1);
+            const double pX = pn.x, pY = pn.y;
+            const double c = pn.cs, s = pn.sn;  // cos/sin(pYaw), cached when the parent was expanded
+            const int m = NODE_MAN(cpk);
+            const int ncols = NODE_COLS(cpk);
             if (lane < ncols) {
-                const d2* ar = area_tab + (size_t)m * 3 * PDMPC_VMAX;
-                const d2 a = ar[lane];                                                       // maneuver.area
-                const d2 b = ar[((cK == Hp) ? 2 : 1) * PDMPC_VMAX + lane];                   // large offset at k == Hp, else without offset
+                const size_t ai = (size_t)m * 3 * PDMPC_VMAX + lane;
+                const size_t bi = ai + (size_t)((cK == Hp) ? 2 : 1) * PDMPC_VMAX;  // large offset at k == Hp, else without offset
+                d2 a, b;
+                if (A.areas_in_lds) {
+                    a = l_area[ai];
+                    b = l_area[bi];
+                } else {
+                    a = g_area[ai];
+                    b = g_area[bi];
+                }
                 d2 sa, sb;
                 sa.x = c * a.x - s * a.y + pX;  // GraphSearch.m:158
                 sa.y = s * a.x + c * a.y + pY;  // :159
@@ -535,24 +667,21 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_search_kernel(con
                 l_shB[lane] = sb;
             }
             __syncthreads();
-            const d2* soup_k = l_soup + l_soff[cK - 1];
-            const int M_k = uni_i(l_soff[cK] - l_soff[cK - 1]);
+            PROF_STOP(1)
+            const int so = uni_i(l_soff[cK - 1]);
+            const int M_k = uni_i(l_soff[cK]) - so;
             if (A.checker == PDMPC_CHECK_INTERX) {
-                // are_constraints_satisfied_interx.m:17-37
-                bool hit = interx_wave(l_shA, ncols, soup_k, M_k, lane);
-                if (!hit) {
-                    const int Hk = uni_i(l_hoff[cK] - l_hoff[cK - 1]);
-                    if (Hk > 0) hit = interx_wave(l_shA, ncols, l_soup + l_hoff[cK - 1], Hk, lane);
-                }
-                if (!hit) hit = interx_wave(l_shB, ncols, l_soup + ll_base, ll_len, lane);
-                valid = !hit;
+                const int ho = uni_i(l_hoff[cK - 1]);
+                const int Hk = uni_i(l_hoff[cK]) - ho;
+                valid = !interx_check(l_shA, ncols, l_soup, so, M_k, ho, Hk, ll_base, ll_len, l_cand, lane);
             } else {
                 // are_constraints_satisfied_sat.m:15-53
-                bool hit = sat_soup_wave(l_shA, ncols, soup_k, M_k, lane);
+                bool hit = sat_soup_wave(l_shA, ncols, l_soup + so, M_k, lane);
                 if (!hit) hit = sat_boundary_wave(l_shB, ncols, l_soup + ll_base, ll_len, lane);
                 valid = !hit;
             }
             __syncthreads();
+            PROF_STOP(2)
         }
         if (!valid) continue;  // GraphSearch.m:75-77
 
@@ -562,23 +691,21 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_search_kernel(con
         }
 
         // ---- expand_node.m:1-91
-        const double curX = uni_d(NODE_RD(S, x, c0));
-        const double curY = uni_d(NODE_RD(S, y, c0));
-        const double curYaw = uni_d(NODE_RD(S, yaw, c0));
-        const double curG = uni_d(NODE_RD(S, g, c0));
+        const double curX = cn.x, curY = cn.y, curYaw = cn.yaw, curG = cn.g;
         double sn, cs;
+        PROF_STOP(3)
         pdmpc_sincos(curYaw, &sn, &cs);  // expand_node.m:50-51
+        PROF_STOP(4)
         if (lane == 0) {
             if (c0 < S.NL) {
-                S.lcs[c0] = cs;
-                S.lsn[c0] = sn;
-            } else {
-                S.g.cs[c0] = cs;
-                S.g.sn[c0] = sn;
+                S.ln[c0].cs = cs;
+                S.ln[c0].sn = sn;
             }
+            S.gn[c0].cs = cs;
+            S.gn[c0].sn = sn;
         }
-        const int k_exp = cK + 1;                // :13
-        const int steps_to_go = Hp - k_exp;      // :37
+        const int k_exp = cK + 1;            // :13
+        const int steps_to_go = Hp - k_exp;  // :37
         const uint64_t* mrow = l_mask + ((size_t)(k_exp - 1) * n + (cTrim - 1)) * nw;
         uint32_t total = 0;
         for (int w = 0; w < nw; ++w) total += (uint32_t)__builtin_popcountll(mrow[w]);
@@ -601,46 +728,39 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_search_kernel(con
                 const int t2 = w * 64 + lane;  // 0-based successor trim
                 const int m = (int)l_mi[(cTrim - 1) * n + t2];
                 const DevManPose mp = l_pose[m];
-                const double expX = cs * mp.dx - sn * mp.dy + curX;  // :53
-                const double expY = sn * mp.dx + cs * mp.dy + curY;  // :54
-                const double expYaw = curYaw + mp.dyaw;              // :55
+                NodeRec ch;
+                ch.x = cs * mp.dx - sn * mp.dy + curX;  // :53
+                ch.y = sn * mp.dx + cs * mp.dy + curY;  // :54
+                ch.yaw = curYaw + mp.dyaw;              // :55
                 double expG = curG;
                 {
-                    const double ddx = expX - l_rx[k_exp - 1], ddy = expY - l_ry[k_exp - 1];
+                    const double ddx = ch.x - l_rx[k_exp - 1], ddy = ch.y - l_ry[k_exp - 1];
                     const double nrm = sqrt(ddx * ddx + ddy * ddy);
                     expG = expG + nrm * nrm;  // :61
                 }
                 double expH = 0.0, dmax = 0.0;
                 for (int it = 1; it <= steps_to_go; ++it) {  // :68-73
                     dmax = dmax + l_dtv[k_exp + it - 1];
-                    const double ddx = expX - l_rx[k_exp + it - 1], ddy = expY - l_ry[k_exp + it - 1];
+                    const double ddx = ch.x - l_rx[k_exp + it - 1], ddy = ch.y - l_ry[k_exp + it - 1];
                     const double nrm = sqrt(ddx * ddx + ddy * ddy);
                     const double df = nrm - dmax;
                     const double m0 = (df > 0) ? df : 0.0;
                     expH = expH + m0 * m0;
                 }
                 f = expG * 1 + expH * 1;  // GraphSearch.m:100-102
+                ch.g = expG;
+                ch.h = expH;
+                ch.cs = 0.0;
+                ch.sn = 0.0;
+                ch.parent = cur;
+                ch.packed = (uint32_t)(t2 + 1) | ((uint32_t)k_exp << 10) | ((uint32_t)m << 15) | ((uint32_t)mp.n_cols << 27);
                 const uint32_t i0 = nnodes + (uint32_t)rank;  // 0-based index of the child (Tree.add_nodes, Tree.m:61)
-                const uint16_t tk = (uint16_t)((t2 + 1) | (k_exp << 10));
-                S.g.x[i0] = expX;
-                S.g.y[i0] = expY;
-                S.g.yaw[i0] = expYaw;
-                S.g.g[i0] = expG;
-                S.g.h[i0] = expH;
-                S.g.parent[i0] = cur;
-                S.g.tk[i0] = tk;
-                if (i0 < S.NL) {
-                    S.lx[i0] = expX;
-                    S.ly[i0] = expY;
-                    S.lyaw[i0] = expYaw;
-                    S.lg[i0] = expG;
-                    S.lh[i0] = expH;
-                    S.lparent[i0] = cur;
-                    S.ltk[i0] = tk;
-                }
+                S.gn[i0] = ch;
+                if (i0 < S.NL) S.ln[i0] = ch;
             }
             if (nnodes + (uint32_t)cnt > S.NL) __threadfence_block();
             __syncthreads();
+            PROF_STOP(5)
             // pq.push(new_open_nodes, new_open_values): one at a time in ascending trim order (mex.cpp:67-72)
             uint64_t mm = mask;
             uint32_t r = 0;
@@ -652,8 +772,13 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_search_kernel(con
                 ++r;
             }
             nnodes += (uint32_t)cnt;
+            PROF_STOP(6)
         }
     }
+#ifdef PDMPC_PROFILE
+    if (lane == 0)
+        for (int i = 0; i < PROF_N; ++i) ((double*)O->shapes[PDMPC_HP_MAX - 1])[i] = (double)S.prof_acc[i];  // unused tail of the record
+#endif
 
     // ---- results (GraphSearch.m:58-59, 82-89; return_path_to.m; return_path_area.m)
     __syncthreads();
@@ -663,48 +788,43 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_search_kernel(con
             uint32_t nd = goal;
             for (int i = Hp; i >= 0; --i) {
                 l_path[i] = nd;
-                nd = NODE_RD(S, parent, nd - 1);
+                nd = node_parent(S, nd - 1);
             }
         }
         __syncthreads();
         if (lane <= Hp) {
             const uint32_t nd = l_path[lane];
-            const uint32_t i0 = nd - 1;
-            const uint32_t tk = (uint32_t)NODE_RD(S, tk, i0);
-            const double x = NODE_RD(S, x, i0), y = NODE_RD(S, y, i0), yaw = NODE_RD(S, yaw, i0);
+            const NodeRec r = node_load(S, nd - 1);
             O->tree_path[lane] = (int32_t)nd;
             double* row = O->path_nodes[lane];  // NodeInfo.m:5-13
-            row[0] = x;
-            row[1] = y;
-            row[2] = yaw;
-            row[3] = (double)(tk & 1023u);
-            row[4] = NODE_RD(S, g, i0);
-            row[5] = NODE_RD(S, h, i0);
-            row[6] = (double)(tk >> 10);
+            row[0] = r.x;
+            row[1] = r.y;
+            row[2] = r.yaw;
+            row[3] = (double)NODE_TRIM(r.packed);
+            row[4] = r.g;
+            row[5] = r.h;
+            row[6] = (double)NODE_K(r.packed);
             row[7] = 1.0;
             if (lane >= 1) {
-                O->y_predicted[lane - 1][0] = x;
-                O->y_predicted[lane - 1][1] = y;
-                O->y_predicted[lane - 1][2] = yaw;
-                O->predicted_trims[lane - 1] = (int32_t)(tk & 1023u);
+                O->y_predicted[lane - 1][0] = r.x;
+                O->y_predicted[lane - 1][1] = r.y;
+                O->y_predicted[lane - 1][2] = r.yaw;
+                O->predicted_trims[lane - 1] = (int32_t)NODE_TRIM(r.packed);
             }
         }
         // shapes along the path: same arithmetic as at pop time (GraphSearch.m:158-160), so the same bits
         for (int idx = lane; idx < Hp * PDMPC_VMAX; idx += PDMPC_WAVE) {
             const int i = idx / PDMPC_VMAX + 1;
             const int v = idx - (i - 1) * PDMPC_VMAX;
-            const uint32_t pn = l_path[i - 1] - 1, cn = l_path[i] - 1;
-            const int pTrim = (int)((uint32_t)NODE_RD(S, tk, pn) & 1023u);
-            const int cTrim = (int)((uint32_t)NODE_RD(S, tk, cn) & 1023u);
-            const int m = (int)l_mi[(pTrim - 1) * n + (cTrim - 1)];
-            const int ncols = l_pose[m].n_cols;
+            const NodeRec pr = node_load(S, l_path[i - 1] - 1);
+            const NodeRec cr = node_load(S, l_path[i] - 1);
+            const int m = NODE_MAN(cr.packed);
+            const int ncols = NODE_COLS(cr.packed);
             if (v == 0) O->shape_cols[i - 1] = ncols;
             if (v < ncols) {
-                const double c = NODE_RD(S, cs, pn), s = NODE_RD(S, sn, pn);
-                const double pX = NODE_RD(S, x, pn), pY = NODE_RD(S, y, pn);
-                const d2 a = area_tab[(size_t)m * 3 * PDMPC_VMAX + v];
-                O->shapes[i - 1][0][v] = c * a.x - s * a.y + pX;
-                O->shapes[i - 1][1][v] = s * a.x + c * a.y + pY;
+                const d2 a = g_area[(size_t)m * 3 * PDMPC_VMAX + v];
+                O->shapes[i - 1][0][v] = pr.cs * a.x - pr.sn * a.y + pr.x;
+                O->shapes[i - 1][1][v] = pr.sn * a.x + pr.cs * a.y + pr.y;
             }
         }
     } else if (V->fb_off[0] >= 0) {
