@@ -191,6 +191,9 @@ int pdmpc_result_device_buffer(pdmpc_handle* handle, void** dev_ptr, size_t* nby
 /* make result records produced elsewhere (e.g. gathered from another GPU into dev_ptr) visible as
  * predecessor outputs: copies n records into slots [first, first+n) of the handle's result buffer */
 int pdmpc_import_results(pdmpc_handle* handle, int32_t first, int32_t n, const void* dev_records);
+/* the other direction: copies the records of slots [first, first+n) into the caller's DEVICE buffer (the send
+ * buffer of the all-gather) and waits for the copy, so the buffer can be handed to another stream */
+int pdmpc_export_results(pdmpc_handle* handle, int32_t first, int32_t n, void* dev_records);
 
 int pdmpc_get_last_stats(pdmpc_handle* handle, pdmpc_stats* stats);
 

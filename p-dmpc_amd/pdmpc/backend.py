@@ -32,6 +32,7 @@ EXPORTS = [
     "pdmpc_pack_step",
     "pdmpc_result_device_buffer",
     "pdmpc_import_results",
+    "pdmpc_export_results",
     "pdmpc_get_last_stats",
     "pdmpc_debug_pop_trace",
     "pdmpc_debug_tree",
@@ -72,6 +73,7 @@ def load_library(path=None):
     L.pdmpc_pack_step.argtypes = [H, C.c_int32, C.POINTER(abi.VehicleIn), abi.c_int32_p, abi.c_int32_p, C.POINTER(abi.PolygonSet)]
     L.pdmpc_result_device_buffer.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.pdmpc_import_results.argtypes = [H, C.c_int32, C.c_int32, C.c_void_p]
+    L.pdmpc_export_results.argtypes = [H, C.c_int32, C.c_int32, C.c_void_p]
     L.pdmpc_get_last_stats.argtypes = [H, C.POINTER(abi.Stats)]
     L.pdmpc_debug_pop_trace.argtypes = [H, C.c_int32, C.c_int32, abi.c_int32_p, abi.c_int32_p]
     L.pdmpc_debug_tree.argtypes = [H, C.c_int32, C.c_int32] + [abi.c_double_p] * 5 + [abi.c_int32_p] * 4
@@ -195,6 +197,9 @@ class Handle:
 
     def import_results(self, first, n, dev_ptr):
         _check(self.L, self.L.pdmpc_import_results(self.h, first, n, C.c_void_p(dev_ptr)), "pdmpc_import_results")
+
+    def export_results(self, first, n, dev_ptr):
+        _check(self.L, self.L.pdmpc_export_results(self.h, first, n, C.c_void_p(dev_ptr)), "pdmpc_export_results")
 
     def stats(self):
         s = abi.Stats()

@@ -1,0 +1,85 @@
+"""Level-sharded planning over several GPUs (BASELINE configs 2 and 3).
+
+The vehicles of one computation level have no sequential coupling (PrioritizedSequentialController.m:83-91), so a
+level is block-partitioned over the ranks.  After each level every rank needs the solved areas of all vehicles of
+that level: in the reference each vehicle publishes its `Predictions` message on a ROS 2 topic every other vehicle
+subscribes to (PrioritizedController.m:356-365, PredictionsCommunication.m:34-63) — semantically an all-gather.  Here
+it IS one all-gather per level of the fixed-stride result records (pdmpc_vehicle_out, 2.9 KB per vehicle), RCCL over
+xGMI on GPUs (`backend="nccl"`), gloo in the CPU tests.  The gathered records are imported into every rank's result
+buffer, where the next level's kernels read them as predecessor areas.
+
+One process per GPU; `planner` hides where a range of slots is planned (the HIP handle in production; tests inject a
+CPU stand-in so the partition/exchange logic runs under gloo without a GPU).
+"""
+import math
+
+import numpy as np
+
+from . import abi
+
+REC_BYTES = abi.VEHICLE_OUT_DTYPE.itemsize
+
+
+def level_partition(first, size, world):
+    """[(lo, hi)] per rank: contiguous blocks of ceil(size / world) slots; trailing ranks may be empty."""
+    per = int(math.ceil(size / world)) if size > 0 else 0
+    out = []
+    for r in range(world):
+        lo = min(first + r * per, first + size)
+        hi = min(lo + per, first + size)
+        out.append((lo, hi))
+    return per, out
+
+
+class HipRangePlanner:
+    """Plans slot ranges on this rank's GPU through the C ABI; records stay in HBM."""
+
+    def __init__(self, optimizer, mpa, device):
+        import torch
+
+        self.torch = torch
+        self.opt = optimizer
+        self.opt._ensure_mpa(mpa)
+        self.h = optimizer.handle
+        self.device = device
+
+    def begin(self, problem):
+        fb = [f if f is not None else [] for f in problem["fallback"]]
+        self.h.pack_step(problem["iters"], problem["preds"], fb)
+        self.h.begin_step()
+
+    def new_buffer(self, n_records):
+        return self.torch.zeros(max(n_records, 1) * REC_BYTES, dtype=self.torch.uint8, device=self.device)
+
+    def plan_range(self, first, count, send):
+        """Launch slots [first, first+count) and copy their records into the device tensor `send`."""
+        if count > 0:
+            self.h.launch_range(first, count)
+        self.h.export_results(first, count, send.data_ptr())
+
+    def import_records(self, first, count, buf):
+        if count > 0:
+            self.h.import_results(first, count, buf.data_ptr())
+
+    def fetch(self, n):
+        return self.h.fetch(n)
+
+
+def plan_step_sharded(problem, planner, dist, rank, world):
+    """Plan one time step (slots in level order, see controller.build_step_problem) with levels sharded over `world`
+    ranks.  Returns the records of all slots (identical on every rank)."""
+    planner.begin(problem)
+    first = 0
+    for size in problem["level_sizes"]:
+        per, parts = level_partition(first, size, world)
+        lo, hi = parts[rank]
+        send = planner.new_buffer(per)
+        planner.plan_range(lo, hi - lo, send)
+        if world > 1:
+            recv = planner.new_buffer(per * world)
+            dist.all_gather_into_tensor(recv, send)
+            for r, (rlo, rhi) in enumerate(parts):
+                if r != rank and rhi > rlo:
+                    planner.import_records(rlo, rhi - rlo, recv[r * per * REC_BYTES : (r * per + (rhi - rlo)) * REC_BYTES])
+        first += size
+    return planner.fetch(len(problem["iters"]))

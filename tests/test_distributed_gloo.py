@@ -1,0 +1,151 @@
+"""world_size-2 gloo test of the level-sharded step planner (no GPU): partition, per-level all-gather, import.
+
+The per-range planner is a CPU stand-in built on the oracle; what is under test is pdmpc.distributed: every rank must
+end with the records of ALL slots, identical to the single-process result.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pdmpc import abi
+from pdmpc.distributed import REC_BYTES, level_partition, plan_step_sharded
+
+
+class OracleRangePlanner:
+    """Same interface as HipRangePlanner, planning with the CPU oracle into a host-side record array."""
+
+    def __init__(self, options, mpa):
+        self.options, self.mpa = options, mpa
+
+    def begin(self, problem):
+        self.problem = problem
+        self.recs = abi.out_array(len(problem["iters"]))
+        self.known = np.zeros(len(problem["iters"]), dtype=bool)
+
+    def new_buffer(self, n):
+        return torch.zeros(max(n, 1) * REC_BYTES, dtype=torch.uint8)
+
+    def plan_range(self, first, count, send):
+        import copy
+
+        from oracle import oracle
+
+        Hp = self.options.Hp
+        iters = []
+        for s in range(first, first + count):
+            it = copy.copy(self.problem["iters"][s])
+            dyn = list(it.dynamic_obstacle_area)
+            for p in self.problem["preds"][s]:
+                assert self.known[p], "slot %d planned before its predecessor %d arrived" % (s, p)
+                if int(self.recs[p]["status"]) == 0:
+                    dyn.append([np.array(self.recs[p]["shapes"][k][:, : int(self.recs[p]["shape_cols"][k])]) for k in range(Hp)])
+            it.dynamic_obstacle_area = dyn
+            iters.append(it)
+        if count:
+            _, out, _ = oracle.plan_batch(self.options, self.mpa, iters)
+            self.recs[first : first + count] = out
+            self.known[first : first + count] = True
+            raw = np.frombuffer(out.tobytes(), dtype=np.uint8)
+            send[: raw.size] = torch.from_numpy(raw.copy())
+
+    def import_records(self, first, count, buf):
+        raw = buf.numpy().tobytes()
+        self.recs[first : first + count] = np.frombuffer(raw, dtype=abi.VEHICLE_OUT_DTYPE)
+        self.known[first : first + count] = True
+
+    def fetch(self, n):
+        assert self.known[:n].all()
+        return self.recs[:n].copy()
+
+
+def make_problem():
+    from pdmpc.config import Config, ScenarioType
+    from pdmpc.controller import PrioritizedSequentialController
+    from pdmpc.mpa import get_mpa
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    from oracle import oracle
+    from pdmpc.iteration_data import info_from_record
+
+    options = Config(scenario_type=ScenarioType.commonroad, amount=12, Hp=5, max_nodes=1 << 15)
+    mpa = get_mpa(options)
+    sc = commonroad_scenario(options, seed=4)
+    ctl = PrioritizedSequentialController(options, sc, mpa, None, coupling="distance", boundary_provider=boundary_provider(sc))
+    probs = []
+
+    def plan_step(prob):
+        probs.append(prob)
+        recs, _ = oracle.plan_step(options, mpa, prob)
+        return [info_from_record(recs[i], options.Hp) for i in range(len(recs))]
+
+    for _ in range(3):
+        ctl.step(plan_step=plan_step)
+    return options, mpa, probs[-1]
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    options, mpa, prob = make_problem()
+    recs = plan_step_sharded(prob, OracleRangePlanner(options, mpa), dist, rank, world)
+    q.put((rank, recs.tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_level_partition_covers_every_slot_once():
+    for size in range(0, 23):
+        for world in (1, 2, 3, 4, 8):
+            per, parts = level_partition(5, size, world)
+            covered = [s for lo, hi in parts for s in range(lo, hi)]
+            assert covered == list(range(5, 5 + size))
+            assert all(hi - lo <= per for lo, hi in parts)
+
+
+@pytest.mark.timeout(300)
+def test_sharded_step_world2_matches_single_process():
+    from oracle import oracle
+
+    options, mpa, prob = make_problem()
+    assert max(prob["level_sizes"]) >= 2 and len(prob["level_sizes"]) >= 2
+    want, _ = oracle.plan_step(options, mpa, prob)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        recs = np.frombuffer(got[r], dtype=abi.VEHICLE_OUT_DTYPE)
+        for name in ("status", "n_expanded", "n_popped", "tree_path", "predicted_trims"):
+            assert np.array_equal(recs[name], want[name]), (r, name)
+        assert np.array_equal(recs["y_predicted"], want["y_predicted"], equal_nan=True)
+        assert np.array_equal(recs["shapes"], want["shapes"])
+
+
+def test_single_rank_is_the_plain_level_loop():
+    from oracle import oracle
+
+    options, mpa, prob = make_problem()
+    want, _ = oracle.plan_step(options, mpa, prob)
+    got = plan_step_sharded(prob, OracleRangePlanner(options, mpa), None, 0, 1)
+    assert np.array_equal(got["n_popped"], want["n_popped"])
+    assert np.array_equal(got["y_predicted"], want["y_predicted"], equal_nan=True)

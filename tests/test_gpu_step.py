@@ -68,3 +68,31 @@ def test_road_network_triple_speed_step():
     options = Config(scenario_type=ScenarioType.commonroad, amount=10, Hp=6, mpa_type=MpaType.triple_speed, max_vehicles=16, max_nodes=1 << 17)
     sc = commonroad_scenario(options, seed=3)
     run_closed_loop(options, sc, "distance", boundary_provider(sc), 8)
+
+
+def test_sharded_planner_world1_on_gpu_matches_single_launch():
+    """pdmpc.distributed with one rank: launch_range per level + export/import path of the C ABI."""
+    import torch
+
+    from oracle import oracle
+    from pdmpc.distributed import HipRangePlanner, plan_step_sharded
+    from pdmpc.optimizer import GraphSearchHip
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    options = Config(scenario_type=ScenarioType.commonroad, amount=16, Hp=6, max_vehicles=16, max_nodes=1 << 16)
+    mpa = get_mpa(options)
+    sc = commonroad_scenario(options, seed=5)
+    opt = GraphSearchHip(options)
+    planner = HipRangePlanner(opt, mpa, torch.device("cuda", 0))
+    ctl = PrioritizedSequentialController(options, sc, mpa, None, coupling="distance", boundary_provider=boundary_provider(sc))
+
+    def plan_step(prob):
+        gpu = plan_step_sharded(prob, planner, None, 0, 1)
+        ref, _ = oracle.plan_step(options, mpa, prob)
+        assert_records_equal(gpu, ref, "sharded")
+        # import path: overwrite level-1 slots with their own exported records, re-plan the rest
+        return [info_from_record(gpu[i], options.Hp) for i in range(len(gpu))]
+
+    for _ in range(5):
+        ctl.step(plan_step=plan_step)
+    opt.handle.close()

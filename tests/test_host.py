@@ -1,0 +1,143 @@
+"""Host-side logic: MPA tables, level assignment, reference sampling, the step driver (CPU only)."""
+import numpy as np
+import pytest
+
+from pdmpc.config import Config, MpaType, ScenarioType
+from pdmpc.controller import PrioritizedSequentialController, directed_coupling_from_priorities, kahn
+from pdmpc.mpa import get_mpa
+from pdmpc.reference_trajectory import get_reference_trajectory, sample_reference_trajectory
+
+
+@pytest.mark.parametrize("mpa_type,n_trims,n_trans,max_dist", [(MpaType.single_speed, 12, 54, 1), (MpaType.triple_speed, 34, 160, 3)])
+def test_mpa_table_shapes(mpa_type, n_trims, n_trans, max_dist):
+    """Counts derived from choose_trims.m:12-84 (n = 12 / 34, T = 54 / 160)."""
+    o = Config(mpa_type=mpa_type, Hp=6)
+    m = get_mpa(o)
+    assert m.n_trims == n_trims
+    assert sum(x is not None for row in m.maneuvers for x in row) == n_trans
+    assert m.distance_to_equilibrium.max() == max_dist
+    T = m.transition_matrix_single
+    assert T.shape == (n_trims, n_trims, 6)
+    # recursive feasibility (MotionPrimitiveAutomaton.m:238-250): the last step may only enter a zero-speed trim
+    last = np.nonzero(T[:, :, -1].any(axis=0))[0] + 1
+    assert set(last) <= set(m.trims_stop)
+    # every allowed transition has a maneuver with closed areas of equal column count
+    for i in range(n_trims):
+        for j in range(n_trims):
+            if T[i, j, 0]:
+                man = m.maneuvers[i][j]
+                assert man.area.shape == man.area_without_offset.shape == man.area_large_offset.shape
+                assert np.array_equal(man.area[:, 0], man.area[:, -1])
+
+
+def test_mpa_convex_vs_non_convex_columns():
+    """generate_maneuver.m:74-101: straight 5 columns; turns 6 (convex) or 7 (non-convex)."""
+    conv = get_mpa(Config(scenario_type=ScenarioType.circle, Hp=5))
+    nonc = get_mpa(Config(scenario_type=ScenarioType.commonroad, Hp=5))
+    cols_c = {m.area.shape[1] for row in conv.maneuvers for m in row if m is not None}
+    cols_n = {m.area.shape[1] for row in nonc.maneuvers for m in row if m is not None}
+    assert cols_c == {5, 6} and cols_n == {5, 7}
+
+
+def test_straight_maneuver_is_exact_kinematics():
+    m = get_mpa(Config(Hp=5))
+    man = m.maneuvers[6][6]  # trim 7: steering 0, speed 0.8
+    assert abs(man.dx - 0.8 * 0.2) < 1e-12 and man.dy == 0 and man.dyaw == 0
+
+
+def test_kahn_levels():
+    A = np.zeros((5, 5), dtype=int)
+    A[0, 1] = A[0, 2] = A[1, 3] = A[2, 3] = 1  # 0 -> {1,2} -> 3 ; 4 isolated
+    assert kahn(A).tolist() == [1, 2, 2, 3, 1]
+    with pytest.raises(ValueError):
+        kahn(np.array([[0, 1], [1, 0]]))
+
+
+def test_directed_coupling_from_priorities():
+    adj = np.ones((3, 3), dtype=int) - np.eye(3, dtype=int)
+    d = directed_coupling_from_priorities(adj, [2, 1, 3])  # vehicle 2 plans first
+    assert d.tolist() == [[0, 0, 1], [1, 0, 1], [0, 0, 0]]
+
+
+def test_reference_sampling_on_a_straight_chord():
+    path = np.array([[0.0, 0.0], [4.0, 0.0]])
+    pts, idx, cpi = sample_reference_trajectory(4, path, 0.5, 0.3, [0.1, 0.2, 0.2, 0.2])
+    assert np.allclose(pts, [[0.6, 0], [0.8, 0], [1.0, 0], [1.2, 0]])
+    m = get_mpa(Config(Hp=5, scenario_type=ScenarioType.circle))
+    p, _, v, _ = get_reference_trajectory(m, path, 0.8, 0.0, 0.0, 1, 0.2)
+    # from standstill the first step covers half a full step (get_reference_trajectory.m:31-36)
+    assert np.allclose(p[:, 0], [0.08, 0.24, 0.40, 0.56, 0.72]) and np.all(v == 0.8)
+
+
+def test_reference_sampling_wraps_around_a_loop():
+    sq = np.array([[0, 0], [1, 0], [1, 1], [0, 1], [0, 0]], dtype=float)
+    pts, idx, _ = sample_reference_trajectory(6, sq, 0.9, 0.0, [0.3] * 6)
+    assert np.allclose(pts[0], [1.0, 0.2]) and np.allclose(pts[1], [1.0, 0.5])
+    assert np.all((pts >= -1e-12) & (pts <= 1 + 1e-12))
+
+
+def _oracle_level(options, mpa):
+    from oracle import oracle
+
+    return lambda iters: oracle.plan_batch(options, mpa, iters)[0]
+
+
+def test_circle_closed_loop_level_mode_equals_step_mode():
+    """The single-launch formulation (predecessor lists) and the level loop produce the same closed loop."""
+    from oracle import oracle
+    from pdmpc.iteration_data import info_from_record
+    from pdmpc.scenario import circle_scenario
+
+    o = Config(scenario_type=ScenarioType.circle, amount=4, Hp=5, T_end=3)
+    mpa = get_mpa(o)
+    a = PrioritizedSequentialController(o, circle_scenario(o), mpa, _oracle_level(o, mpa))
+    b = PrioritizedSequentialController(o, circle_scenario(o), mpa, None)
+
+    def plan_step(prob):
+        recs, _ = oracle.plan_step(o, mpa, prob)
+        return [info_from_record(recs[i], o.Hp) for i in range(len(recs))]
+
+    for _ in range(o.k_end):
+        ia = a.step()
+        ib = b.step(plan_step=plan_step)
+        for x, y in zip(ia, ib):
+            assert np.array_equal(x.y_predicted, y.y_predicted, equal_nan=True)
+            assert x.n_expanded == y.n_expanded and x.is_exhausted == y.is_exhausted
+    # vehicles reached the far side without touching: all pairwise distances stay above the body width
+    pos = np.array([[m.x, m.y] for m in a.meas])
+    assert np.linalg.norm(pos[0] - pos[2]) > 0.1
+
+
+def test_road_network_scenario_and_boundaries():
+    from pdmpc.road_network import boundary_provider, commonroad_scenario, get_reference_lanelets_loop, lab_map
+
+    m = lab_map()
+    assert m.n == 104 and all(l.shape[1] == 6 for l in m.lanelets)
+    assert get_reference_lanelets_loop(10)[0] == 10  # path 10 starts at lanelet 10 of loop 2
+    o = Config(scenario_type=ScenarioType.commonroad, amount=20, Hp=8)
+    sc = commonroad_scenario(o, seed=1)
+    assert len(sc.vehicles) == 20
+    starts = {(round(v.x_start, 6), round(v.y_start, 6)) for v in sc.vehicles}
+    assert len(starts) == 20  # distinct start poses
+    mpa = get_mpa(o)
+    ctl = PrioritizedSequentialController(o, sc, mpa, _oracle_level(o, mpa), coupling="distance", boundary_provider=boundary_provider(sc))
+    infos = ctl.step()
+    it = ctl.last_iters[0]
+    left, right = it.predicted_lanelet_boundary
+    assert left.shape[0] == 2 and right.shape[0] == 2 and left.shape[1] >= 12
+    assert not any(i.is_exhausted for i in infos)
+    # the planned first pose stays between the boundaries: distance to both polylines below the lane width
+    for i, info in enumerate(infos):
+        p = info.y_predicted[:2, 0]
+        l, r = ctl.last_iters[i].predicted_lanelet_boundary
+        assert np.min(np.hypot(*(l - p[:, None]))) < 0.45 and np.min(np.hypot(*(r - p[:, None]))) < 0.45
+
+
+def test_tiled_scenario_for_large_configs():
+    from pdmpc.road_network import commonroad_scenario
+
+    o = Config(scenario_type=ScenarioType.commonroad, amount=128, Hp=8)
+    sc = commonroad_scenario(o, seed=2, tiles=7)
+    assert len(sc.vehicles) == 128
+    xs = np.array([v.x_start for v in sc.vehicles])
+    assert xs.max() > 9.0  # vehicles spread over translated copies of the map
