@@ -1,0 +1,74 @@
+classdef GraphSearchHip < OptimizerInterface
+    % GRAPHSEARCHHIP  Optimal graph search on an AMD MI355X through libpdmpc_hip.so.
+    %
+    % Drop-in replacement for GraphSearch (hlc/optimizer/graph_search/GraphSearch.m): same
+    % run_optimizer signature and the same ControlResultsInfo fields.  Selected with
+    % options.optimizer_type = OptimizerType.HipOptimal (see INTEGRATION.md for the three-line
+    % patch to OptimizerInterface.get_optimizer and OptimizerType).
+    %
+    % This file is shipped as source; it cannot be executed in the build environment of this
+    % backend (no MATLAB there).  The Python class pdmpc.optimizer.GraphSearchHip is the tested
+    % twin of this class.
+
+    properties (Access = private)
+        handle uint64 = uint64(0); % pdmpc_handle*, owned by the MEX file
+        mpa_uploaded (1, 1) logical = false;
+    end
+
+    methods
+
+        function obj = GraphSearchHip(options)
+            obj = obj@OptimizerInterface();
+            % checker follows OptimizerInterface.set_constraint_checker (OptimizerInterface.m:36-46)
+            checker = double(options.are_any_obstacles_non_convex); % 0 = SAT, 1 = InterX
+            obj.handle = pdmpc_mex('create', options.Hp, checker, options.dt_seconds);
+        end
+
+        function delete(obj)
+
+            if obj.handle ~= 0
+                pdmpc_mex('destroy', obj.handle);
+            end
+
+        end
+
+        function info = run_optimizer(obj, ~, iter, mpa, options, ~)
+            % Same contract as GraphSearch.run_optimizer (GraphSearch.m:14-17): one vehicle.
+            assert(iter.amount == 1);
+
+            if ~obj.mpa_uploaded
+                pdmpc_mex('upload_mpa', obj.handle, mpa.transition_matrix_single, mpa.maneuvers);
+                obj.mpa_uploaded = true;
+            end
+
+            info = ControlResultsInfo(iter.amount, options.Hp);
+            % the MEX file flattens the cells of iter into pdmpc_vehicle_in and returns pdmpc_vehicle_out
+            out = pdmpc_mex('plan', obj.handle, ...
+                iter.x0(1, 1:3), iter.trim_indices, ...
+                squeeze(iter.reference_trajectory_points(1, :, :)), iter.v_ref(1, :), ...
+                iter.obstacles, iter.dynamic_obstacle_area, ...
+                iter.predicted_lanelet_boundary(1, 1:2), ...
+                iter.hdv_reachable_sets(find(iter.hdv_adjacency), :)); %#ok<FNDSB>
+
+            info.n_expanded = out.n_expanded;
+            info.is_exhausted = out.status ~= 0; % PDMPC_EXHAUSTED / PDMPC_ARENA_OVERFLOW
+
+            if info.is_exhausted
+                return % y_predicted stays NaN (ControlResultsInfo.m:40); the caller decides on the fallback
+            end
+
+            Hp = options.Hp;
+            % rows in NodeInfo order (NodeInfo.m:5-13), as create_control_results_info_from_mex expects
+            next_nodes = arrayfun(@(k) out.path_nodes(k + 1, :), 1:Hp, UniformOutput = false);
+            trims = [iter.trim_indices, out.predicted_trims(1:Hp)];
+            y_full = {[out.y_predicted(1:Hp, :), zeros(Hp, 1)]}; % one row per step: entries_per_time_step == 1
+            info = OptimizerInterface.create_control_results_info_from_mex(info, iter, options, next_nodes, trims, y_full);
+            % the helper does not fill shapes / needs_fallback; publish_predictions reads info.shapes(1, :)
+            info.shapes = arrayfun(@(k) squeeze(out.shapes(k, :, 1:out.shape_cols(k))), 1:Hp, UniformOutput = false);
+            info.tree_path = 1:(Hp + 1);
+            info.needs_fallback = false;
+        end
+
+    end
+
+end
