@@ -142,7 +142,7 @@ struct pdmpc_handle {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
     LdsLayout lds{};
-    int HL = 0, NL = 0, areas_in_lds = 0;
+    int HL = 0, NL = 0, NV = 0, areas_in_lds = 0;
     pdmpc_stats stats{};
 };
 
@@ -151,7 +151,7 @@ namespace {
 int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in) {
     const int Hp = h->cfg.Hp;
     struct { int soup_cap; } hb{soup_cap_in};
-    const size_t budget = (n_launch > h->n_cu) ? kLdsMax / 2 : kLdsMax;
+    const size_t budget = (n_launch > h->n_cu) ? kLdsMax / 2 : kLdsMax;  // 2 workgroups of 4 waves per CU still fit
     LdsLayout L{};
     uint32_t off = 0;
     L.mask = off;
@@ -163,11 +163,11 @@ int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in) {
     const uint32_t area_bytes = (uint32_t)(h->n_man * 3 * PDMPC_VMAX * 16);
     // fixed part after the tables
     const uint32_t ref_bytes = 3 * PDMPC_HP_MAX * 8;
-    const uint32_t shape_bytes = 2 * PDMPC_VMAX * 16;
-    const uint32_t path_bytes = align16((PDMPC_HP_MAX + 2) * 4 + 2 * (PDMPC_HP_MAX + 1) * 4);
+    const uint32_t shape_bytes = PDMPC_WAVES_PER_VEHICLE * 2 * PDMPC_VMAX * 16;
+    const uint32_t path_bytes = align16((PDMPC_HP_MAX + 2) * 4 + 2 * (PDMPC_HP_MAX + 1) * 4 + 16);
     const uint32_t soup_bytes = (uint32_t)std::max(hb.soup_cap, 1) * 16;
     const uint32_t fixed_rest = ref_bytes + shape_bytes + path_bytes + soup_bytes;
-    const uint32_t cand_bytes = align16((uint32_t)std::max(hb.soup_cap, 1) * 4);
+    const uint32_t cand_bytes = align16((uint32_t)std::max(hb.soup_cap, 1) * 4 * PDMPC_WAVES_PER_VEHICLE);
     const uint32_t min_bytes = 64 * 12 + 64 * (uint32_t)sizeof(NodeRec);
     int areas = 1;
     if ((size_t)off + area_bytes + fixed_rest + cand_bytes + min_bytes + 256 > budget) areas = 0;
@@ -193,12 +193,17 @@ int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in) {
     const uint32_t rest = (uint32_t)(budget - off - 256);
     uint32_t hl = std::min((uint32_t)4096, rest / 2 / 12);
     hl = std::min(hl, h->max_nodes) & ~3u;
-    uint32_t nl = (rest - hl * 12) / (uint32_t)sizeof(NodeRec);
+    // validity cache: one byte per node for the first NV nodes (a quarter of what is left, at most 32768)
+    uint32_t nv = std::min((uint32_t)32768, (rest - hl * 12) / 4);
+    nv = std::min(nv, h->max_nodes) & ~15u;
+    uint32_t nl = (rest - hl * 12 - nv) / (uint32_t)sizeof(NodeRec);
     nl = std::min(nl, h->max_nodes);
     L.heap_key = off;
     off += align16(hl * 8);
     L.heap_id = off;
     off += align16(hl * 4);
+    L.vstate = off;
+    off += align16(nv);
     L.nodes = off;
     off += nl * (uint32_t)sizeof(NodeRec);
     L.total = align16(off);
@@ -206,6 +211,7 @@ int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in) {
     h->lds = L;
     h->HL = (int)hl;
     h->NL = (int)nl;
+    h->NV = (int)nv;
     h->areas_in_lds = areas;
     (void)Hp;
     return PDMPC_OK;
@@ -373,6 +379,7 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.lds = h->lds;
     a.HL = h->HL;
     a.NL = h->NL;
+    a.NV = h->NV;
     a.soup_cap = B.soup_cap;
     a.spin_limit = 1u << 22;
     if (h->events_used == h->events.size()) {

@@ -21,6 +21,8 @@
 #include "../../include/pdmpc.h"
 
 #define PDMPC_WAVE 64
+#define PDMPC_WAVES_PER_VEHICLE 4 /* wave 0 sequences the search, waves 1..3 pre-validate nodes */
+#define PDMPC_THREADS (PDMPC_WAVE * PDMPC_WAVES_PER_VEHICLE)
 
 struct DevManPose {
     double dx, dy, dyaw;
@@ -65,7 +67,8 @@ struct LdsLayout {
     uint32_t shape;                        // shape A [8], shape B [8] (double2)
     uint32_t path;                         // uint32 path[HP_MAX+1] + misc scratch
     uint32_t soup;                         // double2[soup_cap]
-    uint32_t cand;                         // uint32[soup_cap]: compacted candidate segments of one edge check
+    uint32_t cand;                         // uint32[waves][soup_cap]: compacted candidate segments of one edge check
+    uint32_t vstate;                       // uint8[NV]: validity cache (0 unknown, 1 valid, 2 invalid)
     uint32_t heap_key, heap_id;            // double[HL], uint32[HL]
     uint32_t nodes;                        // NodeRec[NL]
     uint32_t total;
@@ -103,7 +106,7 @@ struct KernelArgs {
     int32_t* tree_size;  // per slot: nodes in the tree after the search (debug read-back)
     // LDS
     LdsLayout lds;
-    int32_t HL, NL, soup_cap;
+    int32_t HL, NL, NV, soup_cap;
     uint32_t spin_limit;
 };
 

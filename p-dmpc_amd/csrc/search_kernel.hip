@@ -450,18 +450,94 @@ __device__ bool sat_boundary_wave(const d2* sh, int V1, const d2* ll, int M, int
     return false;
 }
 
-// copy `count` 16-byte elements HBM -> LDS, lane-strided (coalesced 1 KiB per wave instruction)
-__device__ __forceinline__ void stage16(void* dst_lds, const void* src, int count, int lane) {
+// copy `count` 16-byte elements HBM -> LDS, thread-strided over the whole workgroup (coalesced)
+__device__ __forceinline__ void stage16(void* dst_lds, const void* src, int count, int tid) {
     d2* d = (d2*)dst_lds;
     const d2* s = (const d2*)src;
-    for (int i = lane; i < count; i += PDMPC_WAVE) d[i] = s[i];
+    for (int i = tid; i < count; i += PDMPC_THREADS) d[i] = s[i];
 }
+
+// order this wave's LDS/HBM writes before its later reads (same wave: the hardware keeps DS order; this stops the
+// compiler from moving accesses)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// read-only view of what an edge check needs (shared by the sequencing wave and the helper waves)
+struct CheckCtx {
+    const d2* l_area;
+    const d2* g_area;
+    const d2* l_soup;
+    const int32_t* l_soff;
+    const int32_t* l_hoff;
+    int areas_in_lds, ll_base, ll_len, Hp, checker;
+    d2* sh;          // this wave's shape scratch: A in [0, VMAX), B in [VMAX, 2 VMAX)
+    uint32_t* cand;  // this wave's candidate list
+};
+
+// eval_edge_exact (GraphSearch.m:111-196) for node `id` (1-based): true = collision-free.  A pure function of the
+// tree and the obstacle soups, which is what allows helper waves to evaluate it ahead of the pop.
+__device__ bool edge_valid(const Search& S, const CheckCtx& C, uint32_t id, int lane) {
+    const NodeRec cn = node_load(S, id - 1);
+    const uint32_t par = uni_u(cn.parent);
+    if (!par) return true;  // root: no edge (GraphSearch.m:137-139)
+    const uint32_t cpk = uni_u(cn.packed);
+    const int cK = NODE_K(cpk);
+    const NodeRec pn = node_load(S, par - 1);
+    const double pX = pn.x, pY = pn.y;
+    const double c = pn.cs, s = pn.sn;  // cos/sin(pYaw), cached when the parent was expanded
+    const int m = NODE_MAN(cpk);
+    const int ncols = NODE_COLS(cpk);
+    if (lane < ncols) {
+        const size_t ai = (size_t)m * 3 * PDMPC_VMAX + lane;
+        const size_t bi = ai + (size_t)((cK == C.Hp) ? 2 : 1) * PDMPC_VMAX;  // large offset at k == Hp, else without offset
+        d2 a, b;
+        if (C.areas_in_lds) {
+            a = C.l_area[ai];
+            b = C.l_area[bi];
+        } else {
+            a = C.g_area[ai];
+            b = C.g_area[bi];
+        }
+        d2 sa, sb;
+        sa.x = c * a.x - s * a.y + pX;  // GraphSearch.m:158
+        sa.y = s * a.x + c * a.y + pY;  // :159
+        sb.x = c * b.x - s * b.y + pX;  // :162 / :168
+        sb.y = s * b.x + c * b.y + pY;  // :163 / :169
+        C.sh[lane] = sa;
+        C.sh[PDMPC_VMAX + lane] = sb;
+    }
+    wave_sync();
+    const int so = uni_i(C.l_soff[cK - 1]);
+    const int M_k = uni_i(C.l_soff[cK]) - so;
+    bool hit;
+    if (C.checker == PDMPC_CHECK_INTERX) {
+        const int ho = uni_i(C.l_hoff[cK - 1]);
+        const int Hk = uni_i(C.l_hoff[cK]) - ho;
+        hit = interx_check(C.sh, ncols, C.l_soup, so, M_k, ho, Hk, C.ll_base, C.ll_len, C.cand, lane);
+    } else {
+        // are_constraints_satisfied_sat.m:15-53
+        hit = sat_soup_wave(C.sh, ncols, C.l_soup + so, M_k, lane);
+        if (!hit) hit = sat_boundary_wave(C.sh + PDMPC_VMAX, ncols, C.l_soup + C.ll_base, C.ll_len, lane);
+    }
+    wave_sync();
+    return !hit;
+}
+
+__device__ __forceinline__ uint32_t lds_load_u32(const volatile uint32_t* p) { return *p; }
 
 }  // namespace
 
-extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_search_kernel(const KernelArgs A) {
+// LDS words shared between the waves of a workgroup (in the `path` region, after the offset tables)
+#define SH_DONE 0      // sequencing wave finished
+#define SH_HEAP_LEN 1  // current open-list length (for the helpers' scan)
+
+extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(const KernelArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & (PDMPC_WAVE - 1);
+    const int wave = uni_i(tid >> 6);
     const int slot = A.first + blockIdx.x;
     const int Hp = A.Hp;
     const int n = A.n_trims;
@@ -475,15 +551,13 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_search_kernel(con
     double* l_rx = (double*)(smem + A.lds.ref);
     double* l_ry = l_rx + PDMPC_HP_MAX;
     double* l_dtv = l_ry + PDMPC_HP_MAX;
-    d2* l_shA = (d2*)(smem + A.lds.shape);
-    d2* l_shB = l_shA + PDMPC_VMAX;
     uint32_t* l_path = (uint32_t*)(smem + A.lds.path);
     int32_t* l_soff = (int32_t*)(l_path + PDMPC_HP_MAX + 2);  // soup offsets [Hp+1], hdv offsets [Hp+1]
     int32_t* l_hoff = l_soff + PDMPC_HP_MAX + 1;
+    volatile uint32_t* l_shared = (volatile uint32_t*)(l_hoff + PDMPC_HP_MAX + 1);
     d2* l_soup = (d2*)(smem + A.lds.soup);
-    uint32_t* l_cand = (uint32_t*)(smem + A.lds.cand);
-    const d2* l_area = (const d2*)(smem + A.lds.area);
-    const d2* g_area = (const d2*)A.man_area;
+    volatile uint8_t* l_vstate = (volatile uint8_t*)(smem + A.lds.vstate);
+    const uint32_t NV = (uint32_t)A.NV;
 
     Search S;
     S.ln = (NodeRec*)(smem + A.lds.nodes);
@@ -498,21 +572,38 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_search_kernel(con
     S.gkey = A.arena.heap_key + voff;
     S.gid = A.arena.heap_id + voff;
 
+    CheckCtx C;
+    C.l_area = (const d2*)(smem + A.lds.area);
+    C.g_area = (const d2*)A.man_area;
+    C.l_soup = l_soup;
+    C.l_soff = l_soff;
+    C.l_hoff = l_hoff;
+    C.areas_in_lds = A.areas_in_lds;
+    C.Hp = Hp;
+    C.checker = A.checker;
+    C.sh = (d2*)(smem + A.lds.shape) + wave * 2 * PDMPC_VMAX;
+    C.cand = (uint32_t*)(smem + A.lds.cand) + (size_t)wave * A.soup_cap;
+
     pdmpc_vehicle_out* __restrict__ O = A.out + slot;
 
     // ---- prologue 1: stage MPA tables (coalesced 16-byte copies; the host pads every table to 16 B)
     {
         const int mask_bytes = Hp * n * nw * 8;
-        stage16(l_mask, A.succ_mask, (mask_bytes + 15) / 16, lane);
-        stage16(l_mi, A.man_index, (n * n * 2 + 15) / 16, lane);
-        stage16(l_pose, A.man_pose, A.n_man * 2, lane);
-        if (A.areas_in_lds) stage16(smem + A.lds.area, A.man_area, A.n_man * 3 * PDMPC_VMAX, lane);
+        stage16(l_mask, A.succ_mask, (mask_bytes + 15) / 16, tid);
+        stage16(l_mi, A.man_index, (n * n * 2 + 15) / 16, tid);
+        stage16(l_pose, A.man_pose, A.n_man * 2, tid);
+        if (A.areas_in_lds) stage16(smem + A.lds.area, A.man_area, A.n_man * 3 * PDMPC_VMAX, tid);
+        for (uint32_t i = (uint32_t)tid * 16u; i < NV; i += PDMPC_THREADS * 16u) *(d2*)(smem + A.lds.vstate + i) = d2{0.0, 0.0};
     }
     // ---- prologue 2: vehicle record, result record defaults
-    if (lane < Hp) {
-        l_rx[lane] = V->ref_x[lane];
-        l_ry[lane] = V->ref_y[lane];
-        l_dtv[lane] = A.dt * V->v_ref[lane];  // options.dt_seconds * iter.v_ref(k)   expand_node.m:70
+    if (tid < Hp) {
+        l_rx[tid] = V->ref_x[tid];
+        l_ry[tid] = V->ref_y[tid];
+        l_dtv[tid] = A.dt * V->v_ref[tid];  // options.dt_seconds * iter.v_ref(k)   expand_node.m:70
+    }
+    if (tid == 0) {
+        l_shared[SH_DONE] = 0;
+        l_shared[SH_HEAP_LEN] = 0;
     }
     {
         // zero the record; y_predicted starts as NaN (ControlResultsInfo.m:40)
@@ -520,7 +611,7 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_search_kernel(con
         const int nd = (int)(sizeof(pdmpc_vehicle_out) / 8);
         const int y0 = (int)(offsetof(pdmpc_vehicle_out, y_predicted) / 8);
         const double qnan = __longlong_as_double(0x7ff8000000000000LL);
-        for (int i = lane; i < nd; i += PDMPC_WAVE) od[i] = (i >= y0 && i < y0 + PDMPC_HP_MAX * 3) ? qnan : 0.0;
+        for (int i = tid; i < nd; i += PDMPC_THREADS) od[i] = (i >= y0 && i < y0 + PDMPC_HP_MAX * 3) ? qnan : 0.0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // later result stores hit the same bytes from other lanes
     }
     __syncthreads();
@@ -532,25 +623,25 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_search_kernel(con
         int off = 0;
         for (int k = 0; k < Hp; ++k) {
             const int a = V->lit_off[k], b = V->lit_off[k + 1];
-            if (lane == 0) l_soff[k] = off;
-            stage16(l_soup + off, (const d2*)A.points + a, b - a, lane);
+            if (tid == 0) l_soff[k] = off;
+            stage16(l_soup + off, (const d2*)A.points + a, b - a, tid);
             off += (b - a) + pred_cols;
         }
-        if (lane == 0) l_soff[Hp] = off;
+        if (tid == 0) l_soff[Hp] = off;
         for (int k = 0; k < Hp; ++k) {
             const int a = V->hdv_off[k], b = V->hdv_off[k + 1];
-            if (lane == 0) l_hoff[k] = off;
-            stage16(l_soup + off, (const d2*)A.points + a, b - a, lane);
+            if (tid == 0) l_hoff[k] = off;
+            stage16(l_soup + off, (const d2*)A.points + a, b - a, tid);
             off += (b - a);
         }
-        if (lane == 0) l_hoff[Hp] = off;
+        if (tid == 0) l_hoff[Hp] = off;
         // lanelet soup last
-        stage16(l_soup + off, (const d2*)A.points + V->ll_off, V->ll_len, lane);
-        if (lane == 0) l_path[PDMPC_HP_MAX + 1] = (uint32_t)off;
+        stage16(l_soup + off, (const d2*)A.points + V->ll_off, V->ll_len, tid);
+        if (tid == 0) l_path[PDMPC_HP_MAX + 1] = (uint32_t)off;
     }
     __syncthreads();
-    const int ll_base = uni_i((int)l_path[PDMPC_HP_MAX + 1]);
-    const int ll_len = uni_i(V->ll_len);
+    C.ll_base = uni_i((int)l_path[PDMPC_HP_MAX + 1]);
+    C.ll_len = uni_i(V->ll_len);
 
     // ---- prologue 4: wait for sequential predecessors and append their solved areas (PrioritizedController.m:476-491)
     bool dep_timeout = false;
@@ -570,7 +661,7 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_search_kernel(con
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const double qnan = __longlong_as_double(0x7ff8000000000000LL);
-        for (int idx = lane; idx < Hp * pred_cols; idx += PDMPC_WAVE) {
+        for (int idx = tid; idx < Hp * pred_cols; idx += PDMPC_THREADS) {
             const int k = idx / pred_cols;
             const int r = idx - k * pred_cols;
             const int p = r / PDMPC_VMAX;
@@ -588,200 +679,204 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_search_kernel(con
             const int lit = V->lit_off[k + 1] - V->lit_off[k];
             l_soup[l_soff[k] + lit + r] = pt;
         }
-        __syncthreads();
     }
 
     // ---- root node (GraphSearch.m:34-46)
     uint32_t nnodes = 1;
-    {
-        if (lane == 0) {
-            NodeRec r;
-            r.x = V->x0;
-            r.y = V->y0;
-            r.yaw = V->yaw0;
-            r.g = 0.0;
-            r.cs = 0.0;
-            r.sn = 0.0;
-            r.h = 0.0;
-            r.parent = 0;
-            r.packed = (uint32_t)V->trim0;
-            S.gn[0] = r;
-            S.ln[0] = r;
-            S.lkey[0] = 0.0;
-            S.lid[0] = 1;
-        }
-        S.heap_len = 1;
+    if (tid == 0) {
+        NodeRec r;
+        r.x = V->x0;
+        r.y = V->y0;
+        r.yaw = V->yaw0;
+        r.g = 0.0;
+        r.cs = 0.0;
+        r.sn = 0.0;
+        r.h = 0.0;
+        r.parent = 0;
+        r.packed = (uint32_t)V->trim0;
+        S.gn[0] = r;
+        S.ln[0] = r;
+        S.lkey[0] = 0.0;
+        S.lid[0] = 1;
+        l_shared[SH_HEAP_LEN] = 1;
     }
+    S.heap_len = 1;
     __syncthreads();
 
     int status = PDMPC_OK;
     int n_popped = 0;
     uint32_t goal = 0;
-    PROF_DECL
-    PROF_START
 
-    // ---- main loop (GraphSearch.m:53-107)
-    for (;;) {
-        if (S.heap_len == 0) {  // pop on an empty queue returns -1 (mex.cpp:87-93)  GraphSearch.m:57-61
-            status = PDMPC_EXHAUSTED;
-            break;
-        }
-        PROF_STOP(7)
-        const uint32_t cur = uni_u(S.lid[0]);  // 1-based node id (HL >= 1: the top is always in LDS)
-        heap_pop(S);
-        PROF_STOP(0)
-        if (A.trace_cap > 0 && n_popped < A.trace_cap && lane == 0) A.pop_trace[(size_t)slot * A.trace_cap + n_popped] = (int32_t)cur;
-        ++n_popped;
-        const uint32_t c0 = cur - 1;
-        const NodeRec cn = node_load(S, c0);  // same record in every lane
-        const uint32_t par = uni_u(cn.parent);
-        const uint32_t cpk = uni_u(cn.packed);
-        const int cTrim = NODE_TRIM(cpk);  // 1-based
-        const int cK = NODE_K(cpk);
-
-        // ---- eval_edge_exact (GraphSearch.m:111-196)
-        bool valid = true;
-        if (par) {
-            const NodeRec pn = node_load(S, par - 1);
-            const double pX = pn.x, pY = pn.y;
-            const double c = pn.cs, s = pn.sn;  // cos/sin(pYaw), cached when the parent was expanded
-            const int m = NODE_MAN(cpk);
-            const int ncols = NODE_COLS(cpk);
-            if (lane < ncols) {
-                const size_t ai = (size_t)m * 3 * PDMPC_VMAX + lane;
-                const size_t bi = ai + (size_t)((cK == Hp) ? 2 : 1) * PDMPC_VMAX;  // large offset at k == Hp, else without offset
-                d2 a, b;
-                if (A.areas_in_lds) {
-                    a = l_area[ai];
-                    b = l_area[bi];
-                } else {
-                    a = g_area[ai];
-                    b = g_area[bi];
+    if (wave != 0) {
+        // ================= helper waves: pre-validate the nodes near the top of the open list ==================
+        // Any id read from the heap is a fully written node (the sequencing wave publishes ids after the records);
+        // edge validity is a pure function, so evaluating it early, twice, or for a node that is never popped
+        // cannot change the search.  Results land in the shared validity cache (1 = valid, 2 = invalid).
+        const int share = wave - 1;
+        while (lds_load_u32(&l_shared[SH_DONE]) == 0) {
+            const uint32_t hl = lds_load_u32(&l_shared[SH_HEAP_LEN]);
+            const uint32_t K = hl < (uint32_t)PDMPC_WAVE ? hl : (uint32_t)PDMPC_WAVE;
+            uint32_t id = 0;
+            if ((uint32_t)lane < K) id = *(volatile uint32_t*)&S.lid[lane];
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const bool unknown = id != 0 && (id - 1) < NV && l_vstate[id - 1] == 0;
+            unsigned long long b = __ballot(unknown);
+            int skip = share;
+            uint32_t target = 0;
+            while (b) {
+                const int l = __builtin_ctzll(b);
+                b &= b - 1;
+                if (skip == 0) {
+                    target = lane_u(id, l);
+                    break;
                 }
-                d2 sa, sb;
-                sa.x = c * a.x - s * a.y + pX;  // GraphSearch.m:158
-                sa.y = s * a.x + c * a.y + pY;  // :159
-                sb.x = c * b.x - s * b.y + pX;  // :162 / :168
-                sb.y = s * b.x + c * b.y + pY;  // :163 / :169
-                l_shA[lane] = sa;
-                l_shB[lane] = sb;
+                --skip;
             }
-            __syncthreads();
-            PROF_STOP(1)
-            const int so = uni_i(l_soff[cK - 1]);
-            const int M_k = uni_i(l_soff[cK]) - so;
-            if (A.checker == PDMPC_CHECK_INTERX) {
-                const int ho = uni_i(l_hoff[cK - 1]);
-                const int Hk = uni_i(l_hoff[cK]) - ho;
-                valid = !interx_check(l_shA, ncols, l_soup, so, M_k, ho, Hk, ll_base, ll_len, l_cand, lane);
+            if (target) {
+                const bool ok = edge_valid(S, C, target, lane);
+                if (lane == 0) l_vstate[target - 1] = ok ? 1 : 2;
             } else {
-                // are_constraints_satisfied_sat.m:15-53
-                bool hit = sat_soup_wave(l_shA, ncols, l_soup + so, M_k, lane);
-                if (!hit) hit = sat_boundary_wave(l_shB, ncols, l_soup + ll_base, ll_len, lane);
-                valid = !hit;
+                __builtin_amdgcn_s_sleep(2);
             }
-            __syncthreads();
+        }
+    } else {
+        // ================= sequencing wave: GraphSearch.m:53-107 =================================================
+        PROF_DECL
+        PROF_START
+        for (;;) {
+            if (S.heap_len == 0) {  // pop on an empty queue returns -1 (mex.cpp:87-93)  GraphSearch.m:57-61
+                status = PDMPC_EXHAUSTED;
+                break;
+            }
+            PROF_STOP(7)
+            const uint32_t cur = uni_u(*(volatile uint32_t*)&S.lid[0]);  // 1-based node id (HL >= 1: the top is always in LDS)
+            heap_pop(S);
+            if (lane == 0) l_shared[SH_HEAP_LEN] = S.heap_len;
+            PROF_STOP(0)
+            if (A.trace_cap > 0 && n_popped < A.trace_cap && lane == 0) A.pop_trace[(size_t)slot * A.trace_cap + n_popped] = (int32_t)cur;
+            ++n_popped;
+            const uint32_t c0 = cur - 1;
+
+            // ---- eval_edge_exact (GraphSearch.m:111-196): from the validity cache if a helper got there first
+            uint32_t vs = 0;
+            if (c0 < NV) vs = uni_u((uint32_t)l_vstate[c0]);
+            bool valid;
+            if (vs == 0) {
+                valid = edge_valid(S, C, cur, lane);
+                if (c0 < NV && lane == 0) l_vstate[c0] = valid ? 1 : 2;
+                PROF_COUNT(13, 1)
+            } else {
+                valid = (vs == 1);
+            }
             PROF_STOP(2)
-        }
-        if (!valid) continue;  // GraphSearch.m:75-77
+            if (!valid) continue;  // GraphSearch.m:75-77
 
-        if (cK == Hp) {  // :81-90
-            goal = cur;
-            break;
-        }
+            const NodeRec cn = node_load(S, c0);  // same record in every lane
+            const uint32_t cpk = uni_u(cn.packed);
+            const int cTrim = NODE_TRIM(cpk);  // 1-based
+            const int cK = NODE_K(cpk);
+            if (cK == Hp) {  // :81-90
+                goal = cur;
+                break;
+            }
 
-        // ---- expand_node.m:1-91
-        const double curX = cn.x, curY = cn.y, curYaw = cn.yaw, curG = cn.g;
-        double sn, cs;
-        PROF_STOP(3)
-        pdmpc_sincos(curYaw, &sn, &cs);  // expand_node.m:50-51
-        PROF_STOP(4)
-        if (lane == 0) {
-            if (c0 < S.NL) {
-                S.ln[c0].cs = cs;
-                S.ln[c0].sn = sn;
+            // ---- expand_node.m:1-91
+            const double curX = cn.x, curY = cn.y, curYaw = cn.yaw, curG = cn.g;
+            double sn, cs;
+            PROF_STOP(3)
+            pdmpc_sincos(curYaw, &sn, &cs);  // expand_node.m:50-51
+            PROF_STOP(4)
+            if (lane == 0) {
+                if (c0 < S.NL) {
+                    S.ln[c0].cs = cs;
+                    S.ln[c0].sn = sn;
+                }
+                S.gn[c0].cs = cs;
+                S.gn[c0].sn = sn;
             }
-            S.gn[c0].cs = cs;
-            S.gn[c0].sn = sn;
-        }
-        const int k_exp = cK + 1;            // :13
-        const int steps_to_go = Hp - k_exp;  // :37
-        const uint64_t* mrow = l_mask + ((size_t)(k_exp - 1) * n + (cTrim - 1)) * nw;
-        uint32_t total = 0;
-        for (int w = 0; w < nw; ++w) total += (uint32_t)__builtin_popcountll(mrow[w]);
-        total = uni_u(total);
-        if (nnodes + total > S.max_nodes) {
-            status = PDMPC_ARENA_OVERFLOW;
-            break;
-        }
-        for (int w = 0; w < nw; ++w) {
-            uint64_t mask = mrow[w];
-            {
-                const uint32_t lo = uni_u((uint32_t)mask), hi = uni_u((uint32_t)(mask >> 32));
-                mask = ((uint64_t)hi << 32) | lo;
+            const int k_exp = cK + 1;            // :13
+            const int steps_to_go = Hp - k_exp;  // :37
+            const uint64_t* mrow = l_mask + ((size_t)(k_exp - 1) * n + (cTrim - 1)) * nw;
+            uint32_t total = 0;
+            for (int w = 0; w < nw; ++w) total += (uint32_t)__builtin_popcountll(mrow[w]);
+            total = uni_u(total);
+            if (nnodes + total > S.max_nodes) {
+                status = PDMPC_ARENA_OVERFLOW;
+                break;
             }
-            const int cnt = __builtin_popcountll(mask);
-            const bool active = (mask >> lane) & 1ull;
-            const int rank = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-            double f = 0.0;
-            if (active) {
-                const int t2 = w * 64 + lane;  // 0-based successor trim
-                const int m = (int)l_mi[(cTrim - 1) * n + t2];
-                const DevManPose mp = l_pose[m];
-                NodeRec ch;
-                ch.x = cs * mp.dx - sn * mp.dy + curX;  // :53
-                ch.y = sn * mp.dx + cs * mp.dy + curY;  // :54
-                ch.yaw = curYaw + mp.dyaw;              // :55
-                double expG = curG;
+            for (int w = 0; w < nw; ++w) {
+                uint64_t mask = mrow[w];
                 {
-                    const double ddx = ch.x - l_rx[k_exp - 1], ddy = ch.y - l_ry[k_exp - 1];
-                    const double nrm = sqrt(ddx * ddx + ddy * ddy);
-                    expG = expG + nrm * nrm;  // :61
+                    const uint32_t lo = uni_u((uint32_t)mask), hi = uni_u((uint32_t)(mask >> 32));
+                    mask = ((uint64_t)hi << 32) | lo;
                 }
-                double expH = 0.0, dmax = 0.0;
-                for (int it = 1; it <= steps_to_go; ++it) {  // :68-73
-                    dmax = dmax + l_dtv[k_exp + it - 1];
-                    const double ddx = ch.x - l_rx[k_exp + it - 1], ddy = ch.y - l_ry[k_exp + it - 1];
-                    const double nrm = sqrt(ddx * ddx + ddy * ddy);
-                    const double df = nrm - dmax;
-                    const double m0 = (df > 0) ? df : 0.0;
-                    expH = expH + m0 * m0;
+                const int cnt = __builtin_popcountll(mask);
+                const bool active = (mask >> lane) & 1ull;
+                const int rank = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                double f = 0.0;
+                if (active) {
+                    const int t2 = w * 64 + lane;  // 0-based successor trim
+                    const int m = (int)l_mi[(cTrim - 1) * n + t2];
+                    const DevManPose mp = l_pose[m];
+                    NodeRec ch;
+                    ch.x = cs * mp.dx - sn * mp.dy + curX;  // :53
+                    ch.y = sn * mp.dx + cs * mp.dy + curY;  // :54
+                    ch.yaw = curYaw + mp.dyaw;              // :55
+                    double expG = curG;
+                    {
+                        const double ddx = ch.x - l_rx[k_exp - 1], ddy = ch.y - l_ry[k_exp - 1];
+                        const double nrm = sqrt(ddx * ddx + ddy * ddy);
+                        expG = expG + nrm * nrm;  // :61
+                    }
+                    double expH = 0.0, dmax = 0.0;
+                    for (int it = 1; it <= steps_to_go; ++it) {  // :68-73
+                        dmax = dmax + l_dtv[k_exp + it - 1];
+                        const double ddx = ch.x - l_rx[k_exp + it - 1], ddy = ch.y - l_ry[k_exp + it - 1];
+                        const double nrm = sqrt(ddx * ddx + ddy * ddy);
+                        const double df = nrm - dmax;
+                        const double m0 = (df > 0) ? df : 0.0;
+                        expH = expH + m0 * m0;
+                    }
+                    f = expG * 1 + expH * 1;  // GraphSearch.m:100-102
+                    ch.g = expG;
+                    ch.h = expH;
+                    ch.cs = 0.0;
+                    ch.sn = 0.0;
+                    ch.parent = cur;
+                    ch.packed = (uint32_t)(t2 + 1) | ((uint32_t)k_exp << 10) | ((uint32_t)m << 15) | ((uint32_t)mp.n_cols << 27);
+                    const uint32_t i0 = nnodes + (uint32_t)rank;  // 0-based index of the child (Tree.add_nodes, Tree.m:61)
+                    S.gn[i0] = ch;
+                    if (i0 < S.NL) S.ln[i0] = ch;
                 }
-                f = expG * 1 + expH * 1;  // GraphSearch.m:100-102
-                ch.g = expG;
-                ch.h = expH;
-                ch.cs = 0.0;
-                ch.sn = 0.0;
-                ch.parent = cur;
-                ch.packed = (uint32_t)(t2 + 1) | ((uint32_t)k_exp << 10) | ((uint32_t)m << 15) | ((uint32_t)mp.n_cols << 27);
-                const uint32_t i0 = nnodes + (uint32_t)rank;  // 0-based index of the child (Tree.add_nodes, Tree.m:61)
-                S.gn[i0] = ch;
-                if (i0 < S.NL) S.ln[i0] = ch;
+                // records (and the parent's cos/sin) must be visible to the helper waves before any id reaches the heap
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                wave_sync();
+                PROF_STOP(5)
+                // pq.push(new_open_nodes, new_open_values): one at a time in ascending trim order (mex.cpp:67-72)
+                uint64_t mm = mask;
+                uint32_t r = 0;
+                while (mm) {
+                    const int l = __builtin_ctzll(mm);
+                    mm &= mm - 1;
+                    const double fk = lane_d(f, l);
+                    heap_push(S, nnodes + r + 1, fk);
+                    ++r;
+                }
+                nnodes += (uint32_t)cnt;
+                if (lane == 0) l_shared[SH_HEAP_LEN] = S.heap_len;
+                PROF_STOP(6)
             }
-            if (nnodes + (uint32_t)cnt > S.NL) __threadfence_block();
-            __syncthreads();
-            PROF_STOP(5)
-            // pq.push(new_open_nodes, new_open_values): one at a time in ascending trim order (mex.cpp:67-72)
-            uint64_t mm = mask;
-            uint32_t r = 0;
-            while (mm) {
-                const int l = __builtin_ctzll(mm);
-                mm &= mm - 1;
-                const double fk = lane_d(f, l);
-                heap_push(S, nnodes + r + 1, fk);
-                ++r;
-            }
-            nnodes += (uint32_t)cnt;
-            PROF_STOP(6)
         }
-    }
 #ifdef PDMPC_PROFILE
-    if (lane == 0)
-        for (int i = 0; i < PROF_N; ++i) ((double*)O->shapes[PDMPC_HP_MAX - 1])[i] = (double)S.prof_acc[i];  // unused tail of the record
+        if (lane == 0)
+            for (int i = 0; i < PROF_N; ++i) ((double*)O->shapes[PDMPC_HP_MAX - 1])[i] = (double)S.prof_acc[i];  // unused tail of the record
 #endif
-
-    // ---- results (GraphSearch.m:58-59, 82-89; return_path_to.m; return_path_area.m)
+        if (lane == 0) l_shared[SH_DONE] = 1;
+    }
     __syncthreads();
+    if (wave != 0) return;
+
+    // ---- results (GraphSearch.m:58-59, 82-89; return_path_to.m; return_path_area.m), sequencing wave only
     if (goal) {
         // path_to_root (Tree.m:44-52), reversed
         if (lane == 0) {
@@ -791,7 +886,7 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_search_kernel(con
                 nd = node_parent(S, nd - 1);
             }
         }
-        __syncthreads();
+        wave_sync();
         if (lane <= Hp) {
             const uint32_t nd = l_path[lane];
             const NodeRec r = node_load(S, nd - 1);
@@ -822,7 +917,7 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_search_kernel(con
             const int ncols = NODE_COLS(cr.packed);
             if (v == 0) O->shape_cols[i - 1] = ncols;
             if (v < ncols) {
-                const d2 a = g_area[(size_t)m * 3 * PDMPC_VMAX + v];
+                const d2 a = C.g_area[(size_t)m * 3 * PDMPC_VMAX + v];
                 O->shapes[i - 1][0][v] = pr.cs * a.x - pr.sn * a.y + pr.x;
                 O->shapes[i - 1][1][v] = pr.sn * a.x + pr.cs * a.y + pr.y;
             }
@@ -849,9 +944,9 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_search_kernel(con
         O->n_hp = Hp;
         A.tree_size[slot] = (int32_t)nnodes;
     }
-    // ---- publish: plain stores -> every wave's vmcnt(0) -> barrier -> lane-0 agent release -> flag
+    // ---- publish: plain stores -> this wave's vmcnt(0) -> lane-0 agent release -> flag
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    wave_sync();
     if (lane == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -864,6 +959,6 @@ extern "C" int pdmpc_launch_search(const KernelArgs* args, int count, void* stre
     hipError_t e = hipFuncSetAttribute((const void*)pdmpc_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)args->lds.total);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(pdmpc_search_kernel, dim3(count), dim3(PDMPC_WAVE), args->lds.total, (hipStream_t)stream, *args);
+    hipLaunchKernelGGL(pdmpc_search_kernel, dim3(count), dim3(PDMPC_THREADS), args->lds.total, (hipStream_t)stream, *args);
     return (int)hipGetLastError();
 }
