@@ -130,6 +130,7 @@ struct pdmpc_handle {
     DevBuf<NodeRec> anodes;
     DevBuf<double> ahk;
     DevBuf<uint32_t> ahid;
+    DevBuf<uint8_t> avs;
     DevBuf<pdmpc_vehicle_out> d_out;
     DevBuf<uint32_t> d_flag;
     DevBuf<int32_t> d_tree_size;
@@ -166,7 +167,8 @@ int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in) {
     const uint32_t shape_bytes = PDMPC_WAVES_PER_VEHICLE * 2 * PDMPC_VMAX * 16;
     const uint32_t path_bytes = align16((PDMPC_HP_MAX + 2) * 4 + 2 * (PDMPC_HP_MAX + 1) * 4 + 16);
     const uint32_t soup_bytes = (uint32_t)std::max(hb.soup_cap, 1) * 16;
-    const uint32_t fixed_rest = ref_bytes + shape_bytes + path_bytes + soup_bytes;
+    const uint32_t expand_bytes = (2 * PDMPC_HP_MAX * PDMPC_HP_MAX) * 8 + 16 * 16;
+    const uint32_t fixed_rest = ref_bytes + shape_bytes + path_bytes + soup_bytes + expand_bytes;
     const uint32_t cand_bytes = align16((uint32_t)std::max(hb.soup_cap, 1) * 4 * PDMPC_WAVES_PER_VEHICLE);
     const uint32_t min_bytes = 64 * 12 + 64 * (uint32_t)sizeof(NodeRec);
     int areas = 1;
@@ -183,6 +185,8 @@ int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in) {
     off = align16(off + soup_bytes);
     L.cand = off;
     off += cand_bytes;
+    L.expand = off;
+    off += expand_bytes;
     if ((size_t)off + min_bytes + 256 > budget) {
         char buf[256];
         snprintf(buf, sizeof buf, "obstacle soup (%d columns) + MPA tables need %u B of LDS, budget %zu B", hb.soup_cap, off, budget);
@@ -372,6 +376,7 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.arena.nodes = h->anodes.p;
     a.arena.heap_key = h->ahk.p;
     a.arena.heap_id = h->ahid.p;
+    a.arena.vstate = h->avs.p;
     a.max_nodes = h->max_nodes;
     a.pop_trace = h->d_trace.p;
     a.trace_cap = h->cfg.trace_pops;
@@ -436,7 +441,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
     }
     const size_t tot = (size_t)h->max_vehicles * h->max_nodes;
     int bad = 0;
-    bad |= h->anodes.ensure(tot) | h->ahk.ensure(tot) | h->ahid.ensure(tot);
+    bad |= h->anodes.ensure(tot) | h->ahk.ensure(tot) | h->ahid.ensure(tot) | h->avs.ensure(tot);
     bad |= h->d_out.ensure((size_t)h->max_vehicles) | h->d_flag.ensure((size_t)h->max_vehicles) | h->d_tree_size.ensure((size_t)h->max_vehicles);
     bad |= h->d_trace.ensure((size_t)h->max_vehicles * (size_t)std::max(config->trace_pops, 1));
     if (bad) {
@@ -466,6 +471,7 @@ int pdmpc_destroy(pdmpc_handle* h) {
     h->anodes.release();
     h->ahk.release();
     h->ahid.release();
+    h->avs.release();
     h->d_out.release();
     h->d_flag.release();
     h->d_tree_size.release();

@@ -69,6 +69,7 @@ struct LdsLayout {
     uint32_t soup;                         // double2[soup_cap]
     uint32_t cand;                         // uint32[waves][soup_cap]: compacted candidate segments of one edge check
     uint32_t vstate;                       // uint8[NV]: validity cache (0 unknown, 1 valid, 2 invalid)
+    uint32_t expand;                       // expansion scratch: dcum[16][16], term[16][16] doubles, child xy[16] double2
     uint32_t heap_key, heap_id;            // double[HL], uint32[HL]
     uint32_t nodes;                        // NodeRec[NL]
     uint32_t total;
@@ -78,6 +79,7 @@ struct NodeArena {  // HBM arrays, per-vehicle stride = max_nodes entries
     NodeRec* nodes;
     double* heap_key;
     uint32_t* heap_id;
+    uint8_t* vstate;  // validity cache for nodes beyond the LDS-resident NV
 };
 
 struct KernelArgs {

@@ -76,40 +76,119 @@ __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 __device__ __forceinline__ bool is_nan(double v) { return v != v; }
 
 // ---------------------------------------------------------------------------------------------------
+// LDS pointers carry their address space in the type so every access is a ds_* instruction (a generic pointer that
+// may be LDS or HBM compiles to slower flat_* accesses).
+#define LDS_AS __attribute__((address_space(3)))
+typedef LDS_AS d2 lds_d2;
+typedef LDS_AS double lds_f64;
+typedef LDS_AS uint32_t lds_u32;
+
+// per-lane constants of the sift-down rounds (computed once per kernel)
+struct PopLane {
+    int d;                       // level below the hole: 1..5 (6 for the unused lanes 62, 63)
+    uint32_t q;                  // position inside the level
+    unsigned long long ancmask;  // bits (node index n = lane + 2, heap order, hole = node 1) of the node and its ancestors
+};
+__device__ __forceinline__ PopLane make_pop_lane(int lane) {
+    PopLane L;
+    L.d = 31 - __builtin_clz((uint32_t)lane + 2u);
+    L.q = (uint32_t)lane + 2u - (1u << L.d);
+    unsigned long long m = 0;
+    for (uint32_t a = (uint32_t)lane + 2u; a >= 2u; a >>= 1) m |= 1ull << a;
+    L.ancmask = (lane < 62) ? m : ~0ull;  // lanes 62, 63 never match
+    return L;
+}
+
 // Per-vehicle search state.  l* point into LDS, g* into this vehicle's HBM slices.
 struct Search {
-    NodeRec* ln;
+    lds_d2* ln;  // NodeRec[NL] as 4 x double2 each
     NodeRec* gn;
     uint32_t NL, max_nodes;
-    double* lkey;
-    uint32_t* lid;
+    lds_f64* lkey;
+    lds_u32* lid;
     double* gkey;
     uint32_t* gid;
     uint32_t HL;
     uint32_t heap_len;
     int lane;
+    PopLane pl;
     PROF_MEMBERS
 };
 
+union NodeBits {
+    NodeRec r;
+    d2 q[4];
+    __device__ NodeBits() {}
+};
+
 __device__ __forceinline__ NodeRec node_load(const Search& S, uint32_t i0) {
-    if (i0 < S.NL) return S.ln[i0];
-    return S.gn[i0];
+    NodeBits u;
+    if (i0 < S.NL) {
+        lds_d2* p = S.ln + 4 * (size_t)i0;
+        u.q[0] = p[0];
+        u.q[1] = p[1];
+        u.q[2] = p[2];
+        u.q[3] = p[3];
+    } else {
+        const d2* p = (const d2*)(S.gn + i0);
+        u.q[0] = p[0];
+        u.q[1] = p[1];
+        u.q[2] = p[2];
+        u.q[3] = p[3];
+    }
+    return u.r;
+}
+__device__ __forceinline__ void node_store(const Search& S, uint32_t i0, const NodeRec& r) {
+    NodeBits u;
+    u.r = r;
+    d2* g = (d2*)(S.gn + i0);
+    g[0] = u.q[0];
+    g[1] = u.q[1];
+    g[2] = u.q[2];
+    g[3] = u.q[3];
+    if (i0 < S.NL) {
+        lds_d2* p = S.ln + 4 * (size_t)i0;
+        p[0] = u.q[0];
+        p[1] = u.q[1];
+        p[2] = u.q[2];
+        p[3] = u.q[3];
+    }
+}
+__device__ __forceinline__ void node_store_cs(const Search& S, uint32_t i0, double cs, double sn) {
+    d2 v;
+    v.x = cs;
+    v.y = sn;
+    ((d2*)(S.gn + i0))[2] = v;
+    if (i0 < S.NL) S.ln[4 * (size_t)i0 + 2] = v;
 }
 __device__ __forceinline__ uint32_t node_parent(const Search& S, uint32_t i0) {
-    if (i0 < S.NL) return S.ln[i0].parent;
-    return S.gn[i0].parent;
+    d2 v;
+    if (i0 < S.NL)
+        v = S.ln[4 * (size_t)i0 + 3];
+    else
+        v = ((const d2*)(S.gn + i0))[3];
+    return (uint32_t)((uint64_t)__double_as_longlong(v.y) & 0xffffffffull);
 }
 
-// per-lane heap access (index may differ per lane).  LDSONLY: the caller knows every index is < HL.
+// per-lane heap access (index may differ per lane).  LDSONLY: the caller knows every index is < HL.  Otherwise the
+// LDS part and the HBM part are two separately predicated accesses (no generic pointers).
 template <bool LDSONLY>
 __device__ __forceinline__ void heap_load(const Search& S, uint32_t idx, bool valid, double& k, uint32_t& id) {
     k = 0.0;
     id = 0;
-    if (valid) {
-        if (LDSONLY || idx < S.HL) {
+    if (LDSONLY) {
+        if (valid) {
             k = S.lkey[idx];
             id = S.lid[idx];
-        } else {
+        }
+    } else {
+        const bool inl = valid && idx < S.HL;
+        const bool ing = valid && idx >= S.HL;
+        if (inl) {
+            k = S.lkey[idx];
+            id = S.lid[idx];
+        }
+        if (ing) {
             k = S.gkey[idx];
             id = S.gid[idx];
         }
@@ -179,41 +258,44 @@ __device__ __forceinline__ void heap_push(Search& S, uint32_t id, double key) {
 // siblings are lanes l ^ 1 and the children of lane l are lanes 2l + 2, 2l + 3).  Every lane decides whether it is
 // the child its parent would step to; a ballot + five scalar steps follow the chain from the hole; the lanes on
 // the chain store their entry one level up in one instruction.
+// one round of the sift-down: returns the new hole
+template <bool LDSONLY>
+__device__ __forceinline__ uint32_t heap_pop_round(Search& S, uint32_t hole, uint32_t half, const PopLane& L) {
+    const uint32_t idx = ((hole + 1u) << L.d) - 1u + L.q;
+    const uint32_t pidx = (idx - 1u) >> 1;
+    const bool step_ok = pidx < half;  // the parent has two children (adjust_heap loop condition)
+    double k;
+    uint32_t i;
+    heap_load<LDSONLY>(S, idx, step_ok, k, i);
+    const double ks = swap_pair_d(k);  // sibling's key
+    // right child (odd lane) is stepped to unless key[right] > key[left]; left child (even lane) iff key[right] > key[left]
+    const unsigned long long gt_self = __ballot(k > ks);   // on an odd lane: key[right] > key[left]
+    const unsigned long long gt_sib = __ballot(ks > k);    // on an even lane: key[right] > key[left]
+    const unsigned long long ODD = 0xAAAAAAAAAAAAAAAAull;
+    const unsigned long long pref = ((~gt_self) & ODD) | (gt_sib & ~ODD);
+    // bit n of Q: sub-tree node n (= lane + 2) is the child its parent steps to
+    const unsigned long long Q = (pref & __ballot(step_ok)) << 2;
+    const bool on = (Q & L.ancmask) == L.ancmask;  // the node and all its ancestors are stepped to: it is on the chain
+    const unsigned long long pathmask = __ballot(on);
+    if (on) heap_store<LDSONLY>(S, pidx, k, i);
+    const int last = 63 - (int)__builtin_clzll(pathmask);  // deepest chain lane (the chain is never empty: hole < half)
+    return lane_u(idx, last);
+}
+
 template <bool LDSONLY>
 __device__ __forceinline__ void heap_pop_impl(Search& S, uint32_t len) {
     const int lane = S.lane;
     double vkey;
     uint32_t vid;
     heap_load<LDSONLY>(S, len, true, vkey, vid);
-    vkey = uni_d(vkey);
-    vid = uni_u(vid);
     const uint32_t half = (len - 1) >> 1;
     uint32_t hole = 0;
-    const int d = 31 - __builtin_clz((uint32_t)lane + 2u);  // level below the hole: 1..5 (6 for lanes 62, 63)
-    const uint32_t q = (uint32_t)lane + 2u - (1u << d);
     while (hole < half) {
-        const uint32_t idx = ((hole + 1u) << d) - 1u + q;
-        const uint32_t pidx = (idx - 1u) >> 1;
-        const bool step_ok = (lane < 62) && (pidx < half);  // the parent has two children (adjust_heap loop condition)
-        double k;
-        uint32_t i;
-        heap_load<LDSONLY>(S, idx, step_ok, k, i);
-        const double ks = swap_pair_d(k);
-        // odd lane = right child: taken unless key[right] > key[left]; even lane = left child: taken iff key[right] > key[left]
-        const bool pref = (lane & 1) ? !(k > ks) : (ks > k);
-        const unsigned long long P = __ballot(pref && step_ok);
-        int a = -1;
-        unsigned long long pathmask = 0;
-#pragma unroll
-        for (int dd = 0; dd < 5; ++dd) {
-            const int c = 2 * a + 2;
-            const unsigned long long two = (P >> c) & 3ull;
-            if (two == 0) break;
-            a = c + ((two & 1ull) ? 0 : 1);
-            pathmask |= 1ull << a;
-        }
-        if ((pathmask >> lane) & 1ull) heap_store<LDSONLY>(S, pidx, k, i);
-        hole = lane_u(idx, a);
+        // the five levels below `hole` end at index 32 * (hole + 1) + 30
+        if (LDSONLY || ((hole + 1u) << 5) + 30u < S.HL)
+            hole = heap_pop_round<true>(S, hole, half, S.pl);
+        else
+            hole = heap_pop_round<false>(S, hole, half, S.pl);
     }
     if ((len & 1u) == 0 && hole == ((len - 2u) >> 1)) {  // lone left child at the bottom
         const uint32_t child = 2u * (hole + 1u);
@@ -224,6 +306,8 @@ __device__ __forceinline__ void heap_pop_impl(Search& S, uint32_t len) {
         hole = child - 1u;
     }
     heap_fence<LDSONLY>();
+    vkey = uni_d(vkey);
+    vid = uni_u(vid);
     heap_sift_up<LDSONLY>(S, hole, vkey, vid);
     heap_fence<LDSONLY>();
 }
@@ -527,6 +611,23 @@ __device__ bool edge_valid(const Search& S, const CheckCtx& C, uint32_t id, int 
 
 __device__ __forceinline__ uint32_t lds_load_u32(const volatile uint32_t* p) { return *p; }
 
+// validity cache: 0 unknown, 1 valid, 2 invalid; the first NV nodes in LDS, the rest in HBM (same CU -> same L1)
+struct VState {
+    volatile uint8_t* l;
+    uint8_t* g;
+    uint32_t NV;
+};
+__device__ __forceinline__ uint32_t vs_load(const VState& v, uint32_t i0) {
+    if (i0 < v.NV) return (uint32_t)v.l[i0];
+    return (uint32_t)__hip_atomic_load(v.g + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void vs_store(const VState& v, uint32_t i0, uint32_t val) {
+    if (i0 < v.NV)
+        v.l[i0] = (uint8_t)val;
+    else
+        __hip_atomic_store(v.g + i0, (uint8_t)val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 }  // namespace
 
 // LDS words shared between the waves of a workgroup (in the `path` region, after the offset tables)
@@ -543,6 +644,9 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
     const int n = A.n_trims;
     const int nw = A.n_words;
     const DevVehicle* __restrict__ V = A.veh + slot;
+#ifdef PDMPC_PROFILE
+    const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // ---- LDS carve
     uint64_t* l_mask = (uint64_t*)(smem + A.lds.mask);
@@ -556,21 +660,27 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
     int32_t* l_hoff = l_soff + PDMPC_HP_MAX + 1;
     volatile uint32_t* l_shared = (volatile uint32_t*)(l_hoff + PDMPC_HP_MAX + 1);
     d2* l_soup = (d2*)(smem + A.lds.soup);
-    volatile uint8_t* l_vstate = (volatile uint8_t*)(smem + A.lds.vstate);
-    const uint32_t NV = (uint32_t)A.NV;
+    VState VS;
+    VS.l = (volatile uint8_t*)(smem + A.lds.vstate);
+    VS.NV = (uint32_t)A.NV;
+    double* l_dcum = (double*)(smem + A.lds.expand);               // [HP_MAX][HP_MAX] cumulative dt*v_ref per (k_exp, t)
+    double* l_term = l_dcum + PDMPC_HP_MAX * PDMPC_HP_MAX;         // [16 children][HP_MAX] cost-to-go terms
+    d2* l_chxy = (d2*)(l_term + 16 * PDMPC_HP_MAX);                // [16] child positions
 
     Search S;
-    S.ln = (NodeRec*)(smem + A.lds.nodes);
-    S.lkey = (double*)(smem + A.lds.heap_key);
-    S.lid = (uint32_t*)(smem + A.lds.heap_id);
+    S.ln = (lds_d2*)(smem + A.lds.nodes);
+    S.lkey = (lds_f64*)(smem + A.lds.heap_key);
+    S.lid = (lds_u32*)(smem + A.lds.heap_id);
     S.NL = (uint32_t)A.NL;
     S.HL = (uint32_t)A.HL;
     S.max_nodes = A.max_nodes;
     S.lane = lane;
+    S.pl = make_pop_lane(lane);
     const size_t voff = (size_t)slot * A.max_nodes;
     S.gn = A.arena.nodes + voff;
     S.gkey = A.arena.heap_key + voff;
     S.gid = A.arena.heap_id + voff;
+    VS.g = A.arena.vstate + voff;
 
     CheckCtx C;
     C.l_area = (const d2*)(smem + A.lds.area);
@@ -593,13 +703,22 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
         stage16(l_mi, A.man_index, (n * n * 2 + 15) / 16, tid);
         stage16(l_pose, A.man_pose, A.n_man * 2, tid);
         if (A.areas_in_lds) stage16(smem + A.lds.area, A.man_area, A.n_man * 3 * PDMPC_VMAX, tid);
-        for (uint32_t i = (uint32_t)tid * 16u; i < NV; i += PDMPC_THREADS * 16u) *(d2*)(smem + A.lds.vstate + i) = d2{0.0, 0.0};
     }
     // ---- prologue 2: vehicle record, result record defaults
     if (tid < Hp) {
         l_rx[tid] = V->ref_x[tid];
         l_ry[tid] = V->ref_y[tid];
         l_dtv[tid] = A.dt * V->v_ref[tid];  // options.dt_seconds * iter.v_ref(k)   expand_node.m:70
+    }
+    if (tid >= PDMPC_WAVE && tid < PDMPC_WAVE + Hp) {
+        // d_traveled_max of expand_node.m:66-70 for every expansion step k_exp = tid - 63 (1-based): the running sum
+        // dt*v_ref(k_exp+1) + ... in the reference's order, so the bits match the in-loop accumulation
+        const int k_exp = tid - PDMPC_WAVE + 1;
+        double d = 0.0;
+        for (int it = 1; it <= Hp - k_exp; ++it) {
+            d = d + A.dt * V->v_ref[k_exp + it - 1];
+            l_dcum[(k_exp - 1) * PDMPC_HP_MAX + (it - 1)] = d;
+        }
     }
     if (tid == 0) {
         l_shared[SH_DONE] = 0;
@@ -694,10 +813,10 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
         r.h = 0.0;
         r.parent = 0;
         r.packed = (uint32_t)V->trim0;
-        S.gn[0] = r;
-        S.ln[0] = r;
+        node_store(S, 0, r);
         S.lkey[0] = 0.0;
         S.lid[0] = 1;
+        vs_store(VS, 0, 1);  // the root has no edge: valid
         l_shared[SH_HEAP_LEN] = 1;
     }
     S.heap_len = 1;
@@ -706,6 +825,9 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
     int status = PDMPC_OK;
     int n_popped = 0;
     uint32_t goal = 0;
+#ifdef PDMPC_PROFILE
+    const unsigned long long rt_search = __builtin_amdgcn_s_memrealtime();
+#endif
 
     if (wave != 0) {
         // ================= helper waves: pre-validate the nodes near the top of the open list ==================
@@ -717,9 +839,9 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
             const uint32_t hl = lds_load_u32(&l_shared[SH_HEAP_LEN]);
             const uint32_t K = hl < (uint32_t)PDMPC_WAVE ? hl : (uint32_t)PDMPC_WAVE;
             uint32_t id = 0;
-            if ((uint32_t)lane < K) id = *(volatile uint32_t*)&S.lid[lane];
+            if ((uint32_t)lane < K) id = *(volatile lds_u32*)&S.lid[lane];
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const bool unknown = id != 0 && (id - 1) < NV && l_vstate[id - 1] == 0;
+            const bool unknown = id != 0 && vs_load(VS, id - 1) == 0;
             unsigned long long b = __ballot(unknown);
             int skip = share;
             uint32_t target = 0;
@@ -734,7 +856,7 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
             }
             if (target) {
                 const bool ok = edge_valid(S, C, target, lane);
-                if (lane == 0) l_vstate[target - 1] = ok ? 1 : 2;
+                if (lane == 0) vs_store(VS, target - 1, ok ? 1 : 2);
             } else {
                 __builtin_amdgcn_s_sleep(2);
             }
@@ -749,7 +871,7 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
                 break;
             }
             PROF_STOP(7)
-            const uint32_t cur = uni_u(*(volatile uint32_t*)&S.lid[0]);  // 1-based node id (HL >= 1: the top is always in LDS)
+            const uint32_t cur = uni_u(*(volatile lds_u32*)&S.lid[0]);  // 1-based node id (HL >= 1: the top is always in LDS)
             heap_pop(S);
             if (lane == 0) l_shared[SH_HEAP_LEN] = S.heap_len;
             PROF_STOP(0)
@@ -758,12 +880,11 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
             const uint32_t c0 = cur - 1;
 
             // ---- eval_edge_exact (GraphSearch.m:111-196): from the validity cache if a helper got there first
-            uint32_t vs = 0;
-            if (c0 < NV) vs = uni_u((uint32_t)l_vstate[c0]);
+            const uint32_t vs = uni_u(vs_load(VS, c0));
             bool valid;
             if (vs == 0) {
                 valid = edge_valid(S, C, cur, lane);
-                if (c0 < NV && lane == 0) l_vstate[c0] = valid ? 1 : 2;
+                if (lane == 0) vs_store(VS, c0, valid ? 1 : 2);
                 PROF_COUNT(13, 1)
             } else {
                 valid = (vs == 1);
@@ -786,14 +907,7 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
             PROF_STOP(3)
             pdmpc_sincos(curYaw, &sn, &cs);  // expand_node.m:50-51
             PROF_STOP(4)
-            if (lane == 0) {
-                if (c0 < S.NL) {
-                    S.ln[c0].cs = cs;
-                    S.ln[c0].sn = sn;
-                }
-                S.gn[c0].cs = cs;
-                S.gn[c0].sn = sn;
-            }
+            if (lane == 0) node_store_cs(S, c0, cs, sn);
             const int k_exp = cK + 1;            // :13
             const int steps_to_go = Hp - k_exp;  // :37
             const uint64_t* mrow = l_mask + ((size_t)(k_exp - 1) * n + (cTrim - 1)) * nw;
@@ -814,11 +928,12 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
                 const bool active = (mask >> lane) & 1ull;
                 const int rank = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
                 double f = 0.0;
+                NodeRec ch;
+                uint32_t i0 = 0;
                 if (active) {
                     const int t2 = w * 64 + lane;  // 0-based successor trim
                     const int m = (int)l_mi[(cTrim - 1) * n + t2];
                     const DevManPose mp = l_pose[m];
-                    NodeRec ch;
                     ch.x = cs * mp.dx - sn * mp.dy + curX;  // :53
                     ch.y = sn * mp.dx + cs * mp.dy + curY;  // :54
                     ch.yaw = curYaw + mp.dyaw;              // :55
@@ -828,25 +943,42 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
                         const double nrm = sqrt(ddx * ddx + ddy * ddy);
                         expG = expG + nrm * nrm;  // :61
                     }
-                    double expH = 0.0, dmax = 0.0;
-                    for (int it = 1; it <= steps_to_go; ++it) {  // :68-73
-                        dmax = dmax + l_dtv[k_exp + it - 1];
-                        const double ddx = ch.x - l_rx[k_exp + it - 1], ddy = ch.y - l_ry[k_exp + it - 1];
-                        const double nrm = sqrt(ddx * ddx + ddy * ddy);
-                        const double df = nrm - dmax;
-                        const double m0 = (df > 0) ? df : 0.0;
-                        expH = expH + m0 * m0;
-                    }
-                    f = expG * 1 + expH * 1;  // GraphSearch.m:100-102
                     ch.g = expG;
-                    ch.h = expH;
                     ch.cs = 0.0;
                     ch.sn = 0.0;
                     ch.parent = cur;
                     ch.packed = (uint32_t)(t2 + 1) | ((uint32_t)k_exp << 10) | ((uint32_t)m << 15) | ((uint32_t)mp.n_cols << 27);
-                    const uint32_t i0 = nnodes + (uint32_t)rank;  // 0-based index of the child (Tree.add_nodes, Tree.m:61)
-                    S.gn[i0] = ch;
-                    if (i0 < S.NL) S.ln[i0] = ch;
+                    i0 = nnodes + (uint32_t)rank;  // 0-based index of the child (Tree.add_nodes, Tree.m:61)
+                    d2 xy;
+                    xy.x = ch.x;
+                    xy.y = ch.y;
+                    l_chxy[rank] = xy;
+                }
+                wave_sync();
+                // cost-to-go terms (expand_node.m:68-73), one lane per (child, remaining step): the sqrt chains of a
+                // child run side by side instead of one after the other; the SUM below keeps the reference's order
+                const int T = steps_to_go;
+                for (int base = 0; base < cnt * T; base += PDMPC_WAVE) {
+                    const int idx = base + lane;
+                    if (idx < cnt * T) {
+                        const int r = idx / T;
+                        const int it = idx - r * T + 1;
+                        const d2 xy = l_chxy[r];
+                        const double ddx = xy.x - l_rx[k_exp + it - 1], ddy = xy.y - l_ry[k_exp + it - 1];
+                        const double nrm = sqrt(ddx * ddx + ddy * ddy);
+                        const double df = nrm - l_dcum[(k_exp - 1) * PDMPC_HP_MAX + (it - 1)];
+                        const double m0 = (df > 0) ? df : 0.0;
+                        l_term[r * PDMPC_HP_MAX + (it - 1)] = m0 * m0;
+                    }
+                }
+                wave_sync();
+                if (active) {
+                    double expH = 0.0;
+                    for (int it = 0; it < T; ++it) expH = expH + l_term[rank * PDMPC_HP_MAX + it];
+                    ch.h = expH;
+                    f = ch.g * 1 + expH * 1;  // GraphSearch.m:100-102
+                    node_store(S, i0, ch);
+                    vs_store(VS, i0, 0);  // validity unknown
                 }
                 // records (and the parent's cos/sin) must be visible to the helper waves before any id reaches the heap
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -869,7 +1001,14 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
         }
 #ifdef PDMPC_PROFILE
         if (lane == 0)
+        {
             for (int i = 0; i < PROF_N; ++i) ((double*)O->shapes[PDMPC_HP_MAX - 1])[i] = (double)S.prof_acc[i];  // unused tail of the record
+            const unsigned long long rt_end = __builtin_amdgcn_s_memrealtime();
+            O->path_nodes[PDMPC_HP_MAX][0] = (double)(rt_search - rt_start);  // 100 MHz ticks: prologue + predecessor wait
+            O->path_nodes[PDMPC_HP_MAX][1] = (double)(rt_end - rt_search);    // search
+            O->path_nodes[PDMPC_HP_MAX][2] = (double)rt_start;
+            O->path_nodes[PDMPC_HP_MAX][3] = (double)rt_end;
+        }
 #endif
         if (lane == 0) l_shared[SH_DONE] = 1;
     }
