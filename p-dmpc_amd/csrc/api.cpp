@@ -499,6 +499,8 @@ int pdmpc_upload_mpa(pdmpc_handle* h, const pdmpc_mpa* mpa) {
                     if (mi < 0 || mi >= mpa->n_maneuvers) return fail(PDMPC_ERR_INVALID, "transition allowed but maneuver missing");
                     mask[((size_t)k * n + i) * nw + j / 64] |= 1ull << (j % 64);
                 }
+    for (size_t q = 0; q < mask.size(); ++q)
+        if (__builtin_popcountll(mask[q]) > 16) return fail(PDMPC_ERR_CAPACITY, "a trim has more than 16 successors within one 64-trim word");
     std::vector<int16_t> mi((size_t)n * n + 8, -1);
     for (int i = 0; i < n * n; ++i) mi[i] = (int16_t)mpa->maneuver_index[i];
     const int T = mpa->n_maneuvers;

@@ -633,6 +633,7 @@ __device__ __forceinline__ void vs_store(const VState& v, uint32_t i0, uint32_t 
 // LDS words shared between the waves of a workgroup (in the `path` region, after the offset tables)
 #define SH_DONE 0      // sequencing wave finished
 #define SH_HEAP_LEN 1  // current open-list length (for the helpers' scan)
+#define SH_VERSION 2   // bumped by the sequencing wave whenever the open list changed (idle helpers sleep on it)
 
 extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(const KernelArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -723,6 +724,7 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
     if (tid == 0) {
         l_shared[SH_DONE] = 0;
         l_shared[SH_HEAP_LEN] = 0;
+        l_shared[SH_VERSION] = 0;
     }
     {
         // zero the record; y_predicted starts as NaN (ControlResultsInfo.m:40)
@@ -836,6 +838,7 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
         // cannot change the search.  Results land in the shared validity cache (1 = valid, 2 = invalid).
         const int share = wave - 1;
         while (lds_load_u32(&l_shared[SH_DONE]) == 0) {
+            const uint32_t ver = lds_load_u32(&l_shared[SH_VERSION]);
             const uint32_t hl = lds_load_u32(&l_shared[SH_HEAP_LEN]);
             const uint32_t K = hl < (uint32_t)PDMPC_WAVE ? hl : (uint32_t)PDMPC_WAVE;
             uint32_t id = 0;
@@ -858,7 +861,9 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
                 const bool ok = edge_valid(S, C, target, lane);
                 if (lane == 0) vs_store(VS, target - 1, ok ? 1 : 2);
             } else {
-                __builtin_amdgcn_s_sleep(2);
+                // nothing to validate in this view of the open list: sleep until the sequencing wave changes it (one LDS
+                // word per poll, so idle helpers do not compete with the sequencer for LDS bandwidth)
+                while (lds_load_u32(&l_shared[SH_VERSION]) == ver && lds_load_u32(&l_shared[SH_DONE]) == 0) __builtin_amdgcn_s_sleep(4);
             }
         }
     } else {
@@ -873,7 +878,10 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
             PROF_STOP(7)
             const uint32_t cur = uni_u(*(volatile lds_u32*)&S.lid[0]);  // 1-based node id (HL >= 1: the top is always in LDS)
             heap_pop(S);
-            if (lane == 0) l_shared[SH_HEAP_LEN] = S.heap_len;
+            if (lane == 0) {
+                l_shared[SH_HEAP_LEN] = S.heap_len;
+                l_shared[SH_VERSION] = (uint32_t)n_popped * 2u + 1u;
+            }
             PROF_STOP(0)
             if (A.trace_cap > 0 && n_popped < A.trace_cap && lane == 0) A.pop_trace[(size_t)slot * A.trace_cap + n_popped] = (int32_t)cur;
             ++n_popped;
@@ -958,11 +966,13 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
                 // cost-to-go terms (expand_node.m:68-73), one lane per (child, remaining step): the sqrt chains of a
                 // child run side by side instead of one after the other; the SUM below keeps the reference's order
                 const int T = steps_to_go;
-                for (int base = 0; base < cnt * T; base += PDMPC_WAVE) {
+                // lane layout: child r = idx & 15, step it = (idx >> 4) + 1 (no integer division; a word has <= 16 successors,
+                // enforced by pdmpc_upload_mpa; the reference MPAs have at most 12)
+                for (int base = 0; base < 16 * T; base += PDMPC_WAVE) {
                     const int idx = base + lane;
-                    if (idx < cnt * T) {
-                        const int r = idx / T;
-                        const int it = idx - r * T + 1;
+                    const int r = idx & 15;
+                    const int it = (idx >> 4) + 1;
+                    if (r < cnt && it <= T) {
                         const d2 xy = l_chxy[r];
                         const double ddx = xy.x - l_rx[k_exp + it - 1], ddy = xy.y - l_ry[k_exp + it - 1];
                         const double nrm = sqrt(ddx * ddx + ddy * ddy);
@@ -980,8 +990,9 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
                     node_store(S, i0, ch);
                     vs_store(VS, i0, 0);  // validity unknown
                 }
-                // records (and the parent's cos/sin) must be visible to the helper waves before any id reaches the heap
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                // records (and the parent's cos/sin) must be visible to the helper waves before any id reaches the heap: LDS
+                // copies are ordered by the in-order DS queue; records that only live in HBM need the stores drained
+                if (nnodes + (uint32_t)cnt > S.NL) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 wave_sync();
                 PROF_STOP(5)
                 // pq.push(new_open_nodes, new_open_values): one at a time in ascending trim order (mex.cpp:67-72)
@@ -995,7 +1006,10 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
                     ++r;
                 }
                 nnodes += (uint32_t)cnt;
-                if (lane == 0) l_shared[SH_HEAP_LEN] = S.heap_len;
+                if (lane == 0) {
+                    l_shared[SH_HEAP_LEN] = S.heap_len;
+                    l_shared[SH_VERSION] = (uint32_t)n_popped * 2u;
+                }
                 PROF_STOP(6)
             }
         }
