@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -144,6 +145,7 @@ struct pdmpc_handle {
     size_t events_used = 0;
     LdsLayout lds{};
     int HL = 0, NL = 0, NV = 0, areas_in_lds = 0;
+    int speculate = 1;
     pdmpc_stats stats{};
 };
 
@@ -165,7 +167,7 @@ int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in) {
     // fixed part after the tables
     const uint32_t ref_bytes = 3 * PDMPC_HP_MAX * 8;
     const uint32_t shape_bytes = PDMPC_WAVES_PER_VEHICLE * 2 * PDMPC_VMAX * 16;
-    const uint32_t path_bytes = align16((PDMPC_HP_MAX + 2) * 4 + 2 * (PDMPC_HP_MAX + 1) * 4 + 16);
+    const uint32_t path_bytes = align16((PDMPC_HP_MAX + 2) * 4 + 2 * (PDMPC_HP_MAX + 1) * 4 + 16 * 4 + PDMPC_HP_MAX * 4);
     const uint32_t soup_bytes = (uint32_t)std::max(hb.soup_cap, 1) * 16;
     const uint32_t expand_bytes = (2 * PDMPC_HP_MAX * PDMPC_HP_MAX) * 8 + 16 * 16;
     const uint32_t fixed_rest = ref_bytes + shape_bytes + path_bytes + soup_bytes + expand_bytes;
@@ -387,6 +389,7 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.NV = h->NV;
     a.soup_cap = B.soup_cap;
     a.spin_limit = 1u << 22;
+    a.speculate = h->speculate;
     if (h->events_used == h->events.size()) {
         hipEvent_t e0, e1;
         HIPCHK(hipEventCreate(&e0));
@@ -430,6 +433,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
     pdmpc_handle* h = new pdmpc_handle();
     h->cfg = *config;
     h->banks.resize(1);
+    if (const char* e = getenv("PDMPC_SPECULATE")) h->speculate = atoi(e) != 0;  // A/B switch for benchmarking; results are identical
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     h->max_nodes = config->max_nodes > 0 ? (uint32_t)config->max_nodes : 32768u;  // default arena: 256 x 32768 nodes, about 0.6 GB
     h->max_nodes = (h->max_nodes + 1u) & ~1u;

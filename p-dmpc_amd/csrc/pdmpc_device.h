@@ -53,12 +53,13 @@ struct NodeRec {
                           // edge checks read them (GraphSearch.m:155-156)
     double h;             // Tree.h
     uint32_t parent;      // Tree.parent (1-based id, 0 for the root)
-    uint32_t packed;      // trim (10 bit, 1-based) | k << 10 (5 bit) | maneuver index << 15 (12 bit) | area columns << 27
+    uint32_t packed;      // trim (10 bit, 1-based) | k << 10 (5 bit) | maneuver index << 15 (12 bit) | area columns << 27 (4 bit) | popped << 31
 };
 #define NODE_TRIM(p) ((int)((p) & 1023u))
 #define NODE_K(p) ((int)(((p) >> 10) & 31u))
 #define NODE_MAN(p) ((int)(((p) >> 15) & 4095u))
-#define NODE_COLS(p) ((int)((p) >> 27))
+#define NODE_COLS(p) ((int)(((p) >> 27) & 15u))
+#define NODE_POPPED_BIT 0x80000000u /* set by the sequencing wave when the node was popped with a valid edge */
 
 // byte offsets of the regions of the dynamic LDS allocation (all multiples of 16)
 struct LdsLayout {
@@ -109,6 +110,7 @@ struct KernelArgs {
     // LDS
     LdsLayout lds;
     int32_t HL, NL, NV, soup_cap;
+    int32_t speculate;  // 1: start searching before all predecessors have finished (results are identical, see arrival_sync)
     uint32_t spin_limit;
 };
 

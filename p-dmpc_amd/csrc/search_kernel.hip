@@ -161,6 +161,12 @@ __device__ __forceinline__ void node_store_cs(const Search& S, uint32_t i0, doub
     ((d2*)(S.gn + i0))[2] = v;
     if (i0 < S.NL) S.ln[4 * (size_t)i0 + 2] = v;
 }
+// flag the node as popped-with-a-valid-edge (only the sequencing wave writes node records after creation)
+__device__ __forceinline__ void node_mark_popped(const Search& S, uint32_t i0, uint32_t packed) {
+    const uint32_t v = packed | NODE_POPPED_BIT;
+    ((uint32_t*)(S.gn + i0))[15] = v;
+    if (i0 < S.NL) ((lds_u32*)(S.ln + 4 * (size_t)i0))[15] = v;
+}
 __device__ __forceinline__ uint32_t node_parent(const Search& S, uint32_t i0) {
     d2 v;
     if (i0 < S.NL)
@@ -611,6 +617,11 @@ __device__ bool edge_valid(const Search& S, const CheckCtx& C, uint32_t id, int 
 
 __device__ __forceinline__ uint32_t lds_load_u32(const volatile uint32_t* p) { return *p; }
 
+#define VS_UNKNOWN 0u
+#define VS_VALID 1u
+#define VS_INVALID 2u
+
+
 // validity cache: 0 unknown, 1 valid, 2 invalid; the first NV nodes in LDS, the rest in HBM (same CU -> same L1)
 struct VState {
     volatile uint8_t* l;
@@ -631,9 +642,155 @@ __device__ __forceinline__ void vs_store(const VState& v, uint32_t i0, uint32_t 
 }  // namespace
 
 // LDS words shared between the waves of a workgroup (in the `path` region, after the offset tables)
-#define SH_DONE 0      // sequencing wave finished
+#define SH_STATE 0     // 0 searching, 1 predecessor areas arrived (all waves meet in arrival_sync), 2 finished
 #define SH_HEAP_LEN 1  // current open-list length (for the helpers' scan)
 #define SH_VERSION 2   // bumped by the sequencing wave whenever the open list changed (idle helpers sleep on it)
+#define SH_NNODES 3    // tree size, published by the sequencing wave before an arrival is handled
+#define SH_RESTART 4   // set during verification: a node that was already expanded collides with the new areas
+#define SH_PEND_LO 5   // predecessors whose areas are not in the soup yet (bit p = p-th predecessor)
+#define SH_PEND_HI 6
+#define SH_ARR_LO 7    // predecessors that just finished (to be incorporated by arrival_sync)
+#define SH_ARR_HI 8
+#define SH_WORDS 16
+#define ST_RUN 0u
+#define ST_ARRIVED 1u
+#define ST_DONE 2u
+
+namespace {
+
+__device__ __forceinline__ unsigned long long sh_load64(volatile uint32_t* sh, int lo) {
+    return (unsigned long long)sh[lo] | ((unsigned long long)sh[lo + 1] << 32);
+}
+
+struct SpecCtx {
+    volatile uint32_t* sh;
+    d2* l_soup;
+    const int32_t* l_soff;
+    const int32_t* l_lit;  // literal soup length per step
+    const pdmpc_vehicle_out* out;
+    const int32_t* pred;   // this vehicle's predecessor slots
+    int n_pred, Hp;
+};
+
+// copy the solved areas of the predecessors in `arr` into their soup slots (PrioritizedController.m:476-491)
+__device__ void incorporate_areas(const SpecCtx& P, unsigned long long arr, int tid) {
+    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+    while (arr) {
+        const int p = (int)__builtin_ctzll(arr);
+        arr &= arr - 1;
+        const pdmpc_vehicle_out* PO = P.out + P.pred[p];
+        for (int idx = tid; idx < P.Hp * PDMPC_VMAX; idx += PDMPC_THREADS) {
+            const int k = idx / PDMPC_VMAX;
+            const int v = idx - k * PDMPC_VMAX;
+            const int cols = PO->shape_cols[k];
+            d2 pt;
+            pt.x = qnan;
+            pt.y = qnan;
+            if (v < cols) {
+                pt.x = PO->shapes[k][0][v];
+                pt.y = PO->shapes[k][1][v];
+            }
+            P.l_soup[P.l_soff[k] + P.l_lit[k] + p * PDMPC_VMAX + v] = pt;
+        }
+    }
+}
+
+// Does the edge into node i0 (0-based, per lane) cross the areas of the predecessors in `arr`?  Same arithmetic as
+// edge_valid / interx_check restricted to those polygons (InterX.m:63-76), one node per lane.
+__device__ bool node_hits_areas(const Search& S, const CheckCtx& C, const SpecCtx& P, uint32_t i0, unsigned long long arr, bool& popped) {
+    const NodeRec cn = node_load(S, i0);
+    popped = (cn.packed & NODE_POPPED_BIT) != 0;
+    if (!cn.parent) return false;
+    const NodeRec pn = node_load(S, cn.parent - 1);
+    const int m = NODE_MAN(cn.packed), ncols = NODE_COLS(cn.packed), k = NODE_K(cn.packed);
+    const double c = pn.cs, s = pn.sn, pX = pn.x, pY = pn.y;
+    const d2* area = (C.areas_in_lds ? C.l_area : C.g_area) + (size_t)m * 3 * PDMPC_VMAX;
+    bool hit = false;
+    d2 a0 = area[0];
+    d2 p0;
+    p0.x = c * a0.x - s * a0.y + pX;
+    p0.y = s * a0.x + c * a0.y + pY;
+    for (int i = 0; i + 1 < ncols; ++i) {
+        const d2 a1 = area[i + 1];
+        d2 p1;
+        p1.x = c * a1.x - s * a1.y + pX;
+        p1.y = s * a1.x + c * a1.y + pY;
+        const double dx1 = p1.x - p0.x, dy1 = p1.y - p0.y;
+        const double S1 = dx1 * p0.y - dy1 * p0.x;
+        unsigned long long rem = arr;
+        while (rem) {
+            const int p = (int)__builtin_ctzll(rem);
+            rem &= rem - 1;
+            const d2* poly = P.l_soup + P.l_soff[k - 1] + P.l_lit[k - 1] + p * PDMPC_VMAX;
+            d2 q0 = poly[0];
+            for (int j = 0; j + 1 < PDMPC_VMAX; ++j) {
+                const d2 q1 = poly[j + 1];
+                const double dx2 = q1.x - q0.x, dy2 = q1.y - q0.y;
+                const double S2 = dx2 * q0.y - dy2 * q0.x;
+                const double A0 = dx1 * q0.y - dy1 * q0.x;
+                const double A1 = dx1 * q1.y - dy1 * q1.x;
+                const bool c1 = (A0 - S1) * (A1 - S1) < 0;
+                const double B0 = p0.y * dx2 - p0.x * dy2;
+                const double B1 = p1.y * dx2 - p1.x * dy2;
+                const bool c2 = (B0 - S2) * (B1 - S2) < 0;
+                hit = hit || (c1 && c2);
+                q0 = q1;
+            }
+        }
+        p0 = p1;
+    }
+    return hit;
+}
+
+// All four waves meet here when predecessors finished while this vehicle was already searching (speculation).
+// The new areas enter the soup; every node whose cached edge check said "valid" is re-checked against the new areas
+// only: not yet expanded -> it simply becomes invalid; already expanded -> the search so far depended on a wrong
+// answer and restarts (returns true).  If no expanded node is hit, the search is exactly the one the reference would
+// have run with the areas present from the start: the pop sequence only depends on the validity of popped nodes.
+__device__ bool arrival_sync(const Search& S, const CheckCtx& C, const SpecCtx& P, const VState& VS, int tid) {
+    __syncthreads();  // #1: nobody reads the soup or the validity cache any more
+    const unsigned long long arr = sh_load64(P.sh, SH_ARR_LO);
+    const uint32_t nn = P.sh[SH_NNODES];
+    incorporate_areas(P, arr, tid);
+    __syncthreads();  // #2
+    for (uint32_t i0 = (uint32_t)tid; i0 < nn; i0 += PDMPC_THREADS) {
+        if (vs_load(VS, i0) == VS_VALID) {
+            bool popped;
+            if (node_hits_areas(S, C, P, i0, arr, popped)) {
+                if (popped)
+                    P.sh[SH_RESTART] = 1;
+                else
+                    vs_store(VS, i0, VS_INVALID);
+            }
+        }
+    }
+    __syncthreads();  // #3
+    const bool restart = P.sh[SH_RESTART] != 0;
+    __syncthreads();  // #4: everyone has read the verdict
+    if (tid == 0) {
+        if (restart) {
+            // back to the root before any helper looks at the open list again: node ids are about to be reused
+            S.lkey[0] = 0.0;
+            S.lid[0] = 1;
+            P.sh[SH_HEAP_LEN] = 1;
+            P.sh[SH_VERSION] = P.sh[SH_VERSION] + 1;
+            ((uint32_t*)S.gn)[15] &= ~NODE_POPPED_BIT;
+            if (S.NL > 0) ((lds_u32*)S.ln)[15] = ((lds_u32*)S.ln)[15] & ~NODE_POPPED_BIT;
+        }
+        const unsigned long long pend = sh_load64(P.sh, SH_PEND_LO) & ~arr;
+        P.sh[SH_PEND_LO] = (uint32_t)pend;
+        P.sh[SH_PEND_HI] = (uint32_t)(pend >> 32);
+        P.sh[SH_ARR_LO] = 0;
+        P.sh[SH_ARR_HI] = 0;
+        P.sh[SH_RESTART] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        P.sh[SH_STATE] = ST_RUN;
+    }
+    __syncthreads();  // #5
+    return restart;
+}
+
+}  // namespace
 
 extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(const KernelArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -660,6 +817,7 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
     int32_t* l_soff = (int32_t*)(l_path + PDMPC_HP_MAX + 2);  // soup offsets [Hp+1], hdv offsets [Hp+1]
     int32_t* l_hoff = l_soff + PDMPC_HP_MAX + 1;
     volatile uint32_t* l_shared = (volatile uint32_t*)(l_hoff + PDMPC_HP_MAX + 1);
+    int32_t* l_lit = (int32_t*)(l_shared + SH_WORDS);  // literal soup length per step
     d2* l_soup = (d2*)(smem + A.lds.soup);
     VState VS;
     VS.l = (volatile uint8_t*)(smem + A.lds.vstate);
@@ -722,9 +880,7 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
         }
     }
     if (tid == 0) {
-        l_shared[SH_DONE] = 0;
-        l_shared[SH_HEAP_LEN] = 0;
-        l_shared[SH_VERSION] = 0;
+        for (int i = 0; i < SH_WORDS; ++i) l_shared[i] = 0;
     }
     {
         // zero the record; y_predicted starts as NaN (ControlResultsInfo.m:40)
@@ -744,7 +900,10 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
         int off = 0;
         for (int k = 0; k < Hp; ++k) {
             const int a = V->lit_off[k], b = V->lit_off[k + 1];
-            if (tid == 0) l_soff[k] = off;
+            if (tid == 0) {
+                l_soff[k] = off;
+                l_lit[k] = b - a;
+            }
             stage16(l_soup + off, (const d2*)A.points + a, b - a, tid);
             off += (b - a) + pred_cols;
         }
@@ -764,41 +923,82 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
     C.ll_base = uni_i((int)l_path[PDMPC_HP_MAX + 1]);
     C.ll_len = uni_i(V->ll_len);
 
-    // ---- prologue 4: wait for sequential predecessors and append their solved areas (PrioritizedController.m:476-491)
+    // ---- prologue 4: predecessors (PrioritizedController.m:476-491).  Their soup slots start as NaN (no obstacle).
+    // Predecessors that have already finished are incorporated now; the others are "pending": the search starts
+    // without them and arrival_sync() folds them in when they finish (speculation, see arrival_sync).
+    SpecCtx P;
+    P.sh = l_shared;
+    P.l_soup = l_soup;
+    P.l_soff = l_soff;
+    P.l_lit = l_lit;
+    P.out = A.out;
+    P.pred = A.pred + V->pred_off;
+    P.n_pred = n_pred;
+    P.Hp = Hp;
     bool dep_timeout = false;
+    const bool speculate = A.speculate && n_pred <= 64;
     if (n_pred > 0) {
-        for (int p = 0; p < n_pred; ++p) {
-            const int ps = A.pred[V->pred_off + p];
-            uint32_t spins = 0;
-            while (__hip_atomic_load(A.done_flag + ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != A.epoch) {
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > A.spin_limit) {
-                    dep_timeout = true;
-                    break;
+        const d2 nanpt = d2{__longlong_as_double(0x7ff8000000000000LL), __longlong_as_double(0x7ff8000000000000LL)};
+        for (int idx = tid; idx < Hp * pred_cols; idx += PDMPC_THREADS) {
+            const int k = idx / pred_cols;
+            l_soup[l_soff[k] + l_lit[k] + (idx - k * pred_cols)] = nanpt;
+        }
+        if (!speculate) {
+            // blocking wait (more than 64 predecessors, or speculation switched off)
+            for (int p = 0; p < n_pred; ++p) {
+                uint32_t spins = 0;
+                while (__hip_atomic_load(A.done_flag + P.pred[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != A.epoch) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > A.spin_limit) {
+                        dep_timeout = true;
+                        break;
+                    }
                 }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const double qnan = __longlong_as_double(0x7ff8000000000000LL);
-        for (int idx = tid; idx < Hp * pred_cols; idx += PDMPC_THREADS) {
-            const int k = idx / pred_cols;
-            const int r = idx - k * pred_cols;
-            const int p = r / PDMPC_VMAX;
-            const int v = r - p * PDMPC_VMAX;
-            const int ps = A.pred[V->pred_off + p];
-            const pdmpc_vehicle_out* PO = A.out + ps;
-            const int cols = PO->shape_cols[k];
-            d2 pt;
-            pt.x = qnan;
-            pt.y = qnan;
-            if (v < cols) {
-                pt.x = PO->shapes[k][0][v];
-                pt.y = PO->shapes[k][1][v];
+        unsigned long long ready = 0;
+        if (wave == 0) {
+            bool d = false;
+            if (lane < n_pred) d = __hip_atomic_load(A.done_flag + P.pred[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == A.epoch;
+            ready = __ballot(d);
+            if (!speculate) ready = (n_pred >= 64) ? ~0ull : ((1ull << n_pred) - 1ull);
+            if (lane == 0) {
+                const unsigned long long all = (n_pred >= 64) ? ~0ull : ((1ull << n_pred) - 1ull);
+                const unsigned long long pend = speculate ? (all & ~ready) : 0ull;
+                l_shared[SH_PEND_LO] = (uint32_t)pend;
+                l_shared[SH_PEND_HI] = (uint32_t)(pend >> 32);
+                l_shared[SH_ARR_LO] = (uint32_t)ready;
+                l_shared[SH_ARR_HI] = (uint32_t)(ready >> 32);
             }
-            const int lit = V->lit_off[k + 1] - V->lit_off[k];
-            l_soup[l_soff[k] + lit + r] = pt;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (!speculate) {  // n_pred may exceed 64: incorporate everything directly
+            const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+            for (int idx = tid; idx < Hp * pred_cols; idx += PDMPC_THREADS) {
+                const int k = idx / pred_cols;
+                const int r = idx - k * pred_cols;
+                const int p = r / PDMPC_VMAX;
+                const int v = r - p * PDMPC_VMAX;
+                const pdmpc_vehicle_out* PO = A.out + P.pred[p];
+                const int cols = PO->shape_cols[k];
+                d2 pt;
+                pt.x = qnan;
+                pt.y = qnan;
+                if (v < cols) {
+                    pt.x = PO->shapes[k][0][v];
+                    pt.y = PO->shapes[k][1][v];
+                }
+                l_soup[l_soff[k] + l_lit[k] + r] = pt;
+            }
+        } else {
+            incorporate_areas(P, sh_load64(l_shared, SH_ARR_LO), tid);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            l_shared[SH_ARR_LO] = 0;
+            l_shared[SH_ARR_HI] = 0;
         }
     }
 
@@ -837,14 +1037,41 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
         // edge validity is a pure function, so evaluating it early, twice, or for a node that is never popped
         // cannot change the search.  Results land in the shared validity cache (1 = valid, 2 = invalid).
         const int share = wave - 1;
-        while (lds_load_u32(&l_shared[SH_DONE]) == 0) {
+        uint32_t iter = 0;
+        for (;;) {
+            const uint32_t state = lds_load_u32(&l_shared[SH_STATE]);
+            if (state == ST_DONE) break;
+            if (state == ST_ARRIVED) {
+                (void)arrival_sync(S, C, P, VS, tid);
+                continue;
+            }
+            // the last helper wave also polls the pending predecessors' done flags (every 4th round and while idle)
+            if (wave == PDMPC_WAVES_PER_VEHICLE - 1 && (iter++ & 3u) == 0) {
+                const unsigned long long pend = sh_load64(l_shared, SH_PEND_LO);
+                if (pend) {
+                    bool d = false;
+                    if ((pend >> lane) & 1ull) d = __hip_atomic_load(A.done_flag + P.pred[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == A.epoch;
+                    const unsigned long long got = __ballot(d);
+                    if (got) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (lane == 0) {
+                            l_shared[SH_ARR_LO] = (uint32_t)got;
+                            l_shared[SH_ARR_HI] = (uint32_t)(got >> 32);
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            atomicCAS((uint32_t*)&l_shared[SH_STATE], ST_RUN, ST_ARRIVED);  // loses only against ST_DONE
+                        }
+                        continue;
+                    }
+                }
+            }
             const uint32_t ver = lds_load_u32(&l_shared[SH_VERSION]);
             const uint32_t hl = lds_load_u32(&l_shared[SH_HEAP_LEN]);
             const uint32_t K = hl < (uint32_t)PDMPC_WAVE ? hl : (uint32_t)PDMPC_WAVE;
             uint32_t id = 0;
             if ((uint32_t)lane < K) id = *(volatile lds_u32*)&S.lid[lane];
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const bool unknown = id != 0 && vs_load(VS, id - 1) == 0;
+            const bool unknown = id != 0 && vs_load(VS, id - 1) == VS_UNKNOWN;
             unsigned long long b = __ballot(unknown);
             int skip = share;
             uint32_t target = 0;
@@ -859,18 +1086,35 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
             }
             if (target) {
                 const bool ok = edge_valid(S, C, target, lane);
-                if (lane == 0) vs_store(VS, target - 1, ok ? 1 : 2);
+                if (lane == 0) vs_store(VS, target - 1, ok ? VS_VALID : VS_INVALID);
             } else {
                 // nothing to validate in this view of the open list: sleep until the sequencing wave changes it (one LDS
                 // word per poll, so idle helpers do not compete with the sequencer for LDS bandwidth)
-                while (lds_load_u32(&l_shared[SH_VERSION]) == ver && lds_load_u32(&l_shared[SH_DONE]) == 0) __builtin_amdgcn_s_sleep(4);
+                uint32_t naps = 0;
+                while (lds_load_u32(&l_shared[SH_VERSION]) == ver && lds_load_u32(&l_shared[SH_STATE]) == ST_RUN && naps < 64u) {
+                    __builtin_amdgcn_s_sleep(4);
+                    ++naps;
+                }
             }
         }
     } else {
         // ================= sequencing wave: GraphSearch.m:53-107 =================================================
         PROF_DECL
         PROF_START
+        uint32_t waited = 0, ver_ctr = 0;
+      search_again:
         for (;;) {
+            if (lds_load_u32(&l_shared[SH_STATE]) == ST_ARRIVED) {
+                // predecessors finished while we were searching: fold their areas in; restart only if an already
+                // expanded node turns out to collide with them
+                if (lane == 0) l_shared[SH_NNODES] = nnodes;
+                if (arrival_sync(S, C, P, VS, tid)) {
+                    S.heap_len = 1;
+                    nnodes = 1;
+                    n_popped = 0;
+                    continue;
+                }
+            }
             if (S.heap_len == 0) {  // pop on an empty queue returns -1 (mex.cpp:87-93)  GraphSearch.m:57-61
                 status = PDMPC_EXHAUSTED;
                 break;
@@ -880,7 +1124,7 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
             heap_pop(S);
             if (lane == 0) {
                 l_shared[SH_HEAP_LEN] = S.heap_len;
-                l_shared[SH_VERSION] = (uint32_t)n_popped * 2u + 1u;
+                l_shared[SH_VERSION] = ++ver_ctr;
             }
             PROF_STOP(0)
             if (A.trace_cap > 0 && n_popped < A.trace_cap && lane == 0) A.pop_trace[(size_t)slot * A.trace_cap + n_popped] = (int32_t)cur;
@@ -890,12 +1134,12 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
             // ---- eval_edge_exact (GraphSearch.m:111-196): from the validity cache if a helper got there first
             const uint32_t vs = uni_u(vs_load(VS, c0));
             bool valid;
-            if (vs == 0) {
+            if (vs == VS_UNKNOWN) {
                 valid = edge_valid(S, C, cur, lane);
-                if (lane == 0) vs_store(VS, c0, valid ? 1 : 2);
+                if (lane == 0) vs_store(VS, c0, valid ? VS_VALID : VS_INVALID);
                 PROF_COUNT(13, 1)
             } else {
-                valid = (vs == 1);
+                valid = (vs == VS_VALID);
             }
             PROF_STOP(2)
             if (!valid) continue;  // GraphSearch.m:75-77
@@ -904,6 +1148,7 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
             const uint32_t cpk = uni_u(cn.packed);
             const int cTrim = NODE_TRIM(cpk);  // 1-based
             const int cK = NODE_K(cpk);
+            if (lane == 0) node_mark_popped(S, c0, cpk);  // a later arrival that hits this node forces a restart
             if (cK == Hp) {  // :81-90
                 goal = cur;
                 break;
@@ -1008,7 +1253,7 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
                 nnodes += (uint32_t)cnt;
                 if (lane == 0) {
                     l_shared[SH_HEAP_LEN] = S.heap_len;
-                    l_shared[SH_VERSION] = (uint32_t)n_popped * 2u;
+                    l_shared[SH_VERSION] = ++ver_ctr;
                 }
                 PROF_STOP(6)
             }
@@ -1024,7 +1269,36 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
             O->path_nodes[PDMPC_HP_MAX][3] = (double)rt_end;
         }
 #endif
-        if (lane == 0) l_shared[SH_DONE] = 1;
+        // finished — but predecessors that are still planning may yet invalidate what we found
+        for (;;) {
+            const uint32_t st = lds_load_u32(&l_shared[SH_STATE]);
+            if (st == ST_ARRIVED) {
+                if (lane == 0) l_shared[SH_NNODES] = nnodes;
+                if (arrival_sync(S, C, P, VS, tid)) {
+                    S.heap_len = 1;
+                    nnodes = 1;
+                    n_popped = 0;
+                    goal = 0;
+                    status = PDMPC_OK;
+                    goto search_again;
+                }
+                continue;
+            }
+            if (sh_load64(l_shared, SH_PEND_LO) == 0ull) {
+                uint32_t old = 0;
+                if (lane == 0) old = atomicCAS((uint32_t*)&l_shared[SH_STATE], ST_RUN, ST_DONE);
+                if (uni_u(old) == ST_RUN) break;
+                continue;
+            }
+            __builtin_amdgcn_s_sleep(8);
+            if (++waited > A.spin_limit) {  // a predecessor never finished: give up on it (reported as an error status)
+                dep_timeout = true;
+                if (lane == 0) {
+                    l_shared[SH_PEND_LO] = 0;
+                    l_shared[SH_PEND_HI] = 0;
+                }
+            }
+        }
     }
     __syncthreads();
     if (wave != 0) return;
