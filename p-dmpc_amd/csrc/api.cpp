@@ -101,6 +101,7 @@ struct PackedStep {
     DevBuf<int32_t> d_pred;
     int n_packed = 0;
     int soup_cap = 0;
+    int cand_cap = 0;  // most segments any single edge check can see (one step's soups + the boundary)
     std::vector<int64_t> lit_cols;  // per vehicle: literal soup + boundary columns (for the bytes formula)
     void release() {
         h_veh.release();
@@ -151,9 +152,9 @@ struct pdmpc_handle {
 
 namespace {
 
-int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in) {
+int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in, int cand_cap_in) {
     const int Hp = h->cfg.Hp;
-    struct { int soup_cap; } hb{soup_cap_in};
+    struct { int soup_cap, cand_cap; } hb{soup_cap_in, cand_cap_in};
     const size_t budget = (n_launch > h->n_cu) ? kLdsMax / 2 : kLdsMax;  // 2 workgroups of 4 waves per CU still fit
     LdsLayout L{};
     uint32_t off = 0;
@@ -171,7 +172,7 @@ int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in) {
     const uint32_t soup_bytes = (uint32_t)std::max(hb.soup_cap, 1) * 16;
     const uint32_t expand_bytes = (2 * PDMPC_HP_MAX * PDMPC_HP_MAX) * 8 + 16 * 16;
     const uint32_t fixed_rest = ref_bytes + shape_bytes + path_bytes + soup_bytes + expand_bytes;
-    const uint32_t cand_bytes = align16((uint32_t)std::max(hb.soup_cap, 1) * 4 * PDMPC_WAVES_PER_VEHICLE);
+    const uint32_t cand_bytes = align16((uint32_t)std::max(hb.cand_cap, 1) * 4 * PDMPC_WAVES_PER_VEHICLE);
     const uint32_t min_bytes = 64 * 12 + 64 * (uint32_t)sizeof(NodeRec);
     int areas = 1;
     if ((size_t)off + area_bytes + fixed_rest + cand_bytes + min_bytes + 256 > budget) areas = 0;
@@ -250,7 +251,7 @@ int pack_common(pdmpc_handle* h, int n, const pdmpc_vehicle_in* in, const int32_
     std::vector<int32_t> pred;
     if (B.h_veh.ensure((size_t)std::max(n, 1))) return fail(PDMPC_ERR_HIP, "hipHostMalloc failed");
     B.lit_cols.assign((size_t)n, 0);
-    int soup_cap = 0;
+    int soup_cap = 0, cand_cap = 0;
     for (int i = 0; i < n; ++i) {
         const pdmpc_vehicle_in& v = in[i];
         DevVehicle& d = B.h_veh.p[i];
@@ -328,11 +329,14 @@ int pack_common(pdmpc_handle* h, int n, const pdmpc_vehicle_in* in, const int32_
             for (int k = 0; k <= Hp; ++k) d.fb_off[k] = -1;
         }
         soup_cap = std::max(soup_cap, need);
+        for (int k = 0; k < Hp; ++k)
+            cand_cap = std::max(cand_cap, (d.lit_off[k + 1] - d.lit_off[k]) + n_pred * PDMPC_VMAX + (d.hdv_off[k + 1] - d.hdv_off[k]) + d.ll_len);
     }
     // a trailing pad so 16-byte staged copies never run past the allocation
     push_pt(pts, qnan, qnan);
     pred.push_back(0);
     B.soup_cap = soup_cap + 2;
+    B.cand_cap = (cand_cap + 4 + 3) & ~3;
     if (B.h_pts.ensure(pts.size()) || B.h_pred.ensure(pred.size())) return fail(PDMPC_ERR_HIP, "hipHostMalloc failed");
     std::memcpy(B.h_pts.p, pts.data(), pts.size() * sizeof(double));
     std::memcpy(B.h_pred.p, pred.data(), pred.size() * sizeof(int32_t));
@@ -354,7 +358,7 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     PackedStep& B = h->banks[h->bank];
     if (first < 0 || count < 0 || first + count > B.n_packed) return fail(PDMPC_ERR_INVALID, "launch range outside the packed batch");
     if (count == 0) return PDMPC_OK;
-    int rc = compute_lds(h, count, B.soup_cap);
+    int rc = compute_lds(h, count, B.soup_cap, B.cand_cap);
     if (rc) return rc;
     KernelArgs a{};
     a.succ_mask = h->d_mask.p;
@@ -388,6 +392,7 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.NL = h->NL;
     a.NV = h->NV;
     a.soup_cap = B.soup_cap;
+    a.cand_cap = B.cand_cap;
     a.spin_limit = 1u << 22;
     a.speculate = h->speculate;
     if (h->events_used == h->events.size()) {

@@ -68,7 +68,7 @@ struct LdsLayout {
     uint32_t shape;                        // shape A [8], shape B [8] (double2)
     uint32_t path;                         // uint32 path[HP_MAX+1] + misc scratch
     uint32_t soup;                         // double2[soup_cap]
-    uint32_t cand;                         // uint32[waves][soup_cap]: compacted candidate segments of one edge check
+    uint32_t cand;                         // uint32[waves][cand_cap]: compacted candidate segments of one edge check
     uint32_t vstate;                       // uint8[NV]: validity cache (0 unknown, 1 valid, 2 invalid)
     uint32_t expand;                       // expansion scratch: dcum[16][16], term[16][16] doubles, child xy[16] double2
     uint32_t heap_key, heap_id;            // double[HL], uint32[HL]
@@ -109,7 +109,7 @@ struct KernelArgs {
     int32_t* tree_size;  // per slot: nodes in the tree after the search (debug read-back)
     // LDS
     LdsLayout lds;
-    int32_t HL, NL, NV, soup_cap;
+    int32_t HL, NL, NV, soup_cap, cand_cap;
     int32_t speculate;  // 1: start searching before all predecessors have finished (results are identical, see arrival_sync)
     uint32_t spin_limit;
 };

@@ -851,7 +851,7 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
     C.Hp = Hp;
     C.checker = A.checker;
     C.sh = (d2*)(smem + A.lds.shape) + wave * 2 * PDMPC_VMAX;
-    C.cand = (uint32_t*)(smem + A.lds.cand) + (size_t)wave * A.soup_cap;
+    C.cand = (uint32_t*)(smem + A.lds.cand) + (size_t)wave * A.cand_cap;
 
     pdmpc_vehicle_out* __restrict__ O = A.out + slot;
 

@@ -51,6 +51,12 @@ def load_library(path=None):
     if _LIB is not None and path is None:
         return _LIB
     p = path or LIB_PATH
+    # One HIP runtime per process: PyTorch wheels bundle their own libamdhip64; if this library pulled in the system
+    # copy first, torch.cuda would later find "no HIP GPUs".  Importing torch first makes both share torch's copy.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(p):
         raise BackendError(
             "HIP backend %s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

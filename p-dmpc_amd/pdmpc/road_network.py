@@ -191,7 +191,7 @@ def commonroad_scenario(options: Config, seed: int = 1, tiles: int = 1) -> Scena
             ids = list(options.path_ids)
         else:
             ids = randomize_path_ids(n_here, seed * 131 + t)
-        ox, oy = (t % grid) * 5.0, (t // grid) * 4.5
+        ox, oy = (t % grid) * 12.0, (t // grid) * 12.0  # far beyond any coupling distance: tiles never couple
         for pid in ids:
             li = get_reference_lanelets_loop(pid)
             path, points_index = generate_reference_path_loop(li, m.lanelets)

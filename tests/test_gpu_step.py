@@ -96,3 +96,21 @@ def test_sharded_planner_world1_on_gpu_matches_single_launch():
     for _ in range(5):
         ctl.step(plan_step=plan_step)
     opt.handle.close()
+
+
+def test_tiled_128_vehicles_hp8_one_launch():
+    """BASELINE config 2 shape: 128 vehicles on tiled copies of the map, Hp 8, whole step in one launch."""
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    options = Config(scenario_type=ScenarioType.commonroad, amount=128, Hp=8, max_vehicles=128, max_nodes=1 << 15)
+    sc = commonroad_scenario(options, seed=2, tiles=7)
+    run_closed_loop(options, sc, "distance", boundary_provider(sc), 3)
+
+
+def test_tiled_512_vehicles_hp10_one_launch():
+    """BASELINE config 3 shape: 512 vehicles, Hp 10 (two workgroups per CU, 80 KB of LDS each)."""
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    options = Config(scenario_type=ScenarioType.commonroad, amount=512, Hp=10, max_vehicles=512, max_nodes=1 << 14)
+    sc = commonroad_scenario(options, seed=3, tiles=26)
+    run_closed_loop(options, sc, "distance", boundary_provider(sc), 2)
