@@ -18,7 +18,7 @@ def find(pattern):
     return g[0] if g else None
 
 
-summary = {"tag": tag, "command": "python bench.py --steps 100 --warmup 10 --no-cpu-baseline"}
+summary = {"tag": tag, "command": "python bench.py --steps 200 --warmup 20 --no-cpu-baseline (rocprofv3 --kernel-trace --stats; separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes)"}
 ks = find("stats/**/*kernel_stats.csv")
 if ks:
     rows = list(csv.DictReader(open(ks)))
@@ -32,7 +32,9 @@ if kt:
     rows = [r for r in csv.DictReader(open(kt)) if "pdmpc_search" in r["Kernel_Name"]]
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
     if d:
+        timed = d[-200:] if len(d) >= 200 else d
         summary["kernel_trace"] = {"launches": len(d), "avg_ms": sum(d) / len(d), "min_ms": min(d), "max_ms": max(d),
+                                   "timed_region_launches": len(timed), "timed_region_avg_ms": sum(timed) / len(timed),
                                    "lds_block_size": rows[0].get("LDS_Block_Size"), "vgpr": rows[0].get("VGPR_Count"), "sgpr": rows[0].get("SGPR_Count"),
                                    "grid": rows[0].get("Grid_Size"), "workgroup": rows[0].get("Workgroup_Size")}
 traffic = {}
