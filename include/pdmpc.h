@@ -206,6 +206,13 @@ int pdmpc_debug_tree(pdmpc_handle* handle, int32_t vehicle, int32_t capacity, do
                      double* yaw, double* g, double* h, int32_t* trim, int32_t* k, int32_t* parent,
                      int32_t* n);
 
+/* drives the device open list with a command script (op[i] == 0: push (id[i], key[i]); op[i] == 1: pop) the way the
+ * reference drives priority_queue_interface_mex (PUSH / POP, .cpp:62-99); popped[] receives the popped ids (-1 on an empty
+ * queue).  lds_entries = how many heap entries live in LDS (the rest spills to HBM).  Used by the heap-order unit test. */
+int pdmpc_debug_heap_script(pdmpc_handle* handle, int32_t n, const int32_t* op, const int32_t* id, const double* key,
+                            int32_t lds_entries, int32_t* popped, int32_t* n_popped, double* cycles_per_pop,
+                            double* cycles_per_push);
+
 const char* pdmpc_last_error(void);
 const char* pdmpc_version(void);
 

@@ -687,6 +687,47 @@ int pdmpc_get_last_stats(pdmpc_handle* h, pdmpc_stats* stats) {
     return PDMPC_OK;
 }
 
+int pdmpc_debug_heap_script(pdmpc_handle* h, int32_t n, const int32_t* op, const int32_t* id, const double* key, int32_t lds_entries,
+                            int32_t* popped, int32_t* n_popped, double* cycles_per_pop, double* cycles_per_push) {
+    if (!h || n < 0 || (n > 0 && (!op || !id || !key)) || !popped || !n_popped) return fail(PDMPC_ERR_INVALID, "null argument");
+    if (lds_entries < 64 || lds_entries > 8192 || (lds_entries & 1)) return fail(PDMPC_ERR_INVALID, "lds_entries must be even and in 64..8192");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    int32_t *d_op = nullptr, *d_id = nullptr, *d_out = nullptr;
+    double *d_key = nullptr, *d_gkey = nullptr;
+    uint32_t* d_gid = nullptr;
+    unsigned long long* d_stats = nullptr;
+    const size_t m = (size_t)std::max(n, 1);
+    HIPCHK(hipMalloc((void**)&d_op, m * 4));
+    HIPCHK(hipMalloc((void**)&d_id, m * 4));
+    HIPCHK(hipMalloc((void**)&d_out, m * 4));
+    HIPCHK(hipMalloc((void**)&d_key, m * 8));
+    HIPCHK(hipMalloc((void**)&d_gkey, (m + 2) * 8));
+    HIPCHK(hipMalloc((void**)&d_gid, (m + 2) * 4));
+    HIPCHK(hipMalloc((void**)&d_stats, 4 * 8));
+    HIPCHK(hipMemcpy(d_op, op, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_id, id, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_key, key, (size_t)n * 8, hipMemcpyHostToDevice));
+    int lrc = pdmpc_launch_heap_script(d_op, d_id, d_key, n, d_out, d_stats, d_gkey, d_gid, lds_entries, (void*)h->stream);
+    if (lrc != 0) return fail(PDMPC_ERR_HIP, "heap script launch failed");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    unsigned long long st[4];
+    HIPCHK(hipMemcpy(st, d_stats, sizeof st, hipMemcpyDeviceToHost));
+    int cnt = 0;
+    for (int i = 0; i < n; ++i) cnt += op[i] == 1;
+    *n_popped = cnt;
+    if (cnt > 0) HIPCHK(hipMemcpy(popped, d_out, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+    if (cycles_per_pop) *cycles_per_pop = st[1] ? (double)st[0] / (double)st[1] : 0.0;
+    if (cycles_per_push) *cycles_per_push = st[3] ? (double)st[2] / (double)st[3] : 0.0;
+    (void)hipFree(d_op);
+    (void)hipFree(d_id);
+    (void)hipFree(d_out);
+    (void)hipFree(d_key);
+    (void)hipFree(d_gkey);
+    (void)hipFree(d_gid);
+    (void)hipFree(d_stats);
+    return PDMPC_OK;
+}
+
 int pdmpc_debug_pop_trace(pdmpc_handle* h, int32_t vehicle, int32_t capacity, int32_t* ids, int32_t* n) {
     if (!h || !ids || !n) return fail(PDMPC_ERR_INVALID, "null argument");
     if (h->cfg.trace_pops <= 0) return fail(PDMPC_ERR_INVALID, "handle was created with trace_pops == 0");

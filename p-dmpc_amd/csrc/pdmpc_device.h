@@ -119,6 +119,9 @@ extern "C" {
 #endif
 // defined in search_kernel.hip; launches `count` workgroups of 64 threads on `stream`
 int pdmpc_launch_search(const KernelArgs* args, int count, void* stream);
+// defined in search_kernel.hip; runs the open-list command script on one wavefront (debug / unit test)
+int pdmpc_launch_heap_script(const int32_t* op, const int32_t* id, const double* key, int n, int32_t* out, unsigned long long* stats,
+                             double* gkey, uint32_t* gid, int HL, void* stream);
 #ifdef __cplusplus
 }
 #endif

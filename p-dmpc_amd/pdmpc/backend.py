@@ -34,6 +34,7 @@ EXPORTS = [
     "pdmpc_import_results",
     "pdmpc_export_results",
     "pdmpc_get_last_stats",
+    "pdmpc_debug_heap_script",
     "pdmpc_debug_pop_trace",
     "pdmpc_debug_tree",
     "pdmpc_last_error",
@@ -81,6 +82,7 @@ def load_library(path=None):
     L.pdmpc_import_results.argtypes = [H, C.c_int32, C.c_int32, C.c_void_p]
     L.pdmpc_export_results.argtypes = [H, C.c_int32, C.c_int32, C.c_void_p]
     L.pdmpc_get_last_stats.argtypes = [H, C.POINTER(abi.Stats)]
+    L.pdmpc_debug_heap_script.argtypes = [H, C.c_int32, abi.c_int32_p, abi.c_int32_p, abi.c_double_p, C.c_int32, abi.c_int32_p, abi.c_int32_p, abi.c_double_p, abi.c_double_p]
     L.pdmpc_debug_pop_trace.argtypes = [H, C.c_int32, C.c_int32, abi.c_int32_p, abi.c_int32_p]
     L.pdmpc_debug_tree.argtypes = [H, C.c_int32, C.c_int32] + [abi.c_double_p] * 5 + [abi.c_int32_p] * 4
     L.pdmpc_last_error.restype = C.c_char_p
@@ -211,6 +213,22 @@ class Handle:
         s = abi.Stats()
         _check(self.L, self.L.pdmpc_get_last_stats(self.h, C.byref(s)), "pdmpc_get_last_stats")
         return {name: getattr(s, name) for name, _ in abi.Stats._fields_}
+
+    def heap_script(self, ops, ids, keys, lds_entries=4096):
+        """Run a push/pop script on the device open list -> (popped ids, cycles per pop, cycles per push)."""
+        ops = np.ascontiguousarray(ops, dtype=np.int32)
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        keys = np.ascontiguousarray(keys, dtype=np.float64)
+        out = np.zeros(max(len(ops), 1), dtype=np.int32)
+        n = C.c_int32()
+        cp, cq = C.c_double(), C.c_double()
+        _check(
+            self.L,
+            self.L.pdmpc_debug_heap_script(self.h, len(ops), ops.ctypes.data_as(abi.c_int32_p), ids.ctypes.data_as(abi.c_int32_p), keys.ctypes.data_as(abi.c_double_p),
+                                           lds_entries, out.ctypes.data_as(abi.c_int32_p), C.byref(n), C.byref(cp), C.byref(cq)),
+            "pdmpc_debug_heap_script",
+        )
+        return out[: n.value].copy(), cp.value, cq.value
 
     def pop_trace(self, vehicle, capacity=1 << 16):
         ids = np.zeros(capacity, dtype=np.int32)
