@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"])
+    ap.add_argument("--shard", default="components", choices=["components", "levels"],
+                    help="multi-GPU mode of c3/c4: whole coupling-graph components per rank (one speculative launch per rank and step, one "
+                    "all-gather of results) or block-partitioned levels (one all-gather per level)")
     args = ap.parse_args()
     if args.workload == "c3":
         args.vehicles, args.hp = 128, 8
@@ -130,7 +133,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP backend has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("PDMPC_FORCE_DIST") == "1":  # the env switch lets a 1-GPU box exercise the RCCL path
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -144,6 +147,14 @@ def main():
     h = optimizer.handle
     problems = record_steps(options, mpa, ctl, optimizer, args.skip, args.record)
     S = len(problems)
+    parts = None
+    full_problems = problems
+    if sharded and dist is not None and args.shard == "components":
+        from pdmpc.distributed import partition_components, sub_problem
+
+        # every rank recorded the same closed loop; now it keeps only the components assigned to it
+        parts = [partition_components(p["preds"], world) for p in full_problems]
+        problems = [sub_problem(p, parts[b][rank]) for b, p in enumerate(full_problems)]
     # keep every recorded step resident in HBM (one bank each) and collect its algorithmic bytes
     bytes_per_bank, pops_per_bank, nodes_per_bank = [], [], []
     t_host = time.perf_counter()
@@ -161,10 +172,19 @@ def main():
     host_buffer_ms = 1e3 * (time.perf_counter() - t_host) / max(S, 1)  # pack (host buffers -> HBM) + launch + fetch + stats
 
     planner = None
-    if sharded and world > 1:
+    gather_bufs = None
+    if sharded and dist is not None and args.shard == "levels":
         from pdmpc.distributed import HipRangePlanner, plan_step_sharded
 
         planner = HipRangePlanner(optimizer, mpa, torch.device("cuda", local_rank))
+    elif parts is not None:
+        from pdmpc.distributed import REC_BYTES
+
+        per = max(max(len(q) for q in pb) for pb in parts)
+        gather_bufs = (
+            torch.zeros(max(per, 1) * REC_BYTES, dtype=torch.uint8, device="cuda"),
+            torch.zeros(max(per, 1) * REC_BYTES * world, dtype=torch.uint8, device="cuda"),
+        )
 
     def one_step(i):
         if planner is not None:
@@ -173,6 +193,12 @@ def main():
             return
         h.select_bank(i % S)
         h.launch()
+        if gather_bufs is not None:
+            # end-of-step exchange: every rank receives the records of all components (one RCCL all-gather over xGMI)
+            h.export_results(0, len(problems[i % S]["iters"]), gather_bufs[0].data_ptr())  # waits for the kernel
+            dist.all_gather_into_tensor(gather_bufs[1], gather_bufs[0])
+            torch.cuda.current_stream().synchronize()
+            return
         h.synchronize()
 
     for i in range(args.warmup):
@@ -230,12 +256,12 @@ def main():
                 "workload": "%s: %d vehicles on the CPM-lab road network (labmap fixture%s), Hp %d, InterX checker, %s MPA, "
                 "distance coupling, constant priorities, %s; %d recorded closed-loop steps replayed from HBM%s"
                 % (args.workload.upper(), args.vehicles, ", tiled" if sharded else "", args.hp, args.mpa,
-                   "levels sharded over ranks with one all-gather per level" if planner is not None else "one launch per step", S,
+                   "levels sharded over ranks with one all-gather per level" if planner is not None else ("coupling-graph components sharded over ranks, one launch per rank and step, one all-gather of results" if gather_bufs is not None else "one launch per step"), S,
                    "" if sharded else "; per GPU one independent network"),
                 "vehicles": args.vehicles,
                 "Hp": args.hp,
                 "mpa": args.mpa,
-                "levels_per_step": statistics.mean(len(p["level_sizes"]) for p in problems),
+                "levels_per_step": statistics.mean(len(p["level_sizes"]) for p in full_problems),
                 "seed": args.seed,
             },
             "roofline": {
@@ -258,7 +284,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(options, mpa, problems, args.cpu_budget_s)
+            out["cpu_baseline"] = cpu_baseline(options, mpa, full_problems, args.cpu_budget_s)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

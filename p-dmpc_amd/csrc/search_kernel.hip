@@ -195,8 +195,10 @@ __device__ __forceinline__ void heap_load(const Search& S, uint32_t idx, bool va
             id = S.lid[idx];
         }
         if (ing) {
-            k = S.gkey[idx];
-            id = S.gid[idx];
+            // spilled entries: L1-bypassing (sc1) loads, so an entry this wave stored a moment ago is read from L2, where
+            // the wave's in-order write-through store has already landed; no fence / store drain needed between heap phases
+            k = __hip_atomic_load(S.gkey + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            id = __hip_atomic_load(S.gid + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -214,7 +216,8 @@ __device__ __forceinline__ void heap_store(const Search& S, uint32_t idx, double
 // same-CU L1, needs the stores drained)
 template <bool LDSONLY>
 __device__ __forceinline__ void heap_fence() {
-    if (!LDSONLY) __threadfence_block();
+    if (!LDSONLY) __threadfence_block();  // measured: free next to the L2 round trips of the spilled levels
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // compiler ordering only
     __builtin_amdgcn_wave_barrier();
 }
 

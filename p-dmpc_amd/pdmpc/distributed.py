@@ -99,3 +99,75 @@ def plan_step_sharded(problem, planner, dist, rank, world, resident_bank=None, f
     if not fetch:
         return None
     return planner.fetch(len(problem["iters"]))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Component sharding: the preferred multi-GPU mode.
+#
+# Vehicles that are not connected in the coupling graph never exchange anything within a time step (in the reference
+# they do not even subscribe to each other's topics: PrioritizedController.m:208-255 reads only coupled vehicles).  The
+# weakly connected components of the step's coupling graph are therefore independent planning problems: each rank takes
+# whole components and plans them with ONE speculative launch (no per-level synchronisation at all); a single
+# all-gather of the result records at the end of the step gives every rank the full result for its host-side logic.
+# Level sharding (above) remains the fallback for a step whose graph is one big component.
+
+
+def weak_components(preds):
+    """Union-find over the predecessor lists -> component label per slot (labels = smallest slot of the component)."""
+    n = len(preds)
+    parent = list(range(n))
+
+    def find(a):
+        while parent[a] != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
+
+    for s, ps in enumerate(preds):
+        for p in ps:
+            ra, rb = find(s), find(p)
+            if ra != rb:
+                parent[max(ra, rb)] = min(ra, rb)
+    return [find(s) for s in range(n)]
+
+
+def partition_components(preds, world, weights=None):
+    """Longest-processing-time assignment of components to ranks -> per rank the sorted list of slots it plans."""
+    labels = weak_components(preds)
+    comps = {}
+    for s, c in enumerate(labels):
+        comps.setdefault(c, []).append(s)
+    load = [0.0] * world
+    parts = [[] for _ in range(world)]
+    size = (lambda slots: float(len(slots))) if weights is None else (lambda slots: float(sum(weights[s] for s in slots)))
+    for c in sorted(comps, key=lambda c: (-size(comps[c]), c)):
+        r = min(range(world), key=lambda r: (load[r], r))
+        parts[r] += comps[c]
+        load[r] += size(comps[c])
+    return [sorted(p) for p in parts]
+
+
+def sub_problem(problem, slots):
+    """The step problem restricted to `slots` (whole components): predecessor indices are remapped to positions."""
+    pos = {s: i for i, s in enumerate(slots)}
+    return {
+        "order": [problem["order"][s] for s in slots],
+        "iters": [problem["iters"][s] for s in slots],
+        "preds": [[pos[p] for p in problem["preds"][s]] for s in slots],
+        "fallback": [problem["fallback"][s] for s in slots],
+        "level_sizes": [len(slots)],
+        "slots": list(slots),
+    }
+
+
+def gather_records(local_records_tensor, n_local, parts, dist, rank, world, new_buffer):
+    """All-gather the per-rank record blocks (padded to the largest block) and return a list `blocks[r]` of byte tensors."""
+    per = max(len(p) for p in parts)
+    send = new_buffer(per)
+    if n_local:
+        send[: n_local * REC_BYTES] = local_records_tensor[: n_local * REC_BYTES]
+    if world == 1:
+        return [send]
+    recv = new_buffer(per * world)
+    dist.all_gather_into_tensor(recv, send)
+    return [recv[r * per * REC_BYTES : (r * per + len(parts[r])) * REC_BYTES] for r in range(world)]

@@ -149,3 +149,85 @@ def test_single_rank_is_the_plain_level_loop():
     got = plan_step_sharded(prob, OracleRangePlanner(options, mpa), None, 0, 1)
     assert np.array_equal(got["n_popped"], want["n_popped"])
     assert np.array_equal(got["y_predicted"], want["y_predicted"], equal_nan=True)
+
+
+# ---- component sharding ------------------------------------------------------------------------------------------
+def test_partition_components_keeps_components_whole_and_balances():
+    from pdmpc.distributed import partition_components, weak_components
+
+    preds = [[], [0], [], [2], [3], [], [], [6, 5], [], []]  # components {0,1}, {2,3,4}, {5,6,7}, {8}, {9}
+    labels = weak_components(preds)
+    assert labels == [0, 0, 2, 2, 2, 5, 5, 5, 8, 9]
+    for world in (1, 2, 3, 4):
+        parts = partition_components(preds, world)
+        assert sorted(s for p in parts for s in p) == list(range(10))
+        for p in parts:
+            for s in p:
+                assert all(q in p for q in preds[s])
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 3
+
+
+def _component_worker(rank, world, port, q):
+    from oracle import oracle
+    from pdmpc.distributed import gather_records, partition_components, sub_problem
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    options, mpa, prob = make_tiled_problem()
+    parts = partition_components(prob["preds"], world)
+    sub = sub_problem(prob, parts[rank])
+    recs, _ = oracle.plan_step(options, mpa, dict(sub, level_sizes=levels_of(sub["preds"])))
+    local = torch.from_numpy(np.frombuffer(recs.tobytes(), dtype=np.uint8).copy())
+    blocks = gather_records(local, len(parts[rank]), parts, dist, rank, world, lambda n: torch.zeros(max(n, 1) * REC_BYTES, dtype=torch.uint8))
+    full = abi.out_array(len(prob["iters"]))
+    for r in range(world):
+        got = np.frombuffer(blocks[r].numpy().tobytes(), dtype=abi.VEHICLE_OUT_DTYPE)
+        for i, s in enumerate(parts[r]):
+            full[s] = got[i]
+    q.put((rank, full.tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def levels_of(preds):
+    """kahn level sizes of a problem whose slots are already in level order."""
+    lvl = []
+    for s, ps in enumerate(preds):
+        lvl.append(1 + max((lvl[p] for p in ps), default=0))
+    assert lvl == sorted(lvl)
+    return [lvl.count(v) for v in range(1, max(lvl) + 1)]
+
+
+def make_tiled_problem():
+    from pdmpc.config import Config, ScenarioType
+    from pdmpc.controller import PrioritizedSequentialController
+    from pdmpc.mpa import get_mpa
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    options = Config(scenario_type=ScenarioType.commonroad, amount=18, Hp=5, max_nodes=1 << 15)
+    mpa = get_mpa(options)
+    sc = commonroad_scenario(options, seed=6, tiles=3)
+    ctl = PrioritizedSequentialController(options, sc, mpa, None, coupling="distance", boundary_provider=boundary_provider(sc))
+    return options, mpa, ctl.build_step_problem()
+
+
+@pytest.mark.timeout(300)
+def test_component_sharding_world2_matches_single_process():
+    from oracle import oracle
+
+    options, mpa, prob = make_tiled_problem()
+    want, _ = oracle.plan_step(options, mpa, prob)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_component_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        recs = np.frombuffer(got[r], dtype=abi.VEHICLE_OUT_DTYPE)
+        assert np.array_equal(recs.view(np.uint8), want.view(np.uint8))
