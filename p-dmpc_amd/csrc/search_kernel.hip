@@ -623,6 +623,7 @@ __device__ __forceinline__ uint32_t lds_load_u32(const volatile uint32_t* p) { r
 #define VS_UNKNOWN 0u
 #define VS_VALID 1u
 #define VS_INVALID 2u
+#define VS_VALID_CS 3u  // valid, and a helper has already stored cos/sin(yaw) in the node's record (expand_node.m:50-51)
 
 
 // validity cache: 0 unknown, 1 valid, 2 invalid; the first NV nodes in LDS, the rest in HBM (same CU -> same L1)
@@ -757,7 +758,8 @@ __device__ bool arrival_sync(const Search& S, const CheckCtx& C, const SpecCtx& 
     incorporate_areas(P, arr, tid);
     __syncthreads();  // #2
     for (uint32_t i0 = (uint32_t)tid; i0 < nn; i0 += PDMPC_THREADS) {
-        if (vs_load(VS, i0) == VS_VALID) {
+        const uint32_t vst = vs_load(VS, i0);
+        if (vst == VS_VALID || vst == VS_VALID_CS) {
             bool popped;
             if (node_hits_areas(S, C, P, i0, arr, popped)) {
                 if (popped)
@@ -1089,7 +1091,19 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
             }
             if (target) {
                 const bool ok = edge_valid(S, C, target, lane);
-                if (lane == 0) vs_store(VS, target - 1, ok ? VS_VALID : VS_INVALID);
+                uint32_t verdict = ok ? VS_VALID : VS_INVALID;
+                if (ok) {
+                    // the sequencer will expand this node if it pops it: take cos/sin(yaw) off its critical path
+                    const NodeRec tn = node_load(S, target - 1);
+                    if (NODE_K(uni_u(tn.packed)) < Hp) {
+                        double sn, cs;
+                        pdmpc_sincos(tn.yaw, &sn, &cs);
+                        if (lane == 0) node_store_cs(S, target - 1, cs, sn);
+                        if (target - 1 >= S.NL) __threadfence_block();
+                        verdict = VS_VALID_CS;
+                    }
+                }
+                if (lane == 0) vs_store(VS, target - 1, verdict);
             } else {
                 // nothing to validate in this view of the open list: sleep until the sequencing wave changes it (one LDS
                 // word per poll, so idle helpers do not compete with the sequencer for LDS bandwidth)
@@ -1142,7 +1156,7 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
                 if (lane == 0) vs_store(VS, c0, valid ? VS_VALID : VS_INVALID);
                 PROF_COUNT(13, 1)
             } else {
-                valid = (vs == VS_VALID);
+                valid = (vs == VS_VALID || vs == VS_VALID_CS);
             }
             PROF_STOP(2)
             if (!valid) continue;  // GraphSearch.m:75-77
@@ -1161,9 +1175,14 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
             const double curX = cn.x, curY = cn.y, curYaw = cn.yaw, curG = cn.g;
             double sn, cs;
             PROF_STOP(3)
-            pdmpc_sincos(curYaw, &sn, &cs);  // expand_node.m:50-51
+            if (vs == VS_VALID_CS) {  // a helper already evaluated expand_node.m:50-51 for this node
+                cs = cn.cs;
+                sn = cn.sn;
+            } else {
+                pdmpc_sincos(curYaw, &sn, &cs);  // expand_node.m:50-51
+                if (lane == 0) node_store_cs(S, c0, cs, sn);
+            }
             PROF_STOP(4)
-            if (lane == 0) node_store_cs(S, c0, cs, sn);
             const int k_exp = cK + 1;            // :13
             const int steps_to_go = Hp - k_exp;  // :37
             const uint64_t* mrow = l_mask + ((size_t)(k_exp - 1) * n + (cTrim - 1)) * nw;
