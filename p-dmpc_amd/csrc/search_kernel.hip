@@ -269,7 +269,7 @@ __device__ __forceinline__ void heap_push(Search& S, uint32_t id, double key) {
 // the chain store their entry one level up in one instruction.
 // one round of the sift-down: returns the new hole
 template <bool LDSONLY>
-__device__ __forceinline__ uint32_t heap_pop_round(Search& S, uint32_t hole, uint32_t half, const PopLane& L) {
+__device__ __forceinline__ uint32_t heap_pop_round(Search& S, uint32_t hole, uint32_t half, const PopLane& L, double& moved_key) {
     const uint32_t idx = ((hole + 1u) << L.d) - 1u + L.q;
     const uint32_t pidx = (idx - 1u) >> 1;
     const bool step_ok = pidx < half;  // the parent has two children (adjust_heap loop condition)
@@ -288,6 +288,7 @@ __device__ __forceinline__ uint32_t heap_pop_round(Search& S, uint32_t hole, uin
     const unsigned long long pathmask = __ballot(on);
     if (on) heap_store<LDSONLY>(S, pidx, k, i);
     const int last = 63 - (int)__builtin_clzll(pathmask);  // deepest chain lane (the chain is never empty: hole < half)
+    moved_key = lane_d(k, last);  // the entry that now sits in the parent of the new hole
     return lane_u(idx, last);
 }
 
@@ -299,12 +300,13 @@ __device__ __forceinline__ void heap_pop_impl(Search& S, uint32_t len) {
     heap_load<LDSONLY>(S, len, true, vkey, vid);
     const uint32_t half = (len - 1) >> 1;
     uint32_t hole = 0;
+    double parent_key = 0.0;  // key of the entry that moved into the parent of the current hole
     while (hole < half) {
         // the five levels below `hole` end at index 32 * (hole + 1) + 30
         if (LDSONLY || ((hole + 1u) << 5) + 30u < S.HL)
-            hole = heap_pop_round<true>(S, hole, half, S.pl);
+            hole = heap_pop_round<true>(S, hole, half, S.pl, parent_key);
         else
-            hole = heap_pop_round<false>(S, hole, half, S.pl);
+            hole = heap_pop_round<false>(S, hole, half, S.pl, parent_key);
     }
     if ((len & 1u) == 0 && hole == ((len - 2u) >> 1)) {  // lone left child at the bottom
         const uint32_t child = 2u * (hole + 1u);
@@ -312,11 +314,19 @@ __device__ __forceinline__ void heap_pop_impl(Search& S, uint32_t len) {
         uint32_t cid;
         heap_load<LDSONLY>(S, child - 1u, true, ck, cid);
         if (lane == 0) heap_store<LDSONLY>(S, hole, ck, cid);
+        parent_key = uni_d(ck);
         hole = child - 1u;
     }
-    heap_fence<LDSONLY>();
     vkey = uni_d(vkey);
     vid = uni_u(vid);
+    // __push_heap(first, hole, 0, value): the value climbs only while parent.key > value.key; the parent of the hole holds
+    // the entry that just moved up, whose key is still in a register -> the common "stays put" case needs no memory read
+    if (hole == 0 || !(parent_key > vkey)) {
+        if (lane == 0) heap_store<LDSONLY>(S, hole, vkey, vid);
+        heap_fence<LDSONLY>();
+        return;
+    }
+    heap_fence<LDSONLY>();
     heap_sift_up<LDSONLY>(S, hole, vkey, vid);
     heap_fence<LDSONLY>();
 }
