@@ -27,7 +27,7 @@ def corridor(rng, x0=-1.0, x1=7.0, half_width=0.28, n=36, wobble=0.0):
     return left, right, np.column_stack([xs, yc])
 
 
-def road_problem(rng, options: Config, mpa, n_dyn=None, n_static=None, with_boundary=True, convex=False):
+def road_problem(rng, options: Config, mpa, n_dyn=None, n_static=None, with_boundary=True, convex=False, n_hdv=0):
     """One vehicle on a (slightly wobbling) corridor with crossing/oncoming obstacle polygons."""
     Hp = options.Hp
     wob = rng.uniform(0.0, 0.08)
@@ -67,8 +67,15 @@ def road_problem(rng, options: Config, mpa, n_dyn=None, n_static=None, with_boun
         ox = x + rng.uniform(0.8, 3.0)
         oy = float(np.interp(ox, centre[:, 0], centre[:, 1])) + rng.uniform(-0.3, 0.3)
         obstacles.append(rect(ox, oy, rng.uniform(-math.pi, math.pi), 0.24, 0.12))
+    hdv = []
+    for _ in range(n_hdv):  # reachable sets of adjacent human-driven vehicles: larger polygons growing with the step
+        hx = x + rng.uniform(0.6, 2.0)
+        hy = float(np.interp(hx, centre[:, 0], centre[:, 1])) + rng.uniform(-0.2, 0.2)
+        hyaw = rng.uniform(-math.pi, math.pi)
+        hdv.append([rect(hx, hy, hyaw, 0.3 + 0.08 * k, 0.15 + 0.03 * k) for k in range(Hp)])
     boundary = (left, right) if with_boundary else (None, None)
     return VehicleIter(
+        hdv_reachable_sets=hdv,
         x0=np.array([x, y, yaw, mpa.trims[trim - 1].speed]),
         trim_index=trim,
         reference_trajectory_points=path,
@@ -85,9 +92,9 @@ def make_options(mode, Hp=6, mpa_type=MpaType.single_speed, **kw):
     return Config(scenario_type=st, Hp=Hp, mpa_type=mpa_type, **kw)
 
 
-def problem_set(mode, seed, count, Hp=6, mpa_type=MpaType.single_speed, **kw):
+def problem_set(mode, seed, count, Hp=6, mpa_type=MpaType.single_speed, n_hdv=0, with_boundary=True, **kw):
     options = make_options(mode, Hp=Hp, mpa_type=mpa_type, **kw)
     mpa = get_mpa(options)
     rng = np.random.default_rng(seed)
-    iters = [road_problem(rng, options, mpa, convex=(mode == "sat")) for _ in range(count)]
+    iters = [road_problem(rng, options, mpa, convex=(mode == "sat"), n_hdv=n_hdv, with_boundary=with_boundary) for _ in range(count)]
     return options, mpa, iters

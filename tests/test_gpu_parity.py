@@ -155,3 +155,35 @@ def test_empty_batch_and_errors():
     with pytest.raises(BackendError):
         h.plan_batch(iters * 2)  # larger than max_vehicles
     h.close()
+
+
+def test_interx_with_hdv_reachable_sets():
+    """are_constraints_satisfied_interx.m:23-31: the HDV soup is a third curve set checked with the normal-offset area."""
+    options, mpa, iters = problems.problem_set("interx", 31, 16, Hp=6, n_hdv=2)
+    gpu, _ = check_batch(options, mpa, iters)
+    _, _, plain = problems.problem_set("interx", 31, 16, Hp=6, n_hdv=0)
+    ref_plain = _oracle().plan_batch(options, mpa, plain)[1]
+    assert not np.array_equal(gpu["n_popped"], ref_plain["n_popped"])  # the HDV sets actually change some searches
+
+
+def test_realistic_mpa_two_mask_words_areas_in_hbm():
+    """71 trims -> successor masks span two 64-bit words; 527 maneuvers -> the area tables do not fit LDS and are read
+    from HBM/L2.  Both code paths differ from the 12/34-trim MPAs."""
+    options, mpa, iters = problems.problem_set("interx", 41, 8, Hp=6, mpa_type=MpaType.realistic)
+    assert mpa.n_trims > 64
+    check_batch(options, mpa, iters)
+
+
+def test_long_horizon_hp12_and_no_boundary():
+    options, mpa, iters = problems.problem_set("interx", 51, 8, Hp=12, with_boundary=False)
+    check_batch(options, mpa, iters)
+
+
+def test_sat_without_obstacles_or_boundary_is_the_greedy_chain():
+    """Free space (circle scenario, first vehicle): nothing is ever rejected."""
+    options, mpa, iters = problems.problem_set("sat", 61, 6, Hp=5, with_boundary=False)
+    for it in iters:
+        it.obstacles = []
+        it.dynamic_obstacle_area = []
+    gpu, _ = check_batch(options, mpa, iters)
+    assert (gpu["status"] == abi.OK).all()
