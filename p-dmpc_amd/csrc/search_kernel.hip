@@ -581,6 +581,7 @@ struct CheckCtx {
 
 // eval_edge_exact (GraphSearch.m:111-196) for node `id` (1-based): true = collision-free.  A pure function of the
 // tree and the obstacle soups, which is what allows helper waves to evaluate it ahead of the pop.
+template <int CHECKER>
 __device__ bool edge_valid(const Search& S, const CheckCtx& C, uint32_t id, int lane) {
     const NodeRec cn = node_load(S, id - 1);
     const uint32_t par = uni_u(cn.parent);
@@ -615,7 +616,7 @@ __device__ bool edge_valid(const Search& S, const CheckCtx& C, uint32_t id, int 
     const int so = uni_i(C.l_soff[cK - 1]);
     const int M_k = uni_i(C.l_soff[cK]) - so;
     bool hit;
-    if (C.checker == PDMPC_CHECK_INTERX) {
+    if (CHECKER == PDMPC_CHECK_INTERX) {
         const int ho = uni_i(C.l_hoff[cK - 1]);
         const int Hk = uni_i(C.l_hoff[cK]) - ho;
         hit = interx_check(C.sh, ncols, C.l_soup, so, M_k, ho, Hk, C.ll_base, C.ll_len, C.cand, lane);
@@ -807,7 +808,10 @@ __device__ bool arrival_sync(const Search& S, const CheckCtx& C, const SpecCtx& 
 
 }  // namespace
 
-extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(const KernelArgs A) {
+// The kernel body, specialised at compile time on the constraint checker so each variant carries only its own
+// collision code (the search is instruction-cache and issue bound: smaller is faster).
+template <int CHECKER>
+__device__ __forceinline__ void search_body(const KernelArgs& A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & (PDMPC_WAVE - 1);
@@ -951,7 +955,9 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
     P.n_pred = n_pred;
     P.Hp = Hp;
     bool dep_timeout = false;
-    const bool speculate = A.speculate && n_pred <= 64;
+    // the arrival re-check (node_hits_areas) implements the InterX predicate; the convex/SAT checker (circle scenario,
+    // a handful of vehicles) simply waits for its predecessors as the reference does
+    const bool speculate = A.speculate && n_pred <= 64 && CHECKER == PDMPC_CHECK_INTERX;
     if (n_pred > 0) {
         const d2 nanpt = d2{__longlong_as_double(0x7ff8000000000000LL), __longlong_as_double(0x7ff8000000000000LL)};
         for (int idx = tid; idx < Hp * pred_cols; idx += PDMPC_THREADS) {
@@ -1100,7 +1106,7 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
                 --skip;
             }
             if (target) {
-                const bool ok = edge_valid(S, C, target, lane);
+                const bool ok = edge_valid<CHECKER>(S, C, target, lane);
                 uint32_t verdict = ok ? VS_VALID : VS_INVALID;
                 if (ok) {
                     // the sequencer will expand this node if it pops it: take cos/sin(yaw) off its critical path
@@ -1162,7 +1168,7 @@ extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(
             const uint32_t vs = uni_u(vs_load(VS, c0));
             bool valid;
             if (vs == VS_UNKNOWN) {
-                valid = edge_valid(S, C, cur, lane);
+                valid = edge_valid<CHECKER>(S, C, cur, lane);
                 if (lane == 0) vs_store(VS, c0, valid ? VS_VALID : VS_INVALID);
                 PROF_COUNT(13, 1)
             } else {
@@ -1473,11 +1479,17 @@ extern "C" int pdmpc_launch_heap_script(const int32_t* op, const int32_t* id, co
     return (int)hipGetLastError();
 }
 
+extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(const KernelArgs A) { search_body<PDMPC_CHECK_INTERX>(A); }
+extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel_sat(const KernelArgs A) { search_body<PDMPC_CHECK_SAT>(A); }
+
 extern "C" int pdmpc_launch_search(const KernelArgs* args, int count, void* stream) {
     if (count <= 0) return 0;
-    hipError_t e = hipFuncSetAttribute((const void*)pdmpc_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)args->lds.total);
+    const void* fn = args->checker == PDMPC_CHECK_INTERX ? (const void*)pdmpc_search_kernel : (const void*)pdmpc_search_kernel_sat;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)args->lds.total);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(pdmpc_search_kernel, dim3(count), dim3(PDMPC_THREADS), args->lds.total, (hipStream_t)stream, *args);
+    if (args->checker == PDMPC_CHECK_INTERX)
+        hipLaunchKernelGGL(pdmpc_search_kernel, dim3(count), dim3(PDMPC_THREADS), args->lds.total, (hipStream_t)stream, *args);
+    else
+        hipLaunchKernelGGL(pdmpc_search_kernel_sat, dim3(count), dim3(PDMPC_THREADS), args->lds.total, (hipStream_t)stream, *args);
     return (int)hipGetLastError();
 }
