@@ -46,7 +46,7 @@ def build_world(args, rank):
         amount=args.vehicles,
         Hp=args.hp,
         mpa_type=MpaType[args.mpa],
-        max_vehicles=max(args.vehicles, 32),
+        max_vehicles=max(args.vehicles * (args.instances if args.workload == "c5" else 1), 32),
         max_nodes=args.max_nodes,
     )
     mpa = get_mpa(options)
@@ -55,17 +55,24 @@ def build_world(args, rank):
     return options, mpa, ctl
 
 
-def record_steps(options, mpa, ctl, optimizer, n_skip, n_record):
-    """Closed loop with the GPU planner (untimed); returns the recorded step problems."""
+def record_steps(options, mpa, ctl, optimizer, n_skip, n_record, explore_instances=0):
+    """Closed loop with the GPU planner (untimed); returns the recorded step problems.  With `explore_instances` every
+    recorded problem is the flattened batch of that many prioritizations of the step's traffic state (config c5); the
+    closed loop itself advances with the controller's own prioritization."""
     problems = []
 
     def plan_step(prob):
         problems.append(prob)
         return optimizer.run_optimizer_step(prob, mpa)
 
-    for _ in range(n_skip + n_record):
+    batches = []
+    for k in range(n_skip + n_record):
+        if explore_instances and k >= n_skip:
+            from pdmpc.explorative import build_exploration_batch
+
+            batches.append(build_exploration_batch(ctl, explore_instances, seed=ctl.k + 1))
         ctl.step(plan_step=plan_step)
-    return problems[n_skip:]
+    return batches if explore_instances else problems[n_skip:]
 
 
 def cpu_baseline(options, mpa, problems, budget_s):
@@ -109,7 +116,8 @@ def main():
     ap.add_argument("--max-nodes", type=int, default=1 << 17)
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--instances", type=int, default=64, help="c5: simultaneous prioritizations per time step")
     ap.add_argument("--shard", default="components", choices=["components", "levels"],
                     help="multi-GPU mode of c3/c4: whole coupling-graph components per rank (one speculative launch per rank and step, one "
                     "all-gather of results) or block-partitioned levels (one all-gather per level)")
@@ -123,6 +131,7 @@ def main():
         args.record = min(args.record, 8)
         args.skip = min(args.skip, 4)
         args.max_nodes = min(args.max_nodes, 1 << 15)
+    explore = args.workload == "c5"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -145,7 +154,7 @@ def main():
     optimizer = GraphSearchHip(options)
     optimizer._ensure_mpa(mpa)
     h = optimizer.handle
-    problems = record_steps(options, mpa, ctl, optimizer, args.skip, args.record)
+    problems = record_steps(options, mpa, ctl, optimizer, args.skip, args.record, args.instances if explore else 0)
     S = len(problems)
     parts = None
     full_problems = problems
@@ -255,7 +264,8 @@ def main():
             "config": {
                 "workload": "%s: %d vehicles on the CPM-lab road network (labmap fixture%s), Hp %d, InterX checker, %s MPA, "
                 "distance coupling, constant priorities, %s; %d recorded closed-loop steps replayed from HBM%s"
-                % (args.workload.upper(), args.vehicles, ", tiled" if sharded else "", args.hp, args.mpa,
+                % (args.workload.upper() + (" (%d prioritizations of each step flattened into one batch)" % args.instances if explore else ""),
+                   args.vehicles, ", tiled" if sharded and not explore else "", args.hp, args.mpa,
                    "levels sharded over ranks with one all-gather per level" if planner is not None else ("coupling-graph components sharded over ranks, one launch per rank and step, one all-gather of results" if gather_bufs is not None else "one launch per step"), S,
                    "" if sharded else "; per GPU one independent network"),
                 "vehicles": args.vehicles,

@@ -238,12 +238,15 @@ class PrioritizedSequentialController:
             return del_first_rpt_last(self.info_old[i].shapes)
         return None
 
-    def build_step_problem(self):
+    def build_step_problem(self, priorities=None, refresh=True):
         """Everything one launch needs to plan the whole time step: vehicles in level order (slot = position),
-        per-slot predecessor slots, per-slot areas to publish on exhaustion."""
-        self._traffic_info()
-        adjacency = self._couple()
-        directed = directed_coupling_from_priorities(adjacency, self.priorities)
+        per-slot predecessor slots, per-slot areas to publish on exhaustion.  `priorities` overrides the controller's
+        own (used by the explorative driver to build one problem per prioritization of the same traffic state)."""
+        if refresh:
+            self._traffic_info()
+            self.last_adjacency = self._couple()
+        adjacency = self.last_adjacency
+        directed = directed_coupling_from_priorities(adjacency, self.priorities if priorities is None else priorities)
         directed_seq = directed
         levels = kahn(directed_seq)
         self.last_levels = levels
@@ -253,7 +256,7 @@ class PrioritizedSequentialController:
         preds = [[slot_of[j] for j in range(self.n) if directed_seq[j, i]] for i in order]
         fallback = [self._published_on_exhaustion(i) for i in order]
         level_sizes = [int(np.sum(levels == l)) for l in range(1, int(levels.max()) + 1)]
-        return {"order": order, "iters": iters, "preds": preds, "fallback": fallback, "level_sizes": level_sizes}
+        return {"order": order, "iters": iters, "preds": preds, "fallback": fallback, "level_sizes": level_sizes, "levels": [int(levels[i]) for i in order]}
 
     def step(self, plan_step=None):
         """One pass of HighLevelController.main_control_loop (HighLevelController.m:334-373) in simulation.

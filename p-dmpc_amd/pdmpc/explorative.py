@@ -1,0 +1,106 @@
+"""Simultaneous computation of multiple prioritizations (BASELINE config 4).
+
+Restates the host side of the reference's explorative controller
+(hlc/controller/prioritized/PrioritizedExplorativeController.m):
+
+    computation_level_permutations   :241-309  Latin-square-like permutations of the computation levels; the first
+                                               row keeps the current prioritization (random draws use numpy here, the
+                                               reference uses MATLAB's mt19937ar stream seeded with the time step)
+    one plan per permutation         :25-91    every vehicle plans once per permutation
+    solution cost per sub-graph      :94-144   sum over the vehicles of a weakly connected sub-graph of the cost-to-come
+                                               of the final node, tree.get_cost(tree_path(end))
+    choose_solution                  :146-176  per sub-graph the permutation with the smallest cost after round(., 8)
+
+In the reference the permutations are planned one after the other by every vehicle process.  Here all K instances are
+flattened into ONE batch: instance p contributes its 20 vehicles with predecessor lists inside the instance; slots are
+ordered by (level, instance) so that the early levels of every instance are dispatched first.  Instances are independent
+coupling-graph components, so on several GPUs they shard without any collective (pdmpc.distributed.partition_components).
+"""
+import numpy as np
+
+from .controller import kahn, directed_coupling_from_priorities
+from .distributed import weak_components
+
+
+def computation_level_permutations(n_levels, n_perm, seed):
+    """(n_perm, n_levels) array, row 0 = identity.  Rows 1..n_levels-1 follow PrioritizedExplorativeController.m:241-309
+    (no column repeats a level: a Latin rectangle built by 'fewest possibilities first' with random choices and restart
+    on dead ends); further rows (n_perm > n_levels) are plain random permutations."""
+    rng = np.random.default_rng(seed)
+    rows = [list(range(1, n_levels + 1))]
+    while len(rows) < min(n_perm, n_levels):
+        allowed = np.ones((n_levels, n_levels), dtype=bool)  # [level, column]
+        for col in range(n_levels):
+            for r in rows:
+                allowed[r[col] - 1, col] = False
+        perm = [0] * n_levels
+        ok = True
+        for _ in range(n_levels):
+            counts = allowed.sum(axis=0)
+            col = int(np.argmin(counts))
+            if counts[col] == 0:
+                ok = False
+                break
+            choices = np.nonzero(allowed[:, col])[0]
+            lvl = int(choices[rng.integers(len(choices))])
+            perm[col] = lvl + 1
+            allowed[lvl, :] = False
+            allowed[:, col] = True  # never the column with the fewest possibilities again
+        if ok:
+            rows.append(perm)
+    while len(rows) < n_perm:
+        rows.append([int(v) + 1 for v in rng.permutation(n_levels)])
+    return np.array(rows[:n_perm], dtype=np.int64)
+
+
+def build_exploration_batch(ctl, n_perm, seed):
+    """One flattened step problem holding `n_perm` prioritizations of the controller's current traffic state.
+    Returns the problem (slots ordered by (level, instance)) with extra keys `instance` and `vehicle` per slot."""
+    base = ctl.build_step_problem()  # refreshes the traffic state and the adjacency
+    levels0 = kahn(directed_coupling_from_priorities(ctl.last_adjacency, ctl.priorities))
+    n_levels = int(levels0.max())
+    perms = computation_level_permutations(n_levels, n_perm, seed)
+    parts = []
+    for p in range(n_perm):
+        prio = [int(perms[p][levels0[v] - 1]) for v in range(ctl.n)]  # vehicles of one class share a (permuted) level
+        prob = base if p == 0 else ctl.build_step_problem(priorities=prio, refresh=False)
+        parts.append(prob)
+    flat = []
+    for p, prob in enumerate(parts):
+        for s in range(len(prob["iters"])):
+            flat.append((prob["levels"][s], p, s))
+    flat.sort()
+    slot_of = {(p, s): i for i, (_, p, s) in enumerate(flat)}
+    out = {"order": [], "iters": [], "preds": [], "fallback": [], "levels": [], "instance": [], "vehicle": []}
+    for lvl, p, s in flat:
+        prob = parts[p]
+        out["order"].append(prob["order"][s])
+        out["iters"].append(prob["iters"][s])
+        out["preds"].append([slot_of[(p, q)] for q in prob["preds"][s]])
+        out["fallback"].append(prob["fallback"][s])
+        out["levels"].append(lvl)
+        out["instance"].append(p)
+        out["vehicle"].append(prob["order"][s])
+    lv = np.array(out["levels"])
+    out["level_sizes"] = [int(np.sum(lv == l)) for l in range(1, int(lv.max()) + 1)]
+    out["n_instances"] = n_perm
+    out["adjacency"] = np.array(ctl.last_adjacency)
+    return out
+
+
+def choose_solution(batch, records, Hp):
+    """PrioritizedExplorativeController.m:94-176: per weakly connected sub-graph of the coupling graph, the instance with the
+    smallest summed cost-to-come of the final nodes after round(., 8).  Returns {sub-graph label: chosen instance} and the
+    cost table (instances x sub-graphs).  A vehicle whose search was exhausted makes its instance infinitely expensive."""
+    adj = batch["adjacency"]
+    n = adj.shape[0]
+    labels = weak_components([[j for j in range(n) if adj[i, j] or adj[j, i]] for i in range(n)])
+    graphs = sorted(set(labels))
+    K = batch["n_instances"]
+    cost = np.zeros((K, len(graphs)))
+    for slot, (p, v) in enumerate(zip(batch["instance"], batch["vehicle"])):
+        rec = records[slot]
+        c = float(rec["path_nodes"][Hp][4]) if int(rec["status"]) == 0 else np.inf
+        cost[p, graphs.index(labels[v])] += c
+    cost = np.round(cost, 8)
+    return {g: int(np.argmin(cost[:, gi])) for gi, g in enumerate(graphs)}, cost

@@ -114,3 +114,34 @@ def test_tiled_512_vehicles_hp10_one_launch():
     options = Config(scenario_type=ScenarioType.commonroad, amount=512, Hp=10, max_vehicles=512, max_nodes=1 << 14)
     sc = commonroad_scenario(options, seed=3, tiles=26)
     run_closed_loop(options, sc, "distance", boundary_provider(sc), 2)
+
+
+def test_explorative_batch_of_prioritizations_one_launch():
+    """BASELINE config 4 shape: several prioritizations of the same traffic state flattened into one launch
+    (PrioritizedExplorativeController.m:25-176), records identical to the oracle, same chosen prioritization."""
+    from oracle import oracle
+    from pdmpc.explorative import build_exploration_batch, choose_solution
+    from pdmpc.optimizer import GraphSearchHip
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    options = Config(scenario_type=ScenarioType.commonroad, amount=20, Hp=8, max_vehicles=20 * 12, max_nodes=1 << 15)
+    mpa = get_mpa(options)
+    sc = commonroad_scenario(options, seed=1)
+    opt = GraphSearchHip(options)
+    ctl = PrioritizedSequentialController(options, sc, mpa, None, coupling="distance", boundary_provider=boundary_provider(sc))
+    for _ in range(3):
+        ctl.step(plan_step=lambda prob: opt.run_optimizer_step(prob, mpa))
+    batch = build_exploration_batch(ctl, 12, seed=4)
+    assert len(batch["iters"]) == 240 and batch["n_instances"] == 12
+    n = len(batch["iters"])
+    fb = [f if f is not None else [] for f in batch["fallback"]]
+    opt.handle.pack_step(batch["iters"], batch["preds"], fb)
+    opt.handle.launch()
+    gpu = opt.handle.fetch(n)
+    ref, _ = oracle.plan_step(options, mpa, batch)
+    assert_records_equal(gpu, ref, "explorative batch")
+    chosen_gpu, cost_gpu = choose_solution(batch, gpu, options.Hp)
+    chosen_ref, cost_ref = choose_solution(batch, ref, options.Hp)
+    assert chosen_gpu == chosen_ref and np.array_equal(cost_gpu, cost_ref)
+    assert np.isfinite(cost_gpu[0]).all()  # the current prioritization is feasible
+    opt.handle.close()
