@@ -12,7 +12,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libpdmpc_hip.so")
+LIB_PATH = os.environ.get("PDMPC_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libpdmpc_hip.so")
 
 _LIB = None
 

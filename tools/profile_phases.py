@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "p-dmpc_amd"), os.path.join(ROOT, "tests")]
 import numpy as np
 from pdmpc import backend
-backend.LIB_PATH = os.path.join(ROOT, "p-dmpc_amd", "csrc", "libpdmpc_hip_prof.so")
+backend.LIB_PATH = os.environ.get("PDMPC_PROF_LIB", os.path.join(ROOT, "p-dmpc_amd", "csrc", "libpdmpc_hip_prof.so"))
 from pdmpc.backend import Handle
 import problems
 
