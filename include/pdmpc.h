@@ -213,6 +213,13 @@ int pdmpc_debug_heap_script(pdmpc_handle* handle, int32_t n, const int32_t* op, 
                             int32_t lds_entries, int32_t* popped, int32_t* n_popped, double* cycles_per_pop,
                             double* cycles_per_push);
 
+/* the same for the block-min open list the search uses while the minimal key is unique (csrc/blockmin_queue.hpp): ids are
+ * implicit (the i-th push is node i, 1-based), ring_entries = keys kept in LDS (power of two >= 64).  *tie = 1 if some pop
+ * found its minimal key twice, in which case the search would have fallen back to the binary heap. */
+int pdmpc_debug_blockmin_script(pdmpc_handle* handle, int32_t n, const int32_t* op, const double* key, int32_t ring_entries,
+                                int32_t* popped, int32_t* n_popped, int32_t* tie, double* cycles_per_pop,
+                                double* cycles_per_push);
+
 const char* pdmpc_last_error(void);
 const char* pdmpc_version(void);
 

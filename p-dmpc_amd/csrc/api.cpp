@@ -730,6 +730,45 @@ int pdmpc_debug_heap_script(pdmpc_handle* h, int32_t n, const int32_t* op, const
     return PDMPC_OK;
 }
 
+int pdmpc_debug_blockmin_script(pdmpc_handle* h, int32_t n, const int32_t* op, const double* key, int32_t ring_entries, int32_t* popped,
+                                int32_t* n_popped, int32_t* tie, double* cycles_per_pop, double* cycles_per_push) {
+    if (!h || n < 0 || (n > 0 && (!op || !key)) || !popped || !n_popped || !tie) return fail(PDMPC_ERR_INVALID, "null argument");
+    if (ring_entries < 64 || ring_entries > 8192 || (ring_entries & (ring_entries - 1))) return fail(PDMPC_ERR_INVALID, "ring_entries must be a power of two in 64..8192");
+    int n_push = 0;
+    for (int i = 0; i < n; ++i) n_push += op[i] == 0;
+    if (n_push > 64 * 4096) return fail(PDMPC_ERR_INVALID, "at most 262144 pushes");
+    const int NB = (n_push + 63) / 64 + 64;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    int32_t *d_op = nullptr, *d_out = nullptr;
+    double *d_key = nullptr, *d_gkey = nullptr;
+    unsigned long long* d_stats = nullptr;
+    const size_t m = (size_t)std::max(n, 1);
+    HIPCHK(hipMalloc((void**)&d_op, m * 4));
+    HIPCHK(hipMalloc((void**)&d_out, m * 4));
+    HIPCHK(hipMalloc((void**)&d_key, m * 8));
+    HIPCHK(hipMalloc((void**)&d_gkey, ((size_t)n_push + 128) * 8));
+    HIPCHK(hipMalloc((void**)&d_stats, 8 * 8));
+    HIPCHK(hipMemcpy(d_op, op, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_key, key, (size_t)n * 8, hipMemcpyHostToDevice));
+    int lrc = pdmpc_launch_bm_script(d_op, d_key, n, d_out, d_stats, d_gkey, ring_entries, NB, (void*)h->stream);
+    if (lrc != 0) return fail(PDMPC_ERR_HIP, "block-min script launch failed");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    unsigned long long st[5];
+    HIPCHK(hipMemcpy(st, d_stats, sizeof st, hipMemcpyDeviceToHost));
+    const int cnt = n - n_push;
+    *n_popped = cnt;
+    *tie = (int32_t)st[4];
+    if (cnt > 0) HIPCHK(hipMemcpy(popped, d_out, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+    if (cycles_per_pop) *cycles_per_pop = st[1] ? (double)st[0] / (double)st[1] : 0.0;
+    if (cycles_per_push) *cycles_per_push = st[3] ? (double)st[2] / (double)st[3] : 0.0;
+    (void)hipFree(d_op);
+    (void)hipFree(d_out);
+    (void)hipFree(d_key);
+    (void)hipFree(d_gkey);
+    (void)hipFree(d_stats);
+    return PDMPC_OK;
+}
+
 int pdmpc_debug_pop_trace(pdmpc_handle* h, int32_t vehicle, int32_t capacity, int32_t* ids, int32_t* n) {
     if (!h || !ids || !n) return fail(PDMPC_ERR_INVALID, "null argument");
     if (h->cfg.trace_pops <= 0) return fail(PDMPC_ERR_INVALID, "handle was created with trace_pops == 0");

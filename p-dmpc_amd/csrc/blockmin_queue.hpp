@@ -1,0 +1,146 @@
+// Block-min open list (device code, included by search_kernel.hip inside its anonymous namespace).
+//
+// The reference's open list is a std::priority_queue (priority_queue_interface_mex.cpp:23-29): which of several
+// entries with EQUAL minimal key it pops depends on the layout of its binary heap.  As long as the minimal key is
+// unique at every pop, the pop sequence is a function of the key set alone and any exact priority queue reproduces
+// it.  This queue is built for one 64-lane wavefront and certifies that uniqueness at every pop; the first tie makes
+// the search start over on the libstdc++-faithful binary heap (heap_push / heap_pop), so results never depend on it.
+// Measured on the closed-loop C2 workload: 0 tied pops in 311 235 (tools/tie_frequency.py).
+//
+// Layout: the entry of node i (0-based tree index; nodes are pushed exactly once, in index order) is key[i], +inf
+// once popped.  m1[b] = min key of block b = nodes [64 b, 64 b + 64); m2[g] = min of m1[64 g .. 64 g + 64).
+//   push of up to 64 consecutive nodes   one key store per lane + two LDS atomic-min per lane
+//   pop                                  three dependent 64-wide loads (m2, m1 of the best group, keys of the best block),
+//                                        one wave min-reduction each, two more to repair m1[b] and m2[g]
+// Keys of the KR most recent nodes sit in an LDS ring (slot = i & (KR - 1)); every key is also written through to
+// HBM, which is where blocks older than the ring are read from.  Keys are non-negative finite doubles (sums of
+// squares), so their bit patterns order like unsigned integers: the atomics are ds_min_u64.
+#pragma once
+
+typedef LDS_AS unsigned long long lds_u64;
+
+#define BM_INF_BITS 0x7FF0000000000000ull
+
+struct BmQueue {
+    lds_f64* kring;  // [KR]
+    lds_f64* m1;     // [nb_max]
+    lds_f64* m2;     // [64]
+    double* gkey;    // [max_nodes]
+    uint32_t kr_mask;
+    uint32_t nb_max;
+    uint32_t open;  // entries currently in the queue
+    bool tie;       // a pop found its minimal key more than once: the pop order is not certified any more
+};
+
+__device__ __forceinline__ double bm_inf() { return __longlong_as_double((long long)BM_INF_BITS); }
+
+// unsigned minimum over the 64 lanes; lane 63 of the result holds it.  v_min_u32 takes its DPP-permuted operand
+// directly, so a step is one VALU instruction (plus the two wait states a DPP read of a just-written VGPR needs).
+__device__ __forceinline__ uint32_t wave_min_u32_lane63(uint32_t v) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"  // every lane: minimum of its row of 16
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"  // rows 1, 3 take in rows 0, 2
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"  // rows 2, 3 take in lane 31
+        "s_nop 1"
+        : "+v"(v));
+    return v;
+}
+// minimum over the 64 lanes of non-negative doubles (no NaNs), uniform result: their bit patterns order like unsigned
+// integers, so the high words are reduced first and the low words among the lanes that hold the minimal high word
+__device__ __forceinline__ double wave_min_d(double x) {
+    const uint64_t u = (uint64_t)__double_as_longlong(x);
+    const uint32_t hi = (uint32_t)(u >> 32), lo = (uint32_t)u;
+    const uint32_t mh = (uint32_t)__builtin_amdgcn_readlane((int)wave_min_u32_lane63(hi), 63);
+    const uint32_t ml = (uint32_t)__builtin_amdgcn_readlane((int)wave_min_u32_lane63(hi == mh ? lo : 0xFFFFFFFFu), 63);
+    return __longlong_as_double((long long)(((uint64_t)mh << 32) | ml));
+}
+
+__device__ __forceinline__ void bm_init(BmQueue& Q, int tid, int nthreads) {
+    const double inf = bm_inf();
+    for (uint32_t i = (uint32_t)tid; i < Q.nb_max; i += (uint32_t)nthreads) Q.m1[i] = inf;
+    for (uint32_t i = (uint32_t)tid; i < 64u; i += (uint32_t)nthreads) Q.m2[i] = inf;
+}
+
+// Push the nodes i0 (0-based, consecutive over the active lanes, all >= nn_before) with keys f.  Whole wave calls;
+// `active` selects the lanes that carry a node.  nn_after = tree size after this batch.
+__device__ __forceinline__ void bm_push(BmQueue& Q, bool active, uint32_t i0, double f, uint32_t nn_before, uint32_t nn_after) {
+    // entering a second group for the first time: m2 is not maintained while there is a single group
+    if (nn_before <= 4096u && nn_after > 4096u) {
+        const int lane = (int)(threadIdx.x & 63u);
+        const double v = wave_min_d(Q.m1[lane]);
+        if (lane == 0) Q.m2[0] = v;
+    }
+    if (active) {
+        Q.kring[i0 & Q.kr_mask] = f;
+        Q.gkey[i0] = f;
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(f);
+        __hip_atomic_fetch_min((lds_u64*)&Q.m1[i0 >> 6], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (nn_after > 4096u) __hip_atomic_fetch_min((lds_u64*)&Q.m2[i0 >> 12], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    Q.open += (uint32_t)__builtin_popcountll(__ballot(active));
+}
+
+// Pop the entry with the minimal key: returns its 0-based node index, or 0xFFFFFFFF if the queue is empty.
+// nn = current tree size.  Sets Q.tie if the minimum was not unique (the caller must then discard the search).
+__device__ __forceinline__ uint32_t bm_pop(BmQueue& Q, uint32_t nn) {
+    const int lane = (int)(threadIdx.x & 63u);
+    const double inf = bm_inf();
+    const bool multi = nn > 4096u;
+    uint32_t g = 0;
+    if (multi) {
+        const double v2 = Q.m2[lane];
+        const double mn2 = wave_min_d(v2);
+        if (!(mn2 < inf)) return 0xFFFFFFFFu;
+        const unsigned long long b2 = __ballot(v2 == mn2);
+        if (b2 & (b2 - 1ull)) Q.tie = true;
+        g = (uint32_t)__builtin_ctzll(b2);
+    }
+    const double v1 = Q.m1[g * 64u + (uint32_t)lane];  // m1 is +inf beyond the last block
+    const double mn1 = wave_min_d(v1);
+    if (!(mn1 < inf)) return 0xFFFFFFFFu;
+    const unsigned long long b1 = __ballot(v1 == mn1);
+    if (b1 & (b1 - 1ull)) Q.tie = true;
+    const uint32_t bl = (uint32_t)__builtin_ctzll(b1);
+    const uint32_t b = g * 64u + bl;
+    const uint32_t idx = b * 64u + (uint32_t)lane;
+    // the ring holds the nodes [nn - KR, nn): a block that starts inside it is read from LDS, older ones from HBM
+    const bool in_ring = b * 64u + Q.kr_mask + 1u >= nn;
+    double k;
+    if (in_ring) {
+        k = Q.kring[idx & Q.kr_mask];
+    } else {
+        k = Q.gkey[idx];
+        // wait here, not after the join: there the wait would also be paid on the LDS path, where it only drains this
+        // wave's earlier HBM stores (gfx9 counts loads and stores in the same vmcnt)
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    }
+    if (idx >= nn) k = inf;  // slots of nodes that do not exist yet hold stale keys
+    const unsigned long long b0 = __ballot(k == mn1);
+    if (b0 & (b0 - 1ull)) Q.tie = true;
+    const uint32_t e = (uint32_t)__builtin_ctzll(b0);
+    const uint32_t cur = b * 64u + e;
+    // remove: key -> +inf, m1[b] = min of the rest, m2[g] = min over the group's blocks
+    const double krest = (uint32_t)lane == e ? inf : k;
+    const double new1 = wave_min_d(krest);
+    if ((uint32_t)lane == e) {
+        if (in_ring) Q.kring[idx & Q.kr_mask] = inf;
+        Q.gkey[idx] = inf;
+        Q.m1[b] = new1;
+    }
+    if (multi) {
+        const double v1r = (uint32_t)lane == bl ? new1 : v1;
+        const double new2 = wave_min_d(v1r);
+        if (lane == 0) Q.m2[g] = new2;
+    }
+    --Q.open;
+    return cur;
+}

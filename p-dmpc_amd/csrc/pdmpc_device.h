@@ -122,6 +122,8 @@ int pdmpc_launch_search(const KernelArgs* args, int count, void* stream);
 // defined in search_kernel.hip; runs the open-list command script on one wavefront (debug / unit test)
 int pdmpc_launch_heap_script(const int32_t* op, const int32_t* id, const double* key, int n, int32_t* out, unsigned long long* stats,
                              double* gkey, uint32_t* gid, int HL, void* stream);
+int pdmpc_launch_bm_script(const int32_t* op, const double* key, int n, int32_t* out, unsigned long long* stats, double* gkey, int KR, int NB,
+                           void* stream);
 #ifdef __cplusplus
 }
 #endif

@@ -341,6 +341,9 @@ __device__ __forceinline__ void heap_pop(Search& S) {
         heap_pop_impl<false>(S, len);
 }
 
+#include "blockmin_queue.hpp"
+
+
 // ---------------------------------------------------------------------------------------------------
 // are_constraints_satisfied_interx.m:17-37 + InterX.m:63-76,108-110.
 // The three soups (vehicle obstacles of step k -> shape A, HDV sets of step k -> shape A, lanelet boundary ->
@@ -808,220 +811,56 @@ __device__ bool arrival_sync(const Search& S, const CheckCtx& C, const SpecCtx& 
 
 }  // namespace
 
-// The kernel body, specialised at compile time on the constraint checker so each variant carries only its own
-// collision code (the search is instruction-cache and issue bound: smaller is faster).
-template <int CHECKER>
-__device__ __forceinline__ void search_body(const KernelArgs& A) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & (PDMPC_WAVE - 1);
-    const int wave = uni_i(tid >> 6);
-    const int slot = A.first + blockIdx.x;
-    const int Hp = A.Hp;
-    const int n = A.n_trims;
-    const int nw = A.n_words;
-    const DevVehicle* __restrict__ V = A.veh + slot;
-#ifdef PDMPC_PROFILE
-    const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();
-#endif
-
-    // ---- LDS carve
-    uint64_t* l_mask = (uint64_t*)(smem + A.lds.mask);
-    int16_t* l_mi = (int16_t*)(smem + A.lds.man_index);
-    DevManPose* l_pose = (DevManPose*)(smem + A.lds.pose);
-    double* l_rx = (double*)(smem + A.lds.ref);
-    double* l_ry = l_rx + PDMPC_HP_MAX;
-    double* l_dtv = l_ry + PDMPC_HP_MAX;
-    uint32_t* l_path = (uint32_t*)(smem + A.lds.path);
-    int32_t* l_soff = (int32_t*)(l_path + PDMPC_HP_MAX + 2);  // soup offsets [Hp+1], hdv offsets [Hp+1]
-    int32_t* l_hoff = l_soff + PDMPC_HP_MAX + 1;
-    volatile uint32_t* l_shared = (volatile uint32_t*)(l_hoff + PDMPC_HP_MAX + 1);
-    int32_t* l_lit = (int32_t*)(l_shared + SH_WORDS);  // literal soup length per step
-    d2* l_soup = (d2*)(smem + A.lds.soup);
+// Everything the search loops need from the prologue (LDS carve, per-vehicle state) and what they hand to the epilogue.
+struct Ctx {
+    int tid, lane, wave, slot, Hp, n, nw;
+    const DevVehicle* V;
+    uint64_t* l_mask;
+    int16_t* l_mi;
+    DevManPose* l_pose;
+    double *l_rx, *l_ry;
+    volatile uint32_t* l_shared;
     VState VS;
-    VS.l = (volatile uint8_t*)(smem + A.lds.vstate);
-    VS.NV = (uint32_t)A.NV;
-    double* l_dcum = (double*)(smem + A.lds.expand);               // [HP_MAX][HP_MAX] cumulative dt*v_ref per (k_exp, t)
-    double* l_term = l_dcum + PDMPC_HP_MAX * PDMPC_HP_MAX;         // [16 children][HP_MAX] cost-to-go terms
-    d2* l_chxy = (d2*)(l_term + 16 * PDMPC_HP_MAX);                // [16] child positions
-
+    double *l_dcum, *l_term;
+    d2* l_chxy;
     Search S;
-    S.ln = (lds_d2*)(smem + A.lds.nodes);
-    S.lkey = (lds_f64*)(smem + A.lds.heap_key);
-    S.lid = (lds_u32*)(smem + A.lds.heap_id);
-    S.NL = (uint32_t)A.NL;
-    S.HL = (uint32_t)A.HL;
-    S.max_nodes = A.max_nodes;
-    S.lane = lane;
-    S.pl = make_pop_lane(lane);
-    const size_t voff = (size_t)slot * A.max_nodes;
-    S.gn = A.arena.nodes + voff;
-    S.gkey = A.arena.heap_key + voff;
-    S.gid = A.arena.heap_id + voff;
-    VS.g = A.arena.vstate + voff;
-
     CheckCtx C;
-    C.l_area = (const d2*)(smem + A.lds.area);
-    C.g_area = (const d2*)A.man_area;
-    C.l_soup = l_soup;
-    C.l_soff = l_soff;
-    C.l_hoff = l_hoff;
-    C.areas_in_lds = A.areas_in_lds;
-    C.Hp = Hp;
-    C.checker = A.checker;
-    C.sh = (d2*)(smem + A.lds.shape) + wave * 2 * PDMPC_VMAX;
-    C.cand = (uint32_t*)(smem + A.lds.cand) + (size_t)wave * A.cand_cap;
-
-    pdmpc_vehicle_out* __restrict__ O = A.out + slot;
-
-    // ---- prologue 1: stage MPA tables (coalesced 16-byte copies; the host pads every table to 16 B)
-    {
-        const int mask_bytes = Hp * n * nw * 8;
-        stage16(l_mask, A.succ_mask, (mask_bytes + 15) / 16, tid);
-        stage16(l_mi, A.man_index, (n * n * 2 + 15) / 16, tid);
-        stage16(l_pose, A.man_pose, A.n_man * 2, tid);
-        if (A.areas_in_lds) stage16(smem + A.lds.area, A.man_area, A.n_man * 3 * PDMPC_VMAX, tid);
-    }
-    // ---- prologue 2: vehicle record, result record defaults
-    if (tid < Hp) {
-        l_rx[tid] = V->ref_x[tid];
-        l_ry[tid] = V->ref_y[tid];
-        l_dtv[tid] = A.dt * V->v_ref[tid];  // options.dt_seconds * iter.v_ref(k)   expand_node.m:70
-    }
-    if (tid >= PDMPC_WAVE && tid < PDMPC_WAVE + Hp) {
-        // d_traveled_max of expand_node.m:66-70 for every expansion step k_exp = tid - 63 (1-based): the running sum
-        // dt*v_ref(k_exp+1) + ... in the reference's order, so the bits match the in-loop accumulation
-        const int k_exp = tid - PDMPC_WAVE + 1;
-        double d = 0.0;
-        for (int it = 1; it <= Hp - k_exp; ++it) {
-            d = d + A.dt * V->v_ref[k_exp + it - 1];
-            l_dcum[(k_exp - 1) * PDMPC_HP_MAX + (it - 1)] = d;
-        }
-    }
-    if (tid == 0) {
-        for (int i = 0; i < SH_WORDS; ++i) l_shared[i] = 0;
-    }
-    {
-        // zero the record; y_predicted starts as NaN (ControlResultsInfo.m:40)
-        double* od = (double*)O;
-        const int nd = (int)(sizeof(pdmpc_vehicle_out) / 8);
-        const int y0 = (int)(offsetof(pdmpc_vehicle_out, y_predicted) / 8);
-        const double qnan = __longlong_as_double(0x7ff8000000000000LL);
-        for (int i = tid; i < nd; i += PDMPC_THREADS) od[i] = (i >= y0 && i < y0 + PDMPC_HP_MAX * 3) ? qnan : 0.0;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // later result stores hit the same bytes from other lanes
-    }
-    __syncthreads();
-
-    // ---- prologue 3: obstacle soup of every step: [literal polygons + NaN][predecessor areas padded to VMAX]
-    const int n_pred = V->n_pred;
-    const int pred_cols = n_pred * PDMPC_VMAX;
-    {
-        int off = 0;
-        for (int k = 0; k < Hp; ++k) {
-            const int a = V->lit_off[k], b = V->lit_off[k + 1];
-            if (tid == 0) {
-                l_soff[k] = off;
-                l_lit[k] = b - a;
-            }
-            stage16(l_soup + off, (const d2*)A.points + a, b - a, tid);
-            off += (b - a) + pred_cols;
-        }
-        if (tid == 0) l_soff[Hp] = off;
-        for (int k = 0; k < Hp; ++k) {
-            const int a = V->hdv_off[k], b = V->hdv_off[k + 1];
-            if (tid == 0) l_hoff[k] = off;
-            stage16(l_soup + off, (const d2*)A.points + a, b - a, tid);
-            off += (b - a);
-        }
-        if (tid == 0) l_hoff[Hp] = off;
-        // lanelet soup last
-        stage16(l_soup + off, (const d2*)A.points + V->ll_off, V->ll_len, tid);
-        if (tid == 0) l_path[PDMPC_HP_MAX + 1] = (uint32_t)off;
-    }
-    __syncthreads();
-    C.ll_base = uni_i((int)l_path[PDMPC_HP_MAX + 1]);
-    C.ll_len = uni_i(V->ll_len);
-
-    // ---- prologue 4: predecessors (PrioritizedController.m:476-491).  Their soup slots start as NaN (no obstacle).
-    // Predecessors that have already finished are incorporated now; the others are "pending": the search starts
-    // without them and arrival_sync() folds them in when they finish (speculation, see arrival_sync).
     SpecCtx P;
-    P.sh = l_shared;
-    P.l_soup = l_soup;
-    P.l_soff = l_soff;
-    P.l_lit = l_lit;
-    P.out = A.out;
-    P.pred = A.pred + V->pred_off;
-    P.n_pred = n_pred;
-    P.Hp = Hp;
-    bool dep_timeout = false;
-    // the arrival re-check (node_hits_areas) implements the InterX predicate; the convex/SAT checker (circle scenario,
-    // a handful of vehicles) simply waits for its predecessors as the reference does
-    const bool speculate = A.speculate && n_pred <= 64 && CHECKER == PDMPC_CHECK_INTERX;
-    if (n_pred > 0) {
-        const d2 nanpt = d2{__longlong_as_double(0x7ff8000000000000LL), __longlong_as_double(0x7ff8000000000000LL)};
-        for (int idx = tid; idx < Hp * pred_cols; idx += PDMPC_THREADS) {
-            const int k = idx / pred_cols;
-            l_soup[l_soff[k] + l_lit[k] + (idx - k * pred_cols)] = nanpt;
-        }
-        if (!speculate) {
-            // blocking wait (more than 64 predecessors, or speculation switched off)
-            for (int p = 0; p < n_pred; ++p) {
-                uint32_t spins = 0;
-                while (__hip_atomic_load(A.done_flag + P.pred[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != A.epoch) {
-                    __builtin_amdgcn_s_sleep(8);
-                    if (++spins > A.spin_limit) {
-                        dep_timeout = true;
-                        break;
-                    }
-                }
-            }
-        }
-        unsigned long long ready = 0;
-        if (wave == 0) {
-            bool d = false;
-            if (lane < n_pred) d = __hip_atomic_load(A.done_flag + P.pred[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == A.epoch;
-            ready = __ballot(d);
-            if (!speculate) ready = (n_pred >= 64) ? ~0ull : ((1ull << n_pred) - 1ull);
-            if (lane == 0) {
-                const unsigned long long all = (n_pred >= 64) ? ~0ull : ((1ull << n_pred) - 1ull);
-                const unsigned long long pend = speculate ? (all & ~ready) : 0ull;
-                l_shared[SH_PEND_LO] = (uint32_t)pend;
-                l_shared[SH_PEND_HI] = (uint32_t)(pend >> 32);
-                l_shared[SH_ARR_LO] = (uint32_t)ready;
-                l_shared[SH_ARR_HI] = (uint32_t)(ready >> 32);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-        if (!speculate) {  // n_pred may exceed 64: incorporate everything directly
-            const double qnan = __longlong_as_double(0x7ff8000000000000LL);
-            for (int idx = tid; idx < Hp * pred_cols; idx += PDMPC_THREADS) {
-                const int k = idx / pred_cols;
-                const int r = idx - k * pred_cols;
-                const int p = r / PDMPC_VMAX;
-                const int v = r - p * PDMPC_VMAX;
-                const pdmpc_vehicle_out* PO = A.out + P.pred[p];
-                const int cols = PO->shape_cols[k];
-                d2 pt;
-                pt.x = qnan;
-                pt.y = qnan;
-                if (v < cols) {
-                    pt.x = PO->shapes[k][0][v];
-                    pt.y = PO->shapes[k][1][v];
-                }
-                l_soup[l_soff[k] + l_lit[k] + r] = pt;
-            }
-        } else {
-            incorporate_areas(P, sh_load64(l_shared, SH_ARR_LO), tid);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            l_shared[SH_ARR_LO] = 0;
-            l_shared[SH_ARR_HI] = 0;
-        }
-    }
+    pdmpc_vehicle_out* O;
+    BmQueue Q;
+    lds_u32* l_cand;  // block-min mode: node ids the scout wave proposes for pre-validation
+    // results
+    int status, n_popped;
+    uint32_t goal, nnodes;
+    bool dep_timeout;
+#ifdef PDMPC_PROFILE
+    unsigned long long rt_start;
+#endif
+};
+
+// The search proper: root node, sequencing wave, helper waves, and the wait for predecessors that are still planning.
+// BM = false: the libstdc++-faithful binary heap (exact for any keys).  BM = true: the block-min queue, which is only
+// exact while the minimal key is unique; returns true (to every wave) if it met a tie and the search must be redone.
+template <int CHECKER, bool BM>
+__device__ bool search_loops(const KernelArgs& A, Ctx& X) {
+    const int tid = X.tid, lane = X.lane, wave = X.wave, slot = X.slot, Hp = X.Hp, n = X.n, nw = X.nw;
+    const DevVehicle* __restrict__ V = X.V;
+    uint64_t* l_mask = X.l_mask;
+    int16_t* l_mi = X.l_mi;
+    DevManPose* l_pose = X.l_pose;
+    double *l_rx = X.l_rx, *l_ry = X.l_ry;
+    volatile uint32_t* l_shared = X.l_shared;
+    const VState& VS = X.VS;
+    double *l_dcum = X.l_dcum, *l_term = X.l_term;
+    d2* l_chxy = X.l_chxy;
+    Search& S = X.S;
+    const CheckCtx& C = X.C;
+    const SpecCtx& P = X.P;
+    pdmpc_vehicle_out* __restrict__ O = X.O;
+    bool dep_timeout = X.dep_timeout;
+    (void)V;
+    (void)O;
+    (void)slot;
 
     // ---- root node (GraphSearch.m:34-46)
     uint32_t nnodes = 1;
@@ -1301,9 +1140,9 @@ __device__ __forceinline__ void search_body(const KernelArgs& A) {
         {
             for (int i = 0; i < PROF_N; ++i) ((double*)O->shapes[PDMPC_HP_MAX - 1])[i] = (double)S.prof_acc[i];  // unused tail of the record
             const unsigned long long rt_end = __builtin_amdgcn_s_memrealtime();
-            O->path_nodes[PDMPC_HP_MAX][0] = (double)(rt_search - rt_start);  // 100 MHz ticks: prologue + predecessor wait
+            O->path_nodes[PDMPC_HP_MAX][0] = (double)(rt_search - X.rt_start);  // 100 MHz ticks: prologue + predecessor wait
             O->path_nodes[PDMPC_HP_MAX][1] = (double)(rt_end - rt_search);    // search
-            O->path_nodes[PDMPC_HP_MAX][2] = (double)rt_start;
+            O->path_nodes[PDMPC_HP_MAX][2] = (double)X.rt_start;
             O->path_nodes[PDMPC_HP_MAX][3] = (double)rt_end;
         }
 #endif
@@ -1338,6 +1177,263 @@ __device__ __forceinline__ void search_body(const KernelArgs& A) {
             }
         }
     }
+    X.status = status;
+    X.n_popped = n_popped;
+    X.goal = goal;
+    X.nnodes = nnodes;
+    X.dep_timeout = dep_timeout;
+    return false;
+}
+
+// The kernel body, specialised at compile time on the constraint checker so each variant carries only its own
+// collision code (the search is instruction-cache and issue bound: smaller is faster).
+template <int CHECKER>
+__device__ __forceinline__ void search_body(const KernelArgs& A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & (PDMPC_WAVE - 1);
+    const int wave = uni_i(tid >> 6);
+    const int slot = A.first + blockIdx.x;
+    const int Hp = A.Hp;
+    const int n = A.n_trims;
+    const int nw = A.n_words;
+    const DevVehicle* __restrict__ V = A.veh + slot;
+#ifdef PDMPC_PROFILE
+    const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    // ---- LDS carve
+    uint64_t* l_mask = (uint64_t*)(smem + A.lds.mask);
+    int16_t* l_mi = (int16_t*)(smem + A.lds.man_index);
+    DevManPose* l_pose = (DevManPose*)(smem + A.lds.pose);
+    double* l_rx = (double*)(smem + A.lds.ref);
+    double* l_ry = l_rx + PDMPC_HP_MAX;
+    double* l_dtv = l_ry + PDMPC_HP_MAX;
+    uint32_t* l_path = (uint32_t*)(smem + A.lds.path);
+    int32_t* l_soff = (int32_t*)(l_path + PDMPC_HP_MAX + 2);  // soup offsets [Hp+1], hdv offsets [Hp+1]
+    int32_t* l_hoff = l_soff + PDMPC_HP_MAX + 1;
+    volatile uint32_t* l_shared = (volatile uint32_t*)(l_hoff + PDMPC_HP_MAX + 1);
+    int32_t* l_lit = (int32_t*)(l_shared + SH_WORDS);  // literal soup length per step
+    d2* l_soup = (d2*)(smem + A.lds.soup);
+    VState VS;
+    VS.l = (volatile uint8_t*)(smem + A.lds.vstate);
+    VS.NV = (uint32_t)A.NV;
+    double* l_dcum = (double*)(smem + A.lds.expand);               // [HP_MAX][HP_MAX] cumulative dt*v_ref per (k_exp, t)
+    double* l_term = l_dcum + PDMPC_HP_MAX * PDMPC_HP_MAX;         // [16 children][HP_MAX] cost-to-go terms
+    d2* l_chxy = (d2*)(l_term + 16 * PDMPC_HP_MAX);                // [16] child positions
+
+    Search S;
+    S.ln = (lds_d2*)(smem + A.lds.nodes);
+    S.lkey = (lds_f64*)(smem + A.lds.heap_key);
+    S.lid = (lds_u32*)(smem + A.lds.heap_id);
+    S.NL = (uint32_t)A.NL;
+    S.HL = (uint32_t)A.HL;
+    S.max_nodes = A.max_nodes;
+    S.lane = lane;
+    S.pl = make_pop_lane(lane);
+    const size_t voff = (size_t)slot * A.max_nodes;
+    S.gn = A.arena.nodes + voff;
+    S.gkey = A.arena.heap_key + voff;
+    S.gid = A.arena.heap_id + voff;
+    VS.g = A.arena.vstate + voff;
+
+    CheckCtx C;
+    C.l_area = (const d2*)(smem + A.lds.area);
+    C.g_area = (const d2*)A.man_area;
+    C.l_soup = l_soup;
+    C.l_soff = l_soff;
+    C.l_hoff = l_hoff;
+    C.areas_in_lds = A.areas_in_lds;
+    C.Hp = Hp;
+    C.checker = A.checker;
+    C.sh = (d2*)(smem + A.lds.shape) + wave * 2 * PDMPC_VMAX;
+    C.cand = (uint32_t*)(smem + A.lds.cand) + (size_t)wave * A.cand_cap;
+
+    pdmpc_vehicle_out* __restrict__ O = A.out + slot;
+
+    // ---- prologue 1: stage MPA tables (coalesced 16-byte copies; the host pads every table to 16 B)
+    {
+        const int mask_bytes = Hp * n * nw * 8;
+        stage16(l_mask, A.succ_mask, (mask_bytes + 15) / 16, tid);
+        stage16(l_mi, A.man_index, (n * n * 2 + 15) / 16, tid);
+        stage16(l_pose, A.man_pose, A.n_man * 2, tid);
+        if (A.areas_in_lds) stage16(smem + A.lds.area, A.man_area, A.n_man * 3 * PDMPC_VMAX, tid);
+    }
+    // ---- prologue 2: vehicle record, result record defaults
+    if (tid < Hp) {
+        l_rx[tid] = V->ref_x[tid];
+        l_ry[tid] = V->ref_y[tid];
+        l_dtv[tid] = A.dt * V->v_ref[tid];  // options.dt_seconds * iter.v_ref(k)   expand_node.m:70
+    }
+    if (tid >= PDMPC_WAVE && tid < PDMPC_WAVE + Hp) {
+        // d_traveled_max of expand_node.m:66-70 for every expansion step k_exp = tid - 63 (1-based): the running sum
+        // dt*v_ref(k_exp+1) + ... in the reference's order, so the bits match the in-loop accumulation
+        const int k_exp = tid - PDMPC_WAVE + 1;
+        double d = 0.0;
+        for (int it = 1; it <= Hp - k_exp; ++it) {
+            d = d + A.dt * V->v_ref[k_exp + it - 1];
+            l_dcum[(k_exp - 1) * PDMPC_HP_MAX + (it - 1)] = d;
+        }
+    }
+    if (tid == 0) {
+        for (int i = 0; i < SH_WORDS; ++i) l_shared[i] = 0;
+    }
+    {
+        // zero the record; y_predicted starts as NaN (ControlResultsInfo.m:40)
+        double* od = (double*)O;
+        const int nd = (int)(sizeof(pdmpc_vehicle_out) / 8);
+        const int y0 = (int)(offsetof(pdmpc_vehicle_out, y_predicted) / 8);
+        const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+        for (int i = tid; i < nd; i += PDMPC_THREADS) od[i] = (i >= y0 && i < y0 + PDMPC_HP_MAX * 3) ? qnan : 0.0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // later result stores hit the same bytes from other lanes
+    }
+    __syncthreads();
+
+    // ---- prologue 3: obstacle soup of every step: [literal polygons + NaN][predecessor areas padded to VMAX]
+    const int n_pred = V->n_pred;
+    const int pred_cols = n_pred * PDMPC_VMAX;
+    {
+        int off = 0;
+        for (int k = 0; k < Hp; ++k) {
+            const int a = V->lit_off[k], b = V->lit_off[k + 1];
+            if (tid == 0) {
+                l_soff[k] = off;
+                l_lit[k] = b - a;
+            }
+            stage16(l_soup + off, (const d2*)A.points + a, b - a, tid);
+            off += (b - a) + pred_cols;
+        }
+        if (tid == 0) l_soff[Hp] = off;
+        for (int k = 0; k < Hp; ++k) {
+            const int a = V->hdv_off[k], b = V->hdv_off[k + 1];
+            if (tid == 0) l_hoff[k] = off;
+            stage16(l_soup + off, (const d2*)A.points + a, b - a, tid);
+            off += (b - a);
+        }
+        if (tid == 0) l_hoff[Hp] = off;
+        // lanelet soup last
+        stage16(l_soup + off, (const d2*)A.points + V->ll_off, V->ll_len, tid);
+        if (tid == 0) l_path[PDMPC_HP_MAX + 1] = (uint32_t)off;
+    }
+    __syncthreads();
+    C.ll_base = uni_i((int)l_path[PDMPC_HP_MAX + 1]);
+    C.ll_len = uni_i(V->ll_len);
+
+    // ---- prologue 4: predecessors (PrioritizedController.m:476-491).  Their soup slots start as NaN (no obstacle).
+    // Predecessors that have already finished are incorporated now; the others are "pending": the search starts
+    // without them and arrival_sync() folds them in when they finish (speculation, see arrival_sync).
+    SpecCtx P;
+    P.sh = l_shared;
+    P.l_soup = l_soup;
+    P.l_soff = l_soff;
+    P.l_lit = l_lit;
+    P.out = A.out;
+    P.pred = A.pred + V->pred_off;
+    P.n_pred = n_pred;
+    P.Hp = Hp;
+    bool dep_timeout = false;
+    // the arrival re-check (node_hits_areas) implements the InterX predicate; the convex/SAT checker (circle scenario,
+    // a handful of vehicles) simply waits for its predecessors as the reference does
+    const bool speculate = A.speculate && n_pred <= 64 && CHECKER == PDMPC_CHECK_INTERX;
+    if (n_pred > 0) {
+        const d2 nanpt = d2{__longlong_as_double(0x7ff8000000000000LL), __longlong_as_double(0x7ff8000000000000LL)};
+        for (int idx = tid; idx < Hp * pred_cols; idx += PDMPC_THREADS) {
+            const int k = idx / pred_cols;
+            l_soup[l_soff[k] + l_lit[k] + (idx - k * pred_cols)] = nanpt;
+        }
+        if (!speculate) {
+            // blocking wait (more than 64 predecessors, or speculation switched off)
+            for (int p = 0; p < n_pred; ++p) {
+                uint32_t spins = 0;
+                while (__hip_atomic_load(A.done_flag + P.pred[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != A.epoch) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > A.spin_limit) {
+                        dep_timeout = true;
+                        break;
+                    }
+                }
+            }
+        }
+        unsigned long long ready = 0;
+        if (wave == 0) {
+            bool d = false;
+            if (lane < n_pred) d = __hip_atomic_load(A.done_flag + P.pred[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == A.epoch;
+            ready = __ballot(d);
+            if (!speculate) ready = (n_pred >= 64) ? ~0ull : ((1ull << n_pred) - 1ull);
+            if (lane == 0) {
+                const unsigned long long all = (n_pred >= 64) ? ~0ull : ((1ull << n_pred) - 1ull);
+                const unsigned long long pend = speculate ? (all & ~ready) : 0ull;
+                l_shared[SH_PEND_LO] = (uint32_t)pend;
+                l_shared[SH_PEND_HI] = (uint32_t)(pend >> 32);
+                l_shared[SH_ARR_LO] = (uint32_t)ready;
+                l_shared[SH_ARR_HI] = (uint32_t)(ready >> 32);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (!speculate) {  // n_pred may exceed 64: incorporate everything directly
+            const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+            for (int idx = tid; idx < Hp * pred_cols; idx += PDMPC_THREADS) {
+                const int k = idx / pred_cols;
+                const int r = idx - k * pred_cols;
+                const int p = r / PDMPC_VMAX;
+                const int v = r - p * PDMPC_VMAX;
+                const pdmpc_vehicle_out* PO = A.out + P.pred[p];
+                const int cols = PO->shape_cols[k];
+                d2 pt;
+                pt.x = qnan;
+                pt.y = qnan;
+                if (v < cols) {
+                    pt.x = PO->shapes[k][0][v];
+                    pt.y = PO->shapes[k][1][v];
+                }
+                l_soup[l_soff[k] + l_lit[k] + r] = pt;
+            }
+        } else {
+            incorporate_areas(P, sh_load64(l_shared, SH_ARR_LO), tid);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            l_shared[SH_ARR_LO] = 0;
+            l_shared[SH_ARR_HI] = 0;
+        }
+    }
+
+    Ctx X;
+    X.tid = tid;
+    X.lane = lane;
+    X.wave = wave;
+    X.slot = slot;
+    X.Hp = Hp;
+    X.n = n;
+    X.nw = nw;
+    X.V = V;
+    X.l_mask = l_mask;
+    X.l_mi = l_mi;
+    X.l_pose = l_pose;
+    X.l_rx = l_rx;
+    X.l_ry = l_ry;
+    X.l_shared = l_shared;
+    X.VS = VS;
+    X.l_dcum = l_dcum;
+    X.l_term = l_term;
+    X.l_chxy = l_chxy;
+    X.S = S;
+    X.C = C;
+    X.P = P;
+    X.O = O;
+    X.dep_timeout = dep_timeout;
+#ifdef PDMPC_PROFILE
+    X.rt_start = rt_start;
+#endif
+    (void)search_loops<CHECKER, false>(A, X);
+    const int status = X.status;
+    const int n_popped = X.n_popped;
+    const uint32_t goal = X.goal;
+    const uint32_t nnodes = X.nnodes;
+    dep_timeout = X.dep_timeout;
+    S = X.S;
     __syncthreads();
     if (wave != 0) return;
 
@@ -1468,6 +1564,82 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_heap_script_kerne
         stats[2] = c_push;
         stats[3] = n_push;
     }
+}
+
+// Debug/unit-test kernel for the block-min queue: op 0 pushes the next node (ids 1, 2, 3, ... in script order) with key[i],
+// op 1 pops.  Consecutive pushes (up to 16) go in as one batch, like the children of an expansion.  out receives the
+// popped ids (-1 on empty); stats[0..3] as in the heap script kernel, stats[4] = 1 if a pop saw a tied minimum.
+extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_bm_script_kernel(const int32_t* op, const double* key, int n, int32_t* out,
+                                                                               unsigned long long* stats, double* gkey, int KR, int NB) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    BmQueue Q;
+    Q.kring = (lds_f64*)smem;
+    Q.m1 = (lds_f64*)(smem + (size_t)KR * 8);
+    Q.m2 = Q.m1 + NB;
+    Q.gkey = gkey;
+    Q.kr_mask = (uint32_t)KR - 1u;
+    Q.nb_max = (uint32_t)NB;
+    Q.open = 0;
+    Q.tie = false;
+    bm_init(Q, lane, PDMPC_WAVE);
+    __syncthreads();
+    uint32_t nn = 0;
+    int n_out = 0;
+    unsigned long long c_pop = 0, c_push = 0, n_pop = 0, n_push = 0;
+    int i = 0;
+    // the clock is read with nothing of the script's own memory traffic in flight (loads of op/key, the store to out)
+#define BM_CLOCK(t, w)                          \
+    __builtin_amdgcn_s_waitcnt(w);              \
+    __builtin_amdgcn_sched_barrier(0);          \
+    const unsigned long long t = __builtin_readcyclecounter(); \
+    __builtin_amdgcn_sched_barrier(0);
+    while (i < n) {
+        const int o = uni_i(op[i]);
+        if (o == 0) {
+            int cnt = 1;
+            while (cnt < 16 && i + cnt < n && uni_i(op[i + cnt]) == 0) ++cnt;
+            const bool active = lane < cnt;
+            const double f = active ? key[i + lane] : 0.0;
+            BM_CLOCK(t0, 0)
+            bm_push(Q, active, nn + (uint32_t)lane, f, nn, nn + (uint32_t)cnt);
+            BM_CLOCK(t1, 0xC07F)  // lgkmcnt(0): the queue's HBM stores are fire-and-forget
+            nn += (uint32_t)cnt;
+            c_push += t1 - t0;
+            n_push += (unsigned long long)cnt;
+            i += cnt;
+        } else {
+            // a run of consecutive pops is timed as a whole (no clock reads in between)
+            int run = 1;
+            while (i + run < n && uni_i(op[i + run]) == 1) ++run;
+            BM_CLOCK(t0, 0)
+            for (int r = 0; r < run; ++r) {
+                const uint32_t cur = bm_pop(Q, nn);
+                if (lane == 0) out[n_out] = cur == 0xFFFFFFFFu ? -1 : (int32_t)(cur + 1u);
+                ++n_out;
+            }
+            BM_CLOCK(t1, 0xC07F)  // lgkmcnt(0): the queue's HBM stores are fire-and-forget
+            c_pop += t1 - t0;
+            n_pop += (unsigned long long)run;
+            i += run;
+        }
+    }
+    if (lane == 0) {
+        stats[0] = c_pop;
+        stats[1] = n_pop;
+        stats[2] = c_push;
+        stats[3] = n_push;
+        stats[4] = Q.tie ? 1ull : 0ull;
+    }
+}
+
+extern "C" int pdmpc_launch_bm_script(const int32_t* op, const double* key, int n, int32_t* out, unsigned long long* stats, double* gkey, int KR,
+                                      int NB, void* stream) {
+    const size_t lds = (size_t)KR * 8 + (size_t)NB * 8 + 64 * 8;
+    hipError_t e = hipFuncSetAttribute((const void*)pdmpc_bm_script_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(pdmpc_bm_script_kernel, dim3(1), dim3(PDMPC_WAVE), lds, (hipStream_t)stream, op, key, n, out, stats, gkey, KR, NB);
+    return (int)hipGetLastError();
 }
 
 extern "C" int pdmpc_launch_heap_script(const int32_t* op, const int32_t* id, const double* key, int n, int32_t* out, unsigned long long* stats,
