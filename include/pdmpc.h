@@ -141,6 +141,8 @@ typedef struct {
     int64_t lds_bytes;        /* dynamic LDS per workgroup used by the launch */
     int64_t lds_nodes;        /* tree nodes resident in LDS per vehicle */
     int64_t n_launches;       /* kernel launches since the last pdmpc_pack_* (kernel_ms is their sum) */
+    int64_t queue_fallbacks;  /* searches since pdmpc_create / pdmpc_reset_stats that met a tied minimal key in the block-min
+                                 open list and were redone on the binary heap (results are identical either way) */
 } pdmpc_stats;
 
 /* ---- life cycle (replaces GraphSearch() construction in OptimizerInterface.get_optimizer, :26-27,

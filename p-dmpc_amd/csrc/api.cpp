@@ -136,6 +136,9 @@ struct pdmpc_handle {
     DevBuf<pdmpc_vehicle_out> d_out;
     DevBuf<uint32_t> d_flag;
     DevBuf<int32_t> d_tree_size;
+    DevBuf<int32_t> d_tie_count;
+    int queue_mode = PDMPC_QUEUE_BLOCKMIN;
+    int bm_kr = 0, bm_nb = 0;
     DevBuf<int32_t> d_trace;
     // batch blobs: several packed steps can stay resident side by side ("banks", pdmpc_select_bank)
     std::vector<PackedStep> banks;
@@ -217,6 +220,19 @@ int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in, int cand_cap_in)
     off += nl * (uint32_t)sizeof(NodeRec);
     L.total = align16(off);
     if (L.total > budget) return fail(PDMPC_ERR_CAPACITY, "internal: LDS layout exceeds budget");
+    // the block-min queue (key ring + block minima + group minima) lives in the heap's region
+    {
+        const uint32_t nb = ((h->max_nodes + 63u) / 64u + 63u) & ~63u;
+        const uint32_t region = align16(hl * 8) + align16(hl * 4);
+        h->bm_nb = (int)nb;
+        h->bm_kr = 0;
+        if (nb <= 4096u && region >= nb * 8u + 512u + 64u * 8u) {
+            uint32_t kr = 64;
+            while (kr * 2u * 8u + nb * 8u + 512u <= region && kr < 16384u) kr *= 2u;
+            h->bm_kr = (int)kr;
+        }
+        if (h->bm_kr == 0) h->queue_mode = PDMPC_QUEUE_HEAP;  // no room (tiny LDS budget) or more than 262144 nodes per vehicle
+    }
     h->lds = L;
     h->HL = (int)hl;
     h->NL = (int)nl;
@@ -397,6 +413,10 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.cand_cap = B.cand_cap;
     a.spin_limit = 1u << 22;
     a.speculate = h->speculate;
+    a.queue_mode = h->queue_mode;
+    a.bm_kr = h->bm_kr;
+    a.bm_nb = h->bm_nb;
+    a.tie_count = h->d_tie_count.p;
     if (h->events_used == h->events.size()) {
         hipEvent_t e0, e1;
         HIPCHK(hipEventCreate(&e0));
@@ -441,6 +461,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
     h->cfg = *config;
     h->banks.resize(1);
     if (const char* e = getenv("PDMPC_SPECULATE")) h->speculate = atoi(e) != 0;  // A/B switch for benchmarking; results are identical
+    if (const char* e = getenv("PDMPC_QUEUE")) h->queue_mode = atoi(e) != 0 ? PDMPC_QUEUE_BLOCKMIN : PDMPC_QUEUE_HEAP;  // likewise
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     h->max_nodes = config->max_nodes > 0 ? (uint32_t)config->max_nodes : 32768u;  // default arena: 256 x 32768 nodes, about 0.6 GB
     h->max_nodes = (h->max_nodes + 1u) & ~1u;
@@ -453,7 +474,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
     const size_t tot = (size_t)h->max_vehicles * h->max_nodes;
     int bad = 0;
     bad |= h->anodes.ensure(tot) | h->ahk.ensure(tot) | h->ahid.ensure(tot) | h->avs.ensure(tot);
-    bad |= h->d_out.ensure((size_t)h->max_vehicles) | h->d_flag.ensure((size_t)h->max_vehicles) | h->d_tree_size.ensure((size_t)h->max_vehicles);
+    bad |= h->d_out.ensure((size_t)h->max_vehicles) | h->d_flag.ensure((size_t)h->max_vehicles) | h->d_tree_size.ensure((size_t)h->max_vehicles) | h->d_tie_count.ensure(1);
     bad |= h->d_trace.ensure((size_t)h->max_vehicles * (size_t)std::max(config->trace_pops, 1));
     if (bad) {
         pdmpc_destroy(h);
@@ -461,6 +482,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
     }
     (void)hipMemsetAsync(h->d_flag.p, 0, h->d_flag.cap * sizeof(uint32_t), h->stream);
     (void)hipMemsetAsync(h->d_tree_size.p, 0, h->d_tree_size.cap * sizeof(int32_t), h->stream);
+    (void)hipMemsetAsync(h->d_tie_count.p, 0, sizeof(int32_t), h->stream);
     (void)hipMemsetAsync(h->d_out.p, 0, h->d_out.cap * sizeof(pdmpc_vehicle_out), h->stream);
     (void)hipStreamSynchronize(h->stream);
     *out_handle = h;
@@ -486,6 +508,7 @@ int pdmpc_destroy(pdmpc_handle* h) {
     h->d_out.release();
     h->d_flag.release();
     h->d_tree_size.release();
+    h->d_tie_count.release();
     h->d_trace.release();
     for (auto& b : h->banks) b.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -586,6 +609,7 @@ int pdmpc_reset_stats(pdmpc_handle* h) {
     if (!h) return fail(PDMPC_ERR_INVALID, "null handle");
     HIPCHK(hipStreamSynchronize(h->stream));
     h->events_used = 0;
+    HIPCHK(hipMemsetAsync(h->d_tie_count.p, 0, sizeof(int32_t), h->stream));
     return PDMPC_OK;
 }
 
@@ -685,6 +709,9 @@ int pdmpc_get_last_stats(pdmpc_handle* h, pdmpc_stats* stats) {
     }
     h->stats.kernel_ms = ms;
     h->stats.n_launches = (int64_t)h->events_used;
+    int32_t ties = 0;
+    HIPCHK(hipMemcpy(&ties, h->d_tie_count.p, sizeof ties, hipMemcpyDeviceToHost));
+    h->stats.queue_fallbacks = ties;
     *stats = h->stats;
     return PDMPC_OK;
 }

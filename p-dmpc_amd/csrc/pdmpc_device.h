@@ -21,7 +21,9 @@
 #include "../../include/pdmpc.h"
 
 #define PDMPC_WAVE 64
-#define PDMPC_WAVES_PER_VEHICLE 4 /* wave 0 sequences the search, waves 1..3 pre-validate nodes */
+#define PDMPC_WAVES_PER_VEHICLE 8 /* wave 0 sequences the search, the others pre-validate nodes (block-min mode: wave 1 scouts) */
+#define PDMPC_QUEUE_HEAP 0     /* open list = libstdc++-faithful binary heap (exact for any keys) */
+#define PDMPC_QUEUE_BLOCKMIN 1 /* open list = block-min queue while the minimal key is unique, binary heap after the first tie */
 #define PDMPC_THREADS (PDMPC_WAVE * PDMPC_WAVES_PER_VEHICLE)
 
 struct DevManPose {
@@ -110,6 +112,8 @@ struct KernelArgs {
     // LDS
     LdsLayout lds;
     int32_t HL, NL, NV, soup_cap, cand_cap;
+    int32_t queue_mode, bm_kr, bm_nb;  // PDMPC_QUEUE_*; block-min ring entries (power of two) and block count (multiple of 64)
+    int32_t* tie_count;                // searches that met a tied minimum and were redone on the binary heap (cumulative)
     int32_t speculate;  // 1: start searching before all predecessors have finished (results are identical, see arrival_sync)
     uint32_t spin_limit;
 };

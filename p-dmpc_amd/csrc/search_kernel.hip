@@ -637,6 +637,7 @@ __device__ __forceinline__ uint32_t lds_load_u32(const volatile uint32_t* p) { r
 #define VS_UNKNOWN 0u
 #define VS_VALID 1u
 #define VS_INVALID 2u
+#define VS_CLAIMED 4u   // block-min mode: a validator wave is evaluating the edge right now
 #define VS_VALID_CS 3u  // valid, and a helper has already stored cos/sin(yaw) in the node's record (expand_node.m:50-51)
 
 
@@ -656,6 +657,17 @@ __device__ __forceinline__ void vs_store(const VState& v, uint32_t i0, uint32_t 
     else
         __hip_atomic_store(v.g + i0, (uint8_t)val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// unknown -> claimed, by exactly one of the waves that try (one lane calls): the winner evaluates the edge
+__device__ __forceinline__ bool vs_claim(const VState& v, uint32_t i0) {
+    uint8_t* b = (i0 < v.NV) ? (uint8_t*)v.l + i0 : v.g + i0;
+    uint32_t* w = (uint32_t*)((uintptr_t)b & ~(uintptr_t)3);
+    const uint32_t sh = (uint32_t)((uintptr_t)b & 3u) * 8u;
+    for (;;) {
+        const uint32_t old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((old >> sh) & 0xFFu) return false;
+        if (atomicCAS(w, old, old | (VS_CLAIMED << sh)) == old) return true;
+    }
+}
 
 }  // namespace
 
@@ -669,10 +681,14 @@ __device__ __forceinline__ void vs_store(const VState& v, uint32_t i0, uint32_t 
 #define SH_PEND_HI 6
 #define SH_ARR_LO 7    // predecessors that just finished (to be incorporated by arrival_sync)
 #define SH_ARR_HI 8
+#define SH_CAND_VER 9  // block-min mode: bumped by the scout wave when it rewrote the candidate list
+#define SH_CAND 10     // block-min mode: BM_NCAND node ids proposed for pre-validation, most urgent first (0 = none)
+#define BM_NCAND 6
 #define SH_WORDS 16
 #define ST_RUN 0u
 #define ST_ARRIVED 1u
 #define ST_DONE 2u
+#define ST_TIE 3u  // block-min mode: the minimal key was not unique; every wave leaves and the search is redone on the binary heap
 
 namespace {
 
@@ -789,9 +805,11 @@ __device__ bool arrival_sync(const Search& S, const CheckCtx& C, const SpecCtx& 
     if (tid == 0) {
         if (restart) {
             // back to the root before any helper looks at the open list again: node ids are about to be reused
-            S.lkey[0] = 0.0;
+            S.lkey[0] = 0.0;  // (block-min mode rebuilds its own queue after this returns)
             S.lid[0] = 1;
             P.sh[SH_HEAP_LEN] = 1;
+            P.sh[SH_NNODES] = 1;
+            for (int c = 0; c < BM_NCAND; ++c) P.sh[SH_CAND + c] = 0;
             P.sh[SH_VERSION] = P.sh[SH_VERSION] + 1;
             ((uint32_t*)S.gn)[15] &= ~NODE_POPPED_BIT;
             if (S.NL > 0) ((lds_u32*)S.ln)[15] = ((lds_u32*)S.ln)[15] & ~NODE_POPPED_BIT;
@@ -811,6 +829,26 @@ __device__ bool arrival_sync(const Search& S, const CheckCtx& C, const SpecCtx& 
 
 }  // namespace
 
+// One look at the done flags of the predecessors that are still planning; if some finished, their set is posted in
+// SH_ARR and the state goes ST_RUN -> ST_ARRIVED (which loses only against ST_DONE / ST_TIE).  Whole wave calls.
+__device__ __forceinline__ bool poll_predecessors(const KernelArgs& A, const SpecCtx& P, volatile uint32_t* l_shared, int lane) {
+    const unsigned long long pend = sh_load64(l_shared, SH_PEND_LO);
+    if (!pend) return false;
+    bool d = false;
+    if ((pend >> lane) & 1ull) d = __hip_atomic_load(A.done_flag + P.pred[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == A.epoch;
+    const unsigned long long got = __ballot(d);
+    if (!got) return false;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+        l_shared[SH_ARR_LO] = (uint32_t)got;
+        l_shared[SH_ARR_HI] = (uint32_t)(got >> 32);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        atomicCAS((uint32_t*)&l_shared[SH_STATE], ST_RUN, ST_ARRIVED);
+    }
+    return true;
+}
+
 // Everything the search loops need from the prologue (LDS carve, per-vehicle state) and what they hand to the epilogue.
 struct Ctx {
     int tid, lane, wave, slot, Hp, n, nw;
@@ -828,7 +866,6 @@ struct Ctx {
     SpecCtx P;
     pdmpc_vehicle_out* O;
     BmQueue Q;
-    lds_u32* l_cand;  // block-min mode: node ids the scout wave proposes for pre-validation
     // results
     int status, n_popped;
     uint32_t goal, nnodes;
@@ -842,7 +879,7 @@ struct Ctx {
 // BM = false: the libstdc++-faithful binary heap (exact for any keys).  BM = true: the block-min queue, which is only
 // exact while the minimal key is unique; returns true (to every wave) if it met a tie and the search must be redone.
 template <int CHECKER, bool BM>
-__device__ bool search_loops(const KernelArgs& A, Ctx& X) {
+__device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
     const int tid = X.tid, lane = X.lane, wave = X.wave, slot = X.slot, Hp = X.Hp, n = X.n, nw = X.nw;
     const DevVehicle* __restrict__ V = X.V;
     uint64_t* l_mask = X.l_mask;
@@ -876,12 +913,24 @@ __device__ bool search_loops(const KernelArgs& A, Ctx& X) {
         r.parent = 0;
         r.packed = (uint32_t)V->trim0;
         node_store(S, 0, r);
-        S.lkey[0] = 0.0;
-        S.lid[0] = 1;
+        if (!BM) {
+            S.lkey[0] = 0.0;
+            S.lid[0] = 1;
+        }
         vs_store(VS, 0, 1);  // the root has no edge: valid
         l_shared[SH_HEAP_LEN] = 1;
+        l_shared[SH_NNODES] = 1;
+        for (int c = 0; c < BM_NCAND; ++c) l_shared[SH_CAND + c] = 0;
     }
     S.heap_len = 1;
+    BmQueue& Q = X.Q;
+    if (BM) {
+        bm_init(Q, tid, PDMPC_THREADS);
+        __syncthreads();
+        Q.open = 0;
+        Q.tie = false;
+        if (wave == 0) bm_push(Q, lane == 0, 0u, 0.0, 0u, 1u);
+    }
     __syncthreads();
 
     int status = PDMPC_OK;
@@ -891,7 +940,144 @@ __device__ bool search_loops(const KernelArgs& A, Ctx& X) {
     const unsigned long long rt_search = __builtin_amdgcn_s_memrealtime();
 #endif
 
-    if (wave != 0) {
+    if (BM && wave == 1) {
+        // ================= scout wave (block-min mode) ==========================================================
+        // Lists the nodes that will be popped next and whose edge nobody has evaluated yet: the unknown entries with
+        // the smallest keys among the four best blocks of the best group.  Its reads race with the sequencing wave's
+        // updates; a stale or torn view only costs a useless proposal (every id below the published tree size is a
+        // complete node, and edge validity is a pure function of the tree and the soups).  Also polls the predecessors.
+        const double inf = bm_inf();
+        uint32_t last_ver = 0xFFFFFFFFu, cand_ver = 0;
+        for (;;) {
+            const uint32_t state = lds_load_u32(&l_shared[SH_STATE]);
+            if (state == ST_DONE || state == ST_TIE) break;
+            if (state == ST_ARRIVED) {
+                (void)arrival_sync(S, C, P, VS, tid);
+                continue;
+            }
+            if (poll_predecessors(A, P, l_shared, lane)) continue;
+            const uint32_t ver = lds_load_u32(&l_shared[SH_VERSION]);
+            if (ver == last_ver) __builtin_amdgcn_s_sleep(8);  // nothing popped or pushed since the last scan: rescan lazily
+            last_ver = ver;
+            const uint32_t nn = lds_load_u32(&l_shared[SH_NNODES]);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            uint32_t g = 0;
+            bool any = true;
+            if (nn > 4096u) {
+                const double v2 = *(volatile lds_f64*)&Q.m2[lane];
+                const double mn2 = wave_min_d(v2);
+                any = mn2 < inf;
+                if (any) g = (uint32_t)__builtin_ctzll(__ballot(v2 == mn2));
+            }
+            double v1 = any ? *(volatile lds_f64*)&Q.m1[g * 64u + (uint32_t)lane] : inf;
+            double kk[4];
+            uint32_t blk[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                kk[j] = inf;
+                blk[j] = 0;
+                const double mn = wave_min_d(v1);
+                if (mn < inf) {
+                    const uint32_t bl = (uint32_t)__builtin_ctzll(__ballot(v1 == mn));
+                    if ((uint32_t)lane == bl) v1 = inf;
+                    const uint32_t b = g * 64u + bl;
+                    const uint32_t idx = b * 64u + (uint32_t)lane;
+                    blk[j] = b;
+                    double k = inf;
+                    if (idx < nn) {
+                        if (b * 64u + Q.kr_mask + 1u >= nn)
+                            k = *(volatile lds_f64*)&Q.kring[idx & Q.kr_mask];
+                        else
+                            k = __hip_atomic_load(Q.gkey + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (k < inf && vs_load(VS, idx) != VS_UNKNOWN) k = inf;
+                    }
+                    kk[j] = k;
+                }
+            }
+            uint32_t my = 0;  // lane c keeps candidate c
+#pragma unroll
+            for (int c = 0; c < BM_NCAND; ++c) {
+                double loc = kk[0];
+                int js = 0;
+#pragma unroll
+                for (int j = 1; j < 4; ++j) {
+                    if (kk[j] < loc) {
+                        loc = kk[j];
+                        js = j;
+                    }
+                }
+                const double mn = wave_min_d(loc);
+                uint32_t id = 0;
+                if (mn < inf) {
+                    const int l = __builtin_ctzll(__ballot(loc == mn));
+                    uint32_t bsel = blk[0];
+#pragma unroll
+                    for (int j = 1; j < 4; ++j)
+                        if (js == j) bsel = blk[j];
+                    id = lane_u(bsel, l) * 64u + (uint32_t)l + 1u;
+                    if (lane == l) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (js == j) kk[j] = inf;
+                    }
+                }
+                if (lane == c) my = id;
+            }
+            if (lane < BM_NCAND) l_shared[SH_CAND + lane] = my;
+            if (lane == 0) l_shared[SH_CAND_VER] = ++cand_ver;
+        }
+    } else if (BM && wave != 0) {
+        // ================= validator waves (block-min mode) =====================================================
+        // Take the most urgent proposal nobody has claimed yet, evaluate its edge, publish the verdict (and cos/sin of
+        // the node's yaw for the expansion).  Same guarantees as the helper waves of the binary-heap mode.
+        uint32_t seen = 0xFFFFFFFFu;
+        for (;;) {
+            const uint32_t state = lds_load_u32(&l_shared[SH_STATE]);
+            if (state == ST_DONE || state == ST_TIE) break;
+            if (state == ST_ARRIVED) {
+                (void)arrival_sync(S, C, P, VS, tid);
+                continue;
+            }
+            const uint32_t cver = lds_load_u32(&l_shared[SH_CAND_VER]);
+            uint32_t id = 0;
+            if (lane < BM_NCAND) id = l_shared[SH_CAND + lane];
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const bool unknown = id != 0 && vs_load(VS, id - 1) == VS_UNKNOWN;
+            unsigned long long b = __ballot(unknown);
+            uint32_t target = 0;
+            while (b && !target) {
+                const int l = __builtin_ctzll(b);
+                b &= b - 1;
+                const uint32_t cid = lane_u(id, l);
+                uint32_t won = 0;
+                if (lane == 0) won = vs_claim(VS, cid - 1) ? 1u : 0u;
+                if (uni_u(won)) target = cid;
+            }
+            if (target) {
+                const bool ok = edge_valid<CHECKER>(S, C, target, lane);
+                uint32_t verdict = ok ? VS_VALID : VS_INVALID;
+                if (ok) {
+                    const NodeRec tn = node_load(S, target - 1);
+                    if (NODE_K(uni_u(tn.packed)) < Hp) {
+                        double sn, cs;
+                        pdmpc_sincos(tn.yaw, &sn, &cs);
+                        if (lane == 0) node_store_cs(S, target - 1, cs, sn);
+                        if (target - 1 >= S.NL) __threadfence_block();
+                        verdict = VS_VALID_CS;
+                    }
+                }
+                if (lane == 0) vs_store(VS, target - 1, verdict);
+            } else {
+                // nothing to do until the scout rewrites the list
+                uint32_t naps = 0;
+                while (cver == seen && lds_load_u32(&l_shared[SH_CAND_VER]) == cver && lds_load_u32(&l_shared[SH_STATE]) == ST_RUN && naps < 64u) {
+                    __builtin_amdgcn_s_sleep(2);
+                    ++naps;
+                }
+                seen = cver;
+            }
+        }
+    } else if (wave != 0) {
         // ================= helper waves: pre-validate the nodes near the top of the open list ==================
         // Any id read from the heap is a fully written node (the sequencing wave publishes ids after the records);
         // edge validity is a pure function, so evaluating it early, twice, or for a node that is never popped
@@ -907,23 +1093,7 @@ __device__ bool search_loops(const KernelArgs& A, Ctx& X) {
             }
             // the last helper wave also polls the pending predecessors' done flags (every 4th round and while idle)
             if (wave == PDMPC_WAVES_PER_VEHICLE - 1 && (iter++ & 3u) == 0) {
-                const unsigned long long pend = sh_load64(l_shared, SH_PEND_LO);
-                if (pend) {
-                    bool d = false;
-                    if ((pend >> lane) & 1ull) d = __hip_atomic_load(A.done_flag + P.pred[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == A.epoch;
-                    const unsigned long long got = __ballot(d);
-                    if (got) {
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        if (lane == 0) {
-                            l_shared[SH_ARR_LO] = (uint32_t)got;
-                            l_shared[SH_ARR_HI] = (uint32_t)(got >> 32);
-                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                            atomicCAS((uint32_t*)&l_shared[SH_STATE], ST_RUN, ST_ARRIVED);  // loses only against ST_DONE
-                        }
-                        continue;
-                    }
-                }
+                if (poll_predecessors(A, P, l_shared, lane)) continue;
             }
             const uint32_t ver = lds_load_u32(&l_shared[SH_VERSION]);
             const uint32_t hl = lds_load_u32(&l_shared[SH_HEAP_LEN]);
@@ -984,19 +1154,44 @@ __device__ bool search_loops(const KernelArgs& A, Ctx& X) {
                     S.heap_len = 1;
                     nnodes = 1;
                     n_popped = 0;
+                    if (BM) {  // the other waves see an empty candidate list and a tree of one node meanwhile
+                        bm_init(Q, lane, PDMPC_WAVE);
+                        Q.open = 0;
+                        bm_push(Q, lane == 0, 0u, 0.0, 0u, 1u);
+                    }
                     continue;
                 }
             }
-            if (S.heap_len == 0) {  // pop on an empty queue returns -1 (mex.cpp:87-93)  GraphSearch.m:57-61
-                status = PDMPC_EXHAUSTED;
-                break;
+            if (BM && Q.tie) {
+                // the pop order is no longer certified: everybody leaves, the search is redone on the binary heap
+                uint32_t old = 0;
+                if (lane == 0) old = atomicCAS((uint32_t*)&l_shared[SH_STATE], ST_RUN, ST_TIE);
+                if (uni_u(old) == ST_RUN) return true;
+                continue;  // an arrival got in first: handle it, then try again
             }
-            PROF_STOP(7)
-            const uint32_t cur = uni_u(*(volatile lds_u32*)&S.lid[0]);  // 1-based node id (HL >= 1: the top is always in LDS)
-            heap_pop(S);
-            if (lane == 0) {
-                l_shared[SH_HEAP_LEN] = S.heap_len;
-                l_shared[SH_VERSION] = ++ver_ctr;
+            uint32_t cur;
+            if (BM) {
+                PROF_STOP(7)
+                const uint32_t c = bm_pop(Q, nnodes);
+                if (c == 0xFFFFFFFFu) {  // pop on an empty queue returns -1 (mex.cpp:87-93)  GraphSearch.m:57-61
+                    status = PDMPC_EXHAUSTED;
+                    break;
+                }
+                if (Q.tie) continue;
+                cur = c + 1u;
+                if (lane == 0) l_shared[SH_VERSION] = ++ver_ctr;
+            } else {
+                if (S.heap_len == 0) {  // pop on an empty queue returns -1 (mex.cpp:87-93)  GraphSearch.m:57-61
+                    status = PDMPC_EXHAUSTED;
+                    break;
+                }
+                PROF_STOP(7)
+                cur = uni_u(*(volatile lds_u32*)&S.lid[0]);  // 1-based node id (HL >= 1: the top is always in LDS)
+                heap_pop(S);
+                if (lane == 0) {
+                    l_shared[SH_HEAP_LEN] = S.heap_len;
+                    l_shared[SH_VERSION] = ++ver_ctr;
+                }
             }
             PROF_STOP(0)
             if (A.trace_cap > 0 && n_popped < A.trace_cap && lane == 0) A.pop_trace[(size_t)slot * A.trace_cap + n_popped] = (int32_t)cur;
@@ -1006,7 +1201,7 @@ __device__ bool search_loops(const KernelArgs& A, Ctx& X) {
             // ---- eval_edge_exact (GraphSearch.m:111-196): from the validity cache if a helper got there first
             const uint32_t vs = uni_u(vs_load(VS, c0));
             bool valid;
-            if (vs == VS_UNKNOWN) {
+            if (vs == VS_UNKNOWN || vs == VS_CLAIMED) {
                 valid = edge_valid<CHECKER>(S, C, cur, lane);
                 if (lane == 0) vs_store(VS, c0, valid ? VS_VALID : VS_INVALID);
                 PROF_COUNT(13, 1)
@@ -1118,18 +1313,25 @@ __device__ bool search_loops(const KernelArgs& A, Ctx& X) {
                 wave_sync();
                 PROF_STOP(5)
                 // pq.push(new_open_nodes, new_open_values): one at a time in ascending trim order (mex.cpp:67-72)
-                uint64_t mm = mask;
-                uint32_t r = 0;
-                while (mm) {
-                    const int l = __builtin_ctzll(mm);
-                    mm &= mm - 1;
-                    const double fk = lane_d(f, l);
-                    heap_push(S, nnodes + r + 1, fk);
-                    ++r;
+                if (BM) {
+                    bm_push(Q, active, i0, f, nnodes, nnodes + (uint32_t)cnt);
+                } else {
+                    uint64_t mm = mask;
+                    uint32_t r = 0;
+                    while (mm) {
+                        const int l = __builtin_ctzll(mm);
+                        mm &= mm - 1;
+                        const double fk = lane_d(f, l);
+                        heap_push(S, nnodes + r + 1, fk);
+                        ++r;
+                    }
                 }
                 nnodes += (uint32_t)cnt;
                 if (lane == 0) {
-                    l_shared[SH_HEAP_LEN] = S.heap_len;
+                    if (BM)
+                        l_shared[SH_NNODES] = nnodes;
+                    else
+                        l_shared[SH_HEAP_LEN] = S.heap_len;
                     l_shared[SH_VERSION] = ++ver_ctr;
                 }
                 PROF_STOP(6)
@@ -1157,6 +1359,11 @@ __device__ bool search_loops(const KernelArgs& A, Ctx& X) {
                     n_popped = 0;
                     goal = 0;
                     status = PDMPC_OK;
+                    if (BM) {
+                        bm_init(Q, lane, PDMPC_WAVE);
+                        Q.open = 0;
+                        bm_push(Q, lane == 0, 0u, 0.0, 0u, 1u);
+                    }
                     goto search_again;
                 }
                 continue;
@@ -1182,7 +1389,7 @@ __device__ bool search_loops(const KernelArgs& A, Ctx& X) {
     X.goal = goal;
     X.nnodes = nnodes;
     X.dep_timeout = dep_timeout;
-    return false;
+    return BM && lds_load_u32(&l_shared[SH_STATE]) == ST_TIE;  // (helper waves; the sequencing wave returned above)
 }
 
 // The kernel body, specialised at compile time on the constraint checker so each variant carries only its own
@@ -1427,7 +1634,30 @@ __device__ __forceinline__ void search_body(const KernelArgs& A) {
 #ifdef PDMPC_PROFILE
     X.rt_start = rt_start;
 #endif
-    (void)search_loops<CHECKER, false>(A, X);
+    X.Q.kring = (lds_f64*)(smem + A.lds.heap_key);  // the block-min queue lives where the binary heap would
+    X.Q.m1 = X.Q.kring + A.bm_kr;
+    X.Q.m2 = X.Q.m1 + A.bm_nb;
+    X.Q.gkey = S.gkey;
+    X.Q.kr_mask = (uint32_t)A.bm_kr - 1u;
+    X.Q.nb_max = (uint32_t)A.bm_nb;
+    X.Q.open = 0;
+    X.Q.tie = false;
+    bool tie = false;
+    if (A.queue_mode == PDMPC_QUEUE_BLOCKMIN) {
+        tie = search_loops<CHECKER, true>(A, X);
+        if (tie) {  // (uniform over the workgroup) start over with the exact open list; areas that arrived so far stay in the soup
+            __syncthreads();
+            if (tid == 0) {
+                l_shared[SH_STATE] = ST_RUN;
+                l_shared[SH_ARR_LO] = 0;
+                l_shared[SH_ARR_HI] = 0;
+                l_shared[SH_RESTART] = 0;
+                atomicAdd(A.tie_count, 1);
+            }
+            __syncthreads();
+        }
+    }
+    if (A.queue_mode != PDMPC_QUEUE_BLOCKMIN || tie) (void)search_loops<CHECKER, false>(A, X);
     const int status = X.status;
     const int n_popped = X.n_popped;
     const uint32_t goal = X.goal;

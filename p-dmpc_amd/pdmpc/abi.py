@@ -113,6 +113,7 @@ class Stats(C.Structure):
         ("lds_bytes", C.c_int64),
         ("lds_nodes", C.c_int64),
         ("n_launches", C.c_int64),
+        ("queue_fallbacks", C.c_int64),
     ]
 
 
