@@ -98,3 +98,41 @@ def problem_set(mode, seed, count, Hp=6, mpa_type=MpaType.single_speed, n_hdv=0,
     rng = np.random.default_rng(seed)
     iters = [road_problem(rng, options, mpa, convex=(mode == "sat"), n_hdv=n_hdv, with_boundary=with_boundary) for _ in range(count)]
     return options, mpa, iters
+
+
+def symmetric_problem(options, mpa, block_x=0.9, half=0.06, length=0.3):
+    """A vehicle on a straight reference along the x-axis with an obstacle centred on the axis: the left and the right
+    half of the search tree mirror each other bit for bit, so the open list keeps popping TIED minimal keys — the case
+    in which the pop order depends on the layout of the reference's binary heap."""
+    Hp = options.Hp
+    trim = [i + 1 for i, t in enumerate(mpa.trims) if t.steering == 0 and t.speed > 0][0]
+    v = mpa.trims[trim - 1].speed
+    ref = np.column_stack([v * options.dt_seconds * np.arange(1, Hp + 1), np.zeros(Hp)])
+    obst = np.array([[block_x, block_x + length, block_x + length, block_x], [-half, -half, half, half]])
+    return VehicleIter(
+        x0=np.array([0.0, 0.0, 0.0, v]),
+        trim_index=trim,
+        reference_trajectory_points=ref,
+        v_ref=np.full(Hp, v),
+        predicted_lanelet_boundary=(None, None),
+        obstacles=[obst],
+        dynamic_obstacle_area=[],
+    )
+
+
+def tied_pops(trace):
+    """Number of pops of an oracle trace at which the minimal key of the open list was not unique."""
+    from sortedcontainers import SortedList
+
+    f = trace.tree["g"] + trace.tree["h"]
+    par = trace.tree["parent"]
+    order = np.argsort(par, kind="stable")
+    start = np.searchsorted(par[order], np.arange(1, len(f) + 2), side="left")
+    open_list = SortedList([(f[0], 1)])
+    tied = 0
+    for nd in trace.pops:
+        tied += len(open_list) > 1 and open_list[1][0] == open_list[0][0]
+        open_list.remove((f[nd - 1], int(nd)))
+        for c in order[start[nd - 1] : start[nd]]:
+            open_list.add((f[c], int(c) + 1))
+    return tied

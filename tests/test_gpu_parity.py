@@ -187,3 +187,25 @@ def test_sat_without_obstacles_or_boundary_is_the_greedy_chain():
         it.dynamic_obstacle_area = []
     gpu, _ = check_batch(options, mpa, iters)
     assert (gpu["status"] == abi.OK).all()
+
+
+@pytest.mark.parametrize("mode,Hp,block_x", [("interx", 6, 0.5), ("interx", 8, 0.9), ("sat", 6, 0.9)])
+def test_tied_minimal_keys_fall_back_to_the_binary_heap(mode, Hp, block_x):
+    """Mirror-symmetric searches pop tied minima all the time: the block-min open list must notice, and the result must
+    still be the reference's (pop sequence and tree included), now produced by the libstdc++-faithful heap."""
+    options = problems.make_options(mode, Hp=Hp)
+    mpa = problems.get_mpa(options)
+    sym = problems.symmetric_problem(options, mpa, block_x=block_x)
+    _, _, traces = _oracle().plan_batch(options, mpa, [sym], trace=True)
+    assert problems.tied_pops(traces[0]) > 0  # the construction does what it says
+    rng = np.random.default_rng(11)
+    ordinary = [problems.road_problem(rng, options, mpa, convex=(mode == "sat")) for _ in range(3)]
+    gpu, stats = check_batch(options, mpa, [ordinary[0], sym, ordinary[1], sym, ordinary[2]])
+    assert stats["queue_fallbacks"] >= 2
+    assert np.array_equal(gpu[1:2].tobytes(), gpu[3:4].tobytes())
+
+
+def test_random_road_problems_never_fall_back():
+    options, mpa, iters = problems.problem_set("interx", 21, 24, Hp=6)
+    _, stats = check_batch(options, mpa, iters)
+    assert stats["queue_fallbacks"] == 0

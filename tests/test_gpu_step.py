@@ -145,3 +145,31 @@ def test_explorative_batch_of_prioritizations_one_launch():
     assert chosen_gpu == chosen_ref and np.array_equal(cost_gpu, cost_ref)
     assert np.isfinite(cost_gpu[0]).all()  # the current prioritization is feasible
     opt.handle.close()
+
+
+def test_fallback_while_a_predecessor_is_still_planning():
+    """Vehicle 1 (mirror-symmetric: tied keys -> binary-heap fallback) starts speculatively while its predecessor,
+    a long search, is still running; the predecessor's areas arrive during or after the fallback."""
+    from oracle import oracle
+    from pdmpc.optimizer import GraphSearchHip
+    import problems
+
+    options = problems.make_options("interx", Hp=8)
+    options.max_vehicles = 8
+    options.max_nodes = 1 << 16
+    mpa = problems.get_mpa(options)
+    rng = np.random.default_rng(2)
+    heavy = max((problems.road_problem(rng, options, mpa) for _ in range(12)), key=lambda it: len(it.dynamic_obstacle_area) + len(it.obstacles))
+    sym = problems.symmetric_problem(options, mpa, block_x=0.5)
+    prob = {"iters": [heavy, sym, sym], "preds": [[], [0], [0, 1]], "fallback": [None, None, None], "level_sizes": [1, 1, 1]}
+    opt = GraphSearchHip(options)
+    try:
+        opt._ensure_mpa(mpa)
+        opt.handle.pack_step(prob["iters"], prob["preds"], [[], [], []])
+        opt.handle.launch()
+        gpu = opt.handle.fetch(3)
+        ref, _ = oracle.plan_step(options, mpa, prob)
+        assert_records_equal(gpu, ref, "fallback under speculation")
+        assert opt.handle.stats()["queue_fallbacks"] >= 1
+    finally:
+        opt.handle.close()

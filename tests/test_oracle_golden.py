@@ -230,3 +230,16 @@ def test_unobstructed_search_equals_obstructed_search_when_obstacles_are_far():
     for a, b in zip(t1, t2):
         assert np.array_equal(a.pops, b.pops)
     assert np.array_equal(r1["y_predicted"], r2["y_predicted"], equal_nan=True)
+
+
+def test_symmetric_problem_really_ties():
+    """tests/problems.symmetric_problem (used by the GPU fallback tests) pops tied minimal keys in the reference algorithm."""
+    import problems
+
+    options = problems.make_options("interx", Hp=6)
+    mpa = problems.get_mpa(options)
+    _, _, traces = oracle.plan_batch(options, mpa, [problems.symmetric_problem(options, mpa, block_x=0.5)], trace=True)
+    assert problems.tied_pops(traces[0]) > 50
+    rng = np.random.default_rng(3)
+    _, _, traces = oracle.plan_batch(options, mpa, [problems.road_problem(rng, options, mpa)], trace=True)
+    assert problems.tied_pops(traces[0]) == 0
