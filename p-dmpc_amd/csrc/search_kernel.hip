@@ -82,6 +82,11 @@ __device__ __forceinline__ bool is_nan(double v) { return v != v; }
 typedef LDS_AS d2 lds_d2;
 typedef LDS_AS double lds_f64;
 typedef LDS_AS uint32_t lds_u32;
+typedef LDS_AS int32_t lds_i32;
+typedef LDS_AS int16_t lds_i16;
+typedef LDS_AS uint8_t lds_u8;
+typedef LDS_AS uint64_t lds_mask64;
+typedef LDS_AS DevManPose lds_pose;
 
 // per-lane constants of the sift-down rounds (computed once per kernel)
 struct PopLane {
@@ -353,10 +358,10 @@ __device__ __forceinline__ void heap_pop(Search& S) {
 // Pass 1 (one lane per obstacle segment j) evaluates C2 for every shape segment i and keeps a 7-bit mask; lanes with
 // a non-zero mask append (j, mask, shape) to a compact list.  Pass 2 evaluates C1 for the listed pairs only.
 // Pass 1 over one soup range: sh2 holds shape A in [0, VMAX) and shape B in [VMAX, 2*VMAX).
-__device__ __forceinline__ int interx_pass1(const d2* sh2, int shapeB, int V, const d2* soup, int start, int M, uint32_t* cand, int count, int lane) {
+__device__ __forceinline__ int interx_pass1(const lds_d2* sh2, int shapeB, int V, const lds_d2* soup, int start, int M, lds_u32* cand, int count, int lane) {
     if (M < 2) return count;
-    const d2* L2 = soup + start;
-    const d2* sh = sh2 + shapeB * PDMPC_VMAX;
+    const lds_d2* L2 = soup + start;
+    const lds_d2* sh = sh2 + shapeB * PDMPC_VMAX;
     for (int base = 0; base < M - 1; base += PDMPC_WAVE) {
         const int j = base + lane;
         uint32_t bits = 0;
@@ -385,7 +390,7 @@ __device__ __forceinline__ int interx_pass1(const d2* sh2, int shapeB, int V, co
     return count;
 }
 
-__device__ bool interx_check(const d2* sh2, int V, const d2* soup, int so, int M_k, int ho, int Hk, int lo, int Ml, uint32_t* cand, int lane) {
+__device__ bool interx_check(const lds_d2* sh2, int V, const lds_d2* soup, int so, int M_k, int ho, int Hk, int lo, int Ml, lds_u32* cand, int lane) {
     if (V < 2) return false;
     int count = 0;
     count = interx_pass1(sh2, 0, V, soup, so, M_k, cand, count, lane);
@@ -400,7 +405,7 @@ __device__ bool interx_check(const d2* sh2, int V, const d2* soup, int so, int M
             const uint32_t e = cand[t];
             const int j = (int)(e & 0xffffu);
             const uint32_t bits = (e >> 16) & 0xffu;
-            const d2* sh = sh2 + (e >> 24) * PDMPC_VMAX;
+            const lds_d2* sh = sh2 + (e >> 24) * PDMPC_VMAX;
             const d2 q0 = soup[j], q1 = soup[j + 1];
             for (int i = 0; i < V - 1; ++i) {
                 if ((bits >> i) & 1u) {
@@ -421,7 +426,7 @@ __device__ bool interx_check(const d2* sh2, int V, const d2* soup, int so, int M
 // intersect_sat.m:1-42 for shape (V1 points) vs one polygon o (V2 points): one lane per separating axis.
 // An axis separates iff min1 - max2 > 0 or min2 - max1 > 0 (:33-40); a zero-length edge gives a NaN axis whose
 // comparisons are false.  collide <=> no axis of either polygon separates.
-__device__ bool sat_pair_wave(const d2* sh, int V1, const d2* o, int V2, int lane) {
+__device__ bool sat_pair_wave(const lds_d2* sh, int V1, const lds_d2* o, int V2, int lane) {
     const int A = V1 + V2;
     for (int base = 0; base < A; base += PDMPC_WAVE) {
         const int a = base + lane;
@@ -471,7 +476,7 @@ __device__ bool sat_pair_wave(const d2* sh, int V1, const d2* o, int V2, int lan
 }
 
 // are_constraints_satisfied_sat.m:15-35: every polygon of the step's soup (static then dynamic obstacles).
-__device__ bool sat_soup_wave(const d2* sh, int V1, const d2* soup, int M, int lane) {
+__device__ bool sat_soup_wave(const lds_d2* sh, int V1, const lds_d2* soup, int M, int lane) {
     int pos = 0;
     while (pos < M) {
         int end = M;  // next NaN separator at or after pos
@@ -493,7 +498,7 @@ __device__ bool sat_soup_wave(const d2* sh, int V1, const d2* soup, int M, int l
 
 // intersect_lanelet_boundary.m:1-56 on the soup [left, NaN, right, NaN]: one lane per boundary segment,
 // AABB pre-filter (:20,40) then intersect_sat(shape, segment) with the segment as a 2-point polygon.
-__device__ bool sat_boundary_wave(const d2* sh, int V1, const d2* ll, int M, int lane) {
+__device__ bool sat_boundary_wave(const lds_d2* sh, int V1, const lds_d2* ll, int M, int lane) {
     if (M < 2) return false;
     double max_x = sh[0].x, min_x = sh[0].x, max_y = sh[0].y, min_y = sh[0].y;
     for (int v = 1; v < V1; ++v) {
@@ -557,8 +562,8 @@ __device__ bool sat_boundary_wave(const d2* sh, int V1, const d2* ll, int M, int
 }
 
 // copy `count` 16-byte elements HBM -> LDS, thread-strided over the whole workgroup (coalesced)
-__device__ __forceinline__ void stage16(void* dst_lds, const void* src, int count, int tid) {
-    d2* d = (d2*)dst_lds;
+__device__ __forceinline__ void stage16(LDS_AS void* dst_lds, const void* src, int count, int tid) {
+    lds_d2* d = (lds_d2*)dst_lds;
     const d2* s = (const d2*)src;
     for (int i = tid; i < count; i += PDMPC_THREADS) d[i] = s[i];
 }
@@ -572,14 +577,14 @@ __device__ __forceinline__ void wave_sync() {
 
 // read-only view of what an edge check needs (shared by the sequencing wave and the helper waves)
 struct CheckCtx {
-    const d2* l_area;
+    const lds_d2* l_area;
     const d2* g_area;
-    const d2* l_soup;
-    const int32_t* l_soff;
-    const int32_t* l_hoff;
+    const lds_d2* l_soup;
+    const lds_i32* l_soff;
+    const lds_i32* l_hoff;
     int areas_in_lds, ll_base, ll_len, Hp, checker;
-    d2* sh;          // this wave's shape scratch: A in [0, VMAX), B in [VMAX, 2 VMAX)
-    uint32_t* cand;  // this wave's candidate list
+    lds_d2* sh;     // this wave's shape scratch: A in [0, VMAX), B in [VMAX, 2 VMAX)
+    lds_u32* cand;  // this wave's candidate list
 };
 
 // eval_edge_exact (GraphSearch.m:111-196) for node `id` (1-based): true = collision-free.  A pure function of the
@@ -632,7 +637,7 @@ __device__ bool edge_valid(const Search& S, const CheckCtx& C, uint32_t id, int 
     return !hit;
 }
 
-__device__ __forceinline__ uint32_t lds_load_u32(const volatile uint32_t* p) { return *p; }
+__device__ __forceinline__ uint32_t lds_load_u32(const volatile lds_u32* p) { return *p; }
 
 #define VS_UNKNOWN 0u
 #define VS_VALID 1u
@@ -643,7 +648,7 @@ __device__ __forceinline__ uint32_t lds_load_u32(const volatile uint32_t* p) { r
 
 // validity cache: 0 unknown, 1 valid, 2 invalid; the first NV nodes in LDS, the rest in HBM (same CU -> same L1)
 struct VState {
-    volatile uint8_t* l;
+    volatile lds_u8* l;
     uint8_t* g;
     uint32_t NV;
 };
@@ -659,13 +664,22 @@ __device__ __forceinline__ void vs_store(const VState& v, uint32_t i0, uint32_t 
 }
 // unknown -> claimed, by exactly one of the waves that try (one lane calls): the winner evaluates the edge
 __device__ __forceinline__ bool vs_claim(const VState& v, uint32_t i0) {
-    uint8_t* b = (i0 < v.NV) ? (uint8_t*)v.l + i0 : v.g + i0;
-    uint32_t* w = (uint32_t*)((uintptr_t)b & ~(uintptr_t)3);
-    const uint32_t sh = (uint32_t)((uintptr_t)b & 3u) * 8u;
+    const uint32_t sh = (i0 & 3u) * 8u;  // (both arrays are at least 4-byte aligned)
+    if (i0 < v.NV) {
+        lds_u32* w = (lds_u32*)(v.l + (i0 & ~3u));
+        for (;;) {
+            const uint32_t old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((old >> sh) & 0xFFu) return false;
+            uint32_t expect = old;
+            if (__hip_atomic_compare_exchange_strong(w, &expect, old | (VS_CLAIMED << sh), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return true;
+        }
+    }
+    uint32_t* w = (uint32_t*)(v.g + (i0 & ~3u));
     for (;;) {
         const uint32_t old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if ((old >> sh) & 0xFFu) return false;
-        if (atomicCAS(w, old, old | (VS_CLAIMED << sh)) == old) return true;
+        uint32_t expect = old;
+        if (__hip_atomic_compare_exchange_strong(w, &expect, old | (VS_CLAIMED << sh), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return true;
     }
 }
 
@@ -692,15 +706,15 @@ __device__ __forceinline__ bool vs_claim(const VState& v, uint32_t i0) {
 
 namespace {
 
-__device__ __forceinline__ unsigned long long sh_load64(volatile uint32_t* sh, int lo) {
+__device__ __forceinline__ unsigned long long sh_load64(volatile lds_u32* sh, int lo) {
     return (unsigned long long)sh[lo] | ((unsigned long long)sh[lo + 1] << 32);
 }
 
 struct SpecCtx {
-    volatile uint32_t* sh;
-    d2* l_soup;
-    const int32_t* l_soff;
-    const int32_t* l_lit;  // literal soup length per step
+    volatile lds_u32* sh;
+    lds_d2* l_soup;
+    const lds_i32* l_soff;
+    const lds_i32* l_lit;  // literal soup length per step
     const pdmpc_vehicle_out* out;
     const int32_t* pred;   // this vehicle's predecessor slots
     int n_pred, Hp;
@@ -738,14 +752,15 @@ __device__ bool node_hits_areas(const Search& S, const CheckCtx& C, const SpecCt
     const NodeRec pn = node_load(S, cn.parent - 1);
     const int m = NODE_MAN(cn.packed), ncols = NODE_COLS(cn.packed), k = NODE_K(cn.packed);
     const double c = pn.cs, s = pn.sn, pX = pn.x, pY = pn.y;
-    const d2* area = (C.areas_in_lds ? C.l_area : C.g_area) + (size_t)m * 3 * PDMPC_VMAX;
+    const size_t abase = (size_t)m * 3 * PDMPC_VMAX;
+    auto area_at = [&](int i) -> d2 { return C.areas_in_lds ? (d2)C.l_area[abase + i] : C.g_area[abase + i]; };
     bool hit = false;
-    d2 a0 = area[0];
+    d2 a0 = area_at(0);
     d2 p0;
     p0.x = c * a0.x - s * a0.y + pX;
     p0.y = s * a0.x + c * a0.y + pY;
     for (int i = 0; i + 1 < ncols; ++i) {
-        const d2 a1 = area[i + 1];
+        const d2 a1 = area_at(i + 1);
         d2 p1;
         p1.x = c * a1.x - s * a1.y + pX;
         p1.y = s * a1.x + c * a1.y + pY;
@@ -755,7 +770,7 @@ __device__ bool node_hits_areas(const Search& S, const CheckCtx& C, const SpecCt
         while (rem) {
             const int p = (int)__builtin_ctzll(rem);
             rem &= rem - 1;
-            const d2* poly = P.l_soup + P.l_soff[k - 1] + P.l_lit[k - 1] + p * PDMPC_VMAX;
+            const lds_d2* poly = P.l_soup + P.l_soff[k - 1] + P.l_lit[k - 1] + p * PDMPC_VMAX;
             d2 q0 = poly[0];
             for (int j = 0; j + 1 < PDMPC_VMAX; ++j) {
                 const d2 q1 = poly[j + 1];
@@ -831,7 +846,7 @@ __device__ bool arrival_sync(const Search& S, const CheckCtx& C, const SpecCtx& 
 
 // One look at the done flags of the predecessors that are still planning; if some finished, their set is posted in
 // SH_ARR and the state goes ST_RUN -> ST_ARRIVED (which loses only against ST_DONE / ST_TIE).  Whole wave calls.
-__device__ __forceinline__ bool poll_predecessors(const KernelArgs& A, const SpecCtx& P, volatile uint32_t* l_shared, int lane) {
+__device__ __forceinline__ bool poll_predecessors(const KernelArgs& A, const SpecCtx& P, volatile lds_u32* l_shared, int lane) {
     const unsigned long long pend = sh_load64(l_shared, SH_PEND_LO);
     if (!pend) return false;
     bool d = false;
@@ -853,14 +868,14 @@ __device__ __forceinline__ bool poll_predecessors(const KernelArgs& A, const Spe
 struct Ctx {
     int tid, lane, wave, slot, Hp, n, nw;
     const DevVehicle* V;
-    uint64_t* l_mask;
-    int16_t* l_mi;
-    DevManPose* l_pose;
-    double *l_rx, *l_ry;
-    volatile uint32_t* l_shared;
+    lds_mask64* l_mask;
+    lds_i16* l_mi;
+    lds_pose* l_pose;
+    lds_f64 *l_rx, *l_ry;
+    volatile lds_u32* l_shared;
     VState VS;
-    double *l_dcum, *l_term;
-    d2* l_chxy;
+    lds_f64 *l_dcum, *l_term;
+    lds_d2* l_chxy;
     Search S;
     CheckCtx C;
     SpecCtx P;
@@ -882,14 +897,14 @@ template <int CHECKER, bool BM>
 __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
     const int tid = X.tid, lane = X.lane, wave = X.wave, slot = X.slot, Hp = X.Hp, n = X.n, nw = X.nw;
     const DevVehicle* __restrict__ V = X.V;
-    uint64_t* l_mask = X.l_mask;
-    int16_t* l_mi = X.l_mi;
-    DevManPose* l_pose = X.l_pose;
-    double *l_rx = X.l_rx, *l_ry = X.l_ry;
-    volatile uint32_t* l_shared = X.l_shared;
+    lds_mask64* l_mask = X.l_mask;
+    lds_i16* l_mi = X.l_mi;
+    lds_pose* l_pose = X.l_pose;
+    lds_f64 *l_rx = X.l_rx, *l_ry = X.l_ry;
+    volatile lds_u32* l_shared = X.l_shared;
     const VState& VS = X.VS;
-    double *l_dcum = X.l_dcum, *l_term = X.l_term;
-    d2* l_chxy = X.l_chxy;
+    lds_f64 *l_dcum = X.l_dcum, *l_term = X.l_term;
+    lds_d2* l_chxy = X.l_chxy;
     Search& S = X.S;
     const CheckCtx& C = X.C;
     const SpecCtx& P = X.P;
@@ -1235,7 +1250,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
             PROF_STOP(4)
             const int k_exp = cK + 1;            // :13
             const int steps_to_go = Hp - k_exp;  // :37
-            const uint64_t* mrow = l_mask + ((size_t)(k_exp - 1) * n + (cTrim - 1)) * nw;
+            const lds_mask64* mrow = l_mask + ((size_t)(k_exp - 1) * n + (cTrim - 1)) * nw;
             uint32_t total = 0;
             for (int w = 0; w < nw; ++w) total += (uint32_t)__builtin_popcountll(mrow[w]);
             total = uni_u(total);
@@ -1258,7 +1273,11 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                 if (active) {
                     const int t2 = w * 64 + lane;  // 0-based successor trim
                     const int m = (int)l_mi[(cTrim - 1) * n + t2];
-                    const DevManPose mp = l_pose[m];
+                    DevManPose mp;
+                    mp.dx = l_pose[m].dx;
+                    mp.dy = l_pose[m].dy;
+                    mp.dyaw = l_pose[m].dyaw;
+                    mp.n_cols = l_pose[m].n_cols;
                     ch.x = cs * mp.dx - sn * mp.dy + curX;  // :53
                     ch.y = sn * mp.dx + cs * mp.dy + curY;  // :54
                     ch.yaw = curYaw + mp.dyaw;              // :55
@@ -1410,29 +1429,30 @@ __device__ __forceinline__ void search_body(const KernelArgs& A) {
 #endif
 
     // ---- LDS carve
-    uint64_t* l_mask = (uint64_t*)(smem + A.lds.mask);
-    int16_t* l_mi = (int16_t*)(smem + A.lds.man_index);
-    DevManPose* l_pose = (DevManPose*)(smem + A.lds.pose);
-    double* l_rx = (double*)(smem + A.lds.ref);
-    double* l_ry = l_rx + PDMPC_HP_MAX;
-    double* l_dtv = l_ry + PDMPC_HP_MAX;
-    uint32_t* l_path = (uint32_t*)(smem + A.lds.path);
-    int32_t* l_soff = (int32_t*)(l_path + PDMPC_HP_MAX + 2);  // soup offsets [Hp+1], hdv offsets [Hp+1]
-    int32_t* l_hoff = l_soff + PDMPC_HP_MAX + 1;
-    volatile uint32_t* l_shared = (volatile uint32_t*)(l_hoff + PDMPC_HP_MAX + 1);
-    int32_t* l_lit = (int32_t*)(l_shared + SH_WORDS);  // literal soup length per step
-    d2* l_soup = (d2*)(smem + A.lds.soup);
+    LDS_AS unsigned char* lsm = (LDS_AS unsigned char*)smem;  // every LDS pointer carries its address space (ds_* accesses)
+    lds_mask64* l_mask = (lds_mask64*)(lsm + A.lds.mask);
+    lds_i16* l_mi = (lds_i16*)(lsm + A.lds.man_index);
+    lds_pose* l_pose = (lds_pose*)(lsm + A.lds.pose);
+    lds_f64* l_rx = (lds_f64*)(lsm + A.lds.ref);
+    lds_f64* l_ry = l_rx + PDMPC_HP_MAX;
+    lds_f64* l_dtv = l_ry + PDMPC_HP_MAX;
+    lds_u32* l_path = (lds_u32*)(lsm + A.lds.path);
+    lds_i32* l_soff = (lds_i32*)(l_path + PDMPC_HP_MAX + 2);  // soup offsets [Hp+1], hdv offsets [Hp+1]
+    lds_i32* l_hoff = l_soff + PDMPC_HP_MAX + 1;
+    volatile lds_u32* l_shared = (volatile lds_u32*)(l_hoff + PDMPC_HP_MAX + 1);
+    lds_i32* l_lit = (lds_i32*)(l_shared + SH_WORDS);  // literal soup length per step
+    lds_d2* l_soup = (lds_d2*)(lsm + A.lds.soup);
     VState VS;
-    VS.l = (volatile uint8_t*)(smem + A.lds.vstate);
+    VS.l = (volatile lds_u8*)(lsm + A.lds.vstate);
     VS.NV = (uint32_t)A.NV;
-    double* l_dcum = (double*)(smem + A.lds.expand);               // [HP_MAX][HP_MAX] cumulative dt*v_ref per (k_exp, t)
-    double* l_term = l_dcum + PDMPC_HP_MAX * PDMPC_HP_MAX;         // [16 children][HP_MAX] cost-to-go terms
-    d2* l_chxy = (d2*)(l_term + 16 * PDMPC_HP_MAX);                // [16] child positions
+    lds_f64* l_dcum = (lds_f64*)(lsm + A.lds.expand);             // [HP_MAX][HP_MAX] cumulative dt*v_ref per (k_exp, t)
+    lds_f64* l_term = l_dcum + PDMPC_HP_MAX * PDMPC_HP_MAX;       // [16 children][HP_MAX] cost-to-go terms
+    lds_d2* l_chxy = (lds_d2*)(l_term + 16 * PDMPC_HP_MAX);       // [16] child positions
 
     Search S;
-    S.ln = (lds_d2*)(smem + A.lds.nodes);
-    S.lkey = (lds_f64*)(smem + A.lds.heap_key);
-    S.lid = (lds_u32*)(smem + A.lds.heap_id);
+    S.ln = (lds_d2*)(lsm + A.lds.nodes);
+    S.lkey = (lds_f64*)(lsm + A.lds.heap_key);
+    S.lid = (lds_u32*)(lsm + A.lds.heap_id);
     S.NL = (uint32_t)A.NL;
     S.HL = (uint32_t)A.HL;
     S.max_nodes = A.max_nodes;
@@ -1445,7 +1465,7 @@ __device__ __forceinline__ void search_body(const KernelArgs& A) {
     VS.g = A.arena.vstate + voff;
 
     CheckCtx C;
-    C.l_area = (const d2*)(smem + A.lds.area);
+    C.l_area = (const lds_d2*)(lsm + A.lds.area);
     C.g_area = (const d2*)A.man_area;
     C.l_soup = l_soup;
     C.l_soff = l_soff;
@@ -1453,8 +1473,8 @@ __device__ __forceinline__ void search_body(const KernelArgs& A) {
     C.areas_in_lds = A.areas_in_lds;
     C.Hp = Hp;
     C.checker = A.checker;
-    C.sh = (d2*)(smem + A.lds.shape) + wave * 2 * PDMPC_VMAX;
-    C.cand = (uint32_t*)(smem + A.lds.cand) + (size_t)wave * A.cand_cap;
+    C.sh = (lds_d2*)(lsm + A.lds.shape) + wave * 2 * PDMPC_VMAX;
+    C.cand = (lds_u32*)(lsm + A.lds.cand) + (size_t)wave * A.cand_cap;
 
     pdmpc_vehicle_out* __restrict__ O = A.out + slot;
 
@@ -1464,7 +1484,7 @@ __device__ __forceinline__ void search_body(const KernelArgs& A) {
         stage16(l_mask, A.succ_mask, (mask_bytes + 15) / 16, tid);
         stage16(l_mi, A.man_index, (n * n * 2 + 15) / 16, tid);
         stage16(l_pose, A.man_pose, A.n_man * 2, tid);
-        if (A.areas_in_lds) stage16(smem + A.lds.area, A.man_area, A.n_man * 3 * PDMPC_VMAX, tid);
+        if (A.areas_in_lds) stage16(lsm + A.lds.area, A.man_area, A.n_man * 3 * PDMPC_VMAX, tid);
     }
     // ---- prologue 2: vehicle record, result record defaults
     if (tid < Hp) {
@@ -1634,7 +1654,7 @@ __device__ __forceinline__ void search_body(const KernelArgs& A) {
 #ifdef PDMPC_PROFILE
     X.rt_start = rt_start;
 #endif
-    X.Q.kring = (lds_f64*)(smem + A.lds.heap_key);  // the block-min queue lives where the binary heap would
+    X.Q.kring = (lds_f64*)(lsm + A.lds.heap_key);  // the block-min queue lives where the binary heap would
     X.Q.m1 = X.Q.kring + A.bm_kr;
     X.Q.m2 = X.Q.m1 + A.bm_nb;
     X.Q.gkey = S.gkey;
