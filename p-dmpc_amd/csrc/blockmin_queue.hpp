@@ -55,12 +55,18 @@ __device__ __forceinline__ uint32_t wave_min_u32_lane63(uint32_t v) {
     return v;
 }
 // minimum over the 64 lanes of non-negative doubles (no NaNs), uniform result: their bit patterns order like unsigned
-// integers, so the high words are reduced first and the low words among the lanes that hold the minimal high word
+// integers, so the high words are reduced first; if a single lane holds the minimal high word (the usual case) its low
+// word completes the answer, otherwise the low words of those lanes are reduced as well
 __device__ __forceinline__ double wave_min_d(double x) {
     const uint64_t u = (uint64_t)__double_as_longlong(x);
     const uint32_t hi = (uint32_t)(u >> 32), lo = (uint32_t)u;
     const uint32_t mh = (uint32_t)__builtin_amdgcn_readlane((int)wave_min_u32_lane63(hi), 63);
-    const uint32_t ml = (uint32_t)__builtin_amdgcn_readlane((int)wave_min_u32_lane63(hi == mh ? lo : 0xFFFFFFFFu), 63);
+    const unsigned long long holders = __ballot(hi == mh);
+    uint32_t ml;
+    if ((holders & (holders - 1ull)) == 0ull)
+        ml = (uint32_t)__builtin_amdgcn_readlane((int)lo, __builtin_ctzll(holders));
+    else
+        ml = (uint32_t)__builtin_amdgcn_readlane((int)wave_min_u32_lane63(hi == mh ? lo : 0xFFFFFFFFu), 63);
     return __longlong_as_double((long long)(((uint64_t)mh << 32) | ml));
 }
 
@@ -96,17 +102,20 @@ __device__ __forceinline__ uint32_t bm_pop(BmQueue& Q, uint32_t nn) {
     const double inf = bm_inf();
     const bool multi = nn > 4096u;
     uint32_t g = 0;
+    double v1, mn1;
     if (multi) {
         const double v2 = Q.m2[lane];
-        const double mn2 = wave_min_d(v2);
-        if (!(mn2 < inf)) return 0xFFFFFFFFu;
-        const unsigned long long b2 = __ballot(v2 == mn2);
+        mn1 = wave_min_d(v2);  // the minimum of the best group is the minimum of one of its blocks: no second reduction
+        if (!(mn1 < inf)) return 0xFFFFFFFFu;
+        const unsigned long long b2 = __ballot(v2 == mn1);
         if (b2 & (b2 - 1ull)) Q.tie = true;
         g = (uint32_t)__builtin_ctzll(b2);
+        v1 = Q.m1[g * 64u + (uint32_t)lane];
+    } else {
+        v1 = Q.m1[lane];  // m1 is +inf beyond the last block
+        mn1 = wave_min_d(v1);
+        if (!(mn1 < inf)) return 0xFFFFFFFFu;
     }
-    const double v1 = Q.m1[g * 64u + (uint32_t)lane];  // m1 is +inf beyond the last block
-    const double mn1 = wave_min_d(v1);
-    if (!(mn1 < inf)) return 0xFFFFFFFFu;
     const unsigned long long b1 = __ballot(v1 == mn1);
     if (b1 & (b1 - 1ull)) Q.tie = true;
     const uint32_t bl = (uint32_t)__builtin_ctzll(b1);
