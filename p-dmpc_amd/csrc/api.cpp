@@ -171,7 +171,7 @@ int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in, int cand_cap_in)
     // fixed part after the tables
     const uint32_t ref_bytes = 3 * PDMPC_HP_MAX * 8;
     const uint32_t shape_bytes = PDMPC_WAVES_PER_VEHICLE * 2 * PDMPC_VMAX * 16;
-    const uint32_t path_bytes = align16((PDMPC_HP_MAX + 2) * 4 + 2 * (PDMPC_HP_MAX + 1) * 4 + 16 * 4 + PDMPC_HP_MAX * 4);
+    const uint32_t path_bytes = align16((PDMPC_HP_MAX + 2) * 4 + 2 * (PDMPC_HP_MAX + 1) * 4 + 32 * 4 + PDMPC_HP_MAX * 4);  // ... + SH_WORDS shared words + ...
     const uint32_t soup_bytes = (uint32_t)std::max(hb.soup_cap, 1) * 16;
     const uint32_t expand_bytes = (2 * PDMPC_HP_MAX * PDMPC_HP_MAX) * 8 + 16 * 16;
     const uint32_t fixed_rest = ref_bytes + shape_bytes + path_bytes + soup_bytes + expand_bytes;

@@ -76,8 +76,17 @@ __device__ __forceinline__ void bm_init(BmQueue& Q, int tid, int nthreads) {
     for (uint32_t i = (uint32_t)tid; i < 64u; i += (uint32_t)nthreads) Q.m2[i] = inf;
 }
 
-// Push the nodes i0 (0-based, consecutive over the active lanes, all >= nn_before) with keys f.  Whole wave calls;
-// `active` selects the lanes that carry a node.  nn_after = tree size after this batch.
+// Entries written into the ring by the expanding wave but not yet pushed by the queue's owner may already have
+// recycled the ring slots of the oldest nodes: a block counts as resident in the ring only if it starts at least
+// BM_INFLIGHT nodes inside it (the owner's tree size lags the expander's by at most one expansion).
+#define BM_INFLIGHT 128u
+
+__device__ __forceinline__ bool bm_in_ring(const BmQueue& Q, uint32_t block, uint32_t nn) { return block * 64u + Q.kr_mask + 1u >= nn + BM_INFLIGHT; }
+
+// Make the nodes i0 (0-based, consecutive over the active lanes, all >= nn_before) with keys f visible to bm_find.
+// STORE_KEYS = false: the keys are already in the ring and in HBM (written by the expanding wave), only the block and
+// group minima are updated.  Whole wave calls; nn_after = tree size after this batch.
+template <bool STORE_KEYS>
 __device__ __forceinline__ void bm_push(BmQueue& Q, bool active, uint32_t i0, double f, uint32_t nn_before, uint32_t nn_after) {
     // entering a second group for the first time: m2 is not maintained while there is a single group
     if (nn_before <= 4096u && nn_after > 4096u) {
@@ -86,8 +95,10 @@ __device__ __forceinline__ void bm_push(BmQueue& Q, bool active, uint32_t i0, do
         if (lane == 0) Q.m2[0] = v;
     }
     if (active) {
-        Q.kring[i0 & Q.kr_mask] = f;
-        Q.gkey[i0] = f;
+        if (STORE_KEYS) {
+            Q.kring[i0 & Q.kr_mask] = f;
+            Q.gkey[i0] = f;
+        }
         const unsigned long long bits = (unsigned long long)__double_as_longlong(f);
         __hip_atomic_fetch_min((lds_u64*)&Q.m1[i0 >> 6], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (nn_after > 4096u) __hip_atomic_fetch_min((lds_u64*)&Q.m2[i0 >> 12], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -95,34 +106,9 @@ __device__ __forceinline__ void bm_push(BmQueue& Q, bool active, uint32_t i0, do
     Q.open += (uint32_t)__builtin_popcountll(__ballot(active));
 }
 
-// Pop the entry with the minimal key: returns its 0-based node index, or 0xFFFFFFFF if the queue is empty.
-// nn = current tree size.  Sets Q.tie if the minimum was not unique (the caller must then discard the search).
-__device__ __forceinline__ uint32_t bm_pop(BmQueue& Q, uint32_t nn) {
-    const int lane = (int)(threadIdx.x & 63u);
-    const double inf = bm_inf();
-    const bool multi = nn > 4096u;
-    uint32_t g = 0;
-    double v1, mn1;
-    if (multi) {
-        const double v2 = Q.m2[lane];
-        mn1 = wave_min_d(v2);  // the minimum of the best group is the minimum of one of its blocks: no second reduction
-        if (!(mn1 < inf)) return 0xFFFFFFFFu;
-        const unsigned long long b2 = __ballot(v2 == mn1);
-        if (b2 & (b2 - 1ull)) Q.tie = true;
-        g = (uint32_t)__builtin_ctzll(b2);
-        v1 = Q.m1[g * 64u + (uint32_t)lane];
-    } else {
-        v1 = Q.m1[lane];  // m1 is +inf beyond the last block
-        mn1 = wave_min_d(v1);
-        if (!(mn1 < inf)) return 0xFFFFFFFFu;
-    }
-    const unsigned long long b1 = __ballot(v1 == mn1);
-    if (b1 & (b1 - 1ull)) Q.tie = true;
-    const uint32_t bl = (uint32_t)__builtin_ctzll(b1);
-    const uint32_t b = g * 64u + bl;
-    const uint32_t idx = b * 64u + (uint32_t)lane;
-    // the ring holds the nodes [nn - KR, nn): a block that starts inside it is read from LDS, older ones from HBM
-    const bool in_ring = b * 64u + Q.kr_mask + 1u >= nn;
+// keys of block b, one per lane (+inf for nodes that do not exist yet)
+__device__ __forceinline__ double bm_block_keys(const BmQueue& Q, uint32_t b, uint32_t nn, bool in_ring) {
+    const uint32_t idx = b * 64u + (threadIdx.x & 63u);
     double k;
     if (in_ring) {
         k = Q.kring[idx & Q.kr_mask];
@@ -132,24 +118,73 @@ __device__ __forceinline__ uint32_t bm_pop(BmQueue& Q, uint32_t nn) {
         // wave's earlier HBM stores (gfx9 counts loads and stores in the same vmcnt)
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     }
-    if (idx >= nn) k = inf;  // slots of nodes that do not exist yet hold stale keys
+    if (idx >= nn) k = bm_inf();  // slots of nodes that do not exist yet hold stale keys
+    return k;
+}
+
+struct BmFound {
+    uint32_t idx;  // 0-based node index; 0xFFFFFFFF: the queue is empty
+    double key;
+};
+
+// The entry with the minimal key (not removed).  nn = current tree size.  Sets Q.tie if the minimum is not unique.
+__device__ __forceinline__ BmFound bm_find(BmQueue& Q, uint32_t nn) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const double inf = bm_inf();
+    BmFound r;
+    r.idx = 0xFFFFFFFFu;
+    r.key = inf;
+    uint32_t g = 0;
+    double v1, mn1;
+    if (nn > 4096u) {
+        const double v2 = Q.m2[lane];
+        mn1 = wave_min_d(v2);  // the minimum of the best group is the minimum of one of its blocks: no second reduction
+        if (!(mn1 < inf)) return r;
+        const unsigned long long b2 = __ballot(v2 == mn1);
+        if (b2 & (b2 - 1ull)) Q.tie = true;
+        g = (uint32_t)__builtin_ctzll(b2);
+        v1 = Q.m1[g * 64u + lane];
+    } else {
+        v1 = Q.m1[lane];  // m1 is +inf beyond the last block
+        mn1 = wave_min_d(v1);
+        if (!(mn1 < inf)) return r;
+    }
+    const unsigned long long b1 = __ballot(v1 == mn1);
+    if (b1 & (b1 - 1ull)) Q.tie = true;
+    const uint32_t b = g * 64u + (uint32_t)__builtin_ctzll(b1);
+    const double k = bm_block_keys(Q, b, nn, bm_in_ring(Q, b, nn));
     const unsigned long long b0 = __ballot(k == mn1);
     if (b0 & (b0 - 1ull)) Q.tie = true;
-    const uint32_t e = (uint32_t)__builtin_ctzll(b0);
-    const uint32_t cur = b * 64u + e;
-    // remove: key -> +inf, m1[b] = min of the rest, m2[g] = min over the group's blocks
-    const double krest = (uint32_t)lane == e ? inf : k;
-    const double new1 = wave_min_d(krest);
-    if ((uint32_t)lane == e) {
+    r.idx = b * 64u + (uint32_t)__builtin_ctzll(b0);
+    r.key = mn1;
+    return r;
+}
+
+// Remove node idx (which must be in the queue): key -> +inf, block and group minima recomputed.
+__device__ __forceinline__ void bm_remove(BmQueue& Q, uint32_t idx, uint32_t nn) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const double inf = bm_inf();
+    const uint32_t b = idx >> 6, e = idx & 63u;
+    const bool in_ring = bm_in_ring(Q, b, nn);
+    const double k = bm_block_keys(Q, b, nn, in_ring);
+    const double new1 = wave_min_d(lane == e ? inf : k);
+    if (lane == e) {
         if (in_ring) Q.kring[idx & Q.kr_mask] = inf;
         Q.gkey[idx] = inf;
         Q.m1[b] = new1;
     }
-    if (multi) {
-        const double v1r = (uint32_t)lane == bl ? new1 : v1;
-        const double new2 = wave_min_d(v1r);
+    if (nn > 4096u) {
+        const uint32_t g = b >> 6;
+        const double v1 = Q.m1[g * 64u + lane];
+        const double new2 = wave_min_d(lane == (b & 63u) ? new1 : v1);
         if (lane == 0) Q.m2[g] = new2;
     }
     --Q.open;
-    return cur;
+}
+
+// Pop = find + remove.  Returns the 0-based node index, or 0xFFFFFFFF if the queue is empty.
+__device__ __forceinline__ uint32_t bm_pop(BmQueue& Q, uint32_t nn) {
+    const BmFound f = bm_find(Q, nn);
+    if (f.idx != 0xFFFFFFFFu) bm_remove(Q, f.idx, nn);
+    return f.idx;
 }

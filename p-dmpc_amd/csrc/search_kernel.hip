@@ -698,7 +698,16 @@ __device__ __forceinline__ bool vs_claim(const VState& v, uint32_t i0) {
 #define SH_CAND_VER 9  // block-min mode: bumped by the scout wave when it rewrote the candidate list
 #define SH_CAND 10     // block-min mode: BM_NCAND node ids proposed for pre-validation, most urgent first (0 = none)
 #define BM_NCAND 6
-#define SH_WORDS 16
+#define SH_Q2E_SEQ 16   // block-min mode, queue wave -> expander wave: number of the hand-over ...
+#define SH_Q2E_ID 17    // ... and the popped node (1-based id) to evaluate and expand
+#define SH_E2Q_SEQ 18   // expander wave -> queue wave: number of the hand-over this reply answers
+#define SH_E2Q_FLAGS 19 // E2Q_* bits
+#define SH_E2Q_CNT 20   // children created (their keys are in the key ring, their records in the tree)
+#define SH_Q_SYNC 21    // set by the queue wave while it is inside arrival_sync (the expander must not enter before: it may owe a reply)
+#define SH_WORDS 32
+#define E2Q_VALID 1u     // the edge into the node is collision-free
+#define E2Q_GOAL 2u      // ... and the node is at the horizon: the search is over
+#define E2Q_OVERFLOW 4u  // the arena cannot take the node's children
 #define ST_RUN 0u
 #define ST_ARRIVED 1u
 #define ST_DONE 2u
@@ -890,6 +899,120 @@ struct Ctx {
 #endif
 };
 
+struct ExpandEnv {
+    lds_mask64* l_mask;
+    lds_i16* l_mi;
+    lds_pose* l_pose;
+    lds_f64 *l_rx, *l_ry, *l_dcum, *l_term;
+    lds_d2* l_chxy;
+    int Hp, n, nw, lane;
+};
+
+// expand_node.m:1-91 for the popped node `cur` (1-based id, record cn, cos/sin of its yaw): creates the children's
+// records (validity unknown) and calls push(mask, active, i0, f, cnt) once per 64-trim word of the successor mask, with
+// nnodes still the index of the word's first child; the caller's push makes the children visible in its open list.
+// Returns false if the arena cannot take the children (nothing is created then).
+template <class Push>
+__device__ __forceinline__ bool expand_children(const ExpandEnv& E, Search& S, const VState& VS, uint32_t cur, const NodeRec& cn, double cs, double sn,
+                                                uint32_t& nnodes, Push push) {
+    const int Hp = E.Hp, n = E.n, nw = E.nw, lane = E.lane;
+    lds_mask64* l_mask = E.l_mask;
+    lds_i16* l_mi = E.l_mi;
+    lds_pose* l_pose = E.l_pose;
+    lds_f64 *l_rx = E.l_rx, *l_ry = E.l_ry, *l_dcum = E.l_dcum, *l_term = E.l_term;
+    lds_d2* l_chxy = E.l_chxy;
+    const uint32_t cpk = uni_u(cn.packed);
+    const int cTrim = NODE_TRIM(cpk);  // 1-based
+    const int cK = NODE_K(cpk);
+    const double curX = cn.x, curY = cn.y, curYaw = cn.yaw, curG = cn.g;
+    const int k_exp = cK + 1;            // :13
+    const int steps_to_go = Hp - k_exp;  // :37
+    const lds_mask64* mrow = l_mask + ((size_t)(k_exp - 1) * n + (cTrim - 1)) * nw;
+    uint32_t total = 0;
+    for (int w = 0; w < nw; ++w) total += (uint32_t)__builtin_popcountll(mrow[w]);
+    total = uni_u(total);
+    if (nnodes + total > S.max_nodes) {
+        return false;
+    }
+    for (int w = 0; w < nw; ++w) {
+        uint64_t mask = mrow[w];
+        {
+            const uint32_t lo = uni_u((uint32_t)mask), hi = uni_u((uint32_t)(mask >> 32));
+            mask = ((uint64_t)hi << 32) | lo;
+        }
+        const int cnt = __builtin_popcountll(mask);
+        const bool active = (mask >> lane) & 1ull;
+        const int rank = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        double f = 0.0;
+        NodeRec ch;
+        uint32_t i0 = 0;
+        if (active) {
+            const int t2 = w * 64 + lane;  // 0-based successor trim
+            const int m = (int)l_mi[(cTrim - 1) * n + t2];
+            DevManPose mp;
+            mp.dx = l_pose[m].dx;
+            mp.dy = l_pose[m].dy;
+            mp.dyaw = l_pose[m].dyaw;
+            mp.n_cols = l_pose[m].n_cols;
+            ch.x = cs * mp.dx - sn * mp.dy + curX;  // :53
+            ch.y = sn * mp.dx + cs * mp.dy + curY;  // :54
+            ch.yaw = curYaw + mp.dyaw;              // :55
+            double expG = curG;
+            {
+                const double ddx = ch.x - l_rx[k_exp - 1], ddy = ch.y - l_ry[k_exp - 1];
+                const double nrm = sqrt(ddx * ddx + ddy * ddy);
+                expG = expG + nrm * nrm;  // :61
+            }
+            ch.g = expG;
+            ch.cs = 0.0;
+            ch.sn = 0.0;
+            ch.parent = cur;
+            ch.packed = (uint32_t)(t2 + 1) | ((uint32_t)k_exp << 10) | ((uint32_t)m << 15) | ((uint32_t)mp.n_cols << 27);
+            i0 = nnodes + (uint32_t)rank;  // 0-based index of the child (Tree.add_nodes, Tree.m:61)
+            d2 xy;
+            xy.x = ch.x;
+            xy.y = ch.y;
+            l_chxy[rank] = xy;
+        }
+        wave_sync();
+        // cost-to-go terms (expand_node.m:68-73), one lane per (child, remaining step): the sqrt chains of a
+        // child run side by side instead of one after the other; the SUM below keeps the reference's order
+        const int T = steps_to_go;
+        // lane layout: child r = idx & 15, step it = (idx >> 4) + 1 (no integer division; a word has <= 16 successors,
+        // enforced by pdmpc_upload_mpa; the reference MPAs have at most 12)
+        for (int base = 0; base < 16 * T; base += PDMPC_WAVE) {
+            const int idx = base + lane;
+            const int r = idx & 15;
+            const int it = (idx >> 4) + 1;
+            if (r < cnt && it <= T) {
+                const d2 xy = l_chxy[r];
+                const double ddx = xy.x - l_rx[k_exp + it - 1], ddy = xy.y - l_ry[k_exp + it - 1];
+                const double nrm = sqrt(ddx * ddx + ddy * ddy);
+                const double df = nrm - l_dcum[(k_exp - 1) * PDMPC_HP_MAX + (it - 1)];
+                const double m0 = (df > 0) ? df : 0.0;
+                l_term[r * PDMPC_HP_MAX + (it - 1)] = m0 * m0;
+            }
+        }
+        wave_sync();
+        if (active) {
+            double expH = 0.0;
+            for (int it = 0; it < T; ++it) expH = expH + l_term[rank * PDMPC_HP_MAX + it];
+            ch.h = expH;
+            f = ch.g * 1 + expH * 1;  // GraphSearch.m:100-102
+            node_store(S, i0, ch);
+            vs_store(VS, i0, 0);  // validity unknown
+        }
+        // records (and the parent's cos/sin) must be visible to the helper waves before any id reaches the heap: LDS
+        // copies are ordered by the in-order DS queue; records that only live in HBM need the stores drained
+        if (nnodes + (uint32_t)cnt > S.NL) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        wave_sync();
+        PROF_STOP(5)
+        push(mask, active, i0, f, cnt);
+        nnodes += (uint32_t)cnt;
+    }
+    return true;
+}
+
 // The search proper: root node, sequencing wave, helper waves, and the wait for predecessors that are still planning.
 // BM = false: the libstdc++-faithful binary heap (exact for any keys).  BM = true: the block-min queue, which is only
 // exact while the minimal key is unique; returns true (to every wave) if it met a tie and the search must be redone.
@@ -944,7 +1067,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
         __syncthreads();
         Q.open = 0;
         Q.tie = false;
-        if (wave == 0) bm_push(Q, lane == 0, 0u, 0.0, 0u, 1u);
+        if (wave == 0) bm_push<true>(Q, lane == 0, 0u, 0.0, 0u, 1u);
     }
     __syncthreads();
 
@@ -955,7 +1078,270 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
     const unsigned long long rt_search = __builtin_amdgcn_s_memrealtime();
 #endif
 
-    if (BM && wave == 1) {
+    if (BM && wave == 0) {
+        // ================= queue wave (block-min mode): owns the open list and the pop order ====================
+        // GraphSearch.m:53-107 split over two waves.  This one pops (GraphSearch.m:55-56) and discards nodes whose edge
+        // is already known to collide (:75-77) on its own; every other node goes to the expander wave, and while that
+        // one evaluates the edge and creates the children (:111-196, expand_node.m), this wave removes the node from
+        // the open list and finds the best of the remaining entries.  When the reply arrives, the next node to pop is
+        // that entry or, if one is smaller, one of the new children — the same node the reference would pop next.
+        const double inf = bm_inf();
+        uint32_t nn = 1;  // tree size as far as the open list knows (children of the node in flight excluded)
+        uint32_t seq = lds_load_u32(&l_shared[SH_Q2E_SEQ]);
+        uint32_t waited = 0, ver_ctr = 0;
+        PROF_DECL
+        PROF_START
+      q_again:
+        BmFound cand = bm_find(Q, nn);  // the root
+        for (;;) {
+            // (the expander wave is idle whenever this wave is here)
+            if (lds_load_u32(&l_shared[SH_STATE]) == ST_ARRIVED) {
+                if (lane == 0) {
+                    l_shared[SH_NNODES] = nn;
+                    l_shared[SH_Q_SYNC] = 1;
+                }
+                const bool restart = arrival_sync(S, C, P, VS, tid);
+                if (lane == 0) l_shared[SH_Q_SYNC] = 0;
+                if (restart) {
+                    n_popped = 0;
+                    nn = 1;
+                    bm_init(Q, lane, PDMPC_WAVE);  // the other waves see an empty candidate list and a tree of one node meanwhile
+                    Q.open = 0;
+                    bm_push<true>(Q, lane == 0, 0u, 0.0, 0u, 1u);
+                    cand = bm_find(Q, nn);
+                }
+                continue;
+            }
+            if (Q.tie) {
+                // the pop order is no longer certified: everybody leaves, the search is redone on the binary heap
+                uint32_t old = 0;
+                if (lane == 0) old = atomicCAS((uint32_t*)&l_shared[SH_STATE], ST_RUN, ST_TIE);
+                if (uni_u(old) == ST_RUN) return true;
+                continue;  // an arrival got in first: handle it, then try again
+            }
+            if (cand.idx == 0xFFFFFFFFu) {  // pop on an empty queue returns -1 (mex.cpp:87-93)  GraphSearch.m:57-61
+                status = PDMPC_EXHAUSTED;
+                break;
+            }
+            const uint32_t cur = cand.idx + 1u;
+            if (A.trace_cap > 0 && n_popped < A.trace_cap && lane == 0) A.pop_trace[(size_t)slot * A.trace_cap + n_popped] = (int32_t)cur;
+            ++n_popped;
+            PROF_STOP(0)  // loop head
+            if (uni_u(vs_load(VS, cand.idx)) == VS_INVALID) {  // GraphSearch.m:75-77 without leaving this wave
+                PROF_STOP(1)  // validity lookup
+                bm_remove(Q, cand.idx, nn);
+                if (lane == 0) l_shared[SH_VERSION] = ++ver_ctr;
+                PROF_STOP(2)  // remove
+                cand = bm_find(Q, nn);
+                PROF_STOP(3)  // find
+                PROF_COUNT(7, 1)
+                continue;
+            }
+            PROF_STOP(1)
+            ++seq;
+            if (lane == 0) {
+                l_shared[SH_Q2E_ID] = cur;
+                asm volatile("" ::: "memory");  // the LDS executes one wave's accesses in program order
+                l_shared[SH_Q2E_SEQ] = seq;
+            }
+            bm_remove(Q, cand.idx, nn);
+            if (lane == 0) l_shared[SH_VERSION] = ++ver_ctr;
+            PROF_STOP(2)
+            const BmFound tent = bm_find(Q, nn);
+            PROF_STOP(3)
+            uint32_t spins = 0;
+            while (lds_load_u32(&l_shared[SH_E2Q_SEQ]) != seq) {
+                if (++spins > A.spin_limit) break;  // (cannot happen: the expander always answers)
+            }
+            PROF_STOP(4)  // waiting for the expander
+            asm volatile("" ::: "memory");
+            const uint32_t flags = lds_load_u32(&l_shared[SH_E2Q_FLAGS]);
+            const uint32_t cnt = lds_load_u32(&l_shared[SH_E2Q_CNT]);
+            if (spins > A.spin_limit) {
+                dep_timeout = true;
+                status = PDMPC_EXHAUSTED;
+                break;
+            }
+            if (flags & E2Q_GOAL) {  // :81-90
+                goal = cur;
+                break;
+            }
+            if (flags & E2Q_OVERFLOW) {
+                status = PDMPC_ARENA_OVERFLOW;
+                break;
+            }
+            cand = tent;
+            if (cnt) {
+                // the children are nodes nn .. nn + cnt - 1; their keys sit in the ring.  Make them visible and see
+                // whether one of them comes before the best older entry.
+                for (uint32_t base = 0; base < cnt; base += (uint32_t)PDMPC_WAVE) {
+                    const bool active = base + (uint32_t)lane < cnt;
+                    const uint32_t i0 = nn + base + (uint32_t)lane;
+                    const double f = active ? *(volatile lds_f64*)&Q.kring[i0 & Q.kr_mask] : inf;
+                    bm_push<false>(Q, active, i0, f, nn + base, nn + (base + PDMPC_WAVE < cnt ? base + PDMPC_WAVE : cnt));
+                    const unsigned long long better = __ballot(f < cand.key);  // (+inf when there is no older entry)
+                    const unsigned long long same = __ballot(active && f == cand.key);
+                    if (same) Q.tie = true;
+                    if (better) {
+                        int l = __builtin_ctzll(better);
+                        if (better & (better - 1ull)) {  // several: the smallest of them
+                            const double mn = wave_min_d(f);
+                            const unsigned long long at = __ballot(f == mn);
+                            if (at & (at - 1ull)) Q.tie = true;
+                            l = __builtin_ctzll(at);
+                        }
+                        cand.idx = nn + base + (uint32_t)l;
+                        cand.key = lane_d(f, l);
+                    }
+                }
+                nn += cnt;
+            }
+            PROF_STOP(5)  // children made visible
+        }
+#ifdef PDMPC_PROFILE
+        if (lane == 0) {
+            for (int i = 0; i < 8; ++i) ((double*)O->shapes[PDMPC_HP_MAX - 1])[i] = (double)S.prof_acc[i];  // unused tail of the record
+        }
+#endif
+        // finished — but predecessors that are still planning may yet invalidate what we found
+        for (;;) {
+            const uint32_t st = lds_load_u32(&l_shared[SH_STATE]);
+            if (st == ST_ARRIVED) {
+                if (lane == 0) {
+                    l_shared[SH_NNODES] = nn;
+                    l_shared[SH_Q_SYNC] = 1;
+                }
+                const bool restart = arrival_sync(S, C, P, VS, tid);
+                if (lane == 0) l_shared[SH_Q_SYNC] = 0;
+                if (restart) {
+                    n_popped = 0;
+                    goal = 0;
+                    status = PDMPC_OK;
+                    nn = 1;
+                    bm_init(Q, lane, PDMPC_WAVE);
+                    Q.open = 0;
+                    Q.tie = false;
+                    bm_push<true>(Q, lane == 0, 0u, 0.0, 0u, 1u);
+                    goto q_again;
+                }
+                continue;
+            }
+            if (sh_load64(l_shared, SH_PEND_LO) == 0ull) {
+                uint32_t old = 0;
+                if (lane == 0) old = atomicCAS((uint32_t*)&l_shared[SH_STATE], ST_RUN, ST_DONE);
+                if (uni_u(old) == ST_RUN) break;
+                continue;
+            }
+            __builtin_amdgcn_s_sleep(8);
+            if (++waited > A.spin_limit) {  // a predecessor never finished: give up on it (reported as an error status)
+                dep_timeout = true;
+                if (lane == 0) {
+                    l_shared[SH_PEND_LO] = 0;
+                    l_shared[SH_PEND_HI] = 0;
+                }
+            }
+        }
+        nnodes = lds_load_u32(&l_shared[SH_NNODES]);  // the expander wave's count (it is idle: all replies are in)
+    } else if (BM && wave == 1) {
+        // ================= expander wave (block-min mode) ========================================================
+        // Takes the popped nodes the queue wave hands over: eval_edge_exact (GraphSearch.m:111-196) unless a validator
+        // wave has the verdict already, then expand_node.m.  Children: records into the tree, keys into the key ring and
+        // HBM; the queue wave learns how many there are and makes them visible in the open list.
+        ExpandEnv EE;
+        EE.l_mask = l_mask;
+        EE.l_mi = l_mi;
+        EE.l_pose = l_pose;
+        EE.l_rx = l_rx;
+        EE.l_ry = l_ry;
+        EE.l_dcum = l_dcum;
+        EE.l_term = l_term;
+        EE.l_chxy = l_chxy;
+        EE.Hp = Hp;
+        EE.n = n;
+        EE.nw = nw;
+        EE.lane = lane;
+        uint32_t seen = lds_load_u32(&l_shared[SH_Q2E_SEQ]);
+        uint32_t ver_e = 0;
+        PROF_DECL
+        PROF_START
+        for (;;) {
+            const uint32_t state = lds_load_u32(&l_shared[SH_STATE]);
+            if (state == ST_DONE || state == ST_TIE) break;
+            const uint32_t sq = lds_load_u32(&l_shared[SH_Q2E_SEQ]);
+            if (sq == seen) {
+                // nothing handed over.  An arrival is joined only once the queue wave is in it: before that it may
+                // still hand a node over and wait for the reply.
+                if (state == ST_ARRIVED && lds_load_u32(&l_shared[SH_Q_SYNC]) != 0) {
+                    if (arrival_sync(S, C, P, VS, tid)) nnodes = 1;
+                }
+                continue;
+            }
+            seen = sq;
+            PROF_STOP(8)  // idle
+            asm volatile("" ::: "memory");
+            const uint32_t cur = lds_load_u32(&l_shared[SH_Q2E_ID]);
+            const uint32_t c0 = cur - 1;
+            uint32_t flags = 0, cnt = 0;
+            const uint32_t vs = uni_u(vs_load(VS, c0));
+            bool valid;
+            if (vs == VS_UNKNOWN || vs == VS_CLAIMED) {
+                valid = edge_valid<CHECKER>(S, C, cur, lane);
+                if (lane == 0) vs_store(VS, c0, valid ? VS_VALID : VS_INVALID);
+                PROF_COUNT(15, 1)
+            } else {
+                valid = (vs == VS_VALID || vs == VS_VALID_CS);
+            }
+            PROF_STOP(9)  // validity
+            PROF_COUNT(14, 1)
+            if (valid) {
+                flags = E2Q_VALID;
+                const NodeRec cn = node_load(S, c0);  // same record in every lane
+                const uint32_t cpk = uni_u(cn.packed);
+                if (lane == 0) node_mark_popped(S, c0, cpk);  // a later arrival that hits this node forces a restart
+                if (NODE_K(cpk) == Hp) {
+                    flags |= E2Q_GOAL;
+                } else {
+                    double sn, cs;
+                    if (vs == VS_VALID_CS) {  // a validator already evaluated expand_node.m:50-51 for this node
+                        cs = cn.cs;
+                        sn = cn.sn;
+                    } else {
+                        pdmpc_sincos(cn.yaw, &sn, &cs);  // expand_node.m:50-51
+                        if (lane == 0) node_store_cs(S, c0, cs, sn);
+                    }
+                    const uint32_t n0 = nnodes;
+                    const bool fits = expand_children(EE, S, VS, cur, cn, cs, sn, nnodes, [&](uint64_t mask, bool active, uint32_t i0, double f, int ccnt) {
+                        (void)mask;
+                        (void)ccnt;
+                        if (active) {
+                            Q.kring[i0 & Q.kr_mask] = f;
+                            Q.gkey[i0] = f;
+                        }
+                    });
+                    if (!fits) flags |= E2Q_OVERFLOW;
+                    cnt = nnodes - n0;
+                }
+            }
+            if (lane == 0) {
+                l_shared[SH_E2Q_FLAGS] = flags;
+                l_shared[SH_E2Q_CNT] = cnt;
+                asm volatile("" ::: "memory");  // the LDS executes one wave's accesses in program order
+                l_shared[SH_E2Q_SEQ] = sq;
+                if (cnt) {
+                    // the scout and validator waves may look at the new nodes from here on (their records were made
+                    // visible inside expand_children)
+                    l_shared[SH_NNODES] = nnodes;
+                    l_shared[SH_VERSION] = 0x80000000u | ++ver_e;
+                }
+            }
+            PROF_STOP(10)  // expansion + reply
+        }
+#ifdef PDMPC_PROFILE
+        if (lane == 0) {
+            for (int i = 8; i < 16; ++i) ((double*)O->shapes[PDMPC_HP_MAX - 1])[i] = (double)S.prof_acc[i];
+        }
+#endif
+    } else if (BM && wave == 2) {
         // ================= scout wave (block-min mode) ==========================================================
         // Lists the nodes that will be popped next and whose edge nobody has evaluated yet: the unknown entries with
         // the smallest keys among the four best blocks of the best group.  Its reads race with the sequencing wave's
@@ -1169,44 +1555,19 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                     S.heap_len = 1;
                     nnodes = 1;
                     n_popped = 0;
-                    if (BM) {  // the other waves see an empty candidate list and a tree of one node meanwhile
-                        bm_init(Q, lane, PDMPC_WAVE);
-                        Q.open = 0;
-                        bm_push(Q, lane == 0, 0u, 0.0, 0u, 1u);
-                    }
                     continue;
                 }
             }
-            if (BM && Q.tie) {
-                // the pop order is no longer certified: everybody leaves, the search is redone on the binary heap
-                uint32_t old = 0;
-                if (lane == 0) old = atomicCAS((uint32_t*)&l_shared[SH_STATE], ST_RUN, ST_TIE);
-                if (uni_u(old) == ST_RUN) return true;
-                continue;  // an arrival got in first: handle it, then try again
+            if (S.heap_len == 0) {  // pop on an empty queue returns -1 (mex.cpp:87-93)  GraphSearch.m:57-61
+                status = PDMPC_EXHAUSTED;
+                break;
             }
-            uint32_t cur;
-            if (BM) {
-                PROF_STOP(7)
-                const uint32_t c = bm_pop(Q, nnodes);
-                if (c == 0xFFFFFFFFu) {  // pop on an empty queue returns -1 (mex.cpp:87-93)  GraphSearch.m:57-61
-                    status = PDMPC_EXHAUSTED;
-                    break;
-                }
-                if (Q.tie) continue;
-                cur = c + 1u;
-                if (lane == 0) l_shared[SH_VERSION] = ++ver_ctr;
-            } else {
-                if (S.heap_len == 0) {  // pop on an empty queue returns -1 (mex.cpp:87-93)  GraphSearch.m:57-61
-                    status = PDMPC_EXHAUSTED;
-                    break;
-                }
-                PROF_STOP(7)
-                cur = uni_u(*(volatile lds_u32*)&S.lid[0]);  // 1-based node id (HL >= 1: the top is always in LDS)
-                heap_pop(S);
-                if (lane == 0) {
-                    l_shared[SH_HEAP_LEN] = S.heap_len;
-                    l_shared[SH_VERSION] = ++ver_ctr;
-                }
+            PROF_STOP(7)
+            const uint32_t cur = uni_u(*(volatile lds_u32*)&S.lid[0]);  // 1-based node id (HL >= 1: the top is always in LDS)
+            heap_pop(S);
+            if (lane == 0) {
+                l_shared[SH_HEAP_LEN] = S.heap_len;
+                l_shared[SH_VERSION] = ++ver_ctr;
             }
             PROF_STOP(0)
             if (A.trace_cap > 0 && n_popped < A.trace_cap && lane == 0) A.pop_trace[(size_t)slot * A.trace_cap + n_popped] = (int32_t)cur;
@@ -1216,7 +1577,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
             // ---- eval_edge_exact (GraphSearch.m:111-196): from the validity cache if a helper got there first
             const uint32_t vs = uni_u(vs_load(VS, c0));
             bool valid;
-            if (vs == VS_UNKNOWN || vs == VS_CLAIMED) {
+            if (vs == VS_UNKNOWN) {
                 valid = edge_valid<CHECKER>(S, C, cur, lane);
                 if (lane == 0) vs_store(VS, c0, valid ? VS_VALID : VS_INVALID);
                 PROF_COUNT(13, 1)
@@ -1248,93 +1609,24 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                 if (lane == 0) node_store_cs(S, c0, cs, sn);
             }
             PROF_STOP(4)
-            const int k_exp = cK + 1;            // :13
-            const int steps_to_go = Hp - k_exp;  // :37
-            const lds_mask64* mrow = l_mask + ((size_t)(k_exp - 1) * n + (cTrim - 1)) * nw;
-            uint32_t total = 0;
-            for (int w = 0; w < nw; ++w) total += (uint32_t)__builtin_popcountll(mrow[w]);
-            total = uni_u(total);
-            if (nnodes + total > S.max_nodes) {
-                status = PDMPC_ARENA_OVERFLOW;
-                break;
-            }
-            for (int w = 0; w < nw; ++w) {
-                uint64_t mask = mrow[w];
-                {
-                    const uint32_t lo = uni_u((uint32_t)mask), hi = uni_u((uint32_t)(mask >> 32));
-                    mask = ((uint64_t)hi << 32) | lo;
-                }
-                const int cnt = __builtin_popcountll(mask);
-                const bool active = (mask >> lane) & 1ull;
-                const int rank = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-                double f = 0.0;
-                NodeRec ch;
-                uint32_t i0 = 0;
-                if (active) {
-                    const int t2 = w * 64 + lane;  // 0-based successor trim
-                    const int m = (int)l_mi[(cTrim - 1) * n + t2];
-                    DevManPose mp;
-                    mp.dx = l_pose[m].dx;
-                    mp.dy = l_pose[m].dy;
-                    mp.dyaw = l_pose[m].dyaw;
-                    mp.n_cols = l_pose[m].n_cols;
-                    ch.x = cs * mp.dx - sn * mp.dy + curX;  // :53
-                    ch.y = sn * mp.dx + cs * mp.dy + curY;  // :54
-                    ch.yaw = curYaw + mp.dyaw;              // :55
-                    double expG = curG;
-                    {
-                        const double ddx = ch.x - l_rx[k_exp - 1], ddy = ch.y - l_ry[k_exp - 1];
-                        const double nrm = sqrt(ddx * ddx + ddy * ddy);
-                        expG = expG + nrm * nrm;  // :61
-                    }
-                    ch.g = expG;
-                    ch.cs = 0.0;
-                    ch.sn = 0.0;
-                    ch.parent = cur;
-                    ch.packed = (uint32_t)(t2 + 1) | ((uint32_t)k_exp << 10) | ((uint32_t)m << 15) | ((uint32_t)mp.n_cols << 27);
-                    i0 = nnodes + (uint32_t)rank;  // 0-based index of the child (Tree.add_nodes, Tree.m:61)
-                    d2 xy;
-                    xy.x = ch.x;
-                    xy.y = ch.y;
-                    l_chxy[rank] = xy;
-                }
-                wave_sync();
-                // cost-to-go terms (expand_node.m:68-73), one lane per (child, remaining step): the sqrt chains of a
-                // child run side by side instead of one after the other; the SUM below keeps the reference's order
-                const int T = steps_to_go;
-                // lane layout: child r = idx & 15, step it = (idx >> 4) + 1 (no integer division; a word has <= 16 successors,
-                // enforced by pdmpc_upload_mpa; the reference MPAs have at most 12)
-                for (int base = 0; base < 16 * T; base += PDMPC_WAVE) {
-                    const int idx = base + lane;
-                    const int r = idx & 15;
-                    const int it = (idx >> 4) + 1;
-                    if (r < cnt && it <= T) {
-                        const d2 xy = l_chxy[r];
-                        const double ddx = xy.x - l_rx[k_exp + it - 1], ddy = xy.y - l_ry[k_exp + it - 1];
-                        const double nrm = sqrt(ddx * ddx + ddy * ddy);
-                        const double df = nrm - l_dcum[(k_exp - 1) * PDMPC_HP_MAX + (it - 1)];
-                        const double m0 = (df > 0) ? df : 0.0;
-                        l_term[r * PDMPC_HP_MAX + (it - 1)] = m0 * m0;
-                    }
-                }
-                wave_sync();
-                if (active) {
-                    double expH = 0.0;
-                    for (int it = 0; it < T; ++it) expH = expH + l_term[rank * PDMPC_HP_MAX + it];
-                    ch.h = expH;
-                    f = ch.g * 1 + expH * 1;  // GraphSearch.m:100-102
-                    node_store(S, i0, ch);
-                    vs_store(VS, i0, 0);  // validity unknown
-                }
-                // records (and the parent's cos/sin) must be visible to the helper waves before any id reaches the heap: LDS
-                // copies are ordered by the in-order DS queue; records that only live in HBM need the stores drained
-                if (nnodes + (uint32_t)cnt > S.NL) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                wave_sync();
-                PROF_STOP(5)
+            {
+                ExpandEnv EE;
+                EE.l_mask = l_mask;
+                EE.l_mi = l_mi;
+                EE.l_pose = l_pose;
+                EE.l_rx = l_rx;
+                EE.l_ry = l_ry;
+                EE.l_dcum = l_dcum;
+                EE.l_term = l_term;
+                EE.l_chxy = l_chxy;
+                EE.Hp = Hp;
+                EE.n = n;
+                EE.nw = nw;
+                EE.lane = lane;
                 // pq.push(new_open_nodes, new_open_values): one at a time in ascending trim order (mex.cpp:67-72)
-                if (BM) {
-                    bm_push(Q, active, i0, f, nnodes, nnodes + (uint32_t)cnt);
-                } else {
+                const bool fits = expand_children(EE, S, VS, cur, cn, cs, sn, nnodes, [&](uint64_t mask, bool active, uint32_t i0, double f, int cnt) {
+                    (void)active;
+                    (void)i0;
                     uint64_t mm = mask;
                     uint32_t r = 0;
                     while (mm) {
@@ -1344,14 +1636,15 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                         heap_push(S, nnodes + r + 1, fk);
                         ++r;
                     }
-                }
-                nnodes += (uint32_t)cnt;
-                if (lane == 0) {
-                    if (BM)
-                        l_shared[SH_NNODES] = nnodes;
-                    else
+                    if (lane == 0) {
                         l_shared[SH_HEAP_LEN] = S.heap_len;
-                    l_shared[SH_VERSION] = ++ver_ctr;
+                        l_shared[SH_NNODES] = nnodes + (uint32_t)cnt;
+                        l_shared[SH_VERSION] = ++ver_ctr;
+                    }
+                });
+                if (!fits) {
+                    status = PDMPC_ARENA_OVERFLOW;
+                    break;
                 }
                 PROF_STOP(6)
             }
@@ -1378,11 +1671,6 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                     n_popped = 0;
                     goal = 0;
                     status = PDMPC_OK;
-                    if (BM) {
-                        bm_init(Q, lane, PDMPC_WAVE);
-                        Q.open = 0;
-                        bm_push(Q, lane == 0, 0u, 0.0, 0u, 1u);
-                    }
                     goto search_again;
                 }
                 continue;
@@ -1852,7 +2140,7 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_bm_script_kernel(
             const bool active = lane < cnt;
             const double f = active ? key[i + lane] : 0.0;
             BM_CLOCK(t0, 0)
-            bm_push(Q, active, nn + (uint32_t)lane, f, nn, nn + (uint32_t)cnt);
+            bm_push<true>(Q, active, nn + (uint32_t)lane, f, nn, nn + (uint32_t)cnt);
             BM_CLOCK(t1, 0xC07F)  // lgkmcnt(0): the queue's HBM stores are fire-and-forget
             nn += (uint32_t)cnt;
             c_push += t1 - t0;
