@@ -198,41 +198,42 @@ int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in, int cand_cap_in)
         snprintf(buf, sizeof buf, "obstacle soup (%d columns) + MPA tables need %u B of LDS, budget %zu B", hb.soup_cap, off, budget);
         return fail(PDMPC_ERR_CAPACITY, buf);
     }
-    // the open list is touched several times per pop, a node twice: give the heap up to 4096 entries
-    // (12 levels) first, the rest of the budget to 64-byte node records
+    // The open list gets up to three quarters of what is left.  Its region serves the binary heap (hl entries x 12 B)
+    // or the block-min queue (key ring kr x 8 B; block minima and popped bits nb x 16 B; group minima 512 B).
     const uint32_t rest = (uint32_t)(budget - off - 256);
+    const uint32_t region_cap = rest * 3 / 4;
     uint32_t hl_max = 8192;  // 13 heap levels; measured on C2: 4096 -> 8192 entries = +3.5 % steps/s
     if (const char* e = getenv("PDMPC_HL_MAX")) hl_max = (uint32_t)std::max(64, atoi(e));  // tuning knob
-    uint32_t hl = std::min(hl_max, rest * 3 / 4 / 12);
+    uint32_t hl = std::min(hl_max, region_cap / 12);
     hl = std::min(hl, h->max_nodes) & ~3u;
+    uint32_t region = align16(hl * 8) + align16(hl * 4);
+    {
+        const uint32_t nb = ((h->max_nodes + 63u) / 64u + 63u) & ~63u;
+        const uint32_t bm_fixed = nb * 16u + 512u;
+        h->bm_nb = (int)nb;
+        h->bm_kr = 0;
+        if (nb <= 4096u && region_cap >= bm_fixed + 512u * 8u) {
+            uint32_t kr = 512;
+            while (kr * 2u * 8u + bm_fixed <= region_cap && kr < 8192u) kr *= 2u;
+            h->bm_kr = (int)kr;
+            region = std::max(region, kr * 8u + bm_fixed);
+        }
+        if (h->bm_kr == 0) h->queue_mode = PDMPC_QUEUE_HEAP;  // no room (tiny LDS budget) or more than 262144 nodes per vehicle
+    }
     // validity cache: one byte per node for the first NV nodes (a quarter of what is left, at most 32768)
-    uint32_t nv = std::min((uint32_t)32768, (rest - hl * 12) / 4);
+    uint32_t nv = std::min((uint32_t)32768, (rest - region) / 4);
     nv = std::min(nv, h->max_nodes) & ~15u;
-    uint32_t nl = (rest - hl * 12 - nv) / (uint32_t)sizeof(NodeRec);
+    uint32_t nl = (rest - region - nv) / (uint32_t)sizeof(NodeRec);
     nl = std::min(nl, h->max_nodes);
     L.heap_key = off;
-    off += align16(hl * 8);
-    L.heap_id = off;
-    off += align16(hl * 4);
+    L.heap_id = off + align16(hl * 8);
+    off += region;
     L.vstate = off;
     off += align16(nv);
     L.nodes = off;
     off += nl * (uint32_t)sizeof(NodeRec);
     L.total = align16(off);
     if (L.total > budget) return fail(PDMPC_ERR_CAPACITY, "internal: LDS layout exceeds budget");
-    // the block-min queue (key ring + block minima + group minima) lives in the heap's region
-    {
-        const uint32_t nb = ((h->max_nodes + 63u) / 64u + 63u) & ~63u;
-        const uint32_t region = align16(hl * 8) + align16(hl * 4);
-        h->bm_nb = (int)nb;
-        h->bm_kr = 0;
-        if (nb <= 4096u && region >= nb * 8u + 512u + 64u * 8u) {
-            uint32_t kr = 64;
-            while (kr * 2u * 8u + nb * 8u + 512u <= region && kr < 16384u) kr *= 2u;
-            h->bm_kr = (int)kr;
-        }
-        if (h->bm_kr == 0) h->queue_mode = PDMPC_QUEUE_HEAP;  // no room (tiny LDS budget) or more than 262144 nodes per vehicle
-    }
     h->lds = L;
     h->HL = (int)hl;
     h->NL = (int)nl;

@@ -24,6 +24,7 @@ typedef LDS_AS unsigned long long lds_u64;
 struct BmQueue {
     lds_f64* kring;  // [KR]
     lds_f64* m1;     // [nb_max]
+    lds_u64* pbits;  // [nb_max] bit e of word b set: node 64 b + e has been popped (its key stays where it is)
     lds_f64* m2;     // [64]
     double* gkey;    // [max_nodes]
     uint32_t kr_mask;
@@ -72,7 +73,10 @@ __device__ __forceinline__ double wave_min_d(double x) {
 
 __device__ __forceinline__ void bm_init(BmQueue& Q, int tid, int nthreads) {
     const double inf = bm_inf();
-    for (uint32_t i = (uint32_t)tid; i < Q.nb_max; i += (uint32_t)nthreads) Q.m1[i] = inf;
+    for (uint32_t i = (uint32_t)tid; i < Q.nb_max; i += (uint32_t)nthreads) {
+        Q.m1[i] = inf;
+        Q.pbits[i] = 0ull;
+    }
     for (uint32_t i = (uint32_t)tid; i < 64u; i += (uint32_t)nthreads) Q.m2[i] = inf;
 }
 
@@ -106,9 +110,11 @@ __device__ __forceinline__ void bm_push(BmQueue& Q, bool active, uint32_t i0, do
     Q.open += (uint32_t)__builtin_popcountll(__ballot(active));
 }
 
-// keys of block b, one per lane (+inf for nodes that do not exist yet)
+// keys of block b, one per lane (+inf for nodes that do not exist yet or have been popped)
 __device__ __forceinline__ double bm_block_keys(const BmQueue& Q, uint32_t b, uint32_t nn, bool in_ring) {
-    const uint32_t idx = b * 64u + (threadIdx.x & 63u);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t idx = b * 64u + lane;
+    const unsigned long long popped = Q.pbits[b];
     double k;
     if (in_ring) {
         k = Q.kring[idx & Q.kr_mask];
@@ -118,7 +124,7 @@ __device__ __forceinline__ double bm_block_keys(const BmQueue& Q, uint32_t b, ui
         // wave's earlier HBM stores (gfx9 counts loads and stores in the same vmcnt)
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     }
-    if (idx >= nn) k = bm_inf();  // slots of nodes that do not exist yet hold stale keys
+    if (idx >= nn || ((popped >> lane) & 1ull)) k = bm_inf();  // (slots of nodes that do not exist yet hold stale keys)
     return k;
 }
 
@@ -169,8 +175,7 @@ __device__ __forceinline__ void bm_remove(BmQueue& Q, uint32_t idx, uint32_t nn)
     const double k = bm_block_keys(Q, b, nn, in_ring);
     const double new1 = wave_min_d(lane == e ? inf : k);
     if (lane == e) {
-        if (in_ring) Q.kring[idx & Q.kr_mask] = inf;
-        Q.gkey[idx] = inf;
+        __hip_atomic_fetch_or(&Q.pbits[b], 1ull << e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         Q.m1[b] = new1;
     }
     if (nn > 4096u) {
@@ -182,9 +187,61 @@ __device__ __forceinline__ void bm_remove(BmQueue& Q, uint32_t idx, uint32_t nn)
     --Q.open;
 }
 
-// Pop = find + remove.  Returns the 0-based node index, or 0xFFFFFFFF if the queue is empty.
-__device__ __forceinline__ uint32_t bm_pop(BmQueue& Q, uint32_t nn) {
-    const BmFound f = bm_find(Q, nn);
-    if (f.idx != 0xFFFFFFFFu) bm_remove(Q, f.idx, nn);
-    return f.idx;
+// Put a popped node back (its key is still in place): the inverse of a pop that turned out to be premature.
+__device__ __forceinline__ void bm_unpop(BmQueue& Q, uint32_t idx, double key, uint32_t nn) {
+    if ((threadIdx.x & 63u) == 0u) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(key);
+        __hip_atomic_fetch_and(&Q.pbits[idx >> 6], ~(1ull << (idx & 63u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_min((lds_u64*)&Q.m1[idx >> 6], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (nn > 4096u) __hip_atomic_fetch_min((lds_u64*)&Q.m2[idx >> 12], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    ++Q.open;
+}
+
+// Pop: the entry with the minimal key is found and removed with a single look at its block.  Returns idx 0xFFFFFFFF if
+// the queue is empty.  Sets Q.tie if the minimum was not unique.
+__device__ __forceinline__ BmFound bm_pop(BmQueue& Q, uint32_t nn) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const double inf = bm_inf();
+    BmFound r;
+    r.idx = 0xFFFFFFFFu;
+    r.key = inf;
+    const bool multi = nn > 4096u;
+    uint32_t g = 0;
+    double v1, mn1;
+    if (multi) {
+        const double v2 = Q.m2[lane];
+        mn1 = wave_min_d(v2);  // the minimum of the best group is the minimum of one of its blocks: no second reduction
+        if (!(mn1 < inf)) return r;
+        const unsigned long long b2 = __ballot(v2 == mn1);
+        if (b2 & (b2 - 1ull)) Q.tie = true;
+        g = (uint32_t)__builtin_ctzll(b2);
+        v1 = Q.m1[g * 64u + lane];
+    } else {
+        v1 = Q.m1[lane];  // m1 is +inf beyond the last block
+        mn1 = wave_min_d(v1);
+        if (!(mn1 < inf)) return r;
+    }
+    const unsigned long long b1 = __ballot(v1 == mn1);
+    if (b1 & (b1 - 1ull)) Q.tie = true;
+    const uint32_t bl = (uint32_t)__builtin_ctzll(b1);
+    const uint32_t b = g * 64u + bl;
+    const double k = bm_block_keys(Q, b, nn, bm_in_ring(Q, b, nn));
+    const unsigned long long b0 = __ballot(k == mn1);
+    if (b0 & (b0 - 1ull)) Q.tie = true;
+    const uint32_t e = (uint32_t)__builtin_ctzll(b0);
+    r.idx = b * 64u + e;
+    r.key = mn1;
+    // remove: popped bit, m1[b] = min of the rest, m2[g] = min over the group's blocks
+    const double new1 = wave_min_d(lane == e ? inf : k);
+    if (lane == e) {
+        __hip_atomic_fetch_or(&Q.pbits[b], 1ull << e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        Q.m1[b] = new1;
+    }
+    if (multi) {
+        const double new2 = wave_min_d(lane == bl ? new1 : v1);
+        if (lane == 0) Q.m2[g] = new2;
+    }
+    --Q.open;
+    return r;
 }

@@ -1092,7 +1092,8 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
         PROF_DECL
         PROF_START
       q_again:
-        BmFound cand = bm_find(Q, nn);  // the root
+        BmFound cand = bm_pop(Q, nn);  // the root
+        bool cand_in_list = false;     // true: cand is a child that still has to be taken out of the open list
         for (;;) {
             // (the expander wave is idle whenever this wave is here)
             if (lds_load_u32(&l_shared[SH_STATE]) == ST_ARRIVED) {
@@ -1108,7 +1109,8 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                     bm_init(Q, lane, PDMPC_WAVE);  // the other waves see an empty candidate list and a tree of one node meanwhile
                     Q.open = 0;
                     bm_push<true>(Q, lane == 0, 0u, 0.0, 0u, 1u);
-                    cand = bm_find(Q, nn);
+                    cand = bm_pop(Q, nn);
+                    cand_in_list = false;
                 }
                 continue;
             }
@@ -1129,11 +1131,12 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
             PROF_STOP(0)  // loop head
             if (uni_u(vs_load(VS, cand.idx)) == VS_INVALID) {  // GraphSearch.m:75-77 without leaving this wave
                 PROF_STOP(1)  // validity lookup
-                bm_remove(Q, cand.idx, nn);
-                if (lane == 0) l_shared[SH_VERSION] = ++ver_ctr;
+                if (cand_in_list) bm_remove(Q, cand.idx, nn);
                 PROF_STOP(2)  // remove
-                cand = bm_find(Q, nn);
-                PROF_STOP(3)  // find
+                cand = bm_pop(Q, nn);
+                cand_in_list = false;
+                if (lane == 0) l_shared[SH_VERSION] = ++ver_ctr;
+                PROF_STOP(3)  // pop
                 PROF_COUNT(7, 1)
                 continue;
             }
@@ -1144,10 +1147,12 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                 asm volatile("" ::: "memory");  // the LDS executes one wave's accesses in program order
                 l_shared[SH_Q2E_SEQ] = seq;
             }
-            bm_remove(Q, cand.idx, nn);
-            if (lane == 0) l_shared[SH_VERSION] = ++ver_ctr;
+            if (cand_in_list) bm_remove(Q, cand.idx, nn);
             PROF_STOP(2)
-            const BmFound tent = bm_find(Q, nn);
+            // the best of the rest, taken out right away: in the usual case it is popped next; if a child of the node in
+            // flight turns out to come first, it is put back
+            const BmFound tent = bm_pop(Q, nn);
+            if (lane == 0) l_shared[SH_VERSION] = ++ver_ctr;
             PROF_STOP(3)
             uint32_t spins = 0;
             while (lds_load_u32(&l_shared[SH_E2Q_SEQ]) != seq) {
@@ -1171,6 +1176,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                 break;
             }
             cand = tent;
+            cand_in_list = false;
             if (cnt) {
                 // the children are nodes nn .. nn + cnt - 1; their keys sit in the ring.  Make them visible and see
                 // whether one of them comes before the best older entry.
@@ -1192,9 +1198,11 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                         }
                         cand.idx = nn + base + (uint32_t)l;
                         cand.key = lane_d(f, l);
+                        cand_in_list = true;
                     }
                 }
                 nn += cnt;
+                if (cand_in_list && tent.idx != 0xFFFFFFFFu) bm_unpop(Q, tent.idx, tent.key, nn);
             }
             PROF_STOP(5)  // children made visible
         }
@@ -1944,7 +1952,8 @@ __device__ __forceinline__ void search_body(const KernelArgs& A) {
 #endif
     X.Q.kring = (lds_f64*)(lsm + A.lds.heap_key);  // the block-min queue lives where the binary heap would
     X.Q.m1 = X.Q.kring + A.bm_kr;
-    X.Q.m2 = X.Q.m1 + A.bm_nb;
+    X.Q.pbits = (lds_u64*)(X.Q.m1 + A.bm_nb);
+    X.Q.m2 = X.Q.m1 + 2 * A.bm_nb;
     X.Q.gkey = S.gkey;
     X.Q.kr_mask = (uint32_t)A.bm_kr - 1u;
     X.Q.nb_max = (uint32_t)A.bm_nb;
@@ -2114,7 +2123,8 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_bm_script_kernel(
     BmQueue Q;
     Q.kring = (lds_f64*)smem;
     Q.m1 = (lds_f64*)(smem + (size_t)KR * 8);
-    Q.m2 = Q.m1 + NB;
+    Q.pbits = (lds_u64*)(Q.m1 + NB);
+    Q.m2 = Q.m1 + 2 * NB;
     Q.gkey = gkey;
     Q.kr_mask = (uint32_t)KR - 1u;
     Q.nb_max = (uint32_t)NB;
@@ -2152,7 +2162,7 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_bm_script_kernel(
             while (i + run < n && uni_i(op[i + run]) == 1) ++run;
             BM_CLOCK(t0, 0)
             for (int r = 0; r < run; ++r) {
-                const uint32_t cur = bm_pop(Q, nn);
+                const uint32_t cur = bm_pop(Q, nn).idx;
                 if (lane == 0) out[n_out] = cur == 0xFFFFFFFFu ? -1 : (int32_t)(cur + 1u);
                 ++n_out;
             }
@@ -2173,7 +2183,7 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_bm_script_kernel(
 
 extern "C" int pdmpc_launch_bm_script(const int32_t* op, const double* key, int n, int32_t* out, unsigned long long* stats, double* gkey, int KR,
                                       int NB, void* stream) {
-    const size_t lds = (size_t)KR * 8 + (size_t)NB * 8 + 64 * 8;
+    const size_t lds = (size_t)KR * 8 + (size_t)NB * 16 + 64 * 8;
     hipError_t e = hipFuncSetAttribute((const void*)pdmpc_bm_script_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(pdmpc_bm_script_kernel, dim3(1), dim3(PDMPC_WAVE), lds, (hipStream_t)stream, op, key, n, out, stats, gkey, KR, NB);
