@@ -414,6 +414,7 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.cand_cap = B.cand_cap;
     a.spin_limit = 1u << 22;
     a.speculate = h->speculate;
+    a.crowded = count > h->n_cu ? 1 : 0;
     a.queue_mode = h->queue_mode;
     a.bm_kr = h->bm_kr;
     a.bm_nb = h->bm_nb;

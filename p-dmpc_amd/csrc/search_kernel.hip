@@ -1156,6 +1156,10 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
             PROF_STOP(3)
             uint32_t spins = 0;
             while (lds_load_u32(&l_shared[SH_E2Q_SEQ]) != seq) {
+                if (A.crowded)
+                    __builtin_amdgcn_s_sleep(6);  // leave the issue slots to the waves that have work
+                else
+                    __builtin_amdgcn_s_sleep(1);
                 if (++spins > A.spin_limit) break;  // (cannot happen: the expander always answers)
             }
             PROF_STOP(4)  // waiting for the expander
@@ -1281,6 +1285,10 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                 // still hand a node over and wait for the reply.
                 if (state == ST_ARRIVED && lds_load_u32(&l_shared[SH_Q_SYNC]) != 0) {
                     if (arrival_sync(S, C, P, VS, tid)) nnodes = 1;
+                } else if (A.crowded) {
+                    __builtin_amdgcn_s_sleep(6);  // leave the issue slots to the waves that have work
+                } else {
+                    __builtin_amdgcn_s_sleep(1);
                 }
                 continue;
             }
