@@ -291,6 +291,10 @@ def main():
                 "nodes_popped_per_s": pops / elapsed,
                 "nodes_generated_per_s": nodes / elapsed,
                 "nodes_popped_per_step": pops / args.steps,
+                "speculation_arrivals_per_step": st["speculation_arrivals"] / args.steps,
+                "speculation_restarts_per_step": st["speculation_restarts"] / args.steps,
+                "speculation_wasted_pops_per_step": st["speculation_wasted_pops"] / args.steps,
+                "queue_fallbacks_per_step": st["queue_fallbacks"] / args.steps,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

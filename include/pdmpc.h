@@ -143,6 +143,9 @@ typedef struct {
     int64_t n_launches;       /* kernel launches since the last pdmpc_pack_* (kernel_ms is their sum) */
     int64_t queue_fallbacks;  /* searches since pdmpc_create / pdmpc_reset_stats that met a tied minimal key in the block-min
                                  open list and were redone on the binary heap (results are identical either way) */
+    int64_t speculation_restarts; /* searches restarted because a predecessor's areas, arriving late, hit an already expanded node */
+    int64_t speculation_arrivals; /* late arrivals of predecessor areas folded into running searches (same period) */
+    int64_t speculation_wasted_pops; /* nodes popped by searches that were then restarted (block-min mode; same period) */
 } pdmpc_stats;
 
 /* ---- life cycle (replaces GraphSearch() construction in OptimizerInterface.get_optimizer, :26-27,

@@ -476,7 +476,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
     const size_t tot = (size_t)h->max_vehicles * h->max_nodes;
     int bad = 0;
     bad |= h->anodes.ensure(tot) | h->ahk.ensure(tot) | h->ahid.ensure(tot) | h->avs.ensure(tot);
-    bad |= h->d_out.ensure((size_t)h->max_vehicles) | h->d_flag.ensure((size_t)h->max_vehicles) | h->d_tree_size.ensure((size_t)h->max_vehicles) | h->d_tie_count.ensure(1);
+    bad |= h->d_out.ensure((size_t)h->max_vehicles) | h->d_flag.ensure((size_t)h->max_vehicles) | h->d_tree_size.ensure((size_t)h->max_vehicles) | h->d_tie_count.ensure(4);
     bad |= h->d_trace.ensure((size_t)h->max_vehicles * (size_t)std::max(config->trace_pops, 1));
     if (bad) {
         pdmpc_destroy(h);
@@ -484,7 +484,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
     }
     (void)hipMemsetAsync(h->d_flag.p, 0, h->d_flag.cap * sizeof(uint32_t), h->stream);
     (void)hipMemsetAsync(h->d_tree_size.p, 0, h->d_tree_size.cap * sizeof(int32_t), h->stream);
-    (void)hipMemsetAsync(h->d_tie_count.p, 0, sizeof(int32_t), h->stream);
+    (void)hipMemsetAsync(h->d_tie_count.p, 0, 4 * sizeof(int32_t), h->stream);
     (void)hipMemsetAsync(h->d_out.p, 0, h->d_out.cap * sizeof(pdmpc_vehicle_out), h->stream);
     (void)hipStreamSynchronize(h->stream);
     *out_handle = h;
@@ -611,7 +611,7 @@ int pdmpc_reset_stats(pdmpc_handle* h) {
     if (!h) return fail(PDMPC_ERR_INVALID, "null handle");
     HIPCHK(hipStreamSynchronize(h->stream));
     h->events_used = 0;
-    HIPCHK(hipMemsetAsync(h->d_tie_count.p, 0, sizeof(int32_t), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_tie_count.p, 0, 4 * sizeof(int32_t), h->stream));
     return PDMPC_OK;
 }
 
@@ -711,9 +711,12 @@ int pdmpc_get_last_stats(pdmpc_handle* h, pdmpc_stats* stats) {
     }
     h->stats.kernel_ms = ms;
     h->stats.n_launches = (int64_t)h->events_used;
-    int32_t ties = 0;
-    HIPCHK(hipMemcpy(&ties, h->d_tie_count.p, sizeof ties, hipMemcpyDeviceToHost));
-    h->stats.queue_fallbacks = ties;
+    int32_t ctr[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpy(ctr, h->d_tie_count.p, sizeof ctr, hipMemcpyDeviceToHost));
+    h->stats.queue_fallbacks = ctr[0];
+    h->stats.speculation_restarts = ctr[1];
+    h->stats.speculation_arrivals = ctr[2];
+    h->stats.speculation_wasted_pops = ctr[3];
     *stats = h->stats;
     return PDMPC_OK;
 }

@@ -726,6 +726,7 @@ struct SpecCtx {
     const lds_i32* l_lit;  // literal soup length per step
     const pdmpc_vehicle_out* out;
     const int32_t* pred;   // this vehicle's predecessor slots
+    int32_t* counters;     // [0] tie fallbacks, [1] speculation restarts, [2] arrivals handled, [3] pops thrown away by restarts (cumulative, all vehicles)
     int n_pred, Hp;
 };
 
@@ -827,7 +828,9 @@ __device__ bool arrival_sync(const Search& S, const CheckCtx& C, const SpecCtx& 
     const bool restart = P.sh[SH_RESTART] != 0;
     __syncthreads();  // #4: everyone has read the verdict
     if (tid == 0) {
+        atomicAdd(P.counters + 2, 1);
         if (restart) {
+            atomicAdd(P.counters + 1, 1);
             // back to the root before any helper looks at the open list again: node ids are about to be reused
             S.lkey[0] = 0.0;  // (block-min mode rebuilds its own queue after this returns)
             S.lid[0] = 1;
@@ -1104,6 +1107,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                 const bool restart = arrival_sync(S, C, P, VS, tid);
                 if (lane == 0) l_shared[SH_Q_SYNC] = 0;
                 if (restart) {
+                    if (lane == 0) atomicAdd(P.counters + 3, n_popped);
                     n_popped = 0;
                     nn = 1;
                     bm_init(Q, lane, PDMPC_WAVE);  // the other waves see an empty candidate list and a tree of one node meanwhile
@@ -1226,6 +1230,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                 const bool restart = arrival_sync(S, C, P, VS, tid);
                 if (lane == 0) l_shared[SH_Q_SYNC] = 0;
                 if (restart) {
+                    if (lane == 0) atomicAdd(P.counters + 3, n_popped);
                     n_popped = 0;
                     goal = 0;
                     status = PDMPC_OK;
@@ -1860,6 +1865,7 @@ __device__ __forceinline__ void search_body(const KernelArgs& A) {
     P.l_lit = l_lit;
     P.out = A.out;
     P.pred = A.pred + V->pred_off;
+    P.counters = A.tie_count;
     P.n_pred = n_pred;
     P.Hp = Hp;
     bool dep_timeout = false;

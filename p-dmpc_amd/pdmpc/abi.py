@@ -114,6 +114,9 @@ class Stats(C.Structure):
         ("lds_nodes", C.c_int64),
         ("n_launches", C.c_int64),
         ("queue_fallbacks", C.c_int64),
+        ("speculation_restarts", C.c_int64),
+        ("speculation_arrivals", C.c_int64),
+        ("speculation_wasted_pops", C.c_int64),
     ]
 
 
