@@ -213,10 +213,16 @@ int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in, int cand_cap_in)
         h->bm_nb = (int)nb;
         h->bm_kr = 0;
         if (nb <= 4096u && region_cap >= bm_fixed + 512u * 8u) {
-            uint32_t kr = 512;
-            while (kr * 2u * 8u + bm_fixed <= region_cap && kr < 8192u) kr *= 2u;
+            uint32_t kr = 512, kr_max = 8192;
+            if (const char* e = getenv("PDMPC_BM_RING")) kr_max = (uint32_t)std::max(512, atoi(e));  // tuning knob
+            while (kr * 2u * 8u + bm_fixed <= region_cap && kr * 2u <= kr_max) kr *= 2u;
             h->bm_kr = (int)kr;
             region = std::max(region, kr * 8u + bm_fixed);
+        }
+        if (h->queue_mode == PDMPC_QUEUE_BLOCKMIN && h->bm_kr != 0) {
+            // the heap only runs after a fallback: it takes what the block-min queue needs, not the other way round
+            region = (uint32_t)h->bm_kr * 8u + bm_fixed;
+            while (align16(hl * 8) + align16(hl * 4) > region) hl -= 4;
         }
         if (h->bm_kr == 0) h->queue_mode = PDMPC_QUEUE_HEAP;  // no room (tiny LDS budget) or more than 262144 nodes per vehicle
     }

@@ -45,7 +45,12 @@
         S.prof_t0 = t1__;                                       \
     }
 #define PROF_COUNT(i, v) S.prof_acc[i] += (v);
+// hand-over timeline (profile build, trace buffer hijacked): slot k of hand-over j <- clock
+#define PROF_TL(j, k)                                                                                              \
+    if (A.trace_cap > 0 && (int)(8 * (j) + 8) <= A.trace_cap && lane == 0)                                         \
+        A.pop_trace[(size_t)slot * A.trace_cap + 8 * (j) + (k)] = (int32_t)(__builtin_readcyclecounter() & 0x7FFFFFFFull);
 #else
+#define PROF_TL(j, k)
 #define PROF_MEMBERS
 #define PROF_DECL
 #define PROF_START
@@ -915,7 +920,9 @@ struct ExpandEnv {
 // records (validity unknown) and calls push(mask, active, i0, f, cnt) once per 64-trim word of the successor mask, with
 // nnodes still the index of the word's first child; the caller's push makes the children visible in its open list.
 // Returns false if the arena cannot take the children (nothing is created then).
-template <class Push>
+// FENCE: drain the records' HBM stores before push (needed when push makes the children visible to waves that read
+// their records; the expander wave of the block-min mode drains later, before it publishes the new tree size).
+template <bool FENCE, class Push>
 __device__ __forceinline__ bool expand_children(const ExpandEnv& E, Search& S, const VState& VS, uint32_t cur, const NodeRec& cn, double cs, double sn,
                                                 uint32_t& nnodes, Push push) {
     const int Hp = E.Hp, n = E.n, nw = E.nw, lane = E.lane;
@@ -1007,7 +1014,7 @@ __device__ __forceinline__ bool expand_children(const ExpandEnv& E, Search& S, c
         }
         // records (and the parent's cos/sin) must be visible to the helper waves before any id reaches the heap: LDS
         // copies are ordered by the in-order DS queue; records that only live in HBM need the stores drained
-        if (nnodes + (uint32_t)cnt > S.NL) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (FENCE && nnodes + (uint32_t)cnt > S.NL) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         wave_sync();
         PROF_STOP(5)
         push(mask, active, i0, f, cnt);
@@ -1130,7 +1137,9 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                 break;
             }
             const uint32_t cur = cand.idx + 1u;
+#ifndef PDMPC_PROFILE
             if (A.trace_cap > 0 && n_popped < A.trace_cap && lane == 0) A.pop_trace[(size_t)slot * A.trace_cap + n_popped] = (int32_t)cur;
+#endif
             ++n_popped;
             PROF_STOP(0)  // loop head
             if (uni_u(vs_load(VS, cand.idx)) == VS_INVALID) {  // GraphSearch.m:75-77 without leaving this wave
@@ -1146,6 +1155,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
             }
             PROF_STOP(1)
             ++seq;
+            PROF_TL(seq - 1, 0)
             if (lane == 0) {
                 l_shared[SH_Q2E_ID] = cur;
                 asm volatile("" ::: "memory");  // the LDS executes one wave's accesses in program order
@@ -1158,15 +1168,14 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
             const BmFound tent = bm_pop(Q, nn);
             if (lane == 0) l_shared[SH_VERSION] = ++ver_ctr;
             PROF_STOP(3)
+            PROF_TL(seq - 1, 1)
             uint32_t spins = 0;
             while (lds_load_u32(&l_shared[SH_E2Q_SEQ]) != seq) {
-                if (A.crowded)
-                    __builtin_amdgcn_s_sleep(6);  // leave the issue slots to the waves that have work
-                else
-                    __builtin_amdgcn_s_sleep(1);
+                if (A.crowded) __builtin_amdgcn_s_sleep(6);  // leave the issue slots to the waves that have work
                 if (++spins > A.spin_limit) break;  // (cannot happen: the expander always answers)
             }
             PROF_STOP(4)  // waiting for the expander
+            PROF_TL(seq - 1, 2)
             asm volatile("" ::: "memory");
             const uint32_t flags = lds_load_u32(&l_shared[SH_E2Q_FLAGS]);
             const uint32_t cnt = lds_load_u32(&l_shared[SH_E2Q_CNT]);
@@ -1282,23 +1291,22 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
         PROF_DECL
         PROF_START
         for (;;) {
-            const uint32_t state = lds_load_u32(&l_shared[SH_STATE]);
-            if (state == ST_DONE || state == ST_TIE) break;
             const uint32_t sq = lds_load_u32(&l_shared[SH_Q2E_SEQ]);
             if (sq == seen) {
+                const uint32_t state = lds_load_u32(&l_shared[SH_STATE]);
+                if (state == ST_DONE || state == ST_TIE) break;
                 // nothing handed over.  An arrival is joined only once the queue wave is in it: before that it may
                 // still hand a node over and wait for the reply.
                 if (state == ST_ARRIVED && lds_load_u32(&l_shared[SH_Q_SYNC]) != 0) {
                     if (arrival_sync(S, C, P, VS, tid)) nnodes = 1;
                 } else if (A.crowded) {
                     __builtin_amdgcn_s_sleep(6);  // leave the issue slots to the waves that have work
-                } else {
-                    __builtin_amdgcn_s_sleep(1);
                 }
                 continue;
             }
             seen = sq;
             PROF_STOP(8)  // idle
+            PROF_TL(sq - 1, 3)
             asm volatile("" ::: "memory");
             const uint32_t cur = lds_load_u32(&l_shared[SH_Q2E_ID]);
             const uint32_t c0 = cur - 1;
@@ -1314,11 +1322,13 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
             }
             PROF_STOP(9)  // validity
             PROF_COUNT(14, 1)
+            PROF_TL(sq - 1, 5)
             if (valid) {
                 flags = E2Q_VALID;
                 const NodeRec cn = node_load(S, c0);  // same record in every lane
                 const uint32_t cpk = uni_u(cn.packed);
                 if (lane == 0) node_mark_popped(S, c0, cpk);  // a later arrival that hits this node forces a restart
+                PROF_TL(sq - 1, 6)
                 if (NODE_K(cpk) == Hp) {
                     flags |= E2Q_GOAL;
                 } else {
@@ -1331,7 +1341,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                         if (lane == 0) node_store_cs(S, c0, cs, sn);
                     }
                     const uint32_t n0 = nnodes;
-                    const bool fits = expand_children(EE, S, VS, cur, cn, cs, sn, nnodes, [&](uint64_t mask, bool active, uint32_t i0, double f, int ccnt) {
+                    const bool fits = expand_children<false>(EE, S, VS, cur, cn, cs, sn, nnodes, [&](uint64_t mask, bool active, uint32_t i0, double f, int ccnt) {
                         (void)mask;
                         (void)ccnt;
                         if (active) {
@@ -1341,6 +1351,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                     });
                     if (!fits) flags |= E2Q_OVERFLOW;
                     cnt = nnodes - n0;
+                    PROF_TL(sq - 1, 7)
                 }
             }
             if (lane == 0) {
@@ -1348,9 +1359,13 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                 l_shared[SH_E2Q_CNT] = cnt;
                 asm volatile("" ::: "memory");  // the LDS executes one wave's accesses in program order
                 l_shared[SH_E2Q_SEQ] = sq;
-                if (cnt) {
-                    // the scout and validator waves may look at the new nodes from here on (their records were made
-                    // visible inside expand_children)
+                PROF_TL(sq - 1, 4)
+            }
+            if (cnt) {
+                // The queue wave needed the keys (in the ring) and the count only.  The scout and validator waves read
+                // the children's records: those that live in HBM only must have arrived before the new tree size shows.
+                if (nnodes > S.NL) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) {
                     l_shared[SH_NNODES] = nnodes;
                     l_shared[SH_VERSION] = 0x80000000u | ++ver_e;
                 }
@@ -1645,7 +1660,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                 EE.nw = nw;
                 EE.lane = lane;
                 // pq.push(new_open_nodes, new_open_values): one at a time in ascending trim order (mex.cpp:67-72)
-                const bool fits = expand_children(EE, S, VS, cur, cn, cs, sn, nnodes, [&](uint64_t mask, bool active, uint32_t i0, double f, int cnt) {
+                const bool fits = expand_children<true>(EE, S, VS, cur, cn, cs, sn, nnodes, [&](uint64_t mask, bool active, uint32_t i0, double f, int cnt) {
                     (void)active;
                     (void)i0;
                     uint64_t mm = mask;
