@@ -187,6 +187,18 @@ __device__ __forceinline__ void bm_remove(BmQueue& Q, uint32_t idx, uint32_t nn)
     --Q.open;
 }
 
+// Put popped nodes back, one per active lane (their keys are still in place): the inverse of pops that turned out to be
+// premature.  Whole wave calls.
+__device__ __forceinline__ void bm_unpop_lanes(BmQueue& Q, bool active, uint32_t idx, double key, uint32_t nn) {
+    if (active) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(key);
+        __hip_atomic_fetch_and(&Q.pbits[idx >> 6], ~(1ull << (idx & 63u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_min((lds_u64*)&Q.m1[idx >> 6], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (nn > 4096u) __hip_atomic_fetch_min((lds_u64*)&Q.m2[idx >> 12], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    Q.open += (uint32_t)__builtin_popcountll(__ballot(active));
+}
+
 // Put a popped node back (its key is still in place): the inverse of a pop that turned out to be premature.
 __device__ __forceinline__ void bm_unpop(BmQueue& Q, uint32_t idx, double key, uint32_t nn) {
     if ((threadIdx.x & 63u) == 0u) {

@@ -1102,8 +1102,23 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
         PROF_DECL
         PROF_START
       q_again:
-        BmFound cand = bm_pop(Q, nn);  // the root
-        bool cand_in_list = false;     // true: cand is a child that still has to be taken out of the open list
+        // Run-ahead list: entries already taken out of the open list, in pop order (ascending keys), entry j in lane j.
+        // All but the last are known to collide: they are popped and discarded (GraphSearch.m:75-77) without further
+        // ado; the last one is the next node to evaluate.  While the expander wave works on a node, this wave keeps
+        // popping until it holds an entry that is not known to collide, so the pops of colliding nodes overlap with the
+        // expansion.  If a child of the node in flight turns out to come before some of them, those are put back.
+        uint32_t ra_idx = 0xFFFFFFFFu;  // (per lane)
+        double ra_key = inf;            // (per lane)
+        uint32_t ra_n = 0;
+        bool head_in_list = false;  // the last entry is a child that is still in the open list
+        {
+            const BmFound r0 = bm_pop(Q, nn);  // the root
+            if (lane == 0) {
+                ra_idx = r0.idx;
+                ra_key = r0.key;
+            }
+            ra_n = r0.idx != 0xFFFFFFFFu ? 1u : 0u;
+        }
         for (;;) {
             // (the expander wave is idle whenever this wave is here)
             if (lds_load_u32(&l_shared[SH_STATE]) == ST_ARRIVED) {
@@ -1120,8 +1135,11 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                     bm_init(Q, lane, PDMPC_WAVE);  // the other waves see an empty candidate list and a tree of one node meanwhile
                     Q.open = 0;
                     bm_push<true>(Q, lane == 0, 0u, 0.0, 0u, 1u);
-                    cand = bm_pop(Q, nn);
-                    cand_in_list = false;
+                    const BmFound r0 = bm_pop(Q, nn);
+                    ra_idx = lane == 0 ? r0.idx : 0xFFFFFFFFu;
+                    ra_key = lane == 0 ? r0.key : inf;
+                    ra_n = 1;
+                    head_in_list = false;
                 }
                 continue;
             }
@@ -1132,23 +1150,33 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                 if (uni_u(old) == ST_RUN) return true;
                 continue;  // an arrival got in first: handle it, then try again
             }
-            if (cand.idx == 0xFFFFFFFFu) {  // pop on an empty queue returns -1 (mex.cpp:87-93)  GraphSearch.m:57-61
+            if (ra_n == 0) {  // pop on an empty queue returns -1 (mex.cpp:87-93)  GraphSearch.m:57-61
                 status = PDMPC_EXHAUSTED;
                 break;
             }
-            const uint32_t cur = cand.idx + 1u;
+            // the colliding entries in front: popped, discarded
+            const uint32_t n_dead = ra_n - 1u;
 #ifndef PDMPC_PROFILE
-            if (A.trace_cap > 0 && n_popped < A.trace_cap && lane == 0) A.pop_trace[(size_t)slot * A.trace_cap + n_popped] = (int32_t)cur;
+            if (A.trace_cap > 0 && (uint32_t)lane <= n_dead && n_popped + lane < A.trace_cap) A.pop_trace[(size_t)slot * A.trace_cap + n_popped + lane] = (int32_t)(ra_idx + 1u);
 #endif
-            ++n_popped;
+            n_popped += (int)ra_n;
+            const uint32_t cidx = lane_u(ra_idx, (int)n_dead);
+            const uint32_t cur = cidx + 1u;
+            ra_n = 0;
+            PROF_COUNT(7, n_dead)
             PROF_STOP(0)  // loop head
-            if (uni_u(vs_load(VS, cand.idx)) == VS_INVALID) {  // GraphSearch.m:75-77 without leaving this wave
+            if (uni_u(vs_load(VS, cidx)) == VS_INVALID) {  // (the verdict came in after the entry was listed)
                 PROF_STOP(1)  // validity lookup
-                if (cand_in_list) bm_remove(Q, cand.idx, nn);
+                if (head_in_list) bm_remove(Q, cidx, nn);
+                head_in_list = false;
                 PROF_STOP(2)  // remove
-                cand = bm_pop(Q, nn);
-                cand_in_list = false;
-                if (lane == 0) l_shared[SH_VERSION] = ++ver_ctr;
+                const BmFound t = bm_pop(Q, nn);
+                if (lane == 0) {
+                    ra_idx = t.idx;
+                    ra_key = t.key;
+                    l_shared[SH_VERSION] = ++ver_ctr;
+                }
+                ra_n = t.idx != 0xFFFFFFFFu ? 1u : 0u;
                 PROF_STOP(3)  // pop
                 PROF_COUNT(7, 1)
                 continue;
@@ -1161,11 +1189,20 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                 asm volatile("" ::: "memory");  // the LDS executes one wave's accesses in program order
                 l_shared[SH_Q2E_SEQ] = seq;
             }
-            if (cand_in_list) bm_remove(Q, cand.idx, nn);
+            if (head_in_list) bm_remove(Q, cidx, nn);
+            head_in_list = false;
             PROF_STOP(2)
-            // the best of the rest, taken out right away: in the usual case it is popped next; if a child of the node in
-            // flight turns out to come first, it is put back
-            const BmFound tent = bm_pop(Q, nn);
+            // run ahead while the expander works
+            for (;;) {
+                const BmFound t = bm_pop(Q, nn);
+                if (t.idx == 0xFFFFFFFFu) break;
+                if ((uint32_t)lane == ra_n) {
+                    ra_idx = t.idx;
+                    ra_key = t.key;
+                }
+                ++ra_n;
+                if (ra_n == 8u || uni_u(vs_load(VS, t.idx)) != VS_INVALID) break;
+            }
             if (lane == 0) l_shared[SH_VERSION] = ++ver_ctr;
             PROF_STOP(3)
             PROF_TL(seq - 1, 1)
@@ -1192,19 +1229,17 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                 status = PDMPC_ARENA_OVERFLOW;
                 break;
             }
-            cand = tent;
-            cand_in_list = false;
             if (cnt) {
-                // the children are nodes nn .. nn + cnt - 1; their keys sit in the ring.  Make them visible and see
-                // whether one of them comes before the best older entry.
+                // the children are nodes nn .. nn + cnt - 1; their keys sit in the ring.  Make them visible, then see
+                // where the smallest of them falls among the entries of the run-ahead list.
                 for (uint32_t base = 0; base < cnt; base += (uint32_t)PDMPC_WAVE) {
                     const bool active = base + (uint32_t)lane < cnt;
                     const uint32_t i0 = nn + base + (uint32_t)lane;
                     const double f = active ? *(volatile lds_f64*)&Q.kring[i0 & Q.kr_mask] : inf;
                     bm_push<false>(Q, active, i0, f, nn + base, nn + (base + PDMPC_WAVE < cnt ? base + PDMPC_WAVE : cnt));
-                    const unsigned long long better = __ballot(f < cand.key);  // (+inf when there is no older entry)
-                    const unsigned long long same = __ballot(active && f == cand.key);
-                    if (same) Q.tie = true;
+                    const double limit = ra_n ? lane_d(ra_key, (int)ra_n - 1) : inf;  // the key of the list's last entry
+                    if (__ballot(active && f == limit)) Q.tie = true;
+                    const unsigned long long better = __ballot(f < limit);
                     if (better) {
                         int l = __builtin_ctzll(better);
                         if (better & (better - 1ull)) {  // several: the smallest of them
@@ -1213,13 +1248,23 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                             if (at & (at - 1ull)) Q.tie = true;
                             l = __builtin_ctzll(at);
                         }
-                        cand.idx = nn + base + (uint32_t)l;
-                        cand.key = lane_d(f, l);
-                        cand_in_list = true;
+                        const double ck = lane_d(f, l);
+                        const bool listed = (uint32_t)lane < ra_n;
+                        if (__ballot(listed && ra_key == ck)) Q.tie = true;
+                        const uint32_t pos = (uint32_t)__builtin_popcountll(__ballot(listed && ra_key < ck));
+                        // entries pos .. ra_n - 1 come after the child: back into the open list (a listed child that is
+                        // still in the open list just drops off the list)
+                        const bool back = listed && (uint32_t)lane >= pos && !(head_in_list && (uint32_t)lane == ra_n - 1u);
+                        bm_unpop_lanes(Q, back, ra_idx, ra_key, nn + cnt);
+                        if ((uint32_t)lane == pos) {
+                            ra_idx = nn + base + (uint32_t)l;
+                            ra_key = ck;
+                        }
+                        ra_n = pos + 1u;
+                        head_in_list = true;
                     }
                 }
                 nn += cnt;
-                if (cand_in_list && tent.idx != 0xFFFFFFFFu) bm_unpop(Q, tent.idx, tent.key, nn);
             }
             PROF_STOP(5)  // children made visible
         }
