@@ -213,7 +213,7 @@ int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in, int cand_cap_in)
         h->bm_nb = (int)nb;
         h->bm_kr = 0;
         if (nb <= 4096u && region_cap >= bm_fixed + 512u * 8u) {
-            uint32_t kr = 512, kr_max = 8192;
+            uint32_t kr = 512, kr_max = 2048;  // measured on C2: 2048 .. 8192 entries make no difference; the LDS goes to the validity cache instead
             if (const char* e = getenv("PDMPC_BM_RING")) kr_max = (uint32_t)std::max(512, atoi(e));  // tuning knob
             while (kr * 2u * 8u + bm_fixed <= region_cap && kr * 2u <= kr_max) kr *= 2u;
             h->bm_kr = (int)kr;
@@ -226,8 +226,10 @@ int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in, int cand_cap_in)
         }
         if (h->bm_kr == 0) h->queue_mode = PDMPC_QUEUE_HEAP;  // no room (tiny LDS budget) or more than 262144 nodes per vehicle
     }
-    // validity cache: one byte per node for the first NV nodes (a quarter of what is left, at most 32768)
-    uint32_t nv = std::min((uint32_t)32768, (rest - region) / 4);
+    // validity cache: one byte per node for the first NV nodes (three quarters of what is left, at most 65536)
+    uint32_t nv_max = 65536;
+    if (const char* e = getenv("PDMPC_NV_MAX")) nv_max = (uint32_t)std::max(1024, atoi(e));  // tuning knob
+    uint32_t nv = std::min(nv_max, (rest - region) / 4 * 3);
     nv = std::min(nv, h->max_nodes) & ~15u;
     uint32_t nl = (rest - region - nv) / (uint32_t)sizeof(NodeRec);
     nl = std::min(nl, h->max_nodes);
