@@ -709,6 +709,8 @@ __device__ __forceinline__ bool vs_claim(const VState& v, uint32_t i0) {
 #define SH_E2Q_FLAGS 19 // E2Q_* bits
 #define SH_E2Q_CNT 20   // children created (their keys are in the key ring, their records in the tree)
 #define SH_Q_SYNC 21    // set by the queue wave while it is inside arrival_sync (the expander must not enter before: it may owe a reply)
+#define SH_HINT_SEQ 22  // queue wave -> expander wave: the hand-over number SH_HINT_ID will probably be posted under ...
+#define SH_HINT_ID 23   // ... and the node: the expander may evaluate and expand it ahead of time
 #define SH_WORDS 32
 #define E2Q_VALID 1u     // the edge into the node is collision-free
 #define E2Q_GOAL 2u      // ... and the node is at the horizon: the search is over
@@ -842,6 +844,7 @@ __device__ bool arrival_sync(const Search& S, const CheckCtx& C, const SpecCtx& 
             P.sh[SH_HEAP_LEN] = 1;
             P.sh[SH_NNODES] = 1;
             for (int c = 0; c < BM_NCAND; ++c) P.sh[SH_CAND + c] = 0;
+            P.sh[SH_HINT_SEQ] = 0;  // (the hinted node belongs to the tree that is being thrown away)
             P.sh[SH_VERSION] = P.sh[SH_VERSION] + 1;
             ((uint32_t*)S.gn)[15] &= ~NODE_POPPED_BIT;
             if (S.NL > 0) ((lds_u32*)S.ln)[15] = ((lds_u32*)S.ln)[15] & ~NODE_POPPED_BIT;
@@ -1201,7 +1204,16 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                     ra_key = t.key;
                 }
                 ++ra_n;
-                if (ra_n == 8u || uni_u(vs_load(VS, t.idx)) != VS_INVALID) break;
+                if (uni_u(vs_load(VS, t.idx)) != VS_INVALID) {
+                    // most likely the next node to be handed over: the expander may start on it as soon as it is idle
+                    if (lane == 0) {
+                        l_shared[SH_HINT_ID] = t.idx + 1u;
+                        asm volatile("" ::: "memory");
+                        l_shared[SH_HINT_SEQ] = seq + 1u;
+                    }
+                    break;
+                }
+                if (ra_n == 8u) break;
             }
             if (lane == 0) l_shared[SH_VERSION] = ++ver_ctr;
             PROF_STOP(3)
@@ -1335,27 +1347,61 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
         uint32_t ver_e = 0;
         PROF_DECL
         PROF_START
+        // Speculation: when the queue wave already knows which node it will most likely hand over next (the head of its
+        // run-ahead list), this wave evaluates and expands that node as soon as it is idle and keeps the outcome to
+        // itself: children records and keys are written (beyond the published tree size nobody looks), the reply is held
+        // back.  If the node is then handed over, the reply goes out at once; if another node comes (a child of the
+        // previous one came first), the tree size is wound back and the work is redone for the right node.
+        bool spec_valid = false;
+        uint32_t spec_id = 0, spec_flags = 0, spec_cnt = 0, spec_n0 = 0;
         for (;;) {
             const uint32_t sq = lds_load_u32(&l_shared[SH_Q2E_SEQ]);
-            if (sq == seen) {
+            uint32_t cur;
+            bool spec = false, answered = false;
+            uint32_t flags = 0, cnt = 0;
+            if (sq != seen) {
+                seen = sq;
+                PROF_STOP(8)  // idle
+                PROF_TL(sq - 1, 3)
+                asm volatile("" ::: "memory");
+                cur = lds_load_u32(&l_shared[SH_Q2E_ID]);
+                if (spec_valid) {
+                    spec_valid = false;
+                    if (spec_id == cur) {  // guessed right: the answer is ready
+                        flags = spec_flags;
+                        cnt = spec_cnt;
+                        PROF_COUNT(13, 1)
+                        answered = true;
+                    } else {
+                        nnodes = spec_n0;  // guessed wrong: the speculative children are forgotten
+                    }
+                }
+            } else {
                 const uint32_t state = lds_load_u32(&l_shared[SH_STATE]);
                 if (state == ST_DONE || state == ST_TIE) break;
                 // nothing handed over.  An arrival is joined only once the queue wave is in it: before that it may
                 // still hand a node over and wait for the reply.
                 if (state == ST_ARRIVED && lds_load_u32(&l_shared[SH_Q_SYNC]) != 0) {
+                    if (spec_valid) {  // the verdict may change with the new areas
+                        spec_valid = false;
+                        nnodes = spec_n0;
+                    }
                     if (arrival_sync(S, C, P, VS, tid)) nnodes = 1;
-                } else if (A.crowded) {
-                    __builtin_amdgcn_s_sleep(6);  // leave the issue slots to the waves that have work
+                    continue;
                 }
-                continue;
+                if (!spec_valid && A.speculate_expansion && lds_load_u32(&l_shared[SH_HINT_SEQ]) == seen + 1u) {
+                    asm volatile("" ::: "memory");
+                    cur = lds_load_u32(&l_shared[SH_HINT_ID]);
+                    if (lds_load_u32(&l_shared[SH_HINT_SEQ]) != seen + 1u || lds_load_u32(&l_shared[SH_Q2E_SEQ]) != seen) continue;
+                    spec = true;
+                } else {
+                    if (A.crowded) __builtin_amdgcn_s_sleep(6);  // leave the issue slots to the waves that have work
+                    continue;
+                }
             }
-            seen = sq;
-            PROF_STOP(8)  // idle
-            PROF_TL(sq - 1, 3)
-            asm volatile("" ::: "memory");
-            const uint32_t cur = lds_load_u32(&l_shared[SH_Q2E_ID]);
+            const uint32_t n_before = nnodes;
+            if (!answered) {
             const uint32_t c0 = cur - 1;
-            uint32_t flags = 0, cnt = 0;
             const uint32_t vs = uni_u(vs_load(VS, c0));
             bool valid;
             if (vs == VS_UNKNOWN || vs == VS_CLAIMED) {
@@ -1367,13 +1413,13 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
             }
             PROF_STOP(9)  // validity
             PROF_COUNT(14, 1)
-            PROF_TL(sq - 1, 5)
+            PROF_TL(seen - 1 + (spec ? 1 : 0), 5)
             if (valid) {
                 flags = E2Q_VALID;
                 const NodeRec cn = node_load(S, c0);  // same record in every lane
                 const uint32_t cpk = uni_u(cn.packed);
                 if (lane == 0) node_mark_popped(S, c0, cpk);  // a later arrival that hits this node forces a restart
-                PROF_TL(sq - 1, 6)
+                PROF_TL(seen - 1 + (spec ? 1 : 0), 6)
                 if (NODE_K(cpk) == Hp) {
                     flags |= E2Q_GOAL;
                 } else {
@@ -1396,15 +1442,25 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                     });
                     if (!fits) flags |= E2Q_OVERFLOW;
                     cnt = nnodes - n0;
-                    PROF_TL(sq - 1, 7)
+                    PROF_TL(seen - 1 + (spec ? 1 : 0), 7)
                 }
+            }
+            }
+            if (spec) {
+                spec_valid = true;
+                spec_id = cur;
+                spec_flags = flags;
+                spec_cnt = cnt;
+                spec_n0 = n_before;
+                PROF_STOP(11)  // speculative work
+                continue;
             }
             if (lane == 0) {
                 l_shared[SH_E2Q_FLAGS] = flags;
                 l_shared[SH_E2Q_CNT] = cnt;
                 asm volatile("" ::: "memory");  // the LDS executes one wave's accesses in program order
-                l_shared[SH_E2Q_SEQ] = sq;
-                PROF_TL(sq - 1, 4)
+                l_shared[SH_E2Q_SEQ] = seen;
+                PROF_TL(seen - 1, 4)
             }
             if (cnt) {
                 // The queue wave needed the keys (in the ring) and the count only.  The scout and validator waves read
