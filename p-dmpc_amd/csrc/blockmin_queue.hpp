@@ -7,14 +7,18 @@
 // the search start over on the libstdc++-faithful binary heap (heap_push / heap_pop), so results never depend on it.
 // Measured on the closed-loop C2 workload: 0 tied pops in 311 235 (tools/tie_frequency.py).
 //
-// Layout: the entry of node i (0-based tree index; nodes are pushed exactly once, in index order) is key[i], +inf
-// once popped.  m1[b] = min key of block b = nodes [64 b, 64 b + 64); m2[g] = min of m1[64 g .. 64 g + 64).
-//   push of up to 64 consecutive nodes   one key store per lane + two LDS atomic-min per lane
-//   pop                                  three dependent 64-wide loads (m2, m1 of the best group, keys of the best block),
-//                                        one wave min-reduction each, two more to repair m1[b] and m2[g]
-// Keys of the KR most recent nodes sit in an LDS ring (slot = i & (KR - 1)); every key is also written through to
-// HBM, which is where blocks older than the ring are read from.  Keys are non-negative finite doubles (sums of
-// squares), so their bit patterns order like unsigned integers: the atomics are ds_min_u64.
+// Layout: the entry of node i (0-based tree index; nodes are pushed exactly once, in index order) is key[i].  Keys are
+// never overwritten: pbits[b] holds the popped bits of block b = nodes [64 b, 64 b + 64).  m1[b] = min key of the
+// entries of block b that are still in the queue; m2[g] = min of m1[64 g .. 64 g + 64), maintained once the tree has
+// more than 4096 nodes.
+//   push of up to 64 consecutive nodes   one key store per lane + one or two LDS atomic-min per lane
+//   pop                                  up to three dependent 64-wide loads (m2, m1 of the best group, keys of the best
+//                                        block), one wave min-reduction to find the minimum, two ballots to locate it,
+//                                        one or two reductions for the new m1[b] and m2[g]; sets the popped bit
+//   un-pop                               clears the popped bit, one or two LDS atomic-min
+// Keys of the KR most recent nodes sit in an LDS ring (slot = i & (KR - 1)); every key is also written to HBM, which is
+// where blocks older than the ring are read from.  Keys are non-negative finite doubles (sums of squares), so their
+// bit patterns order like unsigned integers: the atomics are ds_min_u64.
 #pragma once
 
 typedef LDS_AS unsigned long long lds_u64;
@@ -29,7 +33,6 @@ struct BmQueue {
     double* gkey;    // [max_nodes]
     uint32_t kr_mask;
     uint32_t nb_max;
-    uint32_t open;  // entries currently in the queue
     bool tie;       // a pop found its minimal key more than once: the pop order is not certified any more
 };
 
@@ -87,7 +90,7 @@ __device__ __forceinline__ void bm_init(BmQueue& Q, int tid, int nthreads) {
 
 __device__ __forceinline__ bool bm_in_ring(const BmQueue& Q, uint32_t block, uint32_t nn) { return block * 64u + Q.kr_mask + 1u >= nn + BM_INFLIGHT; }
 
-// Make the nodes i0 (0-based, consecutive over the active lanes, all >= nn_before) with keys f visible to bm_find.
+// Make the nodes i0 (0-based, consecutive over the active lanes, all >= nn_before) with keys f visible to bm_pop.
 // STORE_KEYS = false: the keys are already in the ring and in HBM (written by the expanding wave), only the block and
 // group minima are updated.  Whole wave calls; nn_after = tree size after this batch.
 template <bool STORE_KEYS>
@@ -107,7 +110,6 @@ __device__ __forceinline__ void bm_push(BmQueue& Q, bool active, uint32_t i0, do
         __hip_atomic_fetch_min((lds_u64*)&Q.m1[i0 >> 6], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (nn_after > 4096u) __hip_atomic_fetch_min((lds_u64*)&Q.m2[i0 >> 12], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    Q.open += (uint32_t)__builtin_popcountll(__ballot(active));
 }
 
 // keys of block b, one per lane (+inf for nodes that do not exist yet or have been popped)
@@ -133,39 +135,6 @@ struct BmFound {
     double key;
 };
 
-// The entry with the minimal key (not removed).  nn = current tree size.  Sets Q.tie if the minimum is not unique.
-__device__ __forceinline__ BmFound bm_find(BmQueue& Q, uint32_t nn) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const double inf = bm_inf();
-    BmFound r;
-    r.idx = 0xFFFFFFFFu;
-    r.key = inf;
-    uint32_t g = 0;
-    double v1, mn1;
-    if (nn > 4096u) {
-        const double v2 = Q.m2[lane];
-        mn1 = wave_min_d(v2);  // the minimum of the best group is the minimum of one of its blocks: no second reduction
-        if (!(mn1 < inf)) return r;
-        const unsigned long long b2 = __ballot(v2 == mn1);
-        if (b2 & (b2 - 1ull)) Q.tie = true;
-        g = (uint32_t)__builtin_ctzll(b2);
-        v1 = Q.m1[g * 64u + lane];
-    } else {
-        v1 = Q.m1[lane];  // m1 is +inf beyond the last block
-        mn1 = wave_min_d(v1);
-        if (!(mn1 < inf)) return r;
-    }
-    const unsigned long long b1 = __ballot(v1 == mn1);
-    if (b1 & (b1 - 1ull)) Q.tie = true;
-    const uint32_t b = g * 64u + (uint32_t)__builtin_ctzll(b1);
-    const double k = bm_block_keys(Q, b, nn, bm_in_ring(Q, b, nn));
-    const unsigned long long b0 = __ballot(k == mn1);
-    if (b0 & (b0 - 1ull)) Q.tie = true;
-    r.idx = b * 64u + (uint32_t)__builtin_ctzll(b0);
-    r.key = mn1;
-    return r;
-}
-
 // Remove node idx (which must be in the queue): key -> +inf, block and group minima recomputed.
 __device__ __forceinline__ void bm_remove(BmQueue& Q, uint32_t idx, uint32_t nn) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -184,7 +153,6 @@ __device__ __forceinline__ void bm_remove(BmQueue& Q, uint32_t idx, uint32_t nn)
         const double new2 = wave_min_d(lane == (b & 63u) ? new1 : v1);
         if (lane == 0) Q.m2[g] = new2;
     }
-    --Q.open;
 }
 
 // Put popped nodes back, one per active lane (their keys are still in place): the inverse of pops that turned out to be
@@ -196,18 +164,6 @@ __device__ __forceinline__ void bm_unpop_lanes(BmQueue& Q, bool active, uint32_t
         __hip_atomic_fetch_min((lds_u64*)&Q.m1[idx >> 6], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (nn > 4096u) __hip_atomic_fetch_min((lds_u64*)&Q.m2[idx >> 12], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    Q.open += (uint32_t)__builtin_popcountll(__ballot(active));
-}
-
-// Put a popped node back (its key is still in place): the inverse of a pop that turned out to be premature.
-__device__ __forceinline__ void bm_unpop(BmQueue& Q, uint32_t idx, double key, uint32_t nn) {
-    if ((threadIdx.x & 63u) == 0u) {
-        const unsigned long long bits = (unsigned long long)__double_as_longlong(key);
-        __hip_atomic_fetch_and(&Q.pbits[idx >> 6], ~(1ull << (idx & 63u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_min((lds_u64*)&Q.m1[idx >> 6], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (nn > 4096u) __hip_atomic_fetch_min((lds_u64*)&Q.m2[idx >> 12], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    ++Q.open;
 }
 
 // Pop: the entry with the minimal key is found and removed with a single look at its block.  Returns idx 0xFFFFFFFF if
@@ -254,6 +210,5 @@ __device__ __forceinline__ BmFound bm_pop(BmQueue& Q, uint32_t nn) {
         const double new2 = wave_min_d(lane == bl ? new1 : v1);
         if (lane == 0) Q.m2[g] = new2;
     }
-    --Q.open;
     return r;
 }

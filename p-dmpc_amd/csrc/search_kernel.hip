@@ -970,13 +970,6 @@ __device__ __forceinline__ bool expand_children(const ExpandEnv& E, Search& S, c
             ch.x = cs * mp.dx - sn * mp.dy + curX;  // :53
             ch.y = sn * mp.dx + cs * mp.dy + curY;  // :54
             ch.yaw = curYaw + mp.dyaw;              // :55
-            double expG = curG;
-            {
-                const double ddx = ch.x - l_rx[k_exp - 1], ddy = ch.y - l_ry[k_exp - 1];
-                const double nrm = sqrt(ddx * ddx + ddy * ddy);
-                expG = expG + nrm * nrm;  // :61
-            }
-            ch.g = expG;
             ch.cs = 0.0;
             ch.sn = 0.0;
             ch.parent = cur;
@@ -988,28 +981,37 @@ __device__ __forceinline__ bool expand_children(const ExpandEnv& E, Search& S, c
             l_chxy[rank] = xy;
         }
         wave_sync();
-        // cost-to-go terms (expand_node.m:68-73), one lane per (child, remaining step): the sqrt chains of a
-        // child run side by side instead of one after the other; the SUM below keeps the reference's order
+        // The distance terms of the cost-to-come (expand_node.m:57-61, slot 0) and of the cost-to-go (:68-73, slots 1..T),
+        // one lane per (child, step): all the sqrt chains of an expansion run side by side, usually in a single pass;
+        // the sums below keep the reference's order.
         const int T = steps_to_go;
-        // lane layout: child r = idx & 15, step it = (idx >> 4) + 1 (no integer division; a word has <= 16 successors,
-        // enforced by pdmpc_upload_mpa; the reference MPAs have at most 12)
-        for (int base = 0; base < 16 * T; base += PDMPC_WAVE) {
+        // lane layout: child r = idx & (2^sh - 1), step it = idx >> sh (no integer division; a word has <= 16
+        // successors, enforced by pdmpc_upload_mpa; the reference MPAs have at most 12, mostly <= 8)
+        const int sh = cnt <= 8 ? 3 : 4;
+        for (int base = 0; base < ((T + 1) << sh); base += PDMPC_WAVE) {
             const int idx = base + lane;
-            const int r = idx & 15;
-            const int it = (idx >> 4) + 1;
+            const int r = idx & ((1 << sh) - 1);
+            const int it = idx >> sh;
             if (r < cnt && it <= T) {
                 const d2 xy = l_chxy[r];
-                const double ddx = xy.x - l_rx[k_exp + it - 1], ddy = xy.y - l_ry[k_exp + it - 1];
+                const double ddx = xy.x - l_rx[k_exp - 1 + it], ddy = xy.y - l_ry[k_exp - 1 + it];
                 const double nrm = sqrt(ddx * ddx + ddy * ddy);
-                const double df = nrm - l_dcum[(k_exp - 1) * PDMPC_HP_MAX + (it - 1)];
-                const double m0 = (df > 0) ? df : 0.0;
-                l_term[r * PDMPC_HP_MAX + (it - 1)] = m0 * m0;
+                double val;
+                if (it == 0) {
+                    val = nrm * nrm;  // :61
+                } else {
+                    const double df = nrm - l_dcum[(k_exp - 1) * PDMPC_HP_MAX + (it - 1)];
+                    const double m0 = (df > 0) ? df : 0.0;
+                    val = m0 * m0;
+                }
+                l_term[r * PDMPC_HP_MAX + it] = val;
             }
         }
         wave_sync();
         if (active) {
+            ch.g = curG + l_term[rank * PDMPC_HP_MAX];  // :61
             double expH = 0.0;
-            for (int it = 0; it < T; ++it) expH = expH + l_term[rank * PDMPC_HP_MAX + it];
+            for (int it = 1; it <= T; ++it) expH = expH + l_term[rank * PDMPC_HP_MAX + it];
             ch.h = expH;
             f = ch.g * 1 + expH * 1;  // GraphSearch.m:100-102
             node_store(S, i0, ch);
@@ -1078,7 +1080,6 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
     if (BM) {
         bm_init(Q, tid, PDMPC_THREADS);
         __syncthreads();
-        Q.open = 0;
         Q.tie = false;
         if (wave == 0) bm_push<true>(Q, lane == 0, 0u, 0.0, 0u, 1u);
     }
@@ -1136,7 +1137,6 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                     n_popped = 0;
                     nn = 1;
                     bm_init(Q, lane, PDMPC_WAVE);  // the other waves see an empty candidate list and a tree of one node meanwhile
-                    Q.open = 0;
                     bm_push<true>(Q, lane == 0, 0u, 0.0, 0u, 1u);
                     const BmFound r0 = bm_pop(Q, nn);
                     ra_idx = lane == 0 ? r0.idx : 0xFFFFFFFFu;
@@ -1302,7 +1302,6 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                     status = PDMPC_OK;
                     nn = 1;
                     bm_init(Q, lane, PDMPC_WAVE);
-                    Q.open = 0;
                     Q.tie = false;
                     bm_push<true>(Q, lane == 0, 0u, 0.0, 0u, 1u);
                     goto q_again;
@@ -1726,16 +1725,14 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
 
             const NodeRec cn = node_load(S, c0);  // same record in every lane
             const uint32_t cpk = uni_u(cn.packed);
-            const int cTrim = NODE_TRIM(cpk);  // 1-based
-            const int cK = NODE_K(cpk);
             if (lane == 0) node_mark_popped(S, c0, cpk);  // a later arrival that hits this node forces a restart
-            if (cK == Hp) {  // :81-90
+            if (NODE_K(cpk) == Hp) {  // :81-90
                 goal = cur;
                 break;
             }
 
             // ---- expand_node.m:1-91
-            const double curX = cn.x, curY = cn.y, curYaw = cn.yaw, curG = cn.g;
+            const double curYaw = cn.yaw;
             double sn, cs;
             PROF_STOP(3)
             if (vs == VS_VALID_CS) {  // a helper already evaluated expand_node.m:50-51 for this node
@@ -2087,7 +2084,6 @@ __device__ __forceinline__ void search_body(const KernelArgs& A) {
     X.Q.gkey = S.gkey;
     X.Q.kr_mask = (uint32_t)A.bm_kr - 1u;
     X.Q.nb_max = (uint32_t)A.bm_nb;
-    X.Q.open = 0;
     X.Q.tie = false;
     bool tie = false;
     if (A.queue_mode == PDMPC_QUEUE_BLOCKMIN) {
@@ -2258,7 +2254,6 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_bm_script_kernel(
     Q.gkey = gkey;
     Q.kr_mask = (uint32_t)KR - 1u;
     Q.nb_max = (uint32_t)NB;
-    Q.open = 0;
     Q.tie = false;
     bm_init(Q, lane, PDMPC_WAVE);
     __syncthreads();
