@@ -925,10 +925,10 @@ struct ExpandEnv {
 // Returns false if the arena cannot take the children (nothing is created then).
 // FENCE: drain the records' HBM stores before push (needed when push makes the children visible to waves that read
 // their records; the expander wave of the block-min mode drains later, before it publishes the new tree size).
-template <bool FENCE, class Push>
+template <bool FENCE, int NW, class Push>
 __device__ __forceinline__ bool expand_children(const ExpandEnv& E, Search& S, const VState& VS, uint32_t cur, const NodeRec& cn, double cs, double sn,
                                                 uint32_t& nnodes, Push push) {
-    const int Hp = E.Hp, n = E.n, nw = E.nw, lane = E.lane;
+    const int Hp = E.Hp, n = E.n, nw = NW > 0 ? NW : E.nw, lane = E.lane;  // NW > 0: mask words known at compile time
     lds_mask64* l_mask = E.l_mask;
     lds_i16* l_mi = E.l_mi;
     lds_pose* l_pose = E.l_pose;
@@ -1031,7 +1031,7 @@ __device__ __forceinline__ bool expand_children(const ExpandEnv& E, Search& S, c
 // The search proper: root node, sequencing wave, helper waves, and the wait for predecessors that are still planning.
 // BM = false: the libstdc++-faithful binary heap (exact for any keys).  BM = true: the block-min queue, which is only
 // exact while the minimal key is unique; returns true (to every wave) if it met a tie and the search must be redone.
-template <int CHECKER, bool BM>
+template <int CHECKER, bool BM, int NW>
 __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
     const int tid = X.tid, lane = X.lane, wave = X.wave, slot = X.slot, Hp = X.Hp, n = X.n, nw = X.nw;
     const DevVehicle* __restrict__ V = X.V;
@@ -1431,7 +1431,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                         if (lane == 0) node_store_cs(S, c0, cs, sn);
                     }
                     const uint32_t n0 = nnodes;
-                    const bool fits = expand_children<false>(EE, S, VS, cur, cn, cs, sn, nnodes, [&](uint64_t mask, bool active, uint32_t i0, double f, int ccnt) {
+                    const bool fits = expand_children<false, NW>(EE, S, VS, cur, cn, cs, sn, nnodes, [&](uint64_t mask, bool active, uint32_t i0, double f, int ccnt) {
                         (void)mask;
                         (void)ccnt;
                         if (active) {
@@ -1758,7 +1758,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                 EE.nw = nw;
                 EE.lane = lane;
                 // pq.push(new_open_nodes, new_open_values): one at a time in ascending trim order (mex.cpp:67-72)
-                const bool fits = expand_children<true>(EE, S, VS, cur, cn, cs, sn, nnodes, [&](uint64_t mask, bool active, uint32_t i0, double f, int cnt) {
+                const bool fits = expand_children<true, NW>(EE, S, VS, cur, cn, cs, sn, nnodes, [&](uint64_t mask, bool active, uint32_t i0, double f, int cnt) {
                     (void)active;
                     (void)i0;
                     uint64_t mm = mask;
@@ -1835,7 +1835,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
 
 // The kernel body, specialised at compile time on the constraint checker so each variant carries only its own
 // collision code (the search is instruction-cache and issue bound: smaller is faster).
-template <int CHECKER>
+template <int CHECKER, int NW>
 __device__ __forceinline__ void search_body(const KernelArgs& A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -2087,7 +2087,7 @@ __device__ __forceinline__ void search_body(const KernelArgs& A) {
     X.Q.tie = false;
     bool tie = false;
     if (A.queue_mode == PDMPC_QUEUE_BLOCKMIN) {
-        tie = search_loops<CHECKER, true>(A, X);
+        tie = search_loops<CHECKER, true, NW>(A, X);
         if (tie) {  // (uniform over the workgroup) start over with the exact open list; areas that arrived so far stay in the soup
             __syncthreads();
             if (tid == 0) {
@@ -2100,7 +2100,7 @@ __device__ __forceinline__ void search_body(const KernelArgs& A) {
             __syncthreads();
         }
     }
-    if (A.queue_mode != PDMPC_QUEUE_BLOCKMIN || tie) (void)search_loops<CHECKER, false>(A, X);
+    if (A.queue_mode != PDMPC_QUEUE_BLOCKMIN || tie) (void)search_loops<CHECKER, false, NW>(A, X);
     const int status = X.status;
     const int n_popped = X.n_popped;
     const uint32_t goal = X.goal;
@@ -2324,17 +2324,19 @@ extern "C" int pdmpc_launch_heap_script(const int32_t* op, const int32_t* id, co
     return (int)hipGetLastError();
 }
 
-extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(const KernelArgs A) { search_body<PDMPC_CHECK_INTERX>(A); }
-extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel_sat(const KernelArgs A) { search_body<PDMPC_CHECK_SAT>(A); }
+// one successor-mask word (MPAs of at most 64 trims: all of the reference's but the "realistic" one) / any number
+extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(const KernelArgs A) { search_body<PDMPC_CHECK_INTERX, 1>(A); }
+extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel_sat(const KernelArgs A) { search_body<PDMPC_CHECK_SAT, 1>(A); }
+extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel_wide(const KernelArgs A) { search_body<PDMPC_CHECK_INTERX, 0>(A); }
+extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel_sat_wide(const KernelArgs A) { search_body<PDMPC_CHECK_SAT, 0>(A); }
 
 extern "C" int pdmpc_launch_search(const KernelArgs* args, int count, void* stream) {
     if (count <= 0) return 0;
-    const void* fn = args->checker == PDMPC_CHECK_INTERX ? (const void*)pdmpc_search_kernel : (const void*)pdmpc_search_kernel_sat;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)args->lds.total);
+    typedef void (*kernel_t)(const KernelArgs);
+    const bool interx = args->checker == PDMPC_CHECK_INTERX, one_word = args->n_words == 1;
+    const kernel_t fn = interx ? (one_word ? pdmpc_search_kernel : pdmpc_search_kernel_wide) : (one_word ? pdmpc_search_kernel_sat : pdmpc_search_kernel_sat_wide);
+    hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)args->lds.total);
     if (e != hipSuccess) return (int)e;
-    if (args->checker == PDMPC_CHECK_INTERX)
-        hipLaunchKernelGGL(pdmpc_search_kernel, dim3(count), dim3(PDMPC_THREADS), args->lds.total, (hipStream_t)stream, *args);
-    else
-        hipLaunchKernelGGL(pdmpc_search_kernel_sat, dim3(count), dim3(PDMPC_THREADS), args->lds.total, (hipStream_t)stream, *args);
+    hipLaunchKernelGGL(fn, dim3(count), dim3(PDMPC_THREADS), args->lds.total, (hipStream_t)stream, *args);
     return (int)hipGetLastError();
 }
