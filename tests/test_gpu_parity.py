@@ -209,3 +209,16 @@ def test_random_road_problems_never_fall_back():
     options, mpa, iters = problems.problem_set("interx", 21, 24, Hp=6)
     _, stats = check_batch(options, mpa, iters)
     assert stats["queue_fallbacks"] == 0
+
+
+@pytest.mark.parametrize("env", [{"PDMPC_QUEUE": "0"}, {"PDMPC_SPEC_EXPAND": "0"}, {"PDMPC_SPECULATE": "0"}, {"PDMPC_BM_RING": "512", "PDMPC_NV_MAX": "1024"}])
+def test_tuning_switches_do_not_change_results(env, monkeypatch):
+    """The binary-heap mode, the pipeline without speculative expansion, no speculative step planning, and a starved LDS
+    layout (small key ring: old blocks come from HBM; small validity cache: verdicts in HBM) all give the reference's
+    records, pop sequences and trees."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    options, mpa, iters = problems.problem_set("interx", 5, 12, Hp=7)
+    check_batch(options, mpa, iters)
+    options, mpa, iters = problems.problem_set("sat", 6, 6, Hp=6)
+    check_batch(options, mpa, iters)
