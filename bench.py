@@ -286,6 +286,7 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes / max(n_launch, 1),
                 "launches": n_launch,
                 "lds_bytes_per_workgroup": lds_bytes,
+                "open_list": "block-min queue, %d keys in LDS" % st["queue_ring_entries"] if st["queue_mode"] == 1 else "binary heap",
             },
             "counters": {
                 "nodes_popped_per_s": pops / elapsed,

@@ -145,6 +145,8 @@ typedef struct {
                                  open list and were redone on the binary heap (results are identical either way) */
     int64_t speculation_restarts; /* searches restarted because a predecessor's areas, arriving late, hit an already expanded node */
     int64_t speculation_arrivals; /* late arrivals of predecessor areas folded into running searches (same period) */
+    int64_t queue_mode;        /* open list of the last launch: 0 binary heap, 1 block-min queue (csrc/blockmin_queue.hpp) */
+    int64_t queue_ring_entries;/* block-min queue: keys resident in LDS per vehicle */
     int64_t speculation_wasted_pops; /* nodes popped by searches that were then restarted (block-min mode; same period) */
 } pdmpc_stats;
 

@@ -178,8 +178,10 @@ int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in, int cand_cap_in)
     const uint32_t fixed_rest = ref_bytes + shape_bytes + path_bytes + soup_bytes + expand_bytes;
     const uint32_t cand_bytes = align16((uint32_t)std::max(hb.cand_cap, 1) * 4 * PDMPC_WAVES_PER_VEHICLE);
     const uint32_t min_bytes = 64 * 12 + 64 * (uint32_t)sizeof(NodeRec);
+    // The maneuver areas stay in LDS only if the open list still gets a useful share: 32 KB (block-min queue with a
+    // 2048-entry key ring for 64 k nodes); otherwise the edge checks read them through L2.
     int areas = 1;
-    if ((size_t)off + area_bytes + fixed_rest + cand_bytes + min_bytes + 256 > budget) areas = 0;
+    if ((size_t)off + area_bytes + fixed_rest + cand_bytes + std::max<uint32_t>(min_bytes, 44 * 1024) + 256 > budget) areas = 0;
     L.area = off;
     if (areas) off = align16(off + area_bytes);
     L.ref = off;
@@ -225,7 +227,7 @@ int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in, int cand_cap_in)
             region = (uint32_t)h->bm_kr * 8u + bm_fixed;
             while (align16(hl * 8) + align16(hl * 4) > region) hl -= 4;
         }
-        if (h->bm_kr == 0) h->queue_mode = PDMPC_QUEUE_HEAP;  // no room (tiny LDS budget) or more than 262144 nodes per vehicle
+        // (bm_kr == 0: no room, or more than 262144 nodes per vehicle -> this launch uses the binary heap)
     }
     // validity cache: one byte per node for the first NV nodes (three quarters of what is left, at most 65536)
     uint32_t nv_max = 65536;
@@ -243,6 +245,9 @@ int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in, int cand_cap_in)
     off += nl * (uint32_t)sizeof(NodeRec);
     L.total = align16(off);
     if (L.total > budget) return fail(PDMPC_ERR_CAPACITY, "internal: LDS layout exceeds budget");
+    if (getenv("PDMPC_DEBUG_LDS"))
+        fprintf(stderr, "pdmpc LDS layout: launch %d budget %zu fixed %u rest %u region %u (cap %u) hl %u ring %d blocks %d nv %u nl %u total %u queue %d\n", n_launch,
+                budget, (unsigned)(budget - 256 - rest), rest, region, region_cap, hl, h->bm_kr, h->bm_nb, nv, nl, L.total, h->queue_mode);
     h->lds = L;
     h->HL = (int)hl;
     h->NL = (int)nl;
@@ -425,7 +430,7 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.speculate = h->speculate;
     a.crowded = count > h->n_cu ? 1 : 0;
     a.speculate_expansion = h->speculate_expansion;
-    a.queue_mode = h->queue_mode;
+    a.queue_mode = (h->queue_mode == PDMPC_QUEUE_BLOCKMIN && h->bm_kr != 0) ? PDMPC_QUEUE_BLOCKMIN : PDMPC_QUEUE_HEAP;
     a.bm_kr = h->bm_kr;
     a.bm_nb = h->bm_nb;
     a.tie_count = h->d_tie_count.p;
@@ -446,6 +451,8 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     HIPCHK(hipEventRecord(ev.second, h->stream));
     h->stats.lds_bytes = h->lds.total;
     h->stats.lds_nodes = h->NL;
+    h->stats.queue_mode = a.queue_mode;
+    h->stats.queue_ring_entries = h->bm_kr;
     return PDMPC_OK;
 }
 

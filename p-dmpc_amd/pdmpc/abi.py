@@ -116,6 +116,8 @@ class Stats(C.Structure):
         ("queue_fallbacks", C.c_int64),
         ("speculation_restarts", C.c_int64),
         ("speculation_arrivals", C.c_int64),
+        ("queue_mode", C.c_int64),
+        ("queue_ring_entries", C.c_int64),
         ("speculation_wasted_pops", C.c_int64),
     ]
 
