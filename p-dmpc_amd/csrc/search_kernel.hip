@@ -47,8 +47,8 @@
 #define PROF_COUNT(i, v) S.prof_acc[i] += (v);
 // hand-over timeline (profile build, trace buffer hijacked): slot k of hand-over j <- clock
 #define PROF_TL(j, k)                                                                                              \
-    if (A.trace_cap > 0 && (int)(8 * (j) + 8) <= A.trace_cap && lane == 0)                                         \
-        A.pop_trace[(size_t)slot * A.trace_cap + 8 * (j) + (k)] = (int32_t)(__builtin_readcyclecounter() & 0x7FFFFFFFull);
+    if (A.trace_cap > 0 && (int)(12 * (j) + 12) <= A.trace_cap && lane == 0)                                         \
+        A.pop_trace[(size_t)slot * A.trace_cap + 12 * (j) + (k)] = (int32_t)(__builtin_readcyclecounter() & 0x7FFFFFFFull);
 #else
 #define PROF_TL(j, k)
 #define PROF_MEMBERS
@@ -1168,6 +1168,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
             ra_n = 0;
             PROF_COUNT(7, n_dead)
             PROF_STOP(0)  // loop head
+            PROF_TL(seq, 9)
             if (uni_u(vs_load(VS, cidx)) == VS_INVALID) {  // (the verdict came in after the entry was listed)
                 PROF_STOP(1)  // validity lookup
                 if (head_in_list) bm_remove(Q, cidx, nn);
@@ -1186,6 +1187,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
             }
             PROF_STOP(1)
             ++seq;
+            PROF_TL(seq - 1, 10)
             PROF_TL(seq - 1, 0)
             if (lane == 0) {
                 l_shared[SH_Q2E_ID] = cur;
@@ -1279,6 +1281,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                 nn += cnt;
             }
             PROF_STOP(5)  // children made visible
+            PROF_TL(seq - 1, 8)
         }
 #ifdef PDMPC_PROFILE
         if (lane == 0) {
