@@ -51,7 +51,8 @@ def build_world(args, rank):
     )
     mpa = get_mpa(options)
     scenario = commonroad_scenario(options, seed=args.seed + rank, tiles=tiles)
-    ctl = PrioritizedSequentialController(options, scenario, mpa, None, coupling="distance", boundary_provider=boundary_provider(scenario))
+    ctl = PrioritizedSequentialController(options, scenario, mpa, None, coupling="distance", boundary_provider=boundary_provider(scenario),
+                                         priority_strategy=getattr(args, "priorities", "constant"))
     return options, mpa, ctl
 
 
@@ -117,6 +118,8 @@ def main():
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--priorities", default="constant", choices=["constant", "coloring"],
+                    help="priority strategy of the host driver: vehicle index (ConstantPrioritizer.m) or graph colouring (ColoringPrioritizer.m)")
     ap.add_argument("--instances", type=int, default=64, help="c5: simultaneous prioritizations per time step")
     ap.add_argument("--shard", default="components", choices=["components", "levels"],
                     help="multi-GPU mode of c3/c4: whole coupling-graph components per rank (one speculative launch per rank and step, one "
@@ -263,9 +266,9 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "%s: %d vehicles on the CPM-lab road network (labmap fixture%s), Hp %d, InterX checker, %s MPA, "
-                "distance coupling, constant priorities, %s; %d recorded closed-loop steps replayed from HBM%s"
+                "distance coupling, %s priorities, %s; %d recorded closed-loop steps replayed from HBM%s"
                 % (args.workload.upper() + (" (%d prioritizations of each step flattened into one batch)" % args.instances if explore else ""),
-                   args.vehicles, ", tiled" if sharded and not explore else "", args.hp, args.mpa,
+                   args.vehicles, ", tiled" if sharded and not explore else "", args.hp, args.mpa, args.priorities,
                    "levels sharded over ranks with one all-gather per level" if planner is not None else ("coupling-graph components sharded over ranks, one launch per rank and step, one all-gather of results" if gather_bufs is not None else "one launch per step"), S,
                    "" if sharded else "; per GPU one independent network"),
                 "vehicles": args.vehicles,

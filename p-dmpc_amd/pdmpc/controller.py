@@ -83,6 +83,7 @@ class PrioritizedSequentialController:
         plan_level: Callable[[List[VehicleIter]], List[ControlResultsInfo]],
         coupling: str = "full",
         priorities: Optional[List[int]] = None,
+        priority_strategy: str = "constant",
         boundary_provider=None,
     ):
         self.options = options
@@ -92,6 +93,7 @@ class PrioritizedSequentialController:
         self.coupling = coupling
         self.n = options.amount
         self.priorities = list(priorities) if priorities is not None else list(range(1, self.n + 1))
+        self.priority_strategy = priority_strategy  # "constant" (ConstantPrioritizer.m) or "coloring" (ColoringPrioritizer.m)
         self.boundary_provider = boundary_provider  # road networks: (vehicle, path, points_index, cpi) -> (left, right)
         # Simulation.setup: initial speed = steering = 0 (Simulation.m:52-65)
         self.meas = [Measurement(v.x_start, v.y_start, v.yaw_start, 0.0, 0.0) for v in scenario.vehicles]
@@ -238,6 +240,15 @@ class PrioritizedSequentialController:
             return del_first_rpt_last(self.info_old[i].shapes)
         return None
 
+    def _direct(self, adjacency, priorities):
+        """Undirected coupling -> directed coupling (Prioritizer.prioritize): explicit priorities win; otherwise the
+        controller's strategy."""
+        if priorities is None and self.priority_strategy == "coloring":
+            from .prioritizer import coloring_directed_coupling
+
+            return coloring_directed_coupling(adjacency)[0].astype(np.int64)
+        return directed_coupling_from_priorities(adjacency, self.priorities if priorities is None else priorities)
+
     def build_step_problem(self, priorities=None, refresh=True):
         """Everything one launch needs to plan the whole time step: vehicles in level order (slot = position),
         per-slot predecessor slots, per-slot areas to publish on exhaustion.  `priorities` overrides the controller's
@@ -246,7 +257,7 @@ class PrioritizedSequentialController:
             self._traffic_info()
             self.last_adjacency = self._couple()
         adjacency = self.last_adjacency
-        directed = directed_coupling_from_priorities(adjacency, self.priorities if priorities is None else priorities)
+        directed = self._direct(adjacency, priorities)
         directed_seq = directed
         levels = kahn(directed_seq)
         self.last_levels = levels
@@ -273,7 +284,7 @@ class PrioritizedSequentialController:
         else:
             self._traffic_info()
             adjacency = self._couple()
-            directed = directed_coupling_from_priorities(adjacency, self.priorities)
+            directed = self._direct(adjacency, None)
             directed_seq = directed  # no cutting: every coupled pair plans sequentially (max_num_CLs >= depth)
             levels = kahn(directed_seq)
             self.last_levels = levels

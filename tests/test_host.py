@@ -141,3 +141,56 @@ def test_tiled_scenario_for_large_configs():
     assert len(sc.vehicles) == 128
     xs = np.array([v.x_start for v in sc.vehicles])
     assert xs.max() > 20.0  # vehicles spread over translated copies of the map
+
+
+def test_coloring_prioritizer_levels():
+    """ColoringPrioritizer.m: adjacent vertices never share a level, edges run from earlier to later levels, the number
+    of levels is at most max degree + 1, and the level whose vertex has the most edges plans first."""
+    from pdmpc.controller import kahn
+    from pdmpc.prioritizer import coloring_directed_coupling, topological_coloring
+
+    rng = np.random.default_rng(4)
+    for n, p in ((8, 0.3), (20, 0.15), (40, 0.1), (12, 0.0), (6, 1.0)):
+        A = rng.random((n, n)) < p
+        A = np.triu(A, 1)
+        A = A | A.T
+        color, L = topological_coloring(A)
+        for i, j in zip(*np.nonzero(A)):
+            assert color[i] != color[j]
+        directed, level = coloring_directed_coupling(A)
+        assert level.max() <= A.sum(axis=0).max() + 1
+        for i, j in zip(*np.nonzero(A)):
+            assert directed[i, j] != directed[j, i]  # every coupling keeps exactly one direction
+            if directed[i, j]:
+                assert level[i] < level[j]
+        lv = kahn(directed.astype(np.int64))
+        assert lv.max() <= level.max()
+        if A.any():
+            busiest = int(np.argmax(A.sum(axis=0)))
+            assert level[busiest] == 1
+    # a path graph 0-1-2-3 needs two colours; constant priorities would chain all four vehicles
+    A = np.zeros((4, 4), dtype=bool)
+    for i in range(3):
+        A[i, i + 1] = A[i + 1, i] = True
+    directed, level = coloring_directed_coupling(A)
+    assert sorted(set(level.tolist())) == [1, 2]
+    assert kahn(directed.astype(np.int64)).max() == 2
+
+
+def test_controller_with_coloring_priorities_plans_in_fewer_levels():
+    from pdmpc.config import Config, ScenarioType
+    from pdmpc.controller import PrioritizedSequentialController
+    from pdmpc.mpa import get_mpa
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    options = Config(scenario_type=ScenarioType.commonroad, amount=20, Hp=6)
+    mpa = get_mpa(options)
+    sc = commonroad_scenario(options, seed=1)
+    levels = {}
+    for strategy in ("constant", "coloring"):
+        ctl = PrioritizedSequentialController(options, sc, mpa, None, coupling="distance", boundary_provider=boundary_provider(sc), priority_strategy=strategy)
+        prob = ctl.build_step_problem()
+        levels[strategy] = len(prob["level_sizes"])
+        for s, ps in enumerate(prob["preds"]):
+            assert all(prob["levels"][q] < prob["levels"][s] for q in ps)
+    assert levels["coloring"] <= levels["constant"]
