@@ -1,0 +1,276 @@
+// Edge validity (GraphSearch.m:111-196): InterX and separating-axis checks of one swept area against the obstacle soups (device code, included by search_kernel.hip inside its anonymous namespace).
+#pragma once
+
+// ---------------------------------------------------------------------------------------------------
+// are_constraints_satisfied_interx.m:17-37 + InterX.m:63-76,108-110.
+// The three soups (vehicle obstacles of step k -> shape A, HDV sets of step k -> shape A, lanelet boundary ->
+// boundary-check shape B) are processed together.  hit(i, j) = C1(i, j) & C2(i, j) with
+//   C1 = (dx1_i*y2_j - dy1_i*x2_j - S1_i) * (dx1_i*y2_{j+1} - dy1_i*x2_{j+1} - S1_i) < 0
+//   C2 = (y1_i*dx2_j - x1_i*dy2_j - S2_j) * (y1_{i+1}*dx2_j - x1_{i+1}*dy2_j - S2_j) < 0     (strict; NaN -> false)
+// Pass 1 (one lane per obstacle segment j) evaluates C2 for every shape segment i and keeps a 7-bit mask; lanes with
+// a non-zero mask append (j, mask, shape) to a compact list.  Pass 2 evaluates C1 for the listed pairs only.
+// Pass 1 over one soup range: sh2 holds shape A in [0, VMAX) and shape B in [VMAX, 2*VMAX).
+__device__ __forceinline__ int interx_pass1(const lds_d2* sh2, int shapeB, int V, const lds_d2* soup, int start, int M, lds_u32* cand, int count, int lane) {
+    if (M < 2) return count;
+    const lds_d2* L2 = soup + start;
+    const lds_d2* sh = sh2 + shapeB * PDMPC_VMAX;
+    for (int base = 0; base < M - 1; base += PDMPC_WAVE) {
+        const int j = base + lane;
+        uint32_t bits = 0;
+        if (j < M - 1) {
+            const d2 q0 = L2[j], q1 = L2[j + 1];
+            const double dx2 = q1.x - q0.x, dy2 = q1.y - q0.y;
+            const double S2 = dx2 * q0.y - dy2 * q0.x;
+            d2 p = sh[0];
+            double e0 = (p.y * dx2 - p.x * dy2) - S2;
+            for (int i = 0; i < V - 1; ++i) {
+                p = sh[i + 1];
+                const double e1 = (p.y * dx2 - p.x * dy2) - S2;
+                if (e0 * e1 < 0) bits |= 1u << i;
+                e0 = e1;
+            }
+        }
+        const unsigned long long b = __ballot(bits != 0);
+        if (b) {
+            if (bits) {
+                const int pos = count + (int)__builtin_popcountll(b & ((1ull << lane) - 1ull));
+                cand[pos] = (uint32_t)(start + j) | (bits << 16) | ((uint32_t)shapeB << 24);
+            }
+            count += (int)__builtin_popcountll(b);
+        }
+    }
+    return count;
+}
+
+__device__ bool interx_check(const lds_d2* sh2, int V, const lds_d2* soup, int so, int M_k, int ho, int Hk, int lo, int Ml, lds_u32* cand, int lane) {
+    if (V < 2) return false;
+    int count = 0;
+    count = interx_pass1(sh2, 0, V, soup, so, M_k, cand, count, lane);
+    if (Hk > 0) count = interx_pass1(sh2, 0, V, soup, ho, Hk, cand, count, lane);
+    count = interx_pass1(sh2, 1, V, soup, lo, Ml, cand, count, lane);
+    if (count == 0) return false;
+    __builtin_amdgcn_wave_barrier();
+    for (int base = 0; base < count; base += PDMPC_WAVE) {
+        const int t = base + lane;
+        bool hit = false;
+        if (t < count) {
+            const uint32_t e = cand[t];
+            const int j = (int)(e & 0xffffu);
+            const uint32_t bits = (e >> 16) & 0xffu;
+            const lds_d2* sh = sh2 + (e >> 24) * PDMPC_VMAX;
+            const d2 q0 = soup[j], q1 = soup[j + 1];
+            for (int i = 0; i < V - 1; ++i) {
+                if ((bits >> i) & 1u) {
+                    const d2 p0 = sh[i], p1 = sh[i + 1];
+                    const double dx1 = p1.x - p0.x, dy1 = p1.y - p0.y;
+                    const double S1 = dx1 * p0.y - dy1 * p0.x;
+                    const double a0 = dx1 * q0.y - dy1 * q0.x;
+                    const double a1 = dx1 * q1.y - dy1 * q1.x;
+                    hit = hit || ((a0 - S1) * (a1 - S1) < 0);
+                }
+            }
+        }
+        if (wave_any(hit)) return true;
+    }
+    return false;
+}
+
+// intersect_sat.m:1-42 for shape (V1 points) vs one polygon o (V2 points): one lane per separating axis.
+// An axis separates iff min1 - max2 > 0 or min2 - max1 > 0 (:33-40); a zero-length edge gives a NaN axis whose
+// comparisons are false.  collide <=> no axis of either polygon separates.
+__device__ bool sat_pair_wave(const lds_d2* sh, int V1, const lds_d2* o, int V2, int lane) {
+    const int A = V1 + V2;
+    for (int base = 0; base < A; base += PDMPC_WAVE) {
+        const int a = base + lane;
+        bool sep = false;
+        if (a < A) {
+            d2 e0, e1;
+            if (a < V1) {
+                e0 = sh[a];
+                e1 = sh[(a + 1 == V1) ? 0 : a + 1];
+            } else {
+                const int b = a - V1;
+                e0 = o[b];
+                e1 = o[(b + 1 == V2) ? 0 : b + 1];
+            }
+            const double ex = e1.x - e0.x, ey = e1.y - e0.y;
+            const double ax = -ey, ay = ex;
+            const double nrm = sqrt(ax * ax + ay * ay);
+            const double nx = ax / nrm, ny = ay / nrm;
+            double minS = 0, maxS = 0, minO = 0, maxO = 0;
+            for (int v = 0; v < V1; ++v) {
+                const d2 p = sh[v];
+                const double d = nx * p.x + ny * p.y;
+                if (v == 0) {
+                    minS = d;
+                    maxS = d;
+                } else {
+                    minS = (d < minS) ? d : minS;
+                    maxS = (d > maxS) ? d : maxS;
+                }
+            }
+            for (int v = 0; v < V2; ++v) {
+                const d2 p = o[v];
+                const double d = nx * p.x + ny * p.y;
+                if (v == 0) {
+                    minO = d;
+                    maxO = d;
+                } else {
+                    minO = (d < minO) ? d : minO;
+                    maxO = (d > maxO) ? d : maxO;
+                }
+            }
+            sep = (minS - maxO > 0) || (minO - maxS > 0);
+        }
+        if (wave_any(sep)) return false;
+    }
+    return true;
+}
+
+// are_constraints_satisfied_sat.m:15-35: every polygon of the step's soup (static then dynamic obstacles).
+__device__ bool sat_soup_wave(const lds_d2* sh, int V1, const lds_d2* soup, int M, int lane) {
+    int pos = 0;
+    while (pos < M) {
+        int end = M;  // next NaN separator at or after pos
+        for (int base = pos; base < M; base += PDMPC_WAVE) {
+            const int j = base + lane;
+            const bool sepr = (j < M) && is_nan(soup[j].x);
+            const unsigned long long b = __ballot(sepr);
+            if (b) {
+                end = base + (int)__builtin_ctzll(b);
+                break;
+            }
+        }
+        const int V2 = end - pos;
+        if (V2 > 0 && sat_pair_wave(sh, V1, soup + pos, V2, lane)) return true;
+        pos = end + 1;
+    }
+    return false;
+}
+
+// intersect_lanelet_boundary.m:1-56 on the soup [left, NaN, right, NaN]: one lane per boundary segment,
+// AABB pre-filter (:20,40) then intersect_sat(shape, segment) with the segment as a 2-point polygon.
+__device__ bool sat_boundary_wave(const lds_d2* sh, int V1, const lds_d2* ll, int M, int lane) {
+    if (M < 2) return false;
+    double max_x = sh[0].x, min_x = sh[0].x, max_y = sh[0].y, min_y = sh[0].y;
+    for (int v = 1; v < V1; ++v) {
+        const d2 p = sh[v];
+        max_x = (p.x > max_x) ? p.x : max_x;
+        min_x = (p.x < min_x) ? p.x : min_x;
+        max_y = (p.y > max_y) ? p.y : max_y;
+        min_y = (p.y < min_y) ? p.y : min_y;
+    }
+    for (int base = 0; base < M - 1; base += PDMPC_WAVE) {
+        const int j = base + lane;
+        bool hit = false;
+        if (j < M - 1) {
+            const d2 q0 = ll[j], q1 = ll[j + 1];
+            const bool real = !(is_nan(q0.x) || is_nan(q1.x));
+            const bool reject = (max_x < q0.x && max_x < q1.x) || (min_x > q0.x && min_x > q1.x) ||
+                                (max_y < q0.y && max_y < q1.y) || (min_y > q0.y && min_y > q1.y);
+            if (real && !reject) {
+                bool sep = false;
+                const int A = V1 + 2;
+                for (int a = 0; a < A; ++a) {
+                    d2 e0, e1;
+                    if (a < V1) {
+                        e0 = sh[a];
+                        e1 = sh[(a + 1 == V1) ? 0 : a + 1];
+                    } else if (a == V1) {
+                        e0 = q0;
+                        e1 = q1;
+                    } else {
+                        e0 = q1;
+                        e1 = q0;
+                    }
+                    const double ex = e1.x - e0.x, ey = e1.y - e0.y;
+                    const double ax = -ey, ay = ex;
+                    const double nrm = sqrt(ax * ax + ay * ay);
+                    const double nx = ax / nrm, ny = ay / nrm;
+                    double minS = 0, maxS = 0;
+                    for (int v = 0; v < V1; ++v) {
+                        const d2 p = sh[v];
+                        const double d = nx * p.x + ny * p.y;
+                        if (v == 0) {
+                            minS = d;
+                            maxS = d;
+                        } else {
+                            minS = (d < minS) ? d : minS;
+                            maxS = (d > maxS) ? d : maxS;
+                        }
+                    }
+                    const double d0 = nx * q0.x + ny * q0.y;
+                    const double d1 = nx * q1.x + ny * q1.y;
+                    const double minO = (d1 < d0) ? d1 : d0;
+                    const double maxO = (d1 > d0) ? d1 : d0;
+                    sep = sep || (minS - maxO > 0) || (minO - maxS > 0);
+                }
+                hit = !sep;
+            }
+        }
+        if (wave_any(hit)) return true;
+    }
+    return false;
+}
+
+// read-only view of what an edge check needs (shared by the sequencing wave and the helper waves)
+struct CheckCtx {
+    const lds_d2* l_area;
+    const d2* g_area;
+    const lds_d2* l_soup;
+    const lds_i32* l_soff;
+    const lds_i32* l_hoff;
+    int areas_in_lds, ll_base, ll_len, Hp, checker;
+    lds_d2* sh;     // this wave's shape scratch: A in [0, VMAX), B in [VMAX, 2 VMAX)
+    lds_u32* cand;  // this wave's candidate list
+};
+
+// eval_edge_exact (GraphSearch.m:111-196) for node `id` (1-based): true = collision-free.  A pure function of the
+// tree and the obstacle soups, which is what allows helper waves to evaluate it ahead of the pop.
+template <int CHECKER>
+__device__ bool edge_valid(const Search& S, const CheckCtx& C, uint32_t id, int lane) {
+    const NodeRec cn = node_load(S, id - 1);
+    const uint32_t par = uni_u(cn.parent);
+    if (!par) return true;  // root: no edge (GraphSearch.m:137-139)
+    const uint32_t cpk = uni_u(cn.packed);
+    const int cK = NODE_K(cpk);
+    const NodeRec pn = node_load(S, par - 1);
+    const double pX = pn.x, pY = pn.y;
+    const double c = pn.cs, s = pn.sn;  // cos/sin(pYaw), cached when the parent was expanded
+    const int m = NODE_MAN(cpk);
+    const int ncols = NODE_COLS(cpk);
+    if (lane < ncols) {
+        const size_t ai = (size_t)m * 3 * PDMPC_VMAX + lane;
+        const size_t bi = ai + (size_t)((cK == C.Hp) ? 2 : 1) * PDMPC_VMAX;  // large offset at k == Hp, else without offset
+        d2 a, b;
+        if (C.areas_in_lds) {
+            a = C.l_area[ai];
+            b = C.l_area[bi];
+        } else {
+            a = C.g_area[ai];
+            b = C.g_area[bi];
+        }
+        d2 sa, sb;
+        sa.x = c * a.x - s * a.y + pX;  // GraphSearch.m:158
+        sa.y = s * a.x + c * a.y + pY;  // :159
+        sb.x = c * b.x - s * b.y + pX;  // :162 / :168
+        sb.y = s * b.x + c * b.y + pY;  // :163 / :169
+        C.sh[lane] = sa;
+        C.sh[PDMPC_VMAX + lane] = sb;
+    }
+    wave_sync();
+    const int so = uni_i(C.l_soff[cK - 1]);
+    const int M_k = uni_i(C.l_soff[cK]) - so;
+    bool hit;
+    if (CHECKER == PDMPC_CHECK_INTERX) {
+        const int ho = uni_i(C.l_hoff[cK - 1]);
+        const int Hk = uni_i(C.l_hoff[cK]) - ho;
+        hit = interx_check(C.sh, ncols, C.l_soup, so, M_k, ho, Hk, C.ll_base, C.ll_len, C.cand, lane);
+    } else {
+        // are_constraints_satisfied_sat.m:15-53
+        hit = sat_soup_wave(C.sh, ncols, C.l_soup + so, M_k, lane);
+        if (!hit) hit = sat_boundary_wave(C.sh + PDMPC_VMAX, ncols, C.l_soup + C.ll_base, C.ll_len, lane);
+    }
+    wave_sync();
+    return !hit;
+}

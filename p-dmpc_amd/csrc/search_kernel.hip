@@ -60,589 +60,12 @@
 
 namespace {
 
-typedef double d2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ uint32_t uni_u(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-__device__ __forceinline__ double uni_d(double v) {
-    uint64_t u = (uint64_t)__double_as_longlong(v);
-    uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
-    uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
-    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
-}
-__device__ __forceinline__ double lane_d(double v, int lane_uniform) {
-    uint64_t u = (uint64_t)__double_as_longlong(v);
-    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, lane_uniform);
-    uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), lane_uniform);
-    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
-}
-__device__ __forceinline__ uint32_t lane_u(uint32_t v, int lane_uniform) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane_uniform); }
-__device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
-__device__ __forceinline__ bool is_nan(double v) { return v != v; }
-
-// ---------------------------------------------------------------------------------------------------
-// LDS pointers carry their address space in the type so every access is a ds_* instruction (a generic pointer that
-// may be LDS or HBM compiles to slower flat_* accesses).
-#define LDS_AS __attribute__((address_space(3)))
-typedef LDS_AS d2 lds_d2;
-typedef LDS_AS double lds_f64;
-typedef LDS_AS uint32_t lds_u32;
-typedef LDS_AS int32_t lds_i32;
-typedef LDS_AS int16_t lds_i16;
-typedef LDS_AS uint8_t lds_u8;
-typedef LDS_AS uint64_t lds_mask64;
-typedef LDS_AS DevManPose lds_pose;
-
-// per-lane constants of the sift-down rounds (computed once per kernel)
-struct PopLane {
-    int d;                       // level below the hole: 1..5 (6 for the unused lanes 62, 63)
-    uint32_t q;                  // position inside the level
-    unsigned long long ancmask;  // bits (node index n = lane + 2, heap order, hole = node 1) of the node and its ancestors
-};
-__device__ __forceinline__ PopLane make_pop_lane(int lane) {
-    PopLane L;
-    L.d = 31 - __builtin_clz((uint32_t)lane + 2u);
-    L.q = (uint32_t)lane + 2u - (1u << L.d);
-    unsigned long long m = 0;
-    for (uint32_t a = (uint32_t)lane + 2u; a >= 2u; a >>= 1) m |= 1ull << a;
-    L.ancmask = (lane < 62) ? m : ~0ull;  // lanes 62, 63 never match
-    return L;
-}
-
-// Per-vehicle search state.  l* point into LDS, g* into this vehicle's HBM slices.
-struct Search {
-    lds_d2* ln;  // NodeRec[NL] as 4 x double2 each
-    NodeRec* gn;
-    uint32_t NL, max_nodes;
-    lds_f64* lkey;
-    lds_u32* lid;
-    double* gkey;
-    uint32_t* gid;
-    uint32_t HL;
-    uint32_t heap_len;
-    int lane;
-    PopLane pl;
-    PROF_MEMBERS
-};
-
-union NodeBits {
-    NodeRec r;
-    d2 q[4];
-    __device__ NodeBits() {}
-};
-
-__device__ __forceinline__ NodeRec node_load(const Search& S, uint32_t i0) {
-    NodeBits u;
-    if (i0 < S.NL) {
-        lds_d2* p = S.ln + 4 * (size_t)i0;
-        u.q[0] = p[0];
-        u.q[1] = p[1];
-        u.q[2] = p[2];
-        u.q[3] = p[3];
-    } else {
-        const d2* p = (const d2*)(S.gn + i0);
-        u.q[0] = p[0];
-        u.q[1] = p[1];
-        u.q[2] = p[2];
-        u.q[3] = p[3];
-    }
-    return u.r;
-}
-__device__ __forceinline__ void node_store(const Search& S, uint32_t i0, const NodeRec& r) {
-    NodeBits u;
-    u.r = r;
-    d2* g = (d2*)(S.gn + i0);
-    g[0] = u.q[0];
-    g[1] = u.q[1];
-    g[2] = u.q[2];
-    g[3] = u.q[3];
-    if (i0 < S.NL) {
-        lds_d2* p = S.ln + 4 * (size_t)i0;
-        p[0] = u.q[0];
-        p[1] = u.q[1];
-        p[2] = u.q[2];
-        p[3] = u.q[3];
-    }
-}
-__device__ __forceinline__ void node_store_cs(const Search& S, uint32_t i0, double cs, double sn) {
-    d2 v;
-    v.x = cs;
-    v.y = sn;
-    ((d2*)(S.gn + i0))[2] = v;
-    if (i0 < S.NL) S.ln[4 * (size_t)i0 + 2] = v;
-}
-// flag the node as popped-with-a-valid-edge (only the sequencing wave writes node records after creation)
-__device__ __forceinline__ void node_mark_popped(const Search& S, uint32_t i0, uint32_t packed) {
-    const uint32_t v = packed | NODE_POPPED_BIT;
-    ((uint32_t*)(S.gn + i0))[15] = v;
-    if (i0 < S.NL) ((lds_u32*)(S.ln + 4 * (size_t)i0))[15] = v;
-}
-__device__ __forceinline__ uint32_t node_parent(const Search& S, uint32_t i0) {
-    d2 v;
-    if (i0 < S.NL)
-        v = S.ln[4 * (size_t)i0 + 3];
-    else
-        v = ((const d2*)(S.gn + i0))[3];
-    return (uint32_t)((uint64_t)__double_as_longlong(v.y) & 0xffffffffull);
-}
-
-// per-lane heap access (index may differ per lane).  LDSONLY: the caller knows every index is < HL.  Otherwise the
-// LDS part and the HBM part are two separately predicated accesses (no generic pointers).
-template <bool LDSONLY>
-__device__ __forceinline__ void heap_load(const Search& S, uint32_t idx, bool valid, double& k, uint32_t& id) {
-    k = 0.0;
-    id = 0;
-    if (LDSONLY) {
-        if (valid) {
-            k = S.lkey[idx];
-            id = S.lid[idx];
-        }
-    } else {
-        const bool inl = valid && idx < S.HL;
-        const bool ing = valid && idx >= S.HL;
-        if (inl) {
-            k = S.lkey[idx];
-            id = S.lid[idx];
-        }
-        if (ing) {
-            // spilled entries: L1-bypassing (sc1) loads, so an entry this wave stored a moment ago is read from L2, where
-            // the wave's in-order write-through store has already landed; no fence / store drain needed between heap phases
-            k = __hip_atomic_load(S.gkey + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            id = __hip_atomic_load(S.gid + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-template <bool LDSONLY>
-__device__ __forceinline__ void heap_store(const Search& S, uint32_t idx, double k, uint32_t id) {
-    if (LDSONLY || idx < S.HL) {
-        S.lkey[idx] = k;
-        S.lid[idx] = id;
-    } else {
-        S.gkey[idx] = k;
-        S.gid[idx] = id;
-    }
-}
-// order one phase's heap writes before the next phase's reads (LDS: in-order DS queue per wave; HBM spill:
-// same-CU L1, needs the stores drained)
-template <bool LDSONLY>
-__device__ __forceinline__ void heap_fence() {
-    if (!LDSONLY) __threadfence_block();  // measured: free next to the L2 round trips of the spilled levels
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // compiler ordering only
-    __builtin_amdgcn_wave_barrier();
-}
-
-// neighbour lane's value (lane ^ 1) through DPP quad_perm [1,0,3,2]: no LDS round trip
-__device__ __forceinline__ double swap_pair_d(double v) {
-    const uint64_t u = (uint64_t)__double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, 0xB1, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), 0xB1, 0xf, 0xf, true);
-    return __longlong_as_double((long long)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo));
-}
-
-// libstdc++ __push_heap(first, hole, top = 0, value) with comp(a, b) = a.key > b.key
-// (priority_queue_interface_mex.cpp:23-29): the value climbs while the parent's key is
-// STRICTLY greater.  Lane t fetches ancestor t of the hole; a ballot finds the first ancestor that stays.
-template <bool LDSONLY>
-__device__ __forceinline__ void heap_sift_up(Search& S, uint32_t hole, double key, uint32_t id) {
-    const uint32_t h1 = hole + 1;
-    const int nlev = 31 - __builtin_clz(h1);  // number of ancestors, <= 17 for a 128k heap
-    const int lane = S.lane;
-    const bool valid = lane < nlev;
-    const uint32_t anc = valid ? ((h1 >> (lane + 1)) - 1u) : 0u;
-    double k;
-    uint32_t i;
-    heap_load<LDSONLY>(S, anc, valid, k, i);
-    const bool gt = valid && (k > key);
-    const unsigned long long b = __ballot(gt);
-    const int cnt = (~b == 0ull) ? 64 : (int)__builtin_ctzll(~b);  // ancestors that move down one level
-    if (lane < cnt) heap_store<LDSONLY>(S, (h1 >> lane) - 1u, k, i);
-    if (lane == 0) heap_store<LDSONLY>(S, (h1 >> cnt) - 1u, key, id);
-}
-
-__device__ __forceinline__ void heap_push(Search& S, uint32_t id, double key) {
-    const uint32_t hole = S.heap_len;
-    S.heap_len = hole + 1;
-    if (hole < S.HL) {
-        heap_sift_up<true>(S, hole, key, id);
-        heap_fence<true>();
-    } else {
-        heap_sift_up<false>(S, hole, key, id);
-        heap_fence<false>();
-    }
-}
-
-// std::pop_heap + pop_back: libstdc++ __pop_heap -> __adjust_heap(first, 0, len, value) -> __push_heap.
-// The hole always sinks to a leaf, choosing the right child unless key[right] > key[left].  Each round fetches the
-// five levels below the hole (2 + 4 + 8 + 16 + 32 = 62 entries, lane l holds sub-tree node l + 2 in heap order, so
-// siblings are lanes l ^ 1 and the children of lane l are lanes 2l + 2, 2l + 3).  Every lane decides whether it is
-// the child its parent would step to; a ballot + five scalar steps follow the chain from the hole; the lanes on
-// the chain store their entry one level up in one instruction.
-// one round of the sift-down: returns the new hole
-template <bool LDSONLY>
-__device__ __forceinline__ uint32_t heap_pop_round(Search& S, uint32_t hole, uint32_t half, const PopLane& L, double& moved_key) {
-    const uint32_t idx = ((hole + 1u) << L.d) - 1u + L.q;
-    const uint32_t pidx = (idx - 1u) >> 1;
-    const bool step_ok = pidx < half;  // the parent has two children (adjust_heap loop condition)
-    double k;
-    uint32_t i;
-    heap_load<LDSONLY>(S, idx, step_ok, k, i);
-    const double ks = swap_pair_d(k);  // sibling's key
-    // right child (odd lane) is stepped to unless key[right] > key[left]; left child (even lane) iff key[right] > key[left]
-    const unsigned long long gt_self = __ballot(k > ks);   // on an odd lane: key[right] > key[left]
-    const unsigned long long gt_sib = __ballot(ks > k);    // on an even lane: key[right] > key[left]
-    const unsigned long long ODD = 0xAAAAAAAAAAAAAAAAull;
-    const unsigned long long pref = ((~gt_self) & ODD) | (gt_sib & ~ODD);
-    // bit n of Q: sub-tree node n (= lane + 2) is the child its parent steps to
-    const unsigned long long Q = (pref & __ballot(step_ok)) << 2;
-    const bool on = (Q & L.ancmask) == L.ancmask;  // the node and all its ancestors are stepped to: it is on the chain
-    const unsigned long long pathmask = __ballot(on);
-    if (on) heap_store<LDSONLY>(S, pidx, k, i);
-    const int last = 63 - (int)__builtin_clzll(pathmask);  // deepest chain lane (the chain is never empty: hole < half)
-    moved_key = lane_d(k, last);  // the entry that now sits in the parent of the new hole
-    return lane_u(idx, last);
-}
-
-template <bool LDSONLY>
-__device__ __forceinline__ void heap_pop_impl(Search& S, uint32_t len) {
-    const int lane = S.lane;
-    double vkey;
-    uint32_t vid;
-    heap_load<LDSONLY>(S, len, true, vkey, vid);
-    const uint32_t half = (len - 1) >> 1;
-    uint32_t hole = 0;
-    double parent_key = 0.0;  // key of the entry that moved into the parent of the current hole
-    while (hole < half) {
-        // the five levels below `hole` end at index 32 * (hole + 1) + 30
-        if (LDSONLY || ((hole + 1u) << 5) + 30u < S.HL)
-            hole = heap_pop_round<true>(S, hole, half, S.pl, parent_key);
-        else
-            hole = heap_pop_round<false>(S, hole, half, S.pl, parent_key);
-    }
-    if ((len & 1u) == 0 && hole == ((len - 2u) >> 1)) {  // lone left child at the bottom
-        const uint32_t child = 2u * (hole + 1u);
-        double ck;
-        uint32_t cid;
-        heap_load<LDSONLY>(S, child - 1u, true, ck, cid);
-        if (lane == 0) heap_store<LDSONLY>(S, hole, ck, cid);
-        parent_key = uni_d(ck);
-        hole = child - 1u;
-    }
-    vkey = uni_d(vkey);
-    vid = uni_u(vid);
-    // __push_heap(first, hole, 0, value): the value climbs only while parent.key > value.key; the parent of the hole holds
-    // the entry that just moved up, whose key is still in a register -> the common "stays put" case needs no memory read
-    if (hole == 0 || !(parent_key > vkey)) {
-        if (lane == 0) heap_store<LDSONLY>(S, hole, vkey, vid);
-        heap_fence<LDSONLY>();
-        return;
-    }
-    heap_fence<LDSONLY>();
-    heap_sift_up<LDSONLY>(S, hole, vkey, vid);
-    heap_fence<LDSONLY>();
-}
-
-__device__ __forceinline__ void heap_pop(Search& S) {
-    const uint32_t len = S.heap_len - 1;  // length after the pop
-    S.heap_len = len;
-    if (len == 0) return;
-    if (len < S.HL)
-        heap_pop_impl<true>(S, len);
-    else
-        heap_pop_impl<false>(S, len);
-}
-
+#include "wave_primitives.hpp"
+#include "search_state.hpp"
+#include "heap_queue.hpp"
 #include "blockmin_queue.hpp"
+#include "edge_checks.hpp"
 
-
-// ---------------------------------------------------------------------------------------------------
-// are_constraints_satisfied_interx.m:17-37 + InterX.m:63-76,108-110.
-// The three soups (vehicle obstacles of step k -> shape A, HDV sets of step k -> shape A, lanelet boundary ->
-// boundary-check shape B) are processed together.  hit(i, j) = C1(i, j) & C2(i, j) with
-//   C1 = (dx1_i*y2_j - dy1_i*x2_j - S1_i) * (dx1_i*y2_{j+1} - dy1_i*x2_{j+1} - S1_i) < 0
-//   C2 = (y1_i*dx2_j - x1_i*dy2_j - S2_j) * (y1_{i+1}*dx2_j - x1_{i+1}*dy2_j - S2_j) < 0     (strict; NaN -> false)
-// Pass 1 (one lane per obstacle segment j) evaluates C2 for every shape segment i and keeps a 7-bit mask; lanes with
-// a non-zero mask append (j, mask, shape) to a compact list.  Pass 2 evaluates C1 for the listed pairs only.
-// Pass 1 over one soup range: sh2 holds shape A in [0, VMAX) and shape B in [VMAX, 2*VMAX).
-__device__ __forceinline__ int interx_pass1(const lds_d2* sh2, int shapeB, int V, const lds_d2* soup, int start, int M, lds_u32* cand, int count, int lane) {
-    if (M < 2) return count;
-    const lds_d2* L2 = soup + start;
-    const lds_d2* sh = sh2 + shapeB * PDMPC_VMAX;
-    for (int base = 0; base < M - 1; base += PDMPC_WAVE) {
-        const int j = base + lane;
-        uint32_t bits = 0;
-        if (j < M - 1) {
-            const d2 q0 = L2[j], q1 = L2[j + 1];
-            const double dx2 = q1.x - q0.x, dy2 = q1.y - q0.y;
-            const double S2 = dx2 * q0.y - dy2 * q0.x;
-            d2 p = sh[0];
-            double e0 = (p.y * dx2 - p.x * dy2) - S2;
-            for (int i = 0; i < V - 1; ++i) {
-                p = sh[i + 1];
-                const double e1 = (p.y * dx2 - p.x * dy2) - S2;
-                if (e0 * e1 < 0) bits |= 1u << i;
-                e0 = e1;
-            }
-        }
-        const unsigned long long b = __ballot(bits != 0);
-        if (b) {
-            if (bits) {
-                const int pos = count + (int)__builtin_popcountll(b & ((1ull << lane) - 1ull));
-                cand[pos] = (uint32_t)(start + j) | (bits << 16) | ((uint32_t)shapeB << 24);
-            }
-            count += (int)__builtin_popcountll(b);
-        }
-    }
-    return count;
-}
-
-__device__ bool interx_check(const lds_d2* sh2, int V, const lds_d2* soup, int so, int M_k, int ho, int Hk, int lo, int Ml, lds_u32* cand, int lane) {
-    if (V < 2) return false;
-    int count = 0;
-    count = interx_pass1(sh2, 0, V, soup, so, M_k, cand, count, lane);
-    if (Hk > 0) count = interx_pass1(sh2, 0, V, soup, ho, Hk, cand, count, lane);
-    count = interx_pass1(sh2, 1, V, soup, lo, Ml, cand, count, lane);
-    if (count == 0) return false;
-    __builtin_amdgcn_wave_barrier();
-    for (int base = 0; base < count; base += PDMPC_WAVE) {
-        const int t = base + lane;
-        bool hit = false;
-        if (t < count) {
-            const uint32_t e = cand[t];
-            const int j = (int)(e & 0xffffu);
-            const uint32_t bits = (e >> 16) & 0xffu;
-            const lds_d2* sh = sh2 + (e >> 24) * PDMPC_VMAX;
-            const d2 q0 = soup[j], q1 = soup[j + 1];
-            for (int i = 0; i < V - 1; ++i) {
-                if ((bits >> i) & 1u) {
-                    const d2 p0 = sh[i], p1 = sh[i + 1];
-                    const double dx1 = p1.x - p0.x, dy1 = p1.y - p0.y;
-                    const double S1 = dx1 * p0.y - dy1 * p0.x;
-                    const double a0 = dx1 * q0.y - dy1 * q0.x;
-                    const double a1 = dx1 * q1.y - dy1 * q1.x;
-                    hit = hit || ((a0 - S1) * (a1 - S1) < 0);
-                }
-            }
-        }
-        if (wave_any(hit)) return true;
-    }
-    return false;
-}
-
-// intersect_sat.m:1-42 for shape (V1 points) vs one polygon o (V2 points): one lane per separating axis.
-// An axis separates iff min1 - max2 > 0 or min2 - max1 > 0 (:33-40); a zero-length edge gives a NaN axis whose
-// comparisons are false.  collide <=> no axis of either polygon separates.
-__device__ bool sat_pair_wave(const lds_d2* sh, int V1, const lds_d2* o, int V2, int lane) {
-    const int A = V1 + V2;
-    for (int base = 0; base < A; base += PDMPC_WAVE) {
-        const int a = base + lane;
-        bool sep = false;
-        if (a < A) {
-            d2 e0, e1;
-            if (a < V1) {
-                e0 = sh[a];
-                e1 = sh[(a + 1 == V1) ? 0 : a + 1];
-            } else {
-                const int b = a - V1;
-                e0 = o[b];
-                e1 = o[(b + 1 == V2) ? 0 : b + 1];
-            }
-            const double ex = e1.x - e0.x, ey = e1.y - e0.y;
-            const double ax = -ey, ay = ex;
-            const double nrm = sqrt(ax * ax + ay * ay);
-            const double nx = ax / nrm, ny = ay / nrm;
-            double minS = 0, maxS = 0, minO = 0, maxO = 0;
-            for (int v = 0; v < V1; ++v) {
-                const d2 p = sh[v];
-                const double d = nx * p.x + ny * p.y;
-                if (v == 0) {
-                    minS = d;
-                    maxS = d;
-                } else {
-                    minS = (d < minS) ? d : minS;
-                    maxS = (d > maxS) ? d : maxS;
-                }
-            }
-            for (int v = 0; v < V2; ++v) {
-                const d2 p = o[v];
-                const double d = nx * p.x + ny * p.y;
-                if (v == 0) {
-                    minO = d;
-                    maxO = d;
-                } else {
-                    minO = (d < minO) ? d : minO;
-                    maxO = (d > maxO) ? d : maxO;
-                }
-            }
-            sep = (minS - maxO > 0) || (minO - maxS > 0);
-        }
-        if (wave_any(sep)) return false;
-    }
-    return true;
-}
-
-// are_constraints_satisfied_sat.m:15-35: every polygon of the step's soup (static then dynamic obstacles).
-__device__ bool sat_soup_wave(const lds_d2* sh, int V1, const lds_d2* soup, int M, int lane) {
-    int pos = 0;
-    while (pos < M) {
-        int end = M;  // next NaN separator at or after pos
-        for (int base = pos; base < M; base += PDMPC_WAVE) {
-            const int j = base + lane;
-            const bool sepr = (j < M) && is_nan(soup[j].x);
-            const unsigned long long b = __ballot(sepr);
-            if (b) {
-                end = base + (int)__builtin_ctzll(b);
-                break;
-            }
-        }
-        const int V2 = end - pos;
-        if (V2 > 0 && sat_pair_wave(sh, V1, soup + pos, V2, lane)) return true;
-        pos = end + 1;
-    }
-    return false;
-}
-
-// intersect_lanelet_boundary.m:1-56 on the soup [left, NaN, right, NaN]: one lane per boundary segment,
-// AABB pre-filter (:20,40) then intersect_sat(shape, segment) with the segment as a 2-point polygon.
-__device__ bool sat_boundary_wave(const lds_d2* sh, int V1, const lds_d2* ll, int M, int lane) {
-    if (M < 2) return false;
-    double max_x = sh[0].x, min_x = sh[0].x, max_y = sh[0].y, min_y = sh[0].y;
-    for (int v = 1; v < V1; ++v) {
-        const d2 p = sh[v];
-        max_x = (p.x > max_x) ? p.x : max_x;
-        min_x = (p.x < min_x) ? p.x : min_x;
-        max_y = (p.y > max_y) ? p.y : max_y;
-        min_y = (p.y < min_y) ? p.y : min_y;
-    }
-    for (int base = 0; base < M - 1; base += PDMPC_WAVE) {
-        const int j = base + lane;
-        bool hit = false;
-        if (j < M - 1) {
-            const d2 q0 = ll[j], q1 = ll[j + 1];
-            const bool real = !(is_nan(q0.x) || is_nan(q1.x));
-            const bool reject = (max_x < q0.x && max_x < q1.x) || (min_x > q0.x && min_x > q1.x) ||
-                                (max_y < q0.y && max_y < q1.y) || (min_y > q0.y && min_y > q1.y);
-            if (real && !reject) {
-                bool sep = false;
-                const int A = V1 + 2;
-                for (int a = 0; a < A; ++a) {
-                    d2 e0, e1;
-                    if (a < V1) {
-                        e0 = sh[a];
-                        e1 = sh[(a + 1 == V1) ? 0 : a + 1];
-                    } else if (a == V1) {
-                        e0 = q0;
-                        e1 = q1;
-                    } else {
-                        e0 = q1;
-                        e1 = q0;
-                    }
-                    const double ex = e1.x - e0.x, ey = e1.y - e0.y;
-                    const double ax = -ey, ay = ex;
-                    const double nrm = sqrt(ax * ax + ay * ay);
-                    const double nx = ax / nrm, ny = ay / nrm;
-                    double minS = 0, maxS = 0;
-                    for (int v = 0; v < V1; ++v) {
-                        const d2 p = sh[v];
-                        const double d = nx * p.x + ny * p.y;
-                        if (v == 0) {
-                            minS = d;
-                            maxS = d;
-                        } else {
-                            minS = (d < minS) ? d : minS;
-                            maxS = (d > maxS) ? d : maxS;
-                        }
-                    }
-                    const double d0 = nx * q0.x + ny * q0.y;
-                    const double d1 = nx * q1.x + ny * q1.y;
-                    const double minO = (d1 < d0) ? d1 : d0;
-                    const double maxO = (d1 > d0) ? d1 : d0;
-                    sep = sep || (minS - maxO > 0) || (minO - maxS > 0);
-                }
-                hit = !sep;
-            }
-        }
-        if (wave_any(hit)) return true;
-    }
-    return false;
-}
-
-// copy `count` 16-byte elements HBM -> LDS, thread-strided over the whole workgroup (coalesced)
-__device__ __forceinline__ void stage16(LDS_AS void* dst_lds, const void* src, int count, int tid) {
-    lds_d2* d = (lds_d2*)dst_lds;
-    const d2* s = (const d2*)src;
-    for (int i = tid; i < count; i += PDMPC_THREADS) d[i] = s[i];
-}
-
-// order this wave's LDS/HBM writes before its later reads (same wave: the hardware keeps DS order; this stops the
-// compiler from moving accesses)
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-// read-only view of what an edge check needs (shared by the sequencing wave and the helper waves)
-struct CheckCtx {
-    const lds_d2* l_area;
-    const d2* g_area;
-    const lds_d2* l_soup;
-    const lds_i32* l_soff;
-    const lds_i32* l_hoff;
-    int areas_in_lds, ll_base, ll_len, Hp, checker;
-    lds_d2* sh;     // this wave's shape scratch: A in [0, VMAX), B in [VMAX, 2 VMAX)
-    lds_u32* cand;  // this wave's candidate list
-};
-
-// eval_edge_exact (GraphSearch.m:111-196) for node `id` (1-based): true = collision-free.  A pure function of the
-// tree and the obstacle soups, which is what allows helper waves to evaluate it ahead of the pop.
-template <int CHECKER>
-__device__ bool edge_valid(const Search& S, const CheckCtx& C, uint32_t id, int lane) {
-    const NodeRec cn = node_load(S, id - 1);
-    const uint32_t par = uni_u(cn.parent);
-    if (!par) return true;  // root: no edge (GraphSearch.m:137-139)
-    const uint32_t cpk = uni_u(cn.packed);
-    const int cK = NODE_K(cpk);
-    const NodeRec pn = node_load(S, par - 1);
-    const double pX = pn.x, pY = pn.y;
-    const double c = pn.cs, s = pn.sn;  // cos/sin(pYaw), cached when the parent was expanded
-    const int m = NODE_MAN(cpk);
-    const int ncols = NODE_COLS(cpk);
-    if (lane < ncols) {
-        const size_t ai = (size_t)m * 3 * PDMPC_VMAX + lane;
-        const size_t bi = ai + (size_t)((cK == C.Hp) ? 2 : 1) * PDMPC_VMAX;  // large offset at k == Hp, else without offset
-        d2 a, b;
-        if (C.areas_in_lds) {
-            a = C.l_area[ai];
-            b = C.l_area[bi];
-        } else {
-            a = C.g_area[ai];
-            b = C.g_area[bi];
-        }
-        d2 sa, sb;
-        sa.x = c * a.x - s * a.y + pX;  // GraphSearch.m:158
-        sa.y = s * a.x + c * a.y + pY;  // :159
-        sb.x = c * b.x - s * b.y + pX;  // :162 / :168
-        sb.y = s * b.x + c * b.y + pY;  // :163 / :169
-        C.sh[lane] = sa;
-        C.sh[PDMPC_VMAX + lane] = sb;
-    }
-    wave_sync();
-    const int so = uni_i(C.l_soff[cK - 1]);
-    const int M_k = uni_i(C.l_soff[cK]) - so;
-    bool hit;
-    if (CHECKER == PDMPC_CHECK_INTERX) {
-        const int ho = uni_i(C.l_hoff[cK - 1]);
-        const int Hk = uni_i(C.l_hoff[cK]) - ho;
-        hit = interx_check(C.sh, ncols, C.l_soup, so, M_k, ho, Hk, C.ll_base, C.ll_len, C.cand, lane);
-    } else {
-        // are_constraints_satisfied_sat.m:15-53
-        hit = sat_soup_wave(C.sh, ncols, C.l_soup + so, M_k, lane);
-        if (!hit) hit = sat_boundary_wave(C.sh + PDMPC_VMAX, ncols, C.l_soup + C.ll_base, C.ll_len, lane);
-    }
-    wave_sync();
-    return !hit;
-}
-
-__device__ __forceinline__ uint32_t lds_load_u32(const volatile lds_u32* p) { return *p; }
 
 #define VS_UNKNOWN 0u
 #define VS_VALID 1u
