@@ -126,13 +126,13 @@ __device__ __forceinline__ bool vs_claim(const VState& v, uint32_t i0) {
 #define SH_CAND_VER 9  // block-min mode: bumped by the scout wave when it rewrote the candidate list
 #define SH_CAND 10     // block-min mode: BM_NCAND node ids proposed for pre-validation, most urgent first (0 = none)
 #define BM_NCAND 6
-#define SH_Q2E_SEQ 16   // block-min mode, queue wave -> expander wave: number of the hand-over ...
+// Mail boxes of the block-min mode: 8-byte words {sequence number, payload} written and read with one LDS access each.
+#define SH_Q2E_SEQ 16   // queue wave -> expander wave: number of the hand-over ...
 #define SH_Q2E_ID 17    // ... and the popped node (1-based id) to evaluate and expand
-#define SH_E2Q_SEQ 18   // expander wave -> queue wave: number of the hand-over this reply answers
-#define SH_E2Q_FLAGS 19 // E2Q_* bits
-#define SH_E2Q_CNT 20   // children created (their keys are in the key ring, their records in the tree)
+#define SH_E2Q_SEQ 18   // expander wave -> queue wave: number of the hand-over this reply answers ...
+#define SH_E2Q_FLAGS 19 // ... E2Q_* bits | children created << 8 (their keys are in the key ring, their records in the tree)
 #define SH_Q_SYNC 21    // set by the queue wave while it is inside arrival_sync (the expander must not enter before: it may owe a reply)
-#define SH_HINT_SEQ 22  // queue wave -> expander wave: the hand-over number SH_HINT_ID will probably be posted under ...
+#define SH_HINT_SEQ 22  // queue wave -> expander wave (mail box): the hand-over number SH_HINT_ID will probably be posted under ...
 #define SH_HINT_ID 23   // ... and the node: the expander may evaluate and expand it ahead of time
 #define SH_WORDS 32
 #define E2Q_VALID 1u     // the edge into the node is collision-free
@@ -148,6 +148,12 @@ namespace {
 __device__ __forceinline__ unsigned long long sh_load64(volatile lds_u32* sh, int lo) {
     return (unsigned long long)sh[lo] | ((unsigned long long)sh[lo + 1] << 32);
 }
+
+// mail box = two consecutive shared words at an even index (8-byte aligned): sequence number in the low half
+__device__ __forceinline__ void mbox_post(volatile lds_u32* sh, int word, uint32_t seq, uint32_t payload) {
+    *(volatile LDS_AS unsigned long long*)(sh + word) = ((unsigned long long)payload << 32) | seq;
+}
+__device__ __forceinline__ unsigned long long mbox_read(volatile lds_u32* sh, int word) { return *(volatile LDS_AS unsigned long long*)(sh + word); }
 
 struct SpecCtx {
     volatile lds_u32* sh;
@@ -268,6 +274,7 @@ __device__ bool arrival_sync(const Search& S, const CheckCtx& C, const SpecCtx& 
             P.sh[SH_NNODES] = 1;
             for (int c = 0; c < BM_NCAND; ++c) P.sh[SH_CAND + c] = 0;
             P.sh[SH_HINT_SEQ] = 0;  // (the hinted node belongs to the tree that is being thrown away)
+            P.sh[SH_HINT_ID] = 0;
             P.sh[SH_VERSION] = P.sh[SH_VERSION] + 1;
             ((uint32_t*)S.gn)[15] &= ~NODE_POPPED_BIT;
             if (S.NL > 0) ((lds_u32*)S.ln)[15] = ((lds_u32*)S.ln)[15] & ~NODE_POPPED_BIT;
@@ -538,6 +545,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
         double ra_key = inf;            // (per lane)
         uint32_t ra_n = 0;
         bool head_in_list = false;  // the last entry is a child that is still in the open list
+        bool head_invalid = false;  // the last entry is known to collide as well (the list is full of colliding entries)
         {
             const BmFound r0 = bm_pop(Q, nn);  // the root
             if (lane == 0) {
@@ -566,6 +574,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                     ra_key = lane == 0 ? r0.key : inf;
                     ra_n = 1;
                     head_in_list = false;
+                    head_invalid = false;
                 }
                 continue;
             }
@@ -592,11 +601,8 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
             PROF_COUNT(7, n_dead)
             PROF_STOP(0)  // loop head
             PROF_TL(seq, 9)
-            if (uni_u(vs_load(VS, cidx)) == VS_INVALID) {  // (the verdict came in after the entry was listed)
-                PROF_STOP(1)  // validity lookup
-                if (head_in_list) bm_remove(Q, cidx, nn);
-                head_in_list = false;
-                PROF_STOP(2)  // remove
+            if (head_invalid) {  // GraphSearch.m:75-77 without leaving this wave (a verdict that comes in after an entry
+                                 // was listed is the expander's business)
                 const BmFound t = bm_pop(Q, nn);
                 if (lane == 0) {
                     ra_idx = t.idx;
@@ -604,6 +610,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                     l_shared[SH_VERSION] = ++ver_ctr;
                 }
                 ra_n = t.idx != 0xFFFFFFFFu ? 1u : 0u;
+                head_invalid = ra_n != 0u && uni_u(vs_load(VS, t.idx)) == VS_INVALID;
                 PROF_STOP(3)  // pop
                 PROF_COUNT(7, 1)
                 continue;
@@ -612,11 +619,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
             ++seq;
             PROF_TL(seq - 1, 10)
             PROF_TL(seq - 1, 0)
-            if (lane == 0) {
-                l_shared[SH_Q2E_ID] = cur;
-                asm volatile("" ::: "memory");  // the LDS executes one wave's accesses in program order
-                l_shared[SH_Q2E_SEQ] = seq;
-            }
+            if (lane == 0) mbox_post(l_shared, SH_Q2E_SEQ, seq, cur);
             if (head_in_list) bm_remove(Q, cidx, nn);
             head_in_list = false;
             PROF_STOP(2)
@@ -631,28 +634,27 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                 ++ra_n;
                 if (uni_u(vs_load(VS, t.idx)) != VS_INVALID) {
                     // most likely the next node to be handed over: the expander may start on it as soon as it is idle
-                    if (lane == 0) {
-                        l_shared[SH_HINT_ID] = t.idx + 1u;
-                        asm volatile("" ::: "memory");
-                        l_shared[SH_HINT_SEQ] = seq + 1u;
-                    }
+                    if (lane == 0) mbox_post(l_shared, SH_HINT_SEQ, seq + 1u, t.idx + 1u);
                     break;
                 }
-                if (ra_n == 8u) break;
+                if (ra_n == 8u) {
+                    head_invalid = true;
+                    break;
+                }
             }
             if (lane == 0) l_shared[SH_VERSION] = ++ver_ctr;
             PROF_STOP(3)
             PROF_TL(seq - 1, 1)
             uint32_t spins = 0;
-            while (lds_load_u32(&l_shared[SH_E2Q_SEQ]) != seq) {
+            unsigned long long reply;
+            while ((uint32_t)(reply = mbox_read(l_shared, SH_E2Q_SEQ)) != seq) {
                 if (A.crowded) __builtin_amdgcn_s_sleep(6);  // leave the issue slots to the waves that have work
                 if (++spins > A.spin_limit) break;  // (cannot happen: the expander always answers)
             }
             PROF_STOP(4)  // waiting for the expander
             PROF_TL(seq - 1, 2)
-            asm volatile("" ::: "memory");
-            const uint32_t flags = lds_load_u32(&l_shared[SH_E2Q_FLAGS]);
-            const uint32_t cnt = lds_load_u32(&l_shared[SH_E2Q_CNT]);
+            const uint32_t flags = (uint32_t)(reply >> 32) & 0xFFu;
+            const uint32_t cnt = (uint32_t)(reply >> 40);
             if (spins > A.spin_limit) {
                 dep_timeout = true;
                 status = PDMPC_EXHAUSTED;
@@ -699,6 +701,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                         }
                         ra_n = pos + 1u;
                         head_in_list = true;
+                        head_invalid = false;
                     }
                 }
                 nn += cnt;
@@ -780,7 +783,8 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
         bool spec_valid = false;
         uint32_t spec_id = 0, spec_flags = 0, spec_cnt = 0, spec_n0 = 0;
         for (;;) {
-            const uint32_t sq = lds_load_u32(&l_shared[SH_Q2E_SEQ]);
+            const unsigned long long post = mbox_read(l_shared, SH_Q2E_SEQ);
+            const uint32_t sq = (uint32_t)post;
             uint32_t cur;
             bool spec = false, answered = false;
             uint32_t flags = 0, cnt = 0;
@@ -788,8 +792,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                 seen = sq;
                 PROF_STOP(8)  // idle
                 PROF_TL(sq - 1, 3)
-                asm volatile("" ::: "memory");
-                cur = lds_load_u32(&l_shared[SH_Q2E_ID]);
+                cur = (uint32_t)(post >> 32);
                 if (spec_valid) {
                     spec_valid = false;
                     if (spec_id == cur) {  // guessed right: the answer is ready
@@ -814,10 +817,9 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                     if (arrival_sync(S, C, P, VS, tid)) nnodes = 1;
                     continue;
                 }
-                if (!spec_valid && A.speculate_expansion && lds_load_u32(&l_shared[SH_HINT_SEQ]) == seen + 1u) {
-                    asm volatile("" ::: "memory");
-                    cur = lds_load_u32(&l_shared[SH_HINT_ID]);
-                    if (lds_load_u32(&l_shared[SH_HINT_SEQ]) != seen + 1u || lds_load_u32(&l_shared[SH_Q2E_SEQ]) != seen) continue;
+                const unsigned long long hint = mbox_read(l_shared, SH_HINT_SEQ);
+                if (!spec_valid && A.speculate_expansion && (uint32_t)hint == seen + 1u) {
+                    cur = (uint32_t)(hint >> 32);
                     spec = true;
                 } else {
                     if (A.crowded) __builtin_amdgcn_s_sleep(6);  // leave the issue slots to the waves that have work
@@ -881,10 +883,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                 continue;
             }
             if (lane == 0) {
-                l_shared[SH_E2Q_FLAGS] = flags;
-                l_shared[SH_E2Q_CNT] = cnt;
-                asm volatile("" ::: "memory");  // the LDS executes one wave's accesses in program order
-                l_shared[SH_E2Q_SEQ] = seen;
+                mbox_post(l_shared, SH_E2Q_SEQ, seen, flags | (cnt << 8));  // (after the key stores of all lanes: LDS order)
                 PROF_TL(seen - 1, 4)
             }
             if (cnt) {
