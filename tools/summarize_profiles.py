@@ -15,7 +15,7 @@ os.makedirs(DST, exist_ok=True)
 
 def find(pattern):
     g = glob.glob(os.path.join(SRC, pattern), recursive=True)
-    return g[0] if g else None
+    return max(g, key=os.path.getmtime) if g else None  # (gpurun merges new output into the old directory: newest wins)
 
 
 summary = {"tag": tag, "command": "python bench.py --steps 200 --warmup 20 --no-cpu-baseline (rocprofv3 --kernel-trace --stats; separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes)"}
