@@ -139,6 +139,7 @@ struct pdmpc_handle {
     DevBuf<int32_t> d_tie_count;
     int queue_mode = PDMPC_QUEUE_BLOCKMIN;
     int speculate_expansion = 1;
+    int n_validators = PDMPC_WAVES_PER_VEHICLE - 3;
     int bm_kr = 0, bm_nb = 0;
     DevBuf<int32_t> d_trace;
     // batch blobs: several packed steps can stay resident side by side ("banks", pdmpc_select_bank)
@@ -430,6 +431,7 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.speculate = h->speculate;
     a.crowded = count > h->n_cu ? 1 : 0;
     a.speculate_expansion = h->speculate_expansion;
+    a.n_validators = h->n_validators;
     a.queue_mode = (h->queue_mode == PDMPC_QUEUE_BLOCKMIN && h->bm_kr != 0) ? PDMPC_QUEUE_BLOCKMIN : PDMPC_QUEUE_HEAP;
     a.bm_kr = h->bm_kr;
     a.bm_nb = h->bm_nb;
@@ -480,6 +482,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
     h->cfg = *config;
     h->banks.resize(1);
     if (const char* e = getenv("PDMPC_SPECULATE")) h->speculate = atoi(e) != 0;  // A/B switch for benchmarking; results are identical
+    if (const char* e = getenv("PDMPC_VALIDATORS")) h->n_validators = std::max(1, atoi(e));  // likewise
     if (const char* e = getenv("PDMPC_SPEC_EXPAND")) h->speculate_expansion = atoi(e) != 0;  // likewise
     if (const char* e = getenv("PDMPC_QUEUE")) h->queue_mode = atoi(e) != 0 ? PDMPC_QUEUE_BLOCKMIN : PDMPC_QUEUE_HEAP;  // likewise
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;

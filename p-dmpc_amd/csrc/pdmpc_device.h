@@ -113,6 +113,7 @@ struct KernelArgs {
     LdsLayout lds;
     int32_t HL, NL, NV, soup_cap, cand_cap;
     int32_t speculate_expansion;       // 1: the expander wave works ahead on the node the queue wave will most likely hand over next
+    int32_t n_validators;              // validator waves that take part (block-min mode; at most PDMPC_WAVES_PER_VEHICLE - 3)
     int32_t crowded;                   // 1: more workgroups than compute units in this launch (idle waves sleep longer between polls)
     int32_t queue_mode, bm_kr, bm_nb;  // PDMPC_QUEUE_*; block-min ring entries (power of two) and block count (multiple of 64)
     int32_t* tie_count;                // [0] searches redone on the binary heap after a tied minimum, [1] speculation restarts, [2] arrivals (cumulative)

@@ -1000,6 +1000,10 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                 (void)arrival_sync(S, C, P, VS, tid);
                 continue;
             }
+            if (wave - 3 >= A.n_validators) {  // (tuning knob: this wave sits the search out)
+                __builtin_amdgcn_s_sleep(32);
+                continue;
+            }
             const uint32_t cver = lds_load_u32(&l_shared[SH_CAND_VER]);
             uint32_t id = 0;
             if (lane < BM_NCAND) id = l_shared[SH_CAND + lane];
