@@ -139,7 +139,9 @@ struct pdmpc_handle {
     DevBuf<int32_t> d_tie_count;
     int queue_mode = PDMPC_QUEUE_BLOCKMIN;
     int speculate_expansion = 1;
-    int n_validators = PDMPC_WAVES_PER_VEHICLE - 3;
+    int waves_latency = PDMPC_WAVES_LATENCY, waves_throughput = PDMPC_WAVES_THROUGHPUT;
+    int n_validators = PDMPC_MAX_WAVES;  // (all there are)
+    int n_waves = PDMPC_WAVES_LATENCY;   // of the last layout
     int bm_kr = 0, bm_nb = 0;
     DevBuf<int32_t> d_trace;
     // batch blobs: several packed steps can stay resident side by side ("banks", pdmpc_select_bank)
@@ -172,12 +174,14 @@ int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in, int cand_cap_in)
     const uint32_t area_bytes = (uint32_t)(h->n_man * 3 * PDMPC_VMAX * 16);
     // fixed part after the tables
     const uint32_t ref_bytes = 3 * PDMPC_HP_MAX * 8;
-    const uint32_t shape_bytes = PDMPC_WAVES_PER_VEHICLE * 2 * PDMPC_VMAX * 16;
+    const int n_waves = (n_launch > h->n_cu) ? h->waves_throughput : h->waves_latency;
+    h->n_waves = n_waves;
+    const uint32_t shape_bytes = (uint32_t)n_waves * 2 * PDMPC_VMAX * 16;
     const uint32_t path_bytes = align16((PDMPC_HP_MAX + 2) * 4 + 2 * (PDMPC_HP_MAX + 1) * 4 + 32 * 4 + PDMPC_HP_MAX * 4);  // ... + SH_WORDS shared words + ...
     const uint32_t soup_bytes = (uint32_t)std::max(hb.soup_cap, 1) * 16;
     const uint32_t expand_bytes = (2 * PDMPC_HP_MAX * PDMPC_HP_MAX) * 8 + 16 * 16;
     const uint32_t fixed_rest = ref_bytes + shape_bytes + path_bytes + soup_bytes + expand_bytes;
-    const uint32_t cand_bytes = align16((uint32_t)std::max(hb.cand_cap, 1) * 4 * PDMPC_WAVES_PER_VEHICLE);
+    const uint32_t cand_bytes = align16((uint32_t)std::max(hb.cand_cap, 1) * 4 * (uint32_t)n_waves);
     const uint32_t min_bytes = 64 * 12 + 64 * (uint32_t)sizeof(NodeRec);
     // The maneuver areas stay in LDS only if the open list still gets a useful share: 32 KB (block-min queue with a
     // 2048-entry key ring for 64 k nodes); otherwise the edge checks read them through L2.
@@ -432,6 +436,7 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.crowded = count > h->n_cu ? 1 : 0;
     a.speculate_expansion = h->speculate_expansion;
     a.n_validators = h->n_validators;
+    a.n_waves = h->n_waves;
     a.queue_mode = (h->queue_mode == PDMPC_QUEUE_BLOCKMIN && h->bm_kr != 0) ? PDMPC_QUEUE_BLOCKMIN : PDMPC_QUEUE_HEAP;
     a.bm_kr = h->bm_kr;
     a.bm_nb = h->bm_nb;
@@ -482,6 +487,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
     h->cfg = *config;
     h->banks.resize(1);
     if (const char* e = getenv("PDMPC_SPECULATE")) h->speculate = atoi(e) != 0;  // A/B switch for benchmarking; results are identical
+    if (const char* e = getenv("PDMPC_WAVES")) h->waves_latency = h->waves_throughput = std::min(PDMPC_MAX_WAVES, std::max(4, atoi(e)));  // likewise
     if (const char* e = getenv("PDMPC_VALIDATORS")) h->n_validators = std::max(1, atoi(e));  // likewise
     if (const char* e = getenv("PDMPC_SPEC_EXPAND")) h->speculate_expansion = atoi(e) != 0;  // likewise
     if (const char* e = getenv("PDMPC_QUEUE")) h->queue_mode = atoi(e) != 0 ? PDMPC_QUEUE_BLOCKMIN : PDMPC_QUEUE_HEAP;  // likewise

@@ -21,10 +21,15 @@
 #include "../../include/pdmpc.h"
 
 #define PDMPC_WAVE 64
-#define PDMPC_WAVES_PER_VEHICLE 8 /* wave 0 sequences the search, the others pre-validate nodes (block-min mode: wave 1 scouts) */
+/* Wavefronts per vehicle (workgroup size / 64), chosen per launch: wave 0 owns the pop order; block-min mode: wave 1 expands,
+ * wave 2 scouts, the others validate; heap mode: all others pre-validate.  More validators shorten the critical vehicle's
+ * search (C2: 5 -> 6.87 ms, 7 -> 6.67 ms, 13 -> 6.64 ms per step) but cost throughput when the chip is full (C5). */
+#define PDMPC_WAVES_LATENCY 12    /* launches with at most one workgroup per CU */
+#define PDMPC_WAVES_THROUGHPUT 8  /* launches with more workgroups than CUs */
+#define PDMPC_MAX_WAVES 16
 #define PDMPC_QUEUE_HEAP 0     /* open list = libstdc++-faithful binary heap (exact for any keys) */
 #define PDMPC_QUEUE_BLOCKMIN 1 /* open list = block-min queue while the minimal key is unique, binary heap after the first tie */
-#define PDMPC_THREADS (PDMPC_WAVE * PDMPC_WAVES_PER_VEHICLE)
+#define PDMPC_MAX_THREADS (PDMPC_WAVE * PDMPC_MAX_WAVES)
 
 struct DevManPose {
     double dx, dy, dyaw;
@@ -113,7 +118,8 @@ struct KernelArgs {
     LdsLayout lds;
     int32_t HL, NL, NV, soup_cap, cand_cap;
     int32_t speculate_expansion;       // 1: the expander wave works ahead on the node the queue wave will most likely hand over next
-    int32_t n_validators;              // validator waves that take part (block-min mode; at most PDMPC_WAVES_PER_VEHICLE - 3)
+    int32_t n_waves;                   // wavefronts per vehicle of this launch (workgroup size / 64)
+    int32_t n_validators;              // validator waves that take part (block-min mode; at most n_waves - 3)
     int32_t crowded;                   // 1: more workgroups than compute units in this launch (idle waves sleep longer between polls)
     int32_t queue_mode, bm_kr, bm_nb;  // PDMPC_QUEUE_*; block-min ring entries (power of two) and block count (multiple of 64)
     int32_t* tie_count;                // [0] searches redone on the binary heap after a tied minimum, [1] speculation restarts, [2] arrivals (cumulative)

@@ -173,7 +173,7 @@ __device__ void incorporate_areas(const SpecCtx& P, unsigned long long arr, int 
         const int p = (int)__builtin_ctzll(arr);
         arr &= arr - 1;
         const pdmpc_vehicle_out* PO = P.out + P.pred[p];
-        for (int idx = tid; idx < P.Hp * PDMPC_VMAX; idx += PDMPC_THREADS) {
+        for (int idx = tid; idx < P.Hp * PDMPC_VMAX; idx += (int)blockDim.x) {
             const int k = idx / PDMPC_VMAX;
             const int v = idx - k * PDMPC_VMAX;
             const int cols = PO->shape_cols[k];
@@ -248,7 +248,7 @@ __device__ bool arrival_sync(const Search& S, const CheckCtx& C, const SpecCtx& 
     const uint32_t nn = P.sh[SH_NNODES];
     incorporate_areas(P, arr, tid);
     __syncthreads();  // #2
-    for (uint32_t i0 = (uint32_t)tid; i0 < nn; i0 += PDMPC_THREADS) {
+    for (uint32_t i0 = (uint32_t)tid; i0 < nn; i0 += blockDim.x) {
         const uint32_t vst = vs_load(VS, i0);
         if (vst == VS_VALID || vst == VS_VALID_CS) {
             bool popped;
@@ -508,7 +508,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
     S.heap_len = 1;
     BmQueue& Q = X.Q;
     if (BM) {
-        bm_init(Q, tid, PDMPC_THREADS);
+        bm_init(Q, tid, (int)blockDim.x);
         __syncthreads();
         Q.tie = false;
         if (wave == 0) bm_push<true>(Q, lane == 0, 0u, 0.0, 0u, 1u);
@@ -1058,7 +1058,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                 continue;
             }
             // the last helper wave also polls the pending predecessors' done flags (every 4th round and while idle)
-            if (wave == PDMPC_WAVES_PER_VEHICLE - 1 && (iter++ & 3u) == 0) {
+            if (wave == (int)(blockDim.x >> 6) - 1 && (iter++ & 3u) == 0) {
                 if (poll_predecessors(A, P, l_shared, lane)) continue;
             }
             const uint32_t ver = lds_load_u32(&l_shared[SH_VERSION]);
@@ -1362,7 +1362,7 @@ __device__ __forceinline__ void search_body(const KernelArgs& A) {
         const int nd = (int)(sizeof(pdmpc_vehicle_out) / 8);
         const int y0 = (int)(offsetof(pdmpc_vehicle_out, y_predicted) / 8);
         const double qnan = __longlong_as_double(0x7ff8000000000000LL);
-        for (int i = tid; i < nd; i += PDMPC_THREADS) od[i] = (i >= y0 && i < y0 + PDMPC_HP_MAX * 3) ? qnan : 0.0;
+        for (int i = tid; i < nd; i += (int)blockDim.x) od[i] = (i >= y0 && i < y0 + PDMPC_HP_MAX * 3) ? qnan : 0.0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // later result stores hit the same bytes from other lanes
     }
     __syncthreads();
@@ -1416,7 +1416,7 @@ __device__ __forceinline__ void search_body(const KernelArgs& A) {
     const bool speculate = A.speculate && n_pred <= 64 && CHECKER == PDMPC_CHECK_INTERX;
     if (n_pred > 0) {
         const d2 nanpt = d2{__longlong_as_double(0x7ff8000000000000LL), __longlong_as_double(0x7ff8000000000000LL)};
-        for (int idx = tid; idx < Hp * pred_cols; idx += PDMPC_THREADS) {
+        for (int idx = tid; idx < Hp * pred_cols; idx += (int)blockDim.x) {
             const int k = idx / pred_cols;
             l_soup[l_soff[k] + l_lit[k] + (idx - k * pred_cols)] = nanpt;
         }
@@ -1453,7 +1453,7 @@ __device__ __forceinline__ void search_body(const KernelArgs& A) {
         __syncthreads();
         if (!speculate) {  // n_pred may exceed 64: incorporate everything directly
             const double qnan = __longlong_as_double(0x7ff8000000000000LL);
-            for (int idx = tid; idx < Hp * pred_cols; idx += PDMPC_THREADS) {
+            for (int idx = tid; idx < Hp * pred_cols; idx += (int)blockDim.x) {
                 const int k = idx / pred_cols;
                 const int r = idx - k * pred_cols;
                 const int p = r / PDMPC_VMAX;
@@ -1754,10 +1754,10 @@ extern "C" int pdmpc_launch_heap_script(const int32_t* op, const int32_t* id, co
 }
 
 // one successor-mask word (MPAs of at most 64 trims: all of the reference's but the "realistic" one) / any number
-extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel(const KernelArgs A) { search_body<PDMPC_CHECK_INTERX, 1>(A); }
-extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel_sat(const KernelArgs A) { search_body<PDMPC_CHECK_SAT, 1>(A); }
-extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel_wide(const KernelArgs A) { search_body<PDMPC_CHECK_INTERX, 0>(A); }
-extern "C" __global__ __launch_bounds__(PDMPC_THREADS) void pdmpc_search_kernel_sat_wide(const KernelArgs A) { search_body<PDMPC_CHECK_SAT, 0>(A); }
+extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) void pdmpc_search_kernel(const KernelArgs A) { search_body<PDMPC_CHECK_INTERX, 1>(A); }
+extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) void pdmpc_search_kernel_sat(const KernelArgs A) { search_body<PDMPC_CHECK_SAT, 1>(A); }
+extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) void pdmpc_search_kernel_wide(const KernelArgs A) { search_body<PDMPC_CHECK_INTERX, 0>(A); }
+extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) void pdmpc_search_kernel_sat_wide(const KernelArgs A) { search_body<PDMPC_CHECK_SAT, 0>(A); }
 
 extern "C" int pdmpc_launch_search(const KernelArgs* args, int count, void* stream) {
     if (count <= 0) return 0;
@@ -1766,6 +1766,6 @@ extern "C" int pdmpc_launch_search(const KernelArgs* args, int count, void* stre
     const kernel_t fn = interx ? (one_word ? pdmpc_search_kernel : pdmpc_search_kernel_wide) : (one_word ? pdmpc_search_kernel_sat : pdmpc_search_kernel_sat_wide);
     hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)args->lds.total);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(fn, dim3(count), dim3(PDMPC_THREADS), args->lds.total, (hipStream_t)stream, *args);
+    hipLaunchKernelGGL(fn, dim3(count), dim3(PDMPC_WAVE * args->n_waves), args->lds.total, (hipStream_t)stream, *args);
     return (int)hipGetLastError();
 }

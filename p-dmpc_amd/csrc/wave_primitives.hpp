@@ -38,7 +38,7 @@ typedef LDS_AS DevManPose lds_pose;
 __device__ __forceinline__ void stage16(LDS_AS void* dst_lds, const void* src, int count, int tid) {
     lds_d2* d = (lds_d2*)dst_lds;
     const d2* s = (const d2*)src;
-    for (int i = tid; i < count; i += PDMPC_THREADS) d[i] = s[i];
+    for (int i = tid; i < count; i += (int)blockDim.x) d[i] = s[i];
 }
 
 // order this wave's LDS/HBM writes before its later reads (same wave: the hardware keeps DS order; this stops the
