@@ -295,6 +295,8 @@ def main():
                 "nodes_popped_per_s": pops / elapsed,
                 "nodes_generated_per_s": nodes / elapsed,
                 "nodes_popped_per_step": pops / args.steps,
+                "edge_checks_per_s": st["edge_checks"] / elapsed,
+                "segment_pair_tests_per_s": st["segment_pair_tests"] / elapsed,
                 "speculation_arrivals_per_step": st["speculation_arrivals"] / args.steps,
                 "speculation_restarts_per_step": st["speculation_restarts"] / args.steps,
                 "speculation_wasted_pops_per_step": st["speculation_wasted_pops"] / args.steps,

@@ -147,6 +147,10 @@ typedef struct {
     int64_t speculation_arrivals; /* late arrivals of predecessor areas folded into running searches (same period) */
     int64_t queue_mode;        /* open list of the last launch: 0 binary heap, 1 block-min queue (csrc/blockmin_queue.hpp) */
     int64_t queue_ring_entries;/* block-min queue: keys resident in LDS per vehicle */
+    int64_t edge_checks;       /* eval_edge_exact evaluations since pdmpc_create / pdmpc_reset_stats (incl. the ones done ahead of
+                                  the pop and never needed) */
+    int64_t segment_pair_tests;/* (area segment, obstacle segment) pairs those checks stand for: sum of (V-1)(M-1) per soup,
+                                  InterX.m:63-76 (InterX checker only) */
     int64_t speculation_wasted_pops; /* nodes popped by searches that were then restarted (block-min mode; same period) */
 } pdmpc_stats;
 

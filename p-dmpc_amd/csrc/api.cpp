@@ -137,6 +137,7 @@ struct pdmpc_handle {
     DevBuf<uint32_t> d_flag;
     DevBuf<int32_t> d_tree_size;
     DevBuf<int32_t> d_tie_count;
+    DevBuf<unsigned long long> d_work_count;
     int queue_mode = PDMPC_QUEUE_BLOCKMIN;
     int speculate_expansion = 1;
     int waves_latency = PDMPC_WAVES_LATENCY, waves_throughput = PDMPC_WAVES_THROUGHPUT;
@@ -176,7 +177,7 @@ int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in, int cand_cap_in)
     const uint32_t ref_bytes = 3 * PDMPC_HP_MAX * 8;
     const int n_waves = (n_launch > h->n_cu) ? h->waves_throughput : h->waves_latency;
     h->n_waves = n_waves;
-    const uint32_t shape_bytes = (uint32_t)n_waves * 2 * PDMPC_VMAX * 16;
+    const uint32_t shape_bytes = (uint32_t)n_waves * (2 * PDMPC_VMAX + 1) * 16;  // two shapes + the wave's work tally
     const uint32_t path_bytes = align16((PDMPC_HP_MAX + 2) * 4 + 2 * (PDMPC_HP_MAX + 1) * 4 + 32 * 4 + PDMPC_HP_MAX * 4);  // ... + SH_WORDS shared words + ...
     const uint32_t soup_bytes = (uint32_t)std::max(hb.soup_cap, 1) * 16;
     const uint32_t expand_bytes = (2 * PDMPC_HP_MAX * PDMPC_HP_MAX) * 8 + 16 * 16;
@@ -441,6 +442,7 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.bm_kr = h->bm_kr;
     a.bm_nb = h->bm_nb;
     a.tie_count = h->d_tie_count.p;
+    a.work_count = h->d_work_count.p;
     if (h->events_used == h->events.size()) {
         hipEvent_t e0, e1;
         HIPCHK(hipEventCreate(&e0));
@@ -503,7 +505,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
     const size_t tot = (size_t)h->max_vehicles * h->max_nodes;
     int bad = 0;
     bad |= h->anodes.ensure(tot) | h->ahk.ensure(tot) | h->ahid.ensure(tot) | h->avs.ensure(tot);
-    bad |= h->d_out.ensure((size_t)h->max_vehicles) | h->d_flag.ensure((size_t)h->max_vehicles) | h->d_tree_size.ensure((size_t)h->max_vehicles) | h->d_tie_count.ensure(4);
+    bad |= h->d_out.ensure((size_t)h->max_vehicles) | h->d_flag.ensure((size_t)h->max_vehicles) | h->d_tree_size.ensure((size_t)h->max_vehicles) | h->d_tie_count.ensure(4) | h->d_work_count.ensure(2);
     bad |= h->d_trace.ensure((size_t)h->max_vehicles * (size_t)std::max(config->trace_pops, 1));
     if (bad) {
         pdmpc_destroy(h);
@@ -512,6 +514,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
     (void)hipMemsetAsync(h->d_flag.p, 0, h->d_flag.cap * sizeof(uint32_t), h->stream);
     (void)hipMemsetAsync(h->d_tree_size.p, 0, h->d_tree_size.cap * sizeof(int32_t), h->stream);
     (void)hipMemsetAsync(h->d_tie_count.p, 0, 4 * sizeof(int32_t), h->stream);
+    (void)hipMemsetAsync(h->d_work_count.p, 0, 2 * sizeof(unsigned long long), h->stream);
     (void)hipMemsetAsync(h->d_out.p, 0, h->d_out.cap * sizeof(pdmpc_vehicle_out), h->stream);
     (void)hipStreamSynchronize(h->stream);
     *out_handle = h;
@@ -538,6 +541,7 @@ int pdmpc_destroy(pdmpc_handle* h) {
     h->d_flag.release();
     h->d_tree_size.release();
     h->d_tie_count.release();
+    h->d_work_count.release();
     h->d_trace.release();
     for (auto& b : h->banks) b.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -639,6 +643,7 @@ int pdmpc_reset_stats(pdmpc_handle* h) {
     HIPCHK(hipStreamSynchronize(h->stream));
     h->events_used = 0;
     HIPCHK(hipMemsetAsync(h->d_tie_count.p, 0, 4 * sizeof(int32_t), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_work_count.p, 0, 2 * sizeof(unsigned long long), h->stream));
     return PDMPC_OK;
 }
 
@@ -744,6 +749,10 @@ int pdmpc_get_last_stats(pdmpc_handle* h, pdmpc_stats* stats) {
     h->stats.speculation_restarts = ctr[1];
     h->stats.speculation_arrivals = ctr[2];
     h->stats.speculation_wasted_pops = ctr[3];
+    unsigned long long work[2] = {0, 0};
+    HIPCHK(hipMemcpy(work, h->d_work_count.p, sizeof work, hipMemcpyDeviceToHost));
+    h->stats.edge_checks = (int64_t)work[0];
+    h->stats.segment_pair_tests = (int64_t)work[1];
     *stats = h->stats;
     return PDMPC_OK;
 }

@@ -223,6 +223,7 @@ struct CheckCtx {
     int areas_in_lds, ll_base, ll_len, Hp, checker;
     lds_d2* sh;     // this wave's shape scratch: A in [0, VMAX), B in [VMAX, 2 VMAX)
     lds_u32* cand;  // this wave's candidate list
+    LDS_AS unsigned long long* tally;  // this wave's work counters: edge checks, (shape segment, obstacle segment) pairs
 };
 
 // eval_edge_exact (GraphSearch.m:111-196) for node `id` (1-based): true = collision-free.  A pure function of the
@@ -265,9 +266,14 @@ __device__ bool edge_valid(const Search& S, const CheckCtx& C, uint32_t id, int 
     if (CHECKER == PDMPC_CHECK_INTERX) {
         const int ho = uni_i(C.l_hoff[cK - 1]);
         const int Hk = uni_i(C.l_hoff[cK]) - ho;
+        if (lane == 0) {  // the pairs the reference's InterX forms for this edge (InterX.m:63-76): (V - 1) x (M - 1) per soup
+            C.tally[0] += 1;
+            C.tally[1] += (unsigned long long)(ncols - 1) * (unsigned long long)((M_k > 1 ? M_k - 1 : 0) + (Hk > 1 ? Hk - 1 : 0) + (C.ll_len > 1 ? C.ll_len - 1 : 0));
+        }
         hit = interx_check(C.sh, ncols, C.l_soup, so, M_k, ho, Hk, C.ll_base, C.ll_len, C.cand, lane);
     } else {
         // are_constraints_satisfied_sat.m:15-53
+        if (lane == 0) C.tally[0] += 1;
         hit = sat_soup_wave(C.sh, ncols, C.l_soup + so, M_k, lane);
         if (!hit) hit = sat_boundary_wave(C.sh + PDMPC_VMAX, ncols, C.l_soup + C.ll_base, C.ll_len, lane);
     }

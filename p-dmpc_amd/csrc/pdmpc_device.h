@@ -122,6 +122,7 @@ struct KernelArgs {
     int32_t n_validators;              // validator waves that take part (block-min mode; at most n_waves - 3)
     int32_t crowded;                   // 1: more workgroups than compute units in this launch (idle waves sleep longer between polls)
     int32_t queue_mode, bm_kr, bm_nb;  // PDMPC_QUEUE_*; block-min ring entries (power of two) and block count (multiple of 64)
+    unsigned long long* work_count;    // [0] edge checks evaluated, [1] segment pairs they stand for (cumulative, all vehicles)
     int32_t* tie_count;                // [0] searches redone on the binary heap after a tied minimum, [1] speculation restarts, [2] arrivals (cumulative)
     int32_t speculate;  // 1: start searching before all predecessors have finished (results are identical, see arrival_sync)
     uint32_t spin_limit;

@@ -1324,7 +1324,12 @@ __device__ __forceinline__ void search_body(const KernelArgs& A) {
     C.areas_in_lds = A.areas_in_lds;
     C.Hp = Hp;
     C.checker = A.checker;
-    C.sh = (lds_d2*)(lsm + A.lds.shape) + wave * 2 * PDMPC_VMAX;
+    C.sh = (lds_d2*)(lsm + A.lds.shape) + wave * (2 * PDMPC_VMAX + 1);
+    C.tally = (LDS_AS unsigned long long*)(C.sh + 2 * PDMPC_VMAX);  // [0] edge checks, [1] segment pairs (this wave)
+    if (lane == 0) {
+        C.tally[0] = 0;
+        C.tally[1] = 0;
+    }
     C.cand = (lds_u32*)(lsm + A.lds.cand) + (size_t)wave * A.cand_cap;
 
     pdmpc_vehicle_out* __restrict__ O = A.out + slot;
@@ -1536,6 +1541,10 @@ __device__ __forceinline__ void search_body(const KernelArgs& A) {
     const uint32_t nnodes = X.nnodes;
     dep_timeout = X.dep_timeout;
     S = X.S;
+    if (lane == 0) {
+        atomicAdd(A.work_count + 0, C.tally[0]);
+        atomicAdd(A.work_count + 1, C.tally[1]);
+    }
     __syncthreads();
     if (wave != 0) return;
 

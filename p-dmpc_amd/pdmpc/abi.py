@@ -118,6 +118,8 @@ class Stats(C.Structure):
         ("speculation_arrivals", C.c_int64),
         ("queue_mode", C.c_int64),
         ("queue_ring_entries", C.c_int64),
+        ("edge_checks", C.c_int64),
+        ("segment_pair_tests", C.c_int64),
         ("speculation_wasted_pops", C.c_int64),
     ]
 
