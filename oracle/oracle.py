@@ -69,6 +69,18 @@ def lib():
             C.c_int,
             C.POINTER(C.c_double),
         ]
+        L.oracle_mt19937_doubles.argtypes = [C.c_uint32, C.c_int, dp]
+        L.oracle_mt19937_doubles.restype = None
+        L.oracle_plan_batch_sampled.argtypes = [
+            C.POINTER(abi.Config),
+            C.POINTER(abi.Mpa),
+            C.c_int,
+            C.POINTER(abi.VehicleIn),
+            C.POINTER(C.c_uint32),
+            C.POINTER(abi.VehicleOut),
+            C.c_int,
+            C.POINTER(C.c_double),
+        ]
         _LIB = L
     return _LIB
 
@@ -249,3 +261,28 @@ def plan_step(options, mpa, problem, n_threads=1, mpa_struct=None):
         first += size
     del keep_m
     return recs, total_ms
+
+
+def mt19937_doubles(seed, n):
+    """n doubles of the mt19937ar stream (what MATLAB's rand(RandStream('mt19937ar', Seed=seed), 1, n) returns)."""
+    out = np.zeros(max(n, 1))
+    lib().oracle_mt19937_doubles(int(seed), int(n), out.ctypes.data_as(abi.c_double_p))
+    return out[:n]
+
+
+def plan_batch_sampled(options, mpa, iters, seeds, n_threads=1):
+    """The sampled optimizer (MonteCarloTreeSearch.m) with the oracle -> (list[ControlResultsInfo], records).
+    seeds[i] = time_step + vehicle_index of vehicle i (MonteCarloTreeSearch.m:32)."""
+    mpa_struct, keep_m = abi.pack_mpa(mpa)
+    arr, keep_v = abi.pack_vehicles(iters, options.Hp)
+    n = len(iters)
+    cfg = make_abi_config(options)
+    out = abi.out_array(n)
+    sd = (C.c_uint32 * max(n, 1))(*[int(v) for v in seeds])
+    elapsed = C.c_double()
+    rc = lib().oracle_plan_batch_sampled(C.byref(cfg), C.byref(mpa_struct), n, arr, sd, out.ctypes.data_as(C.POINTER(abi.VehicleOut)), int(n_threads), C.byref(elapsed))
+    if rc != 0:
+        raise RuntimeError("oracle_plan_batch_sampled failed")
+    infos = [info_from_record(out[i], options.Hp) for i in range(n)]
+    del keep_m, keep_v
+    return infos, out

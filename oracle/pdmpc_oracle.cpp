@@ -461,6 +461,266 @@ void graph_search(const pdmpc_config& opt, const Mpa& mpa, const pdmpc_vehicle_i
     if (trace) trace->tree = std::move(tree);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The sampled optimizer: graph_search/MonteCarloTreeSearch.m (OptimizerType.MatlabSampled, OptimizerInterface.m:29-31).
+//
+// Random numbers: RandStream('mt19937ar', Seed = time_step + vehicle_index) (:32), rand(stream, 1, Hp * n_expansions_max)
+// (:53).  mt19937ar is Matsumoto & Nishimura's reference generator; MATLAB's rand draws 53-bit doubles from two 32-bit
+// outputs (genrand_res53).  Restated here from the published algorithm (parity unpinned against MATLAB itself; pinned
+// against numpy's RandomState, which implements the same two routines, in tests/test_oracle_golden.py).
+struct Mt19937 {
+    uint32_t mt[624];
+    int mti;
+    explicit Mt19937(uint32_t seed) {  // init_genrand
+        mt[0] = seed;
+        for (mti = 1; mti < 624; ++mti) mt[mti] = 1812433253u * (mt[mti - 1] ^ (mt[mti - 1] >> 30)) + (uint32_t)mti;
+    }
+    uint32_t next_u32() {  // genrand_int32
+        if (mti >= 624) {
+            for (int kk = 0; kk < 624; ++kk) {
+                const uint32_t y = (mt[kk] & 0x80000000u) | (mt[(kk + 1) % 624] & 0x7fffffffu);
+                mt[kk] = mt[(kk + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            mti = 0;
+        }
+        uint32_t y = mt[mti++];
+        y ^= (y >> 11);
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= (y >> 18);
+        return y;
+    }
+    double next_double() {  // genrand_res53
+        const uint32_t a = next_u32() >> 5, b = next_u32() >> 6;
+        return (a * 67108864.0 + b) * (1.0 / 9007199254740992.0);
+    }
+};
+
+// are_constraints_satisfied_sat.m:13-66 / are_constraints_satisfied_interx.m:13-37 for one vehicle (the same statements
+// graph_search evaluates inline above)
+bool constraints_satisfied(const pdmpc_config& opt, const pdmpc_vehicle_in& it, const VectorizedObstacles& vo, const Poly& left, const Poly& right,
+                           const Poly& shape, const Poly& shape_bc, int i_step) {
+    const int Hp = opt.Hp;
+    if (opt.checker == PDMPC_CHECK_SAT) {
+        const int n_dyn = it.dynamic_obstacles.n_polygons / Hp;
+        for (int i = 0; i < it.obstacles.n_polygons; ++i)
+            if (intersect_sat(shape, poly_from_set(it.obstacles, i))) return false;
+        for (int i = 0; i < n_dyn; ++i)
+            if (intersect_sat(shape, poly_from_set(it.dynamic_obstacles, i * Hp + (i_step - 1)))) return false;
+        if (intersect_lanelet_boundary(shape_bc, left, right)) return false;
+        return true;
+    }
+    if (interx(shape, vo.vehicle_obstacles[i_step - 1])) return false;
+    const Poly& hdv = vo.hdv_obstacles[i_step - 1];
+    bool all_nan = true;
+    for (size_t q = 0; q < hdv.n(); ++q)
+        if (!(std::isnan(hdv.x[q]) && std::isnan(hdv.y[q]))) all_nan = false;
+    if (!all_nan && interx(shape, hdv)) return false;
+    if (interx(shape_bc, vo.lanelet_boundary)) return false;
+    return true;
+}
+
+// transform * maneuver.dpose added to the pose (MonteCarloTreeSearch.m:131-138): a 3x3 matrix-vector product, each row
+// accumulated left to right, zeros included
+void apply_maneuver(double pose[3], const pdmpc_maneuver& m, double c, double s) {
+    const double t0 = c * m.dx + (-s) * m.dy + 0.0 * m.dyaw;
+    const double t1 = s * m.dx + c * m.dy + 0.0 * m.dyaw;
+    const double t2 = 0.0 * m.dx + 0.0 * m.dy + 1.0 * m.dyaw;
+    pose[0] = pose[0] + t0;
+    pose[1] = pose[1] + t1;
+    pose[2] = pose[2] + t2;
+}
+
+// transform(1:2,1:2) * area + start_pose(1:2)                                          MonteCarloTreeSearch.m:159-166
+Poly transform_area(const double area[2][PDMPC_VMAX], int ncols, double c, double s, double px, double py) {
+    Poly p;
+    for (int v = 0; v < ncols; ++v) p.push((c * area[0][v] + (-s) * area[1][v]) + px, (s * area[0][v] + c * area[1][v]) + py);
+    return p;
+}
+
+// MonteCarloTreeSearch.do_graph_search (:40-249).  `seed` = time_step + vehicle_index (:32).
+void monte_carlo_tree_search(const pdmpc_config& opt, const Mpa& mpa, const pdmpc_vehicle_in& it, uint32_t seed, pdmpc_vehicle_out& info) {
+    const int Hp = opt.Hp;
+    const int n_expansions_max = 250;  // :8 (config/mcts.json, which could override it, does not exist in the reference tree)
+    std::memset(&info, 0, sizeof info);
+    info.n_hp = Hp;
+    for (int k = 0; k < PDMPC_HP_MAX; ++k)
+        for (int c = 0; c < 3; ++c) info.y_predicted[k][c] = kNaN;
+
+    Mt19937 rng(seed);
+    std::vector<double> random_numbers((size_t)Hp * n_expansions_max);  // :53
+    for (double& r : random_numbers) r = rng.next_double();
+
+    auto successor_trims = [&](int trim, int step) {  // mpa.successor_trims{trim, step}: find(transition_matrix_single(trim, :, step))
+        std::vector<int> v;
+        for (int j = 1; j <= mpa.n; ++j)
+            if (mpa.allowed(trim, j, step)) v.push_back(j);
+        return v;
+    };
+    int n_successor_trims_max = 0;  // mpa.maximum_branching_factor()               MotionPrimitiveAutomaton.m:689-692
+    for (int k = 1; k <= mpa.Hp; ++k)
+        for (int i = 1; i <= mpa.n; ++i) n_successor_trims_max = std::max(n_successor_trims_max, (int)successor_trims(i, k).size());
+
+    // :60-74
+    const size_t cap = (size_t)n_expansions_max + 1;  // (the reference's arrays grow when n_nodes passes n_expansions_max)
+    std::vector<int> trims(cap + 1, 0);
+    std::vector<uint32_t> parents(cap + 1, 0);
+    std::vector<std::vector<uint32_t>> children(cap + 1, std::vector<uint32_t>((size_t)n_successor_trims_max, 0));  // children(:, node)
+    const double root_pose[3] = {it.x0, it.y0, it.yaw0};
+    trims[1] = it.trim0;
+    {
+        const std::vector<int> rs = successor_trims(it.trim0, 1);
+        for (size_t q = 0; q < rs.size(); ++q) children[1][q] = 1;
+    }
+    int n_nodes = 1;
+    bool have_best = false;  // valid_nodes_at_hp: only its top is ever read (:197); with the comparator a.key > b.key the first
+    double best_cost = 0;    // entry pushed among those of minimal key stays on top (std::push_heap moves up on strict > only)
+    uint32_t best_node = 0;
+    std::vector<Poly> shapes_tmp(cap + 1);
+
+    VectorizedObstacles vo;  // :78-79
+    if (opt.checker == PDMPC_CHECK_INTERX) vo = vectorize_all_obstacles(it, Hp);
+    const Poly left = make_poly(it.left_x, it.left_y, it.n_left);
+    const Poly right = make_poly(it.right_x, it.right_y, it.n_right);
+
+    int n_expansions = 0, n_traversals = 0;
+    bool is_finished = false;
+    while (n_expansions < n_expansions_max && !is_finished) {  // :89
+        uint32_t node_id = 1;
+        double solution_cost = 0;
+        double node_pose[3] = {root_pose[0], root_pose[1], root_pose[2]};
+        bool is_valid = false;
+        size_t child_position = 0;  // 0-based here
+        uint32_t node_parent = 0;
+        for (int i_step = 1; i_step <= Hp; ++i_step) {  // :95
+            is_valid = false;
+            ++n_traversals;
+            std::vector<size_t> trim_positions;  // find(children(:, node_id))              :100
+            for (size_t q = 0; q < children[node_id].size(); ++q)
+                if (children[node_id][q] != 0) trim_positions.push_back(q);
+            const size_t n_trims = trim_positions.size();
+            if (n_trims != 0) {
+                // child_position = trim_positions(ceil(random_numbers(n_traversals) * n_trims))        :105
+                const double pick = std::ceil(random_numbers[(size_t)n_traversals - 1] * (double)n_trims);
+                child_position = trim_positions[(size_t)pick - 1];
+            } else {
+                if (node_id != 1) {  // remove edge to node without children                      :108-112
+                    const uint32_t parent_id = parents[node_id];
+                    for (uint32_t& c : children[parent_id])
+                        if (c == node_id) c = 0;
+                    break;
+                }
+                is_finished = true;  // :114-115
+                break;
+            }
+            // expand                                                                        :120-138
+            const int parent_trim = trims[node_id];
+            const std::vector<int> succ = successor_trims(parent_trim, i_step);
+            const int goal_trim = succ[child_position];
+            const pdmpc_maneuver& m = mpa.maneuver(parent_trim, goal_trim);
+            double c, s;
+            pdmpc_sincos(node_pose[2], &s, &c);
+            const double start_pose[3] = {node_pose[0], node_pose[1], node_pose[2]};
+            apply_maneuver(node_pose, m, c, s);
+            {  // solution_cost += norm(node_pose(1:2) - reference_trajectory_points(:, i_step))^2       :143
+                const double ddx = node_pose[0] - it.ref_x[i_step - 1], ddy = node_pose[1] - it.ref_y[i_step - 1];
+                const double nrm = std::sqrt(ddx * ddx + ddy * ddy);
+                solution_cost = solution_cost + nrm * nrm;
+            }
+            const bool is_expanded = children[node_id][child_position] != 1;  // :145
+            if (is_expanded) {
+                node_id = children[node_id][child_position];
+                continue;
+            }
+            ++n_expansions;  // :152
+            node_parent = node_id;
+            const Poly shape_wo = transform_area(m.area_without_offset, m.n_cols, c, s, start_pose[0], start_pose[1]);
+            const Poly shape = transform_area(m.area, m.n_cols, c, s, start_pose[0], start_pose[1]);
+            Poly shape_bc;
+            std::vector<int> child_successor_trims;
+            if (i_step != Hp) {  // :162-168
+                shape_bc = shape_wo;
+                child_successor_trims = successor_trims(goal_trim, i_step + 1);
+            } else {
+                shape_bc = transform_area(m.area_large_offset, m.n_cols, c, s, start_pose[0], start_pose[1]);
+            }
+            is_valid = constraints_satisfied(opt, it, vo, left, right, shape, shape_bc, i_step);  // :170-179
+            if (!is_valid) {
+                children[node_parent][child_position] = 0;  // :183
+                break;
+            }
+            ++n_nodes;  // :186-193
+            if ((size_t)n_nodes >= trims.size()) {
+                trims.resize(n_nodes + 1, 0);
+                parents.resize(n_nodes + 1, 0);
+                children.resize(n_nodes + 1, std::vector<uint32_t>((size_t)n_successor_trims_max, 0));
+                shapes_tmp.resize(n_nodes + 1);
+            }
+            parents[n_nodes] = node_parent;
+            trims[n_nodes] = goal_trim;
+            for (size_t q = 0; q < child_successor_trims.size(); ++q) children[n_nodes][q] = 1;
+            children[node_parent][child_position] = (uint32_t)n_nodes;
+            shapes_tmp[n_nodes] = shape;
+            node_id = (uint32_t)n_nodes;
+        }
+        if (is_valid) {  // :199-203
+            if (!have_best || solution_cost < best_cost) {
+                have_best = true;
+                best_cost = solution_cost;
+                best_node = node_id;
+            }
+            children[node_parent][child_position] = 0;  // avoid double exploration
+        }
+    }
+    info.n_expanded = n_expansions;  // :209
+    info.n_popped = n_traversals;    // (not a reference output: the number of tree descents steps, for the statistics)
+    if (!have_best) {  // :212-215
+        info.status = PDMPC_EXHAUSTED;
+        return;
+    }
+    // final path                                                                            :217-248
+    std::vector<uint32_t> path;
+    for (uint32_t nd = best_node;; nd = parents[nd]) {
+        path.push_back(nd);
+        if (nd == 1) break;
+    }
+    std::reverse(path.begin(), path.end());
+    double pose[3] = {root_pose[0], root_pose[1], root_pose[2]};
+    for (size_t i = 0; i < path.size(); ++i) {
+        const uint32_t nd = path[i];
+        if (i >= 1) {
+            const pdmpc_maneuver& m = mpa.maneuver(trims[path[i - 1]], trims[nd]);
+            double c, s;
+            pdmpc_sincos(pose[2], &s, &c);
+            apply_maneuver(pose, m, c, s);
+        }
+        info.tree_path[i] = (int32_t)nd;
+        double* row = info.path_nodes[i];  // NodeInfo order; the reference leaves g/h = -1 except g of the chosen node (:223-225, 244)
+        row[0] = pose[0];
+        row[1] = pose[1];
+        row[2] = pose[2];
+        row[3] = trims[nd];
+        row[4] = (nd == best_node) ? best_cost : -1.0;
+        row[5] = -1.0;
+        row[6] = (double)(i + 1);  // tree.k(final_nodes) = 1:length(final_nodes)                 :242
+        row[7] = 1;
+        if (i >= 1) {
+            info.y_predicted[i - 1][0] = pose[0];
+            info.y_predicted[i - 1][1] = pose[1];
+            info.y_predicted[i - 1][2] = pose[2];
+            info.predicted_trims[i - 1] = trims[nd];
+            const Poly& sh = shapes_tmp[nd];
+            info.shape_cols[i - 1] = (int32_t)sh.n();
+            for (size_t v = 0; v < sh.n(); ++v) {
+                info.shapes[i - 1][0][v] = sh.x[v];
+                info.shapes[i - 1][1][v] = sh.y[v];
+            }
+        }
+    }
+    info.status = PDMPC_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -550,6 +810,40 @@ int oracle_plan_batch(const pdmpc_config* cfg, const pdmpc_mpa* mpa_in, int n, c
                     t.parent[q] = (int32_t)tr.tree.parent[q];
                 }
             }
+        }
+    };
+    const auto t0 = std::chrono::steady_clock::now();
+    if (n_threads <= 1) {
+        worker();
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_threads; ++t) pool.emplace_back(worker);
+        for (auto& th : pool) th.join();
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    if (elapsed_ms) *elapsed_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    return 0;
+}
+
+
+// n doubles of the mt19937ar stream seeded with `seed`, as MATLAB's rand(stream, 1, n) draws them
+void oracle_mt19937_doubles(uint32_t seed, int n, double* out) {
+    Mt19937 rng(seed);
+    for (int i = 0; i < n; ++i) out[i] = rng.next_double();
+}
+
+// The sampled optimizer (MonteCarloTreeSearch.m) for n independent vehicles; seeds[i] = time_step + vehicle_index.
+int oracle_plan_batch_sampled(const pdmpc_config* cfg, const pdmpc_mpa* mpa_in, int n, const pdmpc_vehicle_in* in, const uint32_t* seeds,
+                              pdmpc_vehicle_out* out, int n_threads, double* elapsed_ms) {
+    if (!cfg || !mpa_in || n < 0 || (n > 0 && (!in || !out || !seeds))) return -1;
+    if (cfg->Hp < 1 || cfg->Hp > PDMPC_HP_MAX || mpa_in->Hp < cfg->Hp) return -1;
+    const Mpa mpa = load_mpa(mpa_in);
+    std::atomic<int> next(0);
+    auto worker = [&]() {
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= n) break;
+            monte_carlo_tree_search(*cfg, mpa, in[i], seeds[i], out[i]);
         }
     };
     const auto t0 = std::chrono::steady_clock::now();
