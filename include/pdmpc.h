@@ -231,6 +231,14 @@ int pdmpc_debug_blockmin_script(pdmpc_handle* handle, int32_t n, const int32_t* 
                                 int32_t* popped, int32_t* n_popped, int32_t* tie, double* cycles_per_pop,
                                 double* cycles_per_push);
 
+/* ---- the sampled optimizer (replaces MonteCarloTreeSearch.run_optimizer, graph_search/MonteCarloTreeSearch.m:30-35,
+ *      selected by OptimizerType.MatlabSampled in OptimizerInterface.get_optimizer, OptimizerInterface.m:29-31) ----
+ * One computation level like pdmpc_plan_batch.  seeds[i] = time_step + vehicle_index of vehicle i, the seed of its
+ * mt19937ar stream (:32).  Records: status OK / EXHAUSTED, n_expanded = expansions (:209), tree_path = node ids of the
+ * chosen descent, path_nodes rows with g = -1 except the cost of the chosen node, h = -1, k = 1..Hp+1 (:223-244). */
+int pdmpc_plan_batch_sampled(pdmpc_handle* handle, int32_t n_vehicles, const pdmpc_vehicle_in* in, const uint32_t* seeds,
+                             pdmpc_vehicle_out* out);
+
 const char* pdmpc_last_error(void);
 const char* pdmpc_version(void);
 

@@ -138,6 +138,9 @@ struct pdmpc_handle {
     DevBuf<int32_t> d_tree_size;
     DevBuf<int32_t> d_tie_count;
     DevBuf<unsigned long long> d_work_count;
+    DevBuf<double> d_random;  // sampled optimizer: random numbers of the batch
+    int sampled_n_random = 0;
+    bool sampled_launch = false;
     int queue_mode = PDMPC_QUEUE_BLOCKMIN;
     int speculate_expansion = 1;
     int waves_latency = PDMPC_WAVES_LATENCY, waves_throughput = PDMPC_WAVES_THROUGHPUT;
@@ -443,6 +446,8 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.bm_nb = h->bm_nb;
     a.tie_count = h->d_tie_count.p;
     a.work_count = h->d_work_count.p;
+    a.sampled_random = h->d_random.p;
+    a.sampled_n_random = h->sampled_n_random;
     if (h->events_used == h->events.size()) {
         hipEvent_t e0, e1;
         HIPCHK(hipEventCreate(&e0));
@@ -451,7 +456,7 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     }
     auto& ev = h->events[h->events_used++];
     HIPCHK(hipEventRecord(ev.first, h->stream));
-    int lrc = pdmpc_launch_search(&a, count, (void*)h->stream);
+    int lrc = h->sampled_launch ? pdmpc_launch_sampled(&a, count, (void*)h->stream) : pdmpc_launch_search(&a, count, (void*)h->stream);
     if (lrc != 0) {
         char buf[256];
         snprintf(buf, sizeof buf, "kernel launch failed: %s (LDS %u B)", hipGetErrorString((hipError_t)lrc), h->lds.total);
@@ -542,6 +547,7 @@ int pdmpc_destroy(pdmpc_handle* h) {
     h->d_tree_size.release();
     h->d_tie_count.release();
     h->d_work_count.release();
+    h->d_random.release();
     h->d_trace.release();
     for (auto& b : h->banks) b.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -699,6 +705,56 @@ int pdmpc_plan_batch(pdmpc_handle* h, int32_t n, const pdmpc_vehicle_in* in, pdm
     int rc = pdmpc_pack_batch(h, n, in);
     if (rc) return rc;
     rc = pdmpc_launch_packed(h);
+    if (rc) return rc;
+    return pdmpc_fetch_results(h, n, out);
+}
+
+namespace {
+// mt19937ar (Matsumoto & Nishimura) + genrand_res53: what MATLAB's rand(RandStream('mt19937ar', Seed = s), 1, n) draws
+// (MonteCarloTreeSearch.m:32,53).  Restated from the published algorithm.
+void mt19937ar_doubles(uint32_t seed, int n, double* out) {
+    uint32_t mt[624];
+    mt[0] = seed;
+    for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+    int mti = 624;
+    auto next = [&]() {
+        if (mti >= 624) {
+            for (int k = 0; k < 624; ++k) {
+                const uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+                mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            mti = 0;
+        }
+        uint32_t y = mt[mti++];
+        y ^= (y >> 11);
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= (y >> 18);
+        return y;
+    };
+    for (int i = 0; i < n; ++i) {
+        const uint32_t a = next() >> 5, b = next() >> 6;
+        out[i] = (a * 67108864.0 + b) * (1.0 / 9007199254740992.0);
+    }
+}
+}  // namespace
+
+int pdmpc_plan_batch_sampled(pdmpc_handle* h, int32_t n, const pdmpc_vehicle_in* in, const uint32_t* seeds, pdmpc_vehicle_out* out) {
+    if (!h || n < 0 || (n > 0 && (!in || !seeds || !out))) return fail(PDMPC_ERR_INVALID, "null argument");
+    int rc = pdmpc_pack_batch(h, n, in);
+    if (rc) return rc;
+    if (n == 0) return PDMPC_OK;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const int per = h->cfg.Hp * 250;  // Hp * n_expansions_max                             MonteCarloTreeSearch.m:53
+    std::vector<double> rnd((size_t)n * per);
+    for (int i = 0; i < n; ++i) mt19937ar_doubles(seeds[i], per, rnd.data() + (size_t)i * per);
+    if (h->d_random.ensure(rnd.size())) return fail(PDMPC_ERR_HIP, "hipMalloc failed for the random numbers");
+    HIPCHK(hipMemcpyAsync(h->d_random.p, rnd.data(), rnd.size() * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));  // (rnd goes out of scope)
+    h->sampled_n_random = per;
+    h->sampled_launch = true;
+    rc = pdmpc_launch_packed(h);
+    h->sampled_launch = false;
     if (rc) return rc;
     return pdmpc_fetch_results(h, n, out);
 }

@@ -122,6 +122,8 @@ struct KernelArgs {
     int32_t n_validators;              // validator waves that take part (block-min mode; at most n_waves - 3)
     int32_t crowded;                   // 1: more workgroups than compute units in this launch (idle waves sleep longer between polls)
     int32_t queue_mode, bm_kr, bm_nb;  // PDMPC_QUEUE_*; block-min ring entries (power of two) and block count (multiple of 64)
+    const double* sampled_random;      // sampled optimizer: [max_vehicles][sampled_n_random] mt19937ar doubles (host-generated)
+    int32_t sampled_n_random;
     unsigned long long* work_count;    // [0] edge checks evaluated, [1] segment pairs they stand for (cumulative, all vehicles)
     int32_t* tie_count;                // [0] searches redone on the binary heap after a tied minimum, [1] speculation restarts, [2] arrivals (cumulative)
     int32_t speculate;  // 1: start searching before all predecessors have finished (results are identical, see arrival_sync)
@@ -136,6 +138,8 @@ int pdmpc_launch_search(const KernelArgs* args, int count, void* stream);
 // defined in search_kernel.hip; runs the open-list command script on one wavefront (debug / unit test)
 int pdmpc_launch_heap_script(const int32_t* op, const int32_t* id, const double* key, int n, int32_t* out, unsigned long long* stats,
                              double* gkey, uint32_t* gid, int HL, void* stream);
+// defined in sampled_kernel.hip: the sampled optimizer (MonteCarloTreeSearch.m), `count` workgroups of one wavefront
+int pdmpc_launch_sampled(const KernelArgs* args, int count, void* stream);
 int pdmpc_launch_bm_script(const int32_t* op, const double* key, int n, int32_t* out, unsigned long long* stats, double* gkey, int KR, int NB,
                            void* stream);
 #ifdef __cplusplus

@@ -5,6 +5,7 @@
 // Commands mirror the life cycle of include/pdmpc.h:
 //     h   = pdmpc_mex('create', Hp, checker, dt_seconds)
 //           pdmpc_mex('upload_mpa', h, transition_matrix_single, maneuvers)
+//     out = pdmpc_mex('plan_sampled', ... same arguments ..., seed)      the sampled optimizer (MonteCarloTreeSearch.m)
 //     out = pdmpc_mex('plan', h, x0, trim, ref_points(Hp x 2), v_ref, obstacles, dynamic_obstacle_area,
 //                     lanelet_boundary(1 x 2 cell), hdv_reachable_sets)
 //           pdmpc_mex('destroy', h)
@@ -114,7 +115,7 @@ public:
             if (pdmpc_upload_mpa(h, &mpa) != PDMPC_OK) fail("pdmpc_upload_mpa");
             return;
         }
-        if (cmd == "plan") {
+        if (cmd == "plan" || cmd == "plan_sampled") {  // plan_sampled: one more trailing argument, the seed (time_step + vehicle_index)
             const TypedArray<double> x0 = inputs[2];
             const TypedArray<double> ref = inputs[4];  // Hp x 2
             const TypedArray<double> vref = inputs[5];
@@ -151,7 +152,12 @@ public:
             in.dynamic_obstacles = dyn.view();
             in.hdv_reachable_sets = hdv.view();
             pdmpc_vehicle_out out{};
-            if (pdmpc_plan_batch(h, 1, &in, &out) != PDMPC_OK) fail("pdmpc_plan_batch");
+            if (cmd == "plan") {
+                if (pdmpc_plan_batch(h, 1, &in, &out) != PDMPC_OK) fail("pdmpc_plan_batch");
+            } else {
+                const uint32_t seed = (uint32_t)(double)inputs[10][0];  // MonteCarloTreeSearch.m:32
+                if (pdmpc_plan_batch_sampled(h, 1, &in, &seed, &out) != PDMPC_OK) fail("pdmpc_plan_batch_sampled");
+            }
             StructArray s = f.createStructArray({1, 1}, {"status", "n_expanded", "predicted_trims", "shape_cols", "y_predicted", "shapes", "path_nodes"});
             s[0]["status"] = f.createScalar<double>(out.status);
             s[0]["n_expanded"] = f.createScalar<double>(out.n_expanded);

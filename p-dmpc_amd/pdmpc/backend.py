@@ -21,6 +21,7 @@ EXPORTS = [
     "pdmpc_destroy",
     "pdmpc_upload_mpa",
     "pdmpc_plan_batch",
+    "pdmpc_plan_batch_sampled",
     "pdmpc_pack_batch",
     "pdmpc_launch_packed",
     "pdmpc_launch_range",
@@ -82,6 +83,7 @@ def load_library(path=None):
     L.pdmpc_result_device_buffer.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.pdmpc_import_results.argtypes = [H, C.c_int32, C.c_int32, C.c_void_p]
     L.pdmpc_export_results.argtypes = [H, C.c_int32, C.c_int32, C.c_void_p]
+    L.pdmpc_plan_batch_sampled.argtypes = [H, C.c_int32, C.POINTER(abi.VehicleIn), C.POINTER(C.c_uint32), C.POINTER(abi.VehicleOut)]
     L.pdmpc_get_last_stats.argtypes = [H, C.POINTER(abi.Stats)]
     L.pdmpc_debug_heap_script.argtypes = [H, C.c_int32, abi.c_int32_p, abi.c_int32_p, abi.c_double_p, C.c_int32, abi.c_int32_p, abi.c_int32_p, abi.c_double_p, abi.c_double_p]
     L.pdmpc_debug_blockmin_script.argtypes = [H, C.c_int32, abi.c_int32_p, abi.c_double_p, C.c_int32, abi.c_int32_p, abi.c_int32_p, abi.c_int32_p, abi.c_double_p, abi.c_double_p]
@@ -147,6 +149,16 @@ class Handle:
         arr, keep = abi.pack_vehicles(iters, self.Hp)
         out = abi.out_array(n)
         _check(self.L, self.L.pdmpc_plan_batch(self.h, n, arr, abi.out_ptr(out)), "pdmpc_plan_batch")
+        del keep
+        return out[:n]
+
+    def plan_batch_sampled(self, iters, seeds):
+        """The sampled optimizer for one computation level; seeds[i] = time_step + vehicle_index (MonteCarloTreeSearch.m:32)."""
+        n = len(iters)
+        arr, keep = abi.pack_vehicles(iters, self.Hp)
+        out = abi.out_array(n)
+        sd = (C.c_uint32 * max(n, 1))(*[int(s) for s in seeds])
+        _check(self.L, self.L.pdmpc_plan_batch_sampled(self.h, n, arr, sd, abi.out_ptr(out)), "pdmpc_plan_batch_sampled")
         del keep
         return out[:n]
 

@@ -23,6 +23,7 @@ class OptimizerType(Enum):  # config/enums/OptimizerType.m:3-6 plus this backend
     MatlabOptimal = "MatlabOptimal"
     MatlabSampled = "MatlabSampled"
     HipOptimal = "HipOptimal"
+    HipSampled = "HipSampled"
 
 
 class ConstraintFromSuccessor(Enum):  # config/enums/ConstraintFromSuccessor.m

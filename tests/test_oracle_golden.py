@@ -243,3 +243,34 @@ def test_symmetric_problem_really_ties():
     rng = np.random.default_rng(3)
     _, _, traces = oracle.plan_batch(options, mpa, [problems.road_problem(rng, options, mpa)], trace=True)
     assert problems.tied_pops(traces[0]) == 0
+
+
+def test_mt19937ar_stream_is_numpys():
+    """MATLAB's RandStream('mt19937ar', Seed = s) + rand draw the reference generator's 53-bit doubles; numpy's RandomState
+    implements the same routines (init_genrand, genrand_res53): e.g. seed 42 -> 0.3745, 0.9507, 0.7320 in both worlds."""
+    for seed in (1, 5, 42, 2024):
+        assert np.array_equal(oracle.mt19937_doubles(seed, 3000), np.random.RandomState(seed).random_sample(3000))
+    assert np.allclose(oracle.mt19937_doubles(42, 3), [0.3745401188473625, 0.9507143064099162, 0.7319939418114051], rtol=0, atol=0)
+
+
+def test_sampled_optimizer_structure():
+    """MonteCarloTreeSearch.m invariants: at most 250 + Hp - 1 expansions, the chosen descent starts at the root, its
+    cost is the sum of squared distances to the reference points and never beats the optimal search's."""
+    import problems
+
+    options, mpa, iters = problems.problem_set("interx", 3, 8, Hp=6)
+    infos, recs = oracle.plan_batch_sampled(options, mpa, iters, list(range(10, 18)))
+    opt_infos, opt_recs, _ = oracle.plan_batch(options, mpa, iters)
+    for i, it in enumerate(iters):
+        if recs[i]["status"] != 0:
+            continue
+        assert recs[i]["n_expanded"] <= 250 + options.Hp - 1
+        assert recs[i]["tree_path"][0] == 1
+        yp = recs[i]["y_predicted"][: options.Hp]
+        cost = 0.0
+        for k in range(options.Hp):
+            d = np.hypot(yp[k, 0] - it.reference_trajectory_points[k, 0], yp[k, 1] - it.reference_trajectory_points[k, 1])
+            cost += d * d
+        assert abs(cost - recs[i]["path_nodes"][options.Hp][4]) < 1e-12
+        if opt_recs[i]["status"] == 0:
+            assert recs[i]["path_nodes"][options.Hp][4] >= opt_recs[i]["path_nodes"][options.Hp][4] - 1e-12
