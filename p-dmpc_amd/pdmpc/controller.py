@@ -291,7 +291,12 @@ class PrioritizedSequentialController:
             for lvl in range(1, int(levels.max()) + 1):  # PrioritizedSequentialController.m:83-91
                 members = [i for i in range(self.n) if levels[i] == lvl]
                 iters = [self._iter_for(i, directed, directed_seq) for i in members]
-                results = self.plan_level(iters)
+                # the sampled optimizer draws from a stream seeded with time_step + vehicle_index (MonteCarloTreeSearch.m:32):
+                # a planner that wants them declares it (plan_level.wants_seeds)
+                if getattr(self.plan_level, "wants_seeds", False):
+                    results = self.plan_level(iters, [self.k + (i + 1) for i in members])
+                else:
+                    results = self.plan_level(iters)
                 for i, it, info in zip(members, iters, results):
                     self._post_plan(i, it, info)
         # Simulation.apply (Simulation.m:86-100)

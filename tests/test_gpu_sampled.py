@@ -68,3 +68,38 @@ def test_sampled_exhaustion_and_plugin_interface():
     assert np.array_equal(info.y_predicted.view(np.uint64), ref_infos[0].y_predicted.view(np.uint64))
     assert list(info.tree_path) == list(ref_infos[0].tree_path)
     opt.handle.close()
+
+
+def test_sampled_closed_loop_level_by_level():
+    """PrioritizedSequentialController with the sampled optimizer, level by level (the reference's own loop,
+    PrioritizedSequentialController.m:77-94): the GPU closed loop equals the oracle's closed loop step for step."""
+    from pdmpc.config import Config, ScenarioType
+    from pdmpc.controller import PrioritizedSequentialController
+    from pdmpc.iteration_data import info_from_record
+    from pdmpc.mpa import get_mpa
+    from pdmpc.scenario import circle_scenario
+
+    options = Config(scenario_type=ScenarioType.circle, amount=4, Hp=5, max_vehicles=8)
+    mpa = get_mpa(options)
+    h = Handle(options)
+    h.upload_mpa(mpa)
+    trajectories = {}
+    for who in ("gpu", "oracle"):
+
+        def plan_level(iters, seeds, who=who):
+            if who == "gpu":
+                recs = h.plan_batch_sampled(iters, seeds)
+            else:
+                _, recs = _oracle().plan_batch_sampled(options, mpa, iters, seeds)
+            return [info_from_record(recs[i], options.Hp) for i in range(len(iters))]
+
+        plan_level.wants_seeds = True
+        ctl = PrioritizedSequentialController(options, circle_scenario(options), mpa, plan_level, coupling="full")
+        states = []
+        for _ in range(8):
+            infos = ctl.step()
+            states.append(np.array([[m.x, m.y, m.yaw] for m in ctl.meas]))
+        trajectories[who] = np.array(states)
+    h.close()
+    assert np.array_equal(trajectories["gpu"].view(np.uint64), trajectories["oracle"].view(np.uint64))
+    assert not np.array_equal(trajectories["gpu"][0], trajectories["gpu"][-1])  # the vehicles moved
