@@ -68,6 +68,18 @@ def main():
         )
         print(name, "status", recs["status"].tolist(), "pops", recs["n_popped"].tolist())
 
+    # the sampled optimizer (MonteCarloTreeSearch.m): records of the oracle for seeded problems and seeds
+    for name, mode, seed, count, Hp in (("sampled_interx_hp6", "interx", 111, 10, 6), ("sampled_sat_hp8", "sat", 112, 10, 8)):
+        options, mpa, iters = problems.problem_set(mode, seed, count, Hp=Hp)
+        seeds = [3 + 2 * i for i in range(count)]
+        _, recs = oracle.plan_batch_sampled(options, mpa, iters, seeds)
+        np.savez_compressed(
+            os.path.join(HERE, "oracle_plans_%s.npz" % name),
+            mode=mode, seed=seed, count=count, Hp=Hp, rng_seeds=np.array(seeds),
+            records=recs.view(np.uint8).reshape(count, -1),
+        )
+        print(name, "status", recs["status"].tolist(), "expansions", recs["n_expanded"].tolist())
+
 
 if __name__ == "__main__":
     main()

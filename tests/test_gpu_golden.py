@@ -29,3 +29,15 @@ def test_gpu_reproduces_golden_plans(name):
         assert np.array_equal(pops, g["first_pops"][v, : len(pops)])
         assert h.tree(v)["x"].shape[0] == g["tree_sizes"][v]
     h.close()
+
+
+@pytest.mark.parametrize("name", ["sampled_interx_hp6", "sampled_sat_hp8"])
+def test_gpu_reproduces_golden_sampled_plans(name):
+    g = np.load(os.path.join(GOLDEN, "oracle_plans_%s.npz" % name))
+    options, mpa, iters = problems.problem_set(str(g["mode"]), int(g["seed"]), int(g["count"]), Hp=int(g["Hp"]))
+    options.max_vehicles = len(iters)
+    h = Handle(options)
+    h.upload_mpa(mpa)
+    recs = h.plan_batch_sampled(iters, g["rng_seeds"].tolist())
+    h.close()
+    assert np.array_equal(recs.view(np.uint8).reshape(len(iters), -1), g["records"])

@@ -195,6 +195,14 @@ def test_oracle_reproduces_golden_plans(name):
         assert len(t.tree["x"]) == g["tree_sizes"][i]
 
 
+@pytest.mark.parametrize("name", ["sampled_interx_hp6", "sampled_sat_hp8"])
+def test_oracle_reproduces_golden_sampled_plans(name):
+    g = np.load(os.path.join(GOLDEN, "oracle_plans_%s.npz" % name))
+    options, mpa, iters = problems.problem_set(str(g["mode"]), int(g["seed"]), int(g["count"]), Hp=int(g["Hp"]))
+    _, recs = oracle.plan_batch_sampled(options, mpa, iters, g["rng_seeds"].tolist())
+    assert np.array_equal(recs.view(np.uint8).reshape(len(iters), -1), g["records"])
+
+
 # ---- structural invariants derivable from the reference code ---------------------------
 def test_search_invariants():
     options, mpa, iters = problems.problem_set("interx", 77, 16, Hp=6)
