@@ -402,6 +402,8 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     if (count == 0) return PDMPC_OK;
     int rc = compute_lds(h, count, B.soup_cap, B.cand_cap);
     if (rc) return rc;
+    // the sampled optimizer keeps its tree (288 nodes x (16 children + parent + trim) x 2 B) where the open list would be
+    if (h->sampled_launch && h->lds.total - h->lds.heap_key < 288u * 18u * 2u) return fail(PDMPC_ERR_CAPACITY, "not enough LDS left for the sampled optimizer's tree");
     KernelArgs a{};
     a.succ_mask = h->d_mask.p;
     a.man_index = h->d_mi.p;
