@@ -156,10 +156,10 @@ __device__ __forceinline__ void bm_push(BmQueue& Q, bool active, uint32_t i0, do
 }
 
 // keys of block b, one per lane (+inf for nodes that do not exist yet or have been popped)
-__device__ __forceinline__ double bm_block_keys(const BmQueue& Q, uint32_t b, uint32_t nn, bool in_ring) {
+__device__ __forceinline__ double bm_block_keys(const BmQueue& Q, uint32_t b, uint32_t nn, bool in_ring, unsigned long long& popped) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t idx = b * 64u + lane;
-    const unsigned long long popped = Q.pbits[b];
+    popped = Q.pbits[b];
     double k;
     if (in_ring) {
         k = Q.kring[idx & Q.kr_mask];
@@ -184,10 +184,11 @@ __device__ __forceinline__ void bm_remove(BmQueue& Q, uint32_t idx, uint32_t nn)
     const double inf = bm_inf();
     const uint32_t b = idx >> 6, e = idx & 63u;
     const bool in_ring = bm_in_ring(Q, b, nn);
-    const double k = bm_block_keys(Q, b, nn, in_ring);
+    unsigned long long popped;
+    const double k = bm_block_keys(Q, b, nn, in_ring, popped);
     const double new1 = wave_min_d(lane == e ? inf : k);
     if (lane == e) {
-        __hip_atomic_fetch_or(&Q.pbits[b], 1ull << e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        Q.pbits[b] = popped | (1ull << e);  // (the queue's owner is the only writer of the popped bits)
         Q.m1[b] = new1;
     }
     if (nn > 4096u) {
@@ -237,7 +238,8 @@ __device__ __forceinline__ BmFound bm_pop(BmQueue& Q, uint32_t nn) {
     if (b1 & (b1 - 1ull)) Q.tie = true;
     const uint32_t bl = (uint32_t)__builtin_ctzll(b1);
     const uint32_t b = g * 64u + bl;
-    const double k = bm_block_keys(Q, b, nn, bm_in_ring(Q, b, nn));
+    unsigned long long popped;
+    const double k = bm_block_keys(Q, b, nn, bm_in_ring(Q, b, nn), popped);
     const unsigned long long b0 = __ballot(k == mn1);
     if (b0 & (b0 - 1ull)) Q.tie = true;
     const uint32_t e = (uint32_t)__builtin_ctzll(b0);
@@ -254,7 +256,7 @@ __device__ __forceinline__ BmFound bm_pop(BmQueue& Q, uint32_t nn) {
         new1 = wave_min_d(lane == e ? inf : k);
     }
     if (lane == e) {
-        __hip_atomic_fetch_or(&Q.pbits[b], 1ull << e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        Q.pbits[b] = popped | (1ull << e);  // (the queue's owner is the only writer of the popped bits)
         Q.m1[b] = new1;
     }
     return r;
