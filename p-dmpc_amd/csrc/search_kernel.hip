@@ -1,30 +1,32 @@
-// search_kernel.hip — one workgroup (one 64-lane wavefront) plans one vehicle.
+// search_kernel.hip — the optimal graph search: one workgroup of 8 or 12 wavefronts plans one vehicle.
 //
 // The kernel restates, for gfx950, the reference's optimal graph search:
 //   GraphSearch.do_graph_search      hlc/optimizer/graph_search/GraphSearch.m:23-107
 //   GraphSearch.eval_edge_exact      GraphSearch.m:111-196
 //   expand_node                      graph_search/expand_node.m:1-91
 //   are_constraints_satisfied_sat    graph_search/are_constraints_satisfied_sat.m:1-68  (+ intersect_sat.m,
-//                                    common/intersect_lanelet_boundary.m)
+//                                    common/intersect_lanelet_boundary.m)                       -> edge_checks.hpp
 //   are_constraints_satisfied_interx graph_search/are_constraints_satisfied_interx.m:1-39 (+ InterX.m:48-110)
-//   std::priority_queue semantics    priority_queue/priority_queue_interface_mex.cpp:19-31 (libstdc++ heap)
+//   std::priority_queue semantics    priority_queue/priority_queue_interface_mex.cpp:19-31      -> heap_queue.hpp (exact for any
+//                                    keys), blockmin_queue.hpp (exact while the minimal key is unique; certifies it)
 //   return_path_to / return_path_area / Tree.path_to_root
+//   the hand-over of solved areas between vehicles of one time step (PrioritizedController.m:476-491) -> arrival_sync
 //
-// Mapping to the hardware (DESIGN.md has the full picture):
-//   * MPA tables, the vehicle's obstacle "soup", the open list (binary heap, first HL entries) and the first
-//     NL tree nodes live in LDS; every node is also written through to HBM as one 64-byte record (the children
-//     of an expansion are one contiguous coalesced store); heap entries beyond HL spill to HBM.
-//   * the search is a dependent chain (pop -> check -> expand -> push), so the design minimises the number of
-//     LDS/HBM round trips on that chain rather than bytes:
-//       - pop: libstdc++'s sift-down is replayed on a 5-level sub-tree fetched by 62 lanes in ONE round trip
-//         (3 round trips for a 32k-entry heap instead of 15 dependent ones);
-//       - push: all ancestors of the new leaf are fetched by one lane each, a ballot finds where the value
-//         stops, the shift is one parallel store;
-//       - node fetch: one 64-byte broadcast read;
-//       - edge check (InterX): pass 1 evaluates C2 (which obstacle-segment lines cut the vehicle's area) one
-//         lane per obstacle segment and compacts the few survivors; pass 2 evaluates C1 only for those.
-//         Skipping C1 where C2 is false changes no result: the reference tests C1 & C2 (InterX.m:72-76).
-//   * floating point: every evaluated expression keeps the reference's operation order; compiled with
+// Mapping to the hardware (DESIGN.md section 3 has the full picture):
+//   * The search is a dependent chain (pop -> check -> expand -> push) and one wavefront issues about one instruction
+//     per 9.5 cycles, so the chain is bound by its instruction count.  The work is therefore split over wave roles:
+//     wave 0 owns the open list and the pop order, wave 1 evaluates and expands the popped nodes, wave 2 looks for the
+//     nodes that will be popped next, the remaining waves evaluate their edges ahead of time.  Waves talk through a few
+//     LDS words (8-byte mail boxes with sequence numbers; LDS keeps a wave's accesses in program order).
+//   * MPA tables, the vehicle's obstacle "soup", the open list's index (block minima, popped bits, recent keys), the
+//     validity bytes and the first tree nodes live in LDS; every node is also written to HBM as one 64-byte record (the
+//     children of an expansion are one contiguous coalesced store), every key as 8 bytes.
+//   * Every LDS pointer carries address_space(3) in its type: a generic pointer would compile to flat_* accesses, which on
+//     gfx9 make the wave wait for all its outstanding HBM stores.
+//   * Edge check (InterX): pass 1 evaluates C2 (which obstacle-segment lines cut the vehicle's area) one lane per
+//     obstacle segment and compacts the few survivors; pass 2 evaluates C1 only for those.  Skipping C1 where C2 is
+//     false changes no result: the reference tests C1 & C2 (InterX.m:72-76).
+//   * Floating point: every evaluated expression keeps the reference's operation order; compiled with
 //     -ffp-contract=off (no FMA), IEEE sqrt/div, sin/cos from include/pdmpc_math.h: bit-identical to the oracle.
 #include <hip/hip_runtime.h>
 
