@@ -48,6 +48,7 @@ def build_world(args, rank):
         mpa_type=MpaType[args.mpa],
         max_vehicles=max(args.vehicles * (args.instances if args.workload == "c5" else 1), 32),
         max_nodes=args.max_nodes,
+        max_num_CLs=getattr(args, "max_levels", 99),
     )
     mpa = get_mpa(options)
     scenario = commonroad_scenario(options, seed=args.seed + rank, tiles=tiles)
@@ -118,8 +119,12 @@ def main():
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
-    ap.add_argument("--priorities", default="constant", choices=["constant", "coloring"],
-                    help="priority strategy of the host driver: vehicle index (ConstantPrioritizer.m) or graph colouring (ColoringPrioritizer.m)")
+    ap.add_argument("--priorities", default="constant", choices=["constant", "coloring", "random", "fca"],
+                    help="priority strategy of the host driver: vehicle index (ConstantPrioritizer.m), graph colouring "
+                    "(ColoringPrioritizer.m), random per step (RandomPrioritizer.m), future collision assessment (FcaPrioritizer.m)")
+    ap.add_argument("--max-levels", type=int, default=99,
+                    help="options.max_num_CLs (Config.m:28): couplings that do not fit into this many computation levels are cut "
+                    "(GreedyCutter.m) and handled as parallel couplings")
     ap.add_argument("--instances", type=int, default=64, help="c5: simultaneous prioritizations per time step")
     ap.add_argument("--shard", default="components", choices=["components", "levels"],
                     help="multi-GPU mode of c3/c4: whole coupling-graph components per rank (one speculative launch per rank and step, one "
@@ -275,6 +280,7 @@ def main():
                 "Hp": args.hp,
                 "mpa": args.mpa,
                 "levels_per_step": statistics.mean(len(p["level_sizes"]) for p in full_problems),
+                "max_num_CLs": args.max_levels,
                 "seed": args.seed,
             },
             "roofline": {

@@ -85,6 +85,7 @@ class PrioritizedSequentialController:
         priorities: Optional[List[int]] = None,
         priority_strategy: str = "constant",
         boundary_provider=None,
+        weight_strategy: str = "distance",
     ):
         self.options = options
         self.scenario = scenario
@@ -93,7 +94,12 @@ class PrioritizedSequentialController:
         self.coupling = coupling
         self.n = options.amount
         self.priorities = list(priorities) if priorities is not None else list(range(1, self.n + 1))
-        self.priority_strategy = priority_strategy  # "constant" (ConstantPrioritizer.m) or "coloring" (ColoringPrioritizer.m)
+        # "constant" (ConstantPrioritizer.m), "coloring" (ColoringPrioritizer.m), "random" (RandomPrioritizer.m),
+        # "fca" (FcaPrioritizer.m)
+        self.priority_strategy = priority_strategy
+        # "constant" | "distance" | "random" (weight/*.m; Config.m:25 defaults to distance); only matters when the
+        # coupling DAG is deeper than options.max_num_CLs and has to be cut
+        self.weight_strategy = weight_strategy
         self.boundary_provider = boundary_provider  # road networks: (vehicle, path, points_index, cpi) -> (left, right)
         # Simulation.setup: initial speed = steering = 0 (Simulation.m:52-65)
         self.meas = [Measurement(v.x_start, v.y_start, v.yaw_start, 0.0, 0.0) for v in scenario.vehicles]
@@ -247,7 +253,40 @@ class PrioritizedSequentialController:
             from .prioritizer import coloring_directed_coupling
 
             return coloring_directed_coupling(adjacency)[0].astype(np.int64)
+        if priorities is None and self.priority_strategy == "random":
+            from .prioritizer import random_priorities
+
+            priorities = random_priorities(self.n, self.k)
+        if priorities is None and self.priority_strategy == "fca":
+            from .prioritizer import fca_priorities
+
+            veh = self.scenario.vehicles[0]
+            priorities, _ = fca_priorities(
+                adjacency, self.ref_points, veh.Length, veh.Width, self.options.offset,
+                self.scenario.obstacles, self.scenario.dynamic_obstacle_area,
+            )
         return directed_coupling_from_priorities(adjacency, self.priorities if priorities is None else priorities)
+
+    def _group(self, directed):
+        """PrioritizedController.group (PrioritizedController.m:375-389): weigh the directed couplings and keep as
+        sequential only what fits into options.max_num_CLs computation levels; the remaining couplings are parallel
+        (the successor avoids the predecessor's previous plan, :409-447)."""
+        directed = np.asarray(directed)
+        if int(kahn(directed).max()) <= self.options.max_num_CLs:
+            # every sub-graph of the DAG is at most as deep, so GreedyCutter accepts every edge (GreedyCutter.m:64-82)
+            return directed != 0
+        from . import grouping
+
+        o = self.options
+        if self.weight_strategy == "constant":
+            W = grouping.constant_weight(directed)
+        elif self.weight_strategy == "random":
+            W = grouping.random_weight(directed, self.k)
+        elif self.weight_strategy == "distance":
+            W = grouping.distance_weight(directed, self.x0, self.mpa.get_max_speed_of_mpa(), o.dt_seconds, o.Hp)
+        else:
+            raise ValueError(self.weight_strategy)
+        return grouping.greedy_cut(W, o.max_num_CLs)
 
     def build_step_problem(self, priorities=None, refresh=True):
         """Everything one launch needs to plan the whole time step: vehicles in level order (slot = position),
@@ -258,7 +297,7 @@ class PrioritizedSequentialController:
             self.last_adjacency = self._couple()
         adjacency = self.last_adjacency
         directed = self._direct(adjacency, priorities)
-        directed_seq = directed
+        directed_seq = self._group(directed)
         levels = kahn(directed_seq)
         self.last_levels = levels
         order = sorted(range(self.n), key=lambda i: (int(levels[i]), i))
@@ -285,7 +324,7 @@ class PrioritizedSequentialController:
             self._traffic_info()
             adjacency = self._couple()
             directed = self._direct(adjacency, None)
-            directed_seq = directed  # no cutting: every coupled pair plans sequentially (max_num_CLs >= depth)
+            directed_seq = self._group(directed)
             levels = kahn(directed_seq)
             self.last_levels = levels
             for lvl in range(1, int(levels.max()) + 1):  # PrioritizedSequentialController.m:83-91

@@ -12,14 +12,14 @@ from test_gpu_parity import assert_records_equal
 pytestmark = pytest.mark.gpu
 
 
-def run_closed_loop(options, scenario, coupling, boundary, n_steps):
+def run_closed_loop(options, scenario, coupling, boundary, n_steps, **controller_kw):
     from oracle import oracle
     from pdmpc.optimizer import GraphSearchHip
 
     mpa = get_mpa(options)
     opt = GraphSearchHip(options)
     opt._ensure_mpa(mpa)
-    ctl = PrioritizedSequentialController(options, scenario, mpa, None, coupling=coupling, boundary_provider=boundary)
+    ctl = PrioritizedSequentialController(options, scenario, mpa, None, coupling=coupling, boundary_provider=boundary, **controller_kw)
     n_checked = [0]
 
     def plan_step(prob):
@@ -68,6 +68,27 @@ def test_road_network_triple_speed_step():
     options = Config(scenario_type=ScenarioType.commonroad, amount=10, Hp=6, mpa_type=MpaType.triple_speed, max_vehicles=16, max_nodes=1 << 17)
     sc = commonroad_scenario(options, seed=3)
     run_closed_loop(options, sc, "distance", boundary_provider(sc), 8)
+
+
+@pytest.mark.parametrize("bound,weight", [(2, "distance"), (3, "constant"), (1, "distance")])
+def test_road_network_with_cut_couplings(bound, weight):
+    """options.max_num_CLs < depth of the coupling DAG: GreedyCutter keeps what fits, the other predecessors enter as
+    literal obstacles built from their previous plans (PrioritizedController.m:409-447).  Wide levels, same records."""
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    options = Config(scenario_type=ScenarioType.commonroad, amount=20, Hp=6, max_num_CLs=bound, max_vehicles=32, max_nodes=1 << 17)
+    sc = commonroad_scenario(options, seed=2)
+    ctl = run_closed_loop(options, sc, "distance", boundary_provider(sc), 10, weight_strategy=weight)
+    assert int(ctl.last_levels.max()) <= bound
+
+
+@pytest.mark.parametrize("strategy", ["random", "fca", "coloring"])
+def test_road_network_with_other_prioritizers(strategy):
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    options = Config(scenario_type=ScenarioType.commonroad, amount=16, Hp=6, max_vehicles=32, max_nodes=1 << 17)
+    sc = commonroad_scenario(options, seed=4)
+    run_closed_loop(options, sc, "distance", boundary_provider(sc), 8, priority_strategy=strategy)
 
 
 def test_sharded_planner_world1_on_gpu_matches_single_launch():

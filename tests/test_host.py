@@ -194,3 +194,127 @@ def test_controller_with_coloring_priorities_plans_in_fewer_levels():
         for s, ps in enumerate(prob["preds"]):
             assert all(prob["levels"][q] < prob["levels"][s] for q in ps)
     assert levels["coloring"] <= levels["constant"]
+
+
+def _random_dag(rng, n, p):
+    A = np.triu(rng.random((n, n)) < p, 1)
+    perm = rng.permutation(n)
+    return A[np.ix_(perm, perm)].astype(np.int64)
+
+
+def test_greedy_cutter_bounds_the_number_of_levels():
+    """GreedyCutter.m:5-86: the sequential couplings are a subset of the weighed couplings, fit into max_num_CLs levels,
+    nothing is cut when the bound is loose, everything when it is 1; heavier couplings are kept first."""
+    from pdmpc.controller import kahn
+    from pdmpc.grouping import constant_weight, greedy_cut
+
+    rng = np.random.default_rng(11)
+    for n, p in ((6, 0.6), (12, 0.4), (25, 0.25), (40, 0.1)):
+        D = _random_dag(rng, n, p)
+        W = D * rng.random((n, n))
+        depth = int(kahn(D).max())
+        assert not greedy_cut(W, 1).any()
+        assert np.array_equal(greedy_cut(W, depth), D != 0)
+        assert np.array_equal(greedy_cut(constant_weight(D), 99), D != 0)
+        for bound in range(2, depth):
+            S = greedy_cut(W, bound)
+            assert not (S & (D == 0)).any()
+            assert kahn(S.astype(np.int64)).max() <= bound
+            # maximal: no cut edge could still be added without exceeding the bound
+            for a, b in zip(*np.nonzero((D != 0) & ~S)):
+                T = S.copy()
+                T[a, b] = True
+                assert kahn(T.astype(np.int64)).max() > bound
+    # chain 0 -> 1 -> 2 with bound 2: only one of the two couplings can stay sequential, the heavier one wins
+    W = np.zeros((3, 3))
+    W[0, 1], W[1, 2] = 0.2, 0.9
+    S = greedy_cut(W, 2)
+    assert S[1, 2] and not S[0, 1]
+    W[0, 1], W[1, 2] = 0.9, 0.2
+    S = greedy_cut(W, 2)
+    assert S[0, 1] and not S[1, 2]
+    # equal weights: column-major order of find() decides (edge into column 1 is visited before the one into column 2)
+    W[0, 1] = W[1, 2] = 0.5
+    S = greedy_cut(W, 2)
+    assert S[0, 1] and not S[1, 2]
+
+
+def test_weighers():
+    from pdmpc.grouping import constant_weight, distance_weight, mt19937ar_doubles, random_weight
+
+    D = np.array([[0, 1, 1], [0, 0, 1], [0, 0, 0]])
+    assert np.array_equal(constant_weight(D), D * 0.5)
+    x0 = np.array([[0.0, 0.0, 0, 0], [3.0, 4.0, 0, 0], [0.0, 1.0, 0, 0]])
+    W = distance_weight(D, x0, max_mpa_speed=1.0, dt_seconds=0.5, Hp=10)  # max distance 10
+    assert W[0, 1] == 1 - 5.0 / 10 and W[0, 2] == 1 - 1.0 / 10 and W[1, 0] == 0
+    R = random_weight(D, 7)
+    r = mt19937ar_doubles(7, 3)
+    assert [R[0, 1], R[0, 2], R[1, 2]] == list(r)  # column-major order of find(): (1,2) (1,3) (2,3)
+    # mt19937ar known answer: genrand_res53 after init_genrand(5489) starts 0.8147236863931789 (MATLAB's rand default)
+    assert mt19937ar_doubles(5489, 1)[0] == 0.8147236863931789
+
+
+def test_host_sat_matches_the_oracle():
+    from oracle import oracle
+    from pdmpc.prioritizer import intersect_sat
+
+    rng = np.random.default_rng(5)
+    n_hit = 0
+    for _ in range(300):
+        polys = []
+        for _ in range(2):
+            k = int(rng.integers(3, 7))
+            ang = np.sort(rng.random(k) * 2 * np.pi)
+            c = rng.random(2) * 3
+            r = 0.3 + rng.random()
+            polys.append(np.stack([c[0] + r * np.cos(ang), c[1] + r * np.sin(ang)]))
+        got = intersect_sat(*polys)
+        assert got == bool(oracle.intersect_sat(*polys))
+        n_hit += got
+    assert 30 < n_hit < 270
+
+
+def test_random_and_fca_prioritizers():
+    from pdmpc.controller import directed_coupling_from_priorities, kahn
+    from pdmpc.prioritizer import calculate_yaw, fca_priorities, random_priorities
+
+    p = random_priorities(9, 3)
+    assert sorted(p) == list(range(1, 10)) and p == random_priorities(9, 3) and p != random_priorities(9, 4)
+    yaw = calculate_yaw(np.array([[0.0, 0], [1, 0], [1, 1], [0, 1]]))
+    assert np.allclose(yaw, [0, np.pi / 4, 3 * np.pi / 4, np.pi])
+    # two vehicles crossing at the origin, a third far away: the crossing pair collects collisions and goes first
+    Hp = 5
+    t = np.linspace(-0.4, 0.4, Hp)
+    refs = [np.stack([t, 0 * t], axis=1), np.stack([0 * t, t], axis=1), np.stack([t + 5, 0 * t + 5], axis=1)]
+    A = np.ones((3, 3)) - np.eye(3)
+    prio, collisions = fca_priorities(A, refs, 0.22, 0.10, 0.01)
+    assert collisions[2] == 0 and collisions[0] == collisions[1] > 0
+    assert prio == [1, 2, 3]
+    refs = [refs[2], refs[0], refs[1]]
+    prio, collisions = fca_priorities(A, refs, 0.22, 0.10, 0.01)
+    assert prio == [2, 3, 1]  # positions of the descending sort, as the reference passes them on
+    d = directed_coupling_from_priorities(A, prio)
+    assert kahn(d).max() == 3
+
+
+def test_controller_cuts_to_max_num_CLs():
+    """With options.max_num_CLs the step has at most that many levels; cut couplings turn into literal obstacles from the
+    predecessor's previous plan (PrioritizedController.m:409-447), so they only exist from the second step on."""
+    from pdmpc.config import Config, ScenarioType
+    from pdmpc.controller import PrioritizedSequentialController
+    from pdmpc.mpa import get_mpa
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    results = {}
+    for bound in (99, 2):
+        options = Config(scenario_type=ScenarioType.commonroad, amount=12, Hp=5, max_num_CLs=bound)
+        mpa = get_mpa(options)
+        sc = commonroad_scenario(options, seed=1)
+        ctl = PrioritizedSequentialController(options, sc, mpa, _oracle_level(options, mpa), coupling="distance", boundary_provider=boundary_provider(sc))
+        n_levels = []
+        for _ in range(3):
+            ctl.step()
+            n_levels.append(int(ctl.last_levels.max()))
+        results[bound] = n_levels
+    assert max(results[2]) <= 2
+    assert max(results[99]) > 2  # otherwise the scenario does not exercise the cutter
