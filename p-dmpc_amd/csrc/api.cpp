@@ -446,6 +446,11 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.queue_mode = (h->queue_mode == PDMPC_QUEUE_BLOCKMIN && h->bm_kr != 0) ? PDMPC_QUEUE_BLOCKMIN : PDMPC_QUEUE_HEAP;
     a.bm_kr = h->bm_kr;
     a.bm_nb = h->bm_nb;
+    // dropping hides pops from the pop trace: off while tracing (PDMPC_DROP=2 forces it, for tests that only compare records)
+    a.drop_invalid = h->cfg.trace_pops > 0 ? 0 : 1;
+    if (const char* e = getenv("PDMPC_DROP")) a.drop_invalid = atoi(e) == 2 ? 1 : (atoi(e) == 0 ? 0 : a.drop_invalid);  // tuning knob
+    a.eager_validation = a.drop_invalid;
+    if (const char* e = getenv("PDMPC_EAGER")) a.eager_validation = atoi(e) != 0;  // tuning knob
     a.tie_count = h->d_tie_count.p;
     a.work_count = h->d_work_count.p;
     a.sampled_random = h->d_random.p;

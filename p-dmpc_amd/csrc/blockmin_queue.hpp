@@ -36,6 +36,19 @@ struct BmQueue {
     bool tie;       // a pop found its minimal key more than once: the pop order is not certified any more
 };
 
+// Dropping entries whose edge is already known to collide (GraphSearch.m:75-77 would pop and discard them one by one):
+// whenever a pop looks at a block, the entries of that block with validity byte `invalid_code` leave the open list along
+// with the popped node (same read of the keys, same reduction for the new block minimum).  Their node indices go to
+// `list`; the caller counts those with a key below the key the search ends at as popped (see search_kernel.hip).
+struct BmDrop {
+    bool on;
+    volatile LDS_AS uint8_t* validity;  // one byte per node, the first nv nodes (nodes beyond are not dropped here)
+    uint32_t nv;
+    uint32_t invalid_code, dropped_code;
+    uint32_t* list;
+    uint32_t n;
+};
+
 __device__ __forceinline__ double bm_inf() { return __longlong_as_double((long long)BM_INF_BITS); }
 
 // unsigned minimum over the 64 lanes; lane 63 of the result holds it.  v_min_u32 takes its DPP-permuted operand
@@ -212,7 +225,7 @@ __device__ __forceinline__ void bm_unpop_lanes(BmQueue& Q, bool active, uint32_t
 
 // Pop: the entry with the minimal key is found and removed with a single look at its block.  Returns idx 0xFFFFFFFF if
 // the queue is empty.  Sets Q.tie if the minimum was not unique.
-__device__ __forceinline__ BmFound bm_pop(BmQueue& Q, uint32_t nn) {
+__device__ __forceinline__ BmFound bm_pop(BmQueue& Q, uint32_t nn, BmDrop& D) {
     const uint32_t lane = threadIdx.x & 63u;
     const double inf = bm_inf();
     BmFound r;
@@ -238,6 +251,9 @@ __device__ __forceinline__ BmFound bm_pop(BmQueue& Q, uint32_t nn) {
     if (b1 & (b1 - 1ull)) Q.tie = true;
     const uint32_t bl = (uint32_t)__builtin_ctzll(b1);
     const uint32_t b = g * 64u + bl;
+    const uint32_t idx = b * 64u + lane;
+    uint32_t vcode = 0;
+    if (D.on && idx < D.nv) vcode = D.validity[idx];
     unsigned long long popped;
     const double k = bm_block_keys(Q, b, nn, bm_in_ring(Q, b, nn), popped);
     const unsigned long long b0 = __ballot(k == mn1);
@@ -245,19 +261,40 @@ __device__ __forceinline__ BmFound bm_pop(BmQueue& Q, uint32_t nn) {
     const uint32_t e = (uint32_t)__builtin_ctzll(b0);
     r.idx = b * 64u + e;
     r.key = mn1;
+    // entries of this block that are known to collide leave with it
+    const bool dead = D.on && k < inf && lane != e && vcode == D.invalid_code;
+    const unsigned long long dmask = __ballot(dead);
+    if (dmask) {
+        if (dead) {
+            D.validity[idx] = (uint8_t)D.dropped_code;
+            D.list[D.n + __builtin_amdgcn_mbcnt_hi((uint32_t)(dmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dmask, 0u))] = idx;
+        }
+        D.n += (uint32_t)__builtin_popcountll(dmask);
+    }
+    const bool gone = lane == e || dead;
     // remove: popped bit, m1[b] = min of the rest, m2[g] = min over the group's blocks = the smaller of m1[b] and the best
     // of the other blocks (two independent reductions, interleaved)
     double new1;
     if (multi) {
         double others;
-        wave_min2_d(lane == e ? inf : k, lane == bl ? inf : v1, new1, others);
+        wave_min2_d(gone ? inf : k, lane == bl ? inf : v1, new1, others);
         if (lane == 0) Q.m2[g] = new1 < others ? new1 : others;
     } else {
-        new1 = wave_min_d(lane == e ? inf : k);
+        new1 = wave_min_d(gone ? inf : k);
     }
     if (lane == e) {
-        Q.pbits[b] = popped | (1ull << e);  // (the queue's owner is the only writer of the popped bits)
+        Q.pbits[b] = popped | (1ull << e) | dmask;  // (the queue's owner is the only writer of the popped bits)
         Q.m1[b] = new1;
     }
     return r;
+}
+__device__ __forceinline__ BmFound bm_pop(BmQueue& Q, uint32_t nn) {
+    BmDrop none;
+    none.on = false;
+    none.validity = nullptr;
+    none.nv = 0;
+    none.invalid_code = none.dropped_code = 0;
+    none.list = nullptr;
+    none.n = 0;
+    return bm_pop(Q, nn, none);
 }

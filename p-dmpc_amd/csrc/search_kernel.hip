@@ -74,6 +74,7 @@ namespace {
 #define VS_INVALID 2u
 #define VS_CLAIMED 4u   // block-min mode: a validator wave is evaluating the edge right now
 #define VS_VALID_CS 3u  // valid, and a helper has already stored cos/sin(yaw) in the node's record (expand_node.m:50-51)
+#define VS_DROPPED 5u   // block-min mode: invalid, and already taken out of the open list (counted as popped at the end)
 
 
 // validity cache: 0 unknown, 1 valid, 2 invalid; the first NV nodes in LDS, the rest in HBM (same CU -> same L1)
@@ -136,6 +137,7 @@ __device__ __forceinline__ bool vs_claim(const VState& v, uint32_t i0) {
 #define SH_Q_SYNC 21    // set by the queue wave while it is inside arrival_sync (the expander must not enter before: it may owe a reply)
 #define SH_HINT_SEQ 22  // queue wave -> expander wave (mail box): the hand-over number SH_HINT_ID will probably be posted under ...
 #define SH_HINT_ID 23   // ... and the node: the expander may evaluate and expand it ahead of time
+#define SH_EAGER 24     // block-min mode: next node (0-based) the validator waves evaluate when nothing is urgent
 #define SH_WORDS 32
 #define E2Q_VALID 1u     // the edge into the node is collision-free
 #define E2Q_GOAL 2u      // ... and the node is at the horizon: the search is over
@@ -273,6 +275,7 @@ __device__ bool arrival_sync(const Search& S, const CheckCtx& C, const SpecCtx& 
             S.lkey[0] = 0.0;  // (block-min mode rebuilds its own queue after this returns)
             S.lid[0] = 1;
             P.sh[SH_HEAP_LEN] = 1;
+            P.sh[SH_EAGER] = 1;
             P.sh[SH_NNODES] = 1;
             for (int c = 0; c < BM_NCAND; ++c) P.sh[SH_CAND + c] = 0;
             P.sh[SH_HINT_SEQ] = 0;  // (the hinted node belongs to the tree that is being thrown away)
@@ -505,6 +508,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
         vs_store(VS, 0, 1);  // the root has no edge: valid
         l_shared[SH_HEAP_LEN] = 1;
         l_shared[SH_NNODES] = 1;
+        l_shared[SH_EAGER] = 1;
         for (int c = 0; c < BM_NCAND; ++c) l_shared[SH_CAND + c] = 0;
     }
     S.heap_len = 1;
@@ -535,9 +539,36 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
         uint32_t nn = 1;  // tree size as far as the open list knows (children of the node in flight excluded)
         uint32_t seq = lds_load_u32(&l_shared[SH_Q2E_SEQ]);
         uint32_t waited = 0, ver_ctr = 0;
+        // Entries known to collide leave the open list whenever a pop looks at their block (BmDrop); every one of them
+        // whose key lies below the key the search ends at would have been popped and discarded by the reference
+        // (GraphSearch.m:75-77) and is counted as such at the end.
+        BmDrop D;
+        D.on = A.drop_invalid != 0;
+        D.validity = VS.l;
+        D.nv = VS.NV;
+        D.invalid_code = VS_INVALID;
+        D.dropped_code = VS_DROPPED;
+        D.list = S.gid;
+        D.n = 0;
+        // pops that happened implicitly: dropped entries with a key below `end_key` (whole wave; sets Q.tie if one of
+        // them has exactly that key: whether it came before or after is the heap's business)
+        auto dropped_before = [&](double end_key) -> uint32_t {
+            uint32_t mine = 0;
+            bool same = false;
+            for (uint32_t i = (uint32_t)lane; i < D.n; i += (uint32_t)PDMPC_WAVE) {
+                const double k = Q.gkey[D.list[i]];
+                mine += k < end_key ? 1u : 0u;
+                same = same || k == end_key;
+            }
+            if (__ballot(same)) Q.tie = true;
+            uint32_t total = 0;
+            for (int l = 0; l < PDMPC_WAVE; ++l) total += lane_u(mine, l);
+            return total;
+        };
         PROF_DECL
         PROF_START
       q_again:
+        D.n = 0;
         // Run-ahead list: entries already taken out of the open list, in pop order (ascending keys), entry j in lane j.
         // All but the last are known to collide: they are popped and discarded (GraphSearch.m:75-77) without further
         // ado; the last one is the next node to evaluate.  While the expander wave works on a node, this wave keeps
@@ -549,7 +580,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
         bool head_in_list = false;  // the last entry is a child that is still in the open list
         bool head_invalid = false;  // the last entry is known to collide as well (the list is full of colliding entries)
         {
-            const BmFound r0 = bm_pop(Q, nn);  // the root
+            const BmFound r0 = bm_pop(Q, nn, D);  // the root
             if (lane == 0) {
                 ra_idx = r0.idx;
                 ra_key = r0.key;
@@ -571,7 +602,8 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                     nn = 1;
                     bm_init(Q, lane, PDMPC_WAVE);  // the other waves see an empty candidate list and a tree of one node meanwhile
                     bm_push<true>(Q, lane == 0, 0u, 0.0, 0u, 1u);
-                    const BmFound r0 = bm_pop(Q, nn);
+                    D.n = 0;
+                    const BmFound r0 = bm_pop(Q, nn, D);
                     ra_idx = lane == 0 ? r0.idx : 0xFFFFFFFFu;
                     ra_key = lane == 0 ? r0.key : inf;
                     ra_n = 1;
@@ -589,10 +621,12 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
             }
             if (ra_n == 0) {  // pop on an empty queue returns -1 (mex.cpp:87-93)  GraphSearch.m:57-61
                 status = PDMPC_EXHAUSTED;
+                n_popped += (int)D.n;  // the open list ran empty: everything that was dropped has been "popped" on the way
                 break;
             }
             // the colliding entries in front: popped, discarded
             const uint32_t n_dead = ra_n - 1u;
+            const double ckey = lane_d(ra_key, (int)n_dead);
 #ifndef PDMPC_PROFILE
             if (A.trace_cap > 0 && (uint32_t)lane <= n_dead && n_popped + lane < A.trace_cap) A.pop_trace[(size_t)slot * A.trace_cap + n_popped + lane] = (int32_t)(ra_idx + 1u);
 #endif
@@ -605,7 +639,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
             PROF_TL(seq, 9)
             if (head_invalid) {  // GraphSearch.m:75-77 without leaving this wave (a verdict that comes in after an entry
                                  // was listed is the expander's business)
-                const BmFound t = bm_pop(Q, nn);
+                const BmFound t = bm_pop(Q, nn, D);
                 if (lane == 0) {
                     ra_idx = t.idx;
                     ra_key = t.key;
@@ -627,7 +661,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
             PROF_STOP(2)
             // run ahead while the expander works
             for (;;) {
-                const BmFound t = bm_pop(Q, nn);
+                const BmFound t = bm_pop(Q, nn, D);
                 if (t.idx == 0xFFFFFFFFu) break;
                 if ((uint32_t)lane == ra_n) {
                     ra_idx = t.idx;
@@ -662,12 +696,16 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                 status = PDMPC_EXHAUSTED;
                 break;
             }
-            if (flags & E2Q_GOAL) {  // :81-90
-                goal = cur;
-                break;
-            }
-            if (flags & E2Q_OVERFLOW) {
-                status = PDMPC_ARENA_OVERFLOW;
+            if (flags & (E2Q_GOAL | E2Q_OVERFLOW)) {
+                // the search ends with this node: the dropped entries that come before it were popped by the reference
+                if (D.n) {
+                    n_popped += (int)dropped_before(ckey);
+                    if (Q.tie) continue;
+                }
+                if (flags & E2Q_GOAL)  // :81-90
+                    goal = cur;
+                else
+                    status = PDMPC_ARENA_OVERFLOW;
                 break;
             }
             if (cnt) {
@@ -1021,6 +1059,20 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                 if (lane == 0) won = vs_claim(VS, cid - 1) ? 1u : 0u;
                 if (uni_u(won)) target = cid;
             }
+            bool more = false;
+            if (!target && A.eager_validation) {
+                // Nothing urgent: evaluate the edges of the tree in the order the nodes were created.  Nodes are popped
+                // long after they are created (tools/pop_age.py), so by the time the queue wave meets them the verdict is
+                // in: colliding ones are dropped from the open list on the side, the others expand without waiting.
+                const uint32_t c = lds_load_u32(&l_shared[SH_EAGER]);
+                if (c < lds_load_u32(&l_shared[SH_NNODES])) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    more = true;
+                    uint32_t won = 0;
+                    if (lane == 0) won = (atomicCAS((uint32_t*)&l_shared[SH_EAGER], c, c + 1u) == c && vs_claim(VS, c)) ? 1u : 0u;
+                    if (uni_u(won)) target = c + 1u;
+                }
+            }
             if (target) {
                 const bool ok = edge_valid<CHECKER>(S, C, target, lane);
                 uint32_t verdict = ok ? VS_VALID : VS_INVALID;
@@ -1035,6 +1087,8 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                     }
                 }
                 if (lane == 0) vs_store(VS, target - 1, verdict);
+            } else if (more) {
+                // (lost the race for that node: try the next one)
             } else {
                 // nothing to do until the scout rewrites the list
                 uint32_t naps = 0;
