@@ -132,6 +132,7 @@ struct pdmpc_handle {
     DevBuf<NodeRec> anodes;
     DevBuf<double> ahk;
     DevBuf<uint32_t> ahid;
+    DevBuf<double> alog;
     DevBuf<uint8_t> avs;
     DevBuf<pdmpc_vehicle_out> d_out;
     DevBuf<uint32_t> d_flag;
@@ -426,6 +427,7 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.arena.nodes = h->anodes.p;
     a.arena.heap_key = h->ahk.p;
     a.arena.heap_id = h->ahid.p;
+    a.arena.pop_log = h->alog.p;
     a.arena.vstate = h->avs.p;
     a.max_nodes = h->max_nodes;
     a.pop_trace = h->d_trace.p;
@@ -516,7 +518,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
     }
     const size_t tot = (size_t)h->max_vehicles * h->max_nodes;
     int bad = 0;
-    bad |= h->anodes.ensure(tot) | h->ahk.ensure(tot) | h->ahid.ensure(tot) | h->avs.ensure(tot);
+    bad |= h->anodes.ensure(tot) | h->ahk.ensure(tot) | h->ahid.ensure(tot) | h->avs.ensure(tot) | h->alog.ensure(tot);
     bad |= h->d_out.ensure((size_t)h->max_vehicles) | h->d_flag.ensure((size_t)h->max_vehicles) | h->d_tree_size.ensure((size_t)h->max_vehicles) | h->d_tie_count.ensure(4) | h->d_work_count.ensure(2);
     bad |= h->d_trace.ensure((size_t)h->max_vehicles * (size_t)std::max(config->trace_pops, 1));
     if (bad) {
@@ -548,6 +550,7 @@ int pdmpc_destroy(pdmpc_handle* h) {
     h->anodes.release();
     h->ahk.release();
     h->ahid.release();
+    h->alog.release();
     h->avs.release();
     h->d_out.release();
     h->d_flag.release();

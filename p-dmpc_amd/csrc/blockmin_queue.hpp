@@ -39,13 +39,16 @@ struct BmQueue {
 // Dropping entries whose edge is already known to collide (GraphSearch.m:75-77 would pop and discard them one by one):
 // whenever a pop looks at a block, the entries of that block with validity byte `invalid_code` leave the open list along
 // with the popped node (same read of the keys, same reduction for the new block minimum).  Their node indices go to
-// `list`; the caller counts those with a key below the key the search ends at as popped (see search_kernel.hip).
+// `list`, the number of pops made so far (`stamp`) to `stamps` (filled from the back); the caller works out at the end
+// which of them the reference would have popped (see search_kernel.hip).
 struct BmDrop {
     bool on;
     volatile LDS_AS uint8_t* validity;  // one byte per node, the first nv nodes (nodes beyond are not dropped here)
     uint32_t nv;
     uint32_t invalid_code, dropped_code;
     uint32_t* list;
+    uint32_t* stamps_end;  // stamp of entry i at stamps_end[-1 - i]
+    uint32_t stamp;
     uint32_t n;
 };
 
@@ -267,7 +270,9 @@ __device__ __forceinline__ BmFound bm_pop(BmQueue& Q, uint32_t nn, BmDrop& D) {
     if (dmask) {
         if (dead) {
             D.validity[idx] = (uint8_t)D.dropped_code;
-            D.list[D.n + __builtin_amdgcn_mbcnt_hi((uint32_t)(dmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dmask, 0u))] = idx;
+            const uint32_t at = D.n + __builtin_amdgcn_mbcnt_hi((uint32_t)(dmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dmask, 0u));
+            D.list[at] = idx;
+            D.stamps_end[-1 - (int)at] = D.stamp;
         }
         D.n += (uint32_t)__builtin_popcountll(dmask);
     }
@@ -295,6 +300,8 @@ __device__ __forceinline__ BmFound bm_pop(BmQueue& Q, uint32_t nn) {
     none.nv = 0;
     none.invalid_code = none.dropped_code = 0;
     none.list = nullptr;
+    none.stamps_end = nullptr;
+    none.stamp = 0;
     none.n = 0;
     return bm_pop(Q, nn, none);
 }

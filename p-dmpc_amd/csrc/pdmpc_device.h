@@ -88,6 +88,7 @@ struct NodeArena {  // HBM arrays, per-vehicle stride = max_nodes entries
     double* heap_key;
     uint32_t* heap_id;
     uint8_t* vstate;  // validity cache for nodes beyond the LDS-resident NV
+    double* pop_log;  // block-min mode with dropping: keys of the pops in pop order (front), drop stamps as uint32 (from the back)
 };
 
 struct KernelArgs {

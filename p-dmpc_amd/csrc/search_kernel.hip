@@ -539,9 +539,14 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
         uint32_t nn = 1;  // tree size as far as the open list knows (children of the node in flight excluded)
         uint32_t seq = lds_load_u32(&l_shared[SH_Q2E_SEQ]);
         uint32_t waited = 0, ver_ctr = 0;
-        // Entries known to collide leave the open list whenever a pop looks at their block (BmDrop); every one of them
-        // whose key lies below the key the search ends at would have been popped and discarded by the reference
-        // (GraphSearch.m:75-77) and is counted as such at the end.
+        // Entries known to collide leave the open list whenever a pop looks at their block (BmDrop).  The reference would
+        // have popped and discarded such an entry X (GraphSearch.m:75-77) as soon as it was the minimum of its open
+        // list, that is before the first later pop with a larger key.  X was in the open list until it was dropped, so
+        // no earlier pop had a larger key; whether a later one has is settled at the end from the log of the pops'
+        // keys: X counts as popped iff key(X) < max key of the pops made after it was dropped (equality: the order is
+        // the heap's business -> the search is redone on the binary heap).  Keys are not monotone along the pop sequence
+        // (a child can have a smaller key than its parent), hence the log instead of a comparison with the last key.
+        double* pop_log = A.arena.pop_log + (size_t)slot * A.max_nodes;
         BmDrop D;
         D.on = A.drop_invalid != 0;
         D.validity = VS.l;
@@ -549,16 +554,40 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
         D.invalid_code = VS_INVALID;
         D.dropped_code = VS_DROPPED;
         D.list = S.gid;
+        D.stamps_end = (uint32_t*)(pop_log + A.max_nodes);
+        D.stamp = 0;
         D.n = 0;
-        // pops that happened implicitly: dropped entries with a key below `end_key` (whole wave; sets Q.tie if one of
-        // them has exactly that key: whether it came before or after is the heap's business)
-        auto dropped_before = [&](double end_key) -> uint32_t {
+        // number of dropped entries the reference would have popped, given that the search ends after `n_real` pops
+        // (whole wave; sets Q.tie on an undecidable case)
+        auto dropped_pops = [&](uint32_t n_real) -> uint32_t {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (the log was written by other lanes of this wave)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            // in place: pop_log[j] = max key of the pops j .. n_real - 1
+            double carry = 0.0;  // keys are non-negative
+            for (int32_t base = (int32_t)((n_real - 1u) & ~63u); base >= 0; base -= 64) {
+                const uint32_t j = (uint32_t)base + (uint32_t)lane;
+                double v = j < n_real ? pop_log[j] : 0.0;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const double w = __shfl_down(v, o);
+                    if (lane + o < 64) v = w > v ? w : v;
+                }
+                v = carry > v ? carry : v;
+                if (j < n_real) pop_log[j] = v;
+                carry = lane_d(v, 0);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             uint32_t mine = 0;
             bool same = false;
             for (uint32_t i = (uint32_t)lane; i < D.n; i += (uint32_t)PDMPC_WAVE) {
-                const double k = Q.gkey[D.list[i]];
-                mine += k < end_key ? 1u : 0u;
-                same = same || k == end_key;
+                const uint32_t t = D.stamps_end[-1 - (int)i];
+                if (t < n_real) {
+                    const double k = Q.gkey[D.list[i]];
+                    const double later = pop_log[t];
+                    mine += k < later ? 1u : 0u;
+                    same = same || k == later;
+                }
             }
             if (__ballot(same)) Q.tie = true;
             uint32_t total = 0;
@@ -569,6 +598,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
         PROF_START
       q_again:
         D.n = 0;
+        D.stamp = 0;
         // Run-ahead list: entries already taken out of the open list, in pop order (ascending keys), entry j in lane j.
         // All but the last are known to collide: they are popped and discarded (GraphSearch.m:75-77) without further
         // ado; the last one is the next node to evaluate.  While the expander wave works on a node, this wave keeps
@@ -603,6 +633,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                     bm_init(Q, lane, PDMPC_WAVE);  // the other waves see an empty candidate list and a tree of one node meanwhile
                     bm_push<true>(Q, lane == 0, 0u, 0.0, 0u, 1u);
                     D.n = 0;
+                    D.stamp = 0;
                     const BmFound r0 = bm_pop(Q, nn, D);
                     ra_idx = lane == 0 ? r0.idx : 0xFFFFFFFFu;
                     ra_key = lane == 0 ? r0.key : inf;
@@ -626,11 +657,12 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
             }
             // the colliding entries in front: popped, discarded
             const uint32_t n_dead = ra_n - 1u;
-            const double ckey = lane_d(ra_key, (int)n_dead);
 #ifndef PDMPC_PROFILE
             if (A.trace_cap > 0 && (uint32_t)lane <= n_dead && n_popped + lane < A.trace_cap) A.pop_trace[(size_t)slot * A.trace_cap + n_popped + lane] = (int32_t)(ra_idx + 1u);
 #endif
+            if (D.on && (uint32_t)lane <= n_dead) pop_log[(uint32_t)n_popped + (uint32_t)lane] = ra_key;
             n_popped += (int)ra_n;
+            D.stamp = (uint32_t)n_popped;
             const uint32_t cidx = lane_u(ra_idx, (int)n_dead);
             const uint32_t cur = cidx + 1u;
             ra_n = 0;
@@ -699,7 +731,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
             if (flags & (E2Q_GOAL | E2Q_OVERFLOW)) {
                 // the search ends with this node: the dropped entries that come before it were popped by the reference
                 if (D.n) {
-                    n_popped += (int)dropped_before(ckey);
+                    n_popped += (int)dropped_pops((uint32_t)n_popped);
                     if (Q.tie) continue;
                 }
                 if (flags & E2Q_GOAL)  // :81-90
