@@ -24,7 +24,7 @@
 /* Wavefronts per vehicle (workgroup size / 64), chosen per launch: wave 0 owns the pop order; block-min mode: wave 1 expands,
  * wave 2 scouts, the others validate; heap mode: all others pre-validate.  More validators shorten the critical vehicle's
  * search (C2: 5 -> 6.87 ms, 7 -> 6.67 ms, 13 -> 6.64 ms per step) but cost throughput when the chip is full (C5). */
-#define PDMPC_WAVES_LATENCY 12    /* launches with at most one workgroup per CU */
+#define PDMPC_WAVES_LATENCY 16    /* launches with at most one workgroup per CU */
 #define PDMPC_WAVES_THROUGHPUT 8  /* launches with more workgroups than CUs */
 #define PDMPC_MAX_WAVES 16
 #define PDMPC_QUEUE_HEAP 0     /* open list = libstdc++-faithful binary heap (exact for any keys) */
