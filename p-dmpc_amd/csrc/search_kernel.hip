@@ -1,4 +1,4 @@
-// search_kernel.hip — the optimal graph search: one workgroup of 8 or 12 wavefronts plans one vehicle.
+// search_kernel.hip — the optimal graph search: one workgroup of 8 or 16 wavefronts plans one vehicle.
 //
 // The kernel restates, for gfx950, the reference's optimal graph search:
 //   GraphSearch.do_graph_search      hlc/optimizer/graph_search/GraphSearch.m:23-107
@@ -16,8 +16,11 @@
 //   * The search is a dependent chain (pop -> check -> expand -> push) and one wavefront issues about one instruction
 //     per 9.5 cycles, so the chain is bound by its instruction count.  The work is therefore split over wave roles:
 //     wave 0 owns the open list and the pop order, wave 1 evaluates and expands the popped nodes, wave 2 looks for the
-//     nodes that will be popped next, the remaining waves evaluate their edges ahead of time.  Waves talk through a few
-//     LDS words (8-byte mail boxes with sequence numbers; LDS keeps a wave's accesses in program order).
+//     nodes that will be popped next, the remaining waves evaluate their edges ahead of time — the urgent ones first,
+//     then every node of the tree in creation order.  Entries whose edge is known to collide leave the open list on the
+//     side when a pop looks at their block instead of being popped and discarded one by one (GraphSearch.m:75-77); the
+//     pop count the reference would report is reconstructed exactly at the end.  Waves talk through a few LDS words
+//     (8-byte mail boxes with sequence numbers; LDS keeps a wave's accesses in program order).
 //   * MPA tables, the vehicle's obstacle "soup", the open list's index (block minima, popped bits, recent keys), the
 //     validity bytes and the first tree nodes live in LDS; every node is also written to HBM as one 64-byte record (the
 //     children of an expansion are one contiguous coalesced store), every key as 8 bytes.

@@ -227,7 +227,19 @@ def test_random_road_problems_never_fall_back():
     assert stats["queue_fallbacks"] == 0
 
 
-@pytest.mark.parametrize("env", [{"PDMPC_QUEUE": "0"}, {"PDMPC_SPEC_EXPAND": "0"}, {"PDMPC_SPECULATE": "0"}, {"PDMPC_BM_RING": "512", "PDMPC_NV_MAX": "1024"}])
+@pytest.mark.parametrize(
+    "env",
+    [
+        {"PDMPC_QUEUE": "0"},
+        {"PDMPC_SPEC_EXPAND": "0"},
+        {"PDMPC_SPECULATE": "0"},
+        {"PDMPC_BM_RING": "512", "PDMPC_NV_MAX": "1024"},
+        {"PDMPC_DROP": "0"},
+        {"PDMPC_DROP": "1", "PDMPC_EAGER": "0"},
+        {"PDMPC_WAVES": "8"},
+        {"PDMPC_WAVES": "5", "PDMPC_VALIDATORS": "1"},
+    ],
+)
 def test_tuning_switches_do_not_change_results(env, monkeypatch):
     """The binary-heap mode, the pipeline without speculative expansion, no speculative step planning, and a starved LDS
     layout (small key ring: old blocks come from HBM; small validity cache: verdicts in HBM) all give the reference's

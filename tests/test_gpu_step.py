@@ -91,6 +91,18 @@ def test_road_network_with_other_prioritizers(strategy):
     run_closed_loop(options, sc, "distance", boundary_provider(sc), 8, priority_strategy=strategy)
 
 
+def test_pop_count_with_keys_that_are_not_monotone():
+    """Entries known to collide leave the open list without being popped; whether the reference would have popped such an
+    entry depends on the keys of the pops made after it left (a child can have a smaller key than its parent, so the
+    front does not move monotonically).  On the triple-speed MPA a comparison with the last key alone miscounts in steps
+    14 and 16 of this closed loop (found by tools/stress_parity.py)."""
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    options = Config(scenario_type=ScenarioType.commonroad, amount=20, Hp=6, mpa_type=MpaType.triple_speed, max_vehicles=32, max_nodes=1 << 16)
+    sc = commonroad_scenario(options, seed=3)
+    run_closed_loop(options, sc, "distance", boundary_provider(sc), 18)
+
+
 def test_sharded_planner_world1_on_gpu_matches_single_launch():
     """pdmpc.distributed with one rank: launch_range per level + export/import path of the C ABI."""
     import torch
