@@ -306,6 +306,8 @@ def main():
                 "speculation_arrivals_per_step": st["speculation_arrivals"] / args.steps,
                 "speculation_restarts_per_step": st["speculation_restarts"] / args.steps,
                 "speculation_wasted_pops_per_step": st["speculation_wasted_pops"] / args.steps,
+                "entries_dropped_per_step": st["entries_dropped"] / args.steps,
+                "dropped_counted_as_pops_per_step": st["dropped_counted_as_pops"] / args.steps,
                 "queue_fallbacks_per_step": st["queue_fallbacks"] / args.steps,
             },
         }

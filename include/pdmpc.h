@@ -152,6 +152,8 @@ typedef struct {
     int64_t segment_pair_tests;/* (area segment, obstacle segment) pairs those checks stand for: sum of (V-1)(M-1) per soup,
                                   InterX.m:63-76 (InterX checker only) */
     int64_t speculation_wasted_pops; /* nodes popped by searches that were then restarted (block-min mode; same period) */
+    int64_t entries_dropped;         /* open-list entries known to collide that left the list without being popped (same period) ... */
+    int64_t dropped_counted_as_pops; /* ... and how many of them the reference would have popped: they are part of nodes_popped */
 } pdmpc_stats;
 
 /* ---- life cycle (replaces GraphSearch() construction in OptimizerInterface.get_optimizer, :26-27,

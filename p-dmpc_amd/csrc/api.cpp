@@ -521,7 +521,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
     const size_t tot = (size_t)h->max_vehicles * h->max_nodes;
     int bad = 0;
     bad |= h->anodes.ensure(tot) | h->ahk.ensure(tot) | h->ahid.ensure(tot) | h->avs.ensure(tot) | h->alog.ensure(tot);
-    bad |= h->d_out.ensure((size_t)h->max_vehicles) | h->d_flag.ensure((size_t)h->max_vehicles) | h->d_tree_size.ensure((size_t)h->max_vehicles) | h->d_tie_count.ensure(4) | h->d_work_count.ensure(2);
+    bad |= h->d_out.ensure((size_t)h->max_vehicles) | h->d_flag.ensure((size_t)h->max_vehicles) | h->d_tree_size.ensure((size_t)h->max_vehicles) | h->d_tie_count.ensure(4) | h->d_work_count.ensure(4);
     bad |= h->d_trace.ensure((size_t)h->max_vehicles * (size_t)std::max(config->trace_pops, 1));
     if (bad) {
         pdmpc_destroy(h);
@@ -530,7 +530,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
     (void)hipMemsetAsync(h->d_flag.p, 0, h->d_flag.cap * sizeof(uint32_t), h->stream);
     (void)hipMemsetAsync(h->d_tree_size.p, 0, h->d_tree_size.cap * sizeof(int32_t), h->stream);
     (void)hipMemsetAsync(h->d_tie_count.p, 0, 4 * sizeof(int32_t), h->stream);
-    (void)hipMemsetAsync(h->d_work_count.p, 0, 2 * sizeof(unsigned long long), h->stream);
+    (void)hipMemsetAsync(h->d_work_count.p, 0, 4 * sizeof(unsigned long long), h->stream);
     (void)hipMemsetAsync(h->d_out.p, 0, h->d_out.cap * sizeof(pdmpc_vehicle_out), h->stream);
     (void)hipStreamSynchronize(h->stream);
     *out_handle = h;
@@ -661,7 +661,7 @@ int pdmpc_reset_stats(pdmpc_handle* h) {
     HIPCHK(hipStreamSynchronize(h->stream));
     h->events_used = 0;
     HIPCHK(hipMemsetAsync(h->d_tie_count.p, 0, 4 * sizeof(int32_t), h->stream));
-    HIPCHK(hipMemsetAsync(h->d_work_count.p, 0, 2 * sizeof(unsigned long long), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_work_count.p, 0, 4 * sizeof(unsigned long long), h->stream));
     return PDMPC_OK;
 }
 
@@ -817,10 +817,12 @@ int pdmpc_get_last_stats(pdmpc_handle* h, pdmpc_stats* stats) {
     h->stats.speculation_restarts = ctr[1];
     h->stats.speculation_arrivals = ctr[2];
     h->stats.speculation_wasted_pops = ctr[3];
-    unsigned long long work[2] = {0, 0};
+    unsigned long long work[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpy(work, h->d_work_count.p, sizeof work, hipMemcpyDeviceToHost));
     h->stats.edge_checks = (int64_t)work[0];
     h->stats.segment_pair_tests = (int64_t)work[1];
+    h->stats.entries_dropped = (int64_t)work[2];
+    h->stats.dropped_counted_as_pops = (int64_t)work[3];
     *stats = h->stats;
     return PDMPC_OK;
 }

@@ -128,7 +128,7 @@ struct KernelArgs {
     int32_t eager_validation;          // block-min mode: idle validator waves evaluate every node's edge in creation order
     const double* sampled_random;      // sampled optimizer: [max_vehicles][sampled_n_random] mt19937ar doubles (host-generated)
     int32_t sampled_n_random;
-    unsigned long long* work_count;    // [0] edge checks evaluated, [1] segment pairs they stand for (cumulative, all vehicles)
+    unsigned long long* work_count;    // [0] edge checks evaluated, [1] segment pairs they stand for, [2] entries dropped from the open list, [3] those counted as pops (cumulative, all vehicles)
     int32_t* tie_count;                // [0] searches redone on the binary heap after a tied minimum, [1] speculation restarts, [2] arrivals (cumulative)
     int32_t speculate;  // 1: start searching before all predecessors have finished (results are identical, see arrival_sync)
     uint32_t spin_limit;

@@ -656,6 +656,10 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
             if (ra_n == 0) {  // pop on an empty queue returns -1 (mex.cpp:87-93)  GraphSearch.m:57-61
                 status = PDMPC_EXHAUSTED;
                 n_popped += (int)D.n;  // the open list ran empty: everything that was dropped has been "popped" on the way
+                if (lane == 0 && D.n) {
+                    atomicAdd(A.work_count + 2, (unsigned long long)D.n);
+                    atomicAdd(A.work_count + 3, (unsigned long long)D.n);
+                }
                 break;
             }
             // the colliding entries in front: popped, discarded
@@ -734,8 +738,13 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
             if (flags & (E2Q_GOAL | E2Q_OVERFLOW)) {
                 // the search ends with this node: the dropped entries that come before it were popped by the reference
                 if (D.n) {
-                    n_popped += (int)dropped_pops((uint32_t)n_popped);
+                    const uint32_t counted = dropped_pops((uint32_t)n_popped);
+                    n_popped += (int)counted;
                     if (Q.tie) continue;
+                    if (lane == 0) {
+                        atomicAdd(A.work_count + 2, (unsigned long long)D.n);
+                        atomicAdd(A.work_count + 3, (unsigned long long)counted);
+                    }
                 }
                 if (flags & E2Q_GOAL)  // :81-90
                     goal = cur;

@@ -121,6 +121,8 @@ class Stats(C.Structure):
         ("edge_checks", C.c_int64),
         ("segment_pair_tests", C.c_int64),
         ("speculation_wasted_pops", C.c_int64),
+        ("entries_dropped", C.c_int64),
+        ("dropped_counted_as_pops", C.c_int64),
     ]
 
 
