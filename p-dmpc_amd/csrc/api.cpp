@@ -444,6 +444,8 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.spin_limit = 1u << 22;
     a.speculate = h->speculate;
     a.crowded = count > h->n_cu ? 1 : 0;
+    a.dense = count > 2 * h->n_cu ? 1 : 0;
+    if (const char* e = getenv("PDMPC_DENSE")) a.dense = atoi(e) != 0;  // tuning knob
     a.speculate_expansion = h->speculate_expansion;
     a.n_validators = h->n_validators;
     a.n_waves = h->n_waves;

@@ -26,7 +26,8 @@
  * search (C2: 5 -> 6.87 ms, 7 -> 6.67 ms, 13 -> 6.64 ms per step) but cost throughput when the chip is full (C5). */
 #define PDMPC_WAVES_LATENCY 16    /* launches with at most one workgroup per CU */
 #define PDMPC_WAVES_PAIRED 10     /* launches with at most two workgroups per CU (measured on C4: 19.1 steps/s against 18.2 with 8) */
-#define PDMPC_WAVES_THROUGHPUT 8  /* launches with more workgroups than that (measured on C5: 185 steps/s against 158 with 10) */
+#define PDMPC_WAVES_THROUGHPUT 12 /* launches with more workgroups than that: the build for six wavefronts per SIMD (measured on C5: 216.7 steps/s
+                                     against 198.3 with 10 and 184.4 with 8; the regular build: 185 with 8, 158 with 10) */
 #define PDMPC_MAX_WAVES 16
 #define PDMPC_QUEUE_HEAP 0     /* open list = libstdc++-faithful binary heap (exact for any keys) */
 #define PDMPC_QUEUE_BLOCKMIN 1 /* open list = block-min queue while the minimal key is unique, binary heap after the first tie */
@@ -122,6 +123,7 @@ struct KernelArgs {
     int32_t speculate_expansion;       // 1: the expander wave works ahead on the node the queue wave will most likely hand over next
     int32_t n_waves;                   // wavefronts per vehicle of this launch (workgroup size / 64)
     int32_t n_validators;              // validator waves that take part (block-min mode; at most n_waves - 3)
+    int32_t dense;                     // 1: launch the kernels compiled for six wavefronts per SIMD
     int32_t crowded;                   // 1: more workgroups than compute units in this launch (idle waves sleep longer between polls)
     int32_t queue_mode, bm_kr, bm_nb;  // PDMPC_QUEUE_*; block-min ring entries (power of two) and block count (multiple of 64)
     int32_t drop_invalid;              // block-min mode: entries known to collide leave the open list on the side (counted as popped at the end)
