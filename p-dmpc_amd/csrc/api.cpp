@@ -456,6 +456,8 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.drop_invalid = h->cfg.trace_pops > 0 ? 0 : 1;
     if (const char* e = getenv("PDMPC_DROP")) a.drop_invalid = atoi(e) == 2 ? 1 : (atoi(e) == 0 ? 0 : a.drop_invalid);  // tuning knob
     a.eager_validation = a.drop_invalid;
+    a.drop_beyond_lds = 1;
+    if (const char* e = getenv("PDMPC_DROP_BEYOND_LDS")) a.drop_beyond_lds = atoi(e) != 0;  // tuning knob
     if (const char* e = getenv("PDMPC_EAGER")) a.eager_validation = atoi(e) != 0;  // tuning knob
     a.tie_count = h->d_tie_count.p;
     a.work_count = h->d_work_count.p;

@@ -43,7 +43,8 @@ struct BmQueue {
 // which of them the reference would have popped (see search_kernel.hip).
 struct BmDrop {
     bool on;
-    volatile LDS_AS uint8_t* validity;  // one byte per node, the first nv nodes (nodes beyond are not dropped here)
+    volatile LDS_AS uint8_t* validity;  // one byte per node: the first nv nodes in LDS ...
+    uint8_t* gvalidity;                 // ... the others in HBM (nullptr: nodes beyond nv are not dropped)
     uint32_t nv;
     uint32_t invalid_code, dropped_code;
     uint32_t* list;
@@ -256,7 +257,12 @@ __device__ __forceinline__ BmFound bm_pop(BmQueue& Q, uint32_t nn, BmDrop& D) {
     const uint32_t b = g * 64u + bl;
     const uint32_t idx = b * 64u + lane;
     uint32_t vcode = 0;
-    if (D.on && idx < D.nv) vcode = D.validity[idx];
+    if (D.on) {
+        if (idx < D.nv)
+            vcode = D.validity[idx];
+        else if (D.gvalidity && idx < nn)  // (one coalesced byte load, in flight together with the block's keys)
+            vcode = (uint32_t)__hip_atomic_load(D.gvalidity + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     unsigned long long popped;
     const double k = bm_block_keys(Q, b, nn, bm_in_ring(Q, b, nn), popped);
     const unsigned long long b0 = __ballot(k == mn1);
@@ -269,7 +275,10 @@ __device__ __forceinline__ BmFound bm_pop(BmQueue& Q, uint32_t nn, BmDrop& D) {
     const unsigned long long dmask = __ballot(dead);
     if (dmask) {
         if (dead) {
-            D.validity[idx] = (uint8_t)D.dropped_code;
+            if (idx < D.nv)
+                D.validity[idx] = (uint8_t)D.dropped_code;
+            else
+                __hip_atomic_store(D.gvalidity + idx, (uint8_t)D.dropped_code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const uint32_t at = D.n + __builtin_amdgcn_mbcnt_hi((uint32_t)(dmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dmask, 0u));
             D.list[at] = idx;
             D.stamps_end[-1 - (int)at] = D.stamp;
@@ -297,6 +306,7 @@ __device__ __forceinline__ BmFound bm_pop(BmQueue& Q, uint32_t nn) {
     BmDrop none;
     none.on = false;
     none.validity = nullptr;
+    none.gvalidity = nullptr;
     none.nv = 0;
     none.invalid_code = none.dropped_code = 0;
     none.list = nullptr;

@@ -127,6 +127,7 @@ struct KernelArgs {
     int32_t crowded;                   // 1: more workgroups than compute units in this launch (idle waves sleep longer between polls)
     int32_t queue_mode, bm_kr, bm_nb;  // PDMPC_QUEUE_*; block-min ring entries (power of two) and block count (multiple of 64)
     int32_t drop_invalid;              // block-min mode: entries known to collide leave the open list on the side (counted as popped at the end)
+    int32_t drop_beyond_lds;           // ... also entries whose validity byte lives in HBM (nodes beyond the LDS-resident NV)
     int32_t eager_validation;          // block-min mode: idle validator waves evaluate every node's edge in creation order
     const double* sampled_random;      // sampled optimizer: [max_vehicles][sampled_n_random] mt19937ar doubles (host-generated)
     int32_t sampled_n_random;

@@ -553,6 +553,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
         BmDrop D;
         D.on = A.drop_invalid != 0;
         D.validity = VS.l;
+        D.gvalidity = A.drop_beyond_lds ? VS.g : nullptr;
         D.nv = VS.NV;
         D.invalid_code = VS_INVALID;
         D.dropped_code = VS_DROPPED;

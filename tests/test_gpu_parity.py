@@ -239,6 +239,7 @@ def test_random_road_problems_never_fall_back():
         {"PDMPC_WAVES": "8"},
         {"PDMPC_WAVES": "5", "PDMPC_VALIDATORS": "1"},
         {"PDMPC_DENSE": "1", "PDMPC_WAVES": "12"},
+        {"PDMPC_NV_MAX": "1024", "PDMPC_DROP_BEYOND_LDS": "0"},
     ],
 )
 def test_tuning_switches_do_not_change_results(env, monkeypatch):
