@@ -144,7 +144,7 @@ struct pdmpc_handle {
     bool sampled_launch = false;
     int queue_mode = PDMPC_QUEUE_BLOCKMIN;
     int speculate_expansion = 1;
-    int waves_latency = PDMPC_WAVES_LATENCY, waves_paired = PDMPC_WAVES_PAIRED, waves_throughput = PDMPC_WAVES_THROUGHPUT;
+    int waves_latency = PDMPC_WAVES_LATENCY, waves_crowded = PDMPC_WAVES_CROWDED;
     int n_validators = PDMPC_MAX_WAVES;  // (all there are)
     int n_waves = PDMPC_WAVES_LATENCY;   // of the last layout
     int bm_kr = 0, bm_nb = 0;
@@ -179,9 +179,8 @@ int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in, int cand_cap_in)
     const uint32_t area_bytes = (uint32_t)(h->n_man * 3 * PDMPC_VMAX * 16);
     // fixed part after the tables
     const uint32_t ref_bytes = 3 * PDMPC_HP_MAX * 8;
-    // one workgroup per CU: all the wavefronts a workgroup can have; two per CU (all resident at once): ten each; more
-    // (workgroups queue for a slot, total work decides): eight
-    const int n_waves = (n_launch > 2 * h->n_cu) ? h->waves_throughput : (n_launch > h->n_cu) ? h->waves_paired : h->waves_latency;
+    // one workgroup per CU: all the wavefronts a workgroup can have; more: twelve each, two workgroups per CU
+    const int n_waves = (n_launch > h->n_cu) ? h->waves_crowded : h->waves_latency;
     h->n_waves = n_waves;
     const uint32_t shape_bytes = (uint32_t)n_waves * (2 * PDMPC_VMAX + 1) * 16;  // two shapes + the wave's work tally
     const uint32_t path_bytes = align16((PDMPC_HP_MAX + 2) * 4 + 2 * (PDMPC_HP_MAX + 1) * 4 + 32 * 4 + PDMPC_HP_MAX * 4);  // ... + SH_WORDS shared words + ...
@@ -446,7 +445,7 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.spin_limit = 1u << 22;
     a.speculate = h->speculate;
     a.crowded = count > h->n_cu ? 1 : 0;
-    a.dense = count > 2 * h->n_cu ? 1 : 0;
+    a.dense = count > h->n_cu ? 1 : 0;
     if (const char* e = getenv("PDMPC_DENSE")) a.dense = atoi(e) != 0;  // tuning knob
     a.speculate_expansion = h->speculate_expansion;
     a.n_validators = h->n_validators;
@@ -511,7 +510,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
     h->cfg = *config;
     h->banks.resize(1);
     if (const char* e = getenv("PDMPC_SPECULATE")) h->speculate = atoi(e) != 0;  // A/B switch for benchmarking; results are identical
-    if (const char* e = getenv("PDMPC_WAVES")) h->waves_latency = h->waves_paired = h->waves_throughput = std::min(PDMPC_MAX_WAVES, std::max(4, atoi(e)));  // likewise
+    if (const char* e = getenv("PDMPC_WAVES")) h->waves_latency = h->waves_crowded = std::min(PDMPC_MAX_WAVES, std::max(4, atoi(e)));  // likewise
     if (const char* e = getenv("PDMPC_VALIDATORS")) h->n_validators = std::max(1, atoi(e));  // likewise
     if (const char* e = getenv("PDMPC_SPEC_EXPAND")) h->speculate_expansion = atoi(e) != 0;  // likewise
     if (const char* e = getenv("PDMPC_QUEUE")) h->queue_mode = atoi(e) != 0 ? PDMPC_QUEUE_BLOCKMIN : PDMPC_QUEUE_HEAP;  // likewise

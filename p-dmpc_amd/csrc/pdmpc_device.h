@@ -25,9 +25,9 @@
  * wave 2 scouts, the others validate; heap mode: all others pre-validate.  More validators shorten the critical vehicle's
  * search (C2: 5 -> 6.87 ms, 7 -> 6.67 ms, 13 -> 6.64 ms per step) but cost throughput when the chip is full (C5). */
 #define PDMPC_WAVES_LATENCY 16    /* launches with at most one workgroup per CU */
-#define PDMPC_WAVES_PAIRED 10     /* launches with at most two workgroups per CU (measured on C4: 19.1 steps/s against 18.2 with 8) */
-#define PDMPC_WAVES_THROUGHPUT 12 /* launches with more workgroups than that: the build for six wavefronts per SIMD (measured on C5: 216.7 steps/s
-                                     against 198.3 with 10 and 184.4 with 8; the regular build: 185 with 8, 158 with 10) */
+#define PDMPC_WAVES_CROWDED 12    /* launches with more workgroups than CUs: the build for six wavefronts per SIMD, two workgroups per CU
+                                     (measured: C4, 512 workgroups: 26.3 steps/s against 23.8 with the regular build at 10 wavefronts and 20.2
+                                     at 8; C5, 1280 workgroups: 216.7 against 198.3 with 10, 184.4 with 8, regular build 185 at 8) */
 #define PDMPC_MAX_WAVES 16
 #define PDMPC_QUEUE_HEAP 0     /* open list = libstdc++-faithful binary heap (exact for any keys) */
 #define PDMPC_QUEUE_BLOCKMIN 1 /* open list = block-min queue while the minimal key is unique, binary heap after the first tie */

@@ -1870,9 +1870,9 @@ extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) void pdmpc_search_ker
 extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) void pdmpc_search_kernel_sat_wide(const KernelArgs A) { search_body<PDMPC_CHECK_SAT, 0>(A); }
 
 // The same kernels compiled for six wavefronts per SIMD (at most 80 VGPRs instead of 90): two workgroups of twelve
-// wavefronts fit on a CU.  For launches whose workgroups queue for a slot (more than two per CU), where the total work
-// decides: C5 216.7 steps/s against 184.4 with the regular build at eight wavefronts (which is 2 % faster when a
-// workgroup has its CU to itself, and 3 % faster at two workgroups per CU).
+// wavefronts fit on a CU.  For launches with more workgroups than CUs (C4: 26.3 steps/s against 23.8 with the regular
+// build at ten wavefronts; C5: 216.7 against 185 at eight).  With a CU to itself a workgroup is 2 % faster in the regular
+// build.
 #define PDMPC_DENSE __attribute__((amdgpu_waves_per_eu(6, 6)))
 extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) PDMPC_DENSE void pdmpc_search_kernel_dense(const KernelArgs A) { search_body<PDMPC_CHECK_INTERX, 1>(A); }
 extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) PDMPC_DENSE void pdmpc_search_kernel_sat_dense(const KernelArgs A) { search_body<PDMPC_CHECK_SAT, 1>(A); }
