@@ -9,16 +9,31 @@
 //   C2 = (y1_i*dx2_j - x1_i*dy2_j - S2_j) * (y1_{i+1}*dx2_j - x1_{i+1}*dy2_j - S2_j) < 0     (strict; NaN -> false)
 // Pass 1 (one lane per obstacle segment j) evaluates C2 for every shape segment i and keeps a 7-bit mask; lanes with
 // a non-zero mask append (j, mask, shape) to a compact list.  Pass 2 evaluates C1 for the listed pairs only.
-// Pass 1 over one soup range: sh2 holds shape A in [0, VMAX) and shape B in [VMAX, 2*VMAX).
-__device__ __forceinline__ int interx_pass1(const lds_d2* sh2, int shapeB, int V, const lds_d2* soup, int start, int M, lds_u32* cand, int count, int lane) {
-    if (M < 2) return count;
-    const lds_d2* L2 = soup + start;
-    const lds_d2* sh = sh2 + shapeB * PDMPC_VMAX;
-    for (int base = 0; base < M - 1; base += PDMPC_WAVE) {
-        const int j = base + lane;
+// sh2 holds shape A in [0, VMAX) and shape B in [VMAX, 2*VMAX).
+__device__ bool interx_check(const lds_d2* sh2, int V, const lds_d2* soup, int so, int M_k, int ho, int Hk, int lo, int Ml, lds_u32* cand, int lane) {
+    if (V < 2) return false;
+    // Pass 1 over the segments of all three soups as one index space: ceil(total / 64) rounds instead of one set of rounds
+    // per soup (the soups are short: ~60 obstacle points and ~30 boundary points make two rounds instead of two plus a
+    // nearly empty third; a lane picks its soup and the shape that goes with it).
+    const int n0 = M_k > 1 ? M_k - 1 : 0, n1 = Hk > 1 ? Hk - 1 : 0, n2 = Ml > 1 ? Ml - 1 : 0;
+    const int T = n0 + n1 + n2;
+    int count = 0;
+    for (int base = 0; base < T; base += PDMPC_WAVE) {
+        const int t = base + lane;
         uint32_t bits = 0;
-        if (j < M - 1) {
-            const d2 q0 = L2[j], q1 = L2[j + 1];
+        int j = 0;
+        uint32_t shapeB = 0;
+        if (t < T) {
+            if (t < n0) {
+                j = so + t;
+            } else if (t < n0 + n1) {
+                j = ho + (t - n0);
+            } else {
+                j = lo + (t - n0 - n1);
+                shapeB = 1;
+            }
+            const lds_d2* sh = sh2 + shapeB * PDMPC_VMAX;
+            const d2 q0 = soup[j], q1 = soup[j + 1];
             const double dx2 = q1.x - q0.x, dy2 = q1.y - q0.y;
             const double S2 = dx2 * q0.y - dy2 * q0.x;
             d2 p = sh[0];
@@ -34,20 +49,11 @@ __device__ __forceinline__ int interx_pass1(const lds_d2* sh2, int shapeB, int V
         if (b) {
             if (bits) {
                 const int pos = count + (int)__builtin_popcountll(b & ((1ull << lane) - 1ull));
-                cand[pos] = (uint32_t)(start + j) | (bits << 16) | ((uint32_t)shapeB << 24);
+                cand[pos] = (uint32_t)j | (bits << 16) | (shapeB << 24);
             }
             count += (int)__builtin_popcountll(b);
         }
     }
-    return count;
-}
-
-__device__ bool interx_check(const lds_d2* sh2, int V, const lds_d2* soup, int so, int M_k, int ho, int Hk, int lo, int Ml, lds_u32* cand, int lane) {
-    if (V < 2) return false;
-    int count = 0;
-    count = interx_pass1(sh2, 0, V, soup, so, M_k, cand, count, lane);
-    if (Hk > 0) count = interx_pass1(sh2, 0, V, soup, ho, Hk, cand, count, lane);
-    count = interx_pass1(sh2, 1, V, soup, lo, Ml, cand, count, lane);
     if (count == 0) return false;
     __builtin_amdgcn_wave_barrier();
     for (int base = 0; base < count; base += PDMPC_WAVE) {
