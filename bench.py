@@ -115,14 +115,14 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--record", type=int, default=20, help="distinct recorded time steps kept resident in HBM")
     ap.add_argument("--skip", type=int, default=20, help="closed-loop steps dropped before recording")
-    ap.add_argument("--max-nodes", type=int, default=1 << 17)
+    ap.add_argument("--max-nodes", type=int, default=0, help="initial per-vehicle arena (0: 1<<17 for c2, 1<<16 otherwise); grows while recording if a search needs more")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
-    ap.add_argument("--priorities", default="constant", choices=["constant", "coloring", "random", "fca"],
+    ap.add_argument("--priorities", default=None, choices=["constant", "coloring", "random", "fca"],
                     help="priority strategy of the host driver: vehicle index (ConstantPrioritizer.m), graph colouring "
                     "(ColoringPrioritizer.m), random per step (RandomPrioritizer.m), future collision assessment (FcaPrioritizer.m)")
-    ap.add_argument("--max-levels", type=int, default=99,
+    ap.add_argument("--max-levels", type=int, default=None,
                     help="options.max_num_CLs (Config.m:28): couplings that do not fit into this many computation levels are cut "
                     "(GreedyCutter.m) and handled as parallel couplings")
     ap.add_argument("--instances", type=int, default=64, help="c5: simultaneous prioritizations per time step")
@@ -130,15 +130,27 @@ def main():
                     help="multi-GPU mode of c3/c4: whole coupling-graph components per rank (one speculative launch per rank and step, one "
                     "all-gather of results) or block-partitioned levels (one all-gather per level)")
     args = ap.parse_args()
+    # BASELINE.json configs as named: C3 = 128 vehicles, Hp 8, colouring priorities cut to a 2-level coupling DAG
+    # (max_num_CLs = 2, Config.m:28; the cut couplings become previous-trajectory obstacles, PrioritizedController.m:409-447);
+    # C4 = 512 vehicles, Hp 10, graph-colouring levels (ColoringPrioritizer.m:31-89 + kahn.m); C2 / C5 = constant priorities, no cut
     if args.workload == "c3":
         args.vehicles, args.hp = 128, 8
+        defaults = ("coloring", 2)
     elif args.workload == "c4":
         args.vehicles, args.hp = 512, 10
+        defaults = ("coloring", 99)
+    else:
+        defaults = ("constant", 99)
+    if args.priorities is None:
+        args.priorities = defaults[0]
+    if args.max_levels is None:
+        args.max_levels = defaults[1]
     sharded = args.workload != "c2"
     if sharded:
         args.record = min(args.record, 8)
         args.skip = min(args.skip, 4)
-        args.max_nodes = min(args.max_nodes, 1 << 15)
+    if args.max_nodes <= 0:
+        args.max_nodes = (1 << 17) if args.workload == "c2" else (1 << 16)
     explore = args.workload == "c5"
 
     rank = int(os.environ.get("RANK", "0"))
@@ -174,19 +186,33 @@ def main():
         problems = [sub_problem(p, parts[b][rank]) for b, p in enumerate(full_problems)]
     # keep every recorded step resident in HBM (one bank each) and collect its algorithmic bytes
     bytes_per_bank, pops_per_bank, nodes_per_bank = [], [], []
+    status_counts = {"ok": 0, "exhausted": 0, "arena_overflow": 0, "error": 0}
+    h.allow_overflow = True  # counted below (and grown away), not raised
     t_host = time.perf_counter()
+    t_grow = 0.0
     for b, prob in enumerate(problems):
         h.select_bank(b)
         fb = [f if f is not None else [] for f in prob["fallback"]]
         h.pack_step(prob["iters"], prob["preds"], fb)
-        h.launch()
-        h.fetch(len(prob["iters"]))
+        while True:
+            h.launch()
+            recs = h.fetch(len(prob["iters"]))
+            if not (recs["status"] == 2).any():
+                break
+            # the reference's tree is unbounded (Tree.m:54-70): never measure truncated searches -- double the arenas, plan again
+            tg = time.perf_counter()
+            h.grow_arena(2 * h.arena_nodes()[0])
+            t_grow += time.perf_counter() - tg
+        status_counts["ok"] += int((recs["status"] == 0).sum())
+        status_counts["exhausted"] += int((recs["status"] == 1).sum())
+        status_counts["error"] += int((recs["status"] < 0).sum())
         st = h.stats()
         bytes_per_bank.append(st["algorithmic_bytes"])
         pops_per_bank.append(st["nodes_popped"])
         nodes_per_bank.append(st["nodes_generated"])
+    # a bank recorded before the arenas grew replays in the grown arenas: same searches, none of them truncated
     lds_bytes = h.stats()["lds_bytes"]
-    host_buffer_ms = 1e3 * (time.perf_counter() - t_host) / max(S, 1)  # pack (host buffers -> HBM) + launch + fetch + stats
+    host_buffer_ms = 1e3 * (time.perf_counter() - t_host - t_grow) / max(S, 1)  # pack (host buffers -> HBM) + launch + fetch + stats
 
     planner = None
     gather_bufs = None
@@ -297,6 +323,9 @@ def main():
                 "lds_bytes_per_workgroup": lds_bytes,
                 "open_list": "block-min queue, %d keys in LDS" % st["queue_ring_entries"] if st["queue_mode"] == 1 else "binary heap",
             },
+            # every plan of the recorded steps by outcome; arena_overflow must be 0 (the reference's tree is unbounded, Tree.m:54-70)
+            "status_counts": status_counts,
+            "arena_nodes_per_vehicle": h.arena_nodes()[0],
             "counters": {
                 "nodes_popped_per_s": pops / elapsed,
                 "nodes_generated_per_s": nodes / elapsed,
@@ -314,6 +343,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(options, mpa, full_problems, args.cpu_budget_s)
         print(json.dumps(out))
+        if status_counts["arena_overflow"] or status_counts["error"]:
+            raise SystemExit("bench.py: %d plans overflowed their arena, %d carried an error status -- the measurement is void" % (status_counts["arena_overflow"], status_counts["error"]))
     if dist is not None:
         dist.destroy_process_group()
 

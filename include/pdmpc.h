@@ -37,7 +37,8 @@ extern "C" {
 enum {
     PDMPC_OK = 0,
     PDMPC_EXHAUSTED = 1,        /* per vehicle: open list ran empty == info.is_exhausted (GraphSearch.m:57-61) */
-    PDMPC_ARENA_OVERFLOW = 2,   /* per vehicle: search tree outgrew config.max_nodes (the reference tree is unbounded, Tree.m:54-70) */
+    PDMPC_ARENA_OVERFLOW = 2,   /* per vehicle: search tree outgrew its arena and could not be grown further (see pdmpc_set_arena_limit);
+                                   NOT an exhaustion: the reference tree is unbounded (Tree.m:54-70) and would have kept searching */
     PDMPC_ERR_INVALID = -1,     /* bad argument / inconsistent sizes */
     PDMPC_ERR_NO_DEVICE = -2,   /* no gfx950 device, or the HIP code object failed to load */
     PDMPC_ERR_HIP = -3,         /* a HIP runtime call failed; see pdmpc_last_error() */
@@ -168,6 +169,22 @@ int pdmpc_upload_mpa(pdmpc_handle* handle, const pdmpc_mpa* mpa);
  * GraphSearch.run_optimizer (GraphSearch.m:14-17). */
 int pdmpc_plan_batch(pdmpc_handle* handle, int32_t n_vehicles, const pdmpc_vehicle_in* in,
                      pdmpc_vehicle_out* out);
+
+/* Arena growth.  The reference's search tree is unbounded (Tree.m:54-70: add_nodes appends); this backend keeps the tree of
+ * every vehicle in a fixed HBM arena of config.max_nodes nodes.  pdmpc_plan_batch / pdmpc_plan_step therefore re-plan a
+ * call in which some search outgrew its arena with arenas twice as large (the searches are deterministic: vehicles that
+ * fitted produce the same records again), repeatedly, until every search fits.  PDMPC_ARENA_OVERFLOW is only ever
+ * returned when the limit set here is reached (max_nodes_limit == current size: growth off; 0: up to what HBM holds). */
+int pdmpc_set_arena_limit(pdmpc_handle* handle, int32_t max_nodes_limit);
+/* explicit growth for the device-resident path below (launch / fetch do not grow by themselves) */
+int pdmpc_grow_arena(pdmpc_handle* handle, int32_t max_nodes);
+/* current per-vehicle arena size and how often a call had to be re-planned with larger arenas since pdmpc_create */
+int pdmpc_arena_nodes(pdmpc_handle* handle, int32_t* max_nodes, int64_t* regrows);
+
+/* A whole time step in one call (PrioritizedSequentialController.controller, :77-94): pdmpc_pack_step + launch + fetch,
+ * with arena growth as above.  Arguments as for pdmpc_pack_step (below). */
+int pdmpc_plan_step(pdmpc_handle* handle, int32_t n_vehicles, const pdmpc_vehicle_in* in, const int32_t* pred_offset,
+                    const int32_t* pred_index, const pdmpc_polygon_set* fallback_shapes, pdmpc_vehicle_out* out);
 
 /* ---- device-resident path used by the batched host driver and bench.py ----
  * pdmpc_pack_batch flattens host inputs into the handle's device blob (H2D copy, async on the

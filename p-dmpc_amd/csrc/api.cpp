@@ -57,6 +57,16 @@ struct DevBuf {
         cap = want;
         return 0;
     }
+    int ensure_exact(size_t n) {  // no head room: the arenas are sized in gigabytes
+        if (n <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc((void**)&p, std::max(n, (size_t)64) * sizeof(T));
+        if (e != hipSuccess) return (int)e;
+        cap = std::max(n, (size_t)64);
+        return 0;
+    }
     void release() {
         if (p) (void)hipFree(p);
         p = nullptr;
@@ -128,6 +138,8 @@ struct pdmpc_handle {
     int64_t mpa_alg_bytes = 0;
     // arenas
     uint32_t max_nodes = 0;
+    uint32_t max_nodes_limit = 0;  // pdmpc_plan_* may grow the arenas up to this many nodes per vehicle (0: as far as HBM allows)
+    int64_t arena_regrows = 0;     // times an overflowed call was re-planned with larger arenas
     int max_vehicles = 0;
     DevBuf<NodeRec> anodes;
     DevBuf<double> ahk;
@@ -399,6 +411,23 @@ int pack_common(pdmpc_handle* h, int n, const pdmpc_vehicle_in* in, const int32_
     return PDMPC_OK;
 }
 
+// per-vehicle arenas for `nodes` tree nodes each (contents are scratch: every search starts from an empty tree)
+int alloc_arenas(pdmpc_handle* h, uint32_t nodes) {
+    nodes = (nodes + 1u) & ~1u;
+    const size_t tot = (size_t)h->max_vehicles * nodes;
+    h->anodes.release();
+    h->ahk.release();
+    h->ahid.release();
+    h->avs.release();
+    h->alog.release();
+    h->max_nodes = 0;
+    int bad = 0;
+    bad |= h->anodes.ensure_exact(tot) | h->ahk.ensure_exact(tot) | h->ahid.ensure_exact(tot) | h->avs.ensure_exact(tot) | h->alog.ensure_exact(tot);
+    if (bad) return bad;
+    h->max_nodes = nodes;
+    return 0;
+}
+
 int launch_range(pdmpc_handle* h, int first, int count) {
     if (!h) return fail(PDMPC_ERR_INVALID, "null handle");
     PackedStep& B = h->banks[h->bank];
@@ -515,17 +544,14 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
     if (const char* e = getenv("PDMPC_SPEC_EXPAND")) h->speculate_expansion = atoi(e) != 0;  // likewise
     if (const char* e = getenv("PDMPC_QUEUE")) h->queue_mode = atoi(e) != 0 ? PDMPC_QUEUE_BLOCKMIN : PDMPC_QUEUE_HEAP;  // likewise
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    h->max_nodes = config->max_nodes > 0 ? (uint32_t)config->max_nodes : 32768u;  // default arena: 256 x 32768 nodes, about 0.6 GB
-    h->max_nodes = (h->max_nodes + 1u) & ~1u;
+    const uint32_t want_nodes = config->max_nodes > 0 ? (uint32_t)config->max_nodes : 32768u;  // default arena: 256 x 32768 nodes, about 0.6 GB
     h->max_vehicles = config->max_vehicles > 0 ? config->max_vehicles : 256;
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete h;
         return fail(PDMPC_ERR_HIP, "hipStreamCreate failed");
     }
-    const size_t tot = (size_t)h->max_vehicles * h->max_nodes;
-    int bad = 0;
-    bad |= h->anodes.ensure(tot) | h->ahk.ensure(tot) | h->ahid.ensure(tot) | h->avs.ensure(tot) | h->alog.ensure(tot);
+    int bad = alloc_arenas(h, want_nodes);
     bad |= h->d_out.ensure((size_t)h->max_vehicles) | h->d_flag.ensure((size_t)h->max_vehicles) | h->d_tree_size.ensure((size_t)h->max_vehicles) | h->d_tie_count.ensure(4) | h->d_work_count.ensure(4);
     bad |= h->d_trace.ensure((size_t)h->max_vehicles * (size_t)std::max(config->trace_pops, 1));
     if (bad) {
@@ -718,12 +744,74 @@ int pdmpc_fetch_results(pdmpc_handle* h, int32_t n, pdmpc_vehicle_out* out) {
     return PDMPC_OK;
 }
 
+namespace {
+// The reference's tree grows without bound (Tree.m:54-70); the arenas here are finite.  A call whose search outgrows them
+// is planned again from scratch with arenas twice as large (searches are deterministic, so the vehicles that did fit
+// produce the same records again) until it fits, the limit set with pdmpc_set_arena_limit is reached, or HBM runs out.
+int plan_packed_growing(pdmpc_handle* h, int32_t n, pdmpc_vehicle_out* out) {
+    for (;;) {
+        int rc = pdmpc_launch_packed(h);
+        if (rc) return rc;
+        rc = pdmpc_fetch_results(h, n, out);
+        if (rc) return rc;
+        bool overflow = false;
+        for (int i = 0; i < n; ++i) overflow = overflow || out[i].status == PDMPC_ARENA_OVERFLOW;
+        if (!overflow) return PDMPC_OK;
+        const uint64_t next = (uint64_t)h->max_nodes * 2u;
+        if ((h->max_nodes_limit && next > h->max_nodes_limit) || next > (1ull << 30)) return PDMPC_OK;  // statuses tell
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        const size_t per_node = sizeof(NodeRec) + 8 + 4 + 8 + 1;
+        const size_t have = (size_t)h->max_vehicles * h->max_nodes * per_node;
+        if ((size_t)h->max_vehicles * next * per_node > free_b + have) return PDMPC_OK;  // no room to grow
+        const uint32_t before = h->max_nodes;
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (alloc_arenas(h, (uint32_t)next)) {
+            if (alloc_arenas(h, before)) return fail(PDMPC_ERR_HIP, "hipMalloc failed while restoring the arenas");
+            return PDMPC_OK;
+        }
+        h->arena_regrows += 1;
+    }
+}
+}  // namespace
+
 int pdmpc_plan_batch(pdmpc_handle* h, int32_t n, const pdmpc_vehicle_in* in, pdmpc_vehicle_out* out) {
     int rc = pdmpc_pack_batch(h, n, in);
     if (rc) return rc;
-    rc = pdmpc_launch_packed(h);
+    return plan_packed_growing(h, n, out);
+}
+
+int pdmpc_plan_step(pdmpc_handle* h, int32_t n, const pdmpc_vehicle_in* in, const int32_t* pred_offset, const int32_t* pred_index,
+                    const pdmpc_polygon_set* fallback_shapes, pdmpc_vehicle_out* out) {
+    int rc = pdmpc_pack_step(h, n, in, pred_offset, pred_index, fallback_shapes);
     if (rc) return rc;
-    return pdmpc_fetch_results(h, n, out);
+    return plan_packed_growing(h, n, out);
+}
+
+int pdmpc_set_arena_limit(pdmpc_handle* h, int32_t max_nodes_limit) {
+    if (!h || max_nodes_limit < 0) return fail(PDMPC_ERR_INVALID, "bad argument");
+    h->max_nodes_limit = (uint32_t)max_nodes_limit;
+    return PDMPC_OK;
+}
+
+int pdmpc_grow_arena(pdmpc_handle* h, int32_t max_nodes) {
+    if (!h || max_nodes <= 0) return fail(PDMPC_ERR_INVALID, "bad argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if ((uint32_t)max_nodes <= h->max_nodes) return PDMPC_OK;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const uint32_t before = h->max_nodes;
+    if (alloc_arenas(h, (uint32_t)max_nodes)) {
+        if (alloc_arenas(h, before)) return fail(PDMPC_ERR_HIP, "hipMalloc failed while restoring the arenas");
+        return fail(PDMPC_ERR_CAPACITY, "not enough HBM for arenas of that size");
+    }
+    return PDMPC_OK;
+}
+
+int pdmpc_arena_nodes(pdmpc_handle* h, int32_t* max_nodes, int64_t* regrows) {
+    if (!h) return fail(PDMPC_ERR_INVALID, "null handle");
+    if (max_nodes) *max_nodes = (int32_t)h->max_nodes;
+    if (regrows) *regrows = h->arena_regrows;
+    return PDMPC_OK;
 }
 
 namespace {

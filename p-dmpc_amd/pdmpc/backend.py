@@ -31,6 +31,10 @@ EXPORTS = [
     "pdmpc_fetch_results",
     "pdmpc_synchronize",
     "pdmpc_pack_step",
+    "pdmpc_plan_step",
+    "pdmpc_set_arena_limit",
+    "pdmpc_grow_arena",
+    "pdmpc_arena_nodes",
     "pdmpc_result_device_buffer",
     "pdmpc_import_results",
     "pdmpc_export_results",
@@ -80,6 +84,10 @@ def load_library(path=None):
     L.pdmpc_fetch_results.argtypes = [H, C.c_int32, C.POINTER(abi.VehicleOut)]
     L.pdmpc_synchronize.argtypes = [H]
     L.pdmpc_pack_step.argtypes = [H, C.c_int32, C.POINTER(abi.VehicleIn), abi.c_int32_p, abi.c_int32_p, C.POINTER(abi.PolygonSet)]
+    L.pdmpc_plan_step.argtypes = [H, C.c_int32, C.POINTER(abi.VehicleIn), abi.c_int32_p, abi.c_int32_p, C.POINTER(abi.PolygonSet), C.POINTER(abi.VehicleOut)]
+    L.pdmpc_set_arena_limit.argtypes = [H, C.c_int32]
+    L.pdmpc_grow_arena.argtypes = [H, C.c_int32]
+    L.pdmpc_arena_nodes.argtypes = [H, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     L.pdmpc_result_device_buffer.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.pdmpc_import_results.argtypes = [H, C.c_int32, C.c_int32, C.c_void_p]
     L.pdmpc_export_results.argtypes = [H, C.c_int32, C.c_int32, C.c_void_p]
@@ -123,6 +131,7 @@ class Handle:
             max_vehicles=options.max_vehicles,
             trace_pops=options.trace_pops,
         )
+        self.allow_overflow = False  # tests of the overflow status itself switch this on
         self.h = C.c_void_p()
         _check(self.L, self.L.pdmpc_create(C.byref(self.cfg), C.byref(self.h)), "pdmpc_create")
         self._mpa_keep = None
@@ -150,7 +159,7 @@ class Handle:
         out = abi.out_array(n)
         _check(self.L, self.L.pdmpc_plan_batch(self.h, n, arr, abi.out_ptr(out)), "pdmpc_plan_batch")
         del keep
-        return out[:n]
+        return self._checked(out[:n])
 
     def plan_batch_sampled(self, iters, seeds):
         """The sampled optimizer for one computation level; seeds[i] = time_step + vehicle_index (MonteCarloTreeSearch.m:32)."""
@@ -171,6 +180,16 @@ class Handle:
     def pack_step(self, iters, predecessors, fallback_shapes=None):
         """predecessors: list (per vehicle) of lists of 0-based vehicle indices in this batch."""
         n = len(iters)
+        arr, off, idx, fb, keep = self._step_args(iters, predecessors, fallback_shapes)
+        _check(
+            self.L,
+            self.L.pdmpc_pack_step(self.h, n, arr, off.ctypes.data_as(abi.c_int32_p), idx.ctypes.data_as(abi.c_int32_p), fb),
+            "pdmpc_pack_step",
+        )
+        del keep
+
+    def _step_args(self, iters, predecessors, fallback_shapes):
+        n = len(iters)
         arr, keep = abi.pack_vehicles(iters, self.Hp)
         off = np.zeros(n + 1, dtype=np.int32)
         for i, p in enumerate(predecessors):
@@ -181,12 +200,41 @@ class Handle:
             fb = (abi.PolygonSet * n)()
             for i, shapes in enumerate(fallback_shapes):
                 fb[i] = abi.pack_polygon_set(list(shapes), keep)
+        return arr, off, idx, fb, keep
+
+    def plan_step(self, iters, predecessors, fallback_shapes=None):
+        """A whole time step in one call (pdmpc_plan_step): pack + launch + fetch, arenas grow if a search needs it."""
+        n = len(iters)
+        arr, off, idx, fb, keep = self._step_args(iters, predecessors, fallback_shapes)
+        out = abi.out_array(n)
         _check(
             self.L,
-            self.L.pdmpc_pack_step(self.h, n, arr, off.ctypes.data_as(abi.c_int32_p), idx.ctypes.data_as(abi.c_int32_p), fb),
-            "pdmpc_pack_step",
+            self.L.pdmpc_plan_step(self.h, n, arr, off.ctypes.data_as(abi.c_int32_p), idx.ctypes.data_as(abi.c_int32_p), fb, abi.out_ptr(out)),
+            "pdmpc_plan_step",
         )
         del keep
+        return self._checked(out[:n])
+
+    def _checked(self, recs):
+        """Only PDMPC_EXHAUSTED is a planning result (info.is_exhausted); anything else is an error of this backend."""
+        st = np.asarray(recs["status"])
+        if ((st != abi.OK) & (st != abi.EXHAUSTED)).any() and not self.allow_overflow:
+            bad = int(st[(st != abi.OK) & (st != abi.EXHAUSTED)][0])
+            if bad == abi.ARENA_OVERFLOW:
+                raise BackendError("a search outgrew its arena (%d nodes per vehicle) and the arena limit forbids growing it" % self.arena_nodes()[0])
+            raise BackendError("device-side error status %d in a result record (predecessor wait timed out?)" % bad)
+        return recs
+
+    def set_arena_limit(self, max_nodes_limit):
+        _check(self.L, self.L.pdmpc_set_arena_limit(self.h, int(max_nodes_limit)), "pdmpc_set_arena_limit")
+
+    def grow_arena(self, max_nodes):
+        _check(self.L, self.L.pdmpc_grow_arena(self.h, int(max_nodes)), "pdmpc_grow_arena")
+
+    def arena_nodes(self):
+        n, r = C.c_int32(), C.c_int64()
+        _check(self.L, self.L.pdmpc_arena_nodes(self.h, C.byref(n), C.byref(r)), "pdmpc_arena_nodes")
+        return n.value, r.value
 
     def launch(self):
         _check(self.L, self.L.pdmpc_launch_packed(self.h), "pdmpc_launch_packed")
@@ -209,7 +257,7 @@ class Handle:
     def fetch(self, n):
         out = abi.out_array(n)
         _check(self.L, self.L.pdmpc_fetch_results(self.h, n, abi.out_ptr(out)), "pdmpc_fetch_results")
-        return out[:n]
+        return self._checked(out[:n])
 
     def result_device_buffer(self):
         p = C.c_void_p()

@@ -60,7 +60,11 @@ class ControlResultsInfo:
 def info_from_record(rec, Hp: int) -> ControlResultsInfo:
     """Decode one pdmpc_vehicle_out record (numpy structured scalar, abi.VEHICLE_OUT_DTYPE)."""
     status = int(rec["status"])
-    exhausted = status != 0
+    if status not in (0, 1):
+        # PDMPC_ARENA_OVERFLOW (the reference's unbounded tree would have kept searching, Tree.m:54-70) and device-side error
+        # statuses are not planning results: they must not be mistaken for an exhausted open list (GraphSearch.m:57-61)
+        raise ValueError("result record carries status %d: not a planning result" % status)
+    exhausted = status == 1
     y = np.full((3, Hp), np.nan)
     shapes: List[np.ndarray] = []
     trims = np.zeros(Hp, dtype=np.int64)

@@ -151,10 +151,31 @@ def test_exhaustion_and_overflow_status():
     options2.max_vehicles = 4
     h = Handle(options2)
     h.upload_mpa(mpa2)
+    h.set_arena_limit(64)  # growth off: the status itself is under test
+    h.allow_overflow = True
     gpu2 = h.plan_batch(iters2)
     _, ref2, _ = oracle.plan_batch(options2, mpa2, iters2)
     assert_records_equal(gpu2, ref2, "overflow")
     assert (gpu2["status"] == abi.ARENA_OVERFLOW).any()
+    h.close()
+
+
+def test_arena_grows_like_the_reference_tree():
+    """The reference's tree is unbounded (Tree.m:54-70).  A handle created with a tiny arena re-plans overflowed calls
+    with doubled arenas until every search fits: the records equal the oracle's with an effectively unbounded tree."""
+    options, mpa, iters = problems.problem_set("interx", 22, 6, Hp=6)
+    oracle = _oracle()
+    options.max_nodes = 1 << 22
+    _, ref, _ = oracle.plan_batch(options, mpa, iters)
+    assert (ref["status"] != abi.ARENA_OVERFLOW).all()
+    options.max_nodes = 64
+    options.max_vehicles = 8
+    h = Handle(options)
+    h.upload_mpa(mpa)
+    gpu = h.plan_batch(iters)
+    assert_records_equal(gpu, ref, "grown arena")
+    nodes, regrows = h.arena_nodes()
+    assert regrows >= 1 and nodes >= int(ref["n_expanded"].max())
     h.close()
 
 
