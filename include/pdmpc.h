@@ -225,6 +225,13 @@ int pdmpc_import_results(pdmpc_handle* handle, int32_t first, int32_t n, const v
  * buffer of the all-gather) and waits for the copy, so the buffer can be handed to another stream */
 int pdmpc_export_results(pdmpc_handle* handle, int32_t first, int32_t n, void* dev_records);
 
+/* the same without the wait: the copy is only ordered on the handle's stream (see pdmpc_stream) */
+int pdmpc_export_results_async(pdmpc_handle* handle, int32_t first, int32_t n, void* dev_records);
+/* The HIP stream (hipStream_t) every launch and copy of this handle is enqueued on.  A caller that exchanges records
+ * between GPUs enqueues its collective on THIS stream (e.g. torch.cuda.ExternalStream around it), so export -> all-gather
+ * -> import -> next launch are ordered by the stream itself, with no host synchronisation and no cross-stream race. */
+int pdmpc_stream(pdmpc_handle* handle, void** hip_stream);
+
 int pdmpc_get_last_stats(pdmpc_handle* handle, pdmpc_stats* stats);
 
 /* ---- debug / parity instrumentation (no reference counterpart: the reference keeps the whole

@@ -892,6 +892,20 @@ int pdmpc_export_results(pdmpc_handle* h, int32_t first, int32_t n, void* dev_re
     return PDMPC_OK;
 }
 
+int pdmpc_export_results_async(pdmpc_handle* h, int32_t first, int32_t n, void* dev_records) {
+    if (!h || (n > 0 && !dev_records)) return fail(PDMPC_ERR_INVALID, "null argument");
+    if (first < 0 || n < 0 || first + n > h->max_vehicles) return fail(PDMPC_ERR_INVALID, "slot range out of bounds");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if (n > 0) HIPCHK(hipMemcpyAsync(dev_records, h->d_out.p + first, (size_t)n * sizeof(pdmpc_vehicle_out), hipMemcpyDeviceToDevice, h->stream));
+    return PDMPC_OK;
+}
+
+int pdmpc_stream(pdmpc_handle* h, void** hip_stream) {
+    if (!h || !hip_stream) return fail(PDMPC_ERR_INVALID, "null argument");
+    *hip_stream = (void*)h->stream;
+    return PDMPC_OK;
+}
+
 int pdmpc_get_last_stats(pdmpc_handle* h, pdmpc_stats* stats) {
     if (!h || !stats) return fail(PDMPC_ERR_INVALID, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device));

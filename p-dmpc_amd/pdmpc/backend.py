@@ -38,6 +38,8 @@ EXPORTS = [
     "pdmpc_result_device_buffer",
     "pdmpc_import_results",
     "pdmpc_export_results",
+    "pdmpc_export_results_async",
+    "pdmpc_stream",
     "pdmpc_get_last_stats",
     "pdmpc_debug_heap_script",
     "pdmpc_debug_blockmin_script",
@@ -91,6 +93,8 @@ def load_library(path=None):
     L.pdmpc_result_device_buffer.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.pdmpc_import_results.argtypes = [H, C.c_int32, C.c_int32, C.c_void_p]
     L.pdmpc_export_results.argtypes = [H, C.c_int32, C.c_int32, C.c_void_p]
+    L.pdmpc_export_results_async.argtypes = [H, C.c_int32, C.c_int32, C.c_void_p]
+    L.pdmpc_stream.argtypes = [H, C.POINTER(C.c_void_p)]
     L.pdmpc_plan_batch_sampled.argtypes = [H, C.c_int32, C.POINTER(abi.VehicleIn), C.POINTER(C.c_uint32), C.POINTER(abi.VehicleOut)]
     L.pdmpc_get_last_stats.argtypes = [H, C.POINTER(abi.Stats)]
     L.pdmpc_debug_heap_script.argtypes = [H, C.c_int32, abi.c_int32_p, abi.c_int32_p, abi.c_double_p, C.c_int32, abi.c_int32_p, abi.c_int32_p, abi.c_double_p, abi.c_double_p]
@@ -270,6 +274,14 @@ class Handle:
 
     def export_results(self, first, n, dev_ptr):
         _check(self.L, self.L.pdmpc_export_results(self.h, first, n, C.c_void_p(dev_ptr)), "pdmpc_export_results")
+
+    def export_results_async(self, first, n, dev_ptr):
+        _check(self.L, self.L.pdmpc_export_results_async(self.h, first, n, C.c_void_p(dev_ptr)), "pdmpc_export_results_async")
+
+    def stream_ptr(self):
+        p = C.c_void_p()
+        _check(self.L, self.L.pdmpc_stream(self.h, C.byref(p)), "pdmpc_stream")
+        return p.value or 0
 
     def stats(self):
         s = abi.Stats()

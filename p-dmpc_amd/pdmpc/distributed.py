@@ -32,7 +32,13 @@ def level_partition(first, size, world):
 
 
 class HipRangePlanner:
-    """Plans slot ranges on this rank's GPU through the C ABI; records stay in HBM."""
+    """Plans slot ranges on this rank's GPU through the C ABI; records stay in HBM.
+
+    Stream discipline: every copy, launch and collective of a step is enqueued on the handle's own HIP stream (wrapped as
+    a torch ExternalStream, pdmpc_stream), so export -> all-gather -> import -> next level's launch are ordered by the
+    stream itself.  (RCCL orders a collective against the *current* torch stream only; the handle's stream is created
+    non-blocking, so enqueueing the import there while the collective ran elsewhere would read the receive buffer before
+    the other ranks' records have arrived.)  The send / receive buffers are allocated once per planner."""
 
     def __init__(self, optimizer, mpa, device):
         import torch
@@ -42,6 +48,12 @@ class HipRangePlanner:
         self.opt._ensure_mpa(mpa)
         self.h = optimizer.handle
         self.device = device
+        self.stream = torch.cuda.ExternalStream(self.h.stream_ptr(), device=device)
+        self._send = None
+        self._recv = None
+
+    def stream_context(self):
+        return self.torch.cuda.stream(self.stream)
 
     def begin(self, problem):
         fb = [f if f is not None else [] for f in problem["fallback"]]
@@ -58,14 +70,22 @@ class HipRangePlanner:
         self.h.select_bank(bank)
         self.h.begin_step()
 
-    def new_buffer(self, n_records):
-        return self.torch.zeros(max(n_records, 1) * REC_BYTES, dtype=self.torch.uint8, device=self.device)
+    def buffers(self, per, world):
+        """(send, recv) for levels of at most `per` records per rank; grown geometrically, zero-filled once, and only
+        handed out after the fill has finished (it runs on torch's stream, the copies on the handle's)."""
+        need_s, need_r = max(per, 1) * REC_BYTES, max(per, 1) * world * REC_BYTES
+        if self._send is None or self._send.numel() < need_s or self._recv.numel() < need_r:
+            self._send = self.torch.zeros(2 * need_s, dtype=self.torch.uint8, device=self.device)
+            self._recv = self.torch.zeros(2 * need_r, dtype=self.torch.uint8, device=self.device)
+            self.torch.cuda.synchronize(self.device)
+            self.h.synchronize()
+        return self._send[:need_s], self._recv[:need_r]
 
     def plan_range(self, first, count, send):
-        """Launch slots [first, first+count) and copy their records into the device tensor `send`."""
+        """Launch slots [first, first+count) and enqueue the copy of their records into the device tensor `send`."""
         if count > 0:
             self.h.launch_range(first, count)
-        self.h.export_results(first, count, send.data_ptr())
+            self.h.export_results_async(first, count, send.data_ptr())
 
     def import_records(self, first, count, buf):
         if count > 0:
@@ -73,6 +93,14 @@ class HipRangePlanner:
 
     def fetch(self, n):
         return self.h.fetch(n)
+
+
+class _NoStream:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 def plan_step_sharded(problem, planner, dist, rank, world, resident_bank=None, fetch=True):
@@ -83,19 +111,23 @@ def plan_step_sharded(problem, planner, dist, rank, world, resident_bank=None, f
         planner.begin(problem)
     else:
         planner.begin_resident(resident_bank)
+    per_max = max((level_partition(0, size, world)[0] for size in problem["level_sizes"]), default=0)
+    send_all, recv_all = planner.buffers(per_max, world)
+    ctx = planner.stream_context() if hasattr(planner, "stream_context") else _NoStream()
     first = 0
-    for size in problem["level_sizes"]:
-        per, parts = level_partition(first, size, world)
-        lo, hi = parts[rank]
-        send = planner.new_buffer(per)
-        planner.plan_range(lo, hi - lo, send)
-        if world > 1:
-            recv = planner.new_buffer(per * world)
-            dist.all_gather_into_tensor(recv, send)
-            for r, (rlo, rhi) in enumerate(parts):
-                if r != rank and rhi > rlo:
-                    planner.import_records(rlo, rhi - rlo, recv[r * per * REC_BYTES : (r * per + (rhi - rlo)) * REC_BYTES])
-        first += size
+    with ctx:  # collectives go onto the planner's stream (see HipRangePlanner)
+        for size in problem["level_sizes"]:
+            per, parts = level_partition(first, size, world)
+            lo, hi = parts[rank]
+            send = send_all[: max(per, 1) * REC_BYTES]
+            planner.plan_range(lo, hi - lo, send)
+            if world > 1:
+                recv = recv_all[: max(per, 1) * world * REC_BYTES]
+                dist.all_gather_into_tensor(recv, send)
+                for r, (rlo, rhi) in enumerate(parts):
+                    if r != rank and rhi > rlo:
+                        planner.import_records(rlo, rhi - rlo, recv[r * per * REC_BYTES : (r * per + (rhi - rlo)) * REC_BYTES])
+            first += size
     if not fetch:
         return None
     return planner.fetch(len(problem["iters"]))

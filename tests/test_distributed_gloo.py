@@ -30,6 +30,9 @@ class OracleRangePlanner:
     def new_buffer(self, n):
         return torch.zeros(max(n, 1) * REC_BYTES, dtype=torch.uint8)
 
+    def buffers(self, per, world):
+        return self.new_buffer(per), self.new_buffer(per * world)
+
     def plan_range(self, first, count, send):
         import copy
 

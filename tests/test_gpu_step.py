@@ -1,4 +1,7 @@
 """Whole-step planning in one launch (device-side hand-off of solved areas) vs the oracle's host level loop."""
+import copy
+import os
+
 import numpy as np
 import pytest
 
@@ -12,7 +15,7 @@ from test_gpu_parity import assert_records_equal
 pytestmark = pytest.mark.gpu
 
 
-def run_closed_loop(options, scenario, coupling, boundary, n_steps, **controller_kw):
+def run_closed_loop(options, scenario, coupling, boundary, n_steps, oracle_threads=1, **controller_kw):
     from oracle import oracle
     from pdmpc.optimizer import GraphSearchHip
 
@@ -22,13 +25,16 @@ def run_closed_loop(options, scenario, coupling, boundary, n_steps, **controller
     ctl = PrioritizedSequentialController(options, scenario, mpa, None, coupling=coupling, boundary_provider=boundary, **controller_kw)
     n_checked = [0]
 
+    # the oracle plans with the reference's unbounded tree (Tree.m:54-70); the backend's arenas grow on demand (pdmpc_plan_step)
+    unbounded = copy.copy(options)
+    unbounded.max_nodes = 1 << 30
+
     def plan_step(prob):
         n = len(prob["iters"])
         fb = [f if f is not None else [] for f in prob["fallback"]]
-        opt.handle.pack_step(prob["iters"], prob["preds"], fb)
-        opt.handle.launch()
-        gpu = opt.handle.fetch(n)
-        ref, _ = oracle.plan_step(options, mpa, prob)
+        gpu = opt.handle.plan_step(prob["iters"], prob["preds"], fb)
+        ref, _ = oracle.plan_step(unbounded, mpa, prob, n_threads=oracle_threads)
+        assert (ref["status"] != 2).all()
         assert_records_equal(gpu, ref, "step %d" % n_checked[0])
         n_checked[0] += 1
         return [info_from_record(gpu[i], options.Hp) for i in range(n)]
@@ -131,47 +137,55 @@ def test_sharded_planner_world1_on_gpu_matches_single_launch():
     opt.handle.close()
 
 
-def test_tiled_128_vehicles_hp8_one_launch():
-    """BASELINE config 2 shape: 128 vehicles on tiled copies of the map, Hp 8, whole step in one launch."""
+def test_config_c3_128_vehicles_two_level_coupling_dag():
+    """BASELINE config 2 as named: 128 vehicles on tiled copies of the map, Hp 8, colouring priorities
+    (ColoringPrioritizer.m:31-89), coupling DAG cut to 2 computation levels (max_num_CLs = 2, Config.m:28,
+    GreedyCutter.m:25-86); the cut couplings enter as previous-trajectory obstacles (PrioritizedController.m:409-447).
+    Whole step in one launch, arenas grow on demand, records byte-identical to the oracle's level loop."""
     from pdmpc.road_network import boundary_provider, commonroad_scenario
 
-    options = Config(scenario_type=ScenarioType.commonroad, amount=128, Hp=8, max_vehicles=128, max_nodes=1 << 15)
+    options = Config(scenario_type=ScenarioType.commonroad, amount=128, Hp=8, max_num_CLs=2, max_vehicles=128, max_nodes=1 << 15)
     sc = commonroad_scenario(options, seed=2, tiles=7)
-    run_closed_loop(options, sc, "distance", boundary_provider(sc), 3)
+    ctl = run_closed_loop(options, sc, "distance", boundary_provider(sc), 4, oracle_threads=os.cpu_count() or 1, priority_strategy="coloring")
+    assert int(ctl.last_levels.max()) == 2
 
 
-def test_tiled_512_vehicles_hp10_one_launch():
-    """BASELINE config 3 shape: 512 vehicles, Hp 10 (two workgroups per CU, 80 KB of LDS each)."""
+def test_config_c4_512_vehicles_hp10_colouring_levels():
+    """BASELINE config 3 as named: 512 vehicles, Hp 10, computation levels from graph colouring + kahn
+    (ColoringPrioritizer.m:31-89, utility/kahn.m:1-24); two workgroups per CU.  The arenas start small and grow until no
+    search overflows, as the reference's unbounded tree would (Tree.m:54-70)."""
     from pdmpc.road_network import boundary_provider, commonroad_scenario
 
-    options = Config(scenario_type=ScenarioType.commonroad, amount=512, Hp=10, max_vehicles=512, max_nodes=1 << 14)
+    options = Config(scenario_type=ScenarioType.commonroad, amount=512, Hp=10, max_vehicles=512, max_nodes=1 << 15)
     sc = commonroad_scenario(options, seed=3, tiles=26)
-    run_closed_loop(options, sc, "distance", boundary_provider(sc), 2)
+    ctl = run_closed_loop(options, sc, "distance", boundary_provider(sc), 2, oracle_threads=os.cpu_count() or 1, priority_strategy="coloring")
+    assert int(ctl.last_levels.max()) >= 3
 
 
-def test_explorative_batch_of_prioritizations_one_launch():
-    """BASELINE config 4 shape: several prioritizations of the same traffic state flattened into one launch
-    (PrioritizedExplorativeController.m:25-176), records identical to the oracle, same chosen prioritization."""
+@pytest.mark.parametrize("n_instances", [12, 64])
+def test_explorative_batch_of_prioritizations_one_launch(n_instances):
+    """BASELINE config 4 (64 instances = the config as named): several prioritizations of the same traffic state flattened
+    into one launch (PrioritizedExplorativeController.m:25-176), records identical to the oracle, same chosen prioritization."""
     from oracle import oracle
     from pdmpc.explorative import build_exploration_batch, choose_solution
     from pdmpc.optimizer import GraphSearchHip
     from pdmpc.road_network import boundary_provider, commonroad_scenario
 
-    options = Config(scenario_type=ScenarioType.commonroad, amount=20, Hp=8, max_vehicles=20 * 12, max_nodes=1 << 15)
+    options = Config(scenario_type=ScenarioType.commonroad, amount=20, Hp=8, max_vehicles=20 * n_instances, max_nodes=1 << 15)
     mpa = get_mpa(options)
     sc = commonroad_scenario(options, seed=1)
     opt = GraphSearchHip(options)
     ctl = PrioritizedSequentialController(options, sc, mpa, None, coupling="distance", boundary_provider=boundary_provider(sc))
     for _ in range(3):
         ctl.step(plan_step=lambda prob: opt.run_optimizer_step(prob, mpa))
-    batch = build_exploration_batch(ctl, 12, seed=4)
-    assert len(batch["iters"]) == 240 and batch["n_instances"] == 12
+    batch = build_exploration_batch(ctl, n_instances, seed=4)
+    assert len(batch["iters"]) == 20 * n_instances and batch["n_instances"] == n_instances
     n = len(batch["iters"])
     fb = [f if f is not None else [] for f in batch["fallback"]]
-    opt.handle.pack_step(batch["iters"], batch["preds"], fb)
-    opt.handle.launch()
-    gpu = opt.handle.fetch(n)
-    ref, _ = oracle.plan_step(options, mpa, batch)
+    gpu = opt.handle.plan_step(batch["iters"], batch["preds"], fb)
+    unbounded = copy.copy(options)
+    unbounded.max_nodes = 1 << 30
+    ref, _ = oracle.plan_step(unbounded, mpa, batch, n_threads=os.cpu_count() or 1)
     assert_records_equal(gpu, ref, "explorative batch")
     chosen_gpu, cost_gpu = choose_solution(batch, gpu, options.Hp)
     chosen_ref, cost_ref = choose_solution(batch, ref, options.Hp)
