@@ -209,7 +209,8 @@ def plan_batch(options, mpa, iters, n_threads=1, trace=False):
     mpa_struct, keep_m = abi.pack_mpa(mpa)
     arr, keep_v = abi.pack_vehicles(iters, options.Hp)
     recs, traces, _ = plan_batch_raw(options, mpa_struct, arr, len(iters), n_threads=n_threads, trace=trace)
-    infos = [info_from_record(recs[i], options.Hp) for i in range(len(iters))]
+    # (a record cut short by the oracle's capacity guard, status 2, is not a planning result: no info for it)
+    infos = [info_from_record(recs[i], options.Hp) if int(recs[i]["status"]) in (0, 1) else None for i in range(len(iters))]
     del keep_m, keep_v
     return infos, recs, traces
 
