@@ -145,6 +145,8 @@ struct pdmpc_handle {
     DevBuf<double> ahk;
     DevBuf<uint32_t> ahid;
     DevBuf<double> alog;
+    DevBuf<double> ankey;   // frontier kernel: near list
+    DevBuf<uint32_t> anid;
     DevBuf<uint8_t> avs;
     DevBuf<pdmpc_vehicle_out> d_out;
     DevBuf<uint32_t> d_flag;
@@ -154,12 +156,16 @@ struct pdmpc_handle {
     DevBuf<double> d_random;  // sampled optimizer: random numbers of the batch
     int sampled_n_random = 0;
     bool sampled_launch = false;
+    int kernel_frontier = 1;  // 1: frontier kernel (all wavefronts work on open nodes side by side), 0: the pop-ordered kernel of round 1
+    int fr_round = 0, fr_near_fill = 4096, fr_near_max = 12288;
+    bool last_launch_frontier = false;
     int queue_mode = PDMPC_QUEUE_BLOCKMIN;
     int speculate_expansion = 1;
     int waves_latency = PDMPC_WAVES_LATENCY, waves_crowded = PDMPC_WAVES_CROWDED;
     int n_validators = PDMPC_MAX_WAVES;  // (all there are)
     int n_waves = PDMPC_WAVES_LATENCY;   // of the last layout
     int bm_kr = 0, bm_nb = 0;
+    int fr_cand_cap = 0;  // frontier kernel: 32-bit words of a wave's scratch (its candidate list)
     DevBuf<int32_t> d_trace;
     // batch blobs: several packed steps can stay resident side by side ("banks", pdmpc_select_bank)
     std::vector<PackedStep> banks;
@@ -195,7 +201,7 @@ int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in, int cand_cap_in)
     const int n_waves = (n_launch > h->n_cu) ? h->waves_crowded : h->waves_latency;
     h->n_waves = n_waves;
     const uint32_t shape_bytes = (uint32_t)n_waves * (2 * PDMPC_VMAX + 1) * 16;  // two shapes + the wave's work tally
-    const uint32_t path_bytes = align16((PDMPC_HP_MAX + 2) * 4 + 2 * (PDMPC_HP_MAX + 1) * 4 + 32 * 4 + PDMPC_HP_MAX * 4);  // ... + SH_WORDS shared words + ...
+    const uint32_t path_bytes = align16((PDMPC_HP_MAX + 2) * 4 + 2 * (PDMPC_HP_MAX + 1) * 4 + PDMPC_SH_WORDS * 4 + PDMPC_HP_MAX * 4);  // ... + shared words + ...
     const uint32_t soup_bytes = (uint32_t)std::max(hb.soup_cap, 1) * 16;
     const uint32_t expand_bytes = (2 * PDMPC_HP_MAX * PDMPC_HP_MAX) * 8 + 16 * 16;
     const uint32_t fixed_rest = ref_bytes + shape_bytes + path_bytes + soup_bytes + expand_bytes;
@@ -223,6 +229,49 @@ int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in, int cand_cap_in)
         char buf[256];
         snprintf(buf, sizeof buf, "obstacle soup (%d columns) + MPA tables need %u B of LDS, budget %zu B", hb.soup_cap, off, budget);
         return fail(PDMPC_ERR_CAPACITY, buf);
+    }
+    if (h->kernel_frontier && !h->sampled_launch) {
+        // Frontier kernel: the per-wave candidate lists double as expansion scratch (16 x HP_MAX cost terms + 16 child
+        // positions per wave) and, in phase B, as the chunk state (12 B per thread); ready list + histogram (which is also
+        // where the binary heap of the tie fallback lives); then validity bytes and node records.
+        const uint32_t wscr = align16(std::max<uint32_t>((uint32_t)std::max(hb.cand_cap, 1) * 4u, 16u * PDMPC_HP_MAX * 8u + 16u * 16u));
+        off = L.cand;
+        off += wscr * (uint32_t)n_waves;
+        L.expand = off;
+        off += expand_bytes;
+        const uint32_t region_f = 2048u * 4u + 2048u * 4u + 256u;
+        if ((size_t)off + region_f + min_bytes + 256 > budget) {
+            char buf[256];
+            snprintf(buf, sizeof buf, "obstacle soup (%d columns) + MPA tables need %u B of LDS, budget %zu B", hb.soup_cap, off + region_f, budget);
+            return fail(PDMPC_ERR_CAPACITY, buf);
+        }
+        L.heap_key = off;
+        uint32_t hl_f = (region_f / 12u) & ~3u;
+        hl_f = std::min(hl_f, h->max_nodes & ~3u);
+        L.heap_id = off + align16(hl_f * 8);
+        off += region_f;
+        const uint32_t rest_f = (uint32_t)(budget - off - 256);
+        uint32_t nv_f = std::min<uint32_t>(65536u, rest_f / 4 * 3);
+        nv_f = std::min(nv_f, h->max_nodes) & ~15u;
+        uint32_t nl_f = (rest_f - nv_f) / (uint32_t)sizeof(NodeRec);
+        nl_f = std::min(nl_f, h->max_nodes);
+        L.vstate = off;
+        off += align16(nv_f);
+        L.nodes = off;
+        off += nl_f * (uint32_t)sizeof(NodeRec);
+        L.total = align16(off);
+        if (L.total > budget) return fail(PDMPC_ERR_CAPACITY, "internal: LDS layout exceeds budget");
+        if (getenv("PDMPC_DEBUG_LDS"))
+            fprintf(stderr, "pdmpc LDS layout (frontier): launch %d budget %zu waves %d wscr %u heap fallback %u nv %u nl %u total %u\n", n_launch, budget, n_waves, wscr, hl_f, nv_f, nl_f, L.total);
+        h->lds = L;
+        h->HL = (int)hl_f;
+        h->NL = (int)nl_f;
+        h->NV = (int)nv_f;
+        h->areas_in_lds = areas;
+        h->bm_kr = 0;
+        h->bm_nb = 64;
+        h->fr_cand_cap = (int)(wscr / 4u);
+        return PDMPC_OK;
     }
     // The open list gets up to three quarters of what is left.  Its region serves the binary heap (hl entries x 12 B)
     // or the block-min queue (key ring kr x 8 B; block minima and popped bits nb x 16 B; group minima 512 B).
@@ -420,9 +469,12 @@ int alloc_arenas(pdmpc_handle* h, uint32_t nodes) {
     h->ahid.release();
     h->avs.release();
     h->alog.release();
+    h->ankey.release();
+    h->anid.release();
     h->max_nodes = 0;
     int bad = 0;
     bad |= h->anodes.ensure_exact(tot) | h->ahk.ensure_exact(tot) | h->ahid.ensure_exact(tot) | h->avs.ensure_exact(tot) | h->alog.ensure_exact(tot);
+    bad |= h->ankey.ensure_exact(tot) | h->anid.ensure_exact(tot);
     if (bad) return bad;
     h->max_nodes = nodes;
     return 0;
@@ -461,6 +513,8 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.arena.heap_id = h->ahid.p;
     a.arena.pop_log = h->alog.p;
     a.arena.vstate = h->avs.p;
+    a.arena.near_key = h->ankey.p;
+    a.arena.near_id = h->anid.p;
     a.max_nodes = h->max_nodes;
     a.pop_trace = h->d_trace.p;
     a.trace_cap = h->cfg.trace_pops;
@@ -469,8 +523,13 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.HL = h->HL;
     a.NL = h->NL;
     a.NV = h->NV;
+    const bool frontier = h->kernel_frontier && !h->sampled_launch;
     a.soup_cap = B.soup_cap;
-    a.cand_cap = B.cand_cap;
+    a.cand_cap = frontier ? h->fr_cand_cap : B.cand_cap;
+    a.frontier = frontier ? 1 : 0;
+    a.fr_round = h->fr_round > 0 ? h->fr_round : 4 * h->n_waves;
+    a.fr_near_fill = h->fr_near_fill;
+    a.fr_near_max = h->fr_near_max;
     a.spin_limit = 1u << 22;
     a.speculate = h->speculate;
     a.crowded = count > h->n_cu ? 1 : 0;
@@ -501,7 +560,9 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     }
     auto& ev = h->events[h->events_used++];
     HIPCHK(hipEventRecord(ev.first, h->stream));
-    int lrc = h->sampled_launch ? pdmpc_launch_sampled(&a, count, (void*)h->stream) : pdmpc_launch_search(&a, count, (void*)h->stream);
+    h->last_launch_frontier = frontier;
+    int lrc = h->sampled_launch ? pdmpc_launch_sampled(&a, count, (void*)h->stream)
+                                : (frontier ? pdmpc_launch_frontier(&a, count, (void*)h->stream) : pdmpc_launch_search(&a, count, (void*)h->stream));
     if (lrc != 0) {
         char buf[256];
         snprintf(buf, sizeof buf, "kernel launch failed: %s (LDS %u B)", hipGetErrorString((hipError_t)lrc), h->lds.total);
@@ -542,6 +603,10 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
     if (const char* e = getenv("PDMPC_WAVES")) h->waves_latency = h->waves_crowded = std::min(PDMPC_MAX_WAVES, std::max(4, atoi(e)));  // likewise
     if (const char* e = getenv("PDMPC_VALIDATORS")) h->n_validators = std::max(1, atoi(e));  // likewise
     if (const char* e = getenv("PDMPC_SPEC_EXPAND")) h->speculate_expansion = atoi(e) != 0;  // likewise
+    if (const char* e = getenv("PDMPC_KERNEL")) h->kernel_frontier = std::string(e) != "serial";  // A/B switch: results are identical
+    if (const char* e = getenv("PDMPC_FR_ROUND")) h->fr_round = std::max(1, atoi(e));                 // tuning knobs of the frontier kernel
+    if (const char* e = getenv("PDMPC_FR_NEAR_FILL")) h->fr_near_fill = std::max(64, atoi(e));
+    if (const char* e = getenv("PDMPC_FR_NEAR_MAX")) h->fr_near_max = std::max(256, atoi(e));
     if (const char* e = getenv("PDMPC_QUEUE")) h->queue_mode = atoi(e) != 0 ? PDMPC_QUEUE_BLOCKMIN : PDMPC_QUEUE_HEAP;  // likewise
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const uint32_t want_nodes = config->max_nodes > 0 ? (uint32_t)config->max_nodes : 32768u;  // default arena: 256 x 32768 nodes, about 0.6 GB
@@ -584,6 +649,8 @@ int pdmpc_destroy(pdmpc_handle* h) {
     h->ahk.release();
     h->ahid.release();
     h->alog.release();
+    h->ankey.release();
+    h->anid.release();
     h->avs.release();
     h->d_out.release();
     h->d_flag.release();
@@ -761,7 +828,7 @@ int plan_packed_growing(pdmpc_handle* h, int32_t n, pdmpc_vehicle_out* out) {
         if ((h->max_nodes_limit && next > h->max_nodes_limit) || next > (1ull << 30)) return PDMPC_OK;  // statuses tell
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
-        const size_t per_node = sizeof(NodeRec) + 8 + 4 + 8 + 1;
+        const size_t per_node = sizeof(NodeRec) + 8 + 4 + 8 + 1 + 8 + 4;
         const size_t have = (size_t)h->max_vehicles * h->max_nodes * per_node;
         if ((size_t)h->max_vehicles * next * per_node > free_b + have) return PDMPC_OK;  // no room to grow
         const uint32_t before = h->max_nodes;
@@ -1014,12 +1081,110 @@ int pdmpc_debug_blockmin_script(pdmpc_handle* h, int32_t n, const int32_t* op, c
     return PDMPC_OK;
 }
 
+namespace {
+#define PDMPC_TREE_FRONTIER 0x40000000  /* d_tree_size marker: the arena holds the frontier kernel's raw tree (creation order differs from the reference's) */
+
+// The frontier kernel processes open nodes in parallel, so its arena holds the reference's tree plus some nodes the
+// reference never creates, in another order.  This turns it back into the reference's tree and pop sequence, on the host
+// and independently of the kernel's phase B (it sorts the popped nodes instead of counting them), for the debug read-backs
+// the parity tests use.  Order (frontier_kernel.hip): X is popped before Y iff X is an ancestor of Y or the largest key on
+// the path (LCA, X] is smaller than the largest key on (LCA, Y].
+struct RefTree {
+    std::vector<NodeRec> rec;        // raw records
+    std::vector<uint32_t> pops;      // raw indices in the reference's pop order
+    std::vector<uint32_t> ref_nodes; // raw index of reference node id r (0-based position = id - 1)
+    std::vector<uint32_t> ref_id;    // raw index -> reference id (0: not in the reference's tree)
+};
+int reconstruct_reference_tree(pdmpc_handle* h, int vehicle, uint32_t raw_n, RefTree& T) {
+    const size_t off = (size_t)vehicle * h->max_nodes;
+    const int Hp = h->cfg.Hp;
+    T.rec.resize(raw_n);
+    std::vector<double> key(raw_n);
+    std::vector<uint8_t> vs(raw_n);
+    HIPCHK(hipMemcpy(T.rec.data(), h->anodes.p + off, (size_t)raw_n * sizeof(NodeRec), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(key.data(), h->ahk.p + off, (size_t)raw_n * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(vs.data(), h->avs.p + off, (size_t)raw_n, hipMemcpyDeviceToHost));
+    pdmpc_vehicle_out out;
+    HIPCHK(hipMemcpy(&out, h->d_out.p + vehicle, sizeof out, hipMemcpyDeviceToHost));
+    const std::vector<NodeRec>& R = T.rec;
+    std::vector<uint8_t> alive(raw_n, 0);
+    alive[0] = 1;
+    for (uint32_t i = 1; i < raw_n; ++i) {
+        const uint32_t p = R[i].parent - 1;
+        alive[i] = alive[p] && vs[p] == 1;
+    }
+    auto depth = [&](uint32_t i) { return NODE_K(R[i].packed); };
+    // -1: x first, +1: y first, 0: same node
+    auto before = [&](uint32_t x, uint32_t y) -> int {
+        if (x == y) return 0;
+        double mx = -1.0, my = -1.0;
+        uint32_t a = x, b = y;
+        while (depth(a) > depth(b)) {
+            mx = std::max(mx, key[a]);
+            a = R[a].parent - 1;
+        }
+        while (depth(b) > depth(a)) {
+            my = std::max(my, key[b]);
+            b = R[b].parent - 1;
+        }
+        if (a == b) return depth(x) < depth(y) ? -1 : 1;  // ancestor first
+        while (a != b) {
+            mx = std::max(mx, key[a]);
+            my = std::max(my, key[b]);
+            a = R[a].parent - 1;
+            b = R[b].parent - 1;
+        }
+        return mx < my ? -1 : 1;
+    };
+    // the goal: the first collision-free node at the horizon
+    int64_t goal = -1;
+    if (out.status == PDMPC_OK)
+        for (uint32_t i = 0; i < raw_n; ++i)
+            if (alive[i] && vs[i] == 1 && depth(i) == Hp && (goal < 0 || before(i, (uint32_t)goal) < 0)) goal = i;
+    T.pops.clear();
+    for (uint32_t i = 0; i < raw_n; ++i)
+        if (alive[i] && (goal < 0 || i == (uint32_t)goal || before(i, (uint32_t)goal) < 0)) T.pops.push_back(i);
+    std::sort(T.pops.begin(), T.pops.end(), [&](uint32_t x, uint32_t y) { return before(x, y) < 0; });
+    // children of a node are consecutive raw indices in ascending trim order
+    std::vector<uint32_t> first_child(raw_n, 0), n_child(raw_n, 0);
+    for (uint32_t i = raw_n; i-- > 1;) {
+        const uint32_t p = R[i].parent - 1;
+        first_child[p] = i;
+        n_child[p] += 1;
+    }
+    T.ref_id.assign(raw_n, 0);
+    T.ref_nodes.clear();
+    T.ref_nodes.push_back(0);
+    T.ref_id[0] = 1;
+    for (uint32_t x : T.pops) {
+        if (vs[x] != 1 || depth(x) == Hp) continue;  // discarded (GraphSearch.m:75-77) or the goal
+        for (uint32_t c = 0; c < n_child[x]; ++c) {
+            T.ref_nodes.push_back(first_child[x] + c);
+            T.ref_id[first_child[x] + c] = (uint32_t)T.ref_nodes.size();
+        }
+    }
+    return PDMPC_OK;
+}
+}  // namespace
+
 int pdmpc_debug_pop_trace(pdmpc_handle* h, int32_t vehicle, int32_t capacity, int32_t* ids, int32_t* n) {
     if (!h || !ids || !n) return fail(PDMPC_ERR_INVALID, "null argument");
-    if (h->cfg.trace_pops <= 0) return fail(PDMPC_ERR_INVALID, "handle was created with trace_pops == 0");
+    if (h->cfg.trace_pops <= 0 && !h->last_launch_frontier) return fail(PDMPC_ERR_INVALID, "handle was created with trace_pops == 0");
     if (vehicle < 0 || vehicle >= h->max_vehicles) return fail(PDMPC_ERR_INVALID, "vehicle slot out of range");
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipStreamSynchronize(h->stream));
+    {
+        int32_t sz = 0;
+        HIPCHK(hipMemcpy(&sz, h->d_tree_size.p + vehicle, 4, hipMemcpyDeviceToHost));
+        if (sz & PDMPC_TREE_FRONTIER) {
+            RefTree T;
+            int rc = reconstruct_reference_tree(h, vehicle, (uint32_t)(sz & ~PDMPC_TREE_FRONTIER), T);
+            if (rc) return rc;
+            *n = (int32_t)T.pops.size();
+            for (size_t i = 0; i < T.pops.size() && (int)i < capacity; ++i) ids[i] = (int32_t)T.ref_id[T.pops[i]];
+            return PDMPC_OK;
+        }
+    }
     pdmpc_vehicle_out rec;
     HIPCHK(hipMemcpy(&rec, h->d_out.p + vehicle, sizeof rec, hipMemcpyDeviceToHost));
     const int cnt = std::min(rec.n_popped, h->cfg.trace_pops);
@@ -1037,6 +1202,24 @@ int pdmpc_debug_tree(pdmpc_handle* h, int32_t vehicle, int32_t capacity, double*
     HIPCHK(hipStreamSynchronize(h->stream));
     int32_t sz = 0;
     HIPCHK(hipMemcpy(&sz, h->d_tree_size.p + vehicle, 4, hipMemcpyDeviceToHost));
+    if (sz & PDMPC_TREE_FRONTIER) {
+        RefTree T;
+        int rc = reconstruct_reference_tree(h, vehicle, (uint32_t)(sz & ~PDMPC_TREE_FRONTIER), T);
+        if (rc) return rc;
+        *n = (int32_t)T.ref_nodes.size();
+        for (size_t i = 0; i < T.ref_nodes.size() && (int)i < capacity; ++i) {
+            const NodeRec& r = T.rec[T.ref_nodes[i]];
+            if (x) x[i] = r.x;
+            if (y) y[i] = r.y;
+            if (yaw) yaw[i] = r.yaw;
+            if (g) g[i] = r.g;
+            if (hh) hh[i] = r.h;
+            if (parent) parent[i] = r.parent ? (int32_t)T.ref_id[r.parent - 1] : 0;
+            if (trim) trim[i] = NODE_TRIM(r.packed);
+            if (k) k[i] = NODE_K(r.packed);
+        }
+        return PDMPC_OK;
+    }
     *n = sz;
     const size_t m = (size_t)std::max(std::min(sz, capacity), 0);
     if (m == 0) return PDMPC_OK;

@@ -1,0 +1,938 @@
+// frontier_kernel.hip — the optimal graph search without a pop-ordered open list: every wavefront of the workgroup
+// evaluates and expands nodes side by side; the reference's pop order is reconstructed, not executed.
+//
+// What the reference computes (GraphSearch.m:53-107): pop the open-list entry with the smallest key f = g + h, discard
+// it if its edge collides (:75-77), stop if it is at the horizon (:81-90), otherwise expand it (expand_node.m) and push
+// the children.  Node ids are positions in the tree, i.e. they count the children created before.
+//
+// With pairwise distinct keys that process has a closed form.  For nodes X, Y with lowest common ancestor A:
+//     X is popped before Y  <=>  X is an ancestor of Y,  or  max key on the path (A, X]  <  max key on the path (A, Y].
+// (After A is popped the open list holds both branches; the branch whose largest key is smaller is walked to its end
+// before the other branch's largest key can become the minimum.  tools/sigma_order.py checks this against the oracle's
+// pop sequences.)  Hence, with G the first valid node at the horizon in that order and B(X) the largest key on the
+// path root..X:
+//   * the reference pops exactly the nodes that come before G; all of them have B <= B(G);
+//   * the search may therefore process nodes in ANY order and in parallel, as long as in the end every generated node
+//     with key <= B(G) has been processed.  Phase A below does that in rounds ("process everything with key <= L",
+//     L growing by a few dozen entries per round), one node per wavefront at a time: eval_edge_exact (GraphSearch.m:
+//     111-196) with the wave-wide InterX / SAT code, then expand_node.m.  No wave waits for another one's pop;
+//   * n_popped, n_expanded (= tree size) and the ids along tree_path are counts of nodes that come before the nodes
+//     P_0..P_Hp of G's path; with (d, b) = (depth at which X leaves that path, largest key of X's path below it),
+//     X comes before P_j (j > d) iff b < max key(P_{d+1..j}).  Phase B evaluates that for every node in one pass.
+// Equal keys where the order matters (in a comparison against G's path or between goal candidates) make the result
+// depend on the layout of the reference's binary heap: the search is then redone with the libstdc++-faithful heap
+// (serial_search.hpp), exactly as the round-1 kernel does after a tied pop.
+//
+// Predecessors that finish while the search runs (PrioritizedController.m:476-491): their areas enter the soup at the
+// next round boundary, every edge found collision-free so far is re-checked against the new areas only, and nodes that
+// now collide simply become invalid — their subtrees are ignored by phase B.  Nothing restarts.
+//
+// Open set: `ready` (LDS, this round), `near` (HBM, the few thousand smallest keys), `far` (HBM, the rest); entries are
+// (key, node).  near and far are unordered; a histogram pass picks the key below which a round (or a refill of near)
+// takes its entries, a partition pass moves them.  Arithmetic, operation order and -ffp-contract=off are those of the
+// serial kernel: every record is bit-identical to the oracle's.
+#include <hip/hip_runtime.h>
+
+#include "serial_search.hpp"
+
+// frontier words in the shared block (indices >= 32; the serial search uses the words below)
+#define FR_NNODES 32    // tree size (atomic reservation of node indices)
+#define FR_RD_HEAD 33   // ready list: next entry to claim
+#define FR_RD_TAIL 34   // ready list: entries reserved
+#define FR_PENDING 35   // ready entries not completely processed yet
+#define FR_NEAR_N 36
+#define FR_FAR_N 37
+#define FR_FLAGS 38     // FRF_*
+#define FR_LOCK 39      // guards FR_BEST_*
+#define FR_BEST_ID 40   // best goal candidate so far (1-based node, 0 = none)
+#define FR_SEL_BIN 41   // result of fr_select: bin ...
+#define FR_SEL_CUM 42   // ... and the number of entries up to and including it
+#define FR_SEL2_BIN 43  // second selection of the same histogram (spill boundary)
+#define FR_ROUNDS 44
+#define FR_PROCESSED 45
+#define FR_BEST_B1 46   // (64 bit) largest key on the best candidate's path
+#define FR_NEAR_MIN 48  // (64 bit) exact minimum key of near
+#define FR_NEAR_MAX 50  // (64 bit) upper bound of near's keys
+#define FR_FAR_MIN 52   // (64 bit) exact minimum key of far
+#define FR_FAR_MAX 54   // (64 bit) upper bound of far's keys
+#define FR_L_READY 56   // (64 bit) children with key <= this join the running round
+#define FR_L_FAR 58     // (64 bit) children with key > this go to far
+#define FRF_OVERFLOW 1u
+#define FRF_TIE 2u
+#define FRF_INVALIDATED 4u
+#define FRF_BUG 8u
+#define FR_NBINS 2048
+#define FR_READY_CAP 2048
+
+namespace {
+
+typedef LDS_AS unsigned long long lds_u64s;
+
+__device__ __forceinline__ double sh_ld_d(volatile lds_u32* sh, int w) { return __longlong_as_double((long long)*(volatile lds_u64s*)(sh + w)); }
+__device__ __forceinline__ void sh_st_d(volatile lds_u32* sh, int w, double v) { *(volatile lds_u64s*)(sh + w) = (unsigned long long)__double_as_longlong(v); }
+// keys are non-negative finite doubles (sums of squares): their bit patterns order like unsigned integers
+__device__ __forceinline__ void sh_min_d(volatile lds_u32* sh, int w, double v) {
+    __hip_atomic_fetch_min((lds_u64s*)(sh + w), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void sh_max_d(volatile lds_u32* sh, int w, double v) {
+    __hip_atomic_fetch_max((lds_u64s*)(sh + w), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint32_t sh_add(volatile lds_u32* sh, int w, uint32_t v) {
+    return __hip_atomic_fetch_add((lds_u32*)(sh + w), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint32_t lane_rank(unsigned long long ballot, int lane) { return (uint32_t)__builtin_popcountll(ballot & ((1ull << lane) - 1ull)); }
+
+// monotone map key -> bin of a linear histogram over [lo, lo + nb / scale)
+__device__ __forceinline__ uint32_t fr_bin(double key, double lo, double scale) {
+    const double t = (key - lo) * scale;
+    if (!(t > 0.0)) return 0u;
+    return t < (double)(FR_NBINS - 1) ? (uint32_t)t : (uint32_t)(FR_NBINS - 1);
+}
+
+struct Frontier {
+    volatile lds_u32* sh;
+    lds_u32* ready;  // [FR_READY_CAP] 1-based nodes of the running round (0 = not written yet)
+    lds_u32* hist;   // [FR_NBINS]
+    double* near_key;
+    uint32_t* near_id;
+    double* far_key;
+    uint32_t* far_id;
+    double* gkey;  // key of node i at gkey[i]
+    int n_waves;
+};
+
+// Smallest bin whose cumulative count reaches `target` (the last non-empty bin if the total is smaller).  One wave calls;
+// lane 0 stores bin and cumulative count in sh[w_bin], sh[w_bin + 1].
+__device__ void fr_select(const Frontier& F, uint32_t target, int w_bin, int lane) {
+    const int per = FR_NBINS / PDMPC_WAVE;
+    uint32_t loc = 0;
+    for (int q = 0; q < per; ++q) loc += F.hist[lane * per + q];
+    uint32_t inc = loc;  // inclusive prefix over the lanes
+#pragma unroll
+    for (int o = 1; o < PDMPC_WAVE; o <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)inc, o);
+        if (lane >= o) inc += v;
+    }
+    const uint32_t total = lane_u(inc, PDMPC_WAVE - 1);
+    const uint32_t want = target < total ? target : total;
+    const unsigned long long reach = __ballot(inc >= want && loc != 0u);
+    uint32_t bin = 0, cum = 0;
+    if (reach) {
+        const int l = __builtin_ctzll(reach);
+        if (lane == l) {
+            uint32_t c = inc - loc;
+            for (int q = 0; q < per; ++q) {
+                c += F.hist[lane * per + q];
+                if (c >= want && F.hist[lane * per + q] != 0u) {
+                    bin = (uint32_t)(lane * per + q);
+                    cum = c;
+                    break;
+                }
+            }
+        }
+        bin = lane_u(bin, l);
+        cum = lane_u(cum, l);
+    }
+    if (lane == 0) {
+        F.sh[w_bin] = bin;
+        F.sh[w_bin + 1] = cum;
+    }
+}
+
+// Workgroup-wide stable partition of the list (key[], id[]) of n entries: cls(key, id) == 0 keeps an entry (compacted in
+// place, order preserved), any other class hands it to emit(cls, key, id) — which every lane of a wave calls together
+// (cls < 0: this lane has nothing), so it can aggregate its atomics per wave.  Returns the number of kept entries.
+template <class Cls, class Emit>
+__device__ uint32_t fr_partition(double* key, uint32_t* id, uint32_t n, volatile lds_u32* wsum, int n_waves, Cls cls, Emit emit) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t w = 0;
+    int buf = 0;
+    for (uint32_t base = 0; base < n; base += blockDim.x, buf ^= 16) {
+        const uint32_t e = base + (uint32_t)tid;
+        const bool in = e < n;
+        double k = 0.0;
+        uint32_t i = 0;
+        int c = -1;
+        if (in) {
+            k = key[e];
+            i = id[e];
+            c = cls(k, i);
+        }
+        const unsigned long long keep = __ballot(c == 0);
+        if (lane == 0) wsum[buf + wave] = (uint32_t)__builtin_popcountll(keep);
+        __syncthreads();  // every entry of this chunk has been read
+        uint32_t off = 0, tot = 0;
+        for (int q = 0; q < n_waves; ++q) {
+            const uint32_t v = wsum[buf + q];
+            off += q < wave ? v : 0u;
+            tot += v;
+        }
+        if (c == 0) {
+            const uint32_t pos = w + off + lane_rank(keep, lane);
+            key[pos] = k;
+            id[pos] = i;
+        }
+        emit(c > 0 ? c : -1, k, i);
+        w += tot;
+    }
+    __syncthreads();
+    return w;
+}
+
+// X (1-based, at the horizon, edge known to be collision-free): largest key on its path, and whether every ancestor is
+// still collision-free (a predecessor's late areas may have invalidated one).  Uniform over the wave.
+__device__ bool fr_goal_path(const Search& S, const VState& VS, const double* gkey, uint32_t x, double& b1) {
+    double m = 0.0;
+    bool alive = true;
+    uint32_t nd = x;
+    for (;;) {
+        const double k = gkey[nd - 1];
+        m = k > m ? k : m;
+        if (nd != x && vs_load(VS, nd - 1) != VS_VALID) alive = false;
+        const uint32_t par = node_parent(S, nd - 1);
+        if (!par) break;
+        nd = par;
+    }
+    b1 = m;
+    return alive;
+}
+
+// Which of two nodes of equal depth does the reference pop first?  -1: x, +1: y, 0: undecidable (equal keys).
+__device__ int fr_before(const Search& S, const double* gkey, uint32_t x, uint32_t y) {
+    double mx = -1.0, my = -1.0;
+    while (x != y) {
+        const double kx = gkey[x - 1], ky = gkey[y - 1];
+        mx = kx > mx ? kx : mx;
+        my = ky > my ? ky : my;
+        x = node_parent(S, x - 1);
+        y = node_parent(S, y - 1);
+        if (!x || !y) break;
+    }
+    return mx < my ? -1 : (my < mx ? 1 : 0);
+}
+
+// A valid node at the horizon has been found: keep it if it comes before the best one so far.  Whole wave calls, uniform.
+__device__ void fr_offer_goal(const Frontier& F, const Search& S, const VState& VS, uint32_t x, int lane) {
+    double b1;
+    if (!fr_goal_path(S, VS, F.gkey, x, b1)) return;
+    if (lane == 0) {
+        while (atomicCAS((uint32_t*)&F.sh[FR_LOCK], 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const uint32_t best = uni_u(F.sh[FR_BEST_ID]);
+    bool take = false;
+    if (!best) {
+        take = true;
+    } else {
+        const double bb = sh_ld_d(F.sh, FR_BEST_B1);
+        if (b1 < bb) {
+            take = true;
+        } else if (b1 == bb) {  // same bottleneck node (keys are distinct): the order is decided below it
+            const int r = fr_before(S, F.gkey, x, best);
+            if (r < 0) take = true;
+            if (r == 0 && lane == 0) atomicOr((uint32_t*)&F.sh[FR_FLAGS], FRF_TIE);
+        }
+    }
+    if (lane == 0) {
+        if (take) {
+            F.sh[FR_BEST_ID] = x;
+            sh_st_d(F.sh, FR_BEST_B1, b1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        F.sh[FR_LOCK] = 0u;
+    }
+}
+
+// Children of one expansion join the open set: the running round (ready), near or far by key.  Whole wave calls.
+__device__ __forceinline__ void fr_push_children(const Frontier& F, bool active, uint32_t i0, double f, int lane) {
+    const double l_ready = sh_ld_d(F.sh, FR_L_READY), l_far = sh_ld_d(F.sh, FR_L_FAR);
+    int cls = -1;
+    if (active) cls = f > l_far ? 2 : (f <= l_ready ? 0 : 1);
+    const unsigned long long b0 = __ballot(cls == 0);
+    if (b0) {
+        const uint32_t cnt = (uint32_t)__builtin_popcountll(b0);
+        uint32_t base = 0;
+        if (lane == 0) base = sh_add(F.sh, FR_RD_TAIL, cnt);
+        base = uni_u(base);
+        const uint32_t pos = base + lane_rank(b0, lane);
+        const bool fits = cls == 0 && pos < (uint32_t)FR_READY_CAP;
+        const unsigned long long bf = __ballot(fits);
+        if (lane == 0 && bf) sh_add(F.sh, FR_PENDING, (uint32_t)__builtin_popcountll(bf));  // (this wave's own node is still pending)
+        if (fits) F.ready[pos] = i0 + 1u;
+        if (cls == 0 && !fits) cls = 1;  // the round's list is full: wait in near
+    }
+    const unsigned long long b1 = __ballot(cls == 1);
+    if (b1) {
+        uint32_t base = 0;
+        if (lane == 0) base = sh_add(F.sh, FR_NEAR_N, (uint32_t)__builtin_popcountll(b1));
+        base = uni_u(base);
+        if (cls == 1) {
+            const uint32_t pos = base + lane_rank(b1, lane);
+            F.near_key[pos] = f;
+            F.near_id[pos] = i0 + 1u;
+            sh_min_d(F.sh, FR_NEAR_MIN, f);
+            sh_max_d(F.sh, FR_NEAR_MAX, f);
+        }
+    }
+    const unsigned long long b2 = __ballot(cls == 2);
+    if (b2) {
+        uint32_t base = 0;
+        if (lane == 0) base = sh_add(F.sh, FR_FAR_N, (uint32_t)__builtin_popcountll(b2));
+        base = uni_u(base);
+        if (cls == 2) {
+            const uint32_t pos = base + lane_rank(b2, lane);
+            F.far_key[pos] = f;
+            F.far_id[pos] = i0 + 1u;
+            sh_min_d(F.sh, FR_FAR_MIN, f);
+            sh_max_d(F.sh, FR_FAR_MAX, f);
+        }
+    }
+}
+
+// One node of the round: eval_edge_exact (GraphSearch.m:111-196), the goal test (:81-90), expand_node.m.  Whole wave.
+template <int CHECKER, int NW>
+__device__ __forceinline__ void fr_process(const KernelArgs& A, Ctx& X, const Frontier& F, const ExpandEnv& EE, uint32_t cur) {
+    const int lane = X.lane, Hp = X.Hp;
+    Search& S = X.S;
+    const VState& VS = X.VS;
+    const uint32_t c0 = cur - 1u;
+    const bool valid = edge_valid<CHECKER>(S, X.C, cur, lane);
+    if (!valid) {
+        if (lane == 0) vs_store(VS, c0, VS_INVALID);
+        return;
+    }
+    const NodeRec cn = node_load(S, c0);  // same record in every lane
+    const uint32_t cpk = uni_u(cn.packed);
+    if (NODE_K(cpk) == Hp) {
+        if (lane == 0) vs_store(VS, c0, VS_VALID);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        fr_offer_goal(F, S, VS, cur, lane);
+        return;
+    }
+    double sn, cs;
+    pdmpc_sincos(cn.yaw, &sn, &cs);  // expand_node.m:50-51
+    if (lane == 0) node_store_cs(S, c0, cs, sn);
+    // reserve the children's node indices
+    const int n = EE.n, nw = NW > 0 ? NW : EE.nw;
+    const lds_mask64* mrow = EE.l_mask + ((size_t)NODE_K(cpk) * n + (NODE_TRIM(cpk) - 1)) * nw;
+    uint32_t total = 0;
+    for (int w = 0; w < nw; ++w) total += (uint32_t)__builtin_popcountll(mrow[w]);
+    total = uni_u(total);
+    uint32_t base = 0;
+    if (lane == 0) base = sh_add(F.sh, FR_NNODES, total);
+    base = uni_u(base);
+    if (base + total > S.max_nodes) {
+        if (lane == 0) {
+            atomicOr((uint32_t*)&F.sh[FR_FLAGS], FRF_OVERFLOW);
+            vs_store(VS, c0, VS_VALID);
+        }
+        return;
+    }
+    if (lane == 0) vs_store(VS, c0, VS_VALID);  // before any child can be picked up: a child's path check looks at it
+    uint32_t nn = base;
+    (void)expand_children<false, NW>(EE, S, VS, cur, cn, cs, sn, nn, [&](uint64_t mask, bool active, uint32_t i0, double f, int ccnt) {
+        (void)mask;
+        (void)ccnt;
+        if (active) F.gkey[i0] = f;
+        // records, keys and the parent's cos/sin must be visible before another wave can pick a child up
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        fr_push_children(F, active, i0, f, lane);
+    });
+}
+
+// Phase B: position of every node relative to the goal path P_0..P_Hp (goal == 0: exhausted search, every generated node
+// was popped).  Nodes are visited in index order, a chunk of blockDim nodes at a time (a parent's index is smaller than
+// its children's); a node's (d, b) follows from its parent's.  Results: ref_ids[j] = id of P_j in the reference's tree,
+// n_popped, n_expanded.  Sets FRF_TIE if a comparison that matters is an equality.
+struct PhaseB {
+    uint32_t n_popped, n_expanded;
+};
+#define PB_ALIVE 0x100u
+#define PB_ONPATH 0x200u
+template <int NW>
+__device__ PhaseB fr_phase_b(const KernelArgs& A, Ctx& X, const Frontier& F, const ExpandEnv& EE, uint32_t goal, lds_u32* ref_ids, LDS_AS unsigned char* scratch,
+                             double* st_b, uint32_t* st_d) {
+    const int tid = X.tid, Hp = X.Hp;
+    const Search& S = X.S;
+    const VState& VS = X.VS;
+    lds_u32* l_path = X.l_path;
+    lds_f64* Mp = (lds_f64*)F.hist;                                        // [HP_MAX + 1][HP_MAX + 2]
+    lds_f64* pk = Mp + (PDMPC_HP_MAX + 1) * (PDMPC_HP_MAX + 2);            // [HP_MAX + 1] keys of the path nodes
+    lds_u32* cnt_pop = (lds_u32*)(pk + PDMPC_HP_MAX + 1);                  // [HP_MAX + 2]
+    lds_u32* cnt_ch = cnt_pop + PDMPC_HP_MAX + 2;                          // [HP_MAX + 2]
+    lds_u32* ch_d = (lds_u32*)scratch;                                     // [blockDim] state of the chunk's nodes
+    lds_f64* ch_b = (lds_f64*)(scratch + 4 * (size_t)blockDim.x);          // [blockDim]
+    const int n = EE.n, nw = NW > 0 ? NW : EE.nw;
+    ch_d[tid] = 0;
+    if (tid == 0) {
+        uint32_t nd = goal;
+        for (int i = Hp; i >= 0 && goal; --i) {
+            l_path[i] = nd;
+            pk[i] = F.gkey[nd - 1];
+            nd = node_parent(S, nd - 1);
+        }
+        for (int t = 0; t < PDMPC_HP_MAX + 2; ++t) {
+            cnt_pop[t] = 0;
+            cnt_ch[t] = 0;
+        }
+    }
+    __syncthreads();
+    if (goal && tid <= Hp) {
+        double m = -1.0;
+        for (int j = tid + 1; j <= Hp; ++j) {
+            m = pk[j] > m ? pk[j] : m;
+            Mp[tid * (PDMPC_HP_MAX + 2) + j] = m;
+        }
+    }
+    __syncthreads();
+    uint32_t N = F.sh[FR_NNODES];
+    N = N < S.max_nodes ? N : S.max_nodes;
+    for (uint32_t base = 0; base < N; base += blockDim.x) {
+        const uint32_t i = base + (uint32_t)tid;
+        const bool in = i < N;
+        uint32_t par = 0, pk_ = 0, vst = 0;
+        double key = 0.0;
+        if (in) {
+            const d2 q = i < S.NL ? (d2)S.ln[4 * (size_t)i + 3] : ((const d2*)(S.gn + i))[3];
+            const uint64_t u = (uint64_t)__double_as_longlong(q.y);
+            par = (uint32_t)(u & 0xffffffffull);
+            pk_ = (uint32_t)(u >> 32);
+            key = F.gkey[i];
+            vst = vs_load(VS, i);
+        }
+        const int depth = NODE_K(pk_);
+        bool resolved = !in;
+        uint32_t my_d = 0;
+        double my_b = -1.0;
+        for (;;) {
+            if (!resolved) {
+                if (!par) {  // the root
+                    my_d = PB_ALIVE | (goal ? PB_ONPATH : 0u);
+                    resolved = true;
+                } else {
+                    const uint32_t pi = par - 1u;
+                    bool have = false;
+                    uint32_t pd = 0;
+                    double pb = -1.0;
+                    if (pi < base) {
+                        pd = st_d[pi];
+                        pb = st_b[pi];
+                        have = true;
+                    } else if (ch_d[pi - base] & 0x80000000u) {
+                        pd = ch_d[pi - base] & 0x7fffffffu;
+                        pb = ch_b[pi - base];
+                        have = true;
+                    }
+                    if (have) {
+                        // generated <=> the parent was generated, its edge is collision-free, and it was expanded
+                        const bool alive = (pd & PB_ALIVE) && vs_load(VS, pi) == VS_VALID;
+                        if (!alive) {
+                            my_d = 0;
+                        } else if (!goal) {
+                            my_d = PB_ALIVE;
+                        } else if ((pd & PB_ONPATH) && l_path[depth] == i + 1u) {
+                            my_d = PB_ALIVE | PB_ONPATH | (uint32_t)depth;
+                        } else if (pd & PB_ONPATH) {
+                            my_d = PB_ALIVE | (uint32_t)(depth - 1);
+                            my_b = key;
+                        } else {
+                            my_d = PB_ALIVE | (pd & 0xffu);
+                            my_b = pb > key ? pb : key;
+                        }
+                        resolved = true;
+                    }
+                }
+                if (resolved) {
+                    ch_b[tid] = my_b;
+                    ch_d[tid] = my_d | 0x80000000u;  // (after the value it announces: LDS keeps a wave's accesses in order)
+                    st_d[i] = my_d;
+                    st_b[i] = my_b;
+                }
+            }
+            if (__syncthreads_and(resolved ? 1 : 0)) break;
+        }
+        ch_d[tid] = 0;  // (nobody reads this chunk's states any more)
+        if (in && (my_d & PB_ALIVE)) {
+            int t;
+            if (!goal) {
+                t = 0;
+            } else if (my_d & PB_ONPATH) {
+                t = depth + 1;
+            } else {
+                const int d = (int)(my_d & 0xffu);
+                t = Hp + 1;
+                for (int j = d + 1; j <= Hp; ++j) {
+                    const double m = Mp[d * (PDMPC_HP_MAX + 2) + j];
+                    if (my_b == m) atomicOr((uint32_t*)&F.sh[FR_FLAGS], FRF_TIE);
+                    if (my_b < m) {
+                        t = j;
+                        break;
+                    }
+                }
+            }
+            if (t <= Hp) {
+                if (vst == VS_UNKNOWN) atomicOr((uint32_t*)&F.sh[FR_FLAGS], FRF_BUG);  // a node the reference pops was never processed
+                atomicAdd((uint32_t*)&cnt_pop[t], 1u);
+                if (vst == VS_VALID && depth < Hp) {
+                    const lds_mask64* mrow = EE.l_mask + ((size_t)depth * n + (NODE_TRIM(pk_) - 1)) * nw;
+                    uint32_t c = 0;
+                    for (int w = 0; w < nw; ++w) c += (uint32_t)__builtin_popcountll(mrow[w]);
+                    atomicAdd((uint32_t*)&cnt_ch[t], c);
+                }
+            }
+        }
+        __syncthreads();  // the chunk's LDS state is rewritten by the next chunk
+    }
+    __syncthreads();
+    PhaseB R;
+    R.n_popped = 0;
+    R.n_expanded = 1;
+    if (!goal) {
+        R.n_popped = cnt_pop[0];
+        R.n_expanded = 1u + cnt_ch[0];
+        return R;
+    }
+    if (tid == 0) {
+        uint32_t s = 1;  // S_j = tree size when P_j is popped
+        ref_ids[0] = 1;
+        for (int j = 0; j < Hp; ++j) {
+            s += cnt_ch[j];  // nodes expanded before P_j: t <= j
+            const uint32_t pj = l_path[j] - 1u, cj = l_path[j + 1] - 1u;
+            const uint32_t ppk = ((const uint32_t*)(S.gn + pj))[15], cpk2 = ((const uint32_t*)(S.gn + cj))[15];
+            const lds_mask64* mrow = EE.l_mask + ((size_t)NODE_K(ppk) * n + (NODE_TRIM(ppk) - 1)) * nw;
+            const int t2 = NODE_TRIM(cpk2) - 1;  // 0-based successor trim
+            uint32_t rank = 0;
+            for (int w = 0; w < nw; ++w) {
+                const uint64_t m = mrow[w];
+                if (w < t2 / 64) rank += (uint32_t)__builtin_popcountll(m);
+                if (w == t2 / 64) rank += (uint32_t)__builtin_popcountll(m & ((1ull << (t2 % 64)) - 1ull));
+            }
+            ref_ids[j + 1] = s + 1u + rank;
+        }
+    }
+    uint32_t np = 1, ne = 1;
+    for (int t = 0; t <= Hp; ++t) {
+        np += cnt_pop[t];
+        ne += cnt_ch[t];
+    }
+    R.n_popped = np;
+    R.n_expanded = ne;
+    __syncthreads();
+    return R;
+}
+
+// The search.  Returns true (to every wave) if a tie was met and the search has to be redone on the binary heap.
+template <int CHECKER, int NW>
+__device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds_u32* ref_ids) {
+    const int tid = X.tid, lane = X.lane, wave = X.wave, slot = X.slot, Hp = X.Hp;
+    volatile lds_u32* sh = X.l_shared;
+    Search& S = X.S;
+    const VState& VS = X.VS;
+    const SpecCtx& P = X.P;
+    const DevVehicle* __restrict__ V = X.V;
+    const int n_waves = (int)(blockDim.x >> 6);
+    const double inf = __longlong_as_double(0x7FF0000000000000LL);
+    const size_t voff = (size_t)slot * A.max_nodes;
+
+    Frontier F;
+    F.sh = sh;
+    F.ready = (lds_u32*)(X.lsm + A.lds.heap_key);
+    F.hist = F.ready + FR_READY_CAP;
+    F.near_key = A.arena.near_key + voff;
+    F.near_id = A.arena.near_id + voff;
+    F.far_key = A.arena.pop_log + voff;
+    F.far_id = A.arena.heap_id + voff;
+    F.gkey = S.gkey;
+    F.n_waves = n_waves;
+    volatile lds_u32* wsum = (volatile lds_u32*)(F.hist + FR_NBINS);  // [32] per-wave counts of fr_partition
+
+    // per-wave expansion scratch lives in the wave's candidate list (an edge check is over before its node is expanded)
+    ExpandEnv EE;
+    EE.l_mask = X.l_mask;
+    EE.l_mi = X.l_mi;
+    EE.l_pose = X.l_pose;
+    EE.l_rx = X.l_rx;
+    EE.l_ry = X.l_ry;
+    EE.l_dcum = X.l_dcum;
+    EE.l_term = (lds_f64*)X.C.cand;
+    EE.l_chxy = (lds_d2*)(EE.l_term + 16 * PDMPC_HP_MAX);
+    EE.Hp = Hp;
+    EE.n = X.n;
+    EE.nw = X.nw;
+    EE.lane = lane;
+
+    // ---- root node (GraphSearch.m:34-46): the first round
+    if (tid == 0) {
+        NodeRec r;
+        r.x = V->x0;
+        r.y = V->y0;
+        r.yaw = V->yaw0;
+        r.g = 0.0;
+        r.cs = 0.0;
+        r.sn = 0.0;
+        r.h = 0.0;
+        r.parent = 0;
+        r.packed = (uint32_t)V->trim0;
+        node_store(S, 0, r);
+        F.gkey[0] = 0.0;
+        vs_store(VS, 0, VS_UNKNOWN);
+        for (int w = FR_NNODES; w < SH_WORDS; ++w) sh[w] = 0;
+        sh[FR_NNODES] = 1;
+        sh[FR_RD_TAIL] = 1;
+        sh[FR_PENDING] = 1;
+        sh_st_d(sh, FR_NEAR_MIN, inf);
+        sh_st_d(sh, FR_FAR_MIN, inf);
+        sh_st_d(sh, FR_L_READY, 0.0);
+        sh_st_d(sh, FR_L_FAR, inf);
+        sh[SH_NNODES] = 1;
+    }
+    for (int i = tid; i < FR_READY_CAP; i += (int)blockDim.x) F.ready[i] = i == 0 ? 1u : 0u;
+    __syncthreads();
+
+    int status = PDMPC_OK;
+    bool dep_timeout = X.dep_timeout;
+    uint32_t goal = 0;
+    uint32_t idle_polls = 0;
+    for (;;) {
+        // ================= a round: every wave takes nodes off the ready list until none is pending =================
+        for (;;) {
+            // a ticket: the entry with that index is this wave's, whenever it is written (children of the running round may
+            // still join the list); tickets nobody will ever serve are dropped when nothing is pending any more
+            uint32_t cur = 0;
+            if (lane == 0) {
+                const uint32_t t = sh_add(sh, FR_RD_HEAD, 1u);
+                if (t < (uint32_t)FR_READY_CAP) {
+                    for (;;) {
+                        cur = *(volatile lds_u32*)&F.ready[t];
+                        if (cur != 0u) break;
+                        if (__hip_atomic_load((lds_u32*)(sh + FR_PENDING), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) break;
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                }
+            }
+            cur = uni_u(cur);
+            if (cur == 0u) break;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            fr_process<CHECKER, NW>(A, X, F, EE, cur);
+            if (lane == 0) {
+                sh_add(sh, FR_PROCESSED, 1u);
+                __hip_atomic_fetch_sub((lds_u32*)(sh + FR_PENDING), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        __syncthreads();
+
+        // ================= round boundary (every thread; decisions are uniform) =====================================
+        uint32_t flags = sh[FR_FLAGS];
+        if (flags & FRF_OVERFLOW) {
+            status = PDMPC_ARENA_OVERFLOW;
+            break;
+        }
+        // predecessors that finished meanwhile: their areas enter the soup, collision-free edges are re-checked
+        if (wave == 0) (void)poll_predecessors(A, P, sh, lane);
+        __syncthreads();
+        if (sh[SH_STATE] == ST_ARRIVED) {
+            const unsigned long long arr = sh_load64(sh, SH_ARR_LO);
+            uint32_t nn = sh[FR_NNODES];
+            nn = nn < S.max_nodes ? nn : S.max_nodes;
+            incorporate_areas(P, arr, tid);
+            __syncthreads();
+            for (uint32_t i0 = (uint32_t)tid; i0 < nn; i0 += blockDim.x) {
+                if (vs_load(VS, i0) == VS_VALID) {
+                    bool popped;
+                    if (node_hits_areas(S, X.C, P, i0, arr, popped)) {
+                        vs_store(VS, i0, VS_INVALID);
+                        atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_INVALIDATED);
+                    }
+                }
+            }
+            __syncthreads();
+            flags = sh[FR_FLAGS];
+            __syncthreads();
+            if (tid == 0) {
+                atomicAdd(P.counters + 2, 1);
+                const unsigned long long pend = sh_load64(sh, SH_PEND_LO) & ~arr;
+                sh[SH_PEND_LO] = (uint32_t)pend;
+                sh[SH_PEND_HI] = (uint32_t)(pend >> 32);
+                sh[SH_ARR_LO] = 0;
+                sh[SH_ARR_HI] = 0;
+                sh[SH_STATE] = ST_RUN;
+                if (flags & FRF_INVALIDATED) {
+                    sh[FR_BEST_ID] = 0;  // the best candidate may have lost an ancestor: look at all of them again
+                    sh[FR_FLAGS] = flags & ~FRF_INVALIDATED;
+                }
+            }
+            __syncthreads();
+            if (flags & FRF_INVALIDATED) {
+                for (uint32_t b = (uint32_t)wave * PDMPC_WAVE; b < nn; b += blockDim.x) {
+                    const uint32_t i0 = b + (uint32_t)lane;
+                    bool cand = false;
+                    if (i0 < nn && vs_load(VS, i0) == VS_VALID) cand = NODE_K(((const uint32_t*)(S.gn + i0))[15]) == Hp;
+                    unsigned long long bc = __ballot(cand);
+                    while (bc) {
+                        const int l = __builtin_ctzll(bc);
+                        bc &= bc - 1;
+                        fr_offer_goal(F, S, VS, b + (uint32_t)l + 1u, lane);
+                    }
+                }
+                __syncthreads();
+            }
+            flags = sh[FR_FLAGS];
+        }
+        if (flags & FRF_TIE) return true;
+
+        // are we done?  A collision-free node at the horizon whose path maximum lies below every open key comes before
+        // everything that is still open; an empty open set without one is exhaustion (GraphSearch.m:57-61).
+        const uint32_t best = sh[FR_BEST_ID];
+        const uint32_t near_n = sh[FR_NEAR_N], far_n = sh[FR_FAR_N];
+        const double near_min = near_n ? sh_ld_d(sh, FR_NEAR_MIN) : inf, far_min = far_n ? sh_ld_d(sh, FR_FAR_MIN) : inf;
+        const double open_min = near_min < far_min ? near_min : far_min;
+        bool done = false;
+        if (best) {
+            const double bb = sh_ld_d(sh, FR_BEST_B1);
+            if (bb == open_min) return true;  // a tie between an open node and a node of the best path
+            done = bb < open_min;
+        } else {
+            done = near_n == 0u && far_n == 0u;
+        }
+        if (done) {
+            if (sh_load64(sh, SH_PEND_LO) == 0ull || dep_timeout) {
+                goal = best;
+                status = best ? PDMPC_OK : PDMPC_EXHAUSTED;
+                break;
+            }
+            // finished, but predecessors that are still planning may yet invalidate what we found
+            __builtin_amdgcn_s_sleep(16);
+            if (++idle_polls > A.spin_limit) dep_timeout = true;  // a predecessor never finished: give up on it (reported as an error status)
+            continue;
+        }
+
+        // ---- near is empty: refill it from far with the entries below a key chosen from far's histogram
+        uint32_t nn_near = near_n;
+        if (nn_near == 0u) {
+            double lo = far_min, hi = sh_ld_d(sh, FR_FAR_MAX);
+            uint32_t bsel = FR_NBINS - 1;
+            double scale = 0.0;
+            for (int zoom = 0; zoom < 6; ++zoom) {
+                scale = hi > lo ? (double)FR_NBINS / (hi - lo) : 0.0;
+                for (int i = tid; i < FR_NBINS; i += (int)blockDim.x) F.hist[i] = 0;
+                __syncthreads();
+                for (uint32_t e = (uint32_t)tid; e < far_n; e += blockDim.x) atomicAdd((uint32_t*)&F.hist[fr_bin(F.far_key[e], lo, scale)], 1u);
+                __syncthreads();
+                if (wave == 0) fr_select(F, (uint32_t)A.fr_near_fill, FR_SEL_BIN, lane);
+                __syncthreads();
+                bsel = sh[FR_SEL_BIN];
+                const uint32_t cum = sh[FR_SEL_CUM];
+                __syncthreads();
+                if (bsel != 0u || cum <= 4u * (uint32_t)A.fr_near_fill || scale == 0.0) break;
+                hi = lo + (hi - lo) / (double)FR_NBINS;  // nearly everything sits in the first bin: look closer
+            }
+            const double l_far_new = (bsel >= FR_NBINS - 1 || scale == 0.0) ? inf : lo + (double)(bsel + 1u) / scale;
+            if (tid == 0) {
+                sh_st_d(sh, FR_FAR_MIN, inf);
+                sh_st_d(sh, FR_FAR_MAX, 0.0);
+                sh_st_d(sh, FR_NEAR_MIN, inf);
+                sh_st_d(sh, FR_NEAR_MAX, 0.0);
+                sh_st_d(sh, FR_L_FAR, l_far_new);
+            }
+            __syncthreads();
+            const double lo_c = lo, scale_c = scale;
+            const uint32_t kept = fr_partition(
+                F.far_key, F.far_id, far_n, wsum, n_waves, [&](double k, uint32_t) -> int { return fr_bin(k, lo_c, scale_c) <= bsel ? 1 : 0; },
+                [&](int c, double k, uint32_t i) {
+                    const unsigned long long b = __ballot(c == 1);
+                    if (b) {
+                        uint32_t base = 0;
+                        if (lane == 0) base = sh_add(sh, FR_NEAR_N, (uint32_t)__builtin_popcountll(b));
+                        base = uni_u(base);
+                        if (c == 1) {
+                            const uint32_t pos = base + lane_rank(b, lane);
+                            F.near_key[pos] = k;
+                            F.near_id[pos] = i;
+                            sh_min_d(sh, FR_NEAR_MIN, k);
+                            sh_max_d(sh, FR_NEAR_MAX, k);
+                        }
+                    }
+                    if (c < 0 && i != 0u) {  // (kept entries: i is their node, never 0)
+                        sh_min_d(sh, FR_FAR_MIN, k);
+                        sh_max_d(sh, FR_FAR_MAX, k);
+                    }
+                });
+            if (tid == 0) sh[FR_FAR_N] = kept;
+            __syncthreads();
+            nn_near = sh[FR_NEAR_N];
+        }
+
+        // ---- this round's entries: the smallest keys of near (histogram -> bin -> partition)
+        {
+            const double lo = sh_ld_d(sh, FR_NEAR_MIN);
+            double hi = sh_ld_d(sh, FR_NEAR_MAX);
+            uint32_t bsel = FR_NBINS - 1, bspill = FR_NBINS - 1;
+            double scale = 0.0;
+            for (int zoom = 0; zoom < 8; ++zoom) {
+                scale = hi > lo ? (double)FR_NBINS / (hi - lo) : 0.0;
+                for (int i = tid; i < FR_NBINS; i += (int)blockDim.x) F.hist[i] = 0;
+                __syncthreads();
+                for (uint32_t e = (uint32_t)tid; e < nn_near; e += blockDim.x) atomicAdd((uint32_t*)&F.hist[fr_bin(F.near_key[e], lo, scale)], 1u);
+                __syncthreads();
+                if (wave == 0) {
+                    fr_select(F, (uint32_t)A.fr_round, FR_SEL_BIN, lane);
+                    fr_select(F, (uint32_t)A.fr_near_fill, FR_SEL2_BIN, lane);
+                }
+                __syncthreads();
+                bsel = sh[FR_SEL_BIN];
+                bspill = sh[FR_SEL2_BIN];
+                const uint32_t cum = sh[FR_SEL_CUM];
+                __syncthreads();
+                if (cum <= (uint32_t)FR_READY_CAP / 2u || scale == 0.0) break;
+                hi = lo + (hi - lo) / (double)FR_NBINS;  // too many entries share the first bins: look closer
+            }
+            // near has grown too large to scan every round: everything beyond its smallest entries moves to far
+            const bool spill = nn_near > (uint32_t)A.fr_near_max && bspill < FR_NBINS - 1 && scale != 0.0;
+            const double l_ready = (bsel >= FR_NBINS - 1 || scale == 0.0) ? hi : lo + (double)(bsel + 1u) / scale;
+            if (tid == 0) {
+                sh[FR_RD_HEAD] = 0;
+                sh[FR_RD_TAIL] = 0;
+                sh_st_d(sh, FR_NEAR_MIN, inf);
+                sh_st_d(sh, FR_NEAR_MAX, 0.0);
+                sh_st_d(sh, FR_L_READY, l_ready);
+                if (spill) sh_st_d(sh, FR_L_FAR, lo + (double)(bspill + 1u) / scale);
+                sh_add(sh, FR_ROUNDS, 1u);
+            }
+            for (int i = tid; i < FR_READY_CAP; i += (int)blockDim.x) F.ready[i] = 0u;
+            __syncthreads();
+            const double lo_c = lo, scale_c = scale;
+            const uint32_t kept = fr_partition(
+                F.near_key, F.near_id, nn_near, wsum, n_waves,
+                [&](double k, uint32_t) -> int {
+                    const uint32_t b = fr_bin(k, lo_c, scale_c);
+                    return b <= bsel ? 1 : ((spill && b > bspill) ? 2 : 0);
+                },
+                [&](int c, double k, uint32_t i) {
+                    const unsigned long long b1 = __ballot(c == 1);
+                    if (b1) {
+                        uint32_t base = 0;
+                        if (lane == 0) base = sh_add(sh, FR_RD_TAIL, (uint32_t)__builtin_popcountll(b1));
+                        base = uni_u(base);
+                        if (c == 1) {
+                            const uint32_t pos = base + lane_rank(b1, lane);
+                            if (pos < (uint32_t)FR_READY_CAP)
+                                F.ready[pos] = i;
+                            else
+                                c = 2;  // (only if thousands of keys are equal to the last bit: they wait in far)
+                        }
+                    }
+                    const unsigned long long b2 = __ballot(c == 2);
+                    if (b2) {
+                        uint32_t base = 0;
+                        if (lane == 0) base = sh_add(sh, FR_FAR_N, (uint32_t)__builtin_popcountll(b2));
+                        base = uni_u(base);
+                        if (c == 2) {
+                            const uint32_t pos = base + lane_rank(b2, lane);
+                            F.far_key[pos] = k;
+                            F.far_id[pos] = i;
+                            sh_min_d(sh, FR_FAR_MIN, k);
+                            sh_max_d(sh, FR_FAR_MAX, k);
+                        }
+                    }
+                    if (c < 0 && i != 0u) {  // kept entries
+                        sh_min_d(sh, FR_NEAR_MIN, k);
+                        sh_max_d(sh, FR_NEAR_MAX, k);
+                    }
+                });
+            if (tid == 0) {
+                sh[FR_NEAR_N] = kept;
+                const uint32_t tl = sh[FR_RD_TAIL];
+                sh[FR_PENDING] = tl < (uint32_t)FR_READY_CAP ? tl : (uint32_t)FR_READY_CAP;
+            }
+            __syncthreads();
+        }
+    }
+
+    // ================= phase B: the reference's counts and ids =================
+    uint32_t nnodes_raw = sh[FR_NNODES];
+    nnodes_raw = nnodes_raw < S.max_nodes ? nnodes_raw : S.max_nodes;
+    __syncthreads();
+    PhaseB R;
+    R.n_popped = 0;
+    R.n_expanded = nnodes_raw;
+    if (status != PDMPC_ARENA_OVERFLOW) {
+        R = fr_phase_b<NW>(A, X, F, EE, goal, ref_ids, (LDS_AS unsigned char*)(X.lsm + A.lds.cand), F.far_key, F.far_id);
+        const uint32_t flags = sh[FR_FLAGS];
+        __syncthreads();
+        if (flags & FRF_TIE) return true;
+        if (flags & FRF_BUG) dep_timeout = true;  // reported as an error status: must never happen
+    }
+    // validity bytes of the LDS-resident nodes go to HBM with the rest (debug read-back of the tree, pdmpc_debug_tree)
+    {
+        const uint32_t nv = VS.NV < nnodes_raw ? VS.NV : nnodes_raw;
+        for (uint32_t i = (uint32_t)tid; i < nv; i += blockDim.x) VS.g[i] = VS.l[i];
+    }
+    if (tid == 0) {
+        atomicAdd(A.work_count + 2, (unsigned long long)sh[FR_PROCESSED]);
+        atomicAdd(A.work_count + 3, (unsigned long long)sh[FR_ROUNDS]);
+        A.tree_size[slot] = (int32_t)(nnodes_raw | 0x40000000u);  // marks the arena as a frontier tree (api.cpp reconstructs the reference's)
+    }
+    X.status = status;
+    X.n_popped = (int)R.n_popped;
+    X.goal = goal;
+    X.nnodes = R.n_expanded;
+    X.dep_timeout = dep_timeout;
+    return false;
+}
+
+template <int CHECKER, int NW>
+__device__ __forceinline__ void frontier_body(const KernelArgs& A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Ctx X;
+    search_prologue(A, X, (LDS_AS unsigned char*)smem, CHECKER == PDMPC_CHECK_INTERX);
+    const int tid = X.tid, lane = X.lane, wave = X.wave;
+    volatile lds_u32* l_shared = X.l_shared;
+    lds_u32* ref_ids = (lds_u32*)(X.lsm + A.lds.heap_key) + FR_READY_CAP + 1024;  // in the histogram's region, behind phase B's tables
+    const bool tie = frontier_search<CHECKER, NW>(A, X, ref_ids);
+    bool serial = false;
+    if (tie) {  // (uniform over the workgroup) start over with the exact open list; areas that arrived so far stay in the soup
+        __syncthreads();
+        if (tid == 0) {
+            l_shared[SH_STATE] = ST_RUN;
+            l_shared[SH_ARR_LO] = 0;
+            l_shared[SH_ARR_HI] = 0;
+            l_shared[SH_RESTART] = 0;
+            atomicAdd(A.tie_count, 1);
+        }
+        __syncthreads();
+        (void)search_loops<CHECKER, false, NW>(A, X);
+        serial = true;
+    }
+    if (lane == 0) {
+        atomicAdd(A.work_count + 0, X.C.tally[0]);
+        atomicAdd(A.work_count + 1, X.C.tally[1]);
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    search_epilogue(A, X, serial ? nullptr : ref_ids);
+}
+
+}  // namespace
+
+extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) void pdmpc_frontier_kernel(const KernelArgs A) { frontier_body<PDMPC_CHECK_INTERX, 1>(A); }
+extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) void pdmpc_frontier_kernel_sat(const KernelArgs A) { frontier_body<PDMPC_CHECK_SAT, 1>(A); }
+extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) void pdmpc_frontier_kernel_wide(const KernelArgs A) { frontier_body<PDMPC_CHECK_INTERX, 0>(A); }
+extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) void pdmpc_frontier_kernel_sat_wide(const KernelArgs A) { frontier_body<PDMPC_CHECK_SAT, 0>(A); }
+// compiled for six wavefronts per SIMD: two workgroups of twelve wavefronts per CU (launches with more workgroups than CUs)
+#define PDMPC_DENSE __attribute__((amdgpu_waves_per_eu(6, 6)))
+extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) PDMPC_DENSE void pdmpc_frontier_kernel_dense(const KernelArgs A) { frontier_body<PDMPC_CHECK_INTERX, 1>(A); }
+extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) PDMPC_DENSE void pdmpc_frontier_kernel_sat_dense(const KernelArgs A) { frontier_body<PDMPC_CHECK_SAT, 1>(A); }
+extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) PDMPC_DENSE void pdmpc_frontier_kernel_wide_dense(const KernelArgs A) { frontier_body<PDMPC_CHECK_INTERX, 0>(A); }
+extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) PDMPC_DENSE void pdmpc_frontier_kernel_sat_wide_dense(const KernelArgs A) { frontier_body<PDMPC_CHECK_SAT, 0>(A); }
+
+extern "C" int pdmpc_launch_frontier(const KernelArgs* args, int count, void* stream) {
+    if (count <= 0) return 0;
+    typedef void (*kernel_t)(const KernelArgs);
+    const bool interx = args->checker == PDMPC_CHECK_INTERX, one_word = args->n_words == 1;
+    kernel_t fn = interx ? (one_word ? pdmpc_frontier_kernel : pdmpc_frontier_kernel_wide) : (one_word ? pdmpc_frontier_kernel_sat : pdmpc_frontier_kernel_sat_wide);
+    if (args->dense) fn = interx ? (one_word ? pdmpc_frontier_kernel_dense : pdmpc_frontier_kernel_wide_dense) : (one_word ? pdmpc_frontier_kernel_sat_dense : pdmpc_frontier_kernel_sat_wide_dense);
+    hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)args->lds.total);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(fn, dim3(count), dim3(PDMPC_WAVE * args->n_waves), args->lds.total, (hipStream_t)stream, *args);
+    return (int)hipGetLastError();
+}

@@ -32,6 +32,7 @@
 #define PDMPC_QUEUE_HEAP 0     /* open list = libstdc++-faithful binary heap (exact for any keys) */
 #define PDMPC_QUEUE_BLOCKMIN 1 /* open list = block-min queue while the minimal key is unique, binary heap after the first tie */
 #define PDMPC_MAX_THREADS (PDMPC_WAVE * PDMPC_MAX_WAVES)
+#define PDMPC_SH_WORDS 64 /* 32-bit LDS words shared by the waves of a workgroup (state, mail boxes, counters of the frontier search) */
 
 struct DevManPose {
     double dx, dy, dyaw;
@@ -91,6 +92,9 @@ struct NodeArena {  // HBM arrays, per-vehicle stride = max_nodes entries
     uint32_t* heap_id;
     uint8_t* vstate;  // validity cache for nodes beyond the LDS-resident NV
     double* pop_log;  // block-min mode with dropping: keys of the pops in pop order (front), drop stamps as uint32 (from the back)
+                      // frontier kernel: keys of the `far` open entries (their nodes in heap_id), phase B: a node's branch maximum
+    double* near_key;  // frontier kernel: keys and nodes of the `near` open entries
+    uint32_t* near_id;
 };
 
 struct KernelArgs {
@@ -133,6 +137,10 @@ struct KernelArgs {
     int32_t sampled_n_random;
     unsigned long long* work_count;    // [0] edge checks evaluated, [1] segment pairs they stand for, [2] entries dropped from the open list, [3] those counted as pops (cumulative, all vehicles)
     int32_t* tie_count;                // [0] searches redone on the binary heap after a tied minimum, [1] speculation restarts, [2] arrivals (cumulative)
+    int32_t frontier;      // 1: this launch runs the frontier kernel (frontier_kernel.hip), 0: the pop-ordered kernel (search_kernel.hip)
+    int32_t fr_round;      // frontier kernel: open entries a round aims to take (about four per wavefront)
+    int32_t fr_near_fill;  // ... entries a refill moves from far to near
+    int32_t fr_near_max;   // ... size of near beyond which its tail is moved back to far
     int32_t speculate;  // 1: start searching before all predecessors have finished (results are identical, see arrival_sync)
     uint32_t spin_limit;
 };
@@ -147,6 +155,8 @@ int pdmpc_launch_heap_script(const int32_t* op, const int32_t* id, const double*
                              double* gkey, uint32_t* gid, int HL, void* stream);
 // defined in sampled_kernel.hip: the sampled optimizer (MonteCarloTreeSearch.m), `count` workgroups of one wavefront
 int pdmpc_launch_sampled(const KernelArgs* args, int count, void* stream);
+// defined in frontier_kernel.hip: the search with all wavefronts of a workgroup working on open nodes side by side
+int pdmpc_launch_frontier(const KernelArgs* args, int count, void* stream);
 int pdmpc_launch_bm_script(const int32_t* op, const double* key, int n, int32_t* out, unsigned long long* stats, double* gkey, int KR, int NB,
                            void* stream);
 #ifdef __cplusplus

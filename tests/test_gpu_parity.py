@@ -3,6 +3,8 @@
 The bar is bit-exactness: result records byte-identical, node-pop sequence identical, whole search tree
 identical (x, y, yaw, g, h as raw IEEE bits; trim, k, parent as integers).
 """
+import copy
+
 import numpy as np
 import pytest
 
@@ -40,7 +42,9 @@ def check_batch(options, mpa, iters, full_tree=True):
     h = Handle(options)
     h.upload_mpa(mpa)
     gpu = h.plan_batch(iters)
-    _, ref, traces = oracle.plan_batch(options, mpa, iters, trace=True)
+    unbounded = copy.copy(options)  # the reference's tree is unbounded (Tree.m:54-70); the backend's arenas grow on demand
+    unbounded.max_nodes = 1 << 30
+    _, ref, traces = oracle.plan_batch(unbounded, mpa, iters, trace=True)
     assert_records_equal(gpu, ref, "batch")
     if full_tree:
         for v in range(len(iters)):
