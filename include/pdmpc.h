@@ -243,6 +243,15 @@ int pdmpc_debug_tree(pdmpc_handle* handle, int32_t vehicle, int32_t capacity, do
                      double* yaw, double* g, double* h, int32_t* trim, int32_t* k, int32_t* parent,
                      int32_t* n);
 
+/* the arena of vehicle v as the kernel left it (the frontier kernel's own creation order, incl. nodes the reference never
+ * creates), with every node's open-list key and validity byte (0 never evaluated, 1 collision-free, 2 colliding) */
+int pdmpc_debug_raw_tree(pdmpc_handle* handle, int32_t vehicle, int32_t capacity, double* x, double* y, double* yaw, double* g,
+                         double* h, int32_t* trim, int32_t* k, int32_t* parent, double* key, uint8_t* validity, int32_t* n);
+
+/* live counters of a running frontier launch (needs PDMPC_DEBUG_PROGRESS=1 in the environment; callable from another thread
+ * while pdmpc_plan_* blocks): rounds, nodes processed, tree size, near / far entries, flags, best candidate, stage */
+int pdmpc_debug_progress(pdmpc_handle* handle, int32_t vehicle, uint32_t* words16);
+
 /* drives the device open list with a command script (op[i] == 0: push (id[i], key[i]); op[i] == 1: pop) the way the
  * reference drives priority_queue_interface_mex (PUSH / POP, .cpp:62-99); popped[] receives the popped ids (-1 on an empty
  * queue).  lds_entries = how many heap entries live in LDS (the rest spills to HBM).  Used by the heap-order unit test. */

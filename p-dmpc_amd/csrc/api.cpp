@@ -159,6 +159,7 @@ struct pdmpc_handle {
     int kernel_frontier = 1;  // 1: frontier kernel (all wavefronts work on open nodes side by side), 0: the pop-ordered kernel of round 1
     int fr_round = 0, fr_near_fill = 4096, fr_near_max = 12288;
     bool last_launch_frontier = false;
+    uint32_t* progress = nullptr;  // pinned, PDMPC_DEBUG_PROGRESS=1
     int queue_mode = PDMPC_QUEUE_BLOCKMIN;
     int speculate_expansion = 1;
     int waves_latency = PDMPC_WAVES_LATENCY, waves_crowded = PDMPC_WAVES_CROWDED;
@@ -531,6 +532,13 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.fr_near_fill = h->fr_near_fill;
     a.fr_near_max = h->fr_near_max;
     a.spin_limit = 1u << 22;
+    if (const char* e = getenv("PDMPC_SPIN_LIMIT")) a.spin_limit = (uint32_t)std::max(1024, atoi(e));  // debugging: fail fast
+    a.debug_tail = getenv("PDMPC_DEBUG_TAIL") ? 1 : 0;
+    if (getenv("PDMPC_DEBUG_PROGRESS") && !h->progress) {
+        if (hipHostMalloc((void**)&h->progress, (size_t)h->max_vehicles * 64 * 4, hipHostMallocMapped) != hipSuccess) h->progress = nullptr;
+        if (h->progress) std::memset(h->progress, 0, (size_t)h->max_vehicles * 64 * 4);
+    }
+    a.progress = h->progress;
     a.speculate = h->speculate;
     a.crowded = count > h->n_cu ? 1 : 0;
     a.dense = count > h->n_cu ? 1 : 0;
@@ -817,10 +825,14 @@ namespace {
 // produce the same records again) until it fits, the limit set with pdmpc_set_arena_limit is reached, or HBM runs out.
 int plan_packed_growing(pdmpc_handle* h, int32_t n, pdmpc_vehicle_out* out) {
     for (;;) {
+        const bool dbg = getenv("PDMPC_DEBUG_HOST") != nullptr;
+        if (dbg) fprintf(stderr, "pdmpc: launching %d vehicles, arena %u nodes\n", n, h->max_nodes);
         int rc = pdmpc_launch_packed(h);
         if (rc) return rc;
+        if (dbg) fprintf(stderr, "pdmpc: launched, waiting\n");
         rc = pdmpc_fetch_results(h, n, out);
         if (rc) return rc;
+        if (dbg) fprintf(stderr, "pdmpc: fetched, status[0] %d\n", n > 0 ? out[0].status : 0);
         bool overflow = false;
         for (int i = 0; i < n; ++i) overflow = overflow || out[i].status == PDMPC_ARENA_OVERFLOW;
         if (!overflow) return PDMPC_OK;
@@ -1191,6 +1203,42 @@ int pdmpc_debug_pop_trace(pdmpc_handle* h, int32_t vehicle, int32_t capacity, in
     *n = cnt;
     const int m = std::min(cnt, capacity);
     if (m > 0) HIPCHK(hipMemcpy(ids, h->d_trace.p + (size_t)vehicle * h->cfg.trace_pops, (size_t)m * 4, hipMemcpyDeviceToHost));
+    return PDMPC_OK;
+}
+
+int pdmpc_debug_raw_tree(pdmpc_handle* h, int32_t vehicle, int32_t capacity, double* x, double* y, double* yaw, double* g, double* hh, int32_t* trim,
+                         int32_t* k, int32_t* parent, double* key, uint8_t* validity, int32_t* n) {
+    if (!h || !n) return fail(PDMPC_ERR_INVALID, "null argument");
+    if (vehicle < 0 || vehicle >= h->max_vehicles) return fail(PDMPC_ERR_INVALID, "vehicle slot out of range");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    int32_t sz = 0;
+    HIPCHK(hipMemcpy(&sz, h->d_tree_size.p + vehicle, 4, hipMemcpyDeviceToHost));
+    sz &= ~PDMPC_TREE_FRONTIER;
+    *n = sz;
+    const size_t m = (size_t)std::max(std::min(sz, capacity), 0);
+    if (m == 0) return PDMPC_OK;
+    const size_t off = (size_t)vehicle * h->max_nodes;
+    std::vector<NodeRec> rec(m);
+    HIPCHK(hipMemcpy(rec.data(), h->anodes.p + off, m * sizeof(NodeRec), hipMemcpyDeviceToHost));
+    if (key) HIPCHK(hipMemcpy(key, h->ahk.p + off, m * 8, hipMemcpyDeviceToHost));
+    if (validity) HIPCHK(hipMemcpy(validity, h->avs.p + off, m, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < m; ++i) {
+        if (x) x[i] = rec[i].x;
+        if (y) y[i] = rec[i].y;
+        if (yaw) yaw[i] = rec[i].yaw;
+        if (g) g[i] = rec[i].g;
+        if (hh) hh[i] = rec[i].h;
+        if (parent) parent[i] = (int32_t)rec[i].parent;
+        if (trim) trim[i] = NODE_TRIM(rec[i].packed);
+        if (k) k[i] = NODE_K(rec[i].packed);
+    }
+    return PDMPC_OK;
+}
+
+int pdmpc_debug_progress(pdmpc_handle* h, int32_t vehicle, uint32_t* words16) {
+    if (!h || !words16 || vehicle < 0 || vehicle >= h->max_vehicles) return fail(PDMPC_ERR_INVALID, "bad argument");
+    for (int i = 0; i < 32; ++i) words16[i] = h->progress ? ((volatile uint32_t*)h->progress)[vehicle * 64 + i] : 0u;
     return PDMPC_OK;
 }
 

@@ -47,9 +47,10 @@
 #define FR_BEST_ID 40   // best goal candidate so far (1-based node, 0 = none)
 #define FR_SEL_BIN 41   // result of fr_select: bin ...
 #define FR_SEL_CUM 42   // ... and the number of entries up to and including it
-#define FR_SEL2_BIN 43  // second selection of the same histogram (spill boundary)
-#define FR_ROUNDS 44
-#define FR_PROCESSED 45
+#define FR_SEL2_BIN 43  // second selection of the same histogram (spill boundary) ...
+#define FR_SEL2_CUM 44  // ... and its count
+#define FR_ROUNDS 45
+#define FR_PROCESSED 60
 #define FR_BEST_B1 46   // (64 bit) largest key on the best candidate's path
 #define FR_NEAR_MIN 48  // (64 bit) exact minimum key of near
 #define FR_NEAR_MAX 50  // (64 bit) upper bound of near's keys
@@ -64,9 +65,38 @@
 #define FR_NBINS 2048
 #define FR_READY_CAP 2048
 
+#ifdef PDMPC_FR_PRINTF
+#define FR_LOG(...) printf(__VA_ARGS__)
+#else
+#define FR_LOG(...)
+#endif
+
+// per-wave position (code << 24 | detail) in words 16..31 of the slot's progress block
+#define FR_POS(code, detail)                                                                                                        \
+    if (A.progress && (threadIdx.x & 63) == 0)                                                                                      \
+        ((volatile uint32_t*)A.progress)[(size_t)(A.first + blockIdx.x) * 64 + 16 + (threadIdx.x >> 6)] = ((uint32_t)(code) << 24) | ((uint32_t)(detail) & 0xffffffu);
+
 namespace {
 
 typedef LDS_AS unsigned long long lds_u64s;
+
+// live counters for debugging (host-mapped memory, PDMPC_DEBUG_PROGRESS=1): stage = where the workgroup is
+#define FR_PROGRESS(stage)                                                                    \
+    if (A.progress && threadIdx.x == 0) {                                                     \
+        volatile uint32_t* pg__ = A.progress + (size_t)(A.first + blockIdx.x) * 64;           \
+        pg__[0] = sh[FR_ROUNDS];                                                              \
+        pg__[1] = sh[FR_PROCESSED];                                                           \
+        pg__[2] = sh[FR_NNODES];                                                              \
+        pg__[3] = sh[FR_NEAR_N];                                                              \
+        pg__[4] = sh[FR_FAR_N];                                                               \
+        pg__[5] = sh[FR_FLAGS];                                                               \
+        pg__[6] = sh[FR_BEST_ID];                                                             \
+        pg__[7] = (stage);                                                                    \
+        pg__[8] = sh[FR_PENDING];                                                             \
+        pg__[9] = sh[FR_RD_HEAD];                                                             \
+        pg__[10] = sh[FR_RD_TAIL];                                                            \
+        pg__[11] += 1u;                                                                       \
+    }
 
 __device__ __forceinline__ double sh_ld_d(volatile lds_u32* sh, int w) { return __longlong_as_double((long long)*(volatile lds_u64s*)(sh + w)); }
 __device__ __forceinline__ void sh_st_d(volatile lds_u32* sh, int w, double v) { *(volatile lds_u64s*)(sh + w) = (unsigned long long)__double_as_longlong(v); }
@@ -215,8 +245,11 @@ __device__ int fr_before(const Search& S, const double* gkey, uint32_t x, uint32
 __device__ void fr_offer_goal(const Frontier& F, const Search& S, const VState& VS, uint32_t x, int lane) {
     double b1;
     if (!fr_goal_path(S, VS, F.gkey, x, b1)) return;
-    if (lane == 0) {
-        while (atomicCAS((uint32_t*)&F.sh[FR_LOCK], 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(1);
+    for (;;) {  // (the whole wave loops; lane 0 tries)
+        uint32_t got = 0;
+        if (lane == 0) got = atomicCAS((uint32_t*)&F.sh[FR_LOCK], 0u, 1u) == 0u ? 1u : 0u;
+        if (uni_u(got)) break;
+        __builtin_amdgcn_s_sleep(1);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const uint32_t best = uni_u(F.sh[FR_BEST_ID]);
@@ -402,6 +435,7 @@ __device__ PhaseB fr_phase_b(const KernelArgs& A, Ctx& X, const Frontier& F, con
         }
         const int depth = NODE_K(pk_);
         bool resolved = !in;
+        int guard = 0;
         uint32_t my_d = 0;
         double my_b = -1.0;
         for (;;) {
@@ -450,6 +484,10 @@ __device__ PhaseB fr_phase_b(const KernelArgs& A, Ctx& X, const Frontier& F, con
                 }
             }
             if (__syncthreads_and(resolved ? 1 : 0)) break;
+            if (++guard > PDMPC_HP_MAX + 4) {  // (cannot happen: a chain inside a chunk is at most Hp long)
+                if (tid == 0) atomicOr((uint32_t*)&F.sh[FR_FLAGS], FRF_BUG);
+                break;
+            }
         }
         ch_d[tid] = 0;  // (nobody reads this chunk's states any more)
         if (in && (my_d & PB_ALIVE)) {
@@ -589,6 +627,8 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
     for (int i = tid; i < FR_READY_CAP; i += (int)blockDim.x) F.ready[i] = i == 0 ? 1u : 0u;
     __syncthreads();
 
+    if (lane == 0) FR_LOG("w%d start\n", wave);
+    FR_PROGRESS(10)
     int status = PDMPC_OK;
     bool dep_timeout = X.dep_timeout;
     uint32_t goal = 0;
@@ -599,32 +639,54 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
             // a ticket: the entry with that index is this wave's, whenever it is written (children of the running round may
             // still join the list); tickets nobody will ever serve are dropped when nothing is pending any more
             uint32_t cur = 0;
-            if (lane == 0) {
-                const uint32_t t = sh_add(sh, FR_RD_HEAD, 1u);
-                if (t < (uint32_t)FR_READY_CAP) {
-                    for (;;) {
-                        cur = *(volatile lds_u32*)&F.ready[t];
-                        if (cur != 0u) break;
-                        if (__hip_atomic_load((lds_u32*)(sh + FR_PENDING), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) break;
-                        __builtin_amdgcn_s_sleep(2);
+            uint32_t t = 0;
+            FR_POS(0, 0)
+            if (lane == 0) t = sh_add(sh, FR_RD_HEAD, 1u);
+            t = uni_u(t);
+            FR_POS(1, t)
+            if (t < (uint32_t)FR_READY_CAP) {
+                // the whole wave polls; every value the loop branches on is made wave-uniform explicitly, so the branches are
+                // scalar and the loop keeps all lanes together for the wave-wide operations that follow
+                for (uint32_t spins = 0;; ++spins) {
+                    cur = uni_u(*(volatile lds_u32*)&F.ready[t]);
+                    if (cur != 0u) break;
+                    if (uni_u(__hip_atomic_load((lds_u32*)(sh + FR_PENDING), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0u) break;
+                    if (spins > A.spin_limit) {  // (cannot happen: every pending entry is written and processed)
+                        if (lane == 0) atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_BUG);
+                        break;
                     }
+                    __builtin_amdgcn_s_sleep(2);
                 }
             }
             cur = uni_u(cur);
+            FR_POS(2, cur)
+            if (lane == 0) FR_LOG("w%d ticket %u cur %u pending %u\n", wave, t, cur, sh[FR_PENDING]);
             if (cur == 0u) break;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             fr_process<CHECKER, NW>(A, X, F, EE, cur);
+            FR_POS(3, cur)
+            if (lane == 0) FR_LOG("w%d processed %u nnodes %u near %u\n", wave, cur, sh[FR_NNODES], sh[FR_NEAR_N]);
             if (lane == 0) {
                 sh_add(sh, FR_PROCESSED, 1u);
                 __hip_atomic_fetch_sub((lds_u32*)(sh + FR_PENDING), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
+            FR_POS(4, cur)
         }
+        FR_POS(5, 0)
+        if (lane == 0) FR_LOG("w%d at barrier\n", wave);
         __syncthreads();
+        if (tid == 0) FR_LOG("boundary rounds %u processed %u near %u far %u best %u flags %u\n", sh[FR_ROUNDS], sh[FR_PROCESSED], sh[FR_NEAR_N], sh[FR_FAR_N], sh[FR_BEST_ID], sh[FR_FLAGS]);
+        FR_PROGRESS(1)
 
         // ================= round boundary (every thread; decisions are uniform) =====================================
         uint32_t flags = sh[FR_FLAGS];
         if (flags & FRF_OVERFLOW) {
             status = PDMPC_ARENA_OVERFLOW;
+            break;
+        }
+        if ((flags & FRF_BUG) || sh[FR_ROUNDS] > A.spin_limit) {  // watchdog: reported as an error status
+            dep_timeout = true;
+            status = PDMPC_EXHAUSTED;
             break;
         }
         // predecessors that finished meanwhile: their areas enter the soup, collision-free edges are re-checked
@@ -706,6 +768,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
             continue;
         }
 
+        FR_PROGRESS(2)
         // ---- near is empty: refill it from far with the entries below a key chosen from far's histogram
         uint32_t nn_near = near_n;
         if (nn_near == 0u) {
@@ -762,10 +825,16 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
             nn_near = sh[FR_NEAR_N];
         }
 
+        FR_PROGRESS(3)
         // ---- this round's entries: the smallest keys of near (histogram -> bin -> partition)
         {
             const double lo = sh_ld_d(sh, FR_NEAR_MIN);
             double hi = sh_ld_d(sh, FR_NEAR_MAX);
+            // A round takes the smallest open keys: few while the search is young (everything a round takes beyond what the
+            // reference pops is wasted, and an easy search is over after Hp + 1 pops), up to fr_round once a few hundred nodes
+            // have been processed: the overshoot stays below a quarter of the work done.
+            const uint32_t done_so_far = sh[FR_PROCESSED];
+            const uint32_t round_target = 1u + done_so_far / 4u < (uint32_t)A.fr_round ? 1u + done_so_far / 4u : (uint32_t)A.fr_round;
             uint32_t bsel = FR_NBINS - 1, bspill = FR_NBINS - 1;
             double scale = 0.0;
             for (int zoom = 0; zoom < 8; ++zoom) {
@@ -775,7 +844,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                 for (uint32_t e = (uint32_t)tid; e < nn_near; e += blockDim.x) atomicAdd((uint32_t*)&F.hist[fr_bin(F.near_key[e], lo, scale)], 1u);
                 __syncthreads();
                 if (wave == 0) {
-                    fr_select(F, (uint32_t)A.fr_round, FR_SEL_BIN, lane);
+                    fr_select(F, round_target, FR_SEL_BIN, lane);
                     fr_select(F, (uint32_t)A.fr_near_fill, FR_SEL2_BIN, lane);
                 }
                 __syncthreads();
@@ -839,6 +908,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                         sh_max_d(sh, FR_NEAR_MAX, k);
                     }
                 });
+            FR_PROGRESS(4)
             if (tid == 0) {
                 sh[FR_NEAR_N] = kept;
                 const uint32_t tl = sh[FR_RD_TAIL];
@@ -848,6 +918,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
         }
     }
 
+    FR_PROGRESS(5)
     // ================= phase B: the reference's counts and ids =================
     uint32_t nnodes_raw = sh[FR_NNODES];
     nnodes_raw = nnodes_raw < S.max_nodes ? nnodes_raw : S.max_nodes;
@@ -855,13 +926,14 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
     PhaseB R;
     R.n_popped = 0;
     R.n_expanded = nnodes_raw;
-    if (status != PDMPC_ARENA_OVERFLOW) {
+    if (status != PDMPC_ARENA_OVERFLOW && !dep_timeout) {
         R = fr_phase_b<NW>(A, X, F, EE, goal, ref_ids, (LDS_AS unsigned char*)(X.lsm + A.lds.cand), F.far_key, F.far_id);
         const uint32_t flags = sh[FR_FLAGS];
         __syncthreads();
         if (flags & FRF_TIE) return true;
         if (flags & FRF_BUG) dep_timeout = true;  // reported as an error status: must never happen
     }
+    FR_PROGRESS(6)
     // validity bytes of the LDS-resident nodes go to HBM with the rest (debug read-back of the tree, pdmpc_debug_tree)
     {
         const uint32_t nv = VS.NV < nnodes_raw ? VS.NV : nnodes_raw;
@@ -871,6 +943,15 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
         atomicAdd(A.work_count + 2, (unsigned long long)sh[FR_PROCESSED]);
         atomicAdd(A.work_count + 3, (unsigned long long)sh[FR_ROUNDS]);
         A.tree_size[slot] = (int32_t)(nnodes_raw | 0x40000000u);  // marks the arena as a frontier tree (api.cpp reconstructs the reference's)
+    }
+    if (tid == 0 && A.debug_tail) {  // diagnostics in the unused tail of the record (row HP_MAX of path_nodes); PDMPC_DEBUG_TAIL=1
+        double* dbg = X.O->path_nodes[PDMPC_HP_MAX];
+        dbg[0] = (double)sh[FR_ROUNDS];
+        dbg[1] = (double)sh[FR_PROCESSED];
+        dbg[2] = (double)nnodes_raw;
+        dbg[3] = (double)sh[FR_NEAR_N];
+        dbg[4] = (double)sh[FR_FAR_N];
+        dbg[5] = (double)sh[FR_FLAGS];
     }
     X.status = status;
     X.n_popped = (int)R.n_popped;

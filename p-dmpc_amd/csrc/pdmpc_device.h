@@ -137,6 +137,8 @@ struct KernelArgs {
     int32_t sampled_n_random;
     unsigned long long* work_count;    // [0] edge checks evaluated, [1] segment pairs they stand for, [2] entries dropped from the open list, [3] those counted as pops (cumulative, all vehicles)
     int32_t* tie_count;                // [0] searches redone on the binary heap after a tied minimum, [1] speculation restarts, [2] arrivals (cumulative)
+    uint32_t* progress;    // host-mapped (pinned) words, 16 per slot: the frontier kernel's live counters, for debugging a launch that does not end (or null)
+    int32_t debug_tail;    // 1: the frontier kernel leaves its round / node counters in the unused last row of pdmpc_vehicle_out.path_nodes
     int32_t frontier;      // 1: this launch runs the frontier kernel (frontier_kernel.hip), 0: the pop-ordered kernel (search_kernel.hip)
     int32_t fr_round;      // frontier kernel: open entries a round aims to take (about four per wavefront)
     int32_t fr_near_fill;  // ... entries a refill moves from far to near

@@ -45,6 +45,8 @@ EXPORTS = [
     "pdmpc_debug_blockmin_script",
     "pdmpc_debug_pop_trace",
     "pdmpc_debug_tree",
+    "pdmpc_debug_raw_tree",
+    "pdmpc_debug_progress",
     "pdmpc_last_error",
     "pdmpc_version",
 ]
@@ -101,6 +103,8 @@ def load_library(path=None):
     L.pdmpc_debug_blockmin_script.argtypes = [H, C.c_int32, abi.c_int32_p, abi.c_double_p, C.c_int32, abi.c_int32_p, abi.c_int32_p, abi.c_int32_p, abi.c_double_p, abi.c_double_p]
     L.pdmpc_debug_pop_trace.argtypes = [H, C.c_int32, C.c_int32, abi.c_int32_p, abi.c_int32_p]
     L.pdmpc_debug_tree.argtypes = [H, C.c_int32, C.c_int32] + [abi.c_double_p] * 5 + [abi.c_int32_p] * 4
+    L.pdmpc_debug_raw_tree.argtypes = [H, C.c_int32, C.c_int32] + [abi.c_double_p] * 5 + [abi.c_int32_p] * 3 + [abi.c_double_p, abi.c_uint8_p, abi.c_int32_p]
+    L.pdmpc_debug_progress.argtypes = [H, C.c_int32, C.POINTER(C.c_uint32)]
     L.pdmpc_last_error.restype = C.c_char_p
     L.pdmpc_version.restype = C.c_char_p
     for name in EXPORTS:
@@ -324,6 +328,26 @@ class Handle:
         n = C.c_int32()
         _check(self.L, self.L.pdmpc_debug_pop_trace(self.h, vehicle, capacity, ids.ctypes.data_as(abi.c_int32_p), C.byref(n)), "pdmpc_debug_pop_trace")
         return ids[: min(n.value, capacity)].copy()
+
+    def raw_tree(self, vehicle, capacity=1 << 20):
+        """The arena as the kernel left it: node arrays + key + validity (see pdmpc_debug_raw_tree)."""
+        f = {k: np.zeros(capacity) for k in ("x", "y", "yaw", "g", "h", "key")}
+        i = {k: np.zeros(capacity, dtype=np.int32) for k in ("trim", "k", "parent")}
+        val = np.zeros(capacity, dtype=np.uint8)
+        n = C.c_int32()
+        args = [f[k].ctypes.data_as(abi.c_double_p) for k in ("x", "y", "yaw", "g", "h")] + [i[k].ctypes.data_as(abi.c_int32_p) for k in ("trim", "k", "parent")]
+        args += [f["key"].ctypes.data_as(abi.c_double_p), val.ctypes.data_as(abi.c_uint8_p)]
+        _check(self.L, self.L.pdmpc_debug_raw_tree(self.h, vehicle, capacity, *args, C.byref(n)), "pdmpc_debug_raw_tree")
+        nn = min(n.value, capacity)
+        d = {k: v[:nn].copy() for k, v in f.items()}
+        d.update({k: v[:nn].copy() for k, v in i.items()})
+        d["validity"] = val[:nn].copy()
+        return d
+
+    def progress(self, vehicle):
+        w = (C.c_uint32 * 32)()
+        _check(self.L, self.L.pdmpc_debug_progress(self.h, vehicle, w), "pdmpc_debug_progress")
+        return list(w)
 
     def tree(self, vehicle, capacity=1 << 16):
         f = {k: np.zeros(capacity) for k in ("x", "y", "yaw", "g", "h")}

@@ -246,6 +246,38 @@ class PrioritizedSequentialController:
             return del_first_rpt_last(self.info_old[i].shapes)
         return None
 
+    # ---- HighLevelController.handle_others_fallback (HighLevelController.m:449-463) with
+    #      PrioritizedController.check_others_fallback (PrioritizedController.m:623-676)
+    def _handle_others_fallback(self):
+        """A vehicle that did not fall back itself still takes its fallback (the shifted previous plan, plan_fallback with
+        is_fallback_while_planning = false) if a fallback vehicle reaches it in the coupling graph from which the outgoing
+        sequential edges of the fallback vehicles -- the ones their successors have already planned against -- are removed."""
+        fallbacks = np.array([bool(info.needs_fallback) for info in self.infos])
+        if not fallbacks.any():
+            return
+        adjacency = np.asarray(self.last_adjacency, dtype=np.int64)
+        seq = np.asarray(self.last_directed_seq, dtype=np.int64)
+        outgoing = seq.copy()
+        outgoing[~fallbacks, :] = 0  # :653-654
+        fallback_matrix = adjacency - (outgoing + outgoing.T)  # :655-656
+        reached = np.zeros(self.n, dtype=bool)
+        for f in np.flatnonzero(fallbacks):  # shortestpath(fallback_graph, f, i) non-empty  :661-674
+            seen = np.zeros(self.n, dtype=bool)
+            seen[f] = True
+            stack = [int(f)]
+            while stack:
+                a = stack.pop()
+                for b in np.flatnonzero(fallback_matrix[a] != 0):
+                    if not seen[b]:
+                        seen[b] = True
+                        stack.append(int(b))
+            reached |= seen
+        for i in range(self.n):
+            if reached[i] and not fallbacks[i]:
+                info = self._fallback_info(i, self.infos[i])
+                info.needs_fallback = False  # plan_fallback(is_fallback_while_planning = false)  :717
+                self.infos[i] = info
+
     def _direct(self, adjacency, priorities):
         """Undirected coupling -> directed coupling (Prioritizer.prioritize): explicit priorities win; otherwise the
         controller's strategy."""
@@ -298,6 +330,7 @@ class PrioritizedSequentialController:
         adjacency = self.last_adjacency
         directed = self._direct(adjacency, priorities)
         directed_seq = self._group(directed)
+        self.last_directed_seq = np.asarray(directed_seq, dtype=np.int64)
         levels = kahn(directed_seq)
         self.last_levels = levels
         order = sorted(range(self.n), key=lambda i: (int(levels[i]), i))
@@ -323,8 +356,10 @@ class PrioritizedSequentialController:
         else:
             self._traffic_info()
             adjacency = self._couple()
+            self.last_adjacency = adjacency
             directed = self._direct(adjacency, None)
             directed_seq = self._group(directed)
+            self.last_directed_seq = np.asarray(directed_seq, dtype=np.int64)
             levels = kahn(directed_seq)
             self.last_levels = levels
             for lvl in range(1, int(levels.max()) + 1):  # PrioritizedSequentialController.m:83-91
@@ -338,6 +373,7 @@ class PrioritizedSequentialController:
                     results = self.plan_level(iters)
                 for i, it, info in zip(members, iters, results):
                     self._post_plan(i, it, info)
+        self._handle_others_fallback()
         # Simulation.apply (Simulation.m:86-100)
         for i, info in enumerate(self.infos):
             t = self.mpa.trims[int(info.predicted_trims[0]) - 1]

@@ -318,3 +318,58 @@ def test_controller_cuts_to_max_num_CLs():
         results[bound] = n_levels
     assert max(results[2]) <= 2
     assert max(results[99]) > 2  # otherwise the scenario does not exercise the cutter
+
+
+def test_fallback_spreads_to_coupled_vehicles():
+    """HighLevelController.handle_others_fallback / PrioritizedController.check_others_fallback
+    (HighLevelController.m:449-463, PrioritizedController.m:623-676): when a moving vehicle's search is exhausted it takes
+    its shifted previous plan, and so does every vehicle it reaches in the coupling graph without the fallback vehicle's
+    own outgoing sequential edges (its successors planned against the fallback already)."""
+    from oracle import oracle
+    from pdmpc.scenario import circle_scenario
+
+    options = Config(scenario_type=ScenarioType.circle, amount=4, Hp=5, max_nodes=1 << 15)
+    mpa = get_mpa(options)
+    force = {"on": False}
+
+    def plan(iters):
+        infos, _, _ = oracle.plan_batch(options, mpa, iters)
+        if force["on"] and ctl_box[0].current_level_members == [1]:
+            infos[0].is_exhausted = True  # vehicle 2 (moving): needs the fallback
+        return infos
+
+    ctl_box = [None]
+
+    class Ctl(PrioritizedSequentialController):
+        def step(self, plan_step=None):
+            return super().step(plan_step)
+
+    ctl = Ctl(options, circle_scenario(options), mpa, None, coupling="full")
+    ctl_box[0] = ctl
+    # drive level by level so the stub knows which vehicle it plans
+    orig_iter_for = ctl._iter_for
+    ctl.current_level_members = None
+
+    def plan_level(iters):
+        return plan(iters)
+
+    ctl.plan_level = plan_level
+    real_step = PrioritizedSequentialController.step
+
+    def tracked_iter_for(i, directed, directed_seq, device_handoff=False):
+        ctl.current_level_members = [i]  # full coupling + constant priorities: one vehicle per level
+        return orig_iter_for(i, directed, directed_seq, device_handoff)
+
+    ctl._iter_for = tracked_iter_for
+    for _ in range(3):
+        ctl.step()
+    prev = [ctl.info_old[i] for i in range(4)]
+    assert all(mpa.trims[int(p.predicted_trims[0]) - 1].speed > 0 for p in prev)  # everybody is moving
+    force["on"] = True
+    infos = ctl.step()
+    # vehicle 2 fell back while planning; 1 is reached over the edge 1-2, 3 and 4 over their edges to 1
+    assert infos[1].needs_fallback and not any(infos[i].needs_fallback for i in (0, 2, 3))
+    for i in range(4):
+        assert np.array_equal(infos[i].y_predicted[:, :-1], prev[i].y_predicted[:, 1:]), i
+        assert np.array_equal(infos[i].y_predicted[:, -1], prev[i].y_predicted[:, -1]), i
+        assert np.array_equal(infos[i].predicted_trims[:-1], prev[i].predicted_trims[1:]), i
