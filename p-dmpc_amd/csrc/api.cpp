@@ -166,6 +166,7 @@ struct pdmpc_handle {
     int n_validators = PDMPC_MAX_WAVES;  // (all there are)
     int n_waves = PDMPC_WAVES_LATENCY;   // of the last layout
     int bm_kr = 0, bm_nb = 0;
+    int two_per_cu = 0;   // the layout of the last launch leaves room for two workgroups per CU (80 KB each, dense build)
     int fr_cand_cap = 0;  // frontier kernel: 32-bit words of a wave's scratch (its candidate list)
     DevBuf<int32_t> d_trace;
     // batch blobs: several packed steps can stay resident side by side ("banks", pdmpc_select_bank)
@@ -183,7 +184,93 @@ struct pdmpc_handle {
 
 namespace {
 
+// LDS layout of the frontier kernel for one choice of (budget, wavefronts, maneuver areas in LDS or read through L2).
+// Regions: MPA tables, reference, per-wave shapes, shared words, obstacle soup, per-wave scratch (candidate list of an edge
+// check = expansion scratch of 16 x HP_MAX cost terms + 16 child positions = 12 B per thread of phase B's chunk state),
+// d_traveled table, ready list + histogram (also where the binary heap of the tie fallback lives), validity bytes, nodes.
+bool layout_frontier(pdmpc_handle* h, size_t budget, int n_waves, int areas, int soup_cap, int cand_cap, LdsLayout& L, uint32_t& hl, uint32_t& nv, uint32_t& nl,
+                     uint32_t& wscr) {
+    uint32_t off = 0;
+    L.mask = off;
+    off = align16(off + (uint32_t)h->mask_bytes);
+    L.man_index = off;
+    off = align16(off + (uint32_t)h->mi_bytes);
+    L.pose = off;
+    off = align16(off + (uint32_t)(h->n_man * sizeof(DevManPose)));
+    L.area = off;
+    if (areas) off = align16(off + (uint32_t)(h->n_man * 3 * PDMPC_VMAX * 16));
+    L.ref = off;
+    off += 3 * PDMPC_HP_MAX * 8;
+    L.shape = off;
+    off += (uint32_t)n_waves * (2 * PDMPC_VMAX + 1) * 16;
+    L.path = off;
+    off += align16((PDMPC_HP_MAX + 2) * 4 + 2 * (PDMPC_HP_MAX + 1) * 4 + PDMPC_SH_WORDS * 4 + PDMPC_HP_MAX * 4);
+    L.soup = off;
+    off = align16(off + (uint32_t)std::max(soup_cap, 1) * 16);
+    wscr = align16(std::max<uint32_t>((uint32_t)std::max(cand_cap, 1) * 4u, 16u * PDMPC_HP_MAX * 8u + 16u * 16u));
+    L.cand = off;
+    off += wscr * (uint32_t)n_waves;
+    L.expand = off;
+    off += (2 * PDMPC_HP_MAX * PDMPC_HP_MAX) * 8 + 16 * 16;
+    const uint32_t region = 2048u * 4u + 2048u * 4u + 256u;
+    const uint32_t min_nodes = 64 * (uint32_t)sizeof(NodeRec) + 1024;
+    if ((size_t)off + region + min_nodes + 256 > budget) return false;
+    L.heap_key = off;
+    hl = std::min((region / 12u) & ~3u, h->max_nodes & ~3u);
+    L.heap_id = off + align16(hl * 8);
+    off += region;
+    const uint32_t rest = (uint32_t)(budget - off - 256);
+    nv = std::min<uint32_t>(65536u, rest / 4 * 3);
+    nv = std::min(nv, h->max_nodes) & ~15u;
+    nl = std::min((rest - nv) / (uint32_t)sizeof(NodeRec), h->max_nodes);
+    L.vstate = off;
+    off += align16(nv);
+    L.nodes = off;
+    off += nl * (uint32_t)sizeof(NodeRec);
+    L.total = align16(off);
+    return L.total <= budget;
+}
+
+int compute_lds_frontier(pdmpc_handle* h, int n_launch, int soup_cap, int cand_cap) {
+    // More workgroups than CUs: two workgroups of waves_crowded wavefronts per CU (80 KB each) if the problem fits, with the
+    // maneuver areas read through L2 if need be; otherwise one workgroup per CU with the whole LDS.
+    struct Try { size_t budget; int waves, areas, two_per_cu; };
+    std::vector<Try> tries;
+    bool crowded = n_launch > h->n_cu;
+    if (const char* e = getenv("PDMPC_FR_TWO_PER_CU")) crowded = crowded && atoi(e) != 0;  // tuning knob
+    if (crowded) {
+        tries.push_back({kLdsMax / 2, h->waves_crowded, 1, 1});
+        tries.push_back({kLdsMax / 2, h->waves_crowded, 0, 1});
+    }
+    tries.push_back({kLdsMax, h->waves_latency, 1, 0});
+    tries.push_back({kLdsMax, h->waves_latency, 0, 0});
+    for (const Try& t : tries) {
+        LdsLayout L{};
+        uint32_t hl = 0, nv = 0, nl = 0, wscr = 0;
+        if (!layout_frontier(h, t.budget, t.waves, t.areas, soup_cap, cand_cap, L, hl, nv, nl, wscr)) continue;
+        if (getenv("PDMPC_DEBUG_LDS"))
+            fprintf(stderr, "pdmpc LDS layout (frontier): launch %d budget %zu waves %d areas %d wscr %u heap fallback %u nv %u nl %u total %u\n", n_launch, t.budget,
+                    t.waves, t.areas, wscr, hl, nv, nl, L.total);
+        h->lds = L;
+        h->n_waves = t.waves;
+        h->HL = (int)hl;
+        h->NL = (int)nl;
+        h->NV = (int)nv;
+        h->areas_in_lds = t.areas;
+        h->bm_kr = 0;
+        h->bm_nb = 64;
+        h->fr_cand_cap = (int)(wscr / 4u);
+        h->two_per_cu = t.two_per_cu;
+        return PDMPC_OK;
+    }
+    char buf[256];
+    snprintf(buf, sizeof buf, "obstacle soup (%d columns) + MPA tables do not fit into %zu B of LDS", soup_cap, kLdsMax);
+    return fail(PDMPC_ERR_CAPACITY, buf);
+}
+
 int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in, int cand_cap_in) {
+    if (h->kernel_frontier && !h->sampled_launch) return compute_lds_frontier(h, n_launch, soup_cap_in, cand_cap_in);
+    h->two_per_cu = n_launch > h->n_cu ? 1 : 0;
     const int Hp = h->cfg.Hp;
     struct { int soup_cap, cand_cap; } hb{soup_cap_in, cand_cap_in};
     const size_t budget = (n_launch > h->n_cu) ? kLdsMax / 2 : kLdsMax;  // 2 workgroups of 4 waves per CU still fit
@@ -230,49 +317,6 @@ int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in, int cand_cap_in)
         char buf[256];
         snprintf(buf, sizeof buf, "obstacle soup (%d columns) + MPA tables need %u B of LDS, budget %zu B", hb.soup_cap, off, budget);
         return fail(PDMPC_ERR_CAPACITY, buf);
-    }
-    if (h->kernel_frontier && !h->sampled_launch) {
-        // Frontier kernel: the per-wave candidate lists double as expansion scratch (16 x HP_MAX cost terms + 16 child
-        // positions per wave) and, in phase B, as the chunk state (12 B per thread); ready list + histogram (which is also
-        // where the binary heap of the tie fallback lives); then validity bytes and node records.
-        const uint32_t wscr = align16(std::max<uint32_t>((uint32_t)std::max(hb.cand_cap, 1) * 4u, 16u * PDMPC_HP_MAX * 8u + 16u * 16u));
-        off = L.cand;
-        off += wscr * (uint32_t)n_waves;
-        L.expand = off;
-        off += expand_bytes;
-        const uint32_t region_f = 2048u * 4u + 2048u * 4u + 256u;
-        if ((size_t)off + region_f + min_bytes + 256 > budget) {
-            char buf[256];
-            snprintf(buf, sizeof buf, "obstacle soup (%d columns) + MPA tables need %u B of LDS, budget %zu B", hb.soup_cap, off + region_f, budget);
-            return fail(PDMPC_ERR_CAPACITY, buf);
-        }
-        L.heap_key = off;
-        uint32_t hl_f = (region_f / 12u) & ~3u;
-        hl_f = std::min(hl_f, h->max_nodes & ~3u);
-        L.heap_id = off + align16(hl_f * 8);
-        off += region_f;
-        const uint32_t rest_f = (uint32_t)(budget - off - 256);
-        uint32_t nv_f = std::min<uint32_t>(65536u, rest_f / 4 * 3);
-        nv_f = std::min(nv_f, h->max_nodes) & ~15u;
-        uint32_t nl_f = (rest_f - nv_f) / (uint32_t)sizeof(NodeRec);
-        nl_f = std::min(nl_f, h->max_nodes);
-        L.vstate = off;
-        off += align16(nv_f);
-        L.nodes = off;
-        off += nl_f * (uint32_t)sizeof(NodeRec);
-        L.total = align16(off);
-        if (L.total > budget) return fail(PDMPC_ERR_CAPACITY, "internal: LDS layout exceeds budget");
-        if (getenv("PDMPC_DEBUG_LDS"))
-            fprintf(stderr, "pdmpc LDS layout (frontier): launch %d budget %zu waves %d wscr %u heap fallback %u nv %u nl %u total %u\n", n_launch, budget, n_waves, wscr, hl_f, nv_f, nl_f, L.total);
-        h->lds = L;
-        h->HL = (int)hl_f;
-        h->NL = (int)nl_f;
-        h->NV = (int)nv_f;
-        h->areas_in_lds = areas;
-        h->bm_kr = 0;
-        h->bm_nb = 64;
-        h->fr_cand_cap = (int)(wscr / 4u);
-        return PDMPC_OK;
     }
     // The open list gets up to three quarters of what is left.  Its region serves the binary heap (hl entries x 12 B)
     // or the block-min queue (key ring kr x 8 B; block minima and popped bits nb x 16 B; group minima 512 B).
@@ -541,7 +585,7 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.progress = h->progress;
     a.speculate = h->speculate;
     a.crowded = count > h->n_cu ? 1 : 0;
-    a.dense = count > h->n_cu ? 1 : 0;
+    a.dense = h->two_per_cu;
     if (const char* e = getenv("PDMPC_DENSE")) a.dense = atoi(e) != 0;  // tuning knob
     a.speculate_expansion = h->speculate_expansion;
     a.n_validators = h->n_validators;

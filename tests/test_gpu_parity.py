@@ -34,6 +34,39 @@ def assert_records_equal(gpu, ref, ctx=""):
         assert np.all(same), "%s field %s differs at %s" % (ctx, name, np.argwhere(~same)[:5])
 
 
+def compare_tree_and_pops(h, v, trace, pops=True):
+    """Pop sequence and whole search tree of vehicle v against the oracle's.  Where two popped nodes carry the same key the
+    reference's order is that of its binary heap; the frontier kernel only reproduces it where it decides the result (it
+    then falls back to the heap search), so for such searches the pop sequence and the tree are compared as sets."""
+    cap = 1 << 16
+    if len(trace.tree["x"]) >= cap or len(trace.pops) >= cap:
+        # the oracle's trace is cut at its capacity: counts only (the records, incl. the ids along the path, are compared by the caller)
+        assert len(h.tree(v, capacity=cap)["x"]) == cap or len(h.pop_trace(v, capacity=cap)) == cap
+        return
+    tied = problems.tied_pops(trace) > 0
+    if pops:
+        got = h.pop_trace(v, capacity=cap)
+        want = trace.pops[:cap]
+        assert len(got) == len(want), "pop count of vehicle %d" % v
+        if tied:
+            assert len(trace.pops) > cap or np.array_equal(np.sort(got), np.sort(want)), "popped set of vehicle %d" % v
+        else:
+            assert np.array_equal(got, want), "pop sequence of vehicle %d" % v
+    tree = h.tree(v, capacity=cap)
+    n = min(len(trace.tree["x"]), cap)
+    assert len(tree["x"]) == n
+    if tied:
+        if len(trace.tree["x"]) <= cap:
+            a = np.sort(np.stack([tree[k].view(np.uint64) for k in ("x", "y", "yaw", "g", "h")]), axis=1)
+            b = np.sort(np.stack([trace.tree[k].view(np.uint64) for k in ("x", "y", "yaw", "g", "h")]), axis=1)
+            assert np.array_equal(a, b), v
+        return
+    for key in ("x", "y", "yaw", "g", "h"):
+        assert np.array_equal(tree[key].view(np.uint64), trace.tree[key][:n].view(np.uint64)), (v, key)
+    for key in ("trim", "k", "parent"):
+        assert np.array_equal(tree[key], trace.tree[key][:n]), (v, key)
+
+
 def check_batch(options, mpa, iters, full_tree=True):
     oracle = _oracle()
     options.trace_pops = 1 << 15
@@ -48,14 +81,7 @@ def check_batch(options, mpa, iters, full_tree=True):
     assert_records_equal(gpu, ref, "batch")
     if full_tree:
         for v in range(len(iters)):
-            pops = h.pop_trace(v)
-            assert np.array_equal(pops, traces[v].pops[: len(pops)]), "pop sequence of vehicle %d" % v
-            assert len(pops) == min(len(traces[v].pops), options.trace_pops)
-            tree = h.tree(v)
-            for key in ("x", "y", "yaw", "g", "h"):
-                assert np.array_equal(tree[key].view(np.uint64), traces[v].tree[key].view(np.uint64)), (v, key)
-            for key in ("trim", "k", "parent"):
-                assert np.array_equal(tree[key], traces[v].tree[key]), (v, key)
+            compare_tree_and_pops(h, v, traces[v])
     stats = h.stats()
     h.close()
     # The product configuration (no pop trace): entries known to collide leave the open list on the side and are counted
@@ -67,11 +93,7 @@ def check_batch(options, mpa, iters, full_tree=True):
     assert_records_equal(gpu2, ref, "batch without trace")
     if full_tree:
         for v in range(len(iters)):
-            tree = h2.tree(v)
-            for key in ("x", "y", "yaw", "g", "h"):
-                assert np.array_equal(tree[key].view(np.uint64), traces[v].tree[key].view(np.uint64)), (v, key)
-            for key in ("trim", "k", "parent"):
-                assert np.array_equal(tree[key], traces[v].tree[key]), (v, key)
+            compare_tree_and_pops(h2, v, traces[v], pops=False)
     h2.close()
     options.trace_pops = 1 << 15
     return gpu, stats
@@ -158,9 +180,17 @@ def test_exhaustion_and_overflow_status():
     h.set_arena_limit(64)  # growth off: the status itself is under test
     h.allow_overflow = True
     gpu2 = h.plan_batch(iters2)
-    _, ref2, _ = oracle.plan_batch(options2, mpa2, iters2)
-    assert_records_equal(gpu2, ref2, "overflow")
+    unbounded = copy.copy(options2)
+    unbounded.max_nodes = 1 << 30
+    _, ref2, _ = oracle.plan_batch(unbounded, mpa2, iters2)
+    # a search whose reference tree does not fit must say so (never "exhausted"); one that reports a plan must report the
+    # reference's (the frontier kernel may create a few nodes the reference does not, so it can overflow a little earlier)
     assert (gpu2["status"] == abi.ARENA_OVERFLOW).any()
+    for v in range(len(iters2)):
+        if int(ref2[v]["n_expanded"]) > 64:
+            assert gpu2[v]["status"] == abi.ARENA_OVERFLOW
+        if gpu2[v]["status"] != abi.ARENA_OVERFLOW:
+            assert_records_equal(gpu2[v : v + 1], ref2[v : v + 1], "fits")
     h.close()
 
 
@@ -255,16 +285,22 @@ def test_random_road_problems_never_fall_back():
 @pytest.mark.parametrize(
     "env",
     [
-        {"PDMPC_QUEUE": "0"},
-        {"PDMPC_SPEC_EXPAND": "0"},
+        {"PDMPC_QUEUE": "0", "PDMPC_KERNEL": "serial"},
+        {"PDMPC_SPEC_EXPAND": "0", "PDMPC_KERNEL": "serial"},
         {"PDMPC_SPECULATE": "0"},
-        {"PDMPC_BM_RING": "512", "PDMPC_NV_MAX": "1024"},
-        {"PDMPC_DROP": "0"},
-        {"PDMPC_DROP": "1", "PDMPC_EAGER": "0"},
+        {"PDMPC_BM_RING": "512", "PDMPC_NV_MAX": "1024", "PDMPC_KERNEL": "serial"},
+        {"PDMPC_DROP": "0", "PDMPC_KERNEL": "serial"},
+        {"PDMPC_DROP": "1", "PDMPC_EAGER": "0", "PDMPC_KERNEL": "serial"},
         {"PDMPC_WAVES": "8"},
-        {"PDMPC_WAVES": "5", "PDMPC_VALIDATORS": "1"},
-        {"PDMPC_DENSE": "1", "PDMPC_WAVES": "12"},
-        {"PDMPC_NV_MAX": "1024", "PDMPC_DROP_BEYOND_LDS": "0"},
+        {"PDMPC_WAVES": "5", "PDMPC_VALIDATORS": "1", "PDMPC_KERNEL": "serial"},
+        {"PDMPC_DENSE": "1", "PDMPC_WAVES": "12", "PDMPC_KERNEL": "serial"},
+        {"PDMPC_NV_MAX": "1024", "PDMPC_DROP_BEYOND_LDS": "0", "PDMPC_KERNEL": "serial"},
+        {"PDMPC_KERNEL": "serial"},
+        {"PDMPC_NV_MAX": "1024"},
+        {"PDMPC_FR_ROUND": "1"},
+        {"PDMPC_FR_ROUND": "1000"},
+        {"PDMPC_FR_NEAR_FILL": "64", "PDMPC_FR_NEAR_MAX": "256"},
+        {"PDMPC_FR_NEAR_FILL": "64", "PDMPC_FR_NEAR_MAX": "256", "PDMPC_FR_ROUND": "7", "PDMPC_WAVES": "5"},
     ],
 )
 def test_tuning_switches_do_not_change_results(env, monkeypatch):

@@ -217,6 +217,8 @@ def test_fallback_while_a_predecessor_is_still_planning():
         gpu = opt.handle.fetch(3)
         ref, _ = oracle.plan_step(options, mpa, prob)
         assert_records_equal(gpu, ref, "fallback under speculation")
-        assert opt.handle.stats()["queue_fallbacks"] >= 1
+        # (the pop-ordered kernel falls back at the first tied pop; the frontier kernel only where a tie decides the result)
+        if os.environ.get("PDMPC_KERNEL") == "serial":
+            assert opt.handle.stats()["queue_fallbacks"] >= 1
     finally:
         opt.handle.close()
