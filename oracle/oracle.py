@@ -44,45 +44,58 @@ class TraceOut(C.Structure):
     ]
 
 
-def lib():
+_VARIANTS = {}
+
+
+def lib(variant=None):
+    """The oracle library; `variant` ("libm", "hypot", "fma") loads one of the arithmetic variants of
+    tools/tolerance_study.py instead (built by `make -C oracle variants`)."""
     global _LIB
+    if variant is not None:
+        if variant not in _VARIANTS:
+            subprocess.run(["make", "-s", "-C", _HERE, "variants"], check=True)
+            _VARIANTS[variant] = _declare(C.CDLL(os.path.join(_HERE, "_variants", "libpdmpc_oracle_%s.so" % variant)))
+        return _VARIANTS[variant]
     if _LIB is None:
         path = os.path.join(_HERE, "libpdmpc_oracle.so")
         if not os.path.exists(path):
             build()
-        L = C.CDLL(path)
-        dp, ip = abi.c_double_p, abi.c_int32_p
-        L.oracle_intersect_sat.argtypes = [dp, dp, C.c_int, dp, dp, C.c_int]
-        L.oracle_intersect_lanelet_boundary.argtypes = [dp, dp, C.c_int, dp, dp, C.c_int, dp, dp, C.c_int]
-        L.oracle_intersect_lanelets.argtypes = [dp, dp, C.c_int, dp, C.c_int]
-        L.oracle_interx.argtypes = [dp, dp, C.c_int, dp, dp, C.c_int]
-        L.oracle_pq_script.argtypes = [ip, ip, dp, C.c_int, ip]
-        L.oracle_sincos.argtypes = [dp, C.c_int, dp, dp]
-        L.oracle_sincos.restype = None
-        L.oracle_plan_batch.argtypes = [
-            C.POINTER(abi.Config),
-            C.POINTER(abi.Mpa),
-            C.c_int,
-            C.POINTER(abi.VehicleIn),
-            C.POINTER(abi.VehicleOut),
-            C.POINTER(TraceOut),
-            C.c_int,
-            C.POINTER(C.c_double),
-        ]
-        L.oracle_mt19937_doubles.argtypes = [C.c_uint32, C.c_int, dp]
-        L.oracle_mt19937_doubles.restype = None
-        L.oracle_plan_batch_sampled.argtypes = [
-            C.POINTER(abi.Config),
-            C.POINTER(abi.Mpa),
-            C.c_int,
-            C.POINTER(abi.VehicleIn),
-            C.POINTER(C.c_uint32),
-            C.POINTER(abi.VehicleOut),
-            C.c_int,
-            C.POINTER(C.c_double),
-        ]
-        _LIB = L
+        _LIB = _declare(C.CDLL(path))
     return _LIB
+
+
+def _declare(L):
+    dp, ip = abi.c_double_p, abi.c_int32_p
+    L.oracle_intersect_sat.argtypes = [dp, dp, C.c_int, dp, dp, C.c_int]
+    L.oracle_intersect_lanelet_boundary.argtypes = [dp, dp, C.c_int, dp, dp, C.c_int, dp, dp, C.c_int]
+    L.oracle_intersect_lanelets.argtypes = [dp, dp, C.c_int, dp, C.c_int]
+    L.oracle_interx.argtypes = [dp, dp, C.c_int, dp, dp, C.c_int]
+    L.oracle_pq_script.argtypes = [ip, ip, dp, C.c_int, ip]
+    L.oracle_sincos.argtypes = [dp, C.c_int, dp, dp]
+    L.oracle_sincos.restype = None
+    L.oracle_plan_batch.argtypes = [
+        C.POINTER(abi.Config),
+        C.POINTER(abi.Mpa),
+        C.c_int,
+        C.POINTER(abi.VehicleIn),
+        C.POINTER(abi.VehicleOut),
+        C.POINTER(TraceOut),
+        C.c_int,
+        C.POINTER(C.c_double),
+    ]
+    L.oracle_mt19937_doubles.argtypes = [C.c_uint32, C.c_int, dp]
+    L.oracle_mt19937_doubles.restype = None
+    L.oracle_plan_batch_sampled.argtypes = [
+        C.POINTER(abi.Config),
+        C.POINTER(abi.Mpa),
+        C.c_int,
+        C.POINTER(abi.VehicleIn),
+        C.POINTER(C.c_uint32),
+        C.POINTER(abi.VehicleOut),
+        C.c_int,
+        C.POINTER(C.c_double),
+    ]
+    return L
 
 
 def _xy(p):
@@ -159,7 +172,7 @@ def make_abi_config(options, checker=None):
     )
 
 
-def plan_batch_raw(options, mpa_struct, veh_arr, n, n_threads=1, trace=False, trace_capacity=1 << 16):
+def plan_batch_raw(options, mpa_struct, veh_arr, n, n_threads=1, trace=False, trace_capacity=1 << 16, variant=None):
     """Low-level: returns (records, traces or None, elapsed_ms)."""
     cfg = make_abi_config(options)
     out = abi.out_array(n)
@@ -189,7 +202,7 @@ def plan_batch_raw(options, mpa_struct, veh_arr, n, n_threads=1, trace=False, tr
             for name in ("trim", "k", "parent"):
                 setattr(t, name, b[name].ctypes.data_as(abi.c_int32_p))
     elapsed = C.c_double(0.0)
-    rc = lib().oracle_plan_batch(C.byref(cfg), C.byref(mpa_struct), n, veh_arr, abi.out_ptr(out), tr_arr, n_threads, C.byref(elapsed))
+    rc = lib(variant).oracle_plan_batch(C.byref(cfg), C.byref(mpa_struct), n, veh_arr, abi.out_ptr(out), tr_arr, n_threads, C.byref(elapsed))
     if rc != 0:
         raise RuntimeError("oracle_plan_batch failed: %d" % rc)
     traces = None

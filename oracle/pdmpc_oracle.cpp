@@ -32,6 +32,22 @@
 #include "../include/pdmpc.h"
 #include "../include/pdmpc_math.h"
 
+// Arithmetic variants for tools/tolerance_study.py (never used by the parity tests): MATLAB's cos / sin / norm / matrix
+// products are closed source, so the oracle's single-IEEE-operation reading of them is one of several plausible ones.
+//   ORACLE_LIBM_SINCOS   glibc's sin / cos instead of include/pdmpc_math.h
+//   ORACLE_HYPOT_NORM    hypot(dx, dy) (scaled, correctly rounded in glibc) instead of sqrt(dx*dx + dy*dy) for norm / vecnorm
+//   (FMA contraction of the dot products: the same file compiled with -ffp-contract=fast -mfma)
+#ifdef ORACLE_LIBM_SINCOS
+#define ORACLE_SINCOS(x, s, c) (*(s) = std::sin(x), *(c) = std::cos(x))
+#else
+#define ORACLE_SINCOS(x, s, c) pdmpc_sincos((x), (s), (c))
+#endif
+#ifdef ORACLE_HYPOT_NORM
+#define ORACLE_NORM2(a, b) std::hypot((a), (b))
+#else
+#define ORACLE_NORM2(a, b) std::sqrt((a) * (a) + (b) * (b))
+#endif
+
 namespace {
 
 const double kNaN = std::numeric_limits<double>::quiet_NaN();
@@ -83,7 +99,7 @@ bool intersect_a_b(const Poly& s1, const Poly& s2) {
         // axis = [-edge_vector(2,:); edge_vector(1,:)]                           :21
         const double ax = -ey, ay = ex;
         // normed_axis = axis ./ vecnorm(axis)                                    :23
-        const double nrm = std::sqrt(ax * ax + ay * ay);
+        const double nrm = ORACLE_NORM2(ax, ay);
         const double nx = ax / nrm, ny = ay / nrm;
         // dotprod1 = normed_axis' * shape1; min/max over columns                 :26-29
         double min1 = kNaN, max1 = kNaN, min2 = kNaN, max2 = kNaN;
@@ -333,7 +349,7 @@ void graph_search(const pdmpc_config& opt, const Mpa& mpa, const pdmpc_vehicle_i
             const int cK = tree.k[cur - 1];
             const pdmpc_maneuver& m = mpa.maneuver(t1, t2);
             double c, s;
-            pdmpc_sincos(pYaw, &s, &c);  // c = cos(pYaw); s = sin(pYaw)                   :155-156
+            ORACLE_SINCOS(pYaw, &s, &c);  // c = cos(pYaw); s = sin(pYaw)                   :155-156
             shape = rotate_translate(m.area, m.n_cols, c, s, pX, pY);  // :158-160
             Poly shape_wo = rotate_translate(m.area_without_offset, m.n_cols, c, s, pX, pY);  // :162-164
             Poly shape_bc = (cK == Hp) ? rotate_translate(m.area_large_offset, m.n_cols, c, s, pX, pY)  // :166-170
@@ -422,7 +438,7 @@ void graph_search(const pdmpc_config& opt, const Mpa& mpa, const pdmpc_vehicle_i
             const int t2 = succ[ic];
             const pdmpc_maneuver& m = mpa.maneuver(curTrim, t2);
             double c, s;
-            pdmpc_sincos(curYaw, &s, &c);                         // :50-51
+            ORACLE_SINCOS(curYaw, &s, &c);                         // :50-51
             const double expX = c * m.dx - s * m.dy + curX;       // :53
             const double expY = s * m.dx + c * m.dy + curY;       // :54
             const double expYaw = curYaw + m.dyaw;                // :55
@@ -430,7 +446,7 @@ void graph_search(const pdmpc_config& opt, const Mpa& mpa, const pdmpc_vehicle_i
             {
                 // expG += norm([expX - ref(k_exp,1); expY - ref(k_exp,2)])^2               :61
                 const double ddx = expX - it.ref_x[k_exp - 1], ddy = expY - it.ref_y[k_exp - 1];
-                const double nrm = std::sqrt(ddx * ddx + ddy * ddy);
+                const double nrm = ORACLE_NORM2(ddx, ddy);
                 expG = expG + nrm * nrm;
             }
             double expH = 0;          // :35
@@ -438,7 +454,7 @@ void graph_search(const pdmpc_config& opt, const Mpa& mpa, const pdmpc_vehicle_i
             for (int i_t = 1; i_t <= time_steps_to_go; ++i_t) {  // :68-73
                 d_traveled_max = d_traveled_max + opt.dt_seconds * it.v_ref[k_exp + i_t - 1];
                 const double ddx = expX - it.ref_x[k_exp + i_t - 1], ddy = expY - it.ref_y[k_exp + i_t - 1];
-                const double nrm = std::sqrt(ddx * ddx + ddy * ddy);
+                const double nrm = ORACLE_NORM2(ddx, ddy);
                 const double diff = nrm - d_traveled_max;
                 const double m0 = (diff > 0) ? diff : 0.0;  // max(0, diff): NaN -> 0, -0 handled below
                 expH = expH + m0 * m0;
@@ -620,12 +636,12 @@ void monte_carlo_tree_search(const pdmpc_config& opt, const Mpa& mpa, const pdmp
             const int goal_trim = succ[child_position];
             const pdmpc_maneuver& m = mpa.maneuver(parent_trim, goal_trim);
             double c, s;
-            pdmpc_sincos(node_pose[2], &s, &c);
+            ORACLE_SINCOS(node_pose[2], &s, &c);
             const double start_pose[3] = {node_pose[0], node_pose[1], node_pose[2]};
             apply_maneuver(node_pose, m, c, s);
             {  // solution_cost += norm(node_pose(1:2) - reference_trajectory_points(:, i_step))^2       :143
                 const double ddx = node_pose[0] - it.ref_x[i_step - 1], ddy = node_pose[1] - it.ref_y[i_step - 1];
-                const double nrm = std::sqrt(ddx * ddx + ddy * ddy);
+                const double nrm = ORACLE_NORM2(ddx, ddy);
                 solution_cost = solution_cost + nrm * nrm;
             }
             const bool is_expanded = children[node_id][child_position] != 1;  // :145
@@ -692,7 +708,7 @@ void monte_carlo_tree_search(const pdmpc_config& opt, const Mpa& mpa, const pdmp
         if (i >= 1) {
             const pdmpc_maneuver& m = mpa.maneuver(trims[path[i - 1]], trims[nd]);
             double c, s;
-            pdmpc_sincos(pose[2], &s, &c);
+            ORACLE_SINCOS(pose[2], &s, &c);
             apply_maneuver(pose, m, c, s);
         }
         info.tree_path[i] = (int32_t)nd;

@@ -157,7 +157,7 @@ struct pdmpc_handle {
     int sampled_n_random = 0;
     bool sampled_launch = false;
     int kernel_frontier = 1;  // 1: frontier kernel (all wavefronts work on open nodes side by side), 0: the pop-ordered kernel of round 1
-    int fr_round = 0, fr_near_fill = 4096, fr_near_max = 12288;
+    int fr_round = 0, fr_near_fill = 1024, fr_near_max = 2048;
     bool last_launch_frontier = false;
     uint32_t* progress = nullptr;  // pinned, PDMPC_DEBUG_PROGRESS=1
     int queue_mode = PDMPC_QUEUE_BLOCKMIN;

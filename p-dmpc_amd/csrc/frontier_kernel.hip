@@ -56,14 +56,15 @@
 #define FR_NEAR_MAX 50  // (64 bit) upper bound of near's keys
 #define FR_FAR_MIN 52   // (64 bit) exact minimum key of far
 #define FR_FAR_MAX 54   // (64 bit) upper bound of far's keys
-#define FR_L_READY 56   // (64 bit) children with key <= this join the running round
 #define FR_L_FAR 58     // (64 bit) children with key > this go to far
+#define FR_PATH_FOR 61  // the goal candidate whose path is in the relevance tables (0: none)
+#define FR_DROPPED 62   // open entries dropped because they come after the best candidate (restored if that one is invalidated)
 #define FRF_OVERFLOW 1u
 #define FRF_TIE 2u
 #define FRF_INVALIDATED 4u
 #define FRF_BUG 8u
 #define FR_NBINS 2048
-#define FR_READY_CAP 2048
+#define FR_READY_CAP 1024
 
 #ifdef PDMPC_FR_PRINTF
 #define FR_LOG(...) printf(__VA_ARGS__)
@@ -110,6 +111,15 @@ __device__ __forceinline__ void sh_max_d(volatile lds_u32* sh, int w, double v) 
 __device__ __forceinline__ uint32_t sh_add(volatile lds_u32* sh, int w, uint32_t v) {
     return __hip_atomic_fetch_add((lds_u32*)(sh + w), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// A wave-wide counter update whose old value every lane needs: EVERY lane issues the LDS atomic (lane 0 adds v, the others
+// add 0) and lane 0's result is broadcast.  The obvious `if (lane == 0) old = atomic(...); old = readfirstlane(old)` gives the
+// compiler a divergent branch in front of a wave-uniform value: hipcc 7.2 threads the lanes that skip the branch past it and
+// lets them run the code that follows — wave-wide node processing — apart from lane 0.  No branch, no threading; the
+// atomic optimizer still merges the 64 requests into one.
+__device__ __forceinline__ uint32_t sh_add_uniform(volatile lds_u32* sh, int w, uint32_t v, int lane) {
+    const uint32_t old = __hip_atomic_fetch_add((lds_u32*)(sh + w), lane == 0 ? v : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+}
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long ballot, int lane) { return (uint32_t)__builtin_popcountll(ballot & ((1ull << lane) - 1ull)); }
 
 // monotone map key -> bin of a linear histogram over [lo, lo + nb / scale)
@@ -132,7 +142,7 @@ struct Frontier {
 };
 
 // Smallest bin whose cumulative count reaches `target` (the last non-empty bin if the total is smaller).  One wave calls;
-// lane 0 stores bin and cumulative count in sh[w_bin], sh[w_bin + 1].
+// bin and cumulative count go to sh[w_bin], sh[w_bin + 1].
 __device__ void fr_select(const Frontier& F, uint32_t target, int w_bin, int lane) {
     const int per = FR_NBINS / PDMPC_WAVE;
     uint32_t loc = 0;
@@ -145,51 +155,57 @@ __device__ void fr_select(const Frontier& F, uint32_t target, int w_bin, int lan
     }
     const uint32_t total = lane_u(inc, PDMPC_WAVE - 1);
     const uint32_t want = target < total ? target : total;
-    const unsigned long long reach = __ballot(inc >= want && loc != 0u);
-    uint32_t bin = 0, cum = 0;
-    if (reach) {
-        const int l = __builtin_ctzll(reach);
-        if (lane == l) {
-            uint32_t c = inc - loc;
-            for (int q = 0; q < per; ++q) {
-                c += F.hist[lane * per + q];
-                if (c >= want && F.hist[lane * per + q] != 0u) {
-                    bin = (uint32_t)(lane * per + q);
-                    cum = c;
-                    break;
-                }
-            }
-        }
-        bin = lane_u(bin, l);
-        cum = lane_u(cum, l);
+    // every lane looks for the crossing in its own bins (no lane-dependent branch around values that are broadcast later)
+    uint32_t c = inc - loc, bin = 0, cum = 0;
+    bool found = false;
+    for (int q = 0; q < per; ++q) {
+        const uint32_t hq = F.hist[lane * per + q];
+        c += hq;
+        const bool here = !found && hq != 0u && c >= want;
+        bin = here ? (uint32_t)(lane * per + q) : bin;
+        cum = here ? c : cum;
+        found = found || here;
     }
+    const unsigned long long reach = __ballot(found);
+    const int l = reach ? __builtin_ctzll(reach) : 0;
+    bin = lane_u(bin, l);
+    cum = lane_u(cum, l);
     if (lane == 0) {
-        F.sh[w_bin] = bin;
-        F.sh[w_bin + 1] = cum;
+        F.sh[w_bin] = reach ? bin : 0u;
+        F.sh[w_bin + 1] = reach ? cum : 0u;
     }
 }
 
-// Workgroup-wide stable partition of the list (key[], id[]) of n entries: cls(key, id) == 0 keeps an entry (compacted in
-// place, order preserved), any other class hands it to emit(cls, key, id) — which every lane of a wave calls together
-// (cls < 0: this lane has nothing), so it can aggregate its atomics per wave.  Returns the number of kept entries.
+// Workgroup-wide partition of the list (key[], id[]) of n entries, FR_PER entries per thread and chunk (their loads are
+// issued together: the lists live in HBM and a pass is bound by the latency of its loads).  cls(key, id) == 0 keeps an entry
+// (compacted in place), any other class hands it to emit(cls, key, id) — which every lane of a wave calls together (cls < 0:
+// this lane has nothing), so it can aggregate its atomics per wave.  Returns the number of kept entries.
+#define FR_PER 4
 template <class Cls, class Emit>
 __device__ uint32_t fr_partition(double* key, uint32_t* id, uint32_t n, volatile lds_u32* wsum, int n_waves, Cls cls, Emit emit) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t bd = blockDim.x;
     uint32_t w = 0;
     int buf = 0;
-    for (uint32_t base = 0; base < n; base += blockDim.x, buf ^= 16) {
-        const uint32_t e = base + (uint32_t)tid;
-        const bool in = e < n;
-        double k = 0.0;
-        uint32_t i = 0;
-        int c = -1;
-        if (in) {
-            k = key[e];
-            i = id[e];
-            c = cls(k, i);
+    for (uint32_t base = 0; base < n; base += FR_PER * bd, buf ^= 16) {
+        double k[FR_PER];
+        uint32_t i[FR_PER];
+        int c[FR_PER];
+#pragma unroll
+        for (int j = 0; j < FR_PER; ++j) {
+            const uint32_t e = base + (uint32_t)j * bd + (uint32_t)tid;
+            k[j] = e < n ? key[e] : 0.0;
+            i[j] = e < n ? id[e] : 0u;
         }
-        const unsigned long long keep = __ballot(c == 0);
-        if (lane == 0) wsum[buf + wave] = (uint32_t)__builtin_popcountll(keep);
+        uint32_t mine = 0;
+        unsigned long long keep[FR_PER];
+#pragma unroll
+        for (int j = 0; j < FR_PER; ++j) {
+            c[j] = i[j] ? cls(k[j], i[j]) : -1;
+            keep[j] = __ballot(c[j] == 0);
+            mine += (uint32_t)__builtin_popcountll(keep[j]);
+        }
+        if (lane == 0) wsum[buf + wave] = mine;
         __syncthreads();  // every entry of this chunk has been read
         uint32_t off = 0, tot = 0;
         for (int q = 0; q < n_waves; ++q) {
@@ -197,16 +213,60 @@ __device__ uint32_t fr_partition(double* key, uint32_t* id, uint32_t n, volatile
             off += q < wave ? v : 0u;
             tot += v;
         }
-        if (c == 0) {
-            const uint32_t pos = w + off + lane_rank(keep, lane);
-            key[pos] = k;
-            id[pos] = i;
+#pragma unroll
+        for (int j = 0; j < FR_PER; ++j) {
+            if (c[j] == 0) {
+                const uint32_t pos = w + off + lane_rank(keep[j], lane);
+                key[pos] = k[j];
+                id[pos] = i[j];
+            }
+            off += (uint32_t)__builtin_popcountll(keep[j]);
+            emit(c[j] > 0 ? c[j] : -1, k[j], i[j]);
         }
-        emit(c > 0 ? c : -1, k, i);
         w += tot;
     }
     __syncthreads();
     return w;
+}
+
+// linear histogram (FR_NBINS bins over [lo, lo + FR_NBINS / scale)) of a list's keys; the caller has zeroed the bins
+__device__ void fr_histogram(const Frontier& F, const double* key, uint32_t n, double lo, double scale) {
+    const uint32_t bd = blockDim.x;
+    for (uint32_t base = 0; base < n; base += FR_PER * bd) {
+        double k[FR_PER];
+#pragma unroll
+        for (int j = 0; j < FR_PER; ++j) {
+            const uint32_t e = base + (uint32_t)j * bd + threadIdx.x;
+            k[j] = e < n ? key[e] : -1.0;
+        }
+#pragma unroll
+        for (int j = 0; j < FR_PER; ++j)
+            if (k[j] >= 0.0) __hip_atomic_fetch_add(&F.hist[fr_bin(k[j], lo, scale)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
+// Relevance of an open node once a goal candidate G is known: does the reference pop a (1-based) before G?  gp_path[d] = node
+// of G's path at depth d, gp_mp[d] = largest key of that path below depth d.  a leaves the path at some depth d; it comes
+// first iff the largest key on its own branch is smaller than gp_mp[d].  One thread; sets FRF_TIE on equality.
+__device__ bool fr_relevant(const Search& S, const double* gkey, const lds_u32* gp_path, const lds_f64* gp_mp, uint32_t a, volatile lds_u32* sh) {
+    uint32_t x = a;
+    double mx = -1.0;
+    for (;;) {
+        const uint32_t i = x - 1u;
+        const d2 q = i < S.NL ? (d2)S.ln[4 * (size_t)i + 3] : ((const d2*)(S.gn + i))[3];
+        const uint64_t u = (uint64_t)__double_as_longlong(q.y);
+        const int d = NODE_K((uint32_t)(u >> 32));
+        if (gp_path[d] == x) {
+            if (x == a) return true;  // on the path itself
+            const double m = gp_mp[d];
+            if (mx == m) atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_TIE);
+            return mx < m;
+        }
+        const double k = gkey[i];
+        mx = k > mx ? k : mx;
+        x = (uint32_t)(u & 0xffffffffull);
+        if (!x) return true;  // (cannot happen: the root is on every path)
+    }
 }
 
 // X (1-based, at the horizon, edge known to be collision-free): largest key on its path, and whether every ancestor is
@@ -245,10 +305,10 @@ __device__ int fr_before(const Search& S, const double* gkey, uint32_t x, uint32
 __device__ void fr_offer_goal(const Frontier& F, const Search& S, const VState& VS, uint32_t x, int lane) {
     double b1;
     if (!fr_goal_path(S, VS, F.gkey, x, b1)) return;
-    for (;;) {  // (the whole wave loops; lane 0 tries)
-        uint32_t got = 0;
-        if (lane == 0) got = atomicCAS((uint32_t*)&F.sh[FR_LOCK], 0u, 1u) == 0u ? 1u : 0u;
-        if (uni_u(got)) break;
+    for (;;) {  // (every lane tries — at most one can win — and the wave proceeds when one did: no lane-0-only branch, see sh_add_uniform)
+        uint32_t expect = 0u;
+        const bool won = __hip_atomic_compare_exchange_strong((lds_u32*)(F.sh + FR_LOCK), &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (__ballot(won)) break;
         __builtin_amdgcn_s_sleep(1);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -276,29 +336,16 @@ __device__ void fr_offer_goal(const Frontier& F, const Search& S, const VState& 
     }
 }
 
-// Children of one expansion join the open set: the running round (ready), near or far by key.  Whole wave calls.
+// Children of one expansion join the open set: near or far by key.  (They never join the running round: the reference pops
+// the smallest open key next, and a round that also swallowed everything its own nodes generate would walk whole subtrees
+// the reference leaves as soon as it reaches the horizon.)  Whole wave calls.
 __device__ __forceinline__ void fr_push_children(const Frontier& F, bool active, uint32_t i0, double f, int lane) {
-    const double l_ready = sh_ld_d(F.sh, FR_L_READY), l_far = sh_ld_d(F.sh, FR_L_FAR);
+    const double l_far = sh_ld_d(F.sh, FR_L_FAR);
     int cls = -1;
-    if (active) cls = f > l_far ? 2 : (f <= l_ready ? 0 : 1);
-    const unsigned long long b0 = __ballot(cls == 0);
-    if (b0) {
-        const uint32_t cnt = (uint32_t)__builtin_popcountll(b0);
-        uint32_t base = 0;
-        if (lane == 0) base = sh_add(F.sh, FR_RD_TAIL, cnt);
-        base = uni_u(base);
-        const uint32_t pos = base + lane_rank(b0, lane);
-        const bool fits = cls == 0 && pos < (uint32_t)FR_READY_CAP;
-        const unsigned long long bf = __ballot(fits);
-        if (lane == 0 && bf) sh_add(F.sh, FR_PENDING, (uint32_t)__builtin_popcountll(bf));  // (this wave's own node is still pending)
-        if (fits) F.ready[pos] = i0 + 1u;
-        if (cls == 0 && !fits) cls = 1;  // the round's list is full: wait in near
-    }
+    if (active) cls = f > l_far ? 2 : 1;
     const unsigned long long b1 = __ballot(cls == 1);
     if (b1) {
-        uint32_t base = 0;
-        if (lane == 0) base = sh_add(F.sh, FR_NEAR_N, (uint32_t)__builtin_popcountll(b1));
-        base = uni_u(base);
+        const uint32_t base = sh_add_uniform(F.sh, FR_NEAR_N, (uint32_t)__builtin_popcountll(b1), lane);
         if (cls == 1) {
             const uint32_t pos = base + lane_rank(b1, lane);
             F.near_key[pos] = f;
@@ -309,9 +356,7 @@ __device__ __forceinline__ void fr_push_children(const Frontier& F, bool active,
     }
     const unsigned long long b2 = __ballot(cls == 2);
     if (b2) {
-        uint32_t base = 0;
-        if (lane == 0) base = sh_add(F.sh, FR_FAR_N, (uint32_t)__builtin_popcountll(b2));
-        base = uni_u(base);
+        const uint32_t base = sh_add_uniform(F.sh, FR_FAR_N, (uint32_t)__builtin_popcountll(b2), lane);
         if (cls == 2) {
             const uint32_t pos = base + lane_rank(b2, lane);
             F.far_key[pos] = f;
@@ -351,9 +396,7 @@ __device__ __forceinline__ void fr_process(const KernelArgs& A, Ctx& X, const Fr
     uint32_t total = 0;
     for (int w = 0; w < nw; ++w) total += (uint32_t)__builtin_popcountll(mrow[w]);
     total = uni_u(total);
-    uint32_t base = 0;
-    if (lane == 0) base = sh_add(F.sh, FR_NNODES, total);
-    base = uni_u(base);
+    const uint32_t base = sh_add_uniform(F.sh, FR_NNODES, total, lane);
     if (base + total > S.max_nodes) {
         if (lane == 0) {
             atomicOr((uint32_t*)&F.sh[FR_FLAGS], FRF_OVERFLOW);
@@ -575,7 +618,9 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
     Frontier F;
     F.sh = sh;
     F.ready = (lds_u32*)(X.lsm + A.lds.heap_key);
-    F.hist = F.ready + FR_READY_CAP;
+    F.hist = F.ready + 2048;
+    lds_u32* gp_path = F.ready + FR_READY_CAP;            // [HP_MAX + 1] path of the best goal candidate (relevance test)
+    lds_f64* gp_mp = (lds_f64*)(F.ready + FR_READY_CAP + 32);  // [HP_MAX + 1] largest key of that path below depth d
     F.near_key = A.arena.near_key + voff;
     F.near_id = A.arena.near_id + voff;
     F.far_key = A.arena.pop_log + voff;
@@ -620,62 +665,51 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
         sh[FR_PENDING] = 1;
         sh_st_d(sh, FR_NEAR_MIN, inf);
         sh_st_d(sh, FR_FAR_MIN, inf);
-        sh_st_d(sh, FR_L_READY, 0.0);
         sh_st_d(sh, FR_L_FAR, inf);
         sh[SH_NNODES] = 1;
     }
     for (int i = tid; i < FR_READY_CAP; i += (int)blockDim.x) F.ready[i] = i == 0 ? 1u : 0u;
     __syncthreads();
 
-    if (lane == 0) FR_LOG("w%d start\n", wave);
     FR_PROGRESS(10)
     int status = PDMPC_OK;
     bool dep_timeout = X.dep_timeout;
     uint32_t goal = 0;
     uint32_t idle_polls = 0;
-    for (;;) {
-        // ================= a round: every wave takes nodes off the ready list until none is pending =================
-        for (;;) {
-            // a ticket: the entry with that index is this wave's, whenever it is written (children of the running round may
-            // still join the list); tickets nobody will ever serve are dropped when nothing is pending any more
-            uint32_t cur = 0;
-            uint32_t t = 0;
-            FR_POS(0, 0)
-            if (lane == 0) t = sh_add(sh, FR_RD_HEAD, 1u);
-            t = uni_u(t);
-            FR_POS(1, t)
-            if (t < (uint32_t)FR_READY_CAP) {
-                // the whole wave polls; every value the loop branches on is made wave-uniform explicitly, so the branches are
-                // scalar and the loop keeps all lanes together for the wave-wide operations that follow
-                for (uint32_t spins = 0;; ++spins) {
-                    cur = uni_u(*(volatile lds_u32*)&F.ready[t]);
-                    if (cur != 0u) break;
-                    if (uni_u(__hip_atomic_load((lds_u32*)(sh + FR_PENDING), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0u) break;
-                    if (spins > A.spin_limit) {  // (cannot happen: every pending entry is written and processed)
-                        if (lane == 0) atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_BUG);
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
-                }
+    // where the time goes (100 MHz ticks, reported in the record's spare rows with PDMPC_DEBUG_TAIL=1)
+    unsigned long long tk_work = 0, tk_arrival = 0, tk_select = 0, tk_wait = 0, tk_mark = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long tk_start = tk_mark;
+#define FR_TICK(acc)                                                       \
+    {                                                                      \
+        const unsigned long long now__ = __builtin_amdgcn_s_memrealtime(); \
+        acc += now__ - tk_mark;                                            \
+        tk_mark = now__;                                                   \
+    }
+    // appends (k, i) of the lanes with `take` to far (whole wave calls)
+    auto to_far = [&](bool take, double k, uint32_t i) {
+        const unsigned long long b = __ballot(take);
+        if (b) {
+            const uint32_t base = sh_add_uniform(sh, FR_FAR_N, (uint32_t)__builtin_popcountll(b), lane);
+            if (take) {
+                const uint32_t pos = base + lane_rank(b, lane);
+                F.far_key[pos] = k;
+                F.far_id[pos] = i;
+                sh_min_d(sh, FR_FAR_MIN, k);
+                sh_max_d(sh, FR_FAR_MAX, k);
             }
-            cur = uni_u(cur);
-            FR_POS(2, cur)
-            if (lane == 0) FR_LOG("w%d ticket %u cur %u pending %u\n", wave, t, cur, sh[FR_PENDING]);
-            if (cur == 0u) break;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            fr_process<CHECKER, NW>(A, X, F, EE, cur);
-            FR_POS(3, cur)
-            if (lane == 0) FR_LOG("w%d processed %u nnodes %u near %u\n", wave, cur, sh[FR_NNODES], sh[FR_NEAR_N]);
-            if (lane == 0) {
-                sh_add(sh, FR_PROCESSED, 1u);
-                __hip_atomic_fetch_sub((lds_u32*)(sh + FR_PENDING), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            FR_POS(4, cur)
         }
-        FR_POS(5, 0)
-        if (lane == 0) FR_LOG("w%d at barrier\n", wave);
+    };
+    for (;;) {
+        // ================= a round: every wave takes nodes off the ready list until the list is empty =================
+        for (;;) {
+            const uint32_t t = sh_add_uniform(sh, FR_RD_HEAD, 1u, lane);
+            if (t >= uni_u(sh[FR_RD_TAIL])) break;
+            const uint32_t cur = uni_u(F.ready[t]);
+            fr_process<CHECKER, NW>(A, X, F, EE, cur);
+            (void)sh_add_uniform(sh, FR_PROCESSED, 1u, lane);
+        }
         __syncthreads();
-        if (tid == 0) FR_LOG("boundary rounds %u processed %u near %u far %u best %u flags %u\n", sh[FR_ROUNDS], sh[FR_PROCESSED], sh[FR_NEAR_N], sh[FR_FAR_N], sh[FR_BEST_ID], sh[FR_FLAGS]);
+        FR_TICK(tk_work)
         FR_PROGRESS(1)
 
         // ================= round boundary (every thread; decisions are uniform) =====================================
@@ -709,6 +743,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
             }
             __syncthreads();
             flags = sh[FR_FLAGS];
+            const bool reopen = (flags & FRF_INVALIDATED) && sh[FR_DROPPED] != 0u;
             __syncthreads();
             if (tid == 0) {
                 atomicAdd(P.counters + 2, 1);
@@ -720,15 +755,33 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                 sh[SH_STATE] = ST_RUN;
                 if (flags & FRF_INVALIDATED) {
                     sh[FR_BEST_ID] = 0;  // the best candidate may have lost an ancestor: look at all of them again
+                    sh[FR_PATH_FOR] = 0;
                     sh[FR_FLAGS] = flags & ~FRF_INVALIDATED;
+                }
+                if (reopen) {
+                    // open entries were dropped because they come after a candidate that may be gone now: rebuild the
+                    // open set from the tree (every generated node that was never evaluated is open)
+                    sh[FR_NEAR_N] = 0;
+                    sh[FR_FAR_N] = 0;
+                    sh[FR_DROPPED] = 0;
+                    sh_st_d(sh, FR_NEAR_MIN, inf);
+                    sh_st_d(sh, FR_NEAR_MAX, 0.0);
+                    sh_st_d(sh, FR_FAR_MIN, inf);
+                    sh_st_d(sh, FR_FAR_MAX, 0.0);
+                    sh_st_d(sh, FR_L_FAR, -1.0);  // (everything goes to far until the next refill)
                 }
             }
             __syncthreads();
             if (flags & FRF_INVALIDATED) {
                 for (uint32_t b = (uint32_t)wave * PDMPC_WAVE; b < nn; b += blockDim.x) {
                     const uint32_t i0 = b + (uint32_t)lane;
-                    bool cand = false;
-                    if (i0 < nn && vs_load(VS, i0) == VS_VALID) cand = NODE_K(((const uint32_t*)(S.gn + i0))[15]) == Hp;
+                    bool cand = false, open = false;
+                    if (i0 < nn) {
+                        const uint32_t vst = vs_load(VS, i0);
+                        if (vst == VS_VALID) cand = NODE_K(((const uint32_t*)(S.gn + i0))[15]) == Hp;
+                        if (reopen && vst == VS_UNKNOWN && i0 > 0u) open = vs_load(VS, node_parent(S, i0) - 1u) == VS_VALID;
+                    }
+                    if (reopen) to_far(open, open ? F.gkey[i0] : 0.0, i0 + 1u);
                     unsigned long long bc = __ballot(cand);
                     while (bc) {
                         const int l = __builtin_ctzll(bc);
@@ -741,16 +794,35 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
             flags = sh[FR_FLAGS];
         }
         if (flags & FRF_TIE) return true;
+        FR_TICK(tk_arrival)
 
-        // are we done?  A collision-free node at the horizon whose path maximum lies below every open key comes before
-        // everything that is still open; an empty open set without one is exhaustion (GraphSearch.m:57-61).
+        // the relevance tables follow the best goal candidate
         const uint32_t best = sh[FR_BEST_ID];
+        if (best && sh[FR_PATH_FOR] != best) {
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t nd = best;
+                double m = -1.0;
+                for (int d = Hp; d >= 0; --d) {
+                    gp_path[d] = nd;
+                    gp_mp[d] = m;  // largest key of the path below depth d
+                    const double k = F.gkey[nd - 1];
+                    m = k > m ? k : m;
+                    nd = node_parent(S, nd - 1);
+                }
+                sh[FR_PATH_FOR] = best;
+            }
+            __syncthreads();
+        }
+
+        // are we done?  Open entries above the candidate's path maximum come after it; the others are looked at one by one
+        // when a round selects them (fr_relevant).  An empty open set without a candidate is exhaustion (GraphSearch.m:57-61).
         const uint32_t near_n = sh[FR_NEAR_N], far_n = sh[FR_FAR_N];
         const double near_min = near_n ? sh_ld_d(sh, FR_NEAR_MIN) : inf, far_min = far_n ? sh_ld_d(sh, FR_FAR_MIN) : inf;
         const double open_min = near_min < far_min ? near_min : far_min;
+        const double bb = best ? sh_ld_d(sh, FR_BEST_B1) : inf;
         bool done = false;
         if (best) {
-            const double bb = sh_ld_d(sh, FR_BEST_B1);
             if (bb == open_min) return true;  // a tie between an open node and a node of the best path
             done = bb < open_min;
         } else {
@@ -765,28 +837,42 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
             // finished, but predecessors that are still planning may yet invalidate what we found
             __builtin_amdgcn_s_sleep(16);
             if (++idle_polls > A.spin_limit) dep_timeout = true;  // a predecessor never finished: give up on it (reported as an error status)
+            if (tid == 0) {
+                sh[FR_RD_HEAD] = 0;
+                sh[FR_RD_TAIL] = 0;
+            }
+            __syncthreads();
+            FR_TICK(tk_wait)
             continue;
         }
 
+        // ---- near is empty (or holds nothing below far's smallest key): refill it from far
         FR_PROGRESS(2)
-        // ---- near is empty: refill it from far with the entries below a key chosen from far's histogram
         uint32_t nn_near = near_n;
-        if (nn_near == 0u) {
-            double lo = far_min, hi = sh_ld_d(sh, FR_FAR_MAX);
+        if (nn_near == 0u || far_min < near_min) {
+            if (nn_near != 0u) {  // (rare: merge near into far first so that the refill sees every open entry)
+                const uint32_t kept = fr_partition(
+                    F.near_key, F.near_id, nn_near, wsum, n_waves, [&](double, uint32_t) -> int { return 1; }, [&](int c, double k, uint32_t i) { to_far(c == 1, k, i); });
+                (void)kept;
+                if (tid == 0) sh[FR_NEAR_N] = 0;
+                __syncthreads();
+            }
+            const uint32_t fn = sh[FR_FAR_N];
+            double lo = sh_ld_d(sh, FR_FAR_MIN), hi = sh_ld_d(sh, FR_FAR_MAX);
             uint32_t bsel = FR_NBINS - 1;
             double scale = 0.0;
             for (int zoom = 0; zoom < 6; ++zoom) {
                 scale = hi > lo ? (double)FR_NBINS / (hi - lo) : 0.0;
                 for (int i = tid; i < FR_NBINS; i += (int)blockDim.x) F.hist[i] = 0;
                 __syncthreads();
-                for (uint32_t e = (uint32_t)tid; e < far_n; e += blockDim.x) atomicAdd((uint32_t*)&F.hist[fr_bin(F.far_key[e], lo, scale)], 1u);
+                fr_histogram(F, F.far_key, fn, lo, scale);
                 __syncthreads();
                 if (wave == 0) fr_select(F, (uint32_t)A.fr_near_fill, FR_SEL_BIN, lane);
                 __syncthreads();
                 bsel = sh[FR_SEL_BIN];
                 const uint32_t cum = sh[FR_SEL_CUM];
                 __syncthreads();
-                if (bsel != 0u || cum <= 4u * (uint32_t)A.fr_near_fill || scale == 0.0) break;
+                if (bsel != 0u || cum <= 2u * (uint32_t)A.fr_near_fill || scale == 0.0) break;
                 hi = lo + (hi - lo) / (double)FR_NBINS;  // nearly everything sits in the first bin: look closer
             }
             const double l_far_new = (bsel >= FR_NBINS - 1 || scale == 0.0) ? inf : lo + (double)(bsel + 1u) / scale;
@@ -800,13 +886,11 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
             __syncthreads();
             const double lo_c = lo, scale_c = scale;
             const uint32_t kept = fr_partition(
-                F.far_key, F.far_id, far_n, wsum, n_waves, [&](double k, uint32_t) -> int { return fr_bin(k, lo_c, scale_c) <= bsel ? 1 : 0; },
+                F.far_key, F.far_id, fn, wsum, n_waves, [&](double k, uint32_t) -> int { return fr_bin(k, lo_c, scale_c) <= bsel ? 1 : 0; },
                 [&](int c, double k, uint32_t i) {
                     const unsigned long long b = __ballot(c == 1);
                     if (b) {
-                        uint32_t base = 0;
-                        if (lane == 0) base = sh_add(sh, FR_NEAR_N, (uint32_t)__builtin_popcountll(b));
-                        base = uni_u(base);
+                        const uint32_t base = sh_add_uniform(sh, FR_NEAR_N, (uint32_t)__builtin_popcountll(b), lane);
                         if (c == 1) {
                             const uint32_t pos = base + lane_rank(b, lane);
                             F.near_key[pos] = k;
@@ -815,7 +899,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                             sh_max_d(sh, FR_NEAR_MAX, k);
                         }
                     }
-                    if (c < 0 && i != 0u) {  // (kept entries: i is their node, never 0)
+                    if (c < 0 && i != 0u) {  // kept entries (i is their node, never 0)
                         sh_min_d(sh, FR_FAR_MIN, k);
                         sh_max_d(sh, FR_FAR_MAX, k);
                     }
@@ -825,14 +909,14 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
             nn_near = sh[FR_NEAR_N];
         }
 
-        FR_PROGRESS(3)
         // ---- this round's entries: the smallest keys of near (histogram -> bin -> partition)
+        FR_PROGRESS(3)
         {
             const double lo = sh_ld_d(sh, FR_NEAR_MIN);
             double hi = sh_ld_d(sh, FR_NEAR_MAX);
-            // A round takes the smallest open keys: few while the search is young (everything a round takes beyond what the
-            // reference pops is wasted, and an easy search is over after Hp + 1 pops), up to fr_round once a few hundred nodes
-            // have been processed: the overshoot stays below a quarter of the work done.
+            // A round takes the smallest open keys: few while the search is young (what a round takes beyond what the
+            // reference pops is wasted, and an easy search is over after Hp + 1 pops), up to fr_round once a few hundred
+            // nodes have been processed.
             const uint32_t done_so_far = sh[FR_PROCESSED];
             const uint32_t round_target = 1u + done_so_far / 4u < (uint32_t)A.fr_round ? 1u + done_so_far / 4u : (uint32_t)A.fr_round;
             uint32_t bsel = FR_NBINS - 1, bspill = FR_NBINS - 1;
@@ -841,7 +925,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                 scale = hi > lo ? (double)FR_NBINS / (hi - lo) : 0.0;
                 for (int i = tid; i < FR_NBINS; i += (int)blockDim.x) F.hist[i] = 0;
                 __syncthreads();
-                for (uint32_t e = (uint32_t)tid; e < nn_near; e += blockDim.x) atomicAdd((uint32_t*)&F.hist[fr_bin(F.near_key[e], lo, scale)], 1u);
+                fr_histogram(F, F.near_key, nn_near, lo, scale);
                 __syncthreads();
                 if (wave == 0) {
                     fr_select(F, round_target, FR_SEL_BIN, lane);
@@ -852,57 +936,48 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                 bspill = sh[FR_SEL2_BIN];
                 const uint32_t cum = sh[FR_SEL_CUM];
                 __syncthreads();
-                if (cum <= (uint32_t)FR_READY_CAP / 2u || scale == 0.0) break;
+                if (cum <= 4u * round_target + 16u || scale == 0.0) break;
                 hi = lo + (hi - lo) / (double)FR_NBINS;  // too many entries share the first bins: look closer
             }
             // near has grown too large to scan every round: everything beyond its smallest entries moves to far
             const bool spill = nn_near > (uint32_t)A.fr_near_max && bspill < FR_NBINS - 1 && scale != 0.0;
-            const double l_ready = (bsel >= FR_NBINS - 1 || scale == 0.0) ? hi : lo + (double)(bsel + 1u) / scale;
             if (tid == 0) {
                 sh[FR_RD_HEAD] = 0;
                 sh[FR_RD_TAIL] = 0;
                 sh_st_d(sh, FR_NEAR_MIN, inf);
                 sh_st_d(sh, FR_NEAR_MAX, 0.0);
-                sh_st_d(sh, FR_L_READY, l_ready);
                 if (spill) sh_st_d(sh, FR_L_FAR, lo + (double)(bspill + 1u) / scale);
                 sh_add(sh, FR_ROUNDS, 1u);
             }
-            for (int i = tid; i < FR_READY_CAP; i += (int)blockDim.x) F.ready[i] = 0u;
             __syncthreads();
             const double lo_c = lo, scale_c = scale;
+            const bool have_goal = best != 0u;
             const uint32_t kept = fr_partition(
                 F.near_key, F.near_id, nn_near, wsum, n_waves,
-                [&](double k, uint32_t) -> int {
+                [&](double k, uint32_t i) -> int {
                     const uint32_t b = fr_bin(k, lo_c, scale_c);
-                    return b <= bsel ? 1 : ((spill && b > bspill) ? 2 : 0);
+                    if (b <= bsel) {
+                        if (!have_goal) return 1;
+                        if (k == bb) atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_TIE);
+                        return (k > bb || !fr_relevant(S, F.gkey, gp_path, gp_mp, i, sh)) ? 3 : 1;  // 3: comes after the candidate
+                    }
+                    return (spill && b > bspill) ? 2 : 0;
                 },
                 [&](int c, double k, uint32_t i) {
                     const unsigned long long b1 = __ballot(c == 1);
                     if (b1) {
-                        uint32_t base = 0;
-                        if (lane == 0) base = sh_add(sh, FR_RD_TAIL, (uint32_t)__builtin_popcountll(b1));
-                        base = uni_u(base);
+                        const uint32_t base = sh_add_uniform(sh, FR_RD_TAIL, (uint32_t)__builtin_popcountll(b1), lane);
                         if (c == 1) {
                             const uint32_t pos = base + lane_rank(b1, lane);
                             if (pos < (uint32_t)FR_READY_CAP)
                                 F.ready[pos] = i;
                             else
-                                c = 2;  // (only if thousands of keys are equal to the last bit: they wait in far)
+                                c = 2;  // (only if a thousand keys are equal to the last bit: they wait in far)
                         }
                     }
-                    const unsigned long long b2 = __ballot(c == 2);
-                    if (b2) {
-                        uint32_t base = 0;
-                        if (lane == 0) base = sh_add(sh, FR_FAR_N, (uint32_t)__builtin_popcountll(b2));
-                        base = uni_u(base);
-                        if (c == 2) {
-                            const uint32_t pos = base + lane_rank(b2, lane);
-                            F.far_key[pos] = k;
-                            F.far_id[pos] = i;
-                            sh_min_d(sh, FR_FAR_MIN, k);
-                            sh_max_d(sh, FR_FAR_MAX, k);
-                        }
-                    }
+                    to_far(c == 2, k, i);
+                    const unsigned long long b3 = __ballot(c == 3);
+                    if (b3) (void)sh_add_uniform(sh, FR_DROPPED, (uint32_t)__builtin_popcountll(b3), lane);  // comes after the candidate: never popped
                     if (c < 0 && i != 0u) {  // kept entries
                         sh_min_d(sh, FR_NEAR_MIN, k);
                         sh_max_d(sh, FR_NEAR_MAX, k);
@@ -912,9 +987,10 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
             if (tid == 0) {
                 sh[FR_NEAR_N] = kept;
                 const uint32_t tl = sh[FR_RD_TAIL];
-                sh[FR_PENDING] = tl < (uint32_t)FR_READY_CAP ? tl : (uint32_t)FR_READY_CAP;
+                if (tl > (uint32_t)FR_READY_CAP) sh[FR_RD_TAIL] = FR_READY_CAP;
             }
             __syncthreads();
+            FR_TICK(tk_select)
         }
     }
 
@@ -952,6 +1028,13 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
         dbg[3] = (double)sh[FR_NEAR_N];
         dbg[4] = (double)sh[FR_FAR_N];
         dbg[5] = (double)sh[FR_FLAGS];
+        dbg[6] = (double)(tk_work) + 1e-9 * (double)tk_select;      // work ticks . select ticks (GHz-style packing avoided: see dbg[7])
+        dbg[7] = (double)(__builtin_amdgcn_s_memrealtime() - tk_start);
+        X.O->path_nodes[PDMPC_HP_MAX - 1][0] = (double)tk_work;
+        X.O->path_nodes[PDMPC_HP_MAX - 1][1] = (double)tk_arrival;
+        X.O->path_nodes[PDMPC_HP_MAX - 1][2] = (double)tk_select;
+        X.O->path_nodes[PDMPC_HP_MAX - 1][3] = (double)tk_wait;
+        X.O->path_nodes[PDMPC_HP_MAX - 1][4] = (double)(tk_mark - tk_start);
     }
     X.status = status;
     X.n_popped = (int)R.n_popped;

@@ -1,0 +1,27 @@
+"""Where a time step's time goes in the frontier kernel: per vehicle rounds, nodes processed vs popped, and the 100 MHz
+tick counters of the round phases (needs PDMPC_DEBUG_TAIL=1)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "p-dmpc_amd"), os.path.join(ROOT, "tests")]
+os.environ["PDMPC_DEBUG_TAIL"] = "1"
+import numpy as np
+import bench
+class A: pass
+args = A(); args.vehicles = 20; args.hp = 8; args.mpa = "single_speed"; args.instances = 1; args.workload = "c2"; args.max_nodes = 1 << 17; args.seed = 1; args.max_levels = 99; args.priorities = "constant"
+if len(sys.argv) > 1 and sys.argv[1] == "c3":
+    args.vehicles = 128; args.workload = "c3"; args.max_levels = 2; args.priorities = "coloring"; args.max_nodes = 1 << 16
+options, mpa, ctl = bench.build_world(args, 0)
+from pdmpc.optimizer import GraphSearchHip
+opt = GraphSearchHip(options); opt._ensure_mpa(mpa); h = opt.handle
+probs = bench.record_steps(options, mpa, ctl, opt, 20 if args.workload == "c2" else 4, 6)
+for b, prob in enumerate(probs):
+    fb = [f if f is not None else [] for f in prob["fallback"]]
+    h.pack_step(prob["iters"], prob["preds"], fb)
+    h.launch(); recs = h.fetch(len(prob["iters"])); st = h.stats()
+    print("step", b, "kernel ms %.3f" % st["kernel_ms"], "levels", len(prob["level_sizes"]))
+    rows = []
+    for v in range(len(recs)):
+        t = np.asarray(recs[v]["path_nodes"])
+        rows.append((t[16][7] / 100.0, v, prob["levels"][v], int(recs[v]["n_popped"]), int(t[16][1]), int(t[16][2]), int(t[16][0]), t[15][0] / 100.0, t[15][1] / 100.0, t[15][2] / 100.0, t[15][3] / 100.0, len(prob["preds"][v])))
+    for r in sorted(rows, reverse=True)[:8]:
+        print("   total %.0f us veh %d level %d popped %d processed %d nodes %d rounds %d | work %.0f arrival %.0f select %.0f wait %.0f us | preds %d" % r)
