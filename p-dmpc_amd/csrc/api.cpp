@@ -577,7 +577,7 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.fr_near_max = h->fr_near_max;
     a.spin_limit = 1u << 22;
     if (const char* e = getenv("PDMPC_SPIN_LIMIT")) a.spin_limit = (uint32_t)std::max(1024, atoi(e));  // debugging: fail fast
-    a.debug_tail = getenv("PDMPC_DEBUG_TAIL") ? 1 : 0;
+    a.debug_tail = getenv("PDMPC_DEBUG_TAIL") ? atoi(getenv("PDMPC_DEBUG_TAIL")) : 0;
     if (getenv("PDMPC_DEBUG_PROGRESS") && !h->progress) {
         if (hipHostMalloc((void**)&h->progress, (size_t)h->max_vehicles * 64 * 4, hipHostMallocMapped) != hipSuccess) h->progress = nullptr;
         if (h->progress) std::memset(h->progress, 0, (size_t)h->max_vehicles * 64 * 4);

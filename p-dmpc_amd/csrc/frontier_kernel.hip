@@ -58,11 +58,14 @@
 #define FR_FAR_MAX 54   // (64 bit) upper bound of far's keys
 #define FR_L_FAR 58     // (64 bit) children with key > this go to far
 #define FR_PATH_FOR 61  // the goal candidate whose path is in the relevance tables (0: none)
+#define FR_EVER_INVAL 63 // set once a late arrival has invalidated a node of this search
+#define FR_DEAD 57      // open entries dropped because an ancestor was invalidated
 #define FR_DROPPED 62   // open entries dropped because they come after the best candidate (restored if that one is invalidated)
 #define FRF_OVERFLOW 1u
 #define FRF_TIE 2u
 #define FRF_INVALIDATED 4u
 #define FRF_BUG 8u
+#define FR_SCRATCH 64   // 64 scratch words behind the shared block (targets of the lanes that only take part pro forma, see sh_add_uniform)
 #define FR_NBINS 2048
 #define FR_READY_CAP 1024
 
@@ -111,13 +114,14 @@ __device__ __forceinline__ void sh_max_d(volatile lds_u32* sh, int w, double v) 
 __device__ __forceinline__ uint32_t sh_add(volatile lds_u32* sh, int w, uint32_t v) {
     return __hip_atomic_fetch_add((lds_u32*)(sh + w), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-// A wave-wide counter update whose old value every lane needs: EVERY lane issues the LDS atomic (lane 0 adds v, the others
-// add 0) and lane 0's result is broadcast.  The obvious `if (lane == 0) old = atomic(...); old = readfirstlane(old)` gives the
-// compiler a divergent branch in front of a wave-uniform value: hipcc 7.2 threads the lanes that skip the branch past it and
-// lets them run the code that follows — wave-wide node processing — apart from lane 0.  No branch, no threading; the
-// atomic optimizer still merges the 64 requests into one.
+// A wave-wide counter update whose old value every lane needs.  The obvious `if (lane == 0) old = atomic(...); old =
+// readfirstlane(old)` puts a divergent branch in front of a wave-uniform value: hipcc 7.2 threads the lanes that skip the
+// branch past it and lets them run the code that follows — wave-wide node processing — apart from lane 0.  So there is no
+// branch: EVERY lane issues the LDS atomic, lane 0 on the counter, the others on a scratch word of their own (distinct
+// addresses: one pass through the LDS), and lane 0's result is broadcast.
 __device__ __forceinline__ uint32_t sh_add_uniform(volatile lds_u32* sh, int w, uint32_t v, int lane) {
-    const uint32_t old = __hip_atomic_fetch_add((lds_u32*)(sh + w), lane == 0 ? v : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    lds_u32* p = lane == 0 ? (lds_u32*)(sh + w) : (lds_u32*)(sh + FR_SCRATCH + lane);
+    const uint32_t old = __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
 }
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long ballot, int lane) { return (uint32_t)__builtin_popcountll(ballot & ((1ull << lane) - 1ull)); }
@@ -141,12 +145,17 @@ struct Frontier {
     int n_waves;
 };
 
-// Smallest bin whose cumulative count reaches `target` (the last non-empty bin if the total is smaller).  One wave calls;
-// bin and cumulative count go to sh[w_bin], sh[w_bin + 1].
-__device__ void fr_select(const Frontier& F, uint32_t target, int w_bin, int lane) {
+// Smallest bin whose cumulative count reaches `target` (the last non-empty bin if the total is smaller), for two targets
+// in one pass over the histogram.  One wave calls; bin and cumulative count go to sh[w1], sh[w1 + 1] and sh[w2], sh[w2 + 1].
+__device__ void fr_select2(const Frontier& F, uint32_t target1, uint32_t target2, int w1, int w2, int lane) {
     const int per = FR_NBINS / PDMPC_WAVE;
+    uint32_t hq[FR_NBINS / PDMPC_WAVE];
     uint32_t loc = 0;
-    for (int q = 0; q < per; ++q) loc += F.hist[lane * per + q];
+#pragma unroll
+    for (int q = 0; q < per; ++q) {
+        hq[q] = F.hist[lane * per + q];
+        loc += hq[q];
+    }
     uint32_t inc = loc;  // inclusive prefix over the lanes
 #pragma unroll
     for (int o = 1; o < PDMPC_WAVE; o <<= 1) {
@@ -154,25 +163,32 @@ __device__ void fr_select(const Frontier& F, uint32_t target, int w_bin, int lan
         if (lane >= o) inc += v;
     }
     const uint32_t total = lane_u(inc, PDMPC_WAVE - 1);
-    const uint32_t want = target < total ? target : total;
-    // every lane looks for the crossing in its own bins (no lane-dependent branch around values that are broadcast later)
-    uint32_t c = inc - loc, bin = 0, cum = 0;
-    bool found = false;
+    const uint32_t want1 = target1 < total ? target1 : total, want2 = target2 < total ? target2 : total;
+    // every lane looks for the crossings in its own bins (no lane-dependent branch around values that are broadcast later)
+    uint32_t c = inc - loc, bin1 = 0, cum1 = 0, bin2 = 0, cum2 = 0;
+    bool f1 = false, f2 = false;
+#pragma unroll
     for (int q = 0; q < per; ++q) {
-        const uint32_t hq = F.hist[lane * per + q];
-        c += hq;
-        const bool here = !found && hq != 0u && c >= want;
-        bin = here ? (uint32_t)(lane * per + q) : bin;
-        cum = here ? c : cum;
-        found = found || here;
+        c += hq[q];
+        const bool h1 = !f1 && hq[q] != 0u && c >= want1, h2 = !f2 && hq[q] != 0u && c >= want2;
+        bin1 = h1 ? (uint32_t)(lane * per + q) : bin1;
+        cum1 = h1 ? c : cum1;
+        bin2 = h2 ? (uint32_t)(lane * per + q) : bin2;
+        cum2 = h2 ? c : cum2;
+        f1 = f1 || h1;
+        f2 = f2 || h2;
     }
-    const unsigned long long reach = __ballot(found);
-    const int l = reach ? __builtin_ctzll(reach) : 0;
-    bin = lane_u(bin, l);
-    cum = lane_u(cum, l);
+    const unsigned long long r1 = __ballot(f1), r2 = __ballot(f2);
+    const int l1 = r1 ? __builtin_ctzll(r1) : 0, l2 = r2 ? __builtin_ctzll(r2) : 0;
+    bin1 = lane_u(bin1, l1);
+    cum1 = lane_u(cum1, l1);
+    bin2 = lane_u(bin2, l2);
+    cum2 = lane_u(cum2, l2);
     if (lane == 0) {
-        F.sh[w_bin] = reach ? bin : 0u;
-        F.sh[w_bin + 1] = reach ? cum : 0u;
+        F.sh[w1] = r1 ? bin1 : 0u;
+        F.sh[w1 + 1] = r1 ? cum1 : 0u;
+        F.sh[w2] = r2 ? bin2 : 0u;
+        F.sh[w2 + 1] = r2 ? cum2 : 0u;
     }
 }
 
@@ -201,7 +217,7 @@ __device__ uint32_t fr_partition(double* key, uint32_t* id, uint32_t n, volatile
         unsigned long long keep[FR_PER];
 #pragma unroll
         for (int j = 0; j < FR_PER; ++j) {
-            c[j] = i[j] ? cls(k[j], i[j]) : -1;
+            c[j] = cls(k[j], i[j]);  // (called by every lane; returns -1 for i == 0)
             keep[j] = __ballot(c[j] == 0);
             mine += (uint32_t)__builtin_popcountll(keep[j]);
         }
@@ -245,28 +261,39 @@ __device__ void fr_histogram(const Frontier& F, const double* key, uint32_t n, d
     }
 }
 
-// Relevance of an open node once a goal candidate G is known: does the reference pop a (1-based) before G?  gp_path[d] = node
-// of G's path at depth d, gp_mp[d] = largest key of that path below depth d.  a leaves the path at some depth d; it comes
-// first iff the largest key on its own branch is smaller than gp_mp[d].  One thread; sets FRF_TIE on equality.
-__device__ bool fr_relevant(const Search& S, const double* gkey, const lds_u32* gp_path, const lds_f64* gp_mp, uint32_t a, volatile lds_u32* sh) {
-    uint32_t x = a;
+// What to do with the open nodes a round has selected, one node per lane (a: 1-based, 0 = this lane has none): 1 process it,
+// 3 drop it because the reference pops the goal candidate G first (gp_path[d] = node of G's path at depth d, gp_mp[d] =
+// largest key of that path below depth d; a leaves the path at some depth d and comes first iff the largest key on its own
+// branch is smaller than gp_mp[d]), 4 drop it because one of its ancestors collides with areas that arrived after it was
+// created (the reference never creates a).  Sets FRF_TIE on an equality that decides.
+// The whole wave walks together (a wave-uniform loop over per-lane states): a per-lane loop in a divergent branch followed
+// by a ballot is exactly the shape hipcc 7.2 mis-threads (see sh_add_uniform).
+__device__ int fr_check_wave(const Search& S, const VState& VS, const double* gkey, const lds_u32* gp_path, const lds_f64* gp_mp, bool have_goal, bool check_alive,
+                             uint32_t a, volatile lds_u32* sh) {
+    int res = a ? 0 : 1;  // 0: still walking
+    uint32_t x = a ? a : 1u;
     double mx = -1.0;
-    for (;;) {
+    while (__ballot(res == 0)) {
         const uint32_t i = x - 1u;
         const d2 q = i < S.NL ? (d2)S.ln[4 * (size_t)i + 3] : ((const d2*)(S.gn + i))[3];
         const uint64_t u = (uint64_t)__double_as_longlong(q.y);
         const int d = NODE_K((uint32_t)(u >> 32));
-        if (gp_path[d] == x) {
-            if (x == a) return true;  // on the path itself
-            const double m = gp_mp[d];
-            if (mx == m) atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_TIE);
-            return mx < m;
-        }
+        const bool on_path = have_goal && gp_path[d] == x;  // (the candidate's own ancestors are collision-free: it was validated after the last arrival)
+        const double m = gp_mp[d];
+        const bool dead = !on_path && x != a && check_alive && vs_load(VS, i) != VS_VALID;
         const double k = gkey[i];
-        mx = k > mx ? k : mx;
-        x = (uint32_t)(u & 0xffffffffull);
-        if (!x) return true;  // (cannot happen: the root is on every path)
+        const uint32_t par = (uint32_t)(u & 0xffffffffull);
+        int now = 0;
+        now = on_path ? ((x == a || mx < m) ? 1 : 3) : now;
+        now = dead ? 4 : now;
+        now = (!on_path && !dead && par == 0u) ? 1 : now;  // reached the root: no candidate, every ancestor collision-free
+        if (res == 0 && on_path && x != a && mx == m) atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_TIE);
+        const bool walking = res == 0;
+        res = walking ? now : res;
+        mx = (walking && k > mx) ? k : mx;
+        x = (walking && now == 0) ? par : x;
     }
+    return res;
 }
 
 // X (1-based, at the horizon, edge known to be collision-free): largest key on its path, and whether every ancestor is
@@ -341,8 +368,7 @@ __device__ void fr_offer_goal(const Frontier& F, const Search& S, const VState& 
 // the reference leaves as soon as it reaches the horizon.)  Whole wave calls.
 __device__ __forceinline__ void fr_push_children(const Frontier& F, bool active, uint32_t i0, double f, int lane) {
     const double l_far = sh_ld_d(F.sh, FR_L_FAR);
-    int cls = -1;
-    if (active) cls = f > l_far ? 2 : 1;
+    const int cls = active ? (f > l_far ? 2 : 1) : -1;
     const unsigned long long b1 = __ballot(cls == 1);
     if (b1) {
         const uint32_t base = sh_add_uniform(F.sh, FR_NEAR_N, (uint32_t)__builtin_popcountll(b1), lane);
@@ -667,6 +693,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
         sh_st_d(sh, FR_FAR_MIN, inf);
         sh_st_d(sh, FR_L_FAR, inf);
         sh[SH_NNODES] = 1;
+        if (A.debug_tail == 2) sh[FR_EVER_INVAL] = 1;  // (debugging: exercise the ancestor check without arrivals)
     }
     for (int i = tid; i < FR_READY_CAP; i += (int)blockDim.x) F.ready[i] = i == 0 ? 1u : 0u;
     __syncthreads();
@@ -754,6 +781,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                 sh[SH_ARR_HI] = 0;
                 sh[SH_STATE] = ST_RUN;
                 if (flags & FRF_INVALIDATED) {
+                    sh[FR_EVER_INVAL] = 1;
                     sh[FR_BEST_ID] = 0;  // the best candidate may have lost an ancestor: look at all of them again
                     sh[FR_PATH_FOR] = 0;
                     sh[FR_FLAGS] = flags & ~FRF_INVALIDATED;
@@ -775,13 +803,13 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
             if (flags & FRF_INVALIDATED) {
                 for (uint32_t b = (uint32_t)wave * PDMPC_WAVE; b < nn; b += blockDim.x) {
                     const uint32_t i0 = b + (uint32_t)lane;
-                    bool cand = false, open = false;
-                    if (i0 < nn) {
-                        const uint32_t vst = vs_load(VS, i0);
-                        if (vst == VS_VALID) cand = NODE_K(((const uint32_t*)(S.gn + i0))[15]) == Hp;
-                        if (reopen && vst == VS_UNKNOWN && i0 > 0u) open = vs_load(VS, node_parent(S, i0) - 1u) == VS_VALID;
-                    }
-                    if (reopen) to_far(open, open ? F.gkey[i0] : 0.0, i0 + 1u);
+                    const bool in = i0 < nn;
+                    const uint32_t j0 = in ? i0 : 0u;  // (straight-line code: every lane loads something valid)
+                    const uint32_t vst = vs_load(VS, j0);
+                    const uint32_t par = node_parent(S, j0);
+                    const bool cand = in && vst == VS_VALID && NODE_K(((const uint32_t*)(S.gn + j0))[15]) == Hp;
+                    const bool open = reopen && in && vst == VS_UNKNOWN && par != 0u && vs_load(VS, par ? par - 1u : 0u) == VS_VALID;
+                    if (reopen) to_far(open, F.gkey[j0], j0 + 1u);
                     unsigned long long bc = __ballot(cand);
                     while (bc) {
                         const int l = __builtin_ctzll(bc);
@@ -852,7 +880,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
         if (nn_near == 0u || far_min < near_min) {
             if (nn_near != 0u) {  // (rare: merge near into far first so that the refill sees every open entry)
                 const uint32_t kept = fr_partition(
-                    F.near_key, F.near_id, nn_near, wsum, n_waves, [&](double, uint32_t) -> int { return 1; }, [&](int c, double k, uint32_t i) { to_far(c == 1, k, i); });
+                    F.near_key, F.near_id, nn_near, wsum, n_waves, [&](double, uint32_t i) -> int { return i ? 1 : -1; }, [&](int c, double k, uint32_t i) { to_far(c == 1, k, i); });
                 (void)kept;
                 if (tid == 0) sh[FR_NEAR_N] = 0;
                 __syncthreads();
@@ -867,7 +895,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                 __syncthreads();
                 fr_histogram(F, F.far_key, fn, lo, scale);
                 __syncthreads();
-                if (wave == 0) fr_select(F, (uint32_t)A.fr_near_fill, FR_SEL_BIN, lane);
+                if (wave == 0) fr_select2(F, (uint32_t)A.fr_near_fill, (uint32_t)A.fr_near_fill, FR_SEL_BIN, FR_SEL2_BIN, lane);
                 __syncthreads();
                 bsel = sh[FR_SEL_BIN];
                 const uint32_t cum = sh[FR_SEL_CUM];
@@ -886,7 +914,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
             __syncthreads();
             const double lo_c = lo, scale_c = scale;
             const uint32_t kept = fr_partition(
-                F.far_key, F.far_id, fn, wsum, n_waves, [&](double k, uint32_t) -> int { return fr_bin(k, lo_c, scale_c) <= bsel ? 1 : 0; },
+                F.far_key, F.far_id, fn, wsum, n_waves, [&](double k, uint32_t i) -> int { return i == 0u ? -1 : (fr_bin(k, lo_c, scale_c) <= bsel ? 1 : 0); },
                 [&](int c, double k, uint32_t i) {
                     const unsigned long long b = __ballot(c == 1);
                     if (b) {
@@ -927,10 +955,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                 __syncthreads();
                 fr_histogram(F, F.near_key, nn_near, lo, scale);
                 __syncthreads();
-                if (wave == 0) {
-                    fr_select(F, round_target, FR_SEL_BIN, lane);
-                    fr_select(F, (uint32_t)A.fr_near_fill, FR_SEL2_BIN, lane);
-                }
+                if (wave == 0) fr_select2(F, round_target, (uint32_t)A.fr_near_fill, FR_SEL_BIN, FR_SEL2_BIN, lane);
                 __syncthreads();
                 bsel = sh[FR_SEL_BIN];
                 bspill = sh[FR_SEL2_BIN];
@@ -952,30 +977,36 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
             __syncthreads();
             const double lo_c = lo, scale_c = scale;
             const bool have_goal = best != 0u;
+#ifdef FR_NO_ALIVE
+            const bool check_alive = false;
+#else
+            const bool check_alive = sh[FR_EVER_INVAL] != 0u;  // some node lost its edge to late areas: its descendants are dead
+#endif
             const uint32_t kept = fr_partition(
                 F.near_key, F.near_id, nn_near, wsum, n_waves,
-                [&](double k, uint32_t i) -> int {
+                [&](double k, uint32_t i) -> int {  // (every lane of the wave calls; straight-line code around the wave-wide walk)
                     const uint32_t b = fr_bin(k, lo_c, scale_c);
-                    if (b <= bsel) {
-                        if (!have_goal) return 1;
-                        if (k == bb) atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_TIE);
-                        return (k > bb || !fr_relevant(S, F.gkey, gp_path, gp_mp, i, sh)) ? 3 : 1;  // 3: comes after the candidate
-                    }
-                    return (spill && b > bspill) ? 2 : 0;
+                    const bool sel = i != 0u && b <= bsel;
+                    const bool above = have_goal && k > bb;  // above the candidate's path maximum: comes after it
+                    const bool walk = sel && !above && (have_goal || check_alive);
+                    if (sel && have_goal && k == bb) atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_TIE);
+                    const int r = fr_check_wave(S, VS, F.gkey, gp_path, gp_mp, have_goal, check_alive, walk ? i : 0u, sh);
+                    const int rest = (spill && b > bspill) ? 2 : 0;
+                    return i == 0u ? -1 : (sel ? (above ? 3 : r) : rest);
                 },
                 [&](int c, double k, uint32_t i) {
                     const unsigned long long b1 = __ballot(c == 1);
+                    bool spill_over = false;
                     if (b1) {
                         const uint32_t base = sh_add_uniform(sh, FR_RD_TAIL, (uint32_t)__builtin_popcountll(b1), lane);
-                        if (c == 1) {
-                            const uint32_t pos = base + lane_rank(b1, lane);
-                            if (pos < (uint32_t)FR_READY_CAP)
-                                F.ready[pos] = i;
-                            else
-                                c = 2;  // (only if a thousand keys are equal to the last bit: they wait in far)
-                        }
+                        const uint32_t pos = base + lane_rank(b1, lane);
+                        const bool fits = c == 1 && pos < (uint32_t)FR_READY_CAP;
+                        if (fits) F.ready[pos] = i;
+                        spill_over = c == 1 && !fits;  // (only if a thousand keys are equal to the last bit: they wait in far)
                     }
-                    to_far(c == 2, k, i);
+                    to_far(c == 2 || spill_over, k, i);
+                    const unsigned long long b4 = __ballot(c == 4);
+                    if (b4) (void)sh_add_uniform(sh, FR_DEAD, (uint32_t)__builtin_popcountll(b4), lane);
                     const unsigned long long b3 = __ballot(c == 3);
                     if (b3) (void)sh_add_uniform(sh, FR_DROPPED, (uint32_t)__builtin_popcountll(b3), lane);  // comes after the candidate: never popped
                     if (c < 0 && i != 0u) {  // kept entries

@@ -32,7 +32,7 @@
 #define PDMPC_QUEUE_HEAP 0     /* open list = libstdc++-faithful binary heap (exact for any keys) */
 #define PDMPC_QUEUE_BLOCKMIN 1 /* open list = block-min queue while the minimal key is unique, binary heap after the first tie */
 #define PDMPC_MAX_THREADS (PDMPC_WAVE * PDMPC_MAX_WAVES)
-#define PDMPC_SH_WORDS 64 /* 32-bit LDS words shared by the waves of a workgroup (state, mail boxes, counters of the frontier search) */
+#define PDMPC_SH_WORDS 128 /* 32-bit LDS words shared by the waves of a workgroup (state, mail boxes, counters of the frontier search) */
 
 struct DevManPose {
     double dx, dy, dyaw;
