@@ -942,11 +942,12 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
         {
             const double lo = sh_ld_d(sh, FR_NEAR_MIN);
             double hi = sh_ld_d(sh, FR_NEAR_MAX);
-            // A round takes the smallest open keys: few while the search is young (what a round takes beyond what the
-            // reference pops is wasted, and an easy search is over after Hp + 1 pops), up to fr_round once a few hundred
-            // nodes have been processed.
+            // A round takes the smallest open keys: one per wavefront while the search is young (an easy search is over after
+            // Hp + 1 pops; what a round takes beyond what the reference pops is wasted, but a wavefront that would otherwise idle
+            // costs nothing), growing with the work done up to fr_round: the overshoot stays a fraction of the search.
             const uint32_t done_so_far = sh[FR_PROCESSED];
-            const uint32_t round_target = 1u + done_so_far / 4u < (uint32_t)A.fr_round ? 1u + done_so_far / 4u : (uint32_t)A.fr_round;
+            const uint32_t ramp = (uint32_t)n_waves + done_so_far / 2u;
+            const uint32_t round_target = ramp < (uint32_t)A.fr_round ? ramp : (uint32_t)A.fr_round;
             uint32_t bsel = FR_NBINS - 1, bspill = FR_NBINS - 1;
             double scale = 0.0;
             for (int zoom = 0; zoom < 8; ++zoom) {
