@@ -573,6 +573,8 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.cand_cap = frontier ? h->fr_cand_cap : B.cand_cap;
     a.frontier = frontier ? 1 : 0;
     a.fr_round = h->fr_round > 0 ? h->fr_round : 256;  // measured on C2 / C5: 64 -> 214 / 196 steps/s, 128 -> 263 / 255, 256 -> 291 / 270
+    a.fr_ramp = 4;  // measured on C2 / C3 / C5: 2 -> 301 / 261 / 295 steps/s, 4 -> 304 / 261 / 295, 8 -> 295 / 251 / 275, 16 -> 268 / 232 / 237
+    if (const char* e = getenv("PDMPC_FR_RAMP")) a.fr_ramp = std::max(1, atoi(e));  // tuning knob
     a.fr_near_fill = h->fr_near_fill;
     a.fr_near_max = h->fr_near_max;
     a.spin_limit = 1u << 22;
@@ -613,8 +615,20 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     auto& ev = h->events[h->events_used++];
     HIPCHK(hipEventRecord(ev.first, h->stream));
     h->last_launch_frontier = frontier;
-    int lrc = h->sampled_launch ? pdmpc_launch_sampled(&a, count, (void*)h->stream)
+    int lrc = 0;
+    if (frontier && !h->two_per_cu && count > h->n_cu) {
+        // More workgroups than the chip holds at one per CU (the obstacle soup was too large for the two-per-CU layout): a
+        // workgroup that waits for a predecessor must never keep that predecessor off the chip, so the batch goes in slices
+        // that are resident as a whole.  Slots are in level order: a slice's predecessors are in it or in an earlier slice.
+        for (int done = 0; done < count && lrc == 0; done += h->n_cu) {
+            KernelArgs part = a;
+            part.first = first + done;
+            lrc = pdmpc_launch_frontier(&part, std::min(h->n_cu, count - done), (void*)h->stream);
+        }
+    } else {
+        lrc = h->sampled_launch ? pdmpc_launch_sampled(&a, count, (void*)h->stream)
                                 : (frontier ? pdmpc_launch_frontier(&a, count, (void*)h->stream) : pdmpc_launch_search(&a, count, (void*)h->stream));
+    }
     if (lrc != 0) {
         char buf[256];
         snprintf(buf, sizeof buf, "kernel launch failed: %s (LDS %u B)", hipGetErrorString((hipError_t)lrc), h->lds.total);

@@ -946,7 +946,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
             // Hp + 1 pops; what a round takes beyond what the reference pops is wasted, but a wavefront that would otherwise idle
             // costs nothing), growing with the work done up to fr_round: the overshoot stays a fraction of the search.
             const uint32_t done_so_far = sh[FR_PROCESSED];
-            const uint32_t ramp = (uint32_t)n_waves + done_so_far / 2u;
+            const uint32_t ramp = (uint32_t)n_waves + done_so_far / (uint32_t)A.fr_ramp;
             const uint32_t round_target = ramp < (uint32_t)A.fr_round ? ramp : (uint32_t)A.fr_round;
             uint32_t bsel = FR_NBINS - 1, bspill = FR_NBINS - 1;
             double scale = 0.0;

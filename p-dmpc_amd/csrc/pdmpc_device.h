@@ -141,6 +141,7 @@ struct KernelArgs {
     int32_t debug_tail;    // 1: the frontier kernel leaves its round / node counters in the unused last row of pdmpc_vehicle_out.path_nodes
     int32_t frontier;      // 1: this launch runs the frontier kernel (frontier_kernel.hip), 0: the pop-ordered kernel (search_kernel.hip)
     int32_t fr_round;      // frontier kernel: open entries a round aims to take (about four per wavefront)
+    int32_t fr_ramp;       // ... a young search takes one entry per wavefront plus 1 / fr_ramp of the nodes processed so far
     int32_t fr_near_fill;  // ... entries a refill moves from far to near
     int32_t fr_near_max;   // ... size of near beyond which its tail is moved back to far
     int32_t speculate;  // 1: start searching before all predecessors have finished (results are identical, see arrival_sync)
