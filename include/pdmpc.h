@@ -243,6 +243,14 @@ int pdmpc_debug_tree(pdmpc_handle* handle, int32_t vehicle, int32_t capacity, do
                      double* yaw, double* g, double* h, int32_t* trim, int32_t* k, int32_t* parent,
                      int32_t* n);
 
+/* The collision primitives on given polygons, n_cases at once (one wavefront each, the device functions the search kernels
+ * inline): mode 0 = InterX(a, b) (graph_search/InterX.m:48-103, isReturnPoints = false; b may hold NaN separators),
+ * mode 1 = intersect_sat(a, b) (graph_search/intersect_sat.m:1-42), mode 2 = intersect_lanelet_boundary(a, [left, NaN, right, NaN])
+ * (optimizer/common/intersect_lanelet_boundary.m:1-56).  Case c: a = columns a_off[c] .. a_off[c+1]-1 of (a_x, a_y), at most
+ * PDMPC_VMAX; b likewise, at most 1024 columns.  hit[c] = 1 if the reference function returns true. */
+int pdmpc_debug_edge_check(pdmpc_handle* handle, int32_t mode, int32_t n_cases, const int32_t* a_off, const double* a_x, const double* a_y,
+                           const int32_t* b_off, const double* b_x, const double* b_y, int32_t* hit);
+
 /* the arena of vehicle v as the kernel left it (the frontier kernel's own creation order, incl. nodes the reference never
  * creates), with every node's open-list key and validity byte (0 never evaluated, 1 collision-free, 2 colliding) */
 int pdmpc_debug_raw_tree(pdmpc_handle* handle, int32_t vehicle, int32_t capacity, double* x, double* y, double* yaw, double* g,

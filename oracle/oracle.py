@@ -1,8 +1,9 @@
 """ctypes binding of the CPU oracle (oracle/pdmpc_oracle.cpp).  TEST INFRASTRUCTURE ONLY.
 
-Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.  It reuses the
-struct definitions of the product's ABI mirror (pdmpc.abi) so both sides receive byte-identical inputs;
-the product never imports this module.
+Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; the product never imports this
+module.  Inputs are marshalled by the oracle's own binding of include/pdmpc.h (oracle/packing.py), written independently
+of the product's pdmpc.abi: the two sides share the C header and nothing else, so a marshalling mistake on either side shows
+up as a parity failure instead of cancelling out.
 """
 import ctypes as C
 import os
@@ -16,7 +17,7 @@ _ROOT = os.path.dirname(_HERE)
 if os.path.join(_ROOT, "p-dmpc_amd") not in sys.path:
     sys.path.insert(0, os.path.join(_ROOT, "p-dmpc_amd"))
 
-from pdmpc import abi  # noqa: E402
+from . import packing  # noqa: E402
 from pdmpc.iteration_data import info_from_record  # noqa: E402
 
 _LIB = None
@@ -30,17 +31,17 @@ class TraceOut(C.Structure):
     _fields_ = [
         ("pop_capacity", C.c_int32),
         ("n_pops", C.c_int32),
-        ("pops", abi.c_int32_p),
+        ("pops", packing._iptr),
         ("tree_capacity", C.c_int32),
         ("n_nodes", C.c_int32),
-        ("x", abi.c_double_p),
-        ("y", abi.c_double_p),
-        ("yaw", abi.c_double_p),
-        ("g", abi.c_double_p),
-        ("h", abi.c_double_p),
-        ("trim", abi.c_int32_p),
-        ("k", abi.c_int32_p),
-        ("parent", abi.c_int32_p),
+        ("x", packing._dptr),
+        ("y", packing._dptr),
+        ("yaw", packing._dptr),
+        ("g", packing._dptr),
+        ("h", packing._dptr),
+        ("trim", packing._iptr),
+        ("k", packing._iptr),
+        ("parent", packing._iptr),
     ]
 
 
@@ -65,7 +66,7 @@ def lib(variant=None):
 
 
 def _declare(L):
-    dp, ip = abi.c_double_p, abi.c_int32_p
+    dp, ip = packing._dptr, packing._iptr
     L.oracle_intersect_sat.argtypes = [dp, dp, C.c_int, dp, dp, C.c_int]
     L.oracle_intersect_lanelet_boundary.argtypes = [dp, dp, C.c_int, dp, dp, C.c_int, dp, dp, C.c_int]
     L.oracle_intersect_lanelets.argtypes = [dp, dp, C.c_int, dp, C.c_int]
@@ -73,28 +74,10 @@ def _declare(L):
     L.oracle_pq_script.argtypes = [ip, ip, dp, C.c_int, ip]
     L.oracle_sincos.argtypes = [dp, C.c_int, dp, dp]
     L.oracle_sincos.restype = None
-    L.oracle_plan_batch.argtypes = [
-        C.POINTER(abi.Config),
-        C.POINTER(abi.Mpa),
-        C.c_int,
-        C.POINTER(abi.VehicleIn),
-        C.POINTER(abi.VehicleOut),
-        C.POINTER(TraceOut),
-        C.c_int,
-        C.POINTER(C.c_double),
-    ]
+    L.oracle_plan_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(TraceOut), C.c_int, C.POINTER(C.c_double)]
     L.oracle_mt19937_doubles.argtypes = [C.c_uint32, C.c_int, dp]
     L.oracle_mt19937_doubles.restype = None
-    L.oracle_plan_batch_sampled.argtypes = [
-        C.POINTER(abi.Config),
-        C.POINTER(abi.Mpa),
-        C.c_int,
-        C.POINTER(abi.VehicleIn),
-        C.POINTER(C.c_uint32),
-        C.POINTER(abi.VehicleOut),
-        C.c_int,
-        C.POINTER(C.c_double),
-    ]
+    L.oracle_plan_batch_sampled.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p, C.c_int, C.POINTER(C.c_double)]
     return L
 
 
@@ -102,7 +85,7 @@ def _xy(p):
     p = np.ascontiguousarray(p, dtype=np.float64)
     x = np.ascontiguousarray(p[0])
     y = np.ascontiguousarray(p[1])
-    return x, y, x.ctypes.data_as(abi.c_double_p), y.ctypes.data_as(abi.c_double_p), p.shape[1]
+    return x, y, x.ctypes.data_as(packing._dptr), y.ctypes.data_as(packing._dptr), p.shape[1]
 
 
 def intersect_sat(s1, s2):
@@ -122,7 +105,7 @@ def intersect_lanelets(shape, lanelet_rows):
     xs, ys, pxs, pys, n = _xy(shape)
     rows = np.ascontiguousarray(lanelet_rows, dtype=np.float64)
     assert rows.shape[1] == 6
-    return bool(lib().oracle_intersect_lanelets(pxs, pys, n, rows.ctypes.data_as(abi.c_double_p), rows.shape[0]))
+    return bool(lib().oracle_intersect_lanelets(pxs, pys, n, rows.ctypes.data_as(packing._dptr), rows.shape[0]))
 
 
 def interx(L1, L2):
@@ -137,11 +120,11 @@ def pq_script(ops, ids, keys):
     keys = np.ascontiguousarray(keys, dtype=np.float64)
     out = np.zeros(max(int((ops == 1).sum()), 1), dtype=np.int32)
     n = lib().oracle_pq_script(
-        ops.ctypes.data_as(abi.c_int32_p),
-        ids.ctypes.data_as(abi.c_int32_p),
-        keys.ctypes.data_as(abi.c_double_p),
+        ops.ctypes.data_as(packing._iptr),
+        ids.ctypes.data_as(packing._iptr),
+        keys.ctypes.data_as(packing._dptr),
         len(ops),
-        out.ctypes.data_as(abi.c_int32_p),
+        out.ctypes.data_as(packing._iptr),
     )
     return out[:n]
 
@@ -150,7 +133,7 @@ def sincos(x):
     x = np.ascontiguousarray(x, dtype=np.float64)
     s = np.zeros_like(x)
     c = np.zeros_like(x)
-    lib().oracle_sincos(x.ctypes.data_as(abi.c_double_p), x.size, s.ctypes.data_as(abi.c_double_p), c.ctypes.data_as(abi.c_double_p))
+    lib().oracle_sincos(x.ctypes.data_as(packing._dptr), x.size, s.ctypes.data_as(packing._dptr), c.ctypes.data_as(packing._dptr))
     return s, c
 
 
@@ -161,9 +144,9 @@ class Trace:
 
 
 def make_abi_config(options, checker=None):
-    return abi.Config(
+    return packing.OConfig(
         Hp=options.Hp,
-        checker=(abi.CHECK_INTERX if options.are_any_obstacles_non_convex else abi.CHECK_SAT) if checker is None else checker,
+        checker=(1 if options.are_any_obstacles_non_convex else 0) if checker is None else checker,  # PDMPC_CHECK_INTERX / PDMPC_CHECK_SAT
         dt_seconds=options.dt_seconds,
         device=options.device,
         max_nodes=options.max_nodes,
@@ -175,7 +158,7 @@ def make_abi_config(options, checker=None):
 def plan_batch_raw(options, mpa_struct, veh_arr, n, n_threads=1, trace=False, trace_capacity=1 << 16, variant=None):
     """Low-level: returns (records, traces or None, elapsed_ms)."""
     cfg = make_abi_config(options)
-    out = abi.out_array(n)
+    out = packing.out_array(n)
     tr_arr = None
     bufs = []
     if trace:
@@ -196,13 +179,13 @@ def plan_batch_raw(options, mpa_struct, veh_arr, n, n_threads=1, trace=False, tr
             t = tr_arr[i]
             t.pop_capacity = trace_capacity
             t.tree_capacity = trace_capacity
-            t.pops = b["pops"].ctypes.data_as(abi.c_int32_p)
+            t.pops = b["pops"].ctypes.data_as(packing._iptr)
             for name in ("x", "y", "yaw", "g", "h"):
-                setattr(t, name, b[name].ctypes.data_as(abi.c_double_p))
+                setattr(t, name, b[name].ctypes.data_as(packing._dptr))
             for name in ("trim", "k", "parent"):
-                setattr(t, name, b[name].ctypes.data_as(abi.c_int32_p))
+                setattr(t, name, b[name].ctypes.data_as(packing._iptr))
     elapsed = C.c_double(0.0)
-    rc = lib(variant).oracle_plan_batch(C.byref(cfg), C.byref(mpa_struct), n, veh_arr, abi.out_ptr(out), tr_arr, n_threads, C.byref(elapsed))
+    rc = lib(variant).oracle_plan_batch(C.byref(cfg), C.byref(mpa_struct), n, veh_arr, out.ctypes.data_as(C.c_void_p), tr_arr, n_threads, C.byref(elapsed))
     if rc != 0:
         raise RuntimeError("oracle_plan_batch failed: %d" % rc)
     traces = None
@@ -219,8 +202,8 @@ def plan_batch_raw(options, mpa_struct, veh_arr, n, n_threads=1, trace=False, tr
 
 def plan_batch(options, mpa, iters, n_threads=1, trace=False):
     """Plan a list of VehicleIter with the oracle -> (list[ControlResultsInfo], records, traces)."""
-    mpa_struct, keep_m = abi.pack_mpa(mpa)
-    arr, keep_v = abi.pack_vehicles(iters, options.Hp)
+    mpa_struct, keep_m = packing.pack_mpa(mpa)
+    arr, keep_v = packing.pack_vehicles(iters, options.Hp)
     recs, traces, _ = plan_batch_raw(options, mpa_struct, arr, len(iters), n_threads=n_threads, trace=trace)
     # (a record cut short by the oracle's capacity guard, status 2, is not a planning result: no info for it)
     infos = [info_from_record(recs[i], options.Hp) if int(recs[i]["status"]) in (0, 1) else None for i in range(len(iters))]
@@ -238,9 +221,9 @@ def plan_step(options, mpa, problem, n_threads=1, mpa_struct=None):
     Hp = options.Hp
     keep_m = None
     if mpa_struct is None:
-        mpa_struct, keep_m = abi.pack_mpa(mpa)
+        mpa_struct, keep_m = packing.pack_mpa(mpa)
     n = len(problem["iters"])
-    recs = abi.out_array(n)
+    recs = packing.out_array(n)
     total_ms = 0.0
     first = 0
     for size in problem["level_sizes"]:
@@ -258,7 +241,7 @@ def plan_step(options, mpa, problem, n_threads=1, mpa_struct=None):
                         dyn.append([np.asarray(a, dtype=np.float64) for a in fb])
             it.dynamic_obstacle_area = dyn
             iters.append(it)
-        arr, keep_v = abi.pack_vehicles(iters, Hp)
+        arr, keep_v = packing.pack_vehicles(iters, Hp)
         out, _, ms = plan_batch_raw(options, mpa_struct, arr, size, n_threads=min(n_threads, size))
         total_ms += ms
         for q, s in enumerate(slots):
@@ -280,21 +263,21 @@ def plan_step(options, mpa, problem, n_threads=1, mpa_struct=None):
 def mt19937_doubles(seed, n):
     """n doubles of the mt19937ar stream (what MATLAB's rand(RandStream('mt19937ar', Seed=seed), 1, n) returns)."""
     out = np.zeros(max(n, 1))
-    lib().oracle_mt19937_doubles(int(seed), int(n), out.ctypes.data_as(abi.c_double_p))
+    lib().oracle_mt19937_doubles(int(seed), int(n), out.ctypes.data_as(packing._dptr))
     return out[:n]
 
 
 def plan_batch_sampled(options, mpa, iters, seeds, n_threads=1):
     """The sampled optimizer (MonteCarloTreeSearch.m) with the oracle -> (list[ControlResultsInfo], records).
     seeds[i] = time_step + vehicle_index of vehicle i (MonteCarloTreeSearch.m:32)."""
-    mpa_struct, keep_m = abi.pack_mpa(mpa)
-    arr, keep_v = abi.pack_vehicles(iters, options.Hp)
+    mpa_struct, keep_m = packing.pack_mpa(mpa)
+    arr, keep_v = packing.pack_vehicles(iters, options.Hp)
     n = len(iters)
     cfg = make_abi_config(options)
-    out = abi.out_array(n)
+    out = packing.out_array(n)
     sd = (C.c_uint32 * max(n, 1))(*[int(v) for v in seeds])
     elapsed = C.c_double()
-    rc = lib().oracle_plan_batch_sampled(C.byref(cfg), C.byref(mpa_struct), n, arr, sd, out.ctypes.data_as(C.POINTER(abi.VehicleOut)), int(n_threads), C.byref(elapsed))
+    rc = lib().oracle_plan_batch_sampled(C.byref(cfg), C.byref(mpa_struct), n, arr, sd, out.ctypes.data_as(C.c_void_p), int(n_threads), C.byref(elapsed))
     if rc != 0:
         raise RuntimeError("oracle_plan_batch_sampled failed")
     infos = [info_from_record(out[i], options.Hp) for i in range(n)]

@@ -1264,6 +1264,51 @@ int pdmpc_debug_pop_trace(pdmpc_handle* h, int32_t vehicle, int32_t capacity, in
     return PDMPC_OK;
 }
 
+int pdmpc_debug_edge_check(pdmpc_handle* h, int32_t mode, int32_t n_cases, const int32_t* a_off, const double* a_x, const double* a_y, const int32_t* b_off,
+                           const double* b_x, const double* b_y, int32_t* hit) {
+    if (!h || n_cases < 0 || (n_cases > 0 && (!a_off || !a_x || !a_y || !b_off || !b_x || !b_y || !hit))) return fail(PDMPC_ERR_INVALID, "null argument");
+    if (mode < 0 || mode > 2) return fail(PDMPC_ERR_INVALID, "mode must be 0 (InterX), 1 (intersect_sat) or 2 (intersect_lanelet_boundary)");
+    if (n_cases == 0) return PDMPC_OK;
+    for (int c = 0; c < n_cases; ++c) {
+        const int na = a_off[c + 1] - a_off[c], nb = b_off[c + 1] - b_off[c];
+        if (na < 0 || na > PDMPC_VMAX) return fail(PDMPC_ERR_INVALID, "first operand: at most PDMPC_VMAX columns");
+        if (nb < 0 || nb > 1024) return fail(PDMPC_ERR_INVALID, "second operand: at most 1024 columns");
+    }
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const size_t ta = (size_t)a_off[n_cases], tb = (size_t)b_off[n_cases];
+    int32_t *d_ao = nullptr, *d_bo = nullptr, *d_hit = nullptr;
+    double *d_ax = nullptr, *d_ay = nullptr, *d_bx = nullptr, *d_by = nullptr;
+    HIPCHK(hipMalloc((void**)&d_ao, ((size_t)n_cases + 1) * 4));
+    HIPCHK(hipMalloc((void**)&d_bo, ((size_t)n_cases + 1) * 4));
+    HIPCHK(hipMalloc((void**)&d_hit, (size_t)n_cases * 4));
+    HIPCHK(hipMalloc((void**)&d_ax, std::max<size_t>(ta, 1) * 8));
+    HIPCHK(hipMalloc((void**)&d_ay, std::max<size_t>(ta, 1) * 8));
+    HIPCHK(hipMalloc((void**)&d_bx, std::max<size_t>(tb, 1) * 8));
+    HIPCHK(hipMalloc((void**)&d_by, std::max<size_t>(tb, 1) * 8));
+    HIPCHK(hipMemcpy(d_ao, a_off, ((size_t)n_cases + 1) * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_bo, b_off, ((size_t)n_cases + 1) * 4, hipMemcpyHostToDevice));
+    if (ta) {
+        HIPCHK(hipMemcpy(d_ax, a_x, ta * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_ay, a_y, ta * 8, hipMemcpyHostToDevice));
+    }
+    if (tb) {
+        HIPCHK(hipMemcpy(d_bx, b_x, tb * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_by, b_y, tb * 8, hipMemcpyHostToDevice));
+    }
+    const int lrc = pdmpc_launch_edge_check(mode, n_cases, d_ao, d_ax, d_ay, d_bo, d_bx, d_by, d_hit, (void*)h->stream);
+    if (lrc != 0) return fail(PDMPC_ERR_HIP, "edge-check launch failed");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(hit, d_hit, (size_t)n_cases * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d_ao);
+    (void)hipFree(d_bo);
+    (void)hipFree(d_hit);
+    (void)hipFree(d_ax);
+    (void)hipFree(d_ay);
+    (void)hipFree(d_bx);
+    (void)hipFree(d_by);
+    return PDMPC_OK;
+}
+
 int pdmpc_debug_raw_tree(pdmpc_handle* h, int32_t vehicle, int32_t capacity, double* x, double* y, double* yaw, double* g, double* hh, int32_t* trim,
                          int32_t* k, int32_t* parent, double* key, uint8_t* validity, int32_t* n) {
     if (!h || !n) return fail(PDMPC_ERR_INVALID, "null argument");

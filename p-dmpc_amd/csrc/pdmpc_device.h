@@ -160,6 +160,9 @@ int pdmpc_launch_heap_script(const int32_t* op, const int32_t* id, const double*
 int pdmpc_launch_sampled(const KernelArgs* args, int count, void* stream);
 // defined in frontier_kernel.hip: the search with all wavefronts of a workgroup working on open nodes side by side
 int pdmpc_launch_frontier(const KernelArgs* args, int count, void* stream);
+// defined in debug_kernels.hip: the collision primitives of edge_checks.hpp on given polygons, one wavefront per case
+int pdmpc_launch_edge_check(int mode, int n_cases, const int32_t* a_off, const double* a_x, const double* a_y, const int32_t* b_off, const double* b_x,
+                            const double* b_y, int32_t* hit, void* stream);
 int pdmpc_launch_bm_script(const int32_t* op, const double* key, int n, int32_t* out, unsigned long long* stats, double* gkey, int KR, int NB,
                            void* stream);
 #ifdef __cplusplus

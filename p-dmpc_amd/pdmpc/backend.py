@@ -46,6 +46,7 @@ EXPORTS = [
     "pdmpc_debug_pop_trace",
     "pdmpc_debug_tree",
     "pdmpc_debug_raw_tree",
+    "pdmpc_debug_edge_check",
     "pdmpc_debug_progress",
     "pdmpc_last_error",
     "pdmpc_version",
@@ -104,6 +105,7 @@ def load_library(path=None):
     L.pdmpc_debug_pop_trace.argtypes = [H, C.c_int32, C.c_int32, abi.c_int32_p, abi.c_int32_p]
     L.pdmpc_debug_tree.argtypes = [H, C.c_int32, C.c_int32] + [abi.c_double_p] * 5 + [abi.c_int32_p] * 4
     L.pdmpc_debug_raw_tree.argtypes = [H, C.c_int32, C.c_int32] + [abi.c_double_p] * 5 + [abi.c_int32_p] * 3 + [abi.c_double_p, abi.c_uint8_p, abi.c_int32_p]
+    L.pdmpc_debug_edge_check.argtypes = [H, C.c_int32, C.c_int32, abi.c_int32_p, abi.c_double_p, abi.c_double_p, abi.c_int32_p, abi.c_double_p, abi.c_double_p, abi.c_int32_p]
     L.pdmpc_debug_progress.argtypes = [H, C.c_int32, C.POINTER(C.c_uint32)]
     L.pdmpc_last_error.restype = C.c_char_p
     L.pdmpc_version.restype = C.c_char_p
@@ -343,6 +345,28 @@ class Handle:
         d.update({k: v[:nn].copy() for k, v in i.items()})
         d["validity"] = val[:nn].copy()
         return d
+
+    def edge_check(self, mode, a_list, b_list):
+        """Run a collision primitive on the device for len(a_list) cases: mode 0 InterX, 1 intersect_sat, 2 intersect_lanelet_boundary
+        (b = [left, NaN, right, NaN]).  a_list / b_list: lists of (2, n) arrays.  Returns a bool array."""
+        n = len(a_list)
+        def flat(lst):
+            off = np.zeros(n + 1, dtype=np.int32)
+            for i, p in enumerate(lst):
+                off[i + 1] = off[i] + np.asarray(p).shape[1]
+            x = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.float64)[0] for p in lst] + [np.zeros(1)]))
+            y = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.float64)[1] for p in lst] + [np.zeros(1)]))
+            return off, x, y
+        ao, ax, ay = flat(a_list)
+        bo, bx, by = flat(b_list)
+        hit = np.zeros(max(n, 1), dtype=np.int32)
+        _check(
+            self.L,
+            self.L.pdmpc_debug_edge_check(self.h, mode, n, ao.ctypes.data_as(abi.c_int32_p), ax.ctypes.data_as(abi.c_double_p), ay.ctypes.data_as(abi.c_double_p),
+                                          bo.ctypes.data_as(abi.c_int32_p), bx.ctypes.data_as(abi.c_double_p), by.ctypes.data_as(abi.c_double_p), hit.ctypes.data_as(abi.c_int32_p)),
+            "pdmpc_debug_edge_check",
+        )
+        return hit[:n] != 0
 
     def progress(self, vehicle):
         w = (C.c_uint32 * 32)()

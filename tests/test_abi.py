@@ -62,3 +62,33 @@ def test_product_code_never_touches_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 m = forbidden.search(text)
                 assert m is None, "%s references the oracle: %r" % (os.path.join(dirpath, f), m.group(0))
+
+
+def test_two_independent_packers_agree():
+    """The product's marshalling (pdmpc.abi) and the oracle's own (oracle/packing.py) were written separately from
+    include/pdmpc.h.  Same struct sizes, and the oracle plans identically from either one's structs — a wrong index in one of
+    them (polygon order of dynamic_obstacles, transition[k][i][j], area rows) would show here and in every GPU parity test."""
+    import ctypes as C
+
+    import numpy as np
+
+    import problems
+    from oracle import oracle, packing
+    from pdmpc import abi
+
+    assert C.sizeof(packing.OVehicleIn) == C.sizeof(abi.VehicleIn)
+    assert C.sizeof(packing.OManeuver) == C.sizeof(abi.Maneuver)
+    assert C.sizeof(packing.OMpa) == C.sizeof(abi.Mpa)
+    assert C.sizeof(packing.OConfig) == C.sizeof(abi.Config)
+    assert packing.OUT_DTYPE == abi.VEHICLE_OUT_DTYPE
+    for mode, kw in (("interx", {"n_hdv": 1}), ("sat", {})):
+        options, mpa, iters = problems.problem_set(mode, 3, 6, Hp=6, **kw)
+        options.max_nodes = 1 << 20
+        m1, k1 = abi.pack_mpa(mpa)
+        v1, kv1 = abi.pack_vehicles(iters, options.Hp)
+        m2, k2 = packing.pack_mpa(mpa)
+        v2, kv2 = packing.pack_vehicles(iters, options.Hp)
+        a, _, _ = oracle.plan_batch_raw(options, m1, v1, len(iters))
+        b, _, _ = oracle.plan_batch_raw(options, m2, v2, len(iters))
+        assert a.tobytes() == b.tobytes()
+        assert (a["status"] == 0).any()
