@@ -1,0 +1,865 @@
+// step_controller.cpp — the caller's side of the optimizer boundary, natively: one MPC time step of the prioritized
+// sequential controller around pdmpc_plan_step.  Host code only (no device code in this file).
+//
+// What it restates (file:line relative to the reference root), the C++ twin of p-dmpc_amd/pdmpc/controller.py:
+//   traffic info per step     HighLevelController.update_controlled_vehicles_traffic_info (hlc/controller/HighLevelController.m:167-270)
+//   trim from measurement     MotionPrimitiveAutomaton.trim_from_values (hlc/model/motion_primitive_automaton/MotionPrimitiveAutomaton.m:193-236)
+//   occupied areas            hlc/controller/common/get_occupied_areas.m:21-31, utility/translate_global.m:19-22
+//   reference trajectory      hlc/controller/common/get_reference_trajectory.m:27-46, sample_reference_trajectory.m:1-99,
+//                             get_arc_distance_to_endpoint.m:39-114, projection_2d.m:14-42
+//   predicted lanelets        hlc/controller/common/get_predicted_lanelets.m:25-62, get_lanelets_boundary.m:18-68
+//   coupling                  Coupler.m:31-32 (full), DistanceCoupler.m:15-50 (distance)
+//   priorities -> DAG         ConstantPrioritizer.m:14-20, Prioritizer.m:36-77, ColoringPrioritizer.m:11-131
+//   grouping                  PrioritizedController.group (hlc/controller/prioritized/PrioritizedController.m:375-389),
+//                             weight/DistanceWeigher.m:12-39, weight/ConstantWeigher.m:15-17, cut/GreedyCutter.m:5-86
+//   computation levels        utility/kahn.m:1-24
+//   obstacle assembly         PrioritizedController.plan / consider_predecessors / consider_successors (:297-324, 449-566)
+//   exhaustion, fallbacks     handle_graph_search_exhaustion / plan_fallback (:568-616, 678-718), check_others_fallback (:623-676),
+//                             HighLevelController.handle_others_fallback (HighLevelController.m:449-463)
+//   plant                     Simulation.apply (plant/Simulation.m:86-100)
+// Every floating-point expression keeps the order of the Python twin (which keeps the reference's), and both call the
+// same libm, so the step problems the two build are bit-identical (tests/test_native_controller.py).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/pdmpc.h"
+
+namespace {
+
+struct Poly {  // 2 x V, MATLAB [x; y]
+    std::vector<double> x, y;
+    int n() const { return (int)x.size(); }
+};
+
+struct Plan {  // what the controller keeps of a vehicle's ControlResultsInfo (ControlResultsInfo.m:5-17)
+    bool present = false;
+    bool needs_fallback = false;
+    bool exhausted = false;
+    std::vector<Poly> shapes;         // Hp
+    std::vector<int32_t> trims;       // Hp
+    std::vector<double> yx, yy, yyaw; // Hp
+    int32_t n_expanded = 0;
+};
+
+struct VehicleDef {
+    double x_start, y_start, yaw_start, reference_speed;
+    std::vector<double> px, py;             // reference path
+    std::vector<int32_t> lanelets_index;    // 1-based lanelet ids along the loop (empty: no lanelets, circle scenario)
+    std::vector<int32_t> points_index;      // 1-based index of the last path point of each of those lanelets
+    bool is_loop;
+    double tile_dx, tile_dy;
+};
+
+}  // namespace
+
+struct pdmpc_controller {
+    pdmpc_handle* h = nullptr;
+    pdmpc_controller_config cfg{};
+    int n = 0, Hp = 0;
+    std::vector<VehicleDef> veh;
+    std::vector<Poly> bl_left, bl_right;  // per lanelet boundary polylines (RoadDataCommonRoad.get_lanelet_boundary)
+    std::vector<Poly> static_obstacles;
+    std::vector<double> trim_speed, trim_steering;
+    // state
+    int k = 0;
+    std::vector<double> mx, my, myaw, mspeed, msteer;  // measurements
+    std::vector<Plan> info_old, infos;
+    // per step
+    std::vector<int32_t> trims;
+    std::vector<Poly> occ_offset, occ_plain;
+    std::vector<std::vector<double>> ref_x, ref_y, v_ref;
+    std::vector<Poly> bnd_left, bnd_right;
+    std::vector<uint8_t> adjacency, directed, directed_seq;  // n x n row-major
+    std::vector<int32_t> levels, order, slot_of;
+    // the step problem in the C ABI's form (what pdmpc_plan_step takes); pools keep the pointed-to data alive
+    std::vector<pdmpc_vehicle_in> in;
+    std::vector<pdmpc_polygon_set> fb;
+    std::vector<int32_t> pred_offset, pred_index;
+    std::vector<std::vector<double>> dpool;
+    std::vector<std::vector<int32_t>> ipool;
+    std::vector<pdmpc_vehicle_out> out;
+    std::string err;
+};
+
+namespace {
+
+thread_local std::string g_cerr;
+
+inline uint8_t& at(std::vector<uint8_t>& m, int n, int i, int j) { return m[(size_t)i * n + j]; }
+inline uint8_t at(const std::vector<uint8_t>& m, int n, int i, int j) { return m[(size_t)i * n + j]; }
+
+// utility/kahn.m:1-24: computation level (1-based) of every vertex of the DAG A (A[i][j] = 1: i before j)
+bool kahn(const std::vector<uint8_t>& A_in, int n, std::vector<int32_t>& L) {
+    std::vector<uint8_t> A = A_in;
+    L.assign(n, 0);
+    std::vector<uint8_t> done(n, 0);
+    int n_done = 0, level = 1;
+    while (n_done < n) {
+        std::vector<int> src;
+        for (int j = 0; j < n; ++j) {
+            if (done[j]) continue;
+            int in_d = 0;
+            for (int i = 0; i < n; ++i) in_d += A[(size_t)i * n + j];
+            if (in_d == 0) src.push_back(j);
+        }
+        if (src.empty()) return false;  // a cycle
+        for (int v : src) {
+            L[v] = level;
+            done[v] = 1;
+            ++n_done;
+        }
+        for (int v : src)
+            for (int j = 0; j < n; ++j) A[(size_t)v * n + j] = 0;
+        ++level;
+    }
+    return true;
+}
+
+// MotionPrimitiveAutomaton.trim_from_values (:193-236): 1-based index of the closest trim
+int trim_from_values(const pdmpc_controller& c, double speed, double steering) {
+    const int nt = (int)c.trim_speed.size();
+    if (steering == 0) {
+        int best = -1;
+        double bd = 0;
+        for (int t = 0; t < nt; ++t) {
+            if (c.trim_steering[t] != 0) continue;
+            const double d = std::fabs(c.trim_speed[t] - speed);
+            if (best < 0 || d < bd) {
+                best = t;
+                bd = d;
+            }
+        }
+        return best + 1;
+    }
+    double sp_min = c.trim_speed[0], sp_max = c.trim_speed[0], st_min = c.trim_steering[0], st_max = c.trim_steering[0];
+    for (int t = 1; t < nt; ++t) {
+        sp_min = std::min(sp_min, c.trim_speed[t]);
+        sp_max = std::max(sp_max, c.trim_speed[t]);
+        st_min = std::min(st_min, c.trim_steering[t]);
+        st_max = std::max(st_max, c.trim_steering[t]);
+    }
+    const double sp_s = sp_max - sp_min, st_s = st_max - st_min;
+    int best = 0;
+    double bd = 0;
+    for (int t = 0; t < nt; ++t) {
+        const double a = (c.trim_speed[t] - sp_min) / sp_s - (speed - sp_min) / sp_s;
+        const double b = (c.trim_steering[t] - st_min) / st_s - (steering - st_min) / st_s;
+        const double d = std::hypot(a, b);
+        if (t == 0 || d < bd) {
+            best = t;
+            bd = d;
+        }
+    }
+    return best + 1;
+}
+
+// get_occupied_areas.m:21-31 -> closed rectangles with and without the offset (translate_global.m:19-22)
+void occupied_areas(double x, double y, double yaw, double length, double width, double offset, Poly& with_offset, Poly& plain) {
+    static const double sx[5] = {-1, -1, 1, 1, -1}, sy[5] = {-1, 1, 1, -1, -1};
+    const double c = std::cos(yaw), s = std::sin(yaw);
+    with_offset.x.resize(5);
+    with_offset.y.resize(5);
+    plain.x.resize(5);
+    plain.y.resize(5);
+    for (int q = 0; q < 5; ++q) {
+        const double xa = sx[q] * (length / 2 + offset), ya = sy[q] * (width / 2 + offset);
+        with_offset.x[q] = c * xa + (-s) * ya + x;
+        with_offset.y[q] = s * xa + c * ya + y;
+        const double xb = sx[q] * (length / 2), yb = sy[q] * (width / 2);
+        plain.x[q] = c * xb + (-s) * yb + x;
+        plain.y[q] = s * xb + c * yb + y;
+    }
+}
+
+inline double norm2(double a, double b) { return std::sqrt(a * a + b * b); }
+
+// projection_2d.m:14-42 -> projected point and lambda
+void projection_2d(double x1, double y1, double x2, double y2, double x3, double y3, double& xp, double& yp, double& lambda) {
+    const double b = std::sqrt((x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1));
+    if (b != 0) {
+        const double xn = (x2 - x1) / b, yn = (y2 - y1) / b;
+        const double x31 = x3 - x1, y31 = y3 - y1;
+        const double dot = xn * x31 + yn * y31;
+        xp = x1 + dot * xn;
+        yp = y1 + dot * yn;
+        lambda = dot / b;
+    } else {
+        xp = x1;
+        yp = y1;
+        lambda = 0.0;
+    }
+}
+
+// get_arc_distance_to_endpoint.m:39-114 (the part the sampler uses): projected point and 1-based idx_next
+void arc_projection(double px, double py, const std::vector<double>& cx, const std::vector<double>& cy, double& xp, double& yp, int& idx_next) {
+    const int np = (int)cx.size();
+    int ic = 0;
+    double best = 0;
+    std::vector<double> sq(np);
+    for (int i = 0; i < np; ++i) {
+        sq[i] = (cx[i] - px) * (cx[i] - px) + (cy[i] - py) * (cy[i] - py);
+        if (i == 0 || sq[i] < best) {
+            best = sq[i];
+            ic = i;
+        }
+    }
+    int f, s;
+    if (ic == 0) {
+        f = 0;
+        s = 1;
+    } else if (ic == np - 1) {
+        f = np - 2;
+        s = np - 1;
+    } else if (sq[ic - 1] <= sq[ic + 1]) {
+        f = ic - 1;
+        s = ic;
+    } else {
+        f = ic;
+        s = ic + 1;
+    }
+    double lam;
+    projection_2d(cx[f], cy[f], cx[s], cy[s], px, py, xp, yp, lam);
+    const int idx_closest = ic + 1;
+    idx_next = idx_closest;
+    if ((0 <= lam && lam <= 0.5) || lam >= 1) idx_next = idx_closest < np ? idx_closest + 1 : 1;
+    idx_next = std::max(2, idx_next);
+}
+
+// sample_reference_trajectory.m:1-99 (indices 1-based)
+void sample_reference(int n_samples, const std::vector<double>& rx, const std::vector<double>& ry, double x_cur, double y_cur, const std::vector<double>& step,
+                      std::vector<double>& out_x, std::vector<double>& out_y, std::vector<int32_t>& points_index, int& current_point_index) {
+    out_x.assign(n_samples, 0.0);
+    out_y.assign(n_samples, 0.0);
+    points_index.assign(n_samples, 0);
+    double cx, cy;
+    int point_index;
+    arc_projection(x_cur, y_cur, rx, ry, cx, cy, point_index);
+    current_point_index = point_index;
+    const int n_line = (int)rx.size();
+    const bool is_loop = norm2(rx[0] - rx[n_line - 1], ry[0] - ry[n_line - 1]) < 1e-8;
+    bool at_end = point_index == n_line;
+    int last = point_index - 1;
+    if (is_loop && at_end) point_index = 1;
+    auto X = [&](int i) { return rx[i - 1]; };
+    auto Y = [&](int i) { return ry[i - 1]; };
+    for (int i = 0; i < n_samples; ++i) {
+        double remaining = norm2(cx - X(point_index), cy - Y(point_index));
+        if (remaining > step[i] || point_index == n_line) {
+            while (X(point_index) == X(last) && Y(point_index) == Y(last) && last > 1) --last;
+            const double dx = X(point_index) - X(last), dy = Y(point_index) - Y(last);
+            const double nn = norm2(dx, dy);
+            cx = cx + step[i] * (dx / nn);
+            cy = cy + step[i] * (dy / nn);
+        } else {
+            double reflength = remaining;
+            while (remaining < step[i]) {
+                reflength = remaining;
+                cx = X(point_index);
+                cy = Y(point_index);
+                last = point_index;
+                point_index = std::min(point_index + 1, n_line);
+                at_end = point_index == n_line;
+                if (is_loop && at_end) point_index = 1;
+                remaining = remaining + norm2(cx - X(point_index), cy - Y(point_index));
+            }
+            const double dx = X(point_index) - X(last), dy = Y(point_index) - Y(last);
+            const double nn = norm2(dx, dy);
+            cx = cx + (step[i] - reflength) * (dx / nn);
+            cy = cy + (step[i] - reflength) * (dy / nn);
+        }
+        out_x[i] = cx;
+        out_y[i] = cy;
+        points_index[i] = point_index;
+    }
+}
+
+// get_predicted_lanelets.m:25-62 + get_lanelets_boundary.m:18-68 for vehicle v
+void lanelet_boundary(const pdmpc_controller& c, int v, const std::vector<int32_t>& ref_points_index, int current_point_index, Poly& left, Poly& right) {
+    const VehicleDef& V = c.veh[v];
+    left.x.clear();
+    left.y.clear();
+    right.x.clear();
+    right.y.clear();
+    if (V.lanelets_index.empty()) return;
+    const int n_total = (int)V.px.size(), n_lan = (int)V.lanelets_index.size();
+    std::vector<int> rpi(ref_points_index.begin(), ref_points_index.end());
+    int index_add = rpi.back() + 4;
+    if (index_add > n_total) index_add -= n_total;
+    rpi.push_back(index_add);
+    std::vector<int> seen;
+    for (int p : rpi) {
+        int q = 1;
+        for (int t = 0; t < n_lan; ++t) q += p > V.points_index[t];
+        if (std::find(seen.begin(), seen.end(), q) == seen.end()) seen.push_back(q);  // unique(..., 'stable')
+    }
+    if (seen.size() == 1) {
+        int nxt = seen[0] + 1;
+        if (nxt > n_lan) nxt = 1;
+        seen.push_back(nxt);
+    }
+    (void)current_point_index;
+    std::vector<int> predicted;
+    for (int q : seen) predicted.push_back(V.lanelets_index[std::min(q, n_lan) - 1]);
+    // boundaries of the predicted lanelets back to back, each without its last point but the final one   :26-32
+    auto append = [](Poly& dst, const Poly& src, int from, int to) {
+        for (int i = from; i < to; ++i) {
+            dst.x.push_back(src.x[i]);
+            dst.y.push_back(src.y[i]);
+        }
+    };
+    Poly L, R;
+    for (size_t q = 0; q < predicted.size(); ++q) {
+        const Poly& bl = c.bl_left[predicted[q] - 1];
+        const Poly& br = c.bl_right[predicted[q] - 1];
+        const bool final_one = q + 1 == predicted.size();
+        append(L, bl, 0, final_one ? bl.n() : bl.n() - 1);
+        append(R, br, 0, final_one ? br.n() : br.n() - 1);
+    }
+    // up to four points of the predecessor lanelet in front   :39-65
+    int pos = (int)(std::find(V.lanelets_index.begin(), V.lanelets_index.end(), predicted[0]) - V.lanelets_index.begin());
+    int pred = -1;
+    if (pos != 0)
+        pred = V.lanelets_index[pos - 1];
+    else if (V.is_loop)
+        pred = V.lanelets_index.back();
+    if (pred >= 0) {
+        const Poly& pl = c.bl_left[pred - 1];
+        const Poly& pr = c.bl_right[pred - 1];
+        const int num_added = std::min(4, std::min(pr.n() - 1, pl.n() - 1));
+        append(left, pl, pl.n() - 1 - num_added, pl.n() - 1);
+        append(right, pr, pr.n() - 1 - num_added, pr.n() - 1);
+    }
+    append(left, L, 0, L.n());
+    append(right, R, 0, R.n());
+    for (int i = 0; i < left.n(); ++i) {
+        left.x[i] = left.x[i] + V.tile_dx;
+        left.y[i] = left.y[i] + V.tile_dy;
+    }
+    for (int i = 0; i < right.n(); ++i) {
+        right.x[i] = right.x[i] + V.tile_dx;
+        right.y[i] = right.y[i] + V.tile_dy;
+    }
+}
+
+// ColoringPrioritizer.prioritize (:11-27): directed coupling from a colouring of the undirected graph
+void coloring_directed(const std::vector<uint8_t>& adjacency, int n, std::vector<uint8_t>& directed) {
+    std::vector<uint8_t> A = adjacency;
+    for (int i = 0; i < n; ++i) at(A, n, i, i) = 0;
+    std::vector<int> degree(n, 0), color(n, 0);
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) degree[j] += at(A, n, i, j);
+    for (int i = 0; i < n; ++i)
+        if (degree[i] == 0) color[i] = 1;  // :45
+    auto uncoloured = [&]() { return std::find(color.begin(), color.end(), 0) != color.end(); };
+    while (uncoloured()) {
+        // vertex_sdo_ldo (:65-89): most distinct neighbour colours; among equals the last one whose degree is strictly
+        // larger than the current pick's
+        int best = -1, idx = -1;
+        for (int i = 0; i < n; ++i) {
+            if (color[i] != 0) continue;
+            std::vector<int> seen;
+            for (int j = 0; j < n; ++j)
+                if (at(A, n, i, j) && color[j] != 0 && std::find(seen.begin(), seen.end(), color[j]) == seen.end()) seen.push_back(color[j]);
+            const int d = (int)seen.size();
+            if (d > best) {
+                best = d;
+                idx = i;
+            }
+            if (d == best && degree[i] > degree[idx]) idx = i;
+        }
+        std::vector<uint8_t> used(n + 2, 0);
+        for (int j = 0; j < n; ++j)
+            if (at(A, n, idx, j)) used[color[j]] = 1;  // (colour 0 = uncoloured neighbours: harmless)
+        int cpick = 1;
+        while (used[cpick]) ++cpick;
+        color[idx] = cpick;
+    }
+    // level matrix rows = colours in ascending order; order_topo (:91-131)
+    std::vector<int> colours;
+    for (int i = 0; i < n; ++i)
+        if (std::find(colours.begin(), colours.end(), color[i]) == colours.end()) colours.push_back(color[i]);
+    std::sort(colours.begin(), colours.end());
+    const int nl = (int)colours.size();
+    auto row_of = [&](int v) { return (int)(std::find(colours.begin(), colours.end(), color[v]) - colours.begin()); };
+    std::vector<long> deg(n, 0);
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) deg[j] += adjacency[(size_t)i * n + j] != 0;
+    std::vector<int> order;
+    long total = 0;
+    for (long d : deg) total += d;
+    if (total == 0) {
+        for (int g = 0; g < nl; ++g) order.push_back(g);
+    } else {
+        while (total != 0) {
+            int max_idx = 0;
+            for (int i = 1; i < n; ++i)
+                if (deg[i] > deg[max_idx]) max_idx = i;  // first index of the maximum
+            const int lvl = row_of(max_idx);
+            order.push_back(lvl);
+            for (int i = 0; i < n; ++i)
+                if (row_of(i) == lvl) deg[i] = 0;
+            total = 0;
+            for (long d : deg) total += d;
+        }
+        for (int g = 0; g < nl; ++g)
+            if (std::find(order.begin(), order.end(), g) == order.end()) order.push_back(g);
+    }
+    std::vector<int> level(n, 0);
+    for (int v = 0; v < n; ++v) level[v] = (int)(std::find(order.begin(), order.end(), row_of(v)) - order.begin()) + 1;
+    directed.assign((size_t)n * n, 0);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j)
+            if (i != j && adjacency[(size_t)i * n + j] && !(level[i] > level[j])) at(directed, n, i, j) = 1;  // Prioritizer.m:52-55
+}
+
+// PrioritizedController.group (:375-389): weigh + GreedyCutter.cut (cut/GreedyCutter.m:5-86)
+bool group(pdmpc_controller& c, const std::vector<uint8_t>& directed, std::vector<uint8_t>& seq) {
+    const int n = c.n;
+    std::vector<int32_t> L;
+    if (!kahn(directed, n, L)) return false;
+    int depth = 0;
+    for (int v : L) depth = std::max(depth, v);
+    if (depth <= c.cfg.max_num_CLs) {
+        seq = directed;  // every sub-graph of the DAG is at most as deep: the cutter accepts every edge
+        return true;
+    }
+    seq.assign((size_t)n * n, 0);
+    if (c.cfg.max_num_CLs == 1) return true;
+    // weights; [row, col] = find(M): column-major order
+    struct Edge { int a, b; double w; };
+    std::vector<Edge> edges;
+    const double vmax = *std::max_element(c.trim_speed.begin(), c.trim_speed.end());
+    const double max_distance = 2 * vmax * c.cfg.dt_seconds * c.Hp;
+    for (int b = 0; b < n; ++b)
+        for (int a = 0; a < n; ++a) {
+            if (!at(directed, n, a, b)) continue;
+            double w = 0.5;  // ConstantWeigher
+            if (c.cfg.weight_strategy == PDMPC_WEIGHT_DISTANCE) {
+                const double dx = c.mx[a] - c.mx[b], dy = c.my[a] - c.my[b];
+                w = 1 - std::sqrt(dx * dx + dy * dy) / max_distance;
+            }
+            if (w != 0) edges.push_back({a, b, w});  // (find() on the weighted matrix skips exact zeros)
+        }
+    std::stable_sort(edges.begin(), edges.end(), [](const Edge& p, const Edge& q) { return p.w > q.w; });
+    std::vector<int32_t> levels;
+    kahn(seq, n, levels);
+    for (const Edge& e : edges) {
+        if (levels[e.a] < levels[e.b]) {
+            at(seq, n, e.a, e.b) = 1;
+            continue;
+        }
+        std::vector<uint8_t> trial = seq;
+        at(trial, n, e.a, e.b) = 1;
+        std::vector<int32_t> nl;
+        if (!kahn(trial, n, nl)) continue;
+        int mxl = 0;
+        for (int v : nl) mxl = std::max(mxl, v);
+        if (mxl <= c.cfg.max_num_CLs) {
+            seq.swap(trial);
+            levels.swap(nl);
+        }
+    }
+    return true;
+}
+
+std::vector<Poly> del_first_rpt_last(const std::vector<Poly>& s) {
+    std::vector<Poly> r(s.begin() + 1, s.end());
+    r.push_back(s.back());
+    return r;
+}
+
+struct SetBuilder {  // builds a pdmpc_polygon_set whose arrays live in the controller's pools
+    std::vector<int32_t> off{0};
+    std::vector<double> x, y;
+    void add(const Poly& p) {
+        x.insert(x.end(), p.x.begin(), p.x.end());
+        y.insert(y.end(), p.y.begin(), p.y.end());
+        off.push_back((int32_t)x.size());
+    }
+    pdmpc_polygon_set finish(pdmpc_controller& c) {
+        pdmpc_polygon_set s;
+        s.n_polygons = (int32_t)off.size() - 1;
+        x.push_back(0.0);
+        y.push_back(0.0);
+        c.ipool.push_back(std::move(off));
+        c.dpool.push_back(std::move(x));
+        c.dpool.push_back(std::move(y));
+        s.offset = c.ipool.back().data();
+        s.x = c.dpool[c.dpool.size() - 2].data();
+        s.y = c.dpool.back().data();
+        return s;
+    }
+};
+
+int cfail(pdmpc_controller* c, int code, const std::string& msg) {
+    g_cerr = msg;
+    if (c) c->err = msg;
+    return code;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pdmpc_controller_last_error(void) { return g_cerr.c_str(); }
+
+int pdmpc_controller_create(pdmpc_handle* handle, const pdmpc_controller_config* cfg, const pdmpc_scenario* sc, pdmpc_controller** out) {
+    if (!cfg || !sc || !out) return cfail(nullptr, PDMPC_ERR_INVALID, "null argument");
+    if (sc->n_vehicles < 1 || cfg->Hp < 1 || cfg->Hp > PDMPC_HP_MAX || sc->n_trims < 1) return cfail(nullptr, PDMPC_ERR_INVALID, "bad sizes");
+    pdmpc_controller* c = new pdmpc_controller();
+    c->h = handle;
+    c->cfg = *cfg;
+    c->n = sc->n_vehicles;
+    c->Hp = cfg->Hp;
+    c->trim_speed.assign(sc->trim_speed, sc->trim_speed + sc->n_trims);
+    c->trim_steering.assign(sc->trim_steering, sc->trim_steering + sc->n_trims);
+    for (int v = 0; v < c->n; ++v) {
+        VehicleDef d;
+        d.x_start = sc->x_start[v];
+        d.y_start = sc->y_start[v];
+        d.yaw_start = sc->yaw_start[v];
+        d.reference_speed = sc->reference_speed[v];
+        d.px.assign(sc->path_x + sc->path_offset[v], sc->path_x + sc->path_offset[v + 1]);
+        d.py.assign(sc->path_y + sc->path_offset[v], sc->path_y + sc->path_offset[v + 1]);
+        if (d.px.size() < 2) {
+            delete c;
+            return cfail(nullptr, PDMPC_ERR_INVALID, "a reference path needs at least two points");
+        }
+        if (sc->lanelets_offset) {
+            d.lanelets_index.assign(sc->lanelets_index + sc->lanelets_offset[v], sc->lanelets_index + sc->lanelets_offset[v + 1]);
+            d.points_index.assign(sc->points_index + sc->lanelets_offset[v], sc->points_index + sc->lanelets_offset[v + 1]);
+        }
+        d.is_loop = sc->is_loop ? sc->is_loop[v] != 0 : true;
+        d.tile_dx = sc->tile_dx ? sc->tile_dx[v] : 0.0;
+        d.tile_dy = sc->tile_dy ? sc->tile_dy[v] : 0.0;
+        c->veh.push_back(std::move(d));
+    }
+    for (int l = 0; l < sc->n_lanelets; ++l) {
+        Poly a, b;
+        a.x.assign(sc->left_x + sc->left_offset[l], sc->left_x + sc->left_offset[l + 1]);
+        a.y.assign(sc->left_y + sc->left_offset[l], sc->left_y + sc->left_offset[l + 1]);
+        b.x.assign(sc->right_x + sc->right_offset[l], sc->right_x + sc->right_offset[l + 1]);
+        b.y.assign(sc->right_y + sc->right_offset[l], sc->right_y + sc->right_offset[l + 1]);
+        c->bl_left.push_back(std::move(a));
+        c->bl_right.push_back(std::move(b));
+    }
+    for (int p = 0; p < sc->obstacles.n_polygons; ++p) {
+        Poly o;
+        o.x.assign(sc->obstacles.x + sc->obstacles.offset[p], sc->obstacles.x + sc->obstacles.offset[p + 1]);
+        o.y.assign(sc->obstacles.y + sc->obstacles.offset[p], sc->obstacles.y + sc->obstacles.offset[p + 1]);
+        c->static_obstacles.push_back(std::move(o));
+    }
+    // Simulation.setup: initial speed = steering = 0 (Simulation.m:52-65)
+    c->mx.resize(c->n);
+    c->my.resize(c->n);
+    c->myaw.resize(c->n);
+    c->mspeed.assign(c->n, 0.0);
+    c->msteer.assign(c->n, 0.0);
+    for (int v = 0; v < c->n; ++v) {
+        c->mx[v] = c->veh[v].x_start;
+        c->my[v] = c->veh[v].y_start;
+        c->myaw[v] = c->veh[v].yaw_start;
+    }
+    c->info_old.assign(c->n, Plan());
+    c->infos.assign(c->n, Plan());
+    *out = c;
+    return PDMPC_OK;
+}
+
+int pdmpc_controller_destroy(pdmpc_controller* c) {
+    delete c;
+    return PDMPC_OK;
+}
+
+// Everything one launch needs to plan the whole time step (controller.py: build_step_problem): vehicles in level order
+// (slot = position), per-slot predecessor slots, per-slot areas to publish on exhaustion.
+int pdmpc_controller_build_step(pdmpc_controller* c) {
+    if (!c) return cfail(nullptr, PDMPC_ERR_INVALID, "null controller");
+    const int n = c->n, Hp = c->Hp;
+    c->k += 1;
+    c->infos.assign(n, Plan());
+    c->dpool.clear();
+    c->ipool.clear();
+    // ---- traffic info
+    c->trims.assign(n, 0);
+    c->occ_offset.assign(n, Poly());
+    c->occ_plain.assign(n, Poly());
+    c->ref_x.assign(n, {});
+    c->ref_y.assign(n, {});
+    c->v_ref.assign(n, {});
+    c->bnd_left.assign(n, Poly());
+    c->bnd_right.assign(n, Poly());
+    for (int v = 0; v < n; ++v) {
+        c->trims[v] = trim_from_values(*c, c->mspeed[v], c->msteer[v]);
+        occupied_areas(c->mx[v], c->my[v], c->myaw[v], c->cfg.vehicle_length, c->cfg.vehicle_width, c->cfg.offset, c->occ_offset[v], c->occ_plain[v]);
+        // get_reference_trajectory.m:27-46
+        std::vector<double> vref(Hp, c->veh[v].reference_speed), step(Hp);
+        const double v_current = c->trim_speed[c->trims[v] - 1];
+        for (int q = 0; q < Hp; ++q) step[q] = (((q == 0 ? v_current : vref[q - 1]) + vref[q]) / 2) * c->cfg.dt_seconds;
+        std::vector<int32_t> pidx;
+        int cpi = 0;
+        sample_reference(Hp, c->veh[v].px, c->veh[v].py, c->mx[v], c->my[v], step, c->ref_x[v], c->ref_y[v], pidx, cpi);
+        c->v_ref[v] = vref;
+        lanelet_boundary(*c, v, pidx, cpi, c->bnd_left[v], c->bnd_right[v]);
+    }
+    // ---- coupling
+    c->adjacency.assign((size_t)n * n, 0);
+    if (c->cfg.coupling == PDMPC_COUPLING_FULL) {
+        for (int a = 0; a < n; ++a)
+            for (int b = 0; b < n; ++b) at(c->adjacency, n, a, b) = a != b;
+    } else if (c->cfg.coupling == PDMPC_COUPLING_DISTANCE) {
+        const double vmax = *std::max_element(c->trim_speed.begin(), c->trim_speed.end());
+        const double max_distance = 2 * vmax * c->cfg.dt_seconds * Hp;
+        for (int a = 0; a < n; ++a)
+            for (int b = a + 1; b < n; ++b) {
+                const bool near = std::hypot(c->mx[a] - c->mx[b], c->my[a] - c->my[b]) <= max_distance;
+                at(c->adjacency, n, a, b) = at(c->adjacency, n, b, a) = near;
+            }
+    }
+    // ---- priorities -> directed coupling
+    if (c->cfg.priority_strategy == PDMPC_PRIORITY_COLORING) {
+        coloring_directed(c->adjacency, n, c->directed);
+    } else {  // constant priorities = vehicle index (ConstantPrioritizer.m:14-20): keep i -> j iff i <= j
+        c->directed.assign((size_t)n * n, 0);
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j)
+                if (at(c->adjacency, n, i, j) && !(j < i)) at(c->directed, n, i, j) = 1;
+    }
+    if (!group(*c, c->directed, c->directed_seq)) return cfail(c, PDMPC_ERR_INVALID, "coupling graph has a cycle");
+    if (!kahn(c->directed_seq, n, c->levels)) return cfail(c, PDMPC_ERR_INVALID, "coupling graph has a cycle");
+    c->order.resize(n);
+    for (int i = 0; i < n; ++i) c->order[i] = i;
+    std::stable_sort(c->order.begin(), c->order.end(), [&](int a, int b) { return c->levels[a] < c->levels[b]; });
+    c->slot_of.assign(n, 0);
+    for (int s = 0; s < n; ++s) c->slot_of[c->order[s]] = s;
+    // ---- per slot inputs
+    c->in.assign(n, pdmpc_vehicle_in());
+    c->fb.assign(n, pdmpc_polygon_set());
+    c->pred_offset.assign(n + 1, 0);
+    c->pred_index.clear();
+    for (int s = 0; s < n; ++s) {
+        const int i = c->order[s];
+        pdmpc_vehicle_in& I = c->in[s];
+        std::memset(&I, 0, sizeof I);
+        I.x0 = c->mx[i];
+        I.y0 = c->my[i];
+        I.yaw0 = c->myaw[i];
+        I.trim0 = c->trims[i];
+        I.ref_x = c->ref_x[i].data();
+        I.ref_y = c->ref_y[i].data();
+        I.v_ref = c->v_ref[i].data();
+        I.n_left = c->bnd_left[i].n();
+        I.n_right = c->bnd_right[i].n();
+        I.left_x = c->bnd_left[i].x.data();
+        I.left_y = c->bnd_left[i].y.data();
+        I.right_x = c->bnd_right[i].x.data();
+        I.right_y = c->bnd_right[i].y.data();
+        SetBuilder obst, dyn, hdv;
+        for (const Poly& o : c->static_obstacles) obst.add(o);
+        // consider_predecessors (:449-506): sequential ones are handed over on the device; the others contribute their
+        // previous plan shifted by one step (parallel_coupling_previous_trajectory, :409-447)
+        for (int j = 0; j < n; ++j) {
+            if (!at(c->directed, n, j, i)) continue;
+            if (at(c->directed_seq, n, j, i)) continue;
+            if (c->info_old[j].present && c->k > 1)
+                for (const Poly& p : del_first_rpt_last(c->info_old[j].shapes)) dyn.add(p);
+        }
+        // consider_successors (:508-566)
+        for (int j = 0; j < n; ++j) {
+            if (!at(c->directed, n, i, j)) continue;
+            if (c->cfg.constraint_from_successor == PDMPC_SUCCESSOR_AREA_OF_STANDSTILL) {
+                if (std::fabs(c->mspeed[j]) < 0.01) obst.add(c->occ_offset[j]);  // :536-540
+            } else if (c->cfg.constraint_from_successor == PDMPC_SUCCESSOR_AREA_OF_PREVIOUS_TRAJECTORY) {
+                if (c->info_old[j].present)
+                    for (const Poly& p : del_first_rpt_last(c->info_old[j].shapes)) dyn.add(p);
+            }
+        }
+        I.obstacles = obst.finish(*c);
+        I.dynamic_obstacles = dyn.finish(*c);
+        I.hdv_reachable_sets = hdv.finish(*c);
+        // sequential predecessors as slots
+        for (int j = 0; j < n; ++j)
+            if (at(c->directed_seq, n, j, i)) c->pred_index.push_back(c->slot_of[j]);
+        c->pred_offset[s + 1] = (int32_t)c->pred_index.size();
+        // what the vehicle publishes if its search is exhausted: its standstill rectangle (:602-611) or the previous plan
+        // shifted by one step (:678-718)
+        SetBuilder fbs;
+        const bool standstill = c->trim_speed[c->trims[i] - 1] == 0;
+        if (standstill && c->cfg.constraint_from_successor != PDMPC_SUCCESSOR_NONE) {
+            for (int q = 0; q < Hp; ++q) fbs.add(c->occ_plain[i]);
+        } else if (c->info_old[i].present) {
+            for (const Poly& p : del_first_rpt_last(c->info_old[i].shapes)) fbs.add(p);
+        }
+        c->fb[s] = fbs.finish(*c);
+    }
+    c->pred_index.push_back(0);
+    return PDMPC_OK;
+}
+
+// records of the step in slot order -> plans, exhaustion handling, fallbacks of coupled vehicles, plant update
+int pdmpc_controller_apply(pdmpc_controller* c, const pdmpc_vehicle_out* recs) {
+    if (!c || !recs) return cfail(c, PDMPC_ERR_INVALID, "null argument");
+    const int n = c->n, Hp = c->Hp;
+    auto fallback_plan = [&](int i, Plan& p) -> bool {  // plan_fallback (:678-718)
+        const Plan& old = c->info_old[i];
+        if (!old.present) return false;
+        p.present = true;
+        p.shapes = del_first_rpt_last(old.shapes);
+        p.trims.assign(old.trims.begin() + 1, old.trims.end());
+        p.trims.push_back(old.trims.back());
+        p.yx.assign(old.yx.begin() + 1, old.yx.end());
+        p.yx.push_back(old.yx.back());
+        p.yy.assign(old.yy.begin() + 1, old.yy.end());
+        p.yy.push_back(old.yy.back());
+        p.yyaw.assign(old.yyaw.begin() + 1, old.yyaw.end());
+        p.yyaw.push_back(old.yyaw.back());
+        return true;
+    };
+    for (int s = 0; s < n; ++s) {
+        const int i = c->order[s];
+        const pdmpc_vehicle_out& r = recs[s];
+        Plan p;
+        if (r.status != PDMPC_OK && r.status != PDMPC_EXHAUSTED) return cfail(c, PDMPC_ERR_HIP, "a result record carries an error status: not a planning result");
+        p.n_expanded = r.n_expanded;
+        if (r.status == PDMPC_OK) {
+            p.present = true;
+            for (int q = 0; q < Hp; ++q) {
+                Poly sh;
+                sh.x.assign(r.shapes[q][0], r.shapes[q][0] + r.shape_cols[q]);
+                sh.y.assign(r.shapes[q][1], r.shapes[q][1] + r.shape_cols[q]);
+                p.shapes.push_back(std::move(sh));
+                p.trims.push_back(r.predicted_trims[q]);
+                p.yx.push_back(r.y_predicted[q][0]);
+                p.yy.push_back(r.y_predicted[q][1]);
+                p.yyaw.push_back(r.y_predicted[q][2]);
+            }
+        } else {  // PrioritizedController.m:344-352
+            p.exhausted = true;
+            const bool standstill = c->trim_speed[c->trims[i] - 1] == 0;
+            if (standstill && c->cfg.constraint_from_successor != PDMPC_SUCCESSOR_NONE) {  // handle_graph_search_exhaustion (:568-616)
+                p.present = true;
+                for (int q = 0; q < Hp; ++q) {
+                    p.shapes.push_back(c->occ_plain[i]);
+                    p.trims.push_back(c->trims[i]);
+                    p.yx.push_back(c->mx[i]);
+                    p.yy.push_back(c->my[i]);
+                    p.yyaw.push_back(c->myaw[i]);
+                }
+            } else {
+                if (!fallback_plan(i, p)) return cfail(c, PDMPC_ERR_INVALID, "a vehicle needs a fallback in its first step");
+                p.needs_fallback = true;
+            }
+        }
+        c->infos[i] = std::move(p);
+    }
+    // handle_others_fallback / check_others_fallback
+    bool any = false;
+    for (int i = 0; i < n; ++i) any = any || c->infos[i].needs_fallback;
+    if (any) {
+        std::vector<int> fm((size_t)n * n, 0);
+        for (int a = 0; a < n; ++a)
+            for (int b = 0; b < n; ++b) {
+                int v = at(c->adjacency, n, a, b);
+                if (c->infos[a].needs_fallback && at(c->directed_seq, n, a, b)) v -= 1;
+                if (c->infos[b].needs_fallback && at(c->directed_seq, n, b, a)) v -= 1;
+                fm[(size_t)a * n + b] = v;
+            }
+        std::vector<uint8_t> reached(n, 0);
+        for (int f = 0; f < n; ++f) {
+            if (!c->infos[f].needs_fallback) continue;
+            std::vector<uint8_t> seen(n, 0);
+            std::vector<int> stack{f};
+            seen[f] = 1;
+            while (!stack.empty()) {
+                const int a = stack.back();
+                stack.pop_back();
+                for (int b = 0; b < n; ++b)
+                    if (fm[(size_t)a * n + b] != 0 && !seen[b]) {
+                        seen[b] = 1;
+                        stack.push_back(b);
+                    }
+            }
+            for (int v = 0; v < n; ++v) reached[v] |= seen[v];
+        }
+        for (int i = 0; i < n; ++i)
+            if (reached[i] && !c->infos[i].needs_fallback) {
+                Plan p;
+                p.n_expanded = c->infos[i].n_expanded;
+                p.exhausted = c->infos[i].exhausted;
+                if (!fallback_plan(i, p)) return cfail(c, PDMPC_ERR_INVALID, "a vehicle needs a fallback in its first step");
+                p.needs_fallback = false;  // plan_fallback(is_fallback_while_planning = false)
+                c->infos[i] = std::move(p);
+            }
+    }
+    // Simulation.apply (Simulation.m:86-100)
+    for (int i = 0; i < n; ++i) {
+        const Plan& p = c->infos[i];
+        c->mx[i] = p.yx[0];
+        c->my[i] = p.yy[0];
+        c->myaw[i] = p.yyaw[0];
+        c->mspeed[i] = c->trim_speed[p.trims[0] - 1];
+        c->msteer[i] = c->trim_steering[p.trims[0] - 1];
+    }
+    c->info_old = c->infos;
+    return PDMPC_OK;
+}
+
+// One pass of HighLevelController.main_control_loop (:334-373) in simulation: build, plan on the GPU (one launch), apply.
+int pdmpc_controller_step(pdmpc_controller* c) {
+    if (!c || !c->h) return cfail(c, PDMPC_ERR_INVALID, "controller has no backend handle");
+    int rc = pdmpc_controller_build_step(c);
+    if (rc) return rc;
+    c->out.resize(c->n);
+    rc = pdmpc_plan_step(c->h, c->n, c->in.data(), c->pred_offset.data(), c->pred_index.data(), c->fb.data(), c->out.data());
+    if (rc) return cfail(c, rc, pdmpc_last_error());
+    return pdmpc_controller_apply(c, c->out.data());
+}
+
+// n_steps closed-loop time steps in one call; ms[i] (may be NULL) receives the wall time of step i: build + pack + launch +
+// fetch + apply, everything a caller of the boundary pays per MPC step
+int pdmpc_controller_run(pdmpc_controller* c, int32_t n_steps, double* ms) {
+    for (int i = 0; i < n_steps; ++i) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = pdmpc_controller_step(c);
+        if (rc) return rc;
+        if (ms) ms[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return PDMPC_OK;
+}
+
+int pdmpc_controller_problem(pdmpc_controller* c, int32_t* n, const pdmpc_vehicle_in** in, const int32_t** pred_offset, const int32_t** pred_index,
+                             const pdmpc_polygon_set** fallback, const int32_t** order, const int32_t** levels) {
+    if (!c) return cfail(nullptr, PDMPC_ERR_INVALID, "null controller");
+    if (n) *n = c->n;
+    if (in) *in = c->in.data();
+    if (pred_offset) *pred_offset = c->pred_offset.data();
+    if (pred_index) *pred_index = c->pred_index.data();
+    if (fallback) *fallback = c->fb.data();
+    if (order) *order = c->order.data();
+    if (levels) *levels = c->levels.data();
+    return PDMPC_OK;
+}
+
+int pdmpc_controller_state(pdmpc_controller* c, double* x, double* y, double* yaw, double* speed, double* steering, int32_t* needs_fallback, int32_t* time_step) {
+    if (!c) return cfail(nullptr, PDMPC_ERR_INVALID, "null controller");
+    for (int i = 0; i < c->n; ++i) {
+        if (x) x[i] = c->mx[i];
+        if (y) y[i] = c->my[i];
+        if (yaw) yaw[i] = c->myaw[i];
+        if (speed) speed[i] = c->mspeed[i];
+        if (steering) steering[i] = c->msteer[i];
+        if (needs_fallback) needs_fallback[i] = c->info_old[i].present && c->info_old[i].needs_fallback;
+    }
+    if (time_step) *time_step = c->k;
+    return PDMPC_OK;
+}
+
+const pdmpc_vehicle_out* pdmpc_controller_records(pdmpc_controller* c) { return c && !c->out.empty() ? c->out.data() : nullptr; }
+
+}  // extern "C"

@@ -48,6 +48,16 @@ EXPORTS = [
     "pdmpc_debug_raw_tree",
     "pdmpc_debug_edge_check",
     "pdmpc_debug_progress",
+    "pdmpc_controller_create",
+    "pdmpc_controller_destroy",
+    "pdmpc_controller_step",
+    "pdmpc_controller_run",
+    "pdmpc_controller_build_step",
+    "pdmpc_controller_apply",
+    "pdmpc_controller_problem",
+    "pdmpc_controller_state",
+    "pdmpc_controller_records",
+    "pdmpc_controller_last_error",
     "pdmpc_last_error",
     "pdmpc_version",
 ]
@@ -110,6 +120,8 @@ def load_library(path=None):
     L.pdmpc_last_error.restype = C.c_char_p
     L.pdmpc_version.restype = C.c_char_p
     for name in EXPORTS:
+        if name.startswith("pdmpc_controller_"):
+            continue  # declared by pdmpc.native_controller
         if name not in ("pdmpc_last_error", "pdmpc_version"):
             getattr(L, name).restype = C.c_int
     if path is None:
