@@ -616,7 +616,8 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     HIPCHK(hipEventRecord(ev.first, h->stream));
     h->last_launch_frontier = frontier;
     int lrc = 0;
-    if (frontier && !h->two_per_cu && count > h->n_cu) {
+    const bool slice = !(getenv("PDMPC_FR_SLICE") && atoi(getenv("PDMPC_FR_SLICE")) == 0);  // A/B switch
+    if (frontier && !h->two_per_cu && count > h->n_cu && slice) {
         // More workgroups than the chip holds at one per CU (the obstacle soup was too large for the two-per-CU layout): a
         // workgroup that waits for a predecessor must never keep that predecessor off the chip, so the batch goes in slices
         // that are resident as a whole.  Slots are in level order: a slice's predecessors are in it or in an earlier slice.

@@ -43,7 +43,6 @@
 #define FR_NEAR_N 36
 #define FR_FAR_N 37
 #define FR_FLAGS 38     // FRF_*
-#define FR_LOCK 39      // guards FR_BEST_*
 #define FR_BEST_ID 40   // best goal candidate so far (1-based node, 0 = none)
 #define FR_SEL_BIN 41   // result of fr_select: bin ...
 #define FR_SEL_CUM 42   // ... and the number of entries up to and including it
@@ -59,6 +58,10 @@
 #define FR_L_FAR 58     // (64 bit) children with key > this go to far
 #define FR_PATH_FOR 61  // the goal candidate whose path is in the relevance tables (0: none)
 #define FR_EVER_INVAL 63 // set once a late arrival has invalidated a node of this search
+#define FR_SLOWEST 30   // (64 bit, words 30-31 of the serial block: unused by both searches) debugging: slowest node
+#define FR_GOAL_N 39     // goal candidates of the running round (entries of goal_list)
+#define FR_ROUND_B1 28   // (64 bit, words 28-29 of the serial block: unused by both searches) smallest path maximum among them
+#define FR_GOAL_CAP 1024
 #define FR_DEAD 57      // open entries dropped because an ancestor was invalidated
 #define FR_DROPPED 62   // open entries dropped because they come after the best candidate (restored if that one is invalidated)
 #define FRF_OVERFLOW 1u
@@ -137,6 +140,7 @@ struct Frontier {
     volatile lds_u32* sh;
     lds_u32* ready;  // [FR_READY_CAP] 1-based nodes of the running round (0 = not written yet)
     lds_u32* hist;   // [FR_NBINS]
+    lds_u32* goal_list;  // [FR_GOAL_CAP] goal candidates of the running round (lives in the histogram's first half: free during a round)
     double* near_key;
     uint32_t* near_id;
     double* far_key;
@@ -328,39 +332,96 @@ __device__ int fr_before(const Search& S, const double* gkey, uint32_t x, uint32
     return mx < my ? -1 : (my < mx ? 1 : 0);
 }
 
-// A valid node at the horizon has been found: keep it if it comes before the best one so far.  Whole wave calls, uniform.
+// A valid node at the horizon has been found.  If its ancestors are all collision-free it becomes a goal candidate: the
+// largest key of its path goes into its record (the cos / sin slot, which a node at the horizon never needs) and its id into
+// the round's candidate list; the best candidate is chosen at the round boundary (fr_resolve_goals) — no lock, nothing a
+// wavefront could wait for while it processes a node.  Whole wave calls, uniform.
 __device__ void fr_offer_goal(const Frontier& F, const Search& S, const VState& VS, uint32_t x, int lane) {
     double b1;
-    if (!fr_goal_path(S, VS, F.gkey, x, b1)) return;
-    for (;;) {  // (every lane tries — at most one can win — and the wave proceeds when one did: no lane-0-only branch, see sh_add_uniform)
-        uint32_t expect = 0u;
-        const bool won = __hip_atomic_compare_exchange_strong((lds_u32*)(F.sh + FR_LOCK), &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (__ballot(won)) break;
-        __builtin_amdgcn_s_sleep(1);
+    const bool alive = fr_goal_path(S, VS, F.gkey, x, b1);
+    if (lane == 0 && alive) node_store_cs(S, x - 1u, b1, 0.0);
+    const uint32_t pos = sh_add_uniform(F.sh, FR_GOAL_N, alive ? 1u : 0u, lane);
+    if (lane == 0 && alive && pos < (uint32_t)FR_GOAL_CAP) F.goal_list[pos] = x;
+}
+
+// Round boundary: the best of the round's goal candidates against the best one so far.  The reference pops the candidate
+// with the smallest path maximum first; equal maxima mean the same bottleneck node, and the order is decided below it
+// (fr_before).  Every thread calls (barriers inside).
+__device__ void fr_resolve_goals(const Frontier& F, const Search& S, int tid, int lane, int wave) {
+    volatile lds_u32* sh = F.sh;
+    uint32_t n = sh[FR_GOAL_N];
+    n = n < (uint32_t)FR_GOAL_CAP ? n : (uint32_t)FR_GOAL_CAP;
+    if (n == 0u) return;  // (uniform)
+    const double inf = __longlong_as_double(0x7FF0000000000000LL);
+    if (tid == 0) sh_st_d(sh, FR_ROUND_B1, inf);
+    __syncthreads();
+    double b1 = inf;
+    uint32_t id = 0;
+    if ((uint32_t)tid < n) {
+        id = F.goal_list[tid];
+        const d2 v = (id - 1u) < S.NL ? (d2)S.ln[4 * (size_t)(id - 1u) + 2] : ((const d2*)(S.gn + (id - 1u)))[2];
+        b1 = v.x;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    const uint32_t best = uni_u(F.sh[FR_BEST_ID]);
-    bool take = false;
-    if (!best) {
-        take = true;
-    } else {
-        const double bb = sh_ld_d(F.sh, FR_BEST_B1);
-        if (b1 < bb) {
-            take = true;
-        } else if (b1 == bb) {  // same bottleneck node (keys are distinct): the order is decided below it
-            const int r = fr_before(S, F.gkey, x, best);
-            if (r < 0) take = true;
-            if (r == 0 && lane == 0) atomicOr((uint32_t*)&F.sh[FR_FLAGS], FRF_TIE);
+    for (uint32_t e = (uint32_t)tid + blockDim.x; e < n; e += blockDim.x) {  // (more candidates than threads: keep this thread's best)
+        const uint32_t id2 = F.goal_list[e];
+        const d2 v = (id2 - 1u) < S.NL ? (d2)S.ln[4 * (size_t)(id2 - 1u) + 2] : ((const d2*)(S.gn + (id2 - 1u)))[2];
+        if (v.x < b1) {
+            b1 = v.x;
+            id = id2;
         }
     }
-    if (lane == 0) {
-        if (take) {
-            F.sh[FR_BEST_ID] = x;
-            sh_st_d(F.sh, FR_BEST_B1, b1);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        F.sh[FR_LOCK] = 0u;
+    if (id) sh_min_d(sh, FR_ROUND_B1, b1);
+    __syncthreads();
+    const double rb = sh_ld_d(sh, FR_ROUND_B1);
+    // the candidates that share the smallest maximum go to the front of the list (usually one)
+    __syncthreads();
+    if (tid == 0) sh[FR_GOAL_N] = 0;
+    __syncthreads();
+    uint32_t mine[2] = {0, 0};
+    int nm = 0;
+    for (uint32_t e = (uint32_t)tid; e < n; e += blockDim.x) {
+        const uint32_t id2 = F.goal_list[e];
+        const d2 v = (id2 - 1u) < S.NL ? (d2)S.ln[4 * (size_t)(id2 - 1u) + 2] : ((const d2*)(S.gn + (id2 - 1u)))[2];
+        if (v.x == rb && nm < 2) mine[nm++] = id2;
     }
+    __syncthreads();  // (everybody has read the list)
+    for (int q = 0; q < 2; ++q) {
+        const bool have = q < nm;
+        const unsigned long long bm = __ballot(have);
+        if (bm) {
+            const uint32_t base = sh_add_uniform(sh, FR_GOAL_N, (uint32_t)__builtin_popcountll(bm), lane);
+            if (have) F.goal_list[base + lane_rank(bm, lane)] = mine[q];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {  // uniform scalar code over the (few) finalists
+        const uint32_t nf = sh[FR_GOAL_N];
+        uint32_t best = sh[FR_BEST_ID];
+        double bb = best ? sh_ld_d(sh, FR_BEST_B1) : inf;
+        bool tie = false;
+        for (uint32_t q = 0; q < nf; ++q) {
+            const uint32_t x = uni_u(F.goal_list[q]);
+            bool take = false;
+            if (!best || rb < bb) {
+                take = true;
+            } else if (rb == bb) {
+                const int r = fr_before(S, F.gkey, x, best);
+                take = r < 0;
+                tie = tie || r == 0;
+            }
+            if (take) {
+                best = x;
+                bb = rb;
+            }
+        }
+        if (lane == 0) {
+            sh[FR_BEST_ID] = best;
+            sh_st_d(sh, FR_BEST_B1, bb);
+            sh[FR_GOAL_N] = 0;
+            if (tie) sh[FR_FLAGS] = sh[FR_FLAGS] | FRF_TIE;
+        }
+    }
+    __syncthreads();
 }
 
 // Children of one expansion join the open set: near or far by key.  (They never join the running round: the reference pops
@@ -645,6 +706,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
     F.sh = sh;
     F.ready = (lds_u32*)(X.lsm + A.lds.heap_key);
     F.hist = F.ready + 2048;
+    F.goal_list = F.hist;
     lds_u32* gp_path = F.ready + FR_READY_CAP;            // [HP_MAX + 1] path of the best goal candidate (relevance test)
     lds_f64* gp_mp = (lds_f64*)(F.ready + FR_READY_CAP + 32);  // [HP_MAX + 1] largest key of that path below depth d
     F.near_key = A.arena.near_key + voff;
@@ -732,12 +794,18 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
             const uint32_t t = sh_add_uniform(sh, FR_RD_HEAD, 1u, lane);
             if (t >= uni_u(sh[FR_RD_TAIL])) break;
             const uint32_t cur = uni_u(F.ready[t]);
+            const unsigned long long tp0 = __builtin_amdgcn_s_memrealtime();
             fr_process<CHECKER, NW>(A, X, F, EE, cur);
+            if (A.debug_tail && lane == 0) {  // the slowest single node of this search (ticks << 32 | node)
+                const unsigned long long dtp = __builtin_amdgcn_s_memrealtime() - tp0;
+                __hip_atomic_fetch_max((lds_u64s*)(sh + FR_SLOWEST), (dtp << 32) | cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             (void)sh_add_uniform(sh, FR_PROCESSED, 1u, lane);
         }
         __syncthreads();
         FR_TICK(tk_work)
         FR_PROGRESS(1)
+        fr_resolve_goals(F, S, tid, lane, wave);
 
         // ================= round boundary (every thread; decisions are uniform) =====================================
         uint32_t flags = sh[FR_FLAGS];
@@ -801,7 +869,8 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
             }
             __syncthreads();
             if (flags & FRF_INVALIDATED) {
-                for (uint32_t b = (uint32_t)wave * PDMPC_WAVE; b < nn; b += blockDim.x) {
+                for (uint32_t base = 0; base < nn; base += blockDim.x) {  // (uniform trip count: barriers inside)
+                    const uint32_t b = base + (uint32_t)wave * PDMPC_WAVE;
                     const uint32_t i0 = b + (uint32_t)lane;
                     const bool in = i0 < nn;
                     const uint32_t j0 = in ? i0 : 0u;  // (straight-line code: every lane loads something valid)
@@ -816,6 +885,8 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                         bc &= bc - 1;
                         fr_offer_goal(F, S, VS, b + (uint32_t)l + 1u, lane);
                     }
+                    __syncthreads();  // at most blockDim candidates per pass: the list cannot overflow
+                    fr_resolve_goals(F, S, tid, lane, wave);
                 }
                 __syncthreads();
             }
@@ -1067,6 +1138,9 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
         X.O->path_nodes[PDMPC_HP_MAX - 1][2] = (double)tk_select;
         X.O->path_nodes[PDMPC_HP_MAX - 1][3] = (double)tk_wait;
         X.O->path_nodes[PDMPC_HP_MAX - 1][4] = (double)(tk_mark - tk_start);
+        const unsigned long long slow = *(volatile lds_u64s*)(sh + FR_SLOWEST);
+        X.O->path_nodes[PDMPC_HP_MAX - 1][5] = (double)(slow >> 32);
+        X.O->path_nodes[PDMPC_HP_MAX - 1][6] = (double)(slow & 0xffffffffull);
     }
     X.status = status;
     X.n_popped = (int)R.n_popped;
