@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--max-nodes", type=int, default=0, help="initial per-vehicle arena (0: 1<<17 for c2, 1<<16 otherwise); grows while recording if a search needs more")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-inclusive", action="store_true", help="skip the native closed loop behind `value_host_inclusive` (profiling runs: the timed replay is then the last thing launched)")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--priorities", default=None, choices=["constant", "coloring", "random", "fca"],
                     help="priority strategy of the host driver: vehicle index (ConstantPrioritizer.m), graph colouring "
@@ -275,7 +276,7 @@ def main():
     # scenario, every step = build the step problem on the host + pack (H2D) + one launch + fetch (D2H) + apply, no replay and
     # no interpreter on the path.  Reported next to `value`, never as `value`.
     host_inclusive = None
-    if not explore and dist is None:
+    if not explore and dist is None and not args.no_host_inclusive:
         from pdmpc.native_controller import NativeController
         from pdmpc.road_network import commonroad_scenario
 
@@ -295,7 +296,7 @@ def main():
         nat.close()
     if rank == 0:
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json" if args.workload == "c2" else "none")
         if os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
@@ -340,12 +341,12 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "kernel": "pdmpc_search_kernel",
+                "kernel": "pdmpc_frontier_kernel" if st["kernel"] == 1 else "pdmpc_search_kernel",
                 "kernel_ms_avg": kernel_ms / max(n_launch, 1),
                 "algorithmic_bytes_per_launch": alg_bytes / max(n_launch, 1),
                 "launches": n_launch,
                 "lds_bytes_per_workgroup": lds_bytes,
-                "open_list": "block-min queue, %d keys in LDS" % st["queue_ring_entries"] if st["queue_mode"] == 1 else "binary heap",
+                "open_list": "unordered near / far lists, rounds of the smallest keys (frontier kernel)" if st["kernel"] == 1 else ("block-min queue, %d keys in LDS" % st["queue_ring_entries"] if st["queue_mode"] == 1 else "binary heap"),
             },
             # every plan of the recorded steps by outcome; arena_overflow must be 0 (the reference's tree is unbounded, Tree.m:54-70)
             "status_counts": status_counts,
@@ -359,6 +360,8 @@ def main():
                 "speculation_arrivals_per_step": st["speculation_arrivals"] / args.steps,
                 "speculation_restarts_per_step": st["speculation_restarts"] / args.steps,
                 "speculation_wasted_pops_per_step": st["speculation_wasted_pops"] / args.steps,
+                "nodes_processed_per_step": st["nodes_processed"] / args.steps,  # frontier kernel: edges evaluated; nodes_popped of them are the reference's pops
+                "rounds_per_step": st["rounds"] / args.steps,
                 "entries_dropped_per_step": st["entries_dropped"] / args.steps,
                 "dropped_counted_as_pops_per_step": st["dropped_counted_as_pops"] / args.steps,
                 "queue_fallbacks_per_step": st["queue_fallbacks"] / args.steps,

@@ -72,17 +72,6 @@
 #define FR_NBINS 2048
 #define FR_READY_CAP 1024
 
-#ifdef PDMPC_FR_PRINTF
-#define FR_LOG(...) printf(__VA_ARGS__)
-#else
-#define FR_LOG(...)
-#endif
-
-// per-wave position (code << 24 | detail) in words 16..31 of the slot's progress block
-#define FR_POS(code, detail)                                                                                                        \
-    if (A.progress && (threadIdx.x & 63) == 0)                                                                                      \
-        ((volatile uint32_t*)A.progress)[(size_t)(A.first + blockIdx.x) * 64 + 16 + (threadIdx.x >> 6)] = ((uint32_t)(code) << 24) | ((uint32_t)(detail) & 0xffffffu);
-
 namespace {
 
 typedef LDS_AS unsigned long long lds_u64s;

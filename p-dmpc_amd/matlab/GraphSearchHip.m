@@ -51,7 +51,16 @@ classdef GraphSearchHip < OptimizerInterface
                 iter.hdv_reachable_sets(find(iter.hdv_adjacency), :)); %#ok<FNDSB>
 
             info.n_expanded = out.n_expanded;
-            info.is_exhausted = out.status ~= 0; % PDMPC_EXHAUSTED / PDMPC_ARENA_OVERFLOW
+            % Only an empty open list is an exhaustion (GraphSearch.m:57-61).  pdmpc_plan_batch re-plans with doubled arenas
+            % when a search outgrows its arena, so PDMPC_ARENA_OVERFLOW (2) only comes back when HBM (or the limit set with
+            % pdmpc_set_arena_limit) is used up; the reference's tree is unbounded (Tree.m:54-70) and would have kept searching,
+            % so that is an error of this backend, not a planner fallback.  Negative values are device-side errors.
+            if out.status == 2
+                error('GraphSearchHip:arena', 'search tree outgrew the arena and could not be grown (status PDMPC_ARENA_OVERFLOW)');
+            elseif out.status < 0
+                error('GraphSearchHip:backend', 'pdmpc_plan_batch reported status %d in the result record', out.status);
+            end
+            info.is_exhausted = out.status == 1; % PDMPC_EXHAUSTED
 
             if info.is_exhausted
                 return % y_predicted stays NaN (ControlResultsInfo.m:40); the caller decides on the fallback

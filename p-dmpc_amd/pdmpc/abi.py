@@ -123,6 +123,9 @@ class Stats(C.Structure):
         ("speculation_wasted_pops", C.c_int64),
         ("entries_dropped", C.c_int64),
         ("dropped_counted_as_pops", C.c_int64),
+        ("kernel", C.c_int64),
+        ("nodes_processed", C.c_int64),
+        ("rounds", C.c_int64),
     ]
 
 

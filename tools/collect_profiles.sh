@@ -5,7 +5,7 @@ set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof
 rm -rf $OUT && mkdir -p $OUT
-ARGS="--steps ${STEPS:-100} --warmup ${WARMUP:-10} --no-cpu-baseline"
+ARGS="--steps ${STEPS:-200} --warmup ${WARMUP:-20} --no-cpu-baseline --no-host-inclusive"
 python bench.py $ARGS > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py $ARGS > $OUT/bench_stats.json 2> $OUT/stats.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.err

@@ -8,7 +8,10 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+KERNEL = "pdmpc_frontier"  # the kernel the default bench launches (search_kernel.hip's pdmpc_search_* only with PDMPC_KERNEL=serial)
+TIMED = int(sys.argv[2]) if len(sys.argv) > 2 else 200  # launches of the timed region ...
+TAIL = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # ... followed by this many launches (the native closed loop of `host_inclusive`, steps + skip)
 DST = os.path.join(ROOT, "profiles")
 os.makedirs(DST, exist_ok=True)
 
@@ -25,14 +28,14 @@ if ks:
     with open(os.path.join(DST, "%s_kernel_stats.csv" % tag), "w") as f:
         f.write(open(ks).read())
     for r in rows:
-        if "pdmpc_search" in r["Name"]:
+        if KERNEL in r["Name"]:
             summary["kernel_stats"] = {k: r[k] for k in r}
 kt = find("stats/**/*kernel_trace.csv")
 if kt:
-    rows = [r for r in csv.DictReader(open(kt)) if "pdmpc_search" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(kt)) if KERNEL in r["Kernel_Name"]]
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
     if d:
-        timed = d[-200:] if len(d) >= 200 else d
+        timed = d[len(d) - TAIL - TIMED : len(d) - TAIL] if len(d) >= TIMED + TAIL else d
         summary["kernel_trace"] = {"launches": len(d), "avg_ms": sum(d) / len(d), "min_ms": min(d), "max_ms": max(d),
                                    "timed_region_launches": len(timed), "timed_region_avg_ms": sum(timed) / len(timed),
                                    "lds_block_size": rows[0].get("LDS_Block_Size"), "vgpr": rows[0].get("VGPR_Count"), "sgpr": rows[0].get("SGPR_Count"),
@@ -42,18 +45,24 @@ for name in ("fetch", "write"):
     cc = find("%s/**/*counter_collection.csv" % name)
     if not cc:
         continue
-    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(cc)) if "pdmpc_search" in r["Kernel_Name"]]
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(cc)) if KERNEL in r["Kernel_Name"]]
     if vals:
-        traffic[name] = {"counter": name.upper() + "_SIZE", "unit": "KiB as reported", "per_launch_avg": sum(vals) / len(vals), "launches": len(vals)}
+        timed = vals[len(vals) - TAIL - TIMED : len(vals) - TAIL] if len(vals) >= TIMED + TAIL else vals  # the timed launches only (recording and warm-up launches come first)
+        traffic[name] = {"counter": name.upper() + "_SIZE", "unit": "KiB as reported", "per_launch_avg_timed": sum(timed) / len(timed), "launches_timed": len(timed),
+                         "per_launch_avg_all": sum(vals) / len(vals), "launches_all": len(vals)}
 if traffic:
-    # MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide
-    # coalesced reads -> doubled (upper bound for this kernel, whose reads are mostly 16 B/lane copies and 64 B records)
-    fetch = traffic.get("fetch", {}).get("per_launch_avg", 0.0) * 1024 * 2
-    write = traffic.get("write", {}).get("per_launch_avg", 0.0) * 1024
+    # MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE reports half the bytes of WIDE
+    # COALESCED STREAMING reads (16 B per lane).  This kernel's reads are node records fetched by all lanes of a wave at once
+    # (one 64-byte line per record) and 8-byte-per-lane list scans, not 16 B/lane streams, so the raw value is reported and the
+    # doubled one only as an upper bound.
+    fetch = traffic.get("fetch", {}).get("per_launch_avg_timed", 0.0) * 1024
+    write = traffic.get("write", {}).get("per_launch_avg_timed", 0.0) * 1024
     summary["traffic"] = traffic
     summary["hbm_bytes_per_launch"] = fetch + write
-    summary["hbm_bytes_note"] = "FETCH_SIZE*1024*2 (gfx950 correction) + WRITE_SIZE*1024, averaged over the launches of the profiled bench run"
-    json.dump({"hbm_bytes_per_launch": fetch + write, "source": "%s_summary.json" % tag}, open(os.path.join(DST, "pmc_traffic.json"), "w"))
+    summary["hbm_bytes_per_launch_upper_bound"] = 2 * fetch + write
+    summary["hbm_bytes_note"] = "FETCH_SIZE*1024 + WRITE_SIZE*1024 averaged over the timed launches; upper bound = FETCH_SIZE doubled (gfx950 wide-read correction, not applicable to this access pattern)"
+    json.dump({"hbm_bytes_per_launch": fetch + write, "hbm_bytes_per_launch_upper_bound": 2 * fetch + write, "source": "%s_summary.json" % tag, "launches": traffic.get("fetch", traffic.get("write"))["launches_timed"]},
+              open(os.path.join(DST, "%s_pmc_traffic.json" % tag), "w"))
 for name in ("plain", "stats"):
     p = os.path.join(SRC, "bench_%s.json" % name)
     if os.path.exists(p):
