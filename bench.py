@@ -65,7 +65,9 @@ def record_steps(options, mpa, ctl, optimizer, n_skip, n_record, explore_instanc
 
     def plan_step(prob):
         problems.append(prob)
-        return optimizer.run_optimizer_step(prob, mpa)
+        infos = optimizer.run_optimizer_step(prob, mpa)
+        prob["pops"] = [int(i.n_popped) for i in infos]  # the work each vehicle's search took (weights of the multi-GPU partition)
+        return infos
 
     batches = []
     for k in range(n_skip + n_record):
@@ -183,7 +185,8 @@ def main():
         from pdmpc.distributed import partition_components, sub_problem
 
         # every rank recorded the same closed loop; now it keeps only the components assigned to it
-        parts = [partition_components(p["preds"], world) for p in full_problems]
+        # longest-processing-time assignment by the work the searches took in the closed loop (pops + 1), not by vehicle count
+        parts = [partition_components(p["preds"], world, weights=[w + 1 for w in p["pops"]] if "pops" in p else None) for p in full_problems]
         problems = [sub_problem(p, parts[b][rank]) for b, p in enumerate(full_problems)]
     # keep every recorded step resident in HBM (one bank each) and collect its algorithmic bytes
     bytes_per_bank, pops_per_bank, nodes_per_bank = [], [], []
