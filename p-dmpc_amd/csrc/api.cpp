@@ -167,6 +167,7 @@ struct pdmpc_handle {
     int n_waves = PDMPC_WAVES_LATENCY;   // of the last layout
     int bm_kr = 0, bm_nb = 0;
     int two_per_cu = 0;   // the layout of the last launch leaves room for two workgroups per CU (80 KB each, dense build)
+    int fr_stage_cap = 0;
     int fr_cand_cap = 0;  // frontier kernel: 32-bit words of a wave's scratch (its candidate list)
     DevBuf<int32_t> d_trace;
     // batch blobs: several packed steps can stay resident side by side ("banks", pdmpc_select_bank)
@@ -189,7 +190,7 @@ namespace {
 // check = expansion scratch of 16 x HP_MAX cost terms + 16 child positions = 12 B per thread of phase B's chunk state),
 // d_traveled table, ready list + histogram (also where the binary heap of the tie fallback lives), validity bytes, nodes.
 bool layout_frontier(pdmpc_handle* h, size_t budget, int n_waves, int areas, int soup_cap, int cand_cap, LdsLayout& L, uint32_t& hl, uint32_t& nv, uint32_t& nl,
-                     uint32_t& wscr) {
+                     uint32_t& wscr, uint32_t& stage_cap) {
     uint32_t off = 0;
     L.mask = off;
     off = align16(off + (uint32_t)h->mask_bytes);
@@ -219,8 +220,15 @@ bool layout_frontier(pdmpc_handle* h, size_t budget, int n_waves, int areas, int
     hl = std::min((region / 12u) & ~3u, h->max_nodes & ~3u);
     L.heap_id = off + align16(hl * 8);
     off += region;
-    const uint32_t rest = (uint32_t)(budget - off - 256);
-    nv = std::min<uint32_t>(65536u, rest / 4 * 3);
+    // staged records of a round (node + parent, 128 B per entry): up to 256 entries where a CU has the LDS to itself
+    uint32_t rest = (uint32_t)(budget - off - 256);
+    stage_cap = (budget > kLdsMax / 2) ? 256u : 64u;
+    if (const char* e = getenv("PDMPC_FR_STAGE")) stage_cap = (uint32_t)std::max(0, std::min(1024, atoi(e)));  // tuning knob
+    while (stage_cap && stage_cap * 128u + min_nodes > rest) stage_cap /= 2u;
+    L.stage = off;
+    off += stage_cap * 128u;
+    rest -= stage_cap * 128u;
+    nv = std::min<uint32_t>(32768u, rest / 2);
     nv = std::min(nv, h->max_nodes) & ~15u;
     nl = std::min((rest - nv) / (uint32_t)sizeof(NodeRec), h->max_nodes);
     L.vstate = off;
@@ -246,11 +254,11 @@ int compute_lds_frontier(pdmpc_handle* h, int n_launch, int soup_cap, int cand_c
     tries.push_back({kLdsMax, h->waves_latency, 0, 0});
     for (const Try& t : tries) {
         LdsLayout L{};
-        uint32_t hl = 0, nv = 0, nl = 0, wscr = 0;
-        if (!layout_frontier(h, t.budget, t.waves, t.areas, soup_cap, cand_cap, L, hl, nv, nl, wscr)) continue;
+        uint32_t hl = 0, nv = 0, nl = 0, wscr = 0, stage_cap = 0;
+        if (!layout_frontier(h, t.budget, t.waves, t.areas, soup_cap, cand_cap, L, hl, nv, nl, wscr, stage_cap)) continue;
         if (getenv("PDMPC_DEBUG_LDS"))
-            fprintf(stderr, "pdmpc LDS layout (frontier): launch %d budget %zu waves %d areas %d wscr %u heap fallback %u nv %u nl %u total %u\n", n_launch, t.budget,
-                    t.waves, t.areas, wscr, hl, nv, nl, L.total);
+            fprintf(stderr, "pdmpc LDS layout (frontier): launch %d budget %zu waves %d areas %d wscr %u heap fallback %u stage %u nv %u nl %u total %u\n", n_launch, t.budget,
+                    t.waves, t.areas, wscr, hl, stage_cap, nv, nl, L.total);
         h->lds = L;
         h->n_waves = t.waves;
         h->HL = (int)hl;
@@ -260,6 +268,7 @@ int compute_lds_frontier(pdmpc_handle* h, int n_launch, int soup_cap, int cand_c
         h->bm_kr = 0;
         h->bm_nb = 64;
         h->fr_cand_cap = (int)(wscr / 4u);
+        h->fr_stage_cap = (int)stage_cap;
         h->two_per_cu = t.two_per_cu;
         return PDMPC_OK;
     }
@@ -573,6 +582,7 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.cand_cap = frontier ? h->fr_cand_cap : B.cand_cap;
     a.frontier = frontier ? 1 : 0;
     a.fr_round = h->fr_round > 0 ? h->fr_round : 256;  // measured on C2 / C5: 64 -> 214 / 196 steps/s, 128 -> 263 / 255, 256 -> 291 / 270
+    a.fr_stage_cap = h->fr_stage_cap;
     a.fr_ramp = 4;  // measured on C2 / C3 / C5: 2 -> 301 / 261 / 295 steps/s, 4 -> 304 / 261 / 295, 8 -> 295 / 251 / 275, 16 -> 268 / 232 / 237
     if (const char* e = getenv("PDMPC_FR_RAMP")) a.fr_ramp = std::max(1, atoi(e));  // tuning knob
     a.fr_near_fill = h->fr_near_fill;

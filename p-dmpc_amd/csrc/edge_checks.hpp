@@ -36,12 +36,15 @@ __device__ bool interx_check(const lds_d2* sh2, int V, const lds_d2* soup, int s
             const d2 q0 = soup[j], q1 = soup[j + 1];
             const double dx2 = q1.x - q0.x, dy2 = q1.y - q0.y;
             const double S2 = dx2 * q0.y - dy2 * q0.x;
+            // (unrolled over the most columns an area can have, so the LDS reads of the shape's points are issued together
+            // instead of one round trip per edge; columns beyond V are read but never used)
             d2 p = sh[0];
             double e0 = (p.y * dx2 - p.x * dy2) - S2;
-            for (int i = 0; i < V - 1; ++i) {
+#pragma unroll
+            for (int i = 0; i < PDMPC_VMAX - 1; ++i) {
                 p = sh[i + 1];
                 const double e1 = (p.y * dx2 - p.x * dy2) - S2;
-                if (e0 * e1 < 0) bits |= 1u << i;
+                if (i < V - 1 && e0 * e1 < 0) bits |= 1u << i;
                 e0 = e1;
             }
         }
@@ -234,14 +237,13 @@ struct CheckCtx {
 
 // eval_edge_exact (GraphSearch.m:111-196) for node `id` (1-based): true = collision-free.  A pure function of the
 // tree and the obstacle soups, which is what allows helper waves to evaluate it ahead of the pop.
+// (cn = the node's record, pn = its parent's; the same record in every lane)
 template <int CHECKER>
-__device__ bool edge_valid(const Search& S, const CheckCtx& C, uint32_t id, int lane) {
-    const NodeRec cn = node_load(S, id - 1);
+__device__ bool edge_valid_recs(const CheckCtx& C, const NodeRec& cn, const NodeRec& pn, int lane) {
     const uint32_t par = uni_u(cn.parent);
     if (!par) return true;  // root: no edge (GraphSearch.m:137-139)
     const uint32_t cpk = uni_u(cn.packed);
     const int cK = NODE_K(cpk);
-    const NodeRec pn = node_load(S, par - 1);
     const double pX = pn.x, pY = pn.y;
     const double c = pn.cs, s = pn.sn;  // cos/sin(pYaw), cached when the parent was expanded
     const int m = NODE_MAN(cpk);
@@ -285,4 +287,13 @@ __device__ bool edge_valid(const Search& S, const CheckCtx& C, uint32_t id, int 
     }
     wave_sync();
     return !hit;
+}
+
+template <int CHECKER>
+__device__ bool edge_valid(const Search& S, const CheckCtx& C, uint32_t id, int lane) {
+    const NodeRec cn = node_load(S, id - 1);
+    const uint32_t par = uni_u(cn.parent);
+    if (!par) return true;
+    const NodeRec pn = node_load(S, par - 1);
+    return edge_valid_recs<CHECKER>(C, cn, pn, lane);
 }

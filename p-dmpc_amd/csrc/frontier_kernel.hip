@@ -371,7 +371,12 @@ __device__ void fr_resolve_goals(const Frontier& F, const Search& S, int tid, in
     for (uint32_t e = (uint32_t)tid; e < n; e += blockDim.x) {
         const uint32_t id2 = F.goal_list[e];
         const d2 v = (id2 - 1u) < S.NL ? (d2)S.ln[4 * (size_t)(id2 - 1u) + 2] : ((const d2*)(S.gn + (id2 - 1u)))[2];
-        if (v.x == rb && nm < 2) mine[nm++] = id2;
+        if (v.x == rb) {
+            if (nm < 2)
+                mine[nm++] = id2;
+            else
+                atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_TIE);  // (more finalists than this thread can carry: let the exact search decide)
+        }
     }
     __syncthreads();  // (everybody has read the list)
     for (int q = 0; q < 2; ++q) {
@@ -445,17 +450,31 @@ __device__ __forceinline__ void fr_push_children(const Frontier& F, bool active,
 
 // One node of the round: eval_edge_exact (GraphSearch.m:111-196), the goal test (:81-90), expand_node.m.  Whole wave.
 template <int CHECKER, int NW>
-__device__ __forceinline__ void fr_process(const KernelArgs& A, Ctx& X, const Frontier& F, const ExpandEnv& EE, uint32_t cur) {
+__device__ __forceinline__ void fr_process(const KernelArgs& A, Ctx& X, const Frontier& F, const ExpandEnv& EE, uint32_t cur, const lds_d2* staged) {
     const int lane = X.lane, Hp = X.Hp;
     Search& S = X.S;
     const VState& VS = X.VS;
     const uint32_t c0 = cur - 1u;
-    const bool valid = edge_valid<CHECKER>(S, X.C, cur, lane);
+    // the node's record and its parent's: staged in LDS when the round was selected (one HBM latency per round instead of
+    // two dependent ones per node), else through L2
+    NodeBits cu, pu;
+    if (staged) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            cu.q[q] = staged[q];
+            pu.q[q] = staged[4 + q];
+        }
+    } else {
+        cu.r = node_load(S, c0);
+        const uint32_t par = uni_u(cu.r.parent);
+        pu.r = node_load(S, par ? par - 1u : 0u);
+    }
+    const NodeRec& cn = cu.r;  // same record in every lane
+    const bool valid = edge_valid_recs<CHECKER>(X.C, cn, pu.r, lane);
     if (!valid) {
         if (lane == 0) vs_store(VS, c0, VS_INVALID);
         return;
     }
-    const NodeRec cn = node_load(S, c0);  // same record in every lane
     const uint32_t cpk = uni_u(cn.packed);
     if (NODE_K(cpk) == Hp) {
         if (lane == 0) vs_store(VS, c0, VS_VALID);
@@ -486,8 +505,7 @@ __device__ __forceinline__ void fr_process(const KernelArgs& A, Ctx& X, const Fr
         (void)mask;
         (void)ccnt;
         if (active) F.gkey[i0] = f;
-        // records, keys and the parent's cos/sin must be visible before another wave can pick a child up
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        // (no fence here: nothing reads the children's records, keys or list entries before the barrier that ends the round)
         fr_push_children(F, active, i0, f, lane);
     });
 }
@@ -777,6 +795,8 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
             }
         }
     };
+    const lds_d2* stage = (const lds_d2*)(X.lsm + A.lds.stage);  // [2 * fr_stage_cap] records: node, parent
+    uint32_t n_staged = 0;  // ready entries 0 .. n_staged - 1 have their records staged
     for (;;) {
         // ================= a round: every wave takes nodes off the ready list until the list is empty =================
         for (;;) {
@@ -784,7 +804,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
             if (t >= uni_u(sh[FR_RD_TAIL])) break;
             const uint32_t cur = uni_u(F.ready[t]);
             const unsigned long long tp0 = __builtin_amdgcn_s_memrealtime();
-            fr_process<CHECKER, NW>(A, X, F, EE, cur);
+            fr_process<CHECKER, NW>(A, X, F, EE, cur, t < n_staged ? stage + 8 * (size_t)t : nullptr);
             if (A.debug_tail && lane == 0) {  // the slowest single node of this search (ticks << 32 | node)
                 const unsigned long long dtp = __builtin_amdgcn_s_memrealtime() - tp0;
                 __hip_atomic_fetch_max((lds_u64s*)(sh + FR_SLOWEST), (dtp << 32) | cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1082,6 +1102,24 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                 if (tl > (uint32_t)FR_READY_CAP) sh[FR_RD_TAIL] = FR_READY_CAP;
             }
             __syncthreads();
+            {
+                // stage the records of the round's first entries and of their parents: four threads per entry, one 16-byte
+                // piece each; the parent's index comes out of the node's own last piece
+                uint32_t tl = sh[FR_RD_TAIL];
+                n_staged = tl < (uint32_t)A.fr_stage_cap ? tl : (uint32_t)A.fr_stage_cap;
+                lds_d2* st = (lds_d2*)(X.lsm + A.lds.stage);
+                for (uint32_t w0 = (uint32_t)tid; w0 < n_staged * 4u; w0 += blockDim.x) {
+                    const uint32_t e = w0 >> 2, q = w0 & 3u;
+                    st[8 * (size_t)e + q] = ((const d2*)(S.gn + (F.ready[e] - 1u)))[q];
+                }
+                __syncthreads();
+                for (uint32_t w0 = (uint32_t)tid; w0 < n_staged * 4u; w0 += blockDim.x) {
+                    const uint32_t e = w0 >> 2, q = w0 & 3u;
+                    const uint32_t par = (uint32_t)((uint64_t)__double_as_longlong(st[8 * (size_t)e + 3].y) & 0xffffffffull);
+                    st[8 * (size_t)e + 4 + q] = ((const d2*)(S.gn + (par ? par - 1u : 0u)))[q];
+                }
+                __syncthreads();
+            }
             FR_TICK(tk_select)
         }
     }

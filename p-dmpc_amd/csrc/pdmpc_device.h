@@ -82,6 +82,7 @@ struct LdsLayout {
     uint32_t vstate;                       // uint8[NV]: validity cache (0 unknown, 1 valid, 2 invalid)
     uint32_t expand;                       // expansion scratch: dcum[16][16], term[16][16] doubles, child xy[16] double2
     uint32_t heap_key, heap_id;            // double[HL], uint32[HL]
+    uint32_t stage;                        // frontier kernel: NodeRec[2 * fr_stage_cap]: the records of a round's nodes and of their parents
     uint32_t nodes;                        // NodeRec[NL]
     uint32_t total;
 };
@@ -141,6 +142,7 @@ struct KernelArgs {
     int32_t debug_tail;    // 1: the frontier kernel leaves its round / node counters in the unused last row of pdmpc_vehicle_out.path_nodes
     int32_t frontier;      // 1: this launch runs the frontier kernel (frontier_kernel.hip), 0: the pop-ordered kernel (search_kernel.hip)
     int32_t fr_round;      // frontier kernel: open entries a round aims to take (about four per wavefront)
+    int32_t fr_stage_cap;  // ... entries of a round whose records (node + parent) are staged in LDS when the round is selected
     int32_t fr_ramp;       // ... a young search takes one entry per wavefront plus 1 / fr_ramp of the nodes processed so far
     int32_t fr_near_fill;  // ... entries a refill moves from far to near
     int32_t fr_near_max;   // ... size of near beyond which its tail is moved back to far
