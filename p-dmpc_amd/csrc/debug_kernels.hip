@@ -27,7 +27,6 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_edge_check_kernel
     LDS_AS unsigned char* lsm = (LDS_AS unsigned char*)smem;
     lds_d2* sh2 = (lds_d2*)lsm;                       // shape A in [0, VMAX), shape B (= A) in [VMAX, 2 VMAX)
     lds_d2* soup = sh2 + 2 * PDMPC_VMAX;              // the second operand
-    lds_u32* cand = (lds_u32*)(soup + DBG_MAX_B + 2);
     const int a0 = a_off[c], na = a_off[c + 1] - a0, b0 = b_off[c], nb = b_off[c + 1] - b0;
     for (int i = lane; i < na; i += PDMPC_WAVE) {
         d2 p;
@@ -45,7 +44,7 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_edge_check_kernel
     wave_sync();
     bool r = false;
     if (mode == 0)
-        r = interx_check(sh2, na, soup, 0, nb, 0, 0, 0, 0, cand, lane);
+        r = interx_check(sh2, na, soup, 0, nb, 0, 0, 0, 0, lane);
     else if (mode == 1)
         r = sat_pair_wave(sh2, na, soup, nb, lane);
     else

@@ -7,23 +7,23 @@
 // boundary-check shape B) are processed together.  hit(i, j) = C1(i, j) & C2(i, j) with
 //   C1 = (dx1_i*y2_j - dy1_i*x2_j - S1_i) * (dx1_i*y2_{j+1} - dy1_i*x2_{j+1} - S1_i) < 0
 //   C2 = (y1_i*dx2_j - x1_i*dy2_j - S2_j) * (y1_{i+1}*dx2_j - x1_{i+1}*dy2_j - S2_j) < 0     (strict; NaN -> false)
-// Pass 1 (one lane per obstacle segment j) evaluates C2 for every shape segment i and keeps a 7-bit mask; lanes with
-// a non-zero mask append (j, mask, shape) to a compact list.  Pass 2 evaluates C1 for the listed pairs only.
+// One lane per obstacle segment j: C2 for every shape segment i gives a 7-bit mask; a lane with a non-zero mask evaluates
+// C1 for those pairs right away.  The check ends with the first round of 64 segments that holds a hit (most edges of a
+// blocked search collide: they leave after one or two of the two or three rounds their soups make).
 // sh2 holds shape A in [0, VMAX) and shape B in [VMAX, 2*VMAX).
-__device__ bool interx_check(const lds_d2* sh2, int V, const lds_d2* soup, int so, int M_k, int ho, int Hk, int lo, int Ml, lds_u32* cand, int lane) {
+__device__ bool interx_check(const lds_d2* sh2, int V, const lds_d2* soup, int so, int M_k, int ho, int Hk, int lo, int Ml, int lane) {
     if (V < 2) return false;
-    // Pass 1 over the segments of all three soups as one index space: ceil(total / 64) rounds instead of one set of rounds
-    // per soup (the soups are short: ~60 obstacle points and ~30 boundary points make two rounds instead of two plus a
-    // nearly empty third; a lane picks its soup and the shape that goes with it).
+    // The segments of all three soups form one index space: ceil(total / 64) rounds instead of one set of rounds per soup
+    // (the soups are short: ~60 obstacle points and ~30 boundary points make two rounds instead of two plus a nearly empty
+    // third; a lane picks its soup and the shape that goes with it).
     const int n0 = M_k > 1 ? M_k - 1 : 0, n1 = Hk > 1 ? Hk - 1 : 0, n2 = Ml > 1 ? Ml - 1 : 0;
     const int T = n0 + n1 + n2;
-    int count = 0;
     for (int base = 0; base < T; base += PDMPC_WAVE) {
         const int t = base + lane;
-        uint32_t bits = 0;
-        int j = 0;
-        uint32_t shapeB = 0;
+        bool hit = false;
         if (t < T) {
+            int j;
+            uint32_t shapeB = 0;
             if (t < n0) {
                 j = so + t;
             } else if (t < n0 + n1) {
@@ -38,44 +38,28 @@ __device__ bool interx_check(const lds_d2* sh2, int V, const lds_d2* soup, int s
             const double S2 = dx2 * q0.y - dy2 * q0.x;
             // (unrolled over the most columns an area can have, so the LDS reads of the shape's points are issued together
             // instead of one round trip per edge; columns beyond V are read but never used)
-            d2 p = sh[0];
-            double e0 = (p.y * dx2 - p.x * dy2) - S2;
+            d2 pt[PDMPC_VMAX];
+#pragma unroll
+            for (int i = 0; i < PDMPC_VMAX; ++i) pt[i] = sh[i];
+            uint32_t bits = 0;
+            double e0 = (pt[0].y * dx2 - pt[0].x * dy2) - S2;
 #pragma unroll
             for (int i = 0; i < PDMPC_VMAX - 1; ++i) {
-                p = sh[i + 1];
-                const double e1 = (p.y * dx2 - p.x * dy2) - S2;
+                const double e1 = (pt[i + 1].y * dx2 - pt[i + 1].x * dy2) - S2;
                 if (i < V - 1 && e0 * e1 < 0) bits |= 1u << i;
                 e0 = e1;
             }
-        }
-        const unsigned long long b = __ballot(bits != 0);
-        if (b) {
             if (bits) {
-                const int pos = count + (int)__builtin_popcountll(b & ((1ull << lane) - 1ull));
-                cand[pos] = (uint32_t)j | (bits << 16) | (shapeB << 24);
-            }
-            count += (int)__builtin_popcountll(b);
-        }
-    }
-    if (count == 0) return false;
-    __builtin_amdgcn_wave_barrier();
-    for (int base = 0; base < count; base += PDMPC_WAVE) {
-        const int t = base + lane;
-        bool hit = false;
-        if (t < count) {
-            const uint32_t e = cand[t];
-            const int j = (int)(e & 0xffffu);
-            const uint32_t bits = (e >> 16) & 0xffu;
-            const lds_d2* sh = sh2 + (e >> 24) * PDMPC_VMAX;
-            const d2 q0 = soup[j], q1 = soup[j + 1];
-            for (int i = 0; i < V - 1; ++i) {
-                if ((bits >> i) & 1u) {
-                    const d2 p0 = sh[i], p1 = sh[i + 1];
-                    const double dx1 = p1.x - p0.x, dy1 = p1.y - p0.y;
-                    const double S1 = dx1 * p0.y - dy1 * p0.x;
-                    const double a0 = dx1 * q0.y - dy1 * q0.x;
-                    const double a1 = dx1 * q1.y - dy1 * q1.x;
-                    hit = hit || ((a0 - S1) * (a1 - S1) < 0);
+#pragma unroll
+                for (int i = 0; i < PDMPC_VMAX - 1; ++i) {
+                    if ((bits >> i) & 1u) {
+                        const d2 p0 = pt[i], p1 = pt[i + 1];
+                        const double dx1 = p1.x - p0.x, dy1 = p1.y - p0.y;
+                        const double S1 = dx1 * p0.y - dy1 * p0.x;
+                        const double a0 = dx1 * q0.y - dy1 * q0.x;
+                        const double a1 = dx1 * q1.y - dy1 * q1.x;
+                        hit = hit || ((a0 - S1) * (a1 - S1) < 0);
+                    }
                 }
             }
         }
@@ -278,7 +262,7 @@ __device__ bool edge_valid_recs(const CheckCtx& C, const NodeRec& cn, const Node
             C.tally[0] += 1;
             C.tally[1] += (unsigned long long)(ncols - 1) * (unsigned long long)((M_k > 1 ? M_k - 1 : 0) + (Hk > 1 ? Hk - 1 : 0) + (C.ll_len > 1 ? C.ll_len - 1 : 0));
         }
-        hit = interx_check(C.sh, ncols, C.l_soup, so, M_k, ho, Hk, C.ll_base, C.ll_len, C.cand, lane);
+        hit = interx_check(C.sh, ncols, C.l_soup, so, M_k, ho, Hk, C.ll_base, C.ll_len, lane);
     } else {
         // are_constraints_satisfied_sat.m:15-53
         if (lane == 0) C.tally[0] += 1;

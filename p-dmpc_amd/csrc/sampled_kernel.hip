@@ -245,7 +245,7 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_sampled_kernel(co
                     const int ho = uni_i(C.l_hoff[i_step - 1]);
                     const int Hk = uni_i(C.l_hoff[i_step]) - ho;
                     if (lane == 0) C.tally[1] += (unsigned long long)(ncols - 1) * (unsigned long long)((M_k > 1 ? M_k - 1 : 0) + (Hk > 1 ? Hk - 1 : 0) + (C.ll_len > 1 ? C.ll_len - 1 : 0));
-                    hit = interx_check(C.sh, ncols, C.l_soup, so, M_k, ho, Hk, C.ll_base, C.ll_len, C.cand, lane);
+                    hit = interx_check(C.sh, ncols, C.l_soup, so, M_k, ho, Hk, C.ll_base, C.ll_len, lane);
                 } else {
                     hit = sat_soup_wave(C.sh, ncols, C.l_soup + so, M_k, lane);
                     if (!hit) hit = sat_boundary_wave(C.sh + PDMPC_VMAX, ncols, C.l_soup + C.ll_base, C.ll_len, lane);

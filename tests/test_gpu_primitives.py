@@ -95,6 +95,43 @@ def test_interx_random_pairs(handle, special):
     assert 0.05 < want.mean() < 0.95  # both outcomes occur
 
 
+@pytest.mark.parametrize("special", [0, 2, 3, 4])
+def test_interx_large_soups(handle, special):
+    """Soups long enough (more than PDMPC_CULL_MIN segments) for the bounding-box cull in front of InterX pass 1: the cull is
+    exact, so the results equal the oracle's bit for bit, including obstacles that are collinear with a shape edge far away
+    (where rounding noise alone decides InterX.m:63-76)."""
+    from oracle import oracle
+
+    rng = np.random.default_rng(400 + special)
+    a, b = [], []
+    for _ in range(300):
+        s = _random_shape(rng, convex=False)
+        parts = []
+        n_poly = int(rng.integers(60, 140))
+        spread = rng.uniform(3.0, 12.0)
+        for q in range(n_poly):
+            poly = _random_shape(rng, convex=False) + rng.uniform(-spread, spread, (2, 1))
+            if special == 4 and q % 3 == 0:  # a copy of the shape pushed along one of its own edges: exactly collinear in real arithmetic
+                e = int(rng.integers(0, s.shape[1] - 1))
+                d = s[:, e + 1] - s[:, e]
+                poly = s + (d * rng.uniform(6.0, 30.0))[:, None]
+            parts += [poly, np.full((2, 1), np.nan)]
+        o = np.concatenate(parts, axis=1)[:, :1000]
+        if special == 2:
+            o[:, 0] = s[:, 1]
+            o[:, 1] = s[:, 2]
+        if special == 3:
+            s = np.round(s * 4) / 4
+            o = np.round(o * 4) / 4
+        assert o.shape[1] > 300
+        a.append(s)
+        b.append(o)
+    got = handle.edge_check(0, a, b)
+    want = np.array([oracle.interx(x, y) for x, y in zip(a, b)])
+    assert np.array_equal(got, want), np.flatnonzero(got != want)[:10]
+    assert 0.02 < want.mean() < 0.98
+
+
 @pytest.mark.parametrize("special", [0, 3])
 def test_intersect_sat_random_pairs(handle, special):
     from oracle import oracle
