@@ -157,7 +157,7 @@ struct pdmpc_handle {
     int sampled_n_random = 0;
     bool sampled_launch = false;
     int kernel_frontier = 1;  // 1: frontier kernel (all wavefronts work on open nodes side by side), 0: the pop-ordered kernel of round 1
-    int fr_round = 0, fr_near_fill = 1024, fr_near_max = 2048;
+    int fr_round = 0, fr_near_fill = 2048, fr_near_max = 4096;  // measured on C2 / C3 (round cap 768): 1024/2048 -> 358 / 345 steps/s, 2048/4096 -> 369 / 357, 4096/8192 -> 356 / 351
     bool last_launch_frontier = false;
     uint32_t* progress = nullptr;  // pinned, PDMPC_DEBUG_PROGRESS=1
     int queue_mode = PDMPC_QUEUE_BLOCKMIN;
@@ -581,9 +581,9 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.soup_cap = B.soup_cap;
     a.cand_cap = frontier ? h->fr_cand_cap : B.cand_cap;
     a.frontier = frontier ? 1 : 0;
-    a.fr_round = h->fr_round > 0 ? h->fr_round : 256;  // measured on C2 / C5: 64 -> 214 / 196 steps/s, 128 -> 263 / 255, 256 -> 291 / 270
+    a.fr_round = h->fr_round > 0 ? h->fr_round : 768;  // cap of a round; measured on C2 / C3 (with the early-exit InterX): 256 -> 342 / 322 steps/s, 512 -> 355 / 342, 768 -> 358 / 345, 1024 -> 358 / 345
     a.fr_stage_cap = h->fr_stage_cap;
-    a.fr_ramp = 4;  // measured on C2 / C3 / C5: 2 -> 301 / 261 / 295 steps/s, 4 -> 304 / 261 / 295, 8 -> 295 / 251 / 275, 16 -> 268 / 232 / 237
+    a.fr_ramp = 4;  // a round grows by a quarter of the nodes done so far; measured on C2 / C3 (cap 768): 2 -> 331 / 354 steps/s, 3 -> 354 / 352, 4 -> 358 / 345, 6 -> 355 / 338
     if (const char* e = getenv("PDMPC_FR_RAMP")) a.fr_ramp = std::max(1, atoi(e));  // tuning knob
     a.fr_near_fill = h->fr_near_fill;
     a.fr_near_max = h->fr_near_max;
