@@ -103,6 +103,20 @@ __device__ __forceinline__ void sh_min_d(volatile lds_u32* sh, int w, double v) 
 __device__ __forceinline__ void sh_max_d(volatile lds_u32* sh, int w, double v) {
     __hip_atomic_fetch_max((lds_u64s*)(sh + w), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// Smallest / largest key a wave has met (mn = +inf, mx = 0 where a lane met none) folded into two shared words with one
+// atomic each: sixty-four lanes doing the same-address LDS atomic themselves are served one after the other.  Whole wave calls.
+__device__ __forceinline__ void sh_minmax_wave(volatile lds_u32* sh, int wmin, int wmax, double mn, double mx, int lane) {
+#pragma unroll
+    for (int o = PDMPC_WAVE / 2; o > 0; o >>= 1) {
+        const double a = __shfl_xor(mn, o), c = __shfl_xor(mx, o);
+        mn = a < mn ? a : mn;
+        mx = c > mx ? c : mx;
+    }
+    if (lane == 0) {
+        sh_min_d(sh, wmin, mn);
+        sh_max_d(sh, wmax, mx);
+    }
+}
 __device__ __forceinline__ uint32_t sh_add(volatile lds_u32* sh, int w, uint32_t v) {
     return __hip_atomic_fetch_add((lds_u32*)(sh + w), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -781,7 +795,8 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
         acc += now__ - tk_mark;                                            \
         tk_mark = now__;                                                   \
     }
-    // appends (k, i) of the lanes with `take` to far (whole wave calls)
+    // appends (k, i) of the lanes with `take` to far (whole wave calls); the keys' range is folded into FR_FAR_MIN/MAX by flush_far
+    double far_mn = inf, far_mx = 0.0, near_mn = inf, near_mx = 0.0;
     auto to_far = [&](bool take, double k, uint32_t i) {
         const unsigned long long b = __ballot(take);
         if (b) {
@@ -790,10 +805,16 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                 const uint32_t pos = base + lane_rank(b, lane);
                 F.far_key[pos] = k;
                 F.far_id[pos] = i;
-                sh_min_d(sh, FR_FAR_MIN, k);
-                sh_max_d(sh, FR_FAR_MAX, k);
+                far_mn = k < far_mn ? k : far_mn;
+                far_mx = k > far_mx ? k : far_mx;
             }
         }
+    };
+    // (after the pass that called to_far; whole wave)
+    auto flush_far = [&]() {
+        sh_minmax_wave(sh, FR_FAR_MIN, FR_FAR_MAX, far_mn, far_mx, lane);
+        far_mn = inf;
+        far_mx = 0.0;
     };
     const lds_d2* stage = (const lds_d2*)(X.lsm + A.lds.stage);  // [2 * fr_stage_cap] records: node, parent
     uint32_t n_staged = 0;  // ready entries 0 .. n_staged - 1 have their records staged
@@ -897,6 +918,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                     __syncthreads();  // at most blockDim candidates per pass: the list cannot overflow
                     fr_resolve_goals(F, S, tid, lane, wave);
                 }
+                flush_far();
                 __syncthreads();
             }
             flags = sh[FR_FLAGS];
@@ -962,6 +984,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                 const uint32_t kept = fr_partition(
                     F.near_key, F.near_id, nn_near, wsum, n_waves, [&](double, uint32_t i) -> int { return i ? 1 : -1; }, [&](int c, double k, uint32_t i) { to_far(c == 1, k, i); });
                 (void)kept;
+                flush_far();
                 if (tid == 0) sh[FR_NEAR_N] = 0;
                 __syncthreads();
             }
@@ -1003,15 +1026,19 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                             const uint32_t pos = base + lane_rank(b, lane);
                             F.near_key[pos] = k;
                             F.near_id[pos] = i;
-                            sh_min_d(sh, FR_NEAR_MIN, k);
-                            sh_max_d(sh, FR_NEAR_MAX, k);
+                            near_mn = k < near_mn ? k : near_mn;
+                            near_mx = k > near_mx ? k : near_mx;
                         }
                     }
                     if (c < 0 && i != 0u) {  // kept entries (i is their node, never 0)
-                        sh_min_d(sh, FR_FAR_MIN, k);
-                        sh_max_d(sh, FR_FAR_MAX, k);
+                        far_mn = k < far_mn ? k : far_mn;
+                        far_mx = k > far_mx ? k : far_mx;
                     }
                 });
+            flush_far();
+            sh_minmax_wave(sh, FR_NEAR_MIN, FR_NEAR_MAX, near_mn, near_mx, lane);
+            near_mn = inf;
+            near_mx = 0.0;
             if (tid == 0) sh[FR_FAR_N] = kept;
             __syncthreads();
             nn_near = sh[FR_NEAR_N];
@@ -1091,10 +1118,14 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                     const unsigned long long b3 = __ballot(c == 3);
                     if (b3) (void)sh_add_uniform(sh, FR_DROPPED, (uint32_t)__builtin_popcountll(b3), lane);  // comes after the candidate: never popped
                     if (c < 0 && i != 0u) {  // kept entries
-                        sh_min_d(sh, FR_NEAR_MIN, k);
-                        sh_max_d(sh, FR_NEAR_MAX, k);
+                        near_mn = k < near_mn ? k : near_mn;
+                        near_mx = k > near_mx ? k : near_mx;
                     }
                 });
+            flush_far();
+            sh_minmax_wave(sh, FR_NEAR_MIN, FR_NEAR_MAX, near_mn, near_mx, lane);
+            near_mn = inf;
+            near_mx = 0.0;
             FR_PROGRESS(4)
             if (tid == 0) {
                 sh[FR_NEAR_N] = kept;
