@@ -10,6 +10,39 @@
 // One lane per obstacle segment j: C2 for every shape segment i gives a 7-bit mask; a lane with a non-zero mask evaluates
 // C1 for those pairs right away.  The check ends with the first round of 64 segments that holds a hit (most edges of a
 // blocked search collide: they leave after one or two of the two or three rounds their soups make).
+// interx_segment_n: one obstacle segment (q0, q1) against the shape edges (pt[i], pt[i + 1]), i < ne <= NP - 1.
+template <int NP>
+__device__ __forceinline__ bool interx_segment_n(const d2 (&pt)[NP], int ne, d2 q0, d2 q1) {
+    const double dx2 = q1.x - q0.x, dy2 = q1.y - q0.y;
+    const double S2 = dx2 * q0.y - dy2 * q0.x;
+    uint32_t bits = 0;
+    double e0 = (pt[0].y * dx2 - pt[0].x * dy2) - S2;
+#pragma unroll
+    for (int i = 0; i < NP - 1; ++i) {
+        const double e1 = (pt[i + 1].y * dx2 - pt[i + 1].x * dy2) - S2;
+        if (i < ne && e0 * e1 < 0) bits |= 1u << i;
+        e0 = e1;
+    }
+    bool hit = false;
+    if (bits) {
+#pragma unroll
+        for (int i = 0; i < NP - 1; ++i) {
+            if ((bits >> i) & 1u) {
+                const d2 p0 = pt[i], p1 = pt[i + 1];
+                const double dx1 = p1.x - p0.x, dy1 = p1.y - p0.y;
+                const double S1 = dx1 * p0.y - dy1 * p0.x;
+                const double a0 = dx1 * q0.y - dy1 * q0.x;
+                const double a1 = dx1 * q1.y - dy1 * q1.x;
+                hit = hit || ((a0 - S1) * (a1 - S1) < 0);
+            }
+        }
+    }
+    return hit;
+}
+
+// interx_segment: one obstacle segment against the whole shape pt[0 .. V-1].
+__device__ __forceinline__ bool interx_segment(const d2 (&pt)[PDMPC_VMAX], int V, d2 q0, d2 q1) { return interx_segment_n<PDMPC_VMAX>(pt, V - 1, q0, q1); }
+
 // sh2 holds shape A in [0, VMAX) and shape B in [VMAX, 2*VMAX).
 __device__ bool interx_check(const lds_d2* sh2, int V, const lds_d2* soup, int so, int M_k, int ho, int Hk, int lo, int Ml, int lane) {
     if (V < 2) return false;
@@ -34,34 +67,12 @@ __device__ bool interx_check(const lds_d2* sh2, int V, const lds_d2* soup, int s
             }
             const lds_d2* sh = sh2 + shapeB * PDMPC_VMAX;
             const d2 q0 = soup[j], q1 = soup[j + 1];
-            const double dx2 = q1.x - q0.x, dy2 = q1.y - q0.y;
-            const double S2 = dx2 * q0.y - dy2 * q0.x;
-            // (unrolled over the most columns an area can have, so the LDS reads of the shape's points are issued together
-            // instead of one round trip per edge; columns beyond V are read but never used)
+            // (all of the shape's points are read up front, so their LDS reads are issued together instead of one round trip
+            // per edge; columns beyond V are read but never used)
             d2 pt[PDMPC_VMAX];
 #pragma unroll
             for (int i = 0; i < PDMPC_VMAX; ++i) pt[i] = sh[i];
-            uint32_t bits = 0;
-            double e0 = (pt[0].y * dx2 - pt[0].x * dy2) - S2;
-#pragma unroll
-            for (int i = 0; i < PDMPC_VMAX - 1; ++i) {
-                const double e1 = (pt[i + 1].y * dx2 - pt[i + 1].x * dy2) - S2;
-                if (i < V - 1 && e0 * e1 < 0) bits |= 1u << i;
-                e0 = e1;
-            }
-            if (bits) {
-#pragma unroll
-                for (int i = 0; i < PDMPC_VMAX - 1; ++i) {
-                    if ((bits >> i) & 1u) {
-                        const d2 p0 = pt[i], p1 = pt[i + 1];
-                        const double dx1 = p1.x - p0.x, dy1 = p1.y - p0.y;
-                        const double S1 = dx1 * p0.y - dy1 * p0.x;
-                        const double a0 = dx1 * q0.y - dy1 * q0.x;
-                        const double a1 = dx1 * q1.y - dy1 * q1.x;
-                        hit = hit || ((a0 - S1) * (a1 - S1) < 0);
-                    }
-                }
-            }
+            hit = interx_segment(pt, V, q0, q1);
         }
         if (wave_any(hit)) return true;
     }

@@ -33,13 +33,15 @@
 // serial kernel: every record is bit-identical to the oracle's.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "serial_search.hpp"
 
 // frontier words in the shared block (indices >= 32; the serial search uses the words below)
 #define FR_NNODES 32    // tree size (atomic reservation of node indices)
 #define FR_RD_HEAD 33   // ready list: next entry to claim
 #define FR_RD_TAIL 34   // ready list: entries reserved
-#define FR_PENDING 35   // ready entries not completely processed yet
+#define FR_VLIST_N 35   // arrival handling: entries of the list of collision-free nodes that are being re-checked
 #define FR_NEAR_N 36
 #define FR_FAR_N 37
 #define FR_FLAGS 38     // FRF_*
@@ -88,7 +90,7 @@ typedef LDS_AS unsigned long long lds_u64s;
         pg__[5] = sh[FR_FLAGS];                                                               \
         pg__[6] = sh[FR_BEST_ID];                                                             \
         pg__[7] = (stage);                                                                    \
-        pg__[8] = sh[FR_PENDING];                                                             \
+        pg__[8] = sh[FR_VLIST_N];                                                             \
         pg__[9] = sh[FR_RD_HEAD];                                                             \
         pg__[10] = sh[FR_RD_TAIL];                                                            \
         pg__[11] += 1u;                                                                       \
@@ -462,6 +464,49 @@ __device__ __forceinline__ void fr_push_children(const Frontier& F, bool active,
     }
 }
 
+// Does the edge into node i0 (0-based, one node per lane) cross the areas of the predecessors in `arr`?  The arithmetic of
+// interx_check restricted to those polygons (InterX.m:63-76): the edge's area is transformed once, every polygon segment goes
+// through interx_segment.
+__device__ bool fr_node_hits_areas(const Search& S, const CheckCtx& C, const SpecCtx& P, uint32_t i0, unsigned long long arr) {
+    const NodeRec cn = node_load(S, i0);
+    if (!cn.parent) return false;
+    const NodeRec pn = node_load(S, cn.parent - 1);
+    const int m = NODE_MAN(cn.packed), ncols = NODE_COLS(cn.packed), k = NODE_K(cn.packed);
+    const double c = pn.cs, s = pn.sn, pX = pn.x, pY = pn.y;
+    const size_t abase = (size_t)m * 3 * PDMPC_VMAX;
+    const lds_d2* polys = P.l_soup + P.l_soff[k - 1] + P.l_lit[k - 1];
+    bool hit = false;
+    // the area's edges in two parts (0 .. H-1 and H .. VMAX-2): one node per lane means the points live in registers, and all
+    // VMAX of them at once would push the whole kernel into spilling
+    constexpr int H = PDMPC_VMAX / 2;
+    auto part = [&](auto np_tag, int first, int ne) {
+        constexpr int NP = decltype(np_tag)::value;
+        d2 pt[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {  // (columns beyond ncols are padding: transformed, never used)
+            const d2 a = C.areas_in_lds ? (d2)C.l_area[abase + first + i] : C.g_area[abase + first + i];
+            pt[i].x = c * a.x - s * a.y + pX;  // GraphSearch.m:158
+            pt[i].y = s * a.x + c * a.y + pY;  // :159
+        }
+        unsigned long long rem = arr;
+        while (rem) {
+            const int p = (int)__builtin_ctzll(rem);
+            rem &= rem - 1;
+            const lds_d2* poly = polys + p * PDMPC_VMAX;
+            d2 q0 = poly[0];
+#pragma unroll 1
+            for (int j = 0; j + 1 < PDMPC_VMAX; ++j) {
+                const d2 q1 = poly[j + 1];
+                hit = hit || interx_segment_n<NP>(pt, ne, q0, q1);
+                q0 = q1;
+            }
+        }
+    };
+    part(std::integral_constant<int, H + 1>{}, 0, ncols - 1 < H ? ncols - 1 : H);
+    if (ncols - 1 > H) part(std::integral_constant<int, PDMPC_VMAX - H>{}, H, ncols - 1 - H);
+    return hit;
+}
+
 // One node of the round: eval_edge_exact (GraphSearch.m:111-196), the goal test (:81-90), expand_node.m.  Whole wave.
 template <int CHECKER, int NW>
 __device__ __forceinline__ void fr_process(const KernelArgs& A, Ctx& X, const Frontier& F, const ExpandEnv& EE, uint32_t cur, const lds_d2* staged) {
@@ -771,7 +816,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
         for (int w = FR_NNODES; w < SH_WORDS; ++w) sh[w] = 0;
         sh[FR_NNODES] = 1;
         sh[FR_RD_TAIL] = 1;
-        sh[FR_PENDING] = 1;
+        sh[FR_VLIST_N] = 0;
         sh_st_d(sh, FR_NEAR_MIN, inf);
         sh_st_d(sh, FR_FAR_MIN, inf);
         sh_st_d(sh, FR_L_FAR, inf);
@@ -830,8 +875,8 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                 const unsigned long long dtp = __builtin_amdgcn_s_memrealtime() - tp0;
                 __hip_atomic_fetch_max((lds_u64s*)(sh + FR_SLOWEST), (dtp << 32) | cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            (void)sh_add_uniform(sh, FR_PROCESSED, 1u, lane);
         }
+        if (tid == 0) sh[FR_PROCESSED] = sh[FR_PROCESSED] + sh[FR_RD_TAIL];  // (the round's size is fixed while it runs)
         __syncthreads();
         FR_TICK(tk_work)
         FR_PROGRESS(1)
@@ -857,16 +902,32 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
             nn = nn < S.max_nodes ? nn : S.max_nodes;
             incorporate_areas(P, arr, tid);
             __syncthreads();
-            for (uint32_t i0 = (uint32_t)tid; i0 < nn; i0 += blockDim.x) {
-                if (vs_load(VS, i0) == VS_VALID) {
-                    bool popped;
-                    if (node_hits_areas(S, X.C, P, i0, arr, popped)) {
+            // Only collision-free nodes can lose their edge: they are gathered first (a third of the tree, scattered), so that
+            // the check runs on full wavefronts.  The list lives in the histogram's bins, unused at a round boundary.
+            for (uint32_t base0 = 0; base0 < nn; base0 += FR_NBINS) {  // (uniform trip counts: barriers inside)
+                const uint32_t end = base0 + FR_NBINS < nn ? base0 + FR_NBINS : nn;
+                if (tid == 0) sh[FR_VLIST_N] = 0;
+                __syncthreads();
+                for (uint32_t b = base0; b < end; b += blockDim.x) {
+                    const uint32_t i0 = b + (uint32_t)tid;
+                    const bool v = i0 < end && vs_load(VS, i0 < end ? i0 : 0u) == VS_VALID;
+                    const unsigned long long bal = __ballot(v);
+                    if (bal) {
+                        const uint32_t pos0 = sh_add_uniform(sh, FR_VLIST_N, (uint32_t)__builtin_popcountll(bal), lane);
+                        if (v) F.hist[pos0 + lane_rank(bal, lane)] = i0;
+                    }
+                }
+                __syncthreads();
+                const uint32_t nv = sh[FR_VLIST_N];
+                for (uint32_t e = (uint32_t)tid; e < nv; e += blockDim.x) {
+                    const uint32_t i0 = F.hist[e];
+                    if (fr_node_hits_areas(S, X.C, P, i0, arr)) {
                         vs_store(VS, i0, VS_INVALID);
                         atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_INVALIDATED);
                     }
                 }
+                __syncthreads();
             }
-            __syncthreads();
             flags = sh[FR_FLAGS];
             const bool reopen = (flags & FRF_INVALIDATED) && sh[FR_DROPPED] != 0u;
             __syncthreads();
