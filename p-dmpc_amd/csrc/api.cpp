@@ -244,8 +244,10 @@ int compute_lds_frontier(pdmpc_handle* h, int n_launch, int soup_cap, int cand_c
     // maneuver areas read through L2 if need be; otherwise one workgroup per CU with the whole LDS.
     struct Try { size_t budget; int waves, areas, two_per_cu; };
     std::vector<Try> tries;
-    bool crowded = n_launch > h->n_cu;
-    if (const char* e = getenv("PDMPC_FR_TWO_PER_CU")) crowded = crowded && atoi(e) != 0;  // tuning knob
+    // (two workgroups per CU only on request: with more searches than CUs one 16-wave workgroup per CU at a time is faster,
+    // C5: 345 steps/s against 324 with 2 x 8 wavefronts)
+    bool crowded = false;
+    if (const char* e = getenv("PDMPC_FR_TWO_PER_CU")) crowded = n_launch > h->n_cu && atoi(e) != 0;  // tuning knob
     if (crowded) {
         tries.push_back({kLdsMax / 2, h->waves_crowded, 1, 1});
         tries.push_back({kLdsMax / 2, h->waves_crowded, 0, 1});
@@ -587,6 +589,10 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     if (const char* e = getenv("PDMPC_FR_RAMP")) a.fr_ramp = std::max(1, atoi(e));  // tuning knob
     a.fr_near_fill = h->fr_near_fill;
     a.fr_near_max = h->fr_near_max;
+    a.fr_join_scale = 4.0;  // measured on C2 / C3 / C5: 1 -> 419 / 396 / 347 steps/s, 4 -> 434 / 396 / 353, 8 -> 434 / 397 / 345, 32 -> 429 / 394 / 344
+    if (const char* e = getenv("PDMPC_FR_JOIN_SCALE")) a.fr_join_scale = atof(e);  // tuning knob
+    a.fr_dive = 1024;  // in rounds of up to this many entries a wave goes on with the best child while its key stays within the round's range (frontier_kernel.hip, fr_process); measured on C2 / C3 / C5: 0 -> 408 / 391 / 307 steps/s, 64 -> 409 / 391 / 314, 1024 -> 419 / 397 / 323
+    if (const char* e = getenv("PDMPC_FR_DIVE")) a.fr_dive = std::max(0, atoi(e));  // tuning knob / A-B switch (0: never): results are identical
     a.spin_limit = 1u << 22;
     if (const char* e = getenv("PDMPC_SPIN_LIMIT")) a.spin_limit = (uint32_t)std::max(1024, atoi(e));  // debugging: fail fast
     a.debug_tail = getenv("PDMPC_DEBUG_TAIL") ? atoi(getenv("PDMPC_DEBUG_TAIL")) : 0;

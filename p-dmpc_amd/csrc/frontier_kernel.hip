@@ -64,6 +64,7 @@
 #define FR_GOAL_N 39     // goal candidates of the running round (entries of goal_list)
 #define FR_ROUND_B1 28   // (64 bit, words 28-29 of the serial block: unused by both searches) smallest path maximum among them
 #define FR_GOAL_CAP 1024
+#define FR_JOIN_MAX 26    // (64 bit, words 26-27 of the serial block: unused by both searches) largest key among the round's entries
 #define FR_DEAD 57      // open entries dropped because an ancestor was invalidated
 #define FR_DROPPED 62   // open entries dropped because they come after the best candidate (restored if that one is invalidated)
 #define FRF_OVERFLOW 1u
@@ -508,38 +509,29 @@ __device__ bool fr_node_hits_areas(const Search& S, const CheckCtx& C, const Spe
 }
 
 // One node of the round: eval_edge_exact (GraphSearch.m:111-196), the goal test (:81-90), expand_node.m.  Whole wave.
+// cu / pu: the node's record and its parent's (the same in every lane).  Returns 0, or the child this wave goes on with right
+// away (its record then in cu, this node's in pu): the child with the smallest key if that key is not above l_join, the
+// largest key the round has selected.  The reference pops such a child before anything the round left behind, so taking
+// it now is no more of a guess than the round's own entries are — and a search that runs straight to the horizon gets there
+// in one round instead of one round per level.
 template <int CHECKER, int NW>
-__device__ __forceinline__ void fr_process(const KernelArgs& A, Ctx& X, const Frontier& F, const ExpandEnv& EE, uint32_t cur, const lds_d2* staged) {
+__device__ __forceinline__ uint32_t fr_process(const KernelArgs& A, Ctx& X, const Frontier& F, const ExpandEnv& EE, uint32_t cur, NodeBits& cu, NodeBits& pu, double l_join) {
     const int lane = X.lane, Hp = X.Hp;
     Search& S = X.S;
     const VState& VS = X.VS;
     const uint32_t c0 = cur - 1u;
-    // the node's record and its parent's: staged in LDS when the round was selected (one HBM latency per round instead of
-    // two dependent ones per node), else through L2
-    NodeBits cu, pu;
-    if (staged) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            cu.q[q] = staged[q];
-            pu.q[q] = staged[4 + q];
-        }
-    } else {
-        cu.r = node_load(S, c0);
-        const uint32_t par = uni_u(cu.r.parent);
-        pu.r = node_load(S, par ? par - 1u : 0u);
-    }
     const NodeRec& cn = cu.r;  // same record in every lane
     const bool valid = edge_valid_recs<CHECKER>(X.C, cn, pu.r, lane);
     if (!valid) {
         if (lane == 0) vs_store(VS, c0, VS_INVALID);
-        return;
+        return 0u;
     }
     const uint32_t cpk = uni_u(cn.packed);
     if (NODE_K(cpk) == Hp) {
         if (lane == 0) vs_store(VS, c0, VS_VALID);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         fr_offer_goal(F, S, VS, cur, lane);
-        return;
+        return 0u;
     }
     double sn, cs;
     pdmpc_sincos(cn.yaw, &sn, &cs);  // expand_node.m:50-51
@@ -556,17 +548,48 @@ __device__ __forceinline__ void fr_process(const KernelArgs& A, Ctx& X, const Fr
             atomicOr((uint32_t*)&F.sh[FR_FLAGS], FRF_OVERFLOW);
             vs_store(VS, c0, VS_VALID);
         }
-        return;
+        return 0u;
     }
     if (lane == 0) vs_store(VS, c0, VS_VALID);  // before any child can be picked up: a child's path check looks at it
     uint32_t nn = base;
-    (void)expand_children<false, NW>(EE, S, VS, cur, cn, cs, sn, nn, [&](uint64_t mask, bool active, uint32_t i0, double f, int ccnt) {
+    uint32_t next = 0;
+    lds_d2* hand = X.C.sh;  // the chosen child's record travels through the wave's shape scratch (rewritten by the next edge check only)
+    (void)expand_children<false, NW>(EE, S, VS, cur, cn, cs, sn, nn, [&](uint64_t mask, bool active, uint32_t i0, double f, int ccnt, const NodeRec& ch) {
         (void)mask;
         (void)ccnt;
         if (active) F.gkey[i0] = f;
         // (no fence here: nothing reads the children's records, keys or list entries before the barrier that ends the round)
-        fr_push_children(F, active, i0, f, lane);
+        bool mine = false;
+        const unsigned long long bj = __ballot(active && f <= l_join);
+        if (bj && next == 0u) {  // (uniform) the smallest of those keys; equal keys: the lower lane
+            double m = (active && f <= l_join) ? f : __longlong_as_double(0x7FF0000000000000LL);
+#pragma unroll
+            for (int o = PDMPC_WAVE / 2; o > 0; o >>= 1) {
+                const double v = __shfl_xor(m, o);
+                m = v < m ? v : m;
+            }
+            const unsigned long long bw = __ballot(active && f == m);
+            const int wl = (int)__builtin_ctzll(bw);
+            mine = lane == wl;
+            if (mine) {
+                NodeBits u;
+                u.r = ch;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) hand[q] = u.q[q];
+            }
+            next = lane_u(i0, wl) + 1u;
+        }
+        fr_push_children(F, active && !mine, i0, f, lane);
     });
+    if (next) {
+        wave_sync();
+        pu = cu;
+        pu.r.cs = cs;
+        pu.r.sn = sn;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cu.q[q] = hand[q];
+    }
+    return next;
 }
 
 // Phase B: position of every node relative to the goal path P_0..P_Hp (goal == 0: exhausted search, every generated node
@@ -817,6 +840,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
         sh[FR_NNODES] = 1;
         sh[FR_RD_TAIL] = 1;
         sh[FR_VLIST_N] = 0;
+        sh_st_d(sh, FR_JOIN_MAX, 0.0);  // (the root's round: its key)
         sh_st_d(sh, FR_NEAR_MIN, inf);
         sh_st_d(sh, FR_FAR_MIN, inf);
         sh_st_d(sh, FR_L_FAR, inf);
@@ -841,7 +865,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
         tk_mark = now__;                                                   \
     }
     // appends (k, i) of the lanes with `take` to far (whole wave calls); the keys' range is folded into FR_FAR_MIN/MAX by flush_far
-    double far_mn = inf, far_mx = 0.0, near_mn = inf, near_mx = 0.0;
+    double far_mn = inf, far_mx = 0.0, near_mn = inf, near_mx = 0.0, sel_mx = 0.0;
     auto to_far = [&](bool take, double k, uint32_t i) {
         const unsigned long long b = __ballot(take);
         if (b) {
@@ -865,18 +889,46 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
     uint32_t n_staged = 0;  // ready entries 0 .. n_staged - 1 have their records staged
     for (;;) {
         // ================= a round: every wave takes nodes off the ready list until the list is empty =================
+        // children up to the largest key the round took may be taken along (fr_process), but none that comes after the best goal candidate
+        double l_join = sh_ld_d(sh, FR_JOIN_MAX);
+        if (sh[FR_BEST_ID] != 0u) {
+            const double bb1 = sh_ld_d(sh, FR_BEST_B1);
+            l_join = bb1 > 0.0 ? (l_join < bb1 ? l_join : __longlong_as_double(__double_as_longlong(bb1) - 1)) : 0.0;  // (strictly below it)
+        }
+        if (sh[FR_RD_TAIL] > (uint32_t)A.fr_dive) l_join = -1.0;  // (a large round keeps every wave busy as it is; chains only delay its end)
+        uint32_t chained = 0;  // nodes this wave processed beyond the round's entries
         for (;;) {
             const uint32_t t = sh_add_uniform(sh, FR_RD_HEAD, 1u, lane);
             if (t >= uni_u(sh[FR_RD_TAIL])) break;
-            const uint32_t cur = uni_u(F.ready[t]);
+            uint32_t cur = uni_u(F.ready[t]);
+            // the node's record and its parent's: staged in LDS when the round was selected (one HBM latency per round instead of
+            // two dependent ones per node), else through L2
+            NodeBits cu, pu;
+            if (t < n_staged) {
+                const lds_d2* staged = stage + 8 * (size_t)t;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    cu.q[q] = staged[q];
+                    pu.q[q] = staged[4 + q];
+                }
+            } else {
+                cu.r = node_load(S, cur - 1u);
+                const uint32_t par = uni_u(cu.r.parent);
+                pu.r = node_load(S, par ? par - 1u : 0u);
+            }
             const unsigned long long tp0 = __builtin_amdgcn_s_memrealtime();
-            fr_process<CHECKER, NW>(A, X, F, EE, cur, t < n_staged ? stage + 8 * (size_t)t : nullptr);
-            if (A.debug_tail && lane == 0) {  // the slowest single node of this search (ticks << 32 | node)
+            for (;;) {  // the node, then the chain of best children the round's key range covers (fr_process)
+                const uint32_t next = fr_process<CHECKER, NW>(A, X, F, EE, cur, cu, pu, l_join);
+                if (!next) break;
+                cur = next;
+                ++chained;
+            }
+            if (A.debug_tail && lane == 0) {  // the slowest single entry of this search (ticks << 32 | node)
                 const unsigned long long dtp = __builtin_amdgcn_s_memrealtime() - tp0;
                 __hip_atomic_fetch_max((lds_u64s*)(sh + FR_SLOWEST), (dtp << 32) | cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
-        if (tid == 0) sh[FR_PROCESSED] = sh[FR_PROCESSED] + sh[FR_RD_TAIL];  // (the round's size is fixed while it runs)
+        (void)sh_add_uniform(sh, FR_PROCESSED, chained + (tid == 0 ? sh[FR_RD_TAIL] : 0u), lane);  // (the round's size is fixed while it runs)
         __syncthreads();
         FR_TICK(tk_work)
         FR_PROGRESS(1)
@@ -1140,6 +1192,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                 sh[FR_RD_TAIL] = 0;
                 sh_st_d(sh, FR_NEAR_MIN, inf);
                 sh_st_d(sh, FR_NEAR_MAX, 0.0);
+                sh_st_d(sh, FR_JOIN_MAX, 0.0);
                 if (spill) sh_st_d(sh, FR_L_FAR, lo + (double)(bspill + 1u) / scale);
                 sh_add(sh, FR_ROUNDS, 1u);
             }
@@ -1171,6 +1224,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                         const uint32_t pos = base + lane_rank(b1, lane);
                         const bool fits = c == 1 && pos < (uint32_t)FR_READY_CAP;
                         if (fits) F.ready[pos] = i;
+                        sel_mx = (fits && k > sel_mx) ? k : sel_mx;
                         spill_over = c == 1 && !fits;  // (only if a thousand keys are equal to the last bit: they wait in far)
                     }
                     to_far(c == 2 || spill_over, k, i);
@@ -1185,11 +1239,17 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                 });
             flush_far();
             sh_minmax_wave(sh, FR_NEAR_MIN, FR_NEAR_MAX, near_mn, near_mx, lane);
+            sh_minmax_wave(sh, FR_NEAR_MIN, FR_JOIN_MAX, inf, sel_mx, lane);  // (largest key the round takes; min with +inf changes nothing)
             near_mn = inf;
             near_mx = 0.0;
+            sel_mx = 0.0;
             FR_PROGRESS(4)
             if (tid == 0) {
                 sh[FR_NEAR_N] = kept;
+                if (A.fr_join_scale != 1.0) {  // the chains' key range: the round's own, stretched (any range gives the same results)
+                    const double mxk = sh_ld_d(sh, FR_JOIN_MAX);
+                    if (mxk > 0.0) sh_st_d(sh, FR_JOIN_MAX, lo + A.fr_join_scale * (mxk - lo));
+                }
                 const uint32_t tl = sh[FR_RD_TAIL];
                 if (tl > (uint32_t)FR_READY_CAP) sh[FR_RD_TAIL] = FR_READY_CAP;
             }
@@ -1307,19 +1367,14 @@ extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) void pdmpc_frontier_k
 extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) void pdmpc_frontier_kernel_sat(const KernelArgs A) { frontier_body<PDMPC_CHECK_SAT, 1>(A); }
 extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) void pdmpc_frontier_kernel_wide(const KernelArgs A) { frontier_body<PDMPC_CHECK_INTERX, 0>(A); }
 extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) void pdmpc_frontier_kernel_sat_wide(const KernelArgs A) { frontier_body<PDMPC_CHECK_SAT, 0>(A); }
-// compiled for six wavefronts per SIMD: two workgroups of twelve wavefronts per CU (launches with more workgroups than CUs)
-#define PDMPC_DENSE __attribute__((amdgpu_waves_per_eu(6, 6)))
-extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) PDMPC_DENSE void pdmpc_frontier_kernel_dense(const KernelArgs A) { frontier_body<PDMPC_CHECK_INTERX, 1>(A); }
-extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) PDMPC_DENSE void pdmpc_frontier_kernel_sat_dense(const KernelArgs A) { frontier_body<PDMPC_CHECK_SAT, 1>(A); }
-extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) PDMPC_DENSE void pdmpc_frontier_kernel_wide_dense(const KernelArgs A) { frontier_body<PDMPC_CHECK_INTERX, 0>(A); }
-extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) PDMPC_DENSE void pdmpc_frontier_kernel_sat_wide_dense(const KernelArgs A) { frontier_body<PDMPC_CHECK_SAT, 0>(A); }
 
 extern "C" int pdmpc_launch_frontier(const KernelArgs* args, int count, void* stream) {
     if (count <= 0) return 0;
     typedef void (*kernel_t)(const KernelArgs);
     const bool interx = args->checker == PDMPC_CHECK_INTERX, one_word = args->n_words == 1;
     kernel_t fn = interx ? (one_word ? pdmpc_frontier_kernel : pdmpc_frontier_kernel_wide) : (one_word ? pdmpc_frontier_kernel_sat : pdmpc_frontier_kernel_sat_wide);
-    if (args->dense) fn = interx ? (one_word ? pdmpc_frontier_kernel_dense : pdmpc_frontier_kernel_wide_dense) : (one_word ? pdmpc_frontier_kernel_sat_dense : pdmpc_frontier_kernel_sat_wide_dense);
+    // (no register-capped variants for two workgroups per CU: measured on C5, 1280 searches on 256 CUs: 2 x 12 wavefronts at 80
+    // VGPRs 283 steps/s, 2 x 8 at 128 VGPRs 324, one workgroup of 16 per CU 345)
     hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)args->lds.total);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(fn, dim3(count), dim3(PDMPC_WAVE * args->n_waves), args->lds.total, (hipStream_t)stream, *args);

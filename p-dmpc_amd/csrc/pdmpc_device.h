@@ -145,7 +145,9 @@ struct KernelArgs {
     int32_t fr_stage_cap;  // ... entries of a round whose records (node + parent) are staged in LDS when the round is selected
     int32_t fr_ramp;       // ... a young search takes one entry per wavefront plus 1 / fr_ramp of the nodes processed so far
     int32_t fr_near_fill;  // ... entries a refill moves from far to near
+    double fr_join_scale;  // ... the key range within which a wave goes on with a node's best child, as a multiple of the range the round's own entries span
     int32_t fr_near_max;   // ... size of near beyond which its tail is moved back to far
+    int32_t fr_dive;       // ... largest round (entries) in which waves go on with best children (0: never)
     int32_t speculate;  // 1: start searching before all predecessors have finished (results are identical, see arrival_sync)
     uint32_t spin_limit;
 };

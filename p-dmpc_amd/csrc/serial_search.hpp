@@ -330,7 +330,7 @@ struct ExpandEnv {
 };
 
 // expand_node.m:1-91 for the popped node `cur` (1-based id, record cn, cos/sin of its yaw): creates the children's
-// records (validity unknown) and calls push(mask, active, i0, f, cnt) once per 64-trim word of the successor mask, with
+// records (validity unknown) and calls push(mask, active, i0, f, cnt, record) once per 64-trim word of the successor mask, with
 // nnodes still the index of the word's first child; the caller's push makes the children visible in its open list.
 // Returns false if the arena cannot take the children (nothing is created then).
 // FENCE: drain the records' HBM stores before push (needed when push makes the children visible to waves that read
@@ -432,7 +432,7 @@ __device__ __forceinline__ bool expand_children(const ExpandEnv& E, Search& S, c
         if (FENCE && nnodes + (uint32_t)cnt > S.NL) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         wave_sync();
         PROF_STOP(5)
-        push(mask, active, i0, f, cnt);
+        push(mask, active, i0, f, cnt, ch);
         nnodes += (uint32_t)cnt;
     }
     return true;
@@ -916,7 +916,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                         if (lane == 0) node_store_cs(S, c0, cs, sn);
                     }
                     const uint32_t n0 = nnodes;
-                    const bool fits = expand_children<false, NW>(EE, S, VS, cur, cn, cs, sn, nnodes, [&](uint64_t mask, bool active, uint32_t i0, double f, int ccnt) {
+                    const bool fits = expand_children<false, NW>(EE, S, VS, cur, cn, cs, sn, nnodes, [&](uint64_t mask, bool active, uint32_t i0, double f, int ccnt, const NodeRec&) {
                         (void)mask;
                         (void)ccnt;
                         if (active) {
@@ -1260,7 +1260,7 @@ __device__ __forceinline__ bool search_loops(const KernelArgs& A, Ctx& X) {
                 EE.nw = nw;
                 EE.lane = lane;
                 // pq.push(new_open_nodes, new_open_values): one at a time in ascending trim order (mex.cpp:67-72)
-                const bool fits = expand_children<true, NW>(EE, S, VS, cur, cn, cs, sn, nnodes, [&](uint64_t mask, bool active, uint32_t i0, double f, int cnt) {
+                const bool fits = expand_children<true, NW>(EE, S, VS, cur, cn, cs, sn, nnodes, [&](uint64_t mask, bool active, uint32_t i0, double f, int cnt, const NodeRec&) {
                     (void)active;
                     (void)i0;
                     uint64_t mm = mask;

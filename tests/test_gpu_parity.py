@@ -301,6 +301,10 @@ def test_random_road_problems_never_fall_back():
         {"PDMPC_FR_ROUND": "1000"},
         {"PDMPC_FR_NEAR_FILL": "64", "PDMPC_FR_NEAR_MAX": "256"},
         {"PDMPC_FR_NEAR_FILL": "64", "PDMPC_FR_NEAR_MAX": "256", "PDMPC_FR_ROUND": "7", "PDMPC_WAVES": "5"},
+        {"PDMPC_FR_DIVE": "0"},
+        {"PDMPC_FR_JOIN_SCALE": "1000"},
+        {"PDMPC_FR_JOIN_SCALE": "0.25", "PDMPC_FR_DIVE": "16"},
+        {"PDMPC_FR_TWO_PER_CU": "1", "PDMPC_WAVES": "8"},
     ],
 )
 def test_tuning_switches_do_not_change_results(env, monkeypatch):
