@@ -142,6 +142,82 @@ def test_interx_edge_semantics():
     assert not oracle.interx(sq, np.zeros((2, 1)))  # single column: diff() is empty
 
 
+# ---- InterX / SAT against exact geometry (an independent specification, not a second reading of the .m files) -------
+def _crosses_exactly(a0, a1, b0, b1):
+    """Do the open segments a0a1 and b0b1 cross in a single interior point?  Exact rational arithmetic on the doubles."""
+    from fractions import Fraction as Fr
+
+    def orient(p, q, r):
+        return (Fr(q[0]) - Fr(p[0])) * (Fr(r[1]) - Fr(p[1])) - (Fr(q[1]) - Fr(p[1])) * (Fr(r[0]) - Fr(p[0]))
+
+    o1, o2, o3, o4 = orient(a0, a1, b0), orient(a0, a1, b1), orient(b0, b1, a0), orient(b0, b1, a1)
+    margin = min(abs(o1), abs(o2), abs(o3), abs(o4))
+    return (o1 * o2 < 0 and o3 * o4 < 0), float(margin)
+
+
+def test_interx_is_proper_segment_crossing_in_exact_arithmetic():
+    """InterX.m's header: the intersection points of two curves.  For curves in general position that is: some segment of
+    one properly crosses some segment of the other — decided here with exact rationals, independently of how InterX.m:63-76
+    arranges its products.  (Pairs with an orientation within 1e-12 of zero are skipped: there rounding may decide.)"""
+    rng = np.random.default_rng(77)
+    checked = hits = 0
+    for _ in range(250):
+        n1, n2 = int(rng.integers(2, 8)), int(rng.integers(2, 12))
+        L1 = rng.uniform(-1, 1, (2, n1))
+        L2 = rng.uniform(-1.2, 1.2, (2, n2)) * rng.uniform(0.2, 1.0)
+        want, generic = False, True
+        for i in range(n1 - 1):
+            for j in range(n2 - 1):
+                c, m = _crosses_exactly(L1[:, i], L1[:, i + 1], L2[:, j], L2[:, j + 1])
+                want = want or c
+                generic = generic and m > 1e-12
+        if not generic:
+            continue
+        assert oracle.interx(L1, L2) == want
+        checked += 1
+        hits += want
+    assert checked > 200 and 30 < hits < checked - 30
+
+
+def test_intersect_sat_is_convex_overlap_in_exact_arithmetic():
+    """intersect_sat.m: two convex polygons collide iff no edge normal of either separates them (touching counts as
+    colliding: the gap must be > 0).  Decided with exact rationals on unnormalised normals (a positive scale does not move
+    a sign); cases with a gap within 1e-12 of zero are skipped."""
+    from fractions import Fraction as Fr
+
+    def convex(rng):
+        n = int(rng.integers(3, 7))
+        ang = np.sort(rng.uniform(0, 2 * np.pi, n))
+        r = rng.uniform(0.2, 0.6)
+        c = rng.uniform(-0.6, 0.6, 2)
+        return np.stack([c[0] + r * np.cos(ang), c[1] + r * np.sin(ang)])
+
+    def separated(p, q):
+        best = None
+        for poly in (p, q):
+            n = poly.shape[1]
+            for i in range(n):
+                ex, ey = Fr(poly[0, (i + 1) % n]) - Fr(poly[0, i]), Fr(poly[1, (i + 1) % n]) - Fr(poly[1, i])
+                ax, ay = -ey, ex
+                d1 = [ax * Fr(p[0, k]) + ay * Fr(p[1, k]) for k in range(p.shape[1])]
+                d2 = [ax * Fr(q[0, k]) + ay * Fr(q[1, k]) for k in range(q.shape[1])]
+                gap = max(min(d1) - max(d2), min(d2) - max(d1))
+                best = gap if best is None or gap > best else best
+        return best > 0, float(abs(best))
+
+    rng = np.random.default_rng(78)
+    checked = hits = 0
+    for _ in range(250):
+        p, q = convex(rng), convex(rng)
+        sep, m = separated(p, q)
+        if m < 1e-12:
+            continue
+        assert oracle.intersect_sat(p, q) == (not sep)
+        checked += 1
+        hits += not sep
+    assert checked > 200 and 30 < hits < checked - 30
+
+
 def sat_numpy(s1, s2):
     def a_b(p, q):
         e = np.diff(np.hstack([p, p[:, :1]]), axis=1)
