@@ -603,7 +603,7 @@ struct PhaseB {
 #define PB_ONPATH 0x200u
 template <int NW>
 __device__ PhaseB fr_phase_b(const KernelArgs& A, Ctx& X, const Frontier& F, const ExpandEnv& EE, uint32_t goal, lds_u32* ref_ids, LDS_AS unsigned char* scratch,
-                             double* st_b, uint32_t* st_d) {
+                             double* st_b, uint32_t* st_d, const lds_u32* gp_path) {
     const int tid = X.tid, Hp = X.Hp;
     const Search& S = X.S;
     const VState& VS = X.VS;
@@ -615,18 +615,28 @@ __device__ PhaseB fr_phase_b(const KernelArgs& A, Ctx& X, const Frontier& F, con
     lds_u32* ch_d = (lds_u32*)scratch;                                     // [blockDim] state of the chunk's nodes
     lds_f64* ch_b = (lds_f64*)(scratch + 4 * (size_t)blockDim.x);          // [blockDim]
     const int n = EE.n, nw = NW > 0 ? NW : EE.nw;
+    lds_u32* pkw = cnt_ch + PDMPC_HP_MAX + 2;                              // [HP_MAX + 1] packed words of the path nodes
     ch_d[tid] = 0;
-    if (tid == 0) {
+    // G's path: the selection's relevance tables hold it when G was the best candidate at the last round boundary (the usual
+    // end of a search) — then its keys and packed words are one parallel load; else walked from G
+    const bool have_path = goal && F.sh[FR_PATH_FOR] == goal;
+    if (goal && !have_path && tid == 0) {
         uint32_t nd = goal;
-        for (int i = Hp; i >= 0 && goal; --i) {
+        for (int i = Hp; i >= 0; --i) {
             l_path[i] = nd;
-            pk[i] = F.gkey[nd - 1];
             nd = node_parent(S, nd - 1);
         }
-        for (int t = 0; t < PDMPC_HP_MAX + 2; ++t) {
-            cnt_pop[t] = 0;
-            cnt_ch[t] = 0;
-        }
+    }
+    if (have_path && tid <= Hp) l_path[tid] = gp_path[tid];
+    if (tid < PDMPC_HP_MAX + 2) {
+        cnt_pop[tid] = 0;
+        cnt_ch[tid] = 0;
+    }
+    __syncthreads();
+    if (goal && tid <= Hp) {
+        const uint32_t nd = l_path[tid];
+        pk[tid] = F.gkey[nd - 1];
+        pkw[tid] = ((const uint32_t*)(S.gn + (nd - 1u)))[15];
     }
     __syncthreads();
     if (goal && tid <= Hp) {
@@ -754,8 +764,7 @@ __device__ PhaseB fr_phase_b(const KernelArgs& A, Ctx& X, const Frontier& F, con
         ref_ids[0] = 1;
         for (int j = 0; j < Hp; ++j) {
             s += cnt_ch[j];  // nodes expanded before P_j: t <= j
-            const uint32_t pj = l_path[j] - 1u, cj = l_path[j + 1] - 1u;
-            const uint32_t ppk = ((const uint32_t*)(S.gn + pj))[15], cpk2 = ((const uint32_t*)(S.gn + cj))[15];
+            const uint32_t ppk = pkw[j], cpk2 = pkw[j + 1];
             const lds_mask64* mrow = EE.l_mask + ((size_t)NODE_K(ppk) * n + (NODE_TRIM(ppk) - 1)) * nw;
             const int t2 = NODE_TRIM(cpk2) - 1;  // 0-based successor trim
             uint32_t rank = 0;
@@ -1284,8 +1293,10 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
     PhaseB R;
     R.n_popped = 0;
     R.n_expanded = nnodes_raw;
+    bool pb_ran = false;
     if (status != PDMPC_ARENA_OVERFLOW && !dep_timeout) {
-        R = fr_phase_b<NW>(A, X, F, EE, goal, ref_ids, (LDS_AS unsigned char*)(X.lsm + A.lds.cand), F.far_key, F.far_id);
+        R = fr_phase_b<NW>(A, X, F, EE, goal, ref_ids, (LDS_AS unsigned char*)(X.lsm + A.lds.cand), F.far_key, F.far_id, gp_path);
+        pb_ran = true;
         const uint32_t flags = sh[FR_FLAGS];
         __syncthreads();
         if (flags & FRF_TIE) return true;
@@ -1323,6 +1334,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
     }
     X.status = status;
     X.n_popped = (int)R.n_popped;
+    X.path_ready = pb_ran && goal != 0u;  // (l_path holds G's path: the epilogue need not walk it again; not set when a tie sends the search to the heap)
     X.goal = goal;
     X.nnodes = R.n_expanded;
     X.dep_timeout = dep_timeout;

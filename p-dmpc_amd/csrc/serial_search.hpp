@@ -315,6 +315,7 @@ struct Ctx {
     int status, n_popped;
     uint32_t goal, nnodes;
     bool dep_timeout;
+    bool path_ready = false;  // l_path already holds the nodes of the goal's path (the frontier kernel's counting pass has walked it)
 #ifdef PDMPC_PROFILE
     unsigned long long rt_start;
 #endif
@@ -1614,7 +1615,7 @@ __device__ __forceinline__ void search_epilogue(const KernelArgs& A, Ctx& X, con
     // ---- results (GraphSearch.m:58-59, 82-89; return_path_to.m; return_path_area.m), sequencing wave only
     if (goal) {
         // path_to_root (Tree.m:44-52), reversed
-        if (lane == 0) {
+        if (lane == 0 && !X.path_ready) {
             uint32_t nd = goal;
             for (int i = Hp; i >= 0; --i) {
                 l_path[i] = nd;
