@@ -659,7 +659,8 @@ __device__ PhaseB fr_phase_b(const KernelArgs& A, Ctx& X, const Frontier& F, con
             const uint64_t u = (uint64_t)__double_as_longlong(q.y);
             par = (uint32_t)(u & 0xffffffffull);
             pk_ = (uint32_t)(u >> 32);
-            key = F.gkey[i];
+            // key = g + h (GraphSearch.m:100-102), the very sum expand_children stored: from the LDS copy of the record where there is one
+            key = i < S.NL ? ((d2)S.ln[4 * (size_t)i + 1]).y + q.x : F.gkey[i];
             vst = vs_load(VS, i);
         }
         const int depth = NODE_K(pk_);
