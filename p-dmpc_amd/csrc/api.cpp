@@ -146,6 +146,7 @@ struct pdmpc_handle {
     DevBuf<uint32_t> ahid;
     DevBuf<double> alog;
     DevBuf<double> ankey;   // frontier kernel: near list
+    DevBuf<unsigned long long> alink;  // frontier kernel: parent | packed << 32 of every node (the walks' and the counting pass's compact view of the tree)
     DevBuf<uint32_t> anid;
     DevBuf<uint8_t> avs;
     DevBuf<pdmpc_vehicle_out> d_out;
@@ -527,10 +528,11 @@ int alloc_arenas(pdmpc_handle* h, uint32_t nodes) {
     h->alog.release();
     h->ankey.release();
     h->anid.release();
+    h->alink.release();
     h->max_nodes = 0;
     int bad = 0;
     bad |= h->anodes.ensure_exact(tot) | h->ahk.ensure_exact(tot) | h->ahid.ensure_exact(tot) | h->avs.ensure_exact(tot) | h->alog.ensure_exact(tot);
-    bad |= h->ankey.ensure_exact(tot) | h->anid.ensure_exact(tot);
+    bad |= h->ankey.ensure_exact(tot) | h->anid.ensure_exact(tot) | h->alink.ensure_exact(tot);
     if (bad) return bad;
     h->max_nodes = nodes;
     return 0;
@@ -571,6 +573,7 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.arena.vstate = h->avs.p;
     a.arena.near_key = h->ankey.p;
     a.arena.near_id = h->anid.p;
+    a.arena.link = h->alink.p;
     a.max_nodes = h->max_nodes;
     a.pop_trace = h->d_trace.p;
     a.trace_cap = h->cfg.trace_pops;
@@ -736,6 +739,7 @@ int pdmpc_destroy(pdmpc_handle* h) {
     h->alog.release();
     h->ankey.release();
     h->anid.release();
+    h->alink.release();
     h->avs.release();
     h->d_out.release();
     h->d_flag.release();

@@ -147,6 +147,7 @@ struct Frontier {
     lds_u32* ready;  // [FR_READY_CAP] 1-based nodes of the running round (0 = not written yet)
     lds_u32* hist;   // [FR_NBINS]
     lds_u32* goal_list;  // [FR_GOAL_CAP] goal candidates of the running round (lives in the histogram's first half: free during a round)
+    unsigned long long* glink;  // [max_nodes] parent | packed << 32
     double* near_key;
     uint32_t* near_id;
     double* far_key;
@@ -278,15 +279,14 @@ __device__ void fr_histogram(const Frontier& F, const double* key, uint32_t n, d
 // created (the reference never creates a).  Sets FRF_TIE on an equality that decides.
 // The whole wave walks together (a wave-uniform loop over per-lane states): a per-lane loop in a divergent branch followed
 // by a ballot is exactly the shape hipcc 7.2 mis-threads (see sh_add_uniform).
-__device__ int fr_check_wave(const Search& S, const VState& VS, const double* gkey, const lds_u32* gp_path, const lds_f64* gp_mp, bool have_goal, bool check_alive,
+__device__ int fr_check_wave(const unsigned long long* glink, const VState& VS, const double* gkey, const lds_u32* gp_path, const lds_f64* gp_mp, bool have_goal, bool check_alive,
                              uint32_t a, volatile lds_u32* sh) {
     int res = a ? 0 : 1;  // 0: still walking
     uint32_t x = a ? a : 1u;
     double mx = -1.0;
     while (__ballot(res == 0)) {
         const uint32_t i = x - 1u;
-        const d2 q = i < S.NL ? (d2)S.ln[4 * (size_t)i + 3] : ((const d2*)(S.gn + i))[3];
-        const uint64_t u = (uint64_t)__double_as_longlong(q.y);
+        const uint64_t u = glink[i];
         const int d = NODE_K((uint32_t)(u >> 32));
         const bool on_path = have_goal && gp_path[d] == x;  // (the candidate's own ancestors are collision-free: it was validated after the last arrival)
         const double m = gp_mp[d];
@@ -557,7 +557,10 @@ __device__ __forceinline__ uint32_t fr_process(const KernelArgs& A, Ctx& X, cons
     (void)expand_children<false, NW>(EE, S, VS, cur, cn, cs, sn, nn, [&](uint64_t mask, bool active, uint32_t i0, double f, int ccnt, const NodeRec& ch) {
         (void)mask;
         (void)ccnt;
-        if (active) F.gkey[i0] = f;
+        if (active) {
+            F.gkey[i0] = f;
+            F.glink[i0] = (unsigned long long)ch.parent | ((unsigned long long)ch.packed << 32);
+        }
         // (no fence here: nothing reads the children's records, keys or list entries before the barrier that ends the round)
         bool mine = false;
         const unsigned long long bj = __ballot(active && f <= l_join);
@@ -655,12 +658,12 @@ __device__ PhaseB fr_phase_b(const KernelArgs& A, Ctx& X, const Frontier& F, con
         uint32_t par = 0, pk_ = 0, vst = 0;
         double key = 0.0;
         if (in) {
-            const d2 q = i < S.NL ? (d2)S.ln[4 * (size_t)i + 3] : ((const d2*)(S.gn + i))[3];
-            const uint64_t u = (uint64_t)__double_as_longlong(q.y);
+            // (keys and links are compact arrays: a pass over 1024 nodes touches 256 lines, not the 1024 lines of their records —
+            // a single CU keeps only so many misses in flight)
+            const uint64_t u = F.glink[i];
             par = (uint32_t)(u & 0xffffffffull);
             pk_ = (uint32_t)(u >> 32);
-            // key = g + h (GraphSearch.m:100-102), the very sum expand_children stored: from the LDS copy of the record where there is one
-            key = i < S.NL ? ((d2)S.ln[4 * (size_t)i + 1]).y + q.x : F.gkey[i];
+            key = F.gkey[i];
             vst = vs_load(VS, i);
         }
         const int depth = NODE_K(pk_);
@@ -709,8 +712,6 @@ __device__ PhaseB fr_phase_b(const KernelArgs& A, Ctx& X, const Frontier& F, con
                 if (resolved) {
                     ch_b[tid] = my_b;
                     ch_d[tid] = my_d | 0x80000000u;  // (after the value it announces: LDS keeps a wave's accesses in order)
-                    st_d[i] = my_d;
-                    st_b[i] = my_b;
                 }
             }
             if (__syncthreads_and(resolved ? 1 : 0)) break;
@@ -720,6 +721,10 @@ __device__ PhaseB fr_phase_b(const KernelArgs& A, Ctx& X, const Frontier& F, con
             }
         }
         ch_d[tid] = 0;  // (nobody reads this chunk's states any more)
+        if (in) {  // for the children in later chunks (stored here, not where the state is found: a barrier waits for the stores in flight)
+            st_d[i] = my_d;
+            st_b[i] = my_b;
+        }
         if (in && (my_d & PB_ALIVE)) {
             int t;
             if (!goal) {
@@ -813,6 +818,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
     F.far_key = A.arena.pop_log + voff;
     F.far_id = A.arena.heap_id + voff;
     F.gkey = S.gkey;
+    F.glink = A.arena.link + voff;
     F.n_waves = n_waves;
     volatile lds_u32* wsum = (volatile lds_u32*)(F.hist + FR_NBINS);  // [32] per-wave counts of fr_partition
 
@@ -845,6 +851,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
         r.packed = (uint32_t)V->trim0;
         node_store(S, 0, r);
         F.gkey[0] = 0.0;
+        F.glink[0] = (unsigned long long)r.parent | ((unsigned long long)r.packed << 32);
         vs_store(VS, 0, VS_UNKNOWN);
         for (int w = FR_NNODES; w < SH_WORDS; ++w) sh[w] = 0;
         sh[FR_NNODES] = 1;
@@ -1222,7 +1229,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                     const bool above = have_goal && k > bb;  // above the candidate's path maximum: comes after it
                     const bool walk = sel && !above && (have_goal || check_alive);
                     if (sel && have_goal && k == bb) atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_TIE);
-                    const int r = fr_check_wave(S, VS, F.gkey, gp_path, gp_mp, have_goal, check_alive, walk ? i : 0u, sh);
+                    const int r = fr_check_wave(F.glink, VS, F.gkey, gp_path, gp_mp, have_goal, check_alive, walk ? i : 0u, sh);
                     const int rest = (spill && b > bspill) ? 2 : 0;
                     return i == 0u ? -1 : (sel ? (above ? 3 : r) : rest);
                 },

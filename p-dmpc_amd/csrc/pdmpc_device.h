@@ -96,6 +96,7 @@ struct NodeArena {  // HBM arrays, per-vehicle stride = max_nodes entries
                       // frontier kernel: keys of the `far` open entries (their nodes in heap_id), phase B: a node's branch maximum
     double* near_key;  // frontier kernel: keys and nodes of the `near` open entries
     uint32_t* near_id;
+    unsigned long long* link;  // frontier kernel: parent | packed << 32 per node, eight nodes to a 64-byte line (a record's own copy shares its line with nothing the walks need)
 };
 
 struct KernelArgs {
