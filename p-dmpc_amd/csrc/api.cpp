@@ -154,6 +154,12 @@ struct pdmpc_handle {
     DevBuf<int32_t> d_tree_size;
     DevBuf<int32_t> d_tie_count;
     DevBuf<unsigned long long> d_work_count;
+    DevBuf<unsigned long long> d_help_board;  // frontier kernel, helper workgroups (pdmpc_device.h)
+    DevBuf<uint32_t> d_help_list, d_help_finished;
+    DevBuf<uint32_t> d_help_verdict;
+    int helpers_max = 64;
+    hipStream_t help_stream = nullptr;  // the helper kernel runs next to the searches, on its own stream
+    hipEvent_t ev_help_pre = nullptr, ev_help_done = nullptr;
     DevBuf<double> d_random;  // sampled optimizer: random numbers of the batch
     int sampled_n_random = 0;
     bool sampled_launch = false;
@@ -631,6 +637,33 @@ int launch_range(pdmpc_handle* h, int first, int count) {
         HIPCHK(hipEventCreate(&e1));
         h->events.emplace_back(e0, e1);
     }
+    // helper workgroups on the CUs this launch leaves idle (frontier kernel, InterX; never when that would put more workgroups
+    // on the chip than it holds at one per CU: a helper spins until every search has finished)
+    a.n_searches = count;
+    a.n_helpers = 0;
+    a.fr_share_min = 128;
+    if (const char* e = getenv("PDMPC_FR_SHARE_MIN")) a.fr_share_min = std::max(64, atoi(e));  // tuning knob
+    if (frontier && !h->sampled_launch && h->cfg.checker == PDMPC_CHECK_INTERX && h->speculate) {
+        int want = h->helpers_max;
+        if (const char* e = getenv("PDMPC_HELPERS")) want = std::max(0, atoi(e));  // A/B switch (0: none): results are identical
+        a.n_helpers = std::max(0, std::min(want, h->n_cu - count));
+        if (a.n_helpers < 2) a.n_helpers = 0;
+    }
+    a.help_board = h->d_help_board.p;
+    a.help_list = h->d_help_list.p;
+    a.help_verdict = h->d_help_verdict.p;
+    a.help_finished = h->d_help_finished.p;
+    if (a.n_helpers > 0) {
+        HIPCHK(hipMemsetAsync(h->d_help_board.p + (size_t)first * PDMPC_HB_WORDS, 0, (size_t)count * PDMPC_HB_WORDS * sizeof(unsigned long long), h->stream));
+        HIPCHK(hipMemsetAsync(h->d_help_finished.p, 0, 16 * sizeof(uint32_t), h->stream));
+        // the helpers start once the boards are clean; everything the launch stream does after the searches also waits for the
+        // helpers to have left (they leave as soon as the last search has published)
+        HIPCHK(hipEventRecord(h->ev_help_pre, h->stream));
+        HIPCHK(hipStreamWaitEvent(h->help_stream, h->ev_help_pre, 0));
+        const int hrc = pdmpc_launch_helpers(&a, (void*)h->help_stream);
+        if (hrc != 0) return fail(PDMPC_ERR_HIP, std::string("helper kernel launch failed: ") + hipGetErrorString((hipError_t)hrc));
+        HIPCHK(hipEventRecord(h->ev_help_done, h->help_stream));
+    }
     auto& ev = h->events[h->events_used++];
     HIPCHK(hipEventRecord(ev.first, h->stream));
     h->last_launch_frontier = frontier;
@@ -657,6 +690,7 @@ int launch_range(pdmpc_handle* h, int first, int count) {
         return fail(PDMPC_ERR_HIP, buf);
     }
     HIPCHK(hipEventRecord(ev.second, h->stream));
+    if (a.n_helpers > 0) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_help_done, 0));
     h->stats.lds_bytes = h->lds.total;
     h->stats.lds_nodes = h->NL;
     h->stats.queue_mode = a.queue_mode;
@@ -700,12 +734,17 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
     const uint32_t want_nodes = config->max_nodes > 0 ? (uint32_t)config->max_nodes : 32768u;  // default arena: 256 x 32768 nodes, about 0.6 GB
     h->max_vehicles = config->max_vehicles > 0 ? config->max_vehicles : 256;
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->help_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_help_pre, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_help_done, hipEventDisableTiming);
     if (e != hipSuccess) {
         delete h;
         return fail(PDMPC_ERR_HIP, "hipStreamCreate failed");
     }
     int bad = alloc_arenas(h, want_nodes);
     bad |= h->d_out.ensure((size_t)h->max_vehicles) | h->d_flag.ensure((size_t)h->max_vehicles) | h->d_tree_size.ensure((size_t)h->max_vehicles) | h->d_tie_count.ensure(4) | h->d_work_count.ensure(4);
+    bad |= h->d_help_board.ensure((size_t)h->max_vehicles * PDMPC_HB_WORDS) | h->d_help_list.ensure((size_t)h->max_vehicles * PDMPC_HELP_CAP) |
+           h->d_help_verdict.ensure((size_t)h->max_vehicles * PDMPC_HELP_CAP) | h->d_help_finished.ensure(16);
     bad |= h->d_trace.ensure((size_t)h->max_vehicles * (size_t)std::max(config->trace_pops, 1));
     if (bad) {
         pdmpc_destroy(h);
@@ -746,9 +785,16 @@ int pdmpc_destroy(pdmpc_handle* h) {
     h->d_tree_size.release();
     h->d_tie_count.release();
     h->d_work_count.release();
+    h->d_help_board.release();
+    h->d_help_list.release();
+    h->d_help_verdict.release();
+    h->d_help_finished.release();
     h->d_random.release();
     h->d_trace.release();
     for (auto& b : h->banks) b.release();
+    if (h->ev_help_pre) (void)hipEventDestroy(h->ev_help_pre);
+    if (h->ev_help_done) (void)hipEventDestroy(h->ev_help_done);
+    if (h->help_stream) (void)hipStreamDestroy(h->help_stream);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return PDMPC_OK;

@@ -66,6 +66,7 @@
 #define FR_GOAL_CAP 1024
 #define FR_JOIN_MAX 26    // (64 bit, words 26-27 of the serial block: unused by both searches) largest key among the round's entries
 #define FR_DEAD 57      // open entries dropped because an ancestor was invalidated
+#define FR_HELP_CLOSED 56 // shared round: entries of the shared part the helpers claimed before the owner closed it
 #define FR_DROPPED 62   // open entries dropped because they come after the best candidate (restored if that one is invalidated)
 #define FRF_OVERFLOW 1u
 #define FRF_TIE 2u
@@ -515,13 +516,13 @@ __device__ bool fr_node_hits_areas(const Search& S, const CheckCtx& C, const Spe
 // it now is no more of a guess than the round's own entries are — and a search that runs straight to the horizon gets there
 // in one round instead of one round per level.
 template <int CHECKER, int NW>
-__device__ __forceinline__ uint32_t fr_process(const KernelArgs& A, Ctx& X, const Frontier& F, const ExpandEnv& EE, uint32_t cur, NodeBits& cu, NodeBits& pu, double l_join) {
+__device__ __forceinline__ uint32_t fr_process(const KernelArgs& A, Ctx& X, const Frontier& F, const ExpandEnv& EE, uint32_t cur, NodeBits& cu, NodeBits& pu, double l_join, bool known_valid = false) {
     const int lane = X.lane, Hp = X.Hp;
     Search& S = X.S;
     const VState& VS = X.VS;
     const uint32_t c0 = cur - 1u;
     const NodeRec& cn = cu.r;  // same record in every lane
-    const bool valid = edge_valid_recs<CHECKER>(X.C, cn, pu.r, lane);
+    const bool valid = known_valid || edge_valid_recs<CHECKER>(X.C, cn, pu.r, lane);  // (known_valid: a helper workgroup has checked the edge)
     if (!valid) {
         if (lane == 0) vs_store(VS, c0, VS_INVALID);
         return 0u;
@@ -904,6 +905,11 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
     };
     const lds_d2* stage = (const lds_d2*)(X.lsm + A.lds.stage);  // [2 * fr_stage_cap] records: node, parent
     uint32_t n_staged = 0;  // ready entries 0 .. n_staged - 1 have their records staged
+    // shared rounds (helper workgroups)
+    unsigned long long* board = A.help_board + (size_t)slot * PDMPC_HB_WORDS;
+    uint32_t* hlist = A.help_list + (size_t)slot * PDMPC_HELP_CAP;
+    const uint32_t* hverdict = A.help_verdict + (size_t)slot * PDMPC_HELP_CAP;
+    uint32_t help_seq = 0;  // rounds shared so far (same value in every thread)
     for (;;) {
         // ================= a round: every wave takes nodes off the ready list until the list is empty =================
         // children up to the largest key the round took may be taken along (fr_process), but none that comes after the best goal candidate
@@ -914,38 +920,140 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
         }
         if (sh[FR_RD_TAIL] > (uint32_t)A.fr_dive) l_join = -1.0;  // (a large round keeps every wave busy as it is; chains only delay its end)
         uint32_t chained = 0;  // nodes this wave processed beyond the round's entries
-        for (;;) {
-            const uint32_t t = sh_add_uniform(sh, FR_RD_HEAD, 1u, lane);
-            if (t >= uni_u(sh[FR_RD_TAIL])) break;
-            uint32_t cur = uni_u(F.ready[t]);
-            // the node's record and its parent's: staged in LDS when the round was selected (one HBM latency per round instead of
-            // two dependent ones per node), else through L2
-            NodeBits cu, pu;
-            if (t < n_staged) {
-                const lds_d2* staged = stage + 8 * (size_t)t;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    cu.q[q] = staged[q];
-                    pu.q[q] = staged[4 + q];
+        // entries RD_HEAD .. RD_TAIL of the ready list, one LDS ticket each; verdicts != nullptr: their edges have been
+        // checked by helper workgroups (verdicts[t - v0]: 1 collision-free, 2 colliding)
+        auto run_ready = [&](const uint32_t* verdicts, uint32_t v0) {
+            for (;;) {
+                const uint32_t t = sh_add_uniform(sh, FR_RD_HEAD, 1u, lane);
+                if (t >= uni_u(sh[FR_RD_TAIL])) break;
+                uint32_t cur = uni_u(F.ready[t]);
+                bool known_valid = false;
+                if (verdicts) {
+                    uint32_t v = uni_u(verdicts[t - v0]);
+                    if (A.debug_tail == 3) {  // debugging: check the helpers' verdict against this workgroup's own (mismatches in counters[3])
+                        const NodeRec dcn = node_load(S, cur - 1u);
+                        const uint32_t dpar = uni_u(dcn.parent);
+                        const NodeRec dpn = node_load(S, dpar ? dpar - 1u : 0u);
+                        const bool own = edge_valid_recs<CHECKER>(X.C, dcn, dpn, lane);
+                        if (lane == 0 && v != (own ? 1u : 2u)) atomicAdd(P.counters + 3, 1);
+                        v = own ? 1u : 2u;
+                    }
+                    if (v == 2u) {
+                        if (lane == 0) vs_store(VS, cur - 1u, VS_INVALID);
+                        continue;
+                    }
+                    known_valid = v == 1u;  // (anything else: not checked after all, e.g. a helper that gave up: check here)
                 }
-            } else {
-                cu.r = node_load(S, cur - 1u);
-                const uint32_t par = uni_u(cu.r.parent);
-                pu.r = node_load(S, par ? par - 1u : 0u);
+                // the node's record and its parent's: staged in LDS when the round was selected (one HBM latency per round instead of
+                // two dependent ones per node), else through L2
+                NodeBits cu, pu;
+                if (t < n_staged) {
+                    const lds_d2* staged = stage + 8 * (size_t)t;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        cu.q[q] = staged[q];
+                        pu.q[q] = staged[4 + q];
+                    }
+                } else {
+                    cu.r = node_load(S, cur - 1u);
+                    const uint32_t par = uni_u(cu.r.parent);
+                    pu.r = node_load(S, par ? par - 1u : 0u);
+                }
+                const unsigned long long tp0 = __builtin_amdgcn_s_memrealtime();
+                for (;;) {  // the node, then the chain of best children the round's key range covers (fr_process)
+                    const uint32_t next = fr_process<CHECKER, NW>(A, X, F, EE, cur, cu, pu, l_join, known_valid);
+                    if (!next) break;
+                    cur = next;
+                    known_valid = false;
+                    ++chained;
+                }
+                if (A.debug_tail && lane == 0) {  // the slowest single entry of this search (ticks << 32 | node)
+                    const unsigned long long dtp = __builtin_amdgcn_s_memrealtime() - tp0;
+                    __hip_atomic_fetch_max((lds_u64s*)(sh + FR_SLOWEST), (dtp << 32) | cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
-            const unsigned long long tp0 = __builtin_amdgcn_s_memrealtime();
-            for (;;) {  // the node, then the chain of best children the round's key range covers (fr_process)
-                const uint32_t next = fr_process<CHECKER, NW>(A, X, F, EE, cur, cu, pu, l_join);
-                if (!next) break;
-                cur = next;
-                ++chained;
-            }
-            if (A.debug_tail && lane == 0) {  // the slowest single entry of this search (ticks << 32 | node)
-                const unsigned long long dtp = __builtin_amdgcn_s_memrealtime() - tp0;
-                __hip_atomic_fetch_max((lds_u64s*)(sh + FR_SLOWEST), (dtp << 32) | cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+        };
+        // A large round is shared with the helper workgroups (CUs this launch leaves idle): the owner keeps the front of the
+        // ready list, the rest is posted; helpers claim entries from its start, check the edges (the expensive half of a node,
+        // and a pure function of the tree and the soups) and leave verdicts; the owner takes what nobody has claimed when it is
+        // through with its own part, waits for the claimed entries and expands the collision-free ones.
+        const uint32_t tail = sh[FR_RD_TAIL];
+        uint32_t n_own = tail, n_sh = 0;
+        if (A.n_helpers > 0 && tail >= (uint32_t)A.fr_share_min && P.n_pred <= 64) {
+            n_own = tail / 8u > 2u * (uint32_t)n_waves ? tail / 8u : 2u * (uint32_t)n_waves;
+            n_sh = tail - n_own;
         }
-        (void)sh_add_uniform(sh, FR_PROCESSED, chained + (tid == 0 ? sh[FR_RD_TAIL] : 0u), lane);  // (the round's size is fixed while it runs)
+        if (n_sh) {  // (uniform)
+            ++help_seq;
+            for (uint32_t e = (uint32_t)tid; e < n_sh; e += blockDim.x) hlist[e] = F.ready[n_own + e];
+            // every wave's stores so far — the list, the records of the tree — must have reached L2 before thread 0 writes L2 back: a
+            // workgroup barrier alone does not wait for them (one CU, one L1: it has no need to)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned long long all = P.n_pred >= 64 ? ~0ull : ((1ull << P.n_pred) - 1ull);
+                __hip_atomic_store(board + PDMPC_HB_N, (unsigned long long)n_sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(board + PDMPC_HB_MASK, all & ~sh_load64(sh, SH_PEND_LO), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(board + PDMPC_HB_DONE, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __hip_atomic_store(board + PDMPC_HB_TICKET, ((unsigned long long)help_seq << 32) | ((unsigned long long)n_sh << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sh[FR_RD_TAIL] = n_own;
+            }
+            __syncthreads();
+        }
+        // phase 0: the owner's part (or the whole round); 1: what no helper has claimed; 2: the entries the helpers have checked
+        // (one copy of the processing code for all three: not unrolled)
+        const int n_phases = n_sh ? 3 : 1;
+#pragma unroll 1
+        for (int phase = 0; phase < n_phases; ++phase) {
+            if (phase == 1) {
+                __syncthreads();
+                if (tid == 0) {  // close the shared part: what no helper has claimed is the owner's
+                    unsigned long long cur = __hip_atomic_load(board + PDMPC_HB_TICKET, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    uint32_t closed = n_sh;
+                    for (;;) {
+                        const uint32_t idx = (uint32_t)(cur & 0xffffull);
+                        if (idx >= n_sh) break;
+                        if (__hip_atomic_compare_exchange_strong(board + PDMPC_HB_TICKET, &cur, ((unsigned long long)help_seq << 32) | ((unsigned long long)n_sh << 16) | n_sh, __ATOMIC_RELAXED,
+                                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                            closed = idx;
+                            break;
+                        }
+                    }
+                    sh[FR_HELP_CLOSED] = closed;
+                    sh[FR_RD_HEAD] = n_own + closed;
+                    sh[FR_RD_TAIL] = tail;
+                }
+                __syncthreads();
+            }
+            if (phase == 2) {
+                __syncthreads();
+                const uint32_t closed = sh[FR_HELP_CLOSED];
+                if (tid == 0) {
+                    if (closed) {  // wait for the helpers' part
+                        uint32_t spins = 0;
+                        while (__hip_atomic_load(board + PDMPC_HB_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)closed) {
+                            __builtin_amdgcn_s_sleep(4);
+                            if (++spins > A.spin_limit) {
+                                atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_BUG);  // reported as an error status: must never happen
+                                break;
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    }
+                    sh[FR_RD_HEAD] = n_own;
+                    sh[FR_RD_TAIL] = (sh[FR_FLAGS] & FRF_BUG) ? n_own : n_own + closed;
+                }
+                __syncthreads();
+            }
+            run_ready(phase == 2 ? hverdict : nullptr, n_own);
+        }
+        if (n_sh) {
+            __syncthreads();
+            if (tid == 0) sh[FR_RD_TAIL] = tail;
+            __syncthreads();
+        }
+        (void)sh_add_uniform(sh, FR_PROCESSED, chained + (tid == 0 ? tail : 0u), lane);  // (the round's size is fixed while it runs)
         __syncthreads();
         FR_TICK(tk_work)
         FR_PROGRESS(1)
@@ -1349,6 +1457,206 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
     return false;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Helper workgroups (pdmpc_helper_kernel, launched next to the searches on a stream of its own — a kernel of its own so that
+// its registers are its own): they look for a search that has posted the shared part of a large round,
+// claim a run of its entries (compare-and-swap on the board's ticket word, which carries the round's sequence number: a
+// claim made on a stale view fails), mirror that search's obstacle soup in their own LDS (literal obstacles, lanelet
+// boundary, the areas of the predecessors the owner had incorporated when it posted), check the entries' edges with the
+// search's own device function and leave one verdict byte per entry.  A helper never waits for anything but memory, so an
+// owner that waits for claimed entries always gets them; helpers leave when every search of the launch has published.
+#define HS_CMD 0     // 0 nothing found, 1 work, 2 every search has finished
+#define HS_SLOT 1
+#define HS_FIRST 2
+#define HS_COUNT 3
+#define HS_MASK_LO 4
+#define HS_MASK_HI 5
+#define HS_TICKET 6
+#define HELP_CHUNK 64u
+template <int CHECKER>
+__device__ __forceinline__ void helper_body(const KernelArgs& A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    LDS_AS unsigned char* lsm = (LDS_AS unsigned char*)smem;
+    const int tid = threadIdx.x, lane = tid & (PDMPC_WAVE - 1), wave = uni_i(tid >> 6);
+    const int Hp = A.Hp, n_s = A.n_searches;
+    // the owners' carve (search_prologue): only the regions an edge check reads are filled
+    lds_u32* l_path = (lds_u32*)(lsm + A.lds.path);
+    lds_i32* l_soff = (lds_i32*)(l_path + PDMPC_HP_MAX + 2);
+    lds_i32* l_hoff = l_soff + PDMPC_HP_MAX + 1;
+    volatile lds_u32* hs = (volatile lds_u32*)(l_hoff + PDMPC_HP_MAX + 1);
+    lds_i32* l_lit = (lds_i32*)(hs + SH_WORDS);
+    lds_d2* l_soup = (lds_d2*)(lsm + A.lds.soup);
+    CheckCtx C;
+    C.l_area = (const lds_d2*)(lsm + A.lds.area);
+    C.g_area = (const d2*)A.man_area;
+    C.l_soup = l_soup;
+    C.l_soff = l_soff;
+    C.l_hoff = l_hoff;
+    C.areas_in_lds = A.areas_in_lds;
+    C.Hp = Hp;
+    C.checker = A.checker;
+    C.sh = (lds_d2*)(lsm + A.lds.shape) + wave * (2 * PDMPC_VMAX + 1);
+    C.tally = (LDS_AS unsigned long long*)(C.sh + 2 * PDMPC_VMAX);
+    C.cand = nullptr;
+    C.ll_base = 0;
+    C.ll_len = 0;
+    if (lane == 0) {
+        C.tally[0] = 0;
+        C.tally[1] = 0;
+    }
+    if (A.areas_in_lds) stage16(lsm + A.lds.area, A.man_area, A.n_man * 3 * PDMPC_VMAX, tid);
+    if (tid < SH_WORDS) hs[tid] = 0;
+    __syncthreads();
+    int cur_slot = -1;
+    unsigned long long cur_mask = 0;
+    const int pref = (int)blockIdx.x % n_s;  // where this helper starts to look
+    SpecCtx P;
+    P.sh = hs;
+    P.l_soup = l_soup;
+    P.l_soff = l_soff;
+    P.l_lit = l_lit;
+    P.out = A.out;
+    P.pred = A.pred;
+    P.counters = A.tie_count;
+    P.n_pred = 0;
+    P.Hp = Hp;
+    uint32_t idle = 0;
+    for (;;) {
+        // ---- look for work: one lane per search, the first one (from pref on) with unclaimed entries is tried
+        if (wave == 0) {
+            uint32_t cmd = 0;
+            for (int base = 0; base < n_s; base += PDMPC_WAVE) {  // (uniform trip count)
+                const int k = base + lane;
+                const int s_rel = k < n_s ? (pref + k) % n_s : 0;
+                const unsigned long long* b = A.help_board + (size_t)(A.first + s_rel) * PDMPC_HB_WORDS;
+                // one word holds the round's sequence number, its shared entries and the next unclaimed one: two loads could be
+                // served out of order and pair one round's count with another round's ticket
+                unsigned long long word = __hip_atomic_load(b + PDMPC_HB_TICKET, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t nsh = (uint32_t)((word >> 16) & 0xffffull);
+                const uint32_t idx = (uint32_t)(word & 0xffffull);
+                const bool has = k < n_s && (word >> 32) != 0ull && idx < nsh;
+                const unsigned long long m = __ballot(has);
+                const int l = m ? (int)__builtin_ctzll(m) : -1;
+                if (lane == l) {  // (one lane; what it finds goes through LDS)
+                    const uint32_t cnt = nsh - idx < HELP_CHUNK ? nsh - idx : HELP_CHUNK;
+                    unsigned long long* bw = A.help_board + (size_t)(A.first + s_rel) * PDMPC_HB_WORDS;
+                    if (__hip_atomic_compare_exchange_strong(bw + PDMPC_HB_TICKET, &word, word + cnt, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        const unsigned long long mask = __hip_atomic_load(b + PDMPC_HB_MASK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        hs[HS_SLOT] = (uint32_t)(A.first + s_rel);
+                        hs[HS_FIRST] = idx;
+                        hs[HS_COUNT] = cnt;
+                        hs[HS_MASK_LO] = (uint32_t)mask;
+                        hs[HS_MASK_HI] = (uint32_t)(mask >> 32);
+                        hs[HS_TICKET] = 0;
+                        hs[HS_CMD] = 1;
+                    }
+                }
+                wave_sync();
+                cmd = uni_u(hs[HS_CMD]);
+                if (cmd) break;  // (uniform)
+            }
+            if (!cmd) {
+                const uint32_t fin = __hip_atomic_load(A.help_finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0 && fin >= (uint32_t)n_s) hs[HS_CMD] = 2;
+            } else {
+                // what the owner wrote before it posted (and the predecessors it had seen) is visible from here on; not on an idle
+                // poll: the fence empties this XCD's L2, which searches on neighbouring CUs share
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+        }
+        __syncthreads();
+        const uint32_t cmd = hs[HS_CMD];
+        if (cmd == 2u) break;
+        if (cmd == 0u) {
+            if (idle < 64u)
+                __builtin_amdgcn_s_sleep(2);
+            else
+                __builtin_amdgcn_s_sleep(32);
+            if (++idle > (A.spin_limit >> 4)) break;  // (uniform) the searches never came: leave; they do without helpers
+            __syncthreads();
+            continue;
+        }
+        idle = 0;
+        const int slot = (int)hs[HS_SLOT];
+        const uint32_t first = hs[HS_FIRST], cnt = hs[HS_COUNT];
+        const unsigned long long mask = ((unsigned long long)hs[HS_MASK_HI] << 32) | hs[HS_MASK_LO];
+        const DevVehicle* __restrict__ V = A.veh + slot;
+        // ---- the search's obstacle soup (search_prologue, parts 3 and 4)
+        if (slot != cur_slot) {
+            const int pred_cols = V->n_pred * PDMPC_VMAX;
+            int off = 0;
+            for (int k = 0; k < Hp; ++k) {
+                const int a = V->lit_off[k], b = V->lit_off[k + 1];
+                if (tid == 0) {
+                    l_soff[k] = off;
+                    l_lit[k] = b - a;
+                }
+                stage16(l_soup + off, (const d2*)A.points + a, b - a, tid);
+                off += (b - a) + pred_cols;
+            }
+            if (tid == 0) l_soff[Hp] = off;
+            for (int k = 0; k < Hp; ++k) {
+                const int a = V->hdv_off[k], b = V->hdv_off[k + 1];
+                if (tid == 0) l_hoff[k] = off;
+                stage16(l_soup + off, (const d2*)A.points + a, b - a, tid);
+                off += (b - a);
+            }
+            if (tid == 0) l_hoff[Hp] = off;
+            stage16(l_soup + off, (const d2*)A.points + V->ll_off, V->ll_len, tid);
+            C.ll_base = off;
+            C.ll_len = V->ll_len;
+            __syncthreads();
+            const d2 nanpt = d2{__longlong_as_double(0x7ff8000000000000LL), __longlong_as_double(0x7ff8000000000000LL)};
+            for (int idx = tid; idx < Hp * pred_cols; idx += (int)blockDim.x) {
+                const int k = idx / pred_cols;
+                l_soup[l_soff[k] + l_lit[k] + (idx - k * pred_cols)] = nanpt;
+            }
+            __syncthreads();
+            P.pred = A.pred + V->pred_off;
+            P.n_pred = V->n_pred;
+            incorporate_areas(P, mask, tid);
+            cur_slot = slot;
+            cur_mask = mask;
+        } else if (mask != cur_mask) {
+            incorporate_areas(P, mask & ~cur_mask, tid);  // (within a launch a search's set of incorporated predecessors only grows)
+            cur_mask = mask;
+        }
+        __syncthreads();
+        // ---- the claimed entries, one per wave at a time
+        {
+            const NodeRec* gn = A.arena.nodes + (size_t)slot * A.max_nodes;
+            const uint32_t* list = A.help_list + (size_t)slot * PDMPC_HELP_CAP;
+            uint32_t* verdict = A.help_verdict + (size_t)slot * PDMPC_HELP_CAP;
+            for (;;) {
+                const uint32_t t = sh_add_uniform(hs, HS_TICKET, 1u, lane);
+                if (t >= cnt) break;
+                const uint32_t e = first + t;
+                const uint32_t cur = uni_u(list[e]);
+                NodeBits cu, pu;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cu.q[q] = ((const d2*)(gn + (cur - 1u)))[q];
+                const uint32_t par = uni_u(cu.r.parent);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pu.q[q] = ((const d2*)(gn + (par ? par - 1u : 0u)))[q];
+                const bool valid = edge_valid_recs<CHECKER>(C, cu.r, pu.r, lane);
+                if (lane == 0) verdict[e] = valid ? 1u : 2u;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's verdicts have reached L2 (the barrier alone does not wait for them) ...
+        __syncthreads();                                     // ... every wave's have: thread 0 can write L2 back and report
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_fetch_add(A.help_board + (size_t)slot * PDMPC_HB_WORDS + PDMPC_HB_DONE, (unsigned long long)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hs[HS_CMD] = 0;
+        }
+        __syncthreads();
+    }
+    if (lane == 0) {
+        atomicAdd(A.work_count + 0, C.tally[0]);
+        atomicAdd(A.work_count + 1, C.tally[1]);
+    }
+}
+
 template <int CHECKER, int NW>
 __device__ __forceinline__ void frontier_body(const KernelArgs& A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1379,6 +1687,7 @@ __device__ __forceinline__ void frontier_body(const KernelArgs& A) {
     __syncthreads();
     if (wave != 0) return;
     search_epilogue(A, X, serial ? nullptr : ref_ids);
+    if (lane == 0 && A.n_helpers > 0) atomicAdd(A.help_finished, 1u);  // (the helpers leave when every search is through)
 }
 
 }  // namespace
@@ -1398,5 +1707,15 @@ extern "C" int pdmpc_launch_frontier(const KernelArgs* args, int count, void* st
     hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)args->lds.total);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(fn, dim3(count), dim3(PDMPC_WAVE * args->n_waves), args->lds.total, (hipStream_t)stream, *args);
+    return (int)hipGetLastError();
+}
+
+extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) void pdmpc_helper_kernel(const KernelArgs A) { helper_body<PDMPC_CHECK_INTERX>(A); }
+
+extern "C" int pdmpc_launch_helpers(const KernelArgs* args, void* stream) {
+    if (args->n_helpers <= 0) return 0;
+    hipError_t e = hipFuncSetAttribute((const void*)pdmpc_helper_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)args->lds.total);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(pdmpc_helper_kernel, dim3(args->n_helpers), dim3(PDMPC_WAVE * args->n_waves), args->lds.total, (hipStream_t)stream, *args);
     return (int)hipGetLastError();
 }

@@ -99,6 +99,13 @@ struct NodeArena {  // HBM arrays, per-vehicle stride = max_nodes entries
     unsigned long long* link;  // frontier kernel: parent | packed << 32 per node, eight nodes to a 64-byte line (a record's own copy shares its line with nothing the walks need)
 };
 
+#define PDMPC_HELP_CAP 1024 /* entries of a round that can be shared (= the ready list's capacity) */
+#define PDMPC_HB_WORDS 8   /* 64-bit words of a board */
+#define PDMPC_HB_TICKET 0
+#define PDMPC_HB_N 1
+#define PDMPC_HB_MASK 2
+#define PDMPC_HB_DONE 3
+
 struct KernelArgs {
     // MPA
     const uint64_t* succ_mask;
@@ -149,6 +156,14 @@ struct KernelArgs {
     double fr_join_scale;  // ... the key range within which a wave goes on with a node's best child, as a multiple of the range the round's own entries span
     int32_t fr_near_max;   // ... size of near beyond which its tail is moved back to far
     int32_t fr_dive;       // ... largest round (entries) in which waves go on with best children (0: never)
+    // frontier kernel, helper workgroups (blockIdx >= n_searches): CUs the launch leaves idle check edges of other workgroups' large rounds
+    int32_t n_searches;              // workgroups of this launch that run a search (the first ones)
+    int32_t n_helpers;               // helper workgroups behind them (0: none)
+    int32_t fr_share_min;            // a round with at least this many entries is shared with the helpers
+    unsigned long long* help_board;  // [slot][8]: ticket = round << 32 | shared entries << 16 | next unclaimed entry, -, incorporated predecessors, entries finished by helpers
+    uint32_t* help_list;             // [slot][PDMPC_HELP_CAP] nodes of the shared part of the round
+    uint32_t* help_verdict;          // [slot][PDMPC_HELP_CAP] 1 collision-free, 2 colliding (written by helpers; a word each: a helper's run of 64 entries owns whole cache lines)
+    uint32_t* help_finished;         // searches of this launch that have published their result
     int32_t speculate;  // 1: start searching before all predecessors have finished (results are identical, see arrival_sync)
     uint32_t spin_limit;
 };
@@ -165,6 +180,8 @@ int pdmpc_launch_heap_script(const int32_t* op, const int32_t* id, const double*
 int pdmpc_launch_sampled(const KernelArgs* args, int count, void* stream);
 // defined in frontier_kernel.hip: the search with all wavefronts of a workgroup working on open nodes side by side
 int pdmpc_launch_frontier(const KernelArgs* args, int count, void* stream);
+// defined in frontier_kernel.hip; launches args->n_helpers helper workgroups (they serve the searches of a pdmpc_launch_frontier with the same args)
+int pdmpc_launch_helpers(const KernelArgs* args, void* stream);
 // defined in debug_kernels.hip: the collision primitives of edge_checks.hpp on given polygons, one wavefront per case
 int pdmpc_launch_edge_check(int mode, int n_cases, const int32_t* a_off, const double* a_x, const double* a_y, const int32_t* b_off, const double* b_x,
                             const double* b_y, int32_t* hit, void* stream);
