@@ -980,7 +980,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
         const uint32_t tail = sh[FR_RD_TAIL];
         uint32_t n_own = tail, n_sh = 0;
         if (A.n_helpers > 0 && tail >= (uint32_t)A.fr_share_min && P.n_pred <= 64) {
-            n_own = tail / 8u > 2u * (uint32_t)n_waves ? tail / 8u : 2u * (uint32_t)n_waves;
+            n_own = tail / (uint32_t)A.fr_own_div > 2u * (uint32_t)n_waves ? tail / (uint32_t)A.fr_own_div : 2u * (uint32_t)n_waves;
             n_sh = tail - n_own;
         }
         if (n_sh) {  // (uniform)
@@ -1472,7 +1472,6 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
 #define HS_MASK_LO 4
 #define HS_MASK_HI 5
 #define HS_TICKET 6
-#define HELP_CHUNK 64u
 template <int CHECKER>
 __device__ __forceinline__ void helper_body(const KernelArgs& A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1538,7 +1537,7 @@ __device__ __forceinline__ void helper_body(const KernelArgs& A) {
                 const unsigned long long m = __ballot(has);
                 const int l = m ? (int)__builtin_ctzll(m) : -1;
                 if (lane == l) {  // (one lane; what it finds goes through LDS)
-                    const uint32_t cnt = nsh - idx < HELP_CHUNK ? nsh - idx : HELP_CHUNK;
+                    const uint32_t cnt = nsh - idx < (uint32_t)A.help_chunk ? nsh - idx : (uint32_t)A.help_chunk;
                     unsigned long long* bw = A.help_board + (size_t)(A.first + s_rel) * PDMPC_HB_WORDS;
                     if (__hip_atomic_compare_exchange_strong(bw + PDMPC_HB_TICKET, &word, word + cnt, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                         const unsigned long long mask = __hip_atomic_load(b + PDMPC_HB_MASK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1627,19 +1626,41 @@ __device__ __forceinline__ void helper_body(const KernelArgs& A) {
             const NodeRec* gn = A.arena.nodes + (size_t)slot * A.max_nodes;
             const uint32_t* list = A.help_list + (size_t)slot * PDMPC_HELP_CAP;
             uint32_t* verdict = A.help_verdict + (size_t)slot * PDMPC_HELP_CAP;
-            for (;;) {
-                const uint32_t t = sh_add_uniform(hs, HS_TICKET, 1u, lane);
-                if (t >= cnt) break;
-                const uint32_t e = first + t;
-                const uint32_t cur = uni_u(list[e]);
-                NodeBits cu, pu;
+            // Four entries per wave at a time, their loads side by side: an entry is three dependent round trips to memory (list ->
+            // node -> parent) and a helper has nothing else to hide them behind.  Of the records only what an edge check reads.
+            const uint32_t nwv = blockDim.x >> 6;
+            for (uint32_t base = (uint32_t)wave; base < cnt; base += 4u * nwv) {
+                uint32_t ee[4], id[4];
+                bool in[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) cu.q[q] = ((const d2*)(gn + (cur - 1u)))[q];
-                const uint32_t par = uni_u(cu.r.parent);
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t t = base + (uint32_t)j * nwv;
+                    in[j] = t < cnt;
+                    ee[j] = first + (in[j] ? t : 0u);
+                    id[j] = list[ee[j]];
+                }
+                d2 c3[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) pu.q[q] = ((const d2*)(gn + (par ? par - 1u : 0u)))[q];
-                const bool valid = edge_valid_recs<CHECKER>(C, cu.r, pu.r, lane);
-                if (lane == 0) verdict[e] = valid ? 1u : 2u;
+                for (int j = 0; j < 4; ++j) c3[j] = ((const d2*)(gn + (uni_u(id[j]) - 1u)))[3];  // h, parent | packed << 32
+                d2 p0[4], p2[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t par = (uint32_t)((uint64_t)__double_as_longlong(c3[j].y) & 0xffffffffull);
+                    const NodeRec* pr = gn + (par ? uni_u(par) - 1u : 0u);
+                    p0[j] = ((const d2*)pr)[0];  // x, y
+                    p2[j] = ((const d2*)pr)[2];  // cos, sin of its yaw
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (in[j]) {  // (uniform)
+                        NodeBits cu, pu;
+                        cu.q[3] = c3[j];
+                        pu.q[0] = p0[j];
+                        pu.q[2] = p2[j];
+                        const bool valid = edge_valid_recs<CHECKER>(C, cu.r, pu.r, lane);
+                        if (lane == 0) verdict[ee[j]] = valid ? 1u : 2u;
+                    }
+                }
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's verdicts have reached L2 (the barrier alone does not wait for them) ...

@@ -160,6 +160,8 @@ struct KernelArgs {
     int32_t n_searches;              // workgroups of this launch that run a search (the first ones)
     int32_t n_helpers;               // helper workgroups behind them (0: none)
     int32_t fr_share_min;            // a round with at least this many entries is shared with the helpers
+    int32_t fr_own_div;              // ... of which the owner keeps 1 / fr_own_div (at least two per wavefront) for itself
+    int32_t help_chunk;              // entries a helper claims at a time (a multiple of 32: its verdict words own whole cache lines)
     unsigned long long* help_board;  // [slot][8]: ticket = round << 32 | shared entries << 16 | next unclaimed entry, -, incorporated predecessors, entries finished by helpers
     uint32_t* help_list;             // [slot][PDMPC_HELP_CAP] nodes of the shared part of the round
     uint32_t* help_verdict;          // [slot][PDMPC_HELP_CAP] 1 collision-free, 2 colliding (written by helpers; a word each: a helper's run of 64 entries owns whole cache lines)
