@@ -920,35 +920,19 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
         }
         if (sh[FR_RD_TAIL] > (uint32_t)A.fr_dive) l_join = -1.0;  // (a large round keeps every wave busy as it is; chains only delay its end)
         uint32_t chained = 0;  // nodes this wave processed beyond the round's entries
-        // entries RD_HEAD .. RD_TAIL of the ready list, one LDS ticket each; verdicts != nullptr: their edges have been
-        // checked by helper workgroups (verdicts[t - v0]: 1 collision-free, 2 colliding)
-        auto run_ready = [&](const uint32_t* verdicts, uint32_t v0) {
+        // entries RD_HEAD .. RD_TAIL of the ready list, one LDS ticket each; entries st0 .. st0 + stn - 1 have their records in the
+        // staging area; checked: helper workgroups have found their edges collision-free
+        auto run_ready = [&](uint32_t st0, uint32_t stn, bool checked) {
             for (;;) {
                 const uint32_t t = sh_add_uniform(sh, FR_RD_HEAD, 1u, lane);
                 if (t >= uni_u(sh[FR_RD_TAIL])) break;
                 uint32_t cur = uni_u(F.ready[t]);
-                bool known_valid = false;
-                if (verdicts) {
-                    uint32_t v = uni_u(verdicts[t - v0]);
-                    if (A.debug_tail == 3) {  // debugging: check the helpers' verdict against this workgroup's own (mismatches in counters[3])
-                        const NodeRec dcn = node_load(S, cur - 1u);
-                        const uint32_t dpar = uni_u(dcn.parent);
-                        const NodeRec dpn = node_load(S, dpar ? dpar - 1u : 0u);
-                        const bool own = edge_valid_recs<CHECKER>(X.C, dcn, dpn, lane);
-                        if (lane == 0 && v != (own ? 1u : 2u)) atomicAdd(P.counters + 3, 1);
-                        v = own ? 1u : 2u;
-                    }
-                    if (v == 2u) {
-                        if (lane == 0) vs_store(VS, cur - 1u, VS_INVALID);
-                        continue;
-                    }
-                    known_valid = v == 1u;  // (anything else: not checked after all, e.g. a helper that gave up: check here)
-                }
+                bool known_valid = checked;
                 // the node's record and its parent's: staged in LDS when the round was selected (one HBM latency per round instead of
                 // two dependent ones per node), else through L2
                 NodeBits cu, pu;
-                if (t < n_staged) {
-                    const lds_d2* staged = stage + 8 * (size_t)t;
+                if (t - st0 < stn) {  // (unsigned: t < st0 is far outside)
+                    const lds_d2* staged = stage + 8 * (size_t)(t - st0);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         cu.q[q] = staged[q];
@@ -1004,6 +988,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
         // phase 0: the owner's part (or the whole round); 1: what no helper has claimed; 2: the entries the helpers have checked
         // (one copy of the processing code for all three: not unrolled)
         const int n_phases = n_sh ? 3 : 1;
+        uint32_t n_chk = 0;  // collision-free helper-checked entries whose records are staged
 #pragma unroll 1
         for (int phase = 0; phase < n_phases; ++phase) {
             if (phase == 1) {
@@ -1041,12 +1026,54 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     }
+                }
+                __syncthreads();
+                // The verdicts in one pass (a load per entry in the processing loop would be a round trip to memory each):
+                // colliding entries are done with, the collision-free ones are packed to the front of the shared part, their
+                // records staged.  (Not checked after all — a helper gave up — cannot happen once it was claimed; the watchdog
+                // above reports it.)
+                const bool ok = !(sh[FR_FLAGS] & FRF_BUG);
+                if (tid == 0) sh[FR_HELP_CLOSED] = 0;  // now: collision-free entries packed so far
+                __syncthreads();
+                for (uint32_t base = 0; base < closed && ok; base += blockDim.x) {  // (uniform trip count)
+                    const uint32_t e = base + (uint32_t)tid;
+                    const bool in = e < closed;
+                    const uint32_t v = in ? hverdict[e] : 0u;
+                    const uint32_t id = in ? F.ready[n_own + e] : 0u;
+                    if (in && v == 2u) vs_store(VS, id - 1u, VS_INVALID);
+                    if (in && v != 1u && v != 2u) atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_BUG);  // (claimed, reported finished, and no verdict)
+                    const unsigned long long bv = __ballot(in && v == 1u);
+                    uint32_t pos = 0;
+                    if (bv) pos = sh_add_uniform(sh, FR_HELP_CLOSED, (uint32_t)__builtin_popcountll(bv), lane) + lane_rank(bv, lane);
+                    __syncthreads();  // every entry of this pass has been read: the packed ones may overwrite them
+                    if (in && v == 1u) F.ready[n_own + pos] = id;
+                }
+                __syncthreads();
+                const uint32_t n_ok = sh[FR_HELP_CLOSED];
+                n_chk = n_ok < (uint32_t)A.fr_stage_cap ? n_ok : (uint32_t)A.fr_stage_cap;
+                {
+                    lds_d2* st = (lds_d2*)(X.lsm + A.lds.stage);
+                    for (uint32_t w0 = (uint32_t)tid; w0 < n_chk * 4u; w0 += blockDim.x) {
+                        const uint32_t e = w0 >> 2, q = w0 & 3u;
+                        st[8 * (size_t)e + q] = ((const d2*)(S.gn + (F.ready[n_own + e] - 1u)))[q];
+                    }
+                    __syncthreads();
+                    for (uint32_t w0 = (uint32_t)tid; w0 < n_chk * 4u; w0 += blockDim.x) {
+                        const uint32_t e = w0 >> 2, q = w0 & 3u;
+                        const uint32_t par = (uint32_t)((uint64_t)__double_as_longlong(st[8 * (size_t)e + 3].y) & 0xffffffffull);
+                        st[8 * (size_t)e + 4 + q] = ((const d2*)(S.gn + (par ? par - 1u : 0u)))[q];
+                    }
+                }
+                if (tid == 0) {
                     sh[FR_RD_HEAD] = n_own;
-                    sh[FR_RD_TAIL] = (sh[FR_FLAGS] & FRF_BUG) ? n_own : n_own + closed;
+                    sh[FR_RD_TAIL] = n_own + n_ok;
                 }
                 __syncthreads();
             }
-            run_ready(phase == 2 ? hverdict : nullptr, n_own);
+            // (one call site: the processing code is instantiated once.  Phase 1: the staging area holds the round's first entries;
+            // what is left of them here, if anything, goes through L2)
+            const uint32_t st0 = phase == 2 ? n_own : 0u, stn = phase == 0 ? n_staged : (phase == 2 ? n_chk : 0u);
+            run_ready(st0, stn, phase == 2);
         }
         if (n_sh) {
             __syncthreads();
