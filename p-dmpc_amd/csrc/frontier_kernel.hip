@@ -968,6 +968,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
             n_sh = tail - n_own;
         }
         if (n_sh) {  // (uniform)
+            if (A.fr_dive < 2048) l_join = -1.0;  // no chains in a shared round: their edge checks would be the owner's, the next round's are the helpers'
             ++help_seq;
             for (uint32_t e = (uint32_t)tid; e < n_sh; e += blockDim.x) hlist[e] = F.ready[n_own + e];
             // every wave's stores so far — the list, the records of the tree — must have reached L2 before thread 0 writes L2 back: a
