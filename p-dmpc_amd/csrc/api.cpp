@@ -157,6 +157,7 @@ struct pdmpc_handle {
     DevBuf<unsigned long long> d_help_board;  // frontier kernel, helper workgroups (pdmpc_device.h)
     DevBuf<uint32_t> d_help_list, d_help_finished;
     DevBuf<uint32_t> d_help_verdict;
+    DevBuf<double> d_help_cs;
     int helpers_max = 64;
     hipStream_t help_stream = nullptr;  // the helper kernel runs next to the searches, on its own stream
     hipEvent_t ev_help_pre = nullptr, ev_help_done = nullptr;
@@ -657,6 +658,7 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.help_board = h->d_help_board.p;
     a.help_list = h->d_help_list.p;
     a.help_verdict = h->d_help_verdict.p;
+    a.help_cs = h->d_help_cs.p;
     a.help_finished = h->d_help_finished.p;
     if (a.n_helpers > 0) {
         HIPCHK(hipMemsetAsync(h->d_help_board.p + (size_t)first * PDMPC_HB_WORDS, 0, (size_t)count * PDMPC_HB_WORDS * sizeof(unsigned long long), h->stream));
@@ -749,7 +751,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
     int bad = alloc_arenas(h, want_nodes);
     bad |= h->d_out.ensure((size_t)h->max_vehicles) | h->d_flag.ensure((size_t)h->max_vehicles) | h->d_tree_size.ensure((size_t)h->max_vehicles) | h->d_tie_count.ensure(4) | h->d_work_count.ensure(4);
     bad |= h->d_help_board.ensure((size_t)h->max_vehicles * PDMPC_HB_WORDS) | h->d_help_list.ensure((size_t)h->max_vehicles * PDMPC_HELP_CAP) |
-           h->d_help_verdict.ensure((size_t)h->max_vehicles * PDMPC_HELP_CAP) | h->d_help_finished.ensure(16);
+           h->d_help_verdict.ensure((size_t)h->max_vehicles * PDMPC_HELP_CAP) | h->d_help_cs.ensure((size_t)h->max_vehicles * PDMPC_HELP_CAP * 2) | h->d_help_finished.ensure(16);
     bad |= h->d_trace.ensure((size_t)h->max_vehicles * (size_t)std::max(config->trace_pops, 1));
     if (bad) {
         pdmpc_destroy(h);
@@ -793,6 +795,7 @@ int pdmpc_destroy(pdmpc_handle* h) {
     h->d_help_board.release();
     h->d_help_list.release();
     h->d_help_verdict.release();
+    h->d_help_cs.release();
     h->d_help_finished.release();
     h->d_random.release();
     h->d_trace.release();

@@ -516,7 +516,7 @@ __device__ bool fr_node_hits_areas(const Search& S, const CheckCtx& C, const Spe
 // it now is no more of a guess than the round's own entries are — and a search that runs straight to the horizon gets there
 // in one round instead of one round per level.
 template <int CHECKER, int NW>
-__device__ __forceinline__ uint32_t fr_process(const KernelArgs& A, Ctx& X, const Frontier& F, const ExpandEnv& EE, uint32_t cur, NodeBits& cu, NodeBits& pu, double l_join, bool known_valid = false) {
+__device__ __forceinline__ uint32_t fr_process(const KernelArgs& A, Ctx& X, const Frontier& F, const ExpandEnv& EE, uint32_t cur, NodeBits& cu, NodeBits& pu, double l_join, bool known_valid = false, bool have_cs = false) {
     const int lane = X.lane, Hp = X.Hp;
     Search& S = X.S;
     const VState& VS = X.VS;
@@ -535,7 +535,12 @@ __device__ __forceinline__ uint32_t fr_process(const KernelArgs& A, Ctx& X, cons
         return 0u;
     }
     double sn, cs;
-    pdmpc_sincos(cn.yaw, &sn, &cs);  // expand_node.m:50-51
+    if (have_cs) {  // (a helper has evaluated them, with the same function: uniform)
+        cs = cn.cs;
+        sn = cn.sn;
+    } else {
+        pdmpc_sincos(cn.yaw, &sn, &cs);  // expand_node.m:50-51
+    }
     if (lane == 0) node_store_cs(S, c0, cs, sn);
     // reserve the children's node indices
     const int n = EE.n, nw = NW > 0 ? NW : EE.nw;
@@ -909,6 +914,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
     unsigned long long* board = A.help_board + (size_t)slot * PDMPC_HB_WORDS;
     uint32_t* hlist = A.help_list + (size_t)slot * PDMPC_HELP_CAP;
     const uint32_t* hverdict = A.help_verdict + (size_t)slot * PDMPC_HELP_CAP;
+    const d2* hcs = (const d2*)A.help_cs + (size_t)slot * PDMPC_HELP_CAP;
     uint32_t help_seq = 0;  // rounds shared so far (same value in every thread)
     for (;;) {
         // ================= a round: every wave takes nodes off the ready list until the list is empty =================
@@ -928,10 +934,12 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                 if (t >= uni_u(sh[FR_RD_TAIL])) break;
                 uint32_t cur = uni_u(F.ready[t]);
                 bool known_valid = checked;
+                bool have_cs = false;
                 // the node's record and its parent's: staged in LDS when the round was selected (one HBM latency per round instead of
                 // two dependent ones per node), else through L2
                 NodeBits cu, pu;
                 if (t - st0 < stn) {  // (unsigned: t < st0 is far outside)
+                    have_cs = checked;  // (staged with the helper's cos / sin in the record's own slot)
                     const lds_d2* staged = stage + 8 * (size_t)(t - st0);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -945,10 +953,11 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                 }
                 const unsigned long long tp0 = __builtin_amdgcn_s_memrealtime();
                 for (;;) {  // the node, then the chain of best children the round's key range covers (fr_process)
-                    const uint32_t next = fr_process<CHECKER, NW>(A, X, F, EE, cur, cu, pu, l_join, known_valid);
+                    const uint32_t next = fr_process<CHECKER, NW>(A, X, F, EE, cur, cu, pu, l_join, known_valid, have_cs);
                     if (!next) break;
                     cur = next;
                     known_valid = false;
+                    have_cs = false;
                     ++chained;
                 }
                 if (A.debug_tail && lane == 0) {  // the slowest single entry of this search (ticks << 32 | node)
@@ -1047,7 +1056,10 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                     uint32_t pos = 0;
                     if (bv) pos = sh_add_uniform(sh, FR_HELP_CLOSED, (uint32_t)__builtin_popcountll(bv), lane) + lane_rank(bv, lane);
                     __syncthreads();  // every entry of this pass has been read: the packed ones may overwrite them
-                    if (in && v == 1u) F.ready[n_own + pos] = id;
+                    if (in && v == 1u) {
+                        F.ready[n_own + pos] = id;
+                        if (pos < (uint32_t)A.fr_stage_cap) ((lds_d2*)(X.lsm + A.lds.stage))[8 * (size_t)pos + 2] = hcs[e];  // the helper's cos / sin of the node's yaw
+                    }
                 }
                 __syncthreads();
                 const uint32_t n_ok = sh[FR_HELP_CLOSED];
@@ -1056,7 +1068,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                     lds_d2* st = (lds_d2*)(X.lsm + A.lds.stage);
                     for (uint32_t w0 = (uint32_t)tid; w0 < n_chk * 4u; w0 += blockDim.x) {
                         const uint32_t e = w0 >> 2, q = w0 & 3u;
-                        st[8 * (size_t)e + q] = ((const d2*)(S.gn + (F.ready[n_own + e] - 1u)))[q];
+                        if (q != 2u) st[8 * (size_t)e + q] = ((const d2*)(S.gn + (F.ready[n_own + e] - 1u)))[q];  // (piece 2 holds the helper's cos / sin)
                     }
                     __syncthreads();
                     for (uint32_t w0 = (uint32_t)tid; w0 < n_chk * 4u; w0 += blockDim.x) {
@@ -1654,6 +1666,7 @@ __device__ __forceinline__ void helper_body(const KernelArgs& A) {
             const NodeRec* gn = A.arena.nodes + (size_t)slot * A.max_nodes;
             const uint32_t* list = A.help_list + (size_t)slot * PDMPC_HELP_CAP;
             uint32_t* verdict = A.help_verdict + (size_t)slot * PDMPC_HELP_CAP;
+            d2* hcs_out = (d2*)A.help_cs + (size_t)slot * PDMPC_HELP_CAP;
             // Four entries per wave at a time, their loads side by side: an entry is three dependent round trips to memory (list ->
             // node -> parent) and a helper has nothing else to hide them behind.  Of the records only what an edge check reads.
             const uint32_t nwv = blockDim.x >> 6;
@@ -1667,9 +1680,12 @@ __device__ __forceinline__ void helper_body(const KernelArgs& A) {
                     ee[j] = first + (in[j] ? t : 0u);
                     id[j] = list[ee[j]];
                 }
-                d2 c3[4];
+                d2 c3[4], c1[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) c3[j] = ((const d2*)(gn + (uni_u(id[j]) - 1u)))[3];  // h, parent | packed << 32
+                for (int j = 0; j < 4; ++j) {
+                    c3[j] = ((const d2*)(gn + (uni_u(id[j]) - 1u)))[3];  // h, parent | packed << 32
+                    c1[j] = ((const d2*)(gn + (uni_u(id[j]) - 1u)))[1];  // yaw, g
+                }
                 d2 p0[4], p2[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -1686,6 +1702,14 @@ __device__ __forceinline__ void helper_body(const KernelArgs& A) {
                         pu.q[0] = p0[j];
                         pu.q[2] = p2[j];
                         const bool valid = edge_valid_recs<CHECKER>(C, cu.r, pu.r, lane);
+                        if (valid && NODE_K(uni_u(cu.r.packed)) < Hp) {  // (uniform) it will be expanded: cos / sin of its yaw (expand_node.m:50-51) on this CU's time
+                            double hsn, hcos;
+                            pdmpc_sincos(c1[j].x, &hsn, &hcos);
+                            d2 t;
+                            t.x = hcos;
+                            t.y = hsn;
+                            if (lane == 0) hcs_out[ee[j]] = t;
+                        }
                         if (lane == 0) verdict[ee[j]] = valid ? 1u : 2u;
                     }
                 }

@@ -165,6 +165,7 @@ struct KernelArgs {
     unsigned long long* help_board;  // [slot][8]: ticket = round << 32 | shared entries << 16 | next unclaimed entry, -, incorporated predecessors, entries finished by helpers
     uint32_t* help_list;             // [slot][PDMPC_HELP_CAP] nodes of the shared part of the round
     uint32_t* help_verdict;          // [slot][PDMPC_HELP_CAP] 1 collision-free, 2 colliding (written by helpers; a word each: a helper's run of 64 entries owns whole cache lines)
+    double* help_cs;                 // [slot][PDMPC_HELP_CAP][2] cos, sin of the yaw of the collision-free entries that will be expanded (written by helpers)
     uint32_t* help_finished;         // searches of this launch that have published their result
     int32_t speculate;  // 1: start searching before all predecessors have finished (results are identical, see arrival_sync)
     uint32_t spin_limit;
