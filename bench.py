@@ -365,6 +365,8 @@ def main():
                 "speculation_wasted_pops_per_step": st["speculation_wasted_pops"] / args.steps,
                 "nodes_processed_per_step": st["nodes_processed"] / args.steps,  # frontier kernel: edges evaluated; nodes_popped of them are the reference's pops
                 "rounds_per_step": st["rounds"] / args.steps,
+                "shared_rounds_per_step": st["shared_rounds"] / args.steps,  # rounds whose edge checks helper workgroups took part in
+                "helper_checked_per_step": st["helper_checked"] / args.steps,
                 "entries_dropped_per_step": st["entries_dropped"] / args.steps,
                 "dropped_counted_as_pops_per_step": st["dropped_counted_as_pops"] / args.steps,
                 "queue_fallbacks_per_step": st["queue_fallbacks"] / args.steps,

@@ -159,6 +159,8 @@ typedef struct {
     int64_t nodes_processed;         /* frontier kernel: nodes whose edge was evaluated (same period; the reference pops nodes_popped of them,
                                         the rest is what the parallel rounds overshoot) */
     int64_t rounds;                  /* frontier kernel: rounds (select a batch of the smallest open keys, process it) */
+    int64_t shared_rounds;           /* ... of which shared with helper workgroups (CUs the launch left idle; same period) */
+    int64_t helper_checked;          /* ... and the nodes whose edges those helpers evaluated (part of nodes_processed) */
 } pdmpc_stats;
 
 /* ---- life cycle (replaces GraphSearch() construction in OptimizerInterface.get_optimizer, :26-27,

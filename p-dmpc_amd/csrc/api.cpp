@@ -749,7 +749,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
         return fail(PDMPC_ERR_HIP, "hipStreamCreate failed");
     }
     int bad = alloc_arenas(h, want_nodes);
-    bad |= h->d_out.ensure((size_t)h->max_vehicles) | h->d_flag.ensure((size_t)h->max_vehicles) | h->d_tree_size.ensure((size_t)h->max_vehicles) | h->d_tie_count.ensure(4) | h->d_work_count.ensure(4);
+    bad |= h->d_out.ensure((size_t)h->max_vehicles) | h->d_flag.ensure((size_t)h->max_vehicles) | h->d_tree_size.ensure((size_t)h->max_vehicles) | h->d_tie_count.ensure(4) | h->d_work_count.ensure(8);
     bad |= h->d_help_board.ensure((size_t)h->max_vehicles * PDMPC_HB_WORDS) | h->d_help_list.ensure((size_t)h->max_vehicles * PDMPC_HELP_CAP) |
            h->d_help_verdict.ensure((size_t)h->max_vehicles * PDMPC_HELP_CAP) | h->d_help_cs.ensure((size_t)h->max_vehicles * PDMPC_HELP_CAP * 2) | h->d_help_finished.ensure(16);
     bad |= h->d_trace.ensure((size_t)h->max_vehicles * (size_t)std::max(config->trace_pops, 1));
@@ -760,7 +760,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
     (void)hipMemsetAsync(h->d_flag.p, 0, h->d_flag.cap * sizeof(uint32_t), h->stream);
     (void)hipMemsetAsync(h->d_tree_size.p, 0, h->d_tree_size.cap * sizeof(int32_t), h->stream);
     (void)hipMemsetAsync(h->d_tie_count.p, 0, 4 * sizeof(int32_t), h->stream);
-    (void)hipMemsetAsync(h->d_work_count.p, 0, 4 * sizeof(unsigned long long), h->stream);
+    (void)hipMemsetAsync(h->d_work_count.p, 0, 8 * sizeof(unsigned long long), h->stream);
     (void)hipMemsetAsync(h->d_out.p, 0, h->d_out.cap * sizeof(pdmpc_vehicle_out), h->stream);
     (void)hipStreamSynchronize(h->stream);
     *out_handle = h;
@@ -771,6 +771,7 @@ int pdmpc_destroy(pdmpc_handle* h) {
     if (!h) return PDMPC_OK;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->help_stream) (void)hipStreamSynchronize(h->help_stream);
     for (auto& ev : h->events) {
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
@@ -902,7 +903,7 @@ int pdmpc_reset_stats(pdmpc_handle* h) {
     HIPCHK(hipStreamSynchronize(h->stream));
     h->events_used = 0;
     HIPCHK(hipMemsetAsync(h->d_tie_count.p, 0, 4 * sizeof(int32_t), h->stream));
-    HIPCHK(hipMemsetAsync(h->d_work_count.p, 0, 4 * sizeof(unsigned long long), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_work_count.p, 0, 8 * sizeof(unsigned long long), h->stream));
     return PDMPC_OK;
 }
 
@@ -1138,7 +1139,7 @@ int pdmpc_get_last_stats(pdmpc_handle* h, pdmpc_stats* stats) {
     h->stats.speculation_restarts = ctr[1];
     h->stats.speculation_arrivals = ctr[2];
     h->stats.speculation_wasted_pops = ctr[3];
-    unsigned long long work[4] = {0, 0, 0, 0};
+    unsigned long long work[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIPCHK(hipMemcpy(work, h->d_work_count.p, sizeof work, hipMemcpyDeviceToHost));
     h->stats.edge_checks = (int64_t)work[0];
     h->stats.segment_pair_tests = (int64_t)work[1];
@@ -1147,6 +1148,8 @@ int pdmpc_get_last_stats(pdmpc_handle* h, pdmpc_stats* stats) {
     h->stats.dropped_counted_as_pops = h->last_launch_frontier ? 0 : (int64_t)work[3];
     h->stats.nodes_processed = h->last_launch_frontier ? (int64_t)work[2] : 0;
     h->stats.rounds = h->last_launch_frontier ? (int64_t)work[3] : 0;
+    h->stats.shared_rounds = (int64_t)work[4];
+    h->stats.helper_checked = (int64_t)work[5];
     *stats = h->stats;
     return PDMPC_OK;
 }

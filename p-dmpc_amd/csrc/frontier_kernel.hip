@@ -1043,7 +1043,11 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                 // records staged.  (Not checked after all — a helper gave up — cannot happen once it was claimed; the watchdog
                 // above reports it.)
                 const bool ok = !(sh[FR_FLAGS] & FRF_BUG);
-                if (tid == 0) sh[FR_HELP_CLOSED] = 0;  // now: collision-free entries packed so far
+                if (tid == 0) {
+                    atomicAdd(A.work_count + 4, 1ull);
+                    atomicAdd(A.work_count + 5, (unsigned long long)closed);
+                    sh[FR_HELP_CLOSED] = 0;  // now: collision-free entries packed so far
+                }
                 __syncthreads();
                 for (uint32_t base = 0; base < closed && ok; base += blockDim.x) {  // (uniform trip count)
                     const uint32_t e = base + (uint32_t)tid;

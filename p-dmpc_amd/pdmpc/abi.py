@@ -126,6 +126,8 @@ class Stats(C.Structure):
         ("kernel", C.c_int64),
         ("nodes_processed", C.c_int64),
         ("rounds", C.c_int64),
+        ("shared_rounds", C.c_int64),
+        ("helper_checked", C.c_int64),
     ]
 
 

@@ -4,6 +4,7 @@ The bar is bit-exactness: result records byte-identical, node-pop sequence ident
 identical (x, y, yaw, g, h as raw IEEE bits; trim, k, parent as integers).
 """
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -305,6 +306,10 @@ def test_random_road_problems_never_fall_back():
         {"PDMPC_FR_JOIN_SCALE": "1000"},
         {"PDMPC_FR_JOIN_SCALE": "0.25", "PDMPC_FR_DIVE": "16"},
         {"PDMPC_FR_TWO_PER_CU": "1", "PDMPC_WAVES": "8"},
+        {"PDMPC_HELPERS": "0"},
+        {"PDMPC_HELPERS": "3", "PDMPC_FR_SHARE_MIN": "64", "PDMPC_HELP_CHUNK": "32"},
+        {"PDMPC_HELPERS": "200", "PDMPC_FR_SHARE_MIN": "64", "PDMPC_FR_OWN_DIV": "2"},
+        {"PDMPC_FR_SHARE_MIN": "64", "PDMPC_FR_OWN_DIV": "64", "PDMPC_HELP_CHUNK": "128"},
     ],
 )
 def test_tuning_switches_do_not_change_results(env, monkeypatch):
@@ -317,3 +322,18 @@ def test_tuning_switches_do_not_change_results(env, monkeypatch):
     check_batch(options, mpa, iters)
     options, mpa, iters = problems.problem_set("sat", 6, 6, Hp=6)
     check_batch(options, mpa, iters)
+
+
+def test_helper_workgroups_take_part_and_change_nothing():
+    """Large rounds are shared with helper workgroups on the CUs the launch leaves idle (frontier_kernel.hip, helper_body): they
+    check edges for the searches and the records stay those of the oracle — here with the threshold low enough that most rounds
+    of the heavier searches are shared, and the statistics say so."""
+    os.environ["PDMPC_FR_SHARE_MIN"] = "64"
+    try:
+        for seed in (2, 5):
+            options, mpa, iters = problems.problem_set("interx", seed, 24, Hp=6)
+            gpu, stats = check_batch(options, mpa, iters)
+            assert stats["shared_rounds"] > 0 and stats["helper_checked"] > 0, stats
+            assert stats["helper_checked"] < stats["nodes_processed"]
+    finally:
+        del os.environ["PDMPC_FR_SHARE_MIN"]
