@@ -654,6 +654,15 @@ int launch_range(pdmpc_handle* h, int first, int count) {
         if (const char* e = getenv("PDMPC_HELPERS")) want = std::max(0, atoi(e));  // A/B switch (0: none): results are identical
         a.n_helpers = std::max(0, std::min(want, h->n_cu - count));
         if (a.n_helpers < 2) a.n_helpers = 0;
+        if (count > h->n_cu) {
+            // More searches than CUs: the helpers are there for the tail of the launch, when CUs fall idle while a few long searches
+            // still run; until then they cost the CUs they sit on (their stream has the lowest priority, a search that is waiting
+            // for a CU gets it first).  Measured on C4 (512 searches) / C5 (1280): none 25.6 / 352 steps/s, 16 helpers 38.5 / 353,
+            // 32: 41.5 / 352, 64: 43.4 / 332, 96: 42.8 / 299.
+            a.n_helpers = count <= 2 * h->n_cu ? 64 : 32;
+            if (const char* e = getenv("PDMPC_HELPERS_OVERSUB")) a.n_helpers = std::max(0, std::min(atoi(e), h->n_cu / 2));  // tuning knob
+            if (const char* e = getenv("PDMPC_HELPERS")) a.n_helpers = std::min(a.n_helpers, std::max(0, atoi(e)));           // (0 switches every helper off)
+        }
     }
     a.help_board = h->d_help_board.p;
     a.help_list = h->d_help_list.p;
@@ -741,7 +750,11 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
     const uint32_t want_nodes = config->max_nodes > 0 ? (uint32_t)config->max_nodes : 32768u;  // default arena: 256 x 32768 nodes, about 0.6 GB
     h->max_vehicles = config->max_vehicles > 0 ? config->max_vehicles : 256;
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->help_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) {  // the helpers' stream has the lowest priority: where searches and helpers compete for a CU, the search gets it
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        e = hipStreamCreateWithPriority(&h->help_stream, hipStreamNonBlocking, prio_lo);
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_help_pre, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_help_done, hipEventDisableTiming);
     if (e != hipSuccess) {
