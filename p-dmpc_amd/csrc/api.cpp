@@ -646,11 +646,11 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     if (const char* e = getenv("PDMPC_FR_SHARE_MIN")) a.fr_share_min = std::max(64, atoi(e));  // tuning knob
     a.fr_own_div = 8;
     if (const char* e = getenv("PDMPC_FR_OWN_DIV")) a.fr_own_div = std::max(1, atoi(e));  // tuning knob
-    a.help_chunk = 64;
-    if (const char* e = getenv("PDMPC_HELP_CHUNK")) a.help_chunk = std::max(32, atoi(e) / 32 * 32);  // tuning knob
+    a.help_chunk = 0;  // (default chosen below, once it is known whether the helpers expand)
+    if (const char* e = getenv("PDMPC_HELP_CHUNK")) a.help_chunk = std::min(128, std::max(32, atoi(e) / 32 * 32));  // tuning knob
     if (frontier && !h->sampled_launch && h->cfg.checker == PDMPC_CHECK_INTERX && h->speculate) {
         // (measured on C2, 20 searches, / C3, 128: 8 helpers 535 / 476 steps/s, 16: 529 / 506, 32: 516 / 522, 128: 507 / 483)
-        int want = std::min(h->helpers_max, std::max(8, count / 4));
+        int want = std::min(h->helpers_max, std::max(32, count / 2));  // (helpers that expand: the owner of a shared round waits for them, more of them with shorter runs finish sooner)
         if (const char* e = getenv("PDMPC_HELPERS")) want = std::max(0, atoi(e));  // A/B switch (0: none): results are identical
         a.n_helpers = std::max(0, std::min(want, h->n_cu - count));
         if (a.n_helpers < 2) a.n_helpers = 0;
@@ -668,6 +668,12 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.help_list = h->d_help_list.p;
     a.help_verdict = h->d_help_verdict.p;
     a.help_cs = h->d_help_cs.p;
+    a.help_expand = 1;
+    if (const char* e = getenv("PDMPC_HELP_EXPAND")) a.help_expand = atoi(e) != 0;  // A/B switch: results are identical
+    a.help_patience = 8;
+    if (const char* e = getenv("PDMPC_HELP_PATIENCE")) a.help_patience = std::max(0, atoi(e));  // tuning knob
+    if (h->n_words != 1 || h->fr_stage_cap < 128 || count > h->n_cu) a.help_expand = 0;  // (the helper kernel expands one successor-mask word per node; a run's records sit in its staging area; with more searches than CUs helpers are scarce and an owner that waits for them loses: C5 332 against 355 steps/s)
+    if (a.help_chunk == 0) a.help_chunk = a.help_expand ? 32 : 64;  // measured on C2 / C3: expanding helpers 64 -> 555 / 595 steps/s, 32 -> 595 / 584; checking only: 64 best (C4 43.3 against 40.9)
     a.help_finished = h->d_help_finished.p;
     if (a.n_helpers > 0) {
         HIPCHK(hipMemsetAsync(h->d_help_board.p + (size_t)first * PDMPC_HB_WORDS, 0, (size_t)count * PDMPC_HB_WORDS * sizeof(unsigned long long), h->stream));
@@ -764,7 +770,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
     int bad = alloc_arenas(h, want_nodes);
     bad |= h->d_out.ensure((size_t)h->max_vehicles) | h->d_flag.ensure((size_t)h->max_vehicles) | h->d_tree_size.ensure((size_t)h->max_vehicles) | h->d_tie_count.ensure(4) | h->d_work_count.ensure(8);
     bad |= h->d_help_board.ensure((size_t)h->max_vehicles * PDMPC_HB_WORDS) | h->d_help_list.ensure((size_t)h->max_vehicles * PDMPC_HELP_CAP) |
-           h->d_help_verdict.ensure((size_t)h->max_vehicles * PDMPC_HELP_CAP) | h->d_help_cs.ensure((size_t)h->max_vehicles * PDMPC_HELP_CAP * 2) | h->d_help_finished.ensure(16);
+           h->d_help_verdict.ensure((size_t)h->max_vehicles * PDMPC_HELP_CAP) | h->d_help_cs.ensure((size_t)h->max_vehicles * PDMPC_HELP_CAP * 2) |  h->d_help_finished.ensure(16);
     bad |= h->d_trace.ensure((size_t)h->max_vehicles * (size_t)std::max(config->trace_pops, 1));
     if (bad) {
         pdmpc_destroy(h);

@@ -439,6 +439,9 @@ __device__ void fr_resolve_goals(const Frontier& F, const Search& S, int tid, in
 // Children of one expansion join the open set: near or far by key.  (They never join the running round: the reference pops
 // the smallest open key next, and a round that also swallowed everything its own nodes generate would walk whole subtrees
 // the reference leaves as soon as it reaches the horizon.)  Whole wave calls.
+// BULK: most lanes carry a child (the pass over the children helper workgroups created): the lists' key ranges are folded per
+// wave, not per lane.
+template <bool BULK = false>
 __device__ __forceinline__ void fr_push_children(const Frontier& F, bool active, uint32_t i0, double f, int lane) {
     const double l_far = sh_ld_d(F.sh, FR_L_FAR);
     const int cls = active ? (f > l_far ? 2 : 1) : -1;
@@ -449,9 +452,12 @@ __device__ __forceinline__ void fr_push_children(const Frontier& F, bool active,
             const uint32_t pos = base + lane_rank(b1, lane);
             F.near_key[pos] = f;
             F.near_id[pos] = i0 + 1u;
-            sh_min_d(F.sh, FR_NEAR_MIN, f);
-            sh_max_d(F.sh, FR_NEAR_MAX, f);
+            if (!BULK) {
+                sh_min_d(F.sh, FR_NEAR_MIN, f);
+                sh_max_d(F.sh, FR_NEAR_MAX, f);
+            }
         }
+        if (BULK) sh_minmax_wave(F.sh, FR_NEAR_MIN, FR_NEAR_MAX, cls == 1 ? f : __longlong_as_double(0x7FF0000000000000LL), cls == 1 ? f : 0.0, lane);
     }
     const unsigned long long b2 = __ballot(cls == 2);
     if (b2) {
@@ -460,9 +466,12 @@ __device__ __forceinline__ void fr_push_children(const Frontier& F, bool active,
             const uint32_t pos = base + lane_rank(b2, lane);
             F.far_key[pos] = f;
             F.far_id[pos] = i0 + 1u;
-            sh_min_d(F.sh, FR_FAR_MIN, f);
-            sh_max_d(F.sh, FR_FAR_MAX, f);
+            if (!BULK) {
+                sh_min_d(F.sh, FR_FAR_MIN, f);
+                sh_max_d(F.sh, FR_FAR_MAX, f);
+            }
         }
+        if (BULK) sh_minmax_wave(F.sh, FR_FAR_MIN, FR_FAR_MAX, cls == 2 ? f : __longlong_as_double(0x7FF0000000000000LL), cls == 2 ? f : 0.0, lane);
     }
 }
 
@@ -972,8 +981,10 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
         // through with its own part, waits for the claimed entries and expands the collision-free ones.
         const uint32_t tail = sh[FR_RD_TAIL];
         uint32_t n_own = tail, n_sh = 0;
+        const bool hx = A.help_expand != 0 && sh[FR_NNODES] >= S.NL;  // helpers also expand (the round's new nodes then lie beyond the LDS copies)
         if (A.n_helpers > 0 && tail >= (uint32_t)A.fr_share_min && P.n_pred <= 64) {
             n_own = tail / (uint32_t)A.fr_own_div > 2u * (uint32_t)n_waves ? tail / (uint32_t)A.fr_own_div : 2u * (uint32_t)n_waves;
+            if (hx) n_own = 0;  // (node indices come from the board while helpers expand: the owner creates no nodes meanwhile)
             n_sh = tail - n_own;
         }
         if (n_sh) {  // (uniform)
@@ -989,23 +1000,41 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                 __hip_atomic_store(board + PDMPC_HB_N, (unsigned long long)n_sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(board + PDMPC_HB_MASK, all & ~sh_load64(sh, SH_PEND_LO), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(board + PDMPC_HB_DONE, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(board + PDMPC_HB_NNODES, (unsigned long long)sh[FR_NNODES], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(board + PDMPC_HB_FLAGS, hx ? 2ull : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // bit 1: expand what you find collision-free
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 __hip_atomic_store(board + PDMPC_HB_TICKET, ((unsigned long long)help_seq << 32) | ((unsigned long long)n_sh << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 sh[FR_RD_TAIL] = n_own;
             }
             __syncthreads();
         }
-        // phase 0: the owner's part (or the whole round); 1: what no helper has claimed; 2: the entries the helpers have checked
-        // (one copy of the processing code for all three: not unrolled)
+        // Phase 0: the owner's part (or the whole round).  Then: close the shared part (what no helper has claimed is the owner's:
+        // the remainder) and collect what the helpers did.  Helpers that only check: remainder in phase 1 (while the helpers finish),
+        // collect + expand the collision-free entries in phase 2.  Helpers that expand: close + collect in phase 1 (the node counter
+        // comes back from the board; left to do are the goal tests of the collision-free entries at the horizon), remainder in
+        // phase 2.  (One copy of the processing code for all phases: not unrolled.)
         const int n_phases = n_sh ? 3 : 1;
-        uint32_t n_chk = 0;  // collision-free helper-checked entries whose records are staged
+        const int collect_phase = hx ? 1 : 2, remainder_phase = hx ? 2 : 1;
+        uint32_t n_chk = 0;      // collected entries whose records are staged
+        uint32_t closed_at = 0;  // shared entries the helpers claimed
+        const uint32_t nn_post = sh[FR_NNODES];  // (no node is created between here and the posting)
 #pragma unroll 1
         for (int phase = 0; phase < n_phases; ++phase) {
             if (phase == 1) {
                 __syncthreads();
-                if (tid == 0) {  // close the shared part: what no helper has claimed is the owner's
+                if (tid == 0) {  // close the shared part
                     unsigned long long cur = __hip_atomic_load(board + PDMPC_HB_TICKET, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     uint32_t closed = n_sh;
+                    if (hx) {  // (nothing of its own to do meanwhile: the owner gives the helpers time to claim, and closes when the claims stall)
+                        uint32_t last = (uint32_t)(cur & 0xffffull), stall = 0;
+                        while (last < n_sh && stall < (uint32_t)A.help_patience) {
+                            __builtin_amdgcn_s_sleep(8);
+                            cur = __hip_atomic_load(board + PDMPC_HB_TICKET, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const uint32_t idx = (uint32_t)(cur & 0xffffull);
+                            stall = idx == last ? stall + 1u : 0u;
+                            last = idx;
+                        }
+                    }
                     for (;;) {
                         const uint32_t idx = (uint32_t)(cur & 0xffffull);
                         if (idx >= n_sh) break;
@@ -1016,14 +1045,21 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                         }
                     }
                     sh[FR_HELP_CLOSED] = closed;
-                    sh[FR_RD_HEAD] = n_own + closed;
+                }
+                __syncthreads();
+                closed_at = sh[FR_HELP_CLOSED];
+            }
+            if (phase >= 1 && phase == remainder_phase) {
+                __syncthreads();
+                if (tid == 0) {
+                    sh[FR_RD_HEAD] = n_own + closed_at;
                     sh[FR_RD_TAIL] = tail;
                 }
                 __syncthreads();
             }
-            if (phase == 2) {
+            if (phase >= 1 && phase == collect_phase) {
                 __syncthreads();
-                const uint32_t closed = sh[FR_HELP_CLOSED];
+                const uint32_t closed = closed_at;
                 if (tid == 0) {
                     if (closed) {  // wait for the helpers' part
                         uint32_t spins = 0;
@@ -1036,17 +1072,23 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     }
+                    sh[FR_VLIST_N] = 0;
+                    if (hx) {  // the node counter comes back; the children the helpers created wait in the child buffer
+                        const unsigned long long nn = __hip_atomic_load(board + PDMPC_HB_NNODES, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long fl = __hip_atomic_load(board + PDMPC_HB_FLAGS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        sh[FR_NNODES] = (uint32_t)nn;
+                        if (fl & 1ull) atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_OVERFLOW);
+                    }
                 }
                 __syncthreads();
-                // The verdicts in one pass (a load per entry in the processing loop would be a round trip to memory each):
-                // colliding entries are done with, the collision-free ones are packed to the front of the shared part, their
-                // records staged.  (Not checked after all — a helper gave up — cannot happen once it was claimed; the watchdog
-                // above reports it.)
+                // The verdicts in one pass (a load per entry in the processing loop would be a round trip to memory each): 2 collides,
+                // 1 collision-free (expanded, if helpers expand), 3 collision-free at the horizon, 4 collision-free but the arena is full.
+                // What is left to do for an entry is packed to the front of the shared part and its records are staged.
                 const bool ok = !(sh[FR_FLAGS] & FRF_BUG);
                 if (tid == 0) {
                     atomicAdd(A.work_count + 4, 1ull);
                     atomicAdd(A.work_count + 5, (unsigned long long)closed);
-                    sh[FR_HELP_CLOSED] = 0;  // now: collision-free entries packed so far
+                    sh[FR_HELP_CLOSED] = 0;  // now: entries packed so far
                 }
                 __syncthreads();
                 for (uint32_t base = 0; base < closed && ok; base += blockDim.x) {  // (uniform trip count)
@@ -1055,20 +1097,39 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                     const uint32_t v = in ? hverdict[e] : 0u;
                     const uint32_t id = in ? F.ready[n_own + e] : 0u;
                     if (in && v == 2u) vs_store(VS, id - 1u, VS_INVALID);
-                    if (in && v != 1u && v != 2u) atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_BUG);  // (claimed, reported finished, and no verdict)
-                    const unsigned long long bv = __ballot(in && v == 1u);
+                    if (in && (v < 1u || v > 4u)) atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_BUG);  // (claimed, reported finished, and no verdict)
+                    if (in && v == 4u) atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_OVERFLOW);
+                    if (in && hx && (v == 1u || v == 4u)) {  // expanded by a helper (4: found collision-free, then the arena was full)
+                        vs_store(VS, id - 1u, VS_VALID);
+                        if (v == 1u && id - 1u < S.NL) S.ln[4 * (size_t)(id - 1u) + 2] = hcs[e];  // (the LDS copy of its record: cos / sin of its yaw)
+                    }
+                    const bool todo = in && (hx ? v == 3u : (v == 1u || v == 3u));
+                    const unsigned long long bv = __ballot(todo);
                     uint32_t pos = 0;
                     if (bv) pos = sh_add_uniform(sh, FR_HELP_CLOSED, (uint32_t)__builtin_popcountll(bv), lane) + lane_rank(bv, lane);
                     __syncthreads();  // every entry of this pass has been read: the packed ones may overwrite them
-                    if (in && v == 1u) {
+                    if (todo) {
                         F.ready[n_own + pos] = id;
-                        if (pos < (uint32_t)A.fr_stage_cap) ((lds_d2*)(X.lsm + A.lds.stage))[8 * (size_t)pos + 2] = hcs[e];  // the helper's cos / sin of the node's yaw
+                        if (pos < (uint32_t)A.fr_stage_cap) ((lds_d2*)(X.lsm + A.lds.stage))[8 * (size_t)pos + 2] = hcs[e];  // the helper's cos / sin of the node's yaw (unused at the horizon)
+                    }
+                }
+                __syncthreads();
+                // the children the helpers created (node indices from the counter at posting time up to where it stands now): validity
+                // unknown, into the open lists by key (fr_push_children)
+                {
+                    const uint32_t i_lo = nn_post, i_hi = sh[FR_NNODES] < S.max_nodes ? sh[FR_NNODES] : S.max_nodes;
+                    for (uint32_t base = i_lo; base < i_hi && ok && hx; base += blockDim.x) {  // (uniform trip count)
+                        const uint32_t i = base + (uint32_t)tid;
+                        const bool in = i < i_hi;
+                        const double k = in ? F.gkey[i] : 0.0;
+                        if (in) vs_store(VS, i, 0);
+                        fr_push_children<true>(F, in, in ? i : 0u, k, lane);
                     }
                 }
                 __syncthreads();
                 const uint32_t n_ok = sh[FR_HELP_CLOSED];
                 n_chk = n_ok < (uint32_t)A.fr_stage_cap ? n_ok : (uint32_t)A.fr_stage_cap;
-                {
+                if (n_chk) {  // (uniform)
                     lds_d2* st = (lds_d2*)(X.lsm + A.lds.stage);
                     for (uint32_t w0 = (uint32_t)tid; w0 < n_chk * 4u; w0 += blockDim.x) {
                         const uint32_t e = w0 >> 2, q = w0 & 3u;
@@ -1082,15 +1143,17 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                     }
                 }
                 if (tid == 0) {
+                    sh[FR_VLIST_N] = 0;
                     sh[FR_RD_HEAD] = n_own;
                     sh[FR_RD_TAIL] = n_own + n_ok;
                 }
                 __syncthreads();
             }
-            // (one call site: the processing code is instantiated once.  Phase 1: the staging area holds the round's first entries;
-            // what is left of them here, if anything, goes through L2)
-            const uint32_t st0 = phase == 2 ? n_own : 0u, stn = phase == 0 ? n_staged : (phase == 2 ? n_chk : 0u);
-            run_ready(st0, stn, phase == 2);
+            // (one call site: the processing code is instantiated once.  Remainder: the staging area holds the round's first entries;
+            // what is left of them there, if anything, goes through L2)
+            const bool collected = phase >= 1 && phase == collect_phase;
+            const uint32_t st0 = collected ? n_own : 0u, stn = phase == 0 ? n_staged : (collected ? n_chk : 0u);
+            run_ready(st0, stn, collected);
         }
         if (n_sh) {
             __syncthreads();
@@ -1516,6 +1579,9 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
 #define HS_MASK_LO 4
 #define HS_MASK_HI 5
 #define HS_TICKET 6
+#define HS_EXPAND 7  // the claimed round wants its collision-free entries expanded
+#define HS_RUN_BASE 8   // first node index of the block the run's children get
+#define HS_RUN_TOTAL 9  // children of the run
 template <int CHECKER>
 __device__ __forceinline__ void helper_body(const KernelArgs& A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1548,6 +1614,32 @@ __device__ __forceinline__ void helper_body(const KernelArgs& A) {
         C.tally[1] = 0;
     }
     if (A.areas_in_lds) stage16(lsm + A.lds.area, A.man_area, A.n_man * 3 * PDMPC_VMAX, tid);
+    // what an expansion reads (search_prologue, parts 1 and 2): the automaton's tables once, the reference trajectory per search
+    const int n = A.n_trims, nw = A.n_words;
+    lds_mask64* l_mask = (lds_mask64*)(lsm + A.lds.mask);
+    lds_i16* l_mi = (lds_i16*)(lsm + A.lds.man_index);
+    lds_pose* l_pose = (lds_pose*)(lsm + A.lds.pose);
+    lds_f64* l_rx = (lds_f64*)(lsm + A.lds.ref);
+    lds_f64* l_ry = l_rx + PDMPC_HP_MAX;
+    lds_f64* l_dcum = (lds_f64*)(lsm + A.lds.expand);
+    if (A.help_expand) {
+        stage16(l_mask, A.succ_mask, (Hp * n * nw * 8 + 15) / 16, tid);
+        stage16(l_mi, A.man_index, (n * n * 2 + 15) / 16, tid);
+        stage16(l_pose, A.man_pose, A.n_man * 2, tid);
+    }
+    ExpandEnv EE;
+    EE.l_mask = l_mask;
+    EE.l_mi = l_mi;
+    EE.l_pose = l_pose;
+    EE.l_rx = l_rx;
+    EE.l_ry = l_ry;
+    EE.l_dcum = l_dcum;
+    EE.l_term = (lds_f64*)((lds_u32*)(lsm + A.lds.cand) + (size_t)wave * A.cand_cap);  // this wave's scratch (as in the searches)
+    EE.l_chxy = (lds_d2*)(EE.l_term + 16 * PDMPC_HP_MAX);
+    EE.Hp = Hp;
+    EE.n = n;
+    EE.nw = nw;
+    EE.lane = lane;
     if (tid < SH_WORDS) hs[tid] = 0;
     __syncthreads();
     int cur_slot = -1;
@@ -1590,6 +1682,7 @@ __device__ __forceinline__ void helper_body(const KernelArgs& A) {
                         hs[HS_COUNT] = cnt;
                         hs[HS_MASK_LO] = (uint32_t)mask;
                         hs[HS_MASK_HI] = (uint32_t)(mask >> 32);
+                        hs[HS_EXPAND] = (uint32_t)((__hip_atomic_load(b + PDMPC_HB_FLAGS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 1) & 1ull);
                         hs[HS_TICKET] = 0;
                         hs[HS_CMD] = 1;
                     }
@@ -1623,6 +1716,7 @@ __device__ __forceinline__ void helper_body(const KernelArgs& A) {
         const int slot = (int)hs[HS_SLOT];
         const uint32_t first = hs[HS_FIRST], cnt = hs[HS_COUNT];
         const unsigned long long mask = ((unsigned long long)hs[HS_MASK_HI] << 32) | hs[HS_MASK_LO];
+        const bool expand_round = A.help_expand != 0 && hs[HS_EXPAND] != 0u;
         const DevVehicle* __restrict__ V = A.veh + slot;
         // ---- the search's obstacle soup (search_prologue, parts 3 and 4)
         if (slot != cur_slot) {
@@ -1658,12 +1752,31 @@ __device__ __forceinline__ void helper_body(const KernelArgs& A) {
             P.pred = A.pred + V->pred_off;
             P.n_pred = V->n_pred;
             incorporate_areas(P, mask, tid);
+            if (A.help_expand) {  // (search_prologue, part 2)
+                if (tid < Hp) {
+                    l_rx[tid] = V->ref_x[tid];
+                    l_ry[tid] = V->ref_y[tid];
+                }
+                if (tid >= PDMPC_WAVE && tid < PDMPC_WAVE + Hp) {
+                    const int k_exp = tid - PDMPC_WAVE + 1;
+                    double d = 0.0;
+                    for (int it = 1; it <= Hp - k_exp; ++it) {
+                        d = d + A.dt * V->v_ref[k_exp + it - 1];
+                        l_dcum[(k_exp - 1) * PDMPC_HP_MAX + (it - 1)] = d;
+                    }
+                }
+            }
             cur_slot = slot;
             cur_mask = mask;
         } else if (mask != cur_mask) {
             incorporate_areas(P, mask & ~cur_mask, tid);  // (within a launch a search's set of incorporated predecessors only grows)
             cur_mask = mask;
         }
+        __syncthreads();
+        lds_u32* r_cnt = (lds_u32*)(lsm + A.lds.stage);      // [128] children of the run's entries that will be expanded (0: none)
+        lds_u32* r_off = r_cnt + 128;                          // [128] their offsets in the run's block of node indices
+        lds_d2* r_rec = (lds_d2*)(r_off + 128);                // [128][4] their records (piece 2: cos / sin of the yaw)
+        if (tid < 128) r_cnt[tid] = 0;
         __syncthreads();
         // ---- the claimed entries, one per wave at a time
         {
@@ -1684,11 +1797,12 @@ __device__ __forceinline__ void helper_body(const KernelArgs& A) {
                     ee[j] = first + (in[j] ? t : 0u);
                     id[j] = list[ee[j]];
                 }
-                d2 c3[4], c1[4];
+                d2 c3[4], c1[4], c0[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     c3[j] = ((const d2*)(gn + (uni_u(id[j]) - 1u)))[3];  // h, parent | packed << 32
                     c1[j] = ((const d2*)(gn + (uni_u(id[j]) - 1u)))[1];  // yaw, g
+                    c0[j] = ((const d2*)(gn + (uni_u(id[j]) - 1u)))[0];  // x, y
                 }
                 d2 p0[4], p2[4];
 #pragma unroll
@@ -1705,18 +1819,113 @@ __device__ __forceinline__ void helper_body(const KernelArgs& A) {
                         cu.q[3] = c3[j];
                         pu.q[0] = p0[j];
                         pu.q[2] = p2[j];
+                        cu.q[0] = c0[j];
+                        cu.q[1] = c1[j];
                         const bool valid = edge_valid_recs<CHECKER>(C, cu.r, pu.r, lane);
-                        if (valid && NODE_K(uni_u(cu.r.packed)) < Hp) {  // (uniform) it will be expanded: cos / sin of its yaw (expand_node.m:50-51) on this CU's time
+                        uint32_t v = valid ? 1u : 2u;  // 1: collision-free (and expanded, if helpers expand), 2: collides
+                        const uint32_t cpk = uni_u(cu.r.packed);
+                        if (valid && NODE_K(cpk) == Hp) v = 3u;  // at the horizon: the owner's goal test
+                        if (valid && NODE_K(cpk) < Hp) {  // (uniform) it will be expanded: cos / sin of its yaw (expand_node.m:50-51) on this CU's time
                             double hsn, hcos;
                             pdmpc_sincos(c1[j].x, &hsn, &hcos);
                             d2 t;
                             t.x = hcos;
                             t.y = hsn;
                             if (lane == 0) hcs_out[ee[j]] = t;
+                            if (expand_round) {  // remembered for the run's expansion pass (below)
+                                const lds_mask64* mrow = l_mask + ((size_t)NODE_K(cpk) * n + (NODE_TRIM(cpk) - 1)) * nw;
+                                const uint32_t t_run = ee[j] - first;
+                                if (lane == 0) {
+                                    r_cnt[t_run] = (uint32_t)__builtin_popcountll(mrow[0]);
+                                    r_rec[4 * (size_t)t_run + 0] = c0[j];
+                                    r_rec[4 * (size_t)t_run + 1] = c1[j];
+                                    r_rec[4 * (size_t)t_run + 2] = t;
+                                    r_rec[4 * (size_t)t_run + 3] = c3[j];
+                                }
+                            }
                         }
-                        if (lane == 0) verdict[ee[j]] = valid ? 1u : 2u;
+                        if (lane == 0) verdict[ee[j]] = v;
                     }
                 }
+            }
+        }
+        if (expand_round) {
+            // One allocation for the whole run: the children counts of its collision-free entries are summed (wave 0, a lane per
+            // entry), the board's node counter is advanced once, every entry gets its offset; then the wavefronts take the entries
+            // to expand off an LDS ticket.  (A global atomic per expansion cost more than the expansion.)
+            __syncthreads();
+            const NodeRec* gn = A.arena.nodes + (size_t)slot * A.max_nodes;
+            (void)gn;
+            unsigned long long* board = A.help_board + (size_t)slot * PDMPC_HB_WORDS;
+            uint32_t* verdict = A.help_verdict + (size_t)slot * PDMPC_HELP_CAP;
+            if (wave == 0) {
+                uint32_t run_total = 0;
+                for (uint32_t b0 = 0; b0 < cnt; b0 += PDMPC_WAVE) {  // (uniform; a run is at most 128 entries)
+                    const uint32_t t = b0 + (uint32_t)lane;
+                    const uint32_t c = t < cnt ? r_cnt[t] : 0u;
+                    uint32_t inc = c;
+#pragma unroll
+                    for (int o = 1; o < PDMPC_WAVE; o <<= 1) {
+                        const uint32_t vv = (uint32_t)__shfl_up((int)inc, o);
+                        if (lane >= o) inc += vv;
+                    }
+                    if (t < cnt) r_off[t] = run_total + inc - c;
+                    run_total += lane_u(inc, PDMPC_WAVE - 1);
+                }
+                if (lane == 0) {
+                    hs[HS_RUN_BASE] = run_total ? (uint32_t)__hip_atomic_fetch_add(board + PDMPC_HB_NNODES, (unsigned long long)run_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                    hs[HS_RUN_TOTAL] = run_total;
+                    hs[HS_TICKET] = 0;
+                }
+            }
+            __syncthreads();
+            const uint32_t run_base = hs[HS_RUN_BASE], run_total = hs[HS_RUN_TOTAL];
+            const bool full = run_total != 0u && run_base + run_total > A.max_nodes;
+            if (full && tid == 0) __hip_atomic_fetch_or(board + PDMPC_HB_FLAGS, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            double* gkey = A.arena.heap_key + (size_t)slot * A.max_nodes;
+            unsigned long long* glink = A.arena.link + (size_t)slot * A.max_nodes;
+            Search SH;  // the owner's arena, no LDS copies
+            SH.ln = nullptr;
+            SH.gn = A.arena.nodes + (size_t)slot * A.max_nodes;
+            SH.NL = 0;
+            SH.max_nodes = A.max_nodes;
+            SH.lkey = nullptr;
+            SH.lid = nullptr;
+            SH.gkey = gkey;
+            SH.gid = nullptr;
+            SH.HL = 0;
+            SH.heap_len = 0;
+            SH.lane = lane;
+            SH.pl = make_pop_lane(lane);
+            VState VH;  // (the owner sets the children's validity bytes itself: part of them lives in its LDS)
+            VH.l = nullptr;
+            VH.g = A.arena.vstate + (size_t)slot * A.max_nodes;
+            VH.NV = 0;
+            const uint32_t* list = A.help_list + (size_t)slot * PDMPC_HELP_CAP;
+            for (;;) {
+                const uint32_t t = sh_add_uniform(hs, HS_TICKET, 1u, lane);
+                if (t >= cnt) break;
+                const uint32_t c = uni_u(r_cnt[t]);
+                if (c == 0u) continue;  // (collides, or at the horizon)
+                if (full) {
+                    if (lane == 0) verdict[first + t] = 4u;  // collision-free, but the arena is full
+                    continue;
+                }
+                NodeBits cu;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cu.q[q] = r_rec[4 * (size_t)t + q];
+                const double hcos = cu.r.cs, hsn = cu.r.sn;
+                const uint32_t cur = uni_u(list[first + t]);
+                if (lane == 0) node_store_cs(SH, cur - 1u, hcos, hsn);
+                uint32_t nn = run_base + uni_u(r_off[t]);
+                (void)expand_children<false, 1>(EE, SH, VH, cur, cu.r, hcos, hsn, nn, [&](uint64_t mask, bool active, uint32_t i0, double f, int ccnt, const NodeRec& ch) {
+                    (void)mask;
+                    (void)ccnt;
+                    if (active) {
+                        gkey[i0] = f;
+                        glink[i0] = (unsigned long long)ch.parent | ((unsigned long long)ch.packed << 32);
+                    }
+                });
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's verdicts have reached L2 (the barrier alone does not wait for them) ...

@@ -105,6 +105,8 @@ struct NodeArena {  // HBM arrays, per-vehicle stride = max_nodes entries
 #define PDMPC_HB_N 1
 #define PDMPC_HB_MASK 2
 #define PDMPC_HB_DONE 3
+#define PDMPC_HB_NNODES 4 /* expanding helpers: the search's node counter while a round is shared */
+#define PDMPC_HB_FLAGS 6  /* bit 0: the arena is full (set by a helper), bit 1: expand what you find collision-free (set by the owner) */
 
 struct KernelArgs {
     // MPA
@@ -166,6 +168,8 @@ struct KernelArgs {
     uint32_t* help_list;             // [slot][PDMPC_HELP_CAP] nodes of the shared part of the round
     uint32_t* help_verdict;          // [slot][PDMPC_HELP_CAP] 1 collision-free, 2 colliding (written by helpers; a word each: a helper's run of 64 entries owns whole cache lines)
     double* help_cs;                 // [slot][PDMPC_HELP_CAP][2] cos, sin of the yaw of the collision-free entries that will be expanded (written by helpers)
+    int32_t help_expand;             // 1: helpers also expand the entries they find collision-free
+    int32_t help_patience;           // ... polls without a new claim after which the owner closes the round and does the rest itself
     uint32_t* help_finished;         // searches of this launch that have published their result
     int32_t speculate;  // 1: start searching before all predecessors have finished (results are identical, see arrival_sync)
     uint32_t spin_limit;

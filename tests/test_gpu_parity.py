@@ -310,6 +310,9 @@ def test_random_road_problems_never_fall_back():
         {"PDMPC_HELPERS": "3", "PDMPC_FR_SHARE_MIN": "64", "PDMPC_HELP_CHUNK": "32"},
         {"PDMPC_HELPERS": "200", "PDMPC_FR_SHARE_MIN": "64", "PDMPC_FR_OWN_DIV": "2"},
         {"PDMPC_FR_SHARE_MIN": "64", "PDMPC_FR_OWN_DIV": "64", "PDMPC_HELP_CHUNK": "128"},
+        {"PDMPC_HELP_EXPAND": "0", "PDMPC_FR_SHARE_MIN": "64"},
+        {"PDMPC_HELP_PATIENCE": "0", "PDMPC_FR_SHARE_MIN": "64"},
+        {"PDMPC_HELP_PATIENCE": "200", "PDMPC_HELPERS": "2", "PDMPC_FR_SHARE_MIN": "64", "PDMPC_HELP_CHUNK": "128"},
     ],
 )
 def test_tuning_switches_do_not_change_results(env, monkeypatch):
