@@ -673,6 +673,12 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.help_patience = 8;
     if (const char* e = getenv("PDMPC_HELP_PATIENCE")) a.help_patience = std::max(0, atoi(e));  // tuning knob
     if (h->n_words != 1 || h->fr_stage_cap < 128 || count > h->n_cu) a.help_expand = 0;  // (the helper kernel expands one successor-mask word per node; a run's records sit in its staging area; with more searches than CUs helpers are scarce and an owner that waits for them loses: C5 332 against 355 steps/s)
+    if (a.help_expand && a.n_helpers > 0) {
+        // helpers take the bulk of a large round off the owner, so rounds may grow faster and larger (measured on C2 / C3 with expanding
+        // helpers: ramp 4, cap 768 -> 629 / 616 steps/s; 3, 768 -> 673 / 651; 2, 768 -> 680 / 662; 2, 1024 -> 686 / 656; 1, 1024 -> 632 / 604)
+        if (!getenv("PDMPC_FR_RAMP")) a.fr_ramp = 2;
+        if (h->fr_round <= 0) a.fr_round = 1024;
+    }
     if (a.help_chunk == 0) a.help_chunk = a.help_expand ? 32 : 64;  // measured on C2 / C3: expanding helpers 64 -> 555 / 595 steps/s, 32 -> 595 / 584; checking only: 64 best (C4 43.3 against 40.9)
     a.help_finished = h->d_help_finished.p;
     if (a.n_helpers > 0) {
