@@ -41,11 +41,18 @@ if kt:
                                    "lds_block_size": rows[0].get("LDS_Block_Size"), "vgpr": rows[0].get("VGPR_Count"), "sgpr": rows[0].get("SGPR_Count"),
                                    "grid": rows[0].get("Grid_Size"), "workgroup": rows[0].get("Workgroup_Size")}
 traffic = {}
+helper_traffic = {}
+HELPER = "pdmpc_helper"
 for name in ("fetch", "write"):
     cc = find("%s/**/*counter_collection.csv" % name)
     if not cc:
         continue
-    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(cc)) if KERNEL in r["Kernel_Name"]]
+    rows_cc = list(csv.DictReader(open(cc)))
+    vals = [float(r["Counter_Value"]) for r in rows_cc if KERNEL in r["Kernel_Name"]]
+    hvals = [float(r["Counter_Value"]) for r in rows_cc if HELPER in r["Kernel_Name"]]  # the helper kernel that runs next to every search launch
+    if hvals:
+        ht = hvals[len(hvals) - TAIL - TIMED : len(hvals) - TAIL] if len(hvals) >= TIMED + TAIL else hvals
+        helper_traffic[name] = sum(ht) / len(ht)
     if vals:
         timed = vals[len(vals) - TAIL - TIMED : len(vals) - TAIL] if len(vals) >= TIMED + TAIL else vals  # the timed launches only (recording and warm-up launches come first)
         traffic[name] = {"counter": name.upper() + "_SIZE", "unit": "KiB as reported", "per_launch_avg_timed": sum(timed) / len(timed), "launches_timed": len(timed),
@@ -57,7 +64,14 @@ if traffic:
     # doubled one only as an upper bound.
     fetch = traffic.get("fetch", {}).get("per_launch_avg_timed", 0.0) * 1024
     write = traffic.get("write", {}).get("per_launch_avg_timed", 0.0) * 1024
+    hfetch = helper_traffic.get("fetch", 0.0) * 1024
+    hwrite = helper_traffic.get("write", 0.0) * 1024
     summary["traffic"] = traffic
+    summary["search_kernel_bytes_per_launch"] = fetch + write
+    summary["helper_kernel_bytes_per_launch"] = hfetch + hwrite
+    summary["helper_kernel_fetch_write_KiB"] = [helper_traffic.get("fetch", 0.0), helper_traffic.get("write", 0.0)]
+    fetch += hfetch  # both kernels of a step: the helpers read records and soups and write children, verdicts
+    write += hwrite
     summary["hbm_bytes_per_launch"] = fetch + write
     summary["hbm_bytes_per_launch_upper_bound"] = 2 * fetch + write
     summary["hbm_bytes_note"] = "FETCH_SIZE*1024 + WRITE_SIZE*1024 averaged over the timed launches; upper bound = FETCH_SIZE doubled (gfx950 wide-read correction, not applicable to this access pattern)"
