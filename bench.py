@@ -344,6 +344,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": "profiles/r02_pmc_traffic.json: FETCH_SIZE + WRITE_SIZE of the timed launches of the default command, search kernel + the helper kernel next to it (separate rocprofv3 --pmc passes, tools/collect_profiles.sh)" if traffic is not None else None,
                 "kernel": "pdmpc_frontier_kernel" if st["kernel"] == 1 else "pdmpc_search_kernel",
                 "kernel_ms_avg": kernel_ms / max(n_launch, 1),
                 "algorithmic_bytes_per_launch": alg_bytes / max(n_launch, 1),
