@@ -919,6 +919,10 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
     };
     const lds_d2* stage = (const lds_d2*)(X.lsm + A.lds.stage);  // [2 * fr_stage_cap] records: node, parent
     uint32_t n_staged = 0;  // ready entries 0 .. n_staged - 1 have their records staged
+    PhaseB R;               // phase B's result (valid while pb_valid)
+    R.n_popped = 0;
+    R.n_expanded = 0;
+    bool pb_valid = false, far_clobbered = false;
     // shared rounds (helper workgroups)
     unsigned long long* board = A.help_board + (size_t)slot * PDMPC_HB_WORDS;
     uint32_t* hlist = A.help_list + (size_t)slot * PDMPC_HELP_CAP;
@@ -980,6 +984,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
         // and a pure function of the tree and the soups) and leave verdicts; the owner takes what nobody has claimed when it is
         // through with its own part, waits for the claimed entries and expands the collision-free ones.
         const uint32_t tail = sh[FR_RD_TAIL];
+        if (tail) pb_valid = false;  // (the tree grows: phase B's result is stale)
         uint32_t n_own = tail, n_sh = 0;
         const bool hx = A.help_expand != 0 && sh[FR_NNODES] >= S.NL;  // helpers also expand (the round's new nodes then lie beyond the LDS copies)
         if (A.n_helpers > 0 && tail >= (uint32_t)A.fr_share_min && P.n_pred <= 64) {
@@ -1213,7 +1218,9 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
                 __syncthreads();
             }
             flags = sh[FR_FLAGS];
-            const bool reopen = (flags & FRF_INVALIDATED) && sh[FR_DROPPED] != 0u;
+            const bool reopen = (flags & FRF_INVALIDATED) && (sh[FR_DROPPED] != 0u || far_clobbered);  // (far_clobbered: phase B has run over far's arrays)
+            if (flags & FRF_INVALIDATED) pb_valid = false;
+            if (reopen) far_clobbered = false;
             __syncthreads();
             if (tid == 0) {
                 atomicAdd(P.counters + 2, 1);
@@ -1304,6 +1311,20 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
             done = near_n == 0u && far_n == 0u;
         }
         if (done) {
+            // Phase B right away, also when predecessors are still planning: an arrival that invalidates nothing leaves the tree,
+            // hence the counts and ids, as they are, and the result goes out as soon as the last predecessor has been looked at
+            // (≈ 10 µs earlier on every level of a time step's chain).  Phase B uses far's arrays as scratch: if the search has to
+            // go on after all (an arrival invalidated a node), the open set is rebuilt from the tree.
+            if (!pb_valid && !dep_timeout) {
+                __syncthreads();
+                R = fr_phase_b<NW>(A, X, F, EE, best, ref_ids, (LDS_AS unsigned char*)(X.lsm + A.lds.cand), F.far_key, F.far_id, gp_path);
+                pb_valid = true;
+                far_clobbered = true;
+                const uint32_t pflags = sh[FR_FLAGS];
+                __syncthreads();
+                if (pflags & FRF_TIE) return true;
+                if (pflags & FRF_BUG) dep_timeout = true;  // reported as an error status: must never happen
+            }
             if (sh_load64(sh, SH_PEND_LO) == 0ull || dep_timeout) {
                 goal = best;
                 status = best ? PDMPC_OK : PDMPC_EXHAUSTED;
@@ -1513,17 +1534,10 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
     uint32_t nnodes_raw = sh[FR_NNODES];
     nnodes_raw = nnodes_raw < S.max_nodes ? nnodes_raw : S.max_nodes;
     __syncthreads();
-    PhaseB R;
-    R.n_popped = 0;
-    R.n_expanded = nnodes_raw;
-    bool pb_ran = false;
-    if (status != PDMPC_ARENA_OVERFLOW && !dep_timeout) {
-        R = fr_phase_b<NW>(A, X, F, EE, goal, ref_ids, (LDS_AS unsigned char*)(X.lsm + A.lds.cand), F.far_key, F.far_id, gp_path);
-        pb_ran = true;
-        const uint32_t flags = sh[FR_FLAGS];
-        __syncthreads();
-        if (flags & FRF_TIE) return true;
-        if (flags & FRF_BUG) dep_timeout = true;  // reported as an error status: must never happen
+    const bool pb_ran = pb_valid;
+    if (!pb_valid) {
+        R.n_popped = 0;
+        R.n_expanded = nnodes_raw;
     }
     FR_PROGRESS(6)
     // validity bytes of the LDS-resident nodes go to HBM with the rest (debug read-back of the tree, pdmpc_debug_tree)
@@ -1950,7 +1964,7 @@ __device__ __forceinline__ void frontier_body(const KernelArgs& A) {
     search_prologue(A, X, (LDS_AS unsigned char*)smem, CHECKER == PDMPC_CHECK_INTERX);
     const int tid = X.tid, lane = X.lane, wave = X.wave;
     volatile lds_u32* l_shared = X.l_shared;
-    lds_u32* ref_ids = (lds_u32*)(X.lsm + A.lds.heap_key) + FR_READY_CAP + 1024;  // in the histogram's region, behind phase B's tables
+    lds_u32* ref_ids = (lds_u32*)(X.lsm + A.lds.heap_key) + FR_READY_CAP + 128;  // behind the relevance tables (nothing else uses those words: the ids survive an arrival that changes nothing)
     const bool tie = frontier_search<CHECKER, NW>(A, X, ref_ids);
     bool serial = false;
     if (tie) {  // (uniform over the workgroup) start over with the exact open list; areas that arrived so far stay in the soup
