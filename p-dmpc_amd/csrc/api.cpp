@@ -658,8 +658,8 @@ int launch_range(pdmpc_handle* h, int first, int count) {
             // More searches than CUs: the helpers are there for the tail of the launch, when CUs fall idle while a few long searches
             // still run; until then they cost the CUs they sit on (their stream has the lowest priority, a search that is waiting
             // for a CU gets it first).  Measured on C4 (512 searches) / C5 (1280): none 25.6 / 352 steps/s, 16 helpers 38.5 / 353,
-            // 32: 41.5 / 352, 64: 43.4 / 332, 96: 42.8 / 299.
-            a.n_helpers = count <= 2 * h->n_cu ? 64 : 32;
+            // 32: 41.5 / 352, 64: 43.4 / 332, 96: 42.8 / 299; with helpers that also expand (C4 only, see below) 64: 43.6, 96: 45.9, 128: 46.4.
+            a.n_helpers = count <= 2 * h->n_cu ? 96 : 32;
             if (const char* e = getenv("PDMPC_HELPERS_OVERSUB")) a.n_helpers = std::max(0, std::min(atoi(e), h->n_cu / 2));  // tuning knob
             if (const char* e = getenv("PDMPC_HELPERS")) a.n_helpers = std::min(a.n_helpers, std::max(0, atoi(e)));           // (0 switches every helper off)
         }
@@ -672,12 +672,18 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     if (const char* e = getenv("PDMPC_HELP_EXPAND")) a.help_expand = atoi(e) != 0;  // A/B switch: results are identical
     a.help_patience = 8;
     if (const char* e = getenv("PDMPC_HELP_PATIENCE")) a.help_patience = std::max(0, atoi(e));  // tuning knob
-    if (h->n_words != 1 || h->fr_stage_cap < 128 || count > h->n_cu) a.help_expand = 0;  // (the helper kernel expands one successor-mask word per node; a run's records sit in its staging area; with more searches than CUs helpers are scarce and an owner that waits for them loses: C5 332 against 355 steps/s)
+    // with more searches than CUs helpers are scarce and an owner that waits for them loses (C5, 5 searches per CU: 332 against 355
+    // steps/s); up to two searches per CU the tail of the launch is long enough for expanding helpers to pay (C4: 42.1 -> 46)
+    bool expand_oversub = count <= 2 * h->n_cu;
+    if (const char* e = getenv("PDMPC_HELP_EXPAND_OVERSUB")) expand_oversub = atoi(e) != 0;  // tuning knob
+    if (h->n_words != 1 || h->fr_stage_cap < 128 || (count > h->n_cu && !expand_oversub)) a.help_expand = 0;  // (the helper kernel expands one successor-mask word per node; a run's records sit in its staging area)
     if (a.help_expand && a.n_helpers > 0) {
         // helpers take the bulk of a large round off the owner, so rounds may grow faster and larger (measured on C2 / C3 with expanding
         // helpers: ramp 4, cap 768 -> 629 / 616 steps/s; 3, 768 -> 673 / 651; 2, 768 -> 680 / 662; 2, 1024 -> 686 / 656; 1, 1024 -> 632 / 604)
-        if (!getenv("PDMPC_FR_RAMP")) a.fr_ramp = 2;
-        if (h->fr_round <= 0) a.fr_round = 1024;
+        if (count <= h->n_cu) {
+            if (!getenv("PDMPC_FR_RAMP")) a.fr_ramp = 2;
+            if (h->fr_round <= 0) a.fr_round = 1024;
+        }
     }
     if (a.help_chunk == 0) a.help_chunk = a.help_expand ? 32 : 64;  // measured on C2 / C3: expanding helpers 64 -> 555 / 595 steps/s, 32 -> 595 / 584; checking only: 64 best (C4 43.3 against 40.9)
     a.help_finished = h->d_help_finished.p;
