@@ -153,14 +153,12 @@ __device__ void incorporate_areas(const SpecCtx& P, unsigned long long arr, int 
         for (int idx = tid; idx < P.Hp * PDMPC_VMAX; idx += (int)blockDim.x) {
             const int k = idx / PDMPC_VMAX;
             const int v = idx - k * PDMPC_VMAX;
+            // (all three loads at once: the coordinates do not wait for the column count — every v < VMAX is inside the array)
             const int cols = PO->shape_cols[k];
+            const double sx = PO->shapes[k][0][v], sy = PO->shapes[k][1][v];
             d2 pt;
-            pt.x = qnan;
-            pt.y = qnan;
-            if (v < cols) {
-                pt.x = PO->shapes[k][0][v];
-                pt.y = PO->shapes[k][1][v];
-            }
+            pt.x = v < cols ? sx : qnan;
+            pt.y = v < cols ? sy : qnan;
             P.l_soup[P.l_soff[k] + P.l_lit[k] + p * PDMPC_VMAX + v] = pt;
         }
     }
