@@ -1423,7 +1423,8 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
             const uint32_t round_target = ramp < (uint32_t)A.fr_round ? ramp : (uint32_t)A.fr_round;
             uint32_t bsel = FR_NBINS - 1, bspill = FR_NBINS - 1;
             double scale = 0.0;
-            for (int zoom = 0; zoom < 8; ++zoom) {
+            // (a round that takes all of near needs no histogram: scale 0 puts every key into bin 0 — the rounds of a young search)
+            for (int zoom = 0; zoom < 8 && nn_near > round_target; ++zoom) {
                 scale = hi > lo ? (double)FR_NBINS / (hi - lo) : 0.0;
                 for (int i = tid; i < FR_NBINS; i += (int)blockDim.x) F.hist[i] = 0;
                 __syncthreads();
