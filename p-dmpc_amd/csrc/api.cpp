@@ -602,7 +602,9 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.fr_join_scale = 4.0;  // measured on C2 / C3 / C5: 1 -> 419 / 396 / 347 steps/s, 4 -> 434 / 396 / 353, 8 -> 434 / 397 / 345, 32 -> 429 / 394 / 344
     if (const char* e = getenv("PDMPC_FR_JOIN_SCALE")) a.fr_join_scale = atof(e);  // tuning knob
     a.fr_dive = 1024;  // in rounds of up to this many entries a wave goes on with the best child while its key stays within the round's range (frontier_kernel.hip, fr_process); measured on C2 / C3 / C5: 0 -> 408 / 391 / 307 steps/s, 64 -> 409 / 391 / 314, 1024 -> 419 / 397 / 323
-    if (const char* e = getenv("PDMPC_FR_DIVE")) a.fr_dive = std::max(0, atoi(e));  // tuning knob / A-B switch (0: never): results are identical
+a.fr_root_dive = 0;
+    if (const char* e = getenv("PDMPC_FR_ROOT_DIVE")) a.fr_root_dive = atoi(e) != 0;  // tuning knob
+        if (const char* e = getenv("PDMPC_FR_DIVE")) a.fr_dive = std::max(0, atoi(e));  // tuning knob / A-B switch (0: never): results are identical
     a.spin_limit = 1u << 22;
     if (const char* e = getenv("PDMPC_SPIN_LIMIT")) a.spin_limit = (uint32_t)std::max(1024, atoi(e));  // debugging: fail fast
     a.debug_tail = getenv("PDMPC_DEBUG_TAIL") ? atoi(getenv("PDMPC_DEBUG_TAIL")) : 0;

@@ -872,7 +872,7 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
         sh[FR_NNODES] = 1;
         sh[FR_RD_TAIL] = 1;
         sh[FR_VLIST_N] = 0;
-        sh_st_d(sh, FR_JOIN_MAX, 0.0);  // (the root's round: its key)
+        sh_st_d(sh, FR_JOIN_MAX, A.fr_root_dive ? inf : 0.0);  // the root's round: its own key, or (fr_root_dive) no limit — the wave that expands the root follows the best children to the horizon: on a free road that is the goal, in the first round
         sh_st_d(sh, FR_NEAR_MIN, inf);
         sh_st_d(sh, FR_FAR_MIN, inf);
         sh_st_d(sh, FR_L_FAR, inf);

@@ -158,6 +158,7 @@ struct KernelArgs {
     double fr_join_scale;  // ... the key range within which a wave goes on with a node's best child, as a multiple of the range the round's own entries span
     int32_t fr_near_max;   // ... size of near beyond which its tail is moved back to far
     int32_t fr_dive;       // ... largest round (entries) in which waves go on with best children (0: never)
+    int32_t fr_root_dive;  // ... 1: the root's round follows best children without a key limit
     // frontier kernel, helper workgroups (blockIdx >= n_searches): CUs the launch leaves idle check edges of other workgroups' large rounds
     int32_t n_searches;              // workgroups of this launch that run a search (the first ones)
     int32_t n_helpers;               // helper workgroups behind them (0: none)

@@ -312,6 +312,7 @@ def test_random_road_problems_never_fall_back():
         {"PDMPC_FR_SHARE_MIN": "64", "PDMPC_FR_OWN_DIV": "64", "PDMPC_HELP_CHUNK": "128"},
         {"PDMPC_HELP_EXPAND": "0", "PDMPC_FR_SHARE_MIN": "64"},
         {"PDMPC_HELP_PATIENCE": "0", "PDMPC_FR_SHARE_MIN": "64"},
+        {"PDMPC_FR_ROOT_DIVE": "1"},
         {"PDMPC_HELP_PATIENCE": "200", "PDMPC_HELPERS": "2", "PDMPC_FR_SHARE_MIN": "64", "PDMPC_HELP_CHUNK": "128"},
     ],
 )
