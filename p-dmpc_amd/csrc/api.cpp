@@ -684,7 +684,7 @@ a.fr_root_dive = 0;
         // helpers: ramp 4, cap 768 -> 629 / 616 steps/s; 3, 768 -> 673 / 651; 2, 768 -> 680 / 662; 2, 1024 -> 686 / 656; 1, 1024 -> 632 / 604)
         if (count <= h->n_cu) {
             if (!getenv("PDMPC_FR_RAMP")) a.fr_ramp = 2;
-            if (h->fr_round <= 0) a.fr_round = 1024;
+            if (h->fr_round <= 0) a.fr_round = 1280;  // (ready list: 1536 entries; measured on C2 / C3: 1024 -> 734 / 665 steps/s, 1280 -> 747 / 675, 1536 -> 749 / 667)
         }
     }
     if (a.help_chunk == 0) a.help_chunk = a.help_expand ? 32 : 64;  // measured on C2 / C3: expanding helpers 64 -> 555 / 595 steps/s, 32 -> 595 / 584; checking only: 64 best (C4 43.3 against 40.9)

@@ -63,7 +63,7 @@
 #define FR_SLOWEST 30   // (64 bit, words 30-31 of the serial block: unused by both searches) debugging: slowest node
 #define FR_GOAL_N 39     // goal candidates of the running round (entries of goal_list)
 #define FR_ROUND_B1 28   // (64 bit, words 28-29 of the serial block: unused by both searches) smallest path maximum among them
-#define FR_GOAL_CAP 1024
+#define FR_GOAL_CAP 2048
 #define FR_JOIN_MAX 26    // (64 bit, words 26-27 of the serial block: unused by both searches) largest key among the round's entries
 #define FR_DEAD 57      // open entries dropped because an ancestor was invalidated
 #define FR_HELP_CLOSED 56 // shared round: entries of the shared part the helpers claimed before the owner closed it
@@ -74,7 +74,7 @@
 #define FRF_BUG 8u
 #define FR_SCRATCH 64   // 64 scratch words behind the shared block (targets of the lanes that only take part pro forma, see sh_add_uniform)
 #define FR_NBINS 2048
-#define FR_READY_CAP 1024
+#define FR_READY_CAP 1536
 
 namespace {
 

@@ -99,7 +99,7 @@ struct NodeArena {  // HBM arrays, per-vehicle stride = max_nodes entries
     unsigned long long* link;  // frontier kernel: parent | packed << 32 per node, eight nodes to a 64-byte line (a record's own copy shares its line with nothing the walks need)
 };
 
-#define PDMPC_HELP_CAP 1024 /* entries of a round that can be shared (= the ready list's capacity) */
+#define PDMPC_HELP_CAP 2048 /* entries of a round that can be shared (= the ready list's capacity) */
 #define PDMPC_HB_WORDS 8   /* 64-bit words of a board */
 #define PDMPC_HB_TICKET 0
 #define PDMPC_HB_N 1
