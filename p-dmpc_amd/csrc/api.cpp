@@ -159,7 +159,8 @@ struct pdmpc_handle {
     DevBuf<uint32_t> d_help_verdict;
     DevBuf<double> d_help_cs;
     int helpers_max = 64;
-    hipStream_t help_stream = nullptr;  // the helper kernel runs next to the searches, on its own stream
+    hipStream_t help_stream = nullptr;  // the helper kernel runs next to the searches, on its own stream ...
+    hipStream_t help_stream_low = nullptr;  // ... of the lowest priority when the launch has more searches than CUs
     hipEvent_t ev_help_pre = nullptr, ev_help_done = nullptr;
     DevBuf<double> d_random;  // sampled optimizer: random numbers of the batch
     int sampled_n_random = 0;
@@ -649,7 +650,7 @@ a.fr_root_dive = 0;
     a.fr_own_div = 8;
     if (const char* e = getenv("PDMPC_FR_OWN_DIV")) a.fr_own_div = std::max(1, atoi(e));  // tuning knob
     a.help_chunk = 0;  // (default chosen below, once it is known whether the helpers expand)
-    if (const char* e = getenv("PDMPC_HELP_CHUNK")) a.help_chunk = std::min(128, std::max(32, atoi(e) / 32 * 32));  // tuning knob
+    if (const char* e = getenv("PDMPC_HELP_CHUNK")) a.help_chunk = std::min(128, std::max(16, atoi(e) / 16 * 16));  // tuning knob
     if (frontier && !h->sampled_launch && h->cfg.checker == PDMPC_CHECK_INTERX && h->speculate) {
         // (measured on C2, 20 searches, / C3, 128: 8 helpers 535 / 476 steps/s, 16: 529 / 506, 32: 516 / 522, 128: 507 / 483)
         int want = std::min(h->helpers_max, std::max(32, count / 2));  // (helpers that expand: the owner of a shared round waits for them, more of them with shorter runs finish sooner)
@@ -695,10 +696,11 @@ a.fr_root_dive = 0;
         // the helpers start once the boards are clean; everything the launch stream does after the searches also waits for the
         // helpers to have left (they leave as soon as the last search has published)
         HIPCHK(hipEventRecord(h->ev_help_pre, h->stream));
-        HIPCHK(hipStreamWaitEvent(h->help_stream, h->ev_help_pre, 0));
-        const int hrc = pdmpc_launch_helpers(&a, (void*)h->help_stream);
+        hipStream_t hst = count > h->n_cu ? h->help_stream_low : h->help_stream;
+        HIPCHK(hipStreamWaitEvent(hst, h->ev_help_pre, 0));
+        const int hrc = pdmpc_launch_helpers(&a, (void*)hst);
         if (hrc != 0) return fail(PDMPC_ERR_HIP, std::string("helper kernel launch failed: ") + hipGetErrorString((hipError_t)hrc));
-        HIPCHK(hipEventRecord(h->ev_help_done, h->help_stream));
+        HIPCHK(hipEventRecord(h->ev_help_done, hst));
     }
     auto& ev = h->events[h->events_used++];
     HIPCHK(hipEventRecord(ev.first, h->stream));
@@ -770,10 +772,15 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
     const uint32_t want_nodes = config->max_nodes > 0 ? (uint32_t)config->max_nodes : 32768u;  // default arena: 256 x 32768 nodes, about 0.6 GB
     h->max_vehicles = config->max_vehicles > 0 ? config->max_vehicles : 256;
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) {  // the helpers' stream has the lowest priority: where searches and helpers compete for a CU, the search gets it
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->help_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+        // Two streams for the helper kernel.  Where searches and helpers compete for CUs (more searches than CUs) it runs at the
+        // lowest priority: a search that is waiting for a CU gets it first.  Otherwise at the searches' priority: on the
+        // low-priority stream its dispatch was now and then held back until the searches were through (one step in a hundred
+        // then ran without helpers, 5 ms instead of 2: seen as p99 outliers in two of four bench runs, in none of four this way).
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        e = hipStreamCreateWithPriority(&h->help_stream, hipStreamNonBlocking, prio_lo);
+        e = hipStreamCreateWithPriority(&h->help_stream_low, hipStreamNonBlocking, prio_lo);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_help_pre, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_help_done, hipEventDisableTiming);
@@ -805,6 +812,7 @@ int pdmpc_destroy(pdmpc_handle* h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->help_stream) (void)hipStreamSynchronize(h->help_stream);
+    if (h->help_stream_low) (void)hipStreamSynchronize(h->help_stream_low);
     for (auto& ev : h->events) {
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
@@ -837,6 +845,7 @@ int pdmpc_destroy(pdmpc_handle* h) {
     if (h->ev_help_pre) (void)hipEventDestroy(h->ev_help_pre);
     if (h->ev_help_done) (void)hipEventDestroy(h->ev_help_done);
     if (h->help_stream) (void)hipStreamDestroy(h->help_stream);
+    if (h->help_stream_low) (void)hipStreamDestroy(h->help_stream_low);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return PDMPC_OK;
