@@ -341,3 +341,24 @@ def test_helper_workgroups_take_part_and_change_nothing():
             assert stats["helper_checked"] < stats["nodes_processed"]
     finally:
         del os.environ["PDMPC_FR_SHARE_MIN"]
+
+
+def test_arena_growth_with_shared_rounds(monkeypatch):
+    """Helper workgroups allocate node indices too: a run of theirs that does not fit reports it (verdict 4, the board's flag),
+    the search ends with PDMPC_ARENA_OVERFLOW and the call is planned again with doubled arenas — from 256 nodes up, with most
+    rounds shared, until every search fits; the records are the oracle's."""
+    monkeypatch.setenv("PDMPC_FR_SHARE_MIN", "64")
+    options, mpa, iters = problems.problem_set("interx", 2, 24, Hp=6)
+    oracle = _oracle()
+    options.max_nodes = 1 << 22
+    _, ref, _ = oracle.plan_batch(options, mpa, iters)
+    options.max_nodes = 256
+    options.max_vehicles = len(iters)
+    h = Handle(options)
+    h.upload_mpa(mpa)
+    gpu = h.plan_batch(iters)
+    assert_records_equal(gpu, ref, "grown arena, shared rounds")
+    nodes, regrows = h.arena_nodes()
+    assert regrows >= 3 and nodes >= int(ref["n_expanded"].max())
+    assert h.stats()["shared_rounds"] > 0
+    h.close()
