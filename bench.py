@@ -1,21 +1,32 @@
 #!/usr/bin/env python3
-"""bench.py — MPC steps/s of the HIP graph-search backend on BASELINE config 1 (C2).
+"""bench.py — MPC steps/s of the HIP graph-search backend.
 
-Workload (N = 1): 20 vehicles on the CPM-lab road network, horizon 8, InterX constraint checker,
-constant priorities, distance coupling; one "step" = every vehicle plans once, all computation levels,
-with hand-off of solved areas to successors (one kernel launch per step, dependencies resolved on
-the device).  Inputs are recorded from the framework's own closed-loop simulation (the first 20 steps are
-dropped, as the reference's evaluation does, eval/eval_phd/eval_phd.m:41-49), packed into HBM before the
-timed region, and replayed: the planner is deterministic, so a replayed step does exactly the work of the
-closed-loop step.
+Workload at N = 1 (default, BASELINE config C2): 20 vehicles on the CPM-lab road network, horizon 8, InterX constraint
+checker, constant priorities, distance coupling; one "step" = every vehicle plans once, all computation levels, with hand-off
+of solved areas to successors (one kernel launch per step, dependencies resolved on the device).  Inputs are recorded from the
+framework's own closed-loop simulation (the first 20 steps are dropped, as the reference's evaluation does,
+eval/eval_phd/eval_phd.m:41-49), packed into HBM before the timed region, and replayed: the planner is deterministic, so a
+replayed step does exactly the work of the closed-loop step.
 
-N > 1 (`--gpus N`, launched by torch.distributed.run): weak scaling — every rank plans its own independent
-20-vehicle road network (vehicles of different networks are not coupled, so the data path has no collective);
-value = network-steps per second summed over ranks.
+The measurement validates itself (outside the timed region):
+  * `parity_checked` / `parity_mismatches`: the CPU oracle plans every recorded step for `cpu_baseline` anyway; its records are
+    compared byte for byte (status, ids along the path, pop count, tree size, trajectory, areas) with the records the GPU
+    produced for the same bank.  A mismatch makes the run exit non-zero.
+  * `bad_status_plans_in_timed_region` (counted on the device: no truncated, overflowed or timed-out search can hide in the timed
+    region) and `replay_checked` / `replay_mismatches`: after the timed loop every bank is launched once more and its records are
+    compared with the recording's.
 
-`--workload c3` (128 vehicles, Hp 8) and `--workload c4` (512 vehicles, Hp 10) are BASELINE configs 2 and 3 on a
-tiled map: at N = 1 one launch per step, at N > 1 every computation level is block-partitioned over the ranks and the
-solved areas are exchanged with one RCCL all-gather per level (strong scaling; see pdmpc/distributed.py).
+Next to `value` (inputs resident in HBM), never as `value`:
+  * `value_host_inclusive`: the native closed loop (pdmpc_controller_run): host step logic + pack + H2D + launch + D2H + apply;
+  * `value_run_optimizer_literal`: the recorded steps the way an UNMODIFIED reference controller would drive the backend — one
+    pdmpc_plan_batch(h, 1, ...) per vehicle in kahn order, hand-over on the host (pdmpc_plan_step_literal).
+
+N > 1 (`--gpus N`, launched by torch.distributed.run) defaults to north_star's scaling workload: C4 (512 vehicles, Hp 10,
+colouring levels) in STRONG scaling — coupling-graph components sharded over the ranks, one launch per rank and step, one RCCL
+all-gather of the result records (`--shard levels`: every level block-partitioned, one all-gather per level).
+`--workload c3` (128 vehicles, 2-level DAG; 1 -> 4 GPUs) and `--workload c5` (64 prioritizations, instances sharded, no
+collective on the data path) likewise.  `--weak` is the old mode: N independent C2 networks.  The default N = 1 line carries
+`scaling_reference`: the C4 rate on one GPU, the base of the strong-scaling curve.
 
 Prints ONE JSON line on rank 0.
 """
@@ -32,9 +43,33 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "p-dmpc_amd")]
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, MI355X_MICROARCH.md
+PROFILE_ROUND = "r03"
 
 
-def build_world(args, rank):
+def workload_defaults(args):
+    """BASELINE.json configs as named: C3 = 128 vehicles, Hp 8, colouring priorities cut to a 2-level coupling DAG (max_num_CLs = 2,
+    Config.m:28; the cut couplings become previous-trajectory obstacles, PrioritizedController.m:409-447); C4 = 512 vehicles, Hp 10,
+    graph-colouring levels (ColoringPrioritizer.m:31-89 + kahn.m); C2 / C5 = constant priorities, no cut."""
+    if args.workload == "c3":
+        args.vehicles, args.hp = 128, 8
+        defaults = ("coloring", 2)
+    elif args.workload == "c4":
+        args.vehicles, args.hp = 512, 10
+        defaults = ("coloring", 99)
+    else:
+        defaults = ("constant", 99)
+    if args.priorities is None:
+        args.priorities = defaults[0]
+    if args.max_levels is None:
+        args.max_levels = defaults[1]
+    if args.workload != "c2":
+        args.record = min(args.record, 8)
+        args.skip = min(args.skip, 4)
+    if args.max_nodes <= 0:
+        args.max_nodes = (1 << 17) if args.workload == "c2" else (1 << 16)
+
+
+def build_world(args, seed_offset):
     from pdmpc.config import Config, MpaType, ScenarioType
     from pdmpc.controller import PrioritizedSequentialController
     from pdmpc.mpa import get_mpa
@@ -48,12 +83,12 @@ def build_world(args, rank):
         mpa_type=MpaType[args.mpa],
         max_vehicles=max(args.vehicles * (args.instances if args.workload == "c5" else 1), 32),
         max_nodes=args.max_nodes,
-        max_num_CLs=getattr(args, "max_levels", 99),
+        max_num_CLs=args.max_levels,
     )
     mpa = get_mpa(options)
-    scenario = commonroad_scenario(options, seed=args.seed + rank, tiles=tiles)
+    scenario = commonroad_scenario(options, seed=args.seed + seed_offset, tiles=tiles)
     ctl = PrioritizedSequentialController(options, scenario, mpa, None, coupling="distance", boundary_provider=boundary_provider(scenario),
-                                         priority_strategy=getattr(args, "priorities", "constant"))
+                                         priority_strategy=args.priorities)
     return options, mpa, ctl
 
 
@@ -79,20 +114,43 @@ def record_steps(options, mpa, ctl, optimizer, n_skip, n_record, explore_instanc
     return batches if explore_instances else problems[n_skip:]
 
 
-def cpu_baseline(options, mpa, problems, budget_s):
-    """The CPU oracle on the same recorded steps: all vehicles of a level concurrently on min(level, cores) threads
-    (the stand-in for ComputationMode.parallel_threads).  Bounded by `budget_s`."""
+PARITY_FIELDS = ("status", "n_expanded", "n_popped", "n_hp", "tree_path", "predicted_trims", "shape_cols", "y_predicted", "shapes", "path_nodes")
+
+
+def count_record_mismatches(a, b):
+    """Vehicles whose result records differ in any bit of any field the ABI defines (floating point compared as raw IEEE bits)."""
+    bad = np.zeros(len(a), dtype=bool)
+    for name in PARITY_FIELDS:
+        x, y = np.ascontiguousarray(a[name]), np.ascontiguousarray(b[name])
+        if x.dtype.kind == "f":
+            x, y = x.view(np.uint64), y.view(np.uint64)
+        bad |= (x != y).reshape(len(a), -1).any(axis=1)
+    return int(bad.sum())
+
+
+def cpu_baseline(options, mpa, problems, gpu_records, budget_s):
+    """The CPU oracle on the same recorded steps: all vehicles of a level concurrently on min(level, cores) threads of a pool
+    that persists across levels and steps (the stand-in for ComputationMode.parallel_threads), whole
+    level loop in C++ (oracle_plan_step).  Bounded by `budget_s`.  Its records are the parity check of the measured work."""
+    import copy
+
     from oracle import oracle
-    from pdmpc import abi
+    from oracle import packing
 
     cores = os.cpu_count() or 1
-    mpa_struct, keep = abi.pack_mpa(mpa)
-    ms_total, n_done = 0.0, 0
+    unbounded = copy.copy(options)
+    unbounded.max_nodes = 1 << 30  # the reference's tree is unbounded (Tree.m:54-70)
+    mpa_struct, keep = packing.pack_mpa(mpa)
+    oracle.plan_step_native(unbounded, mpa, problems[0], n_threads=cores, mpa_struct=mpa_struct)  # (starts the pool: not timed)
+    ms_total, thr_total, n_done, mismatches, plans = 0.0, 0.0, 0, 0, 0
     t0 = time.time()
-    for prob in problems:
-        _, ms = oracle.plan_step(options, mpa, prob, n_threads=cores, mpa_struct=mpa_struct)
+    for prob, gpu in zip(problems, gpu_records):
+        recs, ms, thr = oracle.plan_step_native(unbounded, mpa, prob, n_threads=cores, mpa_struct=mpa_struct)
         ms_total += ms
+        thr_total += thr * ms
         n_done += 1
+        plans += len(recs)
+        mismatches += count_record_mismatches(gpu, recs)
         if time.time() - t0 > budget_s:
             break
     del keep
@@ -100,10 +158,98 @@ def cpu_baseline(options, mpa, problems, budget_s):
         "value": n_done / (ms_total / 1e3) if ms_total > 0 else None,
         "unit": "MPC steps/s",
         "cores": cores,
+        "threads_used_mean": thr_total / ms_total if ms_total > 0 else None,  # time-weighted: a level of one vehicle uses one thread
         "kind": "port",
-        "sample": "%d recorded steps of the same workload, C++ oracle, levels in kahn order, min(level size, %d) threads per level, planning time only" % (n_done, cores),
+        "sample": "%d recorded steps of the same workload (%d plans), C++ oracle, whole level loop in C++ (kahn order, hand-over of solved areas on the host), "
+        "min(level size, %d) threads of a persistent pool per level" % (n_done, plans, cores),
         "ms_per_step": ms_total / max(n_done, 1),
-    }
+    }, n_done, plans, mismatches
+
+
+def measure_replay(h, problems, steps, warmup, one_step, dist, torch):
+    for i in range(warmup):
+        one_step(i)
+    h.reset_stats()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    lat = []
+    t_begin = time.perf_counter()
+    for i in range(steps):
+        t0 = time.perf_counter()
+        one_step(i)
+        lat.append(time.perf_counter() - t0)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_begin
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        elapsed = float(t.item())
+    return elapsed, lat
+
+
+def pack_banks(h, problems, first_bank=0):
+    """Keeps every recorded step resident in HBM (one bank each); returns per-bank records, algorithmic bytes, pops, nodes."""
+    recs_per_bank, bytes_per_bank, pops_per_bank, nodes_per_bank = [], [], [], []
+    t_grow = 0.0
+    for b, prob in enumerate(problems):
+        h.select_bank(first_bank + b)
+        fb = [f if f is not None else [] for f in prob["fallback"]]
+        h.pack_step(prob["iters"], prob["preds"], fb)
+        while True:
+            h.launch()
+            recs = h.fetch(len(prob["iters"]))
+            if not (recs["status"] == 2).any():
+                break
+            # the reference's tree is unbounded (Tree.m:54-70): never measure truncated searches -- double the arenas, plan again
+            tg = time.perf_counter()
+            h.grow_arena(2 * h.arena_nodes()[0])
+            t_grow += time.perf_counter() - tg
+        st = h.stats()
+        recs_per_bank.append(recs.copy())
+        bytes_per_bank.append(st["algorithmic_bytes"])
+        pops_per_bank.append(st["nodes_popped"])
+        nodes_per_bank.append(st["nodes_generated"])
+    return recs_per_bank, bytes_per_bank, pops_per_bank, nodes_per_bank, t_grow
+
+
+def scaling_reference(args_in, local_rank, torch):
+    """The C4 rate on this one GPU (few recorded steps, replayed): the N = 1 point of the strong-scaling curve `--gpus N > 1` reports."""
+    import copy
+
+    from pdmpc.optimizer import GraphSearchHip
+
+    a = copy.copy(args_in)
+    a.workload, a.priorities, a.max_levels, a.max_nodes = "c4", None, None, 0
+    a.record, a.skip = 4, 2
+    workload_defaults(a)
+    a.record, a.skip = 4, 2
+    options, mpa, ctl = build_world(a, 0)
+    options.device = local_rank
+    opt = GraphSearchHip(options)
+    opt._ensure_mpa(mpa)
+    h = opt.handle
+    h.allow_overflow = True
+    problems = record_steps(options, mpa, ctl, opt, a.skip, a.record)
+    recs, _, _, _, _ = pack_banks(h, problems)
+    S = len(problems)
+
+    def one_step(i):
+        h.select_bank(i % S)
+        h.launch()
+        h.synchronize()
+
+    elapsed, _ = measure_replay(h, problems, 2 * S, S, one_step, None, torch)
+    bad = 0
+    for b in range(S):
+        h.select_bank(b)
+        h.launch()
+        bad += count_record_mismatches(h.fetch(len(problems[b]["iters"])), recs[b])
+    h.close()
+    return {"workload": "c4", "n_gpus": 1, "value": 2 * S / elapsed, "unit": "MPC steps/s", "ms_per_step": 1e3 * elapsed / (2 * S),
+            "steps": 2 * S, "recorded_steps": S, "replay_mismatches": bad,
+            "what": "C4 (512 vehicles, Hp 10, colouring levels) replayed from HBM on one GPU: divide the value of a `--gpus N` line (default workload c4, strong scaling) by this"}
 
 
 def main():
@@ -118,10 +264,12 @@ def main():
     ap.add_argument("--record", type=int, default=20, help="distinct recorded time steps kept resident in HBM")
     ap.add_argument("--skip", type=int, default=20, help="closed-loop steps dropped before recording")
     ap.add_argument("--max-nodes", type=int, default=0, help="initial per-vehicle arena (0: 1<<17 for c2, 1<<16 otherwise); grows while recording if a search needs more")
-    ap.add_argument("--cpu-budget-s", type=float, default=15.0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-host-inclusive", action="store_true", help="skip the native closed loop behind `value_host_inclusive` (profiling runs: the timed replay is then the last thing launched)")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skips the oracle (and with it the parity check of the measured steps)")
+    ap.add_argument("--no-host-inclusive", action="store_true", help="skip the native closed loop behind `value_host_inclusive` and the literal per-vehicle loop (profiling runs: the timed replay is then the last thing launched)")
+    ap.add_argument("--no-scaling-reference", action="store_true", help="N = 1, default workload: skip the C4 single-GPU rate")
+    ap.add_argument("--workload", default=None, choices=["c2", "c3", "c4", "c5"], help="default: c2 on one GPU, c4 (strong scaling) on several")
+    ap.add_argument("--weak", action="store_true", help="N > 1: one independent C2 network per GPU (weak scaling, no collective) instead of a sharded workload")
     ap.add_argument("--priorities", default=None, choices=["constant", "coloring", "random", "fca"],
                     help="priority strategy of the host driver: vehicle index (ConstantPrioritizer.m), graph colouring "
                     "(ColoringPrioritizer.m), random per step (RandomPrioritizer.m), future collision assessment (FcaPrioritizer.m)")
@@ -129,36 +277,22 @@ def main():
                     help="options.max_num_CLs (Config.m:28): couplings that do not fit into this many computation levels are cut "
                     "(GreedyCutter.m) and handled as parallel couplings")
     ap.add_argument("--instances", type=int, default=64, help="c5: simultaneous prioritizations per time step")
-    ap.add_argument("--shard", default="components", choices=["components", "levels"],
+    ap.add_argument("--shard", default="components", choices=["components", "levels", "hybrid"],
                     help="multi-GPU mode of c3/c4: whole coupling-graph components per rank (one speculative launch per rank and step, one "
-                    "all-gather of results) or block-partitioned levels (one all-gather per level)")
+                    "all-gather of results), block-partitioned levels (one all-gather per level), or hybrid (components, the heaviest one split by level)")
     args = ap.parse_args()
-    # BASELINE.json configs as named: C3 = 128 vehicles, Hp 8, colouring priorities cut to a 2-level coupling DAG
-    # (max_num_CLs = 2, Config.m:28; the cut couplings become previous-trajectory obstacles, PrioritizedController.m:409-447);
-    # C4 = 512 vehicles, Hp 10, graph-colouring levels (ColoringPrioritizer.m:31-89 + kahn.m); C2 / C5 = constant priorities, no cut
-    if args.workload == "c3":
-        args.vehicles, args.hp = 128, 8
-        defaults = ("coloring", 2)
-    elif args.workload == "c4":
-        args.vehicles, args.hp = 512, 10
-        defaults = ("coloring", 99)
-    else:
-        defaults = ("constant", 99)
-    if args.priorities is None:
-        args.priorities = defaults[0]
-    if args.max_levels is None:
-        args.max_levels = defaults[1]
-    sharded = args.workload != "c2"
-    if sharded:
-        args.record = min(args.record, 8)
-        args.skip = min(args.skip, 4)
-    if args.max_nodes <= 0:
-        args.max_nodes = (1 << 17) if args.workload == "c2" else (1 << 16)
-    explore = args.workload == "c5"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    default_workload = args.workload is None
+    if args.workload is None:
+        args.workload = "c2" if (world == 1 or args.weak) else "c4"
+    workload_defaults(args)
+    weak = args.workload == "c2"  # every rank its own network
+    sharded = not weak
+    explore = args.workload == "c5"
+
     import torch
 
     if not torch.cuda.is_available():
@@ -172,7 +306,7 @@ def main():
 
     from pdmpc.optimizer import GraphSearchHip
 
-    options, mpa, ctl = build_world(args, 0 if sharded else rank)
+    options, mpa, ctl = build_world(args, rank if weak else 0)
     options.device = local_rank
     optimizer = GraphSearchHip(options)
     optimizer._ensure_mpa(mpa)
@@ -181,46 +315,36 @@ def main():
     S = len(problems)
     parts = None
     full_problems = problems
-    if sharded and dist is not None and args.shard == "components":
+    if sharded and dist is not None and args.shard in ("components", "hybrid") and not explore:
         from pdmpc.distributed import partition_components, sub_problem
 
-        # every rank recorded the same closed loop; now it keeps only the components assigned to it
-        # longest-processing-time assignment by the work the searches took in the closed loop (pops + 1), not by vehicle count
+        # every rank recorded the same closed loop; now it keeps only the components assigned to it: longest-processing-time
+        # assignment by the work the searches took in the closed loop (pops + 1), not by vehicle count
         parts = [partition_components(p["preds"], world, weights=[w + 1 for w in p["pops"]] if "pops" in p else None) for p in full_problems]
         problems = [sub_problem(p, parts[b][rank]) for b, p in enumerate(full_problems)]
+    elif explore and dist is not None:
+        from pdmpc.distributed import partition_instances, sub_problem
+
+        # C5: the prioritization instances are independent until the final cost comparison: instances are dealt out to the ranks
+        parts = [partition_instances(p, world) for p in full_problems]
+        problems = [sub_problem(p, parts[b][rank]) for b, p in enumerate(full_problems)]
     # keep every recorded step resident in HBM (one bank each) and collect its algorithmic bytes
-    bytes_per_bank, pops_per_bank, nodes_per_bank = [], [], []
-    status_counts = {"ok": 0, "exhausted": 0, "arena_overflow": 0, "error": 0}
-    h.allow_overflow = True  # counted below (and grown away), not raised
+    h.allow_overflow = True  # statuses are checked below, per bank
     t_host = time.perf_counter()
-    t_grow = 0.0
-    for b, prob in enumerate(problems):
-        h.select_bank(b)
-        fb = [f if f is not None else [] for f in prob["fallback"]]
-        h.pack_step(prob["iters"], prob["preds"], fb)
-        while True:
-            h.launch()
-            recs = h.fetch(len(prob["iters"]))
-            if not (recs["status"] == 2).any():
-                break
-            # the reference's tree is unbounded (Tree.m:54-70): never measure truncated searches -- double the arenas, plan again
-            tg = time.perf_counter()
-            h.grow_arena(2 * h.arena_nodes()[0])
-            t_grow += time.perf_counter() - tg
+    bank_recs, bytes_per_bank, pops_per_bank, nodes_per_bank, t_grow = pack_banks(h, problems)
+    status_counts = {"ok": 0, "exhausted": 0, "arena_overflow": 0, "error": 0}
+    for recs in bank_recs:
         status_counts["ok"] += int((recs["status"] == 0).sum())
         status_counts["exhausted"] += int((recs["status"] == 1).sum())
+        status_counts["arena_overflow"] += int((recs["status"] == 2).sum())
         status_counts["error"] += int((recs["status"] < 0).sum())
-        st = h.stats()
-        bytes_per_bank.append(st["algorithmic_bytes"])
-        pops_per_bank.append(st["nodes_popped"])
-        nodes_per_bank.append(st["nodes_generated"])
     # a bank recorded before the arenas grew replays in the grown arenas: same searches, none of them truncated
     lds_bytes = h.stats()["lds_bytes"]
     host_buffer_ms = 1e3 * (time.perf_counter() - t_host - t_grow) / max(S, 1)  # pack (host buffers -> HBM) + launch + fetch + stats
 
     planner = None
     gather_bufs = None
-    if sharded and dist is not None and args.shard == "levels":
+    if sharded and dist is not None and args.shard == "levels" and not explore:
         from pdmpc.distributed import HipRangePlanner, plan_step_sharded
 
         planner = HipRangePlanner(optimizer, mpa, torch.device("cuda", local_rank))
@@ -232,6 +356,9 @@ def main():
             torch.zeros(max(per, 1) * REC_BYTES, dtype=torch.uint8, device="cuda"),
             torch.zeros(max(per, 1) * REC_BYTES * world, dtype=torch.uint8, device="cuda"),
         )
+    ext_stream = None
+    if gather_bufs is not None:
+        ext_stream = torch.cuda.ExternalStream(h.stream_ptr(), device=torch.device("cuda", local_rank))
 
     def one_step(i):
         if planner is not None:
@@ -241,32 +368,14 @@ def main():
         h.select_bank(i % S)
         h.launch()
         if gather_bufs is not None:
-            # end-of-step exchange: every rank receives the records of all components (one RCCL all-gather over xGMI)
-            h.export_results(0, len(problems[i % S]["iters"]), gather_bufs[0].data_ptr())  # waits for the kernel
-            dist.all_gather_into_tensor(gather_bufs[1], gather_bufs[0])
-            torch.cuda.current_stream().synchronize()
-            return
+            # end-of-step exchange: every rank receives the records of all components (one RCCL all-gather over xGMI), enqueued on
+            # the handle's own stream behind the launch: no host synchronisation between kernel and collective
+            h.export_results_async(0, len(problems[i % S]["iters"]), gather_bufs[0].data_ptr())
+            with torch.cuda.stream(ext_stream):
+                dist.all_gather_into_tensor(gather_bufs[1], gather_bufs[0])
         h.synchronize()
 
-    for i in range(args.warmup):
-        one_step(i)
-    h.reset_stats()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    lat = []
-    t_begin = time.perf_counter()
-    for i in range(args.steps):
-        t0 = time.perf_counter()
-        one_step(i)
-        lat.append(time.perf_counter() - t0)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t_begin
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.barrier()
-        elapsed = float(t.item())
+    elapsed, lat = measure_replay(h, problems, args.steps, args.warmup, one_step, dist, torch)
     st = h.stats()
     kernel_ms = st["kernel_ms"]
     n_launch = st["n_launches"]
@@ -275,16 +384,30 @@ def main():
     nodes = sum(nodes_per_bank[i % S] for i in range(args.steps))
     achieved = (alg_bytes / max(n_launch, 1)) / ((kernel_ms / max(n_launch, 1)) * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
 
+    # ---- the timed launches did the recorded work.  Their records are not fetched (no copies in the timed region), so: the device
+    # counts every plan that ended with anything but OK / EXHAUSTED (overflow, time-out) since the reset in front of the timed loop,
+    # and every bank is launched once more, in the arenas and under the conditions of the timed loop, and compared with the recording.
+    bad_status_timed = st["bad_status_plans"]
+    replay_mismatches, replay_checked = 0, 0
+    if planner is None:
+        for b in range(S):
+            h.select_bank(b)
+            h.launch()
+            after = h.fetch(len(problems[b]["iters"]))
+            replay_mismatches += count_record_mismatches(after, bank_recs[b])
+            replay_checked += len(after)
+
     # ---- the closed loop a caller of the boundary sees: the native step controller (csrc/step_controller.cpp) drives the same
     # scenario, every step = build the step problem on the host + pack (H2D) + one launch + fetch (D2H) + apply, no replay and
     # no interpreter on the path.  Reported next to `value`, never as `value`.
     host_inclusive = None
+    literal = None
     if not explore and dist is None and not args.no_host_inclusive:
         from pdmpc.native_controller import NativeController
         from pdmpc.road_network import commonroad_scenario
 
         tiles = max(1, (args.vehicles + 19) // 20)
-        nat = NativeController(options, commonroad_scenario(options, seed=args.seed + (0 if sharded else rank), tiles=tiles), mpa, h, coupling="distance",
+        nat = NativeController(options, commonroad_scenario(options, seed=args.seed + (rank if weak else 0), tiles=tiles), mpa, h, coupling="distance",
                                priority_strategy=args.priorities)
         nat.run(args.skip)
         ms = nat.run(args.steps)
@@ -294,17 +417,46 @@ def main():
             "ms_per_step": float(np.mean(ms)),
             "p50_latency_ms": float(np.median(ms)),
             "p99_latency_ms": float(np.sort(ms)[min(len(ms) - 1, int(0.99 * len(ms)))]),
-            "what": "closed loop through the C ABI (pdmpc_controller_run): host step logic in C++ + pack + H2D + one launch + D2H + apply per step, %d steps after %d" % (args.steps, args.skip),
+            "what": "closed loop through the C ABI (pdmpc_controller_run): host step logic in C++ + pack + H2D + one launch + D2H + apply per step, closed-loop steps %d..%d" % (args.skip + 1, args.skip + args.steps),
         }
         nat.close()
+        # ---- the same recorded steps, one run_optimizer call per vehicle (what GraphSearchHip.m gives an unmodified controller)
+        n_lit = min(S, max(1, args.steps))
+        h.select_bank(S)  # a scratch bank: the recorded banks stay as they are
+        marshalled = [h.step_args(p["iters"], p["preds"], [f if f is not None else [] for f in p["fallback"]]) for p in problems[:n_lit]]
+        h.plan_step_literal(marshalled[0])  # warm-up
+        lit_ms, lit_bad = [], 0
+        for b in range(n_lit):
+            t0 = time.perf_counter()
+            recs = h.plan_step_literal(marshalled[b])
+            lit_ms.append(1e3 * (time.perf_counter() - t0))
+            lit_bad += count_record_mismatches(recs, bank_recs[b])
+        literal = {
+            "value": 1e3 / float(np.mean(lit_ms)),
+            "unit": "MPC steps/s",
+            "ms_per_step": float(np.mean(lit_ms)),
+            "p50_latency_ms": float(np.median(lit_ms)),
+            "calls_per_step": args.vehicles,
+            "record_mismatches_vs_single_launch": lit_bad,
+            "what": "%d recorded steps, each as %d sequential pdmpc_plan_batch(h, 1, ...) calls in kahn order with the hand-over of solved areas on the host "
+            "(pdmpc_plan_step_literal: pack + H2D + launch + D2H per vehicle; marshalling from Python objects excluded)" % (n_lit, args.vehicles),
+        }
+        replay_mismatches += lit_bad
+    scal_ref = None
+    if world == 1 and dist is None and default_workload and not args.no_scaling_reference:
+        h.close()
+        scal_ref = scaling_reference(args, local_rank, torch)
     if rank == 0:
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json" if args.workload == "c2" else "none")
-        if os.path.exists(tpath):
+        traffic, tsrc = None, None
+        tpath = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (PROFILE_ROUND, args.workload))
+        if os.path.exists(tpath) and world == 1:
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tsrc = "profiles/%s: FETCH_SIZE + WRITE_SIZE of the timed launches of this workload, search kernel + the helper kernel next to it (separate rocprofv3 --pmc passes, tools/collect_profiles.sh)" % os.path.basename(tpath)
             except Exception:
                 traffic = None
+        mode = "levels sharded over ranks with one all-gather per level" if planner is not None else (
+            ("prioritization instances sharded over ranks" if explore else "coupling-graph components sharded over ranks") + ", one launch per rank and step, one all-gather of results" if gather_bufs is not None else "one launch per step")
         out = {
             "metric": "MPC steps/sec (whole node) + p50 per-step plan latency, N vehicles H=8",
             "value": (1 if sharded else world) * args.steps / elapsed,
@@ -318,6 +470,8 @@ def main():
             "host_buffer_ms_per_step": host_buffer_ms,  # PCIe-inclusive path incl. Python marshalling (never `value`)
             "value_host_inclusive": host_inclusive["value"] if host_inclusive else None,
             "host_inclusive": host_inclusive,
+            "value_run_optimizer_literal": literal["value"] if literal else None,
+            "run_optimizer_literal": literal,
             "higher_is_better": True,
             "scaling": "strong" if sharded else "weak",
             "vs_baseline": None,
@@ -327,8 +481,7 @@ def main():
                 "workload": "%s: %d vehicles on the CPM-lab road network (labmap fixture%s), Hp %d, InterX checker, %s MPA, "
                 "distance coupling, %s priorities, %s; %d recorded closed-loop steps replayed from HBM%s"
                 % (args.workload.upper() + (" (%d prioritizations of each step flattened into one batch)" % args.instances if explore else ""),
-                   args.vehicles, ", tiled" if sharded and not explore else "", args.hp, args.mpa, args.priorities,
-                   "levels sharded over ranks with one all-gather per level" if planner is not None else ("coupling-graph components sharded over ranks, one launch per rank and step, one all-gather of results" if gather_bufs is not None else "one launch per step"), S,
+                   args.vehicles, ", tiled" if sharded and not explore else "", args.hp, args.mpa, args.priorities, mode, S,
                    "" if sharded else "; per GPU one independent network"),
                 "vehicles": args.vehicles,
                 "Hp": args.hp,
@@ -344,7 +497,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_source": "profiles/r02_pmc_traffic.json: FETCH_SIZE + WRITE_SIZE of the timed launches of the default command, search kernel + the helper kernel next to it (separate rocprofv3 --pmc passes, tools/collect_profiles.sh)" if traffic is not None else None,
+                "traffic_source": tsrc,
                 "kernel": "pdmpc_frontier_kernel" if st["kernel"] == 1 else "pdmpc_search_kernel",
                 "kernel_ms_avg": kernel_ms / max(n_launch, 1),
                 "algorithmic_bytes_per_launch": alg_bytes / max(n_launch, 1),
@@ -352,9 +505,13 @@ def main():
                 "lds_bytes_per_workgroup": lds_bytes,
                 "open_list": "unordered near / far lists, rounds of the smallest keys (frontier kernel)" if st["kernel"] == 1 else ("block-min queue, %d keys in LDS" % st["queue_ring_entries"] if st["queue_mode"] == 1 else "binary heap"),
             },
-            # every plan of the recorded steps by outcome; arena_overflow must be 0 (the reference's tree is unbounded, Tree.m:54-70)
+            # every plan of the recorded steps by outcome; arena_overflow and error must be 0 (the reference's tree is unbounded, Tree.m:54-70)
             "status_counts": status_counts,
-            "arena_nodes_per_vehicle": h.arena_nodes()[0],
+            "bad_status_plans_in_timed_region": bad_status_timed,  # device-side count: must be 0
+            "replay_checked": replay_checked,  # plans planned once more after the timed loop and compared with the recording's records
+            "replay_mismatches": replay_mismatches,
+            "safe_replans": st["safe_replans"],
+            "arena_nodes_per_vehicle": None if scal_ref is not None else h.arena_nodes()[0],
             "counters": {
                 "nodes_popped_per_s": pops / elapsed,
                 "nodes_generated_per_s": nodes / elapsed,
@@ -363,21 +520,36 @@ def main():
                 "segment_pair_tests_per_s": st["segment_pair_tests"] / elapsed,
                 "speculation_arrivals_per_step": st["speculation_arrivals"] / args.steps,
                 "speculation_restarts_per_step": st["speculation_restarts"] / args.steps,
-                "speculation_wasted_pops_per_step": st["speculation_wasted_pops"] / args.steps,
                 "nodes_processed_per_step": st["nodes_processed"] / args.steps,  # frontier kernel: edges evaluated; nodes_popped of them are the reference's pops
                 "rounds_per_step": st["rounds"] / args.steps,
                 "shared_rounds_per_step": st["shared_rounds"] / args.steps,  # rounds whose edge checks helper workgroups took part in
                 "helper_checked_per_step": st["helper_checked"] / args.steps,
-                "entries_dropped_per_step": st["entries_dropped"] / args.steps,
-                "dropped_counted_as_pops_per_step": st["dropped_counted_as_pops"] / args.steps,
                 "queue_fallbacks_per_step": st["queue_fallbacks"] / args.steps,
             },
+            "scaling_reference": scal_ref,
         }
+        parity_mismatches = 0
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(options, mpa, full_problems, args.cpu_budget_s)
+            out["cpu_baseline"], n_steps_checked, n_plans, parity_mismatches = cpu_baseline(options, mpa, full_problems, bank_recs, args.cpu_budget_s)
+            out["parity_checked"] = n_steps_checked == S
+            out["parity_steps_checked"] = n_steps_checked
+            out["parity_plans_checked"] = n_plans
+            out["parity_mismatches"] = parity_mismatches
         print(json.dumps(out))
+        sys.stdout.flush()
+        bad = []
         if status_counts["arena_overflow"] or status_counts["error"]:
-            raise SystemExit("bench.py: %d plans overflowed their arena, %d carried an error status -- the measurement is void" % (status_counts["arena_overflow"], status_counts["error"]))
+            bad.append("%d plans overflowed their arena, %d carried an error status" % (status_counts["arena_overflow"], status_counts["error"]))
+        if bad_status_timed:
+            bad.append("%d plans of the timed region ended with an error or overflow status" % bad_status_timed)
+        if replay_mismatches:
+            bad.append("%d plans of the timed replay / the literal loop differ from the recording" % replay_mismatches)
+        if parity_mismatches:
+            bad.append("%d plans differ from the CPU oracle's" % parity_mismatches)
+        if scal_ref is not None and scal_ref["replay_mismatches"]:
+            bad.append("scaling reference: %d plans differ between recording and replay" % scal_ref["replay_mismatches"])
+        if bad:
+            raise SystemExit("bench.py: " + "; ".join(bad) + " -- the measurement is void")
     if dist is not None:
         dist.destroy_process_group()
 

@@ -161,12 +161,19 @@ typedef struct {
     int64_t rounds;                  /* frontier kernel: rounds (select a batch of the smallest open keys, process it) */
     int64_t shared_rounds;           /* ... of which shared with helper workgroups (CUs the launch left idle; same period) */
     int64_t helper_checked;          /* ... and the nodes whose edges those helpers evaluated (part of nodes_processed) */
+    int64_t safe_replans;            /* calls since pdmpc_create that were planned a second time in resident slices because a search of an
+                                        oversubscribed launch gave up waiting for a predecessor (see pdmpc_set_safe_launch) */
+    int64_t bad_status_plans;        /* plans since pdmpc_create / pdmpc_reset_stats whose record carries neither PDMPC_OK nor PDMPC_EXHAUSTED
+                                        (arena overflow, predecessor time-out), counted on the device: also covers launches nobody fetched */
 } pdmpc_stats;
 
 /* ---- life cycle (replaces GraphSearch() construction in OptimizerInterface.get_optimizer, :26-27,
  *      and the MEX instance table of priority_queue_interface_mex.cpp:48-53,111) ---- */
 int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle);
 int pdmpc_destroy(pdmpc_handle* handle);
+
+/* the configuration the handle runs with (defaults filled in, max_nodes = current arena size) and whether the MPA is uploaded */
+int pdmpc_get_config(pdmpc_handle* handle, pdmpc_config* config, int32_t* mpa_uploaded);
 
 /* uploads mpa.maneuvers / mpa.transition_matrix_single once (MotionPrimitiveAutomaton.m:5-9) */
 int pdmpc_upload_mpa(pdmpc_handle* handle, const pdmpc_mpa* mpa);
@@ -192,6 +199,13 @@ int pdmpc_arena_nodes(pdmpc_handle* handle, int32_t* max_nodes, int64_t* regrows
 int pdmpc_plan_step(pdmpc_handle* handle, int32_t n_vehicles, const pdmpc_vehicle_in* in, const int32_t* pred_offset,
                     const int32_t* pred_index, const pdmpc_polygon_set* fallback_shapes, pdmpc_vehicle_out* out);
 
+/* The same step the way an UNMODIFIED reference controller drives this backend: one pdmpc_plan_batch of ONE vehicle per
+ * run_optimizer call (PrioritizedController.m:335-341) in kahn order (PrioritizedSequentialController.m:77-94), the predecessors'
+ * solved areas handed over on the host as dynamic obstacles (PrioritizedController.m:476-491).  Arguments and records as for
+ * pdmpc_plan_step (slots in level order).  The slow way to use the library: bench.py reports it as value_run_optimizer_literal. */
+int pdmpc_plan_step_literal(pdmpc_handle* handle, int32_t n_vehicles, const pdmpc_vehicle_in* in, const int32_t* pred_offset, const int32_t* pred_index,
+                            const pdmpc_polygon_set* fallback_shapes, pdmpc_vehicle_out* out);
+
 /* ---- device-resident path used by the batched host driver and bench.py ----
  * pdmpc_pack_batch flattens host inputs into the handle's device blob (H2D copy, async on the
  * handle's stream); pdmpc_launch_packed runs the search kernel on whatever is packed (no copies);
@@ -202,6 +216,13 @@ int pdmpc_launch_packed(pdmpc_handle* handle);
 int pdmpc_launch_range(pdmpc_handle* handle, int32_t first, int32_t count);
 int pdmpc_fetch_results(pdmpc_handle* handle, int32_t n_vehicles, pdmpc_vehicle_out* out);
 int pdmpc_synchronize(pdmpc_handle* handle);
+/* Forward progress of launches with more searches than compute units.  A search spins for predecessors of the same launch; slots
+ * are in level order (pdmpc_pack_step reorders a batch that is not), so a launch whose workgroups are dispatched in index order
+ * cannot stall.  Should one stall anyway, the kernel's watchdog ends the waiting searches with status PDMPC_ERR_HIP and
+ * pdmpc_plan_batch / pdmpc_plan_step plan the call again in slices that are resident as a whole (predecessors in the same or an
+ * earlier slice): counted in pdmpc_stats.safe_replans.  on != 0 makes every launch of this handle use those slices from the start
+ * (the device-resident path below does not re-plan by itself). */
+int pdmpc_set_safe_launch(pdmpc_handle* handle, int32_t on);
 /* starts a new time step for launches issued with pdmpc_launch_range: results of earlier steps stop
  * satisfying predecessor waits (pdmpc_launch_packed does this implicitly) */
 int pdmpc_begin_step(pdmpc_handle* handle);

@@ -75,6 +75,8 @@ def _declare(L):
     L.oracle_sincos.argtypes = [dp, C.c_int, dp, dp]
     L.oracle_sincos.restype = None
     L.oracle_plan_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(TraceOut), C.c_int, C.POINTER(C.c_double)]
+    if hasattr(L, "oracle_plan_step"):  # (the arithmetic variants of tools/tolerance_study.py are built from the same file)
+        L.oracle_plan_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, ip, ip, C.c_void_p, C.c_int, ip, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.oracle_mt19937_doubles.argtypes = [C.c_uint32, C.c_int, dp]
     L.oracle_mt19937_doubles.restype = None
     L.oracle_plan_batch_sampled.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p, C.c_int, C.POINTER(C.c_double)]
@@ -258,6 +260,39 @@ def plan_step(options, mpa, problem, n_threads=1, mpa_struct=None):
         first += size
     del keep_m
     return recs, total_ms
+
+
+def plan_step_native(options, mpa, problem, n_threads=1, mpa_struct=None, variant=None):
+    """The same whole step as plan_step, with the level loop and the hand-over in C++ (oracle_plan_step) on a thread pool that
+    persists across levels and calls: what bench.py times as cpu_baseline.  Returns (records in slot order, milliseconds of the
+    whole step, time-weighted mean of the threads that were busy)."""
+    Hp = options.Hp
+    keep_m = None
+    if mpa_struct is None:
+        mpa_struct, keep_m = packing.pack_mpa(mpa)
+    iters = problem["iters"]
+    n = len(iters)
+    arr, keep_v = packing.pack_vehicles(iters, Hp)
+    off = np.zeros(n + 1, dtype=np.int32)
+    for i, p in enumerate(problem["preds"]):
+        off[i + 1] = off[i] + len(p)
+    idx = np.array([j for p in problem["preds"] for j in p] + [0], dtype=np.int32)
+    pool = packing._Pool()
+    fb = (packing.OPolygonSet * max(n, 1))()
+    for i in range(n):
+        shapes = problem["fallback"][i]
+        packing._polygon_set(pool, fb[i], [np.asarray(a, dtype=np.float64) for a in shapes] if shapes is not None and len(shapes) else [])
+    pool.freeze()
+    levels = np.asarray(problem["level_sizes"], dtype=np.int32)
+    recs = packing.out_array(n)
+    ms, thr = C.c_double(0.0), C.c_double(0.0)
+    cfg = make_abi_config(options)
+    rc = lib(variant).oracle_plan_step(C.byref(cfg), C.byref(mpa_struct), n, arr, off.ctypes.data_as(packing._iptr), idx.ctypes.data_as(packing._iptr), fb, len(levels),
+                                       levels.ctypes.data_as(packing._iptr), recs.ctypes.data_as(C.c_void_p), int(n_threads), C.byref(ms), C.byref(thr))
+    if rc != 0:
+        raise RuntimeError("oracle_plan_step failed: %d" % rc)
+    del keep_m, keep_v, pool
+    return recs[:n], ms.value, thr.value
 
 
 def mt19937_doubles(seed, n):

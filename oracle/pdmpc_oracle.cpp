@@ -24,6 +24,10 @@
 #include <cstdint>
 #include <cstring>
 #include <limits>
+#include <memory>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <queue>
 #include <thread>
 #include <tuple>
@@ -876,3 +880,180 @@ int oracle_plan_batch_sampled(const pdmpc_config* cfg, const pdmpc_mpa* mpa_in, 
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------
+// One whole time step on the host: the level loop of PrioritizedSequentialController.m:77-94 with the hand-over of
+// PrioritizedController.m:476-491 (a vehicle's dynamic obstacles = its own + info.shapes(1, :) of every sequential
+// predecessor, read from the records planned in earlier levels) and the published fallback areas of exhausted vehicles
+// (:568-616, 678-718).  Arguments as for pdmpc_plan_step (include/pdmpc.h); slots are in level order and level_sizes[l]
+// vehicles form level l.  All vehicles of a level plan concurrently on min(level size, n_threads) threads of a pool that
+// lives across levels and calls -- the stand-in for ComputationMode.parallel_threads (main.m:43-60), with no thread
+// start-up inside the timed region.  *elapsed_ms = wall time of the whole step (hand-over included, as the reference's
+// `plan` timer includes it, PrioritizedController.m:288-290); *threads_mean = time-weighted mean of the threads that
+// were actually busy (level times x min(level size, n_threads) / step time).
+namespace {
+class WorkerPool {
+public:
+    explicit WorkerPool(int n) {
+        for (int t = 0; t < n; ++t) threads_.emplace_back([this] { loop(); });
+    }
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+    int size() const { return (int)threads_.size(); }
+    // runs job(i) for i in [0, n) on at most `width` workers and waits
+    void run(int n, int width, const std::function<void(int)>& job) {
+        if (n <= 0) return;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            job_ = &job;
+            n_ = n;
+            next_ = 0;
+            pending_ = n;
+            width_ = std::min(width, (int)threads_.size());
+            active_ = 0;
+            gen_ += 1;
+        }
+        cv_.notify_all();
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+
+private:
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(m_);
+            cv_.wait(lk, [&] { return stop_ || (gen_ != seen && job_ && next_ < n_ && active_ < width_); });
+            if (stop_) return;
+            seen = gen_;
+            active_ += 1;
+            while (next_ < n_) {
+                const int i = next_++;
+                const std::function<void(int)>* job = job_;
+                lk.unlock();
+                (*job)(i);
+                lk.lock();
+                if (--pending_ == 0) done_.notify_all();
+            }
+            active_ -= 1;
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)>* job_ = nullptr;
+    int n_ = 0, next_ = 0, pending_ = 0, width_ = 0, active_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+
+WorkerPool& pool_of(int n_threads) {
+    static std::mutex m;
+    static std::unique_ptr<WorkerPool> pool;
+    std::lock_guard<std::mutex> g(m);
+    if (!pool || pool->size() < n_threads) pool.reset(new WorkerPool(n_threads));
+    return *pool;
+}
+}  // namespace
+
+extern "C" int oracle_plan_step(const pdmpc_config* cfg, const pdmpc_mpa* mpa_in, int n, const pdmpc_vehicle_in* in, const int32_t* pred_offset,
+                                const int32_t* pred_index, const pdmpc_polygon_set* fallback, int n_levels, const int32_t* level_sizes,
+                                pdmpc_vehicle_out* out, int n_threads, double* elapsed_ms, double* threads_mean) {
+    if (!cfg || !mpa_in || n < 0 || (n > 0 && (!in || !out || !pred_offset || !level_sizes))) return -1;
+    if (cfg->Hp < 1 || cfg->Hp > PDMPC_HP_MAX || mpa_in->Hp < cfg->Hp) return -1;
+    const int Hp = cfg->Hp;
+    const Mpa mpa = load_mpa(mpa_in);
+    int total = 0;
+    for (int l = 0; l < n_levels; ++l) total += level_sizes[l];
+    if (total != n) return -1;
+    if (n_threads < 1) n_threads = 1;
+    WorkerPool* pool = n_threads > 1 ? &pool_of(n_threads) : nullptr;
+    struct Scratch {  // the vehicle's dynamic obstacles with its predecessors' areas appended (PrioritizedController.m:476-491)
+        std::vector<int32_t> off;
+        std::vector<double> x, y;
+    };
+    std::vector<Scratch> scratch((size_t)n);
+    double busy = 0.0;
+    const auto t0 = std::chrono::steady_clock::now();
+    int first = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        const int size = level_sizes[l];
+        const auto tl0 = std::chrono::steady_clock::now();
+        std::function<void(int)> job = [&](int q) {
+            const int s = first + q;
+            pdmpc_vehicle_in v = in[s];
+            const int np = pred_offset[s + 1] - pred_offset[s];
+            if (np > 0) {
+                Scratch& sc = scratch[(size_t)s];
+                const pdmpc_polygon_set& d = in[s].dynamic_obstacles;
+                const int nd = d.n_polygons / Hp;
+                sc.off.assign(1, 0);
+                sc.x.clear();
+                sc.y.clear();
+                auto push_poly = [&](const double* px, const double* py, int cnt) {
+                    for (int c = 0; c < cnt; ++c) {
+                        sc.x.push_back(px[c]);
+                        sc.y.push_back(py[c]);
+                    }
+                    sc.off.push_back((int32_t)sc.x.size());
+                };
+                for (int r = 0; r < nd; ++r)
+                    for (int k = 0; k < Hp; ++k) {
+                        const int p = r * Hp + k;
+                        push_poly(d.x + d.offset[p], d.y + d.offset[p], d.offset[p + 1] - d.offset[p]);
+                    }
+                int rows = nd;
+                for (int e = pred_offset[s]; e < pred_offset[s + 1]; ++e) {
+                    const int ps = pred_index[e];
+                    const pdmpc_vehicle_out& po = out[ps];
+                    if (po.status == PDMPC_OK) {
+                        for (int k = 0; k < Hp; ++k) push_poly(po.shapes[k][0], po.shapes[k][1], po.shape_cols[k]);
+                        rows += 1;
+                    } else if (fallback && fallback[ps].n_polygons == Hp) {
+                        const pdmpc_polygon_set& fb = fallback[ps];
+                        for (int k = 0; k < Hp; ++k) push_poly(fb.x + fb.offset[k], fb.y + fb.offset[k], fb.offset[k + 1] - fb.offset[k]);
+                        rows += 1;
+                    }
+                }
+                static const double zero = 0.0;
+                v.dynamic_obstacles.n_polygons = rows * Hp;
+                v.dynamic_obstacles.offset = sc.off.data();
+                v.dynamic_obstacles.x = sc.x.empty() ? &zero : sc.x.data();
+                v.dynamic_obstacles.y = sc.y.empty() ? &zero : sc.y.data();
+            }
+            graph_search(*cfg, mpa, v, out[s], nullptr);
+            // the device publishes the fallback areas of an exhausted vehicle in its record: so does this loop
+            if (out[s].status != PDMPC_OK && fallback && fallback[s].n_polygons == Hp) {
+                const pdmpc_polygon_set& fb = fallback[s];
+                for (int k = 0; k < Hp; ++k) {
+                    const int cnt = std::min(fb.offset[k + 1] - fb.offset[k], (int32_t)PDMPC_VMAX);
+                    out[s].shape_cols[k] = cnt;
+                    for (int c = 0; c < cnt; ++c) {
+                        out[s].shapes[k][0][c] = fb.x[fb.offset[k] + c];
+                        out[s].shapes[k][1][c] = fb.y[fb.offset[k] + c];
+                    }
+                }
+            }
+        };
+        const int width = std::min(size, n_threads);
+        if (pool && width > 1)
+            pool->run(size, width, job);
+        else
+            for (int q = 0; q < size; ++q) job(q);
+        const auto tl1 = std::chrono::steady_clock::now();
+        busy += std::chrono::duration<double, std::milli>(tl1 - tl0).count() * (double)std::max(width, 1);
+        first += size;
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    if (elapsed_ms) *elapsed_ms = ms;
+    if (threads_mean) *threads_mean = ms > 0.0 ? busy / ms : 1.0;
+    return 0;
+}

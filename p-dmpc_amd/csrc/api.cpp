@@ -112,7 +112,9 @@ struct PackedStep {
     int n_packed = 0;
     int soup_cap = 0;
     int cand_cap = 0;  // most segments any single edge check can see (one step's soups + the boundary)
-    std::vector<int64_t> lit_cols;  // per vehicle: literal soup + boundary columns (for the bytes formula)
+    std::vector<int64_t> lit_cols;  // per slot: literal soup + boundary columns (for the bytes formula)
+    std::vector<int32_t> perm;      // empty: slot s holds the caller's vehicle s; else slot s holds vehicle perm[s] (pack_common put the batch into level order)
+    std::vector<int32_t> inv;       // ... and vehicle v sits in slot inv[v]
     void release() {
         h_veh.release();
         h_pts.release();
@@ -123,8 +125,42 @@ struct PackedStep {
     }
 };
 
+// Tuning knobs and A/B switches (environment variables PDMPC_*), read ONCE in pdmpc_create: a launch makes no getenv call.
+// Every switch leaves the results bit-identical; the defaults are the measured optima quoted next to their use.
+struct Tuning {
+    int fr_stage = -1;          // PDMPC_FR_STAGE: records staged per round (-1: by LDS budget)
+    int fr_two_per_cu = 0;      // PDMPC_FR_TWO_PER_CU
+    int debug_lds = 0;          // PDMPC_DEBUG_LDS
+    int hl_max = 8192;          // PDMPC_HL_MAX (pop-ordered kernel)
+    int bm_ring = -1;           // PDMPC_BM_RING (pop-ordered kernel; -1: by launch size)
+    int nv_max = 65536;         // PDMPC_NV_MAX (pop-ordered kernel)
+    int fr_ramp = -1;           // PDMPC_FR_RAMP (-1: 4, or 2 with expanding helpers)
+    double fr_join_scale = 4.0; // PDMPC_FR_JOIN_SCALE
+    int fr_root_dive = 0;       // PDMPC_FR_ROOT_DIVE
+    int fr_dive = 1024;         // PDMPC_FR_DIVE
+    uint32_t spin_limit = 1u << 22;  // PDMPC_SPIN_LIMIT
+    int debug_tail = 0;         // PDMPC_DEBUG_TAIL
+    int debug_progress = 0;     // PDMPC_DEBUG_PROGRESS
+    int dense = -1;             // PDMPC_DENSE (-1: follows the layout)
+    int drop = -1;              // PDMPC_DROP (pop-ordered kernel)
+    int drop_beyond_lds = 1;    // PDMPC_DROP_BEYOND_LDS
+    int eager = -1;             // PDMPC_EAGER
+    int fr_share_min = 128;     // PDMPC_FR_SHARE_MIN
+    int fr_own_div = 8;         // PDMPC_FR_OWN_DIV
+    int help_chunk = 0;         // PDMPC_HELP_CHUNK (0: 32 expanding, 64 checking)
+    int helpers = -1;           // PDMPC_HELPERS (-1: by launch size, 0: none)
+    int helpers_oversub = -1;   // PDMPC_HELPERS_OVERSUB
+    int help_expand = 1;        // PDMPC_HELP_EXPAND
+    int help_patience = 8;      // PDMPC_HELP_PATIENCE
+    int help_expand_oversub = -1;  // PDMPC_HELP_EXPAND_OVERSUB (-1: up to two searches per CU)
+    int fr_slice = -1;          // PDMPC_FR_SLICE (-1: only after a predecessor time-out, 0: never, 1: always when oversubscribed)
+    int debug_host = 0;         // PDMPC_DEBUG_HOST
+    int slot_order_reverse = 0; // PDMPC_TEST_REVERSE_DISPATCH: testing only, see launch_range
+};
+
 struct pdmpc_handle {
     pdmpc_config cfg{};
+    Tuning tune{};
     hipStream_t stream = nullptr;
     int n_cu = 256;
     // MPA
@@ -140,6 +176,8 @@ struct pdmpc_handle {
     uint32_t max_nodes = 0;
     uint32_t max_nodes_limit = 0;  // pdmpc_plan_* may grow the arenas up to this many nodes per vehicle (0: as far as HBM allows)
     int64_t arena_regrows = 0;     // times an overflowed call was re-planned with larger arenas
+    int64_t safe_replans = 0;      // times a call was re-planned in resident slices after a predecessor time-out
+    bool safe_launches = false;    // pdmpc_set_safe_launch: every launch in resident slices
     int max_vehicles = 0;
     DevBuf<NodeRec> anodes;
     DevBuf<double> ahk;
@@ -232,7 +270,7 @@ bool layout_frontier(pdmpc_handle* h, size_t budget, int n_waves, int areas, int
     // staged records of a round (node + parent, 128 B per entry): up to 256 entries where a CU has the LDS to itself
     uint32_t rest = (uint32_t)(budget - off - 256);
     stage_cap = (budget > kLdsMax / 2) ? 256u : 64u;
-    if (const char* e = getenv("PDMPC_FR_STAGE")) stage_cap = (uint32_t)std::max(0, std::min(1024, atoi(e)));  // tuning knob
+    if (h->tune.fr_stage >= 0) stage_cap = (uint32_t)std::min(1024, h->tune.fr_stage);  // tuning knob
     while (stage_cap && stage_cap * 128u + min_nodes > rest) stage_cap /= 2u;
     L.stage = off;
     off += stage_cap * 128u;
@@ -255,8 +293,7 @@ int compute_lds_frontier(pdmpc_handle* h, int n_launch, int soup_cap, int cand_c
     std::vector<Try> tries;
     // (two workgroups per CU only on request: with more searches than CUs one 16-wave workgroup per CU at a time is faster,
     // C5: 345 steps/s against 324 with 2 x 8 wavefronts)
-    bool crowded = false;
-    if (const char* e = getenv("PDMPC_FR_TWO_PER_CU")) crowded = n_launch > h->n_cu && atoi(e) != 0;  // tuning knob
+    const bool crowded = n_launch > h->n_cu && h->tune.fr_two_per_cu != 0;  // tuning knob
     if (crowded) {
         tries.push_back({kLdsMax / 2, h->waves_crowded, 1, 1});
         tries.push_back({kLdsMax / 2, h->waves_crowded, 0, 1});
@@ -267,7 +304,7 @@ int compute_lds_frontier(pdmpc_handle* h, int n_launch, int soup_cap, int cand_c
         LdsLayout L{};
         uint32_t hl = 0, nv = 0, nl = 0, wscr = 0, stage_cap = 0;
         if (!layout_frontier(h, t.budget, t.waves, t.areas, soup_cap, cand_cap, L, hl, nv, nl, wscr, stage_cap)) continue;
-        if (getenv("PDMPC_DEBUG_LDS"))
+        if (h->tune.debug_lds)
             fprintf(stderr, "pdmpc LDS layout (frontier): launch %d budget %zu waves %d areas %d wscr %u heap fallback %u stage %u nv %u nl %u total %u\n", n_launch, t.budget,
                     t.waves, t.areas, wscr, hl, stage_cap, nv, nl, L.total);
         h->lds = L;
@@ -342,8 +379,7 @@ int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in, int cand_cap_in)
     // or the block-min queue (key ring kr x 8 B; block minima and popped bits nb x 16 B; group minima 512 B).
     const uint32_t rest = (uint32_t)(budget - off - 256);
     const uint32_t region_cap = rest * 3 / 4;
-    uint32_t hl_max = 8192;  // 13 heap levels; measured on C2: 4096 -> 8192 entries = +3.5 % steps/s
-    if (const char* e = getenv("PDMPC_HL_MAX")) hl_max = (uint32_t)std::max(64, atoi(e));  // tuning knob
+    const uint32_t hl_max = (uint32_t)std::max(64, h->tune.hl_max);  // default 8192 = 13 heap levels; measured on C2: 4096 -> 8192 entries = +3.5 % steps/s
     uint32_t hl = std::min(hl_max, region_cap / 12);
     hl = std::min(hl, h->max_nodes) & ~3u;
     uint32_t region = align16(hl * 8) + align16(hl * 4);
@@ -356,7 +392,7 @@ int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in, int cand_cap_in)
             // measured on C2: 1024 .. 8192 entries make no difference.  With two workgroups per CU the LDS is better spent on
             // validity bytes (C4: 23.8 steps/s with 512 entries, 23.5 with 1024, 22.5 with 2048)
             uint32_t kr = 512, kr_max = (n_launch > h->n_cu) ? 512 : 2048;
-            if (const char* e = getenv("PDMPC_BM_RING")) kr_max = (uint32_t)std::max(512, atoi(e));  // tuning knob
+            if (h->tune.bm_ring > 0) kr_max = (uint32_t)std::max(512, h->tune.bm_ring);  // tuning knob
             while (kr * 2u * 8u + bm_fixed <= region_cap && kr * 2u <= kr_max) kr *= 2u;
             h->bm_kr = (int)kr;
             region = std::max(region, kr * 8u + bm_fixed);
@@ -369,8 +405,7 @@ int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in, int cand_cap_in)
         // (bm_kr == 0: no room, or more than 262144 nodes per vehicle -> this launch uses the binary heap)
     }
     // validity cache: one byte per node for the first NV nodes (three quarters of what is left, at most 65536)
-    uint32_t nv_max = 65536;
-    if (const char* e = getenv("PDMPC_NV_MAX")) nv_max = (uint32_t)std::max(1024, atoi(e));  // tuning knob
+    const uint32_t nv_max = (uint32_t)std::max(1024, h->tune.nv_max);  // tuning knob (default 65536)
     uint32_t nv = std::min(nv_max, (rest - region) / 4 * 3);
     nv = std::min(nv, h->max_nodes) & ~15u;
     uint32_t nl = (rest - region - nv) / (uint32_t)sizeof(NodeRec);
@@ -384,7 +419,7 @@ int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in, int cand_cap_in)
     off += nl * (uint32_t)sizeof(NodeRec);
     L.total = align16(off);
     if (L.total > budget) return fail(PDMPC_ERR_CAPACITY, "internal: LDS layout exceeds budget");
-    if (getenv("PDMPC_DEBUG_LDS"))
+    if (h->tune.debug_lds)
         fprintf(stderr, "pdmpc LDS layout: launch %d budget %zu fixed %u rest %u region %u (cap %u) hl %u ring %d blocks %d nv %u nl %u total %u queue %d\n", n_launch,
                 budget, (unsigned)(budget - 256 - rest), rest, region, region_cap, hl, h->bm_kr, h->bm_nb, nv, nl, L.total, h->queue_mode);
     h->lds = L;
@@ -424,8 +459,61 @@ int pack_common(pdmpc_handle* h, int n, const pdmpc_vehicle_in* in, const int32_
     if (B.h_veh.ensure((size_t)std::max(n, 1))) return fail(PDMPC_ERR_HIP, "hipHostMalloc failed");
     B.lit_cols.assign((size_t)n, 0);
     int soup_cap = 0, cand_cap = 0;
-    for (int i = 0; i < n; ++i) {
-        const pdmpc_vehicle_in& v = in[i];
+    // Slot order.  A search spins for predecessors of the same launch, so every predecessor must sit in a lower slot than its
+    // successors (launch_range: forward progress of oversubscribed launches).  Callers hand the vehicles over in level order
+    // (kahn.m); a batch that is not is put into level order here -- computation levels by longest path, stable within a level --
+    // and pdmpc_fetch_results hands the records back in the caller's order.
+    B.perm.clear();
+    B.inv.clear();
+    if (pred_offset) {
+        bool ordered = true;
+        for (int i = 0; i < n && ordered; ++i)
+            for (int q = pred_offset[i]; q < pred_offset[i + 1]; ++q) {
+                const int ps = pred_index[q];
+                if (ps < 0 || ps >= h->max_vehicles) return fail(PDMPC_ERR_INVALID, "predecessor slot out of range");
+                if (ps < n && ps >= i) ordered = false;
+            }
+        if (!ordered) {
+            std::vector<int32_t> level(n, 0), indeg(n, 0), succ_off(n + 1, 0), succ, queue;
+            for (int i = 0; i < n; ++i)
+                for (int q = pred_offset[i]; q < pred_offset[i + 1]; ++q)
+                    if (pred_index[q] >= 0 && pred_index[q] < n) {
+                        if (pred_index[q] == i) return fail(PDMPC_ERR_INVALID, "a vehicle is its own predecessor");
+                        succ_off[pred_index[q] + 1] += 1;
+                        indeg[i] += 1;
+                    }
+            for (int i = 0; i < n; ++i) succ_off[i + 1] += succ_off[i];
+            succ.resize((size_t)succ_off[n]);
+            std::vector<int32_t> fill(succ_off.begin(), succ_off.end() - 1);
+            for (int i = 0; i < n; ++i)
+                for (int q = pred_offset[i]; q < pred_offset[i + 1]; ++q)
+                    if (pred_index[q] >= 0 && pred_index[q] < n) succ[(size_t)fill[pred_index[q]]++] = i;
+            for (int i = 0; i < n; ++i)
+                if (indeg[i] == 0) {
+                    level[i] = 1;
+                    queue.push_back(i);
+                }
+            for (size_t qi = 0; qi < queue.size(); ++qi) {
+                const int u = queue[qi];
+                for (int q = succ_off[u]; q < succ_off[u + 1]; ++q) {
+                    const int w = succ[(size_t)q];
+                    level[w] = std::max(level[w], level[u] + 1);
+                    if (--indeg[w] == 0) queue.push_back(w);
+                }
+            }
+            if ((int)queue.size() != n) return fail(PDMPC_ERR_INVALID, "the sequential coupling graph has a cycle");
+            B.perm.resize((size_t)n);
+            for (int i = 0; i < n; ++i) B.perm[(size_t)i] = i;
+            std::stable_sort(B.perm.begin(), B.perm.end(), [&](int32_t x, int32_t y) { return level[x] < level[y]; });
+            B.inv.resize((size_t)n);
+            for (int sl = 0; sl < n; ++sl) B.inv[(size_t)B.perm[(size_t)sl]] = sl;
+        }
+    }
+    const bool permuted = !B.perm.empty();
+    for (int slot_i = 0; slot_i < n; ++slot_i) {
+        const int i = slot_i;  // (slot: index into the packed arrays)
+        const int vi = permuted ? B.perm[(size_t)slot_i] : slot_i;  // (the caller's vehicle)
+        const pdmpc_vehicle_in& v = in[vi];
         DevVehicle& d = B.h_veh.p[i];
         std::memset(&d, 0, sizeof d);
         if (!v.ref_x || !v.ref_y || !v.v_ref) return fail(PDMPC_ERR_INVALID, "reference trajectory missing");
@@ -447,13 +535,13 @@ int pack_common(pdmpc_handle* h, int n, const pdmpc_vehicle_in* in, const int32_
             d.ref_y[k] = v.ref_y[k];
             d.v_ref[k] = v.v_ref[k];
         }
-        const int n_pred = pred_offset ? pred_offset[i + 1] - pred_offset[i] : 0;
+        const int n_pred = pred_offset ? pred_offset[vi + 1] - pred_offset[vi] : 0;
         d.n_pred = n_pred;
         d.pred_off = (int32_t)pred.size();
         for (int q = 0; q < n_pred; ++q) {
-            const int ps = pred_index[pred_offset[i] + q];
+            const int ps = pred_index[pred_offset[vi] + q];
             if (ps < 0 || ps >= h->max_vehicles) return fail(PDMPC_ERR_INVALID, "predecessor slot out of range");
-            pred.push_back(ps);
+            pred.push_back(permuted && ps < n ? B.inv[(size_t)ps] : ps);
         }
         const int n_dyn = v.dynamic_obstacles.n_polygons / Hp;
         const int n_hdv = v.hdv_reachable_sets.n_polygons / Hp;
@@ -486,15 +574,15 @@ int pack_common(pdmpc_handle* h, int n, const pdmpc_vehicle_in* in, const int32_
         d.ll_len = (int32_t)(pts.size() / 2) - d.ll_off;
         need += d.ll_len;
         B.lit_cols[i] += d.ll_len;
-        if (fallback && fallback[i].n_polygons > 0) {
-            if (fallback[i].n_polygons != Hp) return fail(PDMPC_ERR_INVALID, "fallback_shapes must hold Hp polygons per vehicle");
+        if (fallback && fallback[vi].n_polygons > 0) {
+            if (fallback[vi].n_polygons != Hp) return fail(PDMPC_ERR_INVALID, "fallback_shapes must hold Hp polygons per vehicle");
             int rc2;
-            if ((rc2 = check_set(fallback[i], "fallback_shapes"))) return rc2;
+            if ((rc2 = check_set(fallback[vi], "fallback_shapes"))) return rc2;
             for (int k = 0; k < Hp; ++k) {
                 d.fb_off[k] = (int32_t)(pts.size() / 2);
-                if (fallback[i].offset[k + 1] - fallback[i].offset[k] > PDMPC_VMAX)
+                if (fallback[vi].offset[k + 1] - fallback[vi].offset[k] > PDMPC_VMAX)
                     return fail(PDMPC_ERR_INVALID, "fallback area has more than PDMPC_VMAX columns");
-                append_poly(fallback[i], k, false);
+                append_poly(fallback[vi], k, false);
             }
             d.fb_off[Hp] = (int32_t)(pts.size() / 2);
         } else {
@@ -546,11 +634,15 @@ int alloc_arenas(pdmpc_handle* h, uint32_t nodes) {
     return 0;
 }
 
-int launch_range(pdmpc_handle* h, int first, int count) {
+// safe == true: the recovery path after a predecessor time-out (plan_packed_growing): slices that are resident as a whole,
+// no helper workgroups next to an oversubscribed launch, the default spin limit.
+int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     if (!h) return fail(PDMPC_ERR_INVALID, "null handle");
     PackedStep& B = h->banks[h->bank];
     if (first < 0 || count < 0 || first + count > B.n_packed) return fail(PDMPC_ERR_INVALID, "launch range outside the packed batch");
+    if (!B.perm.empty() && (first != 0 || count != B.n_packed)) return fail(PDMPC_ERR_INVALID, "range launches need a batch packed in level order (predecessors in lower slots)");
     if (count == 0) return PDMPC_OK;
+    const Tuning& T = h->tune;
     int rc = compute_lds(h, count, B.soup_cap, B.cand_cap);
     if (rc) return rc;
     // the sampled optimizer keeps its tree (288 nodes x (16 children + parent + trim) x 2 B) where the open list would be
@@ -596,28 +688,22 @@ int launch_range(pdmpc_handle* h, int first, int count) {
     a.frontier = frontier ? 1 : 0;
     a.fr_round = h->fr_round > 0 ? h->fr_round : 768;  // cap of a round; measured on C2 / C3 (with the early-exit InterX): 256 -> 342 / 322 steps/s, 512 -> 355 / 342, 768 -> 358 / 345, 1024 -> 358 / 345
     a.fr_stage_cap = h->fr_stage_cap;
-    a.fr_ramp = 4;  // a round grows by a quarter of the nodes done so far; measured on C2 / C3 (cap 768): 2 -> 331 / 354 steps/s, 3 -> 354 / 352, 4 -> 358 / 345, 6 -> 355 / 338
-    if (const char* e = getenv("PDMPC_FR_RAMP")) a.fr_ramp = std::max(1, atoi(e));  // tuning knob
+    a.fr_ramp = T.fr_ramp > 0 ? T.fr_ramp : 4;  // a round grows by a quarter of the nodes done so far; measured on C2 / C3 (cap 768): 2 -> 331 / 354 steps/s, 3 -> 354 / 352, 4 -> 358 / 345, 6 -> 355 / 338
     a.fr_near_fill = h->fr_near_fill;
     a.fr_near_max = h->fr_near_max;
-    a.fr_join_scale = 4.0;  // measured on C2 / C3 / C5: 1 -> 419 / 396 / 347 steps/s, 4 -> 434 / 396 / 353, 8 -> 434 / 397 / 345, 32 -> 429 / 394 / 344
-    if (const char* e = getenv("PDMPC_FR_JOIN_SCALE")) a.fr_join_scale = atof(e);  // tuning knob
-    a.fr_dive = 1024;  // in rounds of up to this many entries a wave goes on with the best child while its key stays within the round's range (frontier_kernel.hip, fr_process); measured on C2 / C3 / C5: 0 -> 408 / 391 / 307 steps/s, 64 -> 409 / 391 / 314, 1024 -> 419 / 397 / 323
-a.fr_root_dive = 0;
-    if (const char* e = getenv("PDMPC_FR_ROOT_DIVE")) a.fr_root_dive = atoi(e) != 0;  // tuning knob
-        if (const char* e = getenv("PDMPC_FR_DIVE")) a.fr_dive = std::max(0, atoi(e));  // tuning knob / A-B switch (0: never): results are identical
-    a.spin_limit = 1u << 22;
-    if (const char* e = getenv("PDMPC_SPIN_LIMIT")) a.spin_limit = (uint32_t)std::max(1024, atoi(e));  // debugging: fail fast
-    a.debug_tail = getenv("PDMPC_DEBUG_TAIL") ? atoi(getenv("PDMPC_DEBUG_TAIL")) : 0;
-    if (getenv("PDMPC_DEBUG_PROGRESS") && !h->progress) {
+    a.fr_join_scale = T.fr_join_scale;  // measured on C2 / C3 / C5: 1 -> 419 / 396 / 347 steps/s, 4 -> 434 / 396 / 353, 8 -> 434 / 397 / 345, 32 -> 429 / 394 / 344
+    a.fr_dive = T.fr_dive;  // in rounds of up to this many entries a wave goes on with the best child while its key stays within the round's range (frontier_kernel.hip, fr_process); measured on C2 / C3 / C5: 0 -> 408 / 391 / 307 steps/s, 64 -> 409 / 391 / 314, 1024 -> 419 / 397 / 323
+    a.fr_root_dive = T.fr_root_dive;
+    a.spin_limit = safe ? (1u << 22) : T.spin_limit;
+    a.debug_tail = T.debug_tail;
+    if (T.debug_progress && !h->progress) {
         if (hipHostMalloc((void**)&h->progress, (size_t)h->max_vehicles * 64 * 4, hipHostMallocMapped) != hipSuccess) h->progress = nullptr;
         if (h->progress) std::memset(h->progress, 0, (size_t)h->max_vehicles * 64 * 4);
     }
     a.progress = h->progress;
     a.speculate = h->speculate;
     a.crowded = count > h->n_cu ? 1 : 0;
-    a.dense = h->two_per_cu;
-    if (const char* e = getenv("PDMPC_DENSE")) a.dense = atoi(e) != 0;  // tuning knob
+    a.dense = T.dense >= 0 ? T.dense : h->two_per_cu;
     a.speculate_expansion = h->speculate_expansion;
     a.n_validators = h->n_validators;
     a.n_waves = h->n_waves;
@@ -626,35 +712,40 @@ a.fr_root_dive = 0;
     a.bm_nb = h->bm_nb;
     // dropping hides pops from the pop trace: off while tracing (PDMPC_DROP=2 forces it, for tests that only compare records)
     a.drop_invalid = h->cfg.trace_pops > 0 ? 0 : 1;
-    if (const char* e = getenv("PDMPC_DROP")) a.drop_invalid = atoi(e) == 2 ? 1 : (atoi(e) == 0 ? 0 : a.drop_invalid);  // tuning knob
-    a.eager_validation = a.drop_invalid;
-    a.drop_beyond_lds = 1;
-    if (const char* e = getenv("PDMPC_DROP_BEYOND_LDS")) a.drop_beyond_lds = atoi(e) != 0;  // tuning knob
-    if (const char* e = getenv("PDMPC_EAGER")) a.eager_validation = atoi(e) != 0;  // tuning knob
+    if (T.drop >= 0) a.drop_invalid = T.drop == 2 ? 1 : (T.drop == 0 ? 0 : a.drop_invalid);
+    a.eager_validation = T.eager >= 0 ? T.eager : a.drop_invalid;
+    a.drop_beyond_lds = T.drop_beyond_lds;
     a.tie_count = h->d_tie_count.p;
     a.work_count = h->d_work_count.p;
     a.sampled_random = h->d_random.p;
     a.sampled_n_random = h->sampled_n_random;
+    a.reverse_dispatch = (!safe && T.slot_order_reverse) ? 1 : 0;
     if (h->events_used == h->events.size()) {
         hipEvent_t e0, e1;
         HIPCHK(hipEventCreate(&e0));
         HIPCHK(hipEventCreate(&e1));
         h->events.emplace_back(e0, e1);
     }
-    // helper workgroups on the CUs this launch leaves idle (frontier kernel, InterX; never when that would put more workgroups
-    // on the chip than it holds at one per CU: a helper spins until every search has finished)
+    // Oversubscribed launches (more searches than CUs at one 16-wave workgroup per CU).  A resident search spins for
+    // predecessors of the same launch; slots are in level order (pack_common sees to it), so as long as the hardware hands out
+    // workgroups in index order every predecessor was dispatched before its successors and the launch cannot stall.  That order
+    // is not a documented guarantee: should a launch ever stall, the watchdog (spin_limit) ends the waiting searches with an
+    // error status and plan_packed_growing plans the call again with safe == true, in slices that are resident as a whole (a
+    // slice's predecessors are in it or in an earlier slice) -- forward progress then needs no assumption at all.
+    // PDMPC_FR_SLICE=1 slices always (measured on C4: 9.8 steps/s in one launch against 7.4 in slices), =0 never.
+    const bool oversub = frontier && !h->two_per_cu && count > h->n_cu;
+    const bool slice = oversub && (T.fr_slice == 1 || (safe && T.fr_slice != 0));
+    // helper workgroups on the CUs this launch leaves idle (frontier kernel, InterX).  A helper spins until every search of
+    // the launch has published, so in the safe mode an oversubscribed launch gets none (they would hold CUs a slice counts on).
     a.n_searches = count;
     a.n_helpers = 0;
-    a.fr_share_min = 128;
-    if (const char* e = getenv("PDMPC_FR_SHARE_MIN")) a.fr_share_min = std::max(64, atoi(e));  // tuning knob
-    a.fr_own_div = 8;
-    if (const char* e = getenv("PDMPC_FR_OWN_DIV")) a.fr_own_div = std::max(1, atoi(e));  // tuning knob
-    a.help_chunk = 0;  // (default chosen below, once it is known whether the helpers expand)
-    if (const char* e = getenv("PDMPC_HELP_CHUNK")) a.help_chunk = std::min(128, std::max(16, atoi(e) / 16 * 16));  // tuning knob
-    if (frontier && !h->sampled_launch && h->cfg.checker == PDMPC_CHECK_INTERX && h->speculate) {
+    a.fr_share_min = T.fr_share_min;
+    a.fr_own_div = T.fr_own_div;
+    a.help_chunk = T.help_chunk;  // (0: chosen below, once it is known whether the helpers expand)
+    if (frontier && !h->sampled_launch && h->cfg.checker == PDMPC_CHECK_INTERX && h->speculate && !slice) {
         // (measured on C2, 20 searches, / C3, 128: 8 helpers 535 / 476 steps/s, 16: 529 / 506, 32: 516 / 522, 128: 507 / 483)
         int want = std::min(h->helpers_max, std::max(32, count / 2));  // (helpers that expand: the owner of a shared round waits for them, more of them with shorter runs finish sooner)
-        if (const char* e = getenv("PDMPC_HELPERS")) want = std::max(0, atoi(e));  // A/B switch (0: none): results are identical
+        if (T.helpers >= 0) want = T.helpers;  // A/B switch (0: none): results are identical
         a.n_helpers = std::max(0, std::min(want, h->n_cu - count));
         if (a.n_helpers < 2) a.n_helpers = 0;
         if (count > h->n_cu) {
@@ -663,33 +754,29 @@ a.fr_root_dive = 0;
             // for a CU gets it first).  Measured on C4 (512 searches) / C5 (1280): none 25.6 / 352 steps/s, 16 helpers 38.5 / 353,
             // 32: 41.5 / 352, 64: 43.4 / 332, 96: 42.8 / 299; with helpers that also expand (C4 only, see below) 64: 43.6, 96: 45.9, 128: 46.4.
             a.n_helpers = count <= 2 * h->n_cu ? 96 : 32;
-            if (const char* e = getenv("PDMPC_HELPERS_OVERSUB")) a.n_helpers = std::max(0, std::min(atoi(e), h->n_cu / 2));  // tuning knob
-            if (const char* e = getenv("PDMPC_HELPERS")) a.n_helpers = std::min(a.n_helpers, std::max(0, atoi(e)));           // (0 switches every helper off)
+            if (T.helpers_oversub >= 0) a.n_helpers = std::min(T.helpers_oversub, h->n_cu / 2);
+            if (T.helpers >= 0) a.n_helpers = std::min(a.n_helpers, T.helpers);  // (0 switches every helper off)
         }
     }
     a.help_board = h->d_help_board.p;
     a.help_list = h->d_help_list.p;
     a.help_verdict = h->d_help_verdict.p;
     a.help_cs = h->d_help_cs.p;
-    a.help_expand = 1;
-    if (const char* e = getenv("PDMPC_HELP_EXPAND")) a.help_expand = atoi(e) != 0;  // A/B switch: results are identical
-    a.help_patience = 8;
-    if (const char* e = getenv("PDMPC_HELP_PATIENCE")) a.help_patience = std::max(0, atoi(e));  // tuning knob
+    a.help_expand = T.help_expand;  // A/B switch: results are identical
+    a.help_patience = T.help_patience;
     // with more searches than CUs helpers are scarce and an owner that waits for them loses (C5, 5 searches per CU: 332 against 355
     // steps/s); up to two searches per CU the tail of the launch is long enough for expanding helpers to pay (C4: 42.1 -> 46)
-    bool expand_oversub = count <= 2 * h->n_cu;
-    if (const char* e = getenv("PDMPC_HELP_EXPAND_OVERSUB")) expand_oversub = atoi(e) != 0;  // tuning knob
+    const bool expand_oversub = T.help_expand_oversub >= 0 ? T.help_expand_oversub != 0 : count <= 2 * h->n_cu;
     if (h->n_words != 1 || h->fr_stage_cap < 128 || (count > h->n_cu && !expand_oversub)) a.help_expand = 0;  // (the helper kernel expands one successor-mask word per node; a run's records sit in its staging area)
-    if (a.help_expand && a.n_helpers > 0) {
+    if (a.help_expand && a.n_helpers > 0 && count <= h->n_cu) {
         // helpers take the bulk of a large round off the owner, so rounds may grow faster and larger (measured on C2 / C3 with expanding
         // helpers: ramp 4, cap 768 -> 629 / 616 steps/s; 3, 768 -> 673 / 651; 2, 768 -> 680 / 662; 2, 1024 -> 686 / 656; 1, 1024 -> 632 / 604)
-        if (count <= h->n_cu) {
-            if (!getenv("PDMPC_FR_RAMP")) a.fr_ramp = 2;
-            if (h->fr_round <= 0) a.fr_round = 1280;  // (ready list: 1536 entries; measured on C2 / C3: 1024 -> 734 / 665 steps/s, 1280 -> 747 / 675, 1536 -> 749 / 667)
-        }
+        if (T.fr_ramp <= 0) a.fr_ramp = 2;
+        if (h->fr_round <= 0) a.fr_round = 1280;  // (ready list: 1536 entries; measured on C2 / C3: 1024 -> 734 / 665 steps/s, 1280 -> 747 / 675, 1536 -> 749 / 667)
     }
     if (a.help_chunk == 0) a.help_chunk = a.help_expand ? 32 : 64;  // measured on C2 / C3: expanding helpers 64 -> 555 / 595 steps/s, 32 -> 595 / 584; checking only: 64 best (C4 43.3 against 40.9)
     a.help_finished = h->d_help_finished.p;
+    bool helpers_launched = false;
     if (a.n_helpers > 0) {
         HIPCHK(hipMemsetAsync(h->d_help_board.p + (size_t)first * PDMPC_HB_WORDS, 0, (size_t)count * PDMPC_HB_WORDS * sizeof(unsigned long long), h->stream));
         HIPCHK(hipMemsetAsync(h->d_help_finished.p, 0, 16 * sizeof(uint32_t), h->stream));
@@ -701,34 +788,33 @@ a.fr_root_dive = 0;
         const int hrc = pdmpc_launch_helpers(&a, (void*)hst);
         if (hrc != 0) return fail(PDMPC_ERR_HIP, std::string("helper kernel launch failed: ") + hipGetErrorString((hipError_t)hrc));
         HIPCHK(hipEventRecord(h->ev_help_done, hst));
+        helpers_launched = true;
     }
     auto& ev = h->events[h->events_used++];
     HIPCHK(hipEventRecord(ev.first, h->stream));
     h->last_launch_frontier = frontier;
     int lrc = 0;
-    // (off by default: measured on C4, 512 workgroups at one per CU, 9.8 steps/s in one launch against 7.4 in two slices, and no
-    // launch stalled in 150; PDMPC_FR_SLICE=1 is the safety switch should a dispatch order ever starve a predecessor)
-    const bool slice = getenv("PDMPC_FR_SLICE") && atoi(getenv("PDMPC_FR_SLICE")) != 0;
-    if (frontier && !h->two_per_cu && count > h->n_cu && slice) {
-        // More workgroups than the chip holds at one per CU (the obstacle soup was too large for the two-per-CU layout): a
-        // workgroup that waits for a predecessor must never keep that predecessor off the chip, so the batch goes in slices
-        // that are resident as a whole.  Slots are in level order: a slice's predecessors are in it or in an earlier slice.
+    if (slice) {
         for (int done = 0; done < count && lrc == 0; done += h->n_cu) {
             KernelArgs part = a;
             part.first = first + done;
-            lrc = pdmpc_launch_frontier(&part, std::min(h->n_cu, count - done), (void*)h->stream);
+            part.n_searches = std::min(h->n_cu, count - done);
+            lrc = pdmpc_launch_frontier(&part, part.n_searches, (void*)h->stream);
         }
     } else {
         lrc = h->sampled_launch ? pdmpc_launch_sampled(&a, count, (void*)h->stream)
                                 : (frontier ? pdmpc_launch_frontier(&a, count, (void*)h->stream) : pdmpc_launch_search(&a, count, (void*)h->stream));
     }
     if (lrc != 0) {
+        // the helpers already run and poll the boards until their idle time-out: nothing may free or regrow what they read before
+        // they have left
+        if (helpers_launched) (void)hipStreamSynchronize(count > h->n_cu ? h->help_stream_low : h->help_stream);
         char buf[256];
         snprintf(buf, sizeof buf, "kernel launch failed: %s (LDS %u B)", hipGetErrorString((hipError_t)lrc), h->lds.total);
         return fail(PDMPC_ERR_HIP, buf);
     }
     HIPCHK(hipEventRecord(ev.second, h->stream));
-    if (a.n_helpers > 0) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_help_done, 0));
+    if (helpers_launched) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_help_done, 0));
     h->stats.lds_bytes = h->lds.total;
     h->stats.lds_nodes = h->NL;
     h->stats.queue_mode = a.queue_mode;
@@ -759,15 +845,48 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
     pdmpc_handle* h = new pdmpc_handle();
     h->cfg = *config;
     h->banks.resize(1);
-    if (const char* e = getenv("PDMPC_SPECULATE")) h->speculate = atoi(e) != 0;  // A/B switch for benchmarking; results are identical
-    if (const char* e = getenv("PDMPC_WAVES")) h->waves_latency = h->waves_crowded = std::min(PDMPC_MAX_WAVES, std::max(4, atoi(e)));  // likewise
-    if (const char* e = getenv("PDMPC_VALIDATORS")) h->n_validators = std::max(1, atoi(e));  // likewise
-    if (const char* e = getenv("PDMPC_SPEC_EXPAND")) h->speculate_expansion = atoi(e) != 0;  // likewise
-    if (const char* e = getenv("PDMPC_KERNEL")) h->kernel_frontier = std::string(e) != "serial";  // A/B switch: results are identical
-    if (const char* e = getenv("PDMPC_FR_ROUND")) h->fr_round = std::max(1, atoi(e));                 // tuning knobs of the frontier kernel
-    if (const char* e = getenv("PDMPC_FR_NEAR_FILL")) h->fr_near_fill = std::max(64, atoi(e));
-    if (const char* e = getenv("PDMPC_FR_NEAR_MAX")) h->fr_near_max = std::max(256, atoi(e));
-    if (const char* e = getenv("PDMPC_QUEUE")) h->queue_mode = atoi(e) != 0 ? PDMPC_QUEUE_BLOCKMIN : PDMPC_QUEUE_HEAP;  // likewise
+    {
+        // every environment switch is read here, once (A/B switches for benchmarking and tuning knobs; results are identical)
+        auto env_i = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+        Tuning& T = h->tune;
+        h->speculate = env_i("PDMPC_SPECULATE", 1) != 0;
+        if (getenv("PDMPC_WAVES")) h->waves_latency = h->waves_crowded = std::min(PDMPC_MAX_WAVES, std::max(4, env_i("PDMPC_WAVES", 16)));
+        if (getenv("PDMPC_VALIDATORS")) h->n_validators = std::max(1, env_i("PDMPC_VALIDATORS", 1));
+        h->speculate_expansion = env_i("PDMPC_SPEC_EXPAND", 1) != 0;
+        if (const char* e = getenv("PDMPC_KERNEL")) h->kernel_frontier = std::string(e) != "serial";
+        if (getenv("PDMPC_FR_ROUND")) h->fr_round = std::max(1, env_i("PDMPC_FR_ROUND", 0));
+        if (getenv("PDMPC_FR_NEAR_FILL")) h->fr_near_fill = std::max(64, env_i("PDMPC_FR_NEAR_FILL", 0));
+        if (getenv("PDMPC_FR_NEAR_MAX")) h->fr_near_max = std::max(256, env_i("PDMPC_FR_NEAR_MAX", 0));
+        if (getenv("PDMPC_QUEUE")) h->queue_mode = env_i("PDMPC_QUEUE", 1) != 0 ? PDMPC_QUEUE_BLOCKMIN : PDMPC_QUEUE_HEAP;
+        if (getenv("PDMPC_FR_STAGE")) T.fr_stage = std::max(0, env_i("PDMPC_FR_STAGE", 0));
+        T.fr_two_per_cu = env_i("PDMPC_FR_TWO_PER_CU", 0) != 0;
+        T.debug_lds = getenv("PDMPC_DEBUG_LDS") != nullptr;
+        T.hl_max = env_i("PDMPC_HL_MAX", T.hl_max);
+        T.bm_ring = env_i("PDMPC_BM_RING", T.bm_ring);
+        T.nv_max = env_i("PDMPC_NV_MAX", T.nv_max);
+        if (getenv("PDMPC_FR_RAMP")) T.fr_ramp = std::max(1, env_i("PDMPC_FR_RAMP", 4));
+        if (const char* e = getenv("PDMPC_FR_JOIN_SCALE")) T.fr_join_scale = atof(e);
+        T.fr_root_dive = env_i("PDMPC_FR_ROOT_DIVE", 0) != 0;
+        T.fr_dive = std::max(0, env_i("PDMPC_FR_DIVE", T.fr_dive));
+        if (getenv("PDMPC_SPIN_LIMIT")) T.spin_limit = (uint32_t)std::max(1024, env_i("PDMPC_SPIN_LIMIT", 0));  // debugging: fail fast
+        T.debug_tail = env_i("PDMPC_DEBUG_TAIL", 0);
+        T.debug_progress = getenv("PDMPC_DEBUG_PROGRESS") != nullptr;
+        if (getenv("PDMPC_DENSE")) T.dense = env_i("PDMPC_DENSE", 0) != 0;
+        T.drop = env_i("PDMPC_DROP", -1);
+        T.drop_beyond_lds = env_i("PDMPC_DROP_BEYOND_LDS", 1) != 0;
+        if (getenv("PDMPC_EAGER")) T.eager = env_i("PDMPC_EAGER", 0) != 0;
+        T.fr_share_min = std::max(64, env_i("PDMPC_FR_SHARE_MIN", T.fr_share_min));
+        T.fr_own_div = std::max(1, env_i("PDMPC_FR_OWN_DIV", T.fr_own_div));
+        if (getenv("PDMPC_HELP_CHUNK")) T.help_chunk = std::min(128, std::max(16, env_i("PDMPC_HELP_CHUNK", 32) / 16 * 16));
+        if (getenv("PDMPC_HELPERS")) T.helpers = std::max(0, env_i("PDMPC_HELPERS", 0));
+        if (getenv("PDMPC_HELPERS_OVERSUB")) T.helpers_oversub = std::max(0, env_i("PDMPC_HELPERS_OVERSUB", 0));
+        T.help_expand = env_i("PDMPC_HELP_EXPAND", 1) != 0;
+        T.help_patience = std::max(0, env_i("PDMPC_HELP_PATIENCE", T.help_patience));
+        if (getenv("PDMPC_HELP_EXPAND_OVERSUB")) T.help_expand_oversub = env_i("PDMPC_HELP_EXPAND_OVERSUB", 0) != 0;
+        if (getenv("PDMPC_FR_SLICE")) T.fr_slice = env_i("PDMPC_FR_SLICE", 0) != 0;
+        T.debug_host = getenv("PDMPC_DEBUG_HOST") != nullptr;
+        T.slot_order_reverse = env_i("PDMPC_TEST_REVERSE_DISPATCH", 0) != 0;
+    }
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const uint32_t want_nodes = config->max_nodes > 0 ? (uint32_t)config->max_nodes : 32768u;  // default arena: 256 x 32768 nodes, about 0.6 GB
     h->max_vehicles = config->max_vehicles > 0 ? config->max_vehicles : 256;
@@ -923,7 +1042,13 @@ int pdmpc_launch_packed(pdmpc_handle* h) {
     if (!h) return fail(PDMPC_ERR_INVALID, "null handle");
     HIPCHK(hipSetDevice(h->cfg.device));
     h->epoch += 1;  // a new step: results of earlier launches no longer satisfy predecessor waits
-    return launch_range(h, 0, h->banks[h->bank].n_packed);
+    return launch_range(h, 0, h->banks[h->bank].n_packed, h->safe_launches);
+}
+
+int pdmpc_set_safe_launch(pdmpc_handle* h, int32_t on) {
+    if (!h) return fail(PDMPC_ERR_INVALID, "null handle");
+    h->safe_launches = on != 0;
+    return PDMPC_OK;
 }
 
 int pdmpc_begin_step(pdmpc_handle* h) {
@@ -952,7 +1077,7 @@ int pdmpc_reset_stats(pdmpc_handle* h) {
 int pdmpc_launch_range(pdmpc_handle* h, int32_t first, int32_t count) {
     if (!h) return fail(PDMPC_ERR_INVALID, "null handle");
     HIPCHK(hipSetDevice(h->cfg.device));
-    return launch_range(h, first, count);
+    return launch_range(h, first, count, h->safe_launches);
 }
 
 int pdmpc_synchronize(pdmpc_handle* h) {
@@ -965,12 +1090,14 @@ int pdmpc_fetch_results(pdmpc_handle* h, int32_t n, pdmpc_vehicle_out* out) {
     if (!h || (n > 0 && !out)) return fail(PDMPC_ERR_INVALID, "null argument");
     if (n < 0 || n > h->max_vehicles) return fail(PDMPC_ERR_INVALID, "bad record count");
     HIPCHK(hipSetDevice(h->cfg.device));
+    PackedStep& B = h->banks[h->bank];
+    const bool permuted = !B.perm.empty();
+    if (permuted && n != B.n_packed) return fail(PDMPC_ERR_INVALID, "a batch that pdmpc_pack_step put into level order is fetched as a whole");
     if (n > 0) HIPCHK(hipMemcpyAsync(out, h->d_out.p, (size_t)n * sizeof(pdmpc_vehicle_out), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     // counters + SURVEY.md 8(d) algorithmic bytes of one pass over the packed batch
     pdmpc_stats& s = h->stats;
     const int Hp = h->cfg.Hp;
-    PackedStep& B = h->banks[h->bank];
     const int m = std::min(n, B.n_packed);
     s.n_vehicles = m;
     s.nodes_popped = s.nodes_generated = s.obstacle_columns = 0;
@@ -994,6 +1121,10 @@ int pdmpc_fetch_results(pdmpc_handle* h, int32_t n, pdmpc_vehicle_out* out) {
         bytes += 8 * (3 * Hp + Hp + (Hp + 1)) + 16 * PDMPC_VMAX * Hp;      // B_out
     }
     s.algorithmic_bytes = bytes;
+    if (permuted) {  // back into the caller's order (the tree_path ids are per search: nothing else refers to slots)
+        std::vector<pdmpc_vehicle_out> tmp(out, out + n);
+        for (int sl = 0; sl < n; ++sl) out[B.perm[(size_t)sl]] = tmp[(size_t)sl];
+    }
     return PDMPC_OK;
 }
 
@@ -1002,17 +1133,30 @@ namespace {
 // is planned again from scratch with arenas twice as large (searches are deterministic, so the vehicles that did fit
 // produce the same records again) until it fits, the limit set with pdmpc_set_arena_limit is reached, or HBM runs out.
 int plan_packed_growing(pdmpc_handle* h, int32_t n, pdmpc_vehicle_out* out) {
+    bool safe = h->safe_launches;
     for (;;) {
-        const bool dbg = getenv("PDMPC_DEBUG_HOST") != nullptr;
-        if (dbg) fprintf(stderr, "pdmpc: launching %d vehicles, arena %u nodes\n", n, h->max_nodes);
-        int rc = pdmpc_launch_packed(h);
+        const bool dbg = h->tune.debug_host != 0;
+        if (dbg) fprintf(stderr, "pdmpc: launching %d vehicles, arena %u nodes%s\n", n, h->max_nodes, safe ? " (resident slices)" : "");
+        HIPCHK(hipSetDevice(h->cfg.device));
+        h->epoch += 1;  // a new step: results of earlier launches no longer satisfy predecessor waits
+        int rc = launch_range(h, 0, h->banks[h->bank].n_packed, safe);
         if (rc) return rc;
-        if (dbg) fprintf(stderr, "pdmpc: launched, waiting\n");
         rc = pdmpc_fetch_results(h, n, out);
         if (rc) return rc;
         if (dbg) fprintf(stderr, "pdmpc: fetched, status[0] %d\n", n > 0 ? out[0].status : 0);
-        bool overflow = false;
-        for (int i = 0; i < n; ++i) overflow = overflow || out[i].status == PDMPC_ARENA_OVERFLOW;
+        bool overflow = false, timed_out = false;
+        for (int i = 0; i < n; ++i) {
+            overflow = overflow || out[i].status == PDMPC_ARENA_OVERFLOW;
+            timed_out = timed_out || out[i].status == PDMPC_ERR_HIP;
+        }
+        if (timed_out && !safe) {
+            // A search gave up waiting for a predecessor of the same launch (the watchdog of frontier_kernel.hip): the launch was
+            // oversubscribed and the dispatch order starved a predecessor, or a helper sat where a search should have run.  Plan
+            // the call again in slices that are resident as a whole: forward progress then rests on nothing but slot order.
+            safe = true;
+            h->safe_replans += 1;
+            continue;
+        }
         if (!overflow) return PDMPC_OK;
         const uint64_t next = (uint64_t)h->max_nodes * 2u;
         if ((h->max_nodes_limit && next > h->max_nodes_limit) || next > (1ull << 30)) return PDMPC_OK;  // statuses tell
@@ -1043,6 +1187,82 @@ int pdmpc_plan_step(pdmpc_handle* h, int32_t n, const pdmpc_vehicle_in* in, cons
     int rc = pdmpc_pack_step(h, n, in, pred_offset, pred_index, fallback_shapes);
     if (rc) return rc;
     return plan_packed_growing(h, n, out);
+}
+
+// The step as an UNMODIFIED reference controller drives this backend (GraphSearchHip.m behind OptimizerInterface): one
+// run_optimizer call per vehicle (PrioritizedController.m:335-341) in kahn order (PrioritizedSequentialController.m:77-94), every
+// call a pdmpc_plan_batch of one vehicle -- pack, H2D, launch, D2H -- and the hand-over of solved areas on the host
+// (PrioritizedController.m:476-491: the predecessors' info.shapes(1, :), or their published fallback areas, appended to the
+// vehicle's dynamic obstacles).  Same arguments and records as pdmpc_plan_step; slots must be in level order.
+int pdmpc_plan_step_literal(pdmpc_handle* h, int32_t n, const pdmpc_vehicle_in* in, const int32_t* pred_offset, const int32_t* pred_index,
+                            const pdmpc_polygon_set* fallback_shapes, pdmpc_vehicle_out* out) {
+    if (!h || n < 0 || (n > 0 && (!in || !out))) return fail(PDMPC_ERR_INVALID, "null argument");
+    if (pred_offset && !pred_index) return fail(PDMPC_ERR_INVALID, "pred_index missing");
+    const int Hp = h->cfg.Hp;
+    std::vector<int32_t> off;
+    std::vector<double> xs, ys;
+    for (int s = 0; s < n; ++s) {
+        pdmpc_vehicle_in v = in[s];
+        const int np = pred_offset ? pred_offset[s + 1] - pred_offset[s] : 0;
+        if (np > 0) {
+            const pdmpc_polygon_set& d = in[s].dynamic_obstacles;
+            if (d.n_polygons % Hp) return fail(PDMPC_ERR_INVALID, "dynamic_obstacles must hold n_d * Hp polygons");
+            off.assign(1, 0);
+            xs.clear();
+            ys.clear();
+            auto push_poly = [&](const double* px, const double* py, int cnt) {
+                xs.insert(xs.end(), px, px + cnt);
+                ys.insert(ys.end(), py, py + cnt);
+                off.push_back((int32_t)xs.size());
+            };
+            for (int p = 0; p < d.n_polygons; ++p) push_poly(d.x + d.offset[p], d.y + d.offset[p], d.offset[p + 1] - d.offset[p]);
+            int rows = d.n_polygons / Hp;
+            for (int e = pred_offset[s]; e < pred_offset[s + 1]; ++e) {
+                const int ps = pred_index[e];
+                if (ps < 0 || ps >= s) return fail(PDMPC_ERR_INVALID, "pdmpc_plan_step_literal needs the slots in level order");
+                const pdmpc_vehicle_out& po = out[ps];
+                if (po.status == PDMPC_OK) {
+                    for (int k = 0; k < Hp; ++k) push_poly(po.shapes[k][0], po.shapes[k][1], po.shape_cols[k]);
+                    rows += 1;
+                } else if (fallback_shapes && fallback_shapes[ps].n_polygons == Hp) {
+                    const pdmpc_polygon_set& fb = fallback_shapes[ps];
+                    for (int k = 0; k < Hp; ++k) push_poly(fb.x + fb.offset[k], fb.y + fb.offset[k], fb.offset[k + 1] - fb.offset[k]);
+                    rows += 1;
+                }
+            }
+            static const double zero = 0.0;
+            v.dynamic_obstacles.n_polygons = rows * Hp;
+            v.dynamic_obstacles.offset = off.data();
+            v.dynamic_obstacles.x = xs.empty() ? &zero : xs.data();
+            v.dynamic_obstacles.y = ys.empty() ? &zero : ys.data();
+        }
+        int rc = pdmpc_plan_batch(h, 1, &v, out + s);
+        if (rc) return rc;
+        // the single-launch path publishes the fallback areas of an exhausted vehicle in its record: the same record here
+        if (out[s].status == PDMPC_EXHAUSTED && fallback_shapes && fallback_shapes[s].n_polygons == Hp) {
+            const pdmpc_polygon_set& fb = fallback_shapes[s];
+            for (int k = 0; k < Hp; ++k) {
+                const int cnt = std::min(fb.offset[k + 1] - fb.offset[k], (int32_t)PDMPC_VMAX);
+                out[s].shape_cols[k] = cnt;
+                for (int c = 0; c < cnt; ++c) {
+                    out[s].shapes[k][0][c] = fb.x[fb.offset[k] + c];
+                    out[s].shapes[k][1][c] = fb.y[fb.offset[k] + c];
+                }
+            }
+        }
+    }
+    return PDMPC_OK;
+}
+
+int pdmpc_get_config(pdmpc_handle* h, pdmpc_config* config, int32_t* mpa_uploaded) {
+    if (!h) return fail(PDMPC_ERR_INVALID, "null handle");
+    if (config) {
+        *config = h->cfg;
+        config->max_vehicles = h->max_vehicles;
+        config->max_nodes = (int32_t)h->max_nodes;
+    }
+    if (mpa_uploaded) *mpa_uploaded = h->has_mpa ? 1 : 0;
+    return PDMPC_OK;
 }
 
 int pdmpc_set_arena_limit(pdmpc_handle* h, int32_t max_nodes_limit) {
@@ -1192,6 +1412,8 @@ int pdmpc_get_last_stats(pdmpc_handle* h, pdmpc_stats* stats) {
     h->stats.rounds = h->last_launch_frontier ? (int64_t)work[3] : 0;
     h->stats.shared_rounds = (int64_t)work[4];
     h->stats.helper_checked = (int64_t)work[5];
+    h->stats.safe_replans = h->safe_replans;
+    h->stats.bad_status_plans = (int64_t)work[6];
     *stats = h->stats;
     return PDMPC_OK;
 }
@@ -1366,6 +1588,7 @@ int pdmpc_debug_pop_trace(pdmpc_handle* h, int32_t vehicle, int32_t capacity, in
     if (!h || !ids || !n) return fail(PDMPC_ERR_INVALID, "null argument");
     if (h->cfg.trace_pops <= 0 && !h->last_launch_frontier) return fail(PDMPC_ERR_INVALID, "handle was created with trace_pops == 0");
     if (vehicle < 0 || vehicle >= h->max_vehicles) return fail(PDMPC_ERR_INVALID, "vehicle slot out of range");
+    if (!h->banks[h->bank].inv.empty() && vehicle < h->banks[h->bank].n_packed) vehicle = h->banks[h->bank].inv[(size_t)vehicle];  // (the batch was put into level order)
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipStreamSynchronize(h->stream));
     {
@@ -1401,15 +1624,23 @@ int pdmpc_debug_edge_check(pdmpc_handle* h, int32_t mode, int32_t n_cases, const
     }
     HIPCHK(hipSetDevice(h->cfg.device));
     const size_t ta = (size_t)a_off[n_cases], tb = (size_t)b_off[n_cases];
-    int32_t *d_ao = nullptr, *d_bo = nullptr, *d_hit = nullptr;
-    double *d_ax = nullptr, *d_ay = nullptr, *d_bx = nullptr, *d_by = nullptr;
-    HIPCHK(hipMalloc((void**)&d_ao, ((size_t)n_cases + 1) * 4));
-    HIPCHK(hipMalloc((void**)&d_bo, ((size_t)n_cases + 1) * 4));
-    HIPCHK(hipMalloc((void**)&d_hit, (size_t)n_cases * 4));
-    HIPCHK(hipMalloc((void**)&d_ax, std::max<size_t>(ta, 1) * 8));
-    HIPCHK(hipMalloc((void**)&d_ay, std::max<size_t>(ta, 1) * 8));
-    HIPCHK(hipMalloc((void**)&d_bx, std::max<size_t>(tb, 1) * 8));
-    HIPCHK(hipMalloc((void**)&d_by, std::max<size_t>(tb, 1) * 8));
+    // (DevBuf-style owners: every early return frees what was allocated)
+    struct Owned {
+        void* p = nullptr;
+        ~Owned() {
+            if (p) (void)hipFree(p);
+        }
+        hipError_t alloc(size_t bytes) { return hipMalloc(&p, std::max<size_t>(bytes, 8)); }
+    } o_ao, o_bo, o_hit, o_ax, o_ay, o_bx, o_by;
+    HIPCHK(o_ao.alloc(((size_t)n_cases + 1) * 4));
+    HIPCHK(o_bo.alloc(((size_t)n_cases + 1) * 4));
+    HIPCHK(o_hit.alloc((size_t)n_cases * 4));
+    HIPCHK(o_ax.alloc(ta * 8));
+    HIPCHK(o_ay.alloc(ta * 8));
+    HIPCHK(o_bx.alloc(tb * 8));
+    HIPCHK(o_by.alloc(tb * 8));
+    int32_t *d_ao = (int32_t*)o_ao.p, *d_bo = (int32_t*)o_bo.p, *d_hit = (int32_t*)o_hit.p;
+    double *d_ax = (double*)o_ax.p, *d_ay = (double*)o_ay.p, *d_bx = (double*)o_bx.p, *d_by = (double*)o_by.p;
     HIPCHK(hipMemcpy(d_ao, a_off, ((size_t)n_cases + 1) * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_bo, b_off, ((size_t)n_cases + 1) * 4, hipMemcpyHostToDevice));
     if (ta) {
@@ -1424,13 +1655,6 @@ int pdmpc_debug_edge_check(pdmpc_handle* h, int32_t mode, int32_t n_cases, const
     if (lrc != 0) return fail(PDMPC_ERR_HIP, "edge-check launch failed");
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(hit, d_hit, (size_t)n_cases * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(d_ao);
-    (void)hipFree(d_bo);
-    (void)hipFree(d_hit);
-    (void)hipFree(d_ax);
-    (void)hipFree(d_ay);
-    (void)hipFree(d_bx);
-    (void)hipFree(d_by);
     return PDMPC_OK;
 }
 
@@ -1438,6 +1662,7 @@ int pdmpc_debug_raw_tree(pdmpc_handle* h, int32_t vehicle, int32_t capacity, dou
                          int32_t* k, int32_t* parent, double* key, uint8_t* validity, int32_t* n) {
     if (!h || !n) return fail(PDMPC_ERR_INVALID, "null argument");
     if (vehicle < 0 || vehicle >= h->max_vehicles) return fail(PDMPC_ERR_INVALID, "vehicle slot out of range");
+    if (!h->banks[h->bank].inv.empty() && vehicle < h->banks[h->bank].n_packed) vehicle = h->banks[h->bank].inv[(size_t)vehicle];  // (the batch was put into level order)
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipStreamSynchronize(h->stream));
     int32_t sz = 0;
@@ -1474,6 +1699,7 @@ int pdmpc_debug_tree(pdmpc_handle* h, int32_t vehicle, int32_t capacity, double*
                      int32_t* trim, int32_t* k, int32_t* parent, int32_t* n) {
     if (!h || !n) return fail(PDMPC_ERR_INVALID, "null argument");
     if (vehicle < 0 || vehicle >= h->max_vehicles) return fail(PDMPC_ERR_INVALID, "vehicle slot out of range");
+    if (!h->banks[h->bank].inv.empty() && vehicle < h->banks[h->bank].n_packed) vehicle = h->banks[h->bank].inv[(size_t)vehicle];  // (the batch was put into level order)
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipStreamSynchronize(h->stream));
     int32_t sz = 0;

@@ -83,7 +83,7 @@ typedef LDS_AS unsigned long long lds_u64s;
 // live counters for debugging (host-mapped memory, PDMPC_DEBUG_PROGRESS=1): stage = where the workgroup is
 #define FR_PROGRESS(stage)                                                                    \
     if (A.progress && threadIdx.x == 0) {                                                     \
-        volatile uint32_t* pg__ = A.progress + (size_t)(A.first + blockIdx.x) * 64;           \
+        volatile uint32_t* pg__ = A.progress + (size_t)X.slot * 64;                         \
         pg__[0] = sh[FR_ROUNDS];                                                              \
         pg__[1] = sh[FR_PROCESSED];                                                           \
         pg__[2] = sh[FR_NNODES];                                                              \
@@ -2005,8 +2005,16 @@ extern "C" int pdmpc_launch_frontier(const KernelArgs* args, int count, void* st
     kernel_t fn = interx ? (one_word ? pdmpc_frontier_kernel : pdmpc_frontier_kernel_wide) : (one_word ? pdmpc_frontier_kernel_sat : pdmpc_frontier_kernel_sat_wide);
     // (no register-capped variants for two workgroups per CU: measured on C5, 1280 searches on 256 CUs: 2 x 12 wavefronts at 80
     // VGPRs 283 steps/s, 2 x 8 at 128 VGPRs 324, one workgroup of 16 per CU 345)
-    hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)args->lds.total);
-    if (e != hipSuccess) return (int)e;
+    // (the attribute is a maximum: raised when a launch needs more than any before it, not on every launch)
+    static uint32_t lds_max[16][4] = {};  // per device (function attributes are per device)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    uint32_t& have = lds_max[dev & 15][(interx ? 0 : 1) + (one_word ? 0 : 2)];
+    if (args->lds.total > have) {
+        hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)args->lds.total);
+        if (e != hipSuccess) return (int)e;
+        have = args->lds.total;
+    }
     hipLaunchKernelGGL(fn, dim3(count), dim3(PDMPC_WAVE * args->n_waves), args->lds.total, (hipStream_t)stream, *args);
     return (int)hipGetLastError();
 }
@@ -2015,8 +2023,15 @@ extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) void pdmpc_helper_ker
 
 extern "C" int pdmpc_launch_helpers(const KernelArgs* args, void* stream) {
     if (args->n_helpers <= 0) return 0;
-    hipError_t e = hipFuncSetAttribute((const void*)pdmpc_helper_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)args->lds.total);
-    if (e != hipSuccess) return (int)e;
+    static uint32_t have_dev[16] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    uint32_t& have = have_dev[dev & 15];
+    if (args->lds.total > have) {
+        hipError_t e = hipFuncSetAttribute((const void*)pdmpc_helper_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)args->lds.total);
+        if (e != hipSuccess) return (int)e;
+        have = args->lds.total;
+    }
     hipLaunchKernelGGL(pdmpc_helper_kernel, dim3(args->n_helpers), dim3(PDMPC_WAVE * args->n_waves), args->lds.total, (hipStream_t)stream, *args);
     return (int)hipGetLastError();
 }

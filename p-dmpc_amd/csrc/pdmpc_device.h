@@ -174,6 +174,8 @@ struct KernelArgs {
     uint32_t* help_finished;         // searches of this launch that have published their result
     int32_t speculate;  // 1: start searching before all predecessors have finished (results are identical, see arrival_sync)
     uint32_t spin_limit;
+    int32_t reverse_dispatch;  // testing only (PDMPC_TEST_REVERSE_DISPATCH): workgroup b plans slot first + n_searches - 1 - b, i.e. successors are
+                               // dispatched before their predecessors -- the adversarial order the watchdog + resident slices must survive
 };
 
 #ifdef __cplusplus

@@ -1340,7 +1340,7 @@ __device__ __forceinline__ void search_prologue(const KernelArgs& A, Ctx& X, LDS
     const int tid = threadIdx.x;
     const int lane = tid & (PDMPC_WAVE - 1);
     const int wave = uni_i(tid >> 6);
-    const int slot = A.first + blockIdx.x;
+    const int slot = A.first + (A.reverse_dispatch ? A.n_searches - 1 - (int)blockIdx.x : (int)blockIdx.x);
     const int Hp = A.Hp;
     const int n = A.n_trims;
     const int nw = A.n_words;
@@ -1672,6 +1672,8 @@ __device__ __forceinline__ void search_epilogue(const KernelArgs& A, Ctx& X, con
         }
     }
     if (lane == 0) {
+        // (device-side tally of plans that are not planning results: bench.py reads it after its timed replay, whose launches it does not fetch)
+        if (dep_timeout || (status != PDMPC_OK && status != PDMPC_EXHAUSTED)) atomicAdd(A.work_count + 6, 1ull);
         O->status = dep_timeout ? PDMPC_ERR_HIP : status;
         O->n_expanded = (int32_t)nnodes;
         O->n_popped = n_popped;

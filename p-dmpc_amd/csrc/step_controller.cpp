@@ -555,6 +555,16 @@ const char* pdmpc_controller_last_error(void) { return g_cerr.c_str(); }
 int pdmpc_controller_create(pdmpc_handle* handle, const pdmpc_controller_config* cfg, const pdmpc_scenario* sc, pdmpc_controller** out) {
     if (!cfg || !sc || !out) return cfail(nullptr, PDMPC_ERR_INVALID, "null argument");
     if (sc->n_vehicles < 1 || cfg->Hp < 1 || cfg->Hp > PDMPC_HP_MAX || sc->n_trims < 1) return cfail(nullptr, PDMPC_ERR_INVALID, "bad sizes");
+    if (handle) {
+        // the backend reads Hp entries of every reference and writes one record per vehicle: a handle created for another
+        // horizon or a smaller batch must not be driven by this controller
+        pdmpc_config hc{};
+        int32_t has_mpa = 0;
+        if (pdmpc_get_config(handle, &hc, &has_mpa) != PDMPC_OK) return cfail(nullptr, PDMPC_ERR_INVALID, "bad backend handle");
+        if (hc.Hp != cfg->Hp) return cfail(nullptr, PDMPC_ERR_INVALID, "the handle was created for another horizon (config.Hp) than the controller");
+        if (hc.max_vehicles < sc->n_vehicles) return cfail(nullptr, PDMPC_ERR_CAPACITY, "the handle's max_vehicles is smaller than the scenario");
+        if (!has_mpa) return cfail(nullptr, PDMPC_ERR_NO_MPA, "pdmpc_upload_mpa has not been called on the handle");
+    }
     pdmpc_controller* c = new pdmpc_controller();
     c->h = handle;
     c->cfg = *cfg;
@@ -764,6 +774,9 @@ int pdmpc_controller_apply(pdmpc_controller* c, const pdmpc_vehicle_out* recs) {
         p.yyaw.push_back(old.yyaw.back());
         return true;
     };
+    // (built on the side and committed at the end: an error status or a fallback in the first step leaves the controller's
+    // plans as they were)
+    std::vector<Plan> infos((size_t)n);
     for (int s = 0; s < n; ++s) {
         const int i = c->order[s];
         const pdmpc_vehicle_out& r = recs[s];
@@ -799,23 +812,23 @@ int pdmpc_controller_apply(pdmpc_controller* c, const pdmpc_vehicle_out* recs) {
                 p.needs_fallback = true;
             }
         }
-        c->infos[i] = std::move(p);
+        infos[i] = std::move(p);
     }
     // handle_others_fallback / check_others_fallback
     bool any = false;
-    for (int i = 0; i < n; ++i) any = any || c->infos[i].needs_fallback;
+    for (int i = 0; i < n; ++i) any = any || infos[i].needs_fallback;
     if (any) {
         std::vector<int> fm((size_t)n * n, 0);
         for (int a = 0; a < n; ++a)
             for (int b = 0; b < n; ++b) {
                 int v = at(c->adjacency, n, a, b);
-                if (c->infos[a].needs_fallback && at(c->directed_seq, n, a, b)) v -= 1;
-                if (c->infos[b].needs_fallback && at(c->directed_seq, n, b, a)) v -= 1;
+                if (infos[a].needs_fallback && at(c->directed_seq, n, a, b)) v -= 1;
+                if (infos[b].needs_fallback && at(c->directed_seq, n, b, a)) v -= 1;
                 fm[(size_t)a * n + b] = v;
             }
         std::vector<uint8_t> reached(n, 0);
         for (int f = 0; f < n; ++f) {
-            if (!c->infos[f].needs_fallback) continue;
+            if (!infos[f].needs_fallback) continue;
             std::vector<uint8_t> seen(n, 0);
             std::vector<int> stack{f};
             seen[f] = 1;
@@ -831,15 +844,16 @@ int pdmpc_controller_apply(pdmpc_controller* c, const pdmpc_vehicle_out* recs) {
             for (int v = 0; v < n; ++v) reached[v] |= seen[v];
         }
         for (int i = 0; i < n; ++i)
-            if (reached[i] && !c->infos[i].needs_fallback) {
+            if (reached[i] && !infos[i].needs_fallback) {
                 Plan p;
-                p.n_expanded = c->infos[i].n_expanded;
-                p.exhausted = c->infos[i].exhausted;
+                p.n_expanded = infos[i].n_expanded;
+                p.exhausted = infos[i].exhausted;
                 if (!fallback_plan(i, p)) return cfail(c, PDMPC_ERR_INVALID, "a vehicle needs a fallback in its first step");
                 p.needs_fallback = false;  // plan_fallback(is_fallback_while_planning = false)
-                c->infos[i] = std::move(p);
+                infos[i] = std::move(p);
             }
     }
+    c->infos = std::move(infos);
     // Simulation.apply (Simulation.m:86-100)
     for (int i = 0; i < n; ++i) {
         const Plan& p = c->infos[i];

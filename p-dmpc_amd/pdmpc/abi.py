@@ -128,6 +128,8 @@ class Stats(C.Structure):
         ("rounds", C.c_int64),
         ("shared_rounds", C.c_int64),
         ("helper_checked", C.c_int64),
+        ("safe_replans", C.c_int64),
+        ("bad_status_plans", C.c_int64),
     ]
 
 

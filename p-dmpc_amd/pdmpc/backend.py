@@ -20,6 +20,7 @@ EXPORTS = [
     "pdmpc_create",
     "pdmpc_destroy",
     "pdmpc_upload_mpa",
+    "pdmpc_get_config",
     "pdmpc_plan_batch",
     "pdmpc_plan_batch_sampled",
     "pdmpc_pack_batch",
@@ -30,8 +31,10 @@ EXPORTS = [
     "pdmpc_reset_stats",
     "pdmpc_fetch_results",
     "pdmpc_synchronize",
+    "pdmpc_set_safe_launch",
     "pdmpc_pack_step",
     "pdmpc_plan_step",
+    "pdmpc_plan_step_literal",
     "pdmpc_set_arena_limit",
     "pdmpc_grow_arena",
     "pdmpc_arena_nodes",
@@ -89,6 +92,7 @@ def load_library(path=None):
     L.pdmpc_create.argtypes = [C.POINTER(abi.Config), C.POINTER(H)]
     L.pdmpc_destroy.argtypes = [H]
     L.pdmpc_upload_mpa.argtypes = [H, C.POINTER(abi.Mpa)]
+    L.pdmpc_get_config.argtypes = [H, C.POINTER(abi.Config), C.POINTER(C.c_int32)]
     L.pdmpc_plan_batch.argtypes = [H, C.c_int32, C.POINTER(abi.VehicleIn), C.POINTER(abi.VehicleOut)]
     L.pdmpc_pack_batch.argtypes = [H, C.c_int32, C.POINTER(abi.VehicleIn)]
     L.pdmpc_launch_packed.argtypes = [H]
@@ -98,8 +102,10 @@ def load_library(path=None):
     L.pdmpc_reset_stats.argtypes = [H]
     L.pdmpc_fetch_results.argtypes = [H, C.c_int32, C.POINTER(abi.VehicleOut)]
     L.pdmpc_synchronize.argtypes = [H]
+    L.pdmpc_set_safe_launch.argtypes = [H, C.c_int32]
     L.pdmpc_pack_step.argtypes = [H, C.c_int32, C.POINTER(abi.VehicleIn), abi.c_int32_p, abi.c_int32_p, C.POINTER(abi.PolygonSet)]
     L.pdmpc_plan_step.argtypes = [H, C.c_int32, C.POINTER(abi.VehicleIn), abi.c_int32_p, abi.c_int32_p, C.POINTER(abi.PolygonSet), C.POINTER(abi.VehicleOut)]
+    L.pdmpc_plan_step_literal.argtypes = L.pdmpc_plan_step.argtypes
     L.pdmpc_set_arena_limit.argtypes = [H, C.c_int32]
     L.pdmpc_grow_arena.argtypes = [H, C.c_int32]
     L.pdmpc_arena_nodes.argtypes = [H, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
@@ -237,6 +243,24 @@ class Handle:
         del keep
         return self._checked(out[:n])
 
+    def step_args(self, iters, predecessors, fallback_shapes=None):
+        """The marshalled arguments of pdmpc_plan_step / pdmpc_plan_step_literal, reusable across calls (bench.py times the calls,
+        not the Python marshalling): (n, vehicle array, pred_offset, pred_index, fallback sets, keep-alive)."""
+        arr, off, idx, fb, keep = self._step_args(iters, predecessors, fallback_shapes)
+        return len(iters), arr, off, idx, fb, keep
+
+    def plan_step_literal(self, args):
+        """One pdmpc_plan_batch(h, 1, ...) per vehicle in slot (= kahn) order with the hand-over on the host: what GraphSearchHip.m
+        gives an unmodified controller (pdmpc_plan_step_literal).  args = step_args(...)."""
+        n, arr, off, idx, fb, _ = args
+        out = abi.out_array(n)
+        _check(
+            self.L,
+            self.L.pdmpc_plan_step_literal(self.h, n, arr, off.ctypes.data_as(abi.c_int32_p), idx.ctypes.data_as(abi.c_int32_p), fb, abi.out_ptr(out)),
+            "pdmpc_plan_step_literal",
+        )
+        return self._checked(out[:n])
+
     def _checked(self, recs):
         """Only PDMPC_EXHAUSTED is a planning result (info.is_exhausted); anything else is an error of this backend."""
         st = np.asarray(recs["status"])
@@ -275,6 +299,10 @@ class Handle:
 
     def synchronize(self):
         _check(self.L, self.L.pdmpc_synchronize(self.h), "pdmpc_synchronize")
+
+    def set_safe_launch(self, on):
+        """Every launch in slices that are resident as a whole (forward progress without any assumption on the dispatch order)."""
+        _check(self.L, self.L.pdmpc_set_safe_launch(self.h, 1 if on else 0), "pdmpc_set_safe_launch")
 
     def fetch(self, n):
         out = abi.out_array(n)

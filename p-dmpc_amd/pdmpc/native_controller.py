@@ -132,6 +132,7 @@ class NativeController:
             max_num_CLs=options.max_num_CLs, constraint_from_successor=SUCCESSOR[options.constraint_from_successor], dt_seconds=options.dt_seconds,
             offset=options.offset, vehicle_length=veh[0].Length, vehicle_width=veh[0].Width,
         )
+        self.handle = handle  # keeps the backend handle alive as long as the controller that drives it
         self.c = C.c_void_p()
         rc = self.L.pdmpc_controller_create(handle.h if handle is not None else None, C.byref(cfg), C.byref(s), C.byref(self.c))
         self._check(rc, "pdmpc_controller_create")

@@ -68,6 +68,16 @@ def test_road_network_20_vehicles_step():
     run_closed_loop(options, sc, "distance", boundary_provider(sc), 12)
 
 
+def test_benchmarked_window_c2_steps_1_to_40():
+    """The steps bench.py measures by default: seed 1, closed-loop steps 21-40 (the first 20 are dropped as in eval_phd.m:41-49),
+    incl. the 10 k-pop searches that decide the headline's heavy steps.  Every step of the closed loop against the oracle."""
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    options = Config(scenario_type=ScenarioType.commonroad, amount=20, Hp=8, max_vehicles=32, max_nodes=1 << 17)
+    sc = commonroad_scenario(options, seed=1)
+    run_closed_loop(options, sc, "distance", boundary_provider(sc), 40, oracle_threads=os.cpu_count() or 1)
+
+
 def test_road_network_triple_speed_step():
     from pdmpc.road_network import boundary_provider, commonroad_scenario
 
@@ -150,6 +160,16 @@ def test_config_c3_128_vehicles_two_level_coupling_dag():
     assert int(ctl.last_levels.max()) == 2
 
 
+def test_benchmarked_window_c3_steps_1_to_12():
+    """bench.py --workload c3 records closed-loop steps 5-12 of seed 1 (7 tiles): the same closed loop, every step against the oracle."""
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    options = Config(scenario_type=ScenarioType.commonroad, amount=128, Hp=8, max_num_CLs=2, max_vehicles=128, max_nodes=1 << 16)
+    sc = commonroad_scenario(options, seed=1, tiles=7)
+    ctl = run_closed_loop(options, sc, "distance", boundary_provider(sc), 12, oracle_threads=os.cpu_count() or 1, priority_strategy="coloring")
+    assert int(ctl.last_levels.max()) == 2
+
+
 def test_config_c4_512_vehicles_hp10_colouring_levels():
     """BASELINE config 3 as named: 512 vehicles, Hp 10, computation levels from graph colouring + kahn
     (ColoringPrioritizer.m:31-89, utility/kahn.m:1-24); two workgroups per CU.  The arenas start small and grow until no
@@ -159,6 +179,17 @@ def test_config_c4_512_vehicles_hp10_colouring_levels():
     options = Config(scenario_type=ScenarioType.commonroad, amount=512, Hp=10, max_vehicles=512, max_nodes=1 << 15)
     sc = commonroad_scenario(options, seed=3, tiles=26)
     ctl = run_closed_loop(options, sc, "distance", boundary_provider(sc), 2, oracle_threads=os.cpu_count() or 1, priority_strategy="coloring")
+    assert int(ctl.last_levels.max()) >= 3
+
+
+def test_benchmarked_window_c4_steps_1_to_12():
+    """bench.py --workload c4 records closed-loop steps 5-12 of seed 1 (26 tiles, 512 vehicles, Hp 10, colouring levels): the
+    same closed loop from standstill through step 12, every step against the oracle."""
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    options = Config(scenario_type=ScenarioType.commonroad, amount=512, Hp=10, max_vehicles=512, max_nodes=1 << 16)
+    sc = commonroad_scenario(options, seed=1, tiles=26)
+    ctl = run_closed_loop(options, sc, "distance", boundary_provider(sc), 12, oracle_threads=os.cpu_count() or 1, priority_strategy="coloring")
     assert int(ctl.last_levels.max()) >= 3
 
 
@@ -176,9 +207,11 @@ def test_explorative_batch_of_prioritizations_one_launch(n_instances):
     sc = commonroad_scenario(options, seed=1)
     opt = GraphSearchHip(options)
     ctl = PrioritizedSequentialController(options, sc, mpa, None, coupling="distance", boundary_provider=boundary_provider(sc))
-    for _ in range(3):
+    # (bench.py --workload c5 takes its first batch after 4 closed-loop steps with seed = time step: the 64-instance case is that batch)
+    n_before = 4 if n_instances == 64 else 3
+    for _ in range(n_before):
         ctl.step(plan_step=lambda prob: opt.run_optimizer_step(prob, mpa))
-    batch = build_exploration_batch(ctl, n_instances, seed=4)
+    batch = build_exploration_batch(ctl, n_instances, seed=ctl.k + 1 if n_instances == 64 else 4)
     assert len(batch["iters"]) == 20 * n_instances and batch["n_instances"] == n_instances
     n = len(batch["iters"])
     fb = [f if f is not None else [] for f in batch["fallback"]]
@@ -222,3 +255,159 @@ def test_fallback_while_a_predecessor_is_still_planning():
             assert opt.handle.stats()["queue_fallbacks"] >= 1
     finally:
         opt.handle.close()
+
+
+def native_closed_loop_on_device(options, scenario, boundary, n_steps, **kw):
+    """pdmpc_controller_step with a real handle (C++ build_step -> pdmpc_plan_step on the GPU -> C++ apply: the path behind
+    bench.py's value_host_inclusive) next to the Python controller planned by the oracle: the records of every step and the
+    plant state after every step are identical."""
+    from oracle import oracle
+    from pdmpc.native_controller import NativeController
+    from pdmpc.optimizer import GraphSearchHip
+
+    mpa = get_mpa(options)
+    opt = GraphSearchHip(options)
+    opt._ensure_mpa(mpa)
+    nat = NativeController(options, scenario, mpa, opt.handle, coupling="distance", **kw)
+    py = PrioritizedSequentialController(options, scenario, mpa, None, coupling="distance", boundary_provider=boundary, **kw)
+    unbounded = copy.copy(options)
+    unbounded.max_nodes = 1 << 30
+    for k in range(n_steps):
+        gpu = nat.step()  # records of the native step in slot order
+        ref_box = []
+
+        def plan_step(prob):
+            ref, _ = oracle.plan_step(unbounded, mpa, prob, n_threads=os.cpu_count() or 1)
+            ref_box.append(ref)
+            return [info_from_record(ref[i], options.Hp) for i in range(len(ref))]
+
+        py.step(plan_step=plan_step)
+        assert_records_equal(gpu, ref_box[0], "native step %d" % (k + 1))
+        st = nat.state()
+        assert st["k"] == k + 1
+        assert np.array_equal(st["x"], np.array([m.x for m in py.meas])) and np.array_equal(st["y"], np.array([m.y for m in py.meas])), k
+        assert np.array_equal(st["yaw"], np.array([m.yaw for m in py.meas])), k
+        assert np.array_equal(st["speed"], np.array([m.speed for m in py.meas])) and np.array_equal(st["steering"], np.array([m.steering for m in py.meas])), k
+        assert st["needs_fallback"].tolist() == [bool(i.needs_fallback) for i in py.infos], k
+    # pdmpc_controller_run: the same closed loop in one native call ends in the same plant state
+    nat2 = NativeController(options, scenario, mpa, opt.handle, coupling="distance", **kw)
+    ms = nat2.run(n_steps)
+    assert len(ms) == n_steps and (ms > 0).all()
+    a, b = nat.state(), nat2.state()
+    for key in ("x", "y", "yaw", "speed", "steering"):
+        assert np.array_equal(a[key], b[key]), key
+    nat.close()
+    nat2.close()
+    opt.handle.close()
+
+
+def test_native_controller_on_device_c2_40_steps():
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    options = Config(scenario_type=ScenarioType.commonroad, amount=20, Hp=8, max_vehicles=32, max_nodes=1 << 17)
+    sc = commonroad_scenario(options, seed=1)
+    native_closed_loop_on_device(options, sc, boundary_provider(sc), 40)
+
+
+def test_native_controller_on_device_c3():
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    options = Config(scenario_type=ScenarioType.commonroad, amount=128, Hp=8, max_num_CLs=2, max_vehicles=128, max_nodes=1 << 16)
+    sc = commonroad_scenario(options, seed=1, tiles=7)
+    native_closed_loop_on_device(options, sc, boundary_provider(sc), 8, priority_strategy="coloring")
+
+
+def test_literal_run_optimizer_loop_equals_the_single_launch():
+    """pdmpc_plan_step_literal (one pdmpc_plan_batch of one vehicle per run_optimizer call, hand-over on the host: what an
+    unmodified reference controller does with GraphSearchHip.m) against pdmpc_plan_step and the oracle over a closed loop."""
+    from oracle import oracle
+    from pdmpc.optimizer import GraphSearchHip
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    options = Config(scenario_type=ScenarioType.commonroad, amount=20, Hp=8, max_vehicles=32, max_nodes=1 << 17)
+    mpa = get_mpa(options)
+    sc = commonroad_scenario(options, seed=3)
+    opt = GraphSearchHip(options)
+    opt._ensure_mpa(mpa)
+    ctl = PrioritizedSequentialController(options, sc, mpa, None, coupling="distance", boundary_provider=boundary_provider(sc))
+
+    def plan_step(prob):
+        fb = [f if f is not None else [] for f in prob["fallback"]]
+        lit = opt.handle.plan_step_literal(opt.handle.step_args(prob["iters"], prob["preds"], fb))
+        one = opt.handle.plan_step(prob["iters"], prob["preds"], fb)
+        ref, _ = oracle.plan_step(options, mpa, prob)
+        assert_records_equal(lit, ref, "literal")
+        assert_records_equal(one, ref, "single launch")
+        return [info_from_record(one[i], options.Hp) for i in range(len(one))]
+
+    for _ in range(10):
+        ctl.step(plan_step=plan_step)
+    opt.handle.close()
+
+
+def test_batch_not_in_level_order_is_reordered_by_the_library():
+    """Slots handed over against the level order (successors first): pdmpc_pack_step puts the batch into level order itself
+    and pdmpc_fetch_results hands the records back in the caller's order."""
+    from oracle import oracle
+    from pdmpc.optimizer import GraphSearchHip
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    options = Config(scenario_type=ScenarioType.commonroad, amount=20, Hp=6, max_vehicles=32, max_nodes=1 << 16)
+    mpa = get_mpa(options)
+    sc = commonroad_scenario(options, seed=2)
+    opt = GraphSearchHip(options)
+    opt._ensure_mpa(mpa)
+    ctl = PrioritizedSequentialController(options, sc, mpa, None, coupling="distance", boundary_provider=boundary_provider(sc))
+    rng = np.random.default_rng(5)
+
+    def plan_step(prob):
+        n = len(prob["iters"])
+        fb = [f if f is not None else [] for f in prob["fallback"]]
+        ref, _ = oracle.plan_step(options, mpa, prob)
+        for perm in (list(range(n))[::-1], list(rng.permutation(n))):
+            inv = {s: i for i, s in enumerate(perm)}  # slot s of the problem is handed over at position inv[s]
+            got = opt.handle.plan_step([prob["iters"][s] for s in perm], [[inv[p] for p in prob["preds"][s]] for s in perm], [fb[s] for s in perm])
+            assert_records_equal(got, ref[perm], "permuted batch")
+        return [info_from_record(ref[i], options.Hp) for i in range(n)]
+
+    for _ in range(4):
+        ctl.step(plan_step=plan_step)
+    opt.handle.close()
+
+
+def test_starved_predecessors_are_replanned_in_resident_slices(monkeypatch):
+    """Forward progress of oversubscribed launches.  PDMPC_TEST_REVERSE_DISPATCH hands the slots out in reverse workgroup order:
+    the successors occupy the chip and spin for predecessors that have not been dispatched -- the adversarial order.  With a
+    small PDMPC_SPIN_LIMIT the watchdog ends them with an error status; pdmpc_plan_step then plans the step again in slices that
+    are resident as a whole and the records are the oracle's."""
+    from oracle import oracle
+    from pdmpc.optimizer import GraphSearchHip
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    monkeypatch.setenv("PDMPC_TEST_REVERSE_DISPATCH", "1")
+    monkeypatch.setenv("PDMPC_SPIN_LIMIT", "20000")
+    options = Config(scenario_type=ScenarioType.commonroad, amount=320, Hp=6, max_vehicles=320, max_nodes=1 << 14)
+    mpa = get_mpa(options)
+    sc = commonroad_scenario(options, seed=1, tiles=16)
+    opt = GraphSearchHip(options)
+    opt._ensure_mpa(mpa)
+    ctl = PrioritizedSequentialController(options, sc, mpa, None, coupling="distance", boundary_provider=boundary_provider(sc), priority_strategy="coloring")
+    unbounded = copy.copy(options)
+    unbounded.max_nodes = 1 << 30
+
+    def plan_step(prob):
+        fb = [f if f is not None else [] for f in prob["fallback"]]
+        gpu = opt.handle.plan_step(prob["iters"], prob["preds"], fb)
+        ref, _ = oracle.plan_step(unbounded, mpa, prob, n_threads=os.cpu_count() or 1)
+        assert_records_equal(gpu, ref, "after the safe re-plan")
+        return [info_from_record(gpu[i], options.Hp) for i in range(len(gpu))]
+
+    for _ in range(2):
+        ctl.step(plan_step=plan_step)
+    assert opt.handle.stats()["safe_replans"] >= 1
+    # and with safe launches from the start nothing has to be planned twice
+    before = opt.handle.stats()["safe_replans"]
+    opt.handle.set_safe_launch(True)
+    ctl.step(plan_step=plan_step)
+    assert opt.handle.stats()["safe_replans"] == before
+    opt.handle.close()

@@ -358,3 +358,34 @@ def test_sampled_optimizer_structure():
         assert abs(cost - recs[i]["path_nodes"][options.Hp][4]) < 1e-12
         if opt_recs[i]["status"] == 0:
             assert recs[i]["path_nodes"][options.Hp][4] >= opt_recs[i]["path_nodes"][options.Hp][4] - 1e-12
+
+
+def test_native_step_loop_equals_the_python_level_loop():
+    """oracle_plan_step (level loop + hand-over of solved areas + fallback publication in C++, on a persistent thread pool: what
+    bench.py times as cpu_baseline) against oracle.plan_step (the same loop in Python around oracle_plan_batch): identical records
+    over a closed loop, single- and multi-threaded."""
+    from oracle import oracle
+    from pdmpc.config import Config, ScenarioType
+    from pdmpc.controller import PrioritizedSequentialController
+    from pdmpc.iteration_data import info_from_record
+    from pdmpc.mpa import get_mpa
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    options = Config(scenario_type=ScenarioType.commonroad, amount=12, Hp=5, max_nodes=1 << 30)
+    mpa = get_mpa(options)
+    sc = commonroad_scenario(options, seed=2)
+    ctl = PrioritizedSequentialController(options, sc, mpa, None, coupling="distance", boundary_provider=boundary_provider(sc))
+    seen = []
+
+    def plan_step(prob):
+        a, _ = oracle.plan_step(options, mpa, prob)
+        b, ms, thr = oracle.plan_step_native(options, mpa, prob, n_threads=1)
+        c, _, thr4 = oracle.plan_step_native(options, mpa, prob, n_threads=4)
+        assert a.tobytes() == b.tobytes() == c.tobytes()
+        assert ms > 0 and 0.9 < thr <= 1.0 and 0.9 < thr4 <= 4.0
+        seen.append(len(a))
+        return [info_from_record(a[i], options.Hp) for i in range(len(a))]
+
+    for _ in range(6):
+        ctl.step(plan_step=plan_step)
+    assert len(seen) == 6
