@@ -63,16 +63,11 @@ def compare_tree_and_pops(h, v, trace, pops=True):
         # same node (same row) on both sides.
         if len(trace.tree["x"]) <= cap:
             def rows(t, m):
-                r = np.stack([t[k][:m].view(np.uint64) for k in ("x", "y", "yaw", "g", "h")] + [t[k][:m].astype(np.uint64) for k in ("trim", "k")], axis=1)
-                order = np.lexsort(r.T[::-1])
-                return r, order
-            ra, oa = rows(tree, n)
-            rb, ob = rows(trace.tree, n)
-            assert np.array_equal(ra[oa], rb[ob]), "node set of vehicle %d" % v
-            # parent rows (the root's parent id 0 maps to itself)
-            pa = np.where(tree["parent"][:n] > 0, tree["parent"][:n] - 1, 0)
-            pb = np.where(trace.tree["parent"][:n] > 0, trace.tree["parent"][:n] - 1, 0)
-            assert np.array_equal(ra[pa][oa], rb[pb][ob]), "parent links of vehicle %d" % v
+                own = np.stack([t[k][:m].view(np.uint64) for k in ("x", "y", "yaw", "g", "h")] + [t[k][:m].astype(np.uint64) for k in ("trim", "k")], axis=1)
+                par = np.where(t["parent"][:m] > 0, t["parent"][:m] - 1, 0)  # (the root's parent id 0 maps to the root itself)
+                r = np.concatenate([own, own[par]], axis=1)  # a node and the node it hangs on
+                return r[np.lexsort(r.T[::-1])]
+            assert np.array_equal(rows(tree, n), rows(trace.tree, n)), "nodes and parent links of vehicle %d" % v
         return
     for key in ("x", "y", "yaw", "g", "h"):
         assert np.array_equal(tree[key].view(np.uint64), trace.tree[key][:n].view(np.uint64)), (v, key)
