@@ -41,15 +41,20 @@ classdef GraphSearchHip < OptimizerInterface
                 obj.mpa_uploaded = true;
             end
 
-            info = ControlResultsInfo(iter.amount, options.Hp);
-            % the MEX file flattens the cells of iter into pdmpc_vehicle_in and returns pdmpc_vehicle_out
-            out = pdmpc_mex('plan', obj.handle, ...
-                iter.x0(1, 1:3), iter.trim_indices, ...
-                squeeze(iter.reference_trajectory_points(1, :, :)), iter.v_ref(1, :), ...
-                iter.obstacles, iter.dynamic_obstacle_area, ...
-                iter.predicted_lanelet_boundary(1, 1:2), ...
-                iter.hdv_reachable_sets(find(iter.hdv_adjacency), :)); %#ok<FNDSB>
+            % libpdmpc_hip.so flattens the cells of iter into pdmpc_vehicle_in (csrc/matlab_marshal.cpp) and returns pdmpc_vehicle_out
+            out = pdmpc_mex('plan', obj.handle, pdmpc_iter_struct(iter));
 
+            info = GraphSearchHip.info_from_record(iter, options, out);
+        end
+
+    end
+
+    methods (Static)
+
+        function info = info_from_record(iter, options, out)
+            % pdmpc_vehicle_out (as the struct pdmpc_mex returns) -> ControlResultsInfo; also used by
+            % PrioritizedSequentialHipController, which gets one record per vehicle from a single call
+            info = ControlResultsInfo(iter.amount, options.Hp);
             info.n_expanded = out.n_expanded;
             % Only an empty open list is an exhaustion (GraphSearch.m:57-61).  pdmpc_plan_batch re-plans with doubled arenas
             % when a search outgrows its arena, so PDMPC_ARENA_OVERFLOW (2) only comes back when HBM (or the limit set with

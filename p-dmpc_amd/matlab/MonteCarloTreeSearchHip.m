@@ -40,13 +40,7 @@ classdef MonteCarloTreeSearchHip < OptimizerInterface
 
             Hp = options.Hp;
             info = ControlResultsInfo(iter.amount, Hp);
-            out = pdmpc_mex('plan_sampled', obj.handle, ...
-                iter.x0(1, 1:3), iter.trim_indices, ...
-                squeeze(iter.reference_trajectory_points(1, :, :)), iter.v_ref(1, :), ...
-                iter.obstacles, iter.dynamic_obstacle_area, ...
-                iter.predicted_lanelet_boundary(1, 1:2), ...
-                iter.hdv_reachable_sets(find(iter.hdv_adjacency), :), ... %#ok<FNDSB>
-                time_step + vehicle_index);
+            out = pdmpc_mex('plan_sampled', obj.handle, pdmpc_iter_struct(iter), time_step + vehicle_index);
 
             info.n_expanded = out.n_expanded; % MonteCarloTreeSearch.m:209
             info.is_exhausted = out.status ~= 0; % :212-215

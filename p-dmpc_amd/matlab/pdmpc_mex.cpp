@@ -2,21 +2,30 @@
 //
 // Build inside MATLAB, next to compile_priority_queue.m's recipe:
 //     mex -R2018a pdmpc_mex.cpp -I<repo>/include -L<repo>/p-dmpc_amd/csrc -lpdmpc_hip
-// Commands mirror the life cycle of include/pdmpc.h:
-//     h   = pdmpc_mex('create', Hp, checker, dt_seconds)
-//           pdmpc_mex('upload_mpa', h, transition_matrix_single, maneuvers)
-//     out = pdmpc_mex('plan_sampled', ... same arguments ..., seed)      the sampled optimizer (MonteCarloTreeSearch.m)
-//     out = pdmpc_mex('plan', h, x0, trim, ref_points(Hp x 2), v_ref, obstacles, dynamic_obstacle_area,
-//                     lanelet_boundary(1 x 2 cell), hdv_reachable_sets)
-//           pdmpc_mex('destroy', h)
+// Commands:
+//     h    = pdmpc_mex('create', Hp, checker, dt_seconds [, max_vehicles])
+//            pdmpc_mex('upload_mpa', h, transition_matrix_single, maneuvers)
+//     out  = pdmpc_mex('plan', h, iter_struct)                     one run_optimizer call (GraphSearchHip.m)
+//     out  = pdmpc_mex('plan_sampled', h, iter_struct, seed)       the sampled optimizer (MonteCarloTreeSearchHip.m)
+//     outs = pdmpc_mex('plan_level', h, iter_structs)              one computation level: n vehicles, one launch
+//     outs = pdmpc_mex('plan_step', h, iter_structs, directed_coupling_sequential, fallback_areas)
+//                                                                  ALL levels of a time step in one launch
+//                                                                  (PrioritizedSequentialHipController.m)
+//            pdmpc_mex('destroy', h)
+// iter_struct(s): struct (array) with fields x0, trim_index, reference_trajectory_points (Hp x 2), v_ref, obstacles (cell),
+// dynamic_obstacle_area (n_d x Hp cell), lanelet_boundary (1 x 2 cell), hdv_reachable_sets (n_h x Hp cell).
+//
+// This file holds NO index arithmetic: it turns matlab::data arrays into the (pointer, rows, cols) descriptors of
+// include/pdmpc_matlab.h; the marshalling itself (cell order, column-major matrices, kahn levels, slot order) is
+// csrc/matlab_marshal.cpp, compiled into libpdmpc_hip.so and unit-tested without MATLAB (tests/test_matlab_marshal.py).
 // It replaces the command protocol of priority_queue_interface_mex.cpp:33-40: the queue now lives inside the kernel.
-#include <cstring>
+#include <deque>
 #include <string>
 #include <vector>
 
 #include "mex.hpp"
 #include "mexAdapter.hpp"
-#include "pdmpc.h"
+#include "pdmpc_matlab.h"
 
 using matlab::data::Array;
 using matlab::data::CellArray;
@@ -26,28 +35,46 @@ using matlab::mex::ArgumentList;
 
 namespace {
 
-struct PolySet {  // owns the flattened copy a pdmpc_polygon_set points into
-    std::vector<int32_t> off{0};
-    std::vector<double> x, y;
-    void add(const TypedArray<double>& m) {  // 2 x V
-        const size_t V = m.getDimensions()[1];
-        for (size_t v = 0; v < V; ++v) {
-            x.push_back(m[0][v]);
-            y.push_back(m[1][v]);
-        }
-        off.push_back((int32_t)x.size());
+// descriptors point into the MATLAB arrays themselves (TypedArray<double> storage is contiguous, column-major); the arrays are
+// kept alive in `pins` for the duration of the call
+struct Pins {
+    std::deque<TypedArray<double>> arrays;
+    std::deque<std::vector<pdmpc_ml_matrix>> cells;
+    pdmpc_ml_matrix matrix(const Array& a) {
+        if (a.isEmpty()) return {nullptr, 0, 0};
+        arrays.emplace_back(TypedArray<double>(a));
+        const TypedArray<double>& t = arrays.back();
+        const auto d = t.getDimensions();
+        return {&*t.begin(), (int32_t)d[0], (int32_t)(t.getNumberOfElements() / d[0])};
     }
-    pdmpc_polygon_set view() const {
-        static const double zero = 0.0;
-        return {(int32_t)off.size() - 1, off.data(), x.empty() ? &zero : x.data(), y.empty() ? &zero : y.data()};
+    const pdmpc_ml_matrix* cell(const Array& a, int32_t& rows, int32_t& cols) {  // linear (column-major) cell order, as MATLAB stores it
+        const CellArray c = a;
+        const auto d = c.getDimensions();
+        rows = (int32_t)d[0];
+        cols = d.size() > 1 ? (int32_t)d[1] : 1;
+        cells.emplace_back();
+        std::vector<pdmpc_ml_matrix>& v = cells.back();
+        for (const Array e : c) v.push_back(matrix(e));
+        return v.data();
     }
 };
 
-// cell (rows x Hp) -> polygons in row-major order i*Hp + (k-1), the ABI's indexing
-void flatten_rows(const CellArray& c, PolySet& out) {
-    const auto dims = c.getDimensions();
-    for (size_t i = 0; i < dims[0]; ++i)
-        for (size_t k = 0; k < dims[1]; ++k) out.add(c[i][k]);
+pdmpc_ml_iter iter_from_struct(const StructArray& s, size_t i, Pins& pins) {
+    pdmpc_ml_iter it{};
+    const pdmpc_ml_matrix x0 = pins.matrix(s[i]["x0"]);
+    it.x0 = x0.data;
+    it.n_x0 = x0.rows * x0.cols;
+    it.trim_index = (int32_t)TypedArray<double>(s[i]["trim_index"])[0];
+    it.reference_trajectory_points = pins.matrix(s[i]["reference_trajectory_points"]);
+    it.v_ref = pins.matrix(s[i]["v_ref"]);
+    int32_t r = 0, c = 0;
+    it.obstacles = pins.cell(s[i]["obstacles"], r, c);
+    it.n_obstacles = r * c;
+    it.dynamic_obstacle_area = pins.cell(s[i]["dynamic_obstacle_area"], it.dyn_rows, it.dyn_cols);
+    const pdmpc_ml_matrix* lb = pins.cell(s[i]["lanelet_boundary"], r, c);
+    for (int side = 0; side < 2 && side < r * c; ++side) it.lanelet_boundary[side] = lb[side];
+    it.hdv_reachable_sets = pins.cell(s[i]["hdv_reachable_sets"], it.hdv_rows, it.hdv_cols);
+    return it;
 }
 
 }  // namespace
@@ -55,8 +82,27 @@ void flatten_rows(const CellArray& c, PolySet& out) {
 class MexFunction : public matlab::mex::Function {
     matlab::data::ArrayFactory f;
 
-    void fail(const std::string& what) {
-        getEngine()->feval(u"error", 0, std::vector<Array>({f.createScalar(what + ": " + pdmpc_last_error())}));
+    void fail(const std::string& what, const char* detail) {
+        getEngine()->feval(u"error", 0, std::vector<Array>({f.createScalar(what + ": " + detail)}));
+    }
+
+    // pdmpc_vehicle_out[n] -> 1 x n struct array in MATLAB's layout (pdmpc_ml_record_arrays)
+    StructArray records(const std::vector<pdmpc_vehicle_out>& out, size_t Hp) {
+        StructArray s = f.createStructArray({1, out.size()}, {"status", "n_expanded", "predicted_trims", "shape_cols", "y_predicted", "shapes", "path_nodes", "tree_path"});
+        for (size_t i = 0; i < out.size(); ++i) {
+            TypedArray<double> trims = f.createArray<double>({1, Hp}), cols = f.createArray<double>({1, Hp}), path = f.createArray<double>({1, Hp + 1});
+            TypedArray<double> y = f.createArray<double>({Hp, 3}), nodes = f.createArray<double>({Hp + 1, 8}), shapes = f.createArray<double>({Hp, 2, PDMPC_VMAX});
+            pdmpc_ml_record_arrays(&out[i], (int32_t)Hp, &*trims.begin(), &*cols.begin(), &*y.begin(), &*shapes.begin(), &*nodes.begin(), &*path.begin());
+            s[i]["status"] = f.createScalar<double>(out[i].status);
+            s[i]["n_expanded"] = f.createScalar<double>(out[i].n_expanded);
+            s[i]["predicted_trims"] = trims;
+            s[i]["shape_cols"] = cols;
+            s[i]["y_predicted"] = y;
+            s[i]["shapes"] = shapes;
+            s[i]["path_nodes"] = nodes;
+            s[i]["tree_path"] = path;
+        }
+        return s;
     }
 
 public:
@@ -67,9 +113,9 @@ public:
             cfg.Hp = (int32_t)inputs[1][0];
             cfg.checker = (int32_t)inputs[2][0];
             cfg.dt_seconds = inputs[3][0];
-            cfg.max_vehicles = 1;
+            cfg.max_vehicles = inputs.size() > 4 ? (int32_t)inputs[4][0] : 1;  // GraphSearchHip: 1; the step controller: options.amount
             pdmpc_handle* h = nullptr;
-            if (pdmpc_create(&cfg, &h) != PDMPC_OK) fail("pdmpc_create");
+            if (pdmpc_create(&cfg, &h) != PDMPC_OK) fail("pdmpc_create", pdmpc_last_error());
             outputs[0] = f.createScalar<uint64_t>((uint64_t)h);
             return;
         }
@@ -78,109 +124,63 @@ public:
             pdmpc_destroy(h);
             return;
         }
+        pdmpc_config hc{};
+        if (pdmpc_get_config(h, &hc, nullptr) != PDMPC_OK) fail("pdmpc_get_config", pdmpc_last_error());
+        const size_t Hp = (size_t)hc.Hp;
         if (cmd == "upload_mpa") {
-            const TypedArray<double> T = inputs[2];  // n x n x Hp, column-major
-            const CellArray man = inputs[3];         // n x n cell of structs (generate_maneuver.m:25-34)
-            const auto d = T.getDimensions();
-            const int n = (int)d[0], Hp = (int)d[2];
-            std::vector<uint8_t> trans((size_t)Hp * n * n);
-            std::vector<int32_t> index((size_t)n * n, -1);
-            std::vector<pdmpc_maneuver> mans;
-            for (int k = 0; k < Hp; ++k)
-                for (int i = 0; i < n; ++i)
-                    for (int j = 0; j < n; ++j) trans[((size_t)k * n + i) * n + j] = T[i][j][k] != 0;
-            for (int i = 0; i < n; ++i)
-                for (int j = 0; j < n; ++j) {
-                    const Array cell = man[i][j];
-                    if (cell.isEmpty()) continue;
-                    const StructArray s = cell;
-                    pdmpc_maneuver m{};
+            Pins pins;
+            const pdmpc_ml_matrix T = pins.matrix(inputs[2]);  // n x n x Hp, column-major
+            const CellArray man = inputs[3];                   // n x n cell of structs (generate_maneuver.m:25-34)
+            const int32_t n = T.rows;
+            std::vector<pdmpc_ml_maneuver> cells;
+            for (const Array e : man) {  // linear order
+                pdmpc_ml_maneuver m{};
+                if (!e.isEmpty()) {
+                    const StructArray s = e;
+                    m.present = 1;
                     m.dx = TypedArray<double>(s[0]["dx"])[0];
                     m.dy = TypedArray<double>(s[0]["dy"])[0];
                     m.dyaw = TypedArray<double>(s[0]["dyaw"])[0];
-                    const char* names[3] = {"area", "area_without_offset", "area_large_offset"};
-                    double(*dst[3])[PDMPC_VMAX] = {m.area, m.area_without_offset, m.area_large_offset};
-                    for (int a = 0; a < 3; ++a) {
-                        const TypedArray<double> A = s[0][names[a]];
-                        m.n_cols = (int32_t)A.getDimensions()[1];
-                        for (int v = 0; v < m.n_cols; ++v) {
-                            dst[a][0][v] = A[0][v];
-                            dst[a][1][v] = A[1][v];
-                        }
-                    }
-                    index[(size_t)i * n + j] = (int32_t)mans.size();
-                    mans.push_back(m);
+                    m.area = pins.matrix(s[0]["area"]);
+                    m.area_without_offset = pins.matrix(s[0]["area_without_offset"]);
+                    m.area_large_offset = pins.matrix(s[0]["area_large_offset"]);
                 }
-            pdmpc_mpa mpa{n, Hp, trans.data(), index.data(), (int32_t)mans.size(), mans.data()};
-            if (pdmpc_upload_mpa(h, &mpa) != PDMPC_OK) fail("pdmpc_upload_mpa");
+                cells.push_back(m);
+            }
+            if (pdmpc_ml_upload_mpa(h, T.data, n, T.cols / n, cells.data()) != PDMPC_OK) fail("pdmpc_ml_upload_mpa", pdmpc_ml_last_error());
             return;
         }
-        if (cmd == "plan" || cmd == "plan_sampled") {  // plan_sampled: one more trailing argument, the seed (time_step + vehicle_index)
-            const TypedArray<double> x0 = inputs[2];
-            const TypedArray<double> ref = inputs[4];  // Hp x 2
-            const TypedArray<double> vref = inputs[5];
-            const size_t Hp = vref.getNumberOfElements();
-            std::vector<double> rx(Hp), ry(Hp), vr(Hp);
-            for (size_t k = 0; k < Hp; ++k) {
-                rx[k] = ref[k][0];
-                ry[k] = ref[k][1];
-                vr[k] = vref[k];
-            }
-            PolySet stat, dyn, hdv, lb[2];
-            const CellArray obstacles = inputs[6];
-            for (auto e : obstacles) stat.add(e);
-            flatten_rows(inputs[7], dyn);
-            const CellArray boundary = inputs[8];
-            for (int s = 0; s < 2; ++s)
-                if (!Array(boundary[0][s]).isEmpty()) lb[s].add(boundary[0][s]);
-            flatten_rows(inputs[9], hdv);
-            pdmpc_vehicle_in in{};
-            in.x0 = x0[0];
-            in.y0 = x0[1];
-            in.yaw0 = x0[2];
-            in.trim0 = (int32_t)inputs[3][0];
-            in.ref_x = rx.data();
-            in.ref_y = ry.data();
-            in.v_ref = vr.data();
-            in.n_left = (int32_t)lb[0].x.size();
-            in.n_right = (int32_t)lb[1].x.size();
-            in.left_x = lb[0].x.data();
-            in.left_y = lb[0].y.data();
-            in.right_x = lb[1].x.data();
-            in.right_y = lb[1].y.data();
-            in.obstacles = stat.view();
-            in.dynamic_obstacles = dyn.view();
-            in.hdv_reachable_sets = hdv.view();
-            pdmpc_vehicle_out out{};
-            if (cmd == "plan") {
-                if (pdmpc_plan_batch(h, 1, &in, &out) != PDMPC_OK) fail("pdmpc_plan_batch");
+        if (cmd == "plan" || cmd == "plan_sampled" || cmd == "plan_level" || cmd == "plan_step") {
+            Pins pins;
+            const StructArray iters = inputs[2];
+            const size_t n = iters.getNumberOfElements();
+            std::vector<pdmpc_ml_iter> its;
+            for (size_t i = 0; i < n; ++i) its.push_back(iter_from_struct(iters, i, pins));
+            std::vector<pdmpc_vehicle_out> out(n);
+            if (cmd == "plan_step") {
+                const pdmpc_ml_matrix seq = pins.matrix(inputs[3]);  // n x n directed_coupling_sequential
+                int32_t r = 0, c = 0;
+                const pdmpc_ml_matrix* fb = inputs.size() > 4 && !inputs[4].isEmpty() ? pins.cell(inputs[4], r, c) : nullptr;  // n x Hp cell
+                pdmpc_ml_step* step = nullptr;
+                if (pdmpc_ml_step_create((int32_t)Hp, (int32_t)n, its.data(), seq.data, fb, &step) != PDMPC_OK) fail("pdmpc_ml_step_create", pdmpc_ml_last_error());
+                const int rc = pdmpc_ml_plan_step(h, step, out.data());
+                pdmpc_ml_step_destroy(step);
+                if (rc != PDMPC_OK) fail("pdmpc_ml_plan_step", pdmpc_ml_last_error());
+            } else if (cmd == "plan_sampled") {
+                pdmpc_ml_step* step = nullptr;
+                if (pdmpc_ml_step_create((int32_t)Hp, (int32_t)n, its.data(), nullptr, nullptr, &step) != PDMPC_OK) fail("pdmpc_ml_step_create", pdmpc_ml_last_error());
+                const pdmpc_vehicle_in* in = nullptr;
+                pdmpc_ml_step_problem(step, nullptr, &in, nullptr, nullptr, nullptr, nullptr, nullptr);
+                const uint32_t seed = (uint32_t)(double)inputs[3][0];  // MonteCarloTreeSearch.m:32
+                const int rc = pdmpc_plan_batch_sampled(h, 1, in, &seed, out.data());
+                pdmpc_ml_step_destroy(step);
+                if (rc != PDMPC_OK) fail("pdmpc_plan_batch_sampled", pdmpc_last_error());
             } else {
-                const uint32_t seed = (uint32_t)(double)inputs[10][0];  // MonteCarloTreeSearch.m:32
-                if (pdmpc_plan_batch_sampled(h, 1, &in, &seed, &out) != PDMPC_OK) fail("pdmpc_plan_batch_sampled");
+                if (pdmpc_ml_plan_level(h, (int32_t)Hp, (int32_t)n, its.data(), out.data()) != PDMPC_OK) fail("pdmpc_ml_plan_level", pdmpc_ml_last_error());
             }
-            StructArray s = f.createStructArray({1, 1}, {"status", "n_expanded", "predicted_trims", "shape_cols", "y_predicted", "shapes", "path_nodes"});
-            s[0]["status"] = f.createScalar<double>(out.status);
-            s[0]["n_expanded"] = f.createScalar<double>(out.n_expanded);
-            TypedArray<double> trims = f.createArray<double>({1, Hp}), cols = f.createArray<double>({1, Hp});
-            TypedArray<double> y = f.createArray<double>({Hp, 3}), nodes = f.createArray<double>({Hp + 1, 8});
-            TypedArray<double> shapes = f.createArray<double>({Hp, 2, PDMPC_VMAX});
-            for (size_t k = 0; k < Hp; ++k) {
-                trims[0][k] = out.predicted_trims[k];
-                cols[0][k] = out.shape_cols[k];
-                for (int c = 0; c < 3; ++c) y[k][c] = out.y_predicted[k][c];
-                for (int r = 0; r < 2; ++r)
-                    for (int v = 0; v < PDMPC_VMAX; ++v) shapes[k][r][v] = out.shapes[k][r][v];
-            }
-            for (size_t k = 0; k <= Hp; ++k)
-                for (int c = 0; c < 8; ++c) nodes[k][c] = out.path_nodes[k][c];
-            s[0]["predicted_trims"] = trims;
-            s[0]["shape_cols"] = cols;
-            s[0]["y_predicted"] = y;
-            s[0]["shapes"] = shapes;
-            s[0]["path_nodes"] = nodes;
-            outputs[0] = s;
+            outputs[0] = records(out, Hp);
             return;
         }
-        fail("unknown command " + cmd);
+        fail("unknown command " + cmd, "");
     }
 };

@@ -411,3 +411,38 @@ def test_starved_predecessors_are_replanned_in_resident_slices(monkeypatch):
     ctl.step(plan_step=plan_step)
     assert opt.handle.stats()["safe_replans"] == before
     opt.handle.close()
+
+
+def test_matlab_shaped_entry_points_plan_the_step_like_the_oracle():
+    """pdmpc_ml_upload_mpa + pdmpc_ml_plan_step (include/pdmpc_matlab.h: what the MEX commands `upload_mpa` and `plan_step` call)
+    fed with MATLAB-shaped data in VEHICLE order: records per vehicle equal the oracle's over a closed loop."""
+    import ctypes as C
+
+    import matlab_shapes as ms
+    from oracle import oracle
+    from pdmpc.backend import Handle
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    options = Config(scenario_type=ScenarioType.commonroad, amount=20, Hp=8, max_vehicles=32, max_nodes=1 << 17)
+    mpa = get_mpa(options)
+    sc = commonroad_scenario(options, seed=4)
+    h = Handle(options)
+    keep_m = ms.Keep()
+    T, n_trims, Hp, man = ms.ml_mpa_args(mpa, keep_m)
+    assert ms.lib().pdmpc_ml_upload_mpa(h.h, T, n_trims, Hp, man) == 0
+    ctl = PrioritizedSequentialController(options, sc, mpa, None, coupling="distance", boundary_provider=boundary_provider(sc))
+
+    def plan_step(prob):
+        n = len(prob["iters"])
+        keep = ms.Keep()
+        step = ms.step_create(ms.vehicle_order_problem(prob), options.Hp, keep)
+        by_vehicle = ms.plan_step(h, step, n)
+        ms.lib().pdmpc_ml_step_destroy(step)
+        ref, _ = oracle.plan_step(options, mpa, prob)
+        gpu = by_vehicle[np.asarray(prob["order"])]  # back into slot order
+        assert_records_equal(gpu, ref, "matlab-shaped step")
+        return [info_from_record(gpu[i], options.Hp) for i in range(n)]
+
+    for _ in range(8):
+        ctl.step(plan_step=plan_step)
+    h.close()
