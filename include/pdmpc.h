@@ -374,6 +374,10 @@ int pdmpc_controller_problem(pdmpc_controller* c, int32_t* n, const pdmpc_vehicl
 int pdmpc_controller_state(pdmpc_controller* c, double* x, double* y, double* yaw, double* speed, double* steering, int32_t* needs_fallback,
                            int32_t* time_step);
 const pdmpc_vehicle_out* pdmpc_controller_records(pdmpc_controller* c); /* records of the last pdmpc_controller_step, slot order */
+/* The explorative controller's permutations of the computation levels (PrioritizedExplorativeController.m:241-309): n_perm x
+ * n_levels, row-major, drawn from RandStream("mt19937ar", Seed = seed) / randi as the reference draws them (:249, :283-286);
+ * rows beyond n_levels (the reference stops there) are shuffles from the same stream.  Twin of pdmpc.explorative. */
+int pdmpc_exploration_permutations(int32_t n_levels, int32_t n_perm, uint32_t seed, int32_t* out);
 const char* pdmpc_controller_last_error(void);
 
 const char* pdmpc_last_error(void);

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/pdmpc.h"
+#include "mt19937ar.hpp"
 #include "pdmpc_device.h"
 
 namespace {
@@ -1292,32 +1293,10 @@ int pdmpc_arena_nodes(pdmpc_handle* h, int32_t* max_nodes, int64_t* regrows) {
 }
 
 namespace {
-// mt19937ar (Matsumoto & Nishimura) + genrand_res53: what MATLAB's rand(RandStream('mt19937ar', Seed = s), 1, n) draws
-// (MonteCarloTreeSearch.m:32,53).  Restated from the published algorithm.
+// what MATLAB's rand(RandStream('mt19937ar', Seed = s), 1, n) draws (MonteCarloTreeSearch.m:32,53)
 void mt19937ar_doubles(uint32_t seed, int n, double* out) {
-    uint32_t mt[624];
-    mt[0] = seed;
-    for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
-    int mti = 624;
-    auto next = [&]() {
-        if (mti >= 624) {
-            for (int k = 0; k < 624; ++k) {
-                const uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
-                mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-            }
-            mti = 0;
-        }
-        uint32_t y = mt[mti++];
-        y ^= (y >> 11);
-        y ^= (y << 7) & 0x9d2c5680u;
-        y ^= (y << 15) & 0xefc60000u;
-        y ^= (y >> 18);
-        return y;
-    };
-    for (int i = 0; i < n; ++i) {
-        const uint32_t a = next() >> 5, b = next() >> 6;
-        out[i] = (a * 67108864.0 + b) * (1.0 / 9007199254740992.0);
-    }
+    Mt19937ar rng(seed);
+    for (int i = 0; i < n; ++i) out[i] = rng.rand();
 }
 }  // namespace
 

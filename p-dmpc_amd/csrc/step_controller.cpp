@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "../../include/pdmpc.h"
+#include "mt19937ar.hpp"
 
 namespace {
 
@@ -914,6 +915,62 @@ int pdmpc_controller_state(pdmpc_controller* c, double* x, double* y, double* ya
         if (needs_fallback) needs_fallback[i] = c->info_old[i].present && c->info_old[i].needs_fallback;
     }
     if (time_step) *time_step = c->k;
+    return PDMPC_OK;
+}
+
+// PrioritizedExplorativeController.computation_level_permutations (:241-309): n_perm x n_levels table, row-major, row 0 = 1..n;
+// rows up to n_levels form a Latin square built "fewest possibilities first" with random choices from
+// RandStream("mt19937ar", Seed = seed) / randi (:249, :283-286), a row that meets a dead end is drawn again; further rows
+// (the reference stops at n_levels; BASELINE config C5 asks for 64) are Fisher-Yates shuffles from the same stream.
+// The twin of pdmpc.explorative.computation_level_permutations.
+int pdmpc_exploration_permutations(int32_t n_levels, int32_t n_perm, uint32_t seed, int32_t* out) {
+    if (n_levels < 1 || n_perm < 1 || !out) return cfail(nullptr, PDMPC_ERR_INVALID, "bad argument");
+    Mt19937ar rng(seed);
+    const int n = n_levels;
+    std::vector<std::vector<int32_t>> rows;
+    rows.emplace_back();
+    for (int j = 0; j < n; ++j) rows[0].push_back(j + 1);
+    while ((int)rows.size() < std::min(n_perm, n_levels)) {
+        std::vector<uint8_t> allowed((size_t)n * n, 1);  // [level][class]
+        for (int col = 0; col < n; ++col)
+            for (const auto& r : rows) allowed[(size_t)(r[(size_t)col] - 1) * n + col] = 0;
+        std::vector<int32_t> perm((size_t)n, 0);
+        bool ok = true;
+        for (int filled = 0; filled < n && ok; ++filled) {
+            int best_col = 0, best_cnt = n + 1;
+            for (int col = 0; col < n; ++col) {  // [n_possibilities, i_cell] = min(sum(is_level_allowed, 1)): the first minimum
+                int cnt = 0;
+                for (int l = 0; l < n; ++l) cnt += allowed[(size_t)l * n + col];
+                if (cnt < best_cnt) {
+                    best_cnt = cnt;
+                    best_col = col;
+                }
+            }
+            if (best_cnt == 0) {
+                ok = false;
+                break;
+            }
+            const int pick = rng.randi(best_cnt);  // 1-based position among find(is_level_allowed(:, i_cell))
+            int lvl = -1;
+            for (int l = 0, seen = 0; l < n; ++l)
+                if (allowed[(size_t)l * n + best_col] && ++seen == pick) {
+                    lvl = l;
+                    break;
+                }
+            perm[(size_t)best_col] = lvl + 1;
+            for (int col = 0; col < n; ++col) allowed[(size_t)lvl * n + col] = 0;
+            for (int l = 0; l < n; ++l) allowed[(size_t)l * n + best_col] = 1;
+        }
+        if (ok) rows.push_back(perm);
+    }
+    while ((int)rows.size() < n_perm) {
+        std::vector<int32_t> perm((size_t)n);
+        for (int j = 0; j < n; ++j) perm[(size_t)j] = j + 1;
+        for (int i = n - 1; i > 0; --i) std::swap(perm[(size_t)i], perm[(size_t)(rng.randi(i + 1) - 1)]);
+        rows.push_back(perm);
+    }
+    for (int p = 0; p < n_perm; ++p)
+        for (int j = 0; j < n; ++j) out[(size_t)p * n + j] = rows[(size_t)p][(size_t)j];
     return PDMPC_OK;
 }
 

@@ -61,6 +61,7 @@ EXPORTS = [
     "pdmpc_controller_state",
     "pdmpc_controller_records",
     "pdmpc_controller_last_error",
+    "pdmpc_exploration_permutations",
     "pdmpc_last_error",
     "pdmpc_version",
 ]

@@ -4,8 +4,8 @@ Restates the host side of the reference's explorative controller
 (hlc/controller/prioritized/PrioritizedExplorativeController.m):
 
     computation_level_permutations   :241-309  Latin-square-like permutations of the computation levels; the first
-                                               row keeps the current prioritization (random draws use numpy here, the
-                                               reference uses MATLAB's mt19937ar stream seeded with the time step)
+                                               row keeps the current prioritization; random draws from the reference's
+                                               own stream: RandStream("mt19937ar", Seed = time step) / randi
     one plan per permutation         :25-91    every vehicle plans once per permutation
     solution cost per sub-graph      :94-144   sum over the vehicles of a weakly connected sub-graph of the cost-to-come
                                                of the final node, tree.get_cost(tree_path(end))
@@ -22,14 +22,32 @@ from .controller import kahn, directed_coupling_from_priorities
 from .distributed import weak_components
 
 
+class MatlabRandStream:
+    """RandStream("mt19937ar", Seed = k) as far as the explorative controller uses it (PrioritizedExplorativeController.m:249,283-286):
+    `randi(stream, n)` = floor(n * rand(stream)) + 1 with rand = the 53-bit double of two 32-bit draws (genrand_res53; numpy's
+    RandomState is the same generator, pinned against the repo's own mt19937ar in tests/test_host.py).  MATLAB maps Seed = 0 to
+    the generator's default seed 5489."""
+
+    def __init__(self, seed):
+        self.rs = np.random.RandomState(int(seed) if int(seed) != 0 else 5489)
+
+    def rand(self):
+        return float(self.rs.random_sample())
+
+    def randi(self, n):
+        return int(np.floor(n * self.rand())) + 1
+
+
 def computation_level_permutations(n_levels, n_perm, seed):
-    """(n_perm, n_levels) array, row 0 = identity.  Rows 1..n_levels-1 follow PrioritizedExplorativeController.m:241-309
-    (no column repeats a level: a Latin rectangle built by 'fewest possibilities first' with random choices and restart
-    on dead ends); further rows (n_perm > n_levels) are plain random permutations."""
-    rng = np.random.default_rng(seed)
+    """(n_perm, n_levels) array, row 0 = identity.  Rows 1..n_levels-1 follow PrioritizedExplorativeController.m:241-309: no
+    column repeats a level (a Latin rectangle built 'fewest possibilities first' with random choices, a row that runs into a dead
+    end is drawn again), the random choices from the reference's own stream, RandStream("mt19937ar", Seed = time step) / randi
+    (:249, :283-286).  The reference explores exactly n_levels permutations; rows beyond that (n_perm > n_levels, BASELINE config
+    C5 asks for 64) are this framework's extension: Fisher-Yates shuffles drawn from the same stream."""
+    rng = MatlabRandStream(seed)
     rows = [list(range(1, n_levels + 1))]
     while len(rows) < min(n_perm, n_levels):
-        allowed = np.ones((n_levels, n_levels), dtype=bool)  # [level, column]
+        allowed = np.ones((n_levels, n_levels), dtype=bool)  # is_level_allowed(level, class)
         for col in range(n_levels):
             for r in rows:
                 allowed[r[col] - 1, col] = False
@@ -37,20 +55,39 @@ def computation_level_permutations(n_levels, n_perm, seed):
         ok = True
         for _ in range(n_levels):
             counts = allowed.sum(axis=0)
-            col = int(np.argmin(counts))
+            col = int(np.argmin(counts))  # [n_possibilities, i_cell] = min(sum(is_level_allowed, 1)): the first minimum
             if counts[col] == 0:
                 ok = False
                 break
-            choices = np.nonzero(allowed[:, col])[0]
-            lvl = int(choices[rng.integers(len(choices))])
+            choices = np.nonzero(allowed[:, col])[0]  # find(is_level_allowed(:, i_cell)), ascending
+            lvl = int(choices[rng.randi(len(choices)) - 1])
             perm[col] = lvl + 1
             allowed[lvl, :] = False
             allowed[:, col] = True  # never the column with the fewest possibilities again
         if ok:
             rows.append(perm)
     while len(rows) < n_perm:
-        rows.append([int(v) + 1 for v in rng.permutation(n_levels)])
+        perm = list(range(1, n_levels + 1))
+        for i in range(n_levels - 1, 0, -1):  # Fisher-Yates from the back
+            j = rng.randi(i + 1) - 1
+            perm[i], perm[j] = perm[j], perm[i]
+        rows.append(perm)
     return np.array(rows[:n_perm], dtype=np.int64)
+
+
+def native_computation_level_permutations(n_levels, n_perm, seed):
+    """The same table from libpdmpc_hip.so (pdmpc_exploration_permutations, csrc/step_controller.cpp): the native twin."""
+    import ctypes as C
+
+    from . import backend
+
+    L = backend.load_library()
+    L.pdmpc_exploration_permutations.argtypes = [C.c_int32, C.c_int32, C.c_uint32, C.POINTER(C.c_int32)]
+    out = np.zeros((n_perm, n_levels), dtype=np.int32)
+    rc = L.pdmpc_exploration_permutations(n_levels, n_perm, int(seed), out.ctypes.data_as(C.POINTER(C.c_int32)))
+    if rc != 0:
+        raise backend.BackendError("pdmpc_exploration_permutations failed: %d" % rc)
+    return out.astype(np.int64)
 
 
 def build_exploration_batch(ctl, n_perm, seed):
@@ -62,7 +99,10 @@ def build_exploration_batch(ctl, n_perm, seed):
     perms = computation_level_permutations(n_levels, n_perm, seed)
     parts = []
     for p in range(n_perm):
-        prio = [int(perms[p][levels0[v] - 1]) for v in range(ctl.n)]  # vehicles of one class share a (permuted) level
+        # prepare_permutation (:42-58): i11changem(levels, 1:n, permutation) -- a vehicle of (old) level L gets the POSITION of L in
+        # the permutation as its new level; vehicles of one class share it
+        where = {int(lvl): j + 1 for j, lvl in enumerate(perms[p])}
+        prio = [where[int(levels0[v])] for v in range(ctl.n)]
         prob = base if p == 0 else ctl.build_step_problem(priorities=prio, refresh=False)
         parts.append(prob)
     flat = []

@@ -373,3 +373,29 @@ def test_fallback_spreads_to_coupled_vehicles():
         assert np.array_equal(infos[i].y_predicted[:, :-1], prev[i].y_predicted[:, 1:]), i
         assert np.array_equal(infos[i].y_predicted[:, -1], prev[i].y_predicted[:, -1]), i
         assert np.array_equal(infos[i].predicted_trims[:-1], prev[i].predicted_trims[1:]), i
+
+
+def test_exploration_permutations_follow_the_reference_stream():
+    """PrioritizedExplorativeController.computation_level_permutations (:241-309) with RandStream("mt19937ar", Seed = k) / randi:
+    the Python producer, its native twin (pdmpc_exploration_permutations) and a third statement on the oracle's own mt19937ar
+    agree; the first n_levels rows form a Latin square whose first row is the identity."""
+    from oracle import oracle
+    from pdmpc.explorative import MatlabRandStream, computation_level_permutations, native_computation_level_permutations
+
+    # the stream itself: numpy's RandomState against the oracle's restatement of mt19937ar / genrand_res53
+    for seed in (1, 7, 41):
+        want = oracle.mt19937_doubles(seed, 50)
+        rs = MatlabRandStream(seed)
+        assert [rs.rand() for _ in range(50)] == list(want)
+    # known answer of the published generator: rng(0) -> rand = 0.8147..., randi(10) = 9 (seed 0 = default seed 5489)
+    assert abs(MatlabRandStream(0).rand() - 0.8147236863931789) < 1e-16 and MatlabRandStream(0).randi(10) == 9
+    for n_levels, n_perm, seed in ((5, 5, 3), (13, 64, 21), (12, 12, 8), (1, 4, 2), (14, 64, 40)):
+        a = computation_level_permutations(n_levels, n_perm, seed)
+        b = native_computation_level_permutations(n_levels, n_perm, seed)
+        assert np.array_equal(a, b), (n_levels, n_perm, seed)
+        assert list(a[0]) == list(range(1, n_levels + 1))
+        sq = a[: min(n_perm, n_levels)]
+        for col in range(n_levels):
+            assert len(set(sq[:, col])) == len(sq), "a level twice in column %d" % col
+        for r in a:
+            assert sorted(r) == list(range(1, n_levels + 1))
