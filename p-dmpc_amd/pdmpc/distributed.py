@@ -94,6 +94,11 @@ class HipRangePlanner:
     def fetch(self, n):
         return self.h.fetch(n)
 
+    def plan_whole(self, problem):
+        """A rank-local problem (whole coupling-graph components) in ONE launch with the hand-off on the device."""
+        fb = [f if f is not None else [] for f in problem["fallback"]]
+        return self.h.plan_step(problem["iters"], problem["preds"], fb)
+
 
 class _NoStream:
     def __enter__(self):
@@ -103,10 +108,11 @@ class _NoStream:
         return False
 
 
-def plan_step_sharded(problem, planner, dist, rank, world, resident_bank=None, fetch=True):
+def plan_step_sharded(problem, planner, dist, rank, world, resident_bank=None, fetch=True, always_gather=False):
     """Plan one time step (slots in level order, see controller.build_step_problem) with levels sharded over `world`
     ranks.  Returns the records of all slots (identical on every rank).  With `resident_bank` the inputs are already
-    packed in that HBM bank (bench.py's timed region: no host->device copies)."""
+    packed in that HBM bank (bench.py's timed region: no host->device copies).  always_gather: run the collective and the import
+    also with a single rank (a 1-rank all-gather is a copy): the RCCL path on a 1-GPU box."""
     if resident_bank is None:
         planner.begin(problem)
     else:
@@ -121,11 +127,11 @@ def plan_step_sharded(problem, planner, dist, rank, world, resident_bank=None, f
             lo, hi = parts[rank]
             send = send_all[: max(per, 1) * REC_BYTES]
             planner.plan_range(lo, hi - lo, send)
-            if world > 1:
+            if world > 1 or (always_gather and dist is not None):
                 recv = recv_all[: max(per, 1) * world * REC_BYTES]
                 dist.all_gather_into_tensor(recv, send)
                 for r, (rlo, rhi) in enumerate(parts):
-                    if r != rank and rhi > rlo:
+                    if (r != rank or always_gather) and rhi > rlo:
                         planner.import_records(rlo, rhi - rlo, recv[r * per * REC_BYTES : (r * per + (rhi - rlo)) * REC_BYTES])
             first += size
     if not fetch:
@@ -203,3 +209,104 @@ def gather_records(local_records_tensor, n_local, parts, dist, rank, world, new_
     recv = new_buffer(per * world)
     dist.all_gather_into_tensor(recv, send)
     return [recv[r * per * REC_BYTES : (r * per + len(parts[r])) * REC_BYTES] for r in range(world)]
+
+
+def partition_instances(batch, world):
+    """Config C5 (pdmpc.explorative.build_exploration_batch): the prioritization instances of a time step are independent until the
+    final cost comparison, so they are dealt out to the ranks (instance p -> rank p mod world) and a rank plans its instances
+    with ONE launch; no collective on the data path (the end-of-step all-gather of the records stands for the all-reduce of
+    the 64 solution costs).  Returns per rank the sorted slots it plans."""
+    parts = [[] for _ in range(world)]
+    for s, p in enumerate(batch["instance"]):
+        parts[p % world].append(s)
+    return parts
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Hybrid sharding: components stay whole, except one that is too heavy for a single rank.
+#
+# With whole components the step takes as long as the most loaded rank; a component that alone outweighs the mean load per
+# rank bounds the speed-up by total / heaviest however the others are placed.  Such a component is planned by ALL ranks
+# together, level by level (one all-gather per level among all ranks: the level-sharded protocol above, restricted to
+# the component's slots), while every other component is planned whole by one rank (longest-processing-time assignment by
+# measured pops, as before).  A rank first launches its whole components (one launch, asynchronous on the GPU) and then
+# takes part in the shared component's levels; one all-gather of the whole components' records ends the step.
+#
+# Bounds (equal tiles of the tiled map, one component each; with at most one search per CU a rank's time is the latency of
+# its slowest component's level chain, not the sum over its components): C3 = 7 tiles on 4 GPUs and C4 = 26 tiles on 8 GPUs
+# have no dominating component, so the hybrid falls back to whole components there (ranks hold 2,2,2,1 and 4,4,3,...,3
+# tiles = at most 80 searches per GPU, far below one per CU: the per-rank time is one tile's chain, about 1.3 - 2 ms against
+# 22 ms for all 512 searches on one GPU); a single big component (one 512-vehicle network) is the case the split is for.
+
+
+def hybrid_partition(preds, world, weights=None, dominance=1.0):
+    """-> (parts, shared): `shared` = sorted slots of the heaviest component if its weight exceeds `dominance` x the mean load
+    per rank (else []), `parts[r]` = sorted slots of the whole components rank r plans."""
+    labels = weak_components(preds)
+    comps = {}
+    for s, c in enumerate(labels):
+        comps.setdefault(c, []).append(s)
+    w = (lambda slots: float(len(slots))) if weights is None else (lambda slots: float(sum(weights[s] for s in slots)))
+    total = sum(w(v) for v in comps.values())
+    heavy = max(comps, key=lambda c: (w(comps[c]), -c))
+    shared = []
+    if world > 1 and len(comps[heavy]) >= 2 * world and w(comps[heavy]) > dominance * total / world:
+        shared = sorted(comps.pop(heavy))
+    load = [0.0] * world
+    parts = [[] for _ in range(world)]
+    for c in sorted(comps, key=lambda c: (-w(comps[c]), c)):
+        r = min(range(world), key=lambda r: (load[r], r))
+        parts[r] += comps[c]
+        load[r] += w(comps[c])
+    return [sorted(p) for p in parts], shared
+
+
+def level_sizes_of(preds):
+    """kahn level sizes of a problem whose slots are in level order (every predecessor in a lower slot)."""
+    lvl = []
+    for ps in preds:
+        lvl.append(1 + max((lvl[p] for p in ps), default=0))
+    if lvl != sorted(lvl):
+        raise ValueError("slots are not in level order")
+    return [lvl.count(v) for v in range(1, max(lvl, default=0) + 1)]
+
+
+def plan_step_hybrid(problem, planner, dist, rank, world, weights=None, dominance=1.0):
+    """One time step with hybrid sharding (see above).  `planner` as for plan_step_sharded.  Returns the records of all slots
+    (host array, identical on every rank)."""
+    n = len(problem["iters"])
+    parts, shared = hybrid_partition(problem["preds"], world, weights, dominance)
+    out = np.zeros(n, dtype=abi.VEHICLE_OUT_DTYPE)
+    # ---- this rank's whole components (a rank-local problem: no collective inside)
+    mine = parts[rank]
+    if mine:
+        sub = sub_problem(problem, mine)
+        sub["level_sizes"] = level_sizes_of(sub["preds"])
+        if hasattr(planner, "plan_whole"):
+            local = planner.plan_whole(sub)  # one launch, hand-off on the device
+        else:
+            local = plan_step_sharded(sub, planner, None, 0, 1)
+        out[np.asarray(mine)] = local
+    # ---- the dominating component, by all ranks together
+    if shared:
+        sub = sub_problem(problem, shared)
+        sub["level_sizes"] = level_sizes_of(sub["preds"])
+        out[np.asarray(shared)] = plan_step_sharded(sub, planner, dist, rank, world)
+    # ---- every rank gets the whole components of the others
+    if world > 1:
+        import torch
+
+        per = max(max(len(p) for p in parts), 1)
+        send = torch.zeros(per * REC_BYTES, dtype=torch.uint8)
+        if mine:
+            raw = np.frombuffer(out[np.asarray(mine)].tobytes(), dtype=np.uint8)
+            send[: raw.size] = torch.from_numpy(raw.copy())
+        dev = getattr(planner, "device", None)
+        recv = torch.zeros(per * world * REC_BYTES, dtype=torch.uint8, device=dev) if dev is not None else torch.zeros(per * world * REC_BYTES, dtype=torch.uint8)
+        dist.all_gather_into_tensor(recv, send.to(dev) if dev is not None else send)
+        host = recv.cpu().numpy()
+        for r in range(world):
+            if r != rank and parts[r]:
+                blk = host[r * per * REC_BYTES : (r * per + len(parts[r])) * REC_BYTES]
+                out[np.asarray(parts[r])] = np.frombuffer(blk.tobytes(), dtype=abi.VEHICLE_OUT_DTYPE)
+    return out

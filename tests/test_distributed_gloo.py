@@ -234,3 +234,75 @@ def test_component_sharding_world2_matches_single_process():
     for r in range(2):
         recs = np.frombuffer(got[r], dtype=abi.VEHICLE_OUT_DTYPE)
         assert np.array_equal(recs.view(np.uint8), want.view(np.uint8))
+
+
+# ---- hybrid sharding: a dominating component is level-sharded over all ranks, the others stay whole ------------------
+def make_dominated_problem():
+    """One 12-vehicle network (a single component) next to two small tiles... built by merging a coupled problem with a tiled one."""
+    options, mpa, big = make_problem()  # 12 vehicles, coupled: one or two components
+    return options, mpa, big
+
+
+def _hybrid_worker(rank, world, port, q):
+    from pdmpc.distributed import plan_step_hybrid
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = {}
+    options, mpa, prob = make_dominated_problem()
+    out["dominated"] = plan_step_hybrid(prob, OracleRangePlanner(options, mpa), dist, rank, world, dominance=0.5).tobytes()
+    options2, mpa2, prob2 = make_tiled_problem()
+    out["tiled"] = plan_step_hybrid(prob2, OracleRangePlanner(options2, mpa2), dist, rank, world).tobytes()
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_hybrid_partition_shares_only_a_dominating_component():
+    from pdmpc.distributed import hybrid_partition
+
+    preds = [[]] + [[i - 1] for i in range(1, 12)] + [[], [12], [], []]  # a chain of 12, a pair, two singles
+    parts, shared = hybrid_partition(preds, 2)
+    assert shared == list(range(12))
+    assert sorted(s for p in parts for s in p) == [12, 13, 14, 15]
+    parts, shared = hybrid_partition(preds, 2, dominance=2.0)
+    assert shared == [] and sorted(s for p in parts for s in p) == list(range(16))
+    parts, shared = hybrid_partition([[], [0], [], [2], [], [4]], 2)  # three equal components: nothing dominates
+    assert shared == []
+
+
+@pytest.mark.timeout(300)
+def test_hybrid_sharding_world2_matches_single_process():
+    from oracle import oracle
+    from pdmpc.distributed import hybrid_partition
+
+    options, mpa, prob = make_dominated_problem()
+    assert hybrid_partition(prob["preds"], 2, dominance=0.5)[1], "the test problem has no dominating component"
+    want = oracle.plan_step(options, mpa, prob)[0]
+    options2, mpa2, prob2 = make_tiled_problem()
+    want2 = oracle.plan_step(options2, mpa2, prob2)[0]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hybrid_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        assert np.array_equal(np.frombuffer(got[r]["dominated"], dtype=np.uint8), want.view(np.uint8))
+        assert np.array_equal(np.frombuffer(got[r]["tiled"], dtype=np.uint8), want2.view(np.uint8))
+
+
+def test_partition_instances_deals_instances_round_robin():
+    from pdmpc.distributed import partition_instances, sub_problem
+
+    batch = {"instance": [0, 1, 2, 3, 0, 1, 2, 3, 0, 2], "preds": [[], [], [], [], [0], [1], [2], [3], [4], [6]], "iters": list(range(10)),
+             "order": list(range(10)), "fallback": [None] * 10}
+    parts = partition_instances(batch, 2)
+    assert parts == [[0, 2, 4, 6, 8, 9], [1, 3, 5, 7]]
+    sub = sub_problem(batch, parts[0])
+    assert sub["preds"] == [[], [], [0], [1], [2], [3]]

@@ -446,3 +446,69 @@ def test_matlab_shaped_entry_points_plan_the_step_like_the_oracle():
     for _ in range(8):
         ctl.step(plan_step=plan_step)
     h.close()
+
+
+def test_rccl_paths_with_one_rank_match_the_single_launch():
+    """torch.distributed with backend "nccl" (= RCCL) initialised on this one GPU: the level-sharded planner with its all-gather +
+    import per level (always_gather: a 1-rank all-gather is a copy through RCCL), the component path (one launch, asynchronous
+    export, all_gather_into_tensor on the handle's own stream wrapped as an ExternalStream) and the hybrid planner, all against
+    the single launch and the oracle."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from oracle import oracle
+    from pdmpc.distributed import REC_BYTES, HipRangePlanner, plan_step_hybrid, plan_step_sharded
+    from pdmpc.optimizer import GraphSearchHip
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+    from pdmpc import abi
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        options = Config(scenario_type=ScenarioType.commonroad, amount=40, Hp=6, max_vehicles=64, max_nodes=1 << 16)
+        mpa = get_mpa(options)
+        sc = commonroad_scenario(options, seed=5, tiles=2)
+        opt = GraphSearchHip(options)
+        planner = HipRangePlanner(opt, mpa, torch.device("cuda", 0))
+        ctl = PrioritizedSequentialController(options, sc, mpa, None, coupling="distance", boundary_provider=boundary_provider(sc))
+        h = opt.handle
+        ext = torch.cuda.ExternalStream(h.stream_ptr(), device=torch.device("cuda", 0))
+
+        def plan_step(prob):
+            n = len(prob["iters"])
+            fb = [f if f is not None else [] for f in prob["fallback"]]
+            ref, _ = oracle.plan_step(options, mpa, prob)
+            single = h.plan_step(prob["iters"], prob["preds"], fb)
+            assert_records_equal(single, ref, "single launch")
+            # level-sharded: launch_range per level -> export -> RCCL all-gather -> import, all on the handle's stream
+            lv = plan_step_sharded(prob, planner, dist, 0, 1, always_gather=True)
+            assert_records_equal(lv, ref, "levels through RCCL")
+            # component path as bench.py runs it: one launch, export, all-gather on the ExternalStream, records read from the gathered buffer
+            h.pack_step(prob["iters"], prob["preds"], fb)
+            send = torch.zeros(n * REC_BYTES, dtype=torch.uint8, device="cuda")
+            recv = torch.zeros(n * REC_BYTES, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            h.launch()
+            h.export_results_async(0, n, send.data_ptr())
+            with torch.cuda.stream(ext):
+                dist.all_gather_into_tensor(recv, send)
+            h.synchronize()
+            got = np.frombuffer(recv.cpu().numpy().tobytes(), dtype=abi.VEHICLE_OUT_DTYPE)
+            assert_records_equal(got, ref, "components through RCCL")
+            hy = plan_step_hybrid(prob, planner, dist, 0, 1)
+            assert_records_equal(hy, ref, "hybrid")
+            return [info_from_record(single[i], options.Hp) for i in range(n)]
+
+        for _ in range(4):
+            ctl.step(plan_step=plan_step)
+        h.close()
+    finally:
+        dist.destroy_process_group()
