@@ -777,19 +777,17 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     }
     if (a.help_chunk == 0) a.help_chunk = a.help_expand ? 32 : 64;  // measured on C2 / C3: expanding helpers 64 -> 555 / 595 steps/s, 32 -> 595 / 584; checking only: 64 best (C4 43.3 against 40.9)
     a.help_finished = h->d_help_finished.p;
-    bool helpers_launched = false;
     if (a.n_helpers > 0) {
         HIPCHK(hipMemsetAsync(h->d_help_board.p + (size_t)first * PDMPC_HB_WORDS, 0, (size_t)count * PDMPC_HB_WORDS * sizeof(unsigned long long), h->stream));
         HIPCHK(hipMemsetAsync(h->d_help_finished.p, 0, 16 * sizeof(uint32_t), h->stream));
-        // the helpers start once the boards are clean; everything the launch stream does after the searches also waits for the
-        // helpers to have left (they leave as soon as the last search has published)
-        HIPCHK(hipEventRecord(h->ev_help_pre, h->stream));
-        hipStream_t hst = count > h->n_cu ? h->help_stream_low : h->help_stream;
-        HIPCHK(hipStreamWaitEvent(hst, h->ev_help_pre, 0));
-        const int hrc = pdmpc_launch_helpers(&a, (void*)hst);
-        if (hrc != 0) return fail(PDMPC_ERR_HIP, std::string("helper kernel launch failed: ") + hipGetErrorString((hipError_t)hrc));
-        HIPCHK(hipEventRecord(h->ev_help_done, hst));
-        helpers_launched = true;
+        HIPCHK(hipEventRecord(h->ev_help_pre, h->stream));  // the boards are clean
+        if (getenv("PDMPC_HELP_FIRST")) {  // diagnostic: the old order, helpers in front of the searches
+            hipStream_t hst0 = count > h->n_cu ? h->help_stream_low : h->help_stream;
+            HIPCHK(hipStreamWaitEvent(hst0, h->ev_help_pre, 0));
+            const int hrc0 = pdmpc_launch_helpers(&a, (void*)hst0);
+            if (hrc0 != 0) return fail(PDMPC_ERR_HIP, "helper kernel launch failed");
+            HIPCHK(hipEventRecord(h->ev_help_done, hst0));
+        }
     }
     auto& ev = h->events[h->events_used++];
     HIPCHK(hipEventRecord(ev.first, h->stream));
@@ -807,15 +805,28 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
                                 : (frontier ? pdmpc_launch_frontier(&a, count, (void*)h->stream) : pdmpc_launch_search(&a, count, (void*)h->stream));
     }
     if (lrc != 0) {
-        // the helpers already run and poll the boards until their idle time-out: nothing may free or regrow what they read before
-        // they have left
-        if (helpers_launched) (void)hipStreamSynchronize(count > h->n_cu ? h->help_stream_low : h->help_stream);
         char buf[256];
         snprintf(buf, sizeof buf, "kernel launch failed: %s (LDS %u B)", hipGetErrorString((hipError_t)lrc), h->lds.total);
         return fail(PDMPC_ERR_HIP, buf);
     }
     HIPCHK(hipEventRecord(ev.second, h->stream));
-    if (helpers_launched) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_help_done, 0));
+    if (a.n_helpers > 0 && getenv("PDMPC_HELP_FIRST")) {
+        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_help_done, 0));
+    } else if (a.n_helpers > 0) {
+        // The helper kernel goes out BEHIND the searches, on a stream of its own: it starts once the boards are clean and runs next
+        // to the searches.  The order matters where the runtime maps both streams onto one hardware queue (few queues, many
+        // streams: seen with RCCL initialised in the process): a helper spins until every search has published, so helpers in front
+        // of the searches on a shared queue would hold them up until the helpers' idle time-out (0.7 s per launch); behind them
+        // they find every search finished and leave at once -- the launch then simply ran without helpers.  Searches never wait for
+        // a helper that has not claimed anything.  Everything the launch stream does after the searches also waits for the helpers
+        // to have left (they leave as soon as the last search has published).
+        hipStream_t hst = count > h->n_cu ? h->help_stream_low : h->help_stream;
+        HIPCHK(hipStreamWaitEvent(hst, h->ev_help_pre, 0));
+        const int hrc = pdmpc_launch_helpers(&a, (void*)hst);
+        if (hrc != 0) return fail(PDMPC_ERR_HIP, std::string("helper kernel launch failed: ") + hipGetErrorString((hipError_t)hrc));
+        HIPCHK(hipEventRecord(h->ev_help_done, hst));
+        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_help_done, 0));
+    }
     h->stats.lds_bytes = h->lds.total;
     h->stats.lds_nodes = h->NL;
     h->stats.queue_mode = a.queue_mode;
@@ -892,7 +903,12 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
     const uint32_t want_nodes = config->max_nodes > 0 ? (uint32_t)config->max_nodes : 32768u;  // default arena: 256 x 32768 nodes, about 0.6 GB
     h->max_vehicles = config->max_vehicles > 0 ? config->max_vehicles : 256;
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->help_stream, hipStreamNonBlocking);
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    // (the helper stream above the launch stream's priority: streams of different priorities do not share a hardware queue, and a
+    // helper only ever occupies CUs the launch leaves idle)
+    if (getenv("PDMPC_HELP_PRIO") && atoi(getenv("PDMPC_HELP_PRIO")) == 0) prio_greatest = 0;  // A/B switch: the helper stream at the launch stream's priority
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->help_stream, hipStreamNonBlocking, prio_greatest);
     if (e == hipSuccess) {
         // Two streams for the helper kernel.  Where searches and helpers compete for CUs (more searches than CUs) it runs at the
         // lowest priority: a search that is waiting for a CU gets it first.  Otherwise at the searches' priority: on the
