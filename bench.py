@@ -442,6 +442,28 @@ def main():
             "(pdmpc_plan_step_literal: pack + H2D + launch + D2H per vehicle; marshalling from Python objects excluded)" % (n_lit, args.vehicles),
         }
         replay_mismatches += lit_bad
+    if explore and dist is None and not args.no_host_inclusive:
+        # config c5 through the C ABI: the native explorative step (pdmpc_controller_explore_step) builds the prioritizations of the
+        # step, flattens them, plans them with one launch, chooses per sub-graph and goes on with the chosen plans
+        from pdmpc.native_controller import NativeController
+        from pdmpc.road_network import commonroad_scenario
+
+        nat = NativeController(options, commonroad_scenario(options, seed=args.seed, tiles=max(1, (args.vehicles + 19) // 20)), mpa, h, coupling="distance",
+                               priority_strategy=args.priorities)
+        nat.run(args.skip)
+        n_x = min(args.steps, 40)
+        nat.explore_run(args.instances, 2)
+        ms = nat.explore_run(args.instances, n_x)
+        host_inclusive = {
+            "value": 1e3 / float(np.mean(ms)),
+            "unit": "MPC steps/s",
+            "ms_per_step": float(np.mean(ms)),
+            "p50_latency_ms": float(np.median(ms)),
+            "p99_latency_ms": float(np.sort(ms)[min(len(ms) - 1, int(0.99 * len(ms)))]),
+            "what": "explorative closed loop through the C ABI (pdmpc_controller_explore_run): per step the %d prioritizations built and flattened in C++ + pack + H2D + "
+            "one launch + D2H + choice per sub-graph + apply of the chosen plans, closed-loop steps %d..%d" % (args.instances, args.skip + 3, args.skip + 2 + n_x),
+        }
+        nat.close()
     scal_ref = None
     if world == 1 and dist is None and default_workload and not args.no_scaling_reference:
         h.close()

@@ -378,6 +378,20 @@ const pdmpc_vehicle_out* pdmpc_controller_records(pdmpc_controller* c); /* recor
  * n_levels, row-major, drawn from RandStream("mt19937ar", Seed = seed) / randi as the reference draws them (:249, :283-286);
  * rows beyond n_levels (the reference stops there) are shuffles from the same stream.  Twin of pdmpc.explorative. */
 int pdmpc_exploration_permutations(int32_t n_levels, int32_t n_perm, uint32_t seed, int32_t* out);
+/* The explorative time step (PrioritizedExplorativeController.m:25-176): the step's traffic state under n_perm
+ * prioritizations — instance 0 the controller's own, instance p the computation levels permuted by row p of the table above —
+ * flattened into one batch whose slots are ordered by (level, instance).  explore_build advances the time step like build_step and
+ * leaves the batch readable with explore_problem (instance / vehicle / level per slot); explore_choose takes the batch's records:
+ * per weakly connected sub-graph the instance with the smallest summed cost-to-come of the final nodes after round(., 8)
+ * (:94-176), chosen[v] = the instance vehicle v goes on with, cost = n_perm x n_graphs; explore_step = build + ONE launch +
+ * choose + apply of the chosen plans (seed = time step, :249); explore_run = n_steps of them, ms[i] = wall-clock of step i. */
+int pdmpc_controller_explore_build(pdmpc_controller* c, int32_t n_perm, uint32_t seed);
+int pdmpc_controller_explore_problem(pdmpc_controller* c, int32_t* n_slots, const pdmpc_vehicle_in** in, const int32_t** pred_offset, const int32_t** pred_index,
+                                     const pdmpc_polygon_set** fallback, const int32_t** instance, const int32_t** vehicle, const int32_t** level);
+int pdmpc_controller_explore_choose(pdmpc_controller* c, const pdmpc_vehicle_out* records, int32_t* chosen, int32_t* n_graphs, double* cost);
+int pdmpc_controller_explore_step(pdmpc_controller* c, int32_t n_perm);
+int pdmpc_controller_explore_run(pdmpc_controller* c, int32_t n_perm, int32_t n_steps, double* ms);
+int pdmpc_controller_explore_result(pdmpc_controller* c, int32_t* chosen, int32_t* n_graphs, const double** cost, const pdmpc_vehicle_out** records);
 const char* pdmpc_controller_last_error(void);
 
 const char* pdmpc_last_error(void);

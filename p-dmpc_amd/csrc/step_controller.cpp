@@ -86,6 +86,19 @@ struct pdmpc_controller {
     std::vector<std::vector<double>> dpool;
     std::vector<std::vector<int32_t>> ipool;
     std::vector<pdmpc_vehicle_out> out;
+    // explorative step (PrioritizedExplorativeController): the prioritizations of the current traffic state, flattened
+    struct Instance {
+        std::vector<uint8_t> directed, directed_seq;
+        std::vector<int32_t> levels, order, slot_of;
+    };
+    std::vector<Instance> inst;
+    std::vector<pdmpc_vehicle_in> x_in;
+    std::vector<pdmpc_polygon_set> x_fb;
+    std::vector<int32_t> x_pred_offset, x_pred_index, x_instance, x_vehicle, x_level, x_slot;  // x_slot[p * n + vehicle] = slot in the flattened batch
+    std::vector<pdmpc_vehicle_out> x_out;
+    std::vector<int32_t> x_chosen;  // per vehicle: the instance its sub-graph chose
+    std::vector<double> x_cost;     // n_perm x n_graphs
+    int x_graphs = 0;
     std::string err;
 };
 
@@ -633,6 +646,10 @@ int pdmpc_controller_destroy(pdmpc_controller* c) {
 
 // Everything one launch needs to plan the whole time step (controller.py: build_step_problem): vehicles in level order
 // (slot = position), per-slot predecessor slots, per-slot areas to publish on exhaustion.
+namespace {
+int assemble_step(pdmpc_controller* c);
+}
+
 int pdmpc_controller_build_step(pdmpc_controller* c) {
     if (!c) return cfail(nullptr, PDMPC_ERR_INVALID, "null controller");
     const int n = c->n, Hp = c->Hp;
@@ -685,6 +702,14 @@ int pdmpc_controller_build_step(pdmpc_controller* c) {
             for (int j = 0; j < n; ++j)
                 if (at(c->adjacency, n, i, j) && !(j < i)) at(c->directed, n, i, j) = 1;
     }
+    return assemble_step(c);
+}
+
+namespace {
+// c->directed -> sequential couplings, levels, slot order and the per-slot inputs of pdmpc_plan_step (the pools are the caller's
+// to clear: the explorative step keeps several problems alive side by side)
+int assemble_step(pdmpc_controller* c) {
+    const int n = c->n, Hp = c->Hp;
     if (!group(*c, c->directed, c->directed_seq)) return cfail(c, PDMPC_ERR_INVALID, "coupling graph has a cycle");
     if (!kahn(c->directed_seq, n, c->levels)) return cfail(c, PDMPC_ERR_INVALID, "coupling graph has a cycle");
     c->order.resize(n);
@@ -755,6 +780,7 @@ int pdmpc_controller_build_step(pdmpc_controller* c) {
     c->pred_index.push_back(0);
     return PDMPC_OK;
 }
+}  // namespace
 
 // records of the step in slot order -> plans, exhaustion handling, fallbacks of coupled vehicles, plant update
 int pdmpc_controller_apply(pdmpc_controller* c, const pdmpc_vehicle_out* recs) {
@@ -971,6 +997,201 @@ int pdmpc_exploration_permutations(int32_t n_levels, int32_t n_perm, uint32_t se
     }
     for (int p = 0; p < n_perm; ++p)
         for (int j = 0; j < n; ++j) out[(size_t)p * n + j] = rows[(size_t)p][(size_t)j];
+    return PDMPC_OK;
+}
+
+// ---- the explorative step (twin of pdmpc.explorative.build_exploration_batch / choose_solution / explore_step)
+// PrioritizedExplorativeController.m:25-91: the step's traffic state under n_perm prioritizations, one flattened batch: instance p
+// permutes the computation levels of the base prioritization (prepare_permutation :42-58: a vehicle of level L gets the position
+// of L in permutation p as its priority), slots ordered by (level, instance, slot).  Advances the time step like build_step.
+int pdmpc_controller_explore_build(pdmpc_controller* c, int32_t n_perm, uint32_t seed) {
+    if (!c || n_perm < 1) return cfail(c, PDMPC_ERR_INVALID, "bad argument");
+    int rc = pdmpc_controller_build_step(c);  // instance 0: the controller's own prioritization
+    if (rc) return rc;
+    const int n = c->n;
+    // base levels: kahn of the coupling directed by the constant priorities (vehicle index)
+    std::vector<uint8_t> d0((size_t)n * n, 0);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j)
+            if (at(c->adjacency, n, i, j) && !(j < i)) at(d0, n, i, j) = 1;
+    std::vector<int32_t> levels0;
+    if (!kahn(d0, n, levels0)) return cfail(c, PDMPC_ERR_INVALID, "coupling graph has a cycle");
+    const int n_levels = *std::max_element(levels0.begin(), levels0.end());
+    std::vector<int32_t> perms((size_t)n_perm * n_levels);
+    rc = pdmpc_exploration_permutations(n_levels, n_perm, seed, perms.data());
+    if (rc) return rc;
+    struct Part {
+        std::vector<pdmpc_vehicle_in> in;
+        std::vector<pdmpc_polygon_set> fb;
+        std::vector<int32_t> pred_offset, pred_index;
+    };
+    std::vector<Part> parts((size_t)n_perm);
+    c->inst.assign((size_t)n_perm, pdmpc_controller::Instance());
+    auto keep = [&](int p) {
+        parts[(size_t)p] = Part{c->in, c->fb, c->pred_offset, c->pred_index};
+        c->inst[(size_t)p] = pdmpc_controller::Instance{c->directed, c->directed_seq, c->levels, c->order, c->slot_of};
+    };
+    keep(0);
+    for (int p = 1; p < n_perm; ++p) {
+        std::vector<int32_t> where((size_t)n_levels + 1, 0);
+        for (int j = 0; j < n_levels; ++j) where[(size_t)perms[(size_t)p * n_levels + j]] = j + 1;
+        // Prioritizer.directed_coupling_from_priorities (Prioritizer.m:64-77): i -> j stays unless j has the smaller number
+        c->directed.assign((size_t)n * n, 0);
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j)
+                if (at(c->adjacency, n, i, j) && !(where[(size_t)levels0[j]] < where[(size_t)levels0[i]])) at(c->directed, n, i, j) = 1;
+        rc = assemble_step(c);
+        if (rc) return rc;
+        keep(p);
+    }
+    // flatten: (level, instance, slot)
+    struct Key {
+        int32_t level, p, s;
+    };
+    std::vector<Key> flat;
+    for (int p = 0; p < n_perm; ++p)
+        for (int s = 0; s < n; ++s) flat.push_back(Key{c->inst[(size_t)p].levels[(size_t)c->inst[(size_t)p].order[(size_t)s]], p, s});
+    std::stable_sort(flat.begin(), flat.end(), [](const Key& a, const Key& b) { return a.level < b.level; });  // (generated in (p, s) order)
+    const int N = n_perm * n;
+    std::vector<int32_t> slot_of((size_t)N);  // [p * n + s]
+    for (int i = 0; i < N; ++i) slot_of[(size_t)flat[(size_t)i].p * n + flat[(size_t)i].s] = i;
+    c->x_in.resize((size_t)N);
+    c->x_fb.resize((size_t)N);
+    c->x_pred_offset.assign((size_t)N + 1, 0);
+    c->x_pred_index.clear();
+    c->x_instance.resize((size_t)N);
+    c->x_vehicle.resize((size_t)N);
+    c->x_level.resize((size_t)N);
+    c->x_slot.assign((size_t)N, 0);
+    for (int i = 0; i < N; ++i) {
+        const Key& k = flat[(size_t)i];
+        const Part& P = parts[(size_t)k.p];
+        c->x_in[(size_t)i] = P.in[(size_t)k.s];
+        c->x_fb[(size_t)i] = P.fb[(size_t)k.s];
+        for (int32_t q = P.pred_offset[(size_t)k.s]; q < P.pred_offset[(size_t)k.s + 1]; ++q) c->x_pred_index.push_back(slot_of[(size_t)k.p * n + P.pred_index[(size_t)q]]);
+        c->x_pred_offset[(size_t)i + 1] = (int32_t)c->x_pred_index.size();
+        c->x_instance[(size_t)i] = k.p;
+        c->x_vehicle[(size_t)i] = c->inst[(size_t)k.p].order[(size_t)k.s];
+        c->x_level[(size_t)i] = k.level;
+        c->x_slot[(size_t)k.p * n + c->x_vehicle[(size_t)i]] = i;
+    }
+    c->x_pred_index.push_back(0);
+    // the controller's own problem again (instance 0)
+    c->in = parts[0].in;
+    c->fb = parts[0].fb;
+    c->pred_offset = parts[0].pred_offset;
+    c->pred_index = parts[0].pred_index;
+    const pdmpc_controller::Instance& I0 = c->inst[0];
+    c->directed = I0.directed;
+    c->directed_seq = I0.directed_seq;
+    c->levels = I0.levels;
+    c->order = I0.order;
+    c->slot_of = I0.slot_of;
+    return PDMPC_OK;
+}
+
+int pdmpc_controller_explore_problem(pdmpc_controller* c, int32_t* n_slots, const pdmpc_vehicle_in** in, const int32_t** pred_offset, const int32_t** pred_index,
+                                     const pdmpc_polygon_set** fallback, const int32_t** instance, const int32_t** vehicle, const int32_t** level) {
+    if (!c || c->x_in.empty()) return cfail(c, PDMPC_ERR_INVALID, "no exploration batch has been built");
+    if (n_slots) *n_slots = (int32_t)c->x_in.size();
+    if (in) *in = c->x_in.data();
+    if (pred_offset) *pred_offset = c->x_pred_offset.data();
+    if (pred_index) *pred_index = c->x_pred_index.data();
+    if (fallback) *fallback = c->x_fb.data();
+    if (instance) *instance = c->x_instance.data();
+    if (vehicle) *vehicle = c->x_vehicle.data();
+    if (level) *level = c->x_level.data();
+    return PDMPC_OK;
+}
+
+// compute_solution_cost / choose_solution (:94-176): per weakly connected sub-graph of the coupling graph the instance with the
+// smallest sum of the cost-to-come of the vehicles' final nodes after round(., 8); a vehicle whose search was exhausted makes its
+// instance infinitely expensive.  chosen[v] = instance of vehicle v's sub-graph; cost (may be NULL): n_perm x n_graphs, graphs
+// ordered by their smallest vehicle.  The chosen instances' couplings become the controller's (what apply's fallback handling sees).
+int pdmpc_controller_explore_choose(pdmpc_controller* c, const pdmpc_vehicle_out* recs, int32_t* chosen, int32_t* n_graphs, double* cost) {
+    if (!c || !recs || c->inst.empty()) return cfail(c, PDMPC_ERR_INVALID, "no exploration batch has been built");
+    const int n = c->n, Hp = c->Hp, K = (int)c->inst.size();
+    std::vector<int> label((size_t)n);
+    for (int i = 0; i < n; ++i) label[(size_t)i] = i;
+    auto find = [&](int a) {
+        while (label[(size_t)a] != a) a = label[(size_t)a] = label[(size_t)label[(size_t)a]];
+        return a;
+    };
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j)
+            if (at(c->adjacency, n, i, j) || at(c->adjacency, n, j, i)) {
+                const int a = find(i), b = find(j);
+                if (a != b) label[(size_t)std::max(a, b)] = std::min(a, b);
+            }
+    std::vector<int> graph_of((size_t)n), roots;
+    for (int i = 0; i < n; ++i)
+        if (find(i) == i) roots.push_back(i);  // ascending: the graphs ordered by their smallest vehicle
+    for (int i = 0; i < n; ++i) graph_of[(size_t)i] = (int)(std::lower_bound(roots.begin(), roots.end(), find(i)) - roots.begin());
+    const int G = (int)roots.size();
+    c->x_graphs = G;
+    c->x_cost.assign((size_t)K * G, 0.0);
+    const int N = K * n;
+    for (int s = 0; s < N; ++s) {  // (slot order: the order the twin adds in)
+        const pdmpc_vehicle_out& r = recs[s];
+        if (r.status != PDMPC_OK && r.status != PDMPC_EXHAUSTED) return cfail(c, PDMPC_ERR_HIP, "a result record carries an error status: not a planning result");
+        const double v = r.status == PDMPC_OK ? r.path_nodes[Hp][4] : std::numeric_limits<double>::infinity();
+        c->x_cost[(size_t)c->x_instance[(size_t)s] * G + graph_of[(size_t)c->x_vehicle[(size_t)s]]] += v;
+    }
+    for (double& v : c->x_cost) v = std::nearbyint(v * 1e8) / 1e8;
+    std::vector<int> best((size_t)G, 0);
+    for (int g = 0; g < G; ++g)
+        for (int p = 1; p < K; ++p)
+            if (c->x_cost[(size_t)p * G + g] < c->x_cost[(size_t)best[(size_t)g] * G + g]) best[(size_t)g] = p;  // [~, chosen] = min(.): the first minimum
+    c->x_chosen.resize((size_t)n);
+    for (int i = 0; i < n; ++i) c->x_chosen[(size_t)i] = best[(size_t)graph_of[(size_t)i]];
+    // obj.iter = obj.iter_array_tmp{chosen_solution} (:157-158): every vehicle goes on with the couplings of its sub-graph's choice
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            const pdmpc_controller::Instance& I = c->inst[(size_t)c->x_chosen[(size_t)i]];
+            at(c->directed, n, i, j) = at(I.directed, n, i, j);
+            at(c->directed_seq, n, i, j) = at(I.directed_seq, n, i, j);
+        }
+    if (chosen) std::copy(c->x_chosen.begin(), c->x_chosen.end(), chosen);
+    if (n_graphs) *n_graphs = G;
+    if (cost) std::copy(c->x_cost.begin(), c->x_cost.end(), cost);
+    return PDMPC_OK;
+}
+
+// One explorative time step: build the batch, plan all prioritizations with ONE launch, choose per sub-graph, apply the chosen plans.
+int pdmpc_controller_explore_step(pdmpc_controller* c, int32_t n_perm) {
+    if (!c || !c->h) return cfail(c, PDMPC_ERR_INVALID, "controller has no backend handle");
+    int rc = pdmpc_controller_explore_build(c, n_perm, (uint32_t)(c->k + 1));  // RandStream("mt19937ar", Seed = obj.k) (:249)
+    if (rc) return rc;
+    const int N = (int)c->x_in.size();
+    c->x_out.resize((size_t)N);
+    rc = pdmpc_plan_step(c->h, N, c->x_in.data(), c->x_pred_offset.data(), c->x_pred_index.data(), c->x_fb.data(), c->x_out.data());
+    if (rc) return cfail(c, rc, pdmpc_last_error());
+    rc = pdmpc_controller_explore_choose(c, c->x_out.data(), nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    c->out.resize((size_t)c->n);
+    for (int s = 0; s < c->n; ++s) {
+        const int v = c->order[(size_t)s];
+        c->out[(size_t)s] = c->x_out[(size_t)c->x_slot[(size_t)c->x_chosen[(size_t)v] * c->n + v]];
+    }
+    return pdmpc_controller_apply(c, c->out.data());
+}
+
+int pdmpc_controller_explore_run(pdmpc_controller* c, int32_t n_perm, int32_t n_steps, double* ms) {
+    for (int i = 0; i < n_steps; ++i) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = pdmpc_controller_explore_step(c, n_perm);
+        if (rc) return rc;
+        if (ms) ms[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return PDMPC_OK;
+}
+
+int pdmpc_controller_explore_result(pdmpc_controller* c, int32_t* chosen, int32_t* n_graphs, const double** cost, const pdmpc_vehicle_out** records) {
+    if (!c || c->x_chosen.empty()) return cfail(c, PDMPC_ERR_INVALID, "no explorative step has been chosen");
+    if (chosen) std::copy(c->x_chosen.begin(), c->x_chosen.end(), chosen);
+    if (n_graphs) *n_graphs = c->x_graphs;
+    if (cost) *cost = c->x_cost.data();
+    if (records) *records = c->x_out.empty() ? nullptr : c->x_out.data();
     return PDMPC_OK;
 }
 

@@ -62,6 +62,12 @@ EXPORTS = [
     "pdmpc_controller_records",
     "pdmpc_controller_last_error",
     "pdmpc_exploration_permutations",
+    "pdmpc_controller_explore_build",
+    "pdmpc_controller_explore_problem",
+    "pdmpc_controller_explore_choose",
+    "pdmpc_controller_explore_step",
+    "pdmpc_controller_explore_run",
+    "pdmpc_controller_explore_result",
     "pdmpc_last_error",
     "pdmpc_version",
 ]

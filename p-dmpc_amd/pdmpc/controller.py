@@ -339,7 +339,8 @@ class PrioritizedSequentialController:
         preds = [[slot_of[j] for j in range(self.n) if directed_seq[j, i]] for i in order]
         fallback = [self._published_on_exhaustion(i) for i in order]
         level_sizes = [int(np.sum(levels == l)) for l in range(1, int(levels.max()) + 1)]
-        return {"order": order, "iters": iters, "preds": preds, "fallback": fallback, "level_sizes": level_sizes, "levels": [int(levels[i]) for i in order]}
+        return {"order": order, "iters": iters, "preds": preds, "fallback": fallback, "level_sizes": level_sizes, "levels": [int(levels[i]) for i in order],
+                "directed_seq": np.array(directed_seq, dtype=np.int64)}
 
     def step(self, plan_step=None):
         """One pass of HighLevelController.main_control_loop (HighLevelController.m:334-373) in simulation.

@@ -125,6 +125,7 @@ def build_exploration_batch(ctl, n_perm, seed):
     out["level_sizes"] = [int(np.sum(lv == l)) for l in range(1, int(lv.max()) + 1)]
     out["n_instances"] = n_perm
     out["adjacency"] = np.array(ctl.last_adjacency)
+    out["directed_seq"] = [prob["directed_seq"] for prob in parts]  # per instance: what a vehicle that goes on with it inherits
     return out
 
 
@@ -144,3 +145,32 @@ def choose_solution(batch, records, Hp):
         cost[p, graphs.index(labels[v])] += c
     cost = np.round(cost, 8)
     return {g: int(np.argmin(cost[:, gi])) for gi, g in enumerate(graphs)}, cost
+
+
+def explore_step(ctl, plan_batch, n_perm):
+    """One explorative time step of the Python controller (PrioritizedExplorativeController.m:25-176; twin of
+    pdmpc_controller_explore_step): the step's prioritizations as one batch (seed = time step, :249), `plan_batch(batch)` -> records
+    in slot order, the choice per sub-graph, and every vehicle goes on with the plan and the couplings of its sub-graph's choice
+    (obj.info / obj.iter = ..._array_tmp{chosen_solution}, :157-158).  Returns (batch, records, chosen instance per vehicle)."""
+    from .iteration_data import info_from_record
+
+    Hp = ctl.options.Hp
+    kept = {}
+
+    def plan_step(prob):
+        batch = build_exploration_batch(ctl, n_perm, seed=ctl.k)
+        records = plan_batch(batch)
+        chosen_of_graph, _ = choose_solution(batch, records, Hp)
+        adj = batch["adjacency"]
+        labels = weak_components([[j for j in range(ctl.n) if adj[i, j] or adj[j, i]] for i in range(ctl.n)])
+        chosen = [chosen_of_graph[labels[v]] for v in range(ctl.n)]
+        slot = {(p, v): s for s, (p, v) in enumerate(zip(batch["instance"], batch["vehicle"]))}
+        seq = np.zeros_like(batch["directed_seq"][0])
+        for v in range(ctl.n):
+            seq[v, :] = batch["directed_seq"][chosen[v]][v, :]
+        ctl.last_directed_seq = seq
+        kept.update(batch=batch, records=records, chosen=chosen)
+        return [info_from_record(records[slot[(chosen[v], v)]], Hp) for v in prob["order"]]
+
+    ctl.step(plan_step=plan_step)
+    return kept["batch"], kept["records"], kept["chosen"]

@@ -57,6 +57,16 @@ def _declare(L):
     L.pdmpc_controller_records.argtypes = [H]
     L.pdmpc_controller_records.restype = C.POINTER(abi.VehicleOut)
     L.pdmpc_controller_last_error.restype = C.c_char_p
+    L.pdmpc_controller_explore_build.argtypes = [H, C.c_int32, C.c_uint32]
+    L.pdmpc_controller_explore_problem.argtypes = [H, C.POINTER(C.c_int32), C.POINTER(C.POINTER(abi.VehicleIn)), C.POINTER(abi.c_int32_p), C.POINTER(abi.c_int32_p),
+                                                   C.POINTER(C.POINTER(abi.PolygonSet)), C.POINTER(abi.c_int32_p), C.POINTER(abi.c_int32_p), C.POINTER(abi.c_int32_p)]
+    L.pdmpc_controller_explore_choose.argtypes = [H, C.POINTER(abi.VehicleOut), abi.c_int32_p, C.POINTER(C.c_int32), abi.c_double_p]
+    L.pdmpc_controller_explore_step.argtypes = [H, C.c_int32]
+    L.pdmpc_controller_explore_run.argtypes = [H, C.c_int32, C.c_int32, abi.c_double_p]
+    L.pdmpc_controller_explore_result.argtypes = [H, abi.c_int32_p, C.POINTER(C.c_int32), C.POINTER(abi.c_double_p), C.POINTER(C.POINTER(abi.VehicleOut))]
+    for name in ("pdmpc_controller_explore_build", "pdmpc_controller_explore_problem", "pdmpc_controller_explore_choose", "pdmpc_controller_explore_step",
+                 "pdmpc_controller_explore_run", "pdmpc_controller_explore_result"):
+        getattr(L, name).restype = C.c_int
     for name in ("pdmpc_controller_create", "pdmpc_controller_destroy", "pdmpc_controller_step", "pdmpc_controller_build_step", "pdmpc_controller_apply",
                  "pdmpc_controller_problem", "pdmpc_controller_state"):
         getattr(L, name).restype = C.c_int
@@ -175,16 +185,23 @@ class NativeController:
 
     def problem(self):
         """The last built step problem decoded into the dict form of controller.build_step_problem (for tests)."""
-        from .iteration_data import VehicleIter
-
         n = C.c_int32()
         vin = C.POINTER(abi.VehicleIn)()
         po, pi, order, levels = abi.c_int32_p(), abi.c_int32_p(), abi.c_int32_p(), abi.c_int32_p()
         fb = C.POINTER(abi.PolygonSet)()
         self._check(self.L.pdmpc_controller_problem(self.c, C.byref(n), C.byref(vin), C.byref(po), C.byref(pi), C.byref(fb), C.byref(order), C.byref(levels)), "pdmpc_controller_problem")
+        iters, preds, fallback = self._decode(n.value, vin, po, pi, fb)
+        order_l = [int(order[s]) for s in range(n.value)]
+        lv = [int(levels[v]) for v in range(n.value)]
+        level_sizes = [sum(1 for x in lv if x == l) for l in range(1, max(lv) + 1)]
+        return {"order": order_l, "iters": iters, "preds": preds, "fallback": fallback, "level_sizes": level_sizes, "levels": [lv[v] for v in order_l]}
+
+    def _decode(self, n, vin, po, pi, fb):
+        from .iteration_data import VehicleIter
+
         Hp = self.Hp
         iters, preds, fallback = [], [], []
-        for s in range(n.value):
+        for s in range(n):
             v = vin[s]
             dyn = _polys(v.dynamic_obstacles)
             left = np.array([[v.left_x[q] for q in range(v.n_left)], [v.left_y[q] for q in range(v.n_left)]]) if v.n_left else None
@@ -198,10 +215,51 @@ class NativeController:
             preds.append([int(pi[q]) for q in range(po[s], po[s + 1])])
             f = _polys(fb[s])
             fallback.append(f if f else None)
-        order_l = [int(order[s]) for s in range(n.value)]
-        lv = [int(levels[v]) for v in range(n.value)]
-        level_sizes = [sum(1 for x in lv if x == l) for l in range(1, max(lv) + 1)]
-        return {"order": order_l, "iters": iters, "preds": preds, "fallback": fallback, "level_sizes": level_sizes, "levels": [lv[v] for v in order_l]}
+        return iters, preds, fallback
+
+    # ---- the explorative step: twin of pdmpc.explorative
+    def explore_build(self, n_perm, seed):
+        self._check(self.L.pdmpc_controller_explore_build(self.c, n_perm, int(seed)), "pdmpc_controller_explore_build")
+        self.n_perm = n_perm
+
+    def explore_problem(self):
+        """The flattened batch of the last explore_build in the dict form of explorative.build_exploration_batch (for tests)."""
+        n = C.c_int32()
+        vin = C.POINTER(abi.VehicleIn)()
+        po, pi, inst, veh, lvl = (abi.c_int32_p() for _ in range(5))
+        fb = C.POINTER(abi.PolygonSet)()
+        self._check(self.L.pdmpc_controller_explore_problem(self.c, C.byref(n), C.byref(vin), C.byref(po), C.byref(pi), C.byref(fb), C.byref(inst), C.byref(veh), C.byref(lvl)),
+                    "pdmpc_controller_explore_problem")
+        iters, preds, fallback = self._decode(n.value, vin, po, pi, fb)
+        N = n.value
+        levels = [int(lvl[s]) for s in range(N)]
+        vehicles = [int(veh[s]) for s in range(N)]
+        return {"order": vehicles, "iters": iters, "preds": preds, "fallback": fallback, "levels": levels, "instance": [int(inst[s]) for s in range(N)], "vehicle": vehicles,
+                "level_sizes": [sum(1 for x in levels if x == l) for l in range(1, max(levels) + 1)], "n_instances": self.n_perm}
+
+    def explore_choose(self, records):
+        """-> (instance chosen per vehicle, cost table n_perm x n_graphs)."""
+        recs = np.ascontiguousarray(records)
+        chosen = np.zeros(self.n, dtype=np.int32)
+        g = C.c_int32()
+        cost = np.zeros(self.n_perm * self.n)
+        self._check(self.L.pdmpc_controller_explore_choose(self.c, abi.out_ptr(recs), chosen.ctypes.data_as(abi.c_int32_p), C.byref(g), cost.ctypes.data_as(abi.c_double_p)),
+                    "pdmpc_controller_explore_choose")
+        return chosen, cost[: self.n_perm * g.value].reshape(self.n_perm, g.value)
+
+    def explore_step(self, n_perm):
+        """One explorative time step natively (batch, ONE launch, choice, apply) -> (records of the batch, chosen instance per vehicle)."""
+        self._check(self.L.pdmpc_controller_explore_step(self.c, n_perm), "pdmpc_controller_explore_step")
+        chosen = np.zeros(self.n, dtype=np.int32)
+        p = C.POINTER(abi.VehicleOut)()
+        self._check(self.L.pdmpc_controller_explore_result(self.c, chosen.ctypes.data_as(abi.c_int32_p), None, None, C.byref(p)), "pdmpc_controller_explore_result")
+        recs = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(self.n * n_perm * abi.VEHICLE_OUT_DTYPE.itemsize,)).view(abi.VEHICLE_OUT_DTYPE).copy()
+        return recs, chosen
+
+    def explore_run(self, n_perm, n_steps):
+        ms = np.zeros(max(n_steps, 1))
+        self._check(self.L.pdmpc_controller_explore_run(self.c, n_perm, n_steps, ms.ctypes.data_as(abi.c_double_p)), "pdmpc_controller_explore_run")
+        return ms[:n_steps]
 
     def state(self):
         n = self.n

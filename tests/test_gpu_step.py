@@ -317,6 +317,44 @@ def test_native_controller_on_device_c3():
     native_closed_loop_on_device(options, sc, boundary_provider(sc), 8, priority_strategy="coloring")
 
 
+def test_native_explorative_step_on_device():
+    """SURVEY.md 8(f)-2 through the C ABI: pdmpc_controller_explore_step (the prioritizations of the step built and flattened in
+    C++, ONE launch, choice per sub-graph, apply of the chosen plans: the path behind bench.py --workload c5's
+    value_host_inclusive) next to pdmpc.explorative.explore_step planned by the oracle: records of every batch, the chosen
+    prioritization of every vehicle and the plant state after every step are identical."""
+    from oracle import oracle
+    from pdmpc.explorative import explore_step
+    from pdmpc.native_controller import NativeController
+    from pdmpc.optimizer import GraphSearchHip
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    K = 8
+    options = Config(scenario_type=ScenarioType.commonroad, amount=20, Hp=8, max_vehicles=20 * K, max_nodes=1 << 16)
+    sc = commonroad_scenario(options, seed=1)
+    mpa = get_mpa(options)
+    opt = GraphSearchHip(options)
+    opt._ensure_mpa(mpa)
+    nat = NativeController(options, sc, mpa, opt.handle, coupling="distance")
+    py = PrioritizedSequentialController(options, sc, mpa, None, coupling="distance", boundary_provider=boundary_provider(sc))
+    unbounded = copy.copy(options)
+    unbounded.max_nodes = 1 << 30
+    other = 0
+    for k in range(10):
+        gpu, chosen_nat = nat.explore_step(K)
+        _, ref, chosen = explore_step(py, lambda batch: oracle.plan_step(unbounded, mpa, batch, n_threads=os.cpu_count() or 1)[0], K)
+        assert_records_equal(gpu, ref, "explorative step %d" % (k + 1))
+        assert chosen_nat.tolist() == chosen, k
+        other += sum(1 for c in chosen if c != 0)
+        st = nat.state()
+        assert np.array_equal(st["x"], np.array([m.x for m in py.meas])) and np.array_equal(st["y"], np.array([m.y for m in py.meas])), k
+        assert np.array_equal(st["yaw"], np.array([m.yaw for m in py.meas])) and np.array_equal(st["speed"], np.array([m.speed for m in py.meas])), k
+    assert other > 0
+    ms = nat.explore_run(K, 3)
+    assert len(ms) == 3 and (ms > 0).all()
+    nat.close()
+    opt.handle.close()
+
+
 def test_literal_run_optimizer_loop_equals_the_single_launch():
     """pdmpc_plan_step_literal (one pdmpc_plan_batch of one vehicle per run_optimizer call, hand-over on the host: what an
     unmodified reference controller does with GraphSearchHip.m) against pdmpc_plan_step and the oracle over a closed loop."""

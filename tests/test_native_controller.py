@@ -93,3 +93,46 @@ def test_circle_full_coupling_with_exhaustion_and_fallbacks():
     options = Config(scenario_type=ScenarioType.circle, amount=4, Hp=5, max_nodes=1 << 20)
     # step 1: vehicle 3 (standing) exhausts -> standstill handling; step 4: vehicle 2 (moving) exhausts -> its fallback spreads
     run_both(options, circle_scenario(options), 6, "full", force_exhaustion=lambda k: {1: 2, 4: 1}.get(k))
+
+
+def test_explorative_step_native_twin():
+    """the native explorative step (pdmpc_controller_explore_*) against pdmpc.explorative — the flattened batch of
+    the step's prioritizations bit for bit, the choice per sub-graph and its cost table, and the closed loop that goes on with the
+    chosen plans and couplings (planner = the oracle, no GPU)."""
+    from oracle import oracle
+    from pdmpc.explorative import choose_solution, explore_step
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    options = Config(scenario_type=ScenarioType.commonroad, amount=14, Hp=5, max_nodes=1 << 30)
+    sc = commonroad_scenario(options, seed=5)
+    mpa = get_mpa(options)
+    K = 5
+    py = PrioritizedSequentialController(options, sc, mpa, None, coupling="distance", boundary_provider=boundary_provider(sc))
+    nat = NativeController(options, sc, mpa, None, coupling="distance")
+    differing = 0
+    for k in range(8):
+        nat.explore_build(K, seed=k + 1)
+        q = nat.explore_problem()
+        base_order = nat.problem()["order"]
+
+        def plan_batch(batch):
+            assert_same_problem(batch, q, "explorative step %d" % (k + 1))
+            assert batch["instance"] == q["instance"] and batch["vehicle"] == q["vehicle"]
+            recs, _ = oracle.plan_step(options, mpa, batch)
+            chosen_nat, cost_nat = nat.explore_choose(recs)
+            want, cost = choose_solution(batch, recs, options.Hp)
+            assert np.array_equal(cost_nat, cost)
+            slot = {(p, v): s for s, (p, v) in enumerate(zip(batch["instance"], batch["vehicle"]))}
+            nat.apply(recs[[slot[(int(chosen_nat[v]), v)] for v in base_order]])
+            plan_batch.chosen_nat = chosen_nat
+            return recs
+
+        _, _, chosen = explore_step(py, plan_batch, K)
+        assert chosen == plan_batch.chosen_nat.tolist()
+        differing += sum(1 for c in chosen if c != 0)
+        st = nat.state()
+        assert np.array_equal(st["x"], np.array([m.x for m in py.meas])) and np.array_equal(st["y"], np.array([m.y for m in py.meas])), k
+        assert np.array_equal(st["yaw"], np.array([m.yaw for m in py.meas])) and np.array_equal(st["speed"], np.array([m.speed for m in py.meas])), k
+        assert st["needs_fallback"].tolist() == [bool(i.needs_fallback) for i in py.infos], k
+    assert differing > 0, "the exploration never preferred another prioritization: the test would not notice a wrong choice"
+    nat.close()
