@@ -24,11 +24,15 @@
 /* Wavefronts per vehicle (workgroup size / 64), chosen per launch: wave 0 owns the pop order; block-min mode: wave 1 expands,
  * wave 2 scouts, the others validate; heap mode: all others pre-validate.  More validators shorten the critical vehicle's
  * search (C2: 5 -> 6.87 ms, 7 -> 6.67 ms, 13 -> 6.64 ms per step) but cost throughput when the chip is full (C5). */
-#define PDMPC_WAVES_LATENCY 16    /* launches with at most one workgroup per CU */
+#define PDMPC_WAVES_LATENCY 12    /* launches with at most one workgroup per CU */
 #define PDMPC_WAVES_CROWDED 12    /* launches with more workgroups than CUs: the build for six wavefronts per SIMD, two workgroups per CU
                                      (measured: C4, 512 workgroups: 26.3 steps/s against 23.8 with the regular build at 10 wavefronts and 20.2
                                      at 8; C5, 1280 workgroups: 216.7 against 198.3 with 10, 184.4 with 8, regular build 185 at 8) */
-#define PDMPC_MAX_WAVES 16
+/* Twelve wavefronts per workgroup = three per SIMD = 168 VGPRs per lane.  With sixteen (128 VGPRs) the frontier kernel spilled 44
+ * VGPRs next to ~320 SGPRs held in VGPR lanes; in that regime hipcc 7.2 produced code that lost spilled values depending on
+ * unrelated source changes.  At 168 the kernels spill 2-4 VGPRs, and no workload is slower (C2 753 -> 770
+ * steps/s, C3 680 -> 685, C4 and C5 unchanged: their launches ran twelve wavefronts before). */
+#define PDMPC_MAX_WAVES 12
 #define PDMPC_QUEUE_HEAP 0     /* open list = libstdc++-faithful binary heap (exact for any keys) */
 #define PDMPC_QUEUE_BLOCKMIN 1 /* open list = block-min queue while the minimal key is unique, binary heap after the first tie */
 #define PDMPC_MAX_THREADS (PDMPC_WAVE * PDMPC_MAX_WAVES)
