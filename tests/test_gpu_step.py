@@ -41,6 +41,9 @@ def run_closed_loop(options, scenario, coupling, boundary, n_steps, oracle_threa
 
     for _ in range(n_steps):
         ctl.step(plan_step=plan_step)
+    # pdmpc_plan_step plans a call again in resident slices when a search timed out waiting for a predecessor: the safety net must
+    # not be what makes these loops pass (a kernel that loses a publication now and then would hide behind it)
+    assert opt.handle.stats()["safe_replans"] == 0
     opt.handle.close()
     return ctl
 
@@ -191,6 +194,61 @@ def test_benchmarked_window_c4_steps_1_to_12():
     sc = commonroad_scenario(options, seed=1, tiles=26)
     ctl = run_closed_loop(options, sc, "distance", boundary_provider(sc), 12, oracle_threads=os.cpu_count() or 1, priority_strategy="coloring")
     assert int(ctl.last_levels.max()) >= 3
+
+
+def test_c4_resident_banks_replayed_without_the_safety_net():
+    """What bench.py --workload c4 does in its timed loop: recorded steps stay packed in HBM (one bank each) and are launched again
+    and again with pdmpc_launch_packed -- no re-plan on a predecessor time-out, no arena growth.  Every replay must end with the
+    recorded records and without a single error status (device-side counter), also for the heavy steps beyond the first dozen."""
+    from pdmpc.optimizer import GraphSearchHip
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    options = Config(scenario_type=ScenarioType.commonroad, amount=512, Hp=10, max_vehicles=512, max_nodes=1 << 16)  # (bench.py's initial arena: it grows)
+    sc = commonroad_scenario(options, seed=1, tiles=26)
+    mpa = get_mpa(options)
+    opt = GraphSearchHip(options)
+    opt._ensure_mpa(mpa)
+    h = opt.handle
+    ctl = PrioritizedSequentialController(options, sc, mpa, None, coupling="distance", boundary_provider=boundary_provider(sc), priority_strategy="coloring")
+    problems = []
+
+    def plan_step(prob):
+        problems.append(prob)
+        fb = [f if f is not None else [] for f in prob["fallback"]]
+        recs = h.plan_step(prob["iters"], prob["preds"], fb)
+        return [info_from_record(recs[i], options.Hp) for i in range(len(recs))]
+
+    for _ in range(12):
+        ctl.step(plan_step=plan_step)
+    assert h.stats()["safe_replans"] == 0
+    banks = problems[4:]  # (bench.py --workload c4: 4 steps skipped, 8 recorded)
+    recorded = []
+    h.allow_overflow = True
+    for b, prob in enumerate(banks):
+        h.select_bank(b)
+        fb = [f if f is not None else [] for f in prob["fallback"]]
+        h.pack_step(prob["iters"], prob["preds"], fb)
+        while True:  # (bench.py: pack_banks -- a bank recorded before the arenas grew replays in the grown arenas)
+            h.launch()
+            recs = h.fetch(len(prob["iters"]))
+            if not (recs["status"] == 2).any():
+                break
+            h.grow_arena(2 * h.arena_nodes()[0])
+        recorded.append(recs.copy())
+        assert ((recs["status"] == 0) | (recs["status"] == 1)).all()
+    h.allow_overflow = False
+    h.reset_stats()
+    for rep in range(5):
+        for b, prob in enumerate(banks):
+            h.select_bank(b)
+            h.launch()
+            h.synchronize()
+    assert h.stats()["bad_status_plans"] == 0
+    for b, prob in enumerate(banks):
+        h.select_bank(b)
+        h.launch()
+        assert_records_equal(h.fetch(len(prob["iters"])), recorded[b], "replay of bank %d" % b)
+    h.close()
 
 
 @pytest.mark.parametrize("n_instances", [12, 64])

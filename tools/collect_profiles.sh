@@ -28,6 +28,7 @@ if [ "${SQ:-1}" = "1" ]; then
 fi
 # only the summaries travel back (the raw traces can be large): counter CSVs of the frontier/helper kernels, stats, trace
 python tools/summarize_profiles.py r03_$W $S $OUT > $OUT/summary_stdout.txt 2>&1
+mkdir -p $OUT/profiles && cp profiles/r03_${W}_* profiles/r03_pmc_traffic_${W}.json $OUT/profiles/ 2>/dev/null  # (profiles/ of the box's copy does not travel back: gpurun_out/ does)
 find $OUT -name "*.csv" -size +2M -delete
 find $OUT -name "*.db" -delete
 du -sh $OUT | tail -1
