@@ -6,6 +6,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "p-dmpc_amd"), os.path.join(ROOT, "tests")]
 os.environ["PDMPC_DEBUG_TAIL"] = "1"
 import numpy as np
+if os.environ.get("DIAG_TORCH"):
+    import torch
+    torch.zeros(1, device="cuda")  # (bench.py runs with torch's CUDA context up: its own streams and allocations)
+    torch.cuda.synchronize()
 from pdmpc.config import Config, ScenarioType
 from pdmpc.controller import PrioritizedSequentialController
 from pdmpc.iteration_data import info_from_record
@@ -48,8 +52,8 @@ for rep in range(int(os.environ.get("DIAG_REPS", "12"))):
         bad = [s for s in range(len(recs)) if int(recs[s]["status"]) not in (0, 1)]
         for s in bad[:8]:
             t = np.asarray(recs[s]["path_nodes"])
-            print("BAD rep", rep, "bank", b, "slot", s, "level", prob["levels"][s], "preds", prob["preds"][s][:6], "status", int(recs[s]["status"]), "flags", hex(int(t[16][5])), "rounds", t[16][0], "nodes", t[16][2], flush=True)
+            print("BAD rep", rep, "bank", b, "slot", s, "level", prob["levels"][s], "preds", prob["preds"][s][:6], "status", int(recs[s]["status"]), "flags", hex(int(t[16][5])), "rounds", t[16][0], "nodes", t[16][2], "tail", [float(x) for x in t[16][:12]], flush=True)
         n_bad += len(bad)
         if bad and n_bad > 24:
             print("stopping", flush=True); os._exit(1)
-print("done; bad plans", n_bad, flush=True)
+print("done; bad plans", n_bad, "helper guard hits", h.stats().get("tie_fallbacks"), flush=True)
