@@ -86,6 +86,11 @@ struct pdmpc_controller {
     std::vector<std::vector<double>> dpool;
     std::vector<std::vector<int32_t>> ipool;
     std::vector<pdmpc_vehicle_out> out;
+    // sets that do not depend on the prioritization are built once per time step and shared by the prioritizations of an explorative step
+    std::vector<pdmpc_polygon_set> fb_of;
+    std::vector<uint8_t> fb_done;
+    pdmpc_polygon_set empty_set{};
+    bool empty_done = false;
     // explorative step (PrioritizedExplorativeController): the prioritizations of the current traffic state, flattened
     struct Instance {
         std::vector<uint8_t> directed, directed_seq;
@@ -657,6 +662,9 @@ int pdmpc_controller_build_step(pdmpc_controller* c) {
     c->infos.assign(n, Plan());
     c->dpool.clear();
     c->ipool.clear();
+    c->fb_of.assign(n, pdmpc_polygon_set());
+    c->fb_done.assign(n, 0);
+    c->empty_done = false;
     // ---- traffic info
     c->trims.assign(n, 0);
     c->occ_offset.assign(n, Poly());
@@ -739,15 +747,18 @@ int assemble_step(pdmpc_controller* c) {
         I.left_y = c->bnd_left[i].y.data();
         I.right_x = c->bnd_right[i].x.data();
         I.right_y = c->bnd_right[i].y.data();
-        SetBuilder obst, dyn, hdv;
+        SetBuilder obst, dyn;
+        auto add_shifted = [](SetBuilder& b, const std::vector<Poly>& shapes) {  // del_first_rpt_last without the temporary
+            for (size_t q = 1; q < shapes.size(); ++q) b.add(shapes[q]);
+            b.add(shapes.back());
+        };
         for (const Poly& o : c->static_obstacles) obst.add(o);
         // consider_predecessors (:449-506): sequential ones are handed over on the device; the others contribute their
         // previous plan shifted by one step (parallel_coupling_previous_trajectory, :409-447)
         for (int j = 0; j < n; ++j) {
             if (!at(c->directed, n, j, i)) continue;
             if (at(c->directed_seq, n, j, i)) continue;
-            if (c->info_old[j].present && c->k > 1)
-                for (const Poly& p : del_first_rpt_last(c->info_old[j].shapes)) dyn.add(p);
+            if (c->info_old[j].present && c->k > 1) add_shifted(dyn, c->info_old[j].shapes);
         }
         // consider_successors (:508-566)
         for (int j = 0; j < n; ++j) {
@@ -755,27 +766,35 @@ int assemble_step(pdmpc_controller* c) {
             if (c->cfg.constraint_from_successor == PDMPC_SUCCESSOR_AREA_OF_STANDSTILL) {
                 if (std::fabs(c->mspeed[j]) < 0.01) obst.add(c->occ_offset[j]);  // :536-540
             } else if (c->cfg.constraint_from_successor == PDMPC_SUCCESSOR_AREA_OF_PREVIOUS_TRAJECTORY) {
-                if (c->info_old[j].present)
-                    for (const Poly& p : del_first_rpt_last(c->info_old[j].shapes)) dyn.add(p);
+                if (c->info_old[j].present) add_shifted(dyn, c->info_old[j].shapes);
             }
         }
         I.obstacles = obst.finish(*c);
         I.dynamic_obstacles = dyn.finish(*c);
-        I.hdv_reachable_sets = hdv.finish(*c);
+        if (!c->empty_done) {
+            SetBuilder none;
+            c->empty_set = none.finish(*c);
+            c->empty_done = true;
+        }
+        I.hdv_reachable_sets = c->empty_set;
         // sequential predecessors as slots
         for (int j = 0; j < n; ++j)
             if (at(c->directed_seq, n, j, i)) c->pred_index.push_back(c->slot_of[j]);
         c->pred_offset[s + 1] = (int32_t)c->pred_index.size();
         // what the vehicle publishes if its search is exhausted: its standstill rectangle (:602-611) or the previous plan
         // shifted by one step (:678-718)
-        SetBuilder fbs;
-        const bool standstill = c->trim_speed[c->trims[i] - 1] == 0;
-        if (standstill && c->cfg.constraint_from_successor != PDMPC_SUCCESSOR_NONE) {
-            for (int q = 0; q < Hp; ++q) fbs.add(c->occ_plain[i]);
-        } else if (c->info_old[i].present) {
-            for (const Poly& p : del_first_rpt_last(c->info_old[i].shapes)) fbs.add(p);
+        if (!c->fb_done[i]) {  // (a function of the vehicle alone: shared by the prioritizations of an explorative step)
+            SetBuilder fbs;
+            const bool standstill = c->trim_speed[c->trims[i] - 1] == 0;
+            if (standstill && c->cfg.constraint_from_successor != PDMPC_SUCCESSOR_NONE) {
+                for (int q = 0; q < Hp; ++q) fbs.add(c->occ_plain[i]);
+            } else if (c->info_old[i].present) {
+                add_shifted(fbs, c->info_old[i].shapes);
+            }
+            c->fb_of[i] = fbs.finish(*c);
+            c->fb_done[i] = 1;
         }
-        c->fb[s] = fbs.finish(*c);
+        c->fb[s] = c->fb_of[i];
     }
     c->pred_index.push_back(0);
     return PDMPC_OK;
