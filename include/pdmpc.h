@@ -155,7 +155,7 @@ typedef struct {
     int64_t speculation_wasted_pops; /* nodes popped by searches that were then restarted (block-min mode; same period) */
     int64_t entries_dropped;         /* open-list entries known to collide that left the list without being popped (same period) ... */
     int64_t dropped_counted_as_pops; /* ... and how many of them the reference would have popped: they are part of nodes_popped */
-    int64_t kernel;                  /* kernel of the last launch: 1 frontier (all wavefronts process open nodes side by side), 0 pop-ordered */
+    int64_t kernel;                  /* kernel of the last launch: 2 bulk (bulk-synchronous rounds), 1 frontier (one node per wavefront), 0 pop-ordered */
     int64_t nodes_processed;         /* frontier kernel: nodes whose edge was evaluated (same period; the reference pops nodes_popped of them,
                                         the rest is what the parallel rounds overshoot) */
     int64_t rounds;                  /* frontier kernel: rounds (select a batch of the smallest open keys, process it) */

@@ -154,6 +154,9 @@ struct Tuning {
     int help_expand = 1;        // PDMPC_HELP_EXPAND
     int help_patience = 8;      // PDMPC_HELP_PATIENCE
     int help_expand_oversub = -1;  // PDMPC_HELP_EXPAND_OVERSUB (-1: up to two searches per CU)
+    int bk_round0 = 24;         // PDMPC_BK_ROUND0: nodes a round of a young search takes (bulk kernel)
+    int bk_round = 256;         // PDMPC_BK_ROUND: the most a round takes (bulk kernel)
+    int bk_ramp = 4;            // PDMPC_BK_RAMP: a round grows by 1 / bk_ramp of the nodes processed so far
     int fr_slice = -1;          // PDMPC_FR_SLICE (-1: only after a predecessor time-out, 0: never, 1: always when oversubscribed)
     int debug_host = 0;         // PDMPC_DEBUG_HOST
     int slot_order_reverse = 0; // PDMPC_TEST_REVERSE_DISPATCH: testing only, see launch_range
@@ -204,7 +207,14 @@ struct pdmpc_handle {
     DevBuf<double> d_random;  // sampled optimizer: random numbers of the batch
     int sampled_n_random = 0;
     bool sampled_launch = false;
-    int kernel_frontier = 1;  // 1: frontier kernel (all wavefronts work on open nodes side by side), 0: the pop-ordered kernel of round 1
+    int kernel_frontier = 1;  // 1: round-based kernels (open nodes processed side by side, the reference's order reconstructed), 0: the pop-ordered kernel of round 1
+    int kernel_bulk = 1;      // 1: of the round-based kernels the bulk one (bulk_kernel.hip) where it applies (InterX checker), 0: the frontier kernel
+    bool force_frontier = false;  // this launch: the frontier kernel, which carries the binary heap (a search of the bulk kernel met a tie)
+    bool last_launch_bulk = false;
+    int last_first = 0, last_count = 0;  // slots of the last launch_range
+    uint32_t bulk_lds_hw[2] = {0, 0};    // dynamic LDS size set so far on the bulk kernel's variants (hipFuncSetAttribute is a maximum)
+    int bk_ready_cap = 1024;
+    int64_t tie_replans = 0;  // launches planned again with the heap-carrying kernel because a search of the bulk kernel met a tie
     int fr_round = 0, fr_near_fill = 2048, fr_near_max = 4096;  // measured on C2 / C3 (round cap 768): 1024/2048 -> 358 / 345 steps/s, 2048/4096 -> 369 / 357, 4096/8192 -> 356 / 351
     bool last_launch_frontier = false;
     uint32_t* progress = nullptr;  // pinned, PDMPC_DEBUG_PROGRESS=1
@@ -287,6 +297,89 @@ bool layout_frontier(pdmpc_handle* h, size_t budget, int n_waves, int areas, int
     return L.total <= budget;
 }
 
+// LDS layout of the bulk kernel: MPA tables, reference, per-wave tallies, shared words, obstacle soup, phase B's chunk state (12 B per
+// thread), d_traveled table, the LDS part of the open set (PDMPC_BK_PER entries per thread), the ready list with its collision
+// flags, the histogram / goal list / expansion lists, 1 KB of small tables, validity bytes, then as many node records as fit.
+bool layout_bulk(pdmpc_handle* h, size_t budget, int n_waves, int areas, int soup_cap, LdsLayout& L, uint32_t& nv, uint32_t& nl, uint32_t ready_cap) {
+    const uint32_t threads = (uint32_t)n_waves * PDMPC_WAVE;
+    uint32_t off = 0;
+    L.mask = off;
+    off = align16(off + (uint32_t)h->mask_bytes);
+    L.man_index = off;
+    off = align16(off + (uint32_t)h->mi_bytes);
+    L.pose = off;
+    off = align16(off + (uint32_t)(h->n_man * sizeof(DevManPose)));
+    L.area = off;
+    if (areas) off = align16(off + (uint32_t)(h->n_man * 3 * PDMPC_VMAX * 16));
+    L.ref = off;
+    off += 3 * PDMPC_HP_MAX * 8;
+    L.shape = off;
+    off += (uint32_t)n_waves * (2 * PDMPC_VMAX + 1) * 16;
+    L.path = off;
+    off += align16((PDMPC_HP_MAX + 2) * 4 + 2 * (PDMPC_HP_MAX + 1) * 4 + PDMPC_SH_WORDS * 4 + PDMPC_HP_MAX * 4);
+    L.soup = off;
+    off = align16(off + (uint32_t)std::max(soup_cap, 1) * 16);
+    L.cand = off;
+    off += align16(12u * threads);
+    L.expand = off;
+    off += (2 * PDMPC_HP_MAX * PDMPC_HP_MAX) * 8 + 16 * 16;
+    L.bk_near_key = off;
+    off += align16(PDMPC_BK_PER * threads * 8u);
+    L.bk_near_id = off;
+    off += align16(PDMPC_BK_PER * threads * 4u);
+    L.bk_ready = off;
+    off += align16(ready_cap * 8u);
+    L.bk_hist = off;
+    off += 3072u * 4u;
+    L.bk_misc = off;
+    off += 1024u;
+    L.heap_key = L.bk_hist;  // (the prologue derives pointers from these; the bulk kernel never follows them)
+    L.heap_id = L.bk_hist;
+    L.stage = L.bk_hist;
+    const uint32_t min_nodes = 64 * (uint32_t)sizeof(NodeRec) + 1024;
+    if ((size_t)off + min_nodes + 256 > budget) return false;
+    const uint32_t rest = (uint32_t)(budget - off - 256);
+    nv = std::min<uint32_t>(16384u, std::max<uint32_t>(1024u, rest / 6));
+    nv = std::min(nv, h->max_nodes) & ~15u;
+    nl = std::min((rest - nv) / (uint32_t)sizeof(NodeRec), h->max_nodes);
+    L.vstate = off;
+    off += align16(nv);
+    L.nodes = off;
+    off += nl * (uint32_t)sizeof(NodeRec);
+    L.total = align16(off);
+    return L.total <= budget;
+}
+
+bool use_bulk(const pdmpc_handle* h) {
+    return h->kernel_frontier && h->kernel_bulk && !h->force_frontier && !h->sampled_launch && h->cfg.checker == PDMPC_CHECK_INTERX;
+}
+
+int compute_lds_bulk(pdmpc_handle* h, int n_launch, int soup_cap) {
+    for (int areas = 1; areas >= 0; --areas) {
+        LdsLayout L{};
+        uint32_t nv = 0, nl = 0;
+        if (!layout_bulk(h, kLdsMax, h->waves_latency, areas, soup_cap, L, nv, nl, (uint32_t)h->bk_ready_cap)) continue;
+        if (h->tune.debug_lds)
+            fprintf(stderr, "pdmpc LDS layout (bulk): launch %d waves %d areas %d near %u ready %d nv %u nl %u total %u\n", n_launch, h->waves_latency, areas,
+                    PDMPC_BK_PER * (uint32_t)h->waves_latency * PDMPC_WAVE, h->bk_ready_cap, nv, nl, L.total);
+        h->lds = L;
+        h->n_waves = h->waves_latency;
+        h->HL = 0;
+        h->NL = (int)nl;
+        h->NV = (int)nv;
+        h->areas_in_lds = areas;
+        h->bm_kr = 0;
+        h->bm_nb = 64;
+        h->fr_cand_cap = 0;
+        h->fr_stage_cap = 0;
+        h->two_per_cu = 0;
+        return PDMPC_OK;
+    }
+    char buf[256];
+    snprintf(buf, sizeof buf, "obstacle soup (%d columns) + MPA tables do not fit into %zu B of LDS", soup_cap, kLdsMax);
+    return fail(PDMPC_ERR_CAPACITY, buf);
+}
+
 int compute_lds_frontier(pdmpc_handle* h, int n_launch, int soup_cap, int cand_cap) {
     // More workgroups than CUs: two workgroups of waves_crowded wavefronts per CU (80 KB each) if the problem fits, with the
     // maneuver areas read through L2 if need be; otherwise one workgroup per CU with the whole LDS.
@@ -327,6 +420,7 @@ int compute_lds_frontier(pdmpc_handle* h, int n_launch, int soup_cap, int cand_c
 }
 
 int compute_lds(pdmpc_handle* h, int n_launch, int soup_cap_in, int cand_cap_in) {
+    if (use_bulk(h)) return compute_lds_bulk(h, n_launch, soup_cap_in);
     if (h->kernel_frontier && !h->sampled_launch) return compute_lds_frontier(h, n_launch, soup_cap_in, cand_cap_in);
     h->two_per_cu = n_launch > h->n_cu ? 1 : 0;
     const int Hp = h->cfg.Hp;
@@ -684,12 +778,18 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     a.NL = h->NL;
     a.NV = h->NV;
     const bool frontier = h->kernel_frontier && !h->sampled_launch;
+    const bool bulk = use_bulk(h);
+    a.bulk = bulk ? 1 : 0;
+    a.bk_ready_cap = h->bk_ready_cap;
+    a.bk_round0 = std::max(1, T.bk_round0);
+    a.bk_round = std::min(h->bk_ready_cap / 2, std::max(a.bk_round0, T.bk_round));
     a.soup_cap = B.soup_cap;
     a.cand_cap = frontier ? h->fr_cand_cap : B.cand_cap;
     a.frontier = frontier ? 1 : 0;
     a.fr_round = h->fr_round > 0 ? h->fr_round : 768;  // cap of a round; measured on C2 / C3 (with the early-exit InterX): 256 -> 342 / 322 steps/s, 512 -> 355 / 342, 768 -> 358 / 345, 1024 -> 358 / 345
     a.fr_stage_cap = h->fr_stage_cap;
-    a.fr_ramp = T.fr_ramp > 0 ? T.fr_ramp : 4;  // a round grows by a quarter of the nodes done so far; measured on C2 / C3 (cap 768): 2 -> 331 / 354 steps/s, 3 -> 354 / 352, 4 -> 358 / 345, 6 -> 355 / 338
+    if (bulk) a.fr_ramp = std::max(1, T.bk_ramp);
+    else a.fr_ramp = T.fr_ramp > 0 ? T.fr_ramp : 4;  // a round grows by a quarter of the nodes done so far; measured on C2 / C3 (cap 768): 2 -> 331 / 354 steps/s, 3 -> 354 / 352, 4 -> 358 / 345, 6 -> 355 / 338
     a.fr_near_fill = h->fr_near_fill;
     a.fr_near_max = h->fr_near_max;
     a.fr_join_scale = T.fr_join_scale;  // measured on C2 / C3 / C5: 1 -> 419 / 396 / 347 steps/s, 4 -> 434 / 396 / 353, 8 -> 434 / 397 / 345, 32 -> 429 / 394 / 344
@@ -743,7 +843,7 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     a.fr_share_min = T.fr_share_min;
     a.fr_own_div = T.fr_own_div;
     a.help_chunk = T.help_chunk;  // (0: chosen below, once it is known whether the helpers expand)
-    if (frontier && !h->sampled_launch && h->cfg.checker == PDMPC_CHECK_INTERX && h->speculate && !slice) {
+    if (frontier && !bulk && !h->sampled_launch && h->cfg.checker == PDMPC_CHECK_INTERX && h->speculate && !slice) {
         // (measured on C2, 20 searches, / C3, 128: 8 helpers 535 / 476 steps/s, 16: 529 / 506, 32: 516 / 522, 128: 507 / 483)
         int want = std::min(h->helpers_max, std::max(32, count / 2));  // (helpers that expand: the owner of a shared round waits for them, more of them with shorter runs finish sooner)
         if (T.helpers >= 0) want = T.helpers;  // A/B switch (0: none): results are identical
@@ -769,7 +869,7 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     // steps/s); up to two searches per CU the tail of the launch is long enough for expanding helpers to pay (C4: 42.1 -> 46)
     const bool expand_oversub = T.help_expand_oversub >= 0 ? T.help_expand_oversub != 0 : count <= 2 * h->n_cu;
     if (h->n_words != 1 || h->fr_stage_cap < 128 || (count > h->n_cu && !expand_oversub)) a.help_expand = 0;  // (the helper kernel expands one successor-mask word per node; a run's records sit in its staging area)
-    if (a.help_expand && a.n_helpers > 0 && count <= h->n_cu) {
+    if (!bulk && a.help_expand && a.n_helpers > 0 && count <= h->n_cu) {
         // helpers take the bulk of a large round off the owner, so rounds may grow faster and larger (measured on C2 / C3 with expanding
         // helpers: ramp 4, cap 768 -> 629 / 616 steps/s; 3, 768 -> 673 / 651; 2, 768 -> 680 / 662; 2, 1024 -> 686 / 656; 1, 1024 -> 632 / 604)
         if (T.fr_ramp <= 0) a.fr_ramp = 2;
@@ -792,17 +892,23 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     auto& ev = h->events[h->events_used++];
     HIPCHK(hipEventRecord(ev.first, h->stream));
     h->last_launch_frontier = frontier;
+    h->last_launch_bulk = bulk;
+    h->last_first = first;
+    h->last_count = count;
+    auto launch_round_based = [&](const KernelArgs* ka, int cnt) {
+        return bulk ? pdmpc_launch_bulk(ka, cnt, (void*)h->stream, h->bulk_lds_hw) : pdmpc_launch_frontier(ka, cnt, (void*)h->stream);
+    };
     int lrc = 0;
     if (slice) {
         for (int done = 0; done < count && lrc == 0; done += h->n_cu) {
             KernelArgs part = a;
             part.first = first + done;
             part.n_searches = std::min(h->n_cu, count - done);
-            lrc = pdmpc_launch_frontier(&part, part.n_searches, (void*)h->stream);
+            lrc = launch_round_based(&part, part.n_searches);
         }
     } else {
         lrc = h->sampled_launch ? pdmpc_launch_sampled(&a, count, (void*)h->stream)
-                                : (frontier ? pdmpc_launch_frontier(&a, count, (void*)h->stream) : pdmpc_launch_search(&a, count, (void*)h->stream));
+                                : (frontier ? launch_round_based(&a, count) : pdmpc_launch_search(&a, count, (void*)h->stream));
     }
     if (lrc != 0) {
         char buf[256];
@@ -865,7 +971,13 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
         if (getenv("PDMPC_WAVES")) h->waves_latency = h->waves_crowded = std::min(PDMPC_MAX_WAVES, std::max(4, env_i("PDMPC_WAVES", 16)));
         if (getenv("PDMPC_VALIDATORS")) h->n_validators = std::max(1, env_i("PDMPC_VALIDATORS", 1));
         h->speculate_expansion = env_i("PDMPC_SPEC_EXPAND", 1) != 0;
-        if (const char* e = getenv("PDMPC_KERNEL")) h->kernel_frontier = std::string(e) != "serial";
+        if (const char* e = getenv("PDMPC_KERNEL")) {  // A/B switch: bulk (default) | frontier | serial
+            h->kernel_frontier = std::string(e) != "serial";
+            h->kernel_bulk = std::string(e) != "frontier";
+        }
+        T.bk_round0 = std::max(1, env_i("PDMPC_BK_ROUND0", T.bk_round0));
+        T.bk_round = std::max(1, env_i("PDMPC_BK_ROUND", T.bk_round));
+        T.bk_ramp = std::max(1, env_i("PDMPC_BK_RAMP", T.bk_ramp));
         if (getenv("PDMPC_FR_ROUND")) h->fr_round = std::max(1, env_i("PDMPC_FR_ROUND", 0));
         if (getenv("PDMPC_FR_NEAR_FILL")) h->fr_near_fill = std::max(64, env_i("PDMPC_FR_NEAR_FILL", 0));
         if (getenv("PDMPC_FR_NEAR_MAX")) h->fr_near_max = std::max(256, env_i("PDMPC_FR_NEAR_MAX", 0));
@@ -1112,6 +1224,24 @@ int pdmpc_fetch_results(pdmpc_handle* h, int32_t n, pdmpc_vehicle_out* out) {
     if (permuted && n != B.n_packed) return fail(PDMPC_ERR_INVALID, "a batch that pdmpc_pack_step put into level order is fetched as a whole");
     if (n > 0) HIPCHK(hipMemcpyAsync(out, h->d_out.p, (size_t)n * sizeof(pdmpc_vehicle_out), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->last_launch_bulk) {
+        // A search of the bulk kernel that meets equal keys where the pop order depends on the layout of the reference's binary heap
+        // (priority_queue_interface_mex.cpp:19-31) ends with an internal status: the slots of that launch are planned again by the
+        // frontier kernel, which redoes such a search on the libstdc++-faithful heap.  Same epoch (results of other launches of the
+        // step stay valid), done flags of the range cleared first.
+        bool tie = false;
+        for (int i = 0; i < n; ++i) tie = tie || out[i].status == PDMPC_INTERNAL_TIE;
+        if (tie) {
+            h->tie_replans += 1;
+            HIPCHK(hipMemsetAsync(h->d_flag.p + h->last_first, 0, (size_t)h->last_count * sizeof(uint32_t), h->stream));
+            h->force_frontier = true;
+            const int rc = launch_range(h, h->last_first, h->last_count);
+            h->force_frontier = false;
+            if (rc) return rc;
+            HIPCHK(hipMemcpyAsync(out, h->d_out.p, (size_t)n * sizeof(pdmpc_vehicle_out), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+        }
+    }
     // counters + SURVEY.md 8(d) algorithmic bytes of one pass over the packed batch
     pdmpc_stats& s = h->stats;
     const int Hp = h->cfg.Hp;
@@ -1400,7 +1530,7 @@ int pdmpc_get_last_stats(pdmpc_handle* h, pdmpc_stats* stats) {
     HIPCHK(hipMemcpy(work, h->d_work_count.p, sizeof work, hipMemcpyDeviceToHost));
     h->stats.edge_checks = (int64_t)work[0];
     h->stats.segment_pair_tests = (int64_t)work[1];
-    h->stats.kernel = h->last_launch_frontier ? 1 : 0;
+    h->stats.kernel = h->last_launch_bulk ? 2 : (h->last_launch_frontier ? 1 : 0);
     h->stats.entries_dropped = h->last_launch_frontier ? 0 : (int64_t)work[2];
     h->stats.dropped_counted_as_pops = h->last_launch_frontier ? 0 : (int64_t)work[3];
     h->stats.nodes_processed = h->last_launch_frontier ? (int64_t)work[2] : 0;

@@ -1,0 +1,932 @@
+// bulk_kernel.hip — the optimal graph search as bulk-synchronous passes over a round of open nodes.
+//
+// Same closed form of the reference's pop order as frontier_kernel.hip (GraphSearch.m:53-107; see the header of that file and
+// DESIGN.md section 3.2): any processing order gives the reference's result as long as every generated node that comes before
+// the goal G has been evaluated in the end; ids, n_popped and the tree size are counted afterwards (phase B).  What differs is
+// how a round is executed.  The frontier kernel hands one node to one wavefront, which walks the node's dependent chain of LDS
+// round trips alone (ticket, records, shape, three 64-segment passes with a ballot each, sincos, reservation, cost terms,
+// reductions, list appends: 8 000-16 000 cycles per node whatever the arithmetic).  Here a round is a handful of passes in which
+// every LANE has an item of its own and no lane talks to another one until the barrier that ends the pass:
+//
+//   P1  check      item = (ready node, chunk of S obstacle segments): eval_edge_exact (GraphSearch.m:111-196) with InterX
+//                  (InterX.m:63-76, are_constraints_satisfied_interx.m:17-37) restricted to the chunk; a hit sets the node's flag;
+//                  chunk-major order, so later chunks of a node that already collides are skipped (the reference's early out).
+//                  S is chosen per round so that the items fill the workgroup: a young search spreads ONE node's ~130 segments
+//                  over 130 lanes, a round of a thousand nodes runs 16 segments per lane.
+//       + sincos   item = ready node: cos / sin of its yaw (expand_node.m:50-51) into its record, next to the checks
+//   P2  verdicts   item = ready node: validity byte, goal candidates (GraphSearch.m:81-90), children counts; one workgroup scan
+//                  hands out the children's node indices (Tree.m:61: the children of a node are consecutive, ascending trim)
+//   P3  expand     item = (collision-free node, successor slot): expand_node.m:18-90 — pose, cost-to-come, cost-to-go summed in the
+//                  reference's order by the lane itself —, record, key, link, open-list entry
+//   P4  boundary   goal candidates resolved, predecessors that finished meanwhile folded in (PrioritizedController.m:476-491),
+//                  termination test, phase B when done, else selection of the next round: the smallest keys of `near`
+//
+// The open set: `near` lives in LDS (keys + nodes, unordered, up to BK_PER entries per thread so that a selection pass holds it
+// in registers), `far` in HBM takes what near cannot hold (frontier_kernel.hip's scheme, one level up the memory hierarchy).
+// Arithmetic, operation order and -ffp-contract=off are those of the other kernels: every record is bit-identical to the oracle's.
+// Equal keys where the order matters: the search ends with the internal status PDMPC_INTERNAL_TIE and the host plans the call
+// again with the kernel that carries the libstdc++-faithful heap (api.cpp) — no tie in any BASELINE road-network workload.
+#include <hip/hip_runtime.h>
+
+#include "serial_search.hpp"
+
+#include "frontier_common.hpp"
+
+// shared words of the bulk kernel (aliases of words the frontier kernel uses for things this kernel does not have)
+#define BK_R FR_RD_TAIL          // entries of the ready list (this round)
+#define BK_PER PDMPC_BK_PER       // near entries per thread a selection pass holds in registers (near capacity = BK_PER * blockDim)
+
+namespace {
+
+typedef volatile LDS_AS unsigned long long lds_vu64;
+
+// exclusive prefix of v over the threads of the workgroup (thread order), total to every thread.  Every thread calls; two barriers.
+__device__ __forceinline__ unsigned long long wg_scan_excl(unsigned long long v, lds_vu64* wsum, int lane, int wave, int n_waves, unsigned long long& total) {
+    unsigned long long inc = v;
+#pragma unroll
+    for (int o = 1; o < PDMPC_WAVE; o <<= 1) {
+        const unsigned long long t = __shfl_up(inc, o);
+        inc += lane >= o ? t : 0ull;
+    }
+    if (lane == PDMPC_WAVE - 1) wsum[wave] = inc;
+    __syncthreads();
+    unsigned long long off = 0, tot = 0;
+    for (int q = 0; q < n_waves; ++q) {
+        const unsigned long long w = wsum[q];
+        off += q < wave ? w : 0ull;
+        tot += w;
+    }
+    __syncthreads();
+    total = tot;
+    return off + inc - v;
+}
+
+// piece q (16 bytes) of node i0's record: LDS copy if it has one
+__device__ __forceinline__ d2 node_piece(const Search& S, uint32_t i0, int q) {
+    if (i0 < S.NL) return S.ln[4 * (size_t)i0 + q];
+    return ((const d2*)(S.gn + i0))[q];
+}
+__device__ __forceinline__ void piece_link(d2 p3, uint32_t& parent, uint32_t& packed) {
+    const uint64_t u = (uint64_t)__double_as_longlong(p3.y);
+    parent = (uint32_t)(u & 0xffffffffull);
+    packed = (uint32_t)(u >> 32);
+}
+
+// What a check item reads.  The same for the owner of a search and for a workgroup that helps it.
+struct BkCheck {
+    const lds_d2* l_area;
+    const d2* g_area;
+    const lds_d2* l_soup;
+    const lds_i32* l_soff;
+    const lds_i32* l_hoff;
+    int areas_in_lds, ll_base, ll_len, Hp;
+};
+
+// P1, the check items of ready[0 .. R): item = c * R + r (chunk-major), chunk c = S = 1 << ls consecutive segments of one of the
+// node's three soups (vehicle obstacles of its step and HDV sets against the area, lanelet boundary against the boundary-check
+// area: are_constraints_satisfied_interx.m:17-37).  chmax = chunks of the step with the most segments.  Lanes work alone.
+__device__ __forceinline__ void bk_check_items(const Search& S, const BkCheck& C, const lds_u32* ready, volatile lds_u32* r_flag, uint32_t R, int ls, uint32_t chmax, int tid, int nthreads) {
+    const uint32_t items = R * chmax;
+    const int Sg = 1 << ls;
+    for (uint32_t item = (uint32_t)tid; item < items; item += (uint32_t)nthreads) {
+        const uint32_t c = item / R, r = item - c * R;
+        if (r_flag[r] & 1u) continue;  // collides already: the reference's early out
+        const uint32_t i0 = ready[r] - 1u;
+        uint32_t parent, packed;
+        piece_link(node_piece(S, i0, 3), parent, packed);
+        if (!parent) continue;  // the root has no edge (GraphSearch.m:137-139)
+        const int k = NODE_K(packed), m = NODE_MAN(packed), ncols = NODE_COLS(packed);
+        const int so = C.l_soff[k - 1], ho = C.l_hoff[k - 1];
+        const int M_k = C.l_soff[k] - so, Hk = C.l_hoff[k] - ho;
+        const int n0 = M_k > 1 ? M_k - 1 : 0, n1 = Hk > 1 ? Hk - 1 : 0, n2 = C.ll_len > 1 ? C.ll_len - 1 : 0;
+        const uint32_t c0 = (uint32_t)((n0 + Sg - 1) >> ls), c1 = (uint32_t)((n1 + Sg - 1) >> ls), c2 = (uint32_t)((n2 + Sg - 1) >> ls);
+        int base, t0, left, which = 0;
+        if (c < c0) {
+            base = so;
+            t0 = (int)(c << ls);
+            left = n0 - t0;
+        } else if (c < c0 + c1) {
+            base = ho;
+            t0 = (int)((c - c0) << ls);
+            left = n1 - t0;
+        } else if (c < c0 + c1 + c2) {
+            base = C.ll_base;
+            t0 = (int)((c - c0 - c1) << ls);
+            left = n2 - t0;
+            which = k == C.Hp ? 2 : 1;  // large offset at k == Hp, else without offset (GraphSearch.m:161-174)
+        } else {
+            continue;
+        }
+        const int tn = left < Sg ? left : Sg;
+        const d2 pxy = node_piece(S, parent - 1u, 0), pcs = node_piece(S, parent - 1u, 2);
+        const double cc = pcs.x, ss = pcs.y, pX = pxy.x, pY = pxy.y;
+        const size_t abase = ((size_t)m * 3 + (size_t)which) * PDMPC_VMAX;
+        d2 pt[PDMPC_VMAX];
+#pragma unroll
+        for (int i = 0; i < PDMPC_VMAX; ++i) {  // (columns beyond ncols are padding: transformed, never used)
+            const d2 a = C.areas_in_lds ? (d2)C.l_area[abase + i] : C.g_area[abase + i];
+            pt[i].x = cc * a.x - ss * a.y + pX;  // GraphSearch.m:158 / :162 / :168
+            pt[i].y = ss * a.x + cc * a.y + pY;  // :159 / :163 / :169
+        }
+        const lds_d2* q = C.l_soup + base + t0;
+        d2 q0 = q[0];
+        bool hit = false;
+        for (int t = 0; t < tn; ++t) {
+            const d2 q1 = q[t + 1];
+            hit = hit || interx_segment_n<PDMPC_VMAX>(pt, ncols - 1, q0, q1);
+            q0 = q1;
+        }
+        if (hit) r_flag[r] = 1u;
+    }
+}
+
+// position of the rk-th set bit of mask (rk < popcount)
+__device__ __forceinline__ int nth_bit(uint64_t mask, int rk) {
+    for (int b = 0; b < rk; ++b) mask &= mask - 1ull;
+    return (int)__builtin_ctzll(mask);
+}
+
+// The search.  Returns true (to every thread) if a tie was met: the host plans the call again with the heap-carrying kernel.
+template <int NW>
+__device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32* ref_ids) {
+    const int tid = X.tid, lane = X.lane, wave = X.wave, slot = X.slot, Hp = X.Hp;
+    volatile lds_u32* sh = X.l_shared;
+    Search& S = X.S;
+    const VState& VS = X.VS;
+    const SpecCtx& P = X.P;
+    const DevVehicle* __restrict__ V = X.V;
+    const int n_waves = (int)(blockDim.x >> 6), bd = (int)blockDim.x;
+    const double inf = __longlong_as_double(0x7FF0000000000000LL);
+    const size_t voff = (size_t)slot * A.max_nodes;
+    const int n = X.n, nw = NW > 0 ? NW : X.nw;
+    const uint32_t OC = (uint32_t)(BK_PER * bd), RC = (uint32_t)A.bk_ready_cap;
+
+    // ---- LDS carve of the bulk region
+    lds_f64* near_key = (lds_f64*)(X.lsm + A.lds.bk_near_key);
+    lds_u32* near_id = (lds_u32*)(X.lsm + A.lds.bk_near_id);
+    lds_u32* ready = (lds_u32*)(X.lsm + A.lds.bk_ready);
+    volatile lds_u32* r_flag = (volatile lds_u32*)(ready + RC);
+    lds_u32* hist = (lds_u32*)(X.lsm + A.lds.bk_hist);      // [3072]: histogram [2048] | goal list [1024], vlist [1024], voff [1024]
+    lds_u32* vlist = hist + 1024;
+    lds_u32* voffs = hist + 2048;
+    lds_u32* gp_path = (lds_u32*)(X.lsm + A.lds.bk_misc);    // [32] path of the best goal candidate
+    lds_f64* gp_mp = (lds_f64*)(gp_path + 32);                // [HP_MAX + 1] largest key of that path below depth d
+    lds_vu64* wsum64 = (lds_vu64*)(gp_mp + 32);                // [32] scan partials
+    volatile lds_u32* wsum = (volatile lds_u32*)(wsum64 + 32); // [32] fr_partition's per-wave counts
+    lds_u32* chm = (lds_u32*)(wsum + 32);                      // [8] chunks per node for S = 1, 2, 4, 8, 16, ...; [7] = most segments of a step
+
+    Frontier F;
+    F.sh = sh;
+    F.ready = ready;
+    F.hist = hist;
+    F.goal_list = hist;
+    F.near_key = A.arena.near_key + voff;  // (HBM arrays: phase B's per-node state; near itself lives in LDS)
+    F.near_id = A.arena.near_id + voff;
+    F.far_key = A.arena.pop_log + voff;
+    F.far_id = A.arena.heap_id + voff;
+    F.gkey = S.gkey;
+    F.glink = A.arena.link + voff;
+    F.n_waves = n_waves;
+
+    ExpandEnv EE;
+    EE.l_mask = X.l_mask;
+    EE.l_mi = X.l_mi;
+    EE.l_pose = X.l_pose;
+    EE.l_rx = X.l_rx;
+    EE.l_ry = X.l_ry;
+    EE.l_dcum = X.l_dcum;
+    EE.l_term = nullptr;
+    EE.l_chxy = nullptr;
+    EE.Hp = Hp;
+    EE.n = X.n;
+    EE.nw = X.nw;
+    EE.lane = lane;
+
+    BkCheck CK;
+    CK.l_area = X.C.l_area;
+    CK.g_area = X.C.g_area;
+    CK.l_soup = X.C.l_soup;
+    CK.l_soff = X.C.l_soff;
+    CK.l_hoff = X.C.l_hoff;
+    CK.areas_in_lds = X.C.areas_in_lds;
+    CK.ll_base = X.C.ll_base;
+    CK.ll_len = X.C.ll_len;
+    CK.Hp = Hp;
+
+    // ---- root node (GraphSearch.m:34-46) and the chunk tables
+    if (tid == 0) {
+        NodeRec r;
+        r.x = V->x0;
+        r.y = V->y0;
+        r.yaw = V->yaw0;
+        r.g = 0.0;
+        r.cs = 0.0;
+        r.sn = 0.0;
+        r.h = 0.0;
+        r.parent = 0;
+        r.packed = (uint32_t)V->trim0;
+        node_store(S, 0, r);
+        F.gkey[0] = 0.0;
+        F.glink[0] = (unsigned long long)r.parent | ((unsigned long long)r.packed << 32);
+        vs_store(VS, 0, VS_UNKNOWN);
+        for (int w = 26; w < SH_WORDS; ++w) sh[w] = 0;
+        sh[FR_NNODES] = 1;
+        sh[BK_R] = 1;
+        sh_st_d(sh, FR_NEAR_MIN, inf);
+        sh_st_d(sh, FR_FAR_MIN, inf);
+        sh_st_d(sh, FR_L_FAR, inf);
+        sh[SH_NNODES] = 1;
+        if (A.debug_tail == 2) sh[FR_EVER_INVAL] = 1;  // (debugging: exercise the ancestor check without arrivals)
+        ready[0] = 1u;
+        r_flag[0] = 0u;
+    }
+    if (tid >= 64 && tid < 72) {
+        const int ls = tid - 64;
+        uint32_t mx = 0, mseg = 0;
+        for (int k = 1; k <= Hp; ++k) {
+            const int M_k = CK.l_soff[k] - CK.l_soff[k - 1], Hk = CK.l_hoff[k] - CK.l_hoff[k - 1];
+            const int n0 = M_k > 1 ? M_k - 1 : 0, n1 = Hk > 1 ? Hk - 1 : 0, n2 = CK.ll_len > 1 ? CK.ll_len - 1 : 0;
+            const int Sg = 1 << ls;
+            const uint32_t ch = (uint32_t)(((n0 + Sg - 1) >> ls) + ((n1 + Sg - 1) >> ls) + ((n2 + Sg - 1) >> ls));
+            mx = ch > mx ? ch : mx;
+            mseg = (uint32_t)(n0 + n1 + n2) > mseg ? (uint32_t)(n0 + n1 + n2) : mseg;
+        }
+        if (ls < 7)
+            chm[ls] = mx;
+        else
+            chm[7] = mseg;
+    }
+    __syncthreads();
+
+    int status = PDMPC_OK;
+    bool dep_timeout = X.dep_timeout;
+    uint32_t goal = 0;
+    uint32_t idle_polls = 0;
+    unsigned long long t_checks = 0, t_pairs = 0;  // this thread's share of the work counters
+    unsigned long long tk_work = 0, tk_arrival = 0, tk_select = 0, tk_wait = 0, tk_mark = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long tk_start = tk_mark;
+#define BK_TICK(acc)                                                       \
+    {                                                                      \
+        const unsigned long long now__ = __builtin_amdgcn_s_memrealtime(); \
+        acc += now__ - tk_mark;                                            \
+        tk_mark = now__;                                                   \
+    }
+    double far_mn = inf, far_mx = 0.0, near_mn = inf, near_mx = 0.0;
+    // appends (k, i) of the lanes with `take` to far (whole wave calls, straight-line)
+    auto to_far = [&](bool take, double k, uint32_t i) {
+        const unsigned long long b = __ballot(take);
+        if (b) {
+            const uint32_t base = sh_add_uniform(sh, FR_FAR_N, (uint32_t)__builtin_popcountll(b), lane);
+            if (take) {
+                const uint32_t pos = base + lane_rank(b, lane);
+                F.far_key[pos] = k;
+                F.far_id[pos] = i;
+                far_mn = k < far_mn ? k : far_mn;
+                far_mx = k > far_mx ? k : far_mx;
+            }
+        }
+    };
+    auto flush_far = [&]() {
+        sh_minmax_wave(sh, FR_FAR_MIN, FR_FAR_MAX, far_mn, far_mx, lane);
+        far_mn = inf;
+        far_mx = 0.0;
+    };
+    // appends (k, i) of the lanes with `take` to near (LDS; the caller has made sure there is room)
+    auto to_near = [&](bool take, double k, uint32_t i) {
+        const unsigned long long b = __ballot(take);
+        if (b) {
+            const uint32_t base = sh_add_uniform(sh, FR_NEAR_N, (uint32_t)__builtin_popcountll(b), lane);
+            if (take) {
+                const uint32_t pos = base + lane_rank(b, lane);
+                near_key[pos] = k;
+                near_id[pos] = i;
+                near_mn = k < near_mn ? k : near_mn;
+                near_mx = k > near_mx ? k : near_mx;
+            }
+        }
+    };
+    auto flush_near = [&]() {
+        sh_minmax_wave(sh, FR_NEAR_MIN, FR_NEAR_MAX, near_mn, near_mx, lane);
+        near_mn = inf;
+        near_mx = 0.0;
+    };
+    PhaseB R;
+    R.n_popped = 0;
+    R.n_expanded = 0;
+    bool pb_valid = false;
+
+    for (;;) {
+        // ================= a round =================
+        const uint32_t Rn = sh[BK_R];
+        if (Rn) {
+            pb_valid = false;  // (the tree grows: phase B's result is stale)
+            // ---- P1: check items + sincos items
+            int ls = 0;
+            while (ls < 6 && Rn * chm[ls] > (uint32_t)bd) ++ls;  // the smallest chunk with which the items fit the workgroup once
+            if (ls > 4) ls = 4;                                   // (at most 16 segments per item: large rounds take several trips)
+            bk_check_items(S, CK, ready, r_flag, Rn, ls, chm[ls], tid, bd);
+            for (uint32_t r = (uint32_t)(bd - 1 - tid); r < Rn; r += (uint32_t)bd) {  // (from the last thread down: the first waves carry the first chunks)
+                const uint32_t i0 = ready[r] - 1u;
+                uint32_t parent, packed;
+                piece_link(node_piece(S, i0, 3), parent, packed);
+                if (NODE_K(packed) < Hp) {
+                    const d2 p1 = node_piece(S, i0, 1);
+                    double sn, cs;
+                    pdmpc_sincos(p1.x, &sn, &cs);  // expand_node.m:50-51
+                    node_store_cs(S, i0, cs, sn);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+
+            // ---- P2: verdicts, goal candidates, children counts; node indices by a scan (two ready entries per thread)
+            bool ex[2];
+            uint32_t cnt[2], rr[2];
+            unsigned long long mine = 0;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const uint32_t r = (uint32_t)tid + (uint32_t)s * (uint32_t)bd;
+                const bool in = r < Rn;
+                rr[s] = r;
+                ex[s] = false;
+                cnt[s] = 0;
+                if (in) {
+                    const uint32_t id = ready[r], i0 = id - 1u;
+                    const bool valid = !(r_flag[r] & 1u);
+                    uint32_t parent, packed;
+                    piece_link(node_piece(S, i0, 3), parent, packed);
+                    const int k = NODE_K(packed);
+                    vs_store(VS, i0, valid ? VS_VALID : VS_INVALID);
+                    if (parent) {  // the pairs the reference's InterX forms for this edge (InterX.m:63-76): (V - 1) x (M - 1) per soup
+                        const int M_k = CK.l_soff[k] - CK.l_soff[k - 1], Hk = CK.l_hoff[k] - CK.l_hoff[k - 1];
+                        t_checks += 1;
+                        t_pairs += (unsigned long long)(NODE_COLS(packed) - 1) * (unsigned long long)((M_k > 1 ? M_k - 1 : 0) + (Hk > 1 ? Hk - 1 : 0) + (CK.ll_len > 1 ? CK.ll_len - 1 : 0));
+                    }
+                    if (valid && k == Hp) {
+                        // a goal candidate if its ancestors are all collision-free still: the largest key of its path goes into its
+                        // record (the cos / sin slot, which a node at the horizon never needs), the best one is chosen at the boundary
+                        double b1;
+                        const bool alive = fr_goal_path(S, VS, F.gkey, id, b1);
+                        if (alive) {
+                            node_store_cs(S, i0, b1, 0.0);
+                            const uint32_t pos = sh_add(sh, FR_GOAL_N, 1u);
+                            if (pos < 1024u) F.goal_list[pos] = id;
+                        }
+                    } else if (valid) {
+                        const lds_mask64* mrow = EE.l_mask + ((size_t)k * n + (NODE_TRIM(packed) - 1)) * nw;
+                        uint32_t c = 0;
+                        for (int w = 0; w < nw; ++w) c += (uint32_t)__builtin_popcountll(mrow[w]);
+                        ex[s] = true;
+                        cnt[s] = c;
+                    }
+                }
+                mine += (ex[s] ? 1ull : 0ull) | ((unsigned long long)cnt[s] << 32);
+            }
+            unsigned long long tot = 0;
+            const unsigned long long base = wg_scan_excl(mine, wsum64, lane, wave, n_waves, tot);
+            {
+                uint32_t v = (uint32_t)(base & 0xffffffffull), c = (uint32_t)(base >> 32);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    if (ex[s]) {
+                        vlist[v] = rr[s];
+                        voffs[v] = c;
+                        v += 1u;
+                        c += cnt[s];
+                    }
+                }
+            }
+            const uint32_t NVr = (uint32_t)(tot & 0xffffffffull), NC = (uint32_t)(tot >> 32);
+            const uint32_t nn_base = sh[FR_NNODES];
+            const bool overflow = nn_base + NC > S.max_nodes;
+            const bool all_far = sh[FR_NEAR_N] + NC > OC;  // near cannot take this round's children: they wait in far
+            __syncthreads();  // (vlist / voffs written; FR_NNODES read by everybody)
+            if (tid == 0) {
+                sh[FR_NNODES] = nn_base + (overflow ? 0u : NC);
+                sh[FR_PROCESSED] = sh[FR_PROCESSED] + Rn;
+                if (overflow) sh[FR_FLAGS] = sh[FR_FLAGS] | FRF_OVERFLOW;
+            }
+
+            // ---- P3: expansion items (collision-free node, successor slot): expand_node.m:18-90
+            if (!overflow) {
+                const uint32_t SL = 16u * (uint32_t)nw, items = NVr * SL;
+                const double l_far = all_far ? -1.0 : sh_ld_d(sh, FR_L_FAR);
+                for (uint32_t b0 = 0; b0 < items; b0 += (uint32_t)bd) {  // (uniform trip count: wave-wide appends inside)
+                    const uint32_t item = b0 + (uint32_t)tid;
+                    const bool in = item < items;
+                    const uint32_t v = in ? item / SL : 0u, j = in ? item - v * SL : 0u;
+                    const uint32_t r = vlist[v], id = ready[r], i0 = id - 1u;
+                    NodeBits cu;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) cu.q[q] = node_piece(S, i0, q);
+                    const NodeRec& cn = cu.r;
+                    const int cTrim = NODE_TRIM(cn.packed), cK = NODE_K(cn.packed);
+                    const int k_exp = cK + 1;            // expand_node.m:13
+                    const int steps_to_go = Hp - k_exp;  // :37
+                    const lds_mask64* mrow = EE.l_mask + ((size_t)cK * n + (cTrim - 1)) * nw;
+                    const int w = (int)(j >> 4), rk = (int)(j & 15u);
+                    const uint64_t mask = mrow[w];
+                    const bool active = in && rk < __builtin_popcountll(mask);
+                    uint32_t before = 0;
+                    for (int q = 0; q < w; ++q) before += (uint32_t)__builtin_popcountll(mrow[q]);
+                    double f = 0.0;
+                    uint32_t ci = 0;
+                    if (active) {
+                        const int t2 = w * 64 + nth_bit(mask, rk);  // 0-based successor trim (ascending: expand_node.m:18)
+                        const int m = (int)EE.l_mi[(cTrim - 1) * n + t2];
+                        const double dx = EE.l_pose[m].dx, dy = EE.l_pose[m].dy, dyaw = EE.l_pose[m].dyaw;
+                        const int ncols = EE.l_pose[m].n_cols;
+                        NodeRec ch;
+                        ch.x = cn.cs * dx - cn.sn * dy + cn.x;  // :53
+                        ch.y = cn.sn * dx + cn.cs * dy + cn.y;  // :54
+                        ch.yaw = cn.yaw + dyaw;                 // :55
+                        ch.cs = 0.0;
+                        ch.sn = 0.0;
+                        ch.parent = id;
+                        ch.packed = (uint32_t)(t2 + 1) | ((uint32_t)k_exp << 10) | ((uint32_t)m << 15) | ((uint32_t)ncols << 27);
+                        // cost-to-come (:57-61) and cost-to-go (:66-73), summed in the reference's order
+                        {
+                            const double ddx = ch.x - EE.l_rx[k_exp - 1], ddy = ch.y - EE.l_ry[k_exp - 1];
+                            const double nrm = sqrt(ddx * ddx + ddy * ddy);
+                            ch.g = cn.g + nrm * nrm;  // :61
+                        }
+                        double expH = 0.0;
+                        for (int it = 1; it <= steps_to_go; ++it) {
+                            const double ddx = ch.x - EE.l_rx[k_exp - 1 + it], ddy = ch.y - EE.l_ry[k_exp - 1 + it];
+                            const double nrm = sqrt(ddx * ddx + ddy * ddy);
+                            const double df = nrm - EE.l_dcum[(k_exp - 1) * PDMPC_HP_MAX + (it - 1)];
+                            const double m0 = (df > 0) ? df : 0.0;
+                            expH = expH + m0 * m0;
+                        }
+                        ch.h = expH;
+                        f = ch.g * 1 + expH * 1;  // GraphSearch.m:100-102
+                        ci = nn_base + voffs[v] + before + (uint32_t)rk;  // 0-based index of the child (Tree.add_nodes, Tree.m:61)
+                        node_store(S, ci, ch);
+                        vs_store(VS, ci, 0);  // validity unknown
+                        F.gkey[ci] = f;
+                        F.glink[ci] = (unsigned long long)ch.parent | ((unsigned long long)ch.packed << 32);
+                    }
+                    to_near(active && !(f > l_far), f, ci + 1u);
+                    to_far(active && f > l_far, f, ci + 1u);
+                }
+                flush_near();
+                flush_far();
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                sh[BK_R] = 0;
+                sh_add(sh, FR_ROUNDS, 1u);
+            }
+            __syncthreads();
+        }
+        BK_TICK(tk_work)
+        fr_resolve_goals(F, S, tid, lane, wave);
+
+        // ================= round boundary (every thread; decisions are uniform) =====================================
+        uint32_t flags = sh[FR_FLAGS];
+        if (flags & FRF_OVERFLOW) {
+            status = PDMPC_ARENA_OVERFLOW;
+            break;
+        }
+        if ((flags & FRF_BUG) || sh[FR_ROUNDS] > A.spin_limit) {  // watchdog: reported as an error status
+            dep_timeout = true;
+            status = PDMPC_EXHAUSTED;
+            break;
+        }
+        // predecessors that finished meanwhile: their areas enter the soup, collision-free edges are re-checked
+        if (wave == 0) (void)poll_predecessors(A, P, sh, lane);
+        __syncthreads();
+        if (sh[SH_STATE] == ST_ARRIVED) {
+            const unsigned long long arr = sh_load64(sh, SH_ARR_LO);
+            uint32_t nn = sh[FR_NNODES];
+            nn = nn < S.max_nodes ? nn : S.max_nodes;
+            incorporate_areas(P, arr, tid);
+            __syncthreads();
+            // Only collision-free nodes can lose their edge: gathered first so that the check runs on full wavefronts.
+            for (uint32_t base0 = 0; base0 < nn; base0 += FR_NBINS) {  // (uniform trip counts: barriers inside)
+                const uint32_t end = base0 + FR_NBINS < nn ? base0 + FR_NBINS : nn;
+                if (tid == 0) sh[FR_VLIST_N] = 0;
+                __syncthreads();
+                for (uint32_t b = base0; b < end; b += (uint32_t)bd) {
+                    const uint32_t i0 = b + (uint32_t)tid;
+                    const bool v = i0 < end && vs_load(VS, i0 < end ? i0 : 0u) == VS_VALID;
+                    const unsigned long long bal = __ballot(v);
+                    if (bal) {
+                        const uint32_t pos0 = sh_add_uniform(sh, FR_VLIST_N, (uint32_t)__builtin_popcountll(bal), lane);
+                        if (v) hist[pos0 + lane_rank(bal, lane)] = i0;
+                    }
+                }
+                __syncthreads();
+                const uint32_t nv = sh[FR_VLIST_N];
+                for (uint32_t e = (uint32_t)tid; e < nv; e += (uint32_t)bd) {
+                    const uint32_t i0 = hist[e];
+                    if (fr_node_hits_areas(S, X.C, P, i0, arr)) {
+                        vs_store(VS, i0, VS_INVALID);
+                        atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_INVALIDATED);
+                    }
+                }
+                __syncthreads();
+            }
+            flags = sh[FR_FLAGS];
+            const bool reopen = (flags & FRF_INVALIDATED) && sh[FR_DROPPED] != 0u;
+            if (flags & FRF_INVALIDATED) pb_valid = false;
+            __syncthreads();
+            if (tid == 0) {
+                atomicAdd(P.counters + 2, 1);
+                const unsigned long long pend = sh_load64(sh, SH_PEND_LO) & ~arr;
+                sh[SH_PEND_LO] = (uint32_t)pend;
+                sh[SH_PEND_HI] = (uint32_t)(pend >> 32);
+                sh[SH_ARR_LO] = 0;
+                sh[SH_ARR_HI] = 0;
+                sh[SH_STATE] = ST_RUN;
+                if (flags & FRF_INVALIDATED) {
+                    sh[FR_EVER_INVAL] = 1;
+                    sh[FR_BEST_ID] = 0;  // the best candidate may have lost an ancestor: look at all of them again
+                    sh[FR_PATH_FOR] = 0;
+                    sh[FR_FLAGS] = flags & ~FRF_INVALIDATED;
+                }
+                if (reopen) {
+                    // open entries were dropped because they come after a candidate that may be gone now: rebuild the open set
+                    // from the tree (every generated node that was never evaluated is open)
+                    sh[FR_NEAR_N] = 0;
+                    sh[FR_FAR_N] = 0;
+                    sh[FR_DROPPED] = 0;
+                    sh_st_d(sh, FR_NEAR_MIN, inf);
+                    sh_st_d(sh, FR_NEAR_MAX, 0.0);
+                    sh_st_d(sh, FR_FAR_MIN, inf);
+                    sh_st_d(sh, FR_FAR_MAX, 0.0);
+                    sh_st_d(sh, FR_L_FAR, -1.0);  // (everything goes to far until the next refill)
+                }
+            }
+            __syncthreads();
+            if (flags & FRF_INVALIDATED) {
+                for (uint32_t base = 0; base < nn; base += (uint32_t)bd) {  // (uniform trip count: barriers inside)
+                    const uint32_t b = base + (uint32_t)wave * PDMPC_WAVE;
+                    const uint32_t i0 = b + (uint32_t)lane;
+                    const bool in = i0 < nn;
+                    const uint32_t j0 = in ? i0 : 0u;  // (straight-line code: every lane loads something valid)
+                    const uint32_t vst = vs_load(VS, j0);
+                    const uint32_t par = node_parent(S, j0);
+                    const bool cand = in && vst == VS_VALID && NODE_K(((const uint32_t*)(S.gn + j0))[15]) == Hp;
+                    const bool open = reopen && in && vst == VS_UNKNOWN && par != 0u && vs_load(VS, par ? par - 1u : 0u) == VS_VALID;
+                    if (reopen) to_far(open, F.gkey[j0], j0 + 1u);
+                    unsigned long long bc = __ballot(cand);
+                    while (bc) {
+                        const int l = __builtin_ctzll(bc);
+                        bc &= bc - 1;
+                        fr_offer_goal(F, S, VS, b + (uint32_t)l + 1u, lane);
+                    }
+                    __syncthreads();  // at most blockDim candidates per pass: the list cannot overflow
+                    fr_resolve_goals(F, S, tid, lane, wave);
+                }
+                flush_far();
+                __syncthreads();
+            }
+            flags = sh[FR_FLAGS];
+        }
+        if (flags & FRF_TIE) return true;
+        BK_TICK(tk_arrival)
+
+        // the relevance tables follow the best goal candidate
+        const uint32_t best = sh[FR_BEST_ID];
+        if (best && sh[FR_PATH_FOR] != best) {
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t nd = best;
+                double m = -1.0;
+                for (int d = Hp; d >= 0; --d) {
+                    gp_path[d] = nd;
+                    gp_mp[d] = m;  // largest key of the path below depth d
+                    const double k = F.gkey[nd - 1];
+                    m = k > m ? k : m;
+                    nd = node_parent(S, nd - 1);
+                }
+                sh[FR_PATH_FOR] = best;
+            }
+            __syncthreads();
+        }
+
+        // are we done?  Open entries above the candidate's path maximum come after it; the others are looked at one by one when a
+        // round selects them.  An empty open set without a candidate is exhaustion (GraphSearch.m:57-61).
+        const uint32_t near_n = sh[FR_NEAR_N], far_n = sh[FR_FAR_N];
+        const double near_min = near_n ? sh_ld_d(sh, FR_NEAR_MIN) : inf, far_min = far_n ? sh_ld_d(sh, FR_FAR_MIN) : inf;
+        const double open_min = near_min < far_min ? near_min : far_min;
+        const double bb = best ? sh_ld_d(sh, FR_BEST_B1) : inf;
+        bool done = false;
+        if (best) {
+            if (bb == open_min) return true;  // a tie between an open node and a node of the best path
+            done = bb < open_min;
+        } else {
+            done = near_n == 0u && far_n == 0u;
+        }
+        if (done) {
+            // Phase B right away, also when predecessors are still planning: an arrival that invalidates nothing leaves the tree,
+            // hence the counts and ids, as they are, and the result goes out as soon as the last predecessor has been looked at.
+            if (!pb_valid && !dep_timeout) {
+                __syncthreads();
+                R = fr_phase_b<NW>(A, X, F, EE, best, ref_ids, (LDS_AS unsigned char*)(X.lsm + A.lds.cand), F.near_key, F.near_id, gp_path);
+                pb_valid = true;
+                const uint32_t pflags = sh[FR_FLAGS];
+                __syncthreads();
+                if (pflags & FRF_TIE) return true;
+                if (pflags & FRF_BUG) dep_timeout = true;  // reported as an error status: must never happen
+            }
+            if (sh_load64(sh, SH_PEND_LO) == 0ull || dep_timeout) {
+                goal = best;
+                status = best ? PDMPC_OK : PDMPC_EXHAUSTED;
+                break;
+            }
+            // finished, but predecessors that are still planning may yet invalidate what we found
+            __builtin_amdgcn_s_sleep(8);
+            if (++idle_polls > A.spin_limit) dep_timeout = true;  // a predecessor never finished: give up on it (reported as an error status)
+            BK_TICK(tk_wait)
+            continue;
+        }
+
+        // ---- near is empty (or holds nothing below far's smallest key): refill it from far
+        uint32_t nn_near = near_n;
+        if (nn_near == 0u || far_min < near_min) {
+            if (nn_near != 0u) {  // (rare: merge near into far first so that the refill sees every open entry)
+                for (uint32_t b0 = 0; b0 < nn_near; b0 += (uint32_t)bd) {
+                    const uint32_t e = b0 + (uint32_t)tid;
+                    const bool in = e < nn_near;
+                    to_far(in, in ? near_key[e] : 0.0, in ? near_id[e] : 0u);
+                }
+                flush_far();
+                __syncthreads();
+                if (tid == 0) sh[FR_NEAR_N] = 0;
+                __syncthreads();
+            }
+            const uint32_t fn = sh[FR_FAR_N];
+            const uint32_t fill = OC / 2u;
+            double lo = sh_ld_d(sh, FR_FAR_MIN), hi = sh_ld_d(sh, FR_FAR_MAX);
+            uint32_t bsel = FR_NBINS - 1;
+            double scale = 0.0;
+            for (int zoom = 0; zoom < 6; ++zoom) {
+                scale = hi > lo ? (double)FR_NBINS / (hi - lo) : 0.0;
+                for (int i = tid; i < FR_NBINS; i += bd) hist[i] = 0;
+                __syncthreads();
+                fr_histogram(F, F.far_key, fn, lo, scale);
+                __syncthreads();
+                if (wave == 0) fr_select2(F, fill, fill, FR_SEL_BIN, FR_SEL_BIN, lane);
+                __syncthreads();
+                bsel = sh[FR_SEL_BIN];
+                const uint32_t cum = sh[FR_SEL_CUM];
+                __syncthreads();
+                if (bsel != 0u || cum <= OC - 64u || scale == 0.0) break;
+                hi = lo + (hi - lo) / (double)FR_NBINS;  // nearly everything sits in the first bin: look closer
+            }
+            // (what the chosen bins hold beyond near's capacity stays in far: near_room)
+            const double l_far_new = (bsel >= FR_NBINS - 1 || scale == 0.0) ? inf : lo + (double)(bsel + 1u) / scale;
+            if (tid == 0) {
+                sh_st_d(sh, FR_FAR_MIN, inf);
+                sh_st_d(sh, FR_FAR_MAX, 0.0);
+                sh_st_d(sh, FR_NEAR_MIN, inf);
+                sh_st_d(sh, FR_NEAR_MAX, 0.0);
+                sh_st_d(sh, FR_L_FAR, l_far_new);
+            }
+            __syncthreads();
+            const double lo_c = lo, scale_c = scale;
+            const uint32_t kept = fr_partition(
+                F.far_key, F.far_id, fn, wsum, n_waves, [&](double k, uint32_t i) -> int { return i == 0u ? -1 : (fr_bin(k, lo_c, scale_c) <= bsel ? 1 : 0); },
+                [&](int c, double k, uint32_t i) {
+                    const unsigned long long b = __ballot(c == 1);
+                    bool back = false;
+                    if (b) {
+                        const uint32_t base = sh_add_uniform(sh, FR_NEAR_N, (uint32_t)__builtin_popcountll(b), lane);
+                        const uint32_t pos = base + lane_rank(b, lane);
+                        const bool fits = c == 1 && pos < OC;
+                        if (fits) {
+                            near_key[pos] = k;
+                            near_id[pos] = i;
+                            near_mn = k < near_mn ? k : near_mn;
+                            near_mx = k > near_mx ? k : near_mx;
+                        }
+                        back = c == 1 && !fits;
+                    }
+                    // (an entry that does not fit cannot go back into the list that is being compacted: it is appended behind the
+                    // old end of far and moved down afterwards — only if more than near's capacity of keys share the first bins)
+                    to_far(back, k, i);
+                    if (c < 0 && i != 0u) {  // kept entries (i is their node, never 0)
+                        far_mn = k < far_mn ? k : far_mn;
+                        far_mx = k > far_mx ? k : far_mx;
+                    }
+                });
+            flush_far();
+            flush_near();
+            const uint32_t extra = sh[FR_FAR_N] - fn;  // entries that did not fit into near, appended at fn ..
+            for (uint32_t e = (uint32_t)tid; e < extra; e += (uint32_t)bd) {  // (kept + extra <= fn: the ranges do not overlap)
+                F.far_key[kept + e] = F.far_key[fn + e];
+                F.far_id[kept + e] = F.far_id[fn + e];
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                sh[FR_FAR_N] = kept + extra;
+                if (sh[FR_NEAR_N] > OC) sh[FR_NEAR_N] = OC;
+            }
+            __syncthreads();
+            nn_near = sh[FR_NEAR_N];
+        }
+
+        // ---- this round's entries: the smallest keys of near.  Every thread holds BK_PER entries in registers.
+        {
+            const double lo = sh_ld_d(sh, FR_NEAR_MIN);
+            double hi = sh_ld_d(sh, FR_NEAR_MAX);
+            // A round takes the smallest open keys: bk_round0 while the search is young (a round costs the same for one node as for
+            // a few dozen: the items of a small round run side by side), growing with the work done up to bk_round.
+            const uint32_t done_so_far = sh[FR_PROCESSED];
+            const uint32_t ramp = (uint32_t)A.bk_round0 + done_so_far / (uint32_t)A.fr_ramp;
+            const uint32_t round_target = ramp < (uint32_t)A.bk_round ? ramp : (uint32_t)A.bk_round;
+            double kk[BK_PER];
+            uint32_t ii[BK_PER];
+#pragma unroll
+            for (int j = 0; j < BK_PER; ++j) {
+                const uint32_t e = (uint32_t)j * (uint32_t)bd + (uint32_t)tid;
+                kk[j] = e < nn_near ? near_key[e] : 0.0;
+                ii[j] = e < nn_near ? near_id[e] : 0u;
+            }
+            uint32_t bsel = FR_NBINS - 1;
+            double scale = 0.0;
+            // (a round that takes all of near needs no histogram: scale 0 puts every key into bin 0)
+            for (int zoom = 0; zoom < 8 && nn_near > round_target; ++zoom) {
+                scale = hi > lo ? (double)FR_NBINS / (hi - lo) : 0.0;
+                for (int i = tid; i < FR_NBINS; i += bd) hist[i] = 0;
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < BK_PER; ++j)
+                    if (ii[j]) __hip_atomic_fetch_add(&hist[fr_bin(kk[j], lo, scale)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __syncthreads();
+                if (wave == 0) fr_select2(F, round_target, round_target, FR_SEL_BIN, FR_SEL_BIN, lane);
+                __syncthreads();
+                bsel = sh[FR_SEL_BIN];
+                const uint32_t cum = sh[FR_SEL_CUM];
+                __syncthreads();
+                if (cum <= 2u * round_target + 16u || scale == 0.0) break;
+                hi = lo + (hi - lo) / (double)FR_NBINS;  // too many entries share the first bins: look closer
+            }
+            const bool have_goal = best != 0u;
+            const bool check_alive = sh[FR_EVER_INVAL] != 0u;  // some node lost its edge to late areas: its descendants are dead
+            int cls[BK_PER];
+            unsigned long long mine = 0;
+            uint32_t n_dead = 0, n_drop = 0;
+#pragma unroll
+            for (int j = 0; j < BK_PER; ++j) {  // (every lane of the wave runs this: straight-line code around the wave-wide walk)
+                const double k = kk[j];
+                const uint32_t i = ii[j];
+                const uint32_t b = fr_bin(k, lo, scale);
+                const bool sel = i != 0u && b <= bsel;
+                const bool above = have_goal && k > bb;  // above the candidate's path maximum: comes after it
+                const bool walk = sel && !above && (have_goal || check_alive);
+                if (sel && have_goal && k == bb) atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_TIE);
+                const int r = fr_check_wave(F.glink, VS, F.gkey, gp_path, gp_mp, have_goal, check_alive, walk ? i : 0u, sh);
+                cls[j] = i == 0u ? -1 : (sel ? (above ? 3 : r) : 0);
+                mine += (cls[j] == 0 ? 1ull : 0ull) | (cls[j] == 1 ? (1ull << 32) : 0ull);
+                n_dead += cls[j] == 4 ? 1u : 0u;
+                n_drop += cls[j] == 3 ? 1u : 0u;
+            }
+            unsigned long long tot = 0;
+            const unsigned long long base = wg_scan_excl(mine, wsum64, lane, wave, n_waves, tot);  // (its barriers: every entry has been read)
+            {
+                uint32_t pk = (uint32_t)(base & 0xffffffffull), pr = (uint32_t)(base >> 32);
+                bool over[BK_PER];
+#pragma unroll
+                for (int j = 0; j < BK_PER; ++j) {
+                    over[j] = false;
+                    if (cls[j] == 0) {
+                        near_key[pk] = kk[j];
+                        near_id[pk] = ii[j];
+                        near_mn = kk[j] < near_mn ? kk[j] : near_mn;
+                        near_mx = kk[j] > near_mx ? kk[j] : near_mx;
+                        pk += 1u;
+                    } else if (cls[j] == 1) {
+                        if (pr < RC) {
+                            ready[pr] = ii[j];
+                            r_flag[pr] = 0u;
+                        } else {
+                            over[j] = true;  // (only if hundreds of keys are equal to the last bit: they wait in far)
+                        }
+                        pr += 1u;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < BK_PER; ++j) to_far(over[j], kk[j], ii[j]);
+            }
+            if (n_dead) sh_add(sh, FR_DEAD, n_dead);
+            if (n_drop) sh_add(sh, FR_DROPPED, n_drop);  // comes after the candidate: never popped
+            const uint32_t n_keep = (uint32_t)(tot & 0xffffffffull), n_rdy = (uint32_t)(tot >> 32);
+            __syncthreads();  // (near_min / near_max of the old list have been read by everybody)
+            if (tid == 0) {
+                sh[FR_NEAR_N] = n_keep;
+                sh[BK_R] = n_rdy < RC ? n_rdy : RC;
+                sh_st_d(sh, FR_NEAR_MIN, inf);
+                sh_st_d(sh, FR_NEAR_MAX, 0.0);
+            }
+            __syncthreads();
+            flush_near();
+            flush_far();
+            __syncthreads();
+            BK_TICK(tk_select)
+        }
+    }
+
+    // ================= results =================
+    uint32_t nnodes_raw = sh[FR_NNODES];
+    nnodes_raw = nnodes_raw < S.max_nodes ? nnodes_raw : S.max_nodes;
+    __syncthreads();
+    const bool pb_ran = pb_valid;
+    if (!pb_valid) {
+        R.n_popped = 0;
+        R.n_expanded = nnodes_raw;
+    }
+    // validity bytes of the LDS-resident nodes go to HBM with the rest (debug read-back of the tree, pdmpc_debug_tree)
+    {
+        const uint32_t nv = VS.NV < nnodes_raw ? VS.NV : nnodes_raw;
+        for (uint32_t i = (uint32_t)tid; i < nv; i += (uint32_t)bd) VS.g[i] = VS.l[i];
+    }
+    {  // work counters: one atomic per wave
+        unsigned long long a = t_checks, b = t_pairs;
+#pragma unroll
+        for (int o = PDMPC_WAVE / 2; o > 0; o >>= 1) {
+            a += __shfl_xor(a, o);
+            b += __shfl_xor(b, o);
+        }
+        if (lane == 0) {
+            atomicAdd(A.work_count + 0, a);
+            atomicAdd(A.work_count + 1, b);
+        }
+    }
+    if (tid == 0) {
+        atomicAdd(A.work_count + 2, (unsigned long long)sh[FR_PROCESSED]);
+        atomicAdd(A.work_count + 3, (unsigned long long)sh[FR_ROUNDS]);
+        A.tree_size[slot] = (int32_t)(nnodes_raw | 0x40000000u);  // marks the arena as a raw tree (api.cpp reconstructs the reference's)
+    }
+    if (tid == 0 && A.debug_tail) {  // diagnostics in the unused tail of the record (rows HP_MAX - 1, HP_MAX of path_nodes); PDMPC_DEBUG_TAIL=1
+        double* dbg = X.O->path_nodes[PDMPC_HP_MAX];
+        dbg[0] = (double)sh[FR_ROUNDS];
+        dbg[1] = (double)sh[FR_PROCESSED];
+        dbg[2] = (double)nnodes_raw;
+        dbg[3] = (double)sh[FR_NEAR_N];
+        dbg[4] = (double)sh[FR_FAR_N];
+        dbg[5] = (double)sh[FR_FLAGS];
+        dbg[6] = (double)(tk_work) + 1e-9 * (double)tk_select;
+        dbg[7] = (double)(__builtin_amdgcn_s_memrealtime() - tk_start);
+        X.O->path_nodes[PDMPC_HP_MAX - 1][0] = (double)tk_work;
+        X.O->path_nodes[PDMPC_HP_MAX - 1][1] = (double)tk_arrival;
+        X.O->path_nodes[PDMPC_HP_MAX - 1][2] = (double)tk_select;
+        X.O->path_nodes[PDMPC_HP_MAX - 1][3] = (double)tk_wait;
+        X.O->path_nodes[PDMPC_HP_MAX - 1][4] = (double)(tk_mark - tk_start);
+        X.O->path_nodes[PDMPC_HP_MAX - 1][5] = 0.0;
+        X.O->path_nodes[PDMPC_HP_MAX - 1][6] = 0.0;
+    }
+    X.status = status;
+    X.n_popped = (int)R.n_popped;
+    X.path_ready = pb_ran && goal != 0u;  // (l_path holds G's path: the epilogue need not walk it again)
+    X.goal = goal;
+    X.nnodes = R.n_expanded;
+    X.dep_timeout = dep_timeout;
+    return false;
+}
+
+template <int NW>
+__device__ __forceinline__ void bulk_body(const KernelArgs& A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Ctx X;
+    search_prologue(A, X, (LDS_AS unsigned char*)smem, true);
+    const int lane = X.lane, wave = X.wave;
+    lds_u32* ref_ids = (lds_u32*)(X.lsm + A.lds.bk_misc) + 224;  // behind the scan partials (nothing else uses those words)
+    const bool tie = bulk_search<NW>(A, X, ref_ids);
+    if (tie) {  // (uniform over the workgroup) reported with the internal status: the host plans the call again on the binary heap
+        X.status = PDMPC_INTERNAL_TIE;
+        X.n_popped = 0;
+        X.path_ready = false;
+        X.goal = 0;
+        X.nnodes = 0;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    search_epilogue(A, X, tie ? nullptr : ref_ids);
+    if (lane == 0 && A.n_helpers > 0) atomicAdd(A.help_finished, 1u);
+}
+
+}  // namespace
+
+extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) void pdmpc_bulk_kernel(const KernelArgs A) { bulk_body<1>(A); }
+extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) void pdmpc_bulk_kernel_wide(const KernelArgs A) { bulk_body<0>(A); }
+
+extern "C" int pdmpc_launch_bulk(const KernelArgs* args, int count, void* stream, uint32_t* lds_high_water) {
+    if (count <= 0) return 0;
+    typedef void (*kernel_t)(const KernelArgs);
+    const bool one_word = args->n_words == 1;
+    kernel_t fn = one_word ? pdmpc_bulk_kernel : pdmpc_bulk_kernel_wide;
+    // (the attribute is a maximum: raised when a launch needs more than any before it; the high-water mark lives in the handle)
+    uint32_t& have = lds_high_water[one_word ? 0 : 1];
+    if (args->lds.total > have) {
+        hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)args->lds.total);
+        if (e != hipSuccess) return (int)e;
+        have = args->lds.total;
+    }
+    hipLaunchKernelGGL(fn, dim3(count), dim3(PDMPC_WAVE * args->n_waves), args->lds.total, (hipStream_t)stream, *args);
+    return (int)hipGetLastError();
+}

@@ -89,6 +89,11 @@ struct LdsLayout {
     uint32_t stage;                        // frontier kernel: NodeRec[2 * fr_stage_cap]: the records of a round's nodes and of their parents
     uint32_t nodes;                        // NodeRec[NL]
     uint32_t total;
+    // bulk kernel (bulk_kernel.hip)
+    uint32_t bk_near_key, bk_near_id;      // double[BK_PER * threads], uint32[BK_PER * threads]: the LDS part of the open set
+    uint32_t bk_ready;                     // uint32[bk_ready_cap] nodes of the round + uint32[bk_ready_cap] their collision flags
+    uint32_t bk_hist;                      // uint32[3072]: histogram [2048] | goal list [1024], collision-free nodes of the round [1024], their children's offsets [1024]
+    uint32_t bk_misc;                      // 1 KB: path tables of the best goal candidate, scan partials, chunk table, the reference's ids along the path
 };
 
 struct NodeArena {  // HBM arrays, per-vehicle stride = max_nodes entries
@@ -102,6 +107,12 @@ struct NodeArena {  // HBM arrays, per-vehicle stride = max_nodes entries
     uint32_t* near_id;
     unsigned long long* link;  // frontier kernel: parent | packed << 32 per node, eight nodes to a 64-byte line (a record's own copy shares its line with nothing the walks need)
 };
+
+/* record status of a search that met equal keys where the pop order depends on the reference's binary heap (bulk kernel): never leaves
+ * the library -- api.cpp plans the call again with the kernel that carries the libstdc++-faithful heap */
+#define PDMPC_INTERNAL_TIE 100
+
+#define PDMPC_BK_PER 3 /* bulk kernel: entries of the LDS open list per thread (a selection pass holds them in registers) */
 
 #define PDMPC_HELP_CAP 2048 /* entries of a round that can be shared (= the ready list's capacity) */
 #define PDMPC_HB_WORDS 8   /* 64-bit words of a board */
@@ -176,6 +187,11 @@ struct KernelArgs {
     int32_t help_expand;             // 1: helpers also expand the entries they find collision-free
     int32_t help_patience;           // ... polls without a new claim after which the owner closes the round and does the rest itself
     uint32_t* help_finished;         // searches of this launch that have published their result
+    // bulk kernel
+    int32_t bulk;           // 1: this launch runs the bulk kernel (bulk_kernel.hip)
+    int32_t bk_ready_cap;   // entries of the ready list (a round's nodes)
+    int32_t bk_round0;      // nodes a round of a young search takes
+    int32_t bk_round;       // ... and the most any round takes
     int32_t speculate;  // 1: start searching before all predecessors have finished (results are identical, see arrival_sync)
     uint32_t spin_limit;
     int32_t reverse_dispatch;  // testing only (PDMPC_TEST_REVERSE_DISPATCH): workgroup b plans slot first + n_searches - 1 - b, i.e. successors are
@@ -194,6 +210,8 @@ int pdmpc_launch_heap_script(const int32_t* op, const int32_t* id, const double*
 int pdmpc_launch_sampled(const KernelArgs* args, int count, void* stream);
 // defined in frontier_kernel.hip: the search with all wavefronts of a workgroup working on open nodes side by side
 int pdmpc_launch_frontier(const KernelArgs* args, int count, void* stream);
+// defined in bulk_kernel.hip: the search as bulk-synchronous passes; lds_high_water[2] = the handle's record of the dynamic LDS size set so far per kernel variant
+int pdmpc_launch_bulk(const KernelArgs* args, int count, void* stream, uint32_t* lds_high_water);
 // defined in frontier_kernel.hip; launches args->n_helpers helper workgroups (they serve the searches of a pdmpc_launch_frontier with the same args)
 int pdmpc_launch_helpers(const KernelArgs* args, void* stream);
 // defined in debug_kernels.hip: the collision primitives of edge_checks.hpp on given polygons, one wavefront per case

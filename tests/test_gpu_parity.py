@@ -321,6 +321,10 @@ def test_random_road_problems_never_fall_back():
         {"PDMPC_HELP_PATIENCE": "0", "PDMPC_FR_SHARE_MIN": "64"},
         {"PDMPC_FR_ROOT_DIVE": "1"},
         {"PDMPC_HELP_PATIENCE": "200", "PDMPC_HELPERS": "2", "PDMPC_FR_SHARE_MIN": "64", "PDMPC_HELP_CHUNK": "128"},
+        {"PDMPC_KERNEL": "frontier"},
+        {"PDMPC_KERNEL": "frontier", "PDMPC_FR_SHARE_MIN": "64", "PDMPC_HELP_EXPAND": "0"},
+        {"PDMPC_BK_ROUND0": "1", "PDMPC_BK_RAMP": "16"},
+        {"PDMPC_BK_ROUND0": "200", "PDMPC_BK_ROUND": "512", "PDMPC_BK_RAMP": "1"},
     ],
 )
 def test_tuning_switches_do_not_change_results(env, monkeypatch):
@@ -340,6 +344,7 @@ def test_helper_workgroups_take_part_and_change_nothing():
     check edges for the searches and the records stay those of the oracle — here with the threshold low enough that most rounds
     of the heavier searches are shared, and the statistics say so."""
     os.environ["PDMPC_FR_SHARE_MIN"] = "64"
+    os.environ["PDMPC_KERNEL"] = "frontier"  # (the helper kernel serves the frontier kernel's rounds)
     try:
         for seed in (2, 5):
             options, mpa, iters = problems.problem_set("interx", seed, 24, Hp=6)
@@ -348,6 +353,7 @@ def test_helper_workgroups_take_part_and_change_nothing():
             assert stats["helper_checked"] < stats["nodes_processed"]
     finally:
         del os.environ["PDMPC_FR_SHARE_MIN"]
+        del os.environ["PDMPC_KERNEL"]
 
 
 def test_arena_growth_with_shared_rounds(monkeypatch):
@@ -355,6 +361,7 @@ def test_arena_growth_with_shared_rounds(monkeypatch):
     the search ends with PDMPC_ARENA_OVERFLOW and the call is planned again with doubled arenas — from 256 nodes up, with most
     rounds shared, until every search fits; the records are the oracle's."""
     monkeypatch.setenv("PDMPC_FR_SHARE_MIN", "64")
+    monkeypatch.setenv("PDMPC_KERNEL", "frontier")
     options, mpa, iters = problems.problem_set("interx", 2, 24, Hp=6)
     oracle = _oracle()
     options.max_nodes = 1 << 22
