@@ -263,7 +263,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
     uint32_t goal = 0;
     uint32_t idle_polls = 0;
     unsigned long long t_checks = 0, t_pairs = 0;  // this thread's share of the work counters
-    unsigned long long tk_work = 0, tk_arrival = 0, tk_select = 0, tk_wait = 0, tk_mark = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tk_work = 0, tk_arrival = 0, tk_select = 0, tk_wait = 0, tk_p1 = 0, tk_p2 = 0, tk_p3 = 0, tk_pb = 0, tk_mark = __builtin_amdgcn_s_memrealtime();
     const unsigned long long tk_start = tk_mark;
 #define BK_TICK(acc)                                                       \
     {                                                                      \
@@ -338,6 +338,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            BK_TICK(tk_p1)
 
             // ---- P2: verdicts, goal candidates, children counts; node indices by a scan (two ready entries per thread)
             bool ex[2];
@@ -401,6 +402,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             const bool overflow = nn_base + NC > S.max_nodes;
             const bool all_far = sh[FR_NEAR_N] + NC > OC;  // near cannot take this round's children: they wait in far
             __syncthreads();  // (vlist / voffs written; FR_NNODES read by everybody)
+            BK_TICK(tk_p2)
             if (tid == 0) {
                 sh[FR_NNODES] = nn_base + (overflow ? 0u : NC);
                 sh[FR_PROCESSED] = sh[FR_PROCESSED] + Rn;
@@ -479,9 +481,10 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 sh_add(sh, FR_ROUNDS, 1u);
             }
             __syncthreads();
+            BK_TICK(tk_p3)
         }
-        BK_TICK(tk_work)
         fr_resolve_goals(F, S, tid, lane, wave);
+        BK_TICK(tk_work)
 
         // ================= round boundary (every thread; decisions are uniform) =====================================
         uint32_t flags = sh[FR_FLAGS];
@@ -627,6 +630,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 __syncthreads();
                 R = fr_phase_b<NW>(A, X, F, EE, best, ref_ids, (LDS_AS unsigned char*)(X.lsm + A.lds.cand), F.near_key, F.near_id, gp_path);
                 pb_valid = true;
+                BK_TICK(tk_pb)
                 const uint32_t pflags = sh[FR_FLAGS];
                 __syncthreads();
                 if (pflags & FRF_TIE) return true;
@@ -872,6 +876,12 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         dbg[5] = (double)sh[FR_FLAGS];
         dbg[6] = (double)(tk_work) + 1e-9 * (double)tk_select;
         dbg[7] = (double)(__builtin_amdgcn_s_memrealtime() - tk_start);
+        tk_work += tk_p1 + tk_p2 + tk_p3;
+        X.O->path_nodes[PDMPC_HP_MAX - 2][0] = (double)(tk_start - X.rt_kernel_start);
+        X.O->path_nodes[PDMPC_HP_MAX - 2][1] = (double)tk_p1;
+        X.O->path_nodes[PDMPC_HP_MAX - 2][2] = (double)tk_p2;
+        X.O->path_nodes[PDMPC_HP_MAX - 2][3] = (double)tk_p3;
+        X.O->path_nodes[PDMPC_HP_MAX - 2][4] = (double)tk_pb;
         X.O->path_nodes[PDMPC_HP_MAX - 1][0] = (double)tk_work;
         X.O->path_nodes[PDMPC_HP_MAX - 1][1] = (double)tk_arrival;
         X.O->path_nodes[PDMPC_HP_MAX - 1][2] = (double)tk_select;
@@ -893,7 +903,9 @@ template <int NW>
 __device__ __forceinline__ void bulk_body(const KernelArgs& A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Ctx X;
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
     search_prologue(A, X, (LDS_AS unsigned char*)smem, true);
+    X.rt_kernel_start = rt0;
     const int lane = X.lane, wave = X.wave;
     lds_u32* ref_ids = (lds_u32*)(X.lsm + A.lds.bk_misc) + 224;  // behind the scan partials (nothing else uses those words)
     const bool tie = bulk_search<NW>(A, X, ref_ids);

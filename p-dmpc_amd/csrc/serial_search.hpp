@@ -313,6 +313,7 @@ struct Ctx {
     int status, n_popped;
     uint32_t goal, nnodes;
     bool dep_timeout;
+    unsigned long long rt_kernel_start = 0;  // s_memrealtime at kernel entry (diagnostics of the bulk kernel)
     bool path_ready = false;  // l_path already holds the nodes of the goal's path (the frontier kernel's counting pass has walked it)
 #ifdef PDMPC_PROFILE
     unsigned long long rt_start;

@@ -22,6 +22,8 @@ for b, prob in enumerate(probs):
     rows = []
     for v in range(len(recs)):
         t = np.asarray(recs[v]["path_nodes"])
-        rows.append((t[16][7] / 100.0, v, prob["levels"][v], int(recs[v]["n_popped"]), int(t[16][1]), int(t[16][2]), int(t[16][0]), t[15][0] / 100.0, t[15][1] / 100.0, t[15][2] / 100.0, t[15][3] / 100.0, len(prob["preds"][v])))
-    for r in sorted(rows, reverse=True)[:8]:
-        print("   total %.0f us veh %d level %d popped %d processed %d nodes %d rounds %d | work %.0f arrival %.0f select %.0f wait %.0f us | preds %d" % r)
+        rows.append((t[16][7] / 100.0, v, prob["levels"][v], int(recs[v]["n_popped"]), int(t[16][1]), int(t[16][2]), int(t[16][0]), t[15][0] / 100.0, t[15][1] / 100.0, t[15][2] / 100.0, t[15][3] / 100.0, len(prob["preds"][v]),
+                     t[14][0] / 100.0, t[14][1] / 100.0, t[14][2] / 100.0, t[14][3] / 100.0, t[14][4] / 100.0))
+    top = int(os.environ.get("PROFILE_TOP", "8"))
+    for r in sorted(rows, reverse=True)[:top]:
+        print("   total %.0f us veh %d level %d popped %d processed %d nodes %d rounds %d | work %.0f arrival %.0f select %.0f wait %.0f us | preds %d | prologue %.0f check %.0f verdict %.0f expand %.0f phaseB %.0f us" % r)
