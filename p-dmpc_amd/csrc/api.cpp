@@ -332,7 +332,7 @@ bool layout_bulk(pdmpc_handle* h, size_t budget, int n_waves, int areas, int sou
     L.bk_hist = off;
     off += 3072u * 4u;
     L.bk_misc = off;
-    off += 1024u;
+    off += 2048u;
     L.heap_key = L.bk_hist;  // (the prologue derives pointers from these; the bulk kernel never follows them)
     L.heap_id = L.bk_hist;
     L.stage = L.bk_hist;

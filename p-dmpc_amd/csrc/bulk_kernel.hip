@@ -33,7 +33,6 @@
 #include "frontier_common.hpp"
 
 // shared words of the bulk kernel (aliases of words the frontier kernel uses for things this kernel does not have)
-#define BK_R FR_RD_TAIL          // entries of the ready list (this round)
 #define BK_PER PDMPC_BK_PER       // near entries per thread a selection pass holds in registers (near capacity = BK_PER * blockDim)
 
 namespace {
@@ -146,6 +145,46 @@ __device__ __forceinline__ int nth_bit(uint64_t mask, int rk) {
     return (int)__builtin_ctzll(mask);
 }
 
+// monotone map key -> bin of a linear histogram of BK_NB bins over [lo, lo + BK_NB / scale)
+#define BK_NB 256
+__device__ __forceinline__ uint32_t bk_bin(double key, double lo, double scale) {
+    const double t = (key - lo) * scale;
+    if (!(t > 0.0)) return 0u;
+    return t < (double)(BK_NB - 1) ? (uint32_t)t : (uint32_t)(BK_NB - 1);
+}
+// The first bin at which the cumulative count of the BK_NB-bin histogram reaches `target` (the last non-empty bin if the total is
+// smaller) and that count.  Every lane of a wave calls (four bins per lane); every wave of the workgroup does it for itself, so
+// the result needs no broadcast through LDS and no barrier.
+__device__ __forceinline__ void bk_select(const lds_u32* bins, uint32_t target, int lane, uint32_t& bin, uint32_t& cum) {
+    uint32_t hq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) hq[q] = bins[4 * lane + q];
+    const uint32_t loc = hq[0] + hq[1] + hq[2] + hq[3];
+    uint32_t inc = loc;
+#pragma unroll
+    for (int o = 1; o < PDMPC_WAVE; o <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)inc, o);
+        inc += lane >= o ? v : 0u;
+    }
+    const uint32_t total = lane_u(inc, PDMPC_WAVE - 1);
+    const uint32_t want = target < total ? target : total;
+    uint32_t c = inc - loc, b = 0, cu = 0;
+    bool f = false;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        c += hq[q];
+        const bool hit = !f && hq[q] != 0u && c >= want;
+        b = hit ? (uint32_t)(4 * lane + q) : b;
+        cu = hit ? c : cu;
+        f = f || hit;
+    }
+    const unsigned long long m = __ballot(f);
+    const int l = m ? (int)__builtin_ctzll(m) : 0;
+    const uint32_t bb = lane_u(b, l), cc = lane_u(cu, l);
+    bin = m ? bb : 0u;
+    cum = m ? cc : 0u;
+}
+
 // The search.  Returns true (to every thread) if a tie was met: the host plans the call again with the heap-carrying kernel.
 template <int NW>
 __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32* ref_ids) {
@@ -160,20 +199,22 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
     const size_t voff = (size_t)slot * A.max_nodes;
     const int n = X.n, nw = NW > 0 ? NW : X.nw;
     const uint32_t OC = (uint32_t)(BK_PER * bd), RC = (uint32_t)A.bk_ready_cap;
+    const uint32_t VCAP = 1024u;  // expansion groups per tile (vlist / voffs)
 
     // ---- LDS carve of the bulk region
     lds_f64* near_key = (lds_f64*)(X.lsm + A.lds.bk_near_key);
     lds_u32* near_id = (lds_u32*)(X.lsm + A.lds.bk_near_id);
     lds_u32* ready = (lds_u32*)(X.lsm + A.lds.bk_ready);
     volatile lds_u32* r_flag = (volatile lds_u32*)(ready + RC);
-    lds_u32* hist = (lds_u32*)(X.lsm + A.lds.bk_hist);      // [3072]: histogram [2048] | goal list [1024], vlist [1024], voff [1024]
+    lds_u32* hist = (lds_u32*)(X.lsm + A.lds.bk_hist);      // [3072]: refill histogram [2048] | goal list [1024], expansion groups [1024], their children's offsets [1024]
     lds_u32* vlist = hist + 1024;
     lds_u32* voffs = hist + 2048;
     lds_u32* gp_path = (lds_u32*)(X.lsm + A.lds.bk_misc);    // [32] path of the best goal candidate
     lds_f64* gp_mp = (lds_f64*)(gp_path + 32);                // [HP_MAX + 1] largest key of that path below depth d
     lds_vu64* wsum64 = (lds_vu64*)(gp_mp + 32);                // [32] scan partials
     volatile lds_u32* wsum = (volatile lds_u32*)(wsum64 + 32); // [32] fr_partition's per-wave counts
-    lds_u32* chm = (lds_u32*)(wsum + 32);                      // [8] chunks per node for S = 1, 2, 4, 8, 16, ...; [7] = most segments of a step
+    lds_u32* chm = (lds_u32*)(wsum + 32);                      // [8] chunks per node for S = 1, 2, 4, 8, 16, ...
+    lds_u32* bins = gp_path + 256;                             // [BK_NB] the selection's histogram (second KB of the region)
 
     Frontier F;
     F.sh = sh;
@@ -231,7 +272,6 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         vs_store(VS, 0, VS_UNKNOWN);
         for (int w = 26; w < SH_WORDS; ++w) sh[w] = 0;
         sh[FR_NNODES] = 1;
-        sh[BK_R] = 1;
         sh_st_d(sh, FR_NEAR_MIN, inf);
         sh_st_d(sh, FR_FAR_MIN, inf);
         sh_st_d(sh, FR_L_FAR, inf);
@@ -240,21 +280,18 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         ready[0] = 1u;
         r_flag[0] = 0u;
     }
+    if (tid < BK_NB) bins[tid] = 0u;
     if (tid >= 64 && tid < 72) {
         const int ls = tid - 64;
-        uint32_t mx = 0, mseg = 0;
+        uint32_t mx = 0;
         for (int k = 1; k <= Hp; ++k) {
             const int M_k = CK.l_soff[k] - CK.l_soff[k - 1], Hk = CK.l_hoff[k] - CK.l_hoff[k - 1];
             const int n0 = M_k > 1 ? M_k - 1 : 0, n1 = Hk > 1 ? Hk - 1 : 0, n2 = CK.ll_len > 1 ? CK.ll_len - 1 : 0;
             const int Sg = 1 << ls;
             const uint32_t ch = (uint32_t)(((n0 + Sg - 1) >> ls) + ((n1 + Sg - 1) >> ls) + ((n2 + Sg - 1) >> ls));
             mx = ch > mx ? ch : mx;
-            mseg = (uint32_t)(n0 + n1 + n2) > mseg ? (uint32_t)(n0 + n1 + n2) : mseg;
         }
-        if (ls < 7)
-            chm[ls] = mx;
-        else
-            chm[7] = mseg;
+        chm[ls] = mx;
     }
     __syncthreads();
 
@@ -262,14 +299,22 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
     bool dep_timeout = X.dep_timeout;
     uint32_t goal = 0;
     uint32_t idle_polls = 0;
-    unsigned long long t_checks = 0, t_pairs = 0;  // this thread's share of the work counters
-    unsigned long long tk_work = 0, tk_arrival = 0, tk_select = 0, tk_wait = 0, tk_p1 = 0, tk_p2 = 0, tk_p3 = 0, tk_pb = 0, tk_mark = __builtin_amdgcn_s_memrealtime();
-    const unsigned long long tk_start = tk_mark;
+    uint32_t Rn = 1;  // entries of the ready list (uniform: every thread carries it)
+    uint32_t t_checks = 0, t_pairs = 0;  // this thread's share of the work counters
+    // where the time goes (100 MHz ticks, PDMPC_DEBUG_TAIL=1): accumulated by thread 0 in LDS words, so that the bookkeeping costs
+    // the round loop no registers
+    lds_vu64* tk = (lds_vu64*)(gp_path + 200);  // [10]: mark, start, work, arrival, select, wait, p1, p2, p3, phase B
+    enum { TK_MARK, TK_START, tk_work, tk_arrival, tk_select, tk_wait, tk_p1, tk_p2, tk_p3, tk_pb };
+    const bool ticking = A.debug_tail != 0 && tid == 0;
+    if (ticking) {
+        for (int i = 2; i < 10; ++i) tk[i] = 0ull;
+        tk[TK_MARK] = tk[TK_START] = __builtin_amdgcn_s_memrealtime();
+    }
 #define BK_TICK(acc)                                                       \
-    {                                                                      \
+    if (ticking) {                                                         \
         const unsigned long long now__ = __builtin_amdgcn_s_memrealtime(); \
-        acc += now__ - tk_mark;                                            \
-        tk_mark = now__;                                                   \
+        tk[acc] += now__ - tk[TK_MARK];                                    \
+        tk[TK_MARK] = now__;                                               \
     }
     double far_mn = inf, far_mx = 0.0, near_mn = inf, near_mx = 0.0;
     // appends (k, i) of the lanes with `take` to far (whole wave calls, straight-line)
@@ -317,7 +362,6 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
 
     for (;;) {
         // ================= a round =================
-        const uint32_t Rn = sh[BK_R];
         if (Rn) {
             pb_valid = false;  // (the tree grows: phase B's result is stale)
             // ---- P1: check items + sincos items
@@ -340,7 +384,8 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             __syncthreads();
             BK_TICK(tk_p1)
 
-            // ---- P2: verdicts, goal candidates, children counts; node indices by a scan (two ready entries per thread)
+            // ---- P2: verdicts, goal candidates, children counts; node indices by a scan (two ready entries per thread).
+            // The children of a node are expanded in groups of four lanes.
             bool ex[2];
             uint32_t cnt[2], rr[2];
             unsigned long long mine = 0;
@@ -361,7 +406,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                     if (parent) {  // the pairs the reference's InterX forms for this edge (InterX.m:63-76): (V - 1) x (M - 1) per soup
                         const int M_k = CK.l_soff[k] - CK.l_soff[k - 1], Hk = CK.l_hoff[k] - CK.l_hoff[k - 1];
                         t_checks += 1;
-                        t_pairs += (unsigned long long)(NODE_COLS(packed) - 1) * (unsigned long long)((M_k > 1 ? M_k - 1 : 0) + (Hk > 1 ? Hk - 1 : 0) + (CK.ll_len > 1 ? CK.ll_len - 1 : 0));
+                        t_pairs += (uint32_t)(NODE_COLS(packed) - 1) * (uint32_t)((M_k > 1 ? M_k - 1 : 0) + (Hk > 1 ? Hk - 1 : 0) + (CK.ll_len > 1 ? CK.ll_len - 1 : 0));
                     }
                     if (valid && k == Hp) {
                         // a goal candidate if its ancestors are all collision-free still: the largest key of its path goes into its
@@ -377,47 +422,47 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                         const lds_mask64* mrow = EE.l_mask + ((size_t)k * n + (NODE_TRIM(packed) - 1)) * nw;
                         uint32_t c = 0;
                         for (int w = 0; w < nw; ++w) c += (uint32_t)__builtin_popcountll(mrow[w]);
-                        ex[s] = true;
+                        ex[s] = c != 0u;
                         cnt[s] = c;
                     }
                 }
-                mine += (ex[s] ? 1ull : 0ull) | ((unsigned long long)cnt[s] << 32);
+                mine += (unsigned long long)((cnt[s] + 3u) >> 2) | ((unsigned long long)cnt[s] << 32);
             }
             unsigned long long tot = 0;
             const unsigned long long base = wg_scan_excl(mine, wsum64, lane, wave, n_waves, tot);
-            {
-                uint32_t v = (uint32_t)(base & 0xffffffffull), c = (uint32_t)(base >> 32);
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    if (ex[s]) {
-                        vlist[v] = rr[s];
-                        voffs[v] = c;
-                        v += 1u;
-                        c += cnt[s];
-                    }
-                }
-            }
-            const uint32_t NVr = (uint32_t)(tot & 0xffffffffull), NC = (uint32_t)(tot >> 32);
+            const uint32_t NG = (uint32_t)(tot & 0xffffffffull), NC = (uint32_t)(tot >> 32);
             const uint32_t nn_base = sh[FR_NNODES];
             const bool overflow = nn_base + NC > S.max_nodes;
             const bool all_far = sh[FR_NEAR_N] + NC > OC;  // near cannot take this round's children: they wait in far
-            __syncthreads();  // (vlist / voffs written; FR_NNODES read by everybody)
+            const double l_far = all_far ? -1.0 : sh_ld_d(sh, FR_L_FAR);
             BK_TICK(tk_p2)
-            if (tid == 0) {
-                sh[FR_NNODES] = nn_base + (overflow ? 0u : NC);
-                sh[FR_PROCESSED] = sh[FR_PROCESSED] + Rn;
-                if (overflow) sh[FR_FLAGS] = sh[FR_FLAGS] | FRF_OVERFLOW;
-            }
-
-            // ---- P3: expansion items (collision-free node, successor slot): expand_node.m:18-90
-            if (!overflow) {
-                const uint32_t SL = 16u * (uint32_t)nw, items = NVr * SL;
-                const double l_far = all_far ? -1.0 : sh_ld_d(sh, FR_L_FAR);
+            // ---- P3: expansion items (group of four successors of a collision-free node, lane): expand_node.m:18-90
+            for (uint32_t tile0 = 0; tile0 < NG && !overflow; tile0 += VCAP) {  // (uniform; one tile unless a round has more than VCAP groups)
+                if (tile0) __syncthreads();  // (the previous tile's items have read the lists)
+                {
+                    uint32_t g = (uint32_t)(base & 0xffffffffull), c = (uint32_t)(base >> 32);
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const uint32_t ng = (cnt[s] + 3u) >> 2;
+                        for (uint32_t q = 0; q < ng; ++q) {
+                            const uint32_t gi = g + q - tile0;  // (unsigned: groups of earlier tiles are far outside)
+                            if (gi < VCAP) {
+                                vlist[gi] = rr[s] | (q << 16);
+                                voffs[gi] = c;
+                            }
+                        }
+                        g += ng;
+                        c += cnt[s];
+                    }
+                }
+                __syncthreads();
+                const uint32_t ngt = NG - tile0 < VCAP ? NG - tile0 : VCAP, items = ngt * 4u;
                 for (uint32_t b0 = 0; b0 < items; b0 += (uint32_t)bd) {  // (uniform trip count: wave-wide appends inside)
                     const uint32_t item = b0 + (uint32_t)tid;
                     const bool in = item < items;
-                    const uint32_t v = in ? item / SL : 0u, j = in ? item - v * SL : 0u;
-                    const uint32_t r = vlist[v], id = ready[r], i0 = id - 1u;
+                    const uint32_t gi = in ? item >> 2 : 0u, ent = vlist[gi];
+                    const uint32_t r = ent & 0xffffu, rank = (ent >> 16) * 4u + (item & 3u);
+                    const uint32_t id = ready[r], i0 = id - 1u;
                     NodeBits cu;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) cu.q[q] = node_piece(S, i0, q);
@@ -426,15 +471,20 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                     const int k_exp = cK + 1;            // expand_node.m:13
                     const int steps_to_go = Hp - k_exp;  // :37
                     const lds_mask64* mrow = EE.l_mask + ((size_t)cK * n + (cTrim - 1)) * nw;
-                    const int w = (int)(j >> 4), rk = (int)(j & 15u);
-                    const uint64_t mask = mrow[w];
-                    const bool active = in && rk < __builtin_popcountll(mask);
-                    uint32_t before = 0;
-                    for (int q = 0; q < w; ++q) before += (uint32_t)__builtin_popcountll(mrow[q]);
+                    // the rank-th successor (ascending trim: expand_node.m:18): its mask word and its place in that word
+                    int w = 0;
+                    uint32_t rk = rank;
+                    uint64_t mask = mrow[0];
+                    for (int q = 1; q < nw && rk >= (uint32_t)__builtin_popcountll(mask); ++q) {
+                        rk -= (uint32_t)__builtin_popcountll(mask);
+                        mask = mrow[q];
+                        w = q;
+                    }
+                    const bool active = in && rk < (uint32_t)__builtin_popcountll(mask);
                     double f = 0.0;
                     uint32_t ci = 0;
                     if (active) {
-                        const int t2 = w * 64 + nth_bit(mask, rk);  // 0-based successor trim (ascending: expand_node.m:18)
+                        const int t2 = w * 64 + nth_bit(mask, (int)rk);  // 0-based successor trim
                         const int m = (int)EE.l_mi[(cTrim - 1) * n + t2];
                         const double dx = EE.l_pose[m].dx, dy = EE.l_pose[m].dy, dyaw = EE.l_pose[m].dyaw;
                         const int ncols = EE.l_pose[m].n_cols;
@@ -462,7 +512,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                         }
                         ch.h = expH;
                         f = ch.g * 1 + expH * 1;  // GraphSearch.m:100-102
-                        ci = nn_base + voffs[v] + before + (uint32_t)rk;  // 0-based index of the child (Tree.add_nodes, Tree.m:61)
+                        ci = nn_base + voffs[gi] + rank;  // 0-based index of the child (Tree.add_nodes, Tree.m:61)
                         node_store(S, ci, ch);
                         vs_store(VS, ci, 0);  // validity unknown
                         F.gkey[ci] = f;
@@ -471,18 +521,21 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                     to_near(active && !(f > l_far), f, ci + 1u);
                     to_far(active && f > l_far, f, ci + 1u);
                 }
-                flush_near();
-                flush_far();
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) {
-                sh[BK_R] = 0;
-                sh_add(sh, FR_ROUNDS, 1u);
+            if (tid == 0) {  // (nobody reads these words before the barrier that ends the round)
+                sh[FR_NNODES] = nn_base + (overflow ? 0u : NC);
+                sh[FR_PROCESSED] = sh[FR_PROCESSED] + Rn;
+                sh[FR_ROUNDS] = sh[FR_ROUNDS] + 1u;
+                if (overflow) sh[FR_FLAGS] = sh[FR_FLAGS] | FRF_OVERFLOW;
             }
-            __syncthreads();
+            Rn = 0;
             BK_TICK(tk_p3)
         }
+        // the key ranges the appends of this round and the selection before it have met
+        flush_near();
+        flush_far();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // ---- the barrier that ends the round
         fr_resolve_goals(F, S, tid, lane, wave);
         BK_TICK(tk_work)
 
@@ -498,9 +551,12 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             break;
         }
         // predecessors that finished meanwhile: their areas enter the soup, collision-free edges are re-checked
-        if (wave == 0) (void)poll_predecessors(A, P, sh, lane);
-        __syncthreads();
-        if (sh[SH_STATE] == ST_ARRIVED) {
+        const bool pending = sh_load64(sh, SH_PEND_LO) != 0ull;  // (uniform: written by thread 0 between barriers)
+        if (pending) {
+            if (wave == 0) (void)poll_predecessors(A, P, sh, lane);
+            __syncthreads();
+        }
+        if (pending && sh[SH_STATE] == ST_ARRIVED) {
             const unsigned long long arr = sh_load64(sh, SH_ARR_LO);
             uint32_t nn = sh[FR_NNODES];
             nn = nn < S.max_nodes ? nn : S.max_nodes;
@@ -642,7 +698,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 break;
             }
             // finished, but predecessors that are still planning may yet invalidate what we found
-            __builtin_amdgcn_s_sleep(8);
+            __builtin_amdgcn_s_sleep(4);
             if (++idle_polls > A.spin_limit) dep_timeout = true;  // a predecessor never finished: give up on it (reported as an error status)
             BK_TICK(tk_wait)
             continue;
@@ -681,7 +737,6 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 if (bsel != 0u || cum <= OC - 64u || scale == 0.0) break;
                 hi = lo + (hi - lo) / (double)FR_NBINS;  // nearly everything sits in the first bin: look closer
             }
-            // (what the chosen bins hold beyond near's capacity stays in far: near_room)
             const double l_far_new = (bsel >= FR_NBINS - 1 || scale == 0.0) ? inf : lo + (double)(bsel + 1u) / scale;
             if (tid == 0) {
                 sh_st_d(sh, FR_FAR_MIN, inf);
@@ -738,8 +793,8 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         {
             const double lo = sh_ld_d(sh, FR_NEAR_MIN);
             double hi = sh_ld_d(sh, FR_NEAR_MAX);
-            // A round takes the smallest open keys: bk_round0 while the search is young (a round costs the same for one node as for
-            // a few dozen: the items of a small round run side by side), growing with the work done up to bk_round.
+            // A round takes the smallest open keys: bk_round0 while the search is young (a round costs about the same for one node as
+            // for a few dozen: the items of a small round run side by side), growing with the work done up to bk_round.
             const uint32_t done_so_far = sh[FR_PROCESSED];
             const uint32_t ramp = (uint32_t)A.bk_round0 + done_so_far / (uint32_t)A.fr_ramp;
             const uint32_t round_target = ramp < (uint32_t)A.bk_round ? ramp : (uint32_t)A.bk_round;
@@ -751,24 +806,24 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 kk[j] = e < nn_near ? near_key[e] : 0.0;
                 ii[j] = e < nn_near ? near_id[e] : 0u;
             }
-            uint32_t bsel = FR_NBINS - 1;
+            uint32_t bsel = BK_NB - 1;
             double scale = 0.0;
-            // (a round that takes all of near needs no histogram: scale 0 puts every key into bin 0)
-            for (int zoom = 0; zoom < 8 && nn_near > round_target; ++zoom) {
-                scale = hi > lo ? (double)FR_NBINS / (hi - lo) : 0.0;
-                for (int i = tid; i < FR_NBINS; i += bd) hist[i] = 0;
-                __syncthreads();
+            const bool use_hist = nn_near > round_target;  // (a round that takes all of near needs no histogram: scale 0 puts every key into bin 0)
+            if (use_hist) {
+                for (int zoom = 0; zoom < 8; ++zoom) {
+                    scale = hi > lo ? (double)BK_NB / (hi - lo) : 0.0;
 #pragma unroll
-                for (int j = 0; j < BK_PER; ++j)
-                    if (ii[j]) __hip_atomic_fetch_add(&hist[fr_bin(kk[j], lo, scale)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __syncthreads();
-                if (wave == 0) fr_select2(F, round_target, round_target, FR_SEL_BIN, FR_SEL_BIN, lane);
-                __syncthreads();
-                bsel = sh[FR_SEL_BIN];
-                const uint32_t cum = sh[FR_SEL_CUM];
-                __syncthreads();
-                if (cum <= 2u * round_target + 16u || scale == 0.0) break;
-                hi = lo + (hi - lo) / (double)FR_NBINS;  // too many entries share the first bins: look closer
+                    for (int j = 0; j < BK_PER; ++j)
+                        if (ii[j]) __hip_atomic_fetch_add(&bins[bk_bin(kk[j], lo, scale)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __syncthreads();
+                    uint32_t cum;
+                    bk_select(bins, round_target, lane, bsel, cum);  // (every wave for itself)
+                    if (cum <= 2u * round_target + 16u || scale == 0.0) break;
+                    hi = lo + (hi - lo) / (double)BK_NB;  // too many entries share the first bins: look closer
+                    __syncthreads();                       // every wave has read the bins ...
+                    if (tid < BK_NB) bins[tid] = 0u;
+                    __syncthreads();                       // ... and they are clean again
+                }
             }
             const bool have_goal = best != 0u;
             const bool check_alive = sh[FR_EVER_INVAL] != 0u;  // some node lost its edge to late areas: its descendants are dead
@@ -779,19 +834,27 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             for (int j = 0; j < BK_PER; ++j) {  // (every lane of the wave runs this: straight-line code around the wave-wide walk)
                 const double k = kk[j];
                 const uint32_t i = ii[j];
-                const uint32_t b = fr_bin(k, lo, scale);
+                const uint32_t b = bk_bin(k, lo, scale);
                 const bool sel = i != 0u && b <= bsel;
                 const bool above = have_goal && k > bb;  // above the candidate's path maximum: comes after it
                 const bool walk = sel && !above && (have_goal || check_alive);
                 if (sel && have_goal && k == bb) atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_TIE);
-                const int r = fr_check_wave(F.glink, VS, F.gkey, gp_path, gp_mp, have_goal, check_alive, walk ? i : 0u, sh);
+                int r = 1;
+                if (have_goal || check_alive) r = fr_check_wave(F.glink, VS, F.gkey, gp_path, gp_mp, have_goal, check_alive, walk ? i : 0u, sh);  // (uniform condition)
                 cls[j] = i == 0u ? -1 : (sel ? (above ? 3 : r) : 0);
                 mine += (cls[j] == 0 ? 1ull : 0ull) | (cls[j] == 1 ? (1ull << 32) : 0ull);
                 n_dead += cls[j] == 4 ? 1u : 0u;
                 n_drop += cls[j] == 3 ? 1u : 0u;
             }
             unsigned long long tot = 0;
-            const unsigned long long base = wg_scan_excl(mine, wsum64, lane, wave, n_waves, tot);  // (its barriers: every entry has been read)
+            const unsigned long long base = wg_scan_excl(mine, wsum64, lane, wave, n_waves, tot);  // (its barriers: every entry and every bin has been read)
+            if (use_hist && tid < BK_NB) bins[tid] = 0u;  // (clean for the next selection)
+            const uint32_t n_keep = (uint32_t)(tot & 0xffffffffull), n_rdy = (uint32_t)(tot >> 32);
+            if (tid == 0) {  // (the old list's key range has been read by everybody; nobody touches these words before the next barrier)
+                sh[FR_NEAR_N] = n_keep;
+                sh_st_d(sh, FR_NEAR_MIN, inf);
+                sh_st_d(sh, FR_NEAR_MAX, 0.0);
+            }
             {
                 uint32_t pk = (uint32_t)(base & 0xffffffffull), pr = (uint32_t)(base >> 32);
                 bool over[BK_PER];
@@ -801,7 +864,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                     if (cls[j] == 0) {
                         near_key[pk] = kk[j];
                         near_id[pk] = ii[j];
-                        near_mn = kk[j] < near_mn ? kk[j] : near_mn;
+                        near_mn = kk[j] < near_mn ? kk[j] : near_mn;  // (folded into the shared words at the end of the round)
                         near_mx = kk[j] > near_mx ? kk[j] : near_mx;
                         pk += 1u;
                     } else if (cls[j] == 1) {
@@ -814,23 +877,15 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                         pr += 1u;
                     }
                 }
+                if (n_rdy > RC) {  // (uniform)
 #pragma unroll
-                for (int j = 0; j < BK_PER; ++j) to_far(over[j], kk[j], ii[j]);
+                    for (int j = 0; j < BK_PER; ++j) to_far(over[j], kk[j], ii[j]);
+                }
             }
             if (n_dead) sh_add(sh, FR_DEAD, n_dead);
             if (n_drop) sh_add(sh, FR_DROPPED, n_drop);  // comes after the candidate: never popped
-            const uint32_t n_keep = (uint32_t)(tot & 0xffffffffull), n_rdy = (uint32_t)(tot >> 32);
-            __syncthreads();  // (near_min / near_max of the old list have been read by everybody)
-            if (tid == 0) {
-                sh[FR_NEAR_N] = n_keep;
-                sh[BK_R] = n_rdy < RC ? n_rdy : RC;
-                sh_st_d(sh, FR_NEAR_MIN, inf);
-                sh_st_d(sh, FR_NEAR_MAX, 0.0);
-            }
-            __syncthreads();
-            flush_near();
-            flush_far();
-            __syncthreads();
+            Rn = n_rdy < RC ? n_rdy : RC;
+            __syncthreads();  // the ready list and the compacted near are in place
             BK_TICK(tk_select)
         }
     }
@@ -850,7 +905,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         for (uint32_t i = (uint32_t)tid; i < nv; i += (uint32_t)bd) VS.g[i] = VS.l[i];
     }
     {  // work counters: one atomic per wave
-        unsigned long long a = t_checks, b = t_pairs;
+        unsigned long long a = t_checks, b = t_pairs;  // (a thread's share stays far below 2^32)
 #pragma unroll
         for (int o = PDMPC_WAVE / 2; o > 0; o >>= 1) {
             a += __shfl_xor(a, o);
@@ -866,7 +921,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         atomicAdd(A.work_count + 3, (unsigned long long)sh[FR_ROUNDS]);
         A.tree_size[slot] = (int32_t)(nnodes_raw | 0x40000000u);  // marks the arena as a raw tree (api.cpp reconstructs the reference's)
     }
-    if (tid == 0 && A.debug_tail) {  // diagnostics in the unused tail of the record (rows HP_MAX - 1, HP_MAX of path_nodes); PDMPC_DEBUG_TAIL=1
+    if (tid == 0 && A.debug_tail) {  // diagnostics in the unused tail of the record (rows HP_MAX - 2 .. HP_MAX of path_nodes); PDMPC_DEBUG_TAIL=1
         double* dbg = X.O->path_nodes[PDMPC_HP_MAX];
         dbg[0] = (double)sh[FR_ROUNDS];
         dbg[1] = (double)sh[FR_PROCESSED];
@@ -874,19 +929,18 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         dbg[3] = (double)sh[FR_NEAR_N];
         dbg[4] = (double)sh[FR_FAR_N];
         dbg[5] = (double)sh[FR_FLAGS];
-        dbg[6] = (double)(tk_work) + 1e-9 * (double)tk_select;
-        dbg[7] = (double)(__builtin_amdgcn_s_memrealtime() - tk_start);
-        tk_work += tk_p1 + tk_p2 + tk_p3;
-        X.O->path_nodes[PDMPC_HP_MAX - 2][0] = (double)(tk_start - X.rt_kernel_start);
-        X.O->path_nodes[PDMPC_HP_MAX - 2][1] = (double)tk_p1;
-        X.O->path_nodes[PDMPC_HP_MAX - 2][2] = (double)tk_p2;
-        X.O->path_nodes[PDMPC_HP_MAX - 2][3] = (double)tk_p3;
-        X.O->path_nodes[PDMPC_HP_MAX - 2][4] = (double)tk_pb;
-        X.O->path_nodes[PDMPC_HP_MAX - 1][0] = (double)tk_work;
-        X.O->path_nodes[PDMPC_HP_MAX - 1][1] = (double)tk_arrival;
-        X.O->path_nodes[PDMPC_HP_MAX - 1][2] = (double)tk_select;
-        X.O->path_nodes[PDMPC_HP_MAX - 1][3] = (double)tk_wait;
-        X.O->path_nodes[PDMPC_HP_MAX - 1][4] = (double)(tk_mark - tk_start);
+        dbg[6] = 0.0;
+        dbg[7] = (double)(__builtin_amdgcn_s_memrealtime() - tk[TK_START]);
+        X.O->path_nodes[PDMPC_HP_MAX - 2][0] = (double)(tk[TK_START] - X.rt_kernel_start);
+        X.O->path_nodes[PDMPC_HP_MAX - 2][1] = (double)tk[tk_p1];
+        X.O->path_nodes[PDMPC_HP_MAX - 2][2] = (double)tk[tk_p2];
+        X.O->path_nodes[PDMPC_HP_MAX - 2][3] = (double)tk[tk_p3];
+        X.O->path_nodes[PDMPC_HP_MAX - 2][4] = (double)tk[tk_pb];
+        X.O->path_nodes[PDMPC_HP_MAX - 1][0] = (double)(tk[tk_work] + tk[tk_p1] + tk[tk_p2] + tk[tk_p3]);
+        X.O->path_nodes[PDMPC_HP_MAX - 1][1] = (double)tk[tk_arrival];
+        X.O->path_nodes[PDMPC_HP_MAX - 1][2] = (double)tk[tk_select];
+        X.O->path_nodes[PDMPC_HP_MAX - 1][3] = (double)tk[tk_wait];
+        X.O->path_nodes[PDMPC_HP_MAX - 1][4] = (double)(tk[TK_MARK] - tk[TK_START]);
         X.O->path_nodes[PDMPC_HP_MAX - 1][5] = 0.0;
         X.O->path_nodes[PDMPC_HP_MAX - 1][6] = 0.0;
     }
@@ -907,7 +961,7 @@ __device__ __forceinline__ void bulk_body(const KernelArgs& A) {
     search_prologue(A, X, (LDS_AS unsigned char*)smem, true);
     X.rt_kernel_start = rt0;
     const int lane = X.lane, wave = X.wave;
-    lds_u32* ref_ids = (lds_u32*)(X.lsm + A.lds.bk_misc) + 224;  // behind the scan partials (nothing else uses those words)
+    lds_u32* ref_ids = (lds_u32*)(X.lsm + A.lds.bk_misc) + 224;  // behind the chunk table (nothing else uses those words)
     const bool tie = bulk_search<NW>(A, X, ref_ids);
     if (tie) {  // (uniform over the workgroup) reported with the internal status: the host plans the call again on the binary heap
         X.status = PDMPC_INTERNAL_TIE;

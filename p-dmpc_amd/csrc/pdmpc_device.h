@@ -93,7 +93,7 @@ struct LdsLayout {
     uint32_t bk_near_key, bk_near_id;      // double[BK_PER * threads], uint32[BK_PER * threads]: the LDS part of the open set
     uint32_t bk_ready;                     // uint32[bk_ready_cap] nodes of the round + uint32[bk_ready_cap] their collision flags
     uint32_t bk_hist;                      // uint32[3072]: histogram [2048] | goal list [1024], collision-free nodes of the round [1024], their children's offsets [1024]
-    uint32_t bk_misc;                      // 1 KB: path tables of the best goal candidate, scan partials, chunk table, the reference's ids along the path
+    uint32_t bk_misc;                      // 2 KB: path tables of the best goal candidate, scan partials, chunk table, the reference's ids along the path | the selection's 256-bin histogram
 };
 
 struct NodeArena {  // HBM arrays, per-vehicle stride = max_nodes entries
