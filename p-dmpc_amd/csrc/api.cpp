@@ -155,8 +155,10 @@ struct Tuning {
     int help_patience = 8;      // PDMPC_HELP_PATIENCE
     int help_expand_oversub = -1;  // PDMPC_HELP_EXPAND_OVERSUB (-1: up to two searches per CU)
     int bk_round0 = 24;         // PDMPC_BK_ROUND0: nodes a round of a young search takes (bulk kernel)
-    int bk_round = 256;         // PDMPC_BK_ROUND: the most a round takes (bulk kernel)
-    int bk_ramp = 4;            // PDMPC_BK_RAMP: a round grows by 1 / bk_ramp of the nodes processed so far
+    int bk_round = -1;          // PDMPC_BK_ROUND: the most a round takes (bulk kernel; -1: 1000 with helper workgroups, else 256)
+    int bk_tile = 64;           // PDMPC_BK_TILE: nodes of a tile of a shared round
+    int bk_share_min = 192;     // PDMPC_BK_SHARE_MIN: a round with at least this many nodes is shared with the helper workgroups
+    int bk_ramp = -1;           // PDMPC_BK_RAMP: a round grows by 1 / bk_ramp of the nodes processed so far (-1: 2 with helper workgroups, else 4)
     int fr_slice = -1;          // PDMPC_FR_SLICE (-1: only after a predecessor time-out, 0: never, 1: always when oversubscribed)
     int debug_host = 0;         // PDMPC_DEBUG_HOST
     int slot_order_reverse = 0; // PDMPC_TEST_REVERSE_DISPATCH: testing only, see launch_range
@@ -212,8 +214,10 @@ struct pdmpc_handle {
     bool force_frontier = false;  // this launch: the frontier kernel, which carries the binary heap (a search of the bulk kernel met a tie)
     bool last_launch_bulk = false;
     int last_first = 0, last_count = 0;  // slots of the last launch_range
-    uint32_t bulk_lds_hw[2] = {0, 0};    // dynamic LDS size set so far on the bulk kernel's variants (hipFuncSetAttribute is a maximum)
-    int bk_ready_cap = 1024;
+    uint32_t bulk_lds_hw[3] = {0, 0, 0}; // dynamic LDS size set so far on the bulk kernel's variants and its helper kernel (hipFuncSetAttribute is a maximum)
+    DevBuf<double> d_bk_post;            // bulk kernel: records posted for the helper workgroups (pdmpc_device.h)
+    int bk_ready_cap = 2048;     // entries of the bulk kernel's ready list with helper workgroups (PDMPC_BK_READY), half of it without
+    int bk_ready_launch = 2048;  // ... of the last layout
     int64_t tie_replans = 0;  // launches planned again with the heap-carrying kernel because a search of the bulk kernel met a tie
     int fr_round = 0, fr_near_fill = 2048, fr_near_max = 4096;  // measured on C2 / C3 (round cap 768): 1024/2048 -> 358 / 345 steps/s, 2048/4096 -> 369 / 357, 4096/8192 -> 356 / 351
     bool last_launch_frontier = false;
@@ -354,14 +358,19 @@ bool use_bulk(const pdmpc_handle* h) {
     return h->kernel_frontier && h->kernel_bulk && !h->force_frontier && !h->sampled_launch && h->cfg.checker == PDMPC_CHECK_INTERX;
 }
 
+// helper workgroups serve the bulk kernel's launches that leave CUs idle (launch_range)
+bool bulk_has_helpers(const pdmpc_handle* h, int n_launch) { return h->speculate && h->tune.helpers != 0 && n_launch <= h->n_cu - 2; }
+
 int compute_lds_bulk(pdmpc_handle* h, int n_launch, int soup_cap) {
+    // large rounds pay where helper workgroups share them; without helpers the LDS is better spent on node records
+    h->bk_ready_launch = bulk_has_helpers(h, n_launch) ? h->bk_ready_cap : std::max(256, h->bk_ready_cap / 2);
     for (int areas = 1; areas >= 0; --areas) {
         LdsLayout L{};
         uint32_t nv = 0, nl = 0;
-        if (!layout_bulk(h, kLdsMax, h->waves_latency, areas, soup_cap, L, nv, nl, (uint32_t)h->bk_ready_cap)) continue;
+        if (!layout_bulk(h, kLdsMax, h->waves_latency, areas, soup_cap, L, nv, nl, (uint32_t)h->bk_ready_launch)) continue;
         if (h->tune.debug_lds)
             fprintf(stderr, "pdmpc LDS layout (bulk): launch %d waves %d areas %d near %u ready %d nv %u nl %u total %u\n", n_launch, h->waves_latency, areas,
-                    PDMPC_BK_PER * (uint32_t)h->waves_latency * PDMPC_WAVE, h->bk_ready_cap, nv, nl, L.total);
+                    PDMPC_BK_PER * (uint32_t)h->waves_latency * PDMPC_WAVE, h->bk_ready_launch, nv, nl, L.total);
         h->lds = L;
         h->n_waves = h->waves_latency;
         h->HL = 0;
@@ -780,15 +789,20 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     const bool frontier = h->kernel_frontier && !h->sampled_launch;
     const bool bulk = use_bulk(h);
     a.bulk = bulk ? 1 : 0;
-    a.bk_ready_cap = h->bk_ready_cap;
+    a.bk_ready_cap = h->bk_ready_launch;
     a.bk_round0 = std::max(1, T.bk_round0);
-    a.bk_round = std::min(h->bk_ready_cap / 2, std::max(a.bk_round0, T.bk_round));
+    {
+        // measured on C2 / C3 (20 / 128 searches, helpers): cap 256, ramp 4 -> 646 / 589 steps/s; 512, 2 -> 735 / 786; 1000, 2 -> 769 / 909; 1000, 1 -> 620 / 772
+        const bool helped = bulk && bulk_has_helpers(h, count);
+        const int cap = T.bk_round > 0 ? T.bk_round : (helped ? 1000 : 256);
+        a.bk_round = std::min(h->bk_ready_launch / 2 - 16, std::max(a.bk_round0, cap));
+    }
     a.soup_cap = B.soup_cap;
     a.cand_cap = frontier ? h->fr_cand_cap : B.cand_cap;
     a.frontier = frontier ? 1 : 0;
     a.fr_round = h->fr_round > 0 ? h->fr_round : 768;  // cap of a round; measured on C2 / C3 (with the early-exit InterX): 256 -> 342 / 322 steps/s, 512 -> 355 / 342, 768 -> 358 / 345, 1024 -> 358 / 345
     a.fr_stage_cap = h->fr_stage_cap;
-    if (bulk) a.fr_ramp = std::max(1, T.bk_ramp);
+    if (bulk) a.fr_ramp = T.bk_ramp > 0 ? T.bk_ramp : (bulk_has_helpers(h, count) ? 2 : 4);
     else a.fr_ramp = T.fr_ramp > 0 ? T.fr_ramp : 4;  // a round grows by a quarter of the nodes done so far; measured on C2 / C3 (cap 768): 2 -> 331 / 354 steps/s, 3 -> 354 / 352, 4 -> 358 / 345, 6 -> 355 / 338
     a.fr_near_fill = h->fr_near_fill;
     a.fr_near_max = h->fr_near_max;
@@ -843,7 +857,7 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     a.fr_share_min = T.fr_share_min;
     a.fr_own_div = T.fr_own_div;
     a.help_chunk = T.help_chunk;  // (0: chosen below, once it is known whether the helpers expand)
-    if (frontier && !bulk && !h->sampled_launch && h->cfg.checker == PDMPC_CHECK_INTERX && h->speculate && !slice) {
+    if (frontier && !h->sampled_launch && h->cfg.checker == PDMPC_CHECK_INTERX && h->speculate && !slice) {
         // (measured on C2, 20 searches, / C3, 128: 8 helpers 535 / 476 steps/s, 16: 529 / 506, 32: 516 / 522, 128: 507 / 483)
         int want = std::min(h->helpers_max, std::max(32, count / 2));  // (helpers that expand: the owner of a shared round waits for them, more of them with shorter runs finish sooner)
         if (T.helpers >= 0) want = T.helpers;  // A/B switch (0: none): results are identical
@@ -857,8 +871,12 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
             a.n_helpers = count <= 2 * h->n_cu ? 96 : 32;
             if (T.helpers_oversub >= 0) a.n_helpers = std::min(T.helpers_oversub, h->n_cu / 2);
             if (T.helpers >= 0) a.n_helpers = std::min(a.n_helpers, T.helpers);  // (0 switches every helper off)
+            if (bulk) a.n_helpers = 0;  // (the bulk kernel's helpers serve launches that leave CUs idle)
         }
     }
+    a.bk_share_min = T.bk_share_min;
+    a.bk_tile = T.bk_tile;
+    a.bk_post = h->d_bk_post.p;
     a.help_board = h->d_help_board.p;
     a.help_list = h->d_help_list.p;
     a.help_verdict = h->d_help_verdict.p;
@@ -884,7 +902,7 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
         if (getenv("PDMPC_HELP_FIRST")) {  // diagnostic: the old order, helpers in front of the searches
             hipStream_t hst0 = count > h->n_cu ? h->help_stream_low : h->help_stream;
             HIPCHK(hipStreamWaitEvent(hst0, h->ev_help_pre, 0));
-            const int hrc0 = pdmpc_launch_helpers(&a, (void*)hst0);
+            const int hrc0 = bulk ? pdmpc_launch_bulk_helpers(&a, (void*)hst0, h->bulk_lds_hw) : pdmpc_launch_helpers(&a, (void*)hst0);
             if (hrc0 != 0) return fail(PDMPC_ERR_HIP, "helper kernel launch failed");
             HIPCHK(hipEventRecord(h->ev_help_done, hst0));
         }
@@ -928,7 +946,7 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
         // to have left (they leave as soon as the last search has published).
         hipStream_t hst = count > h->n_cu ? h->help_stream_low : h->help_stream;
         HIPCHK(hipStreamWaitEvent(hst, h->ev_help_pre, 0));
-        const int hrc = pdmpc_launch_helpers(&a, (void*)hst);
+        const int hrc = bulk ? pdmpc_launch_bulk_helpers(&a, (void*)hst, h->bulk_lds_hw) : pdmpc_launch_helpers(&a, (void*)hst);
         if (hrc != 0) return fail(PDMPC_ERR_HIP, std::string("helper kernel launch failed: ") + hipGetErrorString((hipError_t)hrc));
         HIPCHK(hipEventRecord(h->ev_help_done, hst));
         HIPCHK(hipStreamWaitEvent(h->stream, h->ev_help_done, 0));
@@ -976,8 +994,11 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
             h->kernel_bulk = std::string(e) != "frontier";
         }
         T.bk_round0 = std::max(1, env_i("PDMPC_BK_ROUND0", T.bk_round0));
-        T.bk_round = std::max(1, env_i("PDMPC_BK_ROUND", T.bk_round));
-        T.bk_ramp = std::max(1, env_i("PDMPC_BK_RAMP", T.bk_ramp));
+        if (getenv("PDMPC_BK_ROUND")) T.bk_round = std::max(1, env_i("PDMPC_BK_ROUND", 256));
+        if (getenv("PDMPC_BK_RAMP")) T.bk_ramp = std::max(1, env_i("PDMPC_BK_RAMP", 4));
+        T.bk_share_min = std::max(64, env_i("PDMPC_BK_SHARE_MIN", T.bk_share_min));
+        T.bk_tile = std::min(128, std::max(16, env_i("PDMPC_BK_TILE", T.bk_tile)));
+        h->bk_ready_cap = std::min(2048, std::max(256, env_i("PDMPC_BK_READY", h->bk_ready_cap))) & ~63;  // (the most a launch may use: launches without helpers lay out half of it)
         if (getenv("PDMPC_FR_ROUND")) h->fr_round = std::max(1, env_i("PDMPC_FR_ROUND", 0));
         if (getenv("PDMPC_FR_NEAR_FILL")) h->fr_near_fill = std::max(64, env_i("PDMPC_FR_NEAR_FILL", 0));
         if (getenv("PDMPC_FR_NEAR_MAX")) h->fr_near_max = std::max(256, env_i("PDMPC_FR_NEAR_MAX", 0));
@@ -1040,6 +1061,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
     bad |= h->d_out.ensure((size_t)h->max_vehicles) | h->d_flag.ensure((size_t)h->max_vehicles) | h->d_tree_size.ensure((size_t)h->max_vehicles) | h->d_tie_count.ensure(4) | h->d_work_count.ensure(8);
     bad |= h->d_help_board.ensure((size_t)h->max_vehicles * PDMPC_HB_WORDS) | h->d_help_list.ensure((size_t)h->max_vehicles * PDMPC_HELP_CAP) |
            h->d_help_verdict.ensure((size_t)h->max_vehicles * PDMPC_HELP_CAP) | h->d_help_cs.ensure((size_t)h->max_vehicles * PDMPC_HELP_CAP * 2) |  h->d_help_finished.ensure(16);
+    bad |= h->d_bk_post.ensure((size_t)h->max_vehicles * (size_t)h->bk_ready_cap * 6);
     bad |= h->d_trace.ensure((size_t)h->max_vehicles * (size_t)std::max(config->trace_pops, 1));
     if (bad) {
         pdmpc_destroy(h);
@@ -1086,6 +1108,7 @@ int pdmpc_destroy(pdmpc_handle* h) {
     h->d_help_list.release();
     h->d_help_verdict.release();
     h->d_help_cs.release();
+    h->d_bk_post.release();
     h->d_help_finished.release();
     h->d_random.release();
     h->d_trace.release();

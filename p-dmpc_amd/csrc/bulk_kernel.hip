@@ -81,18 +81,44 @@ struct BkCheck {
     int areas_in_lds, ll_base, ll_len, Hp;
 };
 
-// P1, the check items of ready[0 .. R): item = c * R + r (chunk-major), chunk c = S = 1 << ls consecutive segments of one of the
-// node's three soups (vehicle obstacles of its step and HDV sets against the area, lanelet boundary against the boundary-check
-// area: are_constraints_satisfied_interx.m:17-37).  chmax = chunks of the step with the most segments.  Lanes work alone.
-__device__ __forceinline__ void bk_check_items(const Search& S, const BkCheck& C, const lds_u32* ready, volatile lds_u32* r_flag, uint32_t R, int ls, uint32_t chmax, int tid, int nthreads) {
+// Where a check item finds its node: the owner of a search reads the tree (LDS copies where they exist), a workgroup that helps it
+// reads the 48-byte records the owner has posted for the round (staged in the helper's LDS).
+struct BkTreeSrc {
+    const Search* S;
+    const lds_u32* ready;
+    __device__ __forceinline__ void link(uint32_t r, uint32_t& parent, uint32_t& packed) const { piece_link(node_piece(*S, ready[r] - 1u, 3), parent, packed); }
+    __device__ __forceinline__ void pose(uint32_t, uint32_t parent, double& px, double& py, double& cs, double& sn) const {
+        const d2 pxy = node_piece(*S, parent - 1u, 0), pcs = node_piece(*S, parent - 1u, 2);
+        px = pxy.x;
+        py = pxy.y;
+        cs = pcs.x;
+        sn = pcs.y;
+    }
+};
+struct BkPostSrc {
+    const lds_d2* rec;  // [tile][3]: (x, y) and (cos, sin) of the parent, (parent | packed << 32 as bits, -)
+    __device__ __forceinline__ void link(uint32_t r, uint32_t& parent, uint32_t& packed) const { piece_link(d2{0.0, rec[3 * r + 2].x}, parent, packed); }
+    __device__ __forceinline__ void pose(uint32_t r, uint32_t, double& px, double& py, double& cs, double& sn) const {
+        const d2 pxy = rec[3 * r], pcs = rec[3 * r + 1];
+        px = pxy.x;
+        py = pxy.y;
+        cs = pcs.x;
+        sn = pcs.y;
+    }
+};
+
+// P1, the check items of the entries r0 .. r0 + R - 1: item = c * R + r (chunk-major), chunk c = S = 1 << ls consecutive segments of
+// one of the node's three soups (vehicle obstacles of its step and HDV sets against the area, lanelet boundary against the
+// boundary-check area: are_constraints_satisfied_interx.m:17-37).  chmax = chunks of the step with the most segments.  Lanes work alone.
+template <class Src>
+__device__ __forceinline__ void bk_check_items(const BkCheck& C, const Src& src, volatile lds_u32* r_flag, uint32_t r0, uint32_t R, int ls, uint32_t chmax, int tid, int nthreads) {
     const uint32_t items = R * chmax;
     const int Sg = 1 << ls;
     for (uint32_t item = (uint32_t)tid; item < items; item += (uint32_t)nthreads) {
-        const uint32_t c = item / R, r = item - c * R;
+        const uint32_t c = item / R, r = r0 + (item - c * R);
         if (r_flag[r] & 1u) continue;  // collides already: the reference's early out
-        const uint32_t i0 = ready[r] - 1u;
         uint32_t parent, packed;
-        piece_link(node_piece(S, i0, 3), parent, packed);
+        src.link(r, parent, packed);
         if (!parent) continue;  // the root has no edge (GraphSearch.m:137-139)
         const int k = NODE_K(packed), m = NODE_MAN(packed), ncols = NODE_COLS(packed);
         const int so = C.l_soff[k - 1], ho = C.l_hoff[k - 1];
@@ -117,8 +143,8 @@ __device__ __forceinline__ void bk_check_items(const Search& S, const BkCheck& C
             continue;
         }
         const int tn = left < Sg ? left : Sg;
-        const d2 pxy = node_piece(S, parent - 1u, 0), pcs = node_piece(S, parent - 1u, 2);
-        const double cc = pcs.x, ss = pcs.y, pX = pxy.x, pY = pxy.y;
+        double cc, ss, pX, pY;
+        src.pose(r, parent, pX, pY, cc, ss);
         const size_t abase = ((size_t)m * 3 + (size_t)which) * PDMPC_VMAX;
         d2 pt[PDMPC_VMAX];
 #pragma unroll
@@ -137,6 +163,13 @@ __device__ __forceinline__ void bk_check_items(const Search& S, const BkCheck& C
         }
         if (hit) r_flag[r] = 1u;
     }
+}
+
+// the chunk size (as a shift) with which the check items of R entries fit the workgroup once, at most 16 segments per item
+__device__ __forceinline__ int bk_chunk_shift(const lds_u32* chm, uint32_t R, uint32_t nthreads) {
+    int ls = 0;
+    while (ls < 4 && R * chm[ls] > nthreads) ++ls;
+    return ls;
 }
 
 // position of the rk-th set bit of mask (rk < popcount)
@@ -200,6 +233,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
     const int n = X.n, nw = NW > 0 ? NW : X.nw;
     const uint32_t OC = (uint32_t)(BK_PER * bd), RC = (uint32_t)A.bk_ready_cap;
     const uint32_t VCAP = 1024u;  // expansion groups per tile (vlist / voffs)
+    const uint32_t TILE = (uint32_t)A.bk_tile;  // entries of a tile of a shared round (what a helper workgroup claims at a time)
 
     // ---- LDS carve of the bulk region
     lds_f64* near_key = (lds_f64*)(X.lsm + A.lds.bk_near_key);
@@ -359,25 +393,112 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
     R.n_popped = 0;
     R.n_expanded = 0;
     bool pb_valid = false;
+    // shared rounds (helper workgroups)
+    unsigned long long* board = A.help_board + (size_t)slot * PDMPC_HB_WORDS;
+    uint32_t help_seq = 0;  // rounds shared so far (same value in every thread)
 
     for (;;) {
         // ================= a round =================
         if (Rn) {
             pb_valid = false;  // (the tree grows: phase B's result is stale)
-            // ---- P1: check items + sincos items
-            int ls = 0;
-            while (ls < 6 && Rn * chm[ls] > (uint32_t)bd) ++ls;  // the smallest chunk with which the items fit the workgroup once
-            if (ls > 4) ls = 4;                                   // (at most 16 segments per item: large rounds take several trips)
-            bk_check_items(S, CK, ready, r_flag, Rn, ls, chm[ls], tid, bd);
-            for (uint32_t r = (uint32_t)(bd - 1 - tid); r < Rn; r += (uint32_t)bd) {  // (from the last thread down: the first waves carry the first chunks)
-                const uint32_t i0 = ready[r] - 1u;
-                uint32_t parent, packed;
-                piece_link(node_piece(S, i0, 3), parent, packed);
-                if (NODE_K(packed) < Hp) {
-                    const d2 p1 = node_piece(S, i0, 1);
-                    double sn, cs;
-                    pdmpc_sincos(p1.x, &sn, &cs);  // expand_node.m:50-51
-                    node_store_cs(S, i0, cs, sn);
+            // ---- P1: check items + sincos items.  A large round is shared with the helper workgroups (CUs this launch leaves idle):
+            // the owner posts one 48-byte record per entry (what a check reads of the tree), keeps the first tiles of 64 entries and
+            // offers the others; helpers claim tiles (compare-and-swap on the board's ticket word, which carries the round's sequence
+            // number), mirror the search's soup in their LDS and leave one verdict word per entry.  What nobody has claimed when the
+            // owner is through with its part it does itself; then it waits for the claimed tiles.
+            const BkTreeSrc tsrc{&S, ready};
+            const uint32_t n_tiles = (Rn + TILE - 1u) / TILE;
+            const bool share = A.n_helpers > 0 && Rn >= (uint32_t)A.bk_share_min && P.n_pred <= 64;
+            uint32_t own_tiles = n_tiles;
+            if (share) {  // (uniform)
+                own_tiles = n_tiles / (uint32_t)A.fr_own_div > 0u ? n_tiles / (uint32_t)A.fr_own_div : 1u;
+                ++help_seq;
+                d2* post = (d2*)A.bk_post + (size_t)slot * RC * 3u;
+                for (uint32_t r = own_tiles * TILE + (uint32_t)tid; r < Rn; r += (uint32_t)bd) {
+                    uint32_t parent, packed;
+                    const d2 p3 = node_piece(S, ready[r] - 1u, 3);
+                    piece_link(p3, parent, packed);
+                    post[3 * r] = node_piece(S, parent - 1u, 0);
+                    post[3 * r + 1] = node_piece(S, parent - 1u, 2);
+                    post[3 * r + 2] = d2{p3.y, 0.0};
+                }
+                // every wave's stores must have reached L2 before thread 0 writes L2 back: a workgroup barrier alone does not wait for them
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) {
+                    const unsigned long long all = P.n_pred >= 64 ? ~0ull : ((1ull << P.n_pred) - 1ull);
+                    __hip_atomic_store(board + PDMPC_HB_N, (unsigned long long)Rn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(board + PDMPC_HB_MASK, all & ~sh_load64(sh, SH_PEND_LO), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(board + PDMPC_HB_DONE, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    __hip_atomic_store(board + PDMPC_HB_TICKET, ((unsigned long long)help_seq << 32) | ((unsigned long long)n_tiles << 16) | own_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            uint32_t closed = n_tiles;  // tiles own_tiles .. closed - 1 are with the helpers
+#pragma unroll 1
+            for (int pass = 0; pass < (share ? 2 : 1); ++pass) {  // (one call site: the check items are instantiated once)
+                uint32_t rb = 0, Rr = own_tiles * TILE < Rn ? own_tiles * TILE : Rn;
+                if (pass == 1) {
+                    __syncthreads();
+                    if (tid == 0) {  // close the shared part: what no helper has claimed is the owner's
+                        unsigned long long cur = __hip_atomic_load(board + PDMPC_HB_TICKET, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        uint32_t cl = n_tiles;
+                        for (;;) {
+                            const uint32_t idx = (uint32_t)(cur & 0xffffull);
+                            if (idx >= n_tiles) break;
+                            if (__hip_atomic_compare_exchange_strong(board + PDMPC_HB_TICKET, &cur, ((unsigned long long)help_seq << 32) | ((unsigned long long)n_tiles << 16) | n_tiles,
+                                                                     __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                                cl = idx;
+                                break;
+                            }
+                        }
+                        sh[FR_HELP_CLOSED] = cl;
+                    }
+                    __syncthreads();
+                    closed = sh[FR_HELP_CLOSED];
+                    rb = closed * TILE;
+                    Rr = closed < n_tiles ? Rn - rb : 0u;  // the remainder
+                }
+                const int ls = bk_chunk_shift(chm, Rr, (uint32_t)bd);
+                bk_check_items(CK, tsrc, r_flag, rb, Rr, ls, chm[ls], tid, bd);
+                if (pass == 0) {
+                    for (uint32_t r = (uint32_t)(bd - 1 - tid); r < Rn; r += (uint32_t)bd) {  // (from the last thread down: the first waves carry the first chunks)
+                        const uint32_t i0 = ready[r] - 1u;
+                        uint32_t parent, packed;
+                        piece_link(node_piece(S, i0, 3), parent, packed);
+                        if (NODE_K(packed) < Hp) {
+                            const d2 p1 = node_piece(S, i0, 1);
+                            double sn, cs;
+                            pdmpc_sincos(p1.x, &sn, &cs);  // expand_node.m:50-51
+                            node_store_cs(S, i0, cs, sn);
+                        }
+                    }
+                }
+            }
+            if (share) {
+                const uint32_t n_claimed = closed - own_tiles;
+                if (tid == 0) {
+                    if (n_claimed) {  // wait for the helpers' tiles
+                        uint32_t spins = 0;
+                        while (__hip_atomic_load(board + PDMPC_HB_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)n_claimed) {
+                            __builtin_amdgcn_s_sleep(2);
+                            if (++spins > A.spin_limit) {
+                                atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_BUG);  // reported as an error status: must never happen
+                                break;
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    }
+                    atomicAdd(A.work_count + 4, 1ull);
+                    atomicAdd(A.work_count + 5, (unsigned long long)((closed * TILE < Rn ? closed * TILE : Rn) - own_tiles * TILE));
+                }
+                __syncthreads();
+                const uint32_t* hverdict = A.help_verdict + (size_t)slot * PDMPC_HELP_CAP;
+                const uint32_t re = closed * TILE < Rn ? closed * TILE : Rn;
+                for (uint32_t r = own_tiles * TILE + (uint32_t)tid; r < re; r += (uint32_t)bd) {  // 1 collision-free, 2 collides
+                    const uint32_t v = __hip_atomic_load(hverdict + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v != 1u && v != 2u) atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_BUG);  // (claimed, reported finished, and no verdict)
+                    r_flag[r] = v == 2u ? 1u : 0u;
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -416,7 +537,10 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                         if (alive) {
                             node_store_cs(S, i0, b1, 0.0);
                             const uint32_t pos = sh_add(sh, FR_GOAL_N, 1u);
-                            if (pos < 1024u) F.goal_list[pos] = id;
+                            if (pos < 1024u)
+                                F.goal_list[pos] = id;
+                            else
+                                atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_GOALS_LOST);  // (more than a thousand candidates in one round: looked up again in the tree below)
                         }
                     } else if (valid) {
                         const lds_mask64* mrow = EE.l_mask + ((size_t)k * n + (NODE_TRIM(packed) - 1)) * nw;
@@ -536,7 +660,38 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         flush_far();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // ---- the barrier that ends the round
+        if (sh[FR_GOAL_N] > 1024u) {  // (uniform; the list holds the first 1024)
+            __syncthreads();
+            if (tid == 0) sh[FR_GOAL_N] = 1024u;
+            __syncthreads();
+        }
         fr_resolve_goals(F, S, tid, lane, wave);
+        if (sh[FR_FLAGS] & FRF_GOALS_LOST) {  // (uniform) candidates were lost: every collision-free node at the horizon is offered again
+            __syncthreads();
+            if (tid == 0) {
+                sh[FR_BEST_ID] = 0;
+                sh[FR_PATH_FOR] = 0;
+                sh[FR_FLAGS] = sh[FR_FLAGS] & ~FRF_GOALS_LOST;
+            }
+            __syncthreads();
+            uint32_t nn = sh[FR_NNODES];
+            nn = nn < S.max_nodes ? nn : S.max_nodes;
+            for (uint32_t base = 0; base < nn; base += (uint32_t)bd) {  // (uniform trip count: barriers inside)
+                const uint32_t b = base + (uint32_t)wave * PDMPC_WAVE;
+                const uint32_t i0 = b + (uint32_t)lane;
+                const bool in = i0 < nn;
+                const uint32_t j0 = in ? i0 : 0u;
+                const bool cand = in && vs_load(VS, j0) == VS_VALID && NODE_K(((const uint32_t*)(S.gn + j0))[15]) == Hp;
+                unsigned long long bc = __ballot(cand);
+                while (bc) {
+                    const int l = __builtin_ctzll(bc);
+                    bc &= bc - 1;
+                    fr_offer_goal(F, S, VS, b + (uint32_t)l + 1u, lane);
+                }
+                __syncthreads();  // at most blockDim candidates per pass: the list cannot overflow
+                fr_resolve_goals(F, S, tid, lane, wave);
+            }
+        }
         BK_TICK(tk_work)
 
         // ================= round boundary (every thread; decisions are uniform) =====================================
@@ -953,6 +1108,194 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
     return false;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Helper workgroups of the bulk kernel (pdmpc_bulk_helper_kernel, launched next to the searches on a stream of its own): they look
+// for a search that has posted a round, claim a tile of TILE entries, mirror that search's obstacle soup in their own LDS
+// (literal obstacles, lanelet boundary, the areas of the predecessors the owner had incorporated when it posted), run the
+// tile's check items — the owner's own code on the posted records — and leave one verdict word per entry.  A helper never waits
+// for anything but memory, so an owner that waits for claimed tiles always gets them; helpers leave when every search of the
+// launch has published.
+__device__ __forceinline__ void bulk_helper_body(const KernelArgs& A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    LDS_AS unsigned char* lsm = (LDS_AS unsigned char*)smem;
+    const int tid = threadIdx.x, lane = tid & (PDMPC_WAVE - 1), wave = uni_i(tid >> 6), bd = (int)blockDim.x;
+    const int Hp = A.Hp, n_s = A.n_searches;
+    const uint32_t TILE = (uint32_t)A.bk_tile;
+    // the owners' carve (search_prologue): only the regions a check item reads are filled
+    lds_u32* l_path = (lds_u32*)(lsm + A.lds.path);
+    lds_i32* l_soff = (lds_i32*)(l_path + PDMPC_HP_MAX + 2);
+    lds_i32* l_hoff = l_soff + PDMPC_HP_MAX + 1;
+    volatile lds_u32* hs = (volatile lds_u32*)(l_hoff + PDMPC_HP_MAX + 1);
+    lds_i32* l_lit = (lds_i32*)(hs + SH_WORDS);
+    lds_d2* l_soup = (lds_d2*)(lsm + A.lds.soup);
+    lds_d2* t_rec = (lds_d2*)(lsm + A.lds.bk_near_key);              // [bk_tile][3] the tile's posted records
+    volatile lds_u32* t_flag = (volatile lds_u32*)(lsm + A.lds.bk_ready);  // [bk_tile] collision flags
+    lds_u32* chm = (lds_u32*)(lsm + A.lds.bk_misc) + 192;
+    BkCheck CK;
+    CK.l_area = (const lds_d2*)(lsm + A.lds.area);
+    CK.g_area = (const d2*)A.man_area;
+    CK.l_soup = l_soup;
+    CK.l_soff = l_soff;
+    CK.l_hoff = l_hoff;
+    CK.areas_in_lds = A.areas_in_lds;
+    CK.ll_base = 0;
+    CK.ll_len = 0;
+    CK.Hp = Hp;
+    if (A.areas_in_lds) stage16(lsm + A.lds.area, A.man_area, A.n_man * 3 * PDMPC_VMAX, tid);
+    if (tid < SH_WORDS) hs[tid] = 0;
+    __syncthreads();
+    int cur_slot = -1;
+    unsigned long long cur_mask = 0;
+    const int pref = (int)blockIdx.x % n_s;  // where this helper starts to look
+    SpecCtx P;
+    P.sh = hs;
+    P.l_soup = l_soup;
+    P.l_soff = l_soff;
+    P.l_lit = l_lit;
+    P.out = A.out;
+    P.pred = A.pred;
+    P.counters = A.tie_count;
+    P.n_pred = 0;
+    P.Hp = Hp;
+    uint32_t idle = 0;
+    for (;;) {
+        // ---- look for work: one lane per search, the first one (from pref on) with an unclaimed tile is tried
+        if (wave == 0) {
+            uint32_t cmd = 0;
+            for (int base = 0; base < n_s; base += PDMPC_WAVE) {  // (uniform trip count)
+                const int k = base + lane;
+                const int s_rel = k < n_s ? (pref + k) % n_s : 0;
+                unsigned long long* b = A.help_board + (size_t)(A.first + s_rel) * PDMPC_HB_WORDS;
+                // one word holds the round's sequence number, its tiles and the next unclaimed one
+                unsigned long long word = __hip_atomic_load(b + PDMPC_HB_TICKET, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t nt = (uint32_t)((word >> 16) & 0xffffull), idx = (uint32_t)(word & 0xffffull);
+                const bool has = k < n_s && (word >> 32) != 0ull && idx < nt;
+                const unsigned long long m = __ballot(has);
+                const int l = m ? (int)__builtin_ctzll(m) : -1;
+                if (lane == l) {  // (one lane; what it finds goes through LDS)
+                    if (__hip_atomic_compare_exchange_strong(b + PDMPC_HB_TICKET, &word, word + 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        const unsigned long long mask = __hip_atomic_load(b + PDMPC_HB_MASK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        hs[HS_SLOT] = (uint32_t)(A.first + s_rel);
+                        hs[HS_FIRST] = idx;
+                        hs[HS_COUNT] = (uint32_t)__hip_atomic_load(b + PDMPC_HB_N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        hs[HS_MASK_LO] = (uint32_t)mask;
+                        hs[HS_MASK_HI] = (uint32_t)(mask >> 32);
+                        hs[HS_CMD] = 1;
+                    }
+                }
+                wave_sync();
+                cmd = uni_u(hs[HS_CMD]);
+                if (cmd) break;  // (uniform)
+            }
+            if (!cmd) {
+                const uint32_t fin = __hip_atomic_load(A.help_finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0 && fin >= (uint32_t)n_s) hs[HS_CMD] = 2;
+            } else {
+                // what the owner wrote before it posted (and the predecessors it had seen) is visible from here on; not on an idle
+                // poll: the fence empties this XCD's L2, which searches on neighbouring CUs share
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+        }
+        __syncthreads();
+        const uint32_t cmd = hs[HS_CMD];
+        if (cmd == 2u) break;
+        if (cmd == 0u) {
+            if (idle < 64u)
+                __builtin_amdgcn_s_sleep(2);
+            else
+                __builtin_amdgcn_s_sleep(32);
+            if (++idle > (A.spin_limit >> 4)) break;  // (uniform) the searches never came: leave; they do without helpers
+            __syncthreads();
+            continue;
+        }
+        idle = 0;
+        const int slot = (int)hs[HS_SLOT];
+        const uint32_t tile = hs[HS_FIRST], Rn = hs[HS_COUNT];
+        const unsigned long long mask = ((unsigned long long)hs[HS_MASK_HI] << 32) | hs[HS_MASK_LO];
+        const DevVehicle* __restrict__ V = A.veh + slot;
+        // ---- the search's obstacle soup (search_prologue, parts 3 and 4)
+        if (slot != cur_slot) {
+            const int pred_cols = V->n_pred * PDMPC_VMAX;
+            int off = 0;
+            for (int k = 0; k < Hp; ++k) {
+                const int a = V->lit_off[k], b = V->lit_off[k + 1];
+                if (tid == 0) {
+                    l_soff[k] = off;
+                    l_lit[k] = b - a;
+                }
+                stage16(l_soup + off, (const d2*)A.points + a, b - a, tid);
+                off += (b - a) + pred_cols;
+            }
+            if (tid == 0) l_soff[Hp] = off;
+            for (int k = 0; k < Hp; ++k) {
+                const int a = V->hdv_off[k], b = V->hdv_off[k + 1];
+                if (tid == 0) l_hoff[k] = off;
+                stage16(l_soup + off, (const d2*)A.points + a, b - a, tid);
+                off += (b - a);
+            }
+            if (tid == 0) l_hoff[Hp] = off;
+            stage16(l_soup + off, (const d2*)A.points + V->ll_off, V->ll_len, tid);
+            CK.ll_base = off;
+            CK.ll_len = V->ll_len;
+            __syncthreads();
+            const d2 nanpt = d2{__longlong_as_double(0x7ff8000000000000LL), __longlong_as_double(0x7ff8000000000000LL)};
+            for (int idx = tid; idx < Hp * pred_cols; idx += bd) {
+                const int k = idx / pred_cols;
+                l_soup[l_soff[k] + l_lit[k] + (idx - k * pred_cols)] = nanpt;
+            }
+            __syncthreads();
+            P.pred = A.pred + V->pred_off;
+            P.n_pred = V->n_pred;
+            incorporate_areas(P, mask, tid);
+            __syncthreads();
+            if (tid < 8) {  // the chunk table of this soup (bulk_search)
+                const int ls = tid;
+                uint32_t mx = 0;
+                for (int k = 1; k <= Hp; ++k) {
+                    const int M_k = l_soff[k] - l_soff[k - 1], Hk = l_hoff[k] - l_hoff[k - 1];
+                    const int n0 = M_k > 1 ? M_k - 1 : 0, n1 = Hk > 1 ? Hk - 1 : 0, n2 = CK.ll_len > 1 ? CK.ll_len - 1 : 0;
+                    const int Sg = 1 << ls;
+                    const uint32_t ch = (uint32_t)(((n0 + Sg - 1) >> ls) + ((n1 + Sg - 1) >> ls) + ((n2 + Sg - 1) >> ls));
+                    mx = ch > mx ? ch : mx;
+                }
+                chm[ls] = mx;
+            }
+            cur_slot = slot;
+            cur_mask = mask;
+        } else if (mask != cur_mask) {
+            incorporate_areas(P, mask & ~cur_mask, tid);  // (within a launch a search's set of incorporated predecessors only grows)
+            cur_mask = mask;
+        }
+        // ---- the tile: its records into LDS, its check items, its verdicts
+        const uint32_t rb = tile * TILE, Rt = Rn - rb < TILE ? Rn - rb : TILE;
+        {
+            const d2* post = (const d2*)A.bk_post + ((size_t)slot * (size_t)A.bk_ready_cap + rb) * 3u;
+            for (uint32_t i = (uint32_t)tid; i < Rt * 3u; i += (uint32_t)bd) t_rec[i] = post[i];
+            if ((uint32_t)tid < TILE) t_flag[tid] = 0u;
+        }
+        __syncthreads();
+        {
+            const BkPostSrc psrc{t_rec};
+            const int ls = bk_chunk_shift(chm, Rt, (uint32_t)bd);
+            bk_check_items(CK, psrc, t_flag, 0u, Rt, ls, chm[ls], tid, bd);
+        }
+        __syncthreads();
+        {
+            uint32_t* verdict = A.help_verdict + (size_t)slot * PDMPC_HELP_CAP + rb;
+            if ((uint32_t)tid < Rt) __hip_atomic_store(verdict + tid, (t_flag[tid] & 1u) ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's verdicts have reached L2 (the barrier alone does not wait for them) ...
+        __syncthreads();                                     // ... every wave's have: thread 0 can write L2 back and report
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_fetch_add(A.help_board + (size_t)slot * PDMPC_HB_WORDS + PDMPC_HB_DONE, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hs[HS_CMD] = 0;
+        }
+        __syncthreads();
+    }
+}
+
 template <int NW>
 __device__ __forceinline__ void bulk_body(const KernelArgs& A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -980,6 +1323,20 @@ __device__ __forceinline__ void bulk_body(const KernelArgs& A) {
 
 extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) void pdmpc_bulk_kernel(const KernelArgs A) { bulk_body<1>(A); }
 extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) void pdmpc_bulk_kernel_wide(const KernelArgs A) { bulk_body<0>(A); }
+
+extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) void pdmpc_bulk_helper_kernel(const KernelArgs A) { bulk_helper_body(A); }
+
+extern "C" int pdmpc_launch_bulk_helpers(const KernelArgs* args, void* stream, uint32_t* lds_high_water) {
+    if (args->n_helpers <= 0) return 0;
+    uint32_t& have = lds_high_water[2];
+    if (args->lds.total > have) {
+        hipError_t e = hipFuncSetAttribute((const void*)pdmpc_bulk_helper_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)args->lds.total);
+        if (e != hipSuccess) return (int)e;
+        have = args->lds.total;
+    }
+    hipLaunchKernelGGL(pdmpc_bulk_helper_kernel, dim3(args->n_helpers), dim3(PDMPC_WAVE * args->n_waves), args->lds.total, (hipStream_t)stream, *args);
+    return (int)hipGetLastError();
+}
 
 extern "C" int pdmpc_launch_bulk(const KernelArgs* args, int count, void* stream, uint32_t* lds_high_water) {
     if (count <= 0) return 0;

@@ -40,9 +40,22 @@
 #define FRF_TIE 2u
 #define FRF_INVALIDATED 4u
 #define FRF_BUG 8u
+#define FRF_GOALS_LOST 16u  // bulk kernel: a round had more goal candidates than its list holds: every collision-free node at the horizon is offered again
 #define FR_SCRATCH 64   // 64 scratch words behind the shared block (targets of the lanes that only take part pro forma, see sh_add_uniform)
 #define FR_NBINS 2048
 #define FR_READY_CAP 1536
+
+// words of a helper workgroup's shared block
+#define HS_CMD 0     // 0 nothing found, 1 work, 2 every search has finished
+#define HS_SLOT 1
+#define HS_FIRST 2
+#define HS_COUNT 3
+#define HS_MASK_LO 4
+#define HS_MASK_HI 5
+#define HS_TICKET 6
+#define HS_EXPAND 7  // the claimed round wants its collision-free entries expanded
+#define HS_RUN_BASE 8   // first node index of the block the run's children get
+#define HS_RUN_TOTAL 9  // children of the run
 
 namespace {
 

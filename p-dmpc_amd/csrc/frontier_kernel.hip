@@ -913,16 +913,6 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
 // boundary, the areas of the predecessors the owner had incorporated when it posted), check the entries' edges with the
 // search's own device function and leave one verdict byte per entry.  A helper never waits for anything but memory, so an
 // owner that waits for claimed entries always gets them; helpers leave when every search of the launch has published.
-#define HS_CMD 0     // 0 nothing found, 1 work, 2 every search has finished
-#define HS_SLOT 1
-#define HS_FIRST 2
-#define HS_COUNT 3
-#define HS_MASK_LO 4
-#define HS_MASK_HI 5
-#define HS_TICKET 6
-#define HS_EXPAND 7  // the claimed round wants its collision-free entries expanded
-#define HS_RUN_BASE 8   // first node index of the block the run's children get
-#define HS_RUN_TOTAL 9  // children of the run
 template <int CHECKER>
 __device__ __forceinline__ void helper_body(const KernelArgs& A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

@@ -192,6 +192,9 @@ struct KernelArgs {
     int32_t bk_ready_cap;   // entries of the ready list (a round's nodes)
     int32_t bk_round0;      // nodes a round of a young search takes
     int32_t bk_round;       // ... and the most any round takes
+    int32_t bk_tile;        // entries of a tile of a shared round (what a helper workgroup claims at a time; at most 128)
+    int32_t bk_share_min;   // a round with at least this many entries is shared with the helper workgroups
+    double* bk_post;        // [slot][bk_ready_cap][3] double2: what a check item reads of the tree, posted per entry of a shared round
     int32_t speculate;  // 1: start searching before all predecessors have finished (results are identical, see arrival_sync)
     uint32_t spin_limit;
     int32_t reverse_dispatch;  // testing only (PDMPC_TEST_REVERSE_DISPATCH): workgroup b plans slot first + n_searches - 1 - b, i.e. successors are
@@ -212,6 +215,8 @@ int pdmpc_launch_sampled(const KernelArgs* args, int count, void* stream);
 int pdmpc_launch_frontier(const KernelArgs* args, int count, void* stream);
 // defined in bulk_kernel.hip: the search as bulk-synchronous passes; lds_high_water[2] = the handle's record of the dynamic LDS size set so far per kernel variant
 int pdmpc_launch_bulk(const KernelArgs* args, int count, void* stream, uint32_t* lds_high_water);
+// ... and its helper workgroups (args->n_helpers of them; they serve the searches of a pdmpc_launch_bulk with the same args)
+int pdmpc_launch_bulk_helpers(const KernelArgs* args, void* stream, uint32_t* lds_high_water);
 // defined in frontier_kernel.hip; launches args->n_helpers helper workgroups (they serve the searches of a pdmpc_launch_frontier with the same args)
 int pdmpc_launch_helpers(const KernelArgs* args, void* stream);
 // defined in debug_kernels.hip: the collision primitives of edge_checks.hpp on given polygons, one wavefront per case
