@@ -157,6 +157,10 @@ __device__ __forceinline__ void bk_check_items(const BkCheck& C, const Src& src,
         d2 q0 = q[0];
         bool hit = false;
         for (int t = 0; t < tn; ++t) {
+            // (the area's points are made opaque per segment: the compiler would otherwise hoist the seven edges' dx1, dy1, S1 of the
+            // C1 test out of this loop — 42 registers for a test that one segment in ten reaches)
+            asm volatile("" : "+v"(pt[0].x), "+v"(pt[0].y), "+v"(pt[1].x), "+v"(pt[1].y), "+v"(pt[2].x), "+v"(pt[2].y), "+v"(pt[3].x), "+v"(pt[3].y), "+v"(pt[4].x), "+v"(pt[4].y),
+                         "+v"(pt[5].x), "+v"(pt[5].y), "+v"(pt[6].x), "+v"(pt[6].y), "+v"(pt[7].x), "+v"(pt[7].y));
             const d2 q1 = q[t + 1];
             hit = hit || interx_segment_n<PDMPC_VMAX>(pt, ncols - 1, q0, q1);
             q0 = q1;
@@ -176,6 +180,50 @@ __device__ __forceinline__ int bk_chunk_shift(const lds_u32* chm, uint32_t R, ui
 __device__ __forceinline__ int nth_bit(uint64_t mask, int rk) {
     for (int b = 0; b < rk; ++b) mask &= mask - 1ull;
     return (int)__builtin_ctzll(mask);
+}
+
+// Late predecessors (PrioritizedController.m:476-491): the collision-free nodes against the areas of the predecessors in `arr`,
+// which have just entered the soup.  item = (node, arrived predecessor): the edge's area is transformed once, the predecessor's
+// polygon of the node's step goes through interx_segment_n segment by segment (InterX.m:63-76 restricted to those polygons).
+// list == nullptr: the nodes are 0 .. count - 1 themselves (small trees: no gathering pass), the others are skipped.
+__device__ __forceinline__ void bk_recheck_items(const Search& S, const VState& VS, const BkCheck& C, const SpecCtx& P, const lds_u32* list, uint32_t count, unsigned long long arr,
+                                                 volatile lds_u32* sh, int tid, int nthreads) {
+    const uint32_t n_arr = (uint32_t)__builtin_popcountll(arr), items = count * n_arr;
+    for (uint32_t item = (uint32_t)tid; item < items; item += (uint32_t)nthreads) {
+        const uint32_t v = item / n_arr, a = item - v * n_arr;
+        const uint32_t i0 = list ? list[v] : v;
+        if (vs_load(VS, i0) != VS_VALID) continue;
+        uint32_t parent, packed;
+        piece_link(node_piece(S, i0, 3), parent, packed);
+        if (!parent) continue;
+        const int p = nth_bit(arr, (int)a);
+        const int k = NODE_K(packed), m = NODE_MAN(packed), ncols = NODE_COLS(packed);
+        const d2 pxy = node_piece(S, parent - 1u, 0), pcs = node_piece(S, parent - 1u, 2);
+        const double cc = pcs.x, ss = pcs.y, pX = pxy.x, pY = pxy.y;
+        const size_t abase = (size_t)m * 3 * PDMPC_VMAX;
+        d2 pt[PDMPC_VMAX];
+#pragma unroll
+        for (int i = 0; i < PDMPC_VMAX; ++i) {
+            const d2 ar = C.areas_in_lds ? (d2)C.l_area[abase + i] : C.g_area[abase + i];
+            pt[i].x = cc * ar.x - ss * ar.y + pX;  // GraphSearch.m:158
+            pt[i].y = ss * ar.x + cc * ar.y + pY;  // :159
+        }
+        const lds_d2* poly = P.l_soup + P.l_soff[k - 1] + P.l_lit[k - 1] + p * PDMPC_VMAX;
+        d2 q0 = poly[0];
+        bool hit = false;
+#pragma unroll 1
+        for (int j = 0; j + 1 < PDMPC_VMAX; ++j) {
+            asm volatile("" : "+v"(pt[0].x), "+v"(pt[0].y), "+v"(pt[1].x), "+v"(pt[1].y), "+v"(pt[2].x), "+v"(pt[2].y), "+v"(pt[3].x), "+v"(pt[3].y), "+v"(pt[4].x), "+v"(pt[4].y),
+                         "+v"(pt[5].x), "+v"(pt[5].y), "+v"(pt[6].x), "+v"(pt[6].y), "+v"(pt[7].x), "+v"(pt[7].y));  // (as in bk_check_items)
+            const d2 q1 = poly[j + 1];
+            hit = hit || interx_segment_n<PDMPC_VMAX>(pt, ncols - 1, q0, q1);
+            q0 = q1;
+        }
+        if (hit) {
+            vs_store(VS, i0, VS_INVALID);
+            atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_INVALIDATED);
+        }
+    }
 }
 
 // monotone map key -> bin of a linear histogram of BK_NB bins over [lo, lo + BK_NB / scale)
@@ -216,6 +264,104 @@ __device__ __forceinline__ void bk_select(const lds_u32* bins, uint32_t target, 
     const uint32_t bb = lane_u(b, l), cc = lane_u(cu, l);
     bin = m ? bb : 0u;
     cum = m ? cc : 0u;
+}
+
+// The result record (GraphSearch.m:58-59, 82-89; return_path_to.m; return_path_area.m), written by the first wave.  A search that
+// has finished while predecessors are still planning writes it right away: an arrival that invalidates nothing leaves it as it
+// is, and the publication that follows the last arrival is one flag.  `again`: a record of this search was written before
+// (its fields are reset first).  l_path[i] = node (1-based index into this vehicle's arena) of step i along the selected path
+// (walked here unless path_ready); ref_ids = the ids those nodes carry in the reference's tree (info.tree_path).
+__device__ __forceinline__ void bk_write_record(const KernelArgs& A, Ctx& X, uint32_t goal, int status, bool dep_timeout, uint32_t n_popped, uint32_t nnodes, bool path_ready,
+                                                const lds_u32* ref_ids, bool again) {
+    const int lane = X.lane, Hp = X.Hp;
+    const DevVehicle* __restrict__ V = X.V;
+    pdmpc_vehicle_out* __restrict__ O = X.O;
+    lds_u32* l_path = X.l_path;
+    const Search& S = X.S;
+    if (again) {  // as the prologue left it: zeros, y_predicted NaN (ControlResultsInfo.m:40)
+        double* od = (double*)O;
+        const int nd = (int)(offsetof(pdmpc_vehicle_out, path_nodes) / 8) + (PDMPC_HP_MAX - 2) * 8;  // (the diagnostics rows of the tail stay)
+        const int y0 = (int)(offsetof(pdmpc_vehicle_out, y_predicted) / 8);
+        const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+        for (int i = lane; i < nd; i += PDMPC_WAVE) od[i] = (i >= y0 && i < y0 + PDMPC_HP_MAX * 3) ? qnan : 0.0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the result stores below hit the same bytes from other lanes
+    }
+    if (goal) {
+        if (lane == 0 && !path_ready) {  // path_to_root (Tree.m:44-52), reversed
+            uint32_t nd = goal;
+            for (int i = Hp; i >= 0; --i) {
+                l_path[i] = nd;
+                nd = node_parent(S, nd - 1);
+            }
+        }
+        wave_sync();
+        if (lane <= Hp) {
+            const uint32_t nd = l_path[lane];
+            const NodeRec r = node_load(S, nd - 1);
+            O->tree_path[lane] = (int32_t)(ref_ids ? ref_ids[lane] : nd);
+            double* row = O->path_nodes[lane];  // NodeInfo.m:5-13
+            row[0] = r.x;
+            row[1] = r.y;
+            row[2] = r.yaw;
+            row[3] = (double)NODE_TRIM(r.packed);
+            row[4] = r.g;
+            row[5] = r.h;
+            row[6] = (double)NODE_K(r.packed);
+            row[7] = 1.0;
+            if (lane >= 1) {
+                O->y_predicted[lane - 1][0] = r.x;
+                O->y_predicted[lane - 1][1] = r.y;
+                O->y_predicted[lane - 1][2] = r.yaw;
+                O->predicted_trims[lane - 1] = (int32_t)NODE_TRIM(r.packed);
+            }
+        }
+        // shapes along the path: same arithmetic as at pop time (GraphSearch.m:158-160), so the same bits
+        for (int idx = lane; idx < Hp * PDMPC_VMAX; idx += PDMPC_WAVE) {
+            const int i = idx / PDMPC_VMAX + 1;
+            const int v = idx - (i - 1) * PDMPC_VMAX;
+            const NodeRec pr = node_load(S, l_path[i - 1] - 1);
+            const NodeRec cr = node_load(S, l_path[i] - 1);
+            const int m = NODE_MAN(cr.packed);
+            const int ncols = NODE_COLS(cr.packed);
+            if (v == 0) O->shape_cols[i - 1] = ncols;
+            if (v < ncols) {
+                const d2 a = X.C.g_area[(size_t)m * 3 * PDMPC_VMAX + v];
+                O->shapes[i - 1][0][v] = pr.cs * a.x - pr.sn * a.y + pr.x;
+                O->shapes[i - 1][1][v] = pr.sn * a.x + pr.cs * a.y + pr.y;
+            }
+        }
+    } else if (V->fb_off[0] >= 0) {
+        // exhausted: publish the caller-supplied fallback areas so successors of this launch avoid them (PrioritizedController.m:568-616, 678-718)
+        for (int idx = lane; idx < Hp * PDMPC_VMAX; idx += PDMPC_WAVE) {
+            const int k = idx / PDMPC_VMAX;
+            const int v = idx - k * PDMPC_VMAX;
+            const int a = V->fb_off[k], b = V->fb_off[k + 1];
+            const int cols = (b - a < PDMPC_VMAX) ? (b - a) : PDMPC_VMAX;
+            if (v == 0) O->shape_cols[k] = cols;
+            if (v < cols) {
+                O->shapes[k][0][v] = A.points[2 * (size_t)(a + v)];
+                O->shapes[k][1][v] = A.points[2 * (size_t)(a + v) + 1];
+            }
+        }
+    }
+    if (lane == 0) {
+        O->status = dep_timeout ? PDMPC_ERR_HIP : status;
+        O->n_expanded = (int32_t)nnodes;
+        O->n_popped = (int32_t)n_popped;
+        O->n_hp = Hp;
+    }
+}
+
+// Publication: plain stores -> this wave's vmcnt(0) -> lane-0 agent release -> flag.  First wave.
+__device__ __forceinline__ void bk_publish(const KernelArgs& A, const Ctx& X, int status, bool dep_timeout) {
+    if (X.lane == 0 && (dep_timeout || (status != PDMPC_OK && status != PDMPC_EXHAUSTED))) atomicAdd(A.work_count + 6, 1ull);  // (device-side tally of plans that are not planning results)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wave_sync();
+    if (X.lane == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(A.done_flag + X.slot, A.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // The search.  Returns true (to every thread) if a tie was met: the host plans the call again with the heap-carrying kernel.
@@ -393,14 +539,29 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
     R.n_popped = 0;
     R.n_expanded = 0;
     bool pb_valid = false;
+    bool rec_valid = false, rec_written = false;  // the result record in HBM is the one this search would publish now / some record has been written
     // shared rounds (helper workgroups)
     unsigned long long* board = A.help_board + (size_t)slot * PDMPC_HB_WORDS;
     uint32_t help_seq = 0;  // rounds shared so far (same value in every thread)
 
+    const int tid_k = tid, lane_k = lane;
     for (;;) {
+        // (the thread's index is made opaque once per round: what the compiler derives from it — a few dozen per-thread addresses into
+        // the LDS lists — would otherwise be kept in registers across the whole loop, and the kernel runs at the register cap)
+        int tid_o = tid_k, lane_o = lane_k;
+        asm volatile("" : "+v"(tid_o), "+v"(lane_o));
+        int tid = tid_o, lane = lane_o;
+#define BK_OPAQUE_TID                                      \
+    {                                                      \
+        int t__ = tid_k, l__ = lane_k;                     \
+        asm volatile("" : "+v"(t__), "+v"(l__));           \
+        tid = t__;                                         \
+        lane = l__;                                        \
+    }
         // ================= a round =================
         if (Rn) {
             pb_valid = false;  // (the tree grows: phase B's result is stale)
+            rec_valid = false;
             // ---- P1: check items + sincos items.  A large round is shared with the helper workgroups (CUs this launch leaves idle):
             // the owner posts one 48-byte record per entry (what a check reads of the tree), keeps the first tiles of 64 entries and
             // offers the others; helpers claim tiles (compare-and-swap on the board's ticket word, which carries the round's sequence
@@ -505,6 +666,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             __syncthreads();
             BK_TICK(tk_p1)
 
+            BK_OPAQUE_TID
             // ---- P2: verdicts, goal candidates, children counts; node indices by a scan (two ready entries per thread).
             // The children of a node are expanded in groups of four lanes.
             bool ex[2];
@@ -560,6 +722,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             const bool all_far = sh[FR_NEAR_N] + NC > OC;  // near cannot take this round's children: they wait in far
             const double l_far = all_far ? -1.0 : sh_ld_d(sh, FR_L_FAR);
             BK_TICK(tk_p2)
+            BK_OPAQUE_TID
             // ---- P3: expansion items (group of four successors of a collision-free node, lane): expand_node.m:18-90
             for (uint32_t tile0 = 0; tile0 < NG && !overflow; tile0 += VCAP) {  // (uniform; one tile unless a round has more than VCAP groups)
                 if (tile0) __syncthreads();  // (the previous tile's items have read the lists)
@@ -655,6 +818,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             Rn = 0;
             BK_TICK(tk_p3)
         }
+        BK_OPAQUE_TID
         // the key ranges the appends of this round and the selection before it have met
         flush_near();
         flush_far();
@@ -717,34 +881,39 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             nn = nn < S.max_nodes ? nn : S.max_nodes;
             incorporate_areas(P, arr, tid);
             __syncthreads();
-            // Only collision-free nodes can lose their edge: gathered first so that the check runs on full wavefronts.
-            for (uint32_t base0 = 0; base0 < nn; base0 += FR_NBINS) {  // (uniform trip counts: barriers inside)
-                const uint32_t end = base0 + FR_NBINS < nn ? base0 + FR_NBINS : nn;
-                if (tid == 0) sh[FR_VLIST_N] = 0;
-                __syncthreads();
-                for (uint32_t b = base0; b < end; b += (uint32_t)bd) {
-                    const uint32_t i0 = b + (uint32_t)tid;
-                    const bool v = i0 < end && vs_load(VS, i0 < end ? i0 : 0u) == VS_VALID;
-                    const unsigned long long bal = __ballot(v);
-                    if (bal) {
-                        const uint32_t pos0 = sh_add_uniform(sh, FR_VLIST_N, (uint32_t)__builtin_popcountll(bal), lane);
-                        if (v) hist[pos0 + lane_rank(bal, lane)] = i0;
+            // Only collision-free nodes can lose their edge.  Small trees: every node is an item (the others are skipped); large
+            // trees: the collision-free ones (a third of the tree, scattered) are gathered first so that the items are dense.
+            const bool direct = nn <= 4u * (uint32_t)bd;
+#pragma unroll 1
+            for (uint32_t base0 = 0; base0 < nn; base0 += direct ? nn : (uint32_t)FR_NBINS) {  // (uniform trip counts: barriers inside)
+                const lds_u32* list = nullptr;
+                uint32_t cnt = nn;
+                if (!direct) {
+                    const uint32_t end = base0 + FR_NBINS < nn ? base0 + FR_NBINS : nn;
+                    if (tid == 0) sh[FR_VLIST_N] = 0;
+                    __syncthreads();
+                    for (uint32_t b = base0; b < end; b += (uint32_t)bd) {
+                        const uint32_t i0 = b + (uint32_t)tid;
+                        const bool v = i0 < end && vs_load(VS, i0 < end ? i0 : 0u) == VS_VALID;
+                        const unsigned long long bal = __ballot(v);
+                        if (bal) {
+                            const uint32_t pos0 = sh_add_uniform(sh, FR_VLIST_N, (uint32_t)__builtin_popcountll(bal), lane);
+                            if (v) hist[pos0 + lane_rank(bal, lane)] = i0;
+                        }
                     }
+                    __syncthreads();
+                    list = hist;
+                    cnt = sh[FR_VLIST_N];
                 }
-                __syncthreads();
-                const uint32_t nv = sh[FR_VLIST_N];
-                for (uint32_t e = (uint32_t)tid; e < nv; e += (uint32_t)bd) {
-                    const uint32_t i0 = hist[e];
-                    if (fr_node_hits_areas(S, X.C, P, i0, arr)) {
-                        vs_store(VS, i0, VS_INVALID);
-                        atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_INVALIDATED);
-                    }
-                }
+                bk_recheck_items(S, VS, CK, P, list, cnt, arr, sh, tid, bd);
                 __syncthreads();
             }
             flags = sh[FR_FLAGS];
             const bool reopen = (flags & FRF_INVALIDATED) && sh[FR_DROPPED] != 0u;
-            if (flags & FRF_INVALIDATED) pb_valid = false;
+            if (flags & FRF_INVALIDATED) {
+                pb_valid = false;
+                rec_valid = false;
+            }
             __syncthreads();
             if (tid == 0) {
                 atomicAdd(P.counters + 2, 1);
@@ -852,13 +1021,19 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 status = best ? PDMPC_OK : PDMPC_EXHAUSTED;
                 break;
             }
-            // finished, but predecessors that are still planning may yet invalidate what we found
+            // finished, but predecessors that are still planning may yet invalidate what we found: the record is written meanwhile
+            if (!rec_valid && !dep_timeout) {
+                if (wave == 0) bk_write_record(A, X, best, best ? PDMPC_OK : PDMPC_EXHAUSTED, false, R.n_popped, R.n_expanded, best != 0u, ref_ids, rec_written);
+                rec_valid = true;
+                rec_written = true;
+            }
             __builtin_amdgcn_s_sleep(4);
             if (++idle_polls > A.spin_limit) dep_timeout = true;  // a predecessor never finished: give up on it (reported as an error status)
             BK_TICK(tk_wait)
             continue;
         }
 
+        BK_OPAQUE_TID
         // ---- near is empty (or holds nothing below far's smallest key): refill it from far
         uint32_t nn_near = near_n;
         if (nn_near == 0u || far_min < near_min) {
@@ -944,6 +1119,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             nn_near = sh[FR_NEAR_N];
         }
 
+        BK_OPAQUE_TID
         // ---- this round's entries: the smallest keys of near.  Every thread holds BK_PER entries in registers.
         {
             const double lo = sh_ld_d(sh, FR_NEAR_MIN);
@@ -951,7 +1127,9 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             // A round takes the smallest open keys: bk_round0 while the search is young (a round costs about the same for one node as
             // for a few dozen: the items of a small round run side by side), growing with the work done up to bk_round.
             const uint32_t done_so_far = sh[FR_PROCESSED];
-            const uint32_t ramp = (uint32_t)A.bk_round0 + done_so_far / (uint32_t)A.fr_ramp;
+            // (the first Hp + 2 rounds at bk_round0: a light search is over by then and what a round takes beyond what the reference
+            // pops is wasted; a search that goes on is not light and its rounds grow with the work done)
+            const uint32_t ramp = (uint32_t)A.bk_round0 + (sh[FR_ROUNDS] > (uint32_t)Hp + 1u ? done_so_far / (uint32_t)A.fr_ramp : 0u);
             const uint32_t round_target = ramp < (uint32_t)A.bk_round ? ramp : (uint32_t)A.bk_round;
             double kk[BK_PER];
             uint32_t ii[BK_PER];
@@ -1101,10 +1279,12 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
     }
     X.status = status;
     X.n_popped = (int)R.n_popped;
-    X.path_ready = pb_ran && goal != 0u;  // (l_path holds G's path: the epilogue need not walk it again)
+    X.path_ready = pb_ran && goal != 0u;  // (l_path holds G's path: the record need not walk it again)
     X.goal = goal;
     X.nnodes = R.n_expanded;
     X.dep_timeout = dep_timeout;
+    X.rec_valid = rec_valid && !dep_timeout;
+    X.rec_written = rec_written;
     return false;
 }
 
@@ -1312,10 +1492,13 @@ __device__ __forceinline__ void bulk_body(const KernelArgs& A) {
         X.path_ready = false;
         X.goal = 0;
         X.nnodes = 0;
+        X.rec_valid = false;
+        X.dep_timeout = false;
     }
     __syncthreads();
     if (wave != 0) return;
-    search_epilogue(A, X, tie ? nullptr : ref_ids);
+    if (!X.rec_valid) bk_write_record(A, X, X.goal, X.status, X.dep_timeout, (uint32_t)X.n_popped, X.nnodes, X.path_ready, tie ? nullptr : ref_ids, X.rec_written);
+    bk_publish(A, X, X.status, X.dep_timeout);
     if (lane == 0 && A.n_helpers > 0) atomicAdd(A.help_finished, 1u);
 }
 

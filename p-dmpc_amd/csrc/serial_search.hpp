@@ -313,6 +313,7 @@ struct Ctx {
     int status, n_popped;
     uint32_t goal, nnodes;
     bool dep_timeout;
+    bool rec_valid = false, rec_written = false;  // bulk kernel: the result record has been written ahead of the publication / at all
     unsigned long long rt_kernel_start = 0;  // s_memrealtime at kernel entry (diagnostics of the bulk kernel)
     bool path_ready = false;  // l_path already holds the nodes of the goal's path (the frontier kernel's counting pass has walked it)
 #ifdef PDMPC_PROFILE
