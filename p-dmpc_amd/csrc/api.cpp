@@ -156,6 +156,7 @@ struct Tuning {
     int help_expand_oversub = -1;  // PDMPC_HELP_EXPAND_OVERSUB (-1: up to two searches per CU)
     int bk_round0 = 24;         // PDMPC_BK_ROUND0: nodes a round of a young search takes (bulk kernel)
     int bk_round = -1;          // PDMPC_BK_ROUND: the most a round takes (bulk kernel; -1: 1000 with helper workgroups, else 256)
+    int bk_tentative = 1;       // PDMPC_BK_TENTATIVE: expected areas of predecessors that are still planning (A/B switch: results are identical)
     int bk_tile = 64;           // PDMPC_BK_TILE: nodes of a tile of a shared round
     int bk_share_min = 192;     // PDMPC_BK_SHARE_MIN: a round with at least this many nodes is shared with the helper workgroups
     int bk_ramp = -1;           // PDMPC_BK_RAMP: a round grows by 1 / bk_ramp of the nodes processed so far (-1: 2 with helper workgroups, else 4)
@@ -876,6 +877,7 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     }
     a.bk_share_min = T.bk_share_min;
     a.bk_tile = T.bk_tile;
+    a.bk_tentative = T.bk_tentative;
     a.bk_post = h->d_bk_post.p;
     a.help_board = h->d_help_board.p;
     a.help_list = h->d_help_list.p;
@@ -997,6 +999,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
         if (getenv("PDMPC_BK_ROUND")) T.bk_round = std::max(1, env_i("PDMPC_BK_ROUND", 256));
         if (getenv("PDMPC_BK_RAMP")) T.bk_ramp = std::max(1, env_i("PDMPC_BK_RAMP", 4));
         T.bk_share_min = std::max(64, env_i("PDMPC_BK_SHARE_MIN", T.bk_share_min));
+        T.bk_tentative = env_i("PDMPC_BK_TENTATIVE", T.bk_tentative) != 0;
         T.bk_tile = std::min(128, std::max(16, env_i("PDMPC_BK_TILE", T.bk_tile)));
         h->bk_ready_cap = std::min(2048, std::max(256, env_i("PDMPC_BK_READY", h->bk_ready_cap))) & ~63;  // (the most a launch may use: launches without helpers lay out half of it)
         if (getenv("PDMPC_FR_ROUND")) h->fr_round = std::max(1, env_i("PDMPC_FR_ROUND", 0));

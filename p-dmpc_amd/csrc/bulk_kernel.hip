@@ -78,8 +78,39 @@ struct BkCheck {
     const lds_d2* l_soup;
     const lds_i32* l_soff;
     const lds_i32* l_hoff;
+    const lds_i32* l_lit;  // literal soup length per step (the predecessors' slots of VMAX columns each follow)
     int areas_in_lds, ll_base, ll_len, Hp;
 };
+
+// Tentative areas.  A predecessor that is still planning has its EXPECTED areas in its soup slots: what it publishes should its search
+// be exhausted, i.e. its previous plan shifted by one step (PrioritizedController.m:568-616, 678-718) — where it most likely ends up
+// driving.  An edge that crosses only such areas is neither collision-free nor colliding: its node is parked (VS_TENT) and comes back
+// into the open set when a predecessor arrives.  The result is a function of the final areas alone (every node that comes before
+// the goal ends up evaluated against them); what changes is that the plan found ahead of the arrivals usually survives them.
+#define VS_TENT 6u
+#define BK_TENT_MIN FR_JOIN_MAX  // (64 bit) smallest key among the parked nodes
+#define BK_NTENT FR_SEL2_BIN     // parked nodes
+#define BK_ARRIVALS FR_SEL2_CUM  // arrival events handled by this search
+
+// copies the expected areas of the predecessors in `who` into their soup slots
+__device__ __forceinline__ void bk_tentative_areas(const KernelArgs& A, const SpecCtx& P, unsigned long long who, int tid, int nthreads) {
+    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+    while (who) {
+        const int p = (int)__builtin_ctzll(who);
+        who &= who - 1;
+        const DevVehicle* PV = A.veh + P.pred[p];
+        if (PV->fb_off[0] < 0) continue;  // (uniform) no expectation: its slots stay empty
+        for (int idx = tid; idx < P.Hp * PDMPC_VMAX; idx += nthreads) {
+            const int k = idx / PDMPC_VMAX, v = idx - k * PDMPC_VMAX;
+            const int a = PV->fb_off[k], b = PV->fb_off[k + 1];
+            const int cols = (b - a < PDMPC_VMAX) ? (b - a) : PDMPC_VMAX;
+            d2 pt;
+            pt.x = v < cols ? A.points[2 * (size_t)(a + (v < cols ? v : 0))] : qnan;
+            pt.y = v < cols ? A.points[2 * (size_t)(a + (v < cols ? v : 0)) + 1] : qnan;
+            P.l_soup[P.l_soff[k] + P.l_lit[k] + p * PDMPC_VMAX + v] = pt;
+        }
+    }
+}
 
 // Where a check item finds its node: the owner of a search reads the tree (LDS copies where they exist), a workgroup that helps it
 // reads the 48-byte records the owner has posted for the round (staged in the helper's LDS).
@@ -111,7 +142,7 @@ struct BkPostSrc {
 // one of the node's three soups (vehicle obstacles of its step and HDV sets against the area, lanelet boundary against the
 // boundary-check area: are_constraints_satisfied_interx.m:17-37).  chmax = chunks of the step with the most segments.  Lanes work alone.
 template <class Src>
-__device__ __forceinline__ void bk_check_items(const BkCheck& C, const Src& src, volatile lds_u32* r_flag, uint32_t r0, uint32_t R, int ls, uint32_t chmax, int tid, int nthreads) {
+__device__ __forceinline__ void bk_check_items(const BkCheck& C, const Src& src, volatile lds_u32* r_flag, uint32_t r0, uint32_t R, int ls, uint32_t chmax, unsigned long long pend, int tid, int nthreads) {
     const uint32_t items = R * chmax;
     const int Sg = 1 << ls;
     for (uint32_t item = (uint32_t)tid; item < items; item += (uint32_t)nthreads) {
@@ -155,17 +186,23 @@ __device__ __forceinline__ void bk_check_items(const BkCheck& C, const Src& src,
         }
         const lds_d2* q = C.l_soup + base + t0;
         d2 q0 = q[0];
-        bool hit = false;
-        for (int t = 0; t < tn; ++t) {
+        // (segments of the slots of predecessors that are still planning — `pend` — hold expected areas: a crossing there is tentative)
+        const int rel0 = (which == 0 && base == so) ? t0 - C.l_lit[k - 1] : -(1 << 20);
+        uint32_t found = 0;  // 1: crosses a real area, 2: crosses an expected one
+        for (int t = 0; t < tn && !(found & 1u); ++t) {
             // (the area's points are made opaque per segment: the compiler would otherwise hoist the seven edges' dx1, dy1, S1 of the
             // C1 test out of this loop — 42 registers for a test that one segment in ten reaches)
             asm volatile("" : "+v"(pt[0].x), "+v"(pt[0].y), "+v"(pt[1].x), "+v"(pt[1].y), "+v"(pt[2].x), "+v"(pt[2].y), "+v"(pt[3].x), "+v"(pt[3].y), "+v"(pt[4].x), "+v"(pt[4].y),
                          "+v"(pt[5].x), "+v"(pt[5].y), "+v"(pt[6].x), "+v"(pt[6].y), "+v"(pt[7].x), "+v"(pt[7].y));
             const d2 q1 = q[t + 1];
-            hit = hit || interx_segment_n<PDMPC_VMAX>(pt, ncols - 1, q0, q1);
+            if (interx_segment_n<PDMPC_VMAX>(pt, ncols - 1, q0, q1)) {
+                const int rel = rel0 + t;
+                const bool tent = rel >= 0 && ((pend >> (rel >> 3)) & 1ull) != 0ull;  // (rel >> 3 < 64: a search with more predecessors waits for them all)
+                found |= tent ? 2u : 1u;
+            }
             q0 = q1;
         }
-        if (hit) r_flag[r] = 1u;
+        if (found) __hip_atomic_fetch_or((lds_u32*)&r_flag[r], found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
 
@@ -429,6 +466,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
     CK.l_soup = X.C.l_soup;
     CK.l_soff = X.C.l_soff;
     CK.l_hoff = X.C.l_hoff;
+    CK.l_lit = P.l_lit;
     CK.areas_in_lds = X.C.areas_in_lds;
     CK.ll_base = X.C.ll_base;
     CK.ll_len = X.C.ll_len;
@@ -455,12 +493,14 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         sh_st_d(sh, FR_NEAR_MIN, inf);
         sh_st_d(sh, FR_FAR_MIN, inf);
         sh_st_d(sh, FR_L_FAR, inf);
+        sh_st_d(sh, BK_TENT_MIN, inf);
         sh[SH_NNODES] = 1;
         if (A.debug_tail == 2) sh[FR_EVER_INVAL] = 1;  // (debugging: exercise the ancestor check without arrivals)
         ready[0] = 1u;
         r_flag[0] = 0u;
     }
     if (tid < BK_NB) bins[tid] = 0u;
+    if (A.bk_tentative) bk_tentative_areas(A, P, sh_load64(sh, SH_PEND_LO), tid, (int)blockDim.x);  // (the pending set was fixed by the prologue)
     if (tid >= 64 && tid < 72) {
         const int ls = tid - 64;
         uint32_t mx = 0;
@@ -568,6 +608,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             // number), mirror the search's soup in their LDS and leave one verdict word per entry.  What nobody has claimed when the
             // owner is through with its part it does itself; then it waits for the claimed tiles.
             const BkTreeSrc tsrc{&S, ready};
+            const unsigned long long pend_now = A.bk_tentative ? sh_load64(sh, SH_PEND_LO) : 0ull;  // (their slots hold expected areas)
             const uint32_t n_tiles = (Rn + TILE - 1u) / TILE;
             const bool share = A.n_helpers > 0 && Rn >= (uint32_t)A.bk_share_min && P.n_pred <= 64;
             uint32_t own_tiles = n_tiles;
@@ -621,7 +662,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                     Rr = closed < n_tiles ? Rn - rb : 0u;  // the remainder
                 }
                 const int ls = bk_chunk_shift(chm, Rr, (uint32_t)bd);
-                bk_check_items(CK, tsrc, r_flag, rb, Rr, ls, chm[ls], tid, bd);
+                bk_check_items(CK, tsrc, r_flag, rb, Rr, ls, chm[ls], pend_now, tid, bd);
                 if (pass == 0) {
                     for (uint32_t r = (uint32_t)(bd - 1 - tid); r < Rn; r += (uint32_t)bd) {  // (from the last thread down: the first waves carry the first chunks)
                         const uint32_t i0 = ready[r] - 1u;
@@ -656,10 +697,10 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 __syncthreads();
                 const uint32_t* hverdict = A.help_verdict + (size_t)slot * PDMPC_HELP_CAP;
                 const uint32_t re = closed * TILE < Rn ? closed * TILE : Rn;
-                for (uint32_t r = own_tiles * TILE + (uint32_t)tid; r < re; r += (uint32_t)bd) {  // 1 collision-free, 2 collides
+                for (uint32_t r = own_tiles * TILE + (uint32_t)tid; r < re; r += (uint32_t)bd) {  // 1 collision-free, 2 collides, 3 crosses expected areas only
                     const uint32_t v = __hip_atomic_load(hverdict + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (v != 1u && v != 2u) atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_BUG);  // (claimed, reported finished, and no verdict)
-                    r_flag[r] = v == 2u ? 1u : 0u;
+                    if (v < 1u || v > 3u) atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_BUG);  // (claimed, reported finished, and no verdict)
+                    r_flag[r] = v == 2u ? 1u : (v == 3u ? 2u : 0u);
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -681,11 +722,16 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 cnt[s] = 0;
                 if (in) {
                     const uint32_t id = ready[r], i0 = id - 1u;
-                    const bool valid = !(r_flag[r] & 1u);
+                    const uint32_t fl = r_flag[r];
+                    const bool valid = (fl & 3u) == 0u, parked = (fl & 3u) == 2u;  // (crosses nothing / only expected areas)
                     uint32_t parent, packed;
                     piece_link(node_piece(S, i0, 3), parent, packed);
                     const int k = NODE_K(packed);
-                    vs_store(VS, i0, valid ? VS_VALID : VS_INVALID);
+                    vs_store(VS, i0, valid ? VS_VALID : (parked ? VS_TENT : VS_INVALID));
+                    if (parked) {  // (rare: one LDS atomic each)
+                        sh_add(sh, BK_NTENT, 1u);
+                        sh_min_d(sh, BK_TENT_MIN, F.gkey[i0]);
+                    }
                     if (parent) {  // the pairs the reference's InterX forms for this edge (InterX.m:63-76): (V - 1) x (M - 1) per soup
                         const int M_k = CK.l_soff[k] - CK.l_soff[k - 1], Hk = CK.l_hoff[k] - CK.l_hoff[k - 1];
                         t_checks += 1;
@@ -910,19 +956,37 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             }
             flags = sh[FR_FLAGS];
             const bool reopen = (flags & FRF_INVALIDATED) && sh[FR_DROPPED] != 0u;
+            // parked nodes (their edges crossed expected areas only) come back into the open set: never evaluated, as far as anybody
+            // can tell — a round will check them against what the soup holds then.  (reopen: the rebuild below finds them in the tree)
+            const uint32_t n_parked = sh[BK_NTENT];
+            if (n_parked) {  // (uniform)
+                const bool fits = sh[FR_NEAR_N] + n_parked <= OC;
+                const double l_far = sh_ld_d(sh, FR_L_FAR);
+                for (uint32_t base = 0; base < nn; base += (uint32_t)bd) {  // (uniform trip count: wave-wide appends inside)
+                    const uint32_t i0 = base + (uint32_t)tid;
+                    const bool tent = i0 < nn && vs_load(VS, i0 < nn ? i0 : 0u) == VS_TENT;
+                    const double k = tent ? F.gkey[i0] : 0.0;
+                    if (tent) vs_store(VS, i0, VS_UNKNOWN);
+                    const bool push = tent && !reopen;
+                    to_near(push && fits && !(k > l_far), k, i0 + 1u);
+                    to_far(push && !(fits && !(k > l_far)), k, i0 + 1u);
+                }
+            }
             if (flags & FRF_INVALIDATED) {
                 pb_valid = false;
                 rec_valid = false;
             }
             __syncthreads();
             if (tid == 0) {
-                atomicAdd(P.counters + 2, 1);
+                sh[BK_ARRIVALS] = sh[BK_ARRIVALS] + 1u;  // (reported at the end: a global atomic here sits on every level's hand-over)
                 const unsigned long long pend = sh_load64(sh, SH_PEND_LO) & ~arr;
                 sh[SH_PEND_LO] = (uint32_t)pend;
                 sh[SH_PEND_HI] = (uint32_t)(pend >> 32);
                 sh[SH_ARR_LO] = 0;
                 sh[SH_ARR_HI] = 0;
                 sh[SH_STATE] = ST_RUN;
+                sh[BK_NTENT] = 0;
+                sh_st_d(sh, BK_TENT_MIN, inf);
                 if (flags & FRF_INVALIDATED) {
                     sh[FR_EVER_INVAL] = 1;
                     sh[FR_BEST_ID] = 0;  // the best candidate may have lost an ancestor: look at all of them again
@@ -966,6 +1030,11 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 flush_far();
                 __syncthreads();
             }
+            if (n_parked) {  // (uniform) the key ranges of what came back
+                flush_near();
+                flush_far();
+                __syncthreads();
+            }
             flags = sh[FR_FLAGS];
         }
         if (flags & FRF_TIE) return true;
@@ -996,12 +1065,27 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         const double near_min = near_n ? sh_ld_d(sh, FR_NEAR_MIN) : inf, far_min = far_n ? sh_ld_d(sh, FR_FAR_MIN) : inf;
         const double open_min = near_min < far_min ? near_min : far_min;
         const double bb = best ? sh_ld_d(sh, FR_BEST_B1) : inf;
-        bool done = false;
+        // parked nodes (their edges cross only areas a pending predecessor is expected to take) count as open
+        const uint32_t n_tent = sh[BK_NTENT];
+        const double tent_min = n_tent ? sh_ld_d(sh, BK_TENT_MIN) : inf;
+        bool done = false, stalled = false;
         if (best) {
-            if (bb == open_min) return true;  // a tie between an open node and a node of the best path
-            done = bb < open_min;
+            if (bb == open_min || bb == tent_min) return true;  // a tie between an open node and a node of the best path
+            done = bb < open_min && bb < tent_min;
+            stalled = bb < open_min && !done;  // nothing open comes before the candidate, but a parked node may: only an arrival tells
         } else {
-            done = near_n == 0u && far_n == 0u;
+            done = near_n == 0u && far_n == 0u && n_tent == 0u;
+            stalled = near_n == 0u && far_n == 0u && !done;
+        }
+        if (stalled) {  // (uniform) wait for a predecessor
+            __builtin_amdgcn_s_sleep(4);
+            if (++idle_polls > A.spin_limit) {
+                dep_timeout = true;
+                status = PDMPC_EXHAUSTED;
+                break;
+            }
+            BK_TICK(tk_wait)
+            continue;
         }
         if (done) {
             // Phase B right away, also when predecessors are still planning: an arrival that invalidates nothing leaves the tree,
@@ -1250,6 +1334,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         }
     }
     if (tid == 0) {
+        atomicAdd(P.counters + 2, (int)sh[BK_ARRIVALS]);
         atomicAdd(A.work_count + 2, (unsigned long long)sh[FR_PROCESSED]);
         atomicAdd(A.work_count + 3, (unsigned long long)sh[FR_ROUNDS]);
         A.tree_size[slot] = (int32_t)(nnodes_raw | 0x40000000u);  // marks the arena as a raw tree (api.cpp reconstructs the reference's)
@@ -1318,6 +1403,7 @@ __device__ __forceinline__ void bulk_helper_body(const KernelArgs& A) {
     CK.l_soup = l_soup;
     CK.l_soff = l_soff;
     CK.l_hoff = l_hoff;
+    CK.l_lit = l_lit;
     CK.areas_in_lds = A.areas_in_lds;
     CK.ll_base = 0;
     CK.ll_len = 0;
@@ -1428,6 +1514,7 @@ __device__ __forceinline__ void bulk_helper_body(const KernelArgs& A) {
             P.pred = A.pred + V->pred_off;
             P.n_pred = V->n_pred;
             incorporate_areas(P, mask, tid);
+            if (A.bk_tentative) bk_tentative_areas(A, P, (V->n_pred >= 64 ? ~0ull : ((1ull << V->n_pred) - 1ull)) & ~mask, tid, bd);  // (as the owner: expected areas of the others)
             __syncthreads();
             if (tid < 8) {  // the chunk table of this soup (bulk_search)
                 const int ls = tid;
@@ -1458,12 +1545,16 @@ __device__ __forceinline__ void bulk_helper_body(const KernelArgs& A) {
         {
             const BkPostSrc psrc{t_rec};
             const int ls = bk_chunk_shift(chm, Rt, (uint32_t)bd);
-            bk_check_items(CK, psrc, t_flag, 0u, Rt, ls, chm[ls], tid, bd);
+            const unsigned long long pend = A.bk_tentative ? (P.n_pred >= 64 ? ~0ull : ((1ull << P.n_pred) - 1ull)) & ~mask : 0ull;
+            bk_check_items(CK, psrc, t_flag, 0u, Rt, ls, chm[ls], pend, tid, bd);
         }
         __syncthreads();
         {
             uint32_t* verdict = A.help_verdict + (size_t)slot * PDMPC_HELP_CAP + rb;
-            if ((uint32_t)tid < Rt) __hip_atomic_store(verdict + tid, (t_flag[tid] & 1u) ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint32_t)tid < Rt) {  // 1 collision-free, 2 collides, 3 crosses expected areas only
+                const uint32_t fl = t_flag[tid];
+                __hip_atomic_store(verdict + tid, (fl & 1u) ? 2u : ((fl & 2u) ? 3u : 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's verdicts have reached L2 (the barrier alone does not wait for them) ...
         __syncthreads();                                     // ... every wave's have: thread 0 can write L2 back and report

@@ -192,6 +192,7 @@ struct KernelArgs {
     int32_t bk_ready_cap;   // entries of the ready list (a round's nodes)
     int32_t bk_round0;      // nodes a round of a young search takes
     int32_t bk_round;       // ... and the most any round takes
+    int32_t bk_tentative;   // 1: predecessors that are still planning have their expected areas (the ones they publish when exhausted) in their soup slots
     int32_t bk_tile;        // entries of a tile of a shared round (what a helper workgroup claims at a time; at most 128)
     int32_t bk_share_min;   // a round with at least this many entries is shared with the helper workgroups
     double* bk_post;        // [slot][bk_ready_cap][3] double2: what a check item reads of the tree, posted per entry of a shared round
