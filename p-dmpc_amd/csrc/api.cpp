@@ -872,7 +872,7 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
             a.n_helpers = count <= 2 * h->n_cu ? 96 : 32;
             if (T.helpers_oversub >= 0) a.n_helpers = std::min(T.helpers_oversub, h->n_cu / 2);
             if (T.helpers >= 0) a.n_helpers = std::min(a.n_helpers, T.helpers);  // (0 switches every helper off)
-            if (bulk) a.n_helpers = 0;  // (the bulk kernel's helpers serve launches that leave CUs idle)
+            if (bulk && count > 2 * h->n_cu) a.n_helpers = 0;  // (five searches per CU: a helper only takes a CU away from a search)
         }
     }
     a.bk_share_min = T.bk_share_min;

@@ -95,20 +95,19 @@ struct BkCheck {
 // copies the expected areas of the predecessors in `who` into their soup slots
 __device__ __forceinline__ void bk_tentative_areas(const KernelArgs& A, const SpecCtx& P, unsigned long long who, int tid, int nthreads) {
     const double qnan = __longlong_as_double(0x7ff8000000000000LL);
-    while (who) {
-        const int p = (int)__builtin_ctzll(who);
-        who &= who - 1;
+    const int per = P.Hp * PDMPC_VMAX, n_pred = P.n_pred < 64 ? P.n_pred : 64;
+    for (int idx = tid; idx < n_pred * per; idx += nthreads) {  // (every pending predecessor's loads side by side)
+        const int p = idx / per, rest = idx - p * per;
+        if (!((who >> p) & 1ull)) continue;
         const DevVehicle* PV = A.veh + P.pred[p];
-        if (PV->fb_off[0] < 0) continue;  // (uniform) no expectation: its slots stay empty
-        for (int idx = tid; idx < P.Hp * PDMPC_VMAX; idx += nthreads) {
-            const int k = idx / PDMPC_VMAX, v = idx - k * PDMPC_VMAX;
-            const int a = PV->fb_off[k], b = PV->fb_off[k + 1];
-            const int cols = (b - a < PDMPC_VMAX) ? (b - a) : PDMPC_VMAX;
-            d2 pt;
-            pt.x = v < cols ? A.points[2 * (size_t)(a + (v < cols ? v : 0))] : qnan;
-            pt.y = v < cols ? A.points[2 * (size_t)(a + (v < cols ? v : 0)) + 1] : qnan;
-            P.l_soup[P.l_soff[k] + P.l_lit[k] + p * PDMPC_VMAX + v] = pt;
-        }
+        if (PV->fb_off[0] < 0) continue;  // no expectation: its slots stay empty
+        const int k = rest / PDMPC_VMAX, v = rest - k * PDMPC_VMAX;
+        const int a = PV->fb_off[k], b = PV->fb_off[k + 1];
+        const int cols = (b - a < PDMPC_VMAX) ? (b - a) : PDMPC_VMAX;
+        d2 pt;
+        pt.x = v < cols ? A.points[2 * (size_t)(a + (v < cols ? v : 0))] : qnan;
+        pt.y = v < cols ? A.points[2 * (size_t)(a + (v < cols ? v : 0)) + 1] : qnan;
+        P.l_soup[P.l_soff[k] + P.l_lit[k] + p * PDMPC_VMAX + v] = pt;
     }
 }
 
@@ -309,8 +308,8 @@ __device__ __forceinline__ void bk_select(const lds_u32* bins, uint32_t target, 
 // (its fields are reset first).  l_path[i] = node (1-based index into this vehicle's arena) of step i along the selected path
 // (walked here unless path_ready); ref_ids = the ids those nodes carry in the reference's tree (info.tree_path).
 __device__ __forceinline__ void bk_write_record(const KernelArgs& A, Ctx& X, uint32_t goal, int status, bool dep_timeout, uint32_t n_popped, uint32_t nnodes, bool path_ready,
-                                                const lds_u32* ref_ids, bool again) {
-    const int lane = X.lane, Hp = X.Hp;
+                                                const lds_u32* ref_ids, bool again, int lane) {
+    const int Hp = X.Hp;
     const DevVehicle* __restrict__ V = X.V;
     pdmpc_vehicle_out* __restrict__ O = X.O;
     lds_u32* l_path = X.l_path;
@@ -1107,7 +1106,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             }
             // finished, but predecessors that are still planning may yet invalidate what we found: the record is written meanwhile
             if (!rec_valid && !dep_timeout) {
-                if (wave == 0) bk_write_record(A, X, best, best ? PDMPC_OK : PDMPC_EXHAUSTED, false, R.n_popped, R.n_expanded, best != 0u, ref_ids, rec_written);
+                if (wave == 0) bk_write_record(A, X, best, best ? PDMPC_OK : PDMPC_EXHAUSTED, false, R.n_popped, R.n_expanded, best != 0u, ref_ids, rec_written, lane);
                 rec_valid = true;
                 rec_written = true;
             }
@@ -1308,6 +1307,8 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
     }
 
     // ================= results =================
+    int tid_r = tid_k, lane_r = lane_k;  // (opaque once more: see the round loop)
+    asm volatile("" : "+v"(tid_r), "+v"(lane_r));
     uint32_t nnodes_raw = sh[FR_NNODES];
     nnodes_raw = nnodes_raw < S.max_nodes ? nnodes_raw : S.max_nodes;
     __syncthreads();
@@ -1319,7 +1320,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
     // validity bytes of the LDS-resident nodes go to HBM with the rest (debug read-back of the tree, pdmpc_debug_tree)
     {
         const uint32_t nv = VS.NV < nnodes_raw ? VS.NV : nnodes_raw;
-        for (uint32_t i = (uint32_t)tid; i < nv; i += (uint32_t)bd) VS.g[i] = VS.l[i];
+        for (uint32_t i = (uint32_t)tid_r; i < nv; i += (uint32_t)bd) VS.g[i] = VS.l[i];
     }
     {  // work counters: one atomic per wave
         unsigned long long a = t_checks, b = t_pairs;  // (a thread's share stays far below 2^32)
@@ -1328,18 +1329,18 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             a += __shfl_xor(a, o);
             b += __shfl_xor(b, o);
         }
-        if (lane == 0) {
+        if (lane_r == 0) {
             atomicAdd(A.work_count + 0, a);
             atomicAdd(A.work_count + 1, b);
         }
     }
-    if (tid == 0) {
+    if (tid_r == 0) {
         atomicAdd(P.counters + 2, (int)sh[BK_ARRIVALS]);
         atomicAdd(A.work_count + 2, (unsigned long long)sh[FR_PROCESSED]);
         atomicAdd(A.work_count + 3, (unsigned long long)sh[FR_ROUNDS]);
         A.tree_size[slot] = (int32_t)(nnodes_raw | 0x40000000u);  // marks the arena as a raw tree (api.cpp reconstructs the reference's)
     }
-    if (tid == 0 && A.debug_tail) {  // diagnostics in the unused tail of the record (rows HP_MAX - 2 .. HP_MAX of path_nodes); PDMPC_DEBUG_TAIL=1
+    if (tid_r == 0 && A.debug_tail) {  // diagnostics in the unused tail of the record (rows HP_MAX - 2 .. HP_MAX of path_nodes); PDMPC_DEBUG_TAIL=1
         double* dbg = X.O->path_nodes[PDMPC_HP_MAX];
         dbg[0] = (double)sh[FR_ROUNDS];
         dbg[1] = (double)sh[FR_PROCESSED];
@@ -1574,7 +1575,7 @@ __device__ __forceinline__ void bulk_body(const KernelArgs& A) {
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
     search_prologue(A, X, (LDS_AS unsigned char*)smem, true);
     X.rt_kernel_start = rt0;
-    const int lane = X.lane, wave = X.wave;
+    const int wave = X.wave;
     lds_u32* ref_ids = (lds_u32*)(X.lsm + A.lds.bk_misc) + 224;  // behind the chunk table (nothing else uses those words)
     const bool tie = bulk_search<NW>(A, X, ref_ids);
     if (tie) {  // (uniform over the workgroup) reported with the internal status: the host plans the call again on the binary heap
@@ -1588,9 +1589,14 @@ __device__ __forceinline__ void bulk_body(const KernelArgs& A) {
     }
     __syncthreads();
     if (wave != 0) return;
-    if (!X.rec_valid) bk_write_record(A, X, X.goal, X.status, X.dep_timeout, (uint32_t)X.n_popped, X.nnodes, X.path_ready, tie ? nullptr : ref_ids, X.rec_written);
+    {  // (opaque, as in the round loop: nothing derived from the lane index in the prologue is worth a register until here)
+        int l__ = X.lane;
+        asm volatile("" : "+v"(l__));
+        X.lane = l__;
+    }
+    if (!X.rec_valid) bk_write_record(A, X, X.goal, X.status, X.dep_timeout, (uint32_t)X.n_popped, X.nnodes, X.path_ready, tie ? nullptr : ref_ids, X.rec_written, X.lane);
     bk_publish(A, X, X.status, X.dep_timeout);
-    if (lane == 0 && A.n_helpers > 0) atomicAdd(A.help_finished, 1u);
+    if (X.lane == 0 && A.n_helpers > 0) atomicAdd(A.help_finished, 1u);
 }
 
 }  // namespace
