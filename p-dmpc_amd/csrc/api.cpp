@@ -360,7 +360,11 @@ bool use_bulk(const pdmpc_handle* h) {
 }
 
 // helper workgroups serve the bulk kernel's launches that leave CUs idle (launch_range)
-bool bulk_has_helpers(const pdmpc_handle* h, int n_launch) { return h->speculate && h->tune.helpers != 0 && n_launch <= h->n_cu - 2; }
+bool bulk_has_helpers(const pdmpc_handle* h, int n_launch) {
+    if (!h->speculate || h->tune.helpers == 0) return false;
+    if (n_launch > h->n_cu) return n_launch <= 2 * h->n_cu && h->tune.helpers_oversub != 0;  // (the tail of a launch with up to two searches per CU)
+    return n_launch <= h->n_cu - 2;
+}
 
 int compute_lds_bulk(pdmpc_handle* h, int n_launch, int soup_cap) {
     // large rounds pay where helper workgroups share them; without helpers the LDS is better spent on node records
@@ -790,7 +794,7 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     const bool frontier = h->kernel_frontier && !h->sampled_launch;
     const bool bulk = use_bulk(h);
     a.bulk = bulk ? 1 : 0;
-    a.bk_ready_cap = h->bk_ready_launch;
+    a.bk_ready_cap = std::min(h->bk_ready_launch, 3 * PDMPC_WAVE * h->n_waves);  // (the verdict pass handles three entries per thread)
     a.bk_round0 = std::max(1, T.bk_round0);
     {
         // measured on C2 / C3 (20 / 128 searches, helpers): cap 256, ramp 4 -> 646 / 589 steps/s; 512, 2 -> 735 / 786; 1000, 2 -> 769 / 909; 1000, 1 -> 620 / 772

@@ -33,6 +33,7 @@
 #include "frontier_common.hpp"
 
 // shared words of the bulk kernel (aliases of words the frontier kernel uses for things this kernel does not have)
+#define BK_P2 3                   // ready entries a thread handles in the verdict pass (the ready list holds at most BK_P2 * blockDim entries)
 #define BK_PER PDMPC_BK_PER       // near entries per thread a selection pass holds in registers (near capacity = BK_PER * blockDim)
 
 namespace {
@@ -707,13 +708,13 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             BK_TICK(tk_p1)
 
             BK_OPAQUE_TID
-            // ---- P2: verdicts, goal candidates, children counts; node indices by a scan (two ready entries per thread).
+            // ---- P2: verdicts, goal candidates, children counts; node indices by a scan (BK_P2 ready entries per thread).
             // The children of a node are expanded in groups of four lanes.
-            bool ex[2];
-            uint32_t cnt[2], rr[2];
+            bool ex[BK_P2];
+            uint32_t cnt[BK_P2], rr[BK_P2];
             unsigned long long mine = 0;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < BK_P2; ++s) {
                 const uint32_t r = (uint32_t)tid + (uint32_t)s * (uint32_t)bd;
                 const bool in = r < Rn;
                 rr[s] = r;
@@ -774,7 +775,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 {
                     uint32_t g = (uint32_t)(base & 0xffffffffull), c = (uint32_t)(base >> 32);
 #pragma unroll
-                    for (int s = 0; s < 2; ++s) {
+                    for (int s = 0; s < BK_P2; ++s) {
                         const uint32_t ng = (cnt[s] + 3u) >> 2;
                         for (uint32_t q = 0; q < ng; ++q) {
                             const uint32_t gi = g + q - tile0;  // (unsigned: groups of earlier tiles are far outside)
