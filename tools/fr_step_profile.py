@@ -10,10 +10,12 @@ class A: pass
 args = A(); args.vehicles = 20; args.hp = 8; args.mpa = "single_speed"; args.instances = 1; args.workload = "c2"; args.max_nodes = 1 << 17; args.seed = 1; args.max_levels = 99; args.priorities = "constant"
 if len(sys.argv) > 1 and sys.argv[1] == "c3":
     args.vehicles = 128; args.workload = "c3"; args.max_levels = 2; args.priorities = "coloring"; args.max_nodes = 1 << 16
+if len(sys.argv) > 1 and sys.argv[1] == "c4":
+    args.vehicles = 512; args.workload = "c4"; args.hp = 10; args.priorities = "coloring"; args.max_nodes = 1 << 16
 options, mpa, ctl = bench.build_world(args, 0)
 from pdmpc.optimizer import GraphSearchHip
 opt = GraphSearchHip(options); opt._ensure_mpa(mpa); h = opt.handle
-probs = bench.record_steps(options, mpa, ctl, opt, 20 if args.workload == "c2" else 4, 6)
+probs = bench.record_steps(options, mpa, ctl, opt, 20 if args.workload == "c2" else 4, 6 if args.workload != "c4" else 3)
 for b, prob in enumerate(probs):
     fb = [f if f is not None else [] for f in prob["fallback"]]
     h.pack_step(prob["iters"], prob["preds"], fb)
