@@ -43,7 +43,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "p-dmpc_amd")]
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, MI355X_MICROARCH.md
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 
 def workload_defaults(args):
@@ -142,27 +142,30 @@ def cpu_baseline(options, mpa, problems, gpu_records, budget_s):
     unbounded.max_nodes = 1 << 30  # the reference's tree is unbounded (Tree.m:54-70)
     mpa_struct, keep = packing.pack_mpa(mpa)
     oracle.plan_step_native(unbounded, mpa, problems[0], n_threads=cores, mpa_struct=mpa_struct)  # (starts the pool: not timed)
-    ms_total, thr_total, n_done, mismatches, plans = 0.0, 0.0, 0, 0, 0
+    ms_total, thr_total, n_done, mismatches, plans, n_timed, plans_timed = 0.0, 0.0, 0, 0, 0, 0, 0
     t0 = time.time()
     for prob, gpu in zip(problems, gpu_records):
+        # every recorded step is planned by the oracle and compared (the parity check of the measured work); the baseline's rate is
+        # taken from the steps inside the time budget
         recs, ms, thr = oracle.plan_step_native(unbounded, mpa, prob, n_threads=cores, mpa_struct=mpa_struct)
-        ms_total += ms
-        thr_total += thr * ms
+        if n_timed == 0 or time.time() - t0 <= budget_s:
+            ms_total += ms
+            thr_total += thr * ms
+            n_timed += 1
+            plans_timed += len(recs)
         n_done += 1
         plans += len(recs)
         mismatches += count_record_mismatches(gpu, recs)
-        if time.time() - t0 > budget_s:
-            break
     del keep
     return {
-        "value": n_done / (ms_total / 1e3) if ms_total > 0 else None,
+        "value": n_timed / (ms_total / 1e3) if ms_total > 0 else None,
         "unit": "MPC steps/s",
         "cores": cores,
         "threads_used_mean": thr_total / ms_total if ms_total > 0 else None,  # time-weighted: a level of one vehicle uses one thread
         "kind": "port",
         "sample": "%d recorded steps of the same workload (%d plans), C++ oracle, whole level loop in C++ (kahn order, hand-over of solved areas on the host), "
-        "min(level size, %d) threads of a persistent pool per level" % (n_done, plans, cores),
-        "ms_per_step": ms_total / max(n_done, 1),
+        "min(level size, %d) threads of a persistent pool per level" % (n_timed, plans_timed, cores),
+        "ms_per_step": ms_total / max(n_timed, 1),
     }, n_done, plans, mismatches
 
 
@@ -222,9 +225,8 @@ def scaling_reference(args_in, local_rank, torch):
 
     a = copy.copy(args_in)
     a.workload, a.priorities, a.max_levels, a.max_nodes = "c4", None, None, 0
-    a.record, a.skip = 4, 2
+    a.record, a.skip = 8, 4  # what `--workload c4` records (workload_defaults): value(N) / this value is a speed-up on the same steps
     workload_defaults(a)
-    a.record, a.skip = 4, 2
     options, mpa, ctl = build_world(a, 0)
     options.device = local_rank
     opt = GraphSearchHip(options)
@@ -277,9 +279,9 @@ def main():
                     help="options.max_num_CLs (Config.m:28): couplings that do not fit into this many computation levels are cut "
                     "(GreedyCutter.m) and handled as parallel couplings")
     ap.add_argument("--instances", type=int, default=64, help="c5: simultaneous prioritizations per time step")
-    ap.add_argument("--shard", default="components", choices=["components", "levels", "hybrid"],
+    ap.add_argument("--shard", default="components", choices=["components", "levels"],
                     help="multi-GPU mode of c3/c4: whole coupling-graph components per rank (one speculative launch per rank and step, one "
-                    "all-gather of results), block-partitioned levels (one all-gather per level), or hybrid (components, the heaviest one split by level)")
+                    "all-gather of results) or block-partitioned levels (one all-gather per level).  (pdmpc.distributed.plan_step_hybrid -- whole components, a dominating one split by level -- is a library call: the tiled benchmark maps have no dominating component)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -315,19 +317,13 @@ def main():
     S = len(problems)
     parts = None
     full_problems = problems
-    if sharded and dist is not None and args.shard in ("components", "hybrid") and not explore:
-        from pdmpc.distributed import partition_components, sub_problem
+    if (sharded and dist is not None and args.shard == "components" and not explore) or (explore and dist is not None):
+        from pdmpc.distributed import shard_problems
 
-        # every rank recorded the same closed loop; now it keeps only the components assigned to it: longest-processing-time
-        # assignment by the work the searches took in the closed loop (pops + 1), not by vehicle count
-        parts = [partition_components(p["preds"], world, weights=[w + 1 for w in p["pops"]] if "pops" in p else None) for p in full_problems]
-        problems = [sub_problem(p, parts[b][rank]) for b, p in enumerate(full_problems)]
-    elif explore and dist is not None:
-        from pdmpc.distributed import partition_instances, sub_problem
-
-        # C5: the prioritization instances are independent until the final cost comparison: instances are dealt out to the ranks
-        parts = [partition_instances(p, world) for p in full_problems]
-        problems = [sub_problem(p, parts[b][rank]) for b, p in enumerate(full_problems)]
+        # every rank recorded the same closed loop; now it keeps only what is assigned to it: whole coupling-graph components by
+        # longest processing time on the work the searches took in the closed loop (pops + 1) -- C5: the prioritization instances,
+        # which are independent until the final cost comparison (pdmpc.distributed.shard_problems, also driven by the gloo tests)
+        parts, problems = shard_problems(full_problems, world, rank, explore=explore)
     # keep every recorded step resident in HBM (one bank each) and collect its algorithmic bytes
     h.allow_overflow = True  # statuses are checked below, per bank
     t_host = time.perf_counter()
@@ -522,12 +518,12 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": tsrc,
-                "kernel": "pdmpc_frontier_kernel" if st["kernel"] == 1 else "pdmpc_search_kernel",
+                "kernel": {2: "pdmpc_bulk_kernel", 1: "pdmpc_frontier_kernel"}.get(st["kernel"], "pdmpc_search_kernel"),
                 "kernel_ms_avg": kernel_ms / max(n_launch, 1),
                 "algorithmic_bytes_per_launch": alg_bytes / max(n_launch, 1),
                 "launches": n_launch,
                 "lds_bytes_per_workgroup": lds_bytes,
-                "open_list": "unordered near / far lists, rounds of the smallest keys (frontier kernel)" if st["kernel"] == 1 else ("block-min queue, %d keys in LDS" % st["queue_ring_entries"] if st["queue_mode"] == 1 else "binary heap"),
+                "open_list": "unordered near (LDS) / far (HBM) lists, bulk-synchronous rounds of the smallest keys (bulk kernel)" if st["kernel"] == 2 else "unordered near / far lists, rounds of the smallest keys (frontier kernel)" if st["kernel"] == 1 else ("block-min queue, %d keys in LDS" % st["queue_ring_entries"] if st["queue_mode"] == 1 else "binary heap"),
             },
             # every plan of the recorded steps by outcome; arena_overflow and error must be 0 (the reference's tree is unbounded, Tree.m:54-70)
             "status_counts": status_counts,

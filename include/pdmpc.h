@@ -243,7 +243,9 @@ int pdmpc_pack_step(pdmpc_handle* handle, int32_t n_vehicles, const pdmpc_vehicl
                     const pdmpc_polygon_set* fallback_shapes);
 
 /* raw device pointer + byte size of the packed result records (pdmpc_vehicle_out[n]) for exchange
- * between GPUs (RCCL all-gather of solved areas) */
+ * between GPUs (RCCL all-gather of solved areas).  This entry point, pdmpc_import_results and
+ * pdmpc_export_results(_async) address SLOTS: they return PDMPC_ERR_INVALID for a batch that pdmpc_pack_step had to put into level
+ * order itself (slots then are not the caller's vehicles); pack in level order -- predecessors in lower slots -- to use them. */
 int pdmpc_result_device_buffer(pdmpc_handle* handle, void** dev_ptr, size_t* nbytes);
 /* make result records produced elsewhere (e.g. gathered from another GPU into dev_ptr) visible as
  * predecessor outputs: copies n records into slots [first, first+n) of the handle's result buffer */

@@ -1498,6 +1498,7 @@ int pdmpc_plan_batch_sampled(pdmpc_handle* h, int32_t n, const pdmpc_vehicle_in*
 
 int pdmpc_result_device_buffer(pdmpc_handle* h, void** dev_ptr, size_t* nbytes) {
     if (!h || !dev_ptr || !nbytes) return fail(PDMPC_ERR_INVALID, "null argument");
+    if (!h->banks[h->bank].perm.empty()) return fail(PDMPC_ERR_INVALID, "the packed batch was put into level order by the library: raw slots are not the caller's vehicles (pack it in level order to use the device-resident record path)");
     *dev_ptr = h->d_out.p;
     *nbytes = (size_t)h->max_vehicles * sizeof(pdmpc_vehicle_out);
     return PDMPC_OK;
@@ -1505,6 +1506,7 @@ int pdmpc_result_device_buffer(pdmpc_handle* h, void** dev_ptr, size_t* nbytes) 
 
 int pdmpc_import_results(pdmpc_handle* h, int32_t first, int32_t n, const void* dev_records) {
     if (!h || (n > 0 && !dev_records)) return fail(PDMPC_ERR_INVALID, "null argument");
+    if (!h->banks[h->bank].perm.empty()) return fail(PDMPC_ERR_INVALID, "the packed batch was put into level order by the library: raw slots are not the caller's vehicles (pack it in level order to use the device-resident record path)");
     if (first < 0 || n < 0 || first + n > h->max_vehicles) return fail(PDMPC_ERR_INVALID, "slot range out of bounds");
     HIPCHK(hipSetDevice(h->cfg.device));
     if (n == 0) return PDMPC_OK;
@@ -1517,6 +1519,7 @@ int pdmpc_import_results(pdmpc_handle* h, int32_t first, int32_t n, const void* 
 
 int pdmpc_export_results(pdmpc_handle* h, int32_t first, int32_t n, void* dev_records) {
     if (!h || (n > 0 && !dev_records)) return fail(PDMPC_ERR_INVALID, "null argument");
+    if (!h->banks[h->bank].perm.empty()) return fail(PDMPC_ERR_INVALID, "the packed batch was put into level order by the library: raw slots are not the caller's vehicles (pack it in level order to use the device-resident record path)");
     if (first < 0 || n < 0 || first + n > h->max_vehicles) return fail(PDMPC_ERR_INVALID, "slot range out of bounds");
     HIPCHK(hipSetDevice(h->cfg.device));
     if (n > 0) HIPCHK(hipMemcpyAsync(dev_records, h->d_out.p + first, (size_t)n * sizeof(pdmpc_vehicle_out), hipMemcpyDeviceToDevice, h->stream));
@@ -1526,6 +1529,7 @@ int pdmpc_export_results(pdmpc_handle* h, int32_t first, int32_t n, void* dev_re
 
 int pdmpc_export_results_async(pdmpc_handle* h, int32_t first, int32_t n, void* dev_records) {
     if (!h || (n > 0 && !dev_records)) return fail(PDMPC_ERR_INVALID, "null argument");
+    if (!h->banks[h->bank].perm.empty()) return fail(PDMPC_ERR_INVALID, "the packed batch was put into level order by the library: raw slots are not the caller's vehicles (pack it in level order to use the device-resident record path)");
     if (first < 0 || n < 0 || first + n > h->max_vehicles) return fail(PDMPC_ERR_INVALID, "slot range out of bounds");
     HIPCHK(hipSetDevice(h->cfg.device));
     if (n > 0) HIPCHK(hipMemcpyAsync(dev_records, h->d_out.p + first, (size_t)n * sizeof(pdmpc_vehicle_out), hipMemcpyDeviceToDevice, h->stream));
@@ -1846,6 +1850,7 @@ int pdmpc_debug_raw_tree(pdmpc_handle* h, int32_t vehicle, int32_t capacity, dou
 
 int pdmpc_debug_progress(pdmpc_handle* h, int32_t vehicle, uint32_t* words16) {
     if (!h || !words16 || vehicle < 0 || vehicle >= h->max_vehicles) return fail(PDMPC_ERR_INVALID, "bad argument");
+    if (!h->banks[h->bank].inv.empty() && vehicle < h->banks[h->bank].n_packed) vehicle = h->banks[h->bank].inv[(size_t)vehicle];  // (the batch was put into level order)
     for (int i = 0; i < 32; ++i) words16[i] = h->progress ? ((volatile uint32_t*)h->progress)[vehicle * 64 + i] : 0u;
     return PDMPC_OK;
 }

@@ -652,7 +652,7 @@ int pdmpc_controller_destroy(pdmpc_controller* c) {
 // Everything one launch needs to plan the whole time step (controller.py: build_step_problem): vehicles in level order
 // (slot = position), per-slot predecessor slots, per-slot areas to publish on exhaustion.
 namespace {
-int assemble_step(pdmpc_controller* c);
+int assemble_step(pdmpc_controller* c, bool seq_given = false);
 }
 
 int pdmpc_controller_build_step(pdmpc_controller* c) {
@@ -716,9 +716,10 @@ int pdmpc_controller_build_step(pdmpc_controller* c) {
 namespace {
 // c->directed -> sequential couplings, levels, slot order and the per-slot inputs of pdmpc_plan_step (the pools are the caller's
 // to clear: the explorative step keeps several problems alive side by side)
-int assemble_step(pdmpc_controller* c) {
+int assemble_step(pdmpc_controller* c, bool seq_given) {
     const int n = c->n, Hp = c->Hp;
-    if (!group(*c, c->directed, c->directed_seq)) return cfail(c, PDMPC_ERR_INVALID, "coupling graph has a cycle");
+    // (seq_given: c->directed_seq is the caller's -- the explorative step swaps single couplings of the base prioritization)
+    if (!seq_given && !group(*c, c->directed, c->directed_seq)) return cfail(c, PDMPC_ERR_INVALID, "coupling graph has a cycle");
     if (!kahn(c->directed_seq, n, c->levels)) return cfail(c, PDMPC_ERR_INVALID, "coupling graph has a cycle");
     c->order.resize(n);
     for (int i = 0; i < n; ++i) c->order[i] = i;
@@ -1028,13 +1029,10 @@ int pdmpc_controller_explore_build(pdmpc_controller* c, int32_t n_perm, uint32_t
     int rc = pdmpc_controller_build_step(c);  // instance 0: the controller's own prioritization
     if (rc) return rc;
     const int n = c->n;
-    // base levels: kahn of the coupling directed by the constant priorities (vehicle index)
-    std::vector<uint8_t> d0((size_t)n * n, 0);
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j)
-            if (at(c->adjacency, n, i, j) && !(j < i)) at(d0, n, i, j) = 1;
-    std::vector<int32_t> levels0;
-    if (!kahn(d0, n, levels0)) return cfail(c, PDMPC_ERR_INVALID, "coupling graph has a cycle");
+    // base levels: the computation levels of the controller's own prioritization -- kahn of the sequential coupling the step was
+    // just built with, whatever the priority strategy (PrioritizedExplorativeController.m prepare_permutation :42-58 permutes
+    // kahn(iter.directed_coupling_sequential))
+    const std::vector<int32_t> levels0 = c->levels;
     const int n_levels = *std::max_element(levels0.begin(), levels0.end());
     std::vector<int32_t> perms((size_t)n_perm * n_levels);
     rc = pdmpc_exploration_permutations(n_levels, n_perm, seed, perms.data());
@@ -1054,12 +1052,23 @@ int pdmpc_controller_explore_build(pdmpc_controller* c, int32_t n_perm, uint32_t
     for (int p = 1; p < n_perm; ++p) {
         std::vector<int32_t> where((size_t)n_levels + 1, 0);
         for (int j = 0; j < n_levels; ++j) where[(size_t)perms[(size_t)p * n_levels + j]] = j + 1;
-        // Prioritizer.directed_coupling_from_priorities (Prioritizer.m:64-77): i -> j stays unless j has the smaller number
-        c->directed.assign((size_t)n * n, 0);
+        // prepare_permutation (:64-77): every coupling i -> j of the base prioritization whose permuted levels invert it is swapped
+        // in ALL coupling matrices (swap_entries_all_coupling_matrices): a sequential coupling stays sequential, a parallel one
+        // (cut by the grouping, or between vehicles of one level) stays parallel and keeps its direction
+        const pdmpc_controller::Instance& I0 = c->inst[0];
+        c->directed = I0.directed;
+        c->directed_seq = I0.directed_seq;
         for (int i = 0; i < n; ++i)
             for (int j = 0; j < n; ++j)
-                if (at(c->adjacency, n, i, j) && !(where[(size_t)levels0[j]] < where[(size_t)levels0[i]])) at(c->directed, n, i, j) = 1;
-        rc = assemble_step(c);
+                if (at(I0.directed, n, i, j) && where[(size_t)levels0[i]] > where[(size_t)levels0[j]]) {
+                    at(c->directed, n, i, j) = 0;
+                    at(c->directed, n, j, i) = 1;
+                    if (at(I0.directed_seq, n, i, j)) {
+                        at(c->directed_seq, n, i, j) = 0;
+                        at(c->directed_seq, n, j, i) = 1;
+                    }
+                }
+        rc = assemble_step(c, true);
         if (rc) return rc;
         keep(p);
     }
@@ -1136,9 +1145,10 @@ int pdmpc_controller_explore_choose(pdmpc_controller* c, const pdmpc_vehicle_out
         while (label[(size_t)a] != a) a = label[(size_t)a] = label[(size_t)label[(size_t)a]];
         return a;
     };
+    const std::vector<uint8_t>& seq0 = c->inst[0].directed_seq;  // conncomp(directed_coupling_sequential) of the base prioritization (:94-112)
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j)
-            if (at(c->adjacency, n, i, j) || at(c->adjacency, n, j, i)) {
+            if (at(seq0, n, i, j) || at(seq0, n, j, i)) {
                 const int a = find(i), b = find(j);
                 if (a != b) label[(size_t)std::max(a, b)] = std::min(a, b);
             }

@@ -159,8 +159,13 @@ public:
             std::vector<pdmpc_vehicle_out> out(n);
             if (cmd == "plan_step") {
                 const pdmpc_ml_matrix seq = pins.matrix(inputs[3]);  // n x n directed_coupling_sequential
+                // pdmpc_ml_step_create indexes seq[i + j * n] and fallback[v + k * n]: anything smaller reads outside MATLAB's arrays,
+                // and an empty coupling matrix would silently plan the step without couplings
+                if (seq.data == nullptr || (size_t)seq.rows != n || (size_t)seq.cols != n)
+                    fail("plan_step", "directed_coupling_sequential must be an n x n matrix (n = number of iteration structs)");
                 int32_t r = 0, c = 0;
                 const pdmpc_ml_matrix* fb = inputs.size() > 4 && !inputs[4].isEmpty() ? pins.cell(inputs[4], r, c) : nullptr;  // n x Hp cell
+                if (fb != nullptr && ((size_t)r != n || (size_t)c != Hp)) fail("plan_step", "fallback areas must be an n x Hp cell");
                 pdmpc_ml_step* step = nullptr;
                 if (pdmpc_ml_step_create((int32_t)Hp, (int32_t)n, its.data(), seq.data, fb, &step) != PDMPC_OK) fail("pdmpc_ml_step_create", pdmpc_ml_last_error());
                 const int rc = pdmpc_ml_plan_step(h, step, out.data());

@@ -320,16 +320,21 @@ class PrioritizedSequentialController:
             raise ValueError(self.weight_strategy)
         return grouping.greedy_cut(W, o.max_num_CLs)
 
-    def build_step_problem(self, priorities=None, refresh=True):
+    def build_step_problem(self, priorities=None, refresh=True, couplings=None):
         """Everything one launch needs to plan the whole time step: vehicles in level order (slot = position),
         per-slot predecessor slots, per-slot areas to publish on exhaustion.  `priorities` overrides the controller's
-        own (used by the explorative driver to build one problem per prioritization of the same traffic state)."""
+        own; `couplings` = (directed, directed_sequential) replaces the prioritization altogether (the explorative driver builds one
+        problem per prioritization of the same traffic state by swapping single couplings of the base one)."""
         if refresh:
             self._traffic_info()
             self.last_adjacency = self._couple()
         adjacency = self.last_adjacency
-        directed = self._direct(adjacency, priorities)
-        directed_seq = self._group(directed)
+        if couplings is not None:
+            directed, directed_seq = np.asarray(couplings[0]) != 0, np.asarray(couplings[1]) != 0
+        else:
+            directed = self._direct(adjacency, priorities)
+            directed_seq = self._group(directed)
+        self.last_directed = np.asarray(directed, dtype=np.int64)
         self.last_directed_seq = np.asarray(directed_seq, dtype=np.int64)
         levels = kahn(directed_seq)
         self.last_levels = levels

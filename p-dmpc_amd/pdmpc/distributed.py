@@ -99,6 +99,55 @@ class HipRangePlanner:
         fb = [f if f is not None else [] for f in problem["fallback"]]
         return self.h.plan_step(problem["iters"], problem["preds"], fb)
 
+    def _hybrid_buffers(self, n_shared, per, world):
+        """Device buffers of the hybrid step (shared component's records, send / receive blocks of the whole components): allocated
+        once, grown geometrically, zero-filled before they are handed out."""
+        need = (max(n_shared, 1) * REC_BYTES, max(per, 1) * REC_BYTES, max(per, 1) * world * REC_BYTES)
+        have = getattr(self, "_hy", None)
+        if have is None or any(t.numel() < n for t, n in zip(have, need)):
+            self._hy = tuple(self.torch.zeros(2 * n, dtype=self.torch.uint8, device=self.device) for n in need)
+            self.torch.cuda.synchronize(self.device)
+            self.h.synchronize()
+        return tuple(t[:n] for t, n in zip(self._hy, need))
+
+    def plan_hybrid(self, problem, parts, shared, dist, rank, world, banks=(4094, 4095)):
+        """The hybrid step without a host round trip: both sub-problems are packed first (two HBM banks), then everything is
+        enqueued on the handle's stream -- the shared component's levels with their all-gathers, the copy of its records, ONE launch
+        for this rank's whole components, the copy of theirs, the all-gather of the whole components -- and the host waits once,
+        at the end.  Returns the records of all slots (host array)."""
+        n = len(problem["iters"])
+        mine = parts[rank]
+        per = max(max(len(q) for q in parts), 1)
+        shared_buf, send, recv = self._hybrid_buffers(len(shared), per, world)
+        sub_s = sub_w = None
+        if shared:
+            sub_s = sub_problem(problem, shared)
+            sub_s["level_sizes"] = level_sizes_of(sub_s["preds"])
+            self.prepack(banks[0], sub_s)
+        if mine:
+            sub_w = sub_problem(problem, mine)
+            self.prepack(banks[1], sub_w)
+        if sub_s is not None:
+            plan_step_sharded(sub_s, self, dist, rank, world, resident_bank=banks[0], fetch=False)
+            self.h.export_results_async(0, len(shared), shared_buf.data_ptr())  # (before the next launch overwrites the slots)
+        if sub_w is not None:
+            self.begin_resident(banks[1])
+            self.h.launch()  # one launch, the hand-off between levels on the device; not waited for
+            self.h.export_results_async(0, len(mine), send.data_ptr())
+        if world > 1:
+            with self.stream_context():
+                dist.all_gather_into_tensor(recv, send)
+        self.h.synchronize()
+        out = np.zeros(n, dtype=abi.VEHICLE_OUT_DTYPE)
+        if shared:
+            out[np.asarray(shared)] = np.frombuffer(shared_buf.cpu().numpy().tobytes(), dtype=abi.VEHICLE_OUT_DTYPE)[: len(shared)]
+        blocks = recv.cpu().numpy() if world > 1 else send.cpu().numpy()
+        for r in range(world):
+            if parts[r]:
+                blk = blocks[r * per * REC_BYTES : (r * per + len(parts[r])) * REC_BYTES]
+                out[np.asarray(parts[r])] = np.frombuffer(blk.tobytes(), dtype=abi.VEHICLE_OUT_DTYPE)
+        return out
+
 
 class _NoStream:
     def __enter__(self):
@@ -211,6 +260,28 @@ def gather_records(local_records_tensor, n_local, parts, dist, rank, world, new_
     return [recv[r * per * REC_BYTES : (r * per + len(parts[r])) * REC_BYTES] for r in range(world)]
 
 
+def shard_problems(full_problems, world, rank, explore=False):
+    """What bench.py's multi-GPU replay plans on this rank: per recorded step the slots of every rank (`parts`) and this rank's
+    sub-problem.  Whole coupling-graph components by longest processing time on the pops the searches took in the closed loop
+    (`explore`: the prioritization instances of config C5, dealt out round-robin).  The gloo tests drive the same function."""
+    if explore:
+        parts = [partition_instances(p, world) for p in full_problems]
+    else:
+        parts = [partition_components(p["preds"], world, weights=[w + 1 for w in p["pops"]] if "pops" in p else None) for p in full_problems]
+    return parts, [sub_problem(p, parts[b][rank]) for b, p in enumerate(full_problems)]
+
+
+def assemble_records(blocks, parts, n):
+    """The records of all n slots from the per-rank blocks an all-gather delivered (`blocks[r]`: bytes of rank r's records in the
+    order of parts[r])."""
+    full = np.zeros(n, dtype=abi.VEHICLE_OUT_DTYPE)
+    for r, slots in enumerate(parts):
+        if slots:
+            got = np.frombuffer(bytes(blocks[r]), dtype=abi.VEHICLE_OUT_DTYPE)
+            full[np.asarray(slots)] = got[: len(slots)]
+    return full
+
+
 def partition_instances(batch, world):
     """Config C5 (pdmpc.explorative.build_exploration_batch): the prioritization instances of a time step are independent until the
     final cost comparison, so they are dealt out to the ranks (instance p -> rank p mod world) and a rank plans its instances
@@ -229,14 +300,15 @@ def partition_instances(batch, world):
 # rank bounds the speed-up by total / heaviest however the others are placed.  Such a component is planned by ALL ranks
 # together, level by level (one all-gather per level among all ranks: the level-sharded protocol above, restricted to
 # the component's slots), while every other component is planned whole by one rank (longest-processing-time assignment by
-# measured pops, as before).  A rank first launches its whole components (one launch, asynchronous on the GPU) and then
-# takes part in the shared component's levels; one all-gather of the whole components' records ends the step.
+# measured pops, as before).  On the GPU (HipRangePlanner.plan_hybrid) both sub-problems are packed first, then everything is
+# enqueued on the handle's one stream: the shared component's levels (their collectives involve every rank, so they go first), then
+# ONE launch for the rank's whole components, then the all-gather of the whole components' records; the host waits once.
 #
 # Bounds (equal tiles of the tiled map, one component each; with at most one search per CU a rank's time is the latency of
 # its slowest component's level chain, not the sum over its components): C3 = 7 tiles on 4 GPUs and C4 = 26 tiles on 8 GPUs
 # have no dominating component, so the hybrid falls back to whole components there (ranks hold 2,2,2,1 and 4,4,3,...,3
-# tiles = at most 80 searches per GPU, far below one per CU: the per-rank time is one tile's chain, about 1.3 - 2 ms against
-# 22 ms for all 512 searches on one GPU); a single big component (one 512-vehicle network) is the case the split is for.
+# tiles = at most 80 searches per GPU, far below one per CU: the per-rank time is bounded by its heaviest tile, not by a sum);
+# a single big component (one 512-vehicle network) is the case the split is for.  DESIGN.md section 6 states the bounds.
 
 
 def hybrid_partition(preds, world, weights=None, dominance=1.0):
@@ -276,6 +348,9 @@ def plan_step_hybrid(problem, planner, dist, rank, world, weights=None, dominanc
     (host array, identical on every rank)."""
     n = len(problem["iters"])
     parts, shared = hybrid_partition(problem["preds"], world, weights, dominance)
+    if hasattr(planner, "plan_hybrid"):  # the GPU planner: everything on the handle's stream, one wait at the end
+        return planner.plan_hybrid(problem, parts, shared, dist, rank, world)
+    # planners that keep their records on the host (the CPU stand-in of the gloo tests): the same steps, one after the other
     out = np.zeros(n, dtype=abi.VEHICLE_OUT_DTYPE)
     # ---- this rank's whole components (a rank-local problem: no collective inside)
     mine = parts[rank]

@@ -94,16 +94,29 @@ def build_exploration_batch(ctl, n_perm, seed):
     """One flattened step problem holding `n_perm` prioritizations of the controller's current traffic state.
     Returns the problem (slots ordered by (level, instance)) with extra keys `instance` and `vehicle` per slot."""
     base = ctl.build_step_problem()  # refreshes the traffic state and the adjacency
-    levels0 = kahn(directed_coupling_from_priorities(ctl.last_adjacency, ctl.priorities))
+    # the computation levels of the controller's own prioritization: kahn of the sequential coupling the step was just built with
+    # (PrioritizedExplorativeController.m prepare_permutation :42-58 permutes kahn(iter.directed_coupling_sequential))
+    levels0 = np.asarray(ctl.last_levels)
     n_levels = int(levels0.max())
     perms = computation_level_permutations(n_levels, n_perm, seed)
     parts = []
+    directed0, seq0 = np.array(ctl.last_directed) != 0, np.array(base["directed_seq"]) != 0
     for p in range(n_perm):
-        # prepare_permutation (:42-58): i11changem(levels, 1:n, permutation) -- a vehicle of (old) level L gets the POSITION of L in
-        # the permutation as its new level; vehicles of one class share it
+        # prepare_permutation (:42-77): i11changem(levels, 1:n, permutation) -- a vehicle of (old) level L gets the POSITION of L in
+        # the permutation as its new level; every coupling i -> j of the base prioritization that the new levels invert is swapped
+        # in all coupling matrices (a sequential coupling stays sequential, a parallel one parallel and as directed)
         where = {int(lvl): j + 1 for j, lvl in enumerate(perms[p])}
         prio = [where[int(levels0[v])] for v in range(ctl.n)]
-        prob = base if p == 0 else ctl.build_step_problem(priorities=prio, refresh=False)
+        if p == 0:
+            prob = base
+        else:
+            directed, seq = directed0.copy(), seq0.copy()
+            for i, j in zip(*np.nonzero(directed0)):
+                if prio[i] > prio[j]:
+                    directed[i, j], directed[j, i] = False, True
+                    if seq0[i, j]:
+                        seq[i, j], seq[j, i] = False, True
+            prob = ctl.build_step_problem(refresh=False, couplings=(directed, seq))
         parts.append(prob)
     flat = []
     for p, prob in enumerate(parts):
@@ -125,6 +138,7 @@ def build_exploration_batch(ctl, n_perm, seed):
     out["level_sizes"] = [int(np.sum(lv == l)) for l in range(1, int(lv.max()) + 1)]
     out["n_instances"] = n_perm
     out["adjacency"] = np.array(ctl.last_adjacency)
+    out["graph_coupling"] = np.array(base["directed_seq"])  # the sub-graphs of the cost choice: conncomp(directed_coupling_sequential) of the base prioritization (:94-112)
     out["directed_seq"] = [prob["directed_seq"] for prob in parts]  # per instance: what a vehicle that goes on with it inherits
     return out
 
@@ -133,7 +147,7 @@ def choose_solution(batch, records, Hp):
     """PrioritizedExplorativeController.m:94-176: per weakly connected sub-graph of the coupling graph, the instance with the
     smallest summed cost-to-come of the final nodes after round(., 8).  Returns {sub-graph label: chosen instance} and the
     cost table (instances x sub-graphs).  A vehicle whose search was exhausted makes its instance infinitely expensive."""
-    adj = batch["adjacency"]
+    adj = batch["graph_coupling"]
     n = adj.shape[0]
     labels = weak_components([[j for j in range(n) if adj[i, j] or adj[j, i]] for i in range(n)])
     graphs = sorted(set(labels))
@@ -161,7 +175,7 @@ def explore_step(ctl, plan_batch, n_perm):
         batch = build_exploration_batch(ctl, n_perm, seed=ctl.k)
         records = plan_batch(batch)
         chosen_of_graph, _ = choose_solution(batch, records, Hp)
-        adj = batch["adjacency"]
+        adj = batch["graph_coupling"]
         labels = weak_components([[j for j in range(ctl.n) if adj[i, j] or adj[j, i]] for i in range(ctl.n)])
         chosen = [chosen_of_graph[labels[v]] for v in range(ctl.n)]
         slot = {(p, v): s for s, (p, v) in enumerate(zip(batch["instance"], batch["vehicle"]))}

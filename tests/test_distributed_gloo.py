@@ -177,17 +177,17 @@ def _component_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pdmpc.distributed import assemble_records, shard_problems
+
     options, mpa, prob = make_tiled_problem()
-    parts = partition_components(prob["preds"], world)
-    sub = sub_problem(prob, parts[rank])
+    prob["pops"] = [7 * (s % 5) + 1 for s in range(len(prob["iters"]))]  # (the weights bench.py's replay partitions by)
+    # bench.py's replay path: shard_problems -> plan the rank's sub-problem -> all-gather of the blocks -> assemble_records
+    (parts,), (sub,) = shard_problems([prob], world, rank)
+    assert parts == partition_components(prob["preds"], world, weights=[w + 1 for w in prob["pops"]]) and sub["slots"] == parts[rank]
     recs, _ = oracle.plan_step(options, mpa, dict(sub, level_sizes=levels_of(sub["preds"])))
     local = torch.from_numpy(np.frombuffer(recs.tobytes(), dtype=np.uint8).copy())
     blocks = gather_records(local, len(parts[rank]), parts, dist, rank, world, lambda n: torch.zeros(max(n, 1) * REC_BYTES, dtype=torch.uint8))
-    full = abi.out_array(len(prob["iters"]))
-    for r in range(world):
-        got = np.frombuffer(blocks[r].numpy().tobytes(), dtype=abi.VEHICLE_OUT_DTYPE)
-        for i, s in enumerate(parts[r]):
-            full[s] = got[i]
+    full = assemble_records([blk.numpy().tobytes() for blk in blocks], parts, len(prob["iters"]))
     q.put((rank, full.tobytes()))
     dist.barrier()
     dist.destroy_process_group()
@@ -306,3 +306,59 @@ def test_partition_instances_deals_instances_round_robin():
     assert parts == [[0, 2, 4, 6, 8, 9], [1, 3, 5, 7]]
     sub = sub_problem(batch, parts[0])
     assert sub["preds"] == [[], [], [0], [1], [2], [3]]
+
+
+# ---- C5: the instance-sharded replay of bench.py (shard_problems(explore=True) -> plan -> all-gather -> assemble_records) --------
+def make_exploration_problem():
+    from pdmpc.config import Config, ScenarioType
+    from pdmpc.controller import PrioritizedSequentialController
+    from pdmpc.explorative import build_exploration_batch
+    from pdmpc.mpa import get_mpa
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    options = Config(scenario_type=ScenarioType.commonroad, amount=8, Hp=5, max_nodes=1 << 15)
+    mpa = get_mpa(options)
+    sc = commonroad_scenario(options, seed=3)
+    ctl = PrioritizedSequentialController(options, sc, mpa, None, coupling="distance", boundary_provider=boundary_provider(sc))
+    return options, mpa, build_exploration_batch(ctl, 4, 1)
+
+
+def _instance_worker(rank, world, port, q):
+    from oracle import oracle
+    from pdmpc.distributed import assemble_records, gather_records, shard_problems
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    options, mpa, batch = make_exploration_problem()
+    (parts,), (sub,) = shard_problems([batch], world, rank, explore=True)
+    assert all(batch["instance"][s] % world == rank for s in parts[rank])
+    recs, _ = oracle.plan_step(options, mpa, dict(sub, level_sizes=levels_of(sub["preds"])))
+    local = torch.from_numpy(np.frombuffer(recs.tobytes(), dtype=np.uint8).copy())
+    blocks = gather_records(local, len(parts[rank]), parts, dist, rank, world, lambda n: torch.zeros(max(n, 1) * REC_BYTES, dtype=torch.uint8))
+    full = assemble_records([blk.numpy().tobytes() for blk in blocks], parts, len(batch["iters"]))
+    q.put((rank, full.tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_instance_sharding_world2_matches_single_process():
+    """Config C5 on two ranks the way bench.py replays it: instances dealt out, each rank plans its own in one batch, one all-gather,
+    records of all instances on every rank equal to the single-process batch."""
+    from oracle import oracle
+
+    options, mpa, batch = make_exploration_problem()
+    want, _ = oracle.plan_step(options, mpa, dict(batch, level_sizes=levels_of(batch["preds"])))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_instance_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        assert np.array_equal(np.frombuffer(got[r], dtype=np.uint8), want.view(np.uint8))

@@ -95,7 +95,8 @@ def test_circle_full_coupling_with_exhaustion_and_fallbacks():
     run_both(options, circle_scenario(options), 6, "full", force_exhaustion=lambda k: {1: 2, 4: 1}.get(k))
 
 
-def test_explorative_step_native_twin():
+@pytest.mark.parametrize("strategy,max_levels", [("constant", 99), ("coloring", 99), ("coloring", 3)])
+def test_explorative_step_native_twin(strategy, max_levels):
     """the native explorative step (pdmpc_controller_explore_*) against pdmpc.explorative — the flattened batch of
     the step's prioritizations bit for bit, the choice per sub-graph and its cost table, and the closed loop that goes on with the
     chosen plans and couplings (planner = the oracle, no GPU)."""
@@ -103,12 +104,14 @@ def test_explorative_step_native_twin():
     from pdmpc.explorative import choose_solution, explore_step
     from pdmpc.road_network import boundary_provider, commonroad_scenario
 
-    options = Config(scenario_type=ScenarioType.commonroad, amount=14, Hp=5, max_nodes=1 << 30)
+    # (under the colouring strategy instance 0 is the coloured prioritization and the other instances permute ITS computation levels;
+    # with max_num_CLs = 3 the sub-graphs of the cost choice are those of the cut, sequential coupling)
+    options = Config(scenario_type=ScenarioType.commonroad, amount=14, Hp=5, max_num_CLs=max_levels, max_nodes=1 << 30)
     sc = commonroad_scenario(options, seed=5)
     mpa = get_mpa(options)
     K = 5
-    py = PrioritizedSequentialController(options, sc, mpa, None, coupling="distance", boundary_provider=boundary_provider(sc))
-    nat = NativeController(options, sc, mpa, None, coupling="distance")
+    py = PrioritizedSequentialController(options, sc, mpa, None, coupling="distance", boundary_provider=boundary_provider(sc), priority_strategy=strategy)
+    nat = NativeController(options, sc, mpa, None, coupling="distance", priority_strategy=strategy)
     differing = 0
     for k in range(8):
         nat.explore_build(K, seed=k + 1)
