@@ -162,6 +162,8 @@ struct Tuning {
     int bk_ramp = -1;           // PDMPC_BK_RAMP: a round grows by 1 / bk_ramp of the nodes processed so far (-1: 2 with helper workgroups, else 4)
     int fr_slice = -1;          // PDMPC_FR_SLICE (-1: only after a predecessor time-out, 0: never, 1: always when oversubscribed)
     int debug_host = 0;         // PDMPC_DEBUG_HOST
+    int help_first = 0;         // PDMPC_HELP_FIRST (diagnostic: the helper kernel enqueued in front of the searches)
+    int help_prio = 1;          // PDMPC_HELP_PRIO (0: the helper stream at the launch stream's priority)
     int slot_order_reverse = 0; // PDMPC_TEST_REVERSE_DISPATCH: testing only, see launch_range
 };
 
@@ -216,6 +218,7 @@ struct pdmpc_handle {
     bool last_launch_bulk = false;
     int last_first = 0, last_count = 0;  // slots of the last launch_range
     uint32_t bulk_lds_hw[3] = {0, 0, 0}; // dynamic LDS size set so far on the bulk kernel's variants and its helper kernel (hipFuncSetAttribute is a maximum)
+    uint32_t frontier_lds_hw[5] = {0, 0, 0, 0, 0};  // ... and on the frontier kernel's four variants and its helper kernel
     DevBuf<double> d_bk_post;            // bulk kernel: records posted for the helper workgroups (pdmpc_device.h)
     int bk_ready_cap = 2048;     // entries of the bulk kernel's ready list with helper workgroups (PDMPC_BK_READY), half of it without
     int bk_ready_launch = 2048;  // ... of the last layout
@@ -879,6 +882,7 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
             if (bulk && count > 2 * h->n_cu) a.n_helpers = 0;  // (five searches per CU: a helper only takes a CU away from a search)
         }
     }
+    if (safe) a.n_helpers = 0;  // the recovery path counts on nothing but slot order: no helper workgroup sits where a search could run
     a.bk_share_min = T.bk_share_min;
     a.bk_tile = T.bk_tile;
     a.bk_tentative = T.bk_tentative;
@@ -905,10 +909,10 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
         HIPCHK(hipMemsetAsync(h->d_help_board.p + (size_t)first * PDMPC_HB_WORDS, 0, (size_t)count * PDMPC_HB_WORDS * sizeof(unsigned long long), h->stream));
         HIPCHK(hipMemsetAsync(h->d_help_finished.p, 0, 16 * sizeof(uint32_t), h->stream));
         HIPCHK(hipEventRecord(h->ev_help_pre, h->stream));  // the boards are clean
-        if (getenv("PDMPC_HELP_FIRST")) {  // diagnostic: the old order, helpers in front of the searches
+        if (T.help_first) {  // diagnostic: the old order, helpers in front of the searches
             hipStream_t hst0 = count > h->n_cu ? h->help_stream_low : h->help_stream;
             HIPCHK(hipStreamWaitEvent(hst0, h->ev_help_pre, 0));
-            const int hrc0 = bulk ? pdmpc_launch_bulk_helpers(&a, (void*)hst0, h->bulk_lds_hw) : pdmpc_launch_helpers(&a, (void*)hst0);
+            const int hrc0 = bulk ? pdmpc_launch_bulk_helpers(&a, (void*)hst0, h->bulk_lds_hw) : pdmpc_launch_helpers(&a, (void*)hst0, h->frontier_lds_hw);
             if (hrc0 != 0) return fail(PDMPC_ERR_HIP, "helper kernel launch failed");
             HIPCHK(hipEventRecord(h->ev_help_done, hst0));
         }
@@ -920,7 +924,7 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     h->last_first = first;
     h->last_count = count;
     auto launch_round_based = [&](const KernelArgs* ka, int cnt) {
-        return bulk ? pdmpc_launch_bulk(ka, cnt, (void*)h->stream, h->bulk_lds_hw) : pdmpc_launch_frontier(ka, cnt, (void*)h->stream);
+        return bulk ? pdmpc_launch_bulk(ka, cnt, (void*)h->stream, h->bulk_lds_hw) : pdmpc_launch_frontier(ka, cnt, (void*)h->stream, h->frontier_lds_hw);
     };
     int lrc = 0;
     if (slice) {
@@ -940,7 +944,7 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
         return fail(PDMPC_ERR_HIP, buf);
     }
     HIPCHK(hipEventRecord(ev.second, h->stream));
-    if (a.n_helpers > 0 && getenv("PDMPC_HELP_FIRST")) {
+    if (a.n_helpers > 0 && T.help_first) {
         HIPCHK(hipStreamWaitEvent(h->stream, h->ev_help_done, 0));
     } else if (a.n_helpers > 0) {
         // The helper kernel goes out BEHIND the searches, on a stream of its own: it starts once the boards are clean and runs next
@@ -952,7 +956,7 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
         // to have left (they leave as soon as the last search has published).
         hipStream_t hst = count > h->n_cu ? h->help_stream_low : h->help_stream;
         HIPCHK(hipStreamWaitEvent(hst, h->ev_help_pre, 0));
-        const int hrc = bulk ? pdmpc_launch_bulk_helpers(&a, (void*)hst, h->bulk_lds_hw) : pdmpc_launch_helpers(&a, (void*)hst);
+        const int hrc = bulk ? pdmpc_launch_bulk_helpers(&a, (void*)hst, h->bulk_lds_hw) : pdmpc_launch_helpers(&a, (void*)hst, h->frontier_lds_hw);
         if (hrc != 0) return fail(PDMPC_ERR_HIP, std::string("helper kernel launch failed: ") + hipGetErrorString((hipError_t)hrc));
         HIPCHK(hipEventRecord(h->ev_help_done, hst));
         HIPCHK(hipStreamWaitEvent(h->stream, h->ev_help_done, 0));
@@ -1037,6 +1041,8 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
         if (getenv("PDMPC_HELP_EXPAND_OVERSUB")) T.help_expand_oversub = env_i("PDMPC_HELP_EXPAND_OVERSUB", 0) != 0;
         if (getenv("PDMPC_FR_SLICE")) T.fr_slice = env_i("PDMPC_FR_SLICE", 0) != 0;
         T.debug_host = getenv("PDMPC_DEBUG_HOST") != nullptr;
+        T.help_first = getenv("PDMPC_HELP_FIRST") != nullptr;
+        T.help_prio = env_i("PDMPC_HELP_PRIO", 1) != 0;
         T.slot_order_reverse = env_i("PDMPC_TEST_REVERSE_DISPATCH", 0) != 0;
     }
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -1047,7 +1053,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     // (the helper stream above the launch stream's priority: streams of different priorities do not share a hardware queue, and a
     // helper only ever occupies CUs the launch leaves idle)
-    if (getenv("PDMPC_HELP_PRIO") && atoi(getenv("PDMPC_HELP_PRIO")) == 0) prio_greatest = 0;  // A/B switch: the helper stream at the launch stream's priority
+    if (!h->tune.help_prio) prio_greatest = 0;  // A/B switch: the helper stream at the launch stream's priority
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->help_stream, hipStreamNonBlocking, prio_greatest);
     if (e == hipSuccess) {
         // Two streams for the helper kernel.  Where searches and helpers compete for CUs (more searches than CUs) it runs at the
@@ -1326,6 +1332,8 @@ int plan_packed_growing(pdmpc_handle* h, int32_t n, pdmpc_vehicle_out* out) {
             overflow = overflow || out[i].status == PDMPC_ARENA_OVERFLOW;
             timed_out = timed_out || out[i].status == PDMPC_ERR_HIP;
         }
+        if (timed_out && safe)
+            return fail(PDMPC_ERR_HIP, "a search gave up waiting for a predecessor although the call was planned in resident slices without helper workgroups (records carry PDMPC_ERR_HIP)");
         if (timed_out && !safe) {
             // A search gave up waiting for a predecessor of the same launch (the watchdog of frontier_kernel.hip): the launch was
             // oversubscribed and the dispatch order starved a predecessor, or a helper sat where a search should have run.  Plan

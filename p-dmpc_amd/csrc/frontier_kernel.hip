@@ -1314,18 +1314,16 @@ extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) void pdmpc_frontier_k
 extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) void pdmpc_frontier_kernel_wide(const KernelArgs A) { frontier_body<PDMPC_CHECK_INTERX, 0>(A); }
 extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) void pdmpc_frontier_kernel_sat_wide(const KernelArgs A) { frontier_body<PDMPC_CHECK_SAT, 0>(A); }
 
-extern "C" int pdmpc_launch_frontier(const KernelArgs* args, int count, void* stream) {
+extern "C" int pdmpc_launch_frontier(const KernelArgs* args, int count, void* stream, uint32_t* lds_high_water) {
     if (count <= 0) return 0;
     typedef void (*kernel_t)(const KernelArgs);
     const bool interx = args->checker == PDMPC_CHECK_INTERX, one_word = args->n_words == 1;
     kernel_t fn = interx ? (one_word ? pdmpc_frontier_kernel : pdmpc_frontier_kernel_wide) : (one_word ? pdmpc_frontier_kernel_sat : pdmpc_frontier_kernel_sat_wide);
     // (no register-capped variants for two workgroups per CU: measured on C5, 1280 searches on 256 CUs: 2 x 12 wavefronts at 80
     // VGPRs 283 steps/s, 2 x 8 at 128 VGPRs 324, one workgroup of 16 per CU 345)
-    // (the attribute is a maximum: raised when a launch needs more than any before it, not on every launch)
-    static uint32_t lds_max[16][4] = {};  // per device (function attributes are per device)
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    uint32_t& have = lds_max[dev & 15][(interx ? 0 : 1) + (one_word ? 0 : 2)];
+    // (the attribute is a maximum: raised when a launch needs more than any before it, not on every launch; the high-water marks
+    // live in the handle -- one per kernel variant --, so handles on different devices or host threads share nothing)
+    uint32_t& have = lds_high_water[(interx ? 0 : 1) + (one_word ? 0 : 2)];
     if (args->lds.total > have) {
         hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)args->lds.total);
         if (e != hipSuccess) return (int)e;
@@ -1337,12 +1335,9 @@ extern "C" int pdmpc_launch_frontier(const KernelArgs* args, int count, void* st
 
 extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) void pdmpc_helper_kernel(const KernelArgs A) { helper_body<PDMPC_CHECK_INTERX>(A); }
 
-extern "C" int pdmpc_launch_helpers(const KernelArgs* args, void* stream) {
+extern "C" int pdmpc_launch_helpers(const KernelArgs* args, void* stream, uint32_t* lds_high_water) {
     if (args->n_helpers <= 0) return 0;
-    static uint32_t have_dev[16] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    uint32_t& have = have_dev[dev & 15];
+    uint32_t& have = lds_high_water[4];
     if (args->lds.total > have) {
         hipError_t e = hipFuncSetAttribute((const void*)pdmpc_helper_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)args->lds.total);
         if (e != hipSuccess) return (int)e;

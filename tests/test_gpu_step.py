@@ -43,8 +43,10 @@ def run_closed_loop(options, scenario, coupling, boundary, n_steps, oracle_threa
         ctl.step(plan_step=plan_step)
     # pdmpc_plan_step plans a call again in resident slices when a search timed out waiting for a predecessor: the safety net must
     # not be what makes these loops pass (a kernel that loses a publication now and then would hide behind it)
-    assert opt.handle.stats()["safe_replans"] == 0
+    stats = opt.handle.stats()
+    assert stats["safe_replans"] == 0
     opt.handle.close()
+    ctl.handle_stats = stats
     return ctl
 
 
@@ -608,3 +610,25 @@ def test_rccl_paths_with_one_rank_match_the_single_launch():
         h.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_bulk_kernel_shares_large_rounds_and_parks_tentative_nodes(monkeypatch):
+    """The product kernel on the benchmarked C2 window (closed-loop steps 1-30, incl. the 10 k-pop searches), with the thresholds low
+    enough that most rounds are shared with helper workgroups: the statistics say that helpers took part, the records stay the
+    oracle's (run_closed_loop compares every step); and the same loop without tentative areas and without helpers gives them too."""
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    def loop():
+        options = Config(scenario_type=ScenarioType.commonroad, amount=20, Hp=8, max_vehicles=32, max_nodes=1 << 17)
+        sc = commonroad_scenario(options, seed=1)
+        return run_closed_loop(options, sc, "distance", boundary_provider(sc), 30).handle_stats
+
+    monkeypatch.setenv("PDMPC_BK_SHARE_MIN", "64")
+    monkeypatch.setenv("PDMPC_BK_TILE", "32")
+    stats = loop()
+    assert stats["kernel"] == 2
+    assert stats["shared_rounds"] > 0 and 0 < stats["helper_checked"] < stats["nodes_processed"]
+    monkeypatch.setenv("PDMPC_BK_TENTATIVE", "0")
+    monkeypatch.setenv("PDMPC_HELPERS", "0")
+    stats = loop()
+    assert stats["kernel"] == 2 and stats["shared_rounds"] == 0

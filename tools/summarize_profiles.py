@@ -16,11 +16,11 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03_c2"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04_c2"
 workload = tag.split("_")[-1]
 TIMED = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 SRC = os.path.join(ROOT, sys.argv[3]) if len(sys.argv) > 3 else os.path.join(ROOT, "gpurun_out", "prof_" + workload)
-KERNEL, HELPER = "pdmpc_frontier", "pdmpc_helper"
+KERNEL, HELPER = "pdmpc_bulk_kernel", "pdmpc_bulk_helper"  # (round 3: pdmpc_frontier, pdmpc_helper)
 DST = os.path.join(ROOT, "profiles")
 os.makedirs(DST, exist_ok=True)
 
