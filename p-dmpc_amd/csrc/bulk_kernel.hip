@@ -92,6 +92,7 @@ struct BkCheck {
 #define BK_TENT_MIN FR_JOIN_MAX  // (64 bit) smallest key among the parked nodes
 #define BK_NTENT FR_SEL2_BIN     // parked nodes
 #define BK_ARRIVALS FR_SEL2_CUM  // arrival events handled by this search
+#define BK_DEPTH FR_RD_HEAD       // deepest collision-free node so far (its step k)
 
 // copies the expected areas of the predecessors in `who` into their soup slots
 __device__ __forceinline__ void bk_tentative_areas(const KernelArgs& A, const SpecCtx& P, unsigned long long who, int tid, int nthreads) {
@@ -520,6 +521,8 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
     uint32_t goal = 0;
     uint32_t idle_polls = 0;
     uint32_t Rn = 1;  // entries of the ready list (uniform: every thread carries it)
+    uint32_t depth_seen = 0xffffffffu;  // deepest collision-free node at the last selection
+    bool heavy = false;                 // the search has stalled once: its rounds grow
     uint32_t t_checks = 0, t_pairs = 0;  // this thread's share of the work counters
     // where the time goes (100 MHz ticks, PDMPC_DEBUG_TAIL=1): accumulated by thread 0 in LDS words, so that the bookkeeping costs
     // the round loop no registers
@@ -751,6 +754,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                                 atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_GOALS_LOST);  // (more than a thousand candidates in one round: looked up again in the tree below)
                         }
                     } else if (valid) {
+                        if ((uint32_t)k > sh[BK_DEPTH]) __hip_atomic_fetch_max((lds_u32*)&sh[BK_DEPTH], (uint32_t)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (rare: one node per level)
                         const lds_mask64* mrow = EE.l_mask + ((size_t)k * n + (NODE_TRIM(packed) - 1)) * nw;
                         uint32_t c = 0;
                         for (int w = 0; w < nw; ++w) c += (uint32_t)__builtin_popcountll(mrow[w]);
@@ -1211,9 +1215,13 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             // A round takes the smallest open keys: bk_round0 while the search is young (a round costs about the same for one node as
             // for a few dozen: the items of a small round run side by side), growing with the work done up to bk_round.
             const uint32_t done_so_far = sh[FR_PROCESSED];
-            // (the first Hp + 2 rounds at bk_round0: a light search is over by then and what a round takes beyond what the reference
-            // pops is wasted; a search that goes on is not light and its rounds grow with the work done)
-            const uint32_t ramp = (uint32_t)A.bk_round0 + (sh[FR_ROUNDS] > (uint32_t)Hp + 1u ? done_so_far / (uint32_t)A.fr_ramp : 0u);
+            // (rounds stay at bk_round0 while every round gets one level deeper — a light search is over after Hp + 1 of them and
+            // what a round takes beyond what the reference pops is wasted; a search that stalls, or goes on beyond Hp + 2 rounds, is
+            // not light: its rounds grow with the work done)
+            const uint32_t depth_now = sh[BK_DEPTH];
+            heavy = heavy || depth_now == depth_seen || sh[FR_ROUNDS] > (uint32_t)Hp + 1u;
+            depth_seen = depth_now;
+            const uint32_t ramp = (uint32_t)A.bk_round0 + (heavy ? done_so_far / (uint32_t)A.fr_ramp : 0u);
             const uint32_t round_target = ramp < (uint32_t)A.bk_round ? ramp : (uint32_t)A.bk_round;
             double kk[BK_PER];
             uint32_t ii[BK_PER];
