@@ -40,7 +40,9 @@ namespace {
 
 typedef volatile LDS_AS unsigned long long lds_vu64;
 
-// exclusive prefix of v over the threads of the workgroup (thread order), total to every thread.  Every thread calls; two barriers.
+// exclusive prefix of v over the threads of the workgroup (thread order), total to every thread.  Every thread calls; ONE barrier:
+// consecutive calls alternate between two partials arrays (the caller passes them), so the partials of a call are not rewritten
+// before the call after the next — which lies behind at least one more barrier.
 __device__ __forceinline__ unsigned long long wg_scan_excl(unsigned long long v, lds_vu64* wsum, int lane, int wave, int n_waves, unsigned long long& total) {
     unsigned long long inc = v;
 #pragma unroll
@@ -56,7 +58,6 @@ __device__ __forceinline__ unsigned long long wg_scan_excl(unsigned long long v,
         off += q < wave ? w : 0ull;
         tot += w;
     }
-    __syncthreads();
     total = tot;
     return off + inc - v;
 }
@@ -1272,7 +1273,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 n_drop += cls[j] == 3 ? 1u : 0u;
             }
             unsigned long long tot = 0;
-            const unsigned long long base = wg_scan_excl(mine, wsum64, lane, wave, n_waves, tot);  // (its barriers: every entry and every bin has been read)
+            const unsigned long long base = wg_scan_excl(mine, wsum64 + 16, lane, wave, n_waves, tot);  // (its barrier: every entry and every bin has been read)
             if (use_hist && tid < BK_NB) bins[tid] = 0u;  // (clean for the next selection)
             const uint32_t n_keep = (uint32_t)(tot & 0xffffffffull), n_rdy = (uint32_t)(tot >> 32);
             if (tid == 0) {  // (the old list's key range has been read by everybody; nobody touches these words before the next barrier)
