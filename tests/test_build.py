@@ -1,0 +1,38 @@
+"""Build-time properties of the product's kernels (no GPU needed: hipcc cross-compiles gfx950 code objects)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "p-dmpc_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.mark.timeout(600)
+def test_bulk_kernels_use_no_scratch_memory_and_spill_no_vgprs():
+    """the product's search kernel and its helper kernel fit their register budget (168 VGPRs at twelve
+    wavefronts per workgroup) without a byte of scratch memory.  The kernel sits close to the inliner's cliff (one more call site of
+    a large device function and helpers stop being inlined, their context then lives on the stack), so the build is checked."""
+    if not os.path.exists(HIPCC) and shutil.which("hipcc") is None:
+        pytest.skip("no hipcc")
+    cmd = [HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+           "-I" + os.path.join(ROOT, "include"), "-c", "-Rpass-analysis=kernel-resource-usage", "-o", os.devnull, os.path.join(CSRC, "bulk_kernel.hip")]
+    out = subprocess.run(cmd, capture_output=True, text=True, check=True).stderr
+    seen = {}
+    name = None
+    for line in out.splitlines():
+        m = re.search(r"Function Name: (\w+)", line)
+        if m:
+            name = m.group(1)
+            seen[name] = {}
+        for key, pat in (("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"), ("vgpr_spill", r"VGPRs Spill: (\d+)"), ("vgprs", r" VGPRs: (\d+)")):
+            m = re.search(pat, line)
+            if m and name:
+                seen[name][key] = int(m.group(1))
+    for kernel in ("pdmpc_bulk_kernel", "pdmpc_bulk_kernel_wide", "pdmpc_bulk_helper_kernel"):
+        assert kernel in seen, seen.keys()
+        assert seen[kernel]["scratch"] == 0 and seen[kernel]["vgpr_spill"] == 0, (kernel, seen[kernel])
+        assert seen[kernel]["vgprs"] <= 168, (kernel, seen[kernel])

@@ -9,7 +9,7 @@ for setting in "$@"; do
 import json, sys
 try:
     d = json.loads(sys.argv[3])
-    print(sys.argv[2], sys.argv[1], "steps/s", round(d["value"], 1), "ms", round(d["ms_per_step"], 3), "p50", round(d.get("p50_latency_ms", 0), 2), "p99", round(d.get("p99_latency_ms", 0), 2), "mm", d.get("replay_mismatches"), "bad", d.get("bad_status_plans_in_timed_region"), "proc", round(d["counters"]["nodes_processed_per_step"]), "rounds", round(d["counters"]["rounds_per_step"]), "shared", round(d["counters"]["shared_rounds_per_step"]))
+    print(sys.argv[2], sys.argv[1], "steps/s", round(d["value"], 1), "ms", round(d["ms_per_step"], 3), "p50", round(d.get("p50_latency_ms", 0), 2), "p99", round(d.get("p99_latency_ms", 0), 2), "max", round(d.get("max_latency_ms", 0), 2), "mm", d.get("replay_mismatches"), "bad", d.get("bad_status_plans_in_timed_region"), "proc", round(d["counters"]["nodes_processed_per_step"]), "rounds", round(d["counters"]["rounds_per_step"]), "shared", round(d["counters"]["shared_rounds_per_step"]))
 except Exception as e:
     print(sys.argv[2], sys.argv[1], "failed", e)
 PY
