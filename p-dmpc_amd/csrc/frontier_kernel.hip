@@ -137,7 +137,8 @@ __device__ __forceinline__ uint32_t fr_process(const KernelArgs& A, Ctx& X, cons
 // The search.  Returns true (to every wave) if a tie was met and the search has to be redone on the binary heap.
 template <int CHECKER, int NW>
 __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds_u32* ref_ids) {
-    const int tid = X.tid, lane = X.lane, wave = X.wave, slot = X.slot, Hp = X.Hp;
+    const int tid_k = X.tid, lane_k = X.lane, wave = X.wave, slot = X.slot, Hp = X.Hp;
+    int tid = tid_k, lane = lane_k;
     volatile lds_u32* sh = X.l_shared;
     Search& S = X.S;
     const VState& VS = X.VS;
@@ -256,6 +257,11 @@ __device__ __forceinline__ bool frontier_search(const KernelArgs& A, Ctx& X, lds
     const d2* hcs = (const d2*)A.help_cs + (size_t)slot * PDMPC_HELP_CAP;
     uint32_t help_seq = 0;  // rounds shared so far (same value in every thread)
     for (;;) {
+        // (the thread's index is made opaque once per round: the per-thread addresses the compiler derives from it would otherwise stay
+        // in registers across the whole loop; see bulk_kernel.hip / DESIGN.md section 3.4)
+        tid = tid_k;
+        lane = lane_k;
+        asm volatile("" : "+v"(tid), "+v"(lane));
         // ================= a round: every wave takes nodes off the ready list until the list is empty =================
         // children up to the largest key the round took may be taken along (fr_process), but none that comes after the best goal candidate
         double l_join = sh_ld_d(sh, FR_JOIN_MAX);
@@ -917,7 +923,8 @@ template <int CHECKER>
 __device__ __forceinline__ void helper_body(const KernelArgs& A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     LDS_AS unsigned char* lsm = (LDS_AS unsigned char*)smem;
-    const int tid = threadIdx.x, lane = tid & (PDMPC_WAVE - 1), wave = uni_i(tid >> 6);
+    const int tid_k = threadIdx.x, lane_k = tid_k & (PDMPC_WAVE - 1), wave = uni_i(tid_k >> 6);
+    int tid = tid_k, lane = lane_k;
     const int Hp = A.Hp, n_s = A.n_searches;
     // the owners' carve (search_prologue): only the regions an edge check reads are filled
     lds_u32* l_path = (lds_u32*)(lsm + A.lds.path);
@@ -988,6 +995,9 @@ __device__ __forceinline__ void helper_body(const KernelArgs& A) {
     P.Hp = Hp;
     uint32_t idle = 0;
     for (;;) {
+        tid = tid_k;  // (opaque per pass of the loop: see frontier_search)
+        lane = lane_k;
+        asm volatile("" : "+v"(tid), "+v"(lane));
         // ---- look for work: one lane per search, the first one (from pref on) with unclaimed entries is tried
         if (wave == 0) {
             uint32_t cmd = 0;

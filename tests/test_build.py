@@ -12,14 +12,19 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
 @pytest.mark.timeout(600)
-def test_bulk_kernels_use_no_scratch_memory_and_spill_no_vgprs():
-    """the product's search kernel and its helper kernel fit their register budget (168 VGPRs at twelve
-    wavefronts per workgroup) without a byte of scratch memory.  The kernel sits close to the inliner's cliff (one more call site of
-    a large device function and helpers stop being inlined, their context then lives on the stack), so the build is checked."""
+@pytest.mark.parametrize("source,kernels", [
+    ("bulk_kernel.hip", ("pdmpc_bulk_kernel", "pdmpc_bulk_kernel_wide", "pdmpc_bulk_helper_kernel")),
+    ("frontier_kernel.hip", ("pdmpc_frontier_kernel", "pdmpc_frontier_kernel_sat", "pdmpc_frontier_kernel_wide", "pdmpc_frontier_kernel_sat_wide", "pdmpc_helper_kernel")),
+])
+def test_round_based_kernels_use_no_scratch_memory_and_spill_no_vgprs(source, kernels):
+    """the product's search kernels (bulk: InterX; frontier: SAT and the tie fallback) and their helper kernels
+    fit their register budget (168 VGPRs at twelve wavefronts per workgroup) without a byte of scratch memory.  They sit close to the
+    inliner's cliff (one more call site of a large device function and helpers stop being inlined, their context then lives on the
+    stack), so the build is checked."""
     if not os.path.exists(HIPCC) and shutil.which("hipcc") is None:
         pytest.skip("no hipcc")
     cmd = [HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-           "-I" + os.path.join(ROOT, "include"), "-c", "-Rpass-analysis=kernel-resource-usage", "-o", os.devnull, os.path.join(CSRC, "bulk_kernel.hip")]
+           "-I" + os.path.join(ROOT, "include"), "-c", "-Rpass-analysis=kernel-resource-usage", "-o", os.devnull, os.path.join(CSRC, source)]
     out = subprocess.run(cmd, capture_output=True, text=True, check=True).stderr
     seen = {}
     name = None
@@ -32,7 +37,7 @@ def test_bulk_kernels_use_no_scratch_memory_and_spill_no_vgprs():
             m = re.search(pat, line)
             if m and name:
                 seen[name][key] = int(m.group(1))
-    for kernel in ("pdmpc_bulk_kernel", "pdmpc_bulk_kernel_wide", "pdmpc_bulk_helper_kernel"):
+    for kernel in kernels:
         assert kernel in seen, seen.keys()
         assert seen[kernel]["scratch"] == 0 and seen[kernel]["vgpr_spill"] == 0, (kernel, seen[kernel])
         assert seen[kernel]["vgprs"] <= 168, (kernel, seen[kernel])
