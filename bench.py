@@ -486,6 +486,7 @@ def main():
             "p50_latency_ms": 1e3 * statistics.median(lat),
             "p99_latency_ms": 1e3 * sorted(lat)[min(len(lat) - 1, int(0.99 * len(lat)))],
             "max_latency_ms": 1e3 * max(lat),
+            "max_latency_step": int(max(range(len(lat)), key=lambda i: lat[i])),
             "step_latencies_ms": [round(1e3 * x, 3) for x in lat] if len(lat) <= 40 else None,
             "host_buffer_ms_per_step": host_buffer_ms,  # PCIe-inclusive path incl. Python marshalling (never `value`)
             "value_host_inclusive": host_inclusive["value"] if host_inclusive else None,

@@ -908,11 +908,11 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     if (a.n_helpers > 0) {
         HIPCHK(hipMemsetAsync(h->d_help_board.p + (size_t)first * PDMPC_HB_WORDS, 0, (size_t)count * PDMPC_HB_WORDS * sizeof(unsigned long long), h->stream));
         HIPCHK(hipMemsetAsync(h->d_help_finished.p, 0, 16 * sizeof(uint32_t), h->stream));
-        HIPCHK(hipEventRecord(h->ev_help_pre, h->stream));  // the boards are clean
-        if (T.help_first) {  // diagnostic: the old order, helpers in front of the searches
+        if (!bulk) HIPCHK(hipEventRecord(h->ev_help_pre, h->stream));  // the boards are clean (the bulk kernel's helpers are workgroups of the same launch: nothing to order)
+        if (!bulk && T.help_first) {  // diagnostic: the old order, helpers in front of the searches
             hipStream_t hst0 = count > h->n_cu ? h->help_stream_low : h->help_stream;
             HIPCHK(hipStreamWaitEvent(hst0, h->ev_help_pre, 0));
-            const int hrc0 = bulk ? pdmpc_launch_bulk_helpers(&a, (void*)hst0, h->bulk_lds_hw) : pdmpc_launch_helpers(&a, (void*)hst0, h->frontier_lds_hw);
+            const int hrc0 = pdmpc_launch_helpers(&a, (void*)hst0, h->frontier_lds_hw);
             if (hrc0 != 0) return fail(PDMPC_ERR_HIP, "helper kernel launch failed");
             HIPCHK(hipEventRecord(h->ev_help_done, hst0));
         }
@@ -944,7 +944,9 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
         return fail(PDMPC_ERR_HIP, buf);
     }
     HIPCHK(hipEventRecord(ev.second, h->stream));
-    if (a.n_helpers > 0 && T.help_first) {
+    if (bulk) {
+        // (helpers are the trailing workgroups of the search launch itself)
+    } else if (a.n_helpers > 0 && T.help_first) {
         HIPCHK(hipStreamWaitEvent(h->stream, h->ev_help_done, 0));
     } else if (a.n_helpers > 0) {
         // The helper kernel goes out BEHIND the searches, on a stream of its own: it starts once the boards are clean and runs next
@@ -956,7 +958,7 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
         // to have left (they leave as soon as the last search has published).
         hipStream_t hst = count > h->n_cu ? h->help_stream_low : h->help_stream;
         HIPCHK(hipStreamWaitEvent(hst, h->ev_help_pre, 0));
-        const int hrc = bulk ? pdmpc_launch_bulk_helpers(&a, (void*)hst, h->bulk_lds_hw) : pdmpc_launch_helpers(&a, (void*)hst, h->frontier_lds_hw);
+        const int hrc = pdmpc_launch_helpers(&a, (void*)hst, h->frontier_lds_hw);
         if (hrc != 0) return fail(PDMPC_ERR_HIP, std::string("helper kernel launch failed: ") + hipGetErrorString((hipError_t)hrc));
         HIPCHK(hipEventRecord(h->ev_help_done, hst));
         HIPCHK(hipStreamWaitEvent(h->stream, h->ev_help_done, 0));

@@ -319,7 +319,7 @@ __device__ __forceinline__ void bk_write_record(const KernelArgs& A, Ctx& X, uin
     const Search& S = X.S;
     if (again) {  // as the prologue left it: zeros, y_predicted NaN (ControlResultsInfo.m:40)
         double* od = (double*)O;
-        const int nd = (int)(offsetof(pdmpc_vehicle_out, path_nodes) / 8) + (PDMPC_HP_MAX - 2) * 8;  // (the diagnostics rows of the tail stay)
+        const int nd = (int)(offsetof(pdmpc_vehicle_out, path_nodes) / 8) + (Hp + 1) * 8;  // (rows beyond the path are never written here: the diagnostics of the tail stay)
         const int y0 = (int)(offsetof(pdmpc_vehicle_out, y_predicted) / 8);
         const double qnan = __longlong_as_double(0x7ff8000000000000LL);
         for (int i = lane; i < nd; i += PDMPC_WAVE) od[i] = (i >= y0 && i < y0 + PDMPC_HP_MAX * 3) ? qnan : 0.0;
@@ -863,6 +863,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             if (tid == 0) {  // (nobody reads these words before the barrier that ends the round)
                 sh[FR_NNODES] = nn_base + (overflow ? 0u : NC);
                 sh[FR_PROCESSED] = sh[FR_PROCESSED] + Rn;
+                if (A.debug_tail && sh[FR_ROUNDS] < 40u) X.O->path_nodes[PDMPC_HP_MAX - 7 + (int)(sh[FR_ROUNDS] >> 3)][sh[FR_ROUNDS] & 7u] = (double)Rn;  // (diagnostics: the sizes of the first forty rounds in rows HP_MAX - 7 .. HP_MAX - 3)
                 sh[FR_ROUNDS] = sh[FR_ROUNDS] + 1u;
                 if (overflow) sh[FR_FLAGS] = sh[FR_FLAGS] | FRF_OVERFLOW;
             }
@@ -1123,10 +1124,27 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         }
 
         BK_OPAQUE_TID
-        // ---- near is empty (or holds nothing below far's smallest key): refill it from far
+        // A round takes the smallest open keys: bk_round0 while the search is young (a round costs about the same for one node as for a
+        // few dozen: the items of a small round run side by side), growing with the work done up to bk_round.
+        // (rounds stay at bk_round0 while every round gets one level deeper — a light search is over after Hp + 1 of them and what a
+        // round takes beyond what the reference pops is wasted; a search that stalls, or goes on beyond Hp + 2 rounds, is not light:
+        // its rounds grow with the work done)
+        uint32_t round_target;
+        {
+            const uint32_t done_so_far = sh[FR_PROCESSED];
+            const uint32_t depth_now = sh[BK_DEPTH];
+            heavy = heavy || depth_now == depth_seen || sh[FR_ROUNDS] > (uint32_t)Hp + 1u;
+            depth_seen = depth_now;
+            const uint32_t ramp = (uint32_t)A.bk_round0 + (heavy ? done_so_far / (uint32_t)A.fr_ramp : 0u);
+            round_target = ramp < (uint32_t)A.bk_round ? ramp : (uint32_t)A.bk_round;
+        }
+        // ---- near holds fewer entries than the round wants (or nothing below far's smallest key): it is topped up from far with the
+        // smallest entries far holds, as many as leave room for a round's children.  (Topping up when near is EMPTY only made a heavy
+        // search alternate between rounds of a thousand nodes, the few hundred those left behind, and a handful of new children.)
         uint32_t nn_near = near_n;
-        if (nn_near == 0u || far_min < near_min) {
-            if (nn_near != 0u) {  // (rare: merge near into far first so that the refill sees every open entry)
+        const bool merge = nn_near != 0u && far_min < near_min;
+        if (far_n != 0u && (nn_near < round_target || merge)) {
+            if (merge) {  // (rare: near goes into far first so that the refill sees every open entry)
                 for (uint32_t b0 = 0; b0 < nn_near; b0 += (uint32_t)bd) {
                     const uint32_t e = b0 + (uint32_t)tid;
                     const bool in = e < nn_near;
@@ -1136,9 +1154,11 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 __syncthreads();
                 if (tid == 0) sh[FR_NEAR_N] = 0;
                 __syncthreads();
+                nn_near = 0;
             }
             const uint32_t fn = sh[FR_FAR_N];
-            const uint32_t fill = OC / 2u;
+            const uint32_t room = OC - OC / 6u;  // (a sixth of near stays free for the children of the rounds to come)
+            const uint32_t fill = room > nn_near + 64u ? room - nn_near : 64u;
             double lo = sh_ld_d(sh, FR_FAR_MIN), hi = sh_ld_d(sh, FR_FAR_MAX);
             uint32_t bsel = FR_NBINS - 1;
             double scale = 0.0;
@@ -1153,16 +1173,20 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 bsel = sh[FR_SEL_BIN];
                 const uint32_t cum = sh[FR_SEL_CUM];
                 __syncthreads();
-                if (bsel != 0u || cum <= OC - 64u || scale == 0.0) break;
+                if (bsel != 0u || nn_near + cum <= OC - 64u || scale == 0.0) break;
                 hi = lo + (hi - lo) / (double)FR_NBINS;  // nearly everything sits in the first bin: look closer
             }
             const double l_far_new = (bsel >= FR_NBINS - 1 || scale == 0.0) ? inf : lo + (double)(bsel + 1u) / scale;
             if (tid == 0) {
                 sh_st_d(sh, FR_FAR_MIN, inf);
                 sh_st_d(sh, FR_FAR_MAX, 0.0);
-                sh_st_d(sh, FR_NEAR_MIN, inf);
-                sh_st_d(sh, FR_NEAR_MAX, 0.0);
-                sh_st_d(sh, FR_L_FAR, l_far_new);
+                if (nn_near == 0u) {  // (else near's key range stays and takes the new entries in)
+                    sh_st_d(sh, FR_NEAR_MIN, inf);
+                    sh_st_d(sh, FR_NEAR_MAX, 0.0);
+                }
+                // children up to this key join near from now on (what near still holds lies below the old limit, what far held above it)
+                const double l_old = sh_ld_d(sh, FR_L_FAR);
+                sh_st_d(sh, FR_L_FAR, (nn_near != 0u && l_old > l_far_new && l_old < inf) ? l_old : l_far_new);
             }
             __syncthreads();
             const double lo_c = lo, scale_c = scale;
@@ -1213,17 +1237,6 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         {
             const double lo = sh_ld_d(sh, FR_NEAR_MIN);
             double hi = sh_ld_d(sh, FR_NEAR_MAX);
-            // A round takes the smallest open keys: bk_round0 while the search is young (a round costs about the same for one node as
-            // for a few dozen: the items of a small round run side by side), growing with the work done up to bk_round.
-            const uint32_t done_so_far = sh[FR_PROCESSED];
-            // (rounds stay at bk_round0 while every round gets one level deeper — a light search is over after Hp + 1 of them and
-            // what a round takes beyond what the reference pops is wasted; a search that stalls, or goes on beyond Hp + 2 rounds, is
-            // not light: its rounds grow with the work done)
-            const uint32_t depth_now = sh[BK_DEPTH];
-            heavy = heavy || depth_now == depth_seen || sh[FR_ROUNDS] > (uint32_t)Hp + 1u;
-            depth_seen = depth_now;
-            const uint32_t ramp = (uint32_t)A.bk_round0 + (heavy ? done_so_far / (uint32_t)A.fr_ramp : 0u);
-            const uint32_t round_target = ramp < (uint32_t)A.bk_round ? ramp : (uint32_t)A.bk_round;
             double kk[BK_PER];
             uint32_t ii[BK_PER];
 #pragma unroll
@@ -1386,7 +1399,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
 
 
 // ---------------------------------------------------------------------------------------------------
-// Helper workgroups of the bulk kernel (pdmpc_bulk_helper_kernel, launched next to the searches on a stream of its own): they look
+// Helper workgroups of the bulk kernel (the workgroups of a launch behind its searches, bulk_body): they look
 // for a search that has posted a round, claim a tile of TILE entries, mirror that search's obstacle soup in their own LDS
 // (literal obstacles, lanelet boundary, the areas of the predecessors the owner had incorporated when it posted), run the
 // tile's check items — the owner's own code on the posted records — and leave one verdict word per entry.  A helper never waits
@@ -1580,6 +1593,13 @@ __device__ __forceinline__ void bulk_helper_body(const KernelArgs& A) {
 
 template <int NW>
 __device__ __forceinline__ void bulk_body(const KernelArgs& A) {
+    // The workgroups behind the searches are their helpers: one launch, so the helpers are dispatched with (for launches with more
+    // searches than CUs: right behind) the searches they serve — a helper kernel of its own on a second stream now and then shared a
+    // hardware queue with the launch stream and started when the searches were through (one step in a hundred without helpers).
+    if ((int)blockIdx.x >= A.n_searches) {  // (uniform over the workgroup)
+        bulk_helper_body(A);
+        return;
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Ctx X;
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
@@ -1614,20 +1634,6 @@ __device__ __forceinline__ void bulk_body(const KernelArgs& A) {
 extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) void pdmpc_bulk_kernel(const KernelArgs A) { bulk_body<1>(A); }
 extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) void pdmpc_bulk_kernel_wide(const KernelArgs A) { bulk_body<0>(A); }
 
-extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) void pdmpc_bulk_helper_kernel(const KernelArgs A) { bulk_helper_body(A); }
-
-extern "C" int pdmpc_launch_bulk_helpers(const KernelArgs* args, void* stream, uint32_t* lds_high_water) {
-    if (args->n_helpers <= 0) return 0;
-    uint32_t& have = lds_high_water[2];
-    if (args->lds.total > have) {
-        hipError_t e = hipFuncSetAttribute((const void*)pdmpc_bulk_helper_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)args->lds.total);
-        if (e != hipSuccess) return (int)e;
-        have = args->lds.total;
-    }
-    hipLaunchKernelGGL(pdmpc_bulk_helper_kernel, dim3(args->n_helpers), dim3(PDMPC_WAVE * args->n_waves), args->lds.total, (hipStream_t)stream, *args);
-    return (int)hipGetLastError();
-}
-
 extern "C" int pdmpc_launch_bulk(const KernelArgs* args, int count, void* stream, uint32_t* lds_high_water) {
     if (count <= 0) return 0;
     typedef void (*kernel_t)(const KernelArgs);
@@ -1640,6 +1646,6 @@ extern "C" int pdmpc_launch_bulk(const KernelArgs* args, int count, void* stream
         if (e != hipSuccess) return (int)e;
         have = args->lds.total;
     }
-    hipLaunchKernelGGL(fn, dim3(count), dim3(PDMPC_WAVE * args->n_waves), args->lds.total, (hipStream_t)stream, *args);
+    hipLaunchKernelGGL(fn, dim3(count + (args->n_helpers > 0 ? args->n_helpers : 0)), dim3(PDMPC_WAVE * args->n_waves), args->lds.total, (hipStream_t)stream, *args);
     return (int)hipGetLastError();
 }

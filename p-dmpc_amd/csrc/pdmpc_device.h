@@ -214,10 +214,8 @@ int pdmpc_launch_heap_script(const int32_t* op, const int32_t* id, const double*
 int pdmpc_launch_sampled(const KernelArgs* args, int count, void* stream);
 // defined in frontier_kernel.hip: the search with all wavefronts of a workgroup working on open nodes side by side
 int pdmpc_launch_frontier(const KernelArgs* args, int count, void* stream, uint32_t* lds_high_water /* [5], kept by the handle */);
-// defined in bulk_kernel.hip: the search as bulk-synchronous passes; lds_high_water[2] = the handle's record of the dynamic LDS size set so far per kernel variant
+// defined in bulk_kernel.hip: the search as bulk-synchronous passes (count searches + args->n_helpers helper workgroups in ONE launch); lds_high_water[2] = the handle's record of the dynamic LDS size set so far per kernel variant
 int pdmpc_launch_bulk(const KernelArgs* args, int count, void* stream, uint32_t* lds_high_water);
-// ... and its helper workgroups (args->n_helpers of them; they serve the searches of a pdmpc_launch_bulk with the same args)
-int pdmpc_launch_bulk_helpers(const KernelArgs* args, void* stream, uint32_t* lds_high_water);
 // defined in frontier_kernel.hip; launches args->n_helpers helper workgroups (they serve the searches of a pdmpc_launch_frontier with the same args)
 int pdmpc_launch_helpers(const KernelArgs* args, void* stream, uint32_t* lds_high_water);
 // defined in debug_kernels.hip: the collision primitives of edge_checks.hpp on given polygons, one wavefront per case
