@@ -1162,16 +1162,25 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             double lo = sh_ld_d(sh, FR_FAR_MIN), hi = sh_ld_d(sh, FR_FAR_MAX);
             uint32_t bsel = FR_NBINS - 1;
             double scale = 0.0;
+            // (a far list of tens of thousands of entries is histogrammed on a sample: every stride-th entry.  The threshold only has to
+            // bring about `fill` entries; what the chosen bins hold beyond near's room goes back, what they hold less comes next time)
+            const uint32_t stride = fn > 16384u ? fn / 8192u : 1u;
+            const uint32_t fill_s = stride > 1u ? (fill / stride > 16u ? fill / stride : 16u) : fill;
             for (int zoom = 0; zoom < 6; ++zoom) {
                 scale = hi > lo ? (double)FR_NBINS / (hi - lo) : 0.0;
                 for (int i = tid; i < FR_NBINS; i += bd) hist[i] = 0;
                 __syncthreads();
-                fr_histogram(F, F.far_key, fn, lo, scale);
+                if (stride == 1u) {
+                    fr_histogram(F, F.far_key, fn, lo, scale);
+                } else {
+                    for (uint32_t e = (uint32_t)tid * stride; e < fn; e += (uint32_t)bd * stride)
+                        __hip_atomic_fetch_add(&hist[fr_bin(F.far_key[e], lo, scale)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
                 __syncthreads();
-                if (wave == 0) fr_select2(F, fill, fill, FR_SEL_BIN, FR_SEL_BIN, lane);
+                if (wave == 0) fr_select2(F, fill_s, fill_s, FR_SEL_BIN, FR_SEL_BIN, lane);
                 __syncthreads();
                 bsel = sh[FR_SEL_BIN];
-                const uint32_t cum = sh[FR_SEL_CUM];
+                const uint32_t cum = sh[FR_SEL_CUM] * stride;
                 __syncthreads();
                 if (bsel != 0u || nn_near + cum <= OC - 64u || scale == 0.0) break;
                 hi = lo + (hi - lo) / (double)FR_NBINS;  // nearly everything sits in the first bin: look closer
