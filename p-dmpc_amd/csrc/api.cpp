@@ -217,6 +217,8 @@ struct pdmpc_handle {
     bool force_frontier = false;  // this launch: the frontier kernel, which carries the binary heap (a search of the bulk kernel met a tie)
     bool last_launch_bulk = false;
     int last_first = 0, last_count = 0;  // slots of the last launch_range
+    std::vector<std::pair<int, int>> step_ranges;  // the slot ranges launched with the bulk kernel since the step began (this epoch): what a tie plans again
+    uint32_t step_ranges_epoch = 0;
     uint32_t bulk_lds_hw[3] = {0, 0, 0}; // dynamic LDS size set so far on the bulk kernel's variants and its helper kernel (hipFuncSetAttribute is a maximum)
     uint32_t frontier_lds_hw[5] = {0, 0, 0, 0, 0};  // ... and on the frontier kernel's four variants and its helper kernel
     DevBuf<double> d_bk_post;            // bulk kernel: records posted for the helper workgroups (pdmpc_device.h)
@@ -359,7 +361,9 @@ bool layout_bulk(pdmpc_handle* h, size_t budget, int n_waves, int areas, int sou
 }
 
 bool use_bulk(const pdmpc_handle* h) {
-    return h->kernel_frontier && h->kernel_bulk && !h->force_frontier && !h->sampled_launch && h->cfg.checker == PDMPC_CHECK_INTERX;
+    // (InterX checker, one successor-mask word: every BASELINE automaton; the SAT checker, automata with more than 64 trims and a
+    // search that met a tie run the frontier kernel)
+    return h->kernel_frontier && h->kernel_bulk && !h->force_frontier && !h->sampled_launch && h->cfg.checker == PDMPC_CHECK_INTERX && h->n_words == 1;
 }
 
 // helper workgroups serve the bulk kernel's launches that leave CUs idle (launch_range)
@@ -923,6 +927,11 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     h->last_launch_bulk = bulk;
     h->last_first = first;
     h->last_count = count;
+    if (h->step_ranges_epoch != h->epoch) {
+        h->step_ranges.clear();
+        h->step_ranges_epoch = h->epoch;
+    }
+    if (bulk) h->step_ranges.emplace_back(first, count);
     auto launch_round_based = [&](const KernelArgs* ka, int cnt) {
         return bulk ? pdmpc_launch_bulk(ka, cnt, (void*)h->stream, h->bulk_lds_hw) : pdmpc_launch_frontier(ka, cnt, (void*)h->stream, h->frontier_lds_hw);
     };
@@ -1270,10 +1279,15 @@ int pdmpc_fetch_results(pdmpc_handle* h, int32_t n, pdmpc_vehicle_out* out) {
         bool tie = false;
         for (int i = 0; i < n; ++i) tie = tie || out[i].status == PDMPC_INTERNAL_TIE;
         if (tie) {
+            // every range this handle launched in the step (a level-sharded step launches one per level): a later level has read the
+            // tied search's record
             h->tie_replans += 1;
-            HIPCHK(hipMemsetAsync(h->d_flag.p + h->last_first, 0, (size_t)h->last_count * sizeof(uint32_t), h->stream));
+            const std::vector<std::pair<int, int>> ranges = h->step_ranges;
+            for (const auto& r : ranges) HIPCHK(hipMemsetAsync(h->d_flag.p + r.first, 0, (size_t)r.second * sizeof(uint32_t), h->stream));
             h->force_frontier = true;
-            const int rc = launch_range(h, h->last_first, h->last_count);
+            int rc = 0;
+            for (const auto& r : ranges)
+                if (!rc) rc = launch_range(h, r.first, r.second);
             h->force_frontier = false;
             if (rc) return rc;
             HIPCHK(hipMemcpyAsync(out, h->d_out.p, (size_t)n * sizeof(pdmpc_vehicle_out), hipMemcpyDeviceToHost, h->stream));

@@ -94,6 +94,7 @@ struct BkCheck {
 #define BK_NTENT FR_SEL2_BIN     // parked nodes
 #define BK_ARRIVALS FR_SEL2_CUM  // arrival events handled by this search
 #define BK_DEPTH FR_RD_HEAD       // deepest collision-free node so far (its step k)
+#define BK_IDLE FR_RD_TAIL        // polls a waiting search has made (the watchdog's count)
 
 // copies the expected areas of the predecessors in `who` into their soup slots
 __device__ __forceinline__ void bk_tentative_areas(const KernelArgs& A, const SpecCtx& P, unsigned long long who, int tid, int nthreads) {
@@ -403,6 +404,12 @@ __device__ __forceinline__ void bk_publish(const KernelArgs& A, const Ctx& X, in
     }
 }
 
+// The far-list selection stays an out-of-line call: it runs once per refill on one wavefront, and inlined into the search loop its
+// registers push the whole kernel over the 168-VGPR budget of a twelve-wavefront workgroup (tests/test_build.py watches this).
+__device__ __noinline__ void bk_far_select(const Frontier& F, uint32_t fill, int lane) {
+    fr_select2(F, fill, fill, FR_SEL_BIN, FR_SEL_BIN, lane);
+}
+
 // The search.  Returns true (to every thread) if a tie was met: the host plans the call again with the heap-carrying kernel.
 template <int NW>
 __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32* ref_ids) {
@@ -520,7 +527,6 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
     int status = PDMPC_OK;
     bool dep_timeout = X.dep_timeout;
     uint32_t goal = 0;
-    uint32_t idle_polls = 0;
     uint32_t Rn = 1;  // entries of the ready list (uniform: every thread carries it)
     uint32_t depth_seen = 0xffffffffu;  // deepest collision-free node at the last selection
     bool heavy = false;                 // the search has stalled once: its rounds grow
@@ -579,11 +585,24 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         near_mn = inf;
         near_mx = 0.0;
     };
+    // A search that can do nothing but wait for a predecessor (finished, or stalled on parked nodes): the first wave polls the
+    // pending predecessors' done flags in a tight loop — an arrival is on every successor's critical path — while the others wait at
+    // the barrier.  Returns (to every thread) whether the watchdog's limit of polls has been reached.
+    auto bk_wait = [&]() -> bool {
+        if (wave == 0) {
+            uint32_t spins = 0;
+            while (!poll_predecessors(A, P, sh, lane) && ++spins < 4096u) __builtin_amdgcn_s_sleep(1);
+            if (lane == 0) sh[BK_IDLE] = sh[BK_IDLE] + spins + 1u;
+        }
+        __syncthreads();
+        return sh[BK_IDLE] > A.spin_limit;
+    };
     PhaseB R;
     R.n_popped = 0;
     R.n_expanded = 0;
     bool pb_valid = false;
     bool rec_valid = false, rec_written = false;  // the result record in HBM is the one this search would publish now / some record has been written
+    bool vs_copied = false;                       // the LDS validity bytes have been copied to HBM since the tree last changed
     // shared rounds (helper workgroups)
     unsigned long long* board = A.help_board + (size_t)slot * PDMPC_HB_WORDS;
     uint32_t help_seq = 0;  // rounds shared so far (same value in every thread)
@@ -606,6 +625,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         if (Rn) {
             pb_valid = false;  // (the tree grows: phase B's result is stale)
             rec_valid = false;
+            vs_copied = false;
             // ---- P1: check items + sincos items.  A large round is shared with the helper workgroups (CUs this launch leaves idle):
             // the owner posts one 48-byte record per entry (what a check reads of the tree), keeps the first tiles of 64 entries and
             // offers the others; helpers claim tiles (compare-and-swap on the board's ticket word, which carries the round's sequence
@@ -924,7 +944,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         // predecessors that finished meanwhile: their areas enter the soup, collision-free edges are re-checked
         const bool pending = sh_load64(sh, SH_PEND_LO) != 0ull;  // (uniform: written by thread 0 between barriers)
         if (pending) {
-            if (wave == 0) (void)poll_predecessors(A, P, sh, lane);
+            if (wave == 0 && sh[SH_STATE] != ST_ARRIVED) (void)poll_predecessors(A, P, sh, lane);  // (a waiting search has polled already: bk_wait)
             __syncthreads();
         }
         if (pending && sh[SH_STATE] == ST_ARRIVED) {
@@ -982,6 +1002,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 pb_valid = false;
                 rec_valid = false;
             }
+            vs_copied = false;  // (verdicts may have changed, parked nodes have come back)
             __syncthreads();
             if (tid == 0) {
                 sh[BK_ARRIVALS] = sh[BK_ARRIVALS] + 1u;  // (reported at the end: a global atomic here sits on every level's hand-over)
@@ -1084,8 +1105,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             stalled = near_n == 0u && far_n == 0u && !done;
         }
         if (stalled) {  // (uniform) wait for a predecessor
-            __builtin_amdgcn_s_sleep(4);
-            if (++idle_polls > A.spin_limit) {
+            if (bk_wait()) {
                 dep_timeout = true;
                 status = PDMPC_EXHAUSTED;
                 break;
@@ -1117,8 +1137,15 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 rec_valid = true;
                 rec_written = true;
             }
-            __builtin_amdgcn_s_sleep(4);
-            if (++idle_polls > A.spin_limit) dep_timeout = true;  // a predecessor never finished: give up on it (reported as an error status)
+            // (c) the validity bytes of the LDS-resident nodes go to HBM now as well (debug read-back of the tree): not behind the last arrival
+            if (!vs_copied) {
+                uint32_t nn1 = sh[FR_NNODES];
+                nn1 = nn1 < S.max_nodes ? nn1 : S.max_nodes;
+                const uint32_t nv = VS.NV < nn1 ? VS.NV : nn1;
+                for (uint32_t i = (uint32_t)tid; i < nv; i += (uint32_t)bd) VS.g[i] = VS.l[i];
+                vs_copied = true;
+            }
+            if (bk_wait()) dep_timeout = true;  // a predecessor never finished: give up on it (reported as an error status)
             BK_TICK(tk_wait)
             continue;
         }
@@ -1177,7 +1204,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                         __hip_atomic_fetch_add(&hist[fr_bin(F.far_key[e], lo, scale)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 __syncthreads();
-                if (wave == 0) fr_select2(F, fill_s, fill_s, FR_SEL_BIN, FR_SEL_BIN, lane);
+                if (wave == 0) bk_far_select(F, fill_s, lane);
                 __syncthreads();
                 bsel = sh[FR_SEL_BIN];
                 const uint32_t cum = sh[FR_SEL_CUM] * stride;
@@ -1351,7 +1378,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
     }
     // validity bytes of the LDS-resident nodes go to HBM with the rest (debug read-back of the tree, pdmpc_debug_tree)
     {
-        const uint32_t nv = VS.NV < nnodes_raw ? VS.NV : nnodes_raw;
+        const uint32_t nv = vs_copied ? 0u : (VS.NV < nnodes_raw ? VS.NV : nnodes_raw);
         for (uint32_t i = (uint32_t)tid_r; i < nv; i += (uint32_t)bd) VS.g[i] = VS.l[i];
     }
     {  // work counters: one atomic per wave
@@ -1641,15 +1668,14 @@ __device__ __forceinline__ void bulk_body(const KernelArgs& A) {
 }  // namespace
 
 extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) void pdmpc_bulk_kernel(const KernelArgs A) { bulk_body<1>(A); }
-extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) void pdmpc_bulk_kernel_wide(const KernelArgs A) { bulk_body<0>(A); }
 
 extern "C" int pdmpc_launch_bulk(const KernelArgs* args, int count, void* stream, uint32_t* lds_high_water) {
     if (count <= 0) return 0;
     typedef void (*kernel_t)(const KernelArgs);
-    const bool one_word = args->n_words == 1;
-    kernel_t fn = one_word ? pdmpc_bulk_kernel : pdmpc_bulk_kernel_wide;
+    if (args->n_words != 1) return (int)hipErrorInvalidValue;  // (automata with more than 64 trims run the frontier kernel: api.cpp, use_bulk)
+    kernel_t fn = pdmpc_bulk_kernel;
     // (the attribute is a maximum: raised when a launch needs more than any before it; the high-water mark lives in the handle)
-    uint32_t& have = lds_high_water[one_word ? 0 : 1];
+    uint32_t& have = lds_high_water[0];
     if (args->lds.total > have) {
         hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)args->lds.total);
         if (e != hipSuccess) return (int)e;

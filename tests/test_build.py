@@ -13,7 +13,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("source,kernels", [
-    ("bulk_kernel.hip", ("pdmpc_bulk_kernel", "pdmpc_bulk_kernel_wide")),
+    ("bulk_kernel.hip", ("pdmpc_bulk_kernel",)),
     ("frontier_kernel.hip", ("pdmpc_frontier_kernel", "pdmpc_frontier_kernel_sat", "pdmpc_frontier_kernel_wide", "pdmpc_frontier_kernel_sat_wide", "pdmpc_helper_kernel")),
 ])
 def test_round_based_kernels_use_no_scratch_memory_and_spill_no_vgprs(source, kernels):
