@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -102,14 +103,18 @@ const size_t kLdsMax = 160 * 1024;  // gfx950: 160 KiB per CU (MI355X_MICROARCH.
 
 }  // namespace
 
-// one packed batch: host mirror (pinned) + device copy
+// one packed batch: host mirror (pinned) + device copy, each ONE allocation -- [DevVehicle records | points pool | predecessor slots] --
+// so a pack is one host-to-device copy
 struct PackedStep {
-    PinnedBuf<DevVehicle> h_veh;
-    PinnedBuf<double> h_pts;
-    PinnedBuf<int32_t> h_pred;
-    DevBuf<DevVehicle> d_veh;
-    DevBuf<double> d_pts;
-    DevBuf<int32_t> d_pred;
+    PinnedBuf<unsigned char> h_blob;
+    DevBuf<unsigned char> d_blob;
+    DevVehicle* h_veh = nullptr;  // (views into the blobs, set by pack_common)
+    double* h_pts = nullptr;
+    int32_t* h_pred = nullptr;
+    DevVehicle* d_veh = nullptr;
+    double* d_pts = nullptr;
+    int32_t* d_pred = nullptr;
+    uint64_t staged_serial = ~0ull;  // the handle's sync_serial when the copy out of h_blob was queued (pack_common)
     int n_packed = 0;
     int soup_cap = 0;
     int cand_cap = 0;  // most segments any single edge check can see (one step's soups + the boundary)
@@ -117,12 +122,11 @@ struct PackedStep {
     std::vector<int32_t> perm;      // empty: slot s holds the caller's vehicle s; else slot s holds vehicle perm[s] (pack_common put the batch into level order)
     std::vector<int32_t> inv;       // ... and vehicle v sits in slot inv[v]
     void release() {
-        h_veh.release();
-        h_pts.release();
-        h_pred.release();
-        d_veh.release();
-        d_pts.release();
-        d_pred.release();
+        h_blob.release();
+        d_blob.release();
+        h_veh = d_veh = nullptr;
+        h_pts = d_pts = nullptr;
+        h_pred = d_pred = nullptr;
     }
 };
 
@@ -219,6 +223,14 @@ struct pdmpc_handle {
     int last_first = 0, last_count = 0;  // slots of the last launch_range
     std::vector<std::pair<int, int>> step_ranges;  // the slot ranges launched with the bulk kernel since the step began (this epoch): what a tie plans again
     uint32_t step_ranges_epoch = 0;
+    bool boards_dirty = true;            // the helper boards / the finished counter need clearing before the bulk kernel's helpers may read them
+    uint32_t help_fin_total = 0;         // value of the finished counter once every launch so far has ended (bulk kernel)
+    double dbg_us[4] = {0, 0, 0, 0};     // PDMPC_DEBUG_HOST=2: pack, launch, fetch (host clock) and kernel (events) time of the plan_batch calls
+    uint64_t sync_serial = 0;            // stream synchronisations through sync_stream so far (PackedStep::staged_serial)
+    std::vector<double> pack_pts;        // pack_common's scratch (kept: a pack allocates nothing once warm)
+    std::vector<int32_t> pack_pred;
+    std::vector<DevVehicle> pack_veh;
+    PinnedBuf<pdmpc_vehicle_out> h_out;  // pdmpc_fetch_results: the records land in pinned memory (a copy into the caller's pageable array goes through the runtime's staging otherwise)
     uint32_t bulk_lds_hw[3] = {0, 0, 0}; // dynamic LDS size set so far on the bulk kernel's variants and its helper kernel (hipFuncSetAttribute is a maximum)
     uint32_t frontier_lds_hw[5] = {0, 0, 0, 0, 0};  // ... and on the frontier kernel's four variants and its helper kernel
     DevBuf<double> d_bk_post;            // bulk kernel: records posted for the helper workgroups (pdmpc_device.h)
@@ -252,6 +264,13 @@ struct pdmpc_handle {
 };
 
 namespace {
+
+// hipStreamSynchronize on the launch stream, counted: a bank whose staging copy was queued before is free again (pack_common)
+inline hipError_t sync_stream(pdmpc_handle* h) {
+    const hipError_t e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) h->sync_serial += 1;
+    return e;
+}
 
 // LDS layout of the frontier kernel for one choice of (budget, wavefronts, maneuver areas in LDS or read through L2).
 // Regions: MPA tables, reference, per-wave shapes, shared words, obstacle soup, per-wave scratch (candidate list of an edge
@@ -569,10 +588,14 @@ int pack_common(pdmpc_handle* h, int n, const pdmpc_vehicle_in* in, const int32_
     const int Hp = h->cfg.Hp;
     PackedStep& B = h->banks[h->bank];
     const double qnan = std::numeric_limits<double>::quiet_NaN();
-    std::vector<double> pts;
-    pts.reserve((size_t)n * 256);
-    std::vector<int32_t> pred;
-    if (B.h_veh.ensure((size_t)std::max(n, 1))) return fail(PDMPC_ERR_HIP, "hipHostMalloc failed");
+    // the staging blob is reused: a copy out of it that may still be in flight (no stream synchronisation since it was queued) ends first
+    if (B.staged_serial == h->sync_serial) HIPCHK(sync_stream(h));
+    std::vector<double>& pts = h->pack_pts;
+    std::vector<int32_t>& pred = h->pack_pred;
+    std::vector<DevVehicle>& veh = h->pack_veh;
+    pts.clear();
+    pred.clear();
+    veh.resize((size_t)std::max(n, 1));
     B.lit_cols.assign((size_t)n, 0);
     int soup_cap = 0, cand_cap = 0;
     // Slot order.  A search spins for predecessors of the same launch, so every predecessor must sit in a lower slot than its
@@ -630,7 +653,7 @@ int pack_common(pdmpc_handle* h, int n, const pdmpc_vehicle_in* in, const int32_
         const int i = slot_i;  // (slot: index into the packed arrays)
         const int vi = permuted ? B.perm[(size_t)slot_i] : slot_i;  // (the caller's vehicle)
         const pdmpc_vehicle_in& v = in[vi];
-        DevVehicle& d = B.h_veh.p[i];
+        DevVehicle& d = veh[(size_t)i];
         std::memset(&d, 0, sizeof d);
         if (!v.ref_x || !v.ref_y || !v.v_ref) return fail(PDMPC_ERR_INVALID, "reference trajectory missing");
         if (v.trim0 < 1 || v.trim0 > h->n_trims) return fail(PDMPC_ERR_INVALID, "trim0 out of range");
@@ -713,16 +736,24 @@ int pack_common(pdmpc_handle* h, int n, const pdmpc_vehicle_in* in, const int32_
     pred.push_back(0);
     B.soup_cap = soup_cap + 2;
     B.cand_cap = (cand_cap + 4 + 3) & ~3;
-    if (B.h_pts.ensure(pts.size()) || B.h_pred.ensure(pred.size())) return fail(PDMPC_ERR_HIP, "hipHostMalloc failed");
-    std::memcpy(B.h_pts.p, pts.data(), pts.size() * sizeof(double));
-    std::memcpy(B.h_pred.p, pred.data(), pred.size() * sizeof(int32_t));
-    if (B.d_veh.ensure((size_t)std::max(n, 1)) || B.d_pts.ensure(pts.size()) || B.d_pred.ensure(pred.size()))
-        return fail(PDMPC_ERR_HIP, "hipMalloc failed for the batch blob");
-    if (n > 0) HIPCHK(hipMemcpyAsync(B.d_veh.p, B.h_veh.p, (size_t)n * sizeof(DevVehicle), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(B.d_pts.p, B.h_pts.p, pts.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(B.d_pred.p, B.h_pred.p, pred.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-    // the pinned staging buffers are reused by the next pack: finish the copies first
-    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t veh_bytes = ((size_t)std::max(n, 1) * sizeof(DevVehicle) + 15) & ~(size_t)15;
+    const size_t pts_bytes = (pts.size() * sizeof(double) + 15) & ~(size_t)15;
+    const size_t pred_bytes = (pred.size() * sizeof(int32_t) + 15) & ~(size_t)15;
+    const size_t total = veh_bytes + pts_bytes + pred_bytes;
+    if (B.h_blob.ensure(total)) return fail(PDMPC_ERR_HIP, "hipHostMalloc failed");
+    if (B.d_blob.ensure(total)) return fail(PDMPC_ERR_HIP, "hipMalloc failed for the batch blob");
+    B.h_veh = (DevVehicle*)B.h_blob.p;
+    B.h_pts = (double*)(B.h_blob.p + veh_bytes);
+    B.h_pred = (int32_t*)(B.h_blob.p + veh_bytes + pts_bytes);
+    B.d_veh = (DevVehicle*)B.d_blob.p;
+    B.d_pts = (double*)(B.d_blob.p + veh_bytes);
+    B.d_pred = (int32_t*)(B.d_blob.p + veh_bytes + pts_bytes);
+    std::memcpy(B.h_veh, veh.data(), (size_t)std::max(n, 1) * sizeof(DevVehicle));
+    std::memcpy(B.h_pts, pts.data(), pts.size() * sizeof(double));
+    std::memcpy(B.h_pred, pred.data(), pred.size() * sizeof(int32_t));
+    // one copy, not waited for: whatever the stream does next is ordered behind it, and the next pack into this bank waits (above)
+    HIPCHK(hipMemcpyAsync(B.d_blob.p, B.h_blob.p, total, hipMemcpyHostToDevice, h->stream));
+    B.staged_serial = h->sync_serial;
     B.n_packed = n;
     h->events_used = 0;
     std::memset(&h->stats, 0, sizeof h->stats);
@@ -775,9 +806,9 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     a.checker = h->cfg.checker;
     a.areas_in_lds = h->areas_in_lds;
     a.dt = h->cfg.dt_seconds;
-    a.veh = B.d_veh.p;
-    a.points = B.d_pts.p;
-    a.pred = B.d_pred.p;
+    a.veh = B.d_veh;
+    a.points = B.d_pts;
+    a.pred = B.d_pred;
     a.out = h->d_out.p;
     a.done_flag = h->d_flag.p;
     a.epoch = h->epoch;
@@ -909,9 +940,19 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     }
     if (a.help_chunk == 0) a.help_chunk = a.help_expand ? 32 : 64;  // measured on C2 / C3: expanding helpers 64 -> 555 / 595 steps/s, 32 -> 595 / 584; checking only: 64 best (C4 43.3 against 40.9)
     a.help_finished = h->d_help_finished.p;
-    if (a.n_helpers > 0) {
-        HIPCHK(hipMemsetAsync(h->d_help_board.p + (size_t)first * PDMPC_HB_WORDS, 0, (size_t)count * PDMPC_HB_WORDS * sizeof(unsigned long long), h->stream));
+    a.help_fin_base = 0;
+    if (a.n_helpers > 0 && bulk && !h->boards_dirty) {
+        // The bulk kernel leaves its boards closed (a search closes every round it shares before it uses the verdicts, and a closed
+        // ticket word offers nothing) and counts finished searches on from launch to launch: nothing to clear between launches --
+        // two memset dispatches less per launch.  Anything else that touched the boards (the frontier kernel's helpers, a launch
+        // that ended with a watchdog status) marks them dirty and the next launch clears them as before.
+        a.help_fin_base = h->help_fin_total;
+        h->help_fin_total += (uint32_t)count;
+    } else if (a.n_helpers > 0) {
+        HIPCHK(hipMemsetAsync(h->d_help_board.p, 0, (size_t)h->max_vehicles * PDMPC_HB_WORDS * sizeof(unsigned long long), h->stream));
         HIPCHK(hipMemsetAsync(h->d_help_finished.p, 0, 16 * sizeof(uint32_t), h->stream));
+        h->help_fin_total = bulk ? (uint32_t)count : 0u;
+        h->boards_dirty = !bulk;
         if (!bulk) HIPCHK(hipEventRecord(h->ev_help_pre, h->stream));  // the boards are clean (the bulk kernel's helpers are workgroups of the same launch: nothing to order)
         if (!bulk && T.help_first) {  // diagnostic: the old order, helpers in front of the searches
             hipStream_t hst0 = count > h->n_cu ? h->help_stream_low : h->help_stream;
@@ -1051,7 +1092,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
         T.help_patience = std::max(0, env_i("PDMPC_HELP_PATIENCE", T.help_patience));
         if (getenv("PDMPC_HELP_EXPAND_OVERSUB")) T.help_expand_oversub = env_i("PDMPC_HELP_EXPAND_OVERSUB", 0) != 0;
         if (getenv("PDMPC_FR_SLICE")) T.fr_slice = env_i("PDMPC_FR_SLICE", 0) != 0;
-        T.debug_host = getenv("PDMPC_DEBUG_HOST") != nullptr;
+        T.debug_host = getenv("PDMPC_DEBUG_HOST") ? std::max(1, atoi(getenv("PDMPC_DEBUG_HOST"))) : 0;  // 1: a line per launch; 2: the host-time breakdown of the literal path only
         T.help_first = getenv("PDMPC_HELP_FIRST") != nullptr;
         T.help_prio = env_i("PDMPC_HELP_PRIO", 1) != 0;
         T.slot_order_reverse = env_i("PDMPC_TEST_REVERSE_DISPATCH", 0) != 0;
@@ -1124,6 +1165,7 @@ int pdmpc_destroy(pdmpc_handle* h) {
     h->alink.release();
     h->avs.release();
     h->d_out.release();
+    h->h_out.release();
     h->d_flag.release();
     h->d_tree_size.release();
     h->d_tie_count.release();
@@ -1258,7 +1300,7 @@ int pdmpc_launch_range(pdmpc_handle* h, int32_t first, int32_t count) {
 
 int pdmpc_synchronize(pdmpc_handle* h) {
     if (!h) return fail(PDMPC_ERR_INVALID, "null handle");
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(sync_stream(h));
     return PDMPC_OK;
 }
 
@@ -1269,8 +1311,12 @@ int pdmpc_fetch_results(pdmpc_handle* h, int32_t n, pdmpc_vehicle_out* out) {
     PackedStep& B = h->banks[h->bank];
     const bool permuted = !B.perm.empty();
     if (permuted && n != B.n_packed) return fail(PDMPC_ERR_INVALID, "a batch that pdmpc_pack_step put into level order is fetched as a whole");
-    if (n > 0) HIPCHK(hipMemcpyAsync(out, h->d_out.p, (size_t)n * sizeof(pdmpc_vehicle_out), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->h_out.ensure((size_t)std::max(n, 1))) return fail(PDMPC_ERR_HIP, "hipHostMalloc failed");
+    if (n > 0) HIPCHK(hipMemcpyAsync(h->h_out.p, h->d_out.p, (size_t)n * sizeof(pdmpc_vehicle_out), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(sync_stream(h));
+    if (n > 0) std::memcpy(out, h->h_out.p, (size_t)n * sizeof(pdmpc_vehicle_out));
+    for (int i = 0; i < n; ++i)
+        if (out[i].status == PDMPC_ERR_HIP) h->boards_dirty = true;  // (a search left through its watchdog: launch_range clears the helper boards)
     if (h->last_launch_bulk) {
         // A search of the bulk kernel that meets equal keys where the pop order depends on the layout of the reference's binary heap
         // (priority_queue_interface_mex.cpp:19-31) ends with an internal status: the slots of that launch are planned again by the
@@ -1290,8 +1336,9 @@ int pdmpc_fetch_results(pdmpc_handle* h, int32_t n, pdmpc_vehicle_out* out) {
                 if (!rc) rc = launch_range(h, r.first, r.second);
             h->force_frontier = false;
             if (rc) return rc;
-            HIPCHK(hipMemcpyAsync(out, h->d_out.p, (size_t)n * sizeof(pdmpc_vehicle_out), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipStreamSynchronize(h->stream));
+            HIPCHK(hipMemcpyAsync(h->h_out.p, h->d_out.p, (size_t)n * sizeof(pdmpc_vehicle_out), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(sync_stream(h));
+            std::memcpy(out, h->h_out.p, (size_t)n * sizeof(pdmpc_vehicle_out));
         }
     }
     // counters + SURVEY.md 8(d) algorithmic bytes of one pass over the packed batch
@@ -1303,10 +1350,10 @@ int pdmpc_fetch_results(pdmpc_handle* h, int32_t n, pdmpc_vehicle_out* out) {
     int64_t bytes = h->mpa_alg_bytes;
     for (int i = 0; i < m; ++i) {
         const pdmpc_vehicle_out& o = out[i];
-        const DevVehicle& d = B.h_veh.p[i];
+        const DevVehicle& d = B.h_veh[i];
         int64_t cols = B.lit_cols[i];
         for (int q = 0; q < d.n_pred; ++q) {
-            const int ps = B.h_pred.p[d.pred_off + q];
+            const int ps = B.h_pred[d.pred_off + q];
             if (ps < n)
                 for (int k = 0; k < Hp; ++k) cols += out[ps].shape_cols[k] + 1;
         }
@@ -1334,14 +1381,22 @@ namespace {
 int plan_packed_growing(pdmpc_handle* h, int32_t n, pdmpc_vehicle_out* out) {
     bool safe = h->safe_launches;
     for (;;) {
-        const bool dbg = h->tune.debug_host != 0;
+        const bool dbg = h->tune.debug_host == 1;
         if (dbg) fprintf(stderr, "pdmpc: launching %d vehicles, arena %u nodes%s\n", n, h->max_nodes, safe ? " (resident slices)" : "");
         HIPCHK(hipSetDevice(h->cfg.device));
         h->epoch += 1;  // a new step: results of earlier launches no longer satisfy predecessor waits
+        const auto t0 = std::chrono::steady_clock::now();
         int rc = launch_range(h, 0, h->banks[h->bank].n_packed, safe);
         if (rc) return rc;
+        const auto t1 = std::chrono::steady_clock::now();
         rc = pdmpc_fetch_results(h, n, out);
         if (rc) return rc;
+        if (h->tune.debug_host == 2) {  // (PDMPC_DEBUG_HOST=2: where a call's host time goes, printed by pdmpc_plan_step_literal)
+            h->dbg_us[1] += std::chrono::duration<double, std::micro>(t1 - t0).count();
+            h->dbg_us[2] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
+            float ms = 0.f;
+            if (h->events_used > 0 && hipEventElapsedTime(&ms, h->events[h->events_used - 1].first, h->events[h->events_used - 1].second) == hipSuccess) h->dbg_us[3] += 1e3 * ms;
+        }
         if (dbg) fprintf(stderr, "pdmpc: fetched, status[0] %d\n", n > 0 ? out[0].status : 0);
         bool overflow = false, timed_out = false;
         for (int i = 0; i < n; ++i) {
@@ -1378,8 +1433,11 @@ int plan_packed_growing(pdmpc_handle* h, int32_t n, pdmpc_vehicle_out* out) {
 }  // namespace
 
 int pdmpc_plan_batch(pdmpc_handle* h, int32_t n, const pdmpc_vehicle_in* in, pdmpc_vehicle_out* out) {
+    const bool dbg = h && h->tune.debug_host == 2;
+    const auto t0 = std::chrono::steady_clock::now();
     int rc = pdmpc_pack_batch(h, n, in);
     if (rc) return rc;
+    if (dbg) h->dbg_us[0] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     return plan_packed_growing(h, n, out);
 }
 
@@ -1451,6 +1509,11 @@ int pdmpc_plan_step_literal(pdmpc_handle* h, int32_t n, const pdmpc_vehicle_in* 
                 }
             }
         }
+    }
+    if (h->tune.debug_host == 2) {
+        fprintf(stderr, "pdmpc: literal step of %d calls: pack %.0f us, launch %.0f us, fetch (incl. waiting for the kernel) %.0f us, kernels %.0f us\n", n, h->dbg_us[0], h->dbg_us[1],
+                h->dbg_us[2], h->dbg_us[3]);
+        h->dbg_us[0] = h->dbg_us[1] = h->dbg_us[2] = h->dbg_us[3] = 0;
     }
     return PDMPC_OK;
 }

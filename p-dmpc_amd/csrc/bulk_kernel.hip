@@ -1516,7 +1516,7 @@ __device__ __forceinline__ void bulk_helper_body(const KernelArgs& A) {
             }
             if (!cmd) {
                 const uint32_t fin = __hip_atomic_load(A.help_finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (lane == 0 && fin >= (uint32_t)n_s) hs[HS_CMD] = 2;
+                if (lane == 0 && fin - A.help_fin_base >= (uint32_t)n_s) hs[HS_CMD] = 2;
             } else {
                 // what the owner wrote before it posted (and the predecessors it had seen) is visible from here on; not on an idle
                 // poll: the fence empties this XCD's L2, which searches on neighbouring CUs share

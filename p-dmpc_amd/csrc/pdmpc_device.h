@@ -187,6 +187,7 @@ struct KernelArgs {
     int32_t help_expand;             // 1: helpers also expand the entries they find collision-free
     int32_t help_patience;           // ... polls without a new claim after which the owner closes the round and does the rest itself
     uint32_t* help_finished;         // searches of this launch that have published their result
+    uint32_t help_fin_base;          // bulk kernel: the counter's value when the launch went out (it runs on from launch to launch: no clearing in between)
     // bulk kernel
     int32_t bulk;           // 1: this launch runs the bulk kernel (bulk_kernel.hip)
     int32_t bk_ready_cap;   // entries of the ready list (a round's nodes)

@@ -20,7 +20,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r04_c2"
 workload = tag.split("_")[-1]
 TIMED = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 SRC = os.path.join(ROOT, sys.argv[3]) if len(sys.argv) > 3 else os.path.join(ROOT, "gpurun_out", "prof_" + workload)
-KERNEL, HELPER = "pdmpc_bulk_kernel", "pdmpc_bulk_helper"  # (round 3: pdmpc_frontier, pdmpc_helper)
+KERNEL, HELPER = "pdmpc_bulk_kernel", "pdmpc_helper"  # (the bulk kernel's helpers are workgroups of its own launch; pdmpc_helper serves the frontier kernel, which only runs after a tie)
 DST = os.path.join(ROOT, "profiles")
 os.makedirs(DST, exist_ok=True)
 
