@@ -162,6 +162,8 @@ struct Tuning {
     int bk_round = -1;          // PDMPC_BK_ROUND: the most a round takes (bulk kernel; -1: 1000 with helper workgroups, else 256)
     int bk_tentative = 1;       // PDMPC_BK_TENTATIVE: expected areas of predecessors that are still planning (A/B switch: results are identical)
     int bk_tile = 64;           // PDMPC_BK_TILE: nodes of a tile of a shared round
+    int bk_mid_min = 24576;     // PDMPC_BK_MID_MIN: far lists longer than this feed near through the mid list (a band of far's smallest keys)
+    int bk_mid_fill = 12288;    // PDMPC_BK_MID_FILL: entries a refill of mid aims at
     int bk_share_min = 192;     // PDMPC_BK_SHARE_MIN: a round with at least this many nodes is shared with the helper workgroups
     int bk_ramp = -1;           // PDMPC_BK_RAMP: a round grows by 1 / bk_ramp of the nodes processed so far (-1: 2 with helper workgroups, else 4)
     int fr_slice = -1;          // PDMPC_FR_SLICE (-1: only after a predecessor time-out, 0: never, 1: always when oversubscribed)
@@ -199,6 +201,8 @@ struct pdmpc_handle {
     DevBuf<double> ankey;   // frontier kernel: near list
     DevBuf<unsigned long long> alink;  // frontier kernel: parent | packed << 32 of every node (the walks' and the counting pass's compact view of the tree)
     DevBuf<uint32_t> anid;
+    DevBuf<double> amidk;   // bulk kernel: mid list
+    DevBuf<uint32_t> amidi;
     DevBuf<uint8_t> avs;
     DevBuf<pdmpc_vehicle_out> d_out;
     DevBuf<uint32_t> d_flag;
@@ -771,11 +775,13 @@ int alloc_arenas(pdmpc_handle* h, uint32_t nodes) {
     h->alog.release();
     h->ankey.release();
     h->anid.release();
+    h->amidk.release();
+    h->amidi.release();
     h->alink.release();
     h->max_nodes = 0;
     int bad = 0;
     bad |= h->anodes.ensure_exact(tot) | h->ahk.ensure_exact(tot) | h->ahid.ensure_exact(tot) | h->avs.ensure_exact(tot) | h->alog.ensure_exact(tot);
-    bad |= h->ankey.ensure_exact(tot) | h->anid.ensure_exact(tot) | h->alink.ensure_exact(tot);
+    bad |= h->ankey.ensure_exact(tot) | h->anid.ensure_exact(tot) | h->alink.ensure_exact(tot) | h->amidk.ensure_exact(tot) | h->amidi.ensure_exact(tot);
     if (bad) return bad;
     h->max_nodes = nodes;
     return 0;
@@ -820,6 +826,8 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     a.arena.vstate = h->avs.p;
     a.arena.near_key = h->ankey.p;
     a.arena.near_id = h->anid.p;
+    a.arena.mid_key = h->amidk.p;
+    a.arena.mid_id = h->amidi.p;
     a.arena.link = h->alink.p;
     a.max_nodes = h->max_nodes;
     a.pop_trace = h->d_trace.p;
@@ -919,6 +927,8 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     }
     if (safe) a.n_helpers = 0;  // the recovery path counts on nothing but slot order: no helper workgroup sits where a search could run
     a.bk_share_min = T.bk_share_min;
+    a.bk_mid_min = T.bk_mid_min;
+    a.bk_mid_fill = T.bk_mid_fill;
     a.bk_tile = T.bk_tile;
     a.bk_tentative = T.bk_tentative;
     a.bk_post = h->d_bk_post.p;
@@ -1059,6 +1069,8 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
         if (getenv("PDMPC_BK_ROUND")) T.bk_round = std::max(1, env_i("PDMPC_BK_ROUND", 256));
         if (getenv("PDMPC_BK_RAMP")) T.bk_ramp = std::max(1, env_i("PDMPC_BK_RAMP", 4));
         T.bk_share_min = std::max(64, env_i("PDMPC_BK_SHARE_MIN", T.bk_share_min));
+        T.bk_mid_min = std::max(0, env_i("PDMPC_BK_MID_MIN", T.bk_mid_min));
+        T.bk_mid_fill = std::max(256, env_i("PDMPC_BK_MID_FILL", T.bk_mid_fill));
         T.bk_tentative = env_i("PDMPC_BK_TENTATIVE", T.bk_tentative) != 0;
         T.bk_tile = std::min(128, std::max(16, env_i("PDMPC_BK_TILE", T.bk_tile)));
         h->bk_ready_cap = std::min(2048, std::max(256, env_i("PDMPC_BK_READY", h->bk_ready_cap))) & ~63;  // (the most a launch may use: launches without helpers lay out half of it)
@@ -1162,6 +1174,8 @@ int pdmpc_destroy(pdmpc_handle* h) {
     h->alog.release();
     h->ankey.release();
     h->anid.release();
+    h->amidk.release();
+    h->amidi.release();
     h->alink.release();
     h->avs.release();
     h->d_out.release();
@@ -1418,7 +1432,7 @@ int plan_packed_growing(pdmpc_handle* h, int32_t n, pdmpc_vehicle_out* out) {
         if ((h->max_nodes_limit && next > h->max_nodes_limit) || next > (1ull << 30)) return PDMPC_OK;  // statuses tell
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
-        const size_t per_node = sizeof(NodeRec) + 8 + 4 + 8 + 1 + 8 + 4;
+        const size_t per_node = sizeof(NodeRec) + 8 + 4 + 8 + 1 + 8 + 4 + 8 + 8 + 4;
         const size_t have = (size_t)h->max_vehicles * h->max_nodes * per_node;
         if ((size_t)h->max_vehicles * next * per_node > free_b + have) return PDMPC_OK;  // no room to grow
         const uint32_t before = h->max_nodes;

@@ -95,6 +95,10 @@ struct BkCheck {
 #define BK_ARRIVALS FR_SEL2_CUM  // arrival events handled by this search
 #define BK_DEPTH FR_RD_HEAD       // deepest collision-free node so far (its step k)
 #define BK_IDLE FR_RD_TAIL        // polls a waiting search has made (the watchdog's count)
+// the mid list's words (words 10-15 of the serial block: the pop-ordered kernel's candidate list, unused by this search)
+#define BK_MID_N 10    // entries of mid
+#define BK_MID_MIN 12  // (64 bit) exact minimum key of mid
+#define BK_L_MID 14    // (64 bit) open entries that leave near, and children beyond near's limit, go to mid up to this key and to far above it (-1: no mid list)
 
 // copies the expected areas of the predecessors in `who` into their soup slots
 __device__ __forceinline__ void bk_tentative_areas(const KernelArgs& A, const SpecCtx& P, unsigned long long who, int tid, int nthreads) {
@@ -503,6 +507,10 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         sh_st_d(sh, FR_FAR_MIN, inf);
         sh_st_d(sh, FR_L_FAR, inf);
         sh_st_d(sh, BK_TENT_MIN, inf);
+        sh[BK_MID_N] = 0;
+        sh[BK_MID_N + 1] = 0;
+        sh_st_d(sh, BK_MID_MIN, inf);
+        sh_st_d(sh, BK_L_MID, -1.0);
         sh[SH_NNODES] = 1;
         if (A.debug_tail == 2) sh[FR_EVER_INVAL] = 1;  // (debugging: exercise the ancestor check without arrivals)
         ready[0] = 1u;
@@ -533,11 +541,11 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
     uint32_t t_checks = 0, t_pairs = 0;  // this thread's share of the work counters
     // where the time goes (100 MHz ticks, PDMPC_DEBUG_TAIL=1): accumulated by thread 0 in LDS words, so that the bookkeeping costs
     // the round loop no registers
-    lds_vu64* tk = (lds_vu64*)(gp_path + 200);  // [10]: mark, start, work, arrival, select, wait, p1, p2, p3, phase B
-    enum { TK_MARK, TK_START, tk_work, tk_arrival, tk_select, tk_wait, tk_p1, tk_p2, tk_p3, tk_pb };
+    lds_vu64* tk = (lds_vu64*)(gp_path + 200);  // [11]: mark, start, work, arrival, select (without the refills), wait, p1, p2, p3, phase B, refill
+    enum { TK_MARK, TK_START, tk_work, tk_arrival, tk_select, tk_wait, tk_p1, tk_p2, tk_p3, tk_pb, tk_refill };
     const bool ticking = A.debug_tail != 0 && tid == 0;
     if (ticking) {
-        for (int i = 2; i < 10; ++i) tk[i] = 0ull;
+        for (int i = 2; i < 11; ++i) tk[i] = 0ull;
         tk[TK_MARK] = tk[TK_START] = __builtin_amdgcn_s_memrealtime();
     }
 #define BK_TICK(acc)                                                       \
@@ -546,18 +554,29 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         tk[acc] += now__ - tk[TK_MARK];                                    \
         tk[TK_MARK] = now__;                                               \
     }
-    double far_mn = inf, far_mx = 0.0, near_mn = inf, near_mx = 0.0;
-    // appends (k, i) of the lanes with `take` to far (whole wave calls, straight-line)
+    double far_mn = inf, far_mx = 0.0, near_mn = inf, near_mx = 0.0, mid_mn = inf;
+    double* const mid_key = A.arena.mid_key + voff;
+    uint32_t* const mid_id = A.arena.mid_id + voff;
+    // appends (k, i) of the lanes with `take` to the open entries outside LDS (whole wave calls, straight-line): to mid up to the key
+    // l_mid, to far above it.  A light search has no mid list (l_mid = -1): everything goes to far.
     auto to_far = [&](bool take, double k, uint32_t i) {
         const unsigned long long b = __ballot(take);
         if (b) {
-            const uint32_t base = sh_add_uniform(sh, FR_FAR_N, (uint32_t)__builtin_popcountll(b), lane);
+            const double l_mid = sh_ld_d(sh, BK_L_MID);
+            const bool tm = k <= l_mid;
+            const unsigned long long bm = __ballot(take && tm), bf = b & ~bm;
+            // one LDS atomic reserves room in both lists: lane 0 adds far's count, lane 1 mid's (the other lanes add to scratch words, see sh_add_uniform)
+            lds_u32* p = lane == 0 ? (lds_u32*)(sh + FR_FAR_N) : (lane == 1 ? (lds_u32*)(sh + BK_MID_N) : (lds_u32*)(sh + FR_SCRATCH + lane));
+            const uint32_t old = __hip_atomic_fetch_add(p, lane == 0 ? (uint32_t)__builtin_popcountll(bf) : (lane == 1 ? (uint32_t)__builtin_popcountll(bm) : 0u), __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t base_f = (uint32_t)__builtin_amdgcn_readlane((int)old, 0), base_m = (uint32_t)__builtin_amdgcn_readlane((int)old, 1);
             if (take) {
-                const uint32_t pos = base + lane_rank(b, lane);
-                F.far_key[pos] = k;
-                F.far_id[pos] = i;
-                far_mn = k < far_mn ? k : far_mn;
-                far_mx = k > far_mx ? k : far_mx;
+                const uint32_t pos = tm ? base_m + lane_rank(bm, lane) : base_f + lane_rank(bf, lane);
+                (tm ? mid_key : F.far_key)[pos] = k;
+                (tm ? mid_id : F.far_id)[pos] = i;
+                mid_mn = (tm && k < mid_mn) ? k : mid_mn;
+                far_mn = (!tm && k < far_mn) ? k : far_mn;
+                far_mx = (!tm && k > far_mx) ? k : far_mx;
             }
         }
     };
@@ -565,6 +584,16 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         sh_minmax_wave(sh, FR_FAR_MIN, FR_FAR_MAX, far_mn, far_mx, lane);
         far_mn = inf;
         far_mx = 0.0;
+        if (__ballot(mid_mn < inf)) {  // (uniform over the wave)
+            double m = mid_mn;
+#pragma unroll
+            for (int o = PDMPC_WAVE / 2; o > 0; o >>= 1) {
+                const double a = __shfl_xor(m, o);
+                m = a < m ? a : m;
+            }
+            if (lane == 0) sh_min_d(sh, BK_MID_MIN, m);
+            mid_mn = inf;
+        }
     };
     // appends (k, i) of the lanes with `take` to near (LDS; the caller has made sure there is room)
     auto to_near = [&](bool take, double k, uint32_t i) {
@@ -1031,6 +1060,9 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                     sh_st_d(sh, FR_FAR_MIN, inf);
                     sh_st_d(sh, FR_FAR_MAX, 0.0);
                     sh_st_d(sh, FR_L_FAR, -1.0);  // (everything goes to far until the next refill)
+                    sh[BK_MID_N] = 0;
+                    sh_st_d(sh, BK_MID_MIN, inf);
+                    sh_st_d(sh, BK_L_MID, -1.0);
                 }
             }
             __syncthreads();
@@ -1088,8 +1120,14 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
 
         // are we done?  Open entries above the candidate's path maximum come after it; the others are looked at one by one when a
         // round selects them.  An empty open set without a candidate is exhaustion (GraphSearch.m:57-61).
-        const uint32_t near_n = sh[FR_NEAR_N], far_n = sh[FR_FAR_N];
-        const double near_min = near_n ? sh_ld_d(sh, FR_NEAR_MIN) : inf, far_min = far_n ? sh_ld_d(sh, FR_FAR_MIN) : inf;
+        // (far_n / far_min: the open entries outside LDS, mid and far together)
+        const uint32_t near_n = sh[FR_NEAR_N], mid_n = sh[BK_MID_N], far_n = sh[FR_FAR_N] + mid_n;
+        const double near_min = near_n ? sh_ld_d(sh, FR_NEAR_MIN) : inf;
+        double far_min = far_n != mid_n ? sh_ld_d(sh, FR_FAR_MIN) : inf;
+        {
+            const double mm = mid_n ? sh_ld_d(sh, BK_MID_MIN) : inf;
+            far_min = mm < far_min ? mm : far_min;
+        }
         const double open_min = near_min < far_min ? near_min : far_min;
         const double bb = best ? sh_ld_d(sh, FR_BEST_B1) : inf;
         // parked nodes (their edges cross only areas a pending predecessor is expected to take) count as open
@@ -1183,89 +1221,134 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 __syncthreads();
                 nn_near = 0;
             }
-            const uint32_t fn = sh[FR_FAR_N];
+            // A heavy search's far list holds a hundred thousand entries and more; a pass over all of it for every refill of near (every
+            // other round) cost as much as the checks.  Beyond bk_mid_min entries far feeds near through the mid list: stage 0 moves a
+            // band of far's smallest keys (about bk_mid_fill entries, up to the key l_mid) to mid, stage 1 refills near from mid; until
+            // mid runs short again only mid is scanned, and open entries up to l_mid that leave LDS go to mid (to_far).
             const uint32_t room = OC - OC / 6u;  // (a sixth of near stays free for the children of the rounds to come)
-            const uint32_t fill = room > nn_near + 64u ? room - nn_near : 64u;
-            double lo = sh_ld_d(sh, FR_FAR_MIN), hi = sh_ld_d(sh, FR_FAR_MAX);
-            uint32_t bsel = FR_NBINS - 1;
-            double scale = 0.0;
-            // (a far list of tens of thousands of entries is histogrammed on a sample: every stride-th entry.  The threshold only has to
-            // bring about `fill` entries; what the chosen bins hold beyond near's room goes back, what they hold less comes next time)
-            const uint32_t stride = fn > 16384u ? fn / 8192u : 1u;
-            const uint32_t fill_s = stride > 1u ? (fill / stride > 16u ? fill / stride : 16u) : fill;
-            for (int zoom = 0; zoom < 6; ++zoom) {
-                scale = hi > lo ? (double)FR_NBINS / (hi - lo) : 0.0;
-                for (int i = tid; i < FR_NBINS; i += bd) hist[i] = 0;
-                __syncthreads();
-                if (stride == 1u) {
-                    fr_histogram(F, F.far_key, fn, lo, scale);
-                } else {
-                    for (uint32_t e = (uint32_t)tid * stride; e < fn; e += (uint32_t)bd * stride)
-                        __hip_atomic_fetch_add(&hist[fr_bin(F.far_key[e], lo, scale)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t fill_near = room > nn_near + 64u ? room - nn_near : 64u;
+            int stage = (sh[FR_FAR_N] > (uint32_t)A.bk_mid_min && sh[BK_MID_N] < fill_near) ? 0 : 1;
+#pragma unroll 1
+            for (; stage < 2; ++stage) {
+                const bool to_mid = stage == 0;
+                const bool from_mid = !to_mid && sh[BK_MID_N] != 0u;  // (uniform)
+                if (!to_mid && !from_mid && sh[FR_FAR_N] == 0u) break;  // (nothing to refill from)
+                double* const src_key = from_mid ? mid_key : F.far_key;
+                uint32_t* const src_id = from_mid ? mid_id : F.far_id;
+                const int SRC_N = from_mid ? BK_MID_N : FR_FAR_N;
+                const uint32_t fn = sh[SRC_N];
+                const uint32_t fill = to_mid ? (uint32_t)A.bk_mid_fill : fill_near;
+                const double l_mid_old = sh_ld_d(sh, BK_L_MID);
+                const uint32_t far_left = from_mid ? sh[FR_FAR_N] : 0u;  // (entries beyond the source)
+                double lo = from_mid ? sh_ld_d(sh, BK_MID_MIN) : sh_ld_d(sh, FR_FAR_MIN), hi = from_mid ? l_mid_old : sh_ld_d(sh, FR_FAR_MAX);
+                const double hi_src = hi;
+                uint32_t bsel = FR_NBINS - 1;
+                double scale = 0.0;
+                // (a list of tens of thousands of entries is histogrammed on a sample: every stride-th entry.  The threshold only has to
+                // bring about `fill` entries; what the chosen bins hold beyond near's room goes back, what they hold less comes next time)
+                const uint32_t stride = fn > 16384u ? fn / 8192u : 1u;
+                const uint32_t fill_s = stride > 1u ? (fill / stride > 16u ? fill / stride : 16u) : fill;
+                for (int zoom = 0; zoom < 6; ++zoom) {
+                    scale = hi > lo ? (double)FR_NBINS / (hi - lo) : 0.0;
+                    for (int i = tid; i < FR_NBINS; i += bd) hist[i] = 0;
+                    __syncthreads();
+                    if (stride == 1u) {
+                        fr_histogram(F, src_key, fn, lo, scale);
+                    } else {
+                        for (uint32_t e = (uint32_t)tid * stride; e < fn; e += (uint32_t)bd * stride)
+                            __hip_atomic_fetch_add(&hist[fr_bin(src_key[e], lo, scale)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    __syncthreads();
+                    if (wave == 0) bk_far_select(F, fill_s, lane);
+                    __syncthreads();
+                    bsel = sh[FR_SEL_BIN];
+                    const uint32_t cum = sh[FR_SEL_CUM] * stride;
+                    __syncthreads();
+                    if (bsel != 0u || scale == 0.0 || (to_mid ? cum <= 4u * fill : nn_near + cum <= OC - 64u)) break;
+                    hi = lo + (hi - lo) / (double)FR_NBINS;  // nearly everything sits in the first bin: look closer
                 }
-                __syncthreads();
-                if (wave == 0) bk_far_select(F, fill_s, lane);
-                __syncthreads();
-                bsel = sh[FR_SEL_BIN];
-                const uint32_t cum = sh[FR_SEL_CUM] * stride;
-                __syncthreads();
-                if (bsel != 0u || nn_near + cum <= OC - 64u || scale == 0.0) break;
-                hi = lo + (hi - lo) / (double)FR_NBINS;  // nearly everything sits in the first bin: look closer
-            }
-            const double l_far_new = (bsel >= FR_NBINS - 1 || scale == 0.0) ? inf : lo + (double)(bsel + 1u) / scale;
-            if (tid == 0) {
-                sh_st_d(sh, FR_FAR_MIN, inf);
-                sh_st_d(sh, FR_FAR_MAX, 0.0);
-                if (nn_near == 0u) {  // (else near's key range stays and takes the new entries in)
-                    sh_st_d(sh, FR_NEAR_MIN, inf);
-                    sh_st_d(sh, FR_NEAR_MAX, 0.0);
-                }
-                // children up to this key join near from now on (what near still holds lies below the old limit, what far held above it)
-                const double l_old = sh_ld_d(sh, FR_L_FAR);
-                sh_st_d(sh, FR_L_FAR, (nn_near != 0u && l_old > l_far_new && l_old < inf) ? l_old : l_far_new);
-            }
-            __syncthreads();
-            const double lo_c = lo, scale_c = scale;
-            const uint32_t kept = fr_partition(
-                F.far_key, F.far_id, fn, wsum, n_waves, [&](double k, uint32_t i) -> int { return i == 0u ? -1 : (fr_bin(k, lo_c, scale_c) <= bsel ? 1 : 0); },
-                [&](int c, double k, uint32_t i) {
-                    const unsigned long long b = __ballot(c == 1);
-                    bool back = false;
-                    if (b) {
-                        const uint32_t base = sh_add_uniform(sh, FR_NEAR_N, (uint32_t)__builtin_popcountll(b), lane);
-                        const uint32_t pos = base + lane_rank(b, lane);
-                        const bool fits = c == 1 && pos < OC;
-                        if (fits) {
-                            near_key[pos] = k;
-                            near_id[pos] = i;
-                            near_mn = k < near_mn ? k : near_mn;
-                            near_mx = k > near_mx ? k : near_mx;
+                const bool all = bsel >= FR_NBINS - 1 || scale == 0.0;  // every entry of the source is taken
+                const double l_new = all ? inf : lo + (double)(bsel + 1u) / scale;
+                if (tid == 0) {
+                    if (from_mid) {
+                        sh_st_d(sh, BK_MID_MIN, inf);
+                    } else {
+                        sh_st_d(sh, FR_FAR_MIN, inf);
+                        sh_st_d(sh, FR_FAR_MAX, 0.0);
+                    }
+                    if (to_mid) {
+                        sh_st_d(sh, BK_L_MID, all ? hi_src : l_new);  // (from now on what leaves LDS with a key up to here joins mid)
+                    } else {
+                        if (!from_mid) sh_st_d(sh, BK_L_MID, -1.0);  // (near is fed by far directly: no mid list)
+                        if (nn_near == 0u) {  // (else near's key range stays and takes the new entries in)
+                            sh_st_d(sh, FR_NEAR_MIN, inf);
+                            sh_st_d(sh, FR_NEAR_MAX, 0.0);
                         }
-                        back = c == 1 && !fits;
+                        // children up to this key join near from now on (what near still holds lies below the old limit, what the source
+                        // held above it); with all of mid taken and far not empty, near's limit is mid's: far's keys lie above it
+                        const double l_far_new = (all && far_left != 0u) ? l_mid_old : l_new;
+                        const double l_old = sh_ld_d(sh, FR_L_FAR);
+                        sh_st_d(sh, FR_L_FAR, (nn_near != 0u && l_old > l_far_new && l_old < inf) ? l_old : l_far_new);
                     }
-                    // (an entry that does not fit cannot go back into the list that is being compacted: it is appended behind the
-                    // old end of far and moved down afterwards — only if more than near's capacity of keys share the first bins)
-                    to_far(back, k, i);
-                    if (c < 0 && i != 0u) {  // kept entries (i is their node, never 0)
-                        far_mn = k < far_mn ? k : far_mn;
-                        far_mx = k > far_mx ? k : far_mx;
-                    }
-                });
-            flush_far();
-            flush_near();
-            const uint32_t extra = sh[FR_FAR_N] - fn;  // entries that did not fit into near, appended at fn ..
-            for (uint32_t e = (uint32_t)tid; e < extra; e += (uint32_t)bd) {  // (kept + extra <= fn: the ranges do not overlap)
-                F.far_key[kept + e] = F.far_key[fn + e];
-                F.far_id[kept + e] = F.far_id[fn + e];
+                }
+                __syncthreads();
+                const double lo_c = lo, scale_c = scale;
+                const uint32_t kept = fr_partition(
+                    src_key, src_id, fn, wsum, n_waves, [&](double k, uint32_t i) -> int { return i == 0u ? -1 : (fr_bin(k, lo_c, scale_c) <= bsel ? 1 : 0); },
+                    [&](int c, double k, uint32_t i) {
+                        const unsigned long long b = __ballot(c == 1);
+                        bool back = false;
+                        if (b && to_mid) {  // (uniform) far's band joins mid
+                            const uint32_t base = sh_add_uniform(sh, BK_MID_N, (uint32_t)__builtin_popcountll(b), lane);
+                            if (c == 1) {
+                                const uint32_t pos = base + lane_rank(b, lane);
+                                mid_key[pos] = k;
+                                mid_id[pos] = i;
+                                mid_mn = k < mid_mn ? k : mid_mn;
+                            }
+                        } else if (b) {
+                            const uint32_t base = sh_add_uniform(sh, FR_NEAR_N, (uint32_t)__builtin_popcountll(b), lane);
+                            const uint32_t pos = base + lane_rank(b, lane);
+                            const bool fits = c == 1 && pos < OC;
+                            if (fits) {
+                                near_key[pos] = k;
+                                near_id[pos] = i;
+                                near_mn = k < near_mn ? k : near_mn;
+                                near_mx = k > near_mx ? k : near_mx;
+                            }
+                            back = c == 1 && !fits;
+                        }
+                        // (an entry that does not fit cannot go back into the list that is being compacted: it is appended behind the
+                        // old end of its list and moved down afterwards — only if more than near's capacity of keys share the first bins)
+                        if (!to_mid) to_far(back, k, i);
+                        if (c < 0 && i != 0u) {  // kept entries (i is their node, never 0)
+                            if (from_mid) {
+                                mid_mn = k < mid_mn ? k : mid_mn;
+                            } else {
+                                far_mn = k < far_mn ? k : far_mn;
+                                far_mx = k > far_mx ? k : far_mx;
+                            }
+                        }
+                    });
+                flush_far();
+                flush_near();
+                // entries that did not fit into near were appended behind the source's old end (their keys lie in the chosen bins: below
+                // l_mid for a source mid, and without a mid list everything goes to far)
+                const uint32_t extra = sh[SRC_N] - fn;
+                for (uint32_t e = (uint32_t)tid; e < extra; e += (uint32_t)bd) {  // (kept + extra <= fn: the ranges do not overlap)
+                    src_key[kept + e] = src_key[fn + e];
+                    src_id[kept + e] = src_id[fn + e];
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) {
+                    sh[SRC_N] = kept + extra;
+                    if (sh[FR_NEAR_N] > OC) sh[FR_NEAR_N] = OC;
+                }
+                __syncthreads();
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) {
-                sh[FR_FAR_N] = kept + extra;
-                if (sh[FR_NEAR_N] > OC) sh[FR_NEAR_N] = OC;
-            }
-            __syncthreads();
             nn_near = sh[FR_NEAR_N];
+            BK_TICK(tk_refill)
         }
 
         BK_OPAQUE_TID
@@ -1405,7 +1488,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         dbg[1] = (double)sh[FR_PROCESSED];
         dbg[2] = (double)nnodes_raw;
         dbg[3] = (double)sh[FR_NEAR_N];
-        dbg[4] = (double)sh[FR_FAR_N];
+        dbg[4] = (double)(sh[FR_FAR_N] + sh[BK_MID_N]);
         dbg[5] = (double)sh[FR_FLAGS];
         dbg[6] = 0.0;
         dbg[7] = (double)(__builtin_amdgcn_s_memrealtime() - tk[TK_START]);
@@ -1414,6 +1497,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         X.O->path_nodes[PDMPC_HP_MAX - 2][2] = (double)tk[tk_p2];
         X.O->path_nodes[PDMPC_HP_MAX - 2][3] = (double)tk[tk_p3];
         X.O->path_nodes[PDMPC_HP_MAX - 2][4] = (double)tk[tk_pb];
+        X.O->path_nodes[PDMPC_HP_MAX - 2][5] = (double)tk[tk_refill];
         X.O->path_nodes[PDMPC_HP_MAX - 1][0] = (double)(tk[tk_work] + tk[tk_p1] + tk[tk_p2] + tk[tk_p3]);
         X.O->path_nodes[PDMPC_HP_MAX - 1][1] = (double)tk[tk_arrival];
         X.O->path_nodes[PDMPC_HP_MAX - 1][2] = (double)tk[tk_select];

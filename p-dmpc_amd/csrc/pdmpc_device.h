@@ -105,6 +105,8 @@ struct NodeArena {  // HBM arrays, per-vehicle stride = max_nodes entries
                       // frontier kernel: keys of the `far` open entries (their nodes in heap_id), phase B: a node's branch maximum
     double* near_key;  // frontier kernel: keys and nodes of the `near` open entries
     uint32_t* near_id;
+    double* mid_key;   // bulk kernel: keys and nodes of the `mid` open entries (what a heavy search refills near from; far feeds it)
+    uint32_t* mid_id;
     unsigned long long* link;  // frontier kernel: parent | packed << 32 per node, eight nodes to a 64-byte line (a record's own copy shares its line with nothing the walks need)
 };
 
@@ -195,6 +197,8 @@ struct KernelArgs {
     int32_t bk_round;       // ... and the most any round takes
     int32_t bk_tentative;   // 1: predecessors that are still planning have their expected areas (the ones they publish when exhausted) in their soup slots
     int32_t bk_tile;        // entries of a tile of a shared round (what a helper workgroup claims at a time; at most 128)
+    int32_t bk_mid_min;     // a far list longer than this is not scanned by every refill of near: a band of its smallest keys is moved to mid first
+    int32_t bk_mid_fill;    // ... about this many entries at a time
     int32_t bk_share_min;   // a round with at least this many entries is shared with the helper workgroups
     double* bk_post;        // [slot][bk_ready_cap][3] double2: what a check item reads of the tree, posted per entry of a shared round
     int32_t speculate;  // 1: start searching before all predecessors have finished (results are identical, see arrival_sync)

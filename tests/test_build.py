@@ -18,12 +18,13 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ])
 def test_round_based_kernels_use_no_scratch_memory_and_spill_no_vgprs(source, kernels):
     """the product's search kernels (bulk: InterX; frontier: SAT and the tie fallback) and their helper kernels
-    fit their register budget (168 VGPRs at twelve wavefronts per workgroup) without a byte of scratch memory.  They sit close to the
-    inliner's cliff (one more call site of a large device function and helpers stop being inlined, their context then lives on the
-    stack), so the build is checked."""
+    fit their register budget (168 VGPRs at twelve wavefronts per workgroup) without a byte of scratch memory.  The AMDGPU inliner gives up on functions of more than
+    1100 basic blocks (the Makefile raises that limit); a search function left out of line takes the search context through the stack,
+    so the build is checked."""
     if not os.path.exists(HIPCC) and shutil.which("hipcc") is None:
         pytest.skip("no hipcc")
     cmd = [HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+           "-mllvm", "-amdgpu-inline-max-bb=10000",  # (as csrc/Makefile)
            "-I" + os.path.join(ROOT, "include"), "-c", "-Rpass-analysis=kernel-resource-usage", "-o", os.devnull, os.path.join(CSRC, source)]
     out = subprocess.run(cmd, capture_output=True, text=True, check=True).stderr
     seen = {}

@@ -328,6 +328,8 @@ def test_random_road_problems_never_fall_back():
         {"PDMPC_BK_ROUND0": "1000", "PDMPC_BK_ROUND": "1000", "PDMPC_BK_RAMP": "1", "PDMPC_BK_SHARE_MIN": "64", "PDMPC_BK_TILE": "32"},  # rounds of up to two thousand nodes, most of them shared
         {"PDMPC_BK_TENTATIVE": "0"},
         {"PDMPC_BK_READY": "256", "PDMPC_BK_ROUND0": "300", "PDMPC_HELPERS": "0"},  # a ready list smaller than what a round wants: the rest waits in far
+        {"PDMPC_BK_MID_MIN": "0", "PDMPC_BK_MID_FILL": "256"},  # every far list feeds near through the mid list, a few hundred entries at a time
+        {"PDMPC_BK_MID_MIN": "100", "PDMPC_BK_MID_FILL": "1000", "PDMPC_BK_ROUND0": "300", "PDMPC_BK_TENTATIVE": "0"},
     ],
 )
 def test_tuning_switches_do_not_change_results(env, monkeypatch):

@@ -615,7 +615,8 @@ def test_rccl_paths_with_one_rank_match_the_single_launch():
 def test_bulk_kernel_shares_large_rounds_and_parks_tentative_nodes(monkeypatch):
     """The product kernel on the benchmarked C2 window (closed-loop steps 1-30, incl. the 10 k-pop searches), with the thresholds low
     enough that most rounds are shared with helper workgroups: the statistics say that helpers took part, the records stay the
-    oracle's (run_closed_loop compares every step); and the same loop without tentative areas and without helpers gives them too."""
+    oracle's (run_closed_loop compares every step); the same loop without tentative areas and without helpers gives them too, and so
+    does one whose far lists feed near through the mid list."""
     from pdmpc.road_network import boundary_provider, commonroad_scenario
 
     def loop():
@@ -632,3 +633,10 @@ def test_bulk_kernel_shares_large_rounds_and_parks_tentative_nodes(monkeypatch):
     monkeypatch.setenv("PDMPC_HELPERS", "0")
     stats = loop()
     assert stats["kernel"] == 2 and stats["shared_rounds"] == 0
+    # ... and with the mid list in the way of every far list of more than 512 entries (the default keeps it for lists of 24 k and more)
+    monkeypatch.delenv("PDMPC_HELPERS")
+    monkeypatch.delenv("PDMPC_BK_TENTATIVE")
+    monkeypatch.setenv("PDMPC_BK_MID_MIN", "512")
+    monkeypatch.setenv("PDMPC_BK_MID_FILL", "2048")
+    stats = loop()
+    assert stats["kernel"] == 2

@@ -25,11 +25,11 @@ for b, prob in enumerate(probs):
     for v in range(len(recs)):
         t = np.asarray(recs[v]["path_nodes"])
         rows.append((t[16][7] / 100.0, v, prob["levels"][v], int(recs[v]["n_popped"]), int(t[16][1]), int(t[16][2]), int(t[16][0]), t[15][0] / 100.0, t[15][1] / 100.0, t[15][2] / 100.0, t[15][3] / 100.0, len(prob["preds"][v]),
-                     t[14][0] / 100.0, t[14][1] / 100.0, t[14][2] / 100.0, t[14][3] / 100.0, t[14][4] / 100.0))
+                     t[14][0] / 100.0, t[14][1] / 100.0, t[14][2] / 100.0, t[14][3] / 100.0, t[14][4] / 100.0, t[14][5] / 100.0))
     if os.environ.get("PROFILE_ROUNDS"):  # the sizes of the first forty rounds of the step's largest search (bulk kernel; only while Hp <= 8)
         v = max(range(len(recs)), key=lambda i: np.asarray(recs[i]["path_nodes"])[16][1])
         t = np.asarray(recs[v]["path_nodes"])
         print("   round sizes of veh %d:" % v, [int(x) for x in t[9:14].reshape(-1) if x > 0])
     top = int(os.environ.get("PROFILE_TOP", "8"))
     for r in sorted(rows, reverse=True)[:top]:
-        print("   total %.0f us veh %d level %d popped %d processed %d nodes %d rounds %d | work %.0f arrival %.0f select %.0f wait %.0f us | preds %d | prologue %.0f check %.0f verdict %.0f expand %.0f phaseB %.0f us" % r)
+        print("   total %.0f us veh %d level %d popped %d processed %d nodes %d rounds %d | work %.0f arrival %.0f select %.0f wait %.0f us | preds %d | prologue %.0f check %.0f verdict %.0f expand %.0f phaseB %.0f refill %.0f us" % r)

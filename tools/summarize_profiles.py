@@ -128,6 +128,7 @@ if sq:
 
     derived = {}
     if v("SQ_WAVE_CYCLES") and v("SQ_ACTIVE_INST_VALU") is not None:
+        derived["valu_busy_share_of_sq_busy_cycles"] = v("SQ_ACTIVE_INST_VALU") / v("SQ_BUSY_CYCLES") if v("SQ_BUSY_CYCLES") else None
         derived["valu_active_share_of_wave_cycles"] = v("SQ_ACTIVE_INST_VALU") / v("SQ_WAVE_CYCLES")
     if v("SQ_WAVE_CYCLES") and v("SQ_WAIT_ANY") is not None:
         derived["wait_any_share_of_wave_cycles"] = v("SQ_WAIT_ANY") / v("SQ_WAVE_CYCLES")
@@ -138,12 +139,12 @@ if sq:
     if v("SQ_INSTS_VALU") and v("SQ_INSTS_FLAT") is not None:
         derived["flat_instructions_per_valu_instruction"] = v("SQ_INSTS_FLAT") / v("SQ_INSTS_VALU")
     summary["sq_derived_search_kernel"] = derived
-res = os.path.join(DST, "r03_resource_usage.txt")
+res = os.path.join(DST, "%s_resource_usage.txt" % tag.split("_")[0])
 if os.path.exists(res):
     txt = open(res).read()
-    m = re.search(r"Function Name: pdmpc_frontier_kernel\b.*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?SGPRs Spill: (\d+).*?VGPRs Spill: (\d+)", txt, re.S)
+    m = re.search(r"Function Name: %s\b.*?VGPRs: (\d+)" % KERNEL + r".*?ScratchSize \[bytes/lane\]: (\d+).*?SGPRs Spill: (\d+).*?VGPRs Spill: (\d+)", txt, re.S)
     if m:
-        summary["resources"] = {"source": "profiles/r03_resource_usage.txt (hipcc -Rpass-analysis=kernel-resource-usage)", "vgprs": int(m.group(1)), "scratch_bytes_per_lane": int(m.group(2)),
+        summary["resources"] = {"source": "profiles/%s_resource_usage.txt (hipcc" % tag.split("_")[0] + "  -Rpass-analysis=kernel-resource-usage)", "vgprs": int(m.group(1)), "scratch_bytes_per_lane": int(m.group(2)),
                                 "sgpr_spills": int(m.group(3)), "vgpr_spills": int(m.group(4)),
                                 "dynamic_lds_bytes_per_workgroup": plain["roofline"]["lds_bytes_per_workgroup"] if plain else None}
 for name in ("plain", "stats"):
