@@ -559,10 +559,24 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
     uint32_t* const mid_id = A.arena.mid_id + voff;
     // appends (k, i) of the lanes with `take` to the open entries outside LDS (whole wave calls, straight-line): to mid up to the key
     // l_mid, to far above it.  A light search has no mid list (l_mid = -1): everything goes to far.
+    double l_mid = -1.0;  // the value of the shared word BK_L_MID (uniform; read again wherever it changes: the refill, a reopened open set)
+    auto load_l_mid = [&]() {
+        const unsigned long long v = (unsigned long long)__double_as_longlong(sh_ld_d(sh, BK_L_MID));
+        const uint32_t lo32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+        l_mid = __longlong_as_double((long long)(((unsigned long long)hi32 << 32) | lo32));
+    };
     auto to_far = [&](bool take, double k, uint32_t i) {
         const unsigned long long b = __ballot(take);
-        if (b) {
-            const double l_mid = sh_ld_d(sh, BK_L_MID);
+        if (b && l_mid < 0.0) {  // (uniform) no mid list: the light searches' path
+            const uint32_t base = sh_add_uniform(sh, FR_FAR_N, (uint32_t)__builtin_popcountll(b), lane);
+            if (take) {
+                const uint32_t pos = base + lane_rank(b, lane);
+                F.far_key[pos] = k;
+                F.far_id[pos] = i;
+                far_mn = k < far_mn ? k : far_mn;
+                far_mx = k > far_mx ? k : far_mx;
+            }
+        } else if (b) {
             const bool tm = k <= l_mid;
             const unsigned long long bm = __ballot(take && tm), bf = b & ~bm;
             // one LDS atomic reserves room in both lists: lane 0 adds far's count, lane 1 mid's (the other lanes add to scratch words, see sh_add_uniform)
@@ -1066,6 +1080,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 }
             }
             __syncthreads();
+            if (reopen) l_mid = -1.0;  // (uniform)
             if (flags & FRF_INVALIDATED) {
                 for (uint32_t base = 0; base < nn; base += (uint32_t)bd) {  // (uniform trip count: barriers inside)
                     const uint32_t b = base + (uint32_t)wave * PDMPC_WAVE;
@@ -1292,6 +1307,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                     }
                 }
                 __syncthreads();
+                load_l_mid();
                 const double lo_c = lo, scale_c = scale;
                 const uint32_t kept = fr_partition(
                     src_key, src_id, fn, wsum, n_waves, [&](double k, uint32_t i) -> int { return i == 0u ? -1 : (fr_bin(k, lo_c, scale_c) <= bsel ? 1 : 0); },
