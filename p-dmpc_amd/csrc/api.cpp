@@ -201,6 +201,7 @@ struct pdmpc_handle {
     DevBuf<double> ankey;   // frontier kernel: near list
     DevBuf<unsigned long long> alink;  // frontier kernel: parent | packed << 32 of every node (the walks' and the counting pass's compact view of the tree)
     DevBuf<uint32_t> anid;
+    DevBuf<double> awalk;   // bulk kernel: two doubles per node (NodeArena::walk)
     DevBuf<double> amidk;   // bulk kernel: mid list
     DevBuf<uint32_t> amidi;
     DevBuf<uint8_t> avs;
@@ -777,11 +778,12 @@ int alloc_arenas(pdmpc_handle* h, uint32_t nodes) {
     h->anid.release();
     h->amidk.release();
     h->amidi.release();
+    h->awalk.release();
     h->alink.release();
     h->max_nodes = 0;
     int bad = 0;
     bad |= h->anodes.ensure_exact(tot) | h->ahk.ensure_exact(tot) | h->ahid.ensure_exact(tot) | h->avs.ensure_exact(tot) | h->alog.ensure_exact(tot);
-    bad |= h->ankey.ensure_exact(tot) | h->anid.ensure_exact(tot) | h->alink.ensure_exact(tot) | h->amidk.ensure_exact(tot) | h->amidi.ensure_exact(tot);
+    bad |= h->ankey.ensure_exact(tot) | h->anid.ensure_exact(tot) | h->alink.ensure_exact(tot) | h->amidk.ensure_exact(tot) | h->amidi.ensure_exact(tot) | h->awalk.ensure_exact(2 * tot);
     if (bad) return bad;
     h->max_nodes = nodes;
     return 0;
@@ -826,6 +828,7 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     a.arena.vstate = h->avs.p;
     a.arena.near_key = h->ankey.p;
     a.arena.near_id = h->anid.p;
+    a.arena.walk = h->awalk.p;
     a.arena.mid_key = h->amidk.p;
     a.arena.mid_id = h->amidi.p;
     a.arena.link = h->alink.p;
@@ -1176,6 +1179,7 @@ int pdmpc_destroy(pdmpc_handle* h) {
     h->anid.release();
     h->amidk.release();
     h->amidi.release();
+    h->awalk.release();
     h->alink.release();
     h->avs.release();
     h->d_out.release();
@@ -1432,7 +1436,7 @@ int plan_packed_growing(pdmpc_handle* h, int32_t n, pdmpc_vehicle_out* out) {
         if ((h->max_nodes_limit && next > h->max_nodes_limit) || next > (1ull << 30)) return PDMPC_OK;  // statuses tell
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
-        const size_t per_node = sizeof(NodeRec) + 8 + 4 + 8 + 1 + 8 + 4 + 8 + 8 + 4;
+        const size_t per_node = sizeof(NodeRec) + 8 + 4 + 8 + 1 + 8 + 4 + 8 + 8 + 4 + 16;
         const size_t have = (size_t)h->max_vehicles * h->max_nodes * per_node;
         if ((size_t)h->max_vehicles * next * per_node > free_b + have) return PDMPC_OK;  // no room to grow
         const uint32_t before = h->max_nodes;

@@ -408,6 +408,73 @@ __device__ __forceinline__ void bk_publish(const KernelArgs& A, const Ctx& X, in
     }
 }
 
+// fr_check_wave with a memory: what to do with an open node a round has selected (1 process it, 3 it comes after the goal candidate,
+// 4 one of its ancestors lost its edge to late areas), one node per lane, a = 0: none.
+// The answer follows from the branch between the node and the candidate's path — where it joins the path (depth dJ), the largest key on
+// it (M), whether a node on it is invalid — and a child's branch is its parent's plus itself.  Every processed node leaves these three
+// in walk[] (16 bytes per node), stamped with the candidate and the number of arrival events they hold for; a node whose parent carries
+// a current stamp is classified with two reads instead of a walk to the path (up to Hp dependent reads of three arrays each, which for a
+// heavy search with a candidate cost as much as a third of its checks: C4).  Nodes whose parents were processed under another
+// candidate, or before the last arrival, walk as before and leave their own stamp.
+#define WC_DEAD 0x100u
+#define WC_ONPATH 0x200u
+#define WC_VALID 0x400u
+__device__ int bk_classify_wave(const unsigned long long* glink, ulonglong2* walk, const VState& VS, const double* gkey, const lds_u32* gp_path, const lds_f64* gp_mp, bool have_goal,
+                                bool check_alive, uint32_t best, uint32_t epoch, uint32_t a, double ka, volatile lds_u32* sh) {
+    const uint32_t a0 = a ? a : 1u;
+    const uint64_t ua = glink[a0 - 1u];
+    const uint32_t p = (uint32_t)(ua & 0xffffffffull);
+    const int k = NODE_K((uint32_t)(ua >> 32));
+    const bool onp = have_goal && gp_path[k] == a0;
+    const ulonglong2 c = walk[p ? p - 1u : 0u];
+    const uint32_t ctag = (uint32_t)(c.y & 0xffffffffull), cinfo = (uint32_t)(c.y >> 32);
+    const bool hit = p != 0u && ctag == best && (cinfo & (WC_VALID | 0xffff0000u)) == (WC_VALID | (epoch << 16));
+    double M = -1.0;
+    int dJ = k;
+    bool dead = false;
+    // ---- no current stamp at the parent: the walk (the whole wave together, see fr_check_wave)
+    int st = (a == 0u || onp || hit) ? 1 : 0;  // 0: still walking
+    uint32_t x = a0;
+    while (__ballot(st == 0)) {
+        const uint32_t i = x - 1u;
+        const uint64_t u = glink[i];
+        const int d = NODE_K((uint32_t)(u >> 32));
+        const bool on_path = have_goal && gp_path[d] == x;
+        const bool bad = !on_path && x != a0 && check_alive && vs_load(VS, i) != VS_VALID;
+        const double kx = gkey[i];
+        const uint32_t par = (uint32_t)(u & 0xffffffffull);
+        const bool walking = st == 0;
+        const bool stop = on_path || bad || par == 0u;
+        dJ = (walking && on_path) ? d : dJ;
+        dead = dead || (walking && bad);
+        M = (walking && !on_path && !bad && kx > M) ? kx : M;  // (the nodes below the path: a itself, then its ancestors)
+        st = (walking && stop) ? 1 : st;
+        x = (walking && !stop) ? par : x;
+    }
+    if (hit && !onp) {
+        const bool p_on = (cinfo & WC_ONPATH) != 0u;
+        const double pM = __longlong_as_double((long long)c.x);
+        const uint32_t vsp = check_alive && !p_on ? vs_load(VS, p - 1u) : (uint32_t)VS_VALID;
+        dead = !p_on && ((cinfo & WC_DEAD) != 0u || vsp != VS_VALID);
+        M = (!p_on && pM > ka) ? pM : ka;
+        dJ = (int)(cinfo & 0xffu);
+    }
+    // (a node on the path: its children join the path at it)
+    const double thr = gp_mp[dJ];
+    int res = 1;
+    if (a != 0u && !onp) {
+        res = dead ? 4 : ((have_goal && !(M < thr)) ? 3 : 1);
+        if (!dead && have_goal && M == thr) atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_TIE);
+    }
+    if (a != 0u && res == 1) {  // (it will be processed: its children look here)
+        ulonglong2 w;
+        w.x = (unsigned long long)__double_as_longlong(onp ? -1.0 : M);
+        w.y = (unsigned long long)best | ((unsigned long long)((uint32_t)(onp ? k : dJ) | (onp ? WC_ONPATH : 0u) | WC_VALID | (epoch << 16)) << 32);
+        walk[a0 - 1u] = w;
+    }
+    return res;
+}
+
 // The far-list selection stays an out-of-line call: it runs once per refill on one wavefront, and inlined into the search loop its
 // registers push the whole kernel over the 168-VGPR budget of a twelve-wavefront workgroup (tests/test_build.py watches this).
 __device__ __noinline__ void bk_far_select(const Frontier& F, uint32_t fill, int lane) {
@@ -500,6 +567,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         node_store(S, 0, r);
         F.gkey[0] = 0.0;
         F.glink[0] = (unsigned long long)r.parent | ((unsigned long long)r.packed << 32);
+        ((ulonglong2*)A.arena.walk + voff)[0].y = 0ull;
         vs_store(VS, 0, VS_UNKNOWN);
         for (int w = 26; w < SH_WORDS; ++w) sh[w] = 0;
         sh[FR_NNODES] = 1;
@@ -918,6 +986,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                         vs_store(VS, ci, 0);  // validity unknown
                         F.gkey[ci] = f;
                         F.glink[ci] = (unsigned long long)ch.parent | ((unsigned long long)ch.packed << 32);
+                        ((ulonglong2*)A.arena.walk + voff)[ci].y = 0ull;  // (no stamp: the arena holds other searches' leftovers, see bk_classify_wave)
                     }
                     to_near(active && !(f > l_far), f, ci + 1u);
                     to_far(active && f > l_far, f, ci + 1u);
@@ -1401,6 +1470,8 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             }
             const bool have_goal = best != 0u;
             const bool check_alive = sh[FR_EVER_INVAL] != 0u;  // some node lost its edge to late areas: its descendants are dead
+            const uint32_t epoch_now = sh[BK_ARRIVALS] & 0xffffu;
+            ulonglong2* const wcache = (ulonglong2*)A.arena.walk + voff;
             int cls[BK_PER];
             unsigned long long mine = 0;
             uint32_t n_dead = 0, n_drop = 0;
@@ -1414,7 +1485,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 const bool walk = sel && !above && (have_goal || check_alive);
                 if (sel && have_goal && k == bb) atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_TIE);
                 int r = 1;
-                if (have_goal || check_alive) r = fr_check_wave(F.glink, VS, F.gkey, gp_path, gp_mp, have_goal, check_alive, walk ? i : 0u, sh);  // (uniform condition)
+                if (have_goal || check_alive) r = bk_classify_wave(F.glink, wcache, VS, F.gkey, gp_path, gp_mp, have_goal, check_alive, best, epoch_now, walk ? i : 0u, k, sh);  // (uniform condition)
                 cls[j] = i == 0u ? -1 : (sel ? (above ? 3 : r) : 0);
                 mine += (cls[j] == 0 ? 1ull : 0ull) | (cls[j] == 1 ? (1ull << 32) : 0ull);
                 n_dead += cls[j] == 4 ? 1u : 0u;

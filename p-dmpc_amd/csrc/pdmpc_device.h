@@ -105,6 +105,7 @@ struct NodeArena {  // HBM arrays, per-vehicle stride = max_nodes entries
                       // frontier kernel: keys of the `far` open entries (their nodes in heap_id), phase B: a node's branch maximum
     double* near_key;  // frontier kernel: keys and nodes of the `near` open entries
     uint32_t* near_id;
+    double* walk;      // bulk kernel: per node, 16 bytes: what its branch to the goal candidate's path looks like (bk_classify_wave)
     double* mid_key;   // bulk kernel: keys and nodes of the `mid` open entries (what a heavy search refills near from; far feeds it)
     uint32_t* mid_id;
     unsigned long long* link;  // frontier kernel: parent | packed << 32 per node, eight nodes to a 64-byte line (a record's own copy shares its line with nothing the walks need)
