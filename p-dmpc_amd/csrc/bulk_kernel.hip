@@ -745,7 +745,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             const BkTreeSrc tsrc{&S, ready};
             const unsigned long long pend_now = A.bk_tentative ? sh_load64(sh, SH_PEND_LO) : 0ull;  // (their slots hold expected areas)
             const uint32_t n_tiles = (Rn + TILE - 1u) / TILE;
-            const bool share = A.n_helpers > 0 && Rn >= (uint32_t)A.bk_share_min && P.n_pred <= 64;
+            const bool share = A.n_helpers > 0 && Rn >= (uint32_t)A.bk_share_min && P.n_pred <= 64 && n_tiles <= 64u;  // (one bit per tile in the owner's mask)
             uint32_t own_tiles = n_tiles;
             if (share) {  // (uniform)
                 own_tiles = n_tiles / (uint32_t)A.fr_own_div > 0u ? n_tiles / (uint32_t)A.fr_own_div : 1u;
@@ -771,30 +771,43 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                     __hip_atomic_store(board + PDMPC_HB_TICKET, ((unsigned long long)help_seq << 32) | ((unsigned long long)n_tiles << 16) | own_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            uint32_t closed = n_tiles;  // tiles own_tiles .. closed - 1 are with the helpers
+            // The owner and the helpers take tiles off the same counter.  The owner does its first tiles (what the ticket starts at), then
+            // looks how far the helpers have come meanwhile and takes its share of the rest — everything if no helper has shown up, one
+            // tile if they are many — and so on until the counter is through; then it waits for the tiles the helpers hold.  (Taking
+            // everything that was unclaimed after the first tiles, as a first version did, left the owner with five tiles of a sixteen-tile
+            // round while its helpers had long finished theirs: C4, 40 us of a round's 47 in the owner's own part.)
+            unsigned long long omask = 0ull;  // tiles behind the first ones that the owner took (uniform)
+            uint32_t extra_entries = 0;        // ... and their entries
 #pragma unroll 1
-            for (int pass = 0; pass < (share ? 2 : 1); ++pass) {  // (one call site: the check items are instantiated once)
+            for (int pass = 0;; ++pass) {  // (one call site: the check items are instantiated once)
                 uint32_t rb = 0, Rr = own_tiles * TILE < Rn ? own_tiles * TILE : Rn;
-                if (pass == 1) {
+                if (pass > 0) {
+                    if (!share) break;
                     __syncthreads();
-                    if (tid == 0) {  // close the shared part: what no helper has claimed is the owner's
+                    if (tid == 0) {
                         unsigned long long cur = __hip_atomic_load(board + PDMPC_HB_TICKET, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        uint32_t cl = n_tiles;
+                        uint32_t got = n_tiles, take = 0;
                         for (;;) {
                             const uint32_t idx = (uint32_t)(cur & 0xffffull);
                             if (idx >= n_tiles) break;
-                            if (__hip_atomic_compare_exchange_strong(board + PDMPC_HB_TICKET, &cur, ((unsigned long long)help_seq << 32) | ((unsigned long long)n_tiles << 16) | n_tiles,
-                                                                     __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                                cl = idx;
+                            const uint32_t theirs = idx - own_tiles - (uint32_t)__builtin_popcountll(omask), rem = n_tiles - idx;
+                            take = (rem + theirs) / (theirs + 1u);  // ceil(rem / (theirs + 1))
+                            take = take < 1u ? 1u : take;
+                            if (__hip_atomic_compare_exchange_strong(board + PDMPC_HB_TICKET, &cur, cur + (unsigned long long)take, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                                got = idx;
                                 break;
                             }
                         }
-                        sh[FR_HELP_CLOSED] = cl;
+                        sh[FR_HELP_CLOSED] = got | (take << 16);
                     }
                     __syncthreads();
-                    closed = sh[FR_HELP_CLOSED];
-                    rb = closed * TILE;
-                    Rr = closed < n_tiles ? Rn - rb : 0u;  // the remainder
+                    const uint32_t gw = sh[FR_HELP_CLOSED];
+                    const uint32_t got = gw & 0xffffu, take = gw >> 16;
+                    if (got >= n_tiles) break;  // (uniform) every tile has an owner
+                    omask |= ((take >= 64u ? ~0ull : ((1ull << take) - 1ull)) << got);
+                    rb = got * TILE;
+                    Rr = (got + take) * TILE < Rn ? take * TILE : Rn - rb;
+                    extra_entries += Rr;
                 }
                 const int ls = bk_chunk_shift(chm, Rr, (uint32_t)bd);
                 bk_check_items(CK, tsrc, r_flag, rb, Rr, ls, chm[ls], pend_now, tid, bd);
@@ -813,7 +826,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 }
             }
             if (share) {
-                const uint32_t n_claimed = closed - own_tiles;
+                const uint32_t n_claimed = n_tiles - own_tiles - (uint32_t)__builtin_popcountll(omask);  // tiles the helpers took
                 if (tid == 0) {
                     if (n_claimed) {  // wait for the helpers' tiles
                         uint32_t spins = 0;
@@ -827,12 +840,12 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     }
                     atomicAdd(A.work_count + 4, 1ull);
-                    atomicAdd(A.work_count + 5, (unsigned long long)((closed * TILE < Rn ? closed * TILE : Rn) - own_tiles * TILE));
+                    atomicAdd(A.work_count + 5, (unsigned long long)(Rn - (own_tiles * TILE < Rn ? own_tiles * TILE : Rn) - extra_entries));
                 }
                 __syncthreads();
                 const uint32_t* hverdict = A.help_verdict + (size_t)slot * PDMPC_HELP_CAP;
-                const uint32_t re = closed * TILE < Rn ? closed * TILE : Rn;
-                for (uint32_t r = own_tiles * TILE + (uint32_t)tid; r < re; r += (uint32_t)bd) {  // 1 collision-free, 2 collides, 3 crosses expected areas only
+                for (uint32_t r = own_tiles * TILE + (uint32_t)tid; r < Rn; r += (uint32_t)bd) {  // 1 collision-free, 2 collides, 3 crosses expected areas only
+                    if ((omask >> (r / TILE)) & 1ull) continue;  // (the owner's own verdict is in r_flag already)
                     const uint32_t v = __hip_atomic_load(hverdict + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (v < 1u || v > 3u) atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_BUG);  // (claimed, reported finished, and no verdict)
                     r_flag[r] = v == 2u ? 1u : (v == 3u ? 2u : 0u);
