@@ -128,7 +128,6 @@ if sq:
 
     derived = {}
     if v("SQ_WAVE_CYCLES") and v("SQ_ACTIVE_INST_VALU") is not None:
-        derived["valu_busy_share_of_sq_busy_cycles"] = v("SQ_ACTIVE_INST_VALU") / v("SQ_BUSY_CYCLES") if v("SQ_BUSY_CYCLES") else None
         derived["valu_active_share_of_wave_cycles"] = v("SQ_ACTIVE_INST_VALU") / v("SQ_WAVE_CYCLES")
     if v("SQ_WAVE_CYCLES") and v("SQ_WAIT_ANY") is not None:
         derived["wait_any_share_of_wave_cycles"] = v("SQ_WAIT_ANY") / v("SQ_WAVE_CYCLES")
