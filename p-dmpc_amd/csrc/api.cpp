@@ -161,7 +161,7 @@ struct Tuning {
     int bk_round0 = 24;         // PDMPC_BK_ROUND0: nodes a round of a young search takes (bulk kernel)
     int bk_round = -1;          // PDMPC_BK_ROUND: the most a round takes (bulk kernel; -1: 1000 with helper workgroups, else 256)
     int bk_tentative = 1;       // PDMPC_BK_TENTATIVE: expected areas of predecessors that are still planning (A/B switch: results are identical)
-    int bk_tile = 64;           // PDMPC_BK_TILE: nodes of a tile of a shared round
+    int bk_tile = -1;           // PDMPC_BK_TILE: nodes of a tile of a shared round (-1: by launch size)
     int bk_mid_min = 24576;     // PDMPC_BK_MID_MIN: far lists longer than this feed near through the mid list (a band of far's smallest keys)
     int bk_mid_fill = 12288;    // PDMPC_BK_MID_FILL: entries a refill of mid aims at
     int bk_share_min = 192;     // PDMPC_BK_SHARE_MIN: a round with at least this many nodes is shared with the helper workgroups
@@ -932,7 +932,10 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     a.bk_share_min = T.bk_share_min;
     a.bk_mid_min = T.bk_mid_min;
     a.bk_mid_fill = T.bk_mid_fill;
-    a.bk_tile = T.bk_tile;
+    // a tile costs a helper ≈ 10 us besides its checks (claim, acquire, records, verdicts, release, report): launches with many searches,
+    // whose helpers hop between boards, do better with larger tiles (measured C2 / C3 / C4: 64 -> 1 049 / 1 015 / 70.4 steps/s, 96 -> 1 032 / 1 023 / 71.2,
+    // 128 -> 1 028 / 1 028 / 71.6; 32 -> 951 / 833 / -)
+    a.bk_tile = T.bk_tile > 0 ? T.bk_tile : (count >= 64 ? 128 : 64);
     a.bk_tentative = T.bk_tentative;
     a.bk_post = h->d_bk_post.p;
     a.help_board = h->d_help_board.p;
@@ -1075,7 +1078,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
         T.bk_mid_min = std::max(0, env_i("PDMPC_BK_MID_MIN", T.bk_mid_min));
         T.bk_mid_fill = std::max(256, env_i("PDMPC_BK_MID_FILL", T.bk_mid_fill));
         T.bk_tentative = env_i("PDMPC_BK_TENTATIVE", T.bk_tentative) != 0;
-        T.bk_tile = std::min(128, std::max(16, env_i("PDMPC_BK_TILE", T.bk_tile)));
+        if (getenv("PDMPC_BK_TILE")) T.bk_tile = std::min(128, std::max(16, env_i("PDMPC_BK_TILE", 64)));
         h->bk_ready_cap = std::min(2048, std::max(256, env_i("PDMPC_BK_READY", h->bk_ready_cap))) & ~63;  // (the most a launch may use: launches without helpers lay out half of it)
         if (getenv("PDMPC_FR_ROUND")) h->fr_round = std::max(1, env_i("PDMPC_FR_ROUND", 0));
         if (getenv("PDMPC_FR_NEAR_FILL")) h->fr_near_fill = std::max(64, env_i("PDMPC_FR_NEAR_FILL", 0));
