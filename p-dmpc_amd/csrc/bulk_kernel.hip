@@ -1078,9 +1078,12 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             nn = nn < S.max_nodes ? nn : S.max_nodes;
             incorporate_areas(P, arr, tid);
             __syncthreads();
-            // Only collision-free nodes can lose their edge.  Small trees: every node is an item (the others are skipped); large
-            // trees: the collision-free ones (a third of the tree, scattered) are gathered first so that the items are dense.
-            const bool direct = nn <= 4u * (uint32_t)bd;
+            // Only collision-free nodes can lose their edge.  Small trees: every node is an item (the others are skipped); trees of more
+            // nodes than threads: the collision-free ones (a third of the tree, scattered) are gathered first so that the items are dense
+            // — an item is a chain of two dependent reads of the tree, and a lane that walks three or four of them one after the other
+            // (most of them skipped) was what an arrival event cost (C2's last vehicles: 10 of 15 us per event; gathering from 768 nodes
+            // on instead of 3 072: C2 1 041 -> 1 077 steps/s).
+            const bool direct = nn <= (uint32_t)bd;
 #pragma unroll 1
             for (uint32_t base0 = 0; base0 < nn; base0 += direct ? nn : (uint32_t)FR_NBINS) {  // (uniform trip counts: barriers inside)
                 const lds_u32* list = nullptr;
