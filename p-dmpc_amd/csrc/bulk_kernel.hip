@@ -33,6 +33,9 @@
 #include "frontier_common.hpp"
 
 // shared words of the bulk kernel (aliases of words the frontier kernel uses for things this kernel does not have)
+#ifndef PDMPC_BK_CULL
+#define PDMPC_BK_CULL 0
+#endif
 #define BK_P2 3                   // ready entries a thread handles in the verdict pass (the ready list holds at most BK_P2 * blockDim entries)
 #define BK_PER PDMPC_BK_PER       // near entries per thread a selection pass holds in registers (near capacity = BK_PER * blockDim)
 
@@ -196,6 +199,50 @@ __device__ __forceinline__ void bk_check_items(const BkCheck& C, const Src& src,
         // (segments of the slots of predecessors that are still planning — `pend` — hold expected areas: a crossing there is tentative)
         const int rel0 = (which == 0 && base == so) ? t0 - C.l_lit[k - 1] : -(1 << 20);
         uint32_t found = 0;  // 1: crosses a real area, 2: crosses an expected one
+#if PDMPC_BK_CULL
+        // The exact bounding-box cull, built to be measured (-DPDMPC_BK_CULL=1; off in the product): a segment whose supporting line has
+        // the area's bounding box strictly on one side cannot pass C2 — the expression (y dx2 - x dy2) - S2 is monotone in x and in y
+        // under IEEE rounding, so its extremes over the box are taken at two corners and bound every point's value.  Survivors are
+        // collected in a bit mask first and tested afterwards (a lane-level skip inside the segment loop saves nothing: some lane of
+        // the 64 always needs the full test).  Results identical; C2 / C3 / C4 / C5: 1 040 / 1 003 / 69.6 / 458 steps/s against
+        // 1 067 / 1 031 / 71.3 / 478 without — the corner tests cost what the skipped C2 halves save, the survivors' loop runs as
+        // long as the lane with the most survivors, and eleven more live registers spill.
+        double bx0 = pt[0].x, bx1 = pt[0].x, by0 = pt[0].y, by1 = pt[0].y;
+#pragma unroll
+        for (int i = 1; i < PDMPC_VMAX; ++i) {
+            const bool in = i < ncols;
+            bx0 = (in && pt[i].x < bx0) ? pt[i].x : bx0;
+            bx1 = (in && pt[i].x > bx1) ? pt[i].x : bx1;
+            by0 = (in && pt[i].y < by0) ? pt[i].y : by0;
+            by1 = (in && pt[i].y > by1) ? pt[i].y : by1;
+        }
+        uint32_t surv = 0;
+        {
+            d2 c0 = q0;
+            for (int t = 0; t < tn; ++t) {
+                const d2 c1 = q[t + 1];
+                const double dx2 = c1.x - c0.x, dy2 = c1.y - c0.y;
+                const double S2 = dx2 * c0.y - dy2 * c0.x;
+                const double yhi = dx2 >= 0 ? by1 : by0, ylo = dx2 >= 0 ? by0 : by1;
+                const double xlo = dy2 >= 0 ? bx0 : bx1, xhi = dy2 >= 0 ? bx1 : bx0;
+                const double emax = (yhi * dx2 - xlo * dy2) - S2, emin = (ylo * dx2 - xhi * dy2) - S2;
+                const bool culled = emin > 0 || emax < 0;
+                surv |= culled ? 0u : (1u << t);
+                c0 = c1;
+            }
+        }
+        while (surv && !(found & 1u)) {
+            const int t = __builtin_ctz(surv);
+            surv &= surv - 1u;
+            asm volatile("" : "+v"(pt[0].x), "+v"(pt[0].y), "+v"(pt[1].x), "+v"(pt[1].y), "+v"(pt[2].x), "+v"(pt[2].y), "+v"(pt[3].x), "+v"(pt[3].y), "+v"(pt[4].x), "+v"(pt[4].y),
+                         "+v"(pt[5].x), "+v"(pt[5].y), "+v"(pt[6].x), "+v"(pt[6].y), "+v"(pt[7].x), "+v"(pt[7].y));
+            if (interx_segment_n<PDMPC_VMAX>(pt, ncols - 1, q[t], q[t + 1])) {
+                const int rel = rel0 + t;
+                const bool tent = rel >= 0 && ((pend >> (rel >> 3)) & 1ull) != 0ull;
+                found |= tent ? 2u : 1u;
+            }
+        }
+#else
         for (int t = 0; t < tn && !(found & 1u); ++t) {
             // (the area's points are made opaque per segment: the compiler would otherwise hoist the seven edges' dx1, dy1, S1 of the
             // C1 test out of this loop — 42 registers for a test that one segment in ten reaches)
@@ -209,6 +256,7 @@ __device__ __forceinline__ void bk_check_items(const BkCheck& C, const Src& src,
             }
             q0 = q1;
         }
+#endif
         if (found) __hip_atomic_fetch_or((lds_u32*)&r_flag[r], found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
