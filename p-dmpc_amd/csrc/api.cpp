@@ -135,6 +135,7 @@ struct PackedStep {
 struct Tuning {
     int fr_stage = -1;          // PDMPC_FR_STAGE: records staged per round (-1: by LDS budget)
     int fr_two_per_cu = 0;      // PDMPC_FR_TWO_PER_CU
+    int bk_two_per_cu = 0;      // PDMPC_BK_TWO_PER_CU: bulk kernel, launches with more than two searches per CU: two workgroups of six wavefronts per CU (measured: slower)
     int debug_lds = 0;          // PDMPC_DEBUG_LDS
     int hl_max = 8192;          // PDMPC_HL_MAX (pop-ordered kernel)
     int bm_ring = -1;           // PDMPC_BM_RING (pop-ordered kernel; -1: by launch size)
@@ -400,15 +401,30 @@ bool bulk_has_helpers(const pdmpc_handle* h, int n_launch) {
 int compute_lds_bulk(pdmpc_handle* h, int n_launch, int soup_cap) {
     // large rounds pay where helper workgroups share them; without helpers the LDS is better spent on node records
     h->bk_ready_launch = bulk_has_helpers(h, n_launch) ? h->bk_ready_cap : std::max(256, h->bk_ready_cap / 2);
-    for (int areas = 1; areas >= 0; --areas) {
+    // Launches with more than two searches per CU (C5: five) CAN run two workgroups of half as many wavefronts per CU, 80 KB of LDS each —
+    // the same twelve wavefronts and the same register budget per CU, and while one search sits at a barrier or waits for memory the
+    // other computes (PDMPC_BK_TWO_PER_CU=1).  Measured on C5: 388 steps/s against 479 with one workgroup of twelve per CU — in 80 KB the
+    // maneuver areas have to go to L2 and only 70-110 node records stay in LDS (471 otherwise), and a search of 450 nodes lives on those.
+    struct Try { size_t budget; int waves, areas; };
+    std::vector<Try> tries;
+    if (h->tune.bk_two_per_cu && n_launch > 2 * h->n_cu && !bulk_has_helpers(h, n_launch)) {
+        tries.push_back({kLdsMax / 2, h->waves_latency / 2, 1});
+        tries.push_back({kLdsMax / 2, h->waves_latency / 2, 0});
+    }
+    tries.push_back({kLdsMax, h->waves_latency, 1});
+    tries.push_back({kLdsMax, h->waves_latency, 0});
+    for (const Try& t : tries) {
+        const int areas = t.areas;
         LdsLayout L{};
         uint32_t nv = 0, nl = 0;
-        if (!layout_bulk(h, kLdsMax, h->waves_latency, areas, soup_cap, L, nv, nl, (uint32_t)h->bk_ready_launch)) continue;
+        const int ready = std::min(h->bk_ready_launch, 3 * PDMPC_WAVE * t.waves);
+        if (!layout_bulk(h, t.budget, t.waves, areas, soup_cap, L, nv, nl, (uint32_t)ready)) continue;
         if (h->tune.debug_lds)
-            fprintf(stderr, "pdmpc LDS layout (bulk): launch %d waves %d areas %d near %u ready %d nv %u nl %u total %u\n", n_launch, h->waves_latency, areas,
-                    PDMPC_BK_PER * (uint32_t)h->waves_latency * PDMPC_WAVE, h->bk_ready_launch, nv, nl, L.total);
+            fprintf(stderr, "pdmpc LDS layout (bulk): launch %d budget %zu waves %d areas %d near %u ready %d nv %u nl %u total %u\n", n_launch, t.budget, t.waves, areas,
+                    PDMPC_BK_PER * (uint32_t)t.waves * PDMPC_WAVE, ready, nv, nl, L.total);
+        h->bk_ready_launch = ready;
         h->lds = L;
-        h->n_waves = h->waves_latency;
+        h->n_waves = t.waves;
         h->HL = 0;
         h->NL = (int)nl;
         h->NV = (int)nv;
@@ -1086,6 +1102,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
         if (getenv("PDMPC_QUEUE")) h->queue_mode = env_i("PDMPC_QUEUE", 1) != 0 ? PDMPC_QUEUE_BLOCKMIN : PDMPC_QUEUE_HEAP;
         if (getenv("PDMPC_FR_STAGE")) T.fr_stage = std::max(0, env_i("PDMPC_FR_STAGE", 0));
         T.fr_two_per_cu = env_i("PDMPC_FR_TWO_PER_CU", 0) != 0;
+        T.bk_two_per_cu = env_i("PDMPC_BK_TWO_PER_CU", T.bk_two_per_cu) != 0;
         T.debug_lds = getenv("PDMPC_DEBUG_LDS") != nullptr;
         T.hl_max = env_i("PDMPC_HL_MAX", T.hl_max);
         T.bm_ring = env_i("PDMPC_BM_RING", T.bm_ring);

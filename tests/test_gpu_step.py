@@ -253,10 +253,13 @@ def test_c4_resident_banks_replayed_without_the_safety_net():
     h.close()
 
 
-@pytest.mark.parametrize("n_instances", [12, 64])
-def test_explorative_batch_of_prioritizations_one_launch(n_instances):
+@pytest.mark.parametrize("n_instances,two_per_cu", [(12, False), (64, False), (64, True)])
+def test_explorative_batch_of_prioritizations_one_launch(n_instances, two_per_cu, monkeypatch):
     """BASELINE config 4 (64 instances = the config as named): several prioritizations of the same traffic state flattened
-    into one launch (PrioritizedExplorativeController.m:25-176), records identical to the oracle, same chosen prioritization."""
+    into one launch (PrioritizedExplorativeController.m:25-176), records identical to the oracle, same chosen prioritization.
+    Third case: the layout with two workgroups of six wavefronts per CU (PDMPC_BK_TWO_PER_CU=1; measured and off by default)."""
+    if two_per_cu:
+        monkeypatch.setenv("PDMPC_BK_TWO_PER_CU", "1")
     from oracle import oracle
     from pdmpc.explorative import build_exploration_batch, choose_solution
     from pdmpc.optimizer import GraphSearchHip
