@@ -643,3 +643,9 @@ def test_bulk_kernel_shares_large_rounds_and_parks_tentative_nodes(monkeypatch):
     monkeypatch.setenv("PDMPC_BK_MID_FILL", "2048")
     stats = loop()
     assert stats["kernel"] == 2
+    # ... and with it in the way of EVERY far list, a few hundred entries at a time: arrivals, invalidated nodes and reopened open sets all
+    # meet a mid list
+    monkeypatch.setenv("PDMPC_BK_MID_MIN", "0")
+    monkeypatch.setenv("PDMPC_BK_MID_FILL", "256")
+    stats = loop()
+    assert stats["kernel"] == 2
