@@ -115,7 +115,10 @@ struct NodeArena {  // HBM arrays, per-vehicle stride = max_nodes entries
  * the library -- api.cpp plans the call again with the kernel that carries the libstdc++-faithful heap */
 #define PDMPC_INTERNAL_TIE 100
 
-#define PDMPC_BK_PER 4 /* bulk kernel: entries of the LDS open list per thread (a selection pass holds them in registers) */
+#ifndef PDMPC_BK_PER
+#define PDMPC_BK_PER 4
+#endif
+/* bulk kernel: entries of the LDS open list per thread (a selection pass holds them in registers) */
 
 #define PDMPC_HELP_CAP 2048 /* entries of a round that can be shared (= the ready list's capacity) */
 #define PDMPC_HB_WORDS 8   /* 64-bit words of a board */
