@@ -1021,6 +1021,7 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
                                 : (frontier ? launch_round_based(&a, count) : pdmpc_launch_search(&a, count, (void*)h->stream));
     }
     if (lrc != 0) {
+        h->boards_dirty = true;  // (the searches that were to count themselves finished never ran: the next launch starts from cleared counters)
         char buf[256];
         snprintf(buf, sizeof buf, "kernel launch failed: %s (LDS %u B)", hipGetErrorString((hipError_t)lrc), h->lds.total);
         return fail(PDMPC_ERR_HIP, buf);
