@@ -166,6 +166,7 @@ struct Tuning {
     int bk_mid_min = 24576;     // PDMPC_BK_MID_MIN: far lists longer than this feed near through the mid list (a band of far's smallest keys)
     int bk_mid_fill = 12288;    // PDMPC_BK_MID_FILL: entries a refill of mid aims at
     int bk_share_min = 192;     // PDMPC_BK_SHARE_MIN: a round with at least this many nodes is shared with the helper workgroups
+    int bk_fast_arrival = 1;    // PDMPC_BK_FAST_ARRIVAL: finished searches check arrivals against their plan's path first and publish early (A/B switch: results are identical)
     int bk_ramp = -1;           // PDMPC_BK_RAMP: a round grows by 1 / bk_ramp of the nodes processed so far (-1: 2 with helper workgroups, else 4)
     int fr_slice = -1;          // PDMPC_FR_SLICE (-1: only after a predecessor time-out, 0: never, 1: always when oversubscribed)
     int debug_host = 0;         // PDMPC_DEBUG_HOST
@@ -368,6 +369,8 @@ bool layout_bulk(pdmpc_handle* h, size_t budget, int n_waves, int areas, int sou
     off += 3072u * 4u;
     L.bk_misc = off;
     off += 2048u;
+    L.bk_pshape = off;
+    off += align16((uint32_t)h->cfg.Hp * PDMPC_VMAX * 16u + PDMPC_HP_MAX * 4u);
     L.heap_key = L.bk_hist;  // (the prologue derives pointers from these; the bulk kernel never follows them)
     L.heap_id = L.bk_hist;
     L.stage = L.bk_hist;
@@ -953,6 +956,7 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     // 128 -> 1 028 / 1 028 / 71.6; 32 -> 951 / 833 / -)
     a.bk_tile = T.bk_tile > 0 ? T.bk_tile : (count >= 64 ? 128 : 64);
     a.bk_tentative = T.bk_tentative;
+    a.bk_fast_arrival = T.bk_fast_arrival;
     a.bk_post = h->d_bk_post.p;
     a.help_board = h->d_help_board.p;
     a.help_list = h->d_help_list.p;
@@ -1095,6 +1099,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
         T.bk_mid_min = std::max(0, env_i("PDMPC_BK_MID_MIN", T.bk_mid_min));
         T.bk_mid_fill = std::max(256, env_i("PDMPC_BK_MID_FILL", T.bk_mid_fill));
         T.bk_tentative = env_i("PDMPC_BK_TENTATIVE", T.bk_tentative) != 0;
+        T.bk_fast_arrival = env_i("PDMPC_BK_FAST_ARRIVAL", T.bk_fast_arrival) != 0;
         if (getenv("PDMPC_BK_TILE")) T.bk_tile = std::min(128, std::max(16, env_i("PDMPC_BK_TILE", 64)));
         h->bk_ready_cap = std::min(2048, std::max(256, env_i("PDMPC_BK_READY", h->bk_ready_cap))) & ~63;  // (the most a launch may use: launches without helpers lay out half of it)
         if (getenv("PDMPC_FR_ROUND")) h->fr_round = std::max(1, env_i("PDMPC_FR_ROUND", 0));

@@ -102,6 +102,11 @@ struct BkCheck {
 #define BK_MID_N 10    // entries of mid
 #define BK_MID_MIN 12  // (64 bit) exact minimum key of mid
 #define BK_L_MID 14    // (64 bit) open entries that leave near, and children beyond near's limit, go to mid up to this key and to far above it (-1: no mid list)
+// the fast arrival path (bk_wait_done; words 16-19 of the serial block: the pop-ordered kernel's mail boxes, unused by this search)
+#define BK_FD_LO 16    // (64 bit) predecessors whose areas are in the soup and have passed the path of the finished plan, but whose re-check of the
+#define BK_FD_HI 17    //          other collision-free nodes is still to come (they stay in SH_PEND until the arrival block has seen them)
+#define BK_WAITRES 18  // result of bk_wait_done: 0 nothing yet, 1 an arrival crosses the path, 2 the last predecessor has passed: published
+#define BK_PUBLISHED 19 // the done flag is out (bk_wait_done): the areas of the record in HBM are final and may be read; only counts and ids may still be written
 
 // copies the expected areas of the predecessors in `who` into their soup slots
 __device__ __forceinline__ void bk_tentative_areas(const KernelArgs& A, const SpecCtx& P, unsigned long long who, int tid, int nthreads) {
@@ -358,18 +363,43 @@ __device__ __forceinline__ void bk_select(const lds_u32* bins, uint32_t target, 
     cum = m ? cc : 0u;
 }
 
+// The areas of a result record and their column counts — all a successor reads of it (PrioritizedController.m:476-491) — go to memory
+// with agent-scope stores and are read with agent-scope loads: coherent across the XCDs' L2s by themselves.  PDMPC_BK_AREA_FENCES=1
+// (build switch) puts the release / acquire fences of rounds 2-4 back around them (a write-back / invalidation of the whole L2).
+#ifndef PDMPC_BK_AREA_FENCES
+#define PDMPC_BK_AREA_FENCES 0
+#endif
+__device__ __forceinline__ void bk_area_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void bk_area_store_u32(int32_t* p, int v) { __hip_atomic_store(p, (int32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double bk_area_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int bk_area_load_i32(const int32_t* p) { return (int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // The result record (GraphSearch.m:58-59, 82-89; return_path_to.m; return_path_area.m), written by the first wave.  A search that
 // has finished while predecessors are still planning writes it right away: an arrival that invalidates nothing leaves it as it
 // is, and the publication that follows the last arrival is one flag.  `again`: a record of this search was written before
 // (its fields are reset first).  l_path[i] = node (1-based index into this vehicle's arena) of step i along the selected path
 // (walked here unless path_ready); ref_ids = the ids those nodes carry in the reference's tree (info.tree_path).
 __device__ __forceinline__ void bk_write_record(const KernelArgs& A, Ctx& X, uint32_t goal, int status, bool dep_timeout, uint32_t n_popped, uint32_t nnodes, bool path_ready,
-                                                const lds_u32* ref_ids, bool again, int lane) {
+                                                const lds_u32* ref_ids, bool again, bool counts_only, int lane) {
     const int Hp = X.Hp;
     const DevVehicle* __restrict__ V = X.V;
     pdmpc_vehicle_out* __restrict__ O = X.O;
     lds_u32* l_path = X.l_path;
     const Search& S = X.S;
+    if (counts_only) {
+        // The areas of this record are out already (the done flag was set when the last predecessor's areas had passed the path,
+        // bk_wait_done) and successors may be reading them: only what the re-check of the other nodes can still change is written
+        // — the reference's ids along the path and the two counts (the path itself is the one that was published).
+        if (goal && ref_ids && lane <= Hp) O->tree_path[lane] = (int32_t)ref_ids[lane];
+        if (lane == 0) {
+            O->status = dep_timeout ? PDMPC_ERR_HIP : status;
+            O->n_expanded = (int32_t)nnodes;
+            O->n_popped = (int32_t)n_popped;
+        }
+        return;
+    }
+    lds_d2* pshape = (lds_d2*)(X.lsm + A.lds.bk_pshape);
+    lds_u32* pcols = (lds_u32*)(pshape + Hp * PDMPC_VMAX);
     if (again) {  // as the prologue left it: zeros, y_predicted NaN (ControlResultsInfo.m:40)
         double* od = (double*)O;
         const int nd = (int)(offsetof(pdmpc_vehicle_out, path_nodes) / 8) + (Hp + 1) * 8;  // (rows beyond the path are never written here: the diagnostics of the tail stay)
@@ -415,12 +445,21 @@ __device__ __forceinline__ void bk_write_record(const KernelArgs& A, Ctx& X, uin
             const NodeRec cr = node_load(S, l_path[i] - 1);
             const int m = NODE_MAN(cr.packed);
             const int ncols = NODE_COLS(cr.packed);
-            if (v == 0) O->shape_cols[i - 1] = ncols;
+            // (the areas and their column counts are what successors read, bk_area_load: stores that go through to memory, so that
+            // the publication needs no write-back of this XCD's L2)
+            if (v == 0) {
+                bk_area_store_u32(&O->shape_cols[i - 1], ncols);
+                pcols[i - 1] = (uint32_t)ncols;
+            }
+            d2 sp = d2{0.0, 0.0};
             if (v < ncols) {
                 const d2 a = X.C.g_area[(size_t)m * 3 * PDMPC_VMAX + v];
-                O->shapes[i - 1][0][v] = pr.cs * a.x - pr.sn * a.y + pr.x;
-                O->shapes[i - 1][1][v] = pr.sn * a.x + pr.cs * a.y + pr.y;
+                sp.x = pr.cs * a.x - pr.sn * a.y + pr.x;
+                sp.y = pr.sn * a.x + pr.cs * a.y + pr.y;
+                bk_area_store(&O->shapes[i - 1][0][v], sp.x);
+                bk_area_store(&O->shapes[i - 1][1][v], sp.y);
             }
+            pshape[idx] = sp;  // (columns beyond ncols are padding: read, never used)
         }
     } else if (V->fb_off[0] >= 0) {
         // exhausted: publish the caller-supplied fallback areas so successors of this launch avoid them (PrioritizedController.m:568-616, 678-718)
@@ -429,10 +468,10 @@ __device__ __forceinline__ void bk_write_record(const KernelArgs& A, Ctx& X, uin
             const int v = idx - k * PDMPC_VMAX;
             const int a = V->fb_off[k], b = V->fb_off[k + 1];
             const int cols = (b - a < PDMPC_VMAX) ? (b - a) : PDMPC_VMAX;
-            if (v == 0) O->shape_cols[k] = cols;
+            if (v == 0) bk_area_store_u32(&O->shape_cols[k], cols);
             if (v < cols) {
-                O->shapes[k][0][v] = A.points[2 * (size_t)(a + v)];
-                O->shapes[k][1][v] = A.points[2 * (size_t)(a + v) + 1];
+                bk_area_store(&O->shapes[k][0][v], A.points[2 * (size_t)(a + v)]);
+                bk_area_store(&O->shapes[k][1][v], A.points[2 * (size_t)(a + v) + 1]);
             }
         }
     }
@@ -445,15 +484,83 @@ __device__ __forceinline__ void bk_write_record(const KernelArgs& A, Ctx& X, uin
 }
 
 // Publication: plain stores -> this wave's vmcnt(0) -> lane-0 agent release -> flag.  First wave.
-__device__ __forceinline__ void bk_publish(const KernelArgs& A, const Ctx& X, int status, bool dep_timeout) {
-    if (X.lane == 0 && (dep_timeout || (status != PDMPC_OK && status != PDMPC_EXHAUSTED))) atomicAdd(A.work_count + 6, 1ull);  // (device-side tally of plans that are not planning results)
+// (the areas were stored through to memory, bk_area_store: what the flag announces is there once this wave's stores have been
+// acknowledged; the rest of the record is read by the host, after the kernel)
+__device__ __forceinline__ void bk_publish_flag(const KernelArgs& A, int slot, int lane) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wave_sync();
-    if (X.lane == 0) {
+    if (lane == 0) {
+#if PDMPC_BK_AREA_FENCES
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(A.done_flag + X.slot, A.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+        __hip_atomic_store(A.done_flag + slot, A.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+__device__ __forceinline__ void bk_publish(const KernelArgs& A, const Ctx& X, int status, bool dep_timeout) {
+    if (X.lane == 0 && (dep_timeout || (status != PDMPC_OK && status != PDMPC_EXHAUSTED))) atomicAdd(A.work_count + 6, 1ull);  // (device-side tally of plans that are not planning results)
+    bk_publish_flag(A, X.slot, X.lane);
+}
+
+// One look at the done flags of the predecessors in `want` (poll_predecessors without its bookkeeping): the set that has finished.
+// Whole wave calls.
+__device__ __forceinline__ unsigned long long bk_poll_flags(const KernelArgs& A, const SpecCtx& P, unsigned long long want, int lane) {
+    bool d = false;
+    if ((want >> lane) & 1ull) d = __hip_atomic_load(A.done_flag + P.pred[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == A.epoch;
+    const unsigned long long got = __ballot(d);
+#if PDMPC_BK_AREA_FENCES
+    if (got) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#endif
+    return got;
+}
+
+// poll_predecessors on bk_poll_flags: the pending predecessors that have finished are posted in SH_ARR and the state goes
+// ST_RUN -> ST_ARRIVED.  Whole wave calls.
+__device__ __forceinline__ bool bk_poll_predecessors(const KernelArgs& A, const SpecCtx& P, volatile lds_u32* sh, unsigned long long skip, int lane) {
+    const unsigned long long pend = sh_load64(sh, SH_PEND_LO) & ~skip;
+    if (!pend) return false;
+    const unsigned long long got = bk_poll_flags(A, P, pend, lane);
+    if (!got) return false;
+    if (lane == 0) {
+        sh[SH_ARR_LO] = (uint32_t)got;
+        sh[SH_ARR_HI] = (uint32_t)(got >> 32);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        atomicCAS((uint32_t*)&sh[SH_STATE], ST_RUN, ST_ARRIVED);
+    }
+    return true;
+}
+
+// incorporate_areas with loads that are coherent by themselves (bk_area_load): the solved areas of the predecessors in `arr` into
+// their soup slots (PrioritizedController.m:476-491); nthreads threads call (a workgroup, or one wave).  Out of line with scalar
+// arguments (see bk_wait_done).
+__device__ __forceinline__ void bk_incorporate_body(const pdmpc_vehicle_out* out, const int32_t* pred, lds_d2* l_soup, const lds_i32* l_soff, const lds_i32* l_lit, int Hp, unsigned long long arr, int tid,
+                                                    int nthreads) {
+    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+    const int per = Hp * PDMPC_VMAX, n_arr = __builtin_popcountll(arr);
+    for (int idx = tid; idx < n_arr * per; idx += nthreads) {  // (every arrived predecessor's loads side by side)
+        const int a = idx / per, rest = idx - a * per;
+        const int p = nth_bit(arr, a);
+        const pdmpc_vehicle_out* PO = out + pred[p];
+        const int k = rest / PDMPC_VMAX, v = rest - k * PDMPC_VMAX;
+        const int cols = bk_area_load_i32(&PO->shape_cols[k]);
+        const double sx = bk_area_load(&PO->shapes[k][0][v]), sy = bk_area_load(&PO->shapes[k][1][v]);
+        d2 pt;
+        pt.x = v < cols ? sx : qnan;
+        pt.y = v < cols ? sy : qnan;
+        l_soup[l_soff[k] + l_lit[k] + p * PDMPC_VMAX + v] = pt;
+    }
+}
+__device__ __noinline__ void bk_incorporate(const pdmpc_vehicle_out* out_, const int32_t* pred_, lds_d2* l_soup_, const lds_i32* l_soff_, const lds_i32* l_lit_, int Hp_, unsigned long long arr_, int tid,
+                                            int nthreads_) {
+    auto uptr = [](const void* p) -> uint64_t {
+        const uint64_t u = (uint64_t)p;
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
+    };
+    bk_incorporate_body((const pdmpc_vehicle_out*)uptr(out_), (const int32_t*)uptr(pred_), (lds_d2*)(uintptr_t)uni_u((uint32_t)(uintptr_t)l_soup_), (const lds_i32*)(uintptr_t)uni_u((uint32_t)(uintptr_t)l_soff_),
+                        (const lds_i32*)(uintptr_t)uni_u((uint32_t)(uintptr_t)l_lit_), uni_i(Hp_), (unsigned long long)uptr((const void*)arr_), tid, uni_i(nthreads_));
 }
 
 // fr_check_wave with a memory: what to do with an open node a round has selected (1 process it, 3 it comes after the goal candidate,
@@ -521,6 +628,107 @@ __device__ int bk_classify_wave(const unsigned long long* glink, ulonglong2* wal
         walk[a0 - 1u] = w;
     }
     return res;
+}
+
+// A FINISHED search waiting for its predecessors (its record is written, bk_write_record; the areas along its path are in LDS).
+// What its successors wait for are its areas, and those are final as soon as every predecessor's areas have passed the path: nothing
+// open or parked comes before the goal (that is what finished means), and an arrival can only take edges away.  So the first wave
+// alone — no workgroup barrier — polls, copies an arrived predecessor's areas into the soup, checks them against the Hp edges of
+// the path (the arithmetic of bk_recheck_items on the same numbers) and sets the done flag when the last predecessor has passed.
+// The re-check of the other collision-free nodes, which can only change the counts and ids of the record, follows in the
+// arrival block for all of them at once (BK_FD: who is due).  A predecessor that crosses the path goes to the arrival block
+// right away: the search resumes as before.  Leaves BK_WAITRES.
+// Out of line on purpose (scalar arguments, one wavefront, once per wait): inlined, its registers push the search loop beyond the
+// 168 VGPRs of a twelve-wavefront workgroup (tests/test_build.py watches this).
+__device__ __noinline__ void bk_wait_done(const uint32_t* done_flag_, const int32_t* pred_, const pdmpc_vehicle_out* out_, uint32_t epoch_, uint32_t slot_, lds_d2* l_soup_, const lds_i32* l_soff_,
+                                          const lds_i32* l_lit_, lds_d2* pshape_, volatile lds_u32* sh_, int Hp_, int n_pred_, int have_path_, lds_vu64* tk_pub_) {
+    // (arguments of an out-of-line function arrive in vector registers: uniform again from here)
+    auto uptr = [](const void* p) -> uint64_t {
+        const uint64_t u = (uint64_t)p;
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
+    };
+    const uint32_t* done_flag = (const uint32_t*)uptr(done_flag_);
+    const int32_t* pred = (const int32_t*)uptr(pred_);
+    const pdmpc_vehicle_out* out = (const pdmpc_vehicle_out*)uptr(out_);
+    const uint32_t epoch = uni_u(epoch_), slot = uni_u(slot_);
+    lds_d2* l_soup = (lds_d2*)(uintptr_t)uni_u((uint32_t)(uintptr_t)l_soup_);
+    const lds_i32* l_soff = (const lds_i32*)(uintptr_t)uni_u((uint32_t)(uintptr_t)l_soff_);
+    const lds_i32* l_lit = (const lds_i32*)(uintptr_t)uni_u((uint32_t)(uintptr_t)l_lit_);
+    lds_d2* pshape = (lds_d2*)(uintptr_t)uni_u((uint32_t)(uintptr_t)pshape_);
+    volatile lds_u32* sh = (volatile lds_u32*)(uintptr_t)uni_u((uint32_t)(uintptr_t)sh_);
+    lds_vu64* tk_pub = (lds_vu64*)(uintptr_t)uni_u((uint32_t)(uintptr_t)tk_pub_);
+    const int Hp = uni_i(Hp_), n_pred = uni_i(n_pred_);
+    const bool have_path = uni_i(have_path_) != 0;
+    const int lane = (int)(threadIdx.x & (PDMPC_WAVE - 1));
+    const lds_u32* pcols = (const lds_u32*)(pshape + Hp * PDMPC_VMAX);
+    const unsigned long long pend = sh_load64(sh, SH_PEND_LO);
+    unsigned long long fd = sh_load64(sh, BK_FD_LO);
+    uint32_t spins = 0, res = 0;
+    for (;;) {
+        const unsigned long long want = pend & ~fd;
+        bool d = false;
+        if (lane < n_pred && ((want >> lane) & 1ull)) d = __hip_atomic_load(done_flag + pred[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+        const unsigned long long got = __ballot(d);
+        if (!got) {  // (uniform)
+            if (++spins >= 4096u) break;
+            __builtin_amdgcn_s_sleep(1);
+            continue;
+        }
+#if PDMPC_BK_AREA_FENCES
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        const int n_got = __builtin_popcountll(got);
+        bk_incorporate_body(out, pred, l_soup, l_soff, l_lit, Hp, got, lane, PDMPC_WAVE);
+        wave_sync();
+        const int per = Hp * (PDMPC_VMAX - 1), items = have_path ? n_got * per : 0;
+        bool hit = false;
+        for (int base = 0; base < items; base += PDMPC_WAVE) {  // (uniform trip count; item = (arrived predecessor, step, segment of its area))
+            const int item = base + lane;
+            const bool in = item < items;
+            const int it = in ? item : 0;
+            const int a = it / per, rest = it - a * per;
+            const int k0 = rest / (PDMPC_VMAX - 1), j = rest - k0 * (PDMPC_VMAX - 1);
+            const int p = nth_bit(got, a);
+            d2 pt[PDMPC_VMAX];
+#pragma unroll
+            for (int i = 0; i < PDMPC_VMAX; ++i) pt[i] = pshape[k0 * PDMPC_VMAX + i];
+            const lds_d2* poly = l_soup + l_soff[k0] + l_lit[k0] + p * PDMPC_VMAX;
+            const bool h1 = interx_segment_n<PDMPC_VMAX>(pt, (int)pcols[k0] - 1, poly[j], poly[j + 1]);
+            hit = hit || (in && h1);
+        }
+        fd |= got;
+        if (__ballot(hit)) {  // (uniform)
+            res = 1;
+            break;
+        }
+        if ((pend & ~fd) == 0ull) {
+            res = 2;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wave_sync();
+            if (lane == 0) {
+#if PDMPC_BK_AREA_FENCES
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                __hip_atomic_store((uint32_t*)done_flag + slot, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tk_pub) *tk_pub = __builtin_amdgcn_s_memrealtime();
+            }
+            break;
+        }
+    }
+    if (lane == 0) {
+        sh[BK_FD_LO] = (uint32_t)fd;
+        sh[BK_FD_HI] = (uint32_t)(fd >> 32);
+        sh[BK_WAITRES] = res;
+        if (res == 2u) sh[BK_PUBLISHED] = 1u;
+        sh[BK_IDLE] = sh[BK_IDLE] + spins + 1u;
+        if (res) {  // the arrival block takes them from here
+            sh[SH_ARR_LO] = (uint32_t)fd;
+            sh[SH_ARR_HI] = (uint32_t)(fd >> 32);
+            sh[SH_STATE] = ST_ARRIVED;
+        }
+    }
 }
 
 // The far-list selection stays an out-of-line call: it runs once per refill on one wavefront, and inlined into the search loop its
@@ -657,11 +865,11 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
     uint32_t t_checks = 0, t_pairs = 0;  // this thread's share of the work counters
     // where the time goes (100 MHz ticks, PDMPC_DEBUG_TAIL=1): accumulated by thread 0 in LDS words, so that the bookkeeping costs
     // the round loop no registers
-    lds_vu64* tk = (lds_vu64*)(gp_path + 200);  // [11]: mark, start, work, arrival, select (without the refills), wait, p1, p2, p3, phase B, refill
-    enum { TK_MARK, TK_START, tk_work, tk_arrival, tk_select, tk_wait, tk_p1, tk_p2, tk_p3, tk_pb, tk_refill };
+    lds_vu64* tk = (lds_vu64*)(gp_path + 200);  // [12]: mark, start, work, arrival, select (without the refills), wait, p1, p2, p3, phase B, refill, time of the early publication
+    enum { TK_MARK, TK_START, tk_work, tk_arrival, tk_select, tk_wait, tk_p1, tk_p2, tk_p3, tk_pb, tk_refill, tk_pub };
     const bool ticking = A.debug_tail != 0 && tid == 0;
     if (ticking) {
-        for (int i = 2; i < 11; ++i) tk[i] = 0ull;
+        for (int i = 2; i < 12; ++i) tk[i] = 0ull;
         tk[TK_MARK] = tk[TK_START] = __builtin_amdgcn_s_memrealtime();
     }
 #define BK_TICK(acc)                                                       \
@@ -750,7 +958,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
     auto bk_wait = [&]() -> bool {
         if (wave == 0) {
             uint32_t spins = 0;
-            while (!poll_predecessors(A, P, sh, lane) && ++spins < 4096u) __builtin_amdgcn_s_sleep(1);
+            while (!bk_poll_predecessors(A, P, sh, 0ull, lane) && ++spins < 4096u) __builtin_amdgcn_s_sleep(1);
             if (lane == 0) sh[BK_IDLE] = sh[BK_IDLE] + spins + 1u;
         }
         __syncthreads();
@@ -1117,14 +1325,14 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         // predecessors that finished meanwhile: their areas enter the soup, collision-free edges are re-checked
         const bool pending = sh_load64(sh, SH_PEND_LO) != 0ull;  // (uniform: written by thread 0 between barriers)
         if (pending) {
-            if (wave == 0 && sh[SH_STATE] != ST_ARRIVED) (void)poll_predecessors(A, P, sh, lane);  // (a waiting search has polled already: bk_wait)
+            if (wave == 0 && sh[SH_STATE] != ST_ARRIVED) (void)bk_poll_predecessors(A, P, sh, 0ull, lane);  // (a waiting search has polled already: bk_wait / bk_wait_done)
             __syncthreads();
         }
         if (pending && sh[SH_STATE] == ST_ARRIVED) {
             const unsigned long long arr = sh_load64(sh, SH_ARR_LO);
             uint32_t nn = sh[FR_NNODES];
             nn = nn < S.max_nodes ? nn : S.max_nodes;
-            incorporate_areas(P, arr, tid);
+            bk_incorporate(P.out, P.pred, P.l_soup, P.l_soff, P.l_lit, Hp, arr & ~sh_load64(sh, BK_FD_LO), tid, bd);  // (what bk_wait_done has let through is in the soup already)
             __syncthreads();
             // Only collision-free nodes can lose their edge.  Small trees: every node is an item (the others are skipped); trees of more
             // nodes than threads: the collision-free ones (a third of the tree, scattered) are gathered first so that the items are dense
@@ -1187,6 +1395,8 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 sh[SH_PEND_HI] = (uint32_t)(pend >> 32);
                 sh[SH_ARR_LO] = 0;
                 sh[SH_ARR_HI] = 0;
+                sh[BK_FD_LO] = 0;
+                sh[BK_FD_HI] = 0;
                 sh[SH_STATE] = ST_RUN;
                 sh[BK_NTENT] = 0;
                 sh_st_d(sh, BK_TENT_MIN, inf);
@@ -1319,7 +1529,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             }
             // finished, but predecessors that are still planning may yet invalidate what we found: the record is written meanwhile
             if (!rec_valid && !dep_timeout) {
-                if (wave == 0) bk_write_record(A, X, best, best ? PDMPC_OK : PDMPC_EXHAUSTED, false, R.n_popped, R.n_expanded, best != 0u, ref_ids, rec_written, lane);
+                if (wave == 0) bk_write_record(A, X, best, best ? PDMPC_OK : PDMPC_EXHAUSTED, false, R.n_popped, R.n_expanded, best != 0u, ref_ids, rec_written, sh[BK_PUBLISHED] != 0u, lane);
                 rec_valid = true;
                 rec_written = true;
             }
@@ -1331,7 +1541,15 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 for (uint32_t i = (uint32_t)tid; i < nv; i += (uint32_t)bd) VS.g[i] = VS.l[i];
                 vs_copied = true;
             }
-            if (bk_wait()) dep_timeout = true;  // a predecessor never finished: give up on it (reported as an error status)
+            if (A.bk_fast_arrival && !dep_timeout) {
+                if (wave == 0)
+                    bk_wait_done(A.done_flag, P.pred, P.out, A.epoch, (uint32_t)slot, P.l_soup, P.l_soff, P.l_lit, (lds_d2*)(X.lsm + A.lds.bk_pshape), sh, Hp, P.n_pred, best != 0u ? 1 : 0,
+                                 ticking ? (lds_vu64*)(tk + tk_pub) : (lds_vu64*)nullptr);
+                __syncthreads();
+                if (sh[BK_IDLE] > A.spin_limit) dep_timeout = true;
+            } else if (bk_wait()) {
+                dep_timeout = true;  // a predecessor never finished: give up on it (reported as an error status)
+            }
             BK_TICK(tk_wait)
             continue;
         }
@@ -1654,8 +1872,9 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         X.O->path_nodes[PDMPC_HP_MAX - 1][2] = (double)tk[tk_select];
         X.O->path_nodes[PDMPC_HP_MAX - 1][3] = (double)tk[tk_wait];
         X.O->path_nodes[PDMPC_HP_MAX - 1][4] = (double)(tk[TK_MARK] - tk[TK_START]);
-        X.O->path_nodes[PDMPC_HP_MAX - 1][5] = 0.0;
-        X.O->path_nodes[PDMPC_HP_MAX - 1][6] = 0.0;
+        X.O->path_nodes[PDMPC_HP_MAX - 1][5] = (double)tk[tk_pub];                // when the done flag was set ahead of the end (0: at the end), 100 MHz device clock
+        X.O->path_nodes[PDMPC_HP_MAX - 1][6] = (double)__builtin_amdgcn_s_memrealtime();  // ... and now (the flag follows within a microsecond unless it is out)
+        X.O->path_nodes[PDMPC_HP_MAX - 1][7] = (double)X.rt_kernel_start;
     }
     X.status = status;
     X.n_popped = (int)R.n_popped;
@@ -1665,6 +1884,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
     X.dep_timeout = dep_timeout;
     X.rec_valid = rec_valid && !dep_timeout;
     X.rec_written = rec_written;
+    X.published = sh[BK_PUBLISHED] != 0u;
     return false;
 }
 
@@ -1887,6 +2107,7 @@ __device__ __forceinline__ void bulk_body(const KernelArgs& A) {
         X.nnodes = 0;
         X.rec_valid = false;
         X.dep_timeout = false;
+        X.published = false;
     }
     __syncthreads();
     if (wave != 0) return;
@@ -1895,7 +2116,7 @@ __device__ __forceinline__ void bulk_body(const KernelArgs& A) {
         asm volatile("" : "+v"(l__));
         X.lane = l__;
     }
-    if (!X.rec_valid) bk_write_record(A, X, X.goal, X.status, X.dep_timeout, (uint32_t)X.n_popped, X.nnodes, X.path_ready, tie ? nullptr : ref_ids, X.rec_written, X.lane);
+    if (!X.rec_valid) bk_write_record(A, X, X.goal, X.status, X.dep_timeout, (uint32_t)X.n_popped, X.nnodes, X.path_ready, tie ? nullptr : ref_ids, X.rec_written, X.published, X.lane);
     bk_publish(A, X, X.status, X.dep_timeout);
     if (X.lane == 0 && A.n_helpers > 0) atomicAdd(A.help_finished, 1u);
 }

@@ -94,6 +94,7 @@ struct LdsLayout {
     uint32_t bk_ready;                     // uint32[bk_ready_cap] nodes of the round + uint32[bk_ready_cap] their collision flags
     uint32_t bk_hist;                      // uint32[3072]: histogram [2048] | goal list [1024], collision-free nodes of the round [1024], their children's offsets [1024]
     uint32_t bk_misc;                      // 2 KB: path tables of the best goal candidate, scan partials, chunk table, the reference's ids along the path | the selection's 256-bin histogram
+    uint32_t bk_pshape;                    // double2[Hp][VMAX] + uint32[HP_MAX]: the areas along the path of the record written last and their column counts (what an arrival is checked against first)
 };
 
 struct NodeArena {  // HBM arrays, per-vehicle stride = max_nodes entries
@@ -204,6 +205,7 @@ struct KernelArgs {
     int32_t bk_mid_min;     // a far list longer than this is not scanned by every refill of near: a band of its smallest keys is moved to mid first
     int32_t bk_mid_fill;    // ... about this many entries at a time
     int32_t bk_share_min;   // a round with at least this many entries is shared with the helper workgroups
+    int32_t bk_fast_arrival; // 1: a finished search checks an arriving predecessor's areas against its plan's path first and publishes its own areas as soon as the last one has passed (the other collision-free nodes are re-checked afterwards)
     double* bk_post;        // [slot][bk_ready_cap][3] double2: what a check item reads of the tree, posted per entry of a shared round
     int32_t speculate;  // 1: start searching before all predecessors have finished (results are identical, see arrival_sync)
     uint32_t spin_limit;

@@ -314,6 +314,7 @@ struct Ctx {
     uint32_t goal, nnodes;
     bool dep_timeout;
     bool rec_valid = false, rec_written = false;  // bulk kernel: the result record has been written ahead of the publication / at all
+    bool published = false;                       // bulk kernel: the done flag is out already (the record's areas are final, only counts and ids may still be written)
     unsigned long long rt_kernel_start = 0;  // s_memrealtime at kernel entry (diagnostics of the bulk kernel)
     bool path_ready = false;  // l_path already holds the nodes of the goal's path (the frontier kernel's counting pass has walked it)
 #ifdef PDMPC_PROFILE

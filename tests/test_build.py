@@ -25,6 +25,7 @@ def test_round_based_kernels_use_no_scratch_memory_and_spill_no_vgprs(source, ke
         pytest.skip("no hipcc")
     cmd = [HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
            "-mllvm", "-amdgpu-inline-max-bb=10000",  # (as csrc/Makefile)
+           *(["-mllvm", "-disable-machine-licm"] if source == "bulk_kernel.hip" else []),  # (BULK_FLAGS of csrc/Makefile)
            "-I" + os.path.join(ROOT, "include"), "-c", "-Rpass-analysis=kernel-resource-usage", "-o", os.devnull, os.path.join(CSRC, source)]
     out = subprocess.run(cmd, capture_output=True, text=True, check=True).stderr
     seen = {}

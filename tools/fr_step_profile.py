@@ -30,6 +30,16 @@ for b, prob in enumerate(probs):
         v = max(range(len(recs)), key=lambda i: np.asarray(recs[i]["path_nodes"])[16][1])
         t = np.asarray(recs[v]["path_nodes"])
         print("   round sizes of veh %d:" % v, [int(x) for x in t[9:14].reshape(-1) if x > 0])
+    if os.environ.get("PROFILE_CHAIN"):  # when every vehicle's areas went out (done flag) and ended, on the device's 100 MHz clock from the first workgroup's start; hop = after its last predecessor's flag
+        T = [np.asarray(r["path_nodes"]) for r in recs]
+        origin = min(t[15][7] for t in T)
+        pub = [((t[15][5] if t[15][5] > 0 else t[15][6]) - origin) / 100.0 for t in T]
+        end = [(t[15][6] - origin) / 100.0 for t in T]
+        for v in sorted(range(len(recs)), key=lambda i: (prob["levels"][i], i)):
+            pr = prob["preds"][v]
+            last = max([pub[q] for q in pr], default=0.0)
+            print("   chain veh %2d level %2d preds %2d | search done %4.0f us | areas out %4.0f us (hop %4.0f) | end %4.0f us | early %d" % (
+                v, prob["levels"][v], len(pr), (T[v][15][7] - origin) / 100.0 + T[v][14][0] / 100.0 + T[v][15][0] / 100.0 + T[v][15][2] / 100.0, pub[v], pub[v] - last, end[v], int(T[v][15][5] > 0)))
     top = int(os.environ.get("PROFILE_TOP", "8"))
     for r in sorted(rows, reverse=True)[:top]:
         print("   total %.0f us veh %d level %d popped %d processed %d nodes %d rounds %d | work %.0f arrival %.0f select %.0f wait %.0f us | preds %d | prologue %.0f check %.0f verdict %.0f expand %.0f phaseB %.0f refill %.0f us" % r)
