@@ -635,13 +635,15 @@ __device__ int bk_classify_wave(const unsigned long long* glink, ulonglong2* wal
 // open or parked comes before the goal (that is what finished means), and an arrival can only take edges away.  So the first wave
 // alone — no workgroup barrier — polls, copies an arrived predecessor's areas into the soup, checks them against the Hp edges of
 // the path (the arithmetic of bk_recheck_items on the same numbers) and sets the done flag when the last predecessor has passed.
-// The re-check of the other collision-free nodes, which can only change the counts and ids of the record, follows in the
-// arrival block for all of them at once (BK_FD: who is due).  A predecessor that crosses the path goes to the arrival block
-// right away: the search resumes as before.  Leaves BK_WAITRES.
+// The verification of the other collision-free nodes, which can only change the counts and ids of the record, follows at the next
+// round boundary for all of them at once (BK_FD: who is due).  A predecessor that crosses the path ends the wait: the verification
+// takes the path's edge away and the search resumes.  `first`: predecessors whose areas are in the soup already but have not been
+// checked against this path (copied while the search was running); max_spins 0: look at them and at the flags once, do not wait.
+// Leaves BK_WAITRES (0 nothing decided, 1 an arrival crosses the path, 2 published), SH_PEND and BK_FD.
 // Out of line on purpose (scalar arguments, one wavefront, once per wait): inlined, its registers push the search loop beyond the
 // 168 VGPRs of a twelve-wavefront workgroup (tests/test_build.py watches this).
 __device__ __noinline__ void bk_wait_done(const uint32_t* done_flag_, const int32_t* pred_, const pdmpc_vehicle_out* out_, uint32_t epoch_, uint32_t slot_, lds_d2* l_soup_, const lds_i32* l_soff_,
-                                          const lds_i32* l_lit_, lds_d2* pshape_, volatile lds_u32* sh_, int Hp_, int n_pred_, int have_path_, lds_vu64* tk_pub_) {
+                                          const lds_i32* l_lit_, lds_d2* pshape_, volatile lds_u32* sh_, int Hp_, int n_pred_, int have_path_, lds_vu64* tk_pub_, unsigned long long first_, uint32_t max_spins_) {
     // (arguments of an out-of-line function arrive in vector registers: uniform again from here)
     auto uptr = [](const void* p) -> uint64_t {
         const uint64_t u = (uint64_t)p;
@@ -650,7 +652,7 @@ __device__ __noinline__ void bk_wait_done(const uint32_t* done_flag_, const int3
     const uint32_t* done_flag = (const uint32_t*)uptr(done_flag_);
     const int32_t* pred = (const int32_t*)uptr(pred_);
     const pdmpc_vehicle_out* out = (const pdmpc_vehicle_out*)uptr(out_);
-    const uint32_t epoch = uni_u(epoch_), slot = uni_u(slot_);
+    const uint32_t epoch = uni_u(epoch_), slot = uni_u(slot_), max_spins = uni_u(max_spins_);
     lds_d2* l_soup = (lds_d2*)(uintptr_t)uni_u((uint32_t)(uintptr_t)l_soup_);
     const lds_i32* l_soff = (const lds_i32*)(uintptr_t)uni_u((uint32_t)(uintptr_t)l_soff_);
     const lds_i32* l_lit = (const lds_i32*)(uintptr_t)uni_u((uint32_t)(uintptr_t)l_lit_);
@@ -661,26 +663,29 @@ __device__ __noinline__ void bk_wait_done(const uint32_t* done_flag_, const int3
     const bool have_path = uni_i(have_path_) != 0;
     const int lane = (int)(threadIdx.x & (PDMPC_WAVE - 1));
     const lds_u32* pcols = (const lds_u32*)(pshape + Hp * PDMPC_VMAX);
-    const unsigned long long pend = sh_load64(sh, SH_PEND_LO);
-    unsigned long long fd = sh_load64(sh, BK_FD_LO);
+    unsigned long long pend = sh_load64(sh, SH_PEND_LO), fd = sh_load64(sh, BK_FD_LO);
+    unsigned long long got = (unsigned long long)uptr((const void*)first_);  // (in the soup already: checked against the path before anybody is polled)
     uint32_t spins = 0, res = 0;
     for (;;) {
-        const unsigned long long want = pend & ~fd;
-        bool d = false;
-        if (lane < n_pred && ((want >> lane) & 1ull)) d = __hip_atomic_load(done_flag + pred[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
-        const unsigned long long got = __ballot(d);
         if (!got) {  // (uniform)
-            if (++spins >= 4096u) break;
-            __builtin_amdgcn_s_sleep(1);
-            continue;
-        }
+            bool d = false;
+            if (lane < n_pred && ((pend >> lane) & 1ull)) d = __hip_atomic_load(done_flag + pred[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+            got = __ballot(d);
+            if (!got) {
+                if (++spins >= max_spins) break;
+                __builtin_amdgcn_s_sleep(1);
+                continue;
+            }
 #if PDMPC_BK_AREA_FENCES
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
+            bk_incorporate_body(out, pred, l_soup, l_soff, l_lit, Hp, got, lane, PDMPC_WAVE);
+            wave_sync();
+            pend &= ~got;
+            fd |= got;
+        }
         const int n_got = __builtin_popcountll(got);
-        bk_incorporate_body(out, pred, l_soup, l_soff, l_lit, Hp, got, lane, PDMPC_WAVE);
-        wave_sync();
         const int per = Hp * (PDMPC_VMAX - 1), items = have_path ? n_got * per : 0;
         bool hit = false;
         for (int base = 0; base < items; base += PDMPC_WAVE) {  // (uniform trip count; item = (arrived predecessor, step, segment of its area))
@@ -697,12 +702,12 @@ __device__ __noinline__ void bk_wait_done(const uint32_t* done_flag_, const int3
             const bool h1 = interx_segment_n<PDMPC_VMAX>(pt, (int)pcols[k0] - 1, poly[j], poly[j + 1]);
             hit = hit || (in && h1);
         }
-        fd |= got;
+        got = 0ull;
         if (__ballot(hit)) {  // (uniform)
             res = 1;
             break;
         }
-        if ((pend & ~fd) == 0ull) {
+        if (pend == 0ull) {
             res = 2;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             wave_sync();
@@ -716,18 +721,16 @@ __device__ __noinline__ void bk_wait_done(const uint32_t* done_flag_, const int3
             }
             break;
         }
+        if (max_spins == 0u) break;
     }
     if (lane == 0) {
+        sh[SH_PEND_LO] = (uint32_t)pend;
+        sh[SH_PEND_HI] = (uint32_t)(pend >> 32);
         sh[BK_FD_LO] = (uint32_t)fd;
         sh[BK_FD_HI] = (uint32_t)(fd >> 32);
         sh[BK_WAITRES] = res;
         if (res == 2u) sh[BK_PUBLISHED] = 1u;
         sh[BK_IDLE] = sh[BK_IDLE] + spins + 1u;
-        if (res) {  // the arrival block takes them from here
-            sh[SH_ARR_LO] = (uint32_t)fd;
-            sh[SH_ARR_HI] = (uint32_t)(fd >> 32);
-            sh[SH_STATE] = ST_ARRIVED;
-        }
     }
 }
 
@@ -970,6 +973,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
     bool pb_valid = false;
     bool rec_valid = false, rec_written = false;  // the result record in HBM is the one this search would publish now / some record has been written
     bool vs_copied = false;                       // the LDS validity bytes have been copied to HBM since the tree last changed
+    bool verify_req = false;                      // the next round boundary verifies the tree against the areas that were copied since the last verification (BK_FD)
     // shared rounds (helper workgroups)
     unsigned long long* board = A.help_board + (size_t)slot * PDMPC_HB_WORDS;
     uint32_t help_seq = 0;  // rounds shared so far (same value in every thread)
@@ -1322,18 +1326,39 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             status = PDMPC_EXHAUSTED;
             break;
         }
-        // predecessors that finished meanwhile: their areas enter the soup, collision-free edges are re-checked
-        const bool pending = sh_load64(sh, SH_PEND_LO) != 0ull;  // (uniform: written by thread 0 between barriers)
-        if (pending) {
-            if (wave == 0 && sh[SH_STATE] != ST_ARRIVED) (void)bk_poll_predecessors(A, P, sh, 0ull, lane);  // (a waiting search has polled already: bk_wait / bk_wait_done)
+        // Predecessors that finished meanwhile (PrioritizedController.m:476-491).  An arrival is two things.  (1) The COPY: the
+        // predecessor's areas replace its expected ones in the soup — cheap, done here at every round boundary —; from then on edges are
+        // checked against the real areas (the predecessor leaves SH_PEND) and the predecessor is due for (2) the VERIFICATION (BK_FD):
+        // every collision-free edge evaluated before the copy is re-checked against the new areas, parked nodes come back into the
+        // open set.  A finished search that waits (bk_wait_done) copies and checks its plan's path only, and the verification follows
+        // for everybody who has arrived meanwhile; a running search verifies right behind the copy (measured: putting it off until
+        // the search has nothing else to do leaves parked nodes parked and dead subtrees alive — C2's heavy steps 1.35 -> 1.75 ms).
+        if (sh_load64(sh, SH_PEND_LO) != 0ull) {  // (uniform: written by thread 0 between barriers)
+            if (wave == 0 && sh[SH_STATE] != ST_ARRIVED) (void)bk_poll_predecessors(A, P, sh, 0ull, lane);  // (a waiting search has polled already: bk_wait)
             __syncthreads();
+            if (sh[SH_STATE] == ST_ARRIVED) {  // (uniform)
+                const unsigned long long arr = sh_load64(sh, SH_ARR_LO);
+                bk_incorporate(P.out, P.pred, P.l_soup, P.l_soff, P.l_lit, Hp, arr, tid, bd);
+                __syncthreads();
+                if (tid == 0) {
+                    const unsigned long long pend = sh_load64(sh, SH_PEND_LO) & ~arr, fd = sh_load64(sh, BK_FD_LO) | arr;
+                    sh[SH_PEND_LO] = (uint32_t)pend;
+                    sh[SH_PEND_HI] = (uint32_t)(pend >> 32);
+                    sh[BK_FD_LO] = (uint32_t)fd;
+                    sh[BK_FD_HI] = (uint32_t)(fd >> 32);
+                    sh[SH_ARR_LO] = 0;
+                    sh[SH_ARR_HI] = 0;
+                    sh[SH_STATE] = ST_RUN;
+                }
+                __syncthreads();
+                verify_req = true;
+            }
         }
-        if (pending && sh[SH_STATE] == ST_ARRIVED) {
-            const unsigned long long arr = sh_load64(sh, SH_ARR_LO);
+        if (verify_req) {  // (uniform)
+            verify_req = false;
+            const unsigned long long arr = sh_load64(sh, BK_FD_LO);  // everybody whose areas were copied since the last verification
             uint32_t nn = sh[FR_NNODES];
             nn = nn < S.max_nodes ? nn : S.max_nodes;
-            bk_incorporate(P.out, P.pred, P.l_soup, P.l_soff, P.l_lit, Hp, arr & ~sh_load64(sh, BK_FD_LO), tid, bd);  // (what bk_wait_done has let through is in the soup already)
-            __syncthreads();
             // Only collision-free nodes can lose their edge.  Small trees: every node is an item (the others are skipped); trees of more
             // nodes than threads: the collision-free ones (a third of the tree, scattered) are gathered first so that the items are dense
             // — an item is a chain of two dependent reads of the tree, and a lane that walks three or four of them one after the other
@@ -1390,14 +1415,8 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             __syncthreads();
             if (tid == 0) {
                 sh[BK_ARRIVALS] = sh[BK_ARRIVALS] + 1u;  // (reported at the end: a global atomic here sits on every level's hand-over)
-                const unsigned long long pend = sh_load64(sh, SH_PEND_LO) & ~arr;
-                sh[SH_PEND_LO] = (uint32_t)pend;
-                sh[SH_PEND_HI] = (uint32_t)(pend >> 32);
-                sh[SH_ARR_LO] = 0;
-                sh[SH_ARR_HI] = 0;
                 sh[BK_FD_LO] = 0;
                 sh[BK_FD_HI] = 0;
-                sh[SH_STATE] = ST_RUN;
                 sh[BK_NTENT] = 0;
                 sh_st_d(sh, BK_TENT_MIN, inf);
                 if (flags & FRF_INVALIDATED) {
@@ -1500,6 +1519,11 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             done = near_n == 0u && far_n == 0u && n_tent == 0u;
             stalled = near_n == 0u && far_n == 0u && !done;
         }
+        const bool unverified = sh_load64(sh, BK_FD_LO) != 0ull;  // (uniform) areas have been copied since the last verification
+        if (stalled && unverified) {  // the parked nodes are judged against what has arrived
+            verify_req = true;
+            continue;
+        }
         if (stalled) {  // (uniform) wait for a predecessor
             if (bk_wait()) {
                 dep_timeout = true;
@@ -1507,6 +1531,23 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 break;
             }
             BK_TICK(tk_wait)
+            continue;
+        }
+        if (done && unverified && !dep_timeout) {
+            // Finished as far as the verified areas go.  What the successors wait for comes first: the record with the plan's areas (its
+            // counts are rewritten after the verification if that takes edges away), the areas that were copied since against the path,
+            // the done flag if they pass and nobody is outstanding (bk_wait_done without waiting); then the verification.
+            if (!rec_valid && sh[BK_PUBLISHED] == 0u) {
+                if (wave == 0) bk_write_record(A, X, best, best ? PDMPC_OK : PDMPC_EXHAUSTED, false, R.n_popped, R.n_expanded, false, nullptr, rec_written, false, lane);
+                rec_written = true;
+                __syncthreads();  // (the path's areas in LDS: written by the first wave, which is also their reader; the barrier is for the bookkeeping below)
+            }
+            if (wave == 0 && sh[BK_PUBLISHED] == 0u)
+                bk_wait_done(A.done_flag, P.pred, P.out, A.epoch, (uint32_t)slot, P.l_soup, P.l_soff, P.l_lit, (lds_d2*)(X.lsm + A.lds.bk_pshape), sh, Hp, P.n_pred, best != 0u ? 1 : 0,
+                             ticking ? (lds_vu64*)(tk + tk_pub) : (lds_vu64*)nullptr, sh_load64(sh, BK_FD_LO), 0u);
+            __syncthreads();
+            verify_req = true;
+            BK_TICK(tk_arrival)
             continue;
         }
         if (done) {
@@ -1544,7 +1585,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             if (A.bk_fast_arrival && !dep_timeout) {
                 if (wave == 0)
                     bk_wait_done(A.done_flag, P.pred, P.out, A.epoch, (uint32_t)slot, P.l_soup, P.l_soff, P.l_lit, (lds_d2*)(X.lsm + A.lds.bk_pshape), sh, Hp, P.n_pred, best != 0u ? 1 : 0,
-                                 ticking ? (lds_vu64*)(tk + tk_pub) : (lds_vu64*)nullptr);
+                                 ticking ? (lds_vu64*)(tk + tk_pub) : (lds_vu64*)nullptr, 0ull, 4096u);
                 __syncthreads();
                 if (sh[BK_IDLE] > A.spin_limit) dep_timeout = true;
             } else if (bk_wait()) {
