@@ -1,2183 +1,5 @@
-// bulk_kernel.hip — the optimal graph search as bulk-synchronous passes over a round of open nodes.
-//
-// Same closed form of the reference's pop order as frontier_kernel.hip (GraphSearch.m:53-107; see the header of that file and
-// DESIGN.md section 3.2): any processing order gives the reference's result as long as every generated node that comes before
-// the goal G has been evaluated in the end; ids, n_popped and the tree size are counted afterwards (phase B).  What differs is
-// how a round is executed.  The frontier kernel hands one node to one wavefront, which walks the node's dependent chain of LDS
-// round trips alone (ticket, records, shape, three 64-segment passes with a ballot each, sincos, reservation, cost terms,
-// reductions, list appends: 8 000-16 000 cycles per node whatever the arithmetic).  Here a round is a handful of passes in which
-// every LANE has an item of its own and no lane talks to another one until the barrier that ends the pass:
-//
-//   P1  check      item = (ready node, chunk of S obstacle segments): eval_edge_exact (GraphSearch.m:111-196) with InterX
-//                  (InterX.m:63-76, are_constraints_satisfied_interx.m:17-37) restricted to the chunk; a hit sets the node's flag;
-//                  chunk-major order, so later chunks of a node that already collides are skipped (the reference's early out).
-//                  S is chosen per round so that the items fill the workgroup: a young search spreads ONE node's ~130 segments
-//                  over 130 lanes, a round of a thousand nodes runs 16 segments per lane.
-//       + sincos   item = ready node: cos / sin of its yaw (expand_node.m:50-51) into its record, next to the checks
-//   P2  verdicts   item = ready node: validity byte, goal candidates (GraphSearch.m:81-90), children counts; one workgroup scan
-//                  hands out the children's node indices (Tree.m:61: the children of a node are consecutive, ascending trim)
-//   P3  expand     item = (collision-free node, successor slot): expand_node.m:18-90 — pose, cost-to-come, cost-to-go summed in the
-//                  reference's order by the lane itself —, record, key, link, open-list entry
-//   P4  boundary   goal candidates resolved, predecessors that finished meanwhile folded in (PrioritizedController.m:476-491),
-//                  termination test, phase B when done, else selection of the next round: the smallest keys of `near`
-//
-// The open set: `near` lives in LDS (keys + nodes, unordered, up to BK_PER entries per thread so that a selection pass holds it
-// in registers), `far` in HBM takes what near cannot hold (frontier_kernel.hip's scheme, one level up the memory hierarchy).
-// Arithmetic, operation order and -ffp-contract=off are those of the other kernels: every record is bit-identical to the oracle's.
-// Equal keys where the order matters: the search ends with the internal status PDMPC_INTERNAL_TIE and the host plans the call
-// again with the kernel that carries the libstdc++-faithful heap (api.cpp) — no tie in any BASELINE road-network workload.
-#include <hip/hip_runtime.h>
+// bulk_kernel.hip — the product's search kernel for the InterX checker and automata of up to 64 trims (every BASELINE road-network
+// configuration): bulk_search.hpp instantiated with one successor-mask word.
+#include "bulk_search.hpp"
 
-#include "serial_search.hpp"
-
-#include "frontier_common.hpp"
-
-// shared words of the bulk kernel (aliases of words the frontier kernel uses for things this kernel does not have)
-#ifndef PDMPC_BK_CULL
-#define PDMPC_BK_CULL 0
-#endif
-#define BK_P2 3                   // ready entries a thread handles in the verdict pass (the ready list holds at most BK_P2 * blockDim entries)
-#define BK_PER PDMPC_BK_PER       // near entries per thread a selection pass holds in registers (near capacity = BK_PER * blockDim)
-
-namespace {
-
-typedef volatile LDS_AS unsigned long long lds_vu64;
-
-// exclusive prefix of v over the threads of the workgroup (thread order), total to every thread.  Every thread calls; ONE barrier:
-// consecutive calls alternate between two partials arrays (the caller passes them), so the partials of a call are not rewritten
-// before the call after the next — which lies behind at least one more barrier.
-__device__ __forceinline__ unsigned long long wg_scan_excl(unsigned long long v, lds_vu64* wsum, int lane, int wave, int n_waves, unsigned long long& total) {
-    unsigned long long inc = v;
-#pragma unroll
-    for (int o = 1; o < PDMPC_WAVE; o <<= 1) {
-        const unsigned long long t = __shfl_up(inc, o);
-        inc += lane >= o ? t : 0ull;
-    }
-    if (lane == PDMPC_WAVE - 1) wsum[wave] = inc;
-    __syncthreads();
-    unsigned long long off = 0, tot = 0;
-    for (int q = 0; q < n_waves; ++q) {
-        const unsigned long long w = wsum[q];
-        off += q < wave ? w : 0ull;
-        tot += w;
-    }
-    total = tot;
-    return off + inc - v;
-}
-
-// piece q (16 bytes) of node i0's record: LDS copy if it has one
-__device__ __forceinline__ d2 node_piece(const Search& S, uint32_t i0, int q) {
-    if (i0 < S.NL) return S.ln[4 * (size_t)i0 + q];
-    return ((const d2*)(S.gn + i0))[q];
-}
-__device__ __forceinline__ void piece_link(d2 p3, uint32_t& parent, uint32_t& packed) {
-    const uint64_t u = (uint64_t)__double_as_longlong(p3.y);
-    parent = (uint32_t)(u & 0xffffffffull);
-    packed = (uint32_t)(u >> 32);
-}
-
-// What a check item reads.  The same for the owner of a search and for a workgroup that helps it.
-struct BkCheck {
-    const lds_d2* l_area;
-    const d2* g_area;
-    const lds_d2* l_soup;
-    const lds_i32* l_soff;
-    const lds_i32* l_hoff;
-    const lds_i32* l_lit;  // literal soup length per step (the predecessors' slots of VMAX columns each follow)
-    int areas_in_lds, ll_base, ll_len, Hp;
-};
-
-// Tentative areas.  A predecessor that is still planning has its EXPECTED areas in its soup slots: what it publishes should its search
-// be exhausted, i.e. its previous plan shifted by one step (PrioritizedController.m:568-616, 678-718) — where it most likely ends up
-// driving.  An edge that crosses only such areas is neither collision-free nor colliding: its node is parked (VS_TENT) and comes back
-// into the open set when a predecessor arrives.  The result is a function of the final areas alone (every node that comes before
-// the goal ends up evaluated against them); what changes is that the plan found ahead of the arrivals usually survives them.
-#define VS_TENT 6u
-#define BK_TENT_MIN FR_JOIN_MAX  // (64 bit) smallest key among the parked nodes
-#define BK_NTENT FR_SEL2_BIN     // parked nodes
-#define BK_ARRIVALS FR_SEL2_CUM  // arrival events handled by this search
-#define BK_DEPTH FR_RD_HEAD       // deepest collision-free node so far (its step k)
-#define BK_IDLE FR_RD_TAIL        // polls a waiting search has made (the watchdog's count)
-// the mid list's words (words 10-15 of the serial block: the pop-ordered kernel's candidate list, unused by this search)
-#define BK_MID_N 10    // entries of mid
-#define BK_MID_MIN 12  // (64 bit) exact minimum key of mid
-#define BK_L_MID 14    // (64 bit) open entries that leave near, and children beyond near's limit, go to mid up to this key and to far above it (-1: no mid list)
-// the fast arrival path (bk_wait_done; words 16-19 of the serial block: the pop-ordered kernel's mail boxes, unused by this search)
-#define BK_FD_LO 16    // (64 bit) predecessors whose areas are in the soup and have passed the path of the finished plan, but whose re-check of the
-#define BK_FD_HI 17    //          other collision-free nodes is still to come (they stay in SH_PEND until the arrival block has seen them)
-#define BK_WAITRES 18  // result of bk_wait_done: 0 nothing yet, 1 an arrival crosses the path, 2 the last predecessor has passed: published
-#define BK_PUBLISHED 19 // the done flag is out (bk_wait_done): the areas of the record in HBM are final and may be read; only counts and ids may still be written
-
-// copies the expected areas of the predecessors in `who` into their soup slots
-__device__ __forceinline__ void bk_tentative_areas(const KernelArgs& A, const SpecCtx& P, unsigned long long who, int tid, int nthreads) {
-    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
-    const int per = P.Hp * PDMPC_VMAX, n_pred = P.n_pred < 64 ? P.n_pred : 64;
-    for (int idx = tid; idx < n_pred * per; idx += nthreads) {  // (every pending predecessor's loads side by side)
-        const int p = idx / per, rest = idx - p * per;
-        if (!((who >> p) & 1ull)) continue;
-        const DevVehicle* PV = A.veh + P.pred[p];
-        if (PV->fb_off[0] < 0) continue;  // no expectation: its slots stay empty
-        const int k = rest / PDMPC_VMAX, v = rest - k * PDMPC_VMAX;
-        const int a = PV->fb_off[k], b = PV->fb_off[k + 1];
-        const int cols = (b - a < PDMPC_VMAX) ? (b - a) : PDMPC_VMAX;
-        d2 pt;
-        pt.x = v < cols ? A.points[2 * (size_t)(a + (v < cols ? v : 0))] : qnan;
-        pt.y = v < cols ? A.points[2 * (size_t)(a + (v < cols ? v : 0)) + 1] : qnan;
-        P.l_soup[P.l_soff[k] + P.l_lit[k] + p * PDMPC_VMAX + v] = pt;
-    }
-}
-
-// Where a check item finds its node: the owner of a search reads the tree (LDS copies where they exist), a workgroup that helps it
-// reads the 48-byte records the owner has posted for the round (staged in the helper's LDS).
-struct BkTreeSrc {
-    const Search* S;
-    const lds_u32* ready;
-    __device__ __forceinline__ void link(uint32_t r, uint32_t& parent, uint32_t& packed) const { piece_link(node_piece(*S, ready[r] - 1u, 3), parent, packed); }
-    __device__ __forceinline__ void pose(uint32_t, uint32_t parent, double& px, double& py, double& cs, double& sn) const {
-        const d2 pxy = node_piece(*S, parent - 1u, 0), pcs = node_piece(*S, parent - 1u, 2);
-        px = pxy.x;
-        py = pxy.y;
-        cs = pcs.x;
-        sn = pcs.y;
-    }
-};
-struct BkPostSrc {
-    const lds_d2* rec;  // [tile][3]: (x, y) and (cos, sin) of the parent, (parent | packed << 32 as bits, -)
-    __device__ __forceinline__ void link(uint32_t r, uint32_t& parent, uint32_t& packed) const { piece_link(d2{0.0, rec[3 * r + 2].x}, parent, packed); }
-    __device__ __forceinline__ void pose(uint32_t r, uint32_t, double& px, double& py, double& cs, double& sn) const {
-        const d2 pxy = rec[3 * r], pcs = rec[3 * r + 1];
-        px = pxy.x;
-        py = pxy.y;
-        cs = pcs.x;
-        sn = pcs.y;
-    }
-};
-
-// P1, the check items of the entries r0 .. r0 + R - 1: item = c * R + r (chunk-major), chunk c = S = 1 << ls consecutive segments of
-// one of the node's three soups (vehicle obstacles of its step and HDV sets against the area, lanelet boundary against the
-// boundary-check area: are_constraints_satisfied_interx.m:17-37).  chmax = chunks of the step with the most segments.  Lanes work alone.
-template <class Src>
-__device__ __forceinline__ void bk_check_items(const BkCheck& C, const Src& src, volatile lds_u32* r_flag, uint32_t r0, uint32_t R, int ls, uint32_t chmax, unsigned long long pend, int tid, int nthreads) {
-    const uint32_t items = R * chmax;
-    const int Sg = 1 << ls;
-    for (uint32_t item = (uint32_t)tid; item < items; item += (uint32_t)nthreads) {
-        const uint32_t c = item / R, r = r0 + (item - c * R);
-        if (r_flag[r] & 1u) continue;  // collides already: the reference's early out
-        uint32_t parent, packed;
-        src.link(r, parent, packed);
-        if (!parent) continue;  // the root has no edge (GraphSearch.m:137-139)
-        const int k = NODE_K(packed), m = NODE_MAN(packed), ncols = NODE_COLS(packed);
-        const int so = C.l_soff[k - 1], ho = C.l_hoff[k - 1];
-        const int M_k = C.l_soff[k] - so, Hk = C.l_hoff[k] - ho;
-        const int n0 = M_k > 1 ? M_k - 1 : 0, n1 = Hk > 1 ? Hk - 1 : 0, n2 = C.ll_len > 1 ? C.ll_len - 1 : 0;
-        const uint32_t c0 = (uint32_t)((n0 + Sg - 1) >> ls), c1 = (uint32_t)((n1 + Sg - 1) >> ls), c2 = (uint32_t)((n2 + Sg - 1) >> ls);
-        int base, t0, left, which = 0;
-        if (c < c0) {
-            base = so;
-            t0 = (int)(c << ls);
-            left = n0 - t0;
-        } else if (c < c0 + c1) {
-            base = ho;
-            t0 = (int)((c - c0) << ls);
-            left = n1 - t0;
-        } else if (c < c0 + c1 + c2) {
-            base = C.ll_base;
-            t0 = (int)((c - c0 - c1) << ls);
-            left = n2 - t0;
-            which = k == C.Hp ? 2 : 1;  // large offset at k == Hp, else without offset (GraphSearch.m:161-174)
-        } else {
-            continue;
-        }
-        const int tn = left < Sg ? left : Sg;
-        double cc, ss, pX, pY;
-        src.pose(r, parent, pX, pY, cc, ss);
-        const size_t abase = ((size_t)m * 3 + (size_t)which) * PDMPC_VMAX;
-        d2 pt[PDMPC_VMAX];
-#pragma unroll
-        for (int i = 0; i < PDMPC_VMAX; ++i) {  // (columns beyond ncols are padding: transformed, never used)
-            const d2 a = C.areas_in_lds ? (d2)C.l_area[abase + i] : C.g_area[abase + i];
-            pt[i].x = cc * a.x - ss * a.y + pX;  // GraphSearch.m:158 / :162 / :168
-            pt[i].y = ss * a.x + cc * a.y + pY;  // :159 / :163 / :169
-        }
-        const lds_d2* q = C.l_soup + base + t0;
-        d2 q0 = q[0];
-        // (segments of the slots of predecessors that are still planning — `pend` — hold expected areas: a crossing there is tentative)
-        const int rel0 = (which == 0 && base == so) ? t0 - C.l_lit[k - 1] : -(1 << 20);
-        uint32_t found = 0;  // 1: crosses a real area, 2: crosses an expected one
-#if PDMPC_BK_CULL
-        // The exact bounding-box cull, built to be measured (-DPDMPC_BK_CULL=1; off in the product): a segment whose supporting line has
-        // the area's bounding box strictly on one side cannot pass C2 — the expression (y dx2 - x dy2) - S2 is monotone in x and in y
-        // under IEEE rounding, so its extremes over the box are taken at two corners and bound every point's value.  Survivors are
-        // collected in a bit mask first and tested afterwards (a lane-level skip inside the segment loop saves nothing: some lane of
-        // the 64 always needs the full test).  Results identical; C2 / C3 / C4 / C5: 1 040 / 1 003 / 69.6 / 458 steps/s against
-        // 1 067 / 1 031 / 71.3 / 478 without — the corner tests cost what the skipped C2 halves save, the survivors' loop runs as
-        // long as the lane with the most survivors, and eleven more live registers spill.
-        double bx0 = pt[0].x, bx1 = pt[0].x, by0 = pt[0].y, by1 = pt[0].y;
-#pragma unroll
-        for (int i = 1; i < PDMPC_VMAX; ++i) {
-            const bool in = i < ncols;
-            bx0 = (in && pt[i].x < bx0) ? pt[i].x : bx0;
-            bx1 = (in && pt[i].x > bx1) ? pt[i].x : bx1;
-            by0 = (in && pt[i].y < by0) ? pt[i].y : by0;
-            by1 = (in && pt[i].y > by1) ? pt[i].y : by1;
-        }
-        uint32_t surv = 0;
-        {
-            d2 c0 = q0;
-            for (int t = 0; t < tn; ++t) {
-                const d2 c1 = q[t + 1];
-                const double dx2 = c1.x - c0.x, dy2 = c1.y - c0.y;
-                const double S2 = dx2 * c0.y - dy2 * c0.x;
-                const double yhi = dx2 >= 0 ? by1 : by0, ylo = dx2 >= 0 ? by0 : by1;
-                const double xlo = dy2 >= 0 ? bx0 : bx1, xhi = dy2 >= 0 ? bx1 : bx0;
-                const double emax = (yhi * dx2 - xlo * dy2) - S2, emin = (ylo * dx2 - xhi * dy2) - S2;
-                const bool culled = emin > 0 || emax < 0;
-                surv |= culled ? 0u : (1u << t);
-                c0 = c1;
-            }
-        }
-        while (surv && !(found & 1u)) {
-            const int t = __builtin_ctz(surv);
-            surv &= surv - 1u;
-            asm volatile("" : "+v"(pt[0].x), "+v"(pt[0].y), "+v"(pt[1].x), "+v"(pt[1].y), "+v"(pt[2].x), "+v"(pt[2].y), "+v"(pt[3].x), "+v"(pt[3].y), "+v"(pt[4].x), "+v"(pt[4].y),
-                         "+v"(pt[5].x), "+v"(pt[5].y), "+v"(pt[6].x), "+v"(pt[6].y), "+v"(pt[7].x), "+v"(pt[7].y));
-            if (interx_segment_n<PDMPC_VMAX>(pt, ncols - 1, q[t], q[t + 1])) {
-                const int rel = rel0 + t;
-                const bool tent = rel >= 0 && ((pend >> (rel >> 3)) & 1ull) != 0ull;
-                found |= tent ? 2u : 1u;
-            }
-        }
-#else
-        for (int t = 0; t < tn && !(found & 1u); ++t) {
-            // (the area's points are made opaque per segment: the compiler would otherwise hoist the seven edges' dx1, dy1, S1 of the
-            // C1 test out of this loop — 42 registers for a test that one segment in ten reaches)
-            asm volatile("" : "+v"(pt[0].x), "+v"(pt[0].y), "+v"(pt[1].x), "+v"(pt[1].y), "+v"(pt[2].x), "+v"(pt[2].y), "+v"(pt[3].x), "+v"(pt[3].y), "+v"(pt[4].x), "+v"(pt[4].y),
-                         "+v"(pt[5].x), "+v"(pt[5].y), "+v"(pt[6].x), "+v"(pt[6].y), "+v"(pt[7].x), "+v"(pt[7].y));
-            const d2 q1 = q[t + 1];
-            if (interx_segment_n<PDMPC_VMAX>(pt, ncols - 1, q0, q1)) {
-                const int rel = rel0 + t;
-                const bool tent = rel >= 0 && ((pend >> (rel >> 3)) & 1ull) != 0ull;  // (rel >> 3 < 64: a search with more predecessors waits for them all)
-                found |= tent ? 2u : 1u;
-            }
-            q0 = q1;
-        }
-#endif
-        if (found) __hip_atomic_fetch_or((lds_u32*)&r_flag[r], found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-}
-
-// the chunk size (as a shift) with which the check items of R entries fit the workgroup once, at most 16 segments per item
-__device__ __forceinline__ int bk_chunk_shift(const lds_u32* chm, uint32_t R, uint32_t nthreads) {
-    int ls = 0;
-    while (ls < 4 && R * chm[ls] > nthreads) ++ls;
-    return ls;
-}
-
-// position of the rk-th set bit of mask (rk < popcount)
-__device__ __forceinline__ int nth_bit(uint64_t mask, int rk) {
-    for (int b = 0; b < rk; ++b) mask &= mask - 1ull;
-    return (int)__builtin_ctzll(mask);
-}
-
-// Late predecessors (PrioritizedController.m:476-491): the collision-free nodes against the areas of the predecessors in `arr`,
-// which have just entered the soup.  item = (node, arrived predecessor): the edge's area is transformed once, the predecessor's
-// polygon of the node's step goes through interx_segment_n segment by segment (InterX.m:63-76 restricted to those polygons).
-// list == nullptr: the nodes are 0 .. count - 1 themselves (small trees: no gathering pass), the others are skipped.
-__device__ __forceinline__ void bk_recheck_items(const Search& S, const VState& VS, const BkCheck& C, const SpecCtx& P, const lds_u32* list, uint32_t count, unsigned long long arr,
-                                                 volatile lds_u32* sh, int tid, int nthreads) {
-    const uint32_t n_arr = (uint32_t)__builtin_popcountll(arr), items = count * n_arr;
-    for (uint32_t item = (uint32_t)tid; item < items; item += (uint32_t)nthreads) {
-        const uint32_t v = item / n_arr, a = item - v * n_arr;
-        const uint32_t i0 = list ? list[v] : v;
-        if (vs_load(VS, i0) != VS_VALID) continue;
-        uint32_t parent, packed;
-        piece_link(node_piece(S, i0, 3), parent, packed);
-        if (!parent) continue;
-        const int p = nth_bit(arr, (int)a);
-        const int k = NODE_K(packed), m = NODE_MAN(packed), ncols = NODE_COLS(packed);
-        const d2 pxy = node_piece(S, parent - 1u, 0), pcs = node_piece(S, parent - 1u, 2);
-        const double cc = pcs.x, ss = pcs.y, pX = pxy.x, pY = pxy.y;
-        const size_t abase = (size_t)m * 3 * PDMPC_VMAX;
-        d2 pt[PDMPC_VMAX];
-#pragma unroll
-        for (int i = 0; i < PDMPC_VMAX; ++i) {
-            const d2 ar = C.areas_in_lds ? (d2)C.l_area[abase + i] : C.g_area[abase + i];
-            pt[i].x = cc * ar.x - ss * ar.y + pX;  // GraphSearch.m:158
-            pt[i].y = ss * ar.x + cc * ar.y + pY;  // :159
-        }
-        const lds_d2* poly = P.l_soup + P.l_soff[k - 1] + P.l_lit[k - 1] + p * PDMPC_VMAX;
-        d2 q0 = poly[0];
-        bool hit = false;
-#pragma unroll 1
-        for (int j = 0; j + 1 < PDMPC_VMAX; ++j) {
-            asm volatile("" : "+v"(pt[0].x), "+v"(pt[0].y), "+v"(pt[1].x), "+v"(pt[1].y), "+v"(pt[2].x), "+v"(pt[2].y), "+v"(pt[3].x), "+v"(pt[3].y), "+v"(pt[4].x), "+v"(pt[4].y),
-                         "+v"(pt[5].x), "+v"(pt[5].y), "+v"(pt[6].x), "+v"(pt[6].y), "+v"(pt[7].x), "+v"(pt[7].y));  // (as in bk_check_items)
-            const d2 q1 = poly[j + 1];
-            hit = hit || interx_segment_n<PDMPC_VMAX>(pt, ncols - 1, q0, q1);
-            q0 = q1;
-        }
-        if (hit) {
-            vs_store(VS, i0, VS_INVALID);
-            atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_INVALIDATED);
-        }
-    }
-}
-
-// monotone map key -> bin of a linear histogram of BK_NB bins over [lo, lo + BK_NB / scale)
-#define BK_NB 256
-__device__ __forceinline__ uint32_t bk_bin(double key, double lo, double scale) {
-    const double t = (key - lo) * scale;
-    if (!(t > 0.0)) return 0u;
-    return t < (double)(BK_NB - 1) ? (uint32_t)t : (uint32_t)(BK_NB - 1);
-}
-// The first bin at which the cumulative count of the BK_NB-bin histogram reaches `target` (the last non-empty bin if the total is
-// smaller) and that count.  Every lane of a wave calls (four bins per lane); every wave of the workgroup does it for itself, so
-// the result needs no broadcast through LDS and no barrier.
-__device__ __forceinline__ void bk_select(const lds_u32* bins, uint32_t target, int lane, uint32_t& bin, uint32_t& cum) {
-    uint32_t hq[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) hq[q] = bins[4 * lane + q];
-    const uint32_t loc = hq[0] + hq[1] + hq[2] + hq[3];
-    uint32_t inc = loc;
-#pragma unroll
-    for (int o = 1; o < PDMPC_WAVE; o <<= 1) {
-        const uint32_t v = (uint32_t)__shfl_up((int)inc, o);
-        inc += lane >= o ? v : 0u;
-    }
-    const uint32_t total = lane_u(inc, PDMPC_WAVE - 1);
-    const uint32_t want = target < total ? target : total;
-    uint32_t c = inc - loc, b = 0, cu = 0;
-    bool f = false;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        c += hq[q];
-        const bool hit = !f && hq[q] != 0u && c >= want;
-        b = hit ? (uint32_t)(4 * lane + q) : b;
-        cu = hit ? c : cu;
-        f = f || hit;
-    }
-    const unsigned long long m = __ballot(f);
-    const int l = m ? (int)__builtin_ctzll(m) : 0;
-    const uint32_t bb = lane_u(b, l), cc = lane_u(cu, l);
-    bin = m ? bb : 0u;
-    cum = m ? cc : 0u;
-}
-
-// The areas of a result record and their column counts — all a successor reads of it (PrioritizedController.m:476-491) — go to memory
-// with agent-scope stores and are read with agent-scope loads: coherent across the XCDs' L2s by themselves.  PDMPC_BK_AREA_FENCES=1
-// (build switch) puts the release / acquire fences of rounds 2-4 back around them (a write-back / invalidation of the whole L2).
-#ifndef PDMPC_BK_AREA_FENCES
-#define PDMPC_BK_AREA_FENCES 0
-#endif
-__device__ __forceinline__ void bk_area_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void bk_area_store_u32(int32_t* p, int v) { __hip_atomic_store(p, (int32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ double bk_area_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ int bk_area_load_i32(const int32_t* p) { return (int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// The result record (GraphSearch.m:58-59, 82-89; return_path_to.m; return_path_area.m), written by the first wave.  A search that
-// has finished while predecessors are still planning writes it right away: an arrival that invalidates nothing leaves it as it
-// is, and the publication that follows the last arrival is one flag.  `again`: a record of this search was written before
-// (its fields are reset first).  l_path[i] = node (1-based index into this vehicle's arena) of step i along the selected path
-// (walked here unless path_ready); ref_ids = the ids those nodes carry in the reference's tree (info.tree_path).
-__device__ __forceinline__ void bk_write_record(const KernelArgs& A, Ctx& X, uint32_t goal, int status, bool dep_timeout, uint32_t n_popped, uint32_t nnodes, bool path_ready,
-                                                const lds_u32* ref_ids, bool again, bool counts_only, int lane) {
-    const int Hp = X.Hp;
-    const DevVehicle* __restrict__ V = X.V;
-    pdmpc_vehicle_out* __restrict__ O = X.O;
-    lds_u32* l_path = X.l_path;
-    const Search& S = X.S;
-    if (counts_only) {
-        // The areas of this record are out already (the done flag was set when the last predecessor's areas had passed the path,
-        // bk_wait_done) and successors may be reading them: only what the re-check of the other nodes can still change is written
-        // — the reference's ids along the path and the two counts (the path itself is the one that was published).
-        if (goal && ref_ids && lane <= Hp) O->tree_path[lane] = (int32_t)ref_ids[lane];
-        if (lane == 0) {
-            O->status = dep_timeout ? PDMPC_ERR_HIP : status;
-            O->n_expanded = (int32_t)nnodes;
-            O->n_popped = (int32_t)n_popped;
-        }
-        return;
-    }
-    lds_d2* pshape = (lds_d2*)(X.lsm + A.lds.bk_pshape);
-    lds_u32* pcols = (lds_u32*)(pshape + Hp * PDMPC_VMAX);
-    if (again) {  // as the prologue left it: zeros, y_predicted NaN (ControlResultsInfo.m:40)
-        double* od = (double*)O;
-        const int nd = (int)(offsetof(pdmpc_vehicle_out, path_nodes) / 8) + (Hp + 1) * 8;  // (rows beyond the path are never written here: the diagnostics of the tail stay)
-        const int y0 = (int)(offsetof(pdmpc_vehicle_out, y_predicted) / 8);
-        const double qnan = __longlong_as_double(0x7ff8000000000000LL);
-        for (int i = lane; i < nd; i += PDMPC_WAVE) od[i] = (i >= y0 && i < y0 + PDMPC_HP_MAX * 3) ? qnan : 0.0;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the result stores below hit the same bytes from other lanes
-    }
-    if (goal) {
-        if (lane == 0 && !path_ready) {  // path_to_root (Tree.m:44-52), reversed
-            uint32_t nd = goal;
-            for (int i = Hp; i >= 0; --i) {
-                l_path[i] = nd;
-                nd = node_parent(S, nd - 1);
-            }
-        }
-        wave_sync();
-        if (lane <= Hp) {
-            const uint32_t nd = l_path[lane];
-            const NodeRec r = node_load(S, nd - 1);
-            O->tree_path[lane] = (int32_t)(ref_ids ? ref_ids[lane] : nd);
-            double* row = O->path_nodes[lane];  // NodeInfo.m:5-13
-            row[0] = r.x;
-            row[1] = r.y;
-            row[2] = r.yaw;
-            row[3] = (double)NODE_TRIM(r.packed);
-            row[4] = r.g;
-            row[5] = r.h;
-            row[6] = (double)NODE_K(r.packed);
-            row[7] = 1.0;
-            if (lane >= 1) {
-                O->y_predicted[lane - 1][0] = r.x;
-                O->y_predicted[lane - 1][1] = r.y;
-                O->y_predicted[lane - 1][2] = r.yaw;
-                O->predicted_trims[lane - 1] = (int32_t)NODE_TRIM(r.packed);
-            }
-        }
-        // shapes along the path: same arithmetic as at pop time (GraphSearch.m:158-160), so the same bits
-        for (int idx = lane; idx < Hp * PDMPC_VMAX; idx += PDMPC_WAVE) {
-            const int i = idx / PDMPC_VMAX + 1;
-            const int v = idx - (i - 1) * PDMPC_VMAX;
-            const NodeRec pr = node_load(S, l_path[i - 1] - 1);
-            const NodeRec cr = node_load(S, l_path[i] - 1);
-            const int m = NODE_MAN(cr.packed);
-            const int ncols = NODE_COLS(cr.packed);
-            // (the areas and their column counts are what successors read, bk_area_load: stores that go through to memory, so that
-            // the publication needs no write-back of this XCD's L2)
-            if (v == 0) {
-                bk_area_store_u32(&O->shape_cols[i - 1], ncols);
-                pcols[i - 1] = (uint32_t)ncols;
-            }
-            d2 sp = d2{0.0, 0.0};
-            if (v < ncols) {
-                const d2 a = X.C.g_area[(size_t)m * 3 * PDMPC_VMAX + v];
-                sp.x = pr.cs * a.x - pr.sn * a.y + pr.x;
-                sp.y = pr.sn * a.x + pr.cs * a.y + pr.y;
-                bk_area_store(&O->shapes[i - 1][0][v], sp.x);
-                bk_area_store(&O->shapes[i - 1][1][v], sp.y);
-            }
-            pshape[idx] = sp;  // (columns beyond ncols are padding: read, never used)
-        }
-    } else if (V->fb_off[0] >= 0) {
-        // exhausted: publish the caller-supplied fallback areas so successors of this launch avoid them (PrioritizedController.m:568-616, 678-718)
-        for (int idx = lane; idx < Hp * PDMPC_VMAX; idx += PDMPC_WAVE) {
-            const int k = idx / PDMPC_VMAX;
-            const int v = idx - k * PDMPC_VMAX;
-            const int a = V->fb_off[k], b = V->fb_off[k + 1];
-            const int cols = (b - a < PDMPC_VMAX) ? (b - a) : PDMPC_VMAX;
-            if (v == 0) bk_area_store_u32(&O->shape_cols[k], cols);
-            if (v < cols) {
-                bk_area_store(&O->shapes[k][0][v], A.points[2 * (size_t)(a + v)]);
-                bk_area_store(&O->shapes[k][1][v], A.points[2 * (size_t)(a + v) + 1]);
-            }
-        }
-    }
-    if (lane == 0) {
-        O->status = dep_timeout ? PDMPC_ERR_HIP : status;
-        O->n_expanded = (int32_t)nnodes;
-        O->n_popped = (int32_t)n_popped;
-        O->n_hp = Hp;
-    }
-}
-
-// Publication: plain stores -> this wave's vmcnt(0) -> lane-0 agent release -> flag.  First wave.
-// (the areas were stored through to memory, bk_area_store: what the flag announces is there once this wave's stores have been
-// acknowledged; the rest of the record is read by the host, after the kernel)
-__device__ __forceinline__ void bk_publish_flag(const KernelArgs& A, int slot, int lane) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    wave_sync();
-    if (lane == 0) {
-#if PDMPC_BK_AREA_FENCES
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        __hip_atomic_store(A.done_flag + slot, A.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-__device__ __forceinline__ void bk_publish(const KernelArgs& A, const Ctx& X, int status, bool dep_timeout) {
-    if (X.lane == 0 && (dep_timeout || (status != PDMPC_OK && status != PDMPC_EXHAUSTED))) atomicAdd(A.work_count + 6, 1ull);  // (device-side tally of plans that are not planning results)
-    bk_publish_flag(A, X.slot, X.lane);
-}
-
-// One look at the done flags of the predecessors in `want` (poll_predecessors without its bookkeeping): the set that has finished.
-// Whole wave calls.
-__device__ __forceinline__ unsigned long long bk_poll_flags(const KernelArgs& A, const SpecCtx& P, unsigned long long want, int lane) {
-    bool d = false;
-    if ((want >> lane) & 1ull) d = __hip_atomic_load(A.done_flag + P.pred[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == A.epoch;
-    const unsigned long long got = __ballot(d);
-#if PDMPC_BK_AREA_FENCES
-    if (got) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-#endif
-    return got;
-}
-
-// poll_predecessors on bk_poll_flags: the pending predecessors that have finished are posted in SH_ARR and the state goes
-// ST_RUN -> ST_ARRIVED.  Whole wave calls.
-__device__ __forceinline__ bool bk_poll_predecessors(const KernelArgs& A, const SpecCtx& P, volatile lds_u32* sh, unsigned long long skip, int lane) {
-    const unsigned long long pend = sh_load64(sh, SH_PEND_LO) & ~skip;
-    if (!pend) return false;
-    const unsigned long long got = bk_poll_flags(A, P, pend, lane);
-    if (!got) return false;
-    if (lane == 0) {
-        sh[SH_ARR_LO] = (uint32_t)got;
-        sh[SH_ARR_HI] = (uint32_t)(got >> 32);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        atomicCAS((uint32_t*)&sh[SH_STATE], ST_RUN, ST_ARRIVED);
-    }
-    return true;
-}
-
-// incorporate_areas with loads that are coherent by themselves (bk_area_load): the solved areas of the predecessors in `arr` into
-// their soup slots (PrioritizedController.m:476-491); nthreads threads call (a workgroup, or one wave).  Out of line with scalar
-// arguments (see bk_wait_done).
-__device__ __forceinline__ void bk_incorporate_body(const pdmpc_vehicle_out* out, const int32_t* pred, lds_d2* l_soup, const lds_i32* l_soff, const lds_i32* l_lit, int Hp, unsigned long long arr, int tid,
-                                                    int nthreads) {
-    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
-    const int per = Hp * PDMPC_VMAX, n_arr = __builtin_popcountll(arr);
-    for (int idx = tid; idx < n_arr * per; idx += nthreads) {  // (every arrived predecessor's loads side by side)
-        const int a = idx / per, rest = idx - a * per;
-        const int p = nth_bit(arr, a);
-        const pdmpc_vehicle_out* PO = out + pred[p];
-        const int k = rest / PDMPC_VMAX, v = rest - k * PDMPC_VMAX;
-        const int cols = bk_area_load_i32(&PO->shape_cols[k]);
-        const double sx = bk_area_load(&PO->shapes[k][0][v]), sy = bk_area_load(&PO->shapes[k][1][v]);
-        d2 pt;
-        pt.x = v < cols ? sx : qnan;
-        pt.y = v < cols ? sy : qnan;
-        l_soup[l_soff[k] + l_lit[k] + p * PDMPC_VMAX + v] = pt;
-    }
-}
-__device__ __noinline__ void bk_incorporate(const pdmpc_vehicle_out* out_, const int32_t* pred_, lds_d2* l_soup_, const lds_i32* l_soff_, const lds_i32* l_lit_, int Hp_, unsigned long long arr_, int tid,
-                                            int nthreads_) {
-    auto uptr = [](const void* p) -> uint64_t {
-        const uint64_t u = (uint64_t)p;
-        return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
-    };
-    bk_incorporate_body((const pdmpc_vehicle_out*)uptr(out_), (const int32_t*)uptr(pred_), (lds_d2*)(uintptr_t)uni_u((uint32_t)(uintptr_t)l_soup_), (const lds_i32*)(uintptr_t)uni_u((uint32_t)(uintptr_t)l_soff_),
-                        (const lds_i32*)(uintptr_t)uni_u((uint32_t)(uintptr_t)l_lit_), uni_i(Hp_), (unsigned long long)uptr((const void*)arr_), tid, uni_i(nthreads_));
-}
-
-// fr_check_wave with a memory: what to do with an open node a round has selected (1 process it, 3 it comes after the goal candidate,
-// 4 one of its ancestors lost its edge to late areas), one node per lane, a = 0: none.
-// The answer follows from the branch between the node and the candidate's path — where it joins the path (depth dJ), the largest key on
-// it (M), whether a node on it is invalid — and a child's branch is its parent's plus itself.  Every processed node leaves these three
-// in walk[] (16 bytes per node), stamped with the candidate and the number of arrival events they hold for; a node whose parent carries
-// a current stamp is classified with two reads instead of a walk to the path (up to Hp dependent reads of three arrays each, which for a
-// heavy search with a candidate cost as much as a third of its checks: C4).  Nodes whose parents were processed under another
-// candidate, or before the last arrival, walk as before and leave their own stamp.
-#define WC_DEAD 0x100u
-#define WC_ONPATH 0x200u
-#define WC_VALID 0x400u
-__device__ int bk_classify_wave(const unsigned long long* glink, ulonglong2* walk, const VState& VS, const double* gkey, const lds_u32* gp_path, const lds_f64* gp_mp, bool have_goal,
-                                bool check_alive, uint32_t best, uint32_t epoch, uint32_t a, double ka, volatile lds_u32* sh) {
-    const uint32_t a0 = a ? a : 1u;
-    const uint64_t ua = glink[a0 - 1u];
-    const uint32_t p = (uint32_t)(ua & 0xffffffffull);
-    const int k = NODE_K((uint32_t)(ua >> 32));
-    const bool onp = have_goal && gp_path[k] == a0;
-    const ulonglong2 c = walk[p ? p - 1u : 0u];
-    const uint32_t ctag = (uint32_t)(c.y & 0xffffffffull), cinfo = (uint32_t)(c.y >> 32);
-    const bool hit = p != 0u && ctag == best && (cinfo & (WC_VALID | 0xffff0000u)) == (WC_VALID | (epoch << 16));
-    double M = -1.0;
-    int dJ = k;
-    bool dead = false;
-    // ---- no current stamp at the parent: the walk (the whole wave together, see fr_check_wave)
-    int st = (a == 0u || onp || hit) ? 1 : 0;  // 0: still walking
-    uint32_t x = a0;
-    while (__ballot(st == 0)) {
-        const uint32_t i = x - 1u;
-        const uint64_t u = glink[i];
-        const int d = NODE_K((uint32_t)(u >> 32));
-        const bool on_path = have_goal && gp_path[d] == x;
-        const bool bad = !on_path && x != a0 && check_alive && vs_load(VS, i) != VS_VALID;
-        const double kx = gkey[i];
-        const uint32_t par = (uint32_t)(u & 0xffffffffull);
-        const bool walking = st == 0;
-        const bool stop = on_path || bad || par == 0u;
-        dJ = (walking && on_path) ? d : dJ;
-        dead = dead || (walking && bad);
-        M = (walking && !on_path && !bad && kx > M) ? kx : M;  // (the nodes below the path: a itself, then its ancestors)
-        st = (walking && stop) ? 1 : st;
-        x = (walking && !stop) ? par : x;
-    }
-    if (hit && !onp) {
-        const bool p_on = (cinfo & WC_ONPATH) != 0u;
-        const double pM = __longlong_as_double((long long)c.x);
-        const uint32_t vsp = check_alive && !p_on ? vs_load(VS, p - 1u) : (uint32_t)VS_VALID;
-        dead = !p_on && ((cinfo & WC_DEAD) != 0u || vsp != VS_VALID);
-        M = (!p_on && pM > ka) ? pM : ka;
-        dJ = (int)(cinfo & 0xffu);
-    }
-    // (a node on the path: its children join the path at it)
-    const double thr = gp_mp[dJ];
-    int res = 1;
-    if (a != 0u && !onp) {
-        res = dead ? 4 : ((have_goal && !(M < thr)) ? 3 : 1);
-        if (!dead && have_goal && M == thr) atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_TIE);
-    }
-    if (a != 0u && res == 1) {  // (it will be processed: its children look here)
-        ulonglong2 w;
-        w.x = (unsigned long long)__double_as_longlong(onp ? -1.0 : M);
-        w.y = (unsigned long long)best | ((unsigned long long)((uint32_t)(onp ? k : dJ) | (onp ? WC_ONPATH : 0u) | WC_VALID | (epoch << 16)) << 32);
-        walk[a0 - 1u] = w;
-    }
-    return res;
-}
-
-// A FINISHED search waiting for its predecessors (its record is written, bk_write_record; the areas along its path are in LDS).
-// What its successors wait for are its areas, and those are final as soon as every predecessor's areas have passed the path: nothing
-// open or parked comes before the goal (that is what finished means), and an arrival can only take edges away.  So the first wave
-// alone — no workgroup barrier — polls, copies an arrived predecessor's areas into the soup, checks them against the Hp edges of
-// the path (the arithmetic of bk_recheck_items on the same numbers) and sets the done flag when the last predecessor has passed.
-// The verification of the other collision-free nodes, which can only change the counts and ids of the record, follows at the next
-// round boundary for all of them at once (BK_FD: who is due).  A predecessor that crosses the path ends the wait: the verification
-// takes the path's edge away and the search resumes.  `first`: predecessors whose areas are in the soup already but have not been
-// checked against this path (copied while the search was running); max_spins 0: look at them and at the flags once, do not wait.
-// Leaves BK_WAITRES (0 nothing decided, 1 an arrival crosses the path, 2 published), SH_PEND and BK_FD.
-// Out of line on purpose (scalar arguments, one wavefront, once per wait): inlined, its registers push the search loop beyond the
-// 168 VGPRs of a twelve-wavefront workgroup (tests/test_build.py watches this).
-__device__ __noinline__ void bk_wait_done(const uint32_t* done_flag_, const int32_t* pred_, const pdmpc_vehicle_out* out_, uint32_t epoch_, uint32_t slot_, lds_d2* l_soup_, const lds_i32* l_soff_,
-                                          const lds_i32* l_lit_, lds_d2* pshape_, volatile lds_u32* sh_, int Hp_, int n_pred_, int have_path_, lds_vu64* tk_pub_, unsigned long long first_, uint32_t max_spins_) {
-    // (arguments of an out-of-line function arrive in vector registers: uniform again from here)
-    auto uptr = [](const void* p) -> uint64_t {
-        const uint64_t u = (uint64_t)p;
-        return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
-    };
-    const uint32_t* done_flag = (const uint32_t*)uptr(done_flag_);
-    const int32_t* pred = (const int32_t*)uptr(pred_);
-    const pdmpc_vehicle_out* out = (const pdmpc_vehicle_out*)uptr(out_);
-    const uint32_t epoch = uni_u(epoch_), slot = uni_u(slot_), max_spins = uni_u(max_spins_);
-    lds_d2* l_soup = (lds_d2*)(uintptr_t)uni_u((uint32_t)(uintptr_t)l_soup_);
-    const lds_i32* l_soff = (const lds_i32*)(uintptr_t)uni_u((uint32_t)(uintptr_t)l_soff_);
-    const lds_i32* l_lit = (const lds_i32*)(uintptr_t)uni_u((uint32_t)(uintptr_t)l_lit_);
-    lds_d2* pshape = (lds_d2*)(uintptr_t)uni_u((uint32_t)(uintptr_t)pshape_);
-    volatile lds_u32* sh = (volatile lds_u32*)(uintptr_t)uni_u((uint32_t)(uintptr_t)sh_);
-    lds_vu64* tk_pub = (lds_vu64*)(uintptr_t)uni_u((uint32_t)(uintptr_t)tk_pub_);
-    const int Hp = uni_i(Hp_), n_pred = uni_i(n_pred_);
-    const bool have_path = uni_i(have_path_) != 0;
-    const int lane = (int)(threadIdx.x & (PDMPC_WAVE - 1));
-    const lds_u32* pcols = (const lds_u32*)(pshape + Hp * PDMPC_VMAX);
-    unsigned long long pend = sh_load64(sh, SH_PEND_LO), fd = sh_load64(sh, BK_FD_LO);
-    unsigned long long got = (unsigned long long)uptr((const void*)first_);  // (in the soup already: checked against the path before anybody is polled)
-    uint32_t spins = 0, res = 0;
-    for (;;) {
-        if (!got) {  // (uniform)
-            bool d = false;
-            if (lane < n_pred && ((pend >> lane) & 1ull)) d = __hip_atomic_load(done_flag + pred[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
-            got = __ballot(d);
-            if (!got) {
-                if (++spins >= max_spins) break;
-                __builtin_amdgcn_s_sleep(1);
-                continue;
-            }
-#if PDMPC_BK_AREA_FENCES
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-            bk_incorporate_body(out, pred, l_soup, l_soff, l_lit, Hp, got, lane, PDMPC_WAVE);
-            wave_sync();
-            pend &= ~got;
-            fd |= got;
-        }
-        const int n_got = __builtin_popcountll(got);
-        const int per = Hp * (PDMPC_VMAX - 1), items = have_path ? n_got * per : 0;
-        bool hit = false;
-        for (int base = 0; base < items; base += PDMPC_WAVE) {  // (uniform trip count; item = (arrived predecessor, step, segment of its area))
-            const int item = base + lane;
-            const bool in = item < items;
-            const int it = in ? item : 0;
-            const int a = it / per, rest = it - a * per;
-            const int k0 = rest / (PDMPC_VMAX - 1), j = rest - k0 * (PDMPC_VMAX - 1);
-            const int p = nth_bit(got, a);
-            d2 pt[PDMPC_VMAX];
-#pragma unroll
-            for (int i = 0; i < PDMPC_VMAX; ++i) pt[i] = pshape[k0 * PDMPC_VMAX + i];
-            const lds_d2* poly = l_soup + l_soff[k0] + l_lit[k0] + p * PDMPC_VMAX;
-            const bool h1 = interx_segment_n<PDMPC_VMAX>(pt, (int)pcols[k0] - 1, poly[j], poly[j + 1]);
-            hit = hit || (in && h1);
-        }
-        got = 0ull;
-        if (__ballot(hit)) {  // (uniform)
-            res = 1;
-            break;
-        }
-        if (pend == 0ull) {
-            res = 2;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            wave_sync();
-            if (lane == 0) {
-#if PDMPC_BK_AREA_FENCES
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-                __hip_atomic_store((uint32_t*)done_flag + slot, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (tk_pub) *tk_pub = __builtin_amdgcn_s_memrealtime();
-            }
-            break;
-        }
-        if (max_spins == 0u) break;
-    }
-    if (lane == 0) {
-        sh[SH_PEND_LO] = (uint32_t)pend;
-        sh[SH_PEND_HI] = (uint32_t)(pend >> 32);
-        sh[BK_FD_LO] = (uint32_t)fd;
-        sh[BK_FD_HI] = (uint32_t)(fd >> 32);
-        sh[BK_WAITRES] = res;
-        if (res == 2u) sh[BK_PUBLISHED] = 1u;
-        sh[BK_IDLE] = sh[BK_IDLE] + spins + 1u;
-    }
-}
-
-// The far-list selection stays an out-of-line call: it runs once per refill on one wavefront, and inlined into the search loop its
-// registers push the whole kernel over the 168-VGPR budget of a twelve-wavefront workgroup (tests/test_build.py watches this).
-__device__ __noinline__ void bk_far_select(const Frontier& F, uint32_t fill, int lane) {
-    fr_select2(F, fill, fill, FR_SEL_BIN, FR_SEL_BIN, lane);
-}
-
-// The search.  Returns true (to every thread) if a tie was met: the host plans the call again with the heap-carrying kernel.
-template <int NW>
-__device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32* ref_ids) {
-    const int tid = X.tid, lane = X.lane, wave = X.wave, slot = X.slot, Hp = X.Hp;
-    volatile lds_u32* sh = X.l_shared;
-    Search& S = X.S;
-    const VState& VS = X.VS;
-    const SpecCtx& P = X.P;
-    const DevVehicle* __restrict__ V = X.V;
-    const int n_waves = (int)(blockDim.x >> 6), bd = (int)blockDim.x;
-    const double inf = __longlong_as_double(0x7FF0000000000000LL);
-    const size_t voff = (size_t)slot * A.max_nodes;
-    const int n = X.n, nw = NW > 0 ? NW : X.nw;
-    const uint32_t OC = (uint32_t)(BK_PER * bd), RC = (uint32_t)A.bk_ready_cap;
-    const uint32_t VCAP = 1024u;  // expansion groups per tile (vlist / voffs)
-    const uint32_t TILE = (uint32_t)A.bk_tile;  // entries of a tile of a shared round (what a helper workgroup claims at a time)
-
-    // ---- LDS carve of the bulk region
-    lds_f64* near_key = (lds_f64*)(X.lsm + A.lds.bk_near_key);
-    lds_u32* near_id = (lds_u32*)(X.lsm + A.lds.bk_near_id);
-    lds_u32* ready = (lds_u32*)(X.lsm + A.lds.bk_ready);
-    volatile lds_u32* r_flag = (volatile lds_u32*)(ready + RC);
-    lds_u32* hist = (lds_u32*)(X.lsm + A.lds.bk_hist);      // [3072]: refill histogram [2048] | goal list [1024], expansion groups [1024], their children's offsets [1024]
-    lds_u32* vlist = hist + 1024;
-    lds_u32* voffs = hist + 2048;
-    lds_u32* gp_path = (lds_u32*)(X.lsm + A.lds.bk_misc);    // [32] path of the best goal candidate
-    lds_f64* gp_mp = (lds_f64*)(gp_path + 32);                // [HP_MAX + 1] largest key of that path below depth d
-    lds_vu64* wsum64 = (lds_vu64*)(gp_mp + 32);                // [32] scan partials
-    volatile lds_u32* wsum = (volatile lds_u32*)(wsum64 + 32); // [32] fr_partition's per-wave counts
-    lds_u32* chm = (lds_u32*)(wsum + 32);                      // [8] chunks per node for S = 1, 2, 4, 8, 16, ...
-    lds_u32* bins = gp_path + 256;                             // [BK_NB] the selection's histogram (second KB of the region)
-
-    Frontier F;
-    F.sh = sh;
-    F.ready = ready;
-    F.hist = hist;
-    F.goal_list = hist;
-    F.near_key = A.arena.near_key + voff;  // (HBM arrays: phase B's per-node state; near itself lives in LDS)
-    F.near_id = A.arena.near_id + voff;
-    F.far_key = A.arena.pop_log + voff;
-    F.far_id = A.arena.heap_id + voff;
-    F.gkey = S.gkey;
-    F.glink = A.arena.link + voff;
-    F.n_waves = n_waves;
-
-    ExpandEnv EE;
-    EE.l_mask = X.l_mask;
-    EE.l_mi = X.l_mi;
-    EE.l_pose = X.l_pose;
-    EE.l_rx = X.l_rx;
-    EE.l_ry = X.l_ry;
-    EE.l_dcum = X.l_dcum;
-    EE.l_term = nullptr;
-    EE.l_chxy = nullptr;
-    EE.Hp = Hp;
-    EE.n = X.n;
-    EE.nw = X.nw;
-    EE.lane = lane;
-
-    BkCheck CK;
-    CK.l_area = X.C.l_area;
-    CK.g_area = X.C.g_area;
-    CK.l_soup = X.C.l_soup;
-    CK.l_soff = X.C.l_soff;
-    CK.l_hoff = X.C.l_hoff;
-    CK.l_lit = P.l_lit;
-    CK.areas_in_lds = X.C.areas_in_lds;
-    CK.ll_base = X.C.ll_base;
-    CK.ll_len = X.C.ll_len;
-    CK.Hp = Hp;
-
-    // ---- root node (GraphSearch.m:34-46) and the chunk tables
-    if (tid == 0) {
-        NodeRec r;
-        r.x = V->x0;
-        r.y = V->y0;
-        r.yaw = V->yaw0;
-        r.g = 0.0;
-        r.cs = 0.0;
-        r.sn = 0.0;
-        r.h = 0.0;
-        r.parent = 0;
-        r.packed = (uint32_t)V->trim0;
-        node_store(S, 0, r);
-        F.gkey[0] = 0.0;
-        F.glink[0] = (unsigned long long)r.parent | ((unsigned long long)r.packed << 32);
-        ((ulonglong2*)A.arena.walk + voff)[0].y = 0ull;
-        vs_store(VS, 0, VS_UNKNOWN);
-        for (int w = 26; w < SH_WORDS; ++w) sh[w] = 0;
-        sh[FR_NNODES] = 1;
-        sh_st_d(sh, FR_NEAR_MIN, inf);
-        sh_st_d(sh, FR_FAR_MIN, inf);
-        sh_st_d(sh, FR_L_FAR, inf);
-        sh_st_d(sh, BK_TENT_MIN, inf);
-        sh[BK_MID_N] = 0;
-        sh[BK_MID_N + 1] = 0;
-        sh_st_d(sh, BK_MID_MIN, inf);
-        sh_st_d(sh, BK_L_MID, -1.0);
-        sh[SH_NNODES] = 1;
-        if (A.debug_tail == 2) sh[FR_EVER_INVAL] = 1;  // (debugging: exercise the ancestor check without arrivals)
-        ready[0] = 1u;
-        r_flag[0] = 0u;
-    }
-    if (tid < BK_NB) bins[tid] = 0u;
-    if (A.bk_tentative) bk_tentative_areas(A, P, sh_load64(sh, SH_PEND_LO), tid, (int)blockDim.x);  // (the pending set was fixed by the prologue)
-    if (tid >= 64 && tid < 72) {
-        const int ls = tid - 64;
-        uint32_t mx = 0;
-        for (int k = 1; k <= Hp; ++k) {
-            const int M_k = CK.l_soff[k] - CK.l_soff[k - 1], Hk = CK.l_hoff[k] - CK.l_hoff[k - 1];
-            const int n0 = M_k > 1 ? M_k - 1 : 0, n1 = Hk > 1 ? Hk - 1 : 0, n2 = CK.ll_len > 1 ? CK.ll_len - 1 : 0;
-            const int Sg = 1 << ls;
-            const uint32_t ch = (uint32_t)(((n0 + Sg - 1) >> ls) + ((n1 + Sg - 1) >> ls) + ((n2 + Sg - 1) >> ls));
-            mx = ch > mx ? ch : mx;
-        }
-        chm[ls] = mx;
-    }
-    __syncthreads();
-
-    int status = PDMPC_OK;
-    bool dep_timeout = X.dep_timeout;
-    uint32_t goal = 0;
-    uint32_t Rn = 1;  // entries of the ready list (uniform: every thread carries it)
-    uint32_t depth_seen = 0xffffffffu;  // deepest collision-free node at the last selection
-    bool heavy = false;                 // the search has stalled once: its rounds grow
-    uint32_t t_checks = 0, t_pairs = 0;  // this thread's share of the work counters
-    // where the time goes (100 MHz ticks, PDMPC_DEBUG_TAIL=1): accumulated by thread 0 in LDS words, so that the bookkeeping costs
-    // the round loop no registers
-    lds_vu64* tk = (lds_vu64*)(gp_path + 200);  // [12]: mark, start, work, arrival, select (without the refills), wait, p1, p2, p3, phase B, refill, time of the early publication
-    enum { TK_MARK, TK_START, tk_work, tk_arrival, tk_select, tk_wait, tk_p1, tk_p2, tk_p3, tk_pb, tk_refill, tk_pub };
-    const bool ticking = A.debug_tail != 0 && tid == 0;
-    if (ticking) {
-        for (int i = 2; i < 12; ++i) tk[i] = 0ull;
-        tk[TK_MARK] = tk[TK_START] = __builtin_amdgcn_s_memrealtime();
-    }
-#define BK_TICK(acc)                                                       \
-    if (ticking) {                                                         \
-        const unsigned long long now__ = __builtin_amdgcn_s_memrealtime(); \
-        tk[acc] += now__ - tk[TK_MARK];                                    \
-        tk[TK_MARK] = now__;                                               \
-    }
-    double far_mn = inf, far_mx = 0.0, near_mn = inf, near_mx = 0.0, mid_mn = inf;
-    double* const mid_key = A.arena.mid_key + voff;
-    uint32_t* const mid_id = A.arena.mid_id + voff;
-    // appends (k, i) of the lanes with `take` to the open entries outside LDS (whole wave calls, straight-line): to mid up to the key
-    // l_mid, to far above it.  A light search has no mid list (l_mid = -1): everything goes to far.
-    double l_mid = -1.0;  // the value of the shared word BK_L_MID (uniform; read again wherever it changes: the refill, a reopened open set)
-    auto load_l_mid = [&]() {
-        const unsigned long long v = (unsigned long long)__double_as_longlong(sh_ld_d(sh, BK_L_MID));
-        const uint32_t lo32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-        l_mid = __longlong_as_double((long long)(((unsigned long long)hi32 << 32) | lo32));
-    };
-    auto to_far = [&](bool take, double k, uint32_t i) {
-        const unsigned long long b = __ballot(take);
-        if (b && l_mid < 0.0) {  // (uniform) no mid list: the light searches' path
-            const uint32_t base = sh_add_uniform(sh, FR_FAR_N, (uint32_t)__builtin_popcountll(b), lane);
-            if (take) {
-                const uint32_t pos = base + lane_rank(b, lane);
-                F.far_key[pos] = k;
-                F.far_id[pos] = i;
-                far_mn = k < far_mn ? k : far_mn;
-                far_mx = k > far_mx ? k : far_mx;
-            }
-        } else if (b) {
-            const bool tm = k <= l_mid;
-            const unsigned long long bm = __ballot(take && tm), bf = b & ~bm;
-            // one LDS atomic reserves room in both lists: lane 0 adds far's count, lane 1 mid's (the other lanes add to scratch words, see sh_add_uniform)
-            lds_u32* p = lane == 0 ? (lds_u32*)(sh + FR_FAR_N) : (lane == 1 ? (lds_u32*)(sh + BK_MID_N) : (lds_u32*)(sh + FR_SCRATCH + lane));
-            const uint32_t old = __hip_atomic_fetch_add(p, lane == 0 ? (uint32_t)__builtin_popcountll(bf) : (lane == 1 ? (uint32_t)__builtin_popcountll(bm) : 0u), __ATOMIC_RELAXED,
-                                                        __HIP_MEMORY_SCOPE_WORKGROUP);
-            const uint32_t base_f = (uint32_t)__builtin_amdgcn_readlane((int)old, 0), base_m = (uint32_t)__builtin_amdgcn_readlane((int)old, 1);
-            if (take) {
-                const uint32_t pos = tm ? base_m + lane_rank(bm, lane) : base_f + lane_rank(bf, lane);
-                (tm ? mid_key : F.far_key)[pos] = k;
-                (tm ? mid_id : F.far_id)[pos] = i;
-                mid_mn = (tm && k < mid_mn) ? k : mid_mn;
-                far_mn = (!tm && k < far_mn) ? k : far_mn;
-                far_mx = (!tm && k > far_mx) ? k : far_mx;
-            }
-        }
-    };
-    auto flush_far = [&]() {
-        sh_minmax_wave(sh, FR_FAR_MIN, FR_FAR_MAX, far_mn, far_mx, lane);
-        far_mn = inf;
-        far_mx = 0.0;
-        if (__ballot(mid_mn < inf)) {  // (uniform over the wave)
-            double m = mid_mn;
-#pragma unroll
-            for (int o = PDMPC_WAVE / 2; o > 0; o >>= 1) {
-                const double a = __shfl_xor(m, o);
-                m = a < m ? a : m;
-            }
-            if (lane == 0) sh_min_d(sh, BK_MID_MIN, m);
-            mid_mn = inf;
-        }
-    };
-    // appends (k, i) of the lanes with `take` to near (LDS; the caller has made sure there is room)
-    auto to_near = [&](bool take, double k, uint32_t i) {
-        const unsigned long long b = __ballot(take);
-        if (b) {
-            const uint32_t base = sh_add_uniform(sh, FR_NEAR_N, (uint32_t)__builtin_popcountll(b), lane);
-            if (take) {
-                const uint32_t pos = base + lane_rank(b, lane);
-                near_key[pos] = k;
-                near_id[pos] = i;
-                near_mn = k < near_mn ? k : near_mn;
-                near_mx = k > near_mx ? k : near_mx;
-            }
-        }
-    };
-    auto flush_near = [&]() {
-        sh_minmax_wave(sh, FR_NEAR_MIN, FR_NEAR_MAX, near_mn, near_mx, lane);
-        near_mn = inf;
-        near_mx = 0.0;
-    };
-    // A search that can do nothing but wait for a predecessor (finished, or stalled on parked nodes): the first wave polls the
-    // pending predecessors' done flags in a tight loop — an arrival is on every successor's critical path — while the others wait at
-    // the barrier.  Returns (to every thread) whether the watchdog's limit of polls has been reached.
-    auto bk_wait = [&]() -> bool {
-        if (wave == 0) {
-            uint32_t spins = 0;
-            while (!bk_poll_predecessors(A, P, sh, 0ull, lane) && ++spins < 4096u) __builtin_amdgcn_s_sleep(1);
-            if (lane == 0) sh[BK_IDLE] = sh[BK_IDLE] + spins + 1u;
-        }
-        __syncthreads();
-        return sh[BK_IDLE] > A.spin_limit;
-    };
-    PhaseB R;
-    R.n_popped = 0;
-    R.n_expanded = 0;
-    bool pb_valid = false;
-    bool rec_valid = false, rec_written = false;  // the result record in HBM is the one this search would publish now / some record has been written
-    bool vs_copied = false;                       // the LDS validity bytes have been copied to HBM since the tree last changed
-    bool verify_req = false;                      // the next round boundary verifies the tree against the areas that were copied since the last verification (BK_FD)
-    // shared rounds (helper workgroups)
-    unsigned long long* board = A.help_board + (size_t)slot * PDMPC_HB_WORDS;
-    uint32_t help_seq = 0;  // rounds shared so far (same value in every thread)
-
-    const int tid_k = tid, lane_k = lane;
-    for (;;) {
-        // (the thread's index is made opaque once per round: what the compiler derives from it — a few dozen per-thread addresses into
-        // the LDS lists — would otherwise be kept in registers across the whole loop, and the kernel runs at the register cap)
-        int tid_o = tid_k, lane_o = lane_k;
-        asm volatile("" : "+v"(tid_o), "+v"(lane_o));
-        int tid = tid_o, lane = lane_o;
-#define BK_OPAQUE_TID                                      \
-    {                                                      \
-        int t__ = tid_k, l__ = lane_k;                     \
-        asm volatile("" : "+v"(t__), "+v"(l__));           \
-        tid = t__;                                         \
-        lane = l__;                                        \
-    }
-        // ================= a round =================
-        if (Rn) {
-            pb_valid = false;  // (the tree grows: phase B's result is stale)
-            rec_valid = false;
-            vs_copied = false;
-            // ---- P1: check items + sincos items.  A large round is shared with the helper workgroups (CUs this launch leaves idle):
-            // the owner posts one 48-byte record per entry (what a check reads of the tree), keeps the first tiles of 64 entries and
-            // offers the others; helpers claim tiles (compare-and-swap on the board's ticket word, which carries the round's sequence
-            // number), mirror the search's soup in their LDS and leave one verdict word per entry.  What nobody has claimed when the
-            // owner is through with its part it does itself; then it waits for the claimed tiles.
-            const BkTreeSrc tsrc{&S, ready};
-            const unsigned long long pend_now = A.bk_tentative ? sh_load64(sh, SH_PEND_LO) : 0ull;  // (their slots hold expected areas)
-            const uint32_t n_tiles = (Rn + TILE - 1u) / TILE;
-            const bool share = A.n_helpers > 0 && Rn >= (uint32_t)A.bk_share_min && P.n_pred <= 64 && n_tiles <= 64u;  // (one bit per tile in the owner's mask)
-            uint32_t own_tiles = n_tiles;
-            if (share) {  // (uniform)
-                own_tiles = n_tiles / (uint32_t)A.fr_own_div > 0u ? n_tiles / (uint32_t)A.fr_own_div : 1u;
-                ++help_seq;
-                d2* post = (d2*)A.bk_post + (size_t)slot * RC * 3u;
-                for (uint32_t r = own_tiles * TILE + (uint32_t)tid; r < Rn; r += (uint32_t)bd) {
-                    uint32_t parent, packed;
-                    const d2 p3 = node_piece(S, ready[r] - 1u, 3);
-                    piece_link(p3, parent, packed);
-                    post[3 * r] = node_piece(S, parent - 1u, 0);
-                    post[3 * r + 1] = node_piece(S, parent - 1u, 2);
-                    post[3 * r + 2] = d2{p3.y, 0.0};
-                }
-                // every wave's stores must have reached L2 before thread 0 writes L2 back: a workgroup barrier alone does not wait for them
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (tid == 0) {
-                    const unsigned long long all = P.n_pred >= 64 ? ~0ull : ((1ull << P.n_pred) - 1ull);
-                    __hip_atomic_store(board + PDMPC_HB_N, (unsigned long long)Rn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(board + PDMPC_HB_MASK, all & ~sh_load64(sh, SH_PEND_LO), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(board + PDMPC_HB_DONE, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    __hip_atomic_store(board + PDMPC_HB_TICKET, ((unsigned long long)help_seq << 32) | ((unsigned long long)n_tiles << 16) | own_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            // The owner and the helpers take tiles off the same counter.  The owner does its first tiles (what the ticket starts at), then
-            // looks how far the helpers have come meanwhile and takes its share of the rest — everything if no helper has shown up, one
-            // tile if they are many — and so on until the counter is through; then it waits for the tiles the helpers hold.  (Taking
-            // everything that was unclaimed after the first tiles, as a first version did, left the owner with five tiles of a sixteen-tile
-            // round while its helpers had long finished theirs: C4, 40 us of a round's 47 in the owner's own part.)
-            unsigned long long omask = 0ull;  // tiles behind the first ones that the owner took (uniform)
-            uint32_t extra_entries = 0;        // ... and their entries
-#pragma unroll 1
-            for (int pass = 0;; ++pass) {  // (one call site: the check items are instantiated once)
-                uint32_t rb = 0, Rr = own_tiles * TILE < Rn ? own_tiles * TILE : Rn;
-                if (pass > 0) {
-                    if (!share) break;
-                    __syncthreads();
-                    if (tid == 0) {
-                        unsigned long long cur = __hip_atomic_load(board + PDMPC_HB_TICKET, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        uint32_t got = n_tiles, take = 0;
-                        for (;;) {
-                            const uint32_t idx = (uint32_t)(cur & 0xffffull);
-                            if (idx >= n_tiles) break;
-                            const uint32_t theirs = idx - own_tiles - (uint32_t)__builtin_popcountll(omask), rem = n_tiles - idx;
-                            take = (rem + theirs) / (theirs + 1u);  // ceil(rem / (theirs + 1))
-                            take = take < 1u ? 1u : take;
-                            if (__hip_atomic_compare_exchange_strong(board + PDMPC_HB_TICKET, &cur, cur + (unsigned long long)take, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                                got = idx;
-                                break;
-                            }
-                        }
-                        sh[FR_HELP_CLOSED] = got | (take << 16);
-                    }
-                    __syncthreads();
-                    const uint32_t gw = sh[FR_HELP_CLOSED];
-                    const uint32_t got = gw & 0xffffu, take = gw >> 16;
-                    if (got >= n_tiles) break;  // (uniform) every tile has an owner
-                    omask |= ((take >= 64u ? ~0ull : ((1ull << take) - 1ull)) << got);
-                    rb = got * TILE;
-                    Rr = (got + take) * TILE < Rn ? take * TILE : Rn - rb;
-                    extra_entries += Rr;
-                }
-                const int ls = bk_chunk_shift(chm, Rr, (uint32_t)bd);
-                bk_check_items(CK, tsrc, r_flag, rb, Rr, ls, chm[ls], pend_now, tid, bd);
-                if (pass == 0) {
-                    for (uint32_t r = (uint32_t)(bd - 1 - tid); r < Rn; r += (uint32_t)bd) {  // (from the last thread down: the first waves carry the first chunks)
-                        const uint32_t i0 = ready[r] - 1u;
-                        uint32_t parent, packed;
-                        piece_link(node_piece(S, i0, 3), parent, packed);
-                        if (NODE_K(packed) < Hp) {
-                            const d2 p1 = node_piece(S, i0, 1);
-                            double sn, cs;
-                            pdmpc_sincos(p1.x, &sn, &cs);  // expand_node.m:50-51
-                            node_store_cs(S, i0, cs, sn);
-                        }
-                    }
-                }
-            }
-            if (share) {
-                const uint32_t n_claimed = n_tiles - own_tiles - (uint32_t)__builtin_popcountll(omask);  // tiles the helpers took
-                if (tid == 0) {
-                    if (n_claimed) {  // wait for the helpers' tiles
-                        uint32_t spins = 0;
-                        while (__hip_atomic_load(board + PDMPC_HB_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)n_claimed) {
-                            __builtin_amdgcn_s_sleep(2);
-                            if (++spins > A.spin_limit) {
-                                atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_BUG);  // reported as an error status: must never happen
-                                break;
-                            }
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    }
-                    atomicAdd(A.work_count + 4, 1ull);
-                    atomicAdd(A.work_count + 5, (unsigned long long)(Rn - (own_tiles * TILE < Rn ? own_tiles * TILE : Rn) - extra_entries));
-                }
-                __syncthreads();
-                const uint32_t* hverdict = A.help_verdict + (size_t)slot * PDMPC_HELP_CAP;
-                for (uint32_t r = own_tiles * TILE + (uint32_t)tid; r < Rn; r += (uint32_t)bd) {  // 1 collision-free, 2 collides, 3 crosses expected areas only
-                    if ((omask >> (r / TILE)) & 1ull) continue;  // (the owner's own verdict is in r_flag already)
-                    const uint32_t v = __hip_atomic_load(hverdict + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (v < 1u || v > 3u) atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_BUG);  // (claimed, reported finished, and no verdict)
-                    r_flag[r] = v == 2u ? 1u : (v == 3u ? 2u : 0u);
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            BK_TICK(tk_p1)
-
-            BK_OPAQUE_TID
-            // ---- P2: verdicts, goal candidates, children counts; node indices by a scan (BK_P2 ready entries per thread).
-            // The children of a node are expanded in groups of four lanes.
-            bool ex[BK_P2];
-            uint32_t cnt[BK_P2], rr[BK_P2];
-            unsigned long long mine = 0;
-#pragma unroll
-            for (int s = 0; s < BK_P2; ++s) {
-                const uint32_t r = (uint32_t)tid + (uint32_t)s * (uint32_t)bd;
-                const bool in = r < Rn;
-                rr[s] = r;
-                ex[s] = false;
-                cnt[s] = 0;
-                if (in) {
-                    const uint32_t id = ready[r], i0 = id - 1u;
-                    const uint32_t fl = r_flag[r];
-                    const bool valid = (fl & 3u) == 0u, parked = (fl & 3u) == 2u;  // (crosses nothing / only expected areas)
-                    uint32_t parent, packed;
-                    piece_link(node_piece(S, i0, 3), parent, packed);
-                    const int k = NODE_K(packed);
-                    vs_store(VS, i0, valid ? VS_VALID : (parked ? VS_TENT : VS_INVALID));
-                    if (parked) {  // (rare: one LDS atomic each)
-                        sh_add(sh, BK_NTENT, 1u);
-                        sh_min_d(sh, BK_TENT_MIN, F.gkey[i0]);
-                    }
-                    if (parent) {  // the pairs the reference's InterX forms for this edge (InterX.m:63-76): (V - 1) x (M - 1) per soup
-                        const int M_k = CK.l_soff[k] - CK.l_soff[k - 1], Hk = CK.l_hoff[k] - CK.l_hoff[k - 1];
-                        t_checks += 1;
-                        t_pairs += (uint32_t)(NODE_COLS(packed) - 1) * (uint32_t)((M_k > 1 ? M_k - 1 : 0) + (Hk > 1 ? Hk - 1 : 0) + (CK.ll_len > 1 ? CK.ll_len - 1 : 0));
-                    }
-                    if (valid && k == Hp) {
-                        // a goal candidate if its ancestors are all collision-free still: the largest key of its path goes into its
-                        // record (the cos / sin slot, which a node at the horizon never needs), the best one is chosen at the boundary
-                        double b1;
-                        const bool alive = fr_goal_path(S, VS, F.gkey, id, b1);
-                        if (alive) {
-                            node_store_cs(S, i0, b1, 0.0);
-                            const uint32_t pos = sh_add(sh, FR_GOAL_N, 1u);
-                            if (pos < 1024u)
-                                F.goal_list[pos] = id;
-                            else
-                                atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_GOALS_LOST);  // (more than a thousand candidates in one round: looked up again in the tree below)
-                        }
-                    } else if (valid) {
-                        if ((uint32_t)k > sh[BK_DEPTH]) __hip_atomic_fetch_max((lds_u32*)&sh[BK_DEPTH], (uint32_t)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (rare: one node per level)
-                        const lds_mask64* mrow = EE.l_mask + ((size_t)k * n + (NODE_TRIM(packed) - 1)) * nw;
-                        uint32_t c = 0;
-                        for (int w = 0; w < nw; ++w) c += (uint32_t)__builtin_popcountll(mrow[w]);
-                        ex[s] = c != 0u;
-                        cnt[s] = c;
-                    }
-                }
-                mine += (unsigned long long)((cnt[s] + 3u) >> 2) | ((unsigned long long)cnt[s] << 32);
-            }
-            unsigned long long tot = 0;
-            const unsigned long long base = wg_scan_excl(mine, wsum64, lane, wave, n_waves, tot);
-            const uint32_t NG = (uint32_t)(tot & 0xffffffffull), NC = (uint32_t)(tot >> 32);
-            const uint32_t nn_base = sh[FR_NNODES];
-            const bool overflow = nn_base + NC > S.max_nodes;
-            const bool all_far = sh[FR_NEAR_N] + NC > OC;  // near cannot take this round's children: they wait in far
-            const double l_far = all_far ? -1.0 : sh_ld_d(sh, FR_L_FAR);
-            BK_TICK(tk_p2)
-            BK_OPAQUE_TID
-            // ---- P3: expansion items (group of four successors of a collision-free node, lane): expand_node.m:18-90
-            for (uint32_t tile0 = 0; tile0 < NG && !overflow; tile0 += VCAP) {  // (uniform; one tile unless a round has more than VCAP groups)
-                if (tile0) __syncthreads();  // (the previous tile's items have read the lists)
-                {
-                    uint32_t g = (uint32_t)(base & 0xffffffffull), c = (uint32_t)(base >> 32);
-#pragma unroll
-                    for (int s = 0; s < BK_P2; ++s) {
-                        const uint32_t ng = (cnt[s] + 3u) >> 2;
-                        for (uint32_t q = 0; q < ng; ++q) {
-                            const uint32_t gi = g + q - tile0;  // (unsigned: groups of earlier tiles are far outside)
-                            if (gi < VCAP) {
-                                vlist[gi] = rr[s] | (q << 16);
-                                voffs[gi] = c;
-                            }
-                        }
-                        g += ng;
-                        c += cnt[s];
-                    }
-                }
-                __syncthreads();
-                const uint32_t ngt = NG - tile0 < VCAP ? NG - tile0 : VCAP, items = ngt * 4u;
-                for (uint32_t b0 = 0; b0 < items; b0 += (uint32_t)bd) {  // (uniform trip count: wave-wide appends inside)
-                    const uint32_t item = b0 + (uint32_t)tid;
-                    const bool in = item < items;
-                    const uint32_t gi = in ? item >> 2 : 0u, ent = vlist[gi];
-                    const uint32_t r = ent & 0xffffu, rank = (ent >> 16) * 4u + (item & 3u);
-                    const uint32_t id = ready[r], i0 = id - 1u;
-                    NodeBits cu;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) cu.q[q] = node_piece(S, i0, q);
-                    const NodeRec& cn = cu.r;
-                    const int cTrim = NODE_TRIM(cn.packed), cK = NODE_K(cn.packed);
-                    const int k_exp = cK + 1;            // expand_node.m:13
-                    const int steps_to_go = Hp - k_exp;  // :37
-                    const lds_mask64* mrow = EE.l_mask + ((size_t)cK * n + (cTrim - 1)) * nw;
-                    // the rank-th successor (ascending trim: expand_node.m:18): its mask word and its place in that word
-                    int w = 0;
-                    uint32_t rk = rank;
-                    uint64_t mask = mrow[0];
-                    for (int q = 1; q < nw && rk >= (uint32_t)__builtin_popcountll(mask); ++q) {
-                        rk -= (uint32_t)__builtin_popcountll(mask);
-                        mask = mrow[q];
-                        w = q;
-                    }
-                    const bool active = in && rk < (uint32_t)__builtin_popcountll(mask);
-                    double f = 0.0;
-                    uint32_t ci = 0;
-                    if (active) {
-                        const int t2 = w * 64 + nth_bit(mask, (int)rk);  // 0-based successor trim
-                        const int m = (int)EE.l_mi[(cTrim - 1) * n + t2];
-                        const double dx = EE.l_pose[m].dx, dy = EE.l_pose[m].dy, dyaw = EE.l_pose[m].dyaw;
-                        const int ncols = EE.l_pose[m].n_cols;
-                        NodeRec ch;
-                        ch.x = cn.cs * dx - cn.sn * dy + cn.x;  // :53
-                        ch.y = cn.sn * dx + cn.cs * dy + cn.y;  // :54
-                        ch.yaw = cn.yaw + dyaw;                 // :55
-                        ch.cs = 0.0;
-                        ch.sn = 0.0;
-                        ch.parent = id;
-                        ch.packed = (uint32_t)(t2 + 1) | ((uint32_t)k_exp << 10) | ((uint32_t)m << 15) | ((uint32_t)ncols << 27);
-                        // cost-to-come (:57-61) and cost-to-go (:66-73), summed in the reference's order
-                        {
-                            const double ddx = ch.x - EE.l_rx[k_exp - 1], ddy = ch.y - EE.l_ry[k_exp - 1];
-                            const double nrm = sqrt(ddx * ddx + ddy * ddy);
-                            ch.g = cn.g + nrm * nrm;  // :61
-                        }
-                        double expH = 0.0;
-                        for (int it = 1; it <= steps_to_go; ++it) {
-                            const double ddx = ch.x - EE.l_rx[k_exp - 1 + it], ddy = ch.y - EE.l_ry[k_exp - 1 + it];
-                            const double nrm = sqrt(ddx * ddx + ddy * ddy);
-                            const double df = nrm - EE.l_dcum[(k_exp - 1) * PDMPC_HP_MAX + (it - 1)];
-                            const double m0 = (df > 0) ? df : 0.0;
-                            expH = expH + m0 * m0;
-                        }
-                        ch.h = expH;
-                        f = ch.g * 1 + expH * 1;  // GraphSearch.m:100-102
-                        ci = nn_base + voffs[gi] + rank;  // 0-based index of the child (Tree.add_nodes, Tree.m:61)
-                        node_store(S, ci, ch);
-                        vs_store(VS, ci, 0);  // validity unknown
-                        F.gkey[ci] = f;
-                        F.glink[ci] = (unsigned long long)ch.parent | ((unsigned long long)ch.packed << 32);
-                        ((ulonglong2*)A.arena.walk + voff)[ci].y = 0ull;  // (no stamp: the arena holds other searches' leftovers, see bk_classify_wave)
-                    }
-                    to_near(active && !(f > l_far), f, ci + 1u);
-                    to_far(active && f > l_far, f, ci + 1u);
-                }
-            }
-            if (tid == 0) {  // (nobody reads these words before the barrier that ends the round)
-                sh[FR_NNODES] = nn_base + (overflow ? 0u : NC);
-                sh[FR_PROCESSED] = sh[FR_PROCESSED] + Rn;
-                if (A.debug_tail && sh[FR_ROUNDS] < 40u) X.O->path_nodes[PDMPC_HP_MAX - 7 + (int)(sh[FR_ROUNDS] >> 3)][sh[FR_ROUNDS] & 7u] = (double)Rn;  // (diagnostics: the sizes of the first forty rounds in rows HP_MAX - 7 .. HP_MAX - 3)
-                sh[FR_ROUNDS] = sh[FR_ROUNDS] + 1u;
-                if (overflow) sh[FR_FLAGS] = sh[FR_FLAGS] | FRF_OVERFLOW;
-            }
-            Rn = 0;
-            BK_TICK(tk_p3)
-        }
-        BK_OPAQUE_TID
-        // the key ranges the appends of this round and the selection before it have met
-        flush_near();
-        flush_far();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // ---- the barrier that ends the round
-        if (sh[FR_GOAL_N] > 1024u) {  // (uniform; the list holds the first 1024)
-            __syncthreads();
-            if (tid == 0) sh[FR_GOAL_N] = 1024u;
-            __syncthreads();
-        }
-        fr_resolve_goals(F, S, tid, lane, wave);
-        if (sh[FR_FLAGS] & FRF_GOALS_LOST) {  // (uniform) candidates were lost: every collision-free node at the horizon is offered again
-            __syncthreads();
-            if (tid == 0) {
-                sh[FR_BEST_ID] = 0;
-                sh[FR_PATH_FOR] = 0;
-                sh[FR_FLAGS] = sh[FR_FLAGS] & ~FRF_GOALS_LOST;
-            }
-            __syncthreads();
-            uint32_t nn = sh[FR_NNODES];
-            nn = nn < S.max_nodes ? nn : S.max_nodes;
-            for (uint32_t base = 0; base < nn; base += (uint32_t)bd) {  // (uniform trip count: barriers inside)
-                const uint32_t b = base + (uint32_t)wave * PDMPC_WAVE;
-                const uint32_t i0 = b + (uint32_t)lane;
-                const bool in = i0 < nn;
-                const uint32_t j0 = in ? i0 : 0u;
-                const bool cand = in && vs_load(VS, j0) == VS_VALID && NODE_K(((const uint32_t*)(S.gn + j0))[15]) == Hp;
-                unsigned long long bc = __ballot(cand);
-                while (bc) {
-                    const int l = __builtin_ctzll(bc);
-                    bc &= bc - 1;
-                    fr_offer_goal(F, S, VS, b + (uint32_t)l + 1u, lane);
-                }
-                __syncthreads();  // at most blockDim candidates per pass: the list cannot overflow
-                fr_resolve_goals(F, S, tid, lane, wave);
-            }
-        }
-        BK_TICK(tk_work)
-
-        // ================= round boundary (every thread; decisions are uniform) =====================================
-        uint32_t flags = sh[FR_FLAGS];
-        if (flags & FRF_OVERFLOW) {
-            status = PDMPC_ARENA_OVERFLOW;
-            break;
-        }
-        if ((flags & FRF_BUG) || sh[FR_ROUNDS] > A.spin_limit) {  // watchdog: reported as an error status
-            dep_timeout = true;
-            status = PDMPC_EXHAUSTED;
-            break;
-        }
-        // Predecessors that finished meanwhile (PrioritizedController.m:476-491).  An arrival is two things.  (1) The COPY: the
-        // predecessor's areas replace its expected ones in the soup — cheap, done here at every round boundary —; from then on edges are
-        // checked against the real areas (the predecessor leaves SH_PEND) and the predecessor is due for (2) the VERIFICATION (BK_FD):
-        // every collision-free edge evaluated before the copy is re-checked against the new areas, parked nodes come back into the
-        // open set.  A finished search that waits (bk_wait_done) copies and checks its plan's path only, and the verification follows
-        // for everybody who has arrived meanwhile; a running search verifies right behind the copy (measured: putting it off until
-        // the search has nothing else to do leaves parked nodes parked and dead subtrees alive — C2's heavy steps 1.35 -> 1.75 ms).
-        if (sh_load64(sh, SH_PEND_LO) != 0ull) {  // (uniform: written by thread 0 between barriers)
-            if (wave == 0 && sh[SH_STATE] != ST_ARRIVED) (void)bk_poll_predecessors(A, P, sh, 0ull, lane);  // (a waiting search has polled already: bk_wait)
-            __syncthreads();
-            if (sh[SH_STATE] == ST_ARRIVED) {  // (uniform)
-                const unsigned long long arr = sh_load64(sh, SH_ARR_LO);
-                bk_incorporate(P.out, P.pred, P.l_soup, P.l_soff, P.l_lit, Hp, arr, tid, bd);
-                __syncthreads();
-                if (tid == 0) {
-                    const unsigned long long pend = sh_load64(sh, SH_PEND_LO) & ~arr, fd = sh_load64(sh, BK_FD_LO) | arr;
-                    sh[SH_PEND_LO] = (uint32_t)pend;
-                    sh[SH_PEND_HI] = (uint32_t)(pend >> 32);
-                    sh[BK_FD_LO] = (uint32_t)fd;
-                    sh[BK_FD_HI] = (uint32_t)(fd >> 32);
-                    sh[SH_ARR_LO] = 0;
-                    sh[SH_ARR_HI] = 0;
-                    sh[SH_STATE] = ST_RUN;
-                }
-                __syncthreads();
-                verify_req = true;
-            }
-        }
-        if (verify_req) {  // (uniform)
-            verify_req = false;
-            const unsigned long long arr = sh_load64(sh, BK_FD_LO);  // everybody whose areas were copied since the last verification
-            uint32_t nn = sh[FR_NNODES];
-            nn = nn < S.max_nodes ? nn : S.max_nodes;
-            // Only collision-free nodes can lose their edge.  Small trees: every node is an item (the others are skipped); trees of more
-            // nodes than threads: the collision-free ones (a third of the tree, scattered) are gathered first so that the items are dense
-            // — an item is a chain of two dependent reads of the tree, and a lane that walks three or four of them one after the other
-            // (most of them skipped) was what an arrival event cost (C2's last vehicles: 10 of 15 us per event; gathering from 768 nodes
-            // on instead of 3 072: C2 1 041 -> 1 077 steps/s).
-            const bool direct = nn <= (uint32_t)bd;
-#pragma unroll 1
-            for (uint32_t base0 = 0; base0 < nn; base0 += direct ? nn : (uint32_t)FR_NBINS) {  // (uniform trip counts: barriers inside)
-                const lds_u32* list = nullptr;
-                uint32_t cnt = nn;
-                if (!direct) {
-                    const uint32_t end = base0 + FR_NBINS < nn ? base0 + FR_NBINS : nn;
-                    if (tid == 0) sh[FR_VLIST_N] = 0;
-                    __syncthreads();
-                    for (uint32_t b = base0; b < end; b += (uint32_t)bd) {
-                        const uint32_t i0 = b + (uint32_t)tid;
-                        const bool v = i0 < end && vs_load(VS, i0 < end ? i0 : 0u) == VS_VALID;
-                        const unsigned long long bal = __ballot(v);
-                        if (bal) {
-                            const uint32_t pos0 = sh_add_uniform(sh, FR_VLIST_N, (uint32_t)__builtin_popcountll(bal), lane);
-                            if (v) hist[pos0 + lane_rank(bal, lane)] = i0;
-                        }
-                    }
-                    __syncthreads();
-                    list = hist;
-                    cnt = sh[FR_VLIST_N];
-                }
-                bk_recheck_items(S, VS, CK, P, list, cnt, arr, sh, tid, bd);
-                __syncthreads();
-            }
-            flags = sh[FR_FLAGS];
-            const bool reopen = (flags & FRF_INVALIDATED) && sh[FR_DROPPED] != 0u;
-            // parked nodes (their edges crossed expected areas only) come back into the open set: never evaluated, as far as anybody
-            // can tell — a round will check them against what the soup holds then.  (reopen: the rebuild below finds them in the tree)
-            const uint32_t n_parked = sh[BK_NTENT];
-            if (n_parked) {  // (uniform)
-                const bool fits = sh[FR_NEAR_N] + n_parked <= OC;
-                const double l_far = sh_ld_d(sh, FR_L_FAR);
-                for (uint32_t base = 0; base < nn; base += (uint32_t)bd) {  // (uniform trip count: wave-wide appends inside)
-                    const uint32_t i0 = base + (uint32_t)tid;
-                    const bool tent = i0 < nn && vs_load(VS, i0 < nn ? i0 : 0u) == VS_TENT;
-                    const double k = tent ? F.gkey[i0] : 0.0;
-                    if (tent) vs_store(VS, i0, VS_UNKNOWN);
-                    const bool push = tent && !reopen;
-                    to_near(push && fits && !(k > l_far), k, i0 + 1u);
-                    to_far(push && !(fits && !(k > l_far)), k, i0 + 1u);
-                }
-            }
-            if (flags & FRF_INVALIDATED) {
-                pb_valid = false;
-                rec_valid = false;
-            }
-            vs_copied = false;  // (verdicts may have changed, parked nodes have come back)
-            __syncthreads();
-            if (tid == 0) {
-                sh[BK_ARRIVALS] = sh[BK_ARRIVALS] + 1u;  // (reported at the end: a global atomic here sits on every level's hand-over)
-                sh[BK_FD_LO] = 0;
-                sh[BK_FD_HI] = 0;
-                sh[BK_NTENT] = 0;
-                sh_st_d(sh, BK_TENT_MIN, inf);
-                if (flags & FRF_INVALIDATED) {
-                    sh[FR_EVER_INVAL] = 1;
-                    sh[FR_BEST_ID] = 0;  // the best candidate may have lost an ancestor: look at all of them again
-                    sh[FR_PATH_FOR] = 0;
-                    sh[FR_FLAGS] = flags & ~FRF_INVALIDATED;
-                }
-                if (reopen) {
-                    // open entries were dropped because they come after a candidate that may be gone now: rebuild the open set
-                    // from the tree (every generated node that was never evaluated is open)
-                    sh[FR_NEAR_N] = 0;
-                    sh[FR_FAR_N] = 0;
-                    sh[FR_DROPPED] = 0;
-                    sh_st_d(sh, FR_NEAR_MIN, inf);
-                    sh_st_d(sh, FR_NEAR_MAX, 0.0);
-                    sh_st_d(sh, FR_FAR_MIN, inf);
-                    sh_st_d(sh, FR_FAR_MAX, 0.0);
-                    sh_st_d(sh, FR_L_FAR, -1.0);  // (everything goes to far until the next refill)
-                    sh[BK_MID_N] = 0;
-                    sh_st_d(sh, BK_MID_MIN, inf);
-                    sh_st_d(sh, BK_L_MID, -1.0);
-                }
-            }
-            __syncthreads();
-            if (reopen) l_mid = -1.0;  // (uniform)
-            if (flags & FRF_INVALIDATED) {
-                for (uint32_t base = 0; base < nn; base += (uint32_t)bd) {  // (uniform trip count: barriers inside)
-                    const uint32_t b = base + (uint32_t)wave * PDMPC_WAVE;
-                    const uint32_t i0 = b + (uint32_t)lane;
-                    const bool in = i0 < nn;
-                    const uint32_t j0 = in ? i0 : 0u;  // (straight-line code: every lane loads something valid)
-                    const uint32_t vst = vs_load(VS, j0);
-                    const uint32_t par = node_parent(S, j0);
-                    const bool cand = in && vst == VS_VALID && NODE_K(((const uint32_t*)(S.gn + j0))[15]) == Hp;
-                    const bool open = reopen && in && vst == VS_UNKNOWN && par != 0u && vs_load(VS, par ? par - 1u : 0u) == VS_VALID;
-                    if (reopen) to_far(open, F.gkey[j0], j0 + 1u);
-                    unsigned long long bc = __ballot(cand);
-                    while (bc) {
-                        const int l = __builtin_ctzll(bc);
-                        bc &= bc - 1;
-                        fr_offer_goal(F, S, VS, b + (uint32_t)l + 1u, lane);
-                    }
-                    __syncthreads();  // at most blockDim candidates per pass: the list cannot overflow
-                    fr_resolve_goals(F, S, tid, lane, wave);
-                }
-                flush_far();
-                __syncthreads();
-            }
-            if (n_parked) {  // (uniform) the key ranges of what came back
-                flush_near();
-                flush_far();
-                __syncthreads();
-            }
-            flags = sh[FR_FLAGS];
-        }
-        if (flags & FRF_TIE) return true;
-        BK_TICK(tk_arrival)
-
-        // the relevance tables follow the best goal candidate
-        const uint32_t best = sh[FR_BEST_ID];
-        if (best && sh[FR_PATH_FOR] != best) {
-            __syncthreads();
-            if (tid == 0) {
-                uint32_t nd = best;
-                double m = -1.0;
-                for (int d = Hp; d >= 0; --d) {
-                    gp_path[d] = nd;
-                    gp_mp[d] = m;  // largest key of the path below depth d
-                    const double k = F.gkey[nd - 1];
-                    m = k > m ? k : m;
-                    nd = node_parent(S, nd - 1);
-                }
-                sh[FR_PATH_FOR] = best;
-            }
-            __syncthreads();
-        }
-
-        // are we done?  Open entries above the candidate's path maximum come after it; the others are looked at one by one when a
-        // round selects them.  An empty open set without a candidate is exhaustion (GraphSearch.m:57-61).
-        // (far_n / far_min: the open entries outside LDS, mid and far together)
-        const uint32_t near_n = sh[FR_NEAR_N], mid_n = sh[BK_MID_N], far_n = sh[FR_FAR_N] + mid_n;
-        const double near_min = near_n ? sh_ld_d(sh, FR_NEAR_MIN) : inf;
-        double far_min = far_n != mid_n ? sh_ld_d(sh, FR_FAR_MIN) : inf;
-        {
-            const double mm = mid_n ? sh_ld_d(sh, BK_MID_MIN) : inf;
-            far_min = mm < far_min ? mm : far_min;
-        }
-        const double open_min = near_min < far_min ? near_min : far_min;
-        const double bb = best ? sh_ld_d(sh, FR_BEST_B1) : inf;
-        // parked nodes (their edges cross only areas a pending predecessor is expected to take) count as open
-        const uint32_t n_tent = sh[BK_NTENT];
-        const double tent_min = n_tent ? sh_ld_d(sh, BK_TENT_MIN) : inf;
-        bool done = false, stalled = false;
-        if (best) {
-            if (bb == open_min || bb == tent_min) return true;  // a tie between an open node and a node of the best path
-            done = bb < open_min && bb < tent_min;
-            stalled = bb < open_min && !done;  // nothing open comes before the candidate, but a parked node may: only an arrival tells
-        } else {
-            done = near_n == 0u && far_n == 0u && n_tent == 0u;
-            stalled = near_n == 0u && far_n == 0u && !done;
-        }
-        const bool unverified = sh_load64(sh, BK_FD_LO) != 0ull;  // (uniform) areas have been copied since the last verification
-        if (stalled && unverified) {  // the parked nodes are judged against what has arrived
-            verify_req = true;
-            continue;
-        }
-        if (stalled) {  // (uniform) wait for a predecessor
-            if (bk_wait()) {
-                dep_timeout = true;
-                status = PDMPC_EXHAUSTED;
-                break;
-            }
-            BK_TICK(tk_wait)
-            continue;
-        }
-        if (done && unverified && !dep_timeout) {
-            // Finished as far as the verified areas go.  What the successors wait for comes first: the record with the plan's areas (its
-            // counts are rewritten after the verification if that takes edges away), the areas that were copied since against the path,
-            // the done flag if they pass and nobody is outstanding (bk_wait_done without waiting); then the verification.
-            if (!rec_valid && sh[BK_PUBLISHED] == 0u) {
-                if (wave == 0) bk_write_record(A, X, best, best ? PDMPC_OK : PDMPC_EXHAUSTED, false, R.n_popped, R.n_expanded, false, nullptr, rec_written, false, lane);
-                rec_written = true;
-                __syncthreads();  // (the path's areas in LDS: written by the first wave, which is also their reader; the barrier is for the bookkeeping below)
-            }
-            if (wave == 0 && sh[BK_PUBLISHED] == 0u)
-                bk_wait_done(A.done_flag, P.pred, P.out, A.epoch, (uint32_t)slot, P.l_soup, P.l_soff, P.l_lit, (lds_d2*)(X.lsm + A.lds.bk_pshape), sh, Hp, P.n_pred, best != 0u ? 1 : 0,
-                             ticking ? (lds_vu64*)(tk + tk_pub) : (lds_vu64*)nullptr, sh_load64(sh, BK_FD_LO), 0u);
-            __syncthreads();
-            verify_req = true;
-            BK_TICK(tk_arrival)
-            continue;
-        }
-        if (done) {
-            // Phase B right away, also when predecessors are still planning: an arrival that invalidates nothing leaves the tree,
-            // hence the counts and ids, as they are, and the result goes out as soon as the last predecessor has been looked at.
-            if (!pb_valid && !dep_timeout) {
-                __syncthreads();
-                R = fr_phase_b<NW>(A, X, F, EE, best, ref_ids, (LDS_AS unsigned char*)(X.lsm + A.lds.cand), F.near_key, F.near_id, gp_path);
-                pb_valid = true;
-                BK_TICK(tk_pb)
-                const uint32_t pflags = sh[FR_FLAGS];
-                __syncthreads();
-                if (pflags & FRF_TIE) return true;
-                if (pflags & FRF_BUG) dep_timeout = true;  // reported as an error status: must never happen
-            }
-            if (sh_load64(sh, SH_PEND_LO) == 0ull || dep_timeout) {
-                goal = best;
-                status = best ? PDMPC_OK : PDMPC_EXHAUSTED;
-                break;
-            }
-            // finished, but predecessors that are still planning may yet invalidate what we found: the record is written meanwhile
-            if (!rec_valid && !dep_timeout) {
-                if (wave == 0) bk_write_record(A, X, best, best ? PDMPC_OK : PDMPC_EXHAUSTED, false, R.n_popped, R.n_expanded, best != 0u, ref_ids, rec_written, sh[BK_PUBLISHED] != 0u, lane);
-                rec_valid = true;
-                rec_written = true;
-            }
-            // (c) the validity bytes of the LDS-resident nodes go to HBM now as well (debug read-back of the tree): not behind the last arrival
-            if (!vs_copied) {
-                uint32_t nn1 = sh[FR_NNODES];
-                nn1 = nn1 < S.max_nodes ? nn1 : S.max_nodes;
-                const uint32_t nv = VS.NV < nn1 ? VS.NV : nn1;
-                for (uint32_t i = (uint32_t)tid; i < nv; i += (uint32_t)bd) VS.g[i] = VS.l[i];
-                vs_copied = true;
-            }
-            if (A.bk_fast_arrival && !dep_timeout) {
-                if (wave == 0)
-                    bk_wait_done(A.done_flag, P.pred, P.out, A.epoch, (uint32_t)slot, P.l_soup, P.l_soff, P.l_lit, (lds_d2*)(X.lsm + A.lds.bk_pshape), sh, Hp, P.n_pred, best != 0u ? 1 : 0,
-                                 ticking ? (lds_vu64*)(tk + tk_pub) : (lds_vu64*)nullptr, 0ull, 4096u);
-                __syncthreads();
-                if (sh[BK_IDLE] > A.spin_limit) dep_timeout = true;
-            } else if (bk_wait()) {
-                dep_timeout = true;  // a predecessor never finished: give up on it (reported as an error status)
-            }
-            BK_TICK(tk_wait)
-            continue;
-        }
-
-        BK_OPAQUE_TID
-        // A round takes the smallest open keys: bk_round0 while the search is young (a round costs about the same for one node as for a
-        // few dozen: the items of a small round run side by side), growing with the work done up to bk_round.
-        // (rounds stay at bk_round0 while every round gets one level deeper — a light search is over after Hp + 1 of them and what a
-        // round takes beyond what the reference pops is wasted; a search that stalls, or goes on beyond Hp + 2 rounds, is not light:
-        // its rounds grow with the work done)
-        uint32_t round_target;
-        {
-            const uint32_t done_so_far = sh[FR_PROCESSED];
-            const uint32_t depth_now = sh[BK_DEPTH];
-            heavy = heavy || depth_now == depth_seen || sh[FR_ROUNDS] > (uint32_t)Hp + 1u;
-            depth_seen = depth_now;
-            const uint32_t ramp = (uint32_t)A.bk_round0 + (heavy ? done_so_far / (uint32_t)A.fr_ramp : 0u);
-            round_target = ramp < (uint32_t)A.bk_round ? ramp : (uint32_t)A.bk_round;
-        }
-        // ---- near holds fewer entries than the round wants (or nothing below far's smallest key): it is topped up from far with the
-        // smallest entries far holds, as many as leave room for a round's children.  (Topping up when near is EMPTY only made a heavy
-        // search alternate between rounds of a thousand nodes, the few hundred those left behind, and a handful of new children.)
-        uint32_t nn_near = near_n;
-        const bool merge = nn_near != 0u && far_min < near_min;
-        if (far_n != 0u && (nn_near < round_target || merge)) {
-            if (merge) {  // (rare: near goes into far first so that the refill sees every open entry)
-                for (uint32_t b0 = 0; b0 < nn_near; b0 += (uint32_t)bd) {
-                    const uint32_t e = b0 + (uint32_t)tid;
-                    const bool in = e < nn_near;
-                    to_far(in, in ? near_key[e] : 0.0, in ? near_id[e] : 0u);
-                }
-                flush_far();
-                __syncthreads();
-                if (tid == 0) sh[FR_NEAR_N] = 0;
-                __syncthreads();
-                nn_near = 0;
-            }
-            // A heavy search's far list holds a hundred thousand entries and more; a pass over all of it for every refill of near (every
-            // other round) cost as much as the checks.  Beyond bk_mid_min entries far feeds near through the mid list: stage 0 moves a
-            // band of far's smallest keys (about bk_mid_fill entries, up to the key l_mid) to mid, stage 1 refills near from mid; until
-            // mid runs short again only mid is scanned, and open entries up to l_mid that leave LDS go to mid (to_far).
-            const uint32_t room = OC - OC / 6u;  // (a sixth of near stays free for the children of the rounds to come)
-            const uint32_t fill_near = room > nn_near + 64u ? room - nn_near : 64u;
-            int stage = (sh[FR_FAR_N] > (uint32_t)A.bk_mid_min && sh[BK_MID_N] < fill_near) ? 0 : 1;
-#pragma unroll 1
-            for (; stage < 2; ++stage) {
-                const bool to_mid = stage == 0;
-                const bool from_mid = !to_mid && sh[BK_MID_N] != 0u;  // (uniform)
-                if (!to_mid && !from_mid && sh[FR_FAR_N] == 0u) break;  // (nothing to refill from)
-                double* const src_key = from_mid ? mid_key : F.far_key;
-                uint32_t* const src_id = from_mid ? mid_id : F.far_id;
-                const int SRC_N = from_mid ? BK_MID_N : FR_FAR_N;
-                const uint32_t fn = sh[SRC_N];
-                const uint32_t fill = to_mid ? (uint32_t)A.bk_mid_fill : fill_near;
-                const double l_mid_old = sh_ld_d(sh, BK_L_MID);
-                const uint32_t far_left = from_mid ? sh[FR_FAR_N] : 0u;  // (entries beyond the source)
-                double lo = from_mid ? sh_ld_d(sh, BK_MID_MIN) : sh_ld_d(sh, FR_FAR_MIN), hi = from_mid ? l_mid_old : sh_ld_d(sh, FR_FAR_MAX);
-                const double hi_src = hi;
-                uint32_t bsel = FR_NBINS - 1;
-                double scale = 0.0;
-                // (a list of tens of thousands of entries is histogrammed on a sample: every stride-th entry.  The threshold only has to
-                // bring about `fill` entries; what the chosen bins hold beyond near's room goes back, what they hold less comes next time)
-                const uint32_t stride = fn > 16384u ? fn / 8192u : 1u;
-                const uint32_t fill_s = stride > 1u ? (fill / stride > 16u ? fill / stride : 16u) : fill;
-                for (int zoom = 0; zoom < 6; ++zoom) {
-                    scale = hi > lo ? (double)FR_NBINS / (hi - lo) : 0.0;
-                    for (int i = tid; i < FR_NBINS; i += bd) hist[i] = 0;
-                    __syncthreads();
-                    if (stride == 1u) {
-                        fr_histogram(F, src_key, fn, lo, scale);
-                    } else {
-                        for (uint32_t e = (uint32_t)tid * stride; e < fn; e += (uint32_t)bd * stride)
-                            __hip_atomic_fetch_add(&hist[fr_bin(src_key[e], lo, scale)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                    __syncthreads();
-                    if (wave == 0) bk_far_select(F, fill_s, lane);
-                    __syncthreads();
-                    bsel = sh[FR_SEL_BIN];
-                    const uint32_t cum = sh[FR_SEL_CUM] * stride;
-                    __syncthreads();
-                    if (bsel != 0u || scale == 0.0 || (to_mid ? cum <= 4u * fill : nn_near + cum <= OC - 64u)) break;
-                    hi = lo + (hi - lo) / (double)FR_NBINS;  // nearly everything sits in the first bin: look closer
-                }
-                const bool all = bsel >= FR_NBINS - 1 || scale == 0.0;  // every entry of the source is taken
-                const double l_new = all ? inf : lo + (double)(bsel + 1u) / scale;
-                if (tid == 0) {
-                    if (from_mid) {
-                        sh_st_d(sh, BK_MID_MIN, inf);
-                    } else {
-                        sh_st_d(sh, FR_FAR_MIN, inf);
-                        sh_st_d(sh, FR_FAR_MAX, 0.0);
-                    }
-                    if (to_mid) {
-                        sh_st_d(sh, BK_L_MID, all ? hi_src : l_new);  // (from now on what leaves LDS with a key up to here joins mid)
-                    } else {
-                        if (!from_mid) sh_st_d(sh, BK_L_MID, -1.0);  // (near is fed by far directly: no mid list)
-                        if (nn_near == 0u) {  // (else near's key range stays and takes the new entries in)
-                            sh_st_d(sh, FR_NEAR_MIN, inf);
-                            sh_st_d(sh, FR_NEAR_MAX, 0.0);
-                        }
-                        // children up to this key join near from now on (what near still holds lies below the old limit, what the source
-                        // held above it); with all of mid taken and far not empty, near's limit is mid's: far's keys lie above it
-                        const double l_far_new = (all && far_left != 0u) ? l_mid_old : l_new;
-                        const double l_old = sh_ld_d(sh, FR_L_FAR);
-                        sh_st_d(sh, FR_L_FAR, (nn_near != 0u && l_old > l_far_new && l_old < inf) ? l_old : l_far_new);
-                    }
-                }
-                __syncthreads();
-                load_l_mid();
-                const double lo_c = lo, scale_c = scale;
-                const uint32_t kept = fr_partition(
-                    src_key, src_id, fn, wsum, n_waves, [&](double k, uint32_t i) -> int { return i == 0u ? -1 : (fr_bin(k, lo_c, scale_c) <= bsel ? 1 : 0); },
-                    [&](int c, double k, uint32_t i) {
-                        const unsigned long long b = __ballot(c == 1);
-                        bool back = false;
-                        if (b && to_mid) {  // (uniform) far's band joins mid
-                            const uint32_t base = sh_add_uniform(sh, BK_MID_N, (uint32_t)__builtin_popcountll(b), lane);
-                            if (c == 1) {
-                                const uint32_t pos = base + lane_rank(b, lane);
-                                mid_key[pos] = k;
-                                mid_id[pos] = i;
-                                mid_mn = k < mid_mn ? k : mid_mn;
-                            }
-                        } else if (b) {
-                            const uint32_t base = sh_add_uniform(sh, FR_NEAR_N, (uint32_t)__builtin_popcountll(b), lane);
-                            const uint32_t pos = base + lane_rank(b, lane);
-                            const bool fits = c == 1 && pos < OC;
-                            if (fits) {
-                                near_key[pos] = k;
-                                near_id[pos] = i;
-                                near_mn = k < near_mn ? k : near_mn;
-                                near_mx = k > near_mx ? k : near_mx;
-                            }
-                            back = c == 1 && !fits;
-                        }
-                        // (an entry that does not fit cannot go back into the list that is being compacted: it is appended behind the
-                        // old end of its list and moved down afterwards — only if more than near's capacity of keys share the first bins)
-                        if (!to_mid) to_far(back, k, i);
-                        if (c < 0 && i != 0u) {  // kept entries (i is their node, never 0)
-                            if (from_mid) {
-                                mid_mn = k < mid_mn ? k : mid_mn;
-                            } else {
-                                far_mn = k < far_mn ? k : far_mn;
-                                far_mx = k > far_mx ? k : far_mx;
-                            }
-                        }
-                    });
-                flush_far();
-                flush_near();
-                // entries that did not fit into near were appended behind the source's old end (their keys lie in the chosen bins: below
-                // l_mid for a source mid, and without a mid list everything goes to far)
-                const uint32_t extra = sh[SRC_N] - fn;
-                for (uint32_t e = (uint32_t)tid; e < extra; e += (uint32_t)bd) {  // (kept + extra <= fn: the ranges do not overlap)
-                    src_key[kept + e] = src_key[fn + e];
-                    src_id[kept + e] = src_id[fn + e];
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (tid == 0) {
-                    sh[SRC_N] = kept + extra;
-                    if (sh[FR_NEAR_N] > OC) sh[FR_NEAR_N] = OC;
-                }
-                __syncthreads();
-            }
-            nn_near = sh[FR_NEAR_N];
-            BK_TICK(tk_refill)
-        }
-
-        BK_OPAQUE_TID
-        // ---- this round's entries: the smallest keys of near.  Every thread holds BK_PER entries in registers.
-        {
-            const double lo = sh_ld_d(sh, FR_NEAR_MIN);
-            double hi = sh_ld_d(sh, FR_NEAR_MAX);
-            double kk[BK_PER];
-            uint32_t ii[BK_PER];
-#pragma unroll
-            for (int j = 0; j < BK_PER; ++j) {
-                const uint32_t e = (uint32_t)j * (uint32_t)bd + (uint32_t)tid;
-                kk[j] = e < nn_near ? near_key[e] : 0.0;
-                ii[j] = e < nn_near ? near_id[e] : 0u;
-            }
-            uint32_t bsel = BK_NB - 1;
-            double scale = 0.0;
-            const bool use_hist = nn_near > round_target;  // (a round that takes all of near needs no histogram: scale 0 puts every key into bin 0)
-            if (use_hist) {
-                for (int zoom = 0; zoom < 8; ++zoom) {
-                    scale = hi > lo ? (double)BK_NB / (hi - lo) : 0.0;
-#pragma unroll
-                    for (int j = 0; j < BK_PER; ++j)
-                        if (ii[j]) __hip_atomic_fetch_add(&bins[bk_bin(kk[j], lo, scale)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __syncthreads();
-                    uint32_t cum;
-                    bk_select(bins, round_target, lane, bsel, cum);  // (every wave for itself)
-                    if (cum <= 2u * round_target + 16u || scale == 0.0) break;
-                    hi = lo + (hi - lo) / (double)BK_NB;  // too many entries share the first bins: look closer
-                    __syncthreads();                       // every wave has read the bins ...
-                    if (tid < BK_NB) bins[tid] = 0u;
-                    __syncthreads();                       // ... and they are clean again
-                }
-            }
-            const bool have_goal = best != 0u;
-            const bool check_alive = sh[FR_EVER_INVAL] != 0u;  // some node lost its edge to late areas: its descendants are dead
-            const uint32_t epoch_now = sh[BK_ARRIVALS] & 0xffffu;
-            ulonglong2* const wcache = (ulonglong2*)A.arena.walk + voff;
-            int cls[BK_PER];
-            unsigned long long mine = 0;
-            uint32_t n_dead = 0, n_drop = 0;
-#pragma unroll
-            for (int j = 0; j < BK_PER; ++j) {  // (every lane of the wave runs this: straight-line code around the wave-wide walk)
-                const double k = kk[j];
-                const uint32_t i = ii[j];
-                const uint32_t b = bk_bin(k, lo, scale);
-                const bool sel = i != 0u && b <= bsel;
-                const bool above = have_goal && k > bb;  // above the candidate's path maximum: comes after it
-                const bool walk = sel && !above && (have_goal || check_alive);
-                if (sel && have_goal && k == bb) atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_TIE);
-                int r = 1;
-                if (have_goal || check_alive) r = bk_classify_wave(F.glink, wcache, VS, F.gkey, gp_path, gp_mp, have_goal, check_alive, best, epoch_now, walk ? i : 0u, k, sh);  // (uniform condition)
-                cls[j] = i == 0u ? -1 : (sel ? (above ? 3 : r) : 0);
-                mine += (cls[j] == 0 ? 1ull : 0ull) | (cls[j] == 1 ? (1ull << 32) : 0ull);
-                n_dead += cls[j] == 4 ? 1u : 0u;
-                n_drop += cls[j] == 3 ? 1u : 0u;
-            }
-            unsigned long long tot = 0;
-            const unsigned long long base = wg_scan_excl(mine, wsum64 + 16, lane, wave, n_waves, tot);  // (its barrier: every entry and every bin has been read)
-            if (use_hist && tid < BK_NB) bins[tid] = 0u;  // (clean for the next selection)
-            const uint32_t n_keep = (uint32_t)(tot & 0xffffffffull), n_rdy = (uint32_t)(tot >> 32);
-            if (tid == 0) {  // (the old list's key range has been read by everybody; nobody touches these words before the next barrier)
-                sh[FR_NEAR_N] = n_keep;
-                sh_st_d(sh, FR_NEAR_MIN, inf);
-                sh_st_d(sh, FR_NEAR_MAX, 0.0);
-            }
-            {
-                uint32_t pk = (uint32_t)(base & 0xffffffffull), pr = (uint32_t)(base >> 32);
-                bool over[BK_PER];
-#pragma unroll
-                for (int j = 0; j < BK_PER; ++j) {
-                    over[j] = false;
-                    if (cls[j] == 0) {
-                        near_key[pk] = kk[j];
-                        near_id[pk] = ii[j];
-                        near_mn = kk[j] < near_mn ? kk[j] : near_mn;  // (folded into the shared words at the end of the round)
-                        near_mx = kk[j] > near_mx ? kk[j] : near_mx;
-                        pk += 1u;
-                    } else if (cls[j] == 1) {
-                        if (pr < RC) {
-                            ready[pr] = ii[j];
-                            r_flag[pr] = 0u;
-                        } else {
-                            over[j] = true;  // (only if hundreds of keys are equal to the last bit: they wait in far)
-                        }
-                        pr += 1u;
-                    }
-                }
-                if (n_rdy > RC) {  // (uniform)
-#pragma unroll
-                    for (int j = 0; j < BK_PER; ++j) to_far(over[j], kk[j], ii[j]);
-                }
-            }
-            if (n_dead) sh_add(sh, FR_DEAD, n_dead);
-            if (n_drop) sh_add(sh, FR_DROPPED, n_drop);  // comes after the candidate: never popped
-            Rn = n_rdy < RC ? n_rdy : RC;
-            __syncthreads();  // the ready list and the compacted near are in place
-            BK_TICK(tk_select)
-        }
-    }
-
-    // ================= results =================
-    int tid_r = tid_k, lane_r = lane_k;  // (opaque once more: see the round loop)
-    asm volatile("" : "+v"(tid_r), "+v"(lane_r));
-    uint32_t nnodes_raw = sh[FR_NNODES];
-    nnodes_raw = nnodes_raw < S.max_nodes ? nnodes_raw : S.max_nodes;
-    __syncthreads();
-    const bool pb_ran = pb_valid;
-    if (!pb_valid) {
-        R.n_popped = 0;
-        R.n_expanded = nnodes_raw;
-    }
-    // validity bytes of the LDS-resident nodes go to HBM with the rest (debug read-back of the tree, pdmpc_debug_tree)
-    {
-        const uint32_t nv = vs_copied ? 0u : (VS.NV < nnodes_raw ? VS.NV : nnodes_raw);
-        for (uint32_t i = (uint32_t)tid_r; i < nv; i += (uint32_t)bd) VS.g[i] = VS.l[i];
-    }
-    {  // work counters: one atomic per wave
-        unsigned long long a = t_checks, b = t_pairs;  // (a thread's share stays far below 2^32)
-#pragma unroll
-        for (int o = PDMPC_WAVE / 2; o > 0; o >>= 1) {
-            a += __shfl_xor(a, o);
-            b += __shfl_xor(b, o);
-        }
-        if (lane_r == 0) {
-            atomicAdd(A.work_count + 0, a);
-            atomicAdd(A.work_count + 1, b);
-        }
-    }
-    if (tid_r == 0) {
-        atomicAdd(P.counters + 2, (int)sh[BK_ARRIVALS]);
-        atomicAdd(A.work_count + 2, (unsigned long long)sh[FR_PROCESSED]);
-        atomicAdd(A.work_count + 3, (unsigned long long)sh[FR_ROUNDS]);
-        A.tree_size[slot] = (int32_t)(nnodes_raw | 0x40000000u);  // marks the arena as a raw tree (api.cpp reconstructs the reference's)
-    }
-    if (tid_r == 0 && A.debug_tail) {  // diagnostics in the unused tail of the record (rows HP_MAX - 2 .. HP_MAX of path_nodes); PDMPC_DEBUG_TAIL=1
-        double* dbg = X.O->path_nodes[PDMPC_HP_MAX];
-        dbg[0] = (double)sh[FR_ROUNDS];
-        dbg[1] = (double)sh[FR_PROCESSED];
-        dbg[2] = (double)nnodes_raw;
-        dbg[3] = (double)sh[FR_NEAR_N];
-        dbg[4] = (double)(sh[FR_FAR_N] + sh[BK_MID_N]);
-        dbg[5] = (double)sh[FR_FLAGS];
-        dbg[6] = 0.0;
-        dbg[7] = (double)(__builtin_amdgcn_s_memrealtime() - tk[TK_START]);
-        X.O->path_nodes[PDMPC_HP_MAX - 2][0] = (double)(tk[TK_START] - X.rt_kernel_start);
-        X.O->path_nodes[PDMPC_HP_MAX - 2][1] = (double)tk[tk_p1];
-        X.O->path_nodes[PDMPC_HP_MAX - 2][2] = (double)tk[tk_p2];
-        X.O->path_nodes[PDMPC_HP_MAX - 2][3] = (double)tk[tk_p3];
-        X.O->path_nodes[PDMPC_HP_MAX - 2][4] = (double)tk[tk_pb];
-        X.O->path_nodes[PDMPC_HP_MAX - 2][5] = (double)tk[tk_refill];
-        X.O->path_nodes[PDMPC_HP_MAX - 1][0] = (double)(tk[tk_work] + tk[tk_p1] + tk[tk_p2] + tk[tk_p3]);
-        X.O->path_nodes[PDMPC_HP_MAX - 1][1] = (double)tk[tk_arrival];
-        X.O->path_nodes[PDMPC_HP_MAX - 1][2] = (double)tk[tk_select];
-        X.O->path_nodes[PDMPC_HP_MAX - 1][3] = (double)tk[tk_wait];
-        X.O->path_nodes[PDMPC_HP_MAX - 1][4] = (double)(tk[TK_MARK] - tk[TK_START]);
-        X.O->path_nodes[PDMPC_HP_MAX - 1][5] = (double)tk[tk_pub];                // when the done flag was set ahead of the end (0: at the end), 100 MHz device clock
-        X.O->path_nodes[PDMPC_HP_MAX - 1][6] = (double)__builtin_amdgcn_s_memrealtime();  // ... and now (the flag follows within a microsecond unless it is out)
-        X.O->path_nodes[PDMPC_HP_MAX - 1][7] = (double)X.rt_kernel_start;
-    }
-    X.status = status;
-    X.n_popped = (int)R.n_popped;
-    X.path_ready = pb_ran && goal != 0u;  // (l_path holds G's path: the record need not walk it again)
-    X.goal = goal;
-    X.nnodes = R.n_expanded;
-    X.dep_timeout = dep_timeout;
-    X.rec_valid = rec_valid && !dep_timeout;
-    X.rec_written = rec_written;
-    X.published = sh[BK_PUBLISHED] != 0u;
-    return false;
-}
-
-
-// ---------------------------------------------------------------------------------------------------
-// Helper workgroups of the bulk kernel (the workgroups of a launch behind its searches, bulk_body): they look
-// for a search that has posted a round, claim a tile of TILE entries, mirror that search's obstacle soup in their own LDS
-// (literal obstacles, lanelet boundary, the areas of the predecessors the owner had incorporated when it posted), run the
-// tile's check items — the owner's own code on the posted records — and leave one verdict word per entry.  A helper never waits
-// for anything but memory, so an owner that waits for claimed tiles always gets them; helpers leave when every search of the
-// launch has published.
-__device__ __forceinline__ void bulk_helper_body(const KernelArgs& A) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    LDS_AS unsigned char* lsm = (LDS_AS unsigned char*)smem;
-    const int tid = threadIdx.x, lane = tid & (PDMPC_WAVE - 1), wave = uni_i(tid >> 6), bd = (int)blockDim.x;
-    const int Hp = A.Hp, n_s = A.n_searches;
-    const uint32_t TILE = (uint32_t)A.bk_tile;
-    // the owners' carve (search_prologue): only the regions a check item reads are filled
-    lds_u32* l_path = (lds_u32*)(lsm + A.lds.path);
-    lds_i32* l_soff = (lds_i32*)(l_path + PDMPC_HP_MAX + 2);
-    lds_i32* l_hoff = l_soff + PDMPC_HP_MAX + 1;
-    volatile lds_u32* hs = (volatile lds_u32*)(l_hoff + PDMPC_HP_MAX + 1);
-    lds_i32* l_lit = (lds_i32*)(hs + SH_WORDS);
-    lds_d2* l_soup = (lds_d2*)(lsm + A.lds.soup);
-    lds_d2* t_rec = (lds_d2*)(lsm + A.lds.bk_near_key);              // [bk_tile][3] the tile's posted records
-    volatile lds_u32* t_flag = (volatile lds_u32*)(lsm + A.lds.bk_ready);  // [bk_tile] collision flags
-    lds_u32* chm = (lds_u32*)(lsm + A.lds.bk_misc) + 192;
-    BkCheck CK;
-    CK.l_area = (const lds_d2*)(lsm + A.lds.area);
-    CK.g_area = (const d2*)A.man_area;
-    CK.l_soup = l_soup;
-    CK.l_soff = l_soff;
-    CK.l_hoff = l_hoff;
-    CK.l_lit = l_lit;
-    CK.areas_in_lds = A.areas_in_lds;
-    CK.ll_base = 0;
-    CK.ll_len = 0;
-    CK.Hp = Hp;
-    if (A.areas_in_lds) stage16(lsm + A.lds.area, A.man_area, A.n_man * 3 * PDMPC_VMAX, tid);
-    if (tid < SH_WORDS) hs[tid] = 0;
-    __syncthreads();
-    int cur_slot = -1;
-    unsigned long long cur_mask = 0;
-    const int pref = (int)blockIdx.x % n_s;  // where this helper starts to look
-    SpecCtx P;
-    P.sh = hs;
-    P.l_soup = l_soup;
-    P.l_soff = l_soff;
-    P.l_lit = l_lit;
-    P.out = A.out;
-    P.pred = A.pred;
-    P.counters = A.tie_count;
-    P.n_pred = 0;
-    P.Hp = Hp;
-    uint32_t idle = 0;
-    for (;;) {
-        // ---- look for work: one lane per search, the first one (from pref on) with an unclaimed tile is tried
-        if (wave == 0) {
-            uint32_t cmd = 0;
-            for (int base = 0; base < n_s; base += PDMPC_WAVE) {  // (uniform trip count)
-                const int k = base + lane;
-                const int s_rel = k < n_s ? (pref + k) % n_s : 0;
-                unsigned long long* b = A.help_board + (size_t)(A.first + s_rel) * PDMPC_HB_WORDS;
-                // one word holds the round's sequence number, its tiles and the next unclaimed one
-                unsigned long long word = __hip_atomic_load(b + PDMPC_HB_TICKET, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t nt = (uint32_t)((word >> 16) & 0xffffull), idx = (uint32_t)(word & 0xffffull);
-                const bool has = k < n_s && (word >> 32) != 0ull && idx < nt;
-                const unsigned long long m = __ballot(has);
-                const int l = m ? (int)__builtin_ctzll(m) : -1;
-                if (lane == l) {  // (one lane; what it finds goes through LDS)
-                    if (__hip_atomic_compare_exchange_strong(b + PDMPC_HB_TICKET, &word, word + 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                        const unsigned long long mask = __hip_atomic_load(b + PDMPC_HB_MASK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        hs[HS_SLOT] = (uint32_t)(A.first + s_rel);
-                        hs[HS_FIRST] = idx;
-                        hs[HS_COUNT] = (uint32_t)__hip_atomic_load(b + PDMPC_HB_N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        hs[HS_MASK_LO] = (uint32_t)mask;
-                        hs[HS_MASK_HI] = (uint32_t)(mask >> 32);
-                        hs[HS_CMD] = 1;
-                    }
-                }
-                wave_sync();
-                cmd = uni_u(hs[HS_CMD]);
-                if (cmd) break;  // (uniform)
-            }
-            if (!cmd) {
-                const uint32_t fin = __hip_atomic_load(A.help_finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (lane == 0 && fin - A.help_fin_base >= (uint32_t)n_s) hs[HS_CMD] = 2;
-            } else {
-                // what the owner wrote before it posted (and the predecessors it had seen) is visible from here on; not on an idle
-                // poll: the fence empties this XCD's L2, which searches on neighbouring CUs share
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            }
-        }
-        __syncthreads();
-        const uint32_t cmd = hs[HS_CMD];
-        if (cmd == 2u) break;
-        if (cmd == 0u) {
-            if (idle < 64u)
-                __builtin_amdgcn_s_sleep(2);
-            else
-                __builtin_amdgcn_s_sleep(32);
-            if (++idle > (A.spin_limit >> 4)) break;  // (uniform) the searches never came: leave; they do without helpers
-            __syncthreads();
-            continue;
-        }
-        idle = 0;
-        const int slot = (int)hs[HS_SLOT];
-        const uint32_t tile = hs[HS_FIRST], Rn = hs[HS_COUNT];
-        const unsigned long long mask = ((unsigned long long)hs[HS_MASK_HI] << 32) | hs[HS_MASK_LO];
-        const DevVehicle* __restrict__ V = A.veh + slot;
-        // ---- the search's obstacle soup (search_prologue, parts 3 and 4)
-        if (slot != cur_slot) {
-            const int pred_cols = V->n_pred * PDMPC_VMAX;
-            int off = 0;
-            for (int k = 0; k < Hp; ++k) {
-                const int a = V->lit_off[k], b = V->lit_off[k + 1];
-                if (tid == 0) {
-                    l_soff[k] = off;
-                    l_lit[k] = b - a;
-                }
-                stage16(l_soup + off, (const d2*)A.points + a, b - a, tid);
-                off += (b - a) + pred_cols;
-            }
-            if (tid == 0) l_soff[Hp] = off;
-            for (int k = 0; k < Hp; ++k) {
-                const int a = V->hdv_off[k], b = V->hdv_off[k + 1];
-                if (tid == 0) l_hoff[k] = off;
-                stage16(l_soup + off, (const d2*)A.points + a, b - a, tid);
-                off += (b - a);
-            }
-            if (tid == 0) l_hoff[Hp] = off;
-            stage16(l_soup + off, (const d2*)A.points + V->ll_off, V->ll_len, tid);
-            CK.ll_base = off;
-            CK.ll_len = V->ll_len;
-            __syncthreads();
-            const d2 nanpt = d2{__longlong_as_double(0x7ff8000000000000LL), __longlong_as_double(0x7ff8000000000000LL)};
-            for (int idx = tid; idx < Hp * pred_cols; idx += bd) {
-                const int k = idx / pred_cols;
-                l_soup[l_soff[k] + l_lit[k] + (idx - k * pred_cols)] = nanpt;
-            }
-            __syncthreads();
-            P.pred = A.pred + V->pred_off;
-            P.n_pred = V->n_pred;
-            incorporate_areas(P, mask, tid);
-            if (A.bk_tentative) bk_tentative_areas(A, P, (V->n_pred >= 64 ? ~0ull : ((1ull << V->n_pred) - 1ull)) & ~mask, tid, bd);  // (as the owner: expected areas of the others)
-            __syncthreads();
-            if (tid < 8) {  // the chunk table of this soup (bulk_search)
-                const int ls = tid;
-                uint32_t mx = 0;
-                for (int k = 1; k <= Hp; ++k) {
-                    const int M_k = l_soff[k] - l_soff[k - 1], Hk = l_hoff[k] - l_hoff[k - 1];
-                    const int n0 = M_k > 1 ? M_k - 1 : 0, n1 = Hk > 1 ? Hk - 1 : 0, n2 = CK.ll_len > 1 ? CK.ll_len - 1 : 0;
-                    const int Sg = 1 << ls;
-                    const uint32_t ch = (uint32_t)(((n0 + Sg - 1) >> ls) + ((n1 + Sg - 1) >> ls) + ((n2 + Sg - 1) >> ls));
-                    mx = ch > mx ? ch : mx;
-                }
-                chm[ls] = mx;
-            }
-            cur_slot = slot;
-            cur_mask = mask;
-        } else if (mask != cur_mask) {
-            incorporate_areas(P, mask & ~cur_mask, tid);  // (within a launch a search's set of incorporated predecessors only grows)
-            cur_mask = mask;
-        }
-        // ---- the tile: its records into LDS, its check items, its verdicts
-        const uint32_t rb = tile * TILE, Rt = Rn - rb < TILE ? Rn - rb : TILE;
-        {
-            const d2* post = (const d2*)A.bk_post + ((size_t)slot * (size_t)A.bk_ready_cap + rb) * 3u;
-            for (uint32_t i = (uint32_t)tid; i < Rt * 3u; i += (uint32_t)bd) t_rec[i] = post[i];
-            if ((uint32_t)tid < TILE) t_flag[tid] = 0u;
-        }
-        __syncthreads();
-        {
-            const BkPostSrc psrc{t_rec};
-            const int ls = bk_chunk_shift(chm, Rt, (uint32_t)bd);
-            const unsigned long long pend = A.bk_tentative ? (P.n_pred >= 64 ? ~0ull : ((1ull << P.n_pred) - 1ull)) & ~mask : 0ull;
-            bk_check_items(CK, psrc, t_flag, 0u, Rt, ls, chm[ls], pend, tid, bd);
-        }
-        __syncthreads();
-        {
-            uint32_t* verdict = A.help_verdict + (size_t)slot * PDMPC_HELP_CAP + rb;
-            if ((uint32_t)tid < Rt) {  // 1 collision-free, 2 collides, 3 crosses expected areas only
-                const uint32_t fl = t_flag[tid];
-                __hip_atomic_store(verdict + tid, (fl & 1u) ? 2u : ((fl & 2u) ? 3u : 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's verdicts have reached L2 (the barrier alone does not wait for them) ...
-        __syncthreads();                                     // ... every wave's have: thread 0 can write L2 back and report
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __hip_atomic_fetch_add(A.help_board + (size_t)slot * PDMPC_HB_WORDS + PDMPC_HB_DONE, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            hs[HS_CMD] = 0;
-        }
-        __syncthreads();
-    }
-}
-
-template <int NW>
-__device__ __forceinline__ void bulk_body(const KernelArgs& A) {
-    // The workgroups behind the searches are their helpers: one launch, so the helpers are dispatched with (for launches with more
-    // searches than CUs: right behind) the searches they serve — a helper kernel of its own on a second stream now and then shared a
-    // hardware queue with the launch stream and started when the searches were through (one step in a hundred without helpers).
-    if ((int)blockIdx.x >= A.n_searches) {  // (uniform over the workgroup)
-        bulk_helper_body(A);
-        return;
-    }
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    Ctx X;
-    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
-    search_prologue(A, X, (LDS_AS unsigned char*)smem, true);
-    X.rt_kernel_start = rt0;
-    const int wave = X.wave;
-    lds_u32* ref_ids = (lds_u32*)(X.lsm + A.lds.bk_misc) + 224;  // behind the chunk table (nothing else uses those words)
-    const bool tie = bulk_search<NW>(A, X, ref_ids);
-    if (tie) {  // (uniform over the workgroup) reported with the internal status: the host plans the call again on the binary heap
-        X.status = PDMPC_INTERNAL_TIE;
-        X.n_popped = 0;
-        X.path_ready = false;
-        X.goal = 0;
-        X.nnodes = 0;
-        X.rec_valid = false;
-        X.dep_timeout = false;
-        X.published = false;
-    }
-    __syncthreads();
-    if (wave != 0) return;
-    {  // (opaque, as in the round loop: nothing derived from the lane index in the prologue is worth a register until here)
-        int l__ = X.lane;
-        asm volatile("" : "+v"(l__));
-        X.lane = l__;
-    }
-    if (!X.rec_valid) bk_write_record(A, X, X.goal, X.status, X.dep_timeout, (uint32_t)X.n_popped, X.nnodes, X.path_ready, tie ? nullptr : ref_ids, X.rec_written, X.published, X.lane);
-    bk_publish(A, X, X.status, X.dep_timeout);
-    if (X.lane == 0 && A.n_helpers > 0) atomicAdd(A.help_finished, 1u);
-}
-
-}  // namespace
-
-extern "C" __global__ __launch_bounds__(PDMPC_MAX_THREADS) void pdmpc_bulk_kernel(const KernelArgs A) { bulk_body<1>(A); }
-
-extern "C" int pdmpc_launch_bulk(const KernelArgs* args, int count, void* stream, uint32_t* lds_high_water) {
-    if (count <= 0) return 0;
-    typedef void (*kernel_t)(const KernelArgs);
-    if (args->n_words != 1) return (int)hipErrorInvalidValue;  // (automata with more than 64 trims run the frontier kernel: api.cpp, use_bulk)
-    kernel_t fn = pdmpc_bulk_kernel;
-    // (the attribute is a maximum: raised when a launch needs more than any before it; the high-water mark lives in the handle)
-    uint32_t& have = lds_high_water[0];
-    if (args->lds.total > have) {
-        hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)args->lds.total);
-        if (e != hipSuccess) return (int)e;
-        have = args->lds.total;
-    }
-    hipLaunchKernelGGL(fn, dim3(count + (args->n_helpers > 0 ? args->n_helpers : 0)), dim3(PDMPC_WAVE * args->n_waves), args->lds.total, (hipStream_t)stream, *args);
-    return (int)hipGetLastError();
-}
+PDMPC_BULK_KERNEL(pdmpc_bulk_kernel, pdmpc_launch_bulk, 1, PDMPC_CHECK_INTERX)

@@ -42,6 +42,7 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_edge_check_kernel
         soup[i] = p;
     }
     wave_sync();
+    // the wave-wide forms (one lane per segment / per axis: the sampled optimizer's kernel) ...
     bool r = false;
     if (mode == 0)
         r = interx_check(sh2, na, soup, 0, nb, 0, 0, 0, 0, lane);
@@ -49,6 +50,29 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_edge_check_kernel
         r = sat_pair_wave(sh2, na, soup, nb, lane);
     else
         r = sat_boundary_wave(sh2, na, soup, nb, lane);
+    // ... and the per-lane forms of the graph search's check items (bulk_search.hpp, bk_check_items): a lane tests its pair alone
+    bool r2 = false;
+    {
+        d2 pt[PDMPC_VMAX];
+#pragma unroll
+        for (int i = 0; i < PDMPC_VMAX; ++i) pt[i] = i < na ? (d2)sh2[i] : d2{0.0, 0.0};
+        bool mine = false;
+        if (mode == 0) {
+            if (na >= 2)
+                for (int j = lane; j + 1 < nb; j += PDMPC_WAVE) mine = mine || interx_segment_n<PDMPC_VMAX>(pt, na - 1, soup[j], soup[j + 1]);
+        } else if (mode == 1) {
+            if (lane == 0) mine = sat_pair_lane(pt, na, soup, nb);
+        } else {
+            double min_x, max_x, min_y, max_y;
+            sat_area_bbox(pt, na, min_x, max_x, min_y, max_y);
+            for (int j = lane; j + 1 < nb; j += PDMPC_WAVE) mine = mine || sat_boundary_segment_lane(pt, na, min_x, max_x, min_y, max_y, soup[j], soup[j + 1]);
+        }
+        r2 = wave_any(mine);
+    }
+    if (lane == 0 && r != r2) {  // (the two forms evaluate the same expressions: must never happen; reported as 2 + the per-lane answer)
+        hit[c] = 2 + (r2 ? 1 : 0);
+        return;
+    }
     if (lane == 0) hit[c] = r ? 1 : 0;
 }
 

@@ -292,3 +292,125 @@ __device__ bool edge_valid(const Search& S, const CheckCtx& C, uint32_t id, int 
     const NodeRec pn = node_load(S, par - 1);
     return edge_valid_recs<CHECKER>(C, cn, pn, lane);
 }
+
+// ---------------------------------------------------------------------------------------------------
+// The separating-axis checker in the form the bulk kernel uses (bulk_kernel.hip, bk_check_items): ONE LANE tests one pair — the
+// edge's area (its points in registers) against one polygon of the soup, or against one boundary segment —, axis by axis with the
+// arithmetic of sat_pair_wave / sat_boundary_wave above (intersect_sat.m:19-40, intersect_lanelet_boundary.m:16-54): the same
+// operations on the same numbers, so the same bits.  The loops over the area's points are unrolled with compile-time indices
+// (the points are a register array); the polygon's points are read from LDS.
+
+// projections of the area's V1 points on the axis (nx, ny): min and max (intersect_sat.m:26-29)
+__device__ __forceinline__ void sat_project_area(const d2 (&pt)[PDMPC_VMAX], int V1, double nx, double ny, double& mn, double& mx) {
+    mn = 0.0;
+    mx = 0.0;
+#pragma unroll
+    for (int v = 0; v < PDMPC_VMAX; ++v) {
+        const double d = nx * pt[v].x + ny * pt[v].y;
+        if (v == 0) {
+            mn = d;
+            mx = d;
+        } else if (v < V1) {
+            mn = (d < mn) ? d : mn;
+            mx = (d > mx) ? d : mx;
+        }
+    }
+}
+// does the axis normal to the edge e0 -> e1 separate the area from the polygon o[0 .. V2)?  (:21-23, 33-40; a zero-length edge gives a
+// NaN axis whose comparisons are false)
+__device__ __forceinline__ bool sat_axis_separates(const d2 (&pt)[PDMPC_VMAX], int V1, const lds_d2* o, int V2, d2 e0, d2 e1) {
+    const double ex = e1.x - e0.x, ey = e1.y - e0.y;
+    const double ax = -ey, ay = ex;
+    const double nrm = sqrt(ax * ax + ay * ay);
+    const double nx = ax / nrm, ny = ay / nrm;
+    double minS, maxS, minO = 0, maxO = 0;
+    sat_project_area(pt, V1, nx, ny, minS, maxS);
+    for (int v = 0; v < V2; ++v) {
+        const d2 p = o[v];
+        const double d = nx * p.x + ny * p.y;
+        if (v == 0) {
+            minO = d;
+            maxO = d;
+        } else {
+            minO = (d < minO) ? d : minO;
+            maxO = (d > maxO) ? d : maxO;
+        }
+    }
+    return (minS - maxO > 0) || (minO - maxS > 0);
+}
+// point i of the area (i known at run time only: the points live in registers, so the pick is a chain of selects, not an indexed read)
+__device__ __forceinline__ d2 sat_pick(const d2 (&pt)[PDMPC_VMAX], int i) {
+    d2 r = pt[0];
+#pragma unroll
+    for (int v = 1; v < PDMPC_VMAX; ++v) {
+        r.x = (v == i) ? pt[v].x : r.x;
+        r.y = (v == i) ? pt[v].y : r.y;
+    }
+    return r;
+}
+// intersect_sat(area, o): true iff no axis of either polygon separates them.  ONE loop over the V1 + V2 axes (not unrolled: eight
+// copies of the projection side by side cost the kernel sixty spilled registers), edges of closed polygons wrap to the first point.
+__device__ __forceinline__ bool sat_pair_lane(const d2 (&pt)[PDMPC_VMAX], int V1, const lds_d2* o, int V2) {
+    bool sep = false;
+#pragma unroll 1
+    for (int a = 0; a < V1 + V2 && !sep; ++a) {
+        d2 e0, e1;
+        if (a < V1) {
+            e0 = sat_pick(pt, a);
+            e1 = sat_pick(pt, (a + 1 == V1) ? 0 : a + 1);
+        } else {
+            const int b = a - V1;
+            e0 = o[b];
+            e1 = o[(b + 1 == V2) ? 0 : b + 1];
+        }
+        sep = sat_axis_separates(pt, V1, o, V2, e0, e1);
+    }
+    return !sep;
+}
+// intersect_lanelet_boundary for ONE boundary segment (q0, q1): the bounding-box reject (:20, 40), then intersect_sat(area, segment)
+// with the segment as a two-point polygon (:24, 44).  bb = (min_x, max_x, min_y, max_y) of the area.
+__device__ __forceinline__ void sat_area_bbox(const d2 (&pt)[PDMPC_VMAX], int V1, double& min_x, double& max_x, double& min_y, double& max_y) {
+    max_x = pt[0].x;
+    min_x = pt[0].x;
+    max_y = pt[0].y;
+    min_y = pt[0].y;
+#pragma unroll
+    for (int v = 1; v < PDMPC_VMAX; ++v) {
+        if (v < V1) {
+            const d2 p = pt[v];
+            max_x = (p.x > max_x) ? p.x : max_x;
+            min_x = (p.x < min_x) ? p.x : min_x;
+            max_y = (p.y > max_y) ? p.y : max_y;
+            min_y = (p.y < min_y) ? p.y : min_y;
+        }
+    }
+}
+__device__ __forceinline__ bool sat_boundary_segment_lane(const d2 (&pt)[PDMPC_VMAX], int V1, double min_x, double max_x, double min_y, double max_y, d2 q0, d2 q1) {
+    const bool real = !(is_nan(q0.x) || is_nan(q1.x));
+    const bool reject = (max_x < q0.x && max_x < q1.x) || (min_x > q0.x && min_x > q1.x) || (max_y < q0.y && max_y < q1.y) || (min_y > q0.y && min_y > q1.y);
+    if (!real || reject) return false;
+    bool sep = false;
+#pragma unroll 1
+    for (int a = 0; a < V1 + 2; ++a) {  // the area's edges, then the segment both ways (intersect_sat.m:19 on a two-point polygon)
+        d2 e0, e1;
+        if (a < V1) {
+            e0 = sat_pick(pt, a);
+            e1 = sat_pick(pt, (a + 1 == V1) ? 0 : a + 1);
+        } else {
+            e0 = a == V1 ? q0 : q1;
+            e1 = a == V1 ? q1 : q0;
+        }
+        const double ex = e1.x - e0.x, ey = e1.y - e0.y;
+        const double ax = -ey, ay = ex;
+        const double nrm = sqrt(ax * ax + ay * ay);
+        const double nx = ax / nrm, ny = ay / nrm;
+        double minS, maxS;
+        sat_project_area(pt, V1, nx, ny, minS, maxS);
+        const double d0 = nx * q0.x + ny * q0.y;
+        const double d1 = nx * q1.x + ny * q1.y;
+        const double minO = (d1 < d0) ? d1 : d0;
+        const double maxO = (d1 > d0) ? d1 : d0;
+        sep = sep || (minS - maxO > 0) || (minO - maxS > 0);
+    }
+    return !sep;
+}
