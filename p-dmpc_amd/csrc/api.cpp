@@ -166,6 +166,7 @@ struct Tuning {
     int bk_mid_min = 24576;     // PDMPC_BK_MID_MIN: far lists longer than this feed near through the mid list (a band of far's smallest keys)
     int bk_mid_fill = 12288;    // PDMPC_BK_MID_FILL: entries a refill of mid aims at
     int bk_share_min = 192;     // PDMPC_BK_SHARE_MIN: a round with at least this many nodes is shared with the helper workgroups
+    int bk_force_tie = 0;       // PDMPC_BK_FORCE_TIE: testing only: every search ends on the replay through the reference's binary heap (as if it had met equal keys)
     int bk_fast_arrival = 1;    // PDMPC_BK_FAST_ARRIVAL: finished searches check arrivals against their plan's path first and publish early (A/B switch: results are identical)
     int bk_ramp = -1;           // PDMPC_BK_RAMP: a round grows by 1 / bk_ramp of the nodes processed so far (-1: 2 with helper workgroups, else 4)
     int fr_slice = -1;          // PDMPC_FR_SLICE (-1: only after a predecessor time-out, 0: never, 1: always when oversubscribed)
@@ -206,6 +207,7 @@ struct pdmpc_handle {
     DevBuf<double> awalk;   // bulk kernel: two doubles per node (NodeArena::walk)
     DevBuf<double> amidk;   // bulk kernel: mid list
     DevBuf<uint32_t> amidi;
+    DevBuf<uint32_t> achild0;  // bulk kernel: first child per node (NodeArena::child0)
     DevBuf<uint8_t> avs;
     DevBuf<pdmpc_vehicle_out> d_out;
     DevBuf<uint32_t> d_flag;
@@ -797,12 +799,13 @@ int alloc_arenas(pdmpc_handle* h, uint32_t nodes) {
     h->anid.release();
     h->amidk.release();
     h->amidi.release();
+    h->achild0.release();
     h->awalk.release();
     h->alink.release();
     h->max_nodes = 0;
     int bad = 0;
     bad |= h->anodes.ensure_exact(tot) | h->ahk.ensure_exact(tot) | h->ahid.ensure_exact(tot) | h->avs.ensure_exact(tot) | h->alog.ensure_exact(tot);
-    bad |= h->ankey.ensure_exact(tot) | h->anid.ensure_exact(tot) | h->alink.ensure_exact(tot) | h->amidk.ensure_exact(tot) | h->amidi.ensure_exact(tot) | h->awalk.ensure_exact(2 * tot);
+    bad |= h->ankey.ensure_exact(tot) | h->anid.ensure_exact(tot) | h->alink.ensure_exact(tot) | h->amidk.ensure_exact(tot) | h->amidi.ensure_exact(tot) | h->achild0.ensure_exact(tot) | h->awalk.ensure_exact(2 * tot);
     if (bad) return bad;
     h->max_nodes = nodes;
     return 0;
@@ -850,6 +853,7 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     a.arena.walk = h->awalk.p;
     a.arena.mid_key = h->amidk.p;
     a.arena.mid_id = h->amidi.p;
+    a.arena.child0 = h->achild0.p;
     a.arena.link = h->alink.p;
     a.max_nodes = h->max_nodes;
     a.pop_trace = h->d_trace.p;
@@ -957,6 +961,7 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     a.bk_tile = T.bk_tile > 0 ? T.bk_tile : (count >= 64 ? 128 : 64);
     a.bk_tentative = T.bk_tentative;
     a.bk_fast_arrival = T.bk_fast_arrival;
+    a.bk_force_tie = T.bk_force_tie;
     a.bk_post = h->d_bk_post.p;
     a.help_board = h->d_help_board.p;
     a.help_list = h->d_help_list.p;
@@ -1100,6 +1105,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
         T.bk_mid_fill = std::max(256, env_i("PDMPC_BK_MID_FILL", T.bk_mid_fill));
         T.bk_tentative = env_i("PDMPC_BK_TENTATIVE", T.bk_tentative) != 0;
         T.bk_fast_arrival = env_i("PDMPC_BK_FAST_ARRIVAL", T.bk_fast_arrival) != 0;
+        T.bk_force_tie = env_i("PDMPC_BK_FORCE_TIE", T.bk_force_tie) != 0;
         if (getenv("PDMPC_BK_TILE")) T.bk_tile = std::min(128, std::max(16, env_i("PDMPC_BK_TILE", 64)));
         h->bk_ready_cap = std::min(2048, std::max(256, env_i("PDMPC_BK_READY", h->bk_ready_cap))) & ~63;  // (the most a launch may use: launches without helpers lay out half of it)
         if (getenv("PDMPC_FR_ROUND")) h->fr_round = std::max(1, env_i("PDMPC_FR_ROUND", 0));
@@ -1205,6 +1211,7 @@ int pdmpc_destroy(pdmpc_handle* h) {
     h->anid.release();
     h->amidk.release();
     h->amidi.release();
+    h->achild0.release();
     h->awalk.release();
     h->alink.release();
     h->avs.release();
@@ -1462,7 +1469,7 @@ int plan_packed_growing(pdmpc_handle* h, int32_t n, pdmpc_vehicle_out* out) {
         if ((h->max_nodes_limit && next > h->max_nodes_limit) || next > (1ull << 30)) return PDMPC_OK;  // statuses tell
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
-        const size_t per_node = sizeof(NodeRec) + 8 + 4 + 8 + 1 + 8 + 4 + 8 + 8 + 4 + 16;
+        const size_t per_node = sizeof(NodeRec) + 8 + 4 + 8 + 1 + 8 + 4 + 8 + 8 + 4 + 4 + 16;
         const size_t have = (size_t)h->max_vehicles * h->max_nodes * per_node;
         if ((size_t)h->max_vehicles * next * per_node > free_b + have) return PDMPC_OK;  // no room to grow
         const uint32_t before = h->max_nodes;
@@ -1790,6 +1797,8 @@ int pdmpc_debug_blockmin_script(pdmpc_handle* h, int32_t n, const int32_t* op, c
 
 namespace {
 #define PDMPC_TREE_FRONTIER 0x40000000  /* d_tree_size marker: the arena holds the frontier kernel's raw tree (creation order differs from the reference's) */
+#define PDMPC_TREE_REPLAYED 0x20000000  /* ... and the search ended on the replay through the binary heap (equal keys): its pop sequence, in arena indices, is in the mid list's array */
+#define PDMPC_TREE_SIZE(sz) ((sz) & ~(PDMPC_TREE_FRONTIER | PDMPC_TREE_REPLAYED))
 
 // The frontier kernel processes open nodes in parallel, so its arena holds the reference's tree plus some nodes the
 // reference never creates, in another order.  This turns it back into the reference's tree and pop sequence, on the host
@@ -1802,7 +1811,7 @@ struct RefTree {
     std::vector<uint32_t> ref_nodes; // raw index of reference node id r (0-based position = id - 1)
     std::vector<uint32_t> ref_id;    // raw index -> reference id (0: not in the reference's tree)
 };
-int reconstruct_reference_tree(pdmpc_handle* h, int vehicle, uint32_t raw_n, RefTree& T) {
+int reconstruct_reference_tree(pdmpc_handle* h, int vehicle, uint32_t raw_n, RefTree& T, bool replayed = false) {
     const size_t off = (size_t)vehicle * h->max_nodes;
     const int Hp = h->cfg.Hp;
     T.rec.resize(raw_n);
@@ -1849,9 +1858,15 @@ int reconstruct_reference_tree(pdmpc_handle* h, int vehicle, uint32_t raw_n, Ref
         for (uint32_t i = 0; i < raw_n; ++i)
             if (alive[i] && vs[i] == 1 && depth(i) == Hp && (goal < 0 || before(i, (uint32_t)goal) < 0)) goal = i;
     T.pops.clear();
-    for (uint32_t i = 0; i < raw_n; ++i)
-        if (alive[i] && (goal < 0 || i == (uint32_t)goal || before(i, (uint32_t)goal) < 0)) T.pops.push_back(i);
-    std::sort(T.pops.begin(), T.pops.end(), [&](uint32_t x, uint32_t y) { return before(x, y) < 0; });
+    if (replayed) {
+        // equal keys: the order is the binary heap's, which the kernel's replay has run (bulk_search.hpp, bk_replay) and left behind
+        T.pops.resize((size_t)std::max(out.n_popped, 0));
+        if (!T.pops.empty()) HIPCHK(hipMemcpy(T.pops.data(), h->amidi.p + off, T.pops.size() * 4, hipMemcpyDeviceToHost));
+    } else {
+        for (uint32_t i = 0; i < raw_n; ++i)
+            if (alive[i] && (goal < 0 || i == (uint32_t)goal || before(i, (uint32_t)goal) < 0)) T.pops.push_back(i);
+        std::sort(T.pops.begin(), T.pops.end(), [&](uint32_t x, uint32_t y) { return before(x, y) < 0; });
+    }
     // children of a node are consecutive raw indices in ascending trim order
     std::vector<uint32_t> first_child(raw_n, 0), n_child(raw_n, 0);
     for (uint32_t i = raw_n; i-- > 1;) {
@@ -1886,7 +1901,7 @@ int pdmpc_debug_pop_trace(pdmpc_handle* h, int32_t vehicle, int32_t capacity, in
         HIPCHK(hipMemcpy(&sz, h->d_tree_size.p + vehicle, 4, hipMemcpyDeviceToHost));
         if (sz & PDMPC_TREE_FRONTIER) {
             RefTree T;
-            int rc = reconstruct_reference_tree(h, vehicle, (uint32_t)(sz & ~PDMPC_TREE_FRONTIER), T);
+            int rc = reconstruct_reference_tree(h, vehicle, (uint32_t)PDMPC_TREE_SIZE(sz), T, (sz & PDMPC_TREE_REPLAYED) != 0);
             if (rc) return rc;
             *n = (int32_t)T.pops.size();
             for (size_t i = 0; i < T.pops.size() && (int)i < capacity; ++i) ids[i] = (int32_t)T.ref_id[T.pops[i]];
@@ -1957,7 +1972,7 @@ int pdmpc_debug_raw_tree(pdmpc_handle* h, int32_t vehicle, int32_t capacity, dou
     HIPCHK(hipStreamSynchronize(h->stream));
     int32_t sz = 0;
     HIPCHK(hipMemcpy(&sz, h->d_tree_size.p + vehicle, 4, hipMemcpyDeviceToHost));
-    sz &= ~PDMPC_TREE_FRONTIER;
+    sz = PDMPC_TREE_SIZE(sz);
     *n = sz;
     const size_t m = (size_t)std::max(std::min(sz, capacity), 0);
     if (m == 0) return PDMPC_OK;
@@ -1997,7 +2012,7 @@ int pdmpc_debug_tree(pdmpc_handle* h, int32_t vehicle, int32_t capacity, double*
     HIPCHK(hipMemcpy(&sz, h->d_tree_size.p + vehicle, 4, hipMemcpyDeviceToHost));
     if (sz & PDMPC_TREE_FRONTIER) {
         RefTree T;
-        int rc = reconstruct_reference_tree(h, vehicle, (uint32_t)(sz & ~PDMPC_TREE_FRONTIER), T);
+        int rc = reconstruct_reference_tree(h, vehicle, (uint32_t)PDMPC_TREE_SIZE(sz), T, (sz & PDMPC_TREE_REPLAYED) != 0);
         if (rc) return rc;
         *n = (int32_t)T.ref_nodes.size();
         for (size_t i = 0; i < T.ref_nodes.size() && (int)i < capacity; ++i) {

@@ -106,6 +106,11 @@ struct BkCheck {
 #define BK_FD_LO 16    // (64 bit) predecessors whose areas are in the soup and have passed the path of the finished plan, but whose re-check of the
 #define BK_FD_HI 17    //          other collision-free nodes is still to come (they stay in SH_PEND until the arrival block has seen them)
 #define BK_WAITRES 18  // result of bk_wait_done: 0 nothing yet, 1 an arrival crosses the path, 2 the last predecessor has passed: published
+#define BK_TIEMODE 20   // the search has met equal keys where the pop order decides (or PDMPC_BK_FORCE_TIE): it ends on bk_replay
+#define BK_RP_NEED 21   // bk_replay: a node (1-based) the reference's heap pops that no round has evaluated (0: none)
+#define BK_RP_GOAL 22   // ... the goal it ended on (1-based arena index, 0: exhausted)
+#define BK_RP_NPOP 23   // ... nodes popped
+#define BK_RP_NREF 24   // ... nodes of the reference's tree
 #define BK_PUBLISHED 19 // the done flag is out (bk_wait_done): the areas of the record in HBM are final and may be read; only counts and ids may still be written
 
 // copies the expected areas of the predecessors in `who` into their soup slots
@@ -648,7 +653,9 @@ __device__ int bk_classify_wave(const unsigned long long* glink, ulonglong2* wal
     const double thr = gp_mp[dJ];
     int res = 1;
     if (a != 0u && !onp) {
-        res = dead ? 4 : ((have_goal && !(M < thr)) ? 3 : 1);
+        // (equal maxima: the order depends on the reference's binary heap — the node is processed, so that the replay of a tied search
+        // finds everything the heap can pop evaluated, and the search is marked: FRF_TIE -> BK_TIEMODE)
+        res = dead ? 4 : ((have_goal && M > thr) ? 3 : 1);
         if (!dead && have_goal && M == thr) atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_TIE);
     }
     if (a != 0u && res == 1) {  // (it will be processed: its children look here)
@@ -770,6 +777,98 @@ __device__ __noinline__ void bk_far_select(const Frontier& F, uint32_t fill, int
     fr_select2(F, fill, fill, FR_SEL_BIN, FR_SEL_BIN, lane);
 }
 
+// The end of a search that met equal keys where the pop order decides (GraphSearch.m:53-107 on priority_queue_interface_mex.cpp:19-31:
+// which of two equal keys std::priority_queue pops first follows from the layout of its binary heap, not from any property of the
+// nodes).  The rounds have evaluated every node the heap can possibly pop before the goal; here ONE wavefront pops that tree once more
+// through the libstdc++-faithful heap (heap_queue.hpp: entries = (arena index, key), LDS for the first `hl` entries, the far list's
+// arrays beyond), in the reference's own sequence: pop, discard what collides (GraphSearch.m:75-77), stop at the first collision-free
+// node at the horizon (:81-90), else push the children in ascending trim order (expand_node.m:18, mex.cpp:67-72) — validity and
+// children are looked up, nothing is computed.  Leaves the goal, n_popped, the tree size, the reference's ids along the path (ref_ids,
+// X.l_path), per node its reference id (node2ref) and the pop sequence (pops) — or, in BK_RP_NEED, a node the heap popped that no
+// round has evaluated (dropped on account of a candidate that tied with the goal): the caller gives it a round and replays again.
+template <int NW>
+__device__ __forceinline__ void bk_replay(const KernelArgs& A, Ctx& X, const Frontier& F, const ExpandEnv& EE, lds_f64* heap_key, lds_u32* heap_id, uint32_t hl, uint32_t* pops, uint32_t* node2ref,
+                                          const uint32_t* child0, lds_u32* ref_ids, int lane) {
+    volatile lds_u32* sh = F.sh;
+    const VState& VS = X.VS;
+    const int Hp = X.Hp, n = EE.n, nw = NW > 0 ? NW : EE.nw;
+    Search H = X.S;
+    H.lkey = heap_key;
+    H.lid = heap_id;
+    H.HL = hl & ~1u;
+    H.gkey = F.far_key;
+    H.gid = F.far_id;
+    H.heap_len = 0;
+    H.lane = lane;
+    H.pl = make_pop_lane(lane);
+    heap_push(H, 0u, 0.0);  // pq.push(1, 0) (GraphSearch.m:45-46); the entry's id is the node's arena index
+    if (lane == 0) node2ref[0] = 1u;
+    uint32_t n_ref = 1, n_pop = 0, goal = 0, need = 0;
+    bool bug = false;
+    for (;;) {
+        if (H.heap_len == 0u) break;  // exhausted (:57-61)
+        double k0;
+        uint32_t b;
+        heap_load<true>(H, 0u, true, k0, b);
+        b = uni_u(b);
+        heap_pop(H);
+        if (lane == 0) pops[n_pop] = b;
+        n_pop += 1u;
+        const uint32_t v = uni_u(vs_load(VS, b));
+        if (v == VS_UNKNOWN || v == VS_TENT) {
+            need = b + 1u;
+            break;
+        }
+        if (v != VS_VALID) continue;  // :75-77
+        const uint64_t u = F.glink[b];
+        const uint32_t packed = uni_u((uint32_t)(u >> 32));
+        const int k = NODE_K(packed);
+        if (k == Hp) {  // :81-90
+            goal = b + 1u;
+            break;
+        }
+        const lds_mask64* mrow = EE.l_mask + ((size_t)k * n + (NODE_TRIM(packed) - 1)) * nw;
+        uint32_t cnt = 0;
+        for (int w = 0; w < nw; ++w) cnt += (uint32_t)__builtin_popcountll(mrow[w]);
+        cnt = uni_u(cnt);
+        if (cnt == 0u) continue;
+        const uint32_t c0 = uni_u(__hip_atomic_load(child0 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (c0 == 0u) {  // (collision-free and never expanded: must never happen)
+            bug = true;
+            break;
+        }
+        for (uint32_t base = 0; base < cnt; base += PDMPC_WAVE) {  // (uniform) the children, ascending trim = ascending index (Tree.m:61)
+            const uint32_t m = cnt - base < PDMPC_WAVE ? cnt - base : PDMPC_WAVE;
+            const uint32_t c = c0 - 1u + base + (uint32_t)lane;
+            double kc = 0.0;
+            if ((uint32_t)lane < m) {
+                kc = F.gkey[c];
+                node2ref[c] = n_ref + 1u + base + (uint32_t)lane;
+            }
+            for (uint32_t i = 0; i < m; ++i) heap_push(H, lane_u(c, (int)i), lane_d(kc, (int)i));
+        }
+        n_ref += cnt;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wave_sync();
+    if (goal && lane == 0) {  // path_to_root (Tree.m:44-52) in arena indices and in the reference's ids
+        uint32_t nd = goal;
+        for (int i = Hp; i >= 0; --i) {
+            X.l_path[i] = nd;
+            ref_ids[i] = __hip_atomic_load(node2ref + (nd - 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            nd = (uint32_t)(F.glink[nd - 1u] & 0xffffffffull);
+        }
+    }
+    if (lane == 0) {
+        sh[BK_RP_NEED] = need;
+        sh[BK_RP_GOAL] = goal;
+        sh[BK_RP_NPOP] = n_pop;
+        sh[BK_RP_NREF] = n_ref;
+        if (bug) sh[FR_FLAGS] = sh[FR_FLAGS] | FRF_BUG;
+        if (!need && !bug) atomicAdd(X.P.counters + 0, 1);  // (pdmpc_stats.queue_fallbacks: searches that ended on the binary heap)
+    }
+}
+
 // The search.  Returns true (to every thread) if a tie was met: the host plans the call again with the heap-carrying kernel.
 template <int NW, int CHECKER>
 __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32* ref_ids) {
@@ -857,6 +956,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         F.gkey[0] = 0.0;
         F.glink[0] = (unsigned long long)r.parent | ((unsigned long long)r.packed << 32);
         ((ulonglong2*)A.arena.walk + voff)[0].y = 0ull;
+        (A.arena.child0 + voff)[0] = 0u;
         vs_store(VS, 0, VS_UNKNOWN);
         for (int w = 26; w < SH_WORDS; ++w) sh[w] = 0;
         sh[FR_NNODES] = 1;
@@ -869,6 +969,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         sh_st_d(sh, BK_MID_MIN, inf);
         sh_st_d(sh, BK_L_MID, -1.0);
         sh[SH_NNODES] = 1;
+        sh[BK_TIEMODE] = A.bk_force_tie ? 1u : 0u;
         if (A.debug_tail == 2) sh[FR_EVER_INVAL] = 1;  // (debugging: exercise the ancestor check without arrivals)
         ready[0] = 1u;
         r_flag[0] = 0u;
@@ -1004,6 +1105,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
     bool pb_valid = false;
     bool rec_valid = false, rec_written = false;  // the result record in HBM is the one this search would publish now / some record has been written
     bool vs_copied = false;                       // the LDS validity bytes have been copied to HBM since the tree last changed
+    bool tie_replayed = false;                    // the search ended on bk_replay (its pop sequence is in the arena: pdmpc_debug_pop_trace)
     bool verify_req = false;                      // the next round boundary verifies the tree against the areas that were copied since the last verification (BK_FD)
     // shared rounds (helper workgroups)
     unsigned long long* board = A.help_board + (size_t)slot * PDMPC_HB_WORDS;
@@ -1291,6 +1393,8 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                         F.gkey[ci] = f;
                         F.glink[ci] = (unsigned long long)ch.parent | ((unsigned long long)ch.packed << 32);
                         ((ulonglong2*)A.arena.walk + voff)[ci].y = 0ull;  // (no stamp: the arena holds other searches' leftovers, see bk_classify_wave)
+                        (A.arena.child0 + voff)[ci] = 0u;                 // (no children yet)
+                        if (rank == 0u) (A.arena.child0 + voff)[i0] = ci + 1u;
                     }
                     to_near(active && !(f > l_far), f, ci + 1u);
                     to_far(active && f > l_far, f, ci + 1u);
@@ -1504,7 +1608,15 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             }
             flags = sh[FR_FLAGS];
         }
-        if (flags & FRF_TIE) return true;
+        if (flags & FRF_TIE) {  // (uniform) equal keys where the order decides: from here on the search is headed for the replay
+            __syncthreads();
+            if (tid == 0) {
+                sh[BK_TIEMODE] = 1u;
+                sh[FR_FLAGS] = sh[FR_FLAGS] & ~FRF_TIE;
+            }
+            __syncthreads();
+        }
+        const bool tie_mode = sh[BK_TIEMODE] != 0u;
         BK_TICK(tk_arrival)
 
         // the relevance tables follow the best goal candidate
@@ -1543,7 +1655,8 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         const double tent_min = n_tent ? sh_ld_d(sh, BK_TENT_MIN) : inf;
         bool done = false, stalled = false;
         if (best) {
-            if (bb == open_min || bb == tent_min) return true;  // a tie between an open node and a node of the best path
+            // (bb == open_min: a tie between an open node and a node of the best path — not finished: the round takes the entry, its
+            // classification marks the search)
             done = bb < open_min && bb < tent_min;
             stalled = bb < open_min && !done;  // nothing open comes before the candidate, but a parked node may: only an arrival tells
         } else {
@@ -1563,6 +1676,68 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             }
             BK_TICK(tk_wait)
             continue;
+        }
+        if (done && tie_mode && !dep_timeout) {
+            // A search that has met equal keys ends on the replay: its tree — every node the reference's heap can pop has been
+            // evaluated by now — is popped once more in the order of the libstdc++ heap (bk_replay), which yields the goal, the counts
+            // and the ids.  The replay wants final verdicts: every predecessor arrived and verified first.
+            if (unverified) {
+                verify_req = true;
+                continue;
+            }
+            if (sh_load64(sh, SH_PEND_LO) != 0ull) {
+                if (bk_wait()) {
+                    dep_timeout = true;
+                    status = PDMPC_EXHAUSTED;
+                    break;
+                }
+                BK_TICK(tk_wait)
+                continue;
+            }
+            __syncthreads();
+            if (tid == 0) {  // nothing that is still open can be popped before the goal (finished): the open set's room serves the heap
+                sh[FR_NEAR_N] = 0;
+                sh[FR_FAR_N] = 0;
+                sh[BK_MID_N] = 0;
+                sh_st_d(sh, FR_NEAR_MIN, inf);
+                sh_st_d(sh, FR_NEAR_MAX, 0.0);
+                sh_st_d(sh, FR_FAR_MIN, inf);
+                sh_st_d(sh, FR_FAR_MAX, 0.0);
+                sh_st_d(sh, FR_L_FAR, inf);
+                sh_st_d(sh, BK_MID_MIN, inf);
+                sh_st_d(sh, BK_L_MID, -1.0);
+            }
+            l_mid = -1.0;
+            __syncthreads();
+            if (wave == 0) bk_replay<NW>(A, X, F, EE, near_key, near_id, OC, mid_id, F.near_id, A.arena.child0 + voff, ref_ids, lane);
+            __syncthreads();
+            BK_TICK(tk_pb)
+            if (sh[FR_FLAGS] & FRF_BUG) {
+                dep_timeout = true;
+                status = PDMPC_EXHAUSTED;
+                break;
+            }
+            const uint32_t need = sh[BK_RP_NEED];
+            if (need) {  // (uniform) a node the heap pops was dropped as coming after a candidate that tied with the goal: a round of its own
+                if (tid == 0) {
+                    ready[0] = need;
+                    r_flag[0] = 0u;
+                }
+                Rn = 1;
+                __syncthreads();
+                continue;
+            }
+            goal = sh[BK_RP_GOAL];
+            if (sh[BK_PUBLISHED] != 0u && goal != best) atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_BUG);  // (the areas that went out are the candidate's: must never happen)
+            R.n_popped = sh[BK_RP_NPOP];
+            R.n_expanded = sh[BK_RP_NREF];
+            pb_valid = true;
+            rec_valid = false;
+            tie_replayed = true;
+            status = goal ? PDMPC_OK : PDMPC_EXHAUSTED;
+            __syncthreads();
+            if (sh[FR_FLAGS] & FRF_BUG) dep_timeout = true;
+            break;
         }
         if (done && unverified && !dep_timeout) {
             // Finished as far as the verified areas go.  What the successors wait for comes first: the record with the plan's areas (its
@@ -1591,7 +1766,10 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 BK_TICK(tk_pb)
                 const uint32_t pflags = sh[FR_FLAGS];
                 __syncthreads();
-                if (pflags & FRF_TIE) return true;
+                if (pflags & FRF_TIE) {  // (uniform) equal keys among the nodes in front of the goal: the counts and ids come from the replay
+                    pb_valid = false;
+                    continue;  // (the round boundary turns the flag into BK_TIEMODE)
+                }
                 if (pflags & FRF_BUG) dep_timeout = true;  // reported as an error status: must never happen
             }
             if (sh_load64(sh, SH_PEND_LO) == 0ull || dep_timeout) {
@@ -1921,7 +2099,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         atomicAdd(P.counters + 2, (int)sh[BK_ARRIVALS]);
         atomicAdd(A.work_count + 2, (unsigned long long)sh[FR_PROCESSED]);
         atomicAdd(A.work_count + 3, (unsigned long long)sh[FR_ROUNDS]);
-        A.tree_size[slot] = (int32_t)(nnodes_raw | 0x40000000u);  // marks the arena as a raw tree (api.cpp reconstructs the reference's)
+        A.tree_size[slot] = (int32_t)(nnodes_raw | 0x40000000u | (tie_replayed ? 0x20000000u : 0u));  // marks the arena as a raw tree (api.cpp reconstructs the reference's; replayed: the pop sequence is there too)
     }
     if (tid_r == 0 && A.debug_tail) {  // diagnostics in the unused tail of the record (rows HP_MAX - 2 .. HP_MAX of path_nodes); PDMPC_DEBUG_TAIL=1
         double* dbg = X.O->path_nodes[PDMPC_HP_MAX];

@@ -110,6 +110,7 @@ struct NodeArena {  // HBM arrays, per-vehicle stride = max_nodes entries
     double* mid_key;   // bulk kernel: keys and nodes of the `mid` open entries (what a heavy search refills near from; far feeds it)
     uint32_t* mid_id;
     unsigned long long* link;  // frontier kernel: parent | packed << 32 per node, eight nodes to a 64-byte line (a record's own copy shares its line with nothing the walks need)
+    uint32_t* child0;          // bulk kernel: 1-based arena index of a node's first child (its children are consecutive, ascending trim), 0 while it has none: what the replay of a tied search descends by
 };
 
 /* record status of a search that met equal keys where the pop order depends on the reference's binary heap (bulk kernel): never leaves
@@ -205,6 +206,7 @@ struct KernelArgs {
     int32_t bk_mid_min;     // a far list longer than this is not scanned by every refill of near: a band of its smallest keys is moved to mid first
     int32_t bk_mid_fill;    // ... about this many entries at a time
     int32_t bk_share_min;   // a round with at least this many entries is shared with the helper workgroups
+    int32_t bk_force_tie;    // testing only (PDMPC_BK_FORCE_TIE): every search is treated as if it had met equal keys, i.e. ends on the replay of its tree through the reference's binary heap
     int32_t bk_fast_arrival; // 1: a finished search checks an arriving predecessor's areas against its plan's path first and publishes its own areas as soon as the last one has passed (the other collision-free nodes are re-checked afterwards)
     double* bk_post;        // [slot][bk_ready_cap][3] double2: what a check item reads of the tree, posted per entry of a shared round
     int32_t speculate;  // 1: start searching before all predecessors have finished (results are identical, see arrival_sync)
