@@ -519,12 +519,12 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": tsrc,
-                "kernel": {2: "pdmpc_bulk_kernel", 1: "pdmpc_frontier_kernel"}.get(st["kernel"], "pdmpc_search_kernel"),
+                "kernel": "pdmpc_bulk_kernel",
                 "kernel_ms_avg": kernel_ms / max(n_launch, 1),
                 "algorithmic_bytes_per_launch": alg_bytes / max(n_launch, 1),
                 "launches": n_launch,
                 "lds_bytes_per_workgroup": lds_bytes,
-                "open_list": "unordered near (LDS) / far (HBM) lists, bulk-synchronous rounds of the smallest keys (bulk kernel)" if st["kernel"] == 2 else "unordered near / far lists, rounds of the smallest keys (frontier kernel)" if st["kernel"] == 1 else ("block-min queue, %d keys in LDS" % st["queue_ring_entries"] if st["queue_mode"] == 1 else "binary heap"),
+                "open_list": "unordered near (LDS) / mid / far (HBM) lists, bulk-synchronous rounds of the smallest keys; equal keys: replay through the libstdc++-faithful binary heap",
             },
             # every plan of the recorded steps by outcome; arena_overflow and error must be 0 (the reference's tree is unbounded, Tree.m:54-70)
             "status_counts": status_counts,
@@ -540,8 +540,7 @@ def main():
                 "edge_checks_per_s": st["edge_checks"] / elapsed,
                 "segment_pair_tests_per_s": st["segment_pair_tests"] / elapsed,
                 "speculation_arrivals_per_step": st["speculation_arrivals"] / args.steps,
-                "speculation_restarts_per_step": st["speculation_restarts"] / args.steps,
-                "nodes_processed_per_step": st["nodes_processed"] / args.steps,  # frontier kernel: edges evaluated; nodes_popped of them are the reference's pops
+                "nodes_processed_per_step": st["nodes_processed"] / args.steps,  # edges evaluated; nodes_popped of them are the reference's pops
                 "rounds_per_step": st["rounds"] / args.steps,
                 "shared_rounds_per_step": st["shared_rounds"] / args.steps,  # rounds whose edge checks helper workgroups took part in
                 "helper_checked_per_step": st["helper_checked"] / args.steps,

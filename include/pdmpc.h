@@ -63,7 +63,7 @@ typedef struct {
     int32_t device;       /* HIP device ordinal */
     int32_t max_nodes;    /* per-vehicle tree capacity in HBM (0 = default 32768) */
     int32_t max_vehicles; /* largest batch this handle will see (0 = default 256) */
-    int32_t trace_pops;   /* per-vehicle capacity of the debug pop trace (0 = off) */
+    int32_t trace_pops;   /* unused (kept for the layout): pdmpc_debug_pop_trace reconstructs the pop sequence from the tree */
 } pdmpc_config;
 
 /* One maneuver mpa.maneuvers{i,j} (generate_maneuver.m:25-66).  area* are [2][PDMPC_VMAX]
@@ -142,30 +142,30 @@ typedef struct {
     int64_t lds_bytes;        /* dynamic LDS per workgroup used by the launch */
     int64_t lds_nodes;        /* tree nodes resident in LDS per vehicle */
     int64_t n_launches;       /* kernel launches since the last pdmpc_pack_* (kernel_ms is their sum) */
-    int64_t queue_fallbacks;  /* searches since pdmpc_create / pdmpc_reset_stats that met a tied minimal key in the block-min
-                                 open list and were redone on the binary heap (results are identical either way) */
-    int64_t speculation_restarts; /* searches restarted because a predecessor's areas, arriving late, hit an already expanded node */
-    int64_t speculation_arrivals; /* late arrivals of predecessor areas folded into running searches (same period) */
-    int64_t queue_mode;        /* open list of the last launch: 0 binary heap, 1 block-min queue (csrc/blockmin_queue.hpp) */
-    int64_t queue_ring_entries;/* block-min queue: keys resident in LDS per vehicle */
-    int64_t edge_checks;       /* eval_edge_exact evaluations since pdmpc_create / pdmpc_reset_stats (incl. the ones done ahead of
-                                  the pop and never needed) */
+    int64_t queue_fallbacks;  /* searches since pdmpc_create / pdmpc_reset_stats that met equal keys where the pop order decides and ended
+                                 on the replay of their tree through the libstdc++-faithful binary heap (priority_queue_interface_mex.cpp:19-31) */
+    int64_t speculation_arrivals; /* verifications of a running search's tree against areas of predecessors that finished meanwhile (same period) */
+    int64_t edge_checks;       /* eval_edge_exact evaluations since pdmpc_create / pdmpc_reset_stats (incl. the ones the reference never makes) */
     int64_t segment_pair_tests;/* (area segment, obstacle segment) pairs those checks stand for: sum of (V-1)(M-1) per soup,
                                   InterX.m:63-76 (InterX checker only) */
-    int64_t speculation_wasted_pops; /* nodes popped by searches that were then restarted (block-min mode; same period) */
-    int64_t entries_dropped;         /* open-list entries known to collide that left the list without being popped (same period) ... */
-    int64_t dropped_counted_as_pops; /* ... and how many of them the reference would have popped: they are part of nodes_popped */
-    int64_t kernel;                  /* kernel of the last launch: 2 bulk (bulk-synchronous rounds), 1 frontier (one node per wavefront), 0 pop-ordered */
-    int64_t nodes_processed;         /* frontier kernel: nodes whose edge was evaluated (same period; the reference pops nodes_popped of them,
-                                        the rest is what the parallel rounds overshoot) */
-    int64_t rounds;                  /* frontier kernel: rounds (select a batch of the smallest open keys, process it) */
-    int64_t shared_rounds;           /* ... of which shared with helper workgroups (CUs the launch left idle; same period) */
-    int64_t helper_checked;          /* ... and the nodes whose edges those helpers evaluated (part of nodes_processed) */
-    int64_t safe_replans;            /* calls since pdmpc_create that were planned a second time in resident slices because a search of an
-                                        oversubscribed launch gave up waiting for a predecessor (see pdmpc_set_safe_launch) */
-    int64_t bad_status_plans;        /* plans since pdmpc_create / pdmpc_reset_stats whose record carries neither PDMPC_OK nor PDMPC_EXHAUSTED
-                                        (arena overflow, predecessor time-out), counted on the device: also covers launches nobody fetched */
+    int64_t kernel;            /* kernel of the last launch: 2 the graph search (bulk-synchronous rounds), 3 the sampled optimizer */
+    int64_t nodes_processed;   /* nodes whose edge was evaluated (same period; the reference pops nodes_popped of them, the rest is what
+                                  the parallel rounds overshoot) */
+    int64_t rounds;            /* rounds (select a batch of the smallest open keys, process it) */
+    int64_t shared_rounds;     /* ... of which shared with helper workgroups (CUs the launch left idle; same period) */
+    int64_t helper_checked;    /* ... and the nodes whose edges those helpers evaluated (part of nodes_processed) */
+    int64_t safe_replans;      /* calls since pdmpc_create that were planned a second time in resident slices because a search of an
+                                  oversubscribed launch gave up waiting for a predecessor (see pdmpc_set_safe_launch) */
+    int64_t bad_status_plans;  /* plans since pdmpc_create / pdmpc_reset_stats whose record carries neither PDMPC_OK nor PDMPC_EXHAUSTED
+                                  (arena overflow, predecessor time-out), counted on the device: also covers launches nobody fetched */
 } pdmpc_stats;
+
+/* Tuning.  The graph search's knobs (round sizes, helper workgroups, tiles, the open set's lists) and its A/B and test switches have
+ * measured defaults; ONE environment variable, read once in pdmpc_create, overrides them for benchmarking and tests:
+ *     PDMPC_TUNING="key=value,key=value,..."
+ * keys: round0 round ramp ready share_min own_div tile mid_min mid_fill (rounds and lists), tentative fast_arrival speculate helpers
+ * helpers_oversub waves (A/B switches), force_tie reverse_dispatch spin_limit (testing), debug_tail debug_lds debug_host debug_progress
+ * (diagnostics); csrc/api.cpp: struct Tuning documents each.  No setting changes a result; an unknown key fails pdmpc_create. */
 
 /* ---- life cycle (replaces GraphSearch() construction in OptimizerInterface.get_optimizer, :26-27,
  *      and the MEX instance table of priority_queue_interface_mex.cpp:48-53,111) ---- */
@@ -265,7 +265,7 @@ int pdmpc_get_last_stats(pdmpc_handle* handle, pdmpc_stats* stats);
 
 /* ---- debug / parity instrumentation (no reference counterpart: the reference keeps the whole
  *      Tree in info.tree, Tree.m:3-13; these calls read it back from HBM) ---- */
-/* node ids popped by vehicle v in order (needs config.trace_pops > 0); returns count in *n */
+/* node ids popped by vehicle v in order; returns count in *n */
 int pdmpc_debug_pop_trace(pdmpc_handle* handle, int32_t vehicle, int32_t capacity, int32_t* ids, int32_t* n);
 /* the search tree of vehicle v: arrays of length capacity, *n receives tree size */
 int pdmpc_debug_tree(pdmpc_handle* handle, int32_t vehicle, int32_t capacity, double* x, double* y,
@@ -295,13 +295,6 @@ int pdmpc_debug_progress(pdmpc_handle* handle, int32_t vehicle, uint32_t* words1
 int pdmpc_debug_heap_script(pdmpc_handle* handle, int32_t n, const int32_t* op, const int32_t* id, const double* key,
                             int32_t lds_entries, int32_t* popped, int32_t* n_popped, double* cycles_per_pop,
                             double* cycles_per_push);
-
-/* the same for the block-min open list the search uses while the minimal key is unique (csrc/blockmin_queue.hpp): ids are
- * implicit (the i-th push is node i, 1-based), ring_entries = keys kept in LDS (power of two >= 64).  *tie = 1 if some pop
- * found its minimal key twice, in which case the search would have fallen back to the binary heap. */
-int pdmpc_debug_blockmin_script(pdmpc_handle* handle, int32_t n, const int32_t* op, const double* key, int32_t ring_entries,
-                                int32_t* popped, int32_t* n_popped, int32_t* tie, double* cycles_per_pop,
-                                double* cycles_per_push);
 
 /* ---- the sampled optimizer (replaces MonteCarloTreeSearch.run_optimizer, graph_search/MonteCarloTreeSearch.m:30-35,
  *      selected by OptimizerType.MatlabSampled in OptimizerInterface.get_optimizer, OptimizerInterface.m:29-31) ----

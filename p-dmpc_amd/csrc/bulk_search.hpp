@@ -28,7 +28,7 @@
 // again with the kernel that carries the libstdc++-faithful heap (api.cpp) — no tie in any BASELINE road-network workload.
 #include <hip/hip_runtime.h>
 
-#include "serial_search.hpp"
+#include "search_common.hpp"
 
 #include "frontier_common.hpp"
 
@@ -906,10 +906,10 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
     F.ready = ready;
     F.hist = hist;
     F.goal_list = hist;
-    F.near_key = A.arena.near_key + voff;  // (HBM arrays: phase B's per-node state; near itself lives in LDS)
-    F.near_id = A.arena.near_id + voff;
-    F.far_key = A.arena.pop_log + voff;
-    F.far_id = A.arena.heap_id + voff;
+    F.near_key = A.arena.pb_key + voff;  // (HBM arrays: phase B's per-node state; near itself lives in LDS)
+    F.near_id = A.arena.pb_d + voff;
+    F.far_key = A.arena.far_key + voff;
+    F.far_id = A.arena.far_id + voff;
     F.gkey = S.gkey;
     F.glink = A.arena.link + voff;
     F.n_waves = n_waves;
@@ -1141,7 +1141,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             const bool share = A.n_helpers > 0 && Rn >= (uint32_t)A.bk_share_min && P.n_pred <= 64 && n_tiles <= 64u;  // (one bit per tile in the owner's mask)
             uint32_t own_tiles = n_tiles;
             if (share) {  // (uniform)
-                own_tiles = n_tiles / (uint32_t)A.fr_own_div > 0u ? n_tiles / (uint32_t)A.fr_own_div : 1u;
+                own_tiles = n_tiles / (uint32_t)A.own_div > 0u ? n_tiles / (uint32_t)A.own_div : 1u;
                 ++help_seq;
                 d2* post = (d2*)A.bk_post + (size_t)slot * RC * 3u;
                 for (uint32_t r = own_tiles * TILE + (uint32_t)tid; r < Rn; r += (uint32_t)bd) {
@@ -1816,7 +1816,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             const uint32_t depth_now = sh[BK_DEPTH];
             heavy = heavy || depth_now == depth_seen || sh[FR_ROUNDS] > (uint32_t)Hp + 1u;
             depth_seen = depth_now;
-            const uint32_t ramp = (uint32_t)A.bk_round0 + (heavy ? done_so_far / (uint32_t)A.fr_ramp : 0u);
+            const uint32_t ramp = (uint32_t)A.bk_round0 + (heavy ? done_so_far / (uint32_t)A.bk_ramp : 0u);
             round_target = ramp < (uint32_t)A.bk_round ? ramp : (uint32_t)A.bk_round;
         }
         // ---- near holds fewer entries than the round wants (or nothing below far's smallest key): it is topped up from far with the
@@ -2351,16 +2351,7 @@ __device__ __forceinline__ void bulk_body(const KernelArgs& A) {
     const int wave = X.wave;
     lds_u32* ref_ids = (lds_u32*)(X.lsm + A.lds.bk_misc) + 224;  // behind the chunk table (nothing else uses those words)
     const bool tie = bulk_search<NW, CHECKER>(A, X, ref_ids);
-    if (tie) {  // (uniform over the workgroup) reported with the internal status: the host plans the call again on the binary heap
-        X.status = PDMPC_INTERNAL_TIE;
-        X.n_popped = 0;
-        X.path_ready = false;
-        X.goal = 0;
-        X.nnodes = 0;
-        X.rec_valid = false;
-        X.dep_timeout = false;
-        X.published = false;
-    }
+    (void)tie;  // (equal keys are resolved inside the search: bk_replay)
     __syncthreads();
     if (wave != 0) return;
     {  // (opaque, as in the round loop: nothing derived from the lane index in the prologue is worth a register until here)
@@ -2368,9 +2359,14 @@ __device__ __forceinline__ void bulk_body(const KernelArgs& A) {
         asm volatile("" : "+v"(l__));
         X.lane = l__;
     }
-    if (!X.rec_valid) bk_write_record(A, X, X.goal, X.status, X.dep_timeout, (uint32_t)X.n_popped, X.nnodes, X.path_ready, tie ? nullptr : ref_ids, X.rec_written, X.published, X.lane);
+    if (!X.rec_valid) bk_write_record(A, X, X.goal, X.status, X.dep_timeout, (uint32_t)X.n_popped, X.nnodes, X.path_ready, ref_ids, X.rec_written, X.published, X.lane);
     bk_publish(A, X, X.status, X.dep_timeout);
-    if (X.lane == 0 && A.n_helpers > 0) atomicAdd(A.help_finished, 1u);
+    if (X.lane == 0 && A.n_helpers > 0) {
+        // (a search that left through its watchdog in the middle of a shared round: its board must not offer that round to the helpers
+        // of a later launch — the boards are not cleared between launches, api.cpp: launch_range)
+        __hip_atomic_store(A.help_board + (size_t)X.slot * PDMPC_HB_WORDS + PDMPC_HB_TICKET, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicAdd(A.help_finished, 1u);
+    }
 }
 
 }  // namespace

@@ -1,4 +1,6 @@
-// debug_kernels.hip — the collision primitives on their own (pdmpc_debug_edge_check): one wavefront per case runs the same
+// debug_kernels.hip — the graph search's building blocks on their own: the libstdc++-faithful binary heap driven by a command script
+// (pdmpc_debug_heap_script; heap_queue.hpp is what a search with equal keys ends on, bulk_search.hpp: bk_replay), and the collision
+// primitives (pdmpc_debug_edge_check): one wavefront per case runs the same
 // device functions the search kernels inline (edge_checks.hpp), so the reference's known-answer vectors
 // (tests/unittests/hlc/intersect_unittest.m:8-54) and random polygon pairs can be checked on the device directly.
 //   mode 0  InterX(a, b) with isReturnPoints = false            (graph_search/InterX.m:48-103; b may hold NaN separators)
@@ -13,6 +15,7 @@
 namespace {
 #include "wave_primitives.hpp"
 #include "search_state.hpp"
+#include "heap_queue.hpp"
 #include "edge_checks.hpp"
 }  // namespace
 
@@ -82,3 +85,65 @@ extern "C" int pdmpc_launch_edge_check(int mode, int n_cases, const int32_t* a_o
     hipLaunchKernelGGL(pdmpc_edge_check_kernel, dim3(n_cases), dim3(PDMPC_WAVE), 0, (hipStream_t)stream, mode, n_cases, a_off, a_x, a_y, b_off, b_x, b_y, hit);
     return (int)hipGetLastError();
 }
+
+// Debug/unit-test kernel: drives the device open list with a command script (op 0: push (id, key), op 1: pop) exactly
+// like oracle_pq_script drives the reference's std::priority_queue; out receives the popped ids (-1 on empty).
+// stats[0] = shader cycles spent in pops, stats[1] = number of pops, stats[2] = cycles in pushes, stats[3] = pushes.
+extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_heap_script_kernel(const int32_t* op, const int32_t* id, const double* key, int n,
+                                                                                 int32_t* out, unsigned long long* stats, double* gkey, uint32_t* gid, int HL) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Search S;
+    S.lkey = (lds_f64*)smem;
+    S.lid = (lds_u32*)(smem + (size_t)HL * 8);
+    S.gkey = gkey;
+    S.gid = gid;
+    S.HL = (uint32_t)HL;
+    S.heap_len = 0;
+    S.lane = threadIdx.x;
+    S.pl = make_pop_lane(S.lane);
+    S.ln = nullptr;
+    S.gn = nullptr;
+    S.NL = 0;
+    S.max_nodes = 0;
+    int n_out = 0;
+    unsigned long long c_pop = 0, c_push = 0, n_pop = 0, n_push = 0;
+    for (int i = 0; i < n; ++i) {
+        const int o = uni_i(op[i]);
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        if (o == 0) {
+            heap_push(S, (uint32_t)uni_i(id[i]), uni_d(key[i]));
+            c_push += __builtin_readcyclecounter() - t0;
+            ++n_push;
+        } else {
+            int32_t r = -1;
+            if (S.heap_len > 0) {
+                double k0;
+                uint32_t i0;
+                heap_load<false>(S, 0, true, k0, i0);
+                r = (int32_t)uni_u(i0);
+                heap_pop(S);
+            }
+            c_pop += __builtin_readcyclecounter() - t0;
+            ++n_pop;
+            if (S.lane == 0) out[n_out] = r;
+            ++n_out;
+        }
+    }
+    if (S.lane == 0) {
+        stats[0] = c_pop;
+        stats[1] = n_pop;
+        stats[2] = c_push;
+        stats[3] = n_push;
+    }
+}
+
+
+extern "C" int pdmpc_launch_heap_script(const int32_t* op, const int32_t* id, const double* key, int n, int32_t* out, unsigned long long* stats,
+                                        double* gkey, uint32_t* gid, int HL, void* stream) {
+    const size_t lds = (size_t)HL * 12 + 16;
+    hipError_t e = hipFuncSetAttribute((const void*)pdmpc_heap_script_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(pdmpc_heap_script_kernel, dim3(1), dim3(PDMPC_WAVE), lds, (hipStream_t)stream, op, id, key, n, out, stats, gkey, gid, HL);
+    return (int)hipGetLastError();
+}
+

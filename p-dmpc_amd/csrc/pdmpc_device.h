@@ -21,22 +21,12 @@
 #include "../../include/pdmpc.h"
 
 #define PDMPC_WAVE 64
-/* Wavefronts per vehicle (workgroup size / 64), chosen per launch: wave 0 owns the pop order; block-min mode: wave 1 expands,
- * wave 2 scouts, the others validate; heap mode: all others pre-validate.  More validators shorten the critical vehicle's
- * search (C2: 5 -> 6.87 ms, 7 -> 6.67 ms, 13 -> 6.64 ms per step) but cost throughput when the chip is full (C5). */
-#define PDMPC_WAVES_LATENCY 12    /* launches with at most one workgroup per CU */
-#define PDMPC_WAVES_CROWDED 12    /* launches with more workgroups than CUs: the build for six wavefronts per SIMD, two workgroups per CU
-                                     (measured: C4, 512 workgroups: 26.3 steps/s against 23.8 with the regular build at 10 wavefronts and 20.2
-                                     at 8; C5, 1280 workgroups: 216.7 against 198.3 with 10, 184.4 with 8, regular build 185 at 8) */
-/* Twelve wavefronts per workgroup = three per SIMD = 168 VGPRs per lane.  With sixteen (128 VGPRs) the frontier kernel spilled 44
- * VGPRs next to ~320 SGPRs held in VGPR lanes; in that regime hipcc 7.2 produced code that lost spilled values depending on
- * unrelated source changes.  At 168 the kernels spill 2-4 VGPRs, and no workload is slower (C2 753 -> 770
- * steps/s, C3 680 -> 685, C4 and C5 unchanged: their launches ran twelve wavefronts before). */
+/* Twelve wavefronts per workgroup = three per SIMD.  With sixteen (128 VGPRs) the round-3 kernel spilled 44 VGPRs next to ~320 SGPRs held
+ * in VGPR lanes, and in that regime hipcc 7.2 produced code that lost spilled values depending on unrelated source changes (DESIGN.md
+ * section 3.4); at twelve no workload is slower.  The search kernels need 139-155 VGPRs today (profiles/r05_resource_usage.txt). */
 #define PDMPC_MAX_WAVES 12
-#define PDMPC_QUEUE_HEAP 0     /* open list = libstdc++-faithful binary heap (exact for any keys) */
-#define PDMPC_QUEUE_BLOCKMIN 1 /* open list = block-min queue while the minimal key is unique, binary heap after the first tie */
 #define PDMPC_MAX_THREADS (PDMPC_WAVE * PDMPC_MAX_WAVES)
-#define PDMPC_SH_WORDS 128 /* 32-bit LDS words shared by the waves of a workgroup (state, mail boxes, counters of the frontier search) */
+#define PDMPC_SH_WORDS 128 /* 32-bit LDS words shared by the waves of a workgroup (state, counters of the search) */
 
 struct DevManPose {
     double dx, dy, dyaw;
@@ -59,68 +49,60 @@ struct DevVehicle {
     int32_t pad;
 };
 
-// One search-tree node (Tree.m:3-13 row + what the pop of this node needs), 64 bytes so a node is four
+// One search-tree node (Tree.m:3-13 row + what the check of this node's children needs), 64 bytes so a node is four
 // 16-byte accesses and the children of an expansion form one contiguous, coalesced store.
 struct NodeRec {
     double x, y, yaw, g;  // Tree.x/y/yaw/g
-    double cs, sn;        // cos/sin(yaw), filled when the node is expanded (expand_node.m:50-51); its children's
-                          // edge checks read them (GraphSearch.m:155-156)
+    double cs, sn;        // cos/sin(yaw), filled when the node is checked (expand_node.m:50-51); its children's
+                          // edge checks read them (GraphSearch.m:155-156); a goal candidate keeps its path's largest key here
     double h;             // Tree.h
     uint32_t parent;      // Tree.parent (1-based id, 0 for the root)
-    uint32_t packed;      // trim (10 bit, 1-based) | k << 10 (5 bit) | maneuver index << 15 (12 bit) | area columns << 27 (4 bit) | popped << 31
+    uint32_t packed;      // trim (10 bit, 1-based) | k << 10 (5 bit) | maneuver index << 15 (12 bit) | area columns << 27 (4 bit)
 };
 #define NODE_TRIM(p) ((int)((p) & 1023u))
 #define NODE_K(p) ((int)(((p) >> 10) & 31u))
 #define NODE_MAN(p) ((int)(((p) >> 15) & 4095u))
 #define NODE_COLS(p) ((int)(((p) >> 27) & 15u))
-#define NODE_POPPED_BIT 0x80000000u /* set by the sequencing wave when the node was popped with a valid edge */
 
-// byte offsets of the regions of the dynamic LDS allocation (all multiples of 16)
+// byte offsets of the regions of the dynamic LDS allocation (all multiples of 16; api.cpp: layout_bulk / layout_sampled)
 struct LdsLayout {
     uint32_t mask, man_index, pose, area;  // MPA tables
     uint32_t ref;                          // ref_x[16], ref_y[16], dtv[16]
-    uint32_t shape;                        // shape A [8], shape B [8] (double2)
-    uint32_t path;                         // uint32 path[HP_MAX+1] + misc scratch
+    uint32_t shape;                        // sampled optimizer: shape A [8], shape B [8] (double2) + the wave's tally
+    uint32_t path;                         // uint32 path[HP_MAX+2], soup / HDV offsets, the shared words, literal soup lengths
     uint32_t soup;                         // double2[soup_cap]
-    uint32_t cand;                         // uint32[waves][cand_cap]: compacted candidate segments of one edge check
-    uint32_t vstate;                       // uint8[NV]: validity cache (0 unknown, 1 valid, 2 invalid)
-    uint32_t expand;                       // expansion scratch: dcum[16][16], term[16][16] doubles, child xy[16] double2
-    uint32_t heap_key, heap_id;            // double[HL], uint32[HL]
-    uint32_t stage;                        // frontier kernel: NodeRec[2 * fr_stage_cap]: the records of a round's nodes and of their parents
+    uint32_t cand;                         // phase B's chunk state (12 B per thread); sampled optimizer: candidate segments of one edge check
+    uint32_t vstate;                       // uint8[NV]: validity bytes
+    uint32_t expand;                       // d_traveled table: dcum[16][16] doubles (+ the sampled optimizer's expansion scratch)
+    uint32_t tree16;                       // sampled optimizer: its tree (children, parent, trim as uint16)
     uint32_t nodes;                        // NodeRec[NL]
     uint32_t total;
-    // bulk kernel (bulk_kernel.hip)
-    uint32_t bk_near_key, bk_near_id;      // double[BK_PER * threads], uint32[BK_PER * threads]: the LDS part of the open set
+    uint32_t bk_near_key, bk_near_id;      // double[BK_PER * threads], uint32[BK_PER * threads]: the LDS part of the open set (the heap of a replay)
     uint32_t bk_ready;                     // uint32[bk_ready_cap] nodes of the round + uint32[bk_ready_cap] their collision flags
-    uint32_t bk_hist;                      // uint32[3072]: histogram [2048] | goal list [1024], collision-free nodes of the round [1024], their children's offsets [1024]
-    uint32_t bk_misc;                      // 2 KB: path tables of the best goal candidate, scan partials, chunk table, the reference's ids along the path | the selection's 256-bin histogram
+    uint32_t bk_hist;                      // uint32[3072]: refill histogram [2048] | goal list [1024], expansion groups [1024], their children's offsets [1024]
+    uint32_t bk_misc;                      // 2 KB: path tables of the best goal candidate, scan partials, chunk table, tick counters, the reference's ids along the path | the selection's 256-bin histogram
     uint32_t bk_pshape;                    // double2[Hp][VMAX] + uint32[HP_MAX]: the areas along the path of the record written last and their column counts (what an arrival is checked against first)
 };
 
 struct NodeArena {  // HBM arrays, per-vehicle stride = max_nodes entries
     NodeRec* nodes;
-    double* heap_key;
-    uint32_t* heap_id;
-    uint8_t* vstate;  // validity cache for nodes beyond the LDS-resident NV
-    double* pop_log;  // block-min mode with dropping: keys of the pops in pop order (front), drop stamps as uint32 (from the back)
-                      // frontier kernel: keys of the `far` open entries (their nodes in heap_id), phase B: a node's branch maximum
-    double* near_key;  // frontier kernel: keys and nodes of the `near` open entries
-    uint32_t* near_id;
-    double* walk;      // bulk kernel: per node, 16 bytes: what its branch to the goal candidate's path looks like (bk_classify_wave)
-    double* mid_key;   // bulk kernel: keys and nodes of the `mid` open entries (what a heavy search refills near from; far feeds it)
-    uint32_t* mid_id;
-    unsigned long long* link;  // frontier kernel: parent | packed << 32 per node, eight nodes to a 64-byte line (a record's own copy shares its line with nothing the walks need)
-    uint32_t* child0;          // bulk kernel: 1-based arena index of a node's first child (its children are consecutive, ascending trim), 0 while it has none: what the replay of a tied search descends by
+    double* key;       // open-list key f = g + h of node i (GraphSearch.m:100-102)
+    unsigned long long* link;  // parent | packed << 32 per node, eight nodes to a 64-byte line (what walks and phase B read of the tree)
+    uint8_t* vstate;   // validity bytes of the nodes beyond the LDS-resident NV (and the read-back copy of those)
+    double* far_key;   // open entries outside LDS: keys and nodes of `far`; the heap of a replay beyond its LDS part
+    uint32_t* far_id;
+    double* mid_key;   // ... and of `mid` (what a heavy search refills near from; far feeds it)
+    uint32_t* mid_id;  //     (a replay leaves its pop sequence here)
+    double* pb_key;    // phase B: a node's branch maximum
+    uint32_t* pb_d;    // phase B: where a node's branch leaves the goal's path; a replay: the node's id in the reference's tree
+    double* walk;      // per node, 16 bytes: what its branch to the goal candidate's path looks like (bk_classify_wave)
+    uint32_t* child0;  // 1-based arena index of a node's first child (its children are consecutive, ascending trim), 0 while it has none: what the replay of a tied search descends by
 };
-
-/* record status of a search that met equal keys where the pop order depends on the reference's binary heap (bulk kernel): never leaves
- * the library -- api.cpp plans the call again with the kernel that carries the libstdc++-faithful heap */
-#define PDMPC_INTERNAL_TIE 100
 
 #ifndef PDMPC_BK_PER
 #define PDMPC_BK_PER 4
 #endif
-/* bulk kernel: entries of the LDS open list per thread (a selection pass holds them in registers) */
+/* entries of the LDS open list per thread (a selection pass holds them in registers) */
 
 #define PDMPC_HELP_CAP 2048 /* entries of a round that can be shared (= the ready list's capacity) */
 #define PDMPC_HB_WORDS 8   /* 64-bit words of a board */
@@ -128,8 +110,6 @@ struct NodeArena {  // HBM arrays, per-vehicle stride = max_nodes entries
 #define PDMPC_HB_N 1
 #define PDMPC_HB_MASK 2
 #define PDMPC_HB_DONE 3
-#define PDMPC_HB_NNODES 4 /* expanding helpers: the search's node counter while a round is shared */
-#define PDMPC_HB_FLAGS 6  /* bit 0: the arena is full (set by a helper), bit 1: expand what you find collision-free (set by the owner) */
 
 struct KernelArgs {
     // MPA
@@ -152,90 +132,59 @@ struct KernelArgs {
     // arenas
     NodeArena arena;
     uint32_t max_nodes;
-    int32_t* pop_trace;
-    int32_t trace_cap;
-    int32_t* tree_size;  // per slot: nodes in the tree after the search (debug read-back)
+    int32_t* tree_size;  // per slot: nodes in the arena after the search | 0x40000000 (| 0x20000000: ended on a replay) (debug read-back)
     // LDS
     LdsLayout lds;
-    int32_t HL, NL, NV, soup_cap, cand_cap;
-    int32_t speculate_expansion;       // 1: the expander wave works ahead on the node the queue wave will most likely hand over next
-    int32_t n_waves;                   // wavefronts per vehicle of this launch (workgroup size / 64)
-    int32_t n_validators;              // validator waves that take part (block-min mode; at most n_waves - 3)
-    int32_t dense;                     // 1: launch the kernels compiled for six wavefronts per SIMD
-    int32_t crowded;                   // 1: more workgroups than compute units in this launch (idle waves sleep longer between polls)
-    int32_t queue_mode, bm_kr, bm_nb;  // PDMPC_QUEUE_*; block-min ring entries (power of two) and block count (multiple of 64)
-    int32_t drop_invalid;              // block-min mode: entries known to collide leave the open list on the side (counted as popped at the end)
-    int32_t drop_beyond_lds;           // ... also entries whose validity byte lives in HBM (nodes beyond the LDS-resident NV)
-    int32_t eager_validation;          // block-min mode: idle validator waves evaluate every node's edge in creation order
+    int32_t NL, NV, soup_cap, cand_cap;
+    int32_t n_waves;                   // wavefronts per workgroup of this launch (workgroup size / 64)
     const double* sampled_random;      // sampled optimizer: [max_vehicles][sampled_n_random] mt19937ar doubles (host-generated)
     int32_t sampled_n_random;
-    unsigned long long* work_count;    // [0] edge checks evaluated, [1] segment pairs they stand for, [2] entries dropped from the open list, [3] those counted as pops (cumulative, all vehicles)
-    int32_t* tie_count;                // [0] searches redone on the binary heap after a tied minimum, [1] speculation restarts, [2] arrivals (cumulative)
-    uint32_t* progress;    // host-mapped (pinned) words, 16 per slot: the frontier kernel's live counters, for debugging a launch that does not end (or null)
-    int32_t debug_tail;    // 1: the frontier kernel leaves its round / node counters in the unused last row of pdmpc_vehicle_out.path_nodes
-    int32_t frontier;      // 1: this launch runs the frontier kernel (frontier_kernel.hip), 0: the pop-ordered kernel (search_kernel.hip)
-    int32_t fr_round;      // frontier kernel: open entries a round aims to take (about four per wavefront)
-    int32_t fr_stage_cap;  // ... entries of a round whose records (node + parent) are staged in LDS when the round is selected
-    int32_t fr_ramp;       // ... a young search takes one entry per wavefront plus 1 / fr_ramp of the nodes processed so far
-    int32_t fr_near_fill;  // ... entries a refill moves from far to near
-    double fr_join_scale;  // ... the key range within which a wave goes on with a node's best child, as a multiple of the range the round's own entries span
-    int32_t fr_near_max;   // ... size of near beyond which its tail is moved back to far
-    int32_t fr_dive;       // ... largest round (entries) in which waves go on with best children (0: never)
-    int32_t fr_root_dive;  // ... 1: the root's round follows best children without a key limit
-    // frontier kernel, helper workgroups (blockIdx >= n_searches): CUs the launch leaves idle check edges of other workgroups' large rounds
+    unsigned long long* work_count;    // [0] edge checks evaluated, [1] segment pairs they stand for, [2] nodes processed, [3] rounds, [4] shared rounds, [5] nodes checked by helpers, [6] plans that are not planning results (cumulative, all vehicles)
+    int32_t* tie_count;                // [0] searches that ended on the binary heap (equal keys), [2] arrival events (cumulative)
+    uint32_t* progress;    // host-mapped (pinned) words, 64 per slot: live counters, for debugging a launch that does not end (or null)
+    int32_t debug_tail;    // 1: the search leaves its round / node / tick counters in the unused last rows of pdmpc_vehicle_out.path_nodes
+    // helper workgroups (blockIdx >= n_searches): CUs the launch leaves idle check tiles of other workgroups' large rounds
     int32_t n_searches;              // workgroups of this launch that run a search (the first ones)
     int32_t n_helpers;               // helper workgroups behind them (0: none)
-    int32_t fr_share_min;            // a round with at least this many entries is shared with the helpers
-    int32_t fr_own_div;              // ... of which the owner keeps 1 / fr_own_div (at least two per wavefront) for itself
-    int32_t help_chunk;              // entries a helper claims at a time (a multiple of 32: its verdict words own whole cache lines)
-    unsigned long long* help_board;  // [slot][8]: ticket = round << 32 | shared entries << 16 | next unclaimed entry, -, incorporated predecessors, entries finished by helpers
-    uint32_t* help_list;             // [slot][PDMPC_HELP_CAP] nodes of the shared part of the round
-    uint32_t* help_verdict;          // [slot][PDMPC_HELP_CAP] 1 collision-free, 2 colliding (written by helpers; a word each: a helper's run of 64 entries owns whole cache lines)
-    double* help_cs;                 // [slot][PDMPC_HELP_CAP][2] cos, sin of the yaw of the collision-free entries that will be expanded (written by helpers)
-    int32_t help_expand;             // 1: helpers also expand the entries they find collision-free
-    int32_t help_patience;           // ... polls without a new claim after which the owner closes the round and does the rest itself
-    uint32_t* help_finished;         // searches of this launch that have published their result
-    uint32_t help_fin_base;          // bulk kernel: the counter's value when the launch went out (it runs on from launch to launch: no clearing in between)
-    // bulk kernel
-    int32_t bulk;           // 1: this launch runs the bulk kernel (bulk_kernel.hip)
+    int32_t own_div;                 // the owner of a shared round starts on 1 / own_div of its tiles
+    unsigned long long* help_board;  // [slot][8]: ticket = round << 32 | tiles << 16 | next unclaimed tile, entries, incorporated predecessors, tiles finished by helpers
+    uint32_t* help_verdict;          // [slot][PDMPC_HELP_CAP] 1 collision-free, 2 colliding, 3 crosses expected areas only (written by helpers)
+    uint32_t* help_finished;         // searches that have published their result (runs on from launch to launch) ...
+    uint32_t help_fin_base;          // ... and its value when this launch went out
     int32_t bk_ready_cap;   // entries of the ready list (a round's nodes)
     int32_t bk_round0;      // nodes a round of a young search takes
     int32_t bk_round;       // ... and the most any round takes
+    int32_t bk_ramp;        // a round of a search that is no longer young grows by 1 / bk_ramp of the nodes processed so far
     int32_t bk_tentative;   // 1: predecessors that are still planning have their expected areas (the ones they publish when exhausted) in their soup slots
     int32_t bk_tile;        // entries of a tile of a shared round (what a helper workgroup claims at a time; at most 128)
     int32_t bk_mid_min;     // a far list longer than this is not scanned by every refill of near: a band of its smallest keys is moved to mid first
     int32_t bk_mid_fill;    // ... about this many entries at a time
     int32_t bk_share_min;   // a round with at least this many entries is shared with the helper workgroups
-    int32_t bk_force_tie;    // testing only (PDMPC_BK_FORCE_TIE): every search is treated as if it had met equal keys, i.e. ends on the replay of its tree through the reference's binary heap
-    int32_t bk_fast_arrival; // 1: a finished search checks an arriving predecessor's areas against its plan's path first and publishes its own areas as soon as the last one has passed (the other collision-free nodes are re-checked afterwards)
+    int32_t bk_force_tie;    // testing only: every search is treated as if it had met equal keys, i.e. ends on the replay of its tree through the reference's binary heap
+    int32_t bk_fast_arrival; // 1: a finished search checks an arriving predecessor's areas against its plan's path first and publishes its own areas as soon as the last one has passed (the other collision-free nodes are verified afterwards)
     double* bk_post;        // [slot][bk_ready_cap][3] double2: what a check item reads of the tree, posted per entry of a shared round
-    int32_t speculate;  // 1: start searching before all predecessors have finished (results are identical, see arrival_sync)
+    int32_t speculate;  // 1: start searching before all predecessors have finished (results are identical)
     uint32_t spin_limit;
-    int32_t reverse_dispatch;  // testing only (PDMPC_TEST_REVERSE_DISPATCH): workgroup b plans slot first + n_searches - 1 - b, i.e. successors are
+    int32_t reverse_dispatch;  // testing only: workgroup b plans slot first + n_searches - 1 - b, i.e. successors are
                                // dispatched before their predecessors -- the adversarial order the watchdog + resident slices must survive
 };
 
 #ifdef __cplusplus
 extern "C" {
 #endif
-// defined in search_kernel.hip; launches `count` workgroups of 64 threads on `stream`
-int pdmpc_launch_search(const KernelArgs* args, int count, void* stream);
-// defined in search_kernel.hip; runs the open-list command script on one wavefront (debug / unit test)
-int pdmpc_launch_heap_script(const int32_t* op, const int32_t* id, const double* key, int n, int32_t* out, unsigned long long* stats,
-                             double* gkey, uint32_t* gid, int HL, void* stream);
-// defined in sampled_kernel.hip: the sampled optimizer (MonteCarloTreeSearch.m), `count` workgroups of one wavefront
-int pdmpc_launch_sampled(const KernelArgs* args, int count, void* stream);
-// defined in frontier_kernel.hip: the search with all wavefronts of a workgroup working on open nodes side by side
-int pdmpc_launch_frontier(const KernelArgs* args, int count, void* stream, uint32_t* lds_high_water /* [5], kept by the handle */);
-// defined in bulk_kernel.hip: the search as bulk-synchronous passes (count searches + args->n_helpers helper workgroups in ONE launch); lds_high_water[2] = the handle's record of the dynamic LDS size set so far per kernel variant
+// bulk_kernel*.hip: the graph search as bulk-synchronous passes (count searches + args->n_helpers helper workgroups in ONE launch) for the
+// InterX checker with one successor-mask word / with any number of them, and for the separating-axis checker; lds_high_water = the
+// handle's record of the dynamic LDS size set so far on that kernel
 int pdmpc_launch_bulk(const KernelArgs* args, int count, void* stream, uint32_t* lds_high_water);
-// defined in frontier_kernel.hip; launches args->n_helpers helper workgroups (they serve the searches of a pdmpc_launch_frontier with the same args)
-int pdmpc_launch_helpers(const KernelArgs* args, void* stream, uint32_t* lds_high_water);
-// defined in debug_kernels.hip: the collision primitives of edge_checks.hpp on given polygons, one wavefront per case
+int pdmpc_launch_bulk_wide(const KernelArgs* args, int count, void* stream, uint32_t* lds_high_water);
+int pdmpc_launch_bulk_sat(const KernelArgs* args, int count, void* stream, uint32_t* lds_high_water);
+// sampled_kernel.hip: the sampled optimizer (MonteCarloTreeSearch.m), `count` workgroups of one wavefront
+int pdmpc_launch_sampled(const KernelArgs* args, int count, void* stream);
+// debug_kernels.hip: the open-list command script on one wavefront, and the collision primitives on given polygons (one wavefront per case)
+int pdmpc_launch_heap_script(const int32_t* op, const int32_t* id, const double* key, int n, int32_t* out, unsigned long long* stats, double* gkey, uint32_t* gid, int HL,
+                             void* stream);
 int pdmpc_launch_edge_check(int mode, int n_cases, const int32_t* a_off, const double* a_x, const double* a_y, const int32_t* b_off, const double* b_x,
                             const double* b_y, int32_t* hit, void* stream);
-int pdmpc_launch_bm_script(const int32_t* op, const double* key, int n, int32_t* out, unsigned long long* stats, double* gkey, int KR, int NB,
-                           void* stream);
 #ifdef __cplusplus
 }
 #endif

@@ -72,7 +72,7 @@ extern "C" __global__ __launch_bounds__(PDMPC_WAVE) void pdmpc_sampled_kernel(co
     lds_i32* l_soff = (lds_i32*)(l_path + PDMPC_HP_MAX + 2);
     lds_i32* l_hoff = l_soff + PDMPC_HP_MAX + 1;
     lds_d2* l_soup = (lds_d2*)(lsm + A.lds.soup);
-    LDS_AS uint16_t* t_child = (LDS_AS uint16_t*)(lsm + A.lds.heap_key);  // [MCTS_NODE_CAP][MCTS_FANOUT]: children(:, node)
+    LDS_AS uint16_t* t_child = (LDS_AS uint16_t*)(lsm + A.lds.tree16);  // [MCTS_NODE_CAP][MCTS_FANOUT]: children(:, node)
     LDS_AS uint16_t* t_parent = t_child + MCTS_NODE_CAP * MCTS_FANOUT;   // [MCTS_NODE_CAP]
     LDS_AS uint16_t* t_trim = t_parent + MCTS_NODE_CAP;                  // [MCTS_NODE_CAP]
 

@@ -79,12 +79,6 @@ __device__ __forceinline__ void node_store_cs(const Search& S, uint32_t i0, doub
     ((d2*)(S.gn + i0))[2] = v;
     if (i0 < S.NL) S.ln[4 * (size_t)i0 + 2] = v;
 }
-// flag the node as popped-with-a-valid-edge (only the sequencing wave writes node records after creation)
-__device__ __forceinline__ void node_mark_popped(const Search& S, uint32_t i0, uint32_t packed) {
-    const uint32_t v = packed | NODE_POPPED_BIT;
-    ((uint32_t*)(S.gn + i0))[15] = v;
-    if (i0 < S.NL) ((lds_u32*)(S.ln + 4 * (size_t)i0))[15] = v;
-}
 __device__ __forceinline__ uint32_t node_parent(const Search& S, uint32_t i0) {
     d2 v;
     if (i0 < S.NL)

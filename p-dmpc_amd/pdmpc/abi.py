@@ -114,15 +114,9 @@ class Stats(C.Structure):
         ("lds_nodes", C.c_int64),
         ("n_launches", C.c_int64),
         ("queue_fallbacks", C.c_int64),
-        ("speculation_restarts", C.c_int64),
         ("speculation_arrivals", C.c_int64),
-        ("queue_mode", C.c_int64),
-        ("queue_ring_entries", C.c_int64),
         ("edge_checks", C.c_int64),
         ("segment_pair_tests", C.c_int64),
-        ("speculation_wasted_pops", C.c_int64),
-        ("entries_dropped", C.c_int64),
-        ("dropped_counted_as_pops", C.c_int64),
         ("kernel", C.c_int64),
         ("nodes_processed", C.c_int64),
         ("rounds", C.c_int64),

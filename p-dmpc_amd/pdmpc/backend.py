@@ -45,7 +45,6 @@ EXPORTS = [
     "pdmpc_stream",
     "pdmpc_get_last_stats",
     "pdmpc_debug_heap_script",
-    "pdmpc_debug_blockmin_script",
     "pdmpc_debug_pop_trace",
     "pdmpc_debug_tree",
     "pdmpc_debug_raw_tree",
@@ -124,7 +123,6 @@ def load_library(path=None):
     L.pdmpc_plan_batch_sampled.argtypes = [H, C.c_int32, C.POINTER(abi.VehicleIn), C.POINTER(C.c_uint32), C.POINTER(abi.VehicleOut)]
     L.pdmpc_get_last_stats.argtypes = [H, C.POINTER(abi.Stats)]
     L.pdmpc_debug_heap_script.argtypes = [H, C.c_int32, abi.c_int32_p, abi.c_int32_p, abi.c_double_p, C.c_int32, abi.c_int32_p, abi.c_int32_p, abi.c_double_p, abi.c_double_p]
-    L.pdmpc_debug_blockmin_script.argtypes = [H, C.c_int32, abi.c_int32_p, abi.c_double_p, C.c_int32, abi.c_int32_p, abi.c_int32_p, abi.c_int32_p, abi.c_double_p, abi.c_double_p]
     L.pdmpc_debug_pop_trace.argtypes = [H, C.c_int32, C.c_int32, abi.c_int32_p, abi.c_int32_p]
     L.pdmpc_debug_tree.argtypes = [H, C.c_int32, C.c_int32] + [abi.c_double_p] * 5 + [abi.c_int32_p] * 4
     L.pdmpc_debug_raw_tree.argtypes = [H, C.c_int32, C.c_int32] + [abi.c_double_p] * 5 + [abi.c_int32_p] * 3 + [abi.c_double_p, abi.c_uint8_p, abi.c_int32_p]
@@ -356,21 +354,6 @@ class Handle:
             "pdmpc_debug_heap_script",
         )
         return out[: n.value].copy(), cp.value, cq.value
-
-    def blockmin_script(self, ops, keys, ring_entries=8192):
-        """Run a push/pop script on the block-min open list -> (popped ids, tie seen, cycles per pop, cycles per push)."""
-        ops = np.ascontiguousarray(ops, dtype=np.int32)
-        keys = np.ascontiguousarray(keys, dtype=np.float64)
-        out = np.zeros(max(len(ops), 1), dtype=np.int32)
-        n, tie = C.c_int32(), C.c_int32()
-        cp, cq = C.c_double(), C.c_double()
-        _check(
-            self.L,
-            self.L.pdmpc_debug_blockmin_script(self.h, len(ops), ops.ctypes.data_as(abi.c_int32_p), keys.ctypes.data_as(abi.c_double_p), ring_entries,
-                                               out.ctypes.data_as(abi.c_int32_p), C.byref(n), C.byref(tie), C.byref(cp), C.byref(cq)),
-            "pdmpc_debug_blockmin_script",
-        )
-        return out[: n.value].copy(), bool(tie.value), cp.value, cq.value
 
     def pop_trace(self, vehicle, capacity=1 << 16):
         ids = np.zeros(capacity, dtype=np.int32)

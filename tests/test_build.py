@@ -10,24 +10,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "p-dmpc_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
+SEARCH_KERNELS = ("pdmpc_bulk_kernel", "pdmpc_bulk_kernel_wide", "pdmpc_bulk_kernel_sat")
 
-@pytest.mark.timeout(600)
-@pytest.mark.parametrize("source,kernels", [
-    ("bulk_kernel.hip", ("pdmpc_bulk_kernel",)),
-    ("frontier_kernel.hip", ("pdmpc_frontier_kernel", "pdmpc_frontier_kernel_sat", "pdmpc_frontier_kernel_wide", "pdmpc_frontier_kernel_sat_wide", "pdmpc_helper_kernel")),
-])
-def test_round_based_kernels_use_no_scratch_memory_and_spill_no_vgprs(source, kernels):
-    """the product's search kernels (bulk: InterX; frontier: SAT and the tie fallback) and their helper kernels
-    fit their register budget (168 VGPRs at twelve wavefronts per workgroup) without a byte of scratch memory.  The AMDGPU inliner gives up on functions of more than
-    1100 basic blocks (the Makefile raises that limit); a search function left out of line takes the search context through the stack,
-    so the build is checked."""
+
+@pytest.mark.timeout(900)
+def test_search_kernels_use_no_scratch_memory_and_spill_no_vgprs():
+    """the three instantiations of the graph search (InterX with one successor-mask word, InterX with any
+    number, the separating-axis checker) fit the register budget of a twelve-wavefront workgroup (168 VGPRs) without a byte of
+    scratch memory.  `make resources` compiles every kernel with the flags of the build (the inliner's basic-block limit raised, no
+    machine LICM for the search) and prints the compiler's resource remarks."""
     if not os.path.exists(HIPCC) and shutil.which("hipcc") is None:
         pytest.skip("no hipcc")
-    cmd = [HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-           "-mllvm", "-amdgpu-inline-max-bb=10000",  # (as csrc/Makefile)
-           *(["-mllvm", "-disable-machine-licm"] if source == "bulk_kernel.hip" else []),  # (BULK_FLAGS of csrc/Makefile)
-           "-I" + os.path.join(ROOT, "include"), "-c", "-Rpass-analysis=kernel-resource-usage", "-o", os.devnull, os.path.join(CSRC, source)]
-    out = subprocess.run(cmd, capture_output=True, text=True, check=True).stderr
+    out = subprocess.run(["make", "-s", "-C", CSRC, "resources"], capture_output=True, text=True, check=True).stdout
     seen = {}
     name = None
     for line in out.splitlines():
@@ -39,7 +33,13 @@ def test_round_based_kernels_use_no_scratch_memory_and_spill_no_vgprs(source, ke
             m = re.search(pat, line)
             if m and name:
                 seen[name][key] = int(m.group(1))
-    for kernel in kernels:
+    for kernel in SEARCH_KERNELS:
         assert kernel in seen, seen.keys()
         assert seen[kernel]["scratch"] == 0 and seen[kernel]["vgpr_spill"] == 0, (kernel, seen[kernel])
         assert seen[kernel]["vgprs"] <= 168, (kernel, seen[kernel])
+
+
+def test_no_legacy_search_kernels_are_shipped():
+    """One product kernel: the pop-ordered kernel of round 1 and the one-node-per-wavefront kernel of rounds 2-3 are gone."""
+    for name in ("serial_search.hpp", "search_kernel.hip", "frontier_kernel.hip", "blockmin_queue.hpp"):
+        assert not os.path.exists(os.path.join(CSRC, name)), name

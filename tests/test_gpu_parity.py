@@ -37,14 +37,16 @@ def assert_records_equal(gpu, ref, ctx=""):
 
 def compare_tree_and_pops(h, v, trace, pops=True):
     """Pop sequence and whole search tree of vehicle v against the oracle's.  Where two popped nodes carry the same key the
-    reference's order is that of its binary heap; the frontier kernel only reproduces it where it decides the result (it
-    then falls back to the heap search), so for such searches the pop sequence and the tree are compared as sets."""
+    reference's order is that of its binary heap; the kernel only reproduces it where it decides the result (the search then ends
+    on the replay through the libstdc++-faithful heap, which leaves the exact pop sequence behind), so for searches with tied pops
+    the pop sequence and the tree are compared as sets — unless every search is replayed (PDMPC_TUNING=force_tie=1): then the order
+    is the heap's and is compared as such."""
     cap = 1 << 16
     if len(trace.tree["x"]) >= cap or len(trace.pops) >= cap:
         # the oracle's trace is cut at its capacity: counts only (the records, incl. the ids along the path, are compared by the caller)
         assert len(h.tree(v, capacity=cap)["x"]) == cap or len(h.pop_trace(v, capacity=cap)) == cap
         return
-    tied = problems.tied_pops(trace) > 0
+    tied = problems.tied_pops(trace) > 0 and "force_tie=1" not in os.environ.get("PDMPC_TUNING", "")
     if pops:
         got = h.pop_trace(v, capacity=cap)
         want = trace.pops[:cap]
@@ -57,7 +59,7 @@ def compare_tree_and_pops(h, v, trace, pops=True):
     n = min(len(trace.tree["x"]), cap)
     assert len(tree["x"]) == n
     if tied:
-        # Tied keys: the creation order of the reference's tree follows its binary heap, which the frontier kernel only reproduces
+        # Tied keys: the creation order of the reference's tree follows its binary heap, which the kernel only reproduces
         # where it decides the result.  The trees are then compared as sets of NODES (not of independent per-field multisets): rows
         # (x, y, yaw, g, h, trim, k) sorted lexicographically, and the parent links through the sort -- a node's parent must be the
         # same node (same row) on both sides.
@@ -270,8 +272,9 @@ def test_sat_without_obstacles_or_boundary_is_the_greedy_chain():
 
 @pytest.mark.parametrize("mode,Hp,block_x", [("interx", 6, 0.5), ("interx", 8, 0.9), ("sat", 6, 0.9)])
 def test_tied_minimal_keys_fall_back_to_the_binary_heap(mode, Hp, block_x):
-    """Mirror-symmetric searches pop tied minima all the time: the block-min open list must notice, and the result must
-    still be the reference's (pop sequence and tree included), now produced by the libstdc++-faithful heap."""
+    """Mirror-symmetric searches pop tied minima all the time: the search must notice where the order decides, and the result must
+    still be the reference's (pop sequence and tree included) — produced by the replay of its tree through the libstdc++-faithful
+    heap, in the same launch, by the product's kernel."""
     options = problems.make_options(mode, Hp=Hp)
     mpa = problems.get_mpa(options)
     sym = problems.symmetric_problem(options, mpa, block_x=block_x)
@@ -280,7 +283,7 @@ def test_tied_minimal_keys_fall_back_to_the_binary_heap(mode, Hp, block_x):
     rng = np.random.default_rng(11)
     ordinary = [problems.road_problem(rng, options, mpa, convex=(mode == "sat")) for _ in range(3)]
     gpu, stats = check_batch(options, mpa, [ordinary[0], sym, ordinary[1], sym, ordinary[2]])
-    assert stats["queue_fallbacks"] >= 2
+    assert stats["queue_fallbacks"] >= 2 and stats["kernel"] == 2
     assert np.array_equal(gpu[1:2].tobytes(), gpu[3:4].tobytes())
 
 
@@ -291,82 +294,62 @@ def test_random_road_problems_never_fall_back():
 
 
 @pytest.mark.parametrize(
-    "env",
+    "tuning",
     [
-        {"PDMPC_QUEUE": "0", "PDMPC_KERNEL": "serial"},
-        {"PDMPC_SPEC_EXPAND": "0", "PDMPC_KERNEL": "serial"},
-        {"PDMPC_SPECULATE": "0"},
-        {"PDMPC_BM_RING": "512", "PDMPC_NV_MAX": "1024", "PDMPC_KERNEL": "serial"},
-        {"PDMPC_DROP": "0", "PDMPC_KERNEL": "serial"},
-        {"PDMPC_DROP": "1", "PDMPC_EAGER": "0", "PDMPC_KERNEL": "serial"},
-        {"PDMPC_WAVES": "8"},
-        {"PDMPC_WAVES": "5", "PDMPC_VALIDATORS": "1", "PDMPC_KERNEL": "serial"},
-        {"PDMPC_DENSE": "1", "PDMPC_WAVES": "12", "PDMPC_KERNEL": "serial"},
-        {"PDMPC_NV_MAX": "1024", "PDMPC_DROP_BEYOND_LDS": "0", "PDMPC_KERNEL": "serial"},
-        {"PDMPC_KERNEL": "serial"},
-        {"PDMPC_NV_MAX": "1024"},
-        {"PDMPC_FR_ROUND": "1"},
-        {"PDMPC_FR_ROUND": "1000"},
-        {"PDMPC_FR_NEAR_FILL": "64", "PDMPC_FR_NEAR_MAX": "256"},
-        {"PDMPC_FR_NEAR_FILL": "64", "PDMPC_FR_NEAR_MAX": "256", "PDMPC_FR_ROUND": "7", "PDMPC_WAVES": "5"},
-        {"PDMPC_FR_DIVE": "0"},
-        {"PDMPC_FR_JOIN_SCALE": "1000"},
-        {"PDMPC_FR_JOIN_SCALE": "0.25", "PDMPC_FR_DIVE": "16"},
-        {"PDMPC_FR_TWO_PER_CU": "1", "PDMPC_WAVES": "8"},
-        {"PDMPC_HELPERS": "0"},
-        {"PDMPC_HELPERS": "3", "PDMPC_FR_SHARE_MIN": "64", "PDMPC_HELP_CHUNK": "32"},
-        {"PDMPC_HELPERS": "200", "PDMPC_FR_SHARE_MIN": "64", "PDMPC_FR_OWN_DIV": "2"},
-        {"PDMPC_FR_SHARE_MIN": "64", "PDMPC_FR_OWN_DIV": "64", "PDMPC_HELP_CHUNK": "128"},
-        {"PDMPC_HELP_EXPAND": "0", "PDMPC_FR_SHARE_MIN": "64"},
-        {"PDMPC_HELP_PATIENCE": "0", "PDMPC_FR_SHARE_MIN": "64"},
-        {"PDMPC_FR_ROOT_DIVE": "1"},
-        {"PDMPC_HELP_PATIENCE": "200", "PDMPC_HELPERS": "2", "PDMPC_FR_SHARE_MIN": "64", "PDMPC_HELP_CHUNK": "128"},
-        {"PDMPC_KERNEL": "frontier"},
-        {"PDMPC_KERNEL": "frontier", "PDMPC_FR_SHARE_MIN": "64", "PDMPC_HELP_EXPAND": "0"},
-        {"PDMPC_BK_ROUND0": "1", "PDMPC_BK_RAMP": "16"},
-        {"PDMPC_BK_ROUND0": "200", "PDMPC_BK_ROUND": "512", "PDMPC_BK_RAMP": "1"},
-        {"PDMPC_BK_ROUND0": "1000", "PDMPC_BK_ROUND": "1000", "PDMPC_BK_RAMP": "1", "PDMPC_BK_SHARE_MIN": "64", "PDMPC_BK_TILE": "32"},  # rounds of up to two thousand nodes, most of them shared
-        {"PDMPC_BK_TENTATIVE": "0"},
-        {"PDMPC_BK_READY": "256", "PDMPC_BK_ROUND0": "300", "PDMPC_HELPERS": "0"},  # a ready list smaller than what a round wants: the rest waits in far
-        {"PDMPC_BK_MID_MIN": "0", "PDMPC_BK_MID_FILL": "256"},  # every far list feeds near through the mid list, a few hundred entries at a time
-        {"PDMPC_BK_MID_MIN": "100", "PDMPC_BK_MID_FILL": "1000", "PDMPC_BK_ROUND0": "300", "PDMPC_BK_TENTATIVE": "0"},
+        "speculate=0",
+        "waves=8",
+        "waves=5,round0=7",
+        "helpers=0",
+        "helpers=3,share_min=64,tile=32",
+        "helpers=200,share_min=64,own_div=2",
+        "share_min=64,own_div=64,tile=128",
+        "round0=1,ramp=16",
+        "round0=200,round=512,ramp=1",
+        "round0=1000,round=1000,ramp=1,share_min=64,tile=32",  # rounds of up to two thousand nodes, most of them shared
+        "tentative=0",
+        "fast_arrival=0",
+        "ready=256,round0=300,helpers=0",  # a ready list smaller than what a round wants: the rest waits in far
+        "mid_min=0,mid_fill=256",  # every far list feeds near through the mid list, a few hundred entries at a time
+        "mid_min=100,mid_fill=1000,round0=300,tentative=0",
+        "force_tie=1",  # every search ends on the replay through the libstdc++-faithful heap
+        "force_tie=1,round0=300,share_min=64",
     ],
 )
-def test_tuning_switches_do_not_change_results(env, monkeypatch):
-    """The binary-heap mode, the pipeline without speculative expansion, no speculative step planning, and a starved LDS
-    layout (small key ring: old blocks come from HBM; small validity cache: verdicts in HBM) all give the reference's
-    records, pop sequences and trees."""
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+def test_tuning_switches_do_not_change_results(tuning, monkeypatch):
+    """Round sizes, helper workgroups, tile sizes, the open set's lists, expected areas, the early publication, the number of
+    wavefronts, and the replay through the binary heap for every search (PDMPC_TUNING, include/pdmpc.h): all give the reference's
+    records, pop sequences and trees, with both checkers."""
+    monkeypatch.setenv("PDMPC_TUNING", tuning)
     options, mpa, iters = problems.problem_set("interx", 5, 12, Hp=7)
     check_batch(options, mpa, iters)
     options, mpa, iters = problems.problem_set("sat", 6, 6, Hp=6)
     check_batch(options, mpa, iters)
 
 
-def test_helper_workgroups_take_part_and_change_nothing():
-    """Large rounds are shared with helper workgroups on the CUs the launch leaves idle (frontier_kernel.hip, helper_body): they
-    check edges for the searches and the records stay those of the oracle — here with the threshold low enough that most rounds
-    of the heavier searches are shared, and the statistics say so."""
-    os.environ["PDMPC_FR_SHARE_MIN"] = "64"
-    os.environ["PDMPC_KERNEL"] = "frontier"  # (the helper kernel serves the frontier kernel's rounds)
-    try:
-        for seed in (2, 5):
-            options, mpa, iters = problems.problem_set("interx", seed, 24, Hp=6)
-            gpu, stats = check_batch(options, mpa, iters)
-            assert stats["shared_rounds"] > 0 and stats["helper_checked"] > 0, stats
-            assert stats["helper_checked"] < stats["nodes_processed"]
-    finally:
-        del os.environ["PDMPC_FR_SHARE_MIN"]
-        del os.environ["PDMPC_KERNEL"]
+def test_unknown_tuning_key_is_an_error(monkeypatch):
+    monkeypatch.setenv("PDMPC_TUNING", "round0=24,no_such_knob=1")
+    options = problems.make_options("interx", Hp=6)
+    with pytest.raises(Exception):
+        Handle(options)
+
+
+def test_helper_workgroups_take_part_and_change_nothing(monkeypatch):
+    """Large rounds are shared with helper workgroups on the CUs the launch leaves idle (bulk_search.hpp, bulk_helper_body): they
+    check tiles of the searches' rounds and the records stay those of the oracle — here with the threshold low enough that most rounds
+    of the heavier searches are shared, with both checkers, and the statistics say so."""
+    monkeypatch.setenv("PDMPC_TUNING", "share_min=64,round0=128,tile=32")
+    for mode, seed in (("interx", 2), ("interx", 5), ("sat", 3)):
+        options, mpa, iters = problems.problem_set(mode, seed, 24, Hp=6)
+        gpu, stats = check_batch(options, mpa, iters)
+        assert stats["kernel"] == 2
+        assert stats["shared_rounds"] > 0 and stats["helper_checked"] > 0, stats
+        assert stats["helper_checked"] < stats["nodes_processed"]
 
 
 def test_arena_growth_with_shared_rounds(monkeypatch):
-    """Helper workgroups allocate node indices too: a run of theirs that does not fit reports it (verdict 4, the board's flag),
-    the search ends with PDMPC_ARENA_OVERFLOW and the call is planned again with doubled arenas — from 256 nodes up, with most
-    rounds shared, until every search fits; the records are the oracle's."""
-    monkeypatch.setenv("PDMPC_FR_SHARE_MIN", "64")
-    monkeypatch.setenv("PDMPC_KERNEL", "frontier")
+    """A search that outgrows its arena ends with PDMPC_ARENA_OVERFLOW and the call is planned again with doubled arenas — from 256
+    nodes up, with most rounds shared with helper workgroups, until every search fits; the records are the oracle's."""
+    monkeypatch.setenv("PDMPC_TUNING", "share_min=64,round0=128")
     options, mpa, iters = problems.problem_set("interx", 2, 24, Hp=6)
     oracle = _oracle()
     options.max_nodes = 1 << 22

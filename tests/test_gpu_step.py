@@ -253,13 +253,10 @@ def test_c4_resident_banks_replayed_without_the_safety_net():
     h.close()
 
 
-@pytest.mark.parametrize("n_instances,two_per_cu", [(12, False), (64, False), (64, True)])
-def test_explorative_batch_of_prioritizations_one_launch(n_instances, two_per_cu, monkeypatch):
+@pytest.mark.parametrize("n_instances", [12, 64])
+def test_explorative_batch_of_prioritizations_one_launch(n_instances):
     """BASELINE config 4 (64 instances = the config as named): several prioritizations of the same traffic state flattened
-    into one launch (PrioritizedExplorativeController.m:25-176), records identical to the oracle, same chosen prioritization.
-    Third case: the layout with two workgroups of six wavefronts per CU (PDMPC_BK_TWO_PER_CU=1; measured and off by default)."""
-    if two_per_cu:
-        monkeypatch.setenv("PDMPC_BK_TWO_PER_CU", "1")
+    into one launch (PrioritizedExplorativeController.m:25-176), records identical to the oracle, same chosen prioritization."""
     from oracle import oracle
     from pdmpc.explorative import build_exploration_batch, choose_solution
     from pdmpc.optimizer import GraphSearchHip
@@ -313,9 +310,7 @@ def test_fallback_while_a_predecessor_is_still_planning():
         gpu = opt.handle.fetch(3)
         ref, _ = oracle.plan_step(options, mpa, prob)
         assert_records_equal(gpu, ref, "fallback under speculation")
-        # (the pop-ordered kernel falls back at the first tied pop; the frontier kernel only where a tie decides the result)
-        if os.environ.get("PDMPC_KERNEL") == "serial":
-            assert opt.handle.stats()["queue_fallbacks"] >= 1
+        assert opt.handle.stats()["kernel"] == 2
     finally:
         opt.handle.close()
 
@@ -477,16 +472,15 @@ def test_batch_not_in_level_order_is_reordered_by_the_library():
 
 
 def test_starved_predecessors_are_replanned_in_resident_slices(monkeypatch):
-    """Forward progress of oversubscribed launches.  PDMPC_TEST_REVERSE_DISPATCH hands the slots out in reverse workgroup order:
+    """Forward progress of oversubscribed launches.  PDMPC_TUNING=reverse_dispatch=1 hands the slots out in reverse workgroup order:
     the successors occupy the chip and spin for predecessors that have not been dispatched -- the adversarial order.  With a
-    small PDMPC_SPIN_LIMIT the watchdog ends them with an error status; pdmpc_plan_step then plans the step again in slices that
+    small spin_limit the watchdog ends them with an error status; pdmpc_plan_step then plans the step again in slices that
     are resident as a whole and the records are the oracle's."""
     from oracle import oracle
     from pdmpc.optimizer import GraphSearchHip
     from pdmpc.road_network import boundary_provider, commonroad_scenario
 
-    monkeypatch.setenv("PDMPC_TEST_REVERSE_DISPATCH", "1")
-    monkeypatch.setenv("PDMPC_SPIN_LIMIT", "20000")
+    monkeypatch.setenv("PDMPC_TUNING", "reverse_dispatch=1,spin_limit=20000")
     options = Config(scenario_type=ScenarioType.commonroad, amount=320, Hp=6, max_vehicles=320, max_nodes=1 << 14)
     mpa = get_mpa(options)
     sc = commonroad_scenario(options, seed=1, tiles=16)
@@ -627,25 +621,27 @@ def test_bulk_kernel_shares_large_rounds_and_parks_tentative_nodes(monkeypatch):
         sc = commonroad_scenario(options, seed=1)
         return run_closed_loop(options, sc, "distance", boundary_provider(sc), 30).handle_stats
 
-    monkeypatch.setenv("PDMPC_BK_SHARE_MIN", "64")
-    monkeypatch.setenv("PDMPC_BK_TILE", "32")
+    monkeypatch.setenv("PDMPC_TUNING", "share_min=64,tile=32")
     stats = loop()
     assert stats["kernel"] == 2
     assert stats["shared_rounds"] > 0 and 0 < stats["helper_checked"] < stats["nodes_processed"]
-    monkeypatch.setenv("PDMPC_BK_TENTATIVE", "0")
-    monkeypatch.setenv("PDMPC_HELPERS", "0")
+    monkeypatch.setenv("PDMPC_TUNING", "share_min=64,tile=32,tentative=0,helpers=0")
     stats = loop()
     assert stats["kernel"] == 2 and stats["shared_rounds"] == 0
+    # ... without the early publication of a finished search's areas
+    monkeypatch.setenv("PDMPC_TUNING", "fast_arrival=0")
+    stats = loop()
+    assert stats["kernel"] == 2
     # ... and with the mid list in the way of every far list of more than 512 entries (the default keeps it for lists of 24 k and more)
-    monkeypatch.delenv("PDMPC_HELPERS")
-    monkeypatch.delenv("PDMPC_BK_TENTATIVE")
-    monkeypatch.setenv("PDMPC_BK_MID_MIN", "512")
-    monkeypatch.setenv("PDMPC_BK_MID_FILL", "2048")
+    monkeypatch.setenv("PDMPC_TUNING", "share_min=64,tile=32,mid_min=512,mid_fill=2048")
     stats = loop()
     assert stats["kernel"] == 2
     # ... and with it in the way of EVERY far list, a few hundred entries at a time: arrivals, invalidated nodes and reopened open sets all
     # meet a mid list
-    monkeypatch.setenv("PDMPC_BK_MID_MIN", "0")
-    monkeypatch.setenv("PDMPC_BK_MID_FILL", "256")
+    monkeypatch.setenv("PDMPC_TUNING", "share_min=64,tile=32,mid_min=0,mid_fill=256")
     stats = loop()
     assert stats["kernel"] == 2
+    # ... and with every search sent through the replay on the binary heap (what a search with equal keys ends on)
+    monkeypatch.setenv("PDMPC_TUNING", "force_tie=1")
+    stats = loop()
+    assert stats["kernel"] == 2 and stats["queue_fallbacks"] > 0
