@@ -216,23 +216,29 @@ __device__ __forceinline__ void bk_check_items(const BkCheck& C, const Src& src,
         }
         const lds_d2* q = C.l_soup + base + t0;
         if (CHECKER == PDMPC_CHECK_SAT) {
-            bool hit = false;
+            uint32_t fnd = 0;  // 1: overlaps a real area, 2: an expected one (the slot of a predecessor that is still planning, `pend`)
             if (which == 0) {  // the polygons that begin in this chunk of the step's soup ([polygon, NaN] ..., then the predecessors' slots)
-                for (int t = 0; t < tn && !hit; ++t) {
+                const int lit = C.l_lit[k - 1];
+                for (int t = 0; t < tn && !(fnd & 1u); ++t) {
                     const int j = t0 + t;
-                    const bool start = !is_nan(q[t].x) && (j == 0 || is_nan(C.l_soup[base + j - 1].x));
+                    // (a predecessor's slot begins a polygon of its own: its first column follows the last column of a full slot in front of it)
+                    const bool start = !is_nan(q[t].x) && (j == 0 || is_nan(C.l_soup[base + j - 1].x) || (j >= lit && ((j - lit) & (PDMPC_VMAX - 1)) == 0));
                     if (start) {
                         int e = j + 1;
-                        while (e < M_k && !is_nan(C.l_soup[base + e].x)) ++e;
-                        hit = sat_pair_lane(pt, ncols, C.l_soup + base + j, e - j);  // intersect_sat.m:1-42
+                        const int lim = j >= lit ? j + PDMPC_VMAX - ((j - lit) & (PDMPC_VMAX - 1)) : M_k;  // (a slot ends with its VMAX columns)
+                        while (e < lim && !is_nan(C.l_soup[base + e].x)) ++e;
+                        if (sat_pair_lane(pt, ncols, C.l_soup + base + j, e - j)) {  // intersect_sat.m:1-42
+                            const bool tent = j >= lit && ((pend >> ((j - lit) >> 3)) & 1ull) != 0ull;
+                            fnd |= tent ? 2u : 1u;
+                        }
                     }
                 }
             } else {  // intersect_lanelet_boundary.m:16-54 on [left, NaN, right, NaN]
                 double min_x, max_x, min_y, max_y;
                 sat_area_bbox(pt, ncols, min_x, max_x, min_y, max_y);
-                for (int t = 0; t < tn && !hit; ++t) hit = sat_boundary_segment_lane(pt, ncols, min_x, max_x, min_y, max_y, q[t], q[t + 1]);
+                for (int t = 0; t < tn && !fnd; ++t) fnd = sat_boundary_segment_lane(pt, ncols, min_x, max_x, min_y, max_y, q[t], q[t + 1]) ? 1u : 0u;
             }
-            if (hit) __hip_atomic_fetch_or((lds_u32*)&r_flag[r], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (fnd) __hip_atomic_fetch_or((lds_u32*)&r_flag[r], fnd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             continue;
         }
         d2 q0 = q[0];
@@ -318,6 +324,7 @@ __device__ __forceinline__ int nth_bit(uint64_t mask, int rk) {
 // which have just entered the soup.  item = (node, arrived predecessor): the edge's area is transformed once, the predecessor's
 // polygon of the node's step goes through interx_segment_n segment by segment (InterX.m:63-76 restricted to those polygons).
 // list == nullptr: the nodes are 0 .. count - 1 themselves (small trees: no gathering pass), the others are skipped.
+template <int CHECKER>
 __device__ __forceinline__ void bk_recheck_items(const Search& S, const VState& VS, const BkCheck& C, const SpecCtx& P, const lds_u32* list, uint32_t count, unsigned long long arr,
                                                  volatile lds_u32* sh, int tid, int nthreads) {
     const uint32_t n_arr = (uint32_t)__builtin_popcountll(arr), items = count * n_arr;
@@ -343,8 +350,13 @@ __device__ __forceinline__ void bk_recheck_items(const Search& S, const VState& 
         const lds_d2* poly = P.l_soup + P.l_soff[k - 1] + P.l_lit[k - 1] + p * PDMPC_VMAX;
         d2 q0 = poly[0];
         bool hit = false;
+        if (CHECKER == PDMPC_CHECK_SAT) {  // are_constraints_satisfied_sat.m:24-35 for this one dynamic obstacle
+            int cols = 0;
+            while (cols < PDMPC_VMAX && !is_nan(poly[cols].x)) ++cols;
+            hit = cols > 0 && sat_pair_lane(pt, ncols, poly, cols);
+        }
 #pragma unroll 1
-        for (int j = 0; j + 1 < PDMPC_VMAX; ++j) {
+        for (int j = 0; CHECKER == PDMPC_CHECK_INTERX && j + 1 < PDMPC_VMAX; ++j) {
             asm volatile("" : "+v"(pt[0].x), "+v"(pt[0].y), "+v"(pt[1].x), "+v"(pt[1].y), "+v"(pt[2].x), "+v"(pt[2].y), "+v"(pt[3].x), "+v"(pt[3].y), "+v"(pt[4].x), "+v"(pt[4].y),
                          "+v"(pt[5].x), "+v"(pt[5].y), "+v"(pt[6].x), "+v"(pt[6].y), "+v"(pt[7].x), "+v"(pt[7].y));  // (as in bk_check_items)
             const d2 q1 = poly[j + 1];
@@ -569,8 +581,7 @@ __device__ __forceinline__ bool bk_poll_predecessors(const KernelArgs& A, const 
 }
 
 // incorporate_areas with loads that are coherent by themselves (bk_area_load): the solved areas of the predecessors in `arr` into
-// their soup slots (PrioritizedController.m:476-491); nthreads threads call (a workgroup, or one wave).  Out of line with scalar
-// arguments (see bk_wait_done).
+// their soup slots (PrioritizedController.m:476-491); nthreads threads call (a workgroup, or one wave).
 __device__ __forceinline__ void bk_incorporate_body(const pdmpc_vehicle_out* out, const int32_t* pred, lds_d2* l_soup, const lds_i32* l_soff, const lds_i32* l_lit, int Hp, unsigned long long arr, int tid,
                                                     int nthreads) {
     const double qnan = __longlong_as_double(0x7ff8000000000000LL);
@@ -588,14 +599,9 @@ __device__ __forceinline__ void bk_incorporate_body(const pdmpc_vehicle_out* out
         l_soup[l_soff[k] + l_lit[k] + p * PDMPC_VMAX + v] = pt;
     }
 }
-__device__ __noinline__ void bk_incorporate(const pdmpc_vehicle_out* out_, const int32_t* pred_, lds_d2* l_soup_, const lds_i32* l_soff_, const lds_i32* l_lit_, int Hp_, unsigned long long arr_, int tid,
-                                            int nthreads_) {
-    auto uptr = [](const void* p) -> uint64_t {
-        const uint64_t u = (uint64_t)p;
-        return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
-    };
-    bk_incorporate_body((const pdmpc_vehicle_out*)uptr(out_), (const int32_t*)uptr(pred_), (lds_d2*)(uintptr_t)uni_u((uint32_t)(uintptr_t)l_soup_), (const lds_i32*)(uintptr_t)uni_u((uint32_t)(uintptr_t)l_soff_),
-                        (const lds_i32*)(uintptr_t)uni_u((uint32_t)(uintptr_t)l_lit_), uni_i(Hp_), (unsigned long long)uptr((const void*)arr_), tid, uni_i(nthreads_));
+__device__ __forceinline__ void bk_incorporate(const pdmpc_vehicle_out* out, const int32_t* pred, lds_d2* l_soup, const lds_i32* l_soff, const lds_i32* l_lit, int Hp, unsigned long long arr, int tid,
+                                               int nthreads) {
+    bk_incorporate_body(out, pred, l_soup, l_soff, l_lit, Hp, arr, tid, nthreads);
 }
 
 // fr_check_wave with a memory: what to do with an open node a round has selected (1 process it, 3 it comes after the goal candidate,
@@ -677,31 +683,12 @@ __device__ int bk_classify_wave(const unsigned long long* glink, ulonglong2* wal
 // takes the path's edge away and the search resumes.  `first`: predecessors whose areas are in the soup already but have not been
 // checked against this path (copied while the search was running); max_spins 0: look at them and at the flags once, do not wait.
 // Leaves BK_WAITRES (0 nothing decided, 1 an arrival crosses the path, 2 published), SH_PEND and BK_FD.
-// Out of line on purpose (scalar arguments, one wavefront, once per wait): inlined, its registers push the search loop beyond the
-// 168 VGPRs of a twelve-wavefront workgroup (tests/test_build.py watches this).
-__device__ __noinline__ void bk_wait_done(const uint32_t* done_flag_, const int32_t* pred_, const pdmpc_vehicle_out* out_, uint32_t epoch_, uint32_t slot_, lds_d2* l_soup_, const lds_i32* l_soff_,
-                                          const lds_i32* l_lit_, lds_d2* pshape_, volatile lds_u32* sh_, int Hp_, int n_pred_, int have_path_, lds_vu64* tk_pub_, unsigned long long first_, uint32_t max_spins_) {
-    // (arguments of an out-of-line function arrive in vector registers: uniform again from here)
-    auto uptr = [](const void* p) -> uint64_t {
-        const uint64_t u = (uint64_t)p;
-        return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
-    };
-    const uint32_t* done_flag = (const uint32_t*)uptr(done_flag_);
-    const int32_t* pred = (const int32_t*)uptr(pred_);
-    const pdmpc_vehicle_out* out = (const pdmpc_vehicle_out*)uptr(out_);
-    const uint32_t epoch = uni_u(epoch_), slot = uni_u(slot_), max_spins = uni_u(max_spins_);
-    lds_d2* l_soup = (lds_d2*)(uintptr_t)uni_u((uint32_t)(uintptr_t)l_soup_);
-    const lds_i32* l_soff = (const lds_i32*)(uintptr_t)uni_u((uint32_t)(uintptr_t)l_soff_);
-    const lds_i32* l_lit = (const lds_i32*)(uintptr_t)uni_u((uint32_t)(uintptr_t)l_lit_);
-    lds_d2* pshape = (lds_d2*)(uintptr_t)uni_u((uint32_t)(uintptr_t)pshape_);
-    volatile lds_u32* sh = (volatile lds_u32*)(uintptr_t)uni_u((uint32_t)(uintptr_t)sh_);
-    lds_vu64* tk_pub = (lds_vu64*)(uintptr_t)uni_u((uint32_t)(uintptr_t)tk_pub_);
-    const int Hp = uni_i(Hp_), n_pred = uni_i(n_pred_);
-    const bool have_path = uni_i(have_path_) != 0;
-    const int lane = (int)(threadIdx.x & (PDMPC_WAVE - 1));
+__device__ __forceinline__ void bk_wait_done(const uint32_t* done_flag, const int32_t* pred, const pdmpc_vehicle_out* out, uint32_t epoch, uint32_t slot, lds_d2* l_soup, const lds_i32* l_soff,
+                                             const lds_i32* l_lit, lds_d2* pshape, volatile lds_u32* sh, int Hp, int n_pred, bool have_path, lds_vu64* tk_pub, unsigned long long first, uint32_t max_spins,
+                                             bool sat, int lane) {
     const lds_u32* pcols = (const lds_u32*)(pshape + Hp * PDMPC_VMAX);
     unsigned long long pend = sh_load64(sh, SH_PEND_LO), fd = sh_load64(sh, BK_FD_LO);
-    unsigned long long got = (unsigned long long)uptr((const void*)first_);  // (in the soup already: checked against the path before anybody is polled)
+    unsigned long long got = first;  // (in the soup already: checked against the path before anybody is polled)
     uint32_t spins = 0, res = 0;
     for (;;) {
         if (!got) {  // (uniform)
@@ -736,7 +723,14 @@ __device__ __noinline__ void bk_wait_done(const uint32_t* done_flag_, const int3
 #pragma unroll
             for (int i = 0; i < PDMPC_VMAX; ++i) pt[i] = pshape[k0 * PDMPC_VMAX + i];
             const lds_d2* poly = l_soup + l_soff[k0] + l_lit[k0] + p * PDMPC_VMAX;
-            const bool h1 = interx_segment_n<PDMPC_VMAX>(pt, (int)pcols[k0] - 1, poly[j], poly[j + 1]);
+            bool h1;
+            if (sat) {  // (uniform) the separating-axis checker: the lane with the area's first segment tests the pair of polygons
+                int cols = 0;
+                while (cols < PDMPC_VMAX && !is_nan(poly[cols].x)) ++cols;
+                h1 = j == 0 && cols > 0 && sat_pair_lane(pt, (int)pcols[k0], poly, cols);
+            } else {
+                h1 = interx_segment_n<PDMPC_VMAX>(pt, (int)pcols[k0] - 1, poly[j], poly[j + 1]);
+            }
             hit = hit || (in && h1);
         }
         got = 0ull;
@@ -1521,7 +1515,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                     list = hist;
                     cnt = sh[FR_VLIST_N];
                 }
-                bk_recheck_items(S, VS, CK, P, list, cnt, arr, sh, tid, bd);
+                bk_recheck_items<CHECKER>(S, VS, CK, P, list, cnt, arr, sh, tid, bd);
                 __syncthreads();
             }
             flags = sh[FR_FLAGS];
@@ -1749,8 +1743,8 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 __syncthreads();  // (the path's areas in LDS: written by the first wave, which is also their reader; the barrier is for the bookkeeping below)
             }
             if (wave == 0 && sh[BK_PUBLISHED] == 0u)
-                bk_wait_done(A.done_flag, P.pred, P.out, A.epoch, (uint32_t)slot, P.l_soup, P.l_soff, P.l_lit, (lds_d2*)(X.lsm + A.lds.bk_pshape), sh, Hp, P.n_pred, best != 0u ? 1 : 0,
-                             ticking ? (lds_vu64*)(tk + tk_pub) : (lds_vu64*)nullptr, sh_load64(sh, BK_FD_LO), 0u);
+                bk_wait_done(A.done_flag, P.pred, P.out, A.epoch, (uint32_t)slot, P.l_soup, P.l_soff, P.l_lit, (lds_d2*)(X.lsm + A.lds.bk_pshape), sh, Hp, P.n_pred, best != 0u,
+                             ticking ? (lds_vu64*)(tk + tk_pub) : (lds_vu64*)nullptr, sh_load64(sh, BK_FD_LO), 0u, CHECKER == PDMPC_CHECK_SAT, lane);
             __syncthreads();
             verify_req = true;
             BK_TICK(tk_arrival)
@@ -1793,8 +1787,8 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             }
             if (A.bk_fast_arrival && !dep_timeout) {
                 if (wave == 0)
-                    bk_wait_done(A.done_flag, P.pred, P.out, A.epoch, (uint32_t)slot, P.l_soup, P.l_soff, P.l_lit, (lds_d2*)(X.lsm + A.lds.bk_pshape), sh, Hp, P.n_pred, best != 0u ? 1 : 0,
-                                 ticking ? (lds_vu64*)(tk + tk_pub) : (lds_vu64*)nullptr, 0ull, 4096u);
+                    bk_wait_done(A.done_flag, P.pred, P.out, A.epoch, (uint32_t)slot, P.l_soup, P.l_soff, P.l_lit, (lds_d2*)(X.lsm + A.lds.bk_pshape), sh, Hp, P.n_pred, best != 0u,
+                                 ticking ? (lds_vu64*)(tk + tk_pub) : (lds_vu64*)nullptr, 0ull, 4096u, CHECKER == PDMPC_CHECK_SAT, lane);
                 __syncthreads();
                 if (sh[BK_IDLE] > A.spin_limit) dep_timeout = true;
             } else if (bk_wait()) {
@@ -2346,7 +2340,7 @@ __device__ __forceinline__ void bulk_body(const KernelArgs& A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Ctx X;
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
-    search_prologue(A, X, (LDS_AS unsigned char*)smem, CHECKER == PDMPC_CHECK_INTERX);
+    search_prologue(A, X, (LDS_AS unsigned char*)smem);
     X.rt_kernel_start = rt0;
     const int wave = X.wave;
     lds_u32* ref_ids = (lds_u32*)(X.lsm + A.lds.bk_misc) + 224;  // behind the chunk table (nothing else uses those words)

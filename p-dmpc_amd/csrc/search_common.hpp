@@ -130,7 +130,7 @@ struct ExpandEnv {
 
 // Prologue shared by the kernels: carves the LDS allocation (offsets from KernelArgs::lds), stages the MPA tables, the vehicle
 // record and its obstacle soups, initialises the result record and the predecessor bookkeeping, and fills the context X.
-__device__ __forceinline__ void search_prologue(const KernelArgs& A, Ctx& X, LDS_AS unsigned char* lsm, bool interx) {
+__device__ __forceinline__ void search_prologue(const KernelArgs& A, Ctx& X, LDS_AS unsigned char* lsm) {
     const int tid = threadIdx.x;
     const int lane = tid & (PDMPC_WAVE - 1);
     const int wave = uni_i(tid >> 6);
@@ -277,9 +277,7 @@ __device__ __forceinline__ void search_prologue(const KernelArgs& A, Ctx& X, LDS
     P.n_pred = n_pred;
     P.Hp = Hp;
     bool dep_timeout = false;
-    // the arrival re-check (node_hits_areas) implements the InterX predicate; the convex/SAT checker (circle scenario,
-    // a handful of vehicles) simply waits for its predecessors as the reference does
-    const bool speculate = A.speculate && n_pred <= 64 && interx;
+    const bool speculate = A.speculate && n_pred <= 64;
     if (n_pred > 0) {
         const d2 nanpt = d2{__longlong_as_double(0x7ff8000000000000LL), __longlong_as_double(0x7ff8000000000000LL)};
         for (int idx = tid; idx < Hp * pred_cols; idx += (int)blockDim.x) {
