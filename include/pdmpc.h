@@ -389,6 +389,43 @@ int pdmpc_controller_explore_run(pdmpc_controller* c, int32_t n_perm, int32_t n_
 int pdmpc_controller_explore_result(pdmpc_controller* c, int32_t* chosen, int32_t* n_graphs, const double** cost, const pdmpc_vehicle_out** records);
 const char* pdmpc_controller_last_error(void);
 
+/* ---- several GPUs behind the same boundary (csrc/group.cpp) ----
+ * The reference's vehicles exchange their solved areas after every computation level: each publishes a Predictions message that every
+ * coupled vehicle reads (hlc/communication/PredictionsCommunication.m:34-63, sent from PrioritizedController.publish_predictions,
+ * PrioritizedController.m:356-365, read back at :476-491).  A group is that exchange between the GPUs of ONE process: one handle and
+ * one stream per device, bound by an RCCL communicator (ncclCommInitAll; librccl is loaded when the first group is created, the
+ * single-GPU entry points do not need it).  pdmpc_group_plan_step plans a time step over the group:
+ *   PDMPC_SHARD_COMPONENTS  the weakly connected components of the step's coupling graph exchange nothing within the step: every
+ *                           device takes whole components (longest processing time first on `weights`), plans them with ONE
+ *                           launch, and ONE all-gather of the result records ends the step;
+ *   PDMPC_SHARD_LEVELS      every computation level is block-partitioned over the devices; after each level one all-gather of the
+ *                           level's records (2.9 KB per vehicle) on the handles' streams, imported on every device as predecessor
+ *                           areas of the next level -- the literal image of the per-level Predictions broadcast;
+ *   PDMPC_SHARD_AUTO        whole components, except a component that outweighs the mean load per device: that one by levels over
+ *                           all devices, the others whole.
+ * The prioritization instances of an explorative step (pdmpc_controller_explore_*) are components of their batch: COMPONENTS deals
+ * them out.  Arguments as for pdmpc_plan_step (any slot order; records come back in the caller's order); weights (may be NULL: 1
+ * each) = expected work per vehicle, e.g. n_popped of the previous step.  Results are those of the single launch, bit for bit. */
+enum { PDMPC_SHARD_AUTO = 0, PDMPC_SHARD_COMPONENTS = 1, PDMPC_SHARD_LEVELS = 2 };
+typedef struct pdmpc_group pdmpc_group;
+/* devices: n_devices HIP device ordinals (NULL: 0 .. n_devices - 1); config as for pdmpc_create (config.device is ignored) */
+int pdmpc_group_create(const pdmpc_config* config, int32_t n_devices, const int32_t* devices, pdmpc_group** out_group);
+int pdmpc_group_destroy(pdmpc_group* group);
+int pdmpc_group_size(pdmpc_group* group, int32_t* n_devices);
+int pdmpc_group_handle(pdmpc_group* group, int32_t rank, pdmpc_handle** handle); /* rank's handle (statistics, debug read-backs) */
+int pdmpc_group_upload_mpa(pdmpc_group* group, const pdmpc_mpa* mpa);
+int pdmpc_group_plan_step(pdmpc_group* group, int32_t n_vehicles, const pdmpc_vehicle_in* in, const int32_t* pred_offset, const int32_t* pred_index,
+                          const pdmpc_polygon_set* fallback_shapes, const double* weights, int32_t mode, pdmpc_vehicle_out* out);
+/* The partition pdmpc_group_plan_step uses, on its own (no GPU needed): rank_of[v] = device that plans vehicle v as part of a whole
+ * component, or -1 if v belongs to the component that is planned by levels over all devices (then level_of[v] = its computation
+ * level, 1-based, and block_rank[v] = the device of its block within that level; 0 / -1 for the others).  Twin of
+ * pdmpc.distributed.partition_components / hybrid_partition / level_partition. */
+int pdmpc_group_partition(int32_t n_vehicles, const int32_t* pred_offset, const int32_t* pred_index, const double* weights, int32_t n_devices, int32_t mode,
+                          int32_t* rank_of, int32_t* level_of, int32_t* block_rank);
+/* wall-clock milliseconds of the last pdmpc_group_plan_step and of its phases: [0] total, [1] partition + sub-problems, [2] pack,
+ * [3] launches and collectives enqueued, [4] wait, [5] read-back */
+int pdmpc_group_last_timing(pdmpc_group* group, double* ms6);
+
 const char* pdmpc_last_error(void);
 const char* pdmpc_version(void);
 

@@ -17,6 +17,8 @@
  *                            (hlc/controller/prioritized/PrioritizedSequentialController.m:86-88), n run_optimizer calls at once
  *   pdmpc_ml_plan_step       the whole double loop (:77-94) in one call: kahn.m levels from directed_coupling_sequential, the
  *                            predecessors' solved areas handed over on the device (PrioritizedController.m:476-491)
+ *   pdmpc_ml_group_plan_step the same step over several GPUs: the per-level exchange of solved areas between the vehicles
+ *                            (hlc/communication/PredictionsCommunication.m:34-63) as an RCCL all-gather between the devices
  *   pdmpc_ml_record_arrays   the fields of ControlResultsInfo in MATLAB's layout (OptimizerInterface.m:63-101)
  */
 #ifndef PDMPC_MATLAB_H
@@ -81,6 +83,10 @@ int pdmpc_ml_step_problem(const pdmpc_ml_step* s, int32_t* n, const pdmpc_vehicl
 void pdmpc_ml_step_destroy(pdmpc_ml_step* s);
 /* plans the step with ONE launch (pdmpc_plan_step); out[v] = record of VEHICLE v (not of slot v) */
 int pdmpc_ml_plan_step(pdmpc_handle* handle, const pdmpc_ml_step* s, pdmpc_vehicle_out* out);
+/* the same step over the GPUs of a group (pdmpc_group_*, include/pdmpc.h): weights[v] (may be NULL) = expected work of VEHICLE v,
+ * mode = PDMPC_SHARD_*; out[v] = record of vehicle v.  What PredictionsCommunication.m:34-63 does between the vehicles' processes
+ * happens between the devices: an RCCL all-gather of the solved areas. */
+int pdmpc_ml_group_plan_step(pdmpc_group* group, const pdmpc_ml_step* s, const double* weights, int32_t mode, pdmpc_vehicle_out* out);
 /* convenience: n uncoupled vehicles (one computation level) in one launch */
 int pdmpc_ml_plan_level(pdmpc_handle* handle, int32_t Hp, int32_t n, const pdmpc_ml_iter* iters, pdmpc_vehicle_out* out);
 

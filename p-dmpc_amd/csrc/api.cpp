@@ -811,6 +811,7 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
 extern "C" {
 
 const char* pdmpc_last_error(void) { return g_err.c_str(); }
+void pdmpc_set_last_error(const char* msg) { g_err = msg ? msg : ""; }  // (group.cpp reports through the same string)
 const char* pdmpc_version(void) { return "pdmpc-hip 0.1 (gfx950)"; }
 
 int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {

@@ -288,6 +288,24 @@ int pdmpc_ml_plan_step(pdmpc_handle* h, const pdmpc_ml_step* s, pdmpc_vehicle_ou
     return PDMPC_OK;
 }
 
+int pdmpc_ml_group_plan_step(pdmpc_group* g, const pdmpc_ml_step* s, const double* weights, int32_t mode, pdmpc_vehicle_out* out) {
+    if (!g || !s || (s->n > 0 && !out)) return ml_fail(PDMPC_ERR_INVALID, "pdmpc_ml_group_plan_step: null argument");
+    std::vector<pdmpc_vehicle_out> slots((size_t)std::max(s->n, 1));
+    std::vector<double> w;
+    if (weights) {  // (per vehicle -> per slot)
+        w.resize((size_t)s->n);
+        for (int sl = 0; sl < s->n; ++sl) w[(size_t)sl] = weights[(size_t)s->order[(size_t)sl] - 1];
+    }
+    const int rc = pdmpc_group_plan_step(g, s->n, s->in.data(), s->pred_offset.data(), s->pred_index.data(), s->any_fallback ? s->fallback.data() : nullptr,
+                                         weights ? w.data() : nullptr, mode, slots.data());
+    if (rc) {
+        g_ml_err = pdmpc_last_error();
+        return rc;
+    }
+    for (int sl = 0; sl < s->n; ++sl) out[(size_t)s->order[(size_t)sl] - 1] = slots[(size_t)sl];
+    return PDMPC_OK;
+}
+
 int pdmpc_ml_plan_level(pdmpc_handle* h, int32_t Hp, int32_t n, const pdmpc_ml_iter* iters, pdmpc_vehicle_out* out) {
     pdmpc_ml_step* s = nullptr;
     int rc = pdmpc_ml_step_create(Hp, n, iters, nullptr, nullptr, &s);

@@ -44,6 +44,14 @@ EXPORTS = [
     "pdmpc_export_results_async",
     "pdmpc_stream",
     "pdmpc_get_last_stats",
+    "pdmpc_group_create",
+    "pdmpc_group_destroy",
+    "pdmpc_group_size",
+    "pdmpc_group_handle",
+    "pdmpc_group_upload_mpa",
+    "pdmpc_group_plan_step",
+    "pdmpc_group_partition",
+    "pdmpc_group_last_timing",
     "pdmpc_debug_heap_script",
     "pdmpc_debug_pop_trace",
     "pdmpc_debug_tree",
@@ -144,6 +152,88 @@ def _check(L, rc, what):
     if rc != 0:
         msg = L.pdmpc_last_error()
         raise BackendError("%s failed with status %d: %s" % (what, rc, msg.decode() if msg else ""))
+
+
+SHARD_AUTO, SHARD_COMPONENTS, SHARD_LEVELS = 0, 1, 2
+
+
+def group_partition(preds, world, mode=SHARD_AUTO, weights=None):
+    """pdmpc_group_partition (no GPU needed): per vehicle the device of its whole component (-1: planned by levels over all
+    devices), its level (1-based, 0 for whole components) and the device of its block within that level (-1)."""
+    L = load_library()
+    n = len(preds)
+    off = np.zeros(n + 1, dtype=np.int32)
+    for i, p in enumerate(preds):
+        off[i + 1] = off[i] + len(p)
+    idx = np.array([j for p in preds for j in p] + [0], dtype=np.int32)
+    w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+    rank_of, level_of, block = (np.zeros(max(n, 1), dtype=np.int32) for _ in range(3))
+    L.pdmpc_group_partition.argtypes = [C.c_int32, abi.c_int32_p, abi.c_int32_p, abi.c_double_p, C.c_int32, C.c_int32, abi.c_int32_p, abi.c_int32_p, abi.c_int32_p]
+    _check(L, L.pdmpc_group_partition(n, off.ctypes.data_as(abi.c_int32_p), idx.ctypes.data_as(abi.c_int32_p), None if w is None else w.ctypes.data_as(abi.c_double_p), world, mode,
+                                      rank_of.ctypes.data_as(abi.c_int32_p), level_of.ctypes.data_as(abi.c_int32_p), block.ctypes.data_as(abi.c_int32_p)), "pdmpc_group_partition")
+    return rank_of[:n], level_of[:n], block[:n]
+
+
+class Group:
+    """One pdmpc_group: a handle per GPU of this process, bound by an RCCL communicator; plan_step plans a time step over them
+    (include/pdmpc.h: pdmpc_group_*)."""
+
+    def __init__(self, options, n_devices=1, devices=None, checker=None):
+        self.L = load_library()
+        self.options = options
+        self.Hp = options.Hp
+        if checker is None:
+            checker = abi.CHECK_INTERX if options.are_any_obstacles_non_convex else abi.CHECK_SAT
+        self.cfg = abi.Config(Hp=options.Hp, checker=checker, dt_seconds=options.dt_seconds, device=0, max_nodes=options.max_nodes, max_vehicles=options.max_vehicles,
+                              trace_pops=0)
+        self.g = C.c_void_p()
+        devs = None if devices is None else (C.c_int32 * n_devices)(*devices)
+        self.L.pdmpc_group_create.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        _check(self.L, self.L.pdmpc_group_create(C.byref(self.cfg), n_devices, devs, C.byref(self.g)), "pdmpc_group_create")
+        self.n_devices = n_devices
+        self._mpa_keep = None
+
+    def close(self):
+        if self.g:
+            self.L.pdmpc_group_destroy(self.g)
+            self.g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload_mpa(self, mpa):
+        s, keep = abi.pack_mpa(mpa)
+        self.L.pdmpc_group_upload_mpa.argtypes = [C.c_void_p, C.c_void_p]
+        _check(self.L, self.L.pdmpc_group_upload_mpa(self.g, C.byref(s)), "pdmpc_group_upload_mpa")
+        self._mpa_keep = keep
+
+    def plan_step(self, iters, predecessors, fallback_shapes=None, weights=None, mode=SHARD_AUTO):
+        n = len(iters)
+        arr, off, idx, fb, keep = Handle._step_args(self, iters, predecessors, fallback_shapes)
+        out = abi.out_array(n)
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+        self.L.pdmpc_group_plan_step.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, abi.c_int32_p, abi.c_int32_p, C.c_void_p, abi.c_double_p, C.c_int32, C.c_void_p]
+        _check(self.L, self.L.pdmpc_group_plan_step(self.g, n, arr, off.ctypes.data_as(abi.c_int32_p), idx.ctypes.data_as(abi.c_int32_p), fb,
+                                                    None if w is None else w.ctypes.data_as(abi.c_double_p), mode, abi.out_ptr(out)), "pdmpc_group_plan_step")
+        del keep
+        return out[:n]
+
+    def timing(self):
+        t = (C.c_double * 6)()
+        self.L.pdmpc_group_last_timing.argtypes = [C.c_void_p, C.c_void_p]
+        _check(self.L, self.L.pdmpc_group_last_timing(self.g, t), "pdmpc_group_last_timing")
+        return dict(zip(("total", "partition", "pack", "enqueue", "wait", "read_back"), t))
+
+    def stats(self, rank=0):
+        h = C.c_void_p()
+        self.L.pdmpc_group_handle.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        _check(self.L, self.L.pdmpc_group_handle(self.g, rank, C.byref(h)), "pdmpc_group_handle")
+        st = abi.Stats()
+        _check(self.L, self.L.pdmpc_get_last_stats(h, C.byref(st)), "pdmpc_get_last_stats")
+        return {k: getattr(st, k) for k, _ in abi.Stats._fields_}
 
 
 class Handle:

@@ -61,7 +61,10 @@ def test_circle_8_vehicles_step():
     from pdmpc.scenario import circle_scenario
 
     options = Config(scenario_type=ScenarioType.circle, amount=8, Hp=6, max_vehicles=8, max_nodes=1 << 16)
-    run_closed_loop(options, circle_scenario(options), "full", None, 12)
+    ctl = run_closed_loop(options, circle_scenario(options), "full", None, 12)
+    # equal keys are structural here (vehicle 1 drives along the x axis: +dy and -dy cancel exactly): the product kernel, with the
+    # separating-axis check items, and its replay through the binary heap for the tied searches -- all in the step's one launch
+    assert ctl.handle_stats["kernel"] == 2 and ctl.handle_stats["queue_fallbacks"] > 0
 
 
 def test_road_network_20_vehicles_step():
@@ -645,3 +648,48 @@ def test_bulk_kernel_shares_large_rounds_and_parks_tentative_nodes(monkeypatch):
     monkeypatch.setenv("PDMPC_TUNING", "force_tie=1")
     stats = loop()
     assert stats["kernel"] == 2 and stats["queue_fallbacks"] > 0
+
+
+def test_tied_search_in_a_level_sharded_step_on_the_device_resident_path():
+    """A search with equal keys (mirror-symmetric problem) in the middle of a step that is launched level by level and handed on
+    through pdmpc_export_results / pdmpc_import_results without a fetch in between (the multi-GPU path): the tie is
+    resolved inside the launch (bk_replay), so the records that leave the device are the oracle's — no internal status, no re-plan."""
+    import ctypes
+    from oracle import oracle
+    from pdmpc import abi
+    from pdmpc.backend import Handle
+    import problems
+
+    options = problems.make_options("interx", Hp=6)
+    options.max_vehicles = 8
+    options.max_nodes = 1 << 16
+    mpa = problems.get_mpa(options)
+    rng = np.random.default_rng(4)
+    road = [problems.road_problem(rng, options, mpa) for _ in range(3)]
+    sym = problems.symmetric_problem(options, mpa, block_x=0.5)
+    prob = {"iters": [road[0], sym, road[1], sym, road[2]], "preds": [[], [], [0, 1], [1], [2, 3]], "fallback": [None] * 5, "level_sizes": [2, 2, 1]}
+    ref, _ = oracle.plan_step(options, mpa, prob)
+    _, _, traces = oracle.plan_batch(options, mpa, [sym], trace=True)
+    assert problems.tied_pops(traces[0]) > 0
+    h = Handle(options)
+    h.upload_mpa(mpa)
+    h.pack_step(prob["iters"], prob["preds"], [[], [], [], [], []])
+    h.begin_step()
+    hip = ctypes.CDLL("libamdhip64.so")
+    nbytes = abi.VEHICLE_OUT_DTYPE.itemsize
+    buf = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(buf), 5 * nbytes) == 0
+    first = 0
+    for n in prob["level_sizes"]:
+        h.launch_range(first, n)
+        h.export_results(first, n, buf.value + first * nbytes)   # (what the all-gather would send)
+        h.import_results(first, n, buf.value + first * nbytes)   # (... and what every rank takes in)
+        first += n
+    host = np.zeros(5, dtype=abi.VEHICLE_OUT_DTYPE)
+    assert hip.hipMemcpy(host.ctypes.data_as(ctypes.c_void_p), buf, 5 * nbytes, 2) == 0
+    hip.hipFree(buf)
+    assert set(int(x) for x in host["status"]) <= {0, 1}
+    assert_records_equal(host, ref, "level-sharded step with a tied search")
+    st = h.stats()
+    assert st["kernel"] == 2 and st["queue_fallbacks"] >= 2
+    h.close()

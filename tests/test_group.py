@@ -1,0 +1,111 @@
+"""The multi-GPU split behind the C ABI (csrc/group.cpp, include/pdmpc.h: pdmpc_group_*).
+
+CPU: the partition logic in C++ against its Python twin (pdmpc.distributed, which the world-size-2 gloo tests drive).
+GPU: a group of one device plans a time step through the same code path a group of eight takes — sub-problems, banks, RCCL
+all-gather on the handle's stream, import, read-back — and must give the single launch's records."""
+import numpy as np
+import pytest
+
+from pdmpc import backend, distributed
+
+
+def random_dag(rng, n, p_edge, n_islands):
+    """predecessor lists of a random coupling DAG of n vehicles in n_islands weakly connected groups, slots in level order"""
+    island = rng.integers(0, n_islands, n)
+    preds = [[] for _ in range(n)]
+    for j in range(n):
+        for i in range(j):
+            if island[i] == island[j] and rng.random() < p_edge:
+                preds[j].append(i)
+    lvl = []
+    for ps in preds:
+        lvl.append(1 + max((lvl[p] for p in ps), default=0))
+    order = sorted(range(n), key=lambda v: (lvl[v], v))
+    pos = {v: i for i, v in enumerate(order)}
+    return [sorted(pos[p] for p in preds[v]) for v in order]
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_partition_matches_the_python_twin(seed, world):
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(5, 120))
+    preds = random_dag(rng, n, 0.15, int(rng.integers(1, 9)))
+    weights = [float(w) for w in rng.integers(1, 2000, n)] if seed % 2 else None
+    # whole components by longest processing time
+    rank_of, level_of, block = backend.group_partition(preds, world, backend.SHARD_COMPONENTS, weights)
+    parts = distributed.partition_components(preds, world, weights)
+    for r, slots in enumerate(parts):
+        assert sorted(np.nonzero(rank_of == r)[0].tolist()) == slots
+    assert (level_of == 0).all() and (block == -1).all()
+    # hybrid: a dominating component by levels over all ranks
+    rank_of, level_of, block = backend.group_partition(preds, world, backend.SHARD_AUTO, weights)
+    parts, shared = distributed.hybrid_partition(preds, world, weights)
+    for r, slots in enumerate(parts):
+        assert sorted(np.nonzero(rank_of == r)[0].tolist()) == slots
+    assert sorted(np.nonzero(rank_of == -1)[0].tolist()) == shared
+    if shared:
+        sub = distributed.sub_problem({"order": list(range(n)), "iters": [None] * n, "preds": preds, "fallback": [None] * n}, shared)
+        sizes = distributed.level_sizes_of(sub["preds"])
+        first = 0
+        for lv, size in enumerate(sizes):
+            per, blocks = distributed.level_partition(first, size, world)
+            for r, (lo, hi) in enumerate(blocks):
+                for s in range(lo, hi):
+                    assert level_of[shared[s]] == lv + 1 and block[shared[s]] == r
+            first += size
+    # every level sharded
+    rank_of, level_of, block = backend.group_partition(preds, world, backend.SHARD_LEVELS, weights)
+    assert (rank_of == -1).all()
+    sizes = distributed.level_sizes_of(preds)
+    first = 0
+    for lv, size in enumerate(sizes):
+        per, blocks = distributed.level_partition(first, size, world)
+        for r, (lo, hi) in enumerate(blocks):
+            for s in range(lo, hi):
+                assert level_of[s] == lv + 1 and block[s] == r
+        first += size
+
+
+def test_partition_rejects_a_cycle():
+    with pytest.raises(backend.BackendError):
+        backend.group_partition([[1], [0]], 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [backend.SHARD_COMPONENTS, backend.SHARD_LEVELS, backend.SHARD_AUTO])
+def test_group_of_one_device_equals_the_single_launch(mode):
+    """C3-like closed loop (tiled road network, colouring, two computation levels): every step through pdmpc_group_plan_step with
+    one device (sub-problems, RCCL all-gather with one rank, import of the gathered records) and through pdmpc_plan_step."""
+    from pdmpc.config import Config, ScenarioType
+    from pdmpc.controller import PrioritizedSequentialController
+    from pdmpc.iteration_data import info_from_record
+    from pdmpc.mpa import get_mpa
+    from pdmpc.optimizer import GraphSearchHip
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+    from test_gpu_parity import assert_records_equal
+
+    options = Config(scenario_type=ScenarioType.commonroad, amount=40, Hp=8, max_num_CLs=3, max_vehicles=64, max_nodes=1 << 16)
+    mpa = get_mpa(options)
+    sc = commonroad_scenario(options, seed=1, tiles=3)
+    opt = GraphSearchHip(options)
+    opt._ensure_mpa(mpa)
+    grp = backend.Group(options, n_devices=1)
+    grp.upload_mpa(mpa)
+    ctl = PrioritizedSequentialController(options, sc, mpa, None, coupling="distance", boundary_provider=boundary_provider(sc), priority_strategy="coloring")
+    seen = []
+
+    def plan_step(prob):
+        fb = [f if f is not None else [] for f in prob["fallback"]]
+        ref = opt.handle.plan_step(prob["iters"], prob["preds"], fb)
+        weights = [int(p) + 1 for p in ref["n_popped"]]
+        got = grp.plan_step(prob["iters"], prob["preds"], fb, weights=weights, mode=mode)
+        assert_records_equal(got, ref, "group of one, mode %d, step %d" % (mode, len(seen)))
+        seen.append(len(prob["iters"]))
+        return [info_from_record(ref[i], options.Hp) for i in range(len(prob["iters"]))]
+
+    for _ in range(6):
+        ctl.step(plan_step=plan_step)
+    assert grp.stats()["kernel"] == 2 and grp.timing()["total"] > 0
+    grp.close()
+    opt.handle.close()
