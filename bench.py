@@ -142,7 +142,7 @@ def cpu_baseline(options, mpa, problems, gpu_records, budget_s):
     unbounded.max_nodes = 1 << 30  # the reference's tree is unbounded (Tree.m:54-70)
     mpa_struct, keep = packing.pack_mpa(mpa)
     oracle.plan_step_native(unbounded, mpa, problems[0], n_threads=cores, mpa_struct=mpa_struct)  # (starts the pool: not timed)
-    ms_total, thr_total, n_done, mismatches, plans, n_timed, plans_timed = 0.0, 0.0, 0, 0, 0, 0, 0
+    ms_total, thr_total, n_done, mismatches, plans, n_timed, plans_timed, pops_timed = 0.0, 0.0, 0, 0, 0, 0, 0, 0
     t0 = time.time()
     for prob, gpu in zip(problems, gpu_records):
         # every recorded step is planned by the oracle and compared (the parity check of the measured work); the baseline's rate is
@@ -153,6 +153,7 @@ def cpu_baseline(options, mpa, problems, gpu_records, budget_s):
             thr_total += thr * ms
             n_timed += 1
             plans_timed += len(recs)
+            pops_timed += int(recs["n_popped"].sum())
         n_done += 1
         plans += len(recs)
         mismatches += count_record_mismatches(gpu, recs)
@@ -166,13 +167,17 @@ def cpu_baseline(options, mpa, problems, gpu_records, budget_s):
         "sample": "%d recorded steps of the same workload (%d plans), C++ oracle, whole level loop in C++ (kahn order, hand-over of solved areas on the host), "
         "min(level size, %d) threads of a persistent pool per level" % (n_timed, plans_timed, cores),
         "ms_per_step": ms_total / max(n_timed, 1),
+        # what a pop of the reference costs a host thread: busy thread-time / pops (the level chain starves the pool: threads_used_mean)
+        "us_per_pop_per_thread": 1e3 * thr_total / pops_timed if pops_timed else None,
     }, n_done, plans, mismatches
 
 
-def measure_replay(h, problems, steps, warmup, one_step, dist, torch):
+def measure_replay(h, problems, steps, warmup, one_step, dist, torch, reset_extra=None):
     for i in range(warmup):
         one_step(i)
     h.reset_stats()
+    if reset_extra is not None:
+        reset_extra()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -254,7 +259,16 @@ def scaling_reference(args_in, local_rank, torch):
             "what": "C4 (512 vehicles, Hp 10, colouring levels) replayed from HBM on one GPU: divide the value of a `--gpus N` line (default workload c4, strong scaling) by this"}
 
 
+# The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner when a communicator is created):
+# file descriptor 1 is pointed at stderr for the whole run and the JSON line goes to a duplicate of the real stdout.
+JSON_FD = 1
+
+
 def main():
+    global JSON_FD
+    sys.stdout.flush()
+    JSON_FD = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -279,6 +293,10 @@ def main():
                     help="options.max_num_CLs (Config.m:28): couplings that do not fit into this many computation levels are cut "
                     "(GreedyCutter.m) and handled as parallel couplings")
     ap.add_argument("--instances", type=int, default=64, help="c5: simultaneous prioritizations per time step")
+    ap.add_argument("--multi", default="group", choices=["group", "dist"],
+                    help="N > 1, sharded workloads: `group` = the C ABI's own multi-GPU path (pdmpc_group_*: ONE process drives all N devices, RCCL through "
+                    "ncclCommInitAll; rank 0 plans, the other ranks of the launcher only take part in the barriers) with a fall-back to `dist` if the group "
+                    "cannot be created; `dist` = one process per GPU through torch.distributed (pdmpc.distributed)")
     ap.add_argument("--shard", default="components", choices=["components", "levels"],
                     help="multi-GPU mode of c3/c4: whole coupling-graph components per rank (one speculative launch per rank and step, one "
                     "all-gather of results) or block-partitioned levels (one all-gather per level).  (pdmpc.distributed.plan_step_hybrid -- whole components, a dominating one split by level -- is a library call: the tiled benchmark maps have no dominating component)")
@@ -317,7 +335,34 @@ def main():
     S = len(problems)
     parts = None
     full_problems = problems
-    if (sharded and dist is not None and args.shard == "components" and not explore) or (explore and dist is not None):
+    # ---- N > 1 through the C ABI's group (what a MATLAB / C caller has): rank 0 creates one handle per device, packs the recorded steps
+    # into group banks (whole coupling-graph components per device by LPT on the recorded pops, or every level sharded) and plans them;
+    # the other ranks idle between the barriers.  If the group cannot be set up on this node, every rank falls back to torch.distributed.
+    grp = None
+    want_group = sharded and args.multi == "group" and (world > 1 or os.environ.get("PDMPC_FORCE_GROUP") == "1")  # (the env switch: a group of ONE device on a 1-GPU box)
+    if want_group:
+        from pdmpc import backend
+
+        ok = [0]
+        if rank == 0:
+            try:
+                grp = backend.Group(options, n_devices=world)
+                grp.upload_mpa(mpa)
+                gmode = backend.SHARD_LEVELS if args.shard == "levels" else backend.SHARD_COMPONENTS
+                for b, prob in enumerate(problems):
+                    grp.pack_step(b, prob["iters"], prob["preds"], [f if f is not None else [] for f in prob["fallback"]],
+                                  weights=[w + 1 for w in prob["pops"]] if "pops" in prob else None, mode=gmode)
+                    grp.launch(b)
+                ok = [1]
+            except Exception as e:  # noqa: BLE001 (whatever went wrong: the other path is still there)
+                sys.stderr.write("bench.py: pdmpc_group path not available (%s): falling back to torch.distributed\n" % e)
+                grp = None
+        if dist is not None:
+            dist.broadcast_object_list(ok, src=0)
+        if not ok[0]:
+            args.multi = "dist"
+    use_group = want_group and args.multi == "group"
+    if not use_group and ((sharded and dist is not None and args.shard == "components" and not explore) or (explore and dist is not None)):
         from pdmpc.distributed import shard_problems
 
         # every rank recorded the same closed loop; now it keeps only what is assigned to it: whole coupling-graph components by
@@ -340,7 +385,9 @@ def main():
 
     planner = None
     gather_bufs = None
-    if sharded and dist is not None and args.shard == "levels" and not explore:
+    if use_group:
+        pass
+    elif sharded and dist is not None and args.shard == "levels" and not explore:
         from pdmpc.distributed import HipRangePlanner, plan_step_sharded
 
         planner = HipRangePlanner(optimizer, mpa, torch.device("cuda", local_rank))
@@ -357,6 +404,10 @@ def main():
         ext_stream = torch.cuda.ExternalStream(h.stream_ptr(), device=torch.device("cuda", local_rank))
 
     def one_step(i):
+        if use_group:
+            if grp is not None:
+                grp.launch(i % S)  # launches, all-gathers and imports on every device's stream, one wait (csrc/group.cpp)
+            return
         if planner is not None:
             plan_step_sharded(problems[i % S], planner, dist, rank, world, resident_bank=i % S, fetch=False)
             h.synchronize()
@@ -371,21 +422,31 @@ def main():
                 dist.all_gather_into_tensor(gather_bufs[1], gather_bufs[0])
         h.synchronize()
 
-    elapsed, lat = measure_replay(h, problems, args.steps, args.warmup, one_step, dist, torch)
-    st = h.stats()
+    elapsed, lat = measure_replay(h, problems, args.steps, args.warmup, one_step, dist, torch, reset_extra=grp.reset_stats if grp is not None else None)
+    st = grp.stats(0) if (use_group and grp is not None) else h.stats()
     kernel_ms = st["kernel_ms"]
     n_launch = st["n_launches"]
     alg_bytes = sum(bytes_per_bank[i % S] for i in range(args.steps))
     pops = sum(pops_per_bank[i % S] for i in range(args.steps))
     nodes = sum(nodes_per_bank[i % S] for i in range(args.steps))
     achieved = (alg_bytes / max(n_launch, 1)) / ((kernel_ms / max(n_launch, 1)) * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    n_search = max(len(p["iters"]) for p in problems)
+    # (api.cpp: launch_range -- helper workgroups on the CUs a launch of at most one search per CU leaves idle, 96 for up to two per CU)
+    wg_per_launch = n_search + (min(64, max(32, n_search // 2)) if n_search <= 254 else (96 if n_search <= 512 else 0))
 
     # ---- the timed launches did the recorded work.  Their records are not fetched (no copies in the timed region), so: the device
     # counts every plan that ended with anything but OK / EXHAUSTED (overflow, time-out) since the reset in front of the timed loop,
     # and every bank is launched once more, in the arenas and under the conditions of the timed loop, and compared with the recording.
     bad_status_timed = st["bad_status_plans"]
     replay_mismatches, replay_checked = 0, 0
-    if planner is None:
+    if use_group:
+        if grp is not None:
+            for b in range(S):
+                grp.launch(b)
+                after = grp.fetch(b, len(problems[b]["iters"]))
+                replay_mismatches += count_record_mismatches(after, bank_recs[b])
+                replay_checked += len(after)
+    elif planner is None:
         for b in range(S):
             h.select_bank(b)
             h.launch()
@@ -473,7 +534,8 @@ def main():
                 tsrc = "profiles/%s: FETCH_SIZE + WRITE_SIZE of the timed launches of this workload, search kernel + the helper kernel next to it (separate rocprofv3 --pmc passes, tools/collect_profiles.sh)" % os.path.basename(tpath)
             except Exception:
                 traffic = None
-        mode = "levels sharded over ranks with one all-gather per level" if planner is not None else (
+        mode = ("pdmpc_group (C ABI, one process, ncclCommInitAll): " + ("every level sharded over the devices, one all-gather per level" if args.shard == "levels" else
+                "coupling-graph components sharded over the devices, one launch per device and step, one all-gather of results")) if use_group else "levels sharded over ranks with one all-gather per level" if planner is not None else (
             ("prioritization instances sharded over ranks" if explore else "coupling-graph components sharded over ranks") + ", one launch per rank and step, one all-gather of results" if gather_bufs is not None else "one launch per step")
         out = {
             "metric": "MPC steps/sec (whole node) + p50 per-step plan latency, N vehicles H=8",
@@ -489,6 +551,10 @@ def main():
             "max_latency_step": int(max(range(len(lat)), key=lambda i: lat[i])),
             "step_latencies_ms": [round(1e3 * x, 3) for x in lat] if len(lat) <= 40 else None,
             "host_buffer_ms_per_step": host_buffer_ms,  # PCIe-inclusive path incl. Python marshalling (never `value`)
+            # `value` is the contract's number: inputs resident in HBM when the timed region starts.  What a caller of the C ABI gets per
+            # step -- host step logic + pack + H2D + launch + D2H + apply (pdmpc_controller_run) -- is value_host_inclusive, on the same
+            # closed-loop window; DESIGN.md section 7 quotes both.
+            "value_resident": (1 if sharded else world) * args.steps / elapsed,
             "value_host_inclusive": host_inclusive["value"] if host_inclusive else None,
             "host_inclusive": host_inclusive,
             "value_run_optimizer_literal": literal["value"] if literal else None,
@@ -526,6 +592,25 @@ def main():
                 "lds_bytes_per_workgroup": lds_bytes,
                 "open_list": "unordered near (LDS) / mid / far (HBM) lists, bulk-synchronous rounds of the smallest keys; equal keys: replay through the libstdc++-faithful binary heap",
             },
+            # The compute side next to the HBM side: the (area segment, obstacle segment) pairs the reference's InterX forms for the edges the
+            # kernel evaluated (InterX.m:63-76: ~10 flops per pair) against the vector-f64 peak of the CUs that hold a
+            # workgroup of the launch (78.6 TFLOP/s for 256 CUs = half the FP32 vector peak of MI355X_MICROARCH.md).
+            "roofline_compute": {
+                "bound": "valu_f64",
+                "achieved": 10.0 * st["segment_pair_tests"] / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else None,
+                "unit": "TFLOP/s",
+                "peak_chip": 78.6,
+                "workgroups_per_launch": wg_per_launch,
+                "peak_of_occupied_cus": 78.6 * min(wg_per_launch, 256) / 256.0,
+                "frac_of_occupied_cus": (10.0 * st["segment_pair_tests"] / (kernel_ms * 1e-3) / 1e12) / (78.6 * min(wg_per_launch, 256) / 256.0) if kernel_ms > 0 else None,
+                "segment_pair_tests_per_launch": st["segment_pair_tests"] / max(n_launch, 1),
+                "flops_per_pair": 10,
+            },
+            "us_per_pop": {
+                "gpu_whole_step": 1e6 * elapsed / pops if pops else None,  # step time / pops of the reference in it (all searches side by side)
+                "gpu_kernel": 1e3 * kernel_ms / pops if pops else None,
+                "cpu_per_thread": None,  # filled from cpu_baseline below
+            },
             # every plan of the recorded steps by outcome; arena_overflow and error must be 0 (the reference's tree is unbounded, Tree.m:54-70)
             "status_counts": status_counts,
             "bad_status_plans_in_timed_region": bad_status_timed,  # device-side count: must be 0
@@ -551,12 +636,13 @@ def main():
         parity_mismatches = 0
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], n_steps_checked, n_plans, parity_mismatches = cpu_baseline(options, mpa, full_problems, bank_recs, args.cpu_budget_s)
+            out["us_per_pop"]["cpu_per_thread"] = out["cpu_baseline"].get("us_per_pop_per_thread")
             out["parity_checked"] = n_steps_checked == S
             out["parity_steps_checked"] = n_steps_checked
             out["parity_plans_checked"] = n_plans
             out["parity_mismatches"] = parity_mismatches
-        print(json.dumps(out))
         sys.stdout.flush()
+        os.write(JSON_FD, (json.dumps(out) + "\n").encode())  # the ONE line of the contract, on the real stdout
         bad = []
         if status_counts["arena_overflow"] or status_counts["error"]:
             bad.append("%d plans overflowed their arena, %d carried an error status" % (status_counts["arena_overflow"], status_counts["error"]))

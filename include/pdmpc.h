@@ -416,6 +416,14 @@ int pdmpc_group_handle(pdmpc_group* group, int32_t rank, pdmpc_handle** handle);
 int pdmpc_group_upload_mpa(pdmpc_group* group, const pdmpc_mpa* mpa);
 int pdmpc_group_plan_step(pdmpc_group* group, int32_t n_vehicles, const pdmpc_vehicle_in* in, const int32_t* pred_offset, const int32_t* pred_index,
                           const pdmpc_polygon_set* fallback_shapes, const double* weights, int32_t mode, pdmpc_vehicle_out* out);
+/* The three parts of pdmpc_group_plan_step on their own, for steps that stay resident (bench.py's timed replay): pack partitions the
+ * step and makes its sub-problems resident on the devices in group bank `bank` (0 .. 999; the handles' own banks 0 .. 2047 stay the
+ * caller's), launch plans a packed bank (launches, all-gathers and imports enqueued on the handles' streams, ONE wait at the end; no
+ * host-to-device copy), fetch copies the records of the bank launched last to the host.  plan_step = pack(0) + launch(0) + fetch(0). */
+int pdmpc_group_pack_step(pdmpc_group* group, int32_t bank, int32_t n_vehicles, const pdmpc_vehicle_in* in, const int32_t* pred_offset, const int32_t* pred_index,
+                          const pdmpc_polygon_set* fallback_shapes, const double* weights, int32_t mode);
+int pdmpc_group_launch(pdmpc_group* group, int32_t bank);
+int pdmpc_group_fetch(pdmpc_group* group, int32_t bank, int32_t n_vehicles, pdmpc_vehicle_out* out);
 /* The partition pdmpc_group_plan_step uses, on its own (no GPU needed): rank_of[v] = device that plans vehicle v as part of a whole
  * component, or -1 if v belongs to the component that is planned by levels over all devices (then level_of[v] = its computation
  * level, 1-based, and block_rank[v] = the device of its block within that level; 0 / -1 for the others).  Twin of

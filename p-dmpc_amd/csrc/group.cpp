@@ -259,6 +259,13 @@ struct pdmpc_group {
     size_t shared_cap = 0;
     std::vector<unsigned char> host;          // read-back staging
     double timing[6] = {0, 0, 0, 0, 0, 0};
+    struct Plan {                             // a packed step (pdmpc_group_pack_step): how it is split and how large its blocks are
+        bool valid = false;
+        int n = 0;
+        Partition P;
+        size_t per_w = 0;
+    };
+    std::vector<Plan> plans;
 };
 
 namespace {
@@ -287,7 +294,10 @@ namespace {
         if (rc__) return rc__;   \
     } while (0)
 
-const int kBankShared = 4090, kBankWhole = 4091;  // HBM banks of the two sub-problems (pdmpc_select_bank): the caller's banks stay untouched
+// HBM banks of the two sub-problems of group bank b (pdmpc_select_bank): the handles' own banks 0 .. 2047 stay the caller's
+const int kGroupBanks = 1000;
+inline int bank_shared(int b) { return 2048 + 2 * b; }
+inline int bank_whole(int b) { return 2049 + 2 * b; }
 
 int ensure_buffers(pdmpc_group* g, size_t per, size_t n_shared) {
     const size_t world = g->h.size();
@@ -327,13 +337,18 @@ int all_gather(pdmpc_group* g, size_t per) {
     return PDMPC_OK;
 }
 
-int plan_once(pdmpc_group* g, int n, const pdmpc_vehicle_in* in, const int32_t* off, const int32_t* idx, const pdmpc_polygon_set* fb, const double* weights, int mode,
-              pdmpc_vehicle_out* out) {
-    using clk = std::chrono::steady_clock;
-    auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+using clk = std::chrono::steady_clock;
+inline double ms_between(clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); }
+
+// partition the step, build the sub-problems and make them resident on the devices (group bank `bank`)
+int group_pack(pdmpc_group* g, int bank, int n, const pdmpc_vehicle_in* in, const int32_t* off, const int32_t* idx, const pdmpc_polygon_set* fb, const double* weights, int mode) {
     const auto t0 = clk::now();
     const int world = (int)g->h.size();
-    Partition P;
+    if ((size_t)bank >= g->plans.size()) g->plans.resize((size_t)bank + 1);
+    pdmpc_group::Plan& L = g->plans[(size_t)bank];
+    L.valid = false;
+    L.n = n;
+    Partition& P = L.P;
     GRC(make_partition(n, off, idx, weights, world, mode, P));
     SubProblem S;
     std::vector<SubProblem> W((size_t)world);
@@ -344,26 +359,41 @@ int plan_once(pdmpc_group* g, int n, const pdmpc_vehicle_in* in, const int32_t* 
         per_w = std::max(per_w, P.parts[(size_t)r].size());
     }
     for (int sz : P.level_sizes) per_l = std::max(per_l, (size_t)((sz + world - 1) / world));
+    L.per_w = std::max<size_t>(per_w, 1);
     const auto t1 = clk::now();
-    // ---- pack: the shared component on every device, a device's whole components on that device
+    // the shared component on every device, a device's whole components on that device
     const int nS = (int)P.shared.size();
     for (int r = 0; r < world; ++r) {
         if (nS) {
-            GRC(pdmpc_select_bank(g->h[(size_t)r], kBankShared));
+            GRC(pdmpc_select_bank(g->h[(size_t)r], bank_shared(bank)));
             GRC(pdmpc_pack_step(g->h[(size_t)r], nS, S.in.data(), S.pred_off.data(), S.pred_idx.data(), S.any_fallback ? S.fallback.data() : nullptr));
         }
         const SubProblem& w = W[(size_t)r];
         if (!w.in.empty()) {
-            GRC(pdmpc_select_bank(g->h[(size_t)r], kBankWhole));
+            GRC(pdmpc_select_bank(g->h[(size_t)r], bank_whole(bank)));
             GRC(pdmpc_pack_step(g->h[(size_t)r], (int)w.in.size(), w.in.data(), w.pred_off.data(), w.pred_idx.data(), w.any_fallback ? w.fallback.data() : nullptr));
         }
+        GRC(pdmpc_select_bank(g->h[(size_t)r], 0));
     }
     GRC(ensure_buffers(g, std::max<size_t>(std::max(per_w, per_l), 1), (size_t)nS));
+    L.valid = true;
+    g->timing[1] = ms_between(t0, t1);
+    g->timing[2] = ms_between(t1, clk::now());
+    return PDMPC_OK;
+}
+
+// plan the packed step: everything enqueued on the handles' streams, one wait at the end
+int group_launch(pdmpc_group* g, int bank) {
+    if ((size_t)bank >= g->plans.size() || !g->plans[(size_t)bank].valid) return gfail(PDMPC_ERR_INVALID, "pdmpc_group_launch: nothing packed in that bank");
     const auto t2 = clk::now();
+    const int world = (int)g->h.size();
+    const pdmpc_group::Plan& L = g->plans[(size_t)bank];
+    const Partition& P = L.P;
+    const int nS = (int)P.shared.size();
     // ---- the shared component, level by level (PredictionsCommunication.m:34-63 per level)
     if (nS) {
         for (int r = 0; r < world; ++r) {
-            GRC(pdmpc_select_bank(g->h[(size_t)r], kBankShared));
+            GRC(pdmpc_select_bank(g->h[(size_t)r], bank_shared(bank)));
             GRC(pdmpc_begin_step(g->h[(size_t)r]));
         }
         int first = 0;
@@ -398,36 +428,42 @@ int plan_once(pdmpc_group* g, int n, const pdmpc_vehicle_in* in, const int32_t* 
         const int nr = (int)P.parts[(size_t)r].size();
         if (!nr) continue;
         any_whole = true;
-        GRC(pdmpc_select_bank(g->h[(size_t)r], kBankWhole));
+        GRC(pdmpc_select_bank(g->h[(size_t)r], bank_whole(bank)));
         GRC(pdmpc_launch_packed(g->h[(size_t)r]));
         GRC(pdmpc_export_results_async(g->h[(size_t)r], 0, nr, g->send[(size_t)r]));
     }
-    if (any_whole) GRC(all_gather(g, std::max<size_t>(per_w, 1)));
+    if (any_whole) GRC(all_gather(g, L.per_w));
     const auto t3 = clk::now();
     for (int r = 0; r < world; ++r) GRC(pdmpc_synchronize(g->h[(size_t)r]));
+    for (int r = 0; r < world; ++r) GRC(pdmpc_select_bank(g->h[(size_t)r], 0));
+    g->timing[3] = ms_between(t2, t3);
+    g->timing[4] = ms_between(t3, clk::now());
+    return PDMPC_OK;
+}
+
+// the records of the step planned last (every device holds every block: read from device 0), in the caller's order
+int group_fetch(pdmpc_group* g, int bank, int n, pdmpc_vehicle_out* out) {
+    if ((size_t)bank >= g->plans.size() || !g->plans[(size_t)bank].valid) return gfail(PDMPC_ERR_INVALID, "pdmpc_group_fetch: nothing packed in that bank");
     const auto t4 = clk::now();
-    // ---- read-back from device 0 (every device holds every block)
+    const pdmpc_group::Plan& L = g->plans[(size_t)bank];
+    if (n != L.n) return gfail(PDMPC_ERR_INVALID, "pdmpc_group_fetch: the bank holds another number of vehicles");
+    const Partition& P = L.P;
+    const int world = (int)g->h.size(), nS = (int)P.shared.size();
+    bool any_whole = false;
+    for (int r = 0; r < world; ++r) any_whole = any_whole || !P.parts[(size_t)r].empty();
     GHIP(hipSetDevice(g->dev[0]));
     if (any_whole) {
-        g->host.resize(std::max<size_t>(per_w, 1) * kRec * (size_t)world);
+        g->host.resize(L.per_w * kRec * (size_t)world);
         GHIP(hipMemcpy(g->host.data(), g->recv[0], g->host.size(), hipMemcpyDeviceToHost));
         for (int r = 0; r < world; ++r)
-            for (size_t i = 0; i < P.parts[(size_t)r].size(); ++i)
-                std::memcpy(&out[P.parts[(size_t)r][i]], g->host.data() + ((size_t)r * std::max<size_t>(per_w, 1) + i) * kRec, kRec);
+            for (size_t i = 0; i < P.parts[(size_t)r].size(); ++i) std::memcpy(&out[P.parts[(size_t)r][i]], g->host.data() + ((size_t)r * L.per_w + i) * kRec, kRec);
     }
     if (nS) {
         g->host.resize((size_t)nS * kRec);
         GHIP(hipMemcpy(g->host.data(), g->shared_buf, g->host.size(), hipMemcpyDeviceToHost));
         for (int i = 0; i < nS; ++i) std::memcpy(&out[P.shared[(size_t)i]], g->host.data() + (size_t)i * kRec, kRec);
     }
-    for (int r = 0; r < world; ++r) GRC(pdmpc_select_bank(g->h[(size_t)r], 0));
-    const auto t5 = clk::now();
-    g->timing[0] = ms(t0, t5);
-    g->timing[1] = ms(t0, t1);
-    g->timing[2] = ms(t1, t2);
-    g->timing[3] = ms(t2, t3);
-    g->timing[4] = ms(t3, t4);
-    g->timing[5] = ms(t4, t5);
+    g->timing[5] = ms_between(t4, clk::now());
     return PDMPC_OK;
 }
 
@@ -549,7 +585,11 @@ int pdmpc_group_plan_step(pdmpc_group* g, int32_t n, const pdmpc_vehicle_in* in,
     // The reference's tree is unbounded (Tree.m:54-70): a step in which some search outgrew its arena is planned again with arenas twice
     // as large on every device (as pdmpc_plan_step does for one).
     for (;;) {
-        GRC(plan_once(g, n, in, pred_offset, pred_index, fallback_shapes, weights, mode, out));
+        const auto t0 = clk::now();
+        GRC(group_pack(g, 0, n, in, pred_offset, pred_index, fallback_shapes, weights, mode));
+        GRC(group_launch(g, 0));
+        GRC(group_fetch(g, 0, n, out));
+        g->timing[0] = ms_between(t0, clk::now());
         bool overflow = false;
         for (int i = 0; i < n; ++i) overflow = overflow || out[i].status == PDMPC_ARENA_OVERFLOW;
         if (!overflow) return PDMPC_OK;
@@ -559,6 +599,25 @@ int pdmpc_group_plan_step(pdmpc_group* g, int32_t n, const pdmpc_vehicle_in* in,
         for (pdmpc_handle* h : g->h)
             if (pdmpc_grow_arena(h, nodes * 2) != PDMPC_OK) return PDMPC_OK;  // no room to grow: statuses tell
     }
+}
+
+int pdmpc_group_pack_step(pdmpc_group* g, int32_t bank, int32_t n, const pdmpc_vehicle_in* in, const int32_t* pred_offset, const int32_t* pred_index,
+                          const pdmpc_polygon_set* fallback_shapes, const double* weights, int32_t mode) {
+    if (!g || n < 0 || (n > 0 && !in)) return gfail(PDMPC_ERR_INVALID, "pdmpc_group_pack_step: null argument");
+    if (bank < 0 || bank >= kGroupBanks) return gfail(PDMPC_ERR_INVALID, "pdmpc_group_pack_step: bank out of range");
+    if (pred_offset && !pred_index) return gfail(PDMPC_ERR_INVALID, "pred_index missing");
+    if (mode != PDMPC_SHARD_AUTO && mode != PDMPC_SHARD_COMPONENTS && mode != PDMPC_SHARD_LEVELS) return gfail(PDMPC_ERR_INVALID, "unknown sharding mode");
+    return group_pack(g, bank, n, in, pred_offset, pred_index, fallback_shapes, weights, mode);
+}
+
+int pdmpc_group_launch(pdmpc_group* g, int32_t bank) {
+    if (!g || bank < 0) return gfail(PDMPC_ERR_INVALID, "pdmpc_group_launch: bad argument");
+    return group_launch(g, bank);
+}
+
+int pdmpc_group_fetch(pdmpc_group* g, int32_t bank, int32_t n, pdmpc_vehicle_out* out) {
+    if (!g || bank < 0 || (n > 0 && !out)) return gfail(PDMPC_ERR_INVALID, "pdmpc_group_fetch: bad argument");
+    return group_fetch(g, bank, n, out);
 }
 
 int pdmpc_group_last_timing(pdmpc_group* g, double* ms6) {

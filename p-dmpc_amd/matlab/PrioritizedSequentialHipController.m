@@ -26,9 +26,17 @@ classdef PrioritizedSequentialHipController < PrioritizedSequentialController
     % csrc/step_controller.cpp are the tested twins of this logic, tests/test_matlab_marshal.py and
     % test_gpu_step.py::test_matlab_shaped_entry_points_plan_the_step_like_the_oracle test the call this class makes.
 
+    properties (Access = public)
+        n_gpus (1, 1) double = 1; % > 1: the step is planned over that many GPUs of this node (pdmpc_group_*, RCCL all-gather of the
+        %                           solved areas: what PredictionsCommunication.send_message / read_message do between the vehicles'
+        %                           processes, hlc/communication/PredictionsCommunication.m:34-63)
+        shard_mode (1, 1) double = 0; % 0 auto (whole coupling-graph components, a dominating one by levels), 1 components, 2 levels
+    end
+
     properties (Access = private)
-        handle uint64 = uint64(0); % pdmpc_handle* for all vehicles of the step
+        handle uint64 = uint64(0); % pdmpc_handle* (n_gpus == 1) or pdmpc_group* for all vehicles of the step
         mpa_uploaded (1, 1) logical = false;
+        last_work double = []; % n_expanded of every vehicle's last plan: the weights of the next step's partition
     end
 
     methods
@@ -39,7 +47,9 @@ classdef PrioritizedSequentialHipController < PrioritizedSequentialController
 
         function delete(obj)
 
-            if obj.handle ~= 0
+            if obj.handle ~= 0 && obj.n_gpus > 1
+                pdmpc_mex('group_destroy', obj.handle);
+            elseif obj.handle ~= 0
                 pdmpc_mex('destroy', obj.handle);
             end
 
@@ -56,12 +66,24 @@ classdef PrioritizedSequentialHipController < PrioritizedSequentialController
 
             if obj.handle == 0
                 checker = double(options.are_any_obstacles_non_convex); % OptimizerInterface.m:36-46
-                obj.handle = pdmpc_mex('create', Hp, checker, options.dt_seconds, n);
+
+                if obj.n_gpus > 1
+                    obj.handle = pdmpc_mex('group_create', Hp, checker, options.dt_seconds, n, obj.n_gpus);
+                else
+                    obj.handle = pdmpc_mex('create', Hp, checker, options.dt_seconds, n);
+                end
+
             end
 
             if ~obj.mpa_uploaded
                 mpa = obj.hlcs(1).mpa;
-                pdmpc_mex('upload_mpa', obj.handle, mpa.transition_matrix_single, mpa.maneuvers);
+
+                if obj.n_gpus > 1
+                    pdmpc_mex('group_upload_mpa', obj.handle, mpa.transition_matrix_single, mpa.maneuvers);
+                else
+                    pdmpc_mex('upload_mpa', obj.handle, mpa.transition_matrix_single, mpa.maneuvers);
+                end
+
                 obj.mpa_uploaded = true;
             end
 
@@ -82,7 +104,14 @@ classdef PrioritizedSequentialHipController < PrioritizedSequentialController
             end
 
             % ---- the whole double loop of PrioritizedSequentialController.controller: one call, one kernel launch
-            outs = pdmpc_mex('plan_step', obj.handle, iters, double(directed_coupling_sequential), fallback_areas);
+            if obj.n_gpus > 1
+                % ... over the GPUs of the node: whole components of the coupling graph per GPU, the exchange of solved areas between
+                % the levels of a shared component as an all-gather (pdmpc_group_plan_step); same records
+                outs = pdmpc_mex('group_plan_step', obj.handle, iters, double(directed_coupling_sequential), fallback_areas, obj.last_work, obj.shard_mode);
+                obj.last_work = double([outs.n_expanded]);
+            else
+                outs = pdmpc_mex('plan_step', obj.handle, iters, double(directed_coupling_sequential), fallback_areas);
+            end
 
             % ---- results, in kahn order (publish_predictions sends the messages later readers expect in this order)
             for i_level = 1:max(levels_of_vehicles)

@@ -119,7 +119,33 @@ public:
             outputs[0] = f.createScalar<uint64_t>((uint64_t)h);
             return;
         }
-        pdmpc_handle* h = (pdmpc_handle*)(uint64_t)inputs[1][0];
+        // ---- several GPUs (include/pdmpc.h: pdmpc_group_*): 'group_create', Hp, checker, dt, max_vehicles, n_gpus -> group;
+        //      'group_destroy', 'group_upload_mpa' and 'group_plan_step' (iters, coupling, fallback areas [, weights [, mode]]) take it
+        //      where the single-GPU commands take the handle
+        if (cmd == "group_create") {
+            pdmpc_config cfg{};
+            cfg.Hp = (int32_t)inputs[1][0];
+            cfg.checker = (int32_t)inputs[2][0];
+            cfg.dt_seconds = inputs[3][0];
+            cfg.max_vehicles = (int32_t)inputs[4][0];
+            const int32_t n_gpus = (int32_t)inputs[5][0];
+            pdmpc_group* g = nullptr;
+            if (pdmpc_group_create(&cfg, n_gpus, nullptr, &g) != PDMPC_OK) fail("pdmpc_group_create", pdmpc_last_error());
+            outputs[0] = f.createScalar<uint64_t>((uint64_t)g);
+            return;
+        }
+        pdmpc_group* group = nullptr;
+        pdmpc_handle* h = nullptr;
+        if (cmd.rfind("group_", 0) == 0) {
+            group = (pdmpc_group*)(uint64_t)inputs[1][0];
+            if (cmd == "group_destroy") {
+                pdmpc_group_destroy(group);
+                return;
+            }
+            if (pdmpc_group_handle(group, 0, &h) != PDMPC_OK) fail("pdmpc_group_handle", pdmpc_last_error());
+        } else {
+            h = (pdmpc_handle*)(uint64_t)inputs[1][0];
+        }
         if (cmd == "destroy") {
             pdmpc_destroy(h);
             return;
@@ -127,7 +153,7 @@ public:
         pdmpc_config hc{};
         if (pdmpc_get_config(h, &hc, nullptr) != PDMPC_OK) fail("pdmpc_get_config", pdmpc_last_error());
         const size_t Hp = (size_t)hc.Hp;
-        if (cmd == "upload_mpa") {
+        if (cmd == "upload_mpa" || cmd == "group_upload_mpa") {
             Pins pins;
             const pdmpc_ml_matrix T = pins.matrix(inputs[2]);  // n x n x Hp, column-major
             const CellArray man = inputs[3];                   // n x n cell of structs (generate_maneuver.m:25-34)
@@ -147,17 +173,22 @@ public:
                 }
                 cells.push_back(m);
             }
-            if (pdmpc_ml_upload_mpa(h, T.data, n, T.cols / n, cells.data()) != PDMPC_OK) fail("pdmpc_ml_upload_mpa", pdmpc_ml_last_error());
+            int32_t n_dev = 1;
+            if (group && pdmpc_group_size(group, &n_dev) != PDMPC_OK) fail("pdmpc_group_size", pdmpc_last_error());
+            for (int32_t r = 0; r < n_dev; ++r) {  // (every device of a group holds the tables)
+                if (group && pdmpc_group_handle(group, r, &h) != PDMPC_OK) fail("pdmpc_group_handle", pdmpc_last_error());
+                if (pdmpc_ml_upload_mpa(h, T.data, n, T.cols / n, cells.data()) != PDMPC_OK) fail("pdmpc_ml_upload_mpa", pdmpc_ml_last_error());
+            }
             return;
         }
-        if (cmd == "plan" || cmd == "plan_sampled" || cmd == "plan_level" || cmd == "plan_step") {
+        if (cmd == "plan" || cmd == "plan_sampled" || cmd == "plan_level" || cmd == "plan_step" || cmd == "group_plan_step") {
             Pins pins;
             const StructArray iters = inputs[2];
             const size_t n = iters.getNumberOfElements();
             std::vector<pdmpc_ml_iter> its;
             for (size_t i = 0; i < n; ++i) its.push_back(iter_from_struct(iters, i, pins));
             std::vector<pdmpc_vehicle_out> out(n);
-            if (cmd == "plan_step") {
+            if (cmd == "plan_step" || cmd == "group_plan_step") {
                 const pdmpc_ml_matrix seq = pins.matrix(inputs[3]);  // n x n directed_coupling_sequential
                 // pdmpc_ml_step_create indexes seq[i + j * n] and fallback[v + k * n]: anything smaller reads outside MATLAB's arrays,
                 // and an empty coupling matrix would silently plan the step without couplings
@@ -168,9 +199,18 @@ public:
                 if (fb != nullptr && ((size_t)r != n || (size_t)c != Hp)) fail("plan_step", "fallback areas must be an n x Hp cell");
                 pdmpc_ml_step* step = nullptr;
                 if (pdmpc_ml_step_create((int32_t)Hp, (int32_t)n, its.data(), seq.data, fb, &step) != PDMPC_OK) fail("pdmpc_ml_step_create", pdmpc_ml_last_error());
-                const int rc = pdmpc_ml_plan_step(h, step, out.data());
+                int rc;
+                if (group) {
+                    // weights: 1 x n expected work per vehicle (e.g. the n_expanded of its last plan), [] = equal; mode: 0 auto, 1 whole components, 2 levels
+                    const pdmpc_ml_matrix w = inputs.size() > 5 && !inputs[5].isEmpty() ? pins.matrix(inputs[5]) : pdmpc_ml_matrix{nullptr, 0, 0};
+                    if (w.data != nullptr && (size_t)w.rows * (size_t)w.cols != n) fail("group_plan_step", "weights must hold one value per vehicle");
+                    const int32_t mode = inputs.size() > 6 ? (int32_t)inputs[6][0] : PDMPC_SHARD_AUTO;
+                    rc = pdmpc_ml_group_plan_step(group, step, w.data, mode, out.data());
+                } else {
+                    rc = pdmpc_ml_plan_step(h, step, out.data());
+                }
                 pdmpc_ml_step_destroy(step);
-                if (rc != PDMPC_OK) fail("pdmpc_ml_plan_step", pdmpc_ml_last_error());
+                if (rc != PDMPC_OK) fail(group ? "pdmpc_ml_group_plan_step" : "pdmpc_ml_plan_step", pdmpc_ml_last_error());
             } else if (cmd == "plan_sampled") {
                 pdmpc_ml_step* step = nullptr;
                 if (pdmpc_ml_step_create((int32_t)Hp, (int32_t)n, its.data(), nullptr, nullptr, &step) != PDMPC_OK) fail("pdmpc_ml_step_create", pdmpc_ml_last_error());

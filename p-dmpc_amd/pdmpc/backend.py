@@ -50,6 +50,9 @@ EXPORTS = [
     "pdmpc_group_handle",
     "pdmpc_group_upload_mpa",
     "pdmpc_group_plan_step",
+    "pdmpc_group_pack_step",
+    "pdmpc_group_launch",
+    "pdmpc_group_fetch",
     "pdmpc_group_partition",
     "pdmpc_group_last_timing",
     "pdmpc_debug_heap_script",
@@ -221,11 +224,38 @@ class Group:
         del keep
         return out[:n]
 
+    def pack_step(self, bank, iters, predecessors, fallback_shapes=None, weights=None, mode=SHARD_AUTO):
+        """Make a step resident on the devices (group bank `bank`); launch(bank) plans it, fetch(bank, n) reads the records."""
+        n = len(iters)
+        arr, off, idx, fb, keep = Handle._step_args(self, iters, predecessors, fallback_shapes)
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+        self.L.pdmpc_group_pack_step.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, abi.c_int32_p, abi.c_int32_p, C.c_void_p, abi.c_double_p, C.c_int32]
+        _check(self.L, self.L.pdmpc_group_pack_step(self.g, bank, n, arr, off.ctypes.data_as(abi.c_int32_p), idx.ctypes.data_as(abi.c_int32_p), fb,
+                                                    None if w is None else w.ctypes.data_as(abi.c_double_p), mode), "pdmpc_group_pack_step")
+        del keep
+
+    def launch(self, bank):
+        self.L.pdmpc_group_launch.argtypes = [C.c_void_p, C.c_int32]
+        _check(self.L, self.L.pdmpc_group_launch(self.g, bank), "pdmpc_group_launch")
+
+    def fetch(self, bank, n):
+        out = abi.out_array(n)
+        self.L.pdmpc_group_fetch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        _check(self.L, self.L.pdmpc_group_fetch(self.g, bank, n, abi.out_ptr(out)), "pdmpc_group_fetch")
+        return out[:n]
+
     def timing(self):
         t = (C.c_double * 6)()
         self.L.pdmpc_group_last_timing.argtypes = [C.c_void_p, C.c_void_p]
         _check(self.L, self.L.pdmpc_group_last_timing(self.g, t), "pdmpc_group_last_timing")
         return dict(zip(("total", "partition", "pack", "enqueue", "wait", "read_back"), t))
+
+    def reset_stats(self):
+        for r in range(self.n_devices):
+            h = C.c_void_p()
+            self.L.pdmpc_group_handle.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+            _check(self.L, self.L.pdmpc_group_handle(self.g, r, C.byref(h)), "pdmpc_group_handle")
+            _check(self.L, self.L.pdmpc_reset_stats(h), "pdmpc_reset_stats")
 
     def stats(self, rank=0):
         h = C.c_void_p()

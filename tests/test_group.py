@@ -104,8 +104,24 @@ def test_group_of_one_device_equals_the_single_launch(mode):
         seen.append(len(prob["iters"]))
         return [info_from_record(ref[i], options.Hp) for i in range(len(prob["iters"]))]
 
+    kept = []
+
+    def plan_and_keep(prob):
+        kept.append(prob)
+        return plan_step(prob)
+
     for _ in range(6):
-        ctl.step(plan_step=plan_step)
+        ctl.step(plan_step=plan_and_keep)
     assert grp.stats()["kernel"] == 2 and grp.timing()["total"] > 0
+    # ... and as resident banks launched again and again (bench.py's replay): pack once, launch without a host-to-device copy
+    refs = []
+    for b, prob in enumerate(kept[-3:]):
+        fb = [f if f is not None else [] for f in prob["fallback"]]
+        refs.append(opt.handle.plan_step(prob["iters"], prob["preds"], fb))
+        grp.pack_step(b, prob["iters"], prob["preds"], fb, mode=mode)
+    for rep in range(2):
+        for b, prob in enumerate(kept[-3:]):
+            grp.launch(b)
+            assert_records_equal(grp.fetch(b, len(prob["iters"])), refs[b], "resident group bank %d, pass %d" % (b, rep))
     grp.close()
     opt.handle.close()
