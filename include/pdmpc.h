@@ -285,6 +285,10 @@ int pdmpc_debug_edge_check(pdmpc_handle* handle, int32_t mode, int32_t n_cases, 
 int pdmpc_debug_raw_tree(pdmpc_handle* handle, int32_t vehicle, int32_t capacity, double* x, double* y, double* yaw, double* g,
                          double* h, int32_t* trim, int32_t* k, int32_t* parent, double* key, uint8_t* validity, int32_t* n);
 
+/* the device's work counters since pdmpc_create / pdmpc_reset_stats, raw: [0..6] as pdmpc_stats reports them, [8..12] with
+ * PDMPC_TUNING=debug_tail=1 the helper workgroups' time in 100 MHz ticks (idle, claim -> soup, records, checks, verdicts + report), [13] tiles */
+int pdmpc_debug_counters(pdmpc_handle* handle, uint64_t* out16);
+
 /* live counters of a running frontier launch (needs PDMPC_DEBUG_PROGRESS=1 in the environment; callable from another thread
  * while pdmpc_plan_* blocks): rounds, nodes processed, tree size, near / far entries, flags, best candidate, stage */
 int pdmpc_debug_progress(pdmpc_handle* handle, int32_t vehicle, uint32_t* words16);

@@ -139,9 +139,9 @@ struct Tuning {
     int round = -1;         // the most a round takes (-1: 1000 with helper workgroups, else 256)
     int ramp = -1;          // a round grows by 1 / ramp of the nodes processed so far (-1: 2 with helper workgroups, else 4)
     int ready = 2048;       // entries of the ready list with helper workgroups (half of it without): the most a round can take
-    int share_min = 192;    // a round with at least this many nodes is shared with the helper workgroups
+    int share_min = 64;     // a round with at least this many nodes is shared with the helper workgroups (measured on C2 with 230 helpers: 128 -> 1 225 steps/s, 96 -> 1 235, 64 -> 1 258)
     int own_div = 8;        // the owner of a shared round starts on 1 / own_div of its tiles
-    int tile = -1;          // nodes of a tile of a shared round (-1: 64, or 128 for launches of 64 searches and more)
+    int tile = -1;          // the most nodes of a shared round one seated helper takes (-1: 256; what it stages in LDS: at most 768)
     int mid_min = 24576;    // far lists longer than this feed near through the mid list (a band of far's smallest keys)
     int mid_fill = 12288;   // entries a refill of mid aims at
     int tentative = 1;      // expected areas of predecessors that are still planning (A/B switch)
@@ -206,7 +206,7 @@ bool parse_tuning(const char* text, Tuning& T, std::string& err) {
     T.ready = std::min(2048, std::max(256, T.ready)) & ~63;
     T.share_min = std::max(64, T.share_min);
     T.own_div = std::max(1, T.own_div);
-    if (T.tile >= 0) T.tile = std::min(128, std::max(16, T.tile));
+    if (T.tile >= 0) T.tile = std::min(768, std::max(8, T.tile));
     T.mid_min = std::max(0, T.mid_min);
     T.mid_fill = std::max(256, T.mid_fill);
     T.waves = std::min(PDMPC_MAX_WAVES, std::max(4, T.waves));
@@ -257,6 +257,7 @@ struct pdmpc_handle {
     bool last_safe = false;              // ... and whether it went out in resident slices
     bool boards_dirty = true;            // the helper boards / the finished counter need clearing before the helper workgroups may read them
     uint32_t help_fin_total = 0;         // value of the finished counter once every launch so far has ended
+    uint32_t launch_serial = 0;          // launches of this handle so far (KernelArgs::launch_id)
     double dbg_us[4] = {0, 0, 0, 0};     // debug_host 2: pack, launch, fetch (host clock) and kernel (events) time of the plan_batch calls
     uint64_t sync_serial = 0;            // stream synchronisations through sync_stream so far (PackedStep::staged_serial)
     std::vector<double> pack_pts;        // pack_common's scratch (kept: a pack allocates nothing once warm)
@@ -712,10 +713,7 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     a.own_div = T.own_div;
     a.bk_mid_min = T.mid_min;
     a.bk_mid_fill = T.mid_fill;
-    // a tile costs a helper ≈ 10 us besides its checks (claim, acquire, records, verdicts, release, report): launches with many searches,
-    // whose helpers hop between boards, do better with larger tiles (measured C2 / C3 / C4: 64 -> 1 049 / 1 015 / 70.4 steps/s, 96 -> 1 032 / 1 023 / 71.2,
-    // 128 -> 1 028 / 1 028 / 71.6; 32 -> 951 / 833 / -)
-    a.bk_tile = T.tile > 0 ? T.tile : (count >= 64 ? 128 : 64);
+    a.bk_tile = T.tile > 0 ? T.tile : 256;
     a.bk_tentative = T.tentative;
     a.bk_fast_arrival = T.fast_arrival;
     a.bk_force_tie = T.force_tie;
@@ -724,6 +722,9 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     a.help_verdict = h->d_help_verdict.p;
     a.help_finished = h->d_help_finished.p;
     a.help_fin_base = 0;
+    h->launch_serial += 1;
+    if (h->launch_serial == 0) h->launch_serial = 1;
+    a.launch_id = h->launch_serial;
     // Helper workgroups: the trailing workgroups of the launch, on the CUs it leaves idle, check tiles of the searches' large rounds.
     // A launch with more searches than CUs gets them for its tail, when CUs fall idle while a few long searches still run (measured on
     // C4, 512 searches: none 25.6 steps/s, 32 helpers 41.5, 96: 42.8-45.9); five searches per CU: a helper only takes a CU away from a
@@ -732,8 +733,10 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     a.n_helpers = 0;
     if (helped) {
         if (count <= h->n_cu) {
-            // (measured on C2, 20 searches, / C3, 128: 8 helpers 535 / 476 steps/s, 16: 529 / 506, 32: 516 / 522, 128: 507 / 483)
-            int want = std::min(64, std::max(32, count / 2));
+            // every CU the launch leaves idle: a seated helper polls a word of its own, so helpers cost the searches nothing (measured on
+            // C2, 20 searches: 32 helpers 1 110 steps/s, 64: 1 120, 96: 1 190, 128: 1 200, 200: 1 210, 230: 1 235; with the ticket word of
+            // rounds 3-4 that all helpers polled and claimed from, 64 helpers were slower than 32 and 200 cost 40 %)
+            int want = h->n_cu - count;
             if (T.helpers >= 0) want = T.helpers;
             a.n_helpers = std::max(0, std::min(want, h->n_cu - count));
             if (a.n_helpers < 2) a.n_helpers = 0;
@@ -845,7 +848,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
         return fail(PDMPC_ERR_HIP, "hipStreamCreate failed");
     }
     int bad = alloc_arenas(h, want_nodes);
-    bad |= h->d_out.ensure((size_t)h->max_vehicles) | h->d_flag.ensure((size_t)h->max_vehicles) | h->d_tree_size.ensure((size_t)h->max_vehicles) | h->d_tie_count.ensure(4) | h->d_work_count.ensure(8);
+    bad |= h->d_out.ensure((size_t)h->max_vehicles) | h->d_flag.ensure((size_t)h->max_vehicles) | h->d_tree_size.ensure((size_t)h->max_vehicles) | h->d_tie_count.ensure(4) | h->d_work_count.ensure(16);
     bad |= h->d_help_board.ensure((size_t)h->max_vehicles * PDMPC_HB_WORDS) | h->d_help_verdict.ensure((size_t)h->max_vehicles * PDMPC_HELP_CAP) | h->d_help_finished.ensure(16);
     bad |= h->d_bk_post.ensure((size_t)h->max_vehicles * (size_t)h->tune.ready * 6);
     if (bad) {
@@ -855,7 +858,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
     (void)hipMemsetAsync(h->d_flag.p, 0, h->d_flag.cap * sizeof(uint32_t), h->stream);
     (void)hipMemsetAsync(h->d_tree_size.p, 0, h->d_tree_size.cap * sizeof(int32_t), h->stream);
     (void)hipMemsetAsync(h->d_tie_count.p, 0, 4 * sizeof(int32_t), h->stream);
-    (void)hipMemsetAsync(h->d_work_count.p, 0, 8 * sizeof(unsigned long long), h->stream);
+    (void)hipMemsetAsync(h->d_work_count.p, 0, 16 * sizeof(unsigned long long), h->stream);
     (void)hipMemsetAsync(h->d_out.p, 0, h->d_out.cap * sizeof(pdmpc_vehicle_out), h->stream);
     (void)hipStreamSynchronize(h->stream);
     *out_handle = h;
@@ -1002,7 +1005,7 @@ int pdmpc_reset_stats(pdmpc_handle* h) {
     HIPCHK(hipStreamSynchronize(h->stream));
     h->events_used = 0;
     HIPCHK(hipMemsetAsync(h->d_tie_count.p, 0, 4 * sizeof(int32_t), h->stream));
-    HIPCHK(hipMemsetAsync(h->d_work_count.p, 0, 8 * sizeof(unsigned long long), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_work_count.p, 0, 16 * sizeof(unsigned long long), h->stream));
     return PDMPC_OK;
 }
 
@@ -1314,6 +1317,14 @@ int pdmpc_export_results_async(pdmpc_handle* h, int32_t first, int32_t n, void* 
 int pdmpc_stream(pdmpc_handle* h, void** hip_stream) {
     if (!h || !hip_stream) return fail(PDMPC_ERR_INVALID, "null argument");
     *hip_stream = (void*)h->stream;
+    return PDMPC_OK;
+}
+
+int pdmpc_debug_counters(pdmpc_handle* h, uint64_t* out16) {
+    if (!h || !out16) return fail(PDMPC_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out16, h->d_work_count.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return PDMPC_OK;
 }
 

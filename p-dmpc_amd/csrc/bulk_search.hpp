@@ -969,6 +969,17 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         r_flag[0] = 0u;
     }
     if (tid < BK_NB) bins[tid] = 0u;
+    if (A.n_helpers > 0 && tid >= 64 && tid < 64 + PDMPC_HB_SEATS_MAX) {  // this search's board: no seats, no assignments, nothing reported (the words may hold an earlier launch's)
+        unsigned long long* bd0 = A.help_board + (size_t)slot * PDMPC_HB_WORDS;
+        const int k = tid - 64;
+        __hip_atomic_store(bd0 + PDMPC_HB_ASSIGN + k, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(bd0 + PDMPC_HB_DONE + k, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (k == 0) {
+            __hip_atomic_store(bd0 + PDMPC_HB_WANT, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(bd0 + PDMPC_HB_SEATS, (unsigned long long)A.launch_id << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     if (A.bk_tentative) bk_tentative_areas(A, P, sh_load64(sh, SH_PEND_LO), tid, (int)blockDim.x);  // (the pending set was fixed by the prologue)
     if (tid >= 64 && tid < 72) {
         const int ls = tid - 64;
@@ -1104,6 +1115,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
     // shared rounds (helper workgroups)
     unsigned long long* board = A.help_board + (size_t)slot * PDMPC_HB_WORDS;
     uint32_t help_seq = 0;  // rounds shared so far (same value in every thread)
+    bool wanted = false;    // the board says that this search shares its rounds (helpers take seats)
 
     const int tid_k = tid, lane_k = lane;
     for (;;) {
@@ -1124,21 +1136,41 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             pb_valid = false;  // (the tree grows: phase B's result is stale)
             rec_valid = false;
             vs_copied = false;
-            // ---- P1: check items + sincos items.  A large round is shared with the helper workgroups (CUs this launch leaves idle):
-            // the owner posts one 48-byte record per entry (what a check reads of the tree), keeps the first tiles of 64 entries and
-            // offers the others; helpers claim tiles (compare-and-swap on the board's ticket word, which carries the round's sequence
-            // number), mirror the search's soup in their LDS and leave one verdict word per entry.  What nobody has claimed when the
-            // owner is through with its part it does itself; then it waits for the claimed tiles.
+            // ---- P1: check items + sincos items.  A large round is shared with the helper workgroups that have taken a seat at this
+            // search (CUs the launch leaves idle, bulk_helper_body): the owner posts one 48-byte record per entry (what a check reads of
+            // the tree), keeps the first part of the list and hands every seated helper a contiguous range through that helper's own
+            // assignment word; a helper mirrors the search's soup in its LDS, checks its range and leaves one verdict word per entry and
+            // the round's number in its own done word.  Nobody claims anything: no compare-and-swap, and every word that is polled has
+            // exactly one poller (rounds 3-4 let all helpers compete for tiles on one ticket word per search: a tile cost 15 us of which
+            // the checks were 5, and more helpers made every search of the launch slower, profiles/r05_helper_sweep.txt).
             const BkTreeSrc tsrc{&S, ready};
             const unsigned long long pend_now = A.bk_tentative ? sh_load64(sh, SH_PEND_LO) : 0ull;  // (their slots hold expected areas)
-            const uint32_t n_tiles = (Rn + TILE - 1u) / TILE;
-            const bool share = A.n_helpers > 0 && Rn >= (uint32_t)A.bk_share_min && P.n_pred <= 64 && n_tiles <= 64u;  // (one bit per tile in the owner's mask)
-            uint32_t own_tiles = n_tiles;
+            bool share = A.n_helpers > 0 && Rn >= (uint32_t)A.bk_share_min && P.n_pred <= 64;
+            uint32_t own_n = Rn, seats = 0, per_h = 0;
             if (share) {  // (uniform)
-                own_tiles = n_tiles / (uint32_t)A.own_div > 0u ? n_tiles / (uint32_t)A.own_div : 1u;
+                if (tid == 0) {
+                    if (!wanted) __hip_atomic_store(board + PDMPC_HB_WANT, (unsigned long long)A.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // helpers may take seats from now on
+                    const unsigned long long sw = __hip_atomic_load(board + PDMPC_HB_SEATS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    uint32_t k = (uint32_t)(sw >> 32) == A.launch_id ? (uint32_t)(sw & 0xffffffffull) : 0u;
+                    sh[FR_HELP_CLOSED] = k < (uint32_t)PDMPC_HB_SEATS_MAX ? k : (uint32_t)PDMPC_HB_SEATS_MAX;
+                }
+                wanted = true;
+                __syncthreads();
+                seats = sh[FR_HELP_CLOSED];
+                share = seats != 0u;
+            }
+            if (share) {  // (uniform)
+                // the owner's part: a share as large as a helper's, less what posting and waiting cost it (1 / own_div of the round at most)
+                per_h = (Rn + seats) / (seats + 1u);
+                {
+                    const uint32_t cap = (uint32_t)A.bk_tile;  // (a helper stages its range's records in LDS)
+                    per_h = per_h < cap ? per_h : cap;
+                }
+                const uint32_t helped = per_h * seats < Rn ? per_h * seats : Rn;
+                own_n = Rn - helped;
                 ++help_seq;
                 d2* post = (d2*)A.bk_post + (size_t)slot * RC * 3u;
-                for (uint32_t r = own_tiles * TILE + (uint32_t)tid; r < Rn; r += (uint32_t)bd) {
+                for (uint32_t r = own_n + (uint32_t)tid; r < Rn; r += (uint32_t)bd) {
                     uint32_t parent, packed;
                     const d2 p3 = node_piece(S, ready[r] - 1u, 3);
                     piece_link(p3, parent, packed);
@@ -1149,92 +1181,65 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 // every wave's stores must have reached L2 before thread 0 writes L2 back: a workgroup barrier alone does not wait for them
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (tid == 0) {
-                    const unsigned long long all = P.n_pred >= 64 ? ~0ull : ((1ull << P.n_pred) - 1ull);
-                    __hip_atomic_store(board + PDMPC_HB_N, (unsigned long long)Rn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(board + PDMPC_HB_MASK, all & ~sh_load64(sh, SH_PEND_LO), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(board + PDMPC_HB_DONE, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    __hip_atomic_store(board + PDMPC_HB_TICKET, ((unsigned long long)help_seq << 32) | ((unsigned long long)n_tiles << 16) | own_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (wave == 0) {
+                    if (lane == 0) {
+                        const unsigned long long all = P.n_pred >= 64 ? ~0ull : ((1ull << P.n_pred) - 1ull);
+                        __hip_atomic_store(board + PDMPC_HB_N, (unsigned long long)Rn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(board + PDMPC_HB_MASK, all & ~sh_load64(sh, SH_PEND_LO), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    wave_sync();
+                    if ((uint32_t)lane < seats) {  // seat k checks entries own_n + k * per_h .. (its assignment word: round << 40 | first << 20 | count)
+                        const uint32_t first = own_n + (uint32_t)lane * per_h;
+                        const uint32_t cnt = first >= Rn ? 0u : (Rn - first < per_h ? Rn - first : per_h);
+                        __hip_atomic_store(board + PDMPC_HB_ASSIGN + lane, ((unsigned long long)help_seq << 40) | ((unsigned long long)first << 20) | (unsigned long long)cnt, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
             }
-            // The owner and the helpers take tiles off the same counter.  The owner does its first tiles (what the ticket starts at), then
-            // looks how far the helpers have come meanwhile and takes its share of the rest — everything if no helper has shown up, one
-            // tile if they are many — and so on until the counter is through; then it waits for the tiles the helpers hold.  (Taking
-            // everything that was unclaimed after the first tiles, as a first version did, left the owner with five tiles of a sixteen-tile
-            // round while its helpers had long finished theirs: C4, 40 us of a round's 47 in the owner's own part.)
-            unsigned long long omask = 0ull;  // tiles behind the first ones that the owner took (uniform)
-            uint32_t extra_entries = 0;        // ... and their entries
-#pragma unroll 1
-            for (int pass = 0;; ++pass) {  // (one call site: the check items are instantiated once)
-                uint32_t rb = 0, Rr = own_tiles * TILE < Rn ? own_tiles * TILE : Rn;
-                if (pass > 0) {
-                    if (!share) break;
-                    __syncthreads();
-                    if (tid == 0) {
-                        unsigned long long cur = __hip_atomic_load(board + PDMPC_HB_TICKET, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        uint32_t got = n_tiles, take = 0;
-                        for (;;) {
-                            const uint32_t idx = (uint32_t)(cur & 0xffffull);
-                            if (idx >= n_tiles) break;
-                            const uint32_t theirs = idx - own_tiles - (uint32_t)__builtin_popcountll(omask), rem = n_tiles - idx;
-                            take = (rem + theirs) / (theirs + 1u);  // ceil(rem / (theirs + 1))
-                            take = take < 1u ? 1u : take;
-                            if (__hip_atomic_compare_exchange_strong(board + PDMPC_HB_TICKET, &cur, cur + (unsigned long long)take, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                                got = idx;
-                                break;
-                            }
-                        }
-                        sh[FR_HELP_CLOSED] = got | (take << 16);
-                    }
-                    __syncthreads();
-                    const uint32_t gw = sh[FR_HELP_CLOSED];
-                    const uint32_t got = gw & 0xffffu, take = gw >> 16;
-                    if (got >= n_tiles) break;  // (uniform) every tile has an owner
-                    omask |= ((take >= 64u ? ~0ull : ((1ull << take) - 1ull)) << got);
-                    rb = got * TILE;
-                    Rr = (got + take) * TILE < Rn ? take * TILE : Rn - rb;
-                    extra_entries += Rr;
-                }
-                const int ls = bk_chunk_shift(chm, Rr, (uint32_t)bd);
-                bk_check_items<CHECKER>(CK, tsrc, r_flag, rb, Rr, ls, chm[ls], pend_now, tid, bd);
-                if (pass == 0) {
-                    for (uint32_t r = (uint32_t)(bd - 1 - tid); r < Rn; r += (uint32_t)bd) {  // (from the last thread down: the first waves carry the first chunks)
-                        const uint32_t i0 = ready[r] - 1u;
-                        uint32_t parent, packed;
-                        piece_link(node_piece(S, i0, 3), parent, packed);
-                        if (NODE_K(packed) < Hp) {
-                            const d2 p1 = node_piece(S, i0, 1);
-                            double sn, cs;
-                            pdmpc_sincos(p1.x, &sn, &cs);  // expand_node.m:50-51
-                            node_store_cs(S, i0, cs, sn);
-                        }
+            {
+                const uint32_t Rr = own_n;
+                const int ls = bk_chunk_shift(chm, Rr ? Rr : 1u, (uint32_t)bd);
+                bk_check_items<CHECKER>(CK, tsrc, r_flag, 0u, Rr, ls, chm[ls], pend_now, tid, bd);
+                for (uint32_t r = (uint32_t)(bd - 1 - tid); r < Rn; r += (uint32_t)bd) {  // (from the last thread down: the first waves carry the first chunks)
+                    const uint32_t i0 = ready[r] - 1u;
+                    uint32_t parent, packed;
+                    piece_link(node_piece(S, i0, 3), parent, packed);
+                    if (NODE_K(packed) < Hp) {
+                        const d2 p1 = node_piece(S, i0, 1);
+                        double sn, cs;
+                        pdmpc_sincos(p1.x, &sn, &cs);  // expand_node.m:50-51
+                        node_store_cs(S, i0, cs, sn);
                     }
                 }
             }
             if (share) {
-                const uint32_t n_claimed = n_tiles - own_tiles - (uint32_t)__builtin_popcountll(omask);  // tiles the helpers took
-                if (tid == 0) {
-                    if (n_claimed) {  // wait for the helpers' tiles
-                        uint32_t spins = 0;
-                        while (__hip_atomic_load(board + PDMPC_HB_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)n_claimed) {
-                            __builtin_amdgcn_s_sleep(2);
-                            if (++spins > A.spin_limit) {
-                                atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_BUG);  // reported as an error status: must never happen
-                                break;
-                            }
+                if (wave == 0) {  // wait for the seated helpers: every lane on its helper's done word
+                    uint32_t spins = 0;
+                    bool bad = false;
+                    for (;;) {
+                        bool pending_h = false;
+                        if ((uint32_t)lane < seats) pending_h = (uint32_t)__hip_atomic_load(board + PDMPC_HB_DONE + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != help_seq;
+                        if (!__ballot(pending_h)) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > A.spin_limit) {
+                            bad = true;
+                            break;
                         }
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     }
-                    atomicAdd(A.work_count + 4, 1ull);
-                    atomicAdd(A.work_count + 5, (unsigned long long)(Rn - (own_tiles * TILE < Rn ? own_tiles * TILE : Rn) - extra_entries));
+                    if (lane == 0) {
+                        if (bad) atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_BUG);  // reported as an error status: must never happen
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        atomicAdd(A.work_count + 4, 1ull);
+                        atomicAdd(A.work_count + 5, (unsigned long long)(Rn - own_n));
+                    }
                 }
                 __syncthreads();
                 const uint32_t* hverdict = A.help_verdict + (size_t)slot * PDMPC_HELP_CAP;
-                for (uint32_t r = own_tiles * TILE + (uint32_t)tid; r < Rn; r += (uint32_t)bd) {  // 1 collision-free, 2 collides, 3 crosses expected areas only
-                    if ((omask >> (r / TILE)) & 1ull) continue;  // (the owner's own verdict is in r_flag already)
+                for (uint32_t r = own_n + (uint32_t)tid; r < Rn; r += (uint32_t)bd) {  // 1 collision-free, 2 collides, 3 crosses expected areas only
                     const uint32_t v = __hip_atomic_load(hverdict + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (v < 1u || v > 3u) atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_BUG);  // (claimed, reported finished, and no verdict)
+                    if (v < 1u || v > 3u) atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_BUG);  // (assigned, reported finished, and no verdict)
                     r_flag[r] = v == 2u ? 1u : (v == 3u ? 2u : 0u);
                 }
             }
@@ -2134,19 +2139,20 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
 
 
 // ---------------------------------------------------------------------------------------------------
-// Helper workgroups of the bulk kernel (the workgroups of a launch behind its searches, bulk_body): they look
-// for a search that has posted a round, claim a tile of TILE entries, mirror that search's obstacle soup in their own LDS
-// (literal obstacles, lanelet boundary, the areas of the predecessors the owner had incorporated when it posted), run the
-// tile's check items — the owner's own code on the posted records — and leave one verdict word per entry.  A helper never waits
-// for anything but memory, so an owner that waits for claimed tiles always gets them; helpers leave when every search of the
-// launch has published.
+// Helper workgroups (the workgroups of a launch behind its searches, bulk_body).  A helper takes a SEAT at a search that shares its
+// rounds (the board's WANT word; the search with the fewest seats; one fetch-and-add, once), mirrors that search's obstacle soup in
+// its own LDS (literal obstacles, lanelet boundary, the areas of the predecessors the owner has incorporated, the expected areas of
+// the others) and from then on polls ONE word that nobody else polls: its seat's assignment.  An assignment is a range of the
+// round's posted records; the helper runs the owner's own check items on it, leaves one verdict word per entry and the round's number
+// in its seat's done word.  It keeps the seat until the search ends, then looks for another search.  A helper never waits for
+// anything but memory, so an owner that waits for its seats always gets them; helpers leave when every search of the launch has ended.
 template <int CHECKER>
 __device__ __forceinline__ void bulk_helper_body(const KernelArgs& A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     LDS_AS unsigned char* lsm = (LDS_AS unsigned char*)smem;
     const int tid = threadIdx.x, lane = tid & (PDMPC_WAVE - 1), wave = uni_i(tid >> 6), bd = (int)blockDim.x;
     const int Hp = A.Hp, n_s = A.n_searches;
-    const uint32_t TILE = (uint32_t)A.bk_tile;
+    const uint32_t CAP = (uint32_t)A.bk_tile;  // records of a range (what fits the staging area)
     // the owners' carve (search_prologue): only the regions a check item reads are filled
     lds_u32* l_path = (lds_u32*)(lsm + A.lds.path);
     lds_i32* l_soff = (lds_i32*)(l_path + PDMPC_HP_MAX + 2);
@@ -2154,7 +2160,7 @@ __device__ __forceinline__ void bulk_helper_body(const KernelArgs& A) {
     volatile lds_u32* hs = (volatile lds_u32*)(l_hoff + PDMPC_HP_MAX + 1);
     lds_i32* l_lit = (lds_i32*)(hs + SH_WORDS);
     lds_d2* l_soup = (lds_d2*)(lsm + A.lds.soup);
-    lds_d2* t_rec = (lds_d2*)(lsm + A.lds.bk_near_key);              // [bk_tile][3] the tile's posted records
+    lds_d2* t_rec = (lds_d2*)(lsm + A.lds.bk_near_key);              // [bk_tile][3] the range's posted records
     volatile lds_u32* t_flag = (volatile lds_u32*)(lsm + A.lds.bk_ready);  // [bk_tile] collision flags
     lds_u32* chm = (lds_u32*)(lsm + A.lds.bk_misc) + 192;
     BkCheck CK;
@@ -2171,7 +2177,8 @@ __device__ __forceinline__ void bulk_helper_body(const KernelArgs& A) {
     if (A.areas_in_lds) stage16(lsm + A.lds.area, A.man_area, A.n_man * 3 * PDMPC_VMAX, tid);
     if (tid < SH_WORDS) hs[tid] = 0;
     __syncthreads();
-    int cur_slot = -1;
+    int my_slot = -1, my_seat = -1;  // (uniform)
+    uint32_t last_seq = 0;
     unsigned long long cur_mask = 0;
     const int pref = (int)blockIdx.x % n_s;  // where this helper starts to look
     SpecCtx P;
@@ -2185,63 +2192,80 @@ __device__ __forceinline__ void bulk_helper_body(const KernelArgs& A) {
     P.n_pred = 0;
     P.Hp = Hp;
     uint32_t idle = 0;
+    // (PDMPC_TUNING=debug_tail=1: where a helper's time goes, 100 MHz ticks summed over its ranges: idle, from the assignment to the
+    // soup in place, the range's records, its check items, verdicts + report; work_count[8..12], [13] = ranges)
+    const bool hticking = A.debug_tail != 0 && tid == 0;
+    unsigned long long hk_mark = hticking ? __builtin_amdgcn_s_memrealtime() : 0ull, hk[5] = {0, 0, 0, 0, 0}, hk_tiles = 0;
+#define HK_TICK(i)                                                        \
+    if (hticking) {                                                       \
+        const unsigned long long n__ = __builtin_amdgcn_s_memrealtime(); \
+        hk[i] += n__ - hk_mark;                                           \
+        hk_mark = n__;                                                    \
+    }
     for (;;) {
-        // ---- look for work: one lane per search, the first one (from pref on) with an unclaimed tile is tried
-        if (wave == 0) {
-            uint32_t cmd = 0;
-            for (int base = 0; base < n_s; base += PDMPC_WAVE) {  // (uniform trip count)
-                const int k = base + lane;
-                const int s_rel = k < n_s ? (pref + k) % n_s : 0;
-                unsigned long long* b = A.help_board + (size_t)(A.first + s_rel) * PDMPC_HB_WORDS;
-                // one word holds the round's sequence number, its tiles and the next unclaimed one
-                unsigned long long word = __hip_atomic_load(b + PDMPC_HB_TICKET, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t nt = (uint32_t)((word >> 16) & 0xffffull), idx = (uint32_t)(word & 0xffffull);
-                const bool has = k < n_s && (word >> 32) != 0ull && idx < nt;
-                const unsigned long long m = __ballot(has);
-                const int l = m ? (int)__builtin_ctzll(m) : -1;
-                if (lane == l) {  // (one lane; what it finds goes through LDS)
-                    if (__hip_atomic_compare_exchange_strong(b + PDMPC_HB_TICKET, &word, word + 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                        const unsigned long long mask = __hip_atomic_load(b + PDMPC_HB_MASK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        hs[HS_SLOT] = (uint32_t)(A.first + s_rel);
-                        hs[HS_FIRST] = idx;
-                        hs[HS_COUNT] = (uint32_t)__hip_atomic_load(b + PDMPC_HB_N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        hs[HS_MASK_LO] = (uint32_t)mask;
-                        hs[HS_MASK_HI] = (uint32_t)(mask >> 32);
-                        hs[HS_CMD] = 1;
+        // ================= no seat: look for a search that shares its rounds =================
+        if (my_slot < 0) {
+            if (wave == 0) {
+                // one lane per search: candidates say so in their WANT word; the one with the fewest seats is joined
+                uint32_t best_cnt = 0xffffffffu;
+                int best_rel = -1;
+                for (int base = 0; base < n_s; base += PDMPC_WAVE) {  // (uniform trip count)
+                    const int k = base + lane;
+                    const int s_rel = k < n_s ? (pref + k) % n_s : 0;
+                    const unsigned long long* b = A.help_board + (size_t)(A.first + s_rel) * PDMPC_HB_WORDS;
+                    const unsigned long long want = __hip_atomic_load(b + PDMPC_HB_WANT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long sw = __hip_atomic_load(b + PDMPC_HB_SEATS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t cnt = (uint32_t)(sw >> 32) == A.launch_id ? (uint32_t)(sw & 0xffffffffull) : 0u;
+                    const bool cand = k < n_s && want == (unsigned long long)A.launch_id && cnt < (uint32_t)PDMPC_HB_SEATS_MAX;
+                    uint32_t c = cand ? cnt : 0xffffffffu;
+#pragma unroll
+                    for (int o = PDMPC_WAVE / 2; o > 0; o >>= 1) {
+                        const uint32_t v = (uint32_t)__shfl_xor((int)c, o);
+                        c = v < c ? v : c;
+                    }
+                    const unsigned long long m = __ballot(cand && cnt == c);
+                    if (m && c < best_cnt) {  // (uniform)
+                        best_cnt = c;
+                        best_rel = (pref + base + (int)__builtin_ctzll(m)) % n_s;
                     }
                 }
-                wave_sync();
-                cmd = uni_u(hs[HS_CMD]);
-                if (cmd) break;  // (uniform)
+                uint32_t got = 0xffffffffu;
+                if (best_rel >= 0) {  // (uniform) take a seat: one fetch-and-add; a stale word (another launch's) gives nothing
+                    unsigned long long old = 0;
+                    if (lane == 0)
+                        old = __hip_atomic_fetch_add(A.help_board + (size_t)(A.first + best_rel) * PDMPC_HB_WORDS + PDMPC_HB_SEATS, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t lo32 = uni_u((uint32_t)old), hi32 = uni_u((uint32_t)(old >> 32));
+                    if (hi32 == A.launch_id && lo32 < (uint32_t)PDMPC_HB_SEATS_MAX) got = lo32;
+                }
+                uint32_t cmd = 0;
+                if (got != 0xffffffffu) {
+                    cmd = 1;
+                } else {
+                    const uint32_t fin = __hip_atomic_load(A.help_finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (fin - A.help_fin_base >= (uint32_t)n_s) cmd = 2;
+                }
+                if (lane == 0) {
+                    hs[HS_SLOT] = (uint32_t)(A.first + (best_rel >= 0 ? best_rel : 0));
+                    hs[HS_FIRST] = got;
+                    hs[HS_CMD] = cmd;
+                }
             }
-            if (!cmd) {
-                const uint32_t fin = __hip_atomic_load(A.help_finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (lane == 0 && fin - A.help_fin_base >= (uint32_t)n_s) hs[HS_CMD] = 2;
-            } else {
-                // what the owner wrote before it posted (and the predecessors it had seen) is visible from here on; not on an idle
-                // poll: the fence empties this XCD's L2, which searches on neighbouring CUs share
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            }
-        }
-        __syncthreads();
-        const uint32_t cmd = hs[HS_CMD];
-        if (cmd == 2u) break;
-        if (cmd == 0u) {
-            if (idle < 64u)
-                __builtin_amdgcn_s_sleep(2);
-            else
-                __builtin_amdgcn_s_sleep(32);
-            if (++idle > (A.spin_limit >> 4)) break;  // (uniform) the searches never came: leave; they do without helpers
             __syncthreads();
-            continue;
-        }
-        idle = 0;
-        const int slot = (int)hs[HS_SLOT];
-        const uint32_t tile = hs[HS_FIRST], Rn = hs[HS_COUNT];
-        const unsigned long long mask = ((unsigned long long)hs[HS_MASK_HI] << 32) | hs[HS_MASK_LO];
-        const DevVehicle* __restrict__ V = A.veh + slot;
-        // ---- the search's obstacle soup (search_prologue, parts 3 and 4)
-        if (slot != cur_slot) {
+            const uint32_t cmd = hs[HS_CMD];
+            if (cmd == 2u) break;
+            if (cmd == 0u) {  // nobody shares: look again in a while (a search announces itself once; nothing is lost by being a few microseconds late)
+                __builtin_amdgcn_s_sleep(127);
+                __builtin_amdgcn_s_sleep(127);
+                if (++idle > (A.spin_limit >> 4)) break;  // (uniform) the searches never came: leave; they do without helpers
+                __syncthreads();
+                continue;
+            }
+            my_slot = (int)hs[HS_SLOT];
+            my_seat = (int)hs[HS_FIRST];
+            last_seq = 0;
+            idle = 0;
+            // ---- the search's obstacle soup (search_prologue, parts 3 and 4); its predecessors' slots start empty
+            const DevVehicle* __restrict__ V = A.veh + my_slot;
             const int pred_cols = V->n_pred * PDMPC_VMAX;
             int off = 0;
             for (int k = 0; k < Hp; ++k) {
@@ -2273,8 +2297,8 @@ __device__ __forceinline__ void bulk_helper_body(const KernelArgs& A) {
             __syncthreads();
             P.pred = A.pred + V->pred_off;
             P.n_pred = V->n_pred;
-            incorporate_areas(P, mask, tid);
-            if (A.bk_tentative) bk_tentative_areas(A, P, (V->n_pred >= 64 ? ~0ull : ((1ull << V->n_pred) - 1ull)) & ~mask, tid, bd);  // (as the owner: expected areas of the others)
+            if (A.bk_tentative) bk_tentative_areas(A, P, V->n_pred >= 64 ? ~0ull : ((1ull << V->n_pred) - 1ull), tid, bd);  // (as the owner: expected areas until the real ones are in)
+            cur_mask = 0;
             __syncthreads();
             if (tid < 8) {  // the chunk table of this soup (bulk_search)
                 const int ls = tid;
@@ -2289,43 +2313,101 @@ __device__ __forceinline__ void bulk_helper_body(const KernelArgs& A) {
                 }
                 chm[ls] = mx;
             }
-            cur_slot = slot;
-            cur_mask = mask;
-        } else if (mask != cur_mask) {
-            incorporate_areas(P, mask & ~cur_mask, tid);  // (within a launch a search's set of incorporated predecessors only grows)
-            cur_mask = mask;
+            __syncthreads();
+            if (hticking) hk_mark = __builtin_amdgcn_s_memrealtime();
+            continue;
         }
-        // ---- the tile: its records into LDS, its check items, its verdicts
-        const uint32_t rb = tile * TILE, Rt = Rn - rb < TILE ? Rn - rb : TILE;
-        {
-            const d2* post = (const d2*)A.bk_post + ((size_t)slot * (size_t)A.bk_ready_cap + rb) * 3u;
-            for (uint32_t i = (uint32_t)tid; i < Rt * 3u; i += (uint32_t)bd) t_rec[i] = post[i];
-            if ((uint32_t)tid < TILE) t_flag[tid] = 0u;
+        // ================= seated: this seat's assignment word =================
+        unsigned long long* board = A.help_board + (size_t)my_slot * PDMPC_HB_WORDS;
+        if (wave == 0) {
+            const unsigned long long w = __hip_atomic_load(board + PDMPC_HB_ASSIGN + my_seat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t seq = (uint32_t)(w >> 40);
+            uint32_t cmd = 0;
+            if (seq != last_seq && seq != 0u) {
+                cmd = 1;
+                // what the owner wrote before it assigned (and the predecessors it had seen) is visible from here on; not on an idle
+                // poll: the fence empties this XCD's L2, which searches on neighbouring CUs share
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                const unsigned long long mask = __hip_atomic_load(board + PDMPC_HB_MASK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) {
+                    hs[HS_FIRST] = (uint32_t)((w >> 20) & 0xfffffull);
+                    hs[HS_COUNT] = (uint32_t)(w & 0xfffffull);
+                    hs[HS_TICKET] = seq;
+                    hs[HS_MASK_LO] = (uint32_t)mask;
+                    hs[HS_MASK_HI] = (uint32_t)(mask >> 32);
+                }
+            } else if ((idle & 15u) == 15u) {  // (now and then) has the search ended?
+                const unsigned long long want = __hip_atomic_load(board + PDMPC_HB_WANT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (want != (unsigned long long)A.launch_id) cmd = 3;
+            }
+            if (lane == 0) hs[HS_CMD] = cmd;
         }
         __syncthreads();
+        const uint32_t cmd = hs[HS_CMD];
+        if (cmd == 3u) {  // the seat's search is over: look for another one
+            my_slot = -1;
+            my_seat = -1;
+            idle = 0;
+            __syncthreads();
+            continue;
+        }
+        if (cmd == 0u) {
+            if (idle < 256u)
+                __builtin_amdgcn_s_sleep(1);
+            else
+                __builtin_amdgcn_s_sleep(16);
+            if (++idle > A.spin_limit) break;  // (uniform) must never happen: the search ends and says so
+            __syncthreads();
+            continue;
+        }
+        idle = 0;
+        HK_TICK(0)
+        const uint32_t first = hs[HS_FIRST], Rt = hs[HS_COUNT] < CAP ? hs[HS_COUNT] : CAP, seq = hs[HS_TICKET];
+        const unsigned long long mask = ((unsigned long long)hs[HS_MASK_HI] << 32) | hs[HS_MASK_LO];
+        last_seq = seq;
+        if (mask != cur_mask) {  // (within a launch a search's set of incorporated predecessors only grows)
+            incorporate_areas(P, mask & ~cur_mask, tid);
+            cur_mask = mask;
+        }
+        HK_TICK(1)
+        // ---- the range: its records into LDS, its check items, its verdicts
         {
+            const d2* post = (const d2*)A.bk_post + ((size_t)my_slot * (size_t)A.bk_ready_cap + first) * 3u;
+            for (uint32_t i = (uint32_t)tid; i < Rt * 3u; i += (uint32_t)bd) t_rec[i] = post[i];
+            for (uint32_t i = (uint32_t)tid; i < Rt; i += (uint32_t)bd) t_flag[i] = 0u;
+        }
+        __syncthreads();
+        HK_TICK(2)
+        if (Rt) {
             const BkPostSrc psrc{t_rec};
             const int ls = bk_chunk_shift(chm, Rt, (uint32_t)bd);
             const unsigned long long pend = A.bk_tentative ? (P.n_pred >= 64 ? ~0ull : ((1ull << P.n_pred) - 1ull)) & ~mask : 0ull;
             bk_check_items<CHECKER>(CK, psrc, t_flag, 0u, Rt, ls, chm[ls], pend, tid, bd);
         }
         __syncthreads();
+        HK_TICK(3)
         {
-            uint32_t* verdict = A.help_verdict + (size_t)slot * PDMPC_HELP_CAP + rb;
-            if ((uint32_t)tid < Rt) {  // 1 collision-free, 2 collides, 3 crosses expected areas only
-                const uint32_t fl = t_flag[tid];
-                __hip_atomic_store(verdict + tid, (fl & 1u) ? 2u : ((fl & 2u) ? 3u : 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t* verdict = A.help_verdict + (size_t)my_slot * PDMPC_HELP_CAP + first;
+            for (uint32_t i = (uint32_t)tid; i < Rt; i += (uint32_t)bd) {  // 1 collision-free, 2 collides, 3 crosses expected areas only
+                const uint32_t fl = t_flag[i];
+                __hip_atomic_store(verdict + i, (fl & 1u) ? 2u : ((fl & 2u) ? 3u : 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's verdicts have reached L2 (the barrier alone does not wait for them) ...
-        __syncthreads();                                     // ... every wave's have: thread 0 can write L2 back and report
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's verdicts have been acknowledged (the barrier alone does not wait for them) ...
+        __syncthreads();                                     // ... every wave's have: the seat's done word can say so
         if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __hip_atomic_fetch_add(A.help_board + (size_t)slot * PDMPC_HB_WORDS + PDMPC_HB_DONE, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(board + PDMPC_HB_DONE + my_seat, (unsigned long long)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             hs[HS_CMD] = 0;
         }
         __syncthreads();
+        HK_TICK(4)
+        hk_tiles += 1;
     }
+    if (hticking) {
+        for (int i = 0; i < 5; ++i) atomicAdd(A.work_count + 8 + i, hk[i]);
+        atomicAdd(A.work_count + 13, hk_tiles);
+    }
+#undef HK_TICK
 }
 
 template <int NW, int CHECKER>
@@ -2356,9 +2438,7 @@ __device__ __forceinline__ void bulk_body(const KernelArgs& A) {
     if (!X.rec_valid) bk_write_record(A, X, X.goal, X.status, X.dep_timeout, (uint32_t)X.n_popped, X.nnodes, X.path_ready, ref_ids, X.rec_written, X.published, X.lane);
     bk_publish(A, X, X.status, X.dep_timeout);
     if (X.lane == 0 && A.n_helpers > 0) {
-        // (a search that left through its watchdog in the middle of a shared round: its board must not offer that round to the helpers
-        // of a later launch — the boards are not cleared between launches, api.cpp: launch_range)
-        __hip_atomic_store(A.help_board + (size_t)X.slot * PDMPC_HB_WORDS + PDMPC_HB_TICKET, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(A.help_board + (size_t)X.slot * PDMPC_HB_WORDS + PDMPC_HB_WANT, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (the seats are free to go)
         atomicAdd(A.help_finished, 1u);
     }
 }

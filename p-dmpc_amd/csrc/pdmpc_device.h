@@ -105,11 +105,15 @@ struct NodeArena {  // HBM arrays, per-vehicle stride = max_nodes entries
 /* entries of the LDS open list per thread (a selection pass holds them in registers) */
 
 #define PDMPC_HELP_CAP 2048 /* entries of a round that can be shared (= the ready list's capacity) */
-#define PDMPC_HB_WORDS 8   /* 64-bit words of a board */
-#define PDMPC_HB_TICKET 0
-#define PDMPC_HB_N 1
-#define PDMPC_HB_MASK 2
-#define PDMPC_HB_DONE 3
+/* a search's board (64-bit words): what its seated helper workgroups read and write (bulk_search.hpp) */
+#define PDMPC_HB_SEATS_MAX 64
+#define PDMPC_HB_N 1      /* entries of the round that is being shared */
+#define PDMPC_HB_MASK 2   /* predecessors whose areas the owner has in its soup */
+#define PDMPC_HB_SEATS 3  /* launch id << 32 | seats taken (a helper takes one with a fetch-and-add; the owner resets the word when it starts) */
+#define PDMPC_HB_WANT 4   /* == launch id: the search shares its rounds, helpers may take seats; 0 once it has ended */
+#define PDMPC_HB_ASSIGN 8 /* [64] per seat: round << 40 | first entry << 20 | entries: the range that seat checks */
+#define PDMPC_HB_DONE 72  /* [64] per seat: the last round whose range that seat has finished */
+#define PDMPC_HB_WORDS 136
 
 struct KernelArgs {
     // MPA
@@ -147,16 +151,17 @@ struct KernelArgs {
     int32_t n_searches;              // workgroups of this launch that run a search (the first ones)
     int32_t n_helpers;               // helper workgroups behind them (0: none)
     int32_t own_div;                 // the owner of a shared round starts on 1 / own_div of its tiles
-    unsigned long long* help_board;  // [slot][8]: ticket = round << 32 | tiles << 16 | next unclaimed tile, entries, incorporated predecessors, tiles finished by helpers
+    unsigned long long* help_board;  // [slot][PDMPC_HB_WORDS]: see above
     uint32_t* help_verdict;          // [slot][PDMPC_HELP_CAP] 1 collision-free, 2 colliding, 3 crosses expected areas only (written by helpers)
     uint32_t* help_finished;         // searches that have published their result (runs on from launch to launch) ...
     uint32_t help_fin_base;          // ... and its value when this launch went out
+    uint32_t launch_id;              // number of this launch on its handle (never 0): tells this launch's board words from an earlier launch's
     int32_t bk_ready_cap;   // entries of the ready list (a round's nodes)
     int32_t bk_round0;      // nodes a round of a young search takes
     int32_t bk_round;       // ... and the most any round takes
     int32_t bk_ramp;        // a round of a search that is no longer young grows by 1 / bk_ramp of the nodes processed so far
     int32_t bk_tentative;   // 1: predecessors that are still planning have their expected areas (the ones they publish when exhausted) in their soup slots
-    int32_t bk_tile;        // entries of a tile of a shared round (what a helper workgroup claims at a time; at most 128)
+    int32_t bk_tile;        // the most entries of a shared round one seat takes (what a helper stages in LDS; at most 768)
     int32_t bk_mid_min;     // a far list longer than this is not scanned by every refill of near: a band of its smallest keys is moved to mid first
     int32_t bk_mid_fill;    // ... about this many entries at a time
     int32_t bk_share_min;   // a round with at least this many entries is shared with the helper workgroups

@@ -61,6 +61,7 @@ EXPORTS = [
     "pdmpc_debug_raw_tree",
     "pdmpc_debug_edge_check",
     "pdmpc_debug_progress",
+    "pdmpc_debug_counters",
     "pdmpc_controller_create",
     "pdmpc_controller_destroy",
     "pdmpc_controller_step",
@@ -517,6 +518,12 @@ class Handle:
             "pdmpc_debug_edge_check",
         )
         return hit[:n] != 0
+
+    def debug_counters(self):
+        out = (C.c_uint64 * 16)()
+        self.L.pdmpc_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
+        _check(self.L, self.L.pdmpc_debug_counters(self.h, out), "pdmpc_debug_counters")
+        return list(out)
 
     def progress(self, vehicle):
         w = (C.c_uint32 * 32)()

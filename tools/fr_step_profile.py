@@ -3,7 +3,7 @@ tick counters of the round phases (needs PDMPC_DEBUG_TAIL=1)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "p-dmpc_amd"), os.path.join(ROOT, "tests")]
-os.environ["PDMPC_DEBUG_TAIL"] = "1"
+os.environ["PDMPC_TUNING"] = ",".join(x for x in (os.environ.get("PDMPC_TUNING", ""), "debug_tail=1") if x)
 import numpy as np
 import bench
 class A: pass
@@ -19,8 +19,13 @@ probs = bench.record_steps(options, mpa, ctl, opt, 20 if args.workload == "c2" e
 for b, prob in enumerate(probs):
     fb = [f if f is not None else [] for f in prob["fallback"]]
     h.pack_step(prob["iters"], prob["preds"], fb)
+    h.reset_stats()
     h.launch(); recs = h.fetch(len(prob["iters"])); st = h.stats()
     print("step", b, "kernel ms %.3f" % st["kernel_ms"], "levels", len(prob["level_sizes"]))
+    dc = h.debug_counters()
+    if dc[13]:
+        print("   helpers: %d tiles, per tile: claim -> soup %.1f us, records %.1f us, checks %.1f us, verdicts + report %.1f us; idle in all %.0f us; shared rounds %d" % (
+            dc[13], dc[9] / 100.0 / dc[13], dc[10] / 100.0 / dc[13], dc[11] / 100.0 / dc[13], dc[12] / 100.0 / dc[13], dc[8] / 100.0, dc[4]))
     rows = []
     for v in range(len(recs)):
         t = np.asarray(recs[v]["path_nodes"])
