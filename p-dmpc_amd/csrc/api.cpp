@@ -139,7 +139,7 @@ struct Tuning {
     int round = -1;         // the most a round takes (-1: 1000 with helper workgroups, else 256)
     int ramp = -1;          // a round grows by 1 / ramp of the nodes processed so far (-1: 2 with helper workgroups, else 4)
     int ready = 2048;       // entries of the ready list with helper workgroups (half of it without): the most a round can take
-    int share_min = 64;     // a round with at least this many nodes is shared with the helper workgroups (measured on C2 with 230 helpers: 128 -> 1 225 steps/s, 96 -> 1 235, 64 -> 1 258)
+    int share_min = -1;     // a round with at least this many nodes is shared with the helper workgroups (-1: by the number of helpers per search, launch_range)
     int own_div = 8;        // the owner of a shared round starts on 1 / own_div of its tiles
     int tile = -1;          // the most nodes of a shared round one seated helper takes (-1: 256; what it stages in LDS: at most 768)
     int mid_min = 24576;    // far lists longer than this feed near through the mid list (a band of far's smallest keys)
@@ -204,7 +204,7 @@ bool parse_tuning(const char* text, Tuning& T, std::string& err) {
     if (T.round >= 0) T.round = std::max(1, T.round);
     if (T.ramp >= 0) T.ramp = std::max(1, T.ramp);
     T.ready = std::min(2048, std::max(256, T.ready)) & ~63;
-    T.share_min = std::max(64, T.share_min);
+    if (T.share_min >= 0) T.share_min = std::max(32, T.share_min);
     T.own_div = std::max(1, T.own_div);
     if (T.tile >= 0) T.tile = std::min(768, std::max(8, T.tile));
     T.mid_min = std::max(0, T.mid_min);
@@ -709,7 +709,6 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     a.bk_round0 = T.round0;
     a.bk_round = std::min(h->bk_ready_launch / 2 - 16, std::max(a.bk_round0, T.round > 0 ? T.round : (helped ? 1000 : 256)));
     a.bk_ramp = T.ramp > 0 ? T.ramp : (helped ? 2 : 4);
-    a.bk_share_min = T.share_min;
     a.own_div = T.own_div;
     a.bk_mid_min = T.mid_min;
     a.bk_mid_fill = T.mid_fill;
@@ -746,6 +745,10 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
             if (T.helpers >= 0) a.n_helpers = std::min(a.n_helpers, T.helpers);
         }
     }
+    // rounds are shared from 64 nodes on where helpers are plenty (C2: a dozen per search), from a few hundred on where there are
+    // about as many helpers as searches or fewer (measured C3, 128 + 128: 64 -> 1 026 steps/s, 128-192 -> 1 070, 384 -> 986; C4, 512 + 96:
+    // 64 -> 65.5, 192 -> 67, 512 -> 69)
+    a.bk_share_min = T.share_min > 0 ? T.share_min : (a.n_helpers >= 4 * count ? 64 : (count <= h->n_cu ? 160 : 512));
     if (a.n_helpers > 0 && !h->boards_dirty) {
         // The boards stay closed between launches (a search closes every round it shares before it uses the verdicts, and a closed
         // ticket word offers nothing) and the count of finished searches runs on from launch to launch: nothing to clear -- two

@@ -416,6 +416,31 @@ __device__ __forceinline__ void bk_select(const lds_u32* bins, uint32_t target, 
 #ifndef PDMPC_BK_AREA_FENCES
 #define PDMPC_BK_AREA_FENCES 0
 #endif
+// The records a shared round posts for its helpers and everything else owner and helpers exchange likewise go through agent-scope
+// stores and loads; PDMPC_BK_POST_FENCES=1 (build switch) posts with plain stores behind a release fence and reads behind an acquire
+// fence instead, as rounds 2-4 did (every fence writes back / invalidates the whole L2 of its XCD: with a helper on every idle CU
+// that is every L2 of the chip, once per round).
+#ifndef PDMPC_BK_POST_FENCES
+#define PDMPC_BK_POST_FENCES 0
+#endif
+__device__ __forceinline__ void bk_post_store(d2* p, d2 v) {
+#if PDMPC_BK_POST_FENCES
+    *p = v;
+#else
+    __hip_atomic_store((double*)p, (double)v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((double*)p + 1, (double)v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ d2 bk_post_load(const d2* p) {
+#if PDMPC_BK_POST_FENCES
+    return *p;
+#else
+    d2 v;
+    v.x = __hip_atomic_load((const double*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v.y = __hip_atomic_load((const double*)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+#endif
+}
 __device__ __forceinline__ void bk_area_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void bk_area_store_u32(int32_t* p, int v) { __hip_atomic_store(p, (int32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double bk_area_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1149,6 +1174,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             uint32_t own_n = Rn, seats = 0, per_h = 0;
             if (share) {  // (uniform)
                 if (tid == 0) {
+                    __hip_atomic_store(board + PDMPC_HB_WEIGHT, (unsigned long long)(sh[FR_PROCESSED] + Rn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (!wanted) __hip_atomic_store(board + PDMPC_HB_WANT, (unsigned long long)A.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // helpers may take seats from now on
                     const unsigned long long sw = __hip_atomic_load(board + PDMPC_HB_SEATS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     uint32_t k = (uint32_t)(sw >> 32) == A.launch_id ? (uint32_t)(sw & 0xffffffffull) : 0u;
@@ -1174,9 +1200,9 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                     uint32_t parent, packed;
                     const d2 p3 = node_piece(S, ready[r] - 1u, 3);
                     piece_link(p3, parent, packed);
-                    post[3 * r] = node_piece(S, parent - 1u, 0);
-                    post[3 * r + 1] = node_piece(S, parent - 1u, 2);
-                    post[3 * r + 2] = d2{p3.y, 0.0};
+                    bk_post_store(post + 3 * r, node_piece(S, parent - 1u, 0));
+                    bk_post_store(post + 3 * r + 1, node_piece(S, parent - 1u, 2));
+                    bk_post_store(post + 3 * r + 2, d2{p3.y, 0.0});
                 }
                 // every wave's stores must have reached L2 before thread 0 writes L2 back: a workgroup barrier alone does not wait for them
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1186,7 +1212,9 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                         const unsigned long long all = P.n_pred >= 64 ? ~0ull : ((1ull << P.n_pred) - 1ull);
                         __hip_atomic_store(board + PDMPC_HB_N, (unsigned long long)Rn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store(board + PDMPC_HB_MASK, all & ~sh_load64(sh, SH_PEND_LO), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if PDMPC_BK_POST_FENCES
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     wave_sync();
@@ -1230,7 +1258,9 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                     }
                     if (lane == 0) {
                         if (bad) atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_BUG);  // reported as an error status: must never happen
+#if PDMPC_BK_POST_FENCES
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
                         atomicAdd(A.work_count + 4, 1ull);
                         atomicAdd(A.work_count + 5, (unsigned long long)(Rn - own_n));
                     }
@@ -2206,8 +2236,9 @@ __device__ __forceinline__ void bulk_helper_body(const KernelArgs& A) {
         // ================= no seat: look for a search that shares its rounds =================
         if (my_slot < 0) {
             if (wave == 0) {
-                // one lane per search: candidates say so in their WANT word; the one with the fewest seats is joined
-                uint32_t best_cnt = 0xffffffffu;
+                // one lane per search: candidates say so in their WANT word; the one with the most work per seat is joined (work = nodes
+                // processed so far: a step takes as long as its heaviest search, and that is where the helpers belong)
+                float best_score = -1.0f;
                 int best_rel = -1;
                 for (int base = 0; base < n_s; base += PDMPC_WAVE) {  // (uniform trip count)
                     const int k = base + lane;
@@ -2215,17 +2246,24 @@ __device__ __forceinline__ void bulk_helper_body(const KernelArgs& A) {
                     const unsigned long long* b = A.help_board + (size_t)(A.first + s_rel) * PDMPC_HB_WORDS;
                     const unsigned long long want = __hip_atomic_load(b + PDMPC_HB_WANT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const unsigned long long sw = __hip_atomic_load(b + PDMPC_HB_SEATS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long wt = __hip_atomic_load(b + PDMPC_HB_WEIGHT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const uint32_t cnt = (uint32_t)(sw >> 32) == A.launch_id ? (uint32_t)(sw & 0xffffffffull) : 0u;
-                    const bool cand = k < n_s && want == (unsigned long long)A.launch_id && cnt < (uint32_t)PDMPC_HB_SEATS_MAX;
-                    uint32_t c = cand ? cnt : 0xffffffffu;
+                    // (a seat is kept until the search ends, so a search only gets the seats its work so far entitles it to: its share of the
+                    // launch's helpers per 256 nodes processed — plenty of helpers per search (C2): every seat at once; a fifth of a helper
+                    // per search (C4): a medium search holds one or two, the 10^5-node search of the step collects all 64 as it grows)
+                    uint32_t allowed = 1u + (uint32_t)((wt * (unsigned long long)A.n_helpers) / ((unsigned long long)n_s * 256ull));
+                    allowed = allowed < (uint32_t)PDMPC_HB_SEATS_MAX ? allowed : (uint32_t)PDMPC_HB_SEATS_MAX;
+                    const bool cand = k < n_s && want == (unsigned long long)A.launch_id && cnt < allowed;
+                    const float score = cand ? (float)(wt + 1ull) / (float)(cnt + 1u) : -1.0f;
+                    float c = score;
 #pragma unroll
                     for (int o = PDMPC_WAVE / 2; o > 0; o >>= 1) {
-                        const uint32_t v = (uint32_t)__shfl_xor((int)c, o);
-                        c = v < c ? v : c;
+                        const float v = __shfl_xor(c, o);
+                        c = v > c ? v : c;
                     }
-                    const unsigned long long m = __ballot(cand && cnt == c);
-                    if (m && c < best_cnt) {  // (uniform)
-                        best_cnt = c;
+                    const unsigned long long m = __ballot(cand && score == c);
+                    if (m && c > best_score) {  // (uniform)
+                        best_score = c;
                         best_rel = (pref + base + (int)__builtin_ctzll(m)) % n_s;
                     }
                 }
@@ -2325,9 +2363,11 @@ __device__ __forceinline__ void bulk_helper_body(const KernelArgs& A) {
             uint32_t cmd = 0;
             if (seq != last_seq && seq != 0u) {
                 cmd = 1;
+#if PDMPC_BK_POST_FENCES
                 // what the owner wrote before it assigned (and the predecessors it had seen) is visible from here on; not on an idle
                 // poll: the fence empties this XCD's L2, which searches on neighbouring CUs share
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
                 const unsigned long long mask = __hip_atomic_load(board + PDMPC_HB_MASK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (lane == 0) {
                     hs[HS_FIRST] = (uint32_t)((w >> 20) & 0xfffffull);
@@ -2366,14 +2406,14 @@ __device__ __forceinline__ void bulk_helper_body(const KernelArgs& A) {
         const unsigned long long mask = ((unsigned long long)hs[HS_MASK_HI] << 32) | hs[HS_MASK_LO];
         last_seq = seq;
         if (mask != cur_mask) {  // (within a launch a search's set of incorporated predecessors only grows)
-            incorporate_areas(P, mask & ~cur_mask, tid);
+            bk_incorporate(P.out, P.pred, P.l_soup, P.l_soff, P.l_lit, Hp, mask & ~cur_mask, tid, bd);  // (loads that are coherent by themselves)
             cur_mask = mask;
         }
         HK_TICK(1)
         // ---- the range: its records into LDS, its check items, its verdicts
         {
             const d2* post = (const d2*)A.bk_post + ((size_t)my_slot * (size_t)A.bk_ready_cap + first) * 3u;
-            for (uint32_t i = (uint32_t)tid; i < Rt * 3u; i += (uint32_t)bd) t_rec[i] = post[i];
+            for (uint32_t i = (uint32_t)tid; i < Rt * 3u; i += (uint32_t)bd) t_rec[i] = bk_post_load(post + i);
             for (uint32_t i = (uint32_t)tid; i < Rt; i += (uint32_t)bd) t_flag[i] = 0u;
         }
         __syncthreads();

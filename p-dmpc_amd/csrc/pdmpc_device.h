@@ -111,6 +111,7 @@ struct NodeArena {  // HBM arrays, per-vehicle stride = max_nodes entries
 #define PDMPC_HB_MASK 2   /* predecessors whose areas the owner has in its soup */
 #define PDMPC_HB_SEATS 3  /* launch id << 32 | seats taken (a helper takes one with a fetch-and-add; the owner resets the word when it starts) */
 #define PDMPC_HB_WANT 4   /* == launch id: the search shares its rounds, helpers may take seats; 0 once it has ended */
+#define PDMPC_HB_WEIGHT 5 /* nodes the search has processed so far: helpers go where the work per seat is largest */
 #define PDMPC_HB_ASSIGN 8 /* [64] per seat: round << 40 | first entry << 20 | entries: the range that seat checks */
 #define PDMPC_HB_DONE 72  /* [64] per seat: the last round whose range that seat has finished */
 #define PDMPC_HB_WORDS 136
