@@ -43,7 +43,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "p-dmpc_amd")]
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, MI355X_MICROARCH.md
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 
 def workload_defaults(args):
@@ -432,7 +432,7 @@ def main():
     achieved = (alg_bytes / max(n_launch, 1)) / ((kernel_ms / max(n_launch, 1)) * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     n_search = max(len(p["iters"]) for p in problems)
     # (api.cpp: launch_range -- helper workgroups on the CUs a launch of at most one search per CU leaves idle, 96 for up to two per CU)
-    wg_per_launch = n_search + (256 - n_search if n_search <= 254 else (96 if n_search <= 512 else 0))
+    wg_per_launch = n_search + (256 - n_search if n_search <= 254 else (200 if n_search <= 512 else 0))
 
     # ---- the timed launches did the recorded work.  Their records are not fetched (no copies in the timed region), so: the device
     # counts every plan that ended with anything but OK / EXHAUSTED (overflow, time-out) since the reset in front of the timed loop,

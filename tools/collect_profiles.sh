@@ -27,8 +27,8 @@ if [ "${SQ:-1}" = "1" ]; then
   rocprofv3 --kernel-trace --pmc SQ_INSTS_FLAT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA --output-format csv -d $OUT/sq4 -- python3 bench.py $ARGS > $OUT/bench_sq4.json 2> $OUT/sq4.err
 fi
 # only the summaries travel back (the raw traces can be large): counter CSVs of the search / helper kernels, stats, trace
-python tools/summarize_profiles.py ${ROUND:-r04}_$W $S $OUT > $OUT/summary_stdout.txt 2>&1
-mkdir -p $OUT/profiles && cp profiles/${ROUND:-r04}_${W}_* profiles/${ROUND:-r04}_pmc_traffic_${W}.json $OUT/profiles/ 2>/dev/null  # (profiles/ of the box's copy does not travel back: gpurun_out/ does)
+python tools/summarize_profiles.py ${ROUND:-r05}_$W $S $OUT > $OUT/summary_stdout.txt 2>&1
+mkdir -p $OUT/profiles && cp profiles/${ROUND:-r05}_${W}_* profiles/${ROUND:-r05}_pmc_traffic_${W}.json $OUT/profiles/ 2>/dev/null  # (profiles/ of the box's copy does not travel back: gpurun_out/ does)
 find $OUT -name "*.csv" -size +2M -delete
 find $OUT -name "*.db" -delete
 du -sh $OUT | tail -1

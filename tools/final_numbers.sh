@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the GPU box: the round's full bench lines of every workload, the step profiles and the kernels' resource usage, all under
-# gpurun_out/ (the rocprofv3 passes are tools/collect_profiles.sh: WORKLOAD=c2|c4|c5 ROUND=r04).
-R=${ROUND:-r04}
+# gpurun_out/ (the rocprofv3 passes are tools/collect_profiles.sh: WORKLOAD=c2|c4|c5 ROUND=r05).
+R=${ROUND:-r05}
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 python bench.py --steps 200 --warmup 20 2>/dev/null | grep metric > gpurun_out/${R}_bench_c2.json

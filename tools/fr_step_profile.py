@@ -1,5 +1,6 @@
 """Where a time step's time goes in the frontier kernel: per vehicle rounds, nodes processed vs popped, and the 100 MHz
-tick counters of the round phases (needs PDMPC_DEBUG_TAIL=1)."""
+tick counters of the round phases and of the helper workgroups (PDMPC_TUNING=debug_tail=1, set here); PROFILE_CHAIN=1: when every
+vehicle's areas went out; PROFILE_ROUNDS=1: the round sizes of the heaviest search; PROFILE_TOP=n: the n slowest vehicles per step."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "p-dmpc_amd"), os.path.join(ROOT, "tests")]

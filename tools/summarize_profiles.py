@@ -16,11 +16,11 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04_c2"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05_c2"
 workload = tag.split("_")[-1]
 TIMED = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 SRC = os.path.join(ROOT, sys.argv[3]) if len(sys.argv) > 3 else os.path.join(ROOT, "gpurun_out", "prof_" + workload)
-KERNEL, HELPER = "pdmpc_bulk_kernel", "pdmpc_helper"  # (the bulk kernel's helpers are workgroups of its own launch; pdmpc_helper serves the frontier kernel, which only runs after a tie)
+KERNEL, HELPER = "pdmpc_bulk_kernel", "pdmpc_helper"  # (the helpers are workgroups of the search launch itself: there is no helper kernel any more, the second family stays empty)
 DST = os.path.join(ROOT, "profiles")
 os.makedirs(DST, exist_ok=True)
 
@@ -70,9 +70,10 @@ if kt:
         t = timed(d)
         summary[key] = {"launches": len(d), "avg_ms": sum(d) / len(d), "min_ms": min(d), "max_ms": max(d), "timed_region_launches": len(t),
                         "timed_region_avg_ms": sum(t) / len(t), "grid": rows[-1].get("Grid_Size"), "workgroup": rows[-1].get("Workgroup_Size"),
-                        # what the trace reports per dispatch (static LDS of the code object and register counts in its own units); the launch's
-                        # dynamic LDS and the compiler's register / scratch numbers are in `resources` below
-                        "trace_fields_as_reported": {k: rows[-1].get(k) for k in ("LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count") if k in rows[-1]}}
+                        # (the trace's own LDS_Block_Size / VGPR_Count / SGPR_Count columns are not copied: they describe the code object in the
+                        # trace's units — static LDS, allocation granules — and read like evidence they are not; the launch's dynamic LDS and the
+                        # compiler's register / scratch numbers are in `resources` below)
+                        }
 
 
 def counters(passname):
