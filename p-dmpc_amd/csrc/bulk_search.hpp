@@ -2252,6 +2252,7 @@ __device__ __forceinline__ void bulk_helper_body(const KernelArgs& A) {
                     // launch's helpers per 256 nodes processed — plenty of helpers per search (C2): every seat at once; a fifth of a helper
                     // per search (C4): a medium search holds one or two, the 10^5-node search of the step collects all 64 as it grows)
                     uint32_t allowed = 1u + (uint32_t)((wt * (unsigned long long)A.n_helpers) / ((unsigned long long)n_s * 256ull));
+                    if (idle >= 8u) allowed = (uint32_t)PDMPC_HB_SEATS_MAX;  // (this helper has found nothing it was entitled to for a while: better seated than idle)
                     allowed = allowed < (uint32_t)PDMPC_HB_SEATS_MAX ? allowed : (uint32_t)PDMPC_HB_SEATS_MAX;
                     const bool cand = k < n_s && want == (unsigned long long)A.launch_id && cnt < allowed;
                     const float score = cand ? (float)(wt + 1ull) / (float)(cnt + 1u) : -1.0f;
