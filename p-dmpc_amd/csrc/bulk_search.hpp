@@ -716,7 +716,7 @@ __device__ __forceinline__ void bk_wait_done(const uint32_t* done_flag, const in
     unsigned long long got = first;  // (in the soup already: checked against the path before anybody is polled)
     uint32_t spins = 0, res = 0;
     for (;;) {
-        if (!got) {  // (uniform)
+        if (!got && pend != 0ull) {  // (uniform; nobody outstanding and nothing to check: straight to the flag)
             bool d = false;
             if (lane < n_pred && ((pend >> lane) & 1ull)) d = __hip_atomic_load(done_flag + pred[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
             got = __ballot(d);
@@ -1554,7 +1554,17 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 __syncthreads();
             }
             flags = sh[FR_FLAGS];
-            const bool reopen = (flags & FRF_INVALIDATED) && sh[FR_DROPPED] != 0u;
+            // Nodes lost their edges.  The best candidate survives unless one of its own path did (a published plan's path always
+            // does: it was checked before the areas went out): then it stays the best — what comes after it still does, nothing that
+            // was dropped comes back, no candidate has to be looked at again — and only the counts are due again (phase B).
+            bool best_alive = false;
+            if ((flags & FRF_INVALIDATED) && sh[FR_BEST_ID] != 0u) {  // (uniform; every thread walks the same Hp nodes)
+                const uint32_t g = sh[FR_BEST_ID];
+                double b1;
+                best_alive = vs_load(VS, g - 1u) == VS_VALID && fr_goal_path(S, VS, F.gkey, g, b1);
+            }
+            const bool lost_best = (flags & FRF_INVALIDATED) && !best_alive;
+            const bool reopen = lost_best && sh[FR_DROPPED] != 0u;
             // parked nodes (their edges crossed expected areas only) come back into the open set: never evaluated, as far as anybody
             // can tell — a round will check them against what the soup holds then.  (reopen: the rebuild below finds them in the tree)
             const uint32_t n_parked = sh[BK_NTENT];
@@ -1585,8 +1595,10 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 sh_st_d(sh, BK_TENT_MIN, inf);
                 if (flags & FRF_INVALIDATED) {
                     sh[FR_EVER_INVAL] = 1;
-                    sh[FR_BEST_ID] = 0;  // the best candidate may have lost an ancestor: look at all of them again
-                    sh[FR_PATH_FOR] = 0;
+                    if (lost_best) {  // look at all the candidates again
+                        sh[FR_BEST_ID] = 0;
+                        sh[FR_PATH_FOR] = 0;
+                    }
                     sh[FR_FLAGS] = flags & ~FRF_INVALIDATED;
                 }
                 if (reopen) {
@@ -1607,7 +1619,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             }
             __syncthreads();
             if (reopen) l_mid = -1.0;  // (uniform)
-            if (flags & FRF_INVALIDATED) {
+            if (lost_best) {
                 for (uint32_t base = 0; base < nn; base += (uint32_t)bd) {  // (uniform trip count: barriers inside)
                     const uint32_t b = base + (uint32_t)wave * PDMPC_WAVE;
                     const uint32_t i0 = b + (uint32_t)lane;
@@ -1768,10 +1780,13 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             if (sh[FR_FLAGS] & FRF_BUG) dep_timeout = true;
             break;
         }
-        if (done && unverified && !dep_timeout) {
+        const bool publish_first = done && !unverified && !pb_valid && sh[BK_PUBLISHED] == 0u && sh_load64(sh, SH_PEND_LO) == 0ull;
+        if (done && (unverified || publish_first) && !dep_timeout) {
             // Finished as far as the verified areas go.  What the successors wait for comes first: the record with the plan's areas (its
             // counts are rewritten after the verification if that takes edges away), the areas that were copied since against the path,
             // the done flag if they pass and nobody is outstanding (bk_wait_done without waiting); then the verification.
+            // (publish_first: every predecessor has arrived and has been verified — the areas go out before phase B counts the pops,
+            // which only the host waits for: 17-35 us per hop of C2's level chain)
             if (!rec_valid && sh[BK_PUBLISHED] == 0u) {
                 if (wave == 0) bk_write_record(A, X, best, best ? PDMPC_OK : PDMPC_EXHAUSTED, false, R.n_popped, R.n_expanded, false, nullptr, rec_written, false, lane);
                 rec_written = true;
@@ -1781,9 +1796,11 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 bk_wait_done(A.done_flag, P.pred, P.out, A.epoch, (uint32_t)slot, P.l_soup, P.l_soff, P.l_lit, (lds_d2*)(X.lsm + A.lds.bk_pshape), sh, Hp, P.n_pred, best != 0u,
                              ticking ? (lds_vu64*)(tk + tk_pub) : (lds_vu64*)nullptr, sh_load64(sh, BK_FD_LO), 0u, CHECKER == PDMPC_CHECK_SAT, lane);
             __syncthreads();
-            verify_req = true;
-            BK_TICK(tk_arrival)
-            continue;
+            if (unverified) {
+                verify_req = true;
+                BK_TICK(tk_arrival)
+                continue;
+            }
         }
         if (done) {
             // Phase B right away, also when predecessors are still planning: an arrival that invalidates nothing leaves the tree,
