@@ -790,6 +790,35 @@ __device__ __forceinline__ void bk_wait_done(const uint32_t* done_flag, const in
     }
 }
 
+// Collision-free nodes at the horizon are offered as goal candidates again (after an invalidation that took the best one, or
+// when a round had more candidates than its list holds): every lane with a candidate walks that candidate's path by itself — all
+// of them Hp edges long, so the lanes of a wave finish together — instead of the wave walking them one after the other
+// (fr_offer_goal; a walk is Hp dependent reads of the tree: C2's last vehicles spent 30 us per arrival there).  Whole wave calls.
+__device__ __forceinline__ void bk_offer_goals_lanes(const Frontier& F, const Search& S, const VState& VS, bool cand, uint32_t id, int lane) {
+    double m = 0.0;
+    bool alive = cand;
+    if (cand) {
+        uint32_t nd = id;
+        for (;;) {
+            const double k = F.gkey[nd - 1];
+            m = k > m ? k : m;
+            if (nd != id && vs_load(VS, nd - 1) != VS_VALID) alive = false;
+            const uint32_t par = node_parent(S, nd - 1);
+            if (!par) break;
+            nd = par;
+        }
+    }
+    const unsigned long long bal = __ballot(alive);
+    if (bal) {  // (uniform)
+        const uint32_t base = sh_add_uniform(F.sh, FR_GOAL_N, (uint32_t)__builtin_popcountll(bal), lane);
+        if (alive) {
+            node_store_cs(S, id - 1u, m, 0.0);
+            const uint32_t pos = base + lane_rank(bal, lane);
+            if (pos < 1024u) F.goal_list[pos] = id;  // (at most blockDim candidates per pass: cannot overflow)
+        }
+    }
+}
+
 // The far-list selection stays an out-of-line call: it runs once per refill on one wavefront, and inlined into the search loop its
 // registers push the whole kernel over the 168-VGPR budget of a twelve-wavefront workgroup (tests/test_build.py watches this).
 __device__ __noinline__ void bk_far_select(const Frontier& F, uint32_t fill, int lane) {
@@ -1467,12 +1496,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 const bool in = i0 < nn;
                 const uint32_t j0 = in ? i0 : 0u;
                 const bool cand = in && vs_load(VS, j0) == VS_VALID && NODE_K(((const uint32_t*)(S.gn + j0))[15]) == Hp;
-                unsigned long long bc = __ballot(cand);
-                while (bc) {
-                    const int l = __builtin_ctzll(bc);
-                    bc &= bc - 1;
-                    fr_offer_goal(F, S, VS, b + (uint32_t)l + 1u, lane);
-                }
+                bk_offer_goals_lanes(F, S, VS, cand, j0 + 1u, lane);
                 __syncthreads();  // at most blockDim candidates per pass: the list cannot overflow
                 fr_resolve_goals(F, S, tid, lane, wave);
             }
@@ -1513,6 +1537,10 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                     sh[SH_ARR_LO] = 0;
                     sh[SH_ARR_HI] = 0;
                     sh[SH_STATE] = ST_RUN;
+                    if (ticking) {  // (diagnostics: the last arrival that met a running search, and the rounds done by then)
+                        X.O->path_nodes[PDMPC_HP_MAX - 2][6] = (double)sh[FR_ROUNDS];
+                        X.O->path_nodes[PDMPC_HP_MAX - 2][7] = (double)__builtin_amdgcn_s_memrealtime();
+                    }
                 }
                 __syncthreads();
                 verify_req = true;
@@ -1630,12 +1658,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                     const bool cand = in && vst == VS_VALID && NODE_K(((const uint32_t*)(S.gn + j0))[15]) == Hp;
                     const bool open = reopen && in && vst == VS_UNKNOWN && par != 0u && vs_load(VS, par ? par - 1u : 0u) == VS_VALID;
                     if (reopen) to_far(open, F.gkey[j0], j0 + 1u);
-                    unsigned long long bc = __ballot(cand);
-                    while (bc) {
-                        const int l = __builtin_ctzll(bc);
-                        bc &= bc - 1;
-                        fr_offer_goal(F, S, VS, b + (uint32_t)l + 1u, lane);
-                    }
+                    bk_offer_goals_lanes(F, S, VS, cand, j0 + 1u, lane);
                     __syncthreads();  // at most blockDim candidates per pass: the list cannot overflow
                     fr_resolve_goals(F, S, tid, lane, wave);
                 }
@@ -1842,6 +1865,10 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                     bk_wait_done(A.done_flag, P.pred, P.out, A.epoch, (uint32_t)slot, P.l_soup, P.l_soff, P.l_lit, (lds_d2*)(X.lsm + A.lds.bk_pshape), sh, Hp, P.n_pred, best != 0u,
                                  ticking ? (lds_vu64*)(tk + tk_pub) : (lds_vu64*)nullptr, 0ull, 4096u, CHECKER == PDMPC_CHECK_SAT, lane);
                 __syncthreads();
+                if (ticking && sh[BK_WAITRES] == 1u) {  // (diagnostics: an arrival crossed the finished plan's path)
+                    X.O->path_nodes[PDMPC_HP_MAX - 2][6] = (double)sh[FR_ROUNDS];
+                    X.O->path_nodes[PDMPC_HP_MAX - 2][7] = (double)__builtin_amdgcn_s_memrealtime();
+                }
                 if (sh[BK_IDLE] > A.spin_limit) dep_timeout = true;
             } else if (bk_wait()) {
                 dep_timeout = true;  // a predecessor never finished: give up on it (reported as an error status)
@@ -2155,7 +2182,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         dbg[3] = (double)sh[FR_NEAR_N];
         dbg[4] = (double)(sh[FR_FAR_N] + sh[BK_MID_N]);
         dbg[5] = (double)sh[FR_FLAGS];
-        dbg[6] = 0.0;
+        dbg[6] = (double)sh[BK_ARRIVALS];  // verification events
         dbg[7] = (double)(__builtin_amdgcn_s_memrealtime() - tk[TK_START]);
         X.O->path_nodes[PDMPC_HP_MAX - 2][0] = (double)(tk[TK_START] - X.rt_kernel_start);
         X.O->path_nodes[PDMPC_HP_MAX - 2][1] = (double)tk[tk_p1];

@@ -44,8 +44,9 @@ for b, prob in enumerate(probs):
         for v in sorted(range(len(recs)), key=lambda i: (prob["levels"][i], i)):
             pr = prob["preds"][v]
             last = max([pub[q] for q in pr], default=0.0)
-            print("   chain veh %2d level %2d preds %2d | search done %4.0f us | areas out %4.0f us (hop %4.0f) | end %4.0f us | early %d" % (
-                v, prob["levels"][v], len(pr), (T[v][15][7] - origin) / 100.0 + T[v][14][0] / 100.0 + T[v][15][0] / 100.0 + T[v][15][2] / 100.0, pub[v], pub[v] - last, end[v], int(T[v][15][5] > 0)))
+            la = (T[v][14][7] - origin) / 100.0 if T[v][14][7] > 0 else 0.0
+            print("   chain veh %2d level %2d preds %2d | busy %4.0f us | areas out %4.0f us (hop %4.0f) | end %4.0f us | last arrival into the running search %4.0f us at round %2d of %2d | %2d verifications %3.0f us" % (
+                v, prob["levels"][v], len(pr), T[v][14][0] / 100.0 + T[v][15][0] / 100.0 + T[v][15][2] / 100.0, pub[v], pub[v] - last, end[v], la, int(T[v][14][6]), int(T[v][16][0]), int(T[v][16][6]), T[v][15][1] / 100.0))
     top = int(os.environ.get("PROFILE_TOP", "8"))
     for r in sorted(rows, reverse=True)[:top]:
         print("   total %.0f us veh %d level %d popped %d processed %d nodes %d rounds %d | work %.0f arrival %.0f select %.0f wait %.0f us | preds %d | prologue %.0f check %.0f verdict %.0f expand %.0f phaseB %.0f refill %.0f us" % r)
