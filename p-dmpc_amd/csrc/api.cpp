@@ -331,7 +331,7 @@ bool layout_bulk(pdmpc_handle* h, size_t budget, int n_waves, int areas, int sou
     L.bk_misc = off;
     off += 2048u;
     L.bk_pshape = off;
-    off += align16((uint32_t)h->cfg.Hp * PDMPC_VMAX * 16u + PDMPC_HP_MAX * 4u);
+    off += align16((uint32_t)h->cfg.Hp * PDMPC_VMAX * 16u + PDMPC_HP_MAX * 4u + PDMPC_HP_MAX * 8u);
     L.tree16 = L.bk_hist;  // (the sampled optimizer's region: not part of this layout)
     const uint32_t min_nodes = 64 * (uint32_t)sizeof(NodeRec) + 1024;
     if ((size_t)off + min_nodes + 256 > budget) return false;

@@ -320,23 +320,25 @@ __device__ __forceinline__ int nth_bit(uint64_t mask, int rk) {
     return (int)__builtin_ctzll(mask);
 }
 
-// Late predecessors (PrioritizedController.m:476-491): the collision-free nodes against the areas of the predecessors in `arr`,
-// which have just entered the soup.  item = (node, arrived predecessor): the edge's area is transformed once, the predecessor's
-// polygon of the node's step goes through interx_segment_n segment by segment (InterX.m:63-76 restricted to those polygons).
-// list == nullptr: the nodes are 0 .. count - 1 themselves (small trees: no gathering pass), the others are skipped.
+// Late predecessors (PrioritizedController.m:476-491): the collision-free nodes of `list` against the areas of the predecessors in
+// `arr`, which have just entered the soup, as far as those differ from the areas the edges were checked against (chg, see
+// bk_incorporate_body).  item = (node, j): the j-th such predecessor of the node's step, j < maxc = the most any step has; the edge's
+// area is transformed once, the predecessor's polygon of the node's step goes through interx_segment_n segment by segment
+// (InterX.m:63-76 restricted to those polygons).
 template <int CHECKER>
 __device__ __forceinline__ void bk_recheck_items(const Search& S, const VState& VS, const BkCheck& C, const SpecCtx& P, const lds_u32* list, uint32_t count, unsigned long long arr,
-                                                 volatile lds_u32* sh, int tid, int nthreads) {
-    const uint32_t n_arr = (uint32_t)__builtin_popcountll(arr), items = count * n_arr;
+                                                 const lds_u64s* chg, uint32_t maxc, volatile lds_u32* sh, int tid, int nthreads) {
+    const uint32_t items = count * maxc;
     for (uint32_t item = (uint32_t)tid; item < items; item += (uint32_t)nthreads) {
-        const uint32_t v = item / n_arr, a = item - v * n_arr;
-        const uint32_t i0 = list ? list[v] : v;
-        if (vs_load(VS, i0) != VS_VALID) continue;
+        const uint32_t v = item / maxc, a = item - v * maxc;
+        const uint32_t i0 = list[v];
         uint32_t parent, packed;
         piece_link(node_piece(S, i0, 3), parent, packed);
         if (!parent) continue;
-        const int p = nth_bit(arr, (int)a);
         const int k = NODE_K(packed), m = NODE_MAN(packed), ncols = NODE_COLS(packed);
+        const unsigned long long due = chg[k - 1] & arr;
+        if (a >= (uint32_t)__builtin_popcountll(due)) continue;
+        const int p = nth_bit(due, (int)a);
         const d2 pxy = node_piece(S, parent - 1u, 0), pcs = node_piece(S, parent - 1u, 2);
         const double cc = pcs.x, ss = pcs.y, pX = pxy.x, pY = pxy.y;
         const size_t abase = (size_t)m * 3 * PDMPC_VMAX;
@@ -607,8 +609,11 @@ __device__ __forceinline__ bool bk_poll_predecessors(const KernelArgs& A, const 
 
 // incorporate_areas with loads that are coherent by themselves (bk_area_load): the solved areas of the predecessors in `arr` into
 // their soup slots (PrioritizedController.m:476-491); nthreads threads call (a workgroup, or one wave).
+// (chg, when given: [Hp] 64-bit masks — bit p of chg[k] is set when the area predecessor p publishes for step k + 1 differs from what
+// its slot held, i.e. from the area it was expected to take.  A collision-free edge of that step has been checked against exactly
+// those numbers: only the pairs (step, predecessor) marked here are due for the re-check, bk_recheck_items.)
 __device__ __forceinline__ void bk_incorporate_body(const pdmpc_vehicle_out* out, const int32_t* pred, lds_d2* l_soup, const lds_i32* l_soff, const lds_i32* l_lit, int Hp, unsigned long long arr, int tid,
-                                                    int nthreads) {
+                                                    int nthreads, lds_u64s* chg) {
     const double qnan = __longlong_as_double(0x7ff8000000000000LL);
     const int per = Hp * PDMPC_VMAX, n_arr = __builtin_popcountll(arr);
     for (int idx = tid; idx < n_arr * per; idx += nthreads) {  // (every arrived predecessor's loads side by side)
@@ -621,12 +626,18 @@ __device__ __forceinline__ void bk_incorporate_body(const pdmpc_vehicle_out* out
         d2 pt;
         pt.x = v < cols ? sx : qnan;
         pt.y = v < cols ? sy : qnan;
-        l_soup[l_soff[k] + l_lit[k] + p * PDMPC_VMAX + v] = pt;
+        lds_d2* slot = l_soup + l_soff[k] + l_lit[k] + p * PDMPC_VMAX + v;
+        if (chg) {
+            const d2 was = *slot;
+            if (__double_as_longlong(was.x) != __double_as_longlong(pt.x) || __double_as_longlong(was.y) != __double_as_longlong(pt.y))
+                __hip_atomic_fetch_or(chg + k, 1ull << p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        *slot = pt;
     }
 }
 __device__ __forceinline__ void bk_incorporate(const pdmpc_vehicle_out* out, const int32_t* pred, lds_d2* l_soup, const lds_i32* l_soff, const lds_i32* l_lit, int Hp, unsigned long long arr, int tid,
-                                               int nthreads) {
-    bk_incorporate_body(out, pred, l_soup, l_soff, l_lit, Hp, arr, tid, nthreads);
+                                               int nthreads, lds_u64s* chg) {
+    bk_incorporate_body(out, pred, l_soup, l_soff, l_lit, Hp, arr, tid, nthreads, chg);
 }
 
 // fr_check_wave with a memory: what to do with an open node a round has selected (1 process it, 3 it comes after the goal candidate,
@@ -712,6 +723,7 @@ __device__ __forceinline__ void bk_wait_done(const uint32_t* done_flag, const in
                                              const lds_i32* l_lit, lds_d2* pshape, volatile lds_u32* sh, int Hp, int n_pred, bool have_path, lds_vu64* tk_pub, unsigned long long first, uint32_t max_spins,
                                              bool sat, int lane) {
     const lds_u32* pcols = (const lds_u32*)(pshape + Hp * PDMPC_VMAX);
+    lds_u64s* chg = (lds_u64s*)(pcols + PDMPC_HP_MAX);
     unsigned long long pend = sh_load64(sh, SH_PEND_LO), fd = sh_load64(sh, BK_FD_LO);
     unsigned long long got = first;  // (in the soup already: checked against the path before anybody is polled)
     uint32_t spins = 0, res = 0;
@@ -729,7 +741,7 @@ __device__ __forceinline__ void bk_wait_done(const uint32_t* done_flag, const in
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-            bk_incorporate_body(out, pred, l_soup, l_soff, l_lit, Hp, got, lane, PDMPC_WAVE);
+            bk_incorporate_body(out, pred, l_soup, l_soff, l_lit, Hp, got, lane, PDMPC_WAVE, chg);
             wave_sync();
             pend &= ~got;
             fd |= got;
@@ -749,7 +761,9 @@ __device__ __forceinline__ void bk_wait_done(const uint32_t* done_flag, const in
             for (int i = 0; i < PDMPC_VMAX; ++i) pt[i] = pshape[k0 * PDMPC_VMAX + i];
             const lds_d2* poly = l_soup + l_soff[k0] + l_lit[k0] + p * PDMPC_VMAX;
             bool h1;
-            if (sat) {  // (uniform) the separating-axis checker: the lane with the area's first segment tests the pair of polygons
+            if (!((chg[k0] >> p) & 1ull)) {  // the area the path was checked against when its edge was evaluated: nothing new
+                h1 = false;
+            } else if (sat) {  // (uniform) the separating-axis checker: the lane with the area's first segment tests the pair of polygons
                 int cols = 0;
                 while (cols < PDMPC_VMAX && !is_nan(poly[cols].x)) ++cols;
                 h1 = j == 0 && cols > 0 && sat_pair_lane(pt, (int)pcols[k0], poly, cols);
@@ -1066,6 +1080,19 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         for (int i = 2; i < 12; ++i) tk[i] = 0ull;
         tk[TK_MARK] = tk[TK_START] = __builtin_amdgcn_s_memrealtime();
     }
+    lds_u64s* chg = (lds_u64s*)((lds_u32*)((lds_d2*)(X.lsm + A.lds.bk_pshape) + Hp * PDMPC_VMAX) + PDMPC_HP_MAX);  // [HP_MAX] areas that differ from the expected ones (bk_incorporate_body)
+    if (tid < PDMPC_HP_MAX) chg[tid] = 0ull;  // (read behind the barriers of the first round)
+    lds_vu64* tk2 = (lds_vu64*)(gp_path + 242);  // [7] (diagnostics) the arrival handling in detail: poll + copy, re-check, parked nodes, bookkeeping + candidates, record + flag of a finished search
+    if (ticking)
+        for (int i = 0; i < 7; ++i) tk2[i] = 0ull;
+#define BK_TICK2(i)                                                        \
+    if (ticking) {                                                         \
+        const unsigned long long now__ = __builtin_amdgcn_s_memrealtime(); \
+        tk2[i] += now__ - tk2[6];                                          \
+        tk2[6] = now__;                                                    \
+    }
+#define BK_MARK2 \
+    if (ticking) tk2[6] = __builtin_amdgcn_s_memrealtime();
 #define BK_TICK(acc)                                                       \
     if (ticking) {                                                         \
         const unsigned long long now__ = __builtin_amdgcn_s_memrealtime(); \
@@ -1461,7 +1488,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             if (tid == 0) {  // (nobody reads these words before the barrier that ends the round)
                 sh[FR_NNODES] = nn_base + (overflow ? 0u : NC);
                 sh[FR_PROCESSED] = sh[FR_PROCESSED] + Rn;
-                if (A.debug_tail && sh[FR_ROUNDS] < 40u) X.O->path_nodes[PDMPC_HP_MAX - 7 + (int)(sh[FR_ROUNDS] >> 3)][sh[FR_ROUNDS] & 7u] = (double)Rn;  // (diagnostics: the sizes of the first forty rounds in rows HP_MAX - 7 .. HP_MAX - 3)
+                if (A.debug_tail && sh[FR_ROUNDS] < 32u) X.O->path_nodes[PDMPC_HP_MAX - 7 + (int)(sh[FR_ROUNDS] >> 3)][sh[FR_ROUNDS] & 7u] = (double)Rn;  // (diagnostics: the sizes of the first thirty-two rounds in rows HP_MAX - 7 .. HP_MAX - 4)
                 sh[FR_ROUNDS] = sh[FR_ROUNDS] + 1u;
                 if (overflow) sh[FR_FLAGS] = sh[FR_FLAGS] | FRF_OVERFLOW;
             }
@@ -1521,12 +1548,13 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         // open set.  A finished search that waits (bk_wait_done) copies and checks its plan's path only, and the verification follows
         // for everybody who has arrived meanwhile; a running search verifies right behind the copy (measured: putting it off until
         // the search has nothing else to do leaves parked nodes parked and dead subtrees alive — C2's heavy steps 1.35 -> 1.75 ms).
+        BK_MARK2
         if (sh_load64(sh, SH_PEND_LO) != 0ull) {  // (uniform: written by thread 0 between barriers)
             if (wave == 0 && sh[SH_STATE] != ST_ARRIVED) (void)bk_poll_predecessors(A, P, sh, 0ull, lane);  // (a waiting search has polled already: bk_wait)
             __syncthreads();
             if (sh[SH_STATE] == ST_ARRIVED) {  // (uniform)
                 const unsigned long long arr = sh_load64(sh, SH_ARR_LO);
-                bk_incorporate(P.out, P.pred, P.l_soup, P.l_soff, P.l_lit, Hp, arr, tid, bd);
+                bk_incorporate(P.out, P.pred, P.l_soup, P.l_soff, P.l_lit, Hp, arr, tid, bd, chg);
                 __syncthreads();
                 if (tid == 0) {
                     const unsigned long long pend = sh_load64(sh, SH_PEND_LO) & ~arr, fd = sh_load64(sh, BK_FD_LO) | arr;
@@ -1543,44 +1571,55 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                     }
                 }
                 __syncthreads();
-                verify_req = true;
+                verify_req = true;  // (putting it off until the search stalls or is done: C2 1 382 -> 1 212, C3 1 100 -> 939, C4 82.8 -> 71.4 steps/s)
             }
         }
+        BK_TICK2(0)
         if (verify_req) {  // (uniform)
             verify_req = false;
             const unsigned long long arr = sh_load64(sh, BK_FD_LO);  // everybody whose areas were copied since the last verification
             uint32_t nn = sh[FR_NNODES];
             nn = nn < S.max_nodes ? nn : S.max_nodes;
-            // Only collision-free nodes can lose their edge.  Small trees: every node is an item (the others are skipped); trees of more
-            // nodes than threads: the collision-free ones (a third of the tree, scattered) are gathered first so that the items are dense
-            // — an item is a chain of two dependent reads of the tree, and a lane that walks three or four of them one after the other
-            // (most of them skipped) was what an arrival event cost (C2's last vehicles: 10 of 15 us per event; gathering from 768 nodes
-            // on instead of 3 072: C2 1 041 -> 1 077 steps/s).
-            const bool direct = nn <= (uint32_t)bd;
+            // Only collision-free nodes can lose their edge, and only to an area that differs from the one their edge was checked
+            // against (chg: for a predecessor that carries on with its last plan that is the horizon's step alone).  They are gathered
+            // first, a list's worth of the tree at a time, so that the items are dense: an item is a chain of two dependent reads of
+            // the tree and seven segment tests, and lanes that skip theirs cost what the busy lanes of their wave cost (C2's last
+            // vehicles, 15 predecessors each: 25-30 us per arrival event with every node x predecessor an item).
+            uint32_t maxc = 0;
+            for (int k = 0; k < Hp; ++k) {  // (uniform)
+                const uint32_t c = (uint32_t)__builtin_popcountll(chg[k] & arr);
+                maxc = c > maxc ? c : maxc;
+            }
+            if (ticking) {
+                unsigned long long due = 0;
+                for (int k = 0; k < Hp; ++k) due += (unsigned long long)__builtin_popcountll(chg[k] & arr);
+                atomicAdd(A.work_count + 14, due);
+                atomicAdd(A.work_count + 15, (unsigned long long)(Hp * __builtin_popcountll(arr)));
+            }
 #pragma unroll 1
-            for (uint32_t base0 = 0; base0 < nn; base0 += direct ? nn : (uint32_t)FR_NBINS) {  // (uniform trip counts: barriers inside)
-                const lds_u32* list = nullptr;
-                uint32_t cnt = nn;
-                if (!direct) {
-                    const uint32_t end = base0 + FR_NBINS < nn ? base0 + FR_NBINS : nn;
-                    if (tid == 0) sh[FR_VLIST_N] = 0;
-                    __syncthreads();
-                    for (uint32_t b = base0; b < end; b += (uint32_t)bd) {
-                        const uint32_t i0 = b + (uint32_t)tid;
-                        const bool v = i0 < end && vs_load(VS, i0 < end ? i0 : 0u) == VS_VALID;
-                        const unsigned long long bal = __ballot(v);
-                        if (bal) {
-                            const uint32_t pos0 = sh_add_uniform(sh, FR_VLIST_N, (uint32_t)__builtin_popcountll(bal), lane);
-                            if (v) hist[pos0 + lane_rank(bal, lane)] = i0;
-                        }
+            for (uint32_t base0 = 0; base0 < nn && maxc != 0u;) {  // (uniform trip counts: barriers inside)
+                if (tid == 0) sh[FR_VLIST_N] = 0;
+                __syncthreads();
+                uint32_t b = base0;
+                for (; b < nn && b - base0 + (uint32_t)bd <= (uint32_t)FR_NBINS; b += (uint32_t)bd) {  // (the list holds FR_NBINS nodes)
+                    const uint32_t i0 = b + (uint32_t)tid;
+                    const uint32_t j0 = i0 < nn ? i0 : 0u;
+                    const int k = NODE_K((uint32_t)(F.glink[j0] >> 32));
+                    const bool v = i0 < nn && k > 0 && vs_load(VS, j0) == VS_VALID && (chg[k > 0 ? k - 1 : 0] & arr) != 0ull;
+                    const unsigned long long bal = __ballot(v);
+                    if (bal) {
+                        const uint32_t pos0 = sh_add_uniform(sh, FR_VLIST_N, (uint32_t)__builtin_popcountll(bal), lane);
+                        if (v) hist[pos0 + lane_rank(bal, lane)] = i0;
                     }
-                    __syncthreads();
-                    list = hist;
-                    cnt = sh[FR_VLIST_N];
                 }
-                bk_recheck_items<CHECKER>(S, VS, CK, P, list, cnt, arr, sh, tid, bd);
+                __syncthreads();
+                base0 = b;
+                BK_TICK2(5)
+                const uint32_t cnt = sh[FR_VLIST_N];
+                bk_recheck_items<CHECKER>(S, VS, CK, P, hist, cnt, arr, chg, maxc, sh, tid, bd);
                 __syncthreads();
             }
+            BK_TICK2(1)
             flags = sh[FR_FLAGS];
             // Nodes lost their edges.  The best candidate survives unless one of its own path did (a published plan's path always
             // does: it was checked before the areas went out): then it stays the best — what comes after it still does, nothing that
@@ -1609,6 +1648,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                     to_far(push && !(fits && !(k > l_far)), k, i0 + 1u);
                 }
             }
+            BK_TICK2(2)
             if (flags & FRF_INVALIDATED) {
                 pb_valid = false;
                 rec_valid = false;
@@ -1619,6 +1659,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 sh[BK_ARRIVALS] = sh[BK_ARRIVALS] + 1u;  // (reported at the end: a global atomic here sits on every level's hand-over)
                 sh[BK_FD_LO] = 0;
                 sh[BK_FD_HI] = 0;
+                for (int k = 0; k < Hp; ++k) chg[k] = 0ull;
                 sh[BK_NTENT] = 0;
                 sh_st_d(sh, BK_TENT_MIN, inf);
                 if (flags & FRF_INVALIDATED) {
@@ -1671,6 +1712,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 __syncthreads();
             }
             flags = sh[FR_FLAGS];
+            BK_TICK2(3)
         }
         if (flags & FRF_TIE) {  // (uniform) equal keys where the order decides: from here on the search is headed for the replay
             __syncthreads();
@@ -1803,6 +1845,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             if (sh[FR_FLAGS] & FRF_BUG) dep_timeout = true;
             break;
         }
+        BK_MARK2
         const bool publish_first = done && !unverified && !pb_valid && sh[BK_PUBLISHED] == 0u && sh_load64(sh, SH_PEND_LO) == 0ull;
         if (done && (unverified || publish_first) && !dep_timeout) {
             // Finished as far as the verified areas go.  What the successors wait for comes first: the record with the plan's areas (its
@@ -1819,6 +1862,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 bk_wait_done(A.done_flag, P.pred, P.out, A.epoch, (uint32_t)slot, P.l_soup, P.l_soff, P.l_lit, (lds_d2*)(X.lsm + A.lds.bk_pshape), sh, Hp, P.n_pred, best != 0u,
                              ticking ? (lds_vu64*)(tk + tk_pub) : (lds_vu64*)nullptr, sh_load64(sh, BK_FD_LO), 0u, CHECKER == PDMPC_CHECK_SAT, lane);
             __syncthreads();
+            BK_TICK2(4)
             if (unverified) {
                 verify_req = true;
                 BK_TICK(tk_arrival)
@@ -2184,6 +2228,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         dbg[5] = (double)sh[FR_FLAGS];
         dbg[6] = (double)sh[BK_ARRIVALS];  // verification events
         dbg[7] = (double)(__builtin_amdgcn_s_memrealtime() - tk[TK_START]);
+        for (int i = 0; i < 6; ++i) X.O->path_nodes[PDMPC_HP_MAX - 3][i] = (double)tk2[i];
         X.O->path_nodes[PDMPC_HP_MAX - 2][0] = (double)(tk[TK_START] - X.rt_kernel_start);
         X.O->path_nodes[PDMPC_HP_MAX - 2][1] = (double)tk[tk_p1];
         X.O->path_nodes[PDMPC_HP_MAX - 2][2] = (double)tk[tk_p2];
@@ -2451,7 +2496,7 @@ __device__ __forceinline__ void bulk_helper_body(const KernelArgs& A) {
         const unsigned long long mask = ((unsigned long long)hs[HS_MASK_HI] << 32) | hs[HS_MASK_LO];
         last_seq = seq;
         if (mask != cur_mask) {  // (within a launch a search's set of incorporated predecessors only grows)
-            bk_incorporate(P.out, P.pred, P.l_soup, P.l_soff, P.l_lit, Hp, mask & ~cur_mask, tid, bd);  // (loads that are coherent by themselves)
+            bk_incorporate(P.out, P.pred, P.l_soup, P.l_soff, P.l_lit, Hp, mask & ~cur_mask, tid, bd, nullptr);  // (loads that are coherent by themselves)
             cur_mask = mask;
         }
         HK_TICK(1)

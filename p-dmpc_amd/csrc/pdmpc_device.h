@@ -81,7 +81,7 @@ struct LdsLayout {
     uint32_t bk_ready;                     // uint32[bk_ready_cap] nodes of the round + uint32[bk_ready_cap] their collision flags
     uint32_t bk_hist;                      // uint32[3072]: refill histogram [2048] | goal list [1024], expansion groups [1024], their children's offsets [1024]
     uint32_t bk_misc;                      // 2 KB: path tables of the best goal candidate, scan partials, chunk table, tick counters, the reference's ids along the path | the selection's 256-bin histogram
-    uint32_t bk_pshape;                    // double2[Hp][VMAX] + uint32[HP_MAX]: the areas along the path of the record written last and their column counts (what an arrival is checked against first)
+    uint32_t bk_pshape;                    // double2[Hp][VMAX] + uint32[HP_MAX] + uint64[HP_MAX]: the areas along the path of the record written last and their column counts (what an arrival is checked against first); per step the predecessors whose areas differ from the expected ones
 };
 
 struct NodeArena {  // HBM arrays, per-vehicle stride = max_nodes entries

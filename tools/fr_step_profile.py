@@ -27,15 +27,17 @@ for b, prob in enumerate(probs):
     if dc[13]:
         print("   helpers: %d tiles, per tile: claim -> soup %.1f us, records %.1f us, checks %.1f us, verdicts + report %.1f us; idle in all %.0f us; shared rounds %d" % (
             dc[13], dc[9] / 100.0 / dc[13], dc[10] / 100.0 / dc[13], dc[11] / 100.0 / dc[13], dc[12] / 100.0 / dc[13], dc[8] / 100.0, dc[4]))
+    if dc[15]:
+        print("   arrivals: %d of %d (step, predecessor) areas differ from the expected ones" % (dc[14], dc[15]))
     rows = []
     for v in range(len(recs)):
         t = np.asarray(recs[v]["path_nodes"])
         rows.append((t[16][7] / 100.0, v, prob["levels"][v], int(recs[v]["n_popped"]), int(t[16][1]), int(t[16][2]), int(t[16][0]), t[15][0] / 100.0, t[15][1] / 100.0, t[15][2] / 100.0, t[15][3] / 100.0, len(prob["preds"][v]),
                      t[14][0] / 100.0, t[14][1] / 100.0, t[14][2] / 100.0, t[14][3] / 100.0, t[14][4] / 100.0, t[14][5] / 100.0))
-    if os.environ.get("PROFILE_ROUNDS"):  # the sizes of the first forty rounds of the step's largest search (bulk kernel; only while Hp <= 8)
+    if os.environ.get("PROFILE_ROUNDS"):  # the sizes of the first thirty-two rounds of the step's largest search (bulk kernel; only while Hp <= 8)
         v = max(range(len(recs)), key=lambda i: np.asarray(recs[i]["path_nodes"])[16][1])
         t = np.asarray(recs[v]["path_nodes"])
-        print("   round sizes of veh %d:" % v, [int(x) for x in t[9:14].reshape(-1) if x > 0])
+        print("   round sizes of veh %d:" % v, [int(x) for x in t[9:13].reshape(-1) if x > 0])
     if os.environ.get("PROFILE_CHAIN"):  # when every vehicle's areas went out (done flag) and ended, on the device's 100 MHz clock from the first workgroup's start; hop = after its last predecessor's flag
         T = [np.asarray(r["path_nodes"]) for r in recs]
         origin = min(t[15][7] for t in T)
@@ -45,8 +47,8 @@ for b, prob in enumerate(probs):
             pr = prob["preds"][v]
             last = max([pub[q] for q in pr], default=0.0)
             la = (T[v][14][7] - origin) / 100.0 if T[v][14][7] > 0 else 0.0
-            print("   chain veh %2d level %2d preds %2d | busy %4.0f us | areas out %4.0f us (hop %4.0f) | end %4.0f us | last arrival into the running search %4.0f us at round %2d of %2d | %2d verifications %3.0f us" % (
-                v, prob["levels"][v], len(pr), T[v][14][0] / 100.0 + T[v][15][0] / 100.0 + T[v][15][2] / 100.0, pub[v], pub[v] - last, end[v], la, int(T[v][14][6]), int(T[v][16][0]), int(T[v][16][6]), T[v][15][1] / 100.0))
+            print("   chain veh %2d level %2d preds %2d | busy %4.0f us | areas out %4.0f us (hop %4.0f) | end %4.0f us | last arrival into the running search %4.0f us at round %2d of %2d | %2d verifications %3.0f us (copy %.0f re-check %.0f parked %.0f candidates %.0f record+flag %.0f; of the re-check: gathering %.0f)" % (
+                v, prob["levels"][v], len(pr), T[v][14][0] / 100.0 + T[v][15][0] / 100.0 + T[v][15][2] / 100.0, pub[v], pub[v] - last, end[v], la, int(T[v][14][6]), int(T[v][16][0]), int(T[v][16][6]), T[v][15][1] / 100.0, T[v][13][0] / 100.0, T[v][13][1] / 100.0, T[v][13][2] / 100.0, T[v][13][3] / 100.0, T[v][13][4] / 100.0, T[v][13][5] / 100.0))
     top = int(os.environ.get("PROFILE_TOP", "8"))
     for r in sorted(rows, reverse=True)[:top]:
         print("   total %.0f us veh %d level %d popped %d processed %d nodes %d rounds %d | work %.0f arrival %.0f select %.0f wait %.0f us | preds %d | prologue %.0f check %.0f verdict %.0f expand %.0f phaseB %.0f refill %.0f us" % r)
