@@ -1331,6 +1331,15 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            if (ticking && A.debug_tail == 2) {  // (diagnostics: rounds, P1 time, entries and the owner's part by the seats the round had: none, 1-7, 8-31, 32-64)
+                const int bkt = !share ? 0 : (seats < 8u ? 1 : (seats < 32u ? 2 : 3));
+                double* r0 = X.O->path_nodes[PDMPC_HP_MAX - 5];
+                double* r1 = X.O->path_nodes[PDMPC_HP_MAX - 4];
+                r0[bkt] += 1.0;
+                r0[4 + bkt] += (double)(__builtin_amdgcn_s_memrealtime() - tk[TK_MARK]);
+                r1[bkt] += (double)Rn;
+                r1[4 + bkt] += (double)own_n;
+            }
             BK_TICK(tk_p1)
 
             BK_OPAQUE_TID
@@ -1488,7 +1497,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             if (tid == 0) {  // (nobody reads these words before the barrier that ends the round)
                 sh[FR_NNODES] = nn_base + (overflow ? 0u : NC);
                 sh[FR_PROCESSED] = sh[FR_PROCESSED] + Rn;
-                if (A.debug_tail && sh[FR_ROUNDS] < 32u) X.O->path_nodes[PDMPC_HP_MAX - 7 + (int)(sh[FR_ROUNDS] >> 3)][sh[FR_ROUNDS] & 7u] = (double)Rn;  // (diagnostics: the sizes of the first thirty-two rounds in rows HP_MAX - 7 .. HP_MAX - 4)
+                if (A.debug_tail == 1 && sh[FR_ROUNDS] < 32u) X.O->path_nodes[PDMPC_HP_MAX - 7 + (int)(sh[FR_ROUNDS] >> 3)][sh[FR_ROUNDS] & 7u] = (double)Rn;  // (diagnostics: the sizes of the first thirty-two rounds in rows HP_MAX - 7 .. HP_MAX - 4)
                 sh[FR_ROUNDS] = sh[FR_ROUNDS] + 1u;
                 if (overflow) sh[FR_FLAGS] = sh[FR_FLAGS] | FRF_OVERFLOW;
             }
@@ -2315,6 +2324,7 @@ __device__ __forceinline__ void bulk_helper_body(const KernelArgs& A) {
     // soup in place, the range's records, its check items, verdicts + report; work_count[8..12], [13] = ranges)
     const bool hticking = A.debug_tail != 0 && tid == 0;
     unsigned long long hk_mark = hticking ? __builtin_amdgcn_s_memrealtime() : 0ull, hk[5] = {0, 0, 0, 0, 0}, hk_tiles = 0;
+    const unsigned long long hk_start = hk_mark;
 #define HK_TICK(i)                                                        \
     if (hticking) {                                                       \
         const unsigned long long n__ = __builtin_amdgcn_s_memrealtime(); \
@@ -2534,6 +2544,7 @@ __device__ __forceinline__ void bulk_helper_body(const KernelArgs& A) {
         hk_tiles += 1;
     }
     if (hticking) {
+        atomicAdd(A.work_count + 7, __builtin_amdgcn_s_memrealtime() - hk_start);  // (this helper's lifetime)
         for (int i = 0; i < 5; ++i) atomicAdd(A.work_count + 8 + i, hk[i]);
         atomicAdd(A.work_count + 13, hk_tiles);
     }
@@ -2545,7 +2556,9 @@ __device__ __forceinline__ void bulk_body(const KernelArgs& A) {
     // The workgroups behind the searches are their helpers: one launch, so the helpers are dispatched with (for launches with more
     // searches than CUs: right behind) the searches they serve — a helper kernel of its own on a second stream now and then shared a
     // hardware queue with the launch stream and started when the searches were through (one step in a hundred without helpers).
-    if ((int)blockIdx.x >= A.n_searches) {  // (uniform over the workgroup)
+    // (bk_helpers_first of the helpers come in front of the searches: a launch of more searches than CUs, whose finished searches hold
+    // their CUs while they wait for predecessors, leaves the helpers behind the searches no CU until the step is nearly over)
+    if ((int)blockIdx.x < A.bk_helpers_first || (int)blockIdx.x >= A.bk_helpers_first + A.n_searches) {  // (uniform over the workgroup)
         bulk_helper_body<CHECKER>(A);
         return;
     }

@@ -134,7 +134,8 @@ __device__ __forceinline__ void search_prologue(const KernelArgs& A, Ctx& X, LDS
     const int tid = threadIdx.x;
     const int lane = tid & (PDMPC_WAVE - 1);
     const int wave = uni_i(tid >> 6);
-    const int slot = A.first + (A.reverse_dispatch ? A.n_searches - 1 - (int)blockIdx.x : (int)blockIdx.x);
+    const int blk = (int)blockIdx.x - A.bk_helpers_first;  // (helper workgroups in front: bulk_body)
+    const int slot = A.first + (A.reverse_dispatch ? A.n_searches - 1 - blk : blk);
     const int Hp = A.Hp;
     const int n = A.n_trims;
     const int nw = A.n_words;

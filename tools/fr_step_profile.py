@@ -4,7 +4,7 @@ vehicle's areas went out; PROFILE_ROUNDS=1: the round sizes of the heaviest sear
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "p-dmpc_amd"), os.path.join(ROOT, "tests")]
-os.environ["PDMPC_TUNING"] = ",".join(x for x in (os.environ.get("PDMPC_TUNING", ""), "debug_tail=1") if x)
+os.environ["PDMPC_TUNING"] = ",".join(x for x in (os.environ.get("PDMPC_TUNING", ""), "debug_tail=2" if os.environ.get("PROFILE_SEATS") else "debug_tail=1") if x)
 import numpy as np
 import bench
 class A: pass
@@ -25,8 +25,8 @@ for b, prob in enumerate(probs):
     print("step", b, "kernel ms %.3f" % st["kernel_ms"], "levels", len(prob["level_sizes"]))
     dc = h.debug_counters()
     if dc[13]:
-        print("   helpers: %d tiles, per tile: claim -> soup %.1f us, records %.1f us, checks %.1f us, verdicts + report %.1f us; idle in all %.0f us; shared rounds %d" % (
-            dc[13], dc[9] / 100.0 / dc[13], dc[10] / 100.0 / dc[13], dc[11] / 100.0 / dc[13], dc[12] / 100.0 / dc[13], dc[8] / 100.0, dc[4]))
+        print("   helpers: %d tiles, per tile: claim -> soup %.1f us, records %.1f us, checks %.1f us, verdicts + report %.1f us; idle in all %.0f us; shared rounds %d; lifetimes in all %.0f us" % (
+            dc[13], dc[9] / 100.0 / dc[13], dc[10] / 100.0 / dc[13], dc[11] / 100.0 / dc[13], dc[12] / 100.0 / dc[13], dc[8] / 100.0, dc[4], dc[7] / 100.0))
     if dc[15]:
         print("   arrivals: %d of %d (step, predecessor) areas differ from the expected ones" % (dc[14], dc[15]))
     rows = []
@@ -49,6 +49,13 @@ for b, prob in enumerate(probs):
             la = (T[v][14][7] - origin) / 100.0 if T[v][14][7] > 0 else 0.0
             print("   chain veh %2d level %2d preds %2d | busy %4.0f us | areas out %4.0f us (hop %4.0f) | end %4.0f us | last arrival into the running search %4.0f us at round %2d of %2d | %2d verifications %3.0f us (copy %.0f re-check %.0f parked %.0f candidates %.0f record+flag %.0f; of the re-check: gathering %.0f)" % (
                 v, prob["levels"][v], len(pr), T[v][14][0] / 100.0 + T[v][15][0] / 100.0 + T[v][15][2] / 100.0, pub[v], pub[v] - last, end[v], la, int(T[v][14][6]), int(T[v][16][0]), int(T[v][16][6]), T[v][15][1] / 100.0, T[v][13][0] / 100.0, T[v][13][1] / 100.0, T[v][13][2] / 100.0, T[v][13][3] / 100.0, T[v][13][4] / 100.0, T[v][13][5] / 100.0))
+    if os.environ.get("PROFILE_SEATS"):  # the P1 passes of the step's largest search by the number of seated helpers
+        v = max(range(len(recs)), key=lambda i: np.asarray(recs[i]["path_nodes"])[16][1])
+        t = np.asarray(recs[v]["path_nodes"])
+        for bkt, name in enumerate(("not shared", "1-7 seats", "8-31 seats", "32-64 seats")):
+            n = t[11][bkt]
+            if n:
+                print("   veh %d P1 %-11s: %4d rounds, %6.1f us each, %6.0f entries of which the owner checks %5.0f" % (v, name, n, t[11][4 + bkt] / 100.0 / n, t[12][bkt] / n, t[12][4 + bkt] / n))
     top = int(os.environ.get("PROFILE_TOP", "8"))
     for r in sorted(rows, reverse=True)[:top]:
         print("   total %.0f us veh %d level %d popped %d processed %d nodes %d rounds %d | work %.0f arrival %.0f select %.0f wait %.0f us | preds %d | prologue %.0f check %.0f verdict %.0f expand %.0f phaseB %.0f refill %.0f us" % r)
