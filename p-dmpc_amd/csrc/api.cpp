@@ -148,6 +148,7 @@ struct Tuning {
     int fast_arrival = 1;   // finished searches check arrivals against their plan's path first and publish early (A/B switch)
     int helpers = -1;       // helper workgroups of a launch with at most one search per CU (-1: by launch size, 0: none)
     int helpers_oversub = -1;  // ... of a launch with more searches than CUs (-1: 200 up to two searches per CU, else none)
+    int seat_nodes = 256;   // a search may hold its share of the launch's helpers (helpers / searches) per this many nodes it has processed
     int helpers_first = -1; // ... of them dispatched in front of the searches (-1: half the CUs when most searches of the launch have predecessors)
     int speculate = 1;      // 0: every search waits for all its predecessors before it starts
     int waves = PDMPC_MAX_WAVES;  // wavefronts per workgroup (4 .. PDMPC_MAX_WAVES)
@@ -166,7 +167,7 @@ bool parse_tuning(const char* text, Tuning& T, std::string& err) {
     struct Key { const char* name; int* dst; };
     int spin = (int)T.spin_limit;
     const Key keys[] = {{"round0", &T.round0}, {"round", &T.round}, {"ramp", &T.ramp}, {"ready", &T.ready}, {"share_min", &T.share_min}, {"own_div", &T.own_div},
-                        {"tile", &T.tile}, {"mid_min", &T.mid_min}, {"mid_fill", &T.mid_fill}, {"tentative", &T.tentative}, {"fast_arrival", &T.fast_arrival}, {"helpers_first", &T.helpers_first},
+                        {"tile", &T.tile}, {"mid_min", &T.mid_min}, {"mid_fill", &T.mid_fill}, {"tentative", &T.tentative}, {"fast_arrival", &T.fast_arrival}, {"helpers_first", &T.helpers_first}, {"seat_nodes", &T.seat_nodes},
                         {"helpers", &T.helpers}, {"helpers_oversub", &T.helpers_oversub}, {"speculate", &T.speculate}, {"waves", &T.waves}, {"spin_limit", &spin},
                         {"force_tie", &T.force_tie}, {"reverse_dispatch", &T.reverse_dispatch}, {"debug_tail", &T.debug_tail}, {"debug_lds", &T.debug_lds},
                         {"debug_host", &T.debug_host}, {"debug_progress", &T.debug_progress}};
@@ -716,6 +717,7 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     a.bk_tile = T.tile > 0 ? T.tile : 256;
     a.bk_tentative = T.tentative;
     a.bk_fast_arrival = T.fast_arrival;
+    a.bk_seat_nodes = std::max(1, T.seat_nodes);
     a.bk_force_tie = T.force_tie;
     a.bk_post = h->d_bk_post.p;
     a.help_board = h->d_help_board.p;

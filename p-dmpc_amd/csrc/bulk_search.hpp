@@ -2238,6 +2238,10 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         dbg[6] = (double)sh[BK_ARRIVALS];  // verification events
         dbg[7] = (double)(__builtin_amdgcn_s_memrealtime() - tk[TK_START]);
         for (int i = 0; i < 6; ++i) X.O->path_nodes[PDMPC_HP_MAX - 3][i] = (double)tk2[i];
+        if (A.n_helpers > 0) {  // (the seats this search has given out)
+            const unsigned long long sw = __hip_atomic_load(board + PDMPC_HB_SEATS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            X.O->path_nodes[PDMPC_HP_MAX - 3][7] = (double)(sw & 0xffffffffull);
+        }
         X.O->path_nodes[PDMPC_HP_MAX - 2][0] = (double)(tk[TK_START] - X.rt_kernel_start);
         X.O->path_nodes[PDMPC_HP_MAX - 2][1] = (double)tk[tk_p1];
         X.O->path_nodes[PDMPC_HP_MAX - 2][2] = (double)tk[tk_p2];
@@ -2350,7 +2354,7 @@ __device__ __forceinline__ void bulk_helper_body(const KernelArgs& A) {
                     // (a seat is kept until the search ends, so a search only gets the seats its work so far entitles it to: its share of the
                     // launch's helpers per 256 nodes processed — plenty of helpers per search (C2): every seat at once; a fifth of a helper
                     // per search (C4): a medium search holds one or two, the 10^5-node search of the step collects all 64 as it grows)
-                    uint32_t allowed = 1u + (uint32_t)((wt * (unsigned long long)A.n_helpers) / ((unsigned long long)n_s * 256ull));
+                    uint32_t allowed = 1u + (uint32_t)((wt * (unsigned long long)A.n_helpers) / ((unsigned long long)n_s * (unsigned long long)A.bk_seat_nodes));
                     if (idle >= 8u) allowed = (uint32_t)PDMPC_HB_SEATS_MAX;  // (this helper has found nothing it was entitled to for a while: better seated than idle)
                     allowed = allowed < (uint32_t)PDMPC_HB_SEATS_MAX ? allowed : (uint32_t)PDMPC_HB_SEATS_MAX;
                     const bool cand = k < n_s && want == (unsigned long long)A.launch_id && cnt < allowed;

@@ -162,6 +162,7 @@ struct KernelArgs {
     int32_t bk_round;       // ... and the most any round takes
     int32_t bk_ramp;        // a round of a search that is no longer young grows by 1 / bk_ramp of the nodes processed so far
     int32_t bk_helpers_first;  // helper workgroups dispatched in front of the searches (the others follow them)
+    int32_t bk_seat_nodes;     // a search is entitled to its share of the launch's helpers per this many nodes processed (bulk_helper_body)
     int32_t bk_tentative;   // 1: predecessors that are still planning have their expected areas (the ones they publish when exhausted) in their soup slots
     int32_t bk_tile;        // the most entries of a shared round one seat takes (what a helper stages in LDS; at most 768)
     int32_t bk_mid_min;     // a far list longer than this is not scanned by every refill of near: a band of its smallest keys is moved to mid first

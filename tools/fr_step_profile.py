@@ -56,6 +56,11 @@ for b, prob in enumerate(probs):
             n = t[11][bkt]
             if n:
                 print("   veh %d P1 %-11s: %4d rounds, %6.1f us each, %6.0f entries of which the owner checks %5.0f" % (v, name, n, t[11][4 + bkt] / 100.0 / n, t[12][bkt] / n, t[12][4 + bkt] / n))
+    if os.environ.get("PROFILE_SEATS"):
+        held = sorted(((int(np.asarray(r["path_nodes"])[13][7]), v) for v, r in enumerate(recs)), reverse=True)
+        print("   seats given out: %d searches, %d seats; the largest holders (seats: vehicle, nodes processed, us waiting): %s" % (
+            sum(1 for s_, _ in held if s_), sum(s_ for s_, _ in held),
+            ", ".join("%d: veh %d %d %.0f" % (s_, v, int(np.asarray(recs[v]["path_nodes"])[16][1]), np.asarray(recs[v]["path_nodes"])[15][3] / 100.0) for s_, v in held[:14] if s_)))
     top = int(os.environ.get("PROFILE_TOP", "8"))
     for r in sorted(rows, reverse=True)[:top]:
         print("   total %.0f us veh %d level %d popped %d processed %d nodes %d rounds %d | work %.0f arrival %.0f select %.0f wait %.0f us | preds %d | prologue %.0f check %.0f verdict %.0f expand %.0f phaseB %.0f refill %.0f us" % r)
