@@ -300,8 +300,22 @@ inline hipError_t sync_stream(pdmpc_handle* h) {
 // flags, the histogram / goal list / expansion lists, 2 KB of small tables, the areas of the published path, validity bytes, then
 // as many node records as fit.
 bool layout_bulk(pdmpc_handle* h, size_t budget, int n_waves, int areas, int soup_cap, LdsLayout& L, uint32_t& nv, uint32_t& nl, uint32_t ready_cap) {
-    const uint32_t threads = (uint32_t)n_waves * PDMPC_WAVE;
-    uint32_t off = 0;
+    (void)n_waves;
+    if (ready_cap > PDMPC_LK_READY_CAP) return false;
+    // the regions of fixed size at the kernel's compile-time offsets (pdmpc_device.h: PDMPC_LK_*) ...
+    L.ref = PDMPC_LK_REF;
+    L.shape = PDMPC_LK_SHAPE;
+    L.path = PDMPC_LK_PATH;
+    L.cand = PDMPC_LK_CAND;
+    L.expand = PDMPC_LK_EXPAND;
+    L.bk_near_key = PDMPC_LK_NEAR_KEY;
+    L.bk_near_id = PDMPC_LK_NEAR_ID;
+    L.bk_ready = PDMPC_LK_READY;
+    L.bk_hist = PDMPC_LK_HIST;
+    L.bk_misc = PDMPC_LK_MISC;
+    L.bk_pshape = PDMPC_LK_PSHAPE;
+    // ... the automaton's tables and the soup behind them
+    uint32_t off = PDMPC_LK_FIXED_END;
     L.mask = off;
     off = align16(off + (uint32_t)h->mask_bytes);
     L.man_index = off;
@@ -310,30 +324,8 @@ bool layout_bulk(pdmpc_handle* h, size_t budget, int n_waves, int areas, int sou
     off = align16(off + (uint32_t)(h->n_man * sizeof(DevManPose)));
     L.area = off;
     if (areas) off = align16(off + (uint32_t)(h->n_man * 3 * PDMPC_VMAX * 16));
-    L.ref = off;
-    off += 3 * PDMPC_HP_MAX * 8;
-    L.shape = off;
-    off += (uint32_t)n_waves * (2 * PDMPC_VMAX + 1) * 16;
-    L.path = off;
-    off += align16((PDMPC_HP_MAX + 2) * 4 + 2 * (PDMPC_HP_MAX + 1) * 4 + PDMPC_SH_WORDS * 4 + PDMPC_HP_MAX * 4);
     L.soup = off;
     off = align16(off + (uint32_t)std::max(soup_cap, 1) * 16);
-    L.cand = off;
-    off += align16(12u * threads);
-    L.expand = off;
-    off += (2 * PDMPC_HP_MAX * PDMPC_HP_MAX) * 8 + 16 * 16;
-    L.bk_near_key = off;
-    off += align16(PDMPC_BK_PER * threads * 8u);
-    L.bk_near_id = off;
-    off += align16(PDMPC_BK_PER * threads * 4u);
-    L.bk_ready = off;
-    off += align16(ready_cap * 8u);
-    L.bk_hist = off;
-    off += 3072u * 4u;
-    L.bk_misc = off;
-    off += 2048u;
-    L.bk_pshape = off;
-    off += align16((uint32_t)h->cfg.Hp * PDMPC_VMAX * 16u + PDMPC_HP_MAX * 4u + PDMPC_HP_MAX * 8u);
     L.tree16 = L.bk_hist;  // (the sampled optimizer's region: not part of this layout)
     const uint32_t min_nodes = 64 * (uint32_t)sizeof(NodeRec) + 1024;
     if ((size_t)off + min_nodes + 256 > budget) return false;

@@ -472,7 +472,7 @@ __device__ __forceinline__ void bk_write_record(const KernelArgs& A, Ctx& X, uin
         }
         return;
     }
-    lds_d2* pshape = (lds_d2*)(X.lsm + A.lds.bk_pshape);
+    lds_d2* pshape = (lds_d2*)(X.lsm + PDMPC_LK_PSHAPE);
     lds_u32* pcols = (lds_u32*)(pshape + Hp * PDMPC_VMAX);
     if (again) {  // as the prologue left it: zeros, y_predicted NaN (ControlResultsInfo.m:40)
         double* od = (double*)O;
@@ -949,14 +949,14 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
     const uint32_t TILE = (uint32_t)A.bk_tile;  // entries of a tile of a shared round (what a helper workgroup claims at a time)
 
     // ---- LDS carve of the bulk region
-    lds_f64* near_key = (lds_f64*)(X.lsm + A.lds.bk_near_key);
-    lds_u32* near_id = (lds_u32*)(X.lsm + A.lds.bk_near_id);
-    lds_u32* ready = (lds_u32*)(X.lsm + A.lds.bk_ready);
+    lds_f64* near_key = (lds_f64*)(X.lsm + PDMPC_LK_NEAR_KEY);
+    lds_u32* near_id = (lds_u32*)(X.lsm + PDMPC_LK_NEAR_ID);
+    lds_u32* ready = (lds_u32*)(X.lsm + PDMPC_LK_READY);
     volatile lds_u32* r_flag = (volatile lds_u32*)(ready + RC);
-    lds_u32* hist = (lds_u32*)(X.lsm + A.lds.bk_hist);      // [3072]: refill histogram [2048] | goal list [1024], expansion groups [1024], their children's offsets [1024]
+    lds_u32* hist = (lds_u32*)(X.lsm + PDMPC_LK_HIST);      // [3072]: refill histogram [2048] | goal list [1024], expansion groups [1024], their children's offsets [1024]
     lds_u32* vlist = hist + 1024;
     lds_u32* voffs = hist + 2048;
-    lds_u32* gp_path = (lds_u32*)(X.lsm + A.lds.bk_misc);    // [32] path of the best goal candidate
+    lds_u32* gp_path = (lds_u32*)(X.lsm + PDMPC_LK_MISC);    // [32] path of the best goal candidate
     lds_f64* gp_mp = (lds_f64*)(gp_path + 32);                // [HP_MAX + 1] largest key of that path below depth d
     lds_vu64* wsum64 = (lds_vu64*)(gp_mp + 32);                // [32] scan partials
     volatile lds_u32* wsum = (volatile lds_u32*)(wsum64 + 32); // [32] fr_partition's per-wave counts
@@ -1080,7 +1080,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         for (int i = 2; i < 12; ++i) tk[i] = 0ull;
         tk[TK_MARK] = tk[TK_START] = __builtin_amdgcn_s_memrealtime();
     }
-    lds_u64s* chg = (lds_u64s*)((lds_u32*)((lds_d2*)(X.lsm + A.lds.bk_pshape) + Hp * PDMPC_VMAX) + PDMPC_HP_MAX);  // [HP_MAX] areas that differ from the expected ones (bk_incorporate_body)
+    lds_u64s* chg = (lds_u64s*)((lds_u32*)((lds_d2*)(X.lsm + PDMPC_LK_PSHAPE) + Hp * PDMPC_VMAX) + PDMPC_HP_MAX);  // [HP_MAX] areas that differ from the expected ones (bk_incorporate_body)
     if (tid < PDMPC_HP_MAX) chg[tid] = 0ull;  // (read behind the barriers of the first round)
     lds_vu64* tk2 = (lds_vu64*)(gp_path + 242);  // [7] (diagnostics) the arrival handling in detail: poll + copy, re-check, parked nodes, bookkeeping + candidates, record + flag of a finished search
     if (ticking)
@@ -1868,7 +1868,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 __syncthreads();  // (the path's areas in LDS: written by the first wave, which is also their reader; the barrier is for the bookkeeping below)
             }
             if (wave == 0 && sh[BK_PUBLISHED] == 0u)
-                bk_wait_done(A.done_flag, P.pred, P.out, A.epoch, (uint32_t)slot, P.l_soup, P.l_soff, P.l_lit, (lds_d2*)(X.lsm + A.lds.bk_pshape), sh, Hp, P.n_pred, best != 0u,
+                bk_wait_done(A.done_flag, P.pred, P.out, A.epoch, (uint32_t)slot, P.l_soup, P.l_soff, P.l_lit, (lds_d2*)(X.lsm + PDMPC_LK_PSHAPE), sh, Hp, P.n_pred, best != 0u,
                              ticking ? (lds_vu64*)(tk + tk_pub) : (lds_vu64*)nullptr, sh_load64(sh, BK_FD_LO), 0u, CHECKER == PDMPC_CHECK_SAT, lane);
             __syncthreads();
             BK_TICK2(4)
@@ -1883,7 +1883,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             // hence the counts and ids, as they are, and the result goes out as soon as the last predecessor has been looked at.
             if (!pb_valid && !dep_timeout) {
                 __syncthreads();
-                R = fr_phase_b<NW>(A, X, F, EE, best, ref_ids, (LDS_AS unsigned char*)(X.lsm + A.lds.cand), F.near_key, F.near_id, gp_path);
+                R = fr_phase_b<NW>(A, X, F, EE, best, ref_ids, (LDS_AS unsigned char*)(X.lsm + PDMPC_LK_CAND), F.near_key, F.near_id, gp_path);
                 pb_valid = true;
                 BK_TICK(tk_pb)
                 const uint32_t pflags = sh[FR_FLAGS];
@@ -1915,7 +1915,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             }
             if (A.bk_fast_arrival && !dep_timeout) {
                 if (wave == 0)
-                    bk_wait_done(A.done_flag, P.pred, P.out, A.epoch, (uint32_t)slot, P.l_soup, P.l_soff, P.l_lit, (lds_d2*)(X.lsm + A.lds.bk_pshape), sh, Hp, P.n_pred, best != 0u,
+                    bk_wait_done(A.done_flag, P.pred, P.out, A.epoch, (uint32_t)slot, P.l_soup, P.l_soff, P.l_lit, (lds_d2*)(X.lsm + PDMPC_LK_PSHAPE), sh, Hp, P.n_pred, best != 0u,
                                  ticking ? (lds_vu64*)(tk + tk_pub) : (lds_vu64*)nullptr, 0ull, 4096u, CHECKER == PDMPC_CHECK_SAT, lane);
                 __syncthreads();
                 if (ticking && sh[BK_WAITRES] == 1u) {  // (diagnostics: an arrival crossed the finished plan's path)
@@ -2286,15 +2286,15 @@ __device__ __forceinline__ void bulk_helper_body(const KernelArgs& A) {
     const int Hp = A.Hp, n_s = A.n_searches;
     const uint32_t CAP = (uint32_t)A.bk_tile;  // records of a range (what fits the staging area)
     // the owners' carve (search_prologue): only the regions a check item reads are filled
-    lds_u32* l_path = (lds_u32*)(lsm + A.lds.path);
+    lds_u32* l_path = (lds_u32*)(lsm + PDMPC_LK_PATH);
     lds_i32* l_soff = (lds_i32*)(l_path + PDMPC_HP_MAX + 2);
     lds_i32* l_hoff = l_soff + PDMPC_HP_MAX + 1;
     volatile lds_u32* hs = (volatile lds_u32*)(l_hoff + PDMPC_HP_MAX + 1);
     lds_i32* l_lit = (lds_i32*)(hs + SH_WORDS);
     lds_d2* l_soup = (lds_d2*)(lsm + A.lds.soup);
-    lds_d2* t_rec = (lds_d2*)(lsm + A.lds.bk_near_key);              // [bk_tile][3] the range's posted records
-    volatile lds_u32* t_flag = (volatile lds_u32*)(lsm + A.lds.bk_ready);  // [bk_tile] collision flags
-    lds_u32* chm = (lds_u32*)(lsm + A.lds.bk_misc) + 192;
+    lds_d2* t_rec = (lds_d2*)(lsm + PDMPC_LK_NEAR_KEY);              // [bk_tile][3] the range's posted records
+    volatile lds_u32* t_flag = (volatile lds_u32*)(lsm + PDMPC_LK_READY);  // [bk_tile] collision flags
+    lds_u32* chm = (lds_u32*)(lsm + PDMPC_LK_MISC) + 192;
     BkCheck CK;
     CK.l_area = (const lds_d2*)(lsm + A.lds.area);
     CK.g_area = (const d2*)A.man_area;
@@ -2572,7 +2572,7 @@ __device__ __forceinline__ void bulk_body(const KernelArgs& A) {
     search_prologue(A, X, (LDS_AS unsigned char*)smem);
     X.rt_kernel_start = rt0;
     const int wave = X.wave;
-    lds_u32* ref_ids = (lds_u32*)(X.lsm + A.lds.bk_misc) + 224;  // behind the chunk table (nothing else uses those words)
+    lds_u32* ref_ids = (lds_u32*)(X.lsm + PDMPC_LK_MISC) + 224;  // behind the chunk table (nothing else uses those words)
     const bool tie = bulk_search<NW, CHECKER>(A, X, ref_ids);
     (void)tie;  // (equal keys are resolved inside the search: bk_replay)
     __syncthreads();

@@ -84,6 +84,26 @@ struct LdsLayout {
     uint32_t bk_pshape;                    // double2[Hp][VMAX] + uint32[HP_MAX] + uint64[HP_MAX]: the areas along the path of the record written last and their column counts (what an arrival is checked against first); per step the predecessors whose areas differ from the expected ones
 };
 
+// The regions of the graph search's layout whose sizes do not depend on the automaton or on the obstacles come first, at offsets that
+// are compile-time constants (sized for PDMPC_MAX_WAVES wavefronts and the largest ready list): the kernel addresses them with
+// immediates instead of holding two dozen LDS pointers in scalar registers it does not have (layout_bulk fills LdsLayout with the
+// same numbers; the automaton's tables, the soup, the validity bytes and the nodes follow at run-time offsets).
+#define PDMPC_LK_ALIGN16(x) (((x) + 15u) & ~15u)
+#define PDMPC_LK_THREADS ((uint32_t)PDMPC_MAX_WAVES * PDMPC_WAVE)
+#define PDMPC_LK_READY_CAP 2048u
+#define PDMPC_LK_REF 0u
+#define PDMPC_LK_SHAPE (PDMPC_LK_REF + 3u * PDMPC_HP_MAX * 8u)
+#define PDMPC_LK_PATH (PDMPC_LK_SHAPE + (uint32_t)PDMPC_MAX_WAVES * (2u * PDMPC_VMAX + 1u) * 16u)
+#define PDMPC_LK_CAND (PDMPC_LK_PATH + PDMPC_LK_ALIGN16((PDMPC_HP_MAX + 2u) * 4u + 2u * (PDMPC_HP_MAX + 1u) * 4u + PDMPC_SH_WORDS * 4u + PDMPC_HP_MAX * 4u))
+#define PDMPC_LK_EXPAND (PDMPC_LK_CAND + PDMPC_LK_ALIGN16(12u * PDMPC_LK_THREADS))
+#define PDMPC_LK_NEAR_KEY (PDMPC_LK_EXPAND + (2u * PDMPC_HP_MAX * PDMPC_HP_MAX) * 8u + 16u * 16u)
+#define PDMPC_LK_NEAR_ID (PDMPC_LK_NEAR_KEY + PDMPC_LK_ALIGN16(PDMPC_BK_PER * PDMPC_LK_THREADS * 8u))
+#define PDMPC_LK_READY (PDMPC_LK_NEAR_ID + PDMPC_LK_ALIGN16(PDMPC_BK_PER * PDMPC_LK_THREADS * 4u))
+#define PDMPC_LK_HIST (PDMPC_LK_READY + PDMPC_LK_READY_CAP * 8u)
+#define PDMPC_LK_MISC (PDMPC_LK_HIST + 3072u * 4u)
+#define PDMPC_LK_PSHAPE (PDMPC_LK_MISC + 2048u)
+#define PDMPC_LK_FIXED_END (PDMPC_LK_PSHAPE + PDMPC_LK_ALIGN16(PDMPC_HP_MAX * PDMPC_VMAX * 16u + PDMPC_HP_MAX * 4u + PDMPC_HP_MAX * 8u))
+
 struct NodeArena {  // HBM arrays, per-vehicle stride = max_nodes entries
     NodeRec* nodes;
     double* key;       // open-list key f = g + h of node i (GraphSearch.m:100-102)

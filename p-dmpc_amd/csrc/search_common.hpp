@@ -145,10 +145,10 @@ __device__ __forceinline__ void search_prologue(const KernelArgs& A, Ctx& X, LDS
     lds_mask64* l_mask = (lds_mask64*)(lsm + A.lds.mask);
     lds_i16* l_mi = (lds_i16*)(lsm + A.lds.man_index);
     lds_pose* l_pose = (lds_pose*)(lsm + A.lds.pose);
-    lds_f64* l_rx = (lds_f64*)(lsm + A.lds.ref);
+    lds_f64* l_rx = (lds_f64*)(lsm + PDMPC_LK_REF);
     lds_f64* l_ry = l_rx + PDMPC_HP_MAX;
     lds_f64* l_dtv = l_ry + PDMPC_HP_MAX;
-    lds_u32* l_path = (lds_u32*)(lsm + A.lds.path);
+    lds_u32* l_path = (lds_u32*)(lsm + PDMPC_LK_PATH);
     lds_i32* l_soff = (lds_i32*)(l_path + PDMPC_HP_MAX + 2);  // soup offsets [Hp+1], hdv offsets [Hp+1]
     lds_i32* l_hoff = l_soff + PDMPC_HP_MAX + 1;
     volatile lds_u32* l_shared = (volatile lds_u32*)(l_hoff + PDMPC_HP_MAX + 1);
@@ -157,7 +157,7 @@ __device__ __forceinline__ void search_prologue(const KernelArgs& A, Ctx& X, LDS
     VState VS;
     VS.l = (volatile lds_u8*)(lsm + A.lds.vstate);
     VS.NV = (uint32_t)A.NV;
-    lds_f64* l_dcum = (lds_f64*)(lsm + A.lds.expand);             // [HP_MAX][HP_MAX] cumulative dt*v_ref per (k_exp, t)
+    lds_f64* l_dcum = (lds_f64*)(lsm + PDMPC_LK_EXPAND);             // [HP_MAX][HP_MAX] cumulative dt*v_ref per (k_exp, t)
     lds_f64* l_term = l_dcum + PDMPC_HP_MAX * PDMPC_HP_MAX;       // [16 children][HP_MAX] cost-to-go terms
     lds_d2* l_chxy = (lds_d2*)(l_term + 16 * PDMPC_HP_MAX);       // [16] child positions
 
@@ -186,13 +186,13 @@ __device__ __forceinline__ void search_prologue(const KernelArgs& A, Ctx& X, LDS
     C.areas_in_lds = A.areas_in_lds;
     C.Hp = Hp;
     C.checker = A.checker;
-    C.sh = (lds_d2*)(lsm + A.lds.shape) + wave * (2 * PDMPC_VMAX + 1);
+    C.sh = (lds_d2*)(lsm + PDMPC_LK_SHAPE) + wave * (2 * PDMPC_VMAX + 1);
     C.tally = (LDS_AS unsigned long long*)(C.sh + 2 * PDMPC_VMAX);  // [0] edge checks, [1] segment pairs (this wave)
     if (lane == 0) {
         C.tally[0] = 0;
         C.tally[1] = 0;
     }
-    C.cand = (lds_u32*)(lsm + A.lds.cand) + (size_t)wave * A.cand_cap;
+    C.cand = (lds_u32*)(lsm + PDMPC_LK_CAND) + (size_t)wave * A.cand_cap;
 
     pdmpc_vehicle_out* __restrict__ O = A.out + slot;
 
