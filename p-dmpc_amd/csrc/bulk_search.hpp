@@ -1086,13 +1086,24 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
     if (ticking)
         for (int i = 0; i < 7; ++i) tk2[i] = 0ull;
 #define BK_TICK2(i)                                                        \
-    if (ticking) {                                                         \
+    if (ticking && A.debug_tail != 3) {                                                         \
         const unsigned long long now__ = __builtin_amdgcn_s_memrealtime(); \
         tk2[i] += now__ - tk2[6];                                          \
         tk2[6] = now__;                                                    \
     }
 #define BK_MARK2 \
-    if (ticking) tk2[6] = __builtin_amdgcn_s_memrealtime();
+    if (ticking && A.debug_tail != 3) tk2[6] = __builtin_amdgcn_s_memrealtime();
+    // (debug_tail=3: the same six counters take a round's passes apart instead: the share decision, the check items, the sincos items, P1's
+    // last barrier, the boundary up to the selection, the selection)
+    const bool ticking3 = ticking && A.debug_tail == 3;
+#define BK_TICK3(i)                                                        \
+    if (ticking3) {                                                        \
+        const unsigned long long now__ = __builtin_amdgcn_s_memrealtime(); \
+        tk2[i] += now__ - tk2[6];                                          \
+        tk2[6] = now__;                                                    \
+    }
+#define BK_MARK3 \
+    if (ticking3) tk2[6] = __builtin_amdgcn_s_memrealtime();
 #define BK_TICK(acc)                                                       \
     if (ticking) {                                                         \
         const unsigned long long now__ = __builtin_amdgcn_s_memrealtime(); \
@@ -1224,6 +1235,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             // the round's number in its own done word.  Nobody claims anything: no compare-and-swap, and every word that is polled has
             // exactly one poller (rounds 3-4 let all helpers compete for tiles on one ticket word per search: a tile cost 15 us of which
             // the checks were 5, and more helpers made every search of the launch slower, profiles/r05_helper_sweep.txt).
+            BK_MARK3
             const BkTreeSrc tsrc{&S, ready};
             const unsigned long long pend_now = A.bk_tentative ? sh_load64(sh, SH_PEND_LO) : 0ull;  // (their slots hold expected areas)
             bool share = A.n_helpers > 0 && Rn >= (uint32_t)A.bk_share_min && P.n_pred <= 64;
@@ -1283,9 +1295,11 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 }
             }
             {
+                BK_TICK3(0)
                 const uint32_t Rr = own_n;
                 const int ls = bk_chunk_shift(chm, Rr ? Rr : 1u, (uint32_t)bd);
                 bk_check_items<CHECKER>(CK, tsrc, r_flag, 0u, Rr, ls, chm[ls], pend_now, tid, bd);
+                BK_TICK3(1)
                 for (uint32_t r = (uint32_t)(bd - 1 - tid); r < Rn; r += (uint32_t)bd) {  // (from the last thread down: the first waves carry the first chunks)
                     const uint32_t i0 = ready[r] - 1u;
                     uint32_t parent, packed;
@@ -1297,6 +1311,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                         node_store_cs(S, i0, cs, sn);
                     }
                 }
+                BK_TICK3(2)
             }
             if (share) {
                 if (wave == 0) {  // wait for the seated helpers: every lane on its helper's done word
@@ -1340,6 +1355,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 r1[bkt] += (double)Rn;
                 r1[4 + bkt] += (double)own_n;
             }
+            BK_TICK3(3)
             BK_TICK(tk_p1)
 
             BK_OPAQUE_TID
@@ -1733,6 +1749,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         }
         const bool tie_mode = sh[BK_TIEMODE] != 0u;
         BK_TICK(tk_arrival)
+        BK_MARK3
 
         // the relevance tables follow the best goal candidate
         const uint32_t best = sh[FR_BEST_ID];
@@ -2097,6 +2114,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         BK_OPAQUE_TID
         // ---- this round's entries: the smallest keys of near.  Every thread holds BK_PER entries in registers.
         {
+            BK_TICK3(4)
             const double lo = sh_ld_d(sh, FR_NEAR_MIN);
             double hi = sh_ld_d(sh, FR_NEAR_MAX);
             double kk[BK_PER];
@@ -2189,6 +2207,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             if (n_drop) sh_add(sh, FR_DROPPED, n_drop);  // comes after the candidate: never popped
             Rn = n_rdy < RC ? n_rdy : RC;
             __syncthreads();  // the ready list and the compacted near are in place
+            BK_TICK3(5)
             BK_TICK(tk_select)
         }
     }

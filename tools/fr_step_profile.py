@@ -4,7 +4,7 @@ vehicle's areas went out; PROFILE_ROUNDS=1: the round sizes of the heaviest sear
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "p-dmpc_amd"), os.path.join(ROOT, "tests")]
-os.environ["PDMPC_TUNING"] = ",".join(x for x in (os.environ.get("PDMPC_TUNING", ""), "debug_tail=2" if os.environ.get("PROFILE_SEATS") else "debug_tail=1") if x)
+os.environ["PDMPC_TUNING"] = ",".join(x for x in (os.environ.get("PDMPC_TUNING", ""), "debug_tail=2" if os.environ.get("PROFILE_SEATS") else ("debug_tail=3" if os.environ.get("PROFILE_PASSES") else "debug_tail=1")) if x)
 import numpy as np
 import bench
 class A: pass
@@ -61,6 +61,11 @@ for b, prob in enumerate(probs):
         print("   seats given out: %d searches, %d seats; the largest holders (seats: vehicle, nodes processed, us waiting): %s" % (
             sum(1 for s_, _ in held if s_), sum(s_ for s_, _ in held),
             ", ".join("%d: veh %d %d %.0f" % (s_, v, int(np.asarray(recs[v]["path_nodes"])[16][1]), np.asarray(recs[v]["path_nodes"])[15][3] / 100.0) for s_, v in held[:14] if s_)))
+    if os.environ.get("PROFILE_PASSES"):  # a round's passes taken apart, per round, for every vehicle of the step (us)
+        for v in range(len(recs)):
+            t = np.asarray(recs[v]["path_nodes"]); n = max(1.0, t[16][0])
+            print("   veh %2d rounds %3d, per round: share decision %.2f check items %.2f sincos %.2f P1 barrier %.2f | boundary -> selection %.2f selection %.2f us" % (
+                v, int(t[16][0]), *[t[13][i] / 100.0 / n for i in range(6)]))
     top = int(os.environ.get("PROFILE_TOP", "8"))
     for r in sorted(rows, reverse=True)[:top]:
         print("   total %.0f us veh %d level %d popped %d processed %d nodes %d rounds %d | work %.0f arrival %.0f select %.0f wait %.0f us | preds %d | prologue %.0f check %.0f verdict %.0f expand %.0f phaseB %.0f refill %.0f us" % r)
