@@ -164,7 +164,7 @@ typedef struct {
  * measured defaults; ONE environment variable, read once in pdmpc_create, overrides them for benchmarking and tests:
  *     PDMPC_TUNING="key=value,key=value,..."
  * keys: round0 round ramp ready share_min own_div tile mid_min mid_fill (rounds and lists), tentative fast_arrival speculate helpers
- * helpers_oversub waves (A/B switches), force_tie reverse_dispatch spin_limit (testing), debug_tail debug_lds debug_host debug_progress
+ * helpers_oversub helpers_first seat_nodes waves (A/B switches), force_tie reverse_dispatch spin_limit (testing), debug_tail debug_lds debug_host debug_progress
  * (diagnostics); csrc/api.cpp: struct Tuning documents each.  No setting changes a result; an unknown key fails pdmpc_create. */
 
 /* ---- life cycle (replaces GraphSearch() construction in OptimizerInterface.get_optimizer, :26-27,

@@ -190,6 +190,20 @@ def test_config_c4_512_vehicles_hp10_colouring_levels():
     assert int(ctl.last_levels.max()) >= 3
 
 
+@pytest.mark.parametrize("tuning", ["helpers_first=0", "helpers_first=200,seat_nodes=16", "helpers_oversub=40,helpers_first=40,share_min=64"])
+def test_c4_with_the_helper_workgroups_in_other_places(tuning, monkeypatch):
+    """A launch of more searches than CUs puts half a chip's worth of helper workgroups in FRONT of the searches when most searches
+    have predecessors (api.cpp: launch_range, helpers_first) — the searches' workgroup indices then start behind them.  The same
+    closed loop with none in front, with all of them in front, and with a few that share small rounds: the oracle's records."""
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    monkeypatch.setenv("PDMPC_TUNING", tuning)
+    options = Config(scenario_type=ScenarioType.commonroad, amount=512, Hp=10, max_vehicles=512, max_nodes=1 << 15)
+    sc = commonroad_scenario(options, seed=3, tiles=26)
+    ctl = run_closed_loop(options, sc, "distance", boundary_provider(sc), 2, oracle_threads=os.cpu_count() or 1, priority_strategy="coloring")
+    assert int(ctl.last_levels.max()) >= 3
+
+
 def test_benchmarked_window_c4_steps_1_to_12():
     """bench.py --workload c4 records closed-loop steps 5-12 of seed 1 (26 tiles, 512 vehicles, Hp 10, colouring levels): the
     same closed loop from standstill through step 12, every step against the oracle."""

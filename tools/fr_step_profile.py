@@ -67,5 +67,7 @@ for b, prob in enumerate(probs):
             print("   veh %2d rounds %3d, per round: share decision %.2f check items %.2f sincos %.2f P1 barrier %.2f | boundary -> selection %.2f selection %.2f us" % (
                 v, int(t[16][0]), *[t[13][i] / 100.0 / n for i in range(6)]))
     top = int(os.environ.get("PROFILE_TOP", "8"))
+    org = min(np.asarray(r["path_nodes"])[15][7] for r in recs)
     for r in sorted(rows, reverse=True)[:top]:
+        print("   [workgroup started %5.0f us into the kernel]" % ((np.asarray(recs[r[1]]["path_nodes"])[15][7] - org) / 100.0), end="")
         print("   total %.0f us veh %d level %d popped %d processed %d nodes %d rounds %d | work %.0f arrival %.0f select %.0f wait %.0f us | preds %d | prologue %.0f check %.0f verdict %.0f expand %.0f phaseB %.0f refill %.0f us" % r)
