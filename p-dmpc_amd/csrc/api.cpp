@@ -147,7 +147,7 @@ struct Tuning {
     int tentative = 1;      // expected areas of predecessors that are still planning (A/B switch)
     int fast_arrival = 1;   // finished searches check arrivals against their plan's path first and publish early (A/B switch)
     int helpers = -1;       // helper workgroups of a launch with at most one search per CU (-1: by launch size, 0: none)
-    int helpers_oversub = -1;  // ... of a launch with more searches than CUs (-1: 200 up to two searches per CU, else none)
+    int helpers_oversub = -1;  // ... of a launch with more searches than CUs (-1: 200)
     int seat_nodes = 256;   // a search may hold its share of the launch's helpers (helpers / searches) per this many nodes it has processed
     int helpers_first = -1; // ... of them dispatched in front of the searches (-1: half the CUs when most searches of the launch have predecessors)
     int speculate = 1;      // 0: every search waits for all its predecessors before it starts
@@ -344,7 +344,7 @@ bool layout_bulk(pdmpc_handle* h, size_t budget, int n_waves, int areas, int sou
 // helper workgroups serve the launches that leave CUs idle (launch_range)
 bool bulk_has_helpers(const pdmpc_handle* h, int n_launch) {
     if (!h->tune.speculate || h->tune.helpers == 0) return false;
-    if (n_launch > h->n_cu) return n_launch <= 2 * h->n_cu && h->tune.helpers_oversub != 0;  // (the tail of a launch with up to two searches per CU)
+    if (n_launch > h->n_cu) return h->tune.helpers_oversub != 0;  // (the tail of a launch with more searches than CUs)
     return n_launch <= h->n_cu - 2;
 }
 
@@ -721,8 +721,9 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     a.launch_id = h->launch_serial;
     // Helper workgroups: the trailing workgroups of the launch, on the CUs it leaves idle, check tiles of the searches' large rounds.
     // A launch with more searches than CUs gets them for its tail, when CUs fall idle while a few long searches still run (measured on
-    // C4, 512 searches: none 25.6 steps/s, 32 helpers 41.5, 96: 42.8-45.9); five searches per CU: a helper only takes a CU away from a
-    // search (C5).  In the safe mode a launch gets none: they would sit where a slice's search could run.
+    // C4, 512 searches: none 25.6 steps/s, 32 helpers 41.5, 96: 42.8-45.9; C5, 1 280 searches: none 478 steps/s, 64 behind the searches 543,
+    // 200: 549, with rounds shared from 64 nodes on 560 — the last levels' searches, which run when the CUs fall idle, are the tail of
+    // the step).  In the safe mode a launch gets none: they would sit where a slice's search could run.
     a.n_searches = count;
     a.n_helpers = 0;
     if (helped) {
@@ -748,6 +749,7 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     a.bk_helpers_first = 0;
     if (count > h->n_cu && a.n_helpers > 0) {
         int want = T.helpers_first;
+        if (want < 0 && count > 2 * h->n_cu) want = 0;  // (five searches per CU, C5: the searches need every CU — 128 in front 331 steps/s, 32: 515, none: 560)
         if (want < 0) {
             int chained = 0;
             const DevVehicle* hv = h->banks[h->bank].h_veh + first;
@@ -758,8 +760,8 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     }
     // rounds are shared from 64 nodes on where helpers are plenty (C2: a dozen per search), from a few hundred on where there are
     // about as many helpers as searches or fewer (measured C3, 128 + 128: 64 -> 1 026 steps/s, 128-192 -> 1 070, 384 -> 986; C4, 512 + 96:
-    // 64 -> 65.5, 192 -> 67, 512 -> 69)
-    a.bk_share_min = T.share_min > 0 ? T.share_min : (a.n_helpers >= 4 * count ? 64 : (count <= h->n_cu ? 160 : 512));
+    // 64 -> 65.5, 192 -> 67, 512 -> 69; C5, 1 280 + 200 behind the searches, whose helpers only meet the medium searches of the tail: 32-128 -> 560)
+    a.bk_share_min = T.share_min > 0 ? T.share_min : (a.n_helpers >= 4 * count ? 64 : (count <= h->n_cu ? 160 : (count <= 2 * h->n_cu ? 512 : 64)));
     if (a.n_helpers > 0 && !h->boards_dirty) {
         // The boards stay closed between launches (a search closes every round it shares before it uses the verdicts, and a closed
         // ticket word offers nothing) and the count of finished searches runs on from launch to launch: nothing to clear -- two

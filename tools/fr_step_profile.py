@@ -13,10 +13,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "c3":
     args.vehicles = 128; args.workload = "c3"; args.max_levels = 2; args.priorities = "coloring"; args.max_nodes = 1 << 16
 if len(sys.argv) > 1 and sys.argv[1] == "c4":
     args.vehicles = 512; args.workload = "c4"; args.hp = 10; args.priorities = "coloring"; args.max_nodes = 1 << 16
+if len(sys.argv) > 1 and sys.argv[1] == "c5":
+    args.workload = "c5"; args.instances = 64; args.max_nodes = 1 << 15
 options, mpa, ctl = bench.build_world(args, 0)
 from pdmpc.optimizer import GraphSearchHip
 opt = GraphSearchHip(options); opt._ensure_mpa(mpa); h = opt.handle
-probs = bench.record_steps(options, mpa, ctl, opt, 20 if args.workload == "c2" else 4, 6 if args.workload != "c4" else 3)
+probs = bench.record_steps(options, mpa, ctl, opt, 20 if args.workload in ("c2", "c5") else 4, 6 if args.workload not in ("c4", "c5") else 3, explore_instances=64 if args.workload == "c5" else 0)
 for b, prob in enumerate(probs):
     fb = [f if f is not None else [] for f in prob["fallback"]]
     h.pack_step(prob["iters"], prob["preds"], fb)
