@@ -432,7 +432,7 @@ def main():
     achieved = (alg_bytes / max(n_launch, 1)) / ((kernel_ms / max(n_launch, 1)) * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     n_search = max(len(p["iters"]) for p in problems)
     # (api.cpp: launch_range -- helper workgroups on the CUs a launch of at most one search per CU leaves idle, 96 for up to two per CU)
-    wg_per_launch = n_search + (256 - n_search if n_search <= 254 else (200 if n_search <= 512 else 0))
+    wg_per_launch = n_search + (256 - n_search if n_search <= 254 else 200)  # (the searches and the helper workgroups of the launch: api.cpp, launch_range)
 
     # ---- the timed launches did the recorded work.  Their records are not fetched (no copies in the timed region), so: the device
     # counts every plan that ended with anything but OK / EXHAUSTED (overflow, time-out) since the reset in front of the timed loop,
