@@ -151,7 +151,7 @@ struct Tuning {
     int seat_nodes = 256;   // a search may hold its share of the launch's helpers (helpers / searches) per this many nodes it has processed
     int helpers_first = -1; // ... of them dispatched in front of the searches (-1: half the CUs when most searches of the launch have predecessors)
     int speculate = 1;      // 0: every search waits for all its predecessors before it starts
-    int waves = PDMPC_MAX_WAVES;  // wavefronts per workgroup (4 .. PDMPC_MAX_WAVES)
+    int waves = -1;         // wavefronts per workgroup (4 .. PDMPC_MAX_WAVES; -1: 16 for the InterX kernels — 12 for a launch of more than two searches per CU —, 12 for the separating-axis kernel)
     uint32_t spin_limit = 1u << 22;  // the watchdog's limit of polls / rounds (debugging: fail fast)
     int force_tie = 0;      // testing only: every search ends on the replay through the reference's binary heap (as if it had met equal keys)
     int reverse_dispatch = 0;  // testing only: workgroup b takes slot n - 1 - b (successors dispatched before their predecessors)
@@ -211,7 +211,7 @@ bool parse_tuning(const char* text, Tuning& T, std::string& err) {
     if (T.tile >= 0) T.tile = std::min(768, std::max(8, T.tile));
     T.mid_min = std::max(0, T.mid_min);
     T.mid_fill = std::max(256, T.mid_fill);
-    T.waves = std::min(PDMPC_MAX_WAVES, std::max(4, T.waves));
+    if (T.waves >= 0) T.waves = std::min(PDMPC_MAX_WAVES, std::max(4, T.waves));
     T.spin_limit = (uint32_t)std::max(1024, spin);
     return true;
 }
@@ -351,7 +351,10 @@ bool bulk_has_helpers(const pdmpc_handle* h, int n_launch) {
 int compute_lds_bulk(pdmpc_handle* h, int n_launch, int soup_cap) {
     // large rounds pay where helper workgroups share them; without helpers the LDS is better spent on node records
     h->bk_ready_launch = bulk_has_helpers(h, n_launch) ? h->tune.ready : std::max(256, h->tune.ready / 2);
-    const int waves = h->tune.waves;
+    // Sixteen wavefronts where the kernel's registers allow four per SIMD (measured against twelve: C2 +1.5 %, C3 +1.3 %, C4 +7.5 %;
+    // C5, five light searches per CU one after the other, -1.7 %: it keeps twelve and the LDS-resident nodes that go with them)
+    const int cap = h->cfg.checker == PDMPC_CHECK_SAT ? PDMPC_MAX_WAVES_SAT : PDMPC_MAX_WAVES;
+    const int waves = h->tune.waves >= 0 ? std::min(h->tune.waves, cap) : (n_launch > 2 * h->n_cu ? std::min(12, cap) : cap);
     for (int areas = 1; areas >= 0; --areas) {  // (the maneuver areas fall back to L2 when the soup leaves no room)
         LdsLayout L{};
         uint32_t nv = 0, nl = 0;

@@ -2,4 +2,4 @@
 // configuration): bulk_search.hpp instantiated with one successor-mask word.
 #include "bulk_search.hpp"
 
-PDMPC_BULK_KERNEL(pdmpc_bulk_kernel, pdmpc_launch_bulk, 1, PDMPC_CHECK_INTERX)
+PDMPC_BULK_KERNEL(pdmpc_bulk_kernel, pdmpc_launch_bulk, 1, PDMPC_CHECK_INTERX, PDMPC_MAX_WAVES)

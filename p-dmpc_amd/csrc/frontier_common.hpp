@@ -192,7 +192,9 @@ __device__ void fr_select2(const Frontier& F, uint32_t target1, uint32_t target2
 #define FR_PER 4
 template <class Cls, class Emit>
 __device__ uint32_t fr_partition(double* key, uint32_t* id, uint32_t n, volatile lds_u32* wsum, int n_waves, Cls cls, Emit emit) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));  // (opaque, as in fr_phase_b)
+    const int lane = tid & 63, wave = tid >> 6;
     const uint32_t bd = blockDim.x;
     uint32_t w = 0;
     int buf = 0;
@@ -511,7 +513,9 @@ struct PhaseB {
 template <int NW>
 __device__ PhaseB fr_phase_b(const KernelArgs& A, Ctx& X, const Frontier& F, const ExpandEnv& EE, uint32_t goal, lds_u32* ref_ids, LDS_AS unsigned char* scratch,
                              double* st_b, uint32_t* st_d, const lds_u32* gp_path) {
-    const int tid = X.tid, Hp = X.Hp;
+    int tid = X.tid;
+    asm volatile("" : "+v"(tid));  // (opaque: what the compiler derives from the thread index here — a few LDS addresses — would otherwise be computed in front of the caller's round loop and kept, or spilled, across all of it)
+    const int Hp = X.Hp;
     const Search& S = X.S;
     const VState& VS = X.VS;
     lds_u32* l_path = X.l_path;
@@ -618,7 +622,14 @@ __device__ PhaseB fr_phase_b(const KernelArgs& A, Ctx& X, const Frontier& F, con
                     ch_d[tid] = my_d | 0x80000000u;  // (after the value it announces: LDS keeps a wave's accesses in order)
                 }
             }
-            if (__syncthreads_and(resolved ? 1 : 0)) break;
+            {  // all resolved?  (one shared word and two barriers; __syncthreads_and wants the linear thread index — y, z, the block's
+               // dimensions from the dispatch packet —, which then stay alive across the caller's round loop)
+                if (tid == 0) F.sh[FR_SLOWEST] = 1u;
+                __syncthreads();
+                if (!resolved) F.sh[FR_SLOWEST] = 0u;
+                __syncthreads();
+                if (F.sh[FR_SLOWEST] != 0u) break;  // (uniform)
+            }
             if (++guard > PDMPC_HP_MAX + 4) {  // (cannot happen: a chain inside a chunk is at most Hp long)
                 if (tid == 0) atomicOr((uint32_t*)&F.sh[FR_FLAGS], FRF_BUG);
                 break;

@@ -24,7 +24,8 @@
 /* Twelve wavefronts per workgroup = three per SIMD.  With sixteen (128 VGPRs) the round-3 kernel spilled 44 VGPRs next to ~320 SGPRs held
  * in VGPR lanes, and in that regime hipcc 7.2 produced code that lost spilled values depending on unrelated source changes (DESIGN.md
  * section 3.4); at twelve no workload is slower.  The search kernels need 139-155 VGPRs today (profiles/r05_resource_usage.txt). */
-#define PDMPC_MAX_WAVES 12
+#define PDMPC_MAX_WAVES 16     /* wavefronts per workgroup of the InterX search kernels (126 VGPRs: four per SIMD) */
+#define PDMPC_MAX_WAVES_SAT 12 /* ... of the separating-axis kernel (150 VGPRs: three per SIMD) */
 #define PDMPC_MAX_THREADS (PDMPC_WAVE * PDMPC_MAX_WAVES)
 #define PDMPC_SH_WORDS 128 /* 32-bit LDS words shared by the waves of a workgroup (state, counters of the search) */
 
