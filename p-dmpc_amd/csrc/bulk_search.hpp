@@ -1032,7 +1032,6 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         sh_st_d(sh, BK_L_MID, -1.0);
         sh[SH_NNODES] = 1;
         sh[BK_TIEMODE] = A.bk_force_tie ? 1u : 0u;
-        if (A.debug_tail == 2) sh[FR_EVER_INVAL] = 1;  // (debugging: exercise the ancestor check without arrivals)
         ready[0] = 1u;
         r_flag[0] = 0u;
     }
