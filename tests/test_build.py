@@ -16,8 +16,8 @@ SEARCH_KERNELS = ("pdmpc_bulk_kernel", "pdmpc_bulk_kernel_wide", "pdmpc_bulk_ker
 @pytest.mark.timeout(900)
 def test_search_kernels_use_no_scratch_memory_and_spill_no_vgprs():
     """the three instantiations of the graph search (InterX with one successor-mask word, InterX with any
-    number, the separating-axis checker) fit the register budget of a twelve-wavefront workgroup (168 VGPRs) without a byte of
-    scratch memory.  `make resources` compiles every kernel with the flags of the build (the inliner's basic-block limit raised, no
+    number, the separating-axis checker) fit the register budget of their workgroups — sixteen wavefronts for the InterX kernels
+    (four per SIMD: 128 VGPRs), twelve for the separating-axis kernel (168) — without a byte of scratch memory.  `make resources` compiles every kernel with the flags of the build (the inliner's basic-block limit raised, no
     machine LICM for the search) and prints the compiler's resource remarks."""
     if not os.path.exists(HIPCC) and shutil.which("hipcc") is None:
         pytest.skip("no hipcc")
@@ -36,7 +36,7 @@ def test_search_kernels_use_no_scratch_memory_and_spill_no_vgprs():
     for kernel in SEARCH_KERNELS:
         assert kernel in seen, seen.keys()
         assert seen[kernel]["scratch"] == 0 and seen[kernel]["vgpr_spill"] == 0, (kernel, seen[kernel])
-        assert seen[kernel]["vgprs"] <= 168, (kernel, seen[kernel])
+        assert seen[kernel]["vgprs"] <= (168 if kernel.endswith("_sat") else 128), (kernel, seen[kernel])
 
 
 def test_no_legacy_search_kernels_are_shipped():
