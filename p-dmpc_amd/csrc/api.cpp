@@ -135,7 +135,7 @@ struct PackedStep {
 // setting leaves the results bit-identical.  ONE environment variable overrides them, read once in pdmpc_create (a launch makes no
 // getenv call):  PDMPC_TUNING="key=value,key=value,..."  with the keys below (include/pdmpc.h documents the variable).
 struct Tuning {
-    int round0 = 24;        // nodes a round of a young search takes
+    int round0 = -1;        // nodes a round of a young search takes (-1: 24; 32 for a launch that leaves CUs idle but has fewer than four helpers per search, C3)
     int round = -1;         // the most a round takes (-1: 1000 with helper workgroups, else 256)
     int ramp = -1;          // a round grows by 1 / ramp of the nodes processed so far (-1: 2 with helper workgroups, else 4)
     int ready = 2048;       // entries of the ready list with helper workgroups (half of it without): the most a round can take
@@ -202,7 +202,7 @@ bool parse_tuning(const char* text, Tuning& T, std::string& err) {
             return false;
         }
     }
-    T.round0 = std::max(1, T.round0);
+    if (T.round0 >= 0) T.round0 = std::max(1, T.round0);
     if (T.round >= 0) T.round = std::max(1, T.round);
     if (T.ramp >= 0) T.ramp = std::max(1, T.ramp);
     T.ready = std::min(2048, std::max(256, T.ready)) & ~63;
@@ -703,7 +703,7 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     // rounds: measured on C2 / C3 (20 / 128 searches, helpers): cap 256, ramp 4 -> 646 / 589 steps/s; 512, 2 -> 735 / 786; 1000, 2 -> 769 / 909; 1000, 1 -> 620 / 772
     const bool helped = search && !safe && bulk_has_helpers(h, count);
     a.bk_ready_cap = std::min(h->bk_ready_launch, 3 * PDMPC_WAVE * h->n_waves);  // (the verdict pass handles three entries per thread)
-    a.bk_round0 = T.round0;
+    a.bk_round0 = T.round0 > 0 ? T.round0 : 24;  // (C3's class: below, once the helpers are counted)
     a.bk_round = std::min(h->bk_ready_launch / 2 - 16, std::max(a.bk_round0, T.round > 0 ? T.round : (helped ? 1000 : 256)));
     a.bk_ramp = T.ramp > 0 ? T.ramp : (helped ? 2 : 4);
     a.own_div = T.own_div;
@@ -764,7 +764,13 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     // rounds are shared from 64 nodes on where helpers are plenty (C2: a dozen per search), from a few hundred on where there are
     // about as many helpers as searches or fewer (measured C3, 128 + 128: 64 -> 1 026 steps/s, 128-192 -> 1 070, 384 -> 986; C4, 512 + 96:
     // 64 -> 65.5, 192 -> 67, 512 -> 69; C5, 1 280 + 200 behind the searches, whose helpers only meet the medium searches of the tail: 32-128 -> 560)
-    a.bk_share_min = T.share_min > 0 ? T.share_min : (a.n_helpers >= 4 * count ? 64 : (count <= h->n_cu ? 160 : (count <= 2 * h->n_cu ? 512 : 64)));
+    a.bk_share_min = T.share_min > 0 ? T.share_min : (a.n_helpers >= 4 * count ? 64 : (count <= h->n_cu ? 128 : (count <= 2 * h->n_cu ? 512 : 64)));
+    // (sixteen wavefronts: C3 — 128 searches + 128 helpers — 1 135 steps/s with young rounds of 24 nodes and sharing from 160 on, 1 175 with 32
+    // and 128; 28: 1 154, 36: 1 137.  C2 / C4 / C5 with 32: -0.6 % / -1 % / +0.6 %: they stay at 24)
+    if (T.round0 < 0 && helped && count <= h->n_cu && a.n_helpers < 4 * count) {
+        a.bk_round0 = 32;
+        a.bk_round = std::max(a.bk_round, a.bk_round0);
+    }
     if (a.n_helpers > 0 && !h->boards_dirty) {
         // The boards stay closed between launches (a search closes every round it shares before it uses the verdicts, and a closed
         // ticket word offers nothing) and the count of finished searches runs on from launch to launch: nothing to clear -- two
