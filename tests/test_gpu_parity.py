@@ -298,6 +298,7 @@ def test_random_road_problems_never_fall_back():
     [
         "speculate=0",
         "waves=8",
+        "waves=12,round0=32",  # (sixteen wavefronts are the default of the InterX kernels, twelve of the separating-axis kernel)
         "waves=5,round0=7",
         "helpers=0",
         "helpers=3,share_min=64,tile=32",
