@@ -379,6 +379,12 @@ def main():
         status_counts["exhausted"] += int((recs["status"] == 1).sum())
         status_counts["arena_overflow"] += int((recs["status"] == 2).sum())
         status_counts["error"] += int((recs["status"] < 0).sum())
+    if use_group and grp is not None:
+        # the group's devices get arenas as large as the single handle needed for these steps (the resident path does not plan a step
+        # again when a search outgrows its arena: pdmpc_group_plan_step does), and every bank is planned once more in them
+        grp.grow_arena(h.arena_nodes()[0])
+        for b in range(S):
+            grp.launch(b)
     # a bank recorded before the arenas grew replays in the grown arenas: same searches, none of them truncated
     lds_bytes = h.stats()["lds_bytes"]
     host_buffer_ms = 1e3 * (time.perf_counter() - t_host - t_grow) / max(S, 1)  # pack (host buffers -> HBM) + launch + fetch + stats

@@ -417,6 +417,10 @@ int pdmpc_group_create(const pdmpc_config* config, int32_t n_devices, const int3
 int pdmpc_group_destroy(pdmpc_group* group);
 int pdmpc_group_size(pdmpc_group* group, int32_t* n_devices);
 int pdmpc_group_handle(pdmpc_group* group, int32_t rank, pdmpc_handle** handle); /* rank's handle (statistics, debug read-backs) */
+/* The arenas of every device at least `max_nodes` nodes per vehicle (pdmpc_grow_arena on each handle).  pdmpc_group_plan_step grows them
+ * by itself when a search overflows; a caller of the resident path (pack_step / launch / fetch), which does not plan again, sizes them
+ * here — e.g. with what a single handle needed for the same steps — and reads the statuses. */
+int pdmpc_group_grow_arena(pdmpc_group* group, int32_t max_nodes);
 int pdmpc_group_upload_mpa(pdmpc_group* group, const pdmpc_mpa* mpa);
 int pdmpc_group_plan_step(pdmpc_group* group, int32_t n_vehicles, const pdmpc_vehicle_in* in, const int32_t* pred_offset, const int32_t* pred_index,
                           const pdmpc_polygon_set* fallback_shapes, const double* weights, int32_t mode, pdmpc_vehicle_out* out);

@@ -620,6 +620,16 @@ int pdmpc_group_fetch(pdmpc_group* g, int32_t bank, int32_t n, pdmpc_vehicle_out
     return group_fetch(g, bank, n, out);
 }
 
+int pdmpc_group_grow_arena(pdmpc_group* g, int32_t max_nodes) {
+    if (!g || max_nodes <= 0) return gfail(PDMPC_ERR_INVALID, "pdmpc_group_grow_arena: bad argument");
+    for (pdmpc_handle* h : g->h) {
+        int32_t nodes = 0;
+        GRC(pdmpc_arena_nodes(h, &nodes, nullptr));
+        if (nodes < max_nodes) GRC(pdmpc_grow_arena(h, max_nodes));
+    }
+    return PDMPC_OK;
+}
+
 int pdmpc_group_last_timing(pdmpc_group* g, double* ms6) {
     if (!g || !ms6) return gfail(PDMPC_ERR_INVALID, "null argument");
     for (int i = 0; i < 6; ++i) ms6[i] = g->timing[i];

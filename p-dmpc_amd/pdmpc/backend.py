@@ -48,6 +48,7 @@ EXPORTS = [
     "pdmpc_group_destroy",
     "pdmpc_group_size",
     "pdmpc_group_handle",
+    "pdmpc_group_grow_arena",
     "pdmpc_group_upload_mpa",
     "pdmpc_group_plan_step",
     "pdmpc_group_pack_step",
@@ -234,6 +235,11 @@ class Group:
         _check(self.L, self.L.pdmpc_group_pack_step(self.g, bank, n, arr, off.ctypes.data_as(abi.c_int32_p), idx.ctypes.data_as(abi.c_int32_p), fb,
                                                     None if w is None else w.ctypes.data_as(abi.c_double_p), mode), "pdmpc_group_pack_step")
         del keep
+
+    def grow_arena(self, max_nodes):
+        """Arenas of at least max_nodes nodes per vehicle on every device (the resident path does not grow them by itself)."""
+        self.L.pdmpc_group_grow_arena.argtypes = [C.c_void_p, C.c_int32]
+        _check(self.L, self.L.pdmpc_group_grow_arena(self.g, int(max_nodes)), "pdmpc_group_grow_arena")
 
     def launch(self, bank):
         self.L.pdmpc_group_launch.argtypes = [C.c_void_p, C.c_int32]

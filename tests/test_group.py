@@ -125,3 +125,40 @@ def test_group_of_one_device_equals_the_single_launch(mode):
             assert_records_equal(grp.fetch(b, len(prob["iters"])), refs[b], "resident group bank %d, pass %d" % (b, rep))
     grp.close()
     opt.handle.close()
+
+
+@pytest.mark.gpu
+def test_group_arenas_grow_by_themselves_or_on_request():
+    """The reference's tree is unbounded (Tree.m:54-70).  pdmpc_group_plan_step plans a step again with arenas twice as large on every
+    device when a search outgrows its arena; the resident path (pack_step / launch / fetch) does not plan again: its statuses say so, and
+    pdmpc_group_grow_arena sizes the arenas (what bench.py --gpus N does with the size the single handle needed)."""
+    import problems
+    from pdmpc import abi
+    from pdmpc.backend import Handle
+
+    options, mpa, iters = problems.problem_set("interx", 11, 12, Hp=7)
+    options.max_nodes = 1 << 16
+    single = Handle(options)
+    single.upload_mpa(mpa)
+    preds = [[] for _ in iters]
+    ref = single.plan_step(iters, preds, None)
+    need = int(max(ref["n_expanded"]))
+    assert need > 64
+    options.max_nodes = 64  # far too small for most of these searches
+    grp = backend.Group(options, n_devices=1)
+    grp.upload_mpa(mpa)
+    from test_gpu_parity import assert_records_equal
+
+    grp.pack_step(0, iters, preds, None, mode=backend.SHARD_COMPONENTS)
+    grp.launch(0)
+    small = grp.fetch(0, len(iters))
+    assert (small["status"] == abi.ARENA_OVERFLOW).any()  # the resident path reports, it does not grow
+    grp.grow_arena(1 << 16)
+    grp.launch(0)
+    assert_records_equal(grp.fetch(0, len(iters)), ref, "resident group bank after pdmpc_group_grow_arena")
+    grp.close()
+    grp = backend.Group(options, n_devices=1)  # 64 nodes again
+    grp.upload_mpa(mpa)
+    assert_records_equal(grp.plan_step(iters, preds, None), ref, "pdmpc_group_plan_step grows the arenas by itself")
+    grp.close()
+    single.close()
