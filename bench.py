@@ -172,7 +172,7 @@ def cpu_baseline(options, mpa, problems, gpu_records, budget_s):
     }, n_done, plans, mismatches
 
 
-def measure_replay(h, problems, steps, warmup, one_step, dist, torch, reset_extra=None):
+def measure_replay(h, problems, steps, warmup, one_step, dist, torch, reset_extra=None, host_gate=None):
     for i in range(warmup):
         one_step(i)
     h.reset_stats()
@@ -189,6 +189,10 @@ def measure_replay(h, problems, steps, warmup, one_step, dist, torch, reset_extr
         lat.append(time.perf_counter() - t0)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_begin
+    if host_gate is not None:
+        # (the group path: rank 0 plans on every device; the other ranks wait HERE, on the host, until it is through — a collective
+        # entered early would sit on their GPUs as a spinning RCCL kernel next to rank 0's launches for the whole timed region)
+        host_gate()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -428,7 +432,13 @@ def main():
                 dist.all_gather_into_tensor(gather_bufs[1], gather_bufs[0])
         h.synchronize()
 
-    elapsed, lat = measure_replay(h, problems, args.steps, args.warmup, one_step, dist, torch, reset_extra=grp.reset_stats if grp is not None else None)
+    host_gate = None
+    if use_group and dist is not None:
+        from torch.distributed.distributed_c10d import _get_default_store
+
+        store, gate_key = _get_default_store(), "pdmpc_bench_group_done"
+        host_gate = (lambda: store.set(gate_key, "1")) if rank == 0 else (lambda: store.wait([gate_key]))
+    elapsed, lat = measure_replay(h, problems, args.steps, args.warmup, one_step, dist, torch, reset_extra=grp.reset_stats if grp is not None else None, host_gate=host_gate)
     st = grp.stats(0) if (use_group and grp is not None) else h.stats()
     kernel_ms = st["kernel_ms"]
     n_launch = st["n_launches"]
