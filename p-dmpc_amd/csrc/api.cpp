@@ -135,7 +135,7 @@ struct PackedStep {
 // setting leaves the results bit-identical.  ONE environment variable overrides them, read once in pdmpc_create (a launch makes no
 // getenv call):  PDMPC_TUNING="key=value,key=value,..."  with the keys below (include/pdmpc.h documents the variable).
 struct Tuning {
-    int round0 = -1;        // nodes a round of a young search takes (-1: 24; 32 for a launch that leaves CUs idle but has fewer than four helpers per search, C3)
+    int round0 = -1;        // nodes a round of a young search takes (-1: 24; 32 for a launch that leaves CUs idle but has fewer than four helpers per search, C3, and for one of more than two searches per CU, C5)
     int round = -1;         // the most a round takes (-1: 1000 with helper workgroups, else 256)
     int ramp = -1;          // a round grows by 1 / ramp of the nodes processed so far (-1: 2 with helper workgroups, else 4)
     int ready = 2048;       // entries of the ready list with helper workgroups (half of it without): the most a round can take
@@ -767,7 +767,7 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     a.bk_share_min = T.share_min > 0 ? T.share_min : (a.n_helpers >= 4 * count ? 64 : (count <= h->n_cu ? 128 : (count <= 2 * h->n_cu ? 512 : 64)));
     // (sixteen wavefronts: C3 — 128 searches + 128 helpers — 1 135 steps/s with young rounds of 24 nodes and sharing from 160 on, 1 175 with 32
     // and 128; 28: 1 154, 36: 1 137.  C2 / C4 / C5 with 32: -0.6 % / -1 % / +0.6 %: they stay at 24)
-    if (T.round0 < 0 && helped && count <= h->n_cu && a.n_helpers < 4 * count) {
+    if (T.round0 < 0 && helped && ((count <= h->n_cu && a.n_helpers < 4 * count) || count > 2 * h->n_cu)) {  // (C5, 1 280 searches: 558 -> 565)
         a.bk_round0 = 32;
         a.bk_round = std::max(a.bk_round, a.bk_round0);
     }
