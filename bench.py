@@ -194,7 +194,7 @@ def measure_replay(h, problems, steps, warmup, one_step, dist, torch, reset_extr
         # entered early would sit on their GPUs as a spinning RCCL kernel next to rank 0's launches for the whole timed region)
         host_gate()
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.barrier()
         elapsed = float(t.item())
@@ -350,7 +350,9 @@ def main():
         ok = [0]
         if rank == 0:
             try:
-                grp = backend.Group(options, n_devices=world)
+                # (PDMPC_GROUP_LOGICAL=R on a 1-GPU box: R logical ranks on this GPU — the multi-rank protocol with peer copies for RCCL)
+                n_logical = int(os.environ.get("PDMPC_GROUP_LOGICAL", "0"))
+                grp = backend.Group(options, n_devices=n_logical, devices=[local_rank] * n_logical) if n_logical > 1 else backend.Group(options, n_devices=world)
                 grp.upload_mpa(mpa)
                 gmode = backend.SHARD_LEVELS if args.shard == "levels" else backend.SHARD_COMPONENTS
                 for b, prob in enumerate(problems):
@@ -361,6 +363,8 @@ def main():
             except Exception as e:  # noqa: BLE001 (whatever went wrong: the other path is still there)
                 sys.stderr.write("bench.py: pdmpc_group path not available (%s): falling back to torch.distributed\n" % e)
                 grp = None
+        # (the library leaves the current device as it found it; torch's collectives are bound to cuda:local_rank, so make sure anyway)
+        torch.cuda.set_device(local_rank)
         if dist is not None:
             dist.broadcast_object_list(ok, src=0)
         if not ok[0]:
@@ -439,10 +443,14 @@ def main():
         store, gate_key = _get_default_store(), "pdmpc_bench_group_done"
         host_gate = (lambda: store.set(gate_key, "1")) if rank == 0 else (lambda: store.wait([gate_key]))
     elapsed, lat = measure_replay(h, problems, args.steps, args.warmup, one_step, dist, torch, reset_extra=grp.reset_stats if grp is not None else None, host_gate=host_gate)
-    st = grp.stats(0) if (use_group and grp is not None) else h.stats()
+    # the group: counts summed over the ranks, kernel time of the rank whose kernels ran longest (backend.Group.stats_all); the
+    # roofline below is PER DEVICE (the step's algorithmic bytes / ranks, over that time) against one device's peak
+    st = grp.stats_all() if (use_group and grp is not None) else h.stats()
+    n_ranks_planning = grp.n_devices if (use_group and grp is not None) else 1
+    torch.cuda.set_device(local_rank)
     kernel_ms = st["kernel_ms"]
     n_launch = st["n_launches"]
-    alg_bytes = sum(bytes_per_bank[i % S] for i in range(args.steps))
+    alg_bytes = sum(bytes_per_bank[i % S] for i in range(args.steps)) / n_ranks_planning
     pops = sum(pops_per_bank[i % S] for i in range(args.steps))
     nodes = sum(nodes_per_bank[i % S] for i in range(args.steps))
     achieved = (alg_bytes / max(n_launch, 1)) / ((kernel_ms / max(n_launch, 1)) * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
@@ -550,9 +558,9 @@ def main():
                 tsrc = "profiles/%s: FETCH_SIZE + WRITE_SIZE of the timed launches of this workload, search kernel + the helper kernel next to it (separate rocprofv3 --pmc passes, tools/collect_profiles.sh)" % os.path.basename(tpath)
             except Exception:
                 traffic = None
-        mode = ("pdmpc_group (C ABI, one process, ncclCommInitAll): " + ("every level sharded over the devices, one all-gather per level" if args.shard == "levels" else
-                "coupling-graph components sharded over the devices, one launch per device and step, one all-gather of results")) if use_group else "levels sharded over ranks with one all-gather per level" if planner is not None else (
-            ("prioritization instances sharded over ranks" if explore else "coupling-graph components sharded over ranks") + ", one launch per rank and step, one all-gather of results" if gather_bufs is not None else "one launch per step")
+        mode = ("path = group (pdmpc_group_* of the C ABI, ONE process drives %d ranks, exchange = %s): " % (grp.n_devices if grp is not None else world, grp.collective if grp is not None else "-") + ("every level sharded over the devices, one all-gather per level" if args.shard == "levels" else
+                "coupling-graph components sharded over the devices, one launch per device and step, one all-gather of results")) if use_group else "path = dist (one process per GPU, torch.distributed): levels sharded over ranks with one all-gather per level" if planner is not None else (
+            "path = dist (one process per GPU, torch.distributed): " + ("prioritization instances sharded over ranks" if explore else "coupling-graph components sharded over ranks") + ", one launch per rank and step, one all-gather of results" if gather_bufs is not None else "one launch per step")
         out = {
             "metric": "MPC steps/sec (whole node) + p50 per-step plan latency, N vehicles H=8",
             "value": (1 if sharded else world) * args.steps / elapsed,
@@ -586,6 +594,7 @@ def main():
                 % (args.workload.upper() + (" (%d prioritizations of each step flattened into one batch)" % args.instances if explore else ""),
                    args.vehicles, ", tiled" if sharded and not explore else "", args.hp, args.mpa, args.priorities, mode, S,
                    "" if sharded else "; per GPU one independent network"),
+                "multi_path": ("group/" + grp.collective if (use_group and grp is not None) else "dist") if (use_group or planner is not None or gather_bufs is not None) else None,
                 "vehicles": args.vehicles,
                 "Hp": args.hp,
                 "mpa": args.mpa,
@@ -605,6 +614,7 @@ def main():
                 "kernel_ms_avg": kernel_ms / max(n_launch, 1),
                 "algorithmic_bytes_per_launch": alg_bytes / max(n_launch, 1),
                 "launches": n_launch,
+                "ranks": n_ranks_planning,  # > 1 (the group): achieved / bytes / kernel time are per device, the slowest device's time
                 "lds_bytes_per_workgroup": lds_bytes,
                 "open_list": "unordered near (LDS) / mid / far (HBM) lists, bulk-synchronous rounds of the smallest keys; equal keys: replay through the libstdc++-faithful binary heap",
             },

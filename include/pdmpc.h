@@ -412,8 +412,21 @@ const char* pdmpc_controller_last_error(void);
  * each) = expected work per vehicle, e.g. n_popped of the previous step.  Results are those of the single launch, bit for bit. */
 enum { PDMPC_SHARD_AUTO = 0, PDMPC_SHARD_COMPONENTS = 1, PDMPC_SHARD_LEVELS = 2 };
 typedef struct pdmpc_group pdmpc_group;
-/* devices: n_devices HIP device ordinals (NULL: 0 .. n_devices - 1); config as for pdmpc_create (config.device is ignored) */
+/* devices: n_devices HIP device ordinals (NULL: 0 .. n_devices - 1); config as for pdmpc_create (config.device is ignored).
+ * The exchange between the ranks sits behind a function table (csrc/group.cpp: struct Collective):
+ *   PDMPC_COLLECTIVE_RCCL  ncclAllGather on the handles' streams, one communicator per device (ncclCommInitAll) — distinct devices;
+ *   PDMPC_COLLECTIVE_COPY  the same all-gather as peer copies ordered by HIP events on the handles' streams (no library, no host
+ *                          wait).  A device may then be listed more than once: such ranks are LOGICAL ranks — a handle, a stream
+ *                          and arenas of their own on a shared GPU — and the whole multi-rank protocol (slot remapping, block
+ *                          partition of a level, import of the other ranks' blocks) runs on a 1-GPU box;
+ *   PDMPC_COLLECTIVE_AUTO  RCCL for distinct devices (PDMPC_GROUP_COLLECTIVE=copy in the environment: peer copies), peer copies
+ *                          when a device is listed twice.
+ * pdmpc_group_create = pdmpc_group_create_ex(..., PDMPC_COLLECTIVE_AUTO, ...).  Every pdmpc_group_* and pdmpc_* entry point leaves
+ * the calling thread's current HIP device as it found it. */
+enum { PDMPC_COLLECTIVE_AUTO = 0, PDMPC_COLLECTIVE_RCCL = 1, PDMPC_COLLECTIVE_COPY = 2 };
 int pdmpc_group_create(const pdmpc_config* config, int32_t n_devices, const int32_t* devices, pdmpc_group** out_group);
+int pdmpc_group_create_ex(const pdmpc_config* config, int32_t n_devices, const int32_t* devices, int32_t collective, pdmpc_group** out_group);
+int pdmpc_group_collective(pdmpc_group* group, int32_t* collective); /* which of the two the group uses (RCCL or COPY) */
 int pdmpc_group_destroy(pdmpc_group* group);
 int pdmpc_group_size(pdmpc_group* group, int32_t* n_devices);
 int pdmpc_group_handle(pdmpc_group* group, int32_t rank, pdmpc_handle** handle); /* rank's handle (statistics, debug read-backs) */
@@ -427,7 +440,8 @@ int pdmpc_group_plan_step(pdmpc_group* group, int32_t n_vehicles, const pdmpc_ve
 /* The three parts of pdmpc_group_plan_step on their own, for steps that stay resident (bench.py's timed replay): pack partitions the
  * step and makes its sub-problems resident on the devices in group bank `bank` (0 .. 999; the handles' own banks 0 .. 2047 stay the
  * caller's), launch plans a packed bank (launches, all-gathers and imports enqueued on the handles' streams, ONE wait at the end; no
- * host-to-device copy), fetch copies the records of the bank launched last to the host.  plan_step = pack(0) + launch(0) + fetch(0). */
+ * host-to-device copy), fetch copies the records of the bank launched last to the host (PDMPC_ERR_INVALID for any other bank: the
+ * devices hold one step's gathered records).  plan_step = pack(0) + launch(0) + fetch(0). */
 int pdmpc_group_pack_step(pdmpc_group* group, int32_t bank, int32_t n_vehicles, const pdmpc_vehicle_in* in, const int32_t* pred_offset, const int32_t* pred_index,
                           const pdmpc_polygon_set* fallback_shapes, const double* weights, int32_t mode);
 int pdmpc_group_launch(pdmpc_group* group, int32_t bank);

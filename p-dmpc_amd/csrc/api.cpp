@@ -42,6 +42,30 @@ int fail(int code, const std::string& msg) {
         }                                                                                            \
     } while (0)
 
+// The current device belongs to the caller (torch reads it with hipGetDevice: a collective issued after a call into this library
+// must not find itself on another GPU).  Every entry point that works on the handle's device switches to it through this guard,
+// which puts the caller's device back on every exit path.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) {
+            err = hipSetDevice(dev);
+            switched = err == hipSuccess;
+        }
+    }
+    ~DeviceGuard() {
+        if (switched && prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define ON_DEVICE(dev)                 \
+    DeviceGuard device_guard__((dev)); \
+    HIPCHK(device_guard__.err)
+
 inline uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
 
 template <class T>
@@ -151,6 +175,7 @@ struct Tuning {
     int seat_nodes = 256;   // a search may hold its share of the launch's helpers (helpers / searches) per this many nodes it has processed
     int helpers_first = -1; // ... of them dispatched in front of the searches (-1: half the CUs when most searches of the launch have predecessors)
     int speculate = 1;      // 0: every search waits for all its predecessors before it starts
+    int compact = -1;       // 1: the kernel built for two workgroups per CU (8 wavefronts, <= 80 KB of LDS: bulk_kernel_compact.hip) where it applies (InterX, one mask word, the soup fits); 0: never; -1: for launches of more searches than CUs
     int waves = -1;         // wavefronts per workgroup (4 .. PDMPC_MAX_WAVES; -1: 16 for the InterX kernels — 12 for a launch of more than two searches per CU —, 12 for the separating-axis kernel)
     uint32_t spin_limit = 1u << 22;  // the watchdog's limit of polls / rounds (debugging: fail fast)
     int force_tie = 0;      // testing only: every search ends on the replay through the reference's binary heap (as if it had met equal keys)
@@ -168,7 +193,7 @@ bool parse_tuning(const char* text, Tuning& T, std::string& err) {
     int spin = (int)T.spin_limit;
     const Key keys[] = {{"round0", &T.round0}, {"round", &T.round}, {"ramp", &T.ramp}, {"ready", &T.ready}, {"share_min", &T.share_min}, {"own_div", &T.own_div},
                         {"tile", &T.tile}, {"mid_min", &T.mid_min}, {"mid_fill", &T.mid_fill}, {"tentative", &T.tentative}, {"fast_arrival", &T.fast_arrival}, {"helpers_first", &T.helpers_first}, {"seat_nodes", &T.seat_nodes},
-                        {"helpers", &T.helpers}, {"helpers_oversub", &T.helpers_oversub}, {"speculate", &T.speculate}, {"waves", &T.waves}, {"spin_limit", &spin},
+                        {"helpers", &T.helpers}, {"helpers_oversub", &T.helpers_oversub}, {"speculate", &T.speculate}, {"waves", &T.waves}, {"compact", &T.compact}, {"spin_limit", &spin},
                         {"force_tie", &T.force_tie}, {"reverse_dispatch", &T.reverse_dispatch}, {"debug_tail", &T.debug_tail}, {"debug_lds", &T.debug_lds},
                         {"debug_host", &T.debug_host}, {"debug_progress", &T.debug_progress}};
     std::string str(text ? text : "");
@@ -269,6 +294,7 @@ struct pdmpc_handle {
     int bk_ready_launch = 2048;          // entries of the ready list of the last layout
     uint32_t* progress = nullptr;        // pinned, debug_progress
     int n_waves = PDMPC_MAX_WAVES;       // of the last layout
+    bool compact_layout = false;         // the last layout is the compact kernel's (two workgroups per CU)
     // batch blobs: several packed steps can stay resident side by side ("banks", pdmpc_select_bank)
     std::vector<PackedStep> banks;
     int bank = 0;
@@ -276,6 +302,8 @@ struct pdmpc_handle {
     // launches
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
+    double folded_kernel_ms = 0.0;  // launches whose event pairs were recycled (resident launches without a pack or reset in between)
+    int64_t folded_launches = 0;
     LdsLayout lds{};
     int NL = 0, NV = 0, areas_in_lds = 0;
     pdmpc_stats stats{};
@@ -284,9 +312,10 @@ struct pdmpc_handle {
 namespace {
 
 // The dynamic LDS size of a kernel is an attribute of the function ON THE DEVICE, not of a handle (hipFuncSetAttribute sets a
-// maximum): the largest size set so far is kept per device and kernel (0 bulk, 1 bulk wide, 2 bulk SAT), shared by every handle.
+// maximum): the largest size set so far is kept per device and kernel (0 bulk, 1 bulk wide, 2 bulk SAT, 3 bulk compact), shared by every handle.
+const size_t kMaxLaunchEvents = 4096;  // event pairs a handle keeps before it folds their times (launch_range)
 std::mutex g_lds_mutex;
-uint32_t g_lds_high_water[64][3];
+uint32_t g_lds_high_water[64][4];
 
 // hipStreamSynchronize on the launch stream, counted: a bank whose staging copy was queued before is free again (pack_common)
 inline hipError_t sync_stream(pdmpc_handle* h) {
@@ -299,23 +328,13 @@ inline hipError_t sync_stream(pdmpc_handle* h) {
 // thread), d_traveled table, the LDS part of the open set (PDMPC_BK_PER entries per thread), the ready list with its collision
 // flags, the histogram / goal list / expansion lists, 2 KB of small tables, the areas of the published path, validity bytes, then
 // as many node records as fit.
-bool layout_bulk(pdmpc_handle* h, size_t budget, int n_waves, int areas, int soup_cap, LdsLayout& L, uint32_t& nv, uint32_t& nl, uint32_t ready_cap) {
+bool layout_bulk(pdmpc_handle* h, size_t budget, int n_waves, int areas, int soup_cap, LdsLayout& L, uint32_t& nv, uint32_t& nl, uint32_t ready_cap, bool compact) {
     (void)n_waves;
-    if (ready_cap > PDMPC_LK_READY_CAP) return false;
+    const uint32_t lk_waves = compact ? PDMPC_LK_COMPACT_WAVES : PDMPC_MAX_WAVES, lk_ready = compact ? PDMPC_LK_COMPACT_READY_CAP : 2048u;
+    if (ready_cap > lk_ready || (uint32_t)n_waves > lk_waves) return false;
     // the regions of fixed size at the kernel's compile-time offsets (pdmpc_device.h: PDMPC_LK_*) ...
-    L.ref = PDMPC_LK_REF;
-    L.shape = PDMPC_LK_SHAPE;
-    L.path = PDMPC_LK_PATH;
-    L.cand = PDMPC_LK_CAND;
-    L.expand = PDMPC_LK_EXPAND;
-    L.bk_near_key = PDMPC_LK_NEAR_KEY;
-    L.bk_near_id = PDMPC_LK_NEAR_ID;
-    L.bk_ready = PDMPC_LK_READY;
-    L.bk_hist = PDMPC_LK_HIST;
-    L.bk_misc = PDMPC_LK_MISC;
-    L.bk_pshape = PDMPC_LK_PSHAPE;
     // ... the automaton's tables and the soup behind them
-    uint32_t off = PDMPC_LK_FIXED_END;
+    uint32_t off = pdmpc_lk_fixed(lk_waves, lk_ready, &L);
     L.mask = off;
     off = align16(off + (uint32_t)h->mask_bytes);
     L.man_index = off;
@@ -330,7 +349,7 @@ bool layout_bulk(pdmpc_handle* h, size_t budget, int n_waves, int areas, int sou
     const uint32_t min_nodes = 64 * (uint32_t)sizeof(NodeRec) + 1024;
     if ((size_t)off + min_nodes + 256 > budget) return false;
     const uint32_t rest = (uint32_t)(budget - off - 256);
-    nv = std::min<uint32_t>(16384u, std::max<uint32_t>(1024u, rest / 6));
+    nv = std::min<uint32_t>(16384u, std::max<uint32_t>(compact ? 512u : 1024u, rest / 6));
     nv = std::min(nv, h->max_nodes) & ~15u;
     nl = std::min((rest - nv) / (uint32_t)sizeof(NodeRec), h->max_nodes);
     L.vstate = off;
@@ -354,12 +373,35 @@ int compute_lds_bulk(pdmpc_handle* h, int n_launch, int soup_cap) {
     // Sixteen wavefronts where the kernel's registers allow four per SIMD (measured against twelve: C2 +1.5 %, C3 +1.3 %, C4 +7.5 %;
     // C5, five light searches per CU one after the other, -1.7 %: it keeps twelve and the LDS-resident nodes that go with them)
     const int cap = h->cfg.checker == PDMPC_CHECK_SAT ? PDMPC_MAX_WAVES_SAT : PDMPC_MAX_WAVES;
+    // Two workgroups per CU (bulk_kernel_compact.hip: 8 wavefronts, at most half the LDS, the automaton's areas in L2) for launches of
+    // more searches than CUs: every search holds half a CU, so twice as many are resident from the start and a finished search that
+    // waits for its predecessors blocks half as much.  InterX with one mask word only; falls back to the full layout if the soup is too large.
+    const bool want_compact = h->cfg.checker == PDMPC_CHECK_INTERX && h->n_words == 1 && (h->tune.compact > 0 || (h->tune.compact < 0 && n_launch > h->n_cu));
+    h->compact_layout = false;
+    if (want_compact) {
+        LdsLayout L{};
+        uint32_t nv = 0, nl = 0;
+        const int waves = h->tune.waves >= 0 ? std::min(h->tune.waves, PDMPC_LK_COMPACT_WAVES) : PDMPC_LK_COMPACT_WAVES;
+        const int ready = std::min(std::min(h->bk_ready_launch, 3 * PDMPC_WAVE * waves), (int)PDMPC_LK_COMPACT_READY_CAP);
+        if (layout_bulk(h, kLdsMax / 2, waves, 0, soup_cap, L, nv, nl, (uint32_t)ready, true)) {
+            if (h->tune.debug_lds)
+                fprintf(stderr, "pdmpc LDS layout (compact): launch %d waves %d near %u ready %d nv %u nl %u total %u\n", n_launch, waves, PDMPC_BK_PER * (uint32_t)waves * PDMPC_WAVE, ready, nv, nl, L.total);
+            h->bk_ready_launch = ready;
+            h->lds = L;
+            h->n_waves = waves;
+            h->NL = (int)nl;
+            h->NV = (int)nv;
+            h->areas_in_lds = 0;
+            h->compact_layout = true;
+            return PDMPC_OK;
+        }
+    }
     const int waves = h->tune.waves >= 0 ? std::min(h->tune.waves, cap) : (n_launch > 2 * h->n_cu ? std::min(12, cap) : cap);
     for (int areas = 1; areas >= 0; --areas) {  // (the maneuver areas fall back to L2 when the soup leaves no room)
         LdsLayout L{};
         uint32_t nv = 0, nl = 0;
         const int ready = std::min(h->bk_ready_launch, 3 * PDMPC_WAVE * waves);
-        if (!layout_bulk(h, kLdsMax, waves, areas, soup_cap, L, nv, nl, (uint32_t)ready)) continue;
+        if (!layout_bulk(h, kLdsMax, waves, areas, soup_cap, L, nv, nl, (uint32_t)ready, false)) continue;
         if (h->tune.debug_lds)
             fprintf(stderr, "pdmpc LDS layout: launch %d waves %d areas %d near %u ready %d nv %u nl %u total %u\n", n_launch, waves, areas, PDMPC_BK_PER * (uint32_t)waves * PDMPC_WAVE, ready,
                     nv, nl, L.total);
@@ -606,6 +648,8 @@ int pack_common(pdmpc_handle* h, int n, const pdmpc_vehicle_in* in, const int32_
     B.staged_serial = h->sync_serial;
     B.n_packed = n;
     h->events_used = 0;
+    h->folded_kernel_ms = 0.0;
+    h->folded_launches = 0;
     std::memset(&h->stats, 0, sizeof h->stats);
     return PDMPC_OK;
 }
@@ -783,6 +827,17 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
         h->help_fin_total = (uint32_t)count;
         h->boards_dirty = false;
     }
+    if (h->events_used == kMaxLaunchEvents) {
+        // a caller that launches resident banks for ever (no pack, no pdmpc_reset_stats in between) must not make the handle hold an
+        // event pair per launch: the pairs' times are folded into a sum and the pairs used again
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (size_t i = 0; i < h->events_used; ++i) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, h->events[i].first, h->events[i].second) == hipSuccess) h->folded_kernel_ms += t;
+        }
+        h->folded_launches += (int64_t)h->events_used;
+        h->events_used = 0;
+    }
     if (h->events_used == h->events.size()) {
         hipEvent_t e0, e1;
         HIPCHK(hipEventCreate(&e0));
@@ -801,10 +856,11 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     // stall, the watchdog (spin_limit) ends the waiting searches with an error status and plan_packed_growing plans the call again
     // with safe == true, in slices that are resident as a whole (a slice's predecessors are in it or in an earlier slice) -- forward
     // progress then needs no assumption at all.
-    const int variant = h->cfg.checker == PDMPC_CHECK_SAT ? 2 : (h->n_words != 1 ? 1 : 0);
+    const int variant = h->compact_layout ? 3 : (h->cfg.checker == PDMPC_CHECK_SAT ? 2 : (h->n_words != 1 ? 1 : 0));
     auto launch_search = [&](const KernelArgs* ka, int cnt) -> int {
         std::lock_guard<std::mutex> lock(g_lds_mutex);
         uint32_t* hw = &g_lds_high_water[h->cfg.device & 63][variant];
+        if (variant == 3) return pdmpc_launch_bulk_compact(ka, cnt, (void*)h->stream, hw);
         if (variant == 2) return pdmpc_launch_bulk_sat(ka, cnt, (void*)h->stream, hw);
         if (variant == 1) return pdmpc_launch_bulk_wide(ka, cnt, (void*)h->stream, hw);
         return pdmpc_launch_bulk(ka, cnt, (void*)h->stream, hw);
@@ -850,7 +906,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(PDMPC_ERR_NO_DEVICE, "no HIP device visible: this backend has no CPU fallback");
     if (config->device < 0 || config->device >= ndev) return fail(PDMPC_ERR_NO_DEVICE, "device ordinal out of range");
-    HIPCHK(hipSetDevice(config->device));
+    ON_DEVICE(config->device);
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, config->device));
     if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
@@ -892,7 +948,7 @@ int pdmpc_create(const pdmpc_config* config, pdmpc_handle** out_handle) {
 
 int pdmpc_destroy(pdmpc_handle* h) {
     if (!h) return PDMPC_OK;
-    (void)hipSetDevice(h->cfg.device);
+    DeviceGuard device_guard__(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto& ev : h->events) {
         (void)hipEventDestroy(ev.first);
@@ -937,7 +993,7 @@ int pdmpc_upload_mpa(pdmpc_handle* h, const pdmpc_mpa* mpa) {
     if (mpa->n_trims < 1 || mpa->n_trims > 1023) return fail(PDMPC_ERR_INVALID, "n_trims must be in 1..1023");
     if (mpa->Hp < h->cfg.Hp) return fail(PDMPC_ERR_INVALID, "mpa.Hp smaller than config.Hp");
     if (!mpa->transition || !mpa->maneuver_index || (mpa->n_maneuvers > 0 && !mpa->maneuvers)) return fail(PDMPC_ERR_INVALID, "null table");
-    HIPCHK(hipSetDevice(h->cfg.device));
+    ON_DEVICE(h->cfg.device);
     const int n = mpa->n_trims, Hp = h->cfg.Hp;
     const int nw = (n + 63) / 64;
     std::vector<uint64_t> mask((size_t)Hp * n * nw + 2, 0);
@@ -987,20 +1043,22 @@ int pdmpc_upload_mpa(pdmpc_handle* h, const pdmpc_mpa* mpa) {
 }
 
 int pdmpc_pack_batch(pdmpc_handle* h, int32_t n, const pdmpc_vehicle_in* in) {
-    if (h) HIPCHK(hipSetDevice(h->cfg.device));
+    if (!h) return fail(PDMPC_ERR_INVALID, "null handle");
+    ON_DEVICE(h->cfg.device);
     return pack_common(h, n, in, nullptr, nullptr, nullptr);
 }
 
 int pdmpc_pack_step(pdmpc_handle* h, int32_t n, const pdmpc_vehicle_in* in, const int32_t* pred_offset, const int32_t* pred_index,
                     const pdmpc_polygon_set* fallback_shapes) {
-    if (h) HIPCHK(hipSetDevice(h->cfg.device));
+    if (!h) return fail(PDMPC_ERR_INVALID, "null handle");
+    ON_DEVICE(h->cfg.device);
     if (pred_offset && !pred_index) return fail(PDMPC_ERR_INVALID, "pred_index missing");
     return pack_common(h, n, in, pred_offset, pred_index, fallback_shapes);
 }
 
 int pdmpc_launch_packed(pdmpc_handle* h) {
     if (!h) return fail(PDMPC_ERR_INVALID, "null handle");
-    HIPCHK(hipSetDevice(h->cfg.device));
+    ON_DEVICE(h->cfg.device);
     h->epoch += 1;  // a new step: results of earlier launches no longer satisfy predecessor waits
     return launch_range(h, 0, h->banks[h->bank].n_packed, h->safe_launches);
 }
@@ -1027,8 +1085,11 @@ int pdmpc_select_bank(pdmpc_handle* h, int32_t bank) {
 
 int pdmpc_reset_stats(pdmpc_handle* h) {
     if (!h) return fail(PDMPC_ERR_INVALID, "null handle");
+    ON_DEVICE(h->cfg.device);
     HIPCHK(hipStreamSynchronize(h->stream));
     h->events_used = 0;
+    h->folded_kernel_ms = 0.0;
+    h->folded_launches = 0;
     HIPCHK(hipMemsetAsync(h->d_tie_count.p, 0, 4 * sizeof(int32_t), h->stream));
     HIPCHK(hipMemsetAsync(h->d_work_count.p, 0, 16 * sizeof(unsigned long long), h->stream));
     return PDMPC_OK;
@@ -1036,12 +1097,13 @@ int pdmpc_reset_stats(pdmpc_handle* h) {
 
 int pdmpc_launch_range(pdmpc_handle* h, int32_t first, int32_t count) {
     if (!h) return fail(PDMPC_ERR_INVALID, "null handle");
-    HIPCHK(hipSetDevice(h->cfg.device));
+    ON_DEVICE(h->cfg.device);
     return launch_range(h, first, count, h->safe_launches);
 }
 
 int pdmpc_synchronize(pdmpc_handle* h) {
     if (!h) return fail(PDMPC_ERR_INVALID, "null handle");
+    ON_DEVICE(h->cfg.device);
     HIPCHK(sync_stream(h));
     return PDMPC_OK;
 }
@@ -1049,7 +1111,7 @@ int pdmpc_synchronize(pdmpc_handle* h) {
 int pdmpc_fetch_results(pdmpc_handle* h, int32_t n, pdmpc_vehicle_out* out) {
     if (!h || (n > 0 && !out)) return fail(PDMPC_ERR_INVALID, "null argument");
     if (n < 0 || n > h->max_vehicles) return fail(PDMPC_ERR_INVALID, "bad record count");
-    HIPCHK(hipSetDevice(h->cfg.device));
+    ON_DEVICE(h->cfg.device);
     PackedStep& B = h->banks[h->bank];
     const bool permuted = !B.perm.empty();
     if (permuted && n != B.n_packed) return fail(PDMPC_ERR_INVALID, "a batch that pdmpc_pack_step put into level order is fetched as a whole");
@@ -1099,7 +1161,7 @@ int plan_packed_growing(pdmpc_handle* h, int32_t n, pdmpc_vehicle_out* out) {
     for (;;) {
         const bool dbg = h->tune.debug_host == 1;
         if (dbg) fprintf(stderr, "pdmpc: launching %d vehicles, arena %u nodes%s\n", n, h->max_nodes, safe ? " (resident slices)" : "");
-        HIPCHK(hipSetDevice(h->cfg.device));
+        ON_DEVICE(h->cfg.device);
         h->epoch += 1;  // a new step: results of earlier launches no longer satisfy predecessor waits
         const auto t0 = std::chrono::steady_clock::now();
         int rc = launch_range(h, 0, h->banks[h->bank].n_packed, safe);
@@ -1253,7 +1315,7 @@ int pdmpc_set_arena_limit(pdmpc_handle* h, int32_t max_nodes_limit) {
 
 int pdmpc_grow_arena(pdmpc_handle* h, int32_t max_nodes) {
     if (!h || max_nodes <= 0) return fail(PDMPC_ERR_INVALID, "bad argument");
-    HIPCHK(hipSetDevice(h->cfg.device));
+    ON_DEVICE(h->cfg.device);
     if ((uint32_t)max_nodes <= h->max_nodes) return PDMPC_OK;
     HIPCHK(hipStreamSynchronize(h->stream));
     const uint32_t before = h->max_nodes;
@@ -1284,7 +1346,7 @@ int pdmpc_plan_batch_sampled(pdmpc_handle* h, int32_t n, const pdmpc_vehicle_in*
     int rc = pdmpc_pack_batch(h, n, in);
     if (rc) return rc;
     if (n == 0) return PDMPC_OK;
-    HIPCHK(hipSetDevice(h->cfg.device));
+    ON_DEVICE(h->cfg.device);
     const int per = h->cfg.Hp * 250;  // Hp * n_expansions_max                             MonteCarloTreeSearch.m:53
     std::vector<double> rnd((size_t)n * per);
     for (int i = 0; i < n; ++i) mt19937ar_doubles(seeds[i], per, rnd.data() + (size_t)i * per);
@@ -1311,7 +1373,7 @@ int pdmpc_import_results(pdmpc_handle* h, int32_t first, int32_t n, const void* 
     if (!h || (n > 0 && !dev_records)) return fail(PDMPC_ERR_INVALID, "null argument");
     if (!h->banks[h->bank].perm.empty()) return fail(PDMPC_ERR_INVALID, "the packed batch was put into level order by the library: raw slots are not the caller's vehicles (pack it in level order to use the device-resident record path)");
     if (first < 0 || n < 0 || first + n > h->max_vehicles) return fail(PDMPC_ERR_INVALID, "slot range out of bounds");
-    HIPCHK(hipSetDevice(h->cfg.device));
+    ON_DEVICE(h->cfg.device);
     if (n == 0) return PDMPC_OK;
     const void* dst = (const void*)(h->d_out.p + first);
     if (dev_records != dst)
@@ -1324,7 +1386,7 @@ int pdmpc_export_results(pdmpc_handle* h, int32_t first, int32_t n, void* dev_re
     if (!h || (n > 0 && !dev_records)) return fail(PDMPC_ERR_INVALID, "null argument");
     if (!h->banks[h->bank].perm.empty()) return fail(PDMPC_ERR_INVALID, "the packed batch was put into level order by the library: raw slots are not the caller's vehicles (pack it in level order to use the device-resident record path)");
     if (first < 0 || n < 0 || first + n > h->max_vehicles) return fail(PDMPC_ERR_INVALID, "slot range out of bounds");
-    HIPCHK(hipSetDevice(h->cfg.device));
+    ON_DEVICE(h->cfg.device);
     if (n > 0) HIPCHK(hipMemcpyAsync(dev_records, h->d_out.p + first, (size_t)n * sizeof(pdmpc_vehicle_out), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return PDMPC_OK;
@@ -1334,7 +1396,7 @@ int pdmpc_export_results_async(pdmpc_handle* h, int32_t first, int32_t n, void* 
     if (!h || (n > 0 && !dev_records)) return fail(PDMPC_ERR_INVALID, "null argument");
     if (!h->banks[h->bank].perm.empty()) return fail(PDMPC_ERR_INVALID, "the packed batch was put into level order by the library: raw slots are not the caller's vehicles (pack it in level order to use the device-resident record path)");
     if (first < 0 || n < 0 || first + n > h->max_vehicles) return fail(PDMPC_ERR_INVALID, "slot range out of bounds");
-    HIPCHK(hipSetDevice(h->cfg.device));
+    ON_DEVICE(h->cfg.device);
     if (n > 0) HIPCHK(hipMemcpyAsync(dev_records, h->d_out.p + first, (size_t)n * sizeof(pdmpc_vehicle_out), hipMemcpyDeviceToDevice, h->stream));
     return PDMPC_OK;
 }
@@ -1347,7 +1409,7 @@ int pdmpc_stream(pdmpc_handle* h, void** hip_stream) {
 
 int pdmpc_debug_counters(pdmpc_handle* h, uint64_t* out16) {
     if (!h || !out16) return fail(PDMPC_ERR_INVALID, "null argument");
-    HIPCHK(hipSetDevice(h->cfg.device));
+    ON_DEVICE(h->cfg.device);
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(out16, h->d_work_count.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return PDMPC_OK;
@@ -1355,16 +1417,16 @@ int pdmpc_debug_counters(pdmpc_handle* h, uint64_t* out16) {
 
 int pdmpc_get_last_stats(pdmpc_handle* h, pdmpc_stats* stats) {
     if (!h || !stats) return fail(PDMPC_ERR_INVALID, "null argument");
-    HIPCHK(hipSetDevice(h->cfg.device));
+    ON_DEVICE(h->cfg.device);
     HIPCHK(hipStreamSynchronize(h->stream));
-    double ms = 0.0;
+    double ms = h->folded_kernel_ms;
     for (size_t i = 0; i < h->events_used; ++i) {
         float t = 0.f;
         HIPCHK(hipEventElapsedTime(&t, h->events[i].first, h->events[i].second));
         ms += t;
     }
     h->stats.kernel_ms = ms;
-    h->stats.n_launches = (int64_t)h->events_used;
+    h->stats.n_launches = h->folded_launches + (int64_t)h->events_used;
     int32_t ctr[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpy(ctr, h->d_tie_count.p, sizeof ctr, hipMemcpyDeviceToHost));
     h->stats.queue_fallbacks = ctr[0];
@@ -1388,7 +1450,7 @@ int pdmpc_debug_heap_script(pdmpc_handle* h, int32_t n, const int32_t* op, const
                             int32_t* popped, int32_t* n_popped, double* cycles_per_pop, double* cycles_per_push) {
     if (!h || n < 0 || (n > 0 && (!op || !id || !key)) || !popped || !n_popped) return fail(PDMPC_ERR_INVALID, "null argument");
     if (lds_entries < 64 || lds_entries > 8192 || (lds_entries & 1)) return fail(PDMPC_ERR_INVALID, "lds_entries must be even and in 64..8192");
-    HIPCHK(hipSetDevice(h->cfg.device));
+    ON_DEVICE(h->cfg.device);
     int32_t *d_op = nullptr, *d_id = nullptr, *d_out = nullptr;
     double *d_key = nullptr, *d_gkey = nullptr;
     uint32_t* d_gid = nullptr;
@@ -1523,7 +1585,7 @@ int pdmpc_debug_pop_trace(pdmpc_handle* h, int32_t vehicle, int32_t capacity, in
     if (!h || !ids || !n) return fail(PDMPC_ERR_INVALID, "null argument");
     if (vehicle < 0 || vehicle >= h->max_vehicles) return fail(PDMPC_ERR_INVALID, "vehicle slot out of range");
     if (!h->banks[h->bank].inv.empty() && vehicle < h->banks[h->bank].n_packed) vehicle = h->banks[h->bank].inv[(size_t)vehicle];  // (the batch was put into level order)
-    HIPCHK(hipSetDevice(h->cfg.device));
+    ON_DEVICE(h->cfg.device);
     HIPCHK(hipStreamSynchronize(h->stream));
     {
         int32_t sz = 0;
@@ -1550,7 +1612,7 @@ int pdmpc_debug_edge_check(pdmpc_handle* h, int32_t mode, int32_t n_cases, const
         if (na < 0 || na > PDMPC_VMAX) return fail(PDMPC_ERR_INVALID, "first operand: at most PDMPC_VMAX columns");
         if (nb < 0 || nb > 1024) return fail(PDMPC_ERR_INVALID, "second operand: at most 1024 columns");
     }
-    HIPCHK(hipSetDevice(h->cfg.device));
+    ON_DEVICE(h->cfg.device);
     const size_t ta = (size_t)a_off[n_cases], tb = (size_t)b_off[n_cases];
     // (DevBuf-style owners: every early return frees what was allocated)
     struct Owned {
@@ -1591,7 +1653,7 @@ int pdmpc_debug_raw_tree(pdmpc_handle* h, int32_t vehicle, int32_t capacity, dou
     if (!h || !n) return fail(PDMPC_ERR_INVALID, "null argument");
     if (vehicle < 0 || vehicle >= h->max_vehicles) return fail(PDMPC_ERR_INVALID, "vehicle slot out of range");
     if (!h->banks[h->bank].inv.empty() && vehicle < h->banks[h->bank].n_packed) vehicle = h->banks[h->bank].inv[(size_t)vehicle];  // (the batch was put into level order)
-    HIPCHK(hipSetDevice(h->cfg.device));
+    ON_DEVICE(h->cfg.device);
     HIPCHK(hipStreamSynchronize(h->stream));
     int32_t sz = 0;
     HIPCHK(hipMemcpy(&sz, h->d_tree_size.p + vehicle, 4, hipMemcpyDeviceToHost));
@@ -1629,7 +1691,7 @@ int pdmpc_debug_tree(pdmpc_handle* h, int32_t vehicle, int32_t capacity, double*
     if (!h || !n) return fail(PDMPC_ERR_INVALID, "null argument");
     if (vehicle < 0 || vehicle >= h->max_vehicles) return fail(PDMPC_ERR_INVALID, "vehicle slot out of range");
     if (!h->banks[h->bank].inv.empty() && vehicle < h->banks[h->bank].n_packed) vehicle = h->banks[h->bank].inv[(size_t)vehicle];  // (the batch was put into level order)
-    HIPCHK(hipSetDevice(h->cfg.device));
+    ON_DEVICE(h->cfg.device);
     HIPCHK(hipStreamSynchronize(h->stream));
     int32_t sz = 0;
     HIPCHK(hipMemcpy(&sz, h->d_tree_size.p + vehicle, 4, hipMemcpyDeviceToHost));

@@ -2613,8 +2613,11 @@ __device__ __forceinline__ void bulk_body(const KernelArgs& A) {
 // One kernel per (checker, successor-mask words) in a translation unit of its own (bulk_kernel.hip: InterX, one mask word — every
 // BASELINE road-network configuration; bulk_kernel_wide.hip: InterX, automata of more than 64 trims; bulk_kernel_sat.hip: the
 // separating-axis checker, any automaton), so that they compile side by side and each gets its own register allocation.
+#ifndef PDMPC_BULK_KERNEL_ATTR
+#define PDMPC_BULK_KERNEL_ATTR
+#endif
 #define PDMPC_BULK_KERNEL(NAME, LAUNCHER, NW, CHECKER, MAXWAVES)                                                                                   \
-    extern "C" __global__ __launch_bounds__(PDMPC_WAVE * (MAXWAVES)) void NAME(const KernelArgs A) { bulk_body<NW, CHECKER>(A); }             \
+    extern "C" __global__ __launch_bounds__(PDMPC_WAVE * (MAXWAVES)) PDMPC_BULK_KERNEL_ATTR void NAME(const KernelArgs A) { bulk_body<NW, CHECKER>(A); } \
     extern "C" int LAUNCHER(const KernelArgs* args, int count, void* stream, uint32_t* lds_high_water) {                                \
         if (count <= 0) return 0;                                                                                                        \
         typedef void (*kernel_t)(const KernelArgs);                                                                                      \

@@ -15,7 +15,13 @@
 //   - a component that outweighs the mean load per device (or every component, PDMPC_SHARD_LEVELS) is planned by all devices level
 //     by level: the level's slots block-partitioned, pdmpc_launch_range per device, all-gather, pdmpc_import_results of the other
 //     devices' blocks, next level — everything enqueued on the streams, the host waits once per step.
-// librccl is loaded with dlopen when the first group is created: the single-GPU library has no link-time dependency on it.
+// librccl is loaded with dlopen when the first group that needs it is created: the single-GPU library has no link-time dependency on it.
+//
+// The exchange sits behind a function table (struct Collective): RCCL's all-gather between the distinct devices of a group, or the
+// same all-gather as peer copies ordered by events on the handles' streams (PDMPC_COLLECTIVE_COPY) — which also works between
+// LOGICAL ranks that share a physical device (two handles, two streams, two sets of arenas on one GPU), so every line of the
+// multi-rank protocol (slot remapping, block partition of a level, import of the other ranks' blocks) runs on a 1-GPU box
+// (tests/test_group.py).  Every entry point leaves the caller's current device as it found it (DeviceScope).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -25,6 +31,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <numeric>
@@ -84,11 +91,24 @@ bool load_rccl(std::string& err) {
     return true;
 }
 
+// the caller's current device, put back on every exit path (torch takes its current device from hipGetDevice)
+struct DeviceScope {
+    int prev = -1;
+    DeviceScope() {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    }
+    ~DeviceScope() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
 // ---------------------------------------------------------------------------------------------------------------
 // Partition (pure host logic; pdmpc_group_partition exposes it).
 
 struct Partition {
-    std::vector<std::vector<int>> parts;  // per device: the slots (caller's indices, ascending) of its whole components
+    std::vector<std::vector<int>> parts;  // per device: the slots (caller's indices) of its whole components, in level order
     std::vector<int> shared;              // slots of the component planned by levels over all devices, in LEVEL ORDER
     std::vector<int> level_sizes;         // ... and its computation levels
     std::vector<int> level_of;            // [n] computation level (1-based) within the whole problem's coupling DAG
@@ -201,7 +221,13 @@ int make_partition(int n, const int32_t* off, const int32_t* idx, const double* 
         for (int s : comp[(size_t)c]) P.parts[(size_t)r].push_back(s);
         load[(size_t)r] += weight(c);
     }
-    for (auto& p : P.parts) std::sort(p.begin(), p.end());
+    // a device's slots in LEVEL ORDER (ascending caller index within a level): the sub-problem handed to pdmpc_pack_step then has its
+    // predecessors in lower slots whatever order the caller's slots are in, so the handle does not permute it and the device-resident
+    // record path (pdmpc_export_results_async) applies; group_fetch scatters back through these lists
+    for (auto& p : P.parts) {
+        std::sort(p.begin(), p.end());
+        std::stable_sort(p.begin(), p.end(), [&](int a, int b) { return P.level_of[(size_t)a] < P.level_of[(size_t)b]; });
+    }
     // the shared component in level order (levels by longest path, ascending vehicle index within a level: find(levels == i))
     if (!P.shared.empty()) {
         std::stable_sort(P.shared.begin(), P.shared.end(), [&](int a, int b) { return P.level_of[(size_t)a] < P.level_of[(size_t)b]; });
@@ -248,11 +274,24 @@ const size_t kRec = sizeof(pdmpc_vehicle_out);
 
 }  // namespace
 
+struct pdmpc_group;
+namespace {
+// the exchange between the ranks of a group: `per` records from every rank's send buffer into every rank's receive buffer
+// (rank r's block at r * per), enqueued on the handles' streams
+struct Collective {
+    const char* name;
+    int (*all_gather)(pdmpc_group* g, size_t per);
+};
+}  // namespace
+
 struct pdmpc_group {
     std::vector<int> dev;
     std::vector<pdmpc_handle*> h;
     std::vector<hipStream_t> stream;
     std::vector<ncclComm_t> comm;
+    const Collective* coll = nullptr;
+    std::vector<hipEvent_t> ev_sent, ev_got;  // copy collective: rank r's block is ready / rank r has copied every block
+    int last_bank = -1;                       // the bank whose records recv[] / shared_buf hold (pdmpc_group_fetch)
     std::vector<unsigned char*> send, recv;  // per device: its block of records / every device's block
     size_t send_cap = 0;                      // records per block the buffers hold
     unsigned char* shared_buf = nullptr;      // device 0: the records of the component planned by levels
@@ -328,14 +367,45 @@ int ensure_buffers(pdmpc_group* g, size_t per, size_t n_shared) {
     return PDMPC_OK;
 }
 
-// one all-gather of `per` records per device over the whole group, on the handles' streams
-int all_gather(pdmpc_group* g, size_t per) {
+// one all-gather of `per` records per device over the whole group, on the handles' streams: RCCL ...
+int all_gather_rccl(pdmpc_group* g, size_t per) {
     const size_t world = g->h.size();
     GNCCL(g_rccl.GroupStart());
     for (size_t r = 0; r < world; ++r) GNCCL(g_rccl.AllGather(g->send[r], g->recv[r], per * kRec, ncclChar, g->comm[r], g->stream[r]));
     GNCCL(g_rccl.GroupEnd());
     return PDMPC_OK;
 }
+// ... or peer copies.  Rank q's stream waits for every rank's block (an event per rank, recorded behind its export), copies the
+// blocks into its own receive buffer, and says so; a rank's stream goes on (its next export overwrites its send buffer) once
+// everybody has copied.  Nothing waits on the host.
+int all_gather_copy(pdmpc_group* g, size_t per) {
+    const size_t world = g->h.size();
+    for (size_t r = 0; r < world; ++r) {
+        GHIP(hipSetDevice(g->dev[r]));
+        GHIP(hipEventRecord(g->ev_sent[r], g->stream[r]));
+    }
+    for (size_t q = 0; q < world; ++q) {
+        GHIP(hipSetDevice(g->dev[q]));
+        for (size_t r = 0; r < world; ++r) {
+            if (r != q) GHIP(hipStreamWaitEvent(g->stream[q], g->ev_sent[r], 0));
+            unsigned char* dst = g->recv[q] + r * per * kRec;
+            if (g->dev[q] == g->dev[r])
+                GHIP(hipMemcpyAsync(dst, g->send[r], per * kRec, hipMemcpyDeviceToDevice, g->stream[q]));
+            else
+                GHIP(hipMemcpyPeerAsync(dst, g->dev[q], g->send[r], g->dev[r], per * kRec, g->stream[q]));
+        }
+        GHIP(hipEventRecord(g->ev_got[q], g->stream[q]));
+    }
+    for (size_t r = 0; r < world; ++r) {
+        GHIP(hipSetDevice(g->dev[r]));
+        for (size_t q = 0; q < world; ++q)
+            if (q != r) GHIP(hipStreamWaitEvent(g->stream[r], g->ev_got[q], 0));
+    }
+    return PDMPC_OK;
+}
+const Collective kCollRccl = {"rccl", all_gather_rccl};
+const Collective kCollCopy = {"copy", all_gather_copy};
+inline int all_gather(pdmpc_group* g, size_t per) { return g->coll->all_gather(g, per); }
 
 using clk = std::chrono::steady_clock;
 inline double ms_between(clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); }
@@ -347,6 +417,7 @@ int group_pack(pdmpc_group* g, int bank, int n, const pdmpc_vehicle_in* in, cons
     if ((size_t)bank >= g->plans.size()) g->plans.resize((size_t)bank + 1);
     pdmpc_group::Plan& L = g->plans[(size_t)bank];
     L.valid = false;
+    if (g->last_bank == bank) g->last_bank = -1;
     L.n = n;
     Partition& P = L.P;
     GRC(make_partition(n, off, idx, weights, world, mode, P));
@@ -436,6 +507,7 @@ int group_launch(pdmpc_group* g, int bank) {
     const auto t3 = clk::now();
     for (int r = 0; r < world; ++r) GRC(pdmpc_synchronize(g->h[(size_t)r]));
     for (int r = 0; r < world; ++r) GRC(pdmpc_select_bank(g->h[(size_t)r], 0));
+    g->last_bank = bank;
     g->timing[3] = ms_between(t2, t3);
     g->timing[4] = ms_between(t3, clk::now());
     return PDMPC_OK;
@@ -447,6 +519,8 @@ int group_fetch(pdmpc_group* g, int bank, int n, pdmpc_vehicle_out* out) {
     const auto t4 = clk::now();
     const pdmpc_group::Plan& L = g->plans[(size_t)bank];
     if (n != L.n) return gfail(PDMPC_ERR_INVALID, "pdmpc_group_fetch: the bank holds another number of vehicles");
+    // the gathered records are those of the bank launched last, whatever bank is asked for
+    if (bank != g->last_bank) return gfail(PDMPC_ERR_INVALID, "pdmpc_group_fetch: the records on the devices are those of the bank launched last; launch this bank first");
     const Partition& P = L.P;
     const int world = (int)g->h.size(), nS = (int)P.shared.size();
     bool any_whole = false;
@@ -497,20 +571,38 @@ int pdmpc_group_partition(int32_t n, const int32_t* pred_offset, const int32_t* 
     return PDMPC_OK;
 }
 
-int pdmpc_group_create(const pdmpc_config* config, int32_t n_devices, const int32_t* devices, pdmpc_group** out_group) {
+int pdmpc_group_create_ex(const pdmpc_config* config, int32_t n_devices, const int32_t* devices, int32_t collective, pdmpc_group** out_group) {
     if (!config || !out_group || n_devices < 1 || n_devices > 64) return gfail(PDMPC_ERR_INVALID, "pdmpc_group_create: bad argument");
+    if (collective != PDMPC_COLLECTIVE_AUTO && collective != PDMPC_COLLECTIVE_RCCL && collective != PDMPC_COLLECTIVE_COPY)
+        return gfail(PDMPC_ERR_INVALID, "pdmpc_group_create_ex: unknown collective");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return gfail(PDMPC_ERR_NO_DEVICE, "no HIP device visible: this backend has no CPU fallback");
-    std::string err;
-    if (!load_rccl(err)) return gfail(PDMPC_ERR_NO_DEVICE, err);
+    DeviceScope keep;
     pdmpc_group* g = new pdmpc_group();
+    bool repeated = false;
     for (int r = 0; r < n_devices; ++r) {
         const int d = devices ? devices[r] : r;
-        if (d < 0 || d >= ndev || std::find(g->dev.begin(), g->dev.end(), d) != g->dev.end()) {
+        if (d < 0 || d >= ndev) {
             pdmpc_group_destroy(g);
-            return gfail(PDMPC_ERR_NO_DEVICE, "pdmpc_group_create: device ordinal out of range or listed twice");
+            return gfail(PDMPC_ERR_NO_DEVICE, "pdmpc_group_create: device ordinal out of range");
         }
+        repeated = repeated || std::find(g->dev.begin(), g->dev.end(), d) != g->dev.end();
         g->dev.push_back(d);
+    }
+    // ranks that share a device are logical ranks: RCCL has one rank per device, the copy collective does not care
+    if (collective == PDMPC_COLLECTIVE_AUTO) {
+        const char* e = getenv("PDMPC_GROUP_COLLECTIVE");
+        collective = repeated ? PDMPC_COLLECTIVE_COPY : ((e && std::strcmp(e, "copy") == 0) ? PDMPC_COLLECTIVE_COPY : PDMPC_COLLECTIVE_RCCL);
+    }
+    if (repeated && collective == PDMPC_COLLECTIVE_RCCL) {
+        pdmpc_group_destroy(g);
+        return gfail(PDMPC_ERR_NO_DEVICE, "pdmpc_group_create: a device listed twice needs PDMPC_COLLECTIVE_COPY (RCCL has one rank per device)");
+    }
+    g->coll = collective == PDMPC_COLLECTIVE_COPY ? &kCollCopy : &kCollRccl;
+    std::string err;
+    if (g->coll == &kCollRccl && !load_rccl(err)) {
+        pdmpc_group_destroy(g);
+        return gfail(PDMPC_ERR_NO_DEVICE, err);
     }
     g->send.assign((size_t)n_devices, nullptr);
     g->recv.assign((size_t)n_devices, nullptr);
@@ -528,20 +620,56 @@ int pdmpc_group_create(const pdmpc_config* config, int32_t n_devices, const int3
         (void)pdmpc_stream(h, &st);
         g->stream.push_back((hipStream_t)st);
     }
-    g->comm.assign((size_t)n_devices, nullptr);
-    const ncclResult_t nr = g_rccl.CommInitAll(g->comm.data(), n_devices, g->dev.data());
-    if (nr != ncclSuccess) {
-        g->comm.clear();
-        pdmpc_group_destroy(g);
-        return gfail(PDMPC_ERR_HIP, std::string("ncclCommInitAll failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(nr) : "?"));
+    if (g->coll == &kCollRccl) {
+        g->comm.assign((size_t)n_devices, nullptr);
+        const ncclResult_t nr = g_rccl.CommInitAll(g->comm.data(), n_devices, g->dev.data());
+        if (nr != ncclSuccess) {
+            g->comm.clear();
+            pdmpc_group_destroy(g);
+            return gfail(PDMPC_ERR_HIP, std::string("ncclCommInitAll failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(nr) : "?"));
+        }
+    } else {
+        for (int r = 0; r < n_devices; ++r) {
+            hipEvent_t a = nullptr, b = nullptr;
+            if (hipSetDevice(g->dev[(size_t)r]) != hipSuccess || hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) {
+                if (a) (void)hipEventDestroy(a);
+                pdmpc_group_destroy(g);
+                return gfail(PDMPC_ERR_HIP, "pdmpc_group_create: hipEventCreate failed");
+            }
+            g->ev_sent.push_back(a);
+            g->ev_got.push_back(b);
+            // peer access between the distinct devices of the group (a copy between devices without it goes through the host)
+            for (int q = 0; q < n_devices; ++q)
+                if (g->dev[(size_t)q] != g->dev[(size_t)r]) {
+                    int can = 0;
+                    if (hipDeviceCanAccessPeer(&can, g->dev[(size_t)r], g->dev[(size_t)q]) == hipSuccess && can) {
+                        const hipError_t pe = hipDeviceEnablePeerAccess(g->dev[(size_t)q], 0);
+                        if (pe != hipSuccess) (void)hipGetLastError();  // (already enabled: fine)
+                    }
+                }
+        }
     }
     *out_group = g;
     return PDMPC_OK;
 }
 
+int pdmpc_group_create(const pdmpc_config* config, int32_t n_devices, const int32_t* devices, pdmpc_group** out_group) {
+    return pdmpc_group_create_ex(config, n_devices, devices, PDMPC_COLLECTIVE_AUTO, out_group);
+}
+
+int pdmpc_group_collective(pdmpc_group* g, int32_t* collective) {
+    if (!g || !collective) return gfail(PDMPC_ERR_INVALID, "null argument");
+    *collective = g->coll == &kCollCopy ? PDMPC_COLLECTIVE_COPY : PDMPC_COLLECTIVE_RCCL;
+    return PDMPC_OK;
+}
+
 int pdmpc_group_destroy(pdmpc_group* g) {
     if (!g) return PDMPC_OK;
+    DeviceScope keep;
     for (size_t r = 0; r < g->h.size(); ++r) (void)pdmpc_synchronize(g->h[r]);
+    for (hipEvent_t e : g->ev_sent) (void)hipEventDestroy(e);
+    for (hipEvent_t e : g->ev_got) (void)hipEventDestroy(e);
     for (ncclComm_t c : g->comm)
         if (c && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c);
     for (size_t r = 0; r < g->send.size(); ++r) {
@@ -572,6 +700,7 @@ int pdmpc_group_handle(pdmpc_group* g, int32_t rank, pdmpc_handle** handle) {
 
 int pdmpc_group_upload_mpa(pdmpc_group* g, const pdmpc_mpa* mpa) {
     if (!g || !mpa) return gfail(PDMPC_ERR_INVALID, "null argument");
+    DeviceScope keep;
     for (pdmpc_handle* h : g->h) GRC(pdmpc_upload_mpa(h, mpa));
     return PDMPC_OK;
 }
@@ -582,6 +711,7 @@ int pdmpc_group_plan_step(pdmpc_group* g, int32_t n, const pdmpc_vehicle_in* in,
     if (pred_offset && !pred_index) return gfail(PDMPC_ERR_INVALID, "pred_index missing");
     if (mode != PDMPC_SHARD_AUTO && mode != PDMPC_SHARD_COMPONENTS && mode != PDMPC_SHARD_LEVELS) return gfail(PDMPC_ERR_INVALID, "unknown sharding mode");
     if (n == 0) return PDMPC_OK;
+    DeviceScope keep;
     // The reference's tree is unbounded (Tree.m:54-70): a step in which some search outgrew its arena is planned again with arenas twice
     // as large on every device (as pdmpc_plan_step does for one).
     for (;;) {
@@ -593,11 +723,26 @@ int pdmpc_group_plan_step(pdmpc_group* g, int32_t n, const pdmpc_vehicle_in* in,
         bool overflow = false;
         for (int i = 0; i < n; ++i) overflow = overflow || out[i].status == PDMPC_ARENA_OVERFLOW;
         if (!overflow) return PDMPC_OK;
+        // (the devices' arenas may differ after a failed attempt to grow: the step fits when the SMALLEST arena holds every search)
         int32_t nodes = 0;
-        GRC(pdmpc_arena_nodes(g->h[0], &nodes, nullptr));
+        for (pdmpc_handle* h : g->h) {
+            int32_t nr = 0;
+            GRC(pdmpc_arena_nodes(h, &nr, nullptr));
+            nodes = nodes ? std::min(nodes, nr) : nr;
+        }
         if ((int64_t)nodes * 2 > (1ll << 30)) return PDMPC_OK;  // (statuses tell)
-        for (pdmpc_handle* h : g->h)
-            if (pdmpc_grow_arena(h, nodes * 2) != PDMPC_OK) return PDMPC_OK;  // no room to grow: statuses tell
+        for (size_t r = 0; r < g->h.size(); ++r) {
+            int32_t nr = 0;
+            GRC(pdmpc_arena_nodes(g->h[r], &nr, nullptr));
+            if (nr >= nodes * 2) continue;
+            if (pdmpc_grow_arena(g->h[r], nodes * 2) != PDMPC_OK) {
+                // no room to grow on this device: the records keep their PDMPC_ARENA_OVERFLOW statuses AND the error string says why
+                char b[160];
+                snprintf(b, sizeof b, "pdmpc_group_plan_step: the arenas of rank %zu (device %d) cannot grow to %d nodes per vehicle", r, g->dev[r], nodes * 2);
+                pdmpc_set_last_error(b);
+                return PDMPC_OK;
+            }
+        }
     }
 }
 
@@ -607,21 +752,25 @@ int pdmpc_group_pack_step(pdmpc_group* g, int32_t bank, int32_t n, const pdmpc_v
     if (bank < 0 || bank >= kGroupBanks) return gfail(PDMPC_ERR_INVALID, "pdmpc_group_pack_step: bank out of range");
     if (pred_offset && !pred_index) return gfail(PDMPC_ERR_INVALID, "pred_index missing");
     if (mode != PDMPC_SHARD_AUTO && mode != PDMPC_SHARD_COMPONENTS && mode != PDMPC_SHARD_LEVELS) return gfail(PDMPC_ERR_INVALID, "unknown sharding mode");
+    DeviceScope keep;
     return group_pack(g, bank, n, in, pred_offset, pred_index, fallback_shapes, weights, mode);
 }
 
 int pdmpc_group_launch(pdmpc_group* g, int32_t bank) {
     if (!g || bank < 0) return gfail(PDMPC_ERR_INVALID, "pdmpc_group_launch: bad argument");
+    DeviceScope keep;
     return group_launch(g, bank);
 }
 
 int pdmpc_group_fetch(pdmpc_group* g, int32_t bank, int32_t n, pdmpc_vehicle_out* out) {
     if (!g || bank < 0 || (n > 0 && !out)) return gfail(PDMPC_ERR_INVALID, "pdmpc_group_fetch: bad argument");
+    DeviceScope keep;
     return group_fetch(g, bank, n, out);
 }
 
 int pdmpc_group_grow_arena(pdmpc_group* g, int32_t max_nodes) {
     if (!g || max_nodes <= 0) return gfail(PDMPC_ERR_INVALID, "pdmpc_group_grow_arena: bad argument");
+    DeviceScope keep;
     for (pdmpc_handle* h : g->h) {
         int32_t nodes = 0;
         GRC(pdmpc_arena_nodes(h, &nodes, nullptr));

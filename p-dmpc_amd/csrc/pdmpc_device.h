@@ -90,20 +90,43 @@ struct LdsLayout {
 // immediates instead of holding two dozen LDS pointers in scalar registers it does not have (layout_bulk fills LdsLayout with the
 // same numbers; the automaton's tables, the soup, the validity bytes and the nodes follow at run-time offsets).
 #define PDMPC_LK_ALIGN16(x) (((x) + 15u) & ~15u)
-#define PDMPC_LK_THREADS ((uint32_t)PDMPC_MAX_WAVES * PDMPC_WAVE)
+// (W = wavefronts the layout is sized for, RC = entries of its ready list.  The product kernels: PDMPC_MAX_WAVES and 2048 — one
+// workgroup per CU; bulk_kernel_compact.hip: 8 and 1024, which with the automaton's areas left in L2 fits 80 KB — TWO workgroups per CU.
+// A translation unit sets PDMPC_LK_WAVES / PDMPC_LK_READY_CAP before it includes this header; the host lays out with pdmpc_lk_fixed().)
+#ifndef PDMPC_LK_WAVES
+#define PDMPC_LK_WAVES PDMPC_MAX_WAVES
+#endif
+#ifndef PDMPC_LK_READY_CAP
 #define PDMPC_LK_READY_CAP 2048u
-#define PDMPC_LK_REF 0u
-#define PDMPC_LK_SHAPE (PDMPC_LK_REF + 3u * PDMPC_HP_MAX * 8u)
-#define PDMPC_LK_PATH (PDMPC_LK_SHAPE + (uint32_t)PDMPC_MAX_WAVES * (2u * PDMPC_VMAX + 1u) * 16u)
-#define PDMPC_LK_CAND (PDMPC_LK_PATH + PDMPC_LK_ALIGN16((PDMPC_HP_MAX + 2u) * 4u + 2u * (PDMPC_HP_MAX + 1u) * 4u + PDMPC_SH_WORDS * 4u + PDMPC_HP_MAX * 4u))
-#define PDMPC_LK_EXPAND (PDMPC_LK_CAND + PDMPC_LK_ALIGN16(12u * PDMPC_LK_THREADS))
-#define PDMPC_LK_NEAR_KEY (PDMPC_LK_EXPAND + (2u * PDMPC_HP_MAX * PDMPC_HP_MAX) * 8u + 16u * 16u)
-#define PDMPC_LK_NEAR_ID (PDMPC_LK_NEAR_KEY + PDMPC_LK_ALIGN16(PDMPC_BK_PER * PDMPC_LK_THREADS * 8u))
-#define PDMPC_LK_READY (PDMPC_LK_NEAR_ID + PDMPC_LK_ALIGN16(PDMPC_BK_PER * PDMPC_LK_THREADS * 4u))
-#define PDMPC_LK_HIST (PDMPC_LK_READY + PDMPC_LK_READY_CAP * 8u)
-#define PDMPC_LK_MISC (PDMPC_LK_HIST + 3072u * 4u)
-#define PDMPC_LK_PSHAPE (PDMPC_LK_MISC + 2048u)
-#define PDMPC_LK_FIXED_END (PDMPC_LK_PSHAPE + PDMPC_LK_ALIGN16(PDMPC_HP_MAX * PDMPC_VMAX * 16u + PDMPC_HP_MAX * 4u + PDMPC_HP_MAX * 8u))
+#endif
+#define PDMPC_LK_COMPACT_WAVES 8
+#define PDMPC_LK_COMPACT_READY_CAP 1024u
+#define PDMPC_LKX_THREADS(W) ((uint32_t)(W) * PDMPC_WAVE)
+#define PDMPC_LKX_REF 0u
+#define PDMPC_LKX_SHAPE (PDMPC_LKX_REF + 3u * PDMPC_HP_MAX * 8u)
+#define PDMPC_LKX_PATH(W) (PDMPC_LKX_SHAPE + (uint32_t)(W) * (2u * PDMPC_VMAX + 1u) * 16u)
+#define PDMPC_LKX_CAND(W) (PDMPC_LKX_PATH(W) + PDMPC_LK_ALIGN16((PDMPC_HP_MAX + 2u) * 4u + 2u * (PDMPC_HP_MAX + 1u) * 4u + PDMPC_SH_WORDS * 4u + PDMPC_HP_MAX * 4u))
+#define PDMPC_LKX_EXPAND(W) (PDMPC_LKX_CAND(W) + PDMPC_LK_ALIGN16(12u * PDMPC_LKX_THREADS(W)))
+#define PDMPC_LKX_NEAR_KEY(W) (PDMPC_LKX_EXPAND(W) + (2u * PDMPC_HP_MAX * PDMPC_HP_MAX) * 8u + 16u * 16u)
+#define PDMPC_LKX_NEAR_ID(W) (PDMPC_LKX_NEAR_KEY(W) + PDMPC_LK_ALIGN16(PDMPC_BK_PER * PDMPC_LKX_THREADS(W) * 8u))
+#define PDMPC_LKX_READY(W) (PDMPC_LKX_NEAR_ID(W) + PDMPC_LK_ALIGN16(PDMPC_BK_PER * PDMPC_LKX_THREADS(W) * 4u))
+#define PDMPC_LKX_HIST(W, RC) (PDMPC_LKX_READY(W) + (uint32_t)(RC) * 8u)
+#define PDMPC_LKX_MISC(W, RC) (PDMPC_LKX_HIST(W, RC) + 3072u * 4u)
+#define PDMPC_LKX_PSHAPE(W, RC) (PDMPC_LKX_MISC(W, RC) + 2048u)
+#define PDMPC_LKX_FIXED_END(W, RC) (PDMPC_LKX_PSHAPE(W, RC) + PDMPC_LK_ALIGN16(PDMPC_HP_MAX * PDMPC_VMAX * 16u + PDMPC_HP_MAX * 4u + PDMPC_HP_MAX * 8u))
+#define PDMPC_LK_THREADS PDMPC_LKX_THREADS(PDMPC_LK_WAVES)
+#define PDMPC_LK_REF PDMPC_LKX_REF
+#define PDMPC_LK_SHAPE PDMPC_LKX_SHAPE
+#define PDMPC_LK_PATH PDMPC_LKX_PATH(PDMPC_LK_WAVES)
+#define PDMPC_LK_CAND PDMPC_LKX_CAND(PDMPC_LK_WAVES)
+#define PDMPC_LK_EXPAND PDMPC_LKX_EXPAND(PDMPC_LK_WAVES)
+#define PDMPC_LK_NEAR_KEY PDMPC_LKX_NEAR_KEY(PDMPC_LK_WAVES)
+#define PDMPC_LK_NEAR_ID PDMPC_LKX_NEAR_ID(PDMPC_LK_WAVES)
+#define PDMPC_LK_READY PDMPC_LKX_READY(PDMPC_LK_WAVES)
+#define PDMPC_LK_HIST PDMPC_LKX_HIST(PDMPC_LK_WAVES, PDMPC_LK_READY_CAP)
+#define PDMPC_LK_MISC PDMPC_LKX_MISC(PDMPC_LK_WAVES, PDMPC_LK_READY_CAP)
+#define PDMPC_LK_PSHAPE PDMPC_LKX_PSHAPE(PDMPC_LK_WAVES, PDMPC_LK_READY_CAP)
+#define PDMPC_LK_FIXED_END PDMPC_LKX_FIXED_END(PDMPC_LK_WAVES, PDMPC_LK_READY_CAP)
 
 struct NodeArena {  // HBM arrays, per-vehicle stride = max_nodes entries
     NodeRec* nodes;
@@ -124,6 +147,23 @@ struct NodeArena {  // HBM arrays, per-vehicle stride = max_nodes entries
 #define PDMPC_BK_PER 4
 #endif
 /* entries of the LDS open list per thread (a selection pass holds them in registers) */
+
+// the fixed part of the graph search's layout for (W wavefronts, ready list of RC entries): what the kernel built with those two
+// numbers addresses with immediates; returns the first free byte
+static inline uint32_t pdmpc_lk_fixed(uint32_t W, uint32_t RC, LdsLayout* L) {
+    L->ref = PDMPC_LKX_REF;
+    L->shape = PDMPC_LKX_SHAPE;
+    L->path = PDMPC_LKX_PATH(W);
+    L->cand = PDMPC_LKX_CAND(W);
+    L->expand = PDMPC_LKX_EXPAND(W);
+    L->bk_near_key = PDMPC_LKX_NEAR_KEY(W);
+    L->bk_near_id = PDMPC_LKX_NEAR_ID(W);
+    L->bk_ready = PDMPC_LKX_READY(W);
+    L->bk_hist = PDMPC_LKX_HIST(W, RC);
+    L->bk_misc = PDMPC_LKX_MISC(W, RC);
+    L->bk_pshape = PDMPC_LKX_PSHAPE(W, RC);
+    return PDMPC_LKX_FIXED_END(W, RC);
+}
 
 #define PDMPC_HELP_CAP 2048 /* entries of a round that can be shared (= the ready list's capacity) */
 /* a search's board (64-bit words): what its seated helper workgroups read and write (bulk_search.hpp) */
@@ -207,6 +247,8 @@ extern "C" {
 int pdmpc_launch_bulk(const KernelArgs* args, int count, void* stream, uint32_t* lds_high_water);
 int pdmpc_launch_bulk_wide(const KernelArgs* args, int count, void* stream, uint32_t* lds_high_water);
 int pdmpc_launch_bulk_sat(const KernelArgs* args, int count, void* stream, uint32_t* lds_high_water);
+// bulk_kernel_compact.hip: the InterX / one-mask-word kernel built for 8 wavefronts and at most 80 KB of LDS: two workgroups per CU
+int pdmpc_launch_bulk_compact(const KernelArgs* args, int count, void* stream, uint32_t* lds_high_water);
 // sampled_kernel.hip: the sampled optimizer (MonteCarloTreeSearch.m), `count` workgroups of one wavefront
 int pdmpc_launch_sampled(const KernelArgs* args, int count, void* stream);
 // debug_kernels.hip: the open-list command script on one wavefront, and the collision primitives on given polygons (one wavefront per case)

@@ -45,6 +45,8 @@ EXPORTS = [
     "pdmpc_stream",
     "pdmpc_get_last_stats",
     "pdmpc_group_create",
+    "pdmpc_group_create_ex",
+    "pdmpc_group_collective",
     "pdmpc_group_destroy",
     "pdmpc_group_size",
     "pdmpc_group_handle",
@@ -160,6 +162,7 @@ def _check(L, rc, what):
 
 
 SHARD_AUTO, SHARD_COMPONENTS, SHARD_LEVELS = 0, 1, 2
+COLLECTIVE_AUTO, COLLECTIVE_RCCL, COLLECTIVE_COPY = 0, 1, 2  # include/pdmpc.h: how the ranks of a group exchange their records
 
 
 def group_partition(preds, world, mode=SHARD_AUTO, weights=None):
@@ -183,7 +186,9 @@ class Group:
     """One pdmpc_group: a handle per GPU of this process, bound by an RCCL communicator; plan_step plans a time step over them
     (include/pdmpc.h: pdmpc_group_*)."""
 
-    def __init__(self, options, n_devices=1, devices=None, checker=None):
+    def __init__(self, options, n_devices=1, devices=None, checker=None, collective=COLLECTIVE_AUTO):
+        """devices: HIP ordinals of the ranks (None: 0 .. n_devices - 1).  A device listed more than once makes LOGICAL ranks that share
+        a GPU (collective = peer copies instead of RCCL): how the multi-rank protocol is exercised on a 1-GPU box."""
         self.L = load_library()
         self.options = options
         self.Hp = options.Hp
@@ -193,9 +198,13 @@ class Group:
                               trace_pops=0)
         self.g = C.c_void_p()
         devs = None if devices is None else (C.c_int32 * n_devices)(*devices)
-        self.L.pdmpc_group_create.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
-        _check(self.L, self.L.pdmpc_group_create(C.byref(self.cfg), n_devices, devs, C.byref(self.g)), "pdmpc_group_create")
+        self.L.pdmpc_group_create_ex.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+        _check(self.L, self.L.pdmpc_group_create_ex(C.byref(self.cfg), n_devices, devs, collective, C.byref(self.g)), "pdmpc_group_create_ex")
         self.n_devices = n_devices
+        c = C.c_int32(0)
+        self.L.pdmpc_group_collective.argtypes = [C.c_void_p, C.c_void_p]
+        _check(self.L, self.L.pdmpc_group_collective(self.g, C.byref(c)), "pdmpc_group_collective")
+        self.collective = {COLLECTIVE_RCCL: "rccl", COLLECTIVE_COPY: "copy"}[c.value]
         self._mpa_keep = None
 
     def close(self):
@@ -263,6 +272,18 @@ class Group:
             self.L.pdmpc_group_handle.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
             _check(self.L, self.L.pdmpc_group_handle(self.g, r, C.byref(h)), "pdmpc_group_handle")
             _check(self.L, self.L.pdmpc_reset_stats(h), "pdmpc_reset_stats")
+
+    def stats_all(self):
+        """Statistics over the whole group: counts summed over the ranks, kernel_ms / n_launches of the rank whose kernels ran longest
+        (the ranks' launches run side by side), per-rank values under "per_rank"."""
+        per = [self.stats(r) for r in range(self.n_devices)]
+        tot = dict(per[max(range(len(per)), key=lambda r: per[r]["kernel_ms"])])
+        for k in ("edge_checks", "segment_pair_tests", "nodes_processed", "rounds", "shared_rounds", "helper_checked", "bad_status_plans", "queue_fallbacks",
+                  "speculation_arrivals", "safe_replans"):
+            if k in tot:
+                tot[k] = sum(p[k] for p in per)
+        tot["per_rank"] = per
+        return tot
 
     def stats(self, rank=0):
         h = C.c_void_p()

@@ -10,13 +10,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "p-dmpc_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-SEARCH_KERNELS = ("pdmpc_bulk_kernel", "pdmpc_bulk_kernel_wide", "pdmpc_bulk_kernel_sat")
+SEARCH_KERNELS = ("pdmpc_bulk_kernel", "pdmpc_bulk_kernel_wide", "pdmpc_bulk_kernel_sat", "pdmpc_bulk_kernel_compact")
 
 
 @pytest.mark.timeout(900)
 def test_search_kernels_use_no_scratch_memory_and_spill_no_vgprs():
-    """the three instantiations of the graph search (InterX with one successor-mask word, InterX with any
-    number, the separating-axis checker) fit the register budget of their workgroups — sixteen wavefronts for the InterX kernels
+    """the instantiations of the graph search (InterX with one successor-mask word, InterX with any
+    number, the separating-axis checker, and the InterX kernel built for two workgroups per CU) fit the register budget of their workgroups — sixteen wavefronts for the InterX kernels
     (four per SIMD: 128 VGPRs), twelve for the separating-axis kernel (168) — without a byte of scratch memory.  `make resources` compiles every kernel with the flags of the build (the inliner's basic-block limit raised, no
     machine LICM for the search) and prints the compiler's resource remarks."""
     if not os.path.exists(HIPCC) and shutil.which("hipcc") is None:

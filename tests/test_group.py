@@ -162,3 +162,195 @@ def test_group_arenas_grow_by_themselves_or_on_request():
     assert_records_equal(grp.plan_step(iters, preds, None), ref, "pdmpc_group_plan_step grows the arenas by itself")
     grp.close()
     single.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# More than one rank.  Two or four LOGICAL ranks on the one GPU of the box: a handle, a stream and arenas each, the exchange as peer
+# copies ordered by events (PDMPC_COLLECTIVE_COPY behind the function table of csrc/group.cpp) — slot remapping per rank, block
+# partition of a level, export / all-gather / import of the other ranks' blocks, the scatter back into the caller's order: everything
+# a group of distinct devices executes except the transport.  (PrioritizedController.m:356-365 send, :476-491 read.)
+
+ALL_MODES = [backend.SHARD_COMPONENTS, backend.SHARD_LEVELS, backend.SHARD_AUTO]
+
+
+def _current_device():
+    import ctypes
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    d = ctypes.c_int(-1)
+    assert hip.hipGetDevice(ctypes.byref(d)) == 0
+    return d.value
+
+
+def _c3_like(amount=40, tiles=3, max_cls=3):
+    from pdmpc.config import Config, ScenarioType
+    from pdmpc.controller import PrioritizedSequentialController
+    from pdmpc.mpa import get_mpa
+    from pdmpc.optimizer import GraphSearchHip
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    options = Config(scenario_type=ScenarioType.commonroad, amount=amount, Hp=8, max_num_CLs=max_cls, max_vehicles=64, max_nodes=1 << 16)
+    mpa = get_mpa(options)
+    sc = commonroad_scenario(options, seed=1, tiles=tiles)
+    opt = GraphSearchHip(options)
+    opt._ensure_mpa(mpa)
+    ctl = PrioritizedSequentialController(options, sc, mpa, None, coupling="distance", boundary_provider=boundary_provider(sc), priority_strategy="coloring")
+    return options, mpa, opt, ctl
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("mode", ALL_MODES)
+def test_group_of_logical_ranks_c3_step(world, mode):
+    """A C3-like closed loop (tiled road network = several coupling-graph components, colouring, computation levels): every step through
+    a group of 2 / 4 ranks in all three modes, then as resident banks (pack_step / launch / fetch) launched repeatedly — records equal
+    to the single launch's, and the caller's current device untouched."""
+    from pdmpc.iteration_data import info_from_record
+    from test_gpu_parity import assert_records_equal
+
+    options, mpa, opt, ctl = _c3_like()
+    dev0 = _current_device()
+    grp = backend.Group(options, n_devices=world, devices=[0] * world)
+    assert grp.collective == "copy" and _current_device() == dev0
+    grp.upload_mpa(mpa)
+    kept, refs = [], []
+
+    def plan_step(prob):
+        fb = [f if f is not None else [] for f in prob["fallback"]]
+        ref = opt.handle.plan_step(prob["iters"], prob["preds"], fb)
+        weights = [int(p) + 1 for p in ref["n_popped"]]
+        got = grp.plan_step(prob["iters"], prob["preds"], fb, weights=weights, mode=mode)
+        assert_records_equal(got, ref, "group of %d logical ranks, mode %d, step %d" % (world, mode, len(kept)))
+        kept.append(prob)
+        refs.append(ref.copy())
+        return [info_from_record(ref[i], options.Hp) for i in range(len(prob["iters"]))]
+
+    for _ in range(5):
+        ctl.step(plan_step=plan_step)
+    assert _current_device() == dev0
+    # the split really is one: more than one rank plans something
+    rank_of, level_of, block = backend.group_partition(kept[-1]["preds"], world, mode)
+    busy = set(rank_of[rank_of >= 0].tolist()) | set(block[block >= 0].tolist())
+    assert len(busy) >= 2, (rank_of, block)
+    # resident banks
+    for b, prob in enumerate(kept[-3:]):
+        fb = [f if f is not None else [] for f in prob["fallback"]]
+        grp.pack_step(b, prob["iters"], prob["preds"], fb, weights=[int(p) + 1 for p in refs[-3 + b]["n_popped"]], mode=mode)
+    for rep in range(2):
+        for b, prob in enumerate(kept[-3:]):
+            grp.launch(b)
+            assert_records_equal(grp.fetch(b, len(prob["iters"])), refs[-3 + b], "resident bank %d of %d logical ranks, pass %d" % (b, world, rep))
+    # the devices hold the records of the bank launched last: another bank's fetch is refused, not mis-scattered
+    with pytest.raises(backend.BackendError):
+        grp.fetch(0, len(kept[-3]["iters"]))
+    st = grp.stats_all()
+    assert st["bad_status_plans"] == 0 and len(st["per_rank"]) == world and _current_device() == dev0
+    grp.close()
+    opt.handle.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_group_of_logical_ranks_c5_batch(world):
+    """C5's shape: the prioritization instances of an explorative step are components of their batch and are dealt out over the ranks
+    (PrioritizedExplorativeController.m:25-176); one all-gather ends the step.  Records and the chosen prioritization equal the single
+    launch's."""
+    from pdmpc.config import Config, ScenarioType
+    from pdmpc.controller import PrioritizedSequentialController
+    from pdmpc.explorative import build_exploration_batch, choose_solution
+    from pdmpc.mpa import get_mpa
+    from pdmpc.optimizer import GraphSearchHip
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+    from test_gpu_parity import assert_records_equal
+
+    K = 12
+    options = Config(scenario_type=ScenarioType.commonroad, amount=20, Hp=8, max_vehicles=20 * K, max_nodes=1 << 15)
+    mpa = get_mpa(options)
+    sc = commonroad_scenario(options, seed=1)
+    opt = GraphSearchHip(options)
+    ctl = PrioritizedSequentialController(options, sc, mpa, None, coupling="distance", boundary_provider=boundary_provider(sc))
+    for _ in range(3):
+        ctl.step(plan_step=lambda prob: opt.run_optimizer_step(prob, mpa))
+    batch = build_exploration_batch(ctl, K, seed=4)
+    fb = [f if f is not None else [] for f in batch["fallback"]]
+    ref = opt.handle.plan_step(batch["iters"], batch["preds"], fb)
+    grp = backend.Group(options, n_devices=world, devices=[0] * world)
+    grp.upload_mpa(mpa)
+    for mode in (backend.SHARD_COMPONENTS, backend.SHARD_AUTO):
+        got = grp.plan_step(batch["iters"], batch["preds"], fb, weights=[int(p) + 1 for p in ref["n_popped"]], mode=mode)
+        assert_records_equal(got, ref, "explorative batch over %d logical ranks, mode %d" % (world, mode))
+        a, ca = choose_solution(batch, got, options.Hp)
+        b, cb = choose_solution(batch, ref, options.Hp)
+        assert a == b and np.array_equal(ca, cb)
+    rank_of, _, _ = backend.group_partition(batch["preds"], world, backend.SHARD_COMPONENTS)
+    assert len(set(rank_of.tolist())) == world
+    grp.close()
+    opt.handle.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ALL_MODES)
+def test_group_of_logical_ranks_tied_search(mode):
+    """Equal keys (a mirror-symmetric vehicle: the result depends on the binary heap's layout, priority_queue_interface_mex.cpp:19-31)
+    behind a long search of another rank: the replay through the heap happens on whichever rank owns the vehicle, its predecessor's
+    areas arrive through the exchange (levels) or on the device (components)."""
+    import problems
+    from pdmpc.optimizer import GraphSearchHip
+    from test_gpu_parity import assert_records_equal
+
+    options = problems.make_options("interx", Hp=8)
+    options.max_vehicles = 8
+    options.max_nodes = 1 << 16
+    mpa = problems.get_mpa(options)
+    rng = np.random.default_rng(2)
+    heavy = max((problems.road_problem(rng, options, mpa) for _ in range(12)), key=lambda it: len(it.dynamic_obstacle_area) + len(it.obstacles))
+    sym = problems.symmetric_problem(options, mpa, block_x=0.5)
+    # two components: {0, 1, 2} chained and {3, 4} chained; levels of width two and one
+    iters = [heavy, sym, sym, sym, heavy]
+    preds = [[], [0], [0, 1], [], [3]]
+    opt = GraphSearchHip(options)
+    opt._ensure_mpa(mpa)
+    ref = opt.handle.plan_step(iters, preds, [[] for _ in iters])
+    assert opt.handle.stats()["queue_fallbacks"] > 0
+    grp = backend.Group(options, n_devices=2, devices=[0, 0])
+    grp.upload_mpa(mpa)
+    got = grp.plan_step(iters, preds, [[] for _ in iters], mode=mode)
+    assert_records_equal(got, ref, "tied searches over two logical ranks, mode %d" % mode)
+    assert grp.stats_all()["queue_fallbacks"] > 0
+    grp.close()
+    opt.handle.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [backend.SHARD_COMPONENTS, backend.SHARD_AUTO, backend.SHARD_LEVELS])
+def test_group_accepts_any_slot_order(mode):
+    """include/pdmpc.h: "any slot order".  The caller's slots shuffled (predecessors in HIGHER slots): a rank's sub-problem is built in
+    level order, so the handle does not permute it and the device-resident record path applies."""
+    from test_gpu_parity import assert_records_equal
+
+    options, mpa, opt, ctl = _c3_like(amount=30, tiles=2)
+    kept = []
+
+    def plan_step(prob):
+        kept.append(prob)
+        return opt.run_optimizer_step(prob, mpa)
+
+    for _ in range(3):
+        ctl.step(plan_step=plan_step)
+    prob = kept[-1]
+    n = len(prob["iters"])
+    assert any(prob["preds"])
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(n)  # new slot s holds old slot perm[s]
+    inv = np.argsort(perm)
+    iters = [prob["iters"][int(o)] for o in perm]
+    preds = [sorted(int(inv[p]) for p in prob["preds"][int(o)]) for o in perm]
+    fb = [prob["fallback"][int(o)] if prob["fallback"][int(o)] is not None else [] for o in perm]
+    assert any(p > s for s, ps in enumerate(preds) for p in ps)  # some predecessor sits in a higher slot
+    ref = opt.handle.plan_step(iters, preds, fb)
+    grp = backend.Group(options, n_devices=2, devices=[0, 0])
+    grp.upload_mpa(mpa)
+    got = grp.plan_step(iters, preds, fb, mode=mode)
+    assert_records_equal(got, ref, "shuffled slots, mode %d" % mode)
+    grp.close()
+    opt.handle.close()
