@@ -97,11 +97,17 @@ def record_steps(options, mpa, ctl, optimizer, n_skip, n_record, explore_instanc
     recorded problem is the flattened batch of that many prioritizations of the step's traffic state (config c5); the
     closed loop itself advances with the controller's own prioritization."""
     problems = []
+    last = {}  # vehicle -> nodes its search popped in the step before (what a closed-loop caller knows when it packs the next step)
 
     def plan_step(prob):
         problems.append(prob)
+        # expected work per slot = the work of the same vehicle's search in the PREVIOUS time step (pdmpc_set_step_weights: the
+        # dispatch order of the launch; never this step's own pops)
+        prob["prev_pops"] = [last.get(v, 0) + 1 for v in prob["order"]]
         infos = optimizer.run_optimizer_step(prob, mpa)
         prob["pops"] = [int(i.n_popped) for i in infos]  # the work each vehicle's search took (weights of the multi-GPU partition)
+        for v, p in zip(prob["order"], prob["pops"]):
+            last[v] = p
         return infos
 
     batches = []
@@ -109,7 +115,9 @@ def record_steps(options, mpa, ctl, optimizer, n_skip, n_record, explore_instanc
         if explore_instances and k >= n_skip:
             from pdmpc.explorative import build_exploration_batch
 
-            batches.append(build_exploration_batch(ctl, explore_instances, seed=ctl.k + 1))
+            batch = build_exploration_batch(ctl, explore_instances, seed=ctl.k + 1)
+            batch["prev_pops"] = [last.get(v, 0) + 1 for v in batch["vehicle"]]
+            batches.append(batch)
         ctl.step(plan_step=plan_step)
     return batches if explore_instances else problems[n_skip:]
 
@@ -201,14 +209,16 @@ def measure_replay(h, problems, steps, warmup, one_step, dist, torch, reset_extr
     return elapsed, lat
 
 
-def pack_banks(h, problems, first_bank=0):
+def pack_banks(h, problems, first_bank=0, use_weights=True):
     """Keeps every recorded step resident in HBM (one bank each); returns per-bank records, algorithmic bytes, pops, nodes."""
     recs_per_bank, bytes_per_bank, pops_per_bank, nodes_per_bank = [], [], [], []
     t_grow = 0.0
     for b, prob in enumerate(problems):
         h.select_bank(first_bank + b)
         fb = [f if f is not None else [] for f in prob["fallback"]]
-        h.pack_step(prob["iters"], prob["preds"], fb)
+        # (the work of the step before as expected work: the launch fills its slots by priority, pdmpc_set_step_weights; the
+        # one-process-per-GPU twin exchanges raw slots between ranks and keeps level order)
+        h.pack_step(prob["iters"], prob["preds"], fb, weights=prob.get("prev_pops") if use_weights else None)
         while True:
             h.launch()
             recs = h.fetch(len(prob["iters"]))
@@ -357,7 +367,7 @@ def main():
                 gmode = backend.SHARD_LEVELS if args.shard == "levels" else backend.SHARD_COMPONENTS
                 for b, prob in enumerate(problems):
                     grp.pack_step(b, prob["iters"], prob["preds"], [f if f is not None else [] for f in prob["fallback"]],
-                                  weights=[w + 1 for w in prob["pops"]] if "pops" in prob else None, mode=gmode)
+                                  weights=prob.get("prev_pops"), mode=gmode)  # (LPT and dispatch order on the work of the step BEFORE)
                     grp.launch(b)
                 ok = [1]
             except Exception as e:  # noqa: BLE001 (whatever went wrong: the other path is still there)
@@ -380,7 +390,7 @@ def main():
     # keep every recorded step resident in HBM (one bank each) and collect its algorithmic bytes
     h.allow_overflow = True  # statuses are checked below, per bank
     t_host = time.perf_counter()
-    bank_recs, bytes_per_bank, pops_per_bank, nodes_per_bank, t_grow = pack_banks(h, problems)
+    bank_recs, bytes_per_bank, pops_per_bank, nodes_per_bank, t_grow = pack_banks(h, problems, use_weights=dist is None)
     status_counts = {"ok": 0, "exhausted": 0, "arena_overflow": 0, "error": 0}
     for recs in bank_recs:
         status_counts["ok"] += int((recs["status"] == 0).sum())

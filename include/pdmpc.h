@@ -216,12 +216,20 @@ int pdmpc_launch_packed(pdmpc_handle* handle);
 int pdmpc_launch_range(pdmpc_handle* handle, int32_t first, int32_t count);
 int pdmpc_fetch_results(pdmpc_handle* handle, int32_t n_vehicles, pdmpc_vehicle_out* out);
 int pdmpc_synchronize(pdmpc_handle* handle);
-/* Forward progress of launches with more searches than compute units.  A search spins for predecessors of the same launch; slots
- * are in level order (pdmpc_pack_step reorders a batch that is not), so a launch whose workgroups are dispatched in index order
- * cannot stall.  Should one stall anyway, the kernel's watchdog ends the waiting searches with status PDMPC_ERR_HIP and
- * pdmpc_plan_batch / pdmpc_plan_step plan the call again in slices that are resident as a whole (predecessors in the same or an
- * earlier slice): counted in pdmpc_stats.safe_replans.  on != 0 makes every launch of this handle use those slices from the start
- * (the device-resident path below does not re-plan by itself). */
+/* Forward progress of launches with more searches than resident workgroups (256 CUs x 1 workgroup; x 2 with the compact kernel).
+ * A search spins for predecessors of the same launch.  Every predecessor sits in a lower slot (pdmpc_pack_step puts a batch into a
+ * topological order of its coupling DAG — level order, or priority order with pdmpc_set_step_weights — unless it is in one already),
+ * so as long as the hardware hands workgroups out IN INDEX ORDER whoever a search waits for was dispatched before it and the launch
+ * cannot stall.  THAT ORDER IS AN ASSUMPTION about the dispatcher (observed on gfx950 / ROCm 7, not a documented guarantee).
+ * Should a launch stall anyway, the kernel's watchdog (spin limit) ends the waiting searches with status PDMPC_ERR_HIP.
+ * Which entry points recover by themselves:
+ *   pdmpc_plan_batch, pdmpc_plan_step, pdmpc_plan_step_literal, pdmpc_controller_step / _run / _explore_*  — plan the call again in
+ *     slices that are resident as a whole (predecessors in the same or an earlier slice: no assumption left), counted in
+ *     pdmpc_stats.safe_replans;
+ *   pdmpc_launch_packed, pdmpc_launch_range, pdmpc_group_launch, pdmpc_group_plan_step (the resident paths)  — do NOT: the records
+ *     carry the error status (pdmpc_stats.bad_status_plans counts them on the device) and the caller decides.
+ * pdmpc_set_safe_launch(on != 0) makes every launch of this handle, resident paths included, use the resident slices from the start.
+ * Tested against the adversarial order with PDMPC_TUNING=reverse_dispatch=1 (tests/test_gpu_step.py). */
 int pdmpc_set_safe_launch(pdmpc_handle* handle, int32_t on);
 /* starts a new time step for launches issued with pdmpc_launch_range: results of earlier steps stop
  * satisfying predecessor waits (pdmpc_launch_packed does this implicitly) */
@@ -238,6 +246,13 @@ int pdmpc_reset_stats(pdmpc_handle* handle);
  * on the device to the vehicle's dynamic obstacles (PrioritizedController.m:476-491) before it plans.
  * fallback_shapes (may be NULL) gives, per vehicle, the Hp areas published when its search is
  * exhausted (PrioritizedController.m:568-616,678-718): [n][Hp] pdmpc_polygon_set-style via offsets. */
+/* Expected work per vehicle of the NEXT packed step (n = its vehicle count, the caller's vehicle order; e.g. n_popped of the previous
+ * time step), consumed by the next pdmpc_pack_step / pdmpc_plan_step / pdmpc_pack_batch.  With it, a launch of the whole step hands its
+ * searches out by priority — the largest expected work among a vehicle and its descendants in the coupling DAG, descending — instead
+ * of slot order: still a topological order (whoever a search waits for was dispatched before it), but in a launch of more searches
+ * than CUs the heavy searches of late computation levels start with the launch instead of behind the finished searches that wait for
+ * their predecessors.  Slots, records and results are the same bit for bit.  Optional: without it searches go out in slot order. */
+int pdmpc_set_step_weights(pdmpc_handle* handle, int32_t n_vehicles, const double* weights);
 int pdmpc_pack_step(pdmpc_handle* handle, int32_t n_vehicles, const pdmpc_vehicle_in* in,
                     const int32_t* pred_offset, const int32_t* pred_index,
                     const pdmpc_polygon_set* fallback_shapes);

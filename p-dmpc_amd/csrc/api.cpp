@@ -15,6 +15,7 @@
 #include <chrono>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -164,7 +165,7 @@ struct Tuning {
     int ramp = -1;          // a round grows by 1 / ramp of the nodes processed so far (-1: 2 with helper workgroups, else 4)
     int ready = 2048;       // entries of the ready list with helper workgroups (half of it without): the most a round can take
     int share_min = -1;     // a round with at least this many nodes is shared with the helper workgroups (-1: by the number of helpers per search, launch_range)
-    int own_div = 8;        // the owner of a shared round starts on 1 / own_div of its tiles
+    int own_div = 8;        // (accepted, no effect since round 5: the owner takes an equal share of a shared round)
     int tile = -1;          // the most nodes of a shared round one seated helper takes (-1: 256; what it stages in LDS: at most 768)
     int mid_min = 24576;    // far lists longer than this feed near through the mid list (a band of far's smallest keys)
     int mid_fill = 12288;   // entries a refill of mid aims at
@@ -175,7 +176,9 @@ struct Tuning {
     int seat_nodes = 256;   // a search may hold its share of the launch's helpers (helpers / searches) per this many nodes it has processed
     int helpers_first = -1; // ... of them dispatched in front of the searches (-1: half the CUs when most searches of the launch have predecessors)
     int speculate = 1;      // 0: every search waits for all its predecessors before it starts
-    int compact = -1;       // 1: the kernel built for two workgroups per CU (8 wavefronts, <= 80 KB of LDS: bulk_kernel_compact.hip) where it applies (InterX, one mask word, the soup fits); 0: never; -1: for launches of more searches than CUs
+    int dispatch_order = 1; // 0: ignore pdmpc_set_step_weights (slots in level order, never by priority)
+    int fast_select = 1;    // 0: every selection goes through the sixteen-wavefront histogram, also while the open set is small (A/B)
+    int compact = -1;       // 1: the kernel built for two workgroups per CU (8 wavefronts, <= 80 KB of LDS: bulk_kernel_compact.hip) where it applies (InterX, one mask word, the soup fits); 0: never; -1: for launches of more than two searches per CU; 2-5: layout experiments (one workgroup per CU with the compact kernel, slack behind the layout)
     int waves = -1;         // wavefronts per workgroup (4 .. PDMPC_MAX_WAVES; -1: 16 for the InterX kernels — 12 for a launch of more than two searches per CU —, 12 for the separating-axis kernel)
     uint32_t spin_limit = 1u << 22;  // the watchdog's limit of polls / rounds (debugging: fail fast)
     int force_tie = 0;      // testing only: every search ends on the replay through the reference's binary heap (as if it had met equal keys)
@@ -193,7 +196,7 @@ bool parse_tuning(const char* text, Tuning& T, std::string& err) {
     int spin = (int)T.spin_limit;
     const Key keys[] = {{"round0", &T.round0}, {"round", &T.round}, {"ramp", &T.ramp}, {"ready", &T.ready}, {"share_min", &T.share_min}, {"own_div", &T.own_div},
                         {"tile", &T.tile}, {"mid_min", &T.mid_min}, {"mid_fill", &T.mid_fill}, {"tentative", &T.tentative}, {"fast_arrival", &T.fast_arrival}, {"helpers_first", &T.helpers_first}, {"seat_nodes", &T.seat_nodes},
-                        {"helpers", &T.helpers}, {"helpers_oversub", &T.helpers_oversub}, {"speculate", &T.speculate}, {"waves", &T.waves}, {"compact", &T.compact}, {"spin_limit", &spin},
+                        {"helpers", &T.helpers}, {"helpers_oversub", &T.helpers_oversub}, {"speculate", &T.speculate}, {"waves", &T.waves}, {"compact", &T.compact}, {"fast_select", &T.fast_select}, {"dispatch_order", &T.dispatch_order}, {"spin_limit", &spin},
                         {"force_tie", &T.force_tie}, {"reverse_dispatch", &T.reverse_dispatch}, {"debug_tail", &T.debug_tail}, {"debug_lds", &T.debug_lds},
                         {"debug_host", &T.debug_host}, {"debug_progress", &T.debug_progress}};
     std::string str(text ? text : "");
@@ -289,6 +292,7 @@ struct pdmpc_handle {
     uint64_t sync_serial = 0;            // stream synchronisations through sync_stream so far (PackedStep::staged_serial)
     std::vector<double> pack_pts;        // pack_common's scratch (kept: a pack allocates nothing once warm)
     std::vector<int32_t> pack_pred;
+    std::vector<double> next_weights;    // pdmpc_set_step_weights: expected work per vehicle of the NEXT packed step (the caller's order); consumed by that pack
     std::vector<DevVehicle> pack_veh;
     PinnedBuf<pdmpc_vehicle_out> h_out;  // pdmpc_fetch_results: the records land in pinned memory (a copy into the caller's pageable array goes through the runtime's staging otherwise)
     int bk_ready_launch = 2048;          // entries of the ready list of the last layout
@@ -330,11 +334,11 @@ inline hipError_t sync_stream(pdmpc_handle* h) {
 // as many node records as fit.
 bool layout_bulk(pdmpc_handle* h, size_t budget, int n_waves, int areas, int soup_cap, LdsLayout& L, uint32_t& nv, uint32_t& nl, uint32_t ready_cap, bool compact) {
     (void)n_waves;
-    const uint32_t lk_waves = compact ? PDMPC_LK_COMPACT_WAVES : PDMPC_MAX_WAVES, lk_ready = compact ? PDMPC_LK_COMPACT_READY_CAP : 2048u;
+    const uint32_t lk_waves = compact ? PDMPC_LK_COMPACT_WAVES : PDMPC_MAX_WAVES, lk_ready = compact ? PDMPC_LK_COMPACT_READY_CAP : 2048u, lk_per = compact ? PDMPC_LK_COMPACT_BK_PER : PDMPC_BK_PER;
     if (ready_cap > lk_ready || (uint32_t)n_waves > lk_waves) return false;
     // the regions of fixed size at the kernel's compile-time offsets (pdmpc_device.h: PDMPC_LK_*) ...
     // ... the automaton's tables and the soup behind them
-    uint32_t off = pdmpc_lk_fixed(lk_waves, lk_ready, &L);
+    uint32_t off = pdmpc_lk_fixed(lk_waves, lk_ready, lk_per, &L);
     L.mask = off;
     off = align16(off + (uint32_t)h->mask_bytes);
     L.man_index = off;
@@ -373,19 +377,25 @@ int compute_lds_bulk(pdmpc_handle* h, int n_launch, int soup_cap) {
     // Sixteen wavefronts where the kernel's registers allow four per SIMD (measured against twelve: C2 +1.5 %, C3 +1.3 %, C4 +7.5 %;
     // C5, five light searches per CU one after the other, -1.7 %: it keeps twelve and the LDS-resident nodes that go with them)
     const int cap = h->cfg.checker == PDMPC_CHECK_SAT ? PDMPC_MAX_WAVES_SAT : PDMPC_MAX_WAVES;
-    // Two workgroups per CU (bulk_kernel_compact.hip: 8 wavefronts, at most half the LDS, the automaton's areas in L2) for launches of
-    // more searches than CUs: every search holds half a CU, so twice as many are resident from the start and a finished search that
-    // waits for its predecessors blocks half as much.  InterX with one mask word only; falls back to the full layout if the soup is too large.
-    const bool want_compact = h->cfg.checker == PDMPC_CHECK_INTERX && h->n_words == 1 && (h->tune.compact > 0 || (h->tune.compact < 0 && n_launch > h->n_cu));
+    // Two workgroups per CU (bulk_kernel_compact.hip: 8 wavefronts, at most half the LDS, a near list of 1 024 entries, the automaton's
+    // areas in L2) for launches of more than two searches per CU — C5's class: light searches one after the other on every CU, each
+    // bound by the latency of its own passes; two side by side fill each other's gaps (C5 557 -> 710 steps/s).  NOT for launches whose
+    // step is one heavy search (C4, 512 searches: 94.6 -> 31 steps/s with it — half the lanes, a quarter of the near list, rounds of
+    // 240 entries that are never shared).  InterX with one mask word only; falls back to the full layout if the soup does not fit.
+    const bool want_compact = h->cfg.checker == PDMPC_CHECK_INTERX && h->n_words == 1 && (h->tune.compact > 0 || (h->tune.compact < 0 && n_launch > 2 * h->n_cu));
     h->compact_layout = false;
     if (want_compact) {
         LdsLayout L{};
         uint32_t nv = 0, nl = 0;
         const int waves = h->tune.waves >= 0 ? std::min(h->tune.waves, PDMPC_LK_COMPACT_WAVES) : PDMPC_LK_COMPACT_WAVES;
         const int ready = std::min(std::min(h->bk_ready_launch, 3 * PDMPC_WAVE * waves), (int)PDMPC_LK_COMPACT_READY_CAP);
-        if (layout_bulk(h, kLdsMax / 2, waves, 0, soup_cap, L, nv, nl, (uint32_t)ready, true)) {
+        // (compact=2, debugging: the compact kernel with the whole CU's LDS, i.e. ONE workgroup per CU — its layout without the co-residency)
+        // (compact=3: a little more than half — still one workgroup per CU, but with the small budget's few LDS-resident nodes)
+        if (layout_bulk(h, h->tune.compact == 2 ? kLdsMax : (h->tune.compact == 3 ? kLdsMax / 2 + 4096 : (h->tune.compact == 5 ? kLdsMax / 2 - 4096 : kLdsMax / 2)), waves, 0, soup_cap, L, nv, nl, (uint32_t)ready, true)) {
+            if (h->tune.compact == 5) L.total += 4096;  // (debugging: two workgroups per CU with 4 KB of slack behind the layout)
+            if (h->tune.compact == 4) L.total += 4096;  // (debugging: the half-CU layout, allocated too large for two workgroups per CU)
             if (h->tune.debug_lds)
-                fprintf(stderr, "pdmpc LDS layout (compact): launch %d waves %d near %u ready %d nv %u nl %u total %u\n", n_launch, waves, PDMPC_BK_PER * (uint32_t)waves * PDMPC_WAVE, ready, nv, nl, L.total);
+                fprintf(stderr, "pdmpc LDS layout (compact): launch %d waves %d near %u ready %d nv %u nl %u total %u\n", n_launch, waves, PDMPC_LK_COMPACT_BK_PER * (uint32_t)waves * PDMPC_WAVE, ready, nv, nl, L.total);
             h->bk_ready_launch = ready;
             h->lds = L;
             h->n_waves = waves;
@@ -496,6 +506,14 @@ int pack_common(pdmpc_handle* h, int n, const pdmpc_vehicle_in* in, const int32_
     // and pdmpc_fetch_results hands the records back in the caller's order.
     B.perm.clear();
     B.inv.clear();
+    // Priority order (pdmpc_set_step_weights).  Workgroups are handed out in index order, and a launch of more searches than CUs
+    // starts its later workgroups when earlier ones end: in level order a heavy search of a late level starts late — behind finished
+    // searches that hold their CUs while they wait for predecessors (C4: 2.5-4 ms into a 10 ms step).  With an expected work per
+    // vehicle the slots are filled by PRIORITY instead: the largest expected work among a vehicle and its descendants in the coupling
+    // DAG, descending; ties by level, then by the caller's index.  A predecessor's priority is at least its successors' and its level
+    // is lower, so this is a topological order too — every predecessor in a lower slot: the forward-progress argument holds
+    // unchanged — and the records go back in the caller's order as for any batch the library reorders.
+    const bool by_priority = h->tune.dispatch_order && (int)h->next_weights.size() == n && n > 1 && pred_offset != nullptr;
     if (pred_offset) {
         bool ordered = true;
         for (int i = 0; i < n && ordered; ++i)
@@ -504,7 +522,7 @@ int pack_common(pdmpc_handle* h, int n, const pdmpc_vehicle_in* in, const int32_
                 if (ps < 0 || ps >= h->max_vehicles) return fail(PDMPC_ERR_INVALID, "predecessor slot out of range");
                 if (ps < n && ps >= i) ordered = false;
             }
-        if (!ordered) {
+        if (!ordered || by_priority) {
             std::vector<int32_t> level(n, 0), indeg(n, 0), succ_off(n + 1, 0), succ, queue;
             for (int i = 0; i < n; ++i)
                 for (int q = pred_offset[i]; q < pred_offset[i + 1]; ++q)
@@ -535,12 +553,44 @@ int pack_common(pdmpc_handle* h, int n, const pdmpc_vehicle_in* in, const int32_
             if ((int)queue.size() != n) return fail(PDMPC_ERR_INVALID, "the sequential coupling graph has a cycle");
             B.perm.resize((size_t)n);
             for (int i = 0; i < n; ++i) B.perm[(size_t)i] = i;
-            std::stable_sort(B.perm.begin(), B.perm.end(), [&](int32_t x, int32_t y) { return level[x] < level[y]; });
-            B.inv.resize((size_t)n);
-            for (int sl = 0; sl < n; ++sl) B.inv[(size_t)B.perm[(size_t)sl]] = sl;
+            if (by_priority) {
+                std::vector<double> prio((size_t)n);
+                for (int i = 0; i < n; ++i) {
+                    const double w = h->next_weights[(size_t)i];
+                    prio[(size_t)i] = (w == w && w > 0) ? w : 0.0;
+                }
+                for (size_t qi = queue.size(); qi-- > 0;) {  // (reverse topological order: a vehicle after all its successors)
+                    const int u = queue[qi];
+                    for (int q = succ_off[u]; q < succ_off[u + 1]; ++q) prio[(size_t)u] = std::max(prio[(size_t)u], prio[(size_t)succ[(size_t)q]]);
+                }
+                std::stable_sort(B.perm.begin(), B.perm.end(), [&](int32_t x, int32_t y) {
+                    if (prio[(size_t)x] != prio[(size_t)y]) return prio[(size_t)x] > prio[(size_t)y];
+                    return level[x] < level[y];
+                });
+            } else {
+                std::stable_sort(B.perm.begin(), B.perm.end(), [&](int32_t x, int32_t y) { return level[x] < level[y]; });
+            }
+            bool identity = true;
+            for (int i = 0; i < n && identity; ++i) identity = B.perm[(size_t)i] == i;
+            if (identity) {
+                B.perm.clear();  // (the caller's order is the order wanted: raw slots are the caller's vehicles)
+            } else {
+                B.inv.resize((size_t)n);
+                for (int sl = 0; sl < n; ++sl) B.inv[(size_t)B.perm[(size_t)sl]] = sl;
+            }
         }
     }
+    h->next_weights.clear();
     const bool permuted = !B.perm.empty();
+    // Vehicles that hand over THE SAME ARRAYS (same pointers, same counts: the prioritization instances of an explorative step share
+    // every input but the predecessor lists, PrioritizedExplorativeController.m:25-91; step_controller.cpp builds one set per distinct
+    // content) share one copy of their soups in the pool: a vehicle seen before takes over the offsets of the first one.
+    struct SoupKey {
+        const void* p[13];
+        int32_t c[6];
+        bool operator<(const SoupKey& o) const { return std::memcmp(this, &o, sizeof(SoupKey)) < 0; }
+    };
+    std::map<SoupKey, int> seen_soup;
     for (int slot_i = 0; slot_i < n; ++slot_i) {
         const int i = slot_i;  // (slot: index into the packed arrays)
         const int vi = permuted ? B.perm[(size_t)slot_i] : slot_i;  // (the caller's vehicle)
@@ -574,6 +624,37 @@ int pack_common(pdmpc_handle* h, int n, const pdmpc_vehicle_in* in, const int32_
             if (ps < 0 || ps >= h->max_vehicles) return fail(PDMPC_ERR_INVALID, "predecessor slot out of range");
             pred.push_back(permuted && ps < n ? B.inv[(size_t)ps] : ps);
         }
+        SoupKey key;
+        std::memset(&key, 0, sizeof key);
+        {
+            const pdmpc_polygon_set* fbv = (fallback && fallback[vi].n_polygons > 0) ? &fallback[vi] : nullptr;
+            const void* ptrs[13] = {v.obstacles.offset, v.obstacles.x, v.obstacles.y, v.dynamic_obstacles.offset, v.dynamic_obstacles.x, v.dynamic_obstacles.y, v.hdv_reachable_sets.offset,
+                                    v.hdv_reachable_sets.x, v.left_x, v.right_x, fbv ? fbv->offset : nullptr, fbv ? fbv->x : nullptr, fbv ? fbv->y : nullptr};
+            for (int q = 0; q < 13; ++q) key.p[q] = ptrs[q];
+            key.c[0] = v.obstacles.n_polygons;
+            key.c[1] = v.dynamic_obstacles.n_polygons;
+            key.c[2] = v.hdv_reachable_sets.n_polygons;
+            key.c[3] = v.n_left;
+            key.c[4] = v.n_right;
+            key.c[5] = fbv ? fbv->n_polygons : 0;
+        }
+        const auto seen = seen_soup.find(key);
+        if (seen != seen_soup.end() && (v.left_y == in[permuted ? B.perm[(size_t)seen->second] : seen->second].left_y) && (v.right_y == in[permuted ? B.perm[(size_t)seen->second] : seen->second].right_y) &&
+            (v.hdv_reachable_sets.y == in[permuted ? B.perm[(size_t)seen->second] : seen->second].hdv_reachable_sets.y)) {
+            const DevVehicle& f = veh[(size_t)seen->second];  // (validated when it was packed)
+            std::memcpy(d.lit_off, f.lit_off, sizeof d.lit_off);
+            std::memcpy(d.hdv_off, f.hdv_off, sizeof d.hdv_off);
+            std::memcpy(d.fb_off, f.fb_off, sizeof d.fb_off);
+            d.ll_off = f.ll_off;
+            d.ll_len = f.ll_len;
+            B.lit_cols[i] = B.lit_cols[(size_t)seen->second];
+            const int need = (d.lit_off[Hp] - d.lit_off[0]) + Hp * n_pred * PDMPC_VMAX + (d.hdv_off[Hp] - d.hdv_off[0]) + d.ll_len;
+            soup_cap = std::max(soup_cap, need);
+            for (int k = 0; k < Hp; ++k)
+                cand_cap = std::max(cand_cap, (d.lit_off[k + 1] - d.lit_off[k]) + n_pred * PDMPC_VMAX + (d.hdv_off[k + 1] - d.hdv_off[k]) + d.ll_len);
+            continue;
+        }
+        seen_soup.emplace(key, i);
         const int n_dyn = v.dynamic_obstacles.n_polygons / Hp;
         const int n_hdv = v.hdv_reachable_sets.n_polygons / Hp;
         auto append_poly = [&](const pdmpc_polygon_set& s, int p, bool sep) {
@@ -744,16 +825,18 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     a.progress = h->progress;
     a.speculate = T.speculate;
     a.reverse_dispatch = (!safe && T.reverse_dispatch) ? 1 : 0;
+
     // rounds: measured on C2 / C3 (20 / 128 searches, helpers): cap 256, ramp 4 -> 646 / 589 steps/s; 512, 2 -> 735 / 786; 1000, 2 -> 769 / 909; 1000, 1 -> 620 / 772
     const bool helped = search && !safe && bulk_has_helpers(h, count);
     a.bk_ready_cap = std::min(h->bk_ready_launch, 3 * PDMPC_WAVE * h->n_waves);  // (the verdict pass handles three entries per thread)
     a.bk_round0 = T.round0 > 0 ? T.round0 : 24;  // (C3's class: below, once the helpers are counted)
     a.bk_round = std::min(h->bk_ready_launch / 2 - 16, std::max(a.bk_round0, T.round > 0 ? T.round : (helped ? 1000 : 256)));
     a.bk_ramp = T.ramp > 0 ? T.ramp : (helped ? 2 : 4);
-    a.own_div = T.own_div;
+    a.bk_flags = T.fast_select ? 1 : 0;
     a.bk_mid_min = T.mid_min;
     a.bk_mid_fill = T.mid_fill;
     a.bk_tile = T.tile > 0 ? T.tile : 256;
+    if (h->compact_layout) a.bk_tile = std::min(a.bk_tile, 256);  // (a helper stages its range in the near list's room: 12 KB in the compact layout)
     a.bk_tentative = T.tentative;
     a.bk_fast_arrival = T.fast_arrival;
     a.bk_seat_nodes = std::max(1, T.seat_nodes);
@@ -1054,6 +1137,12 @@ int pdmpc_pack_step(pdmpc_handle* h, int32_t n, const pdmpc_vehicle_in* in, cons
     ON_DEVICE(h->cfg.device);
     if (pred_offset && !pred_index) return fail(PDMPC_ERR_INVALID, "pred_index missing");
     return pack_common(h, n, in, pred_offset, pred_index, fallback_shapes);
+}
+
+int pdmpc_set_step_weights(pdmpc_handle* h, int32_t n, const double* weights) {
+    if (!h || n < 0 || (n > 0 && !weights)) return fail(PDMPC_ERR_INVALID, "pdmpc_set_step_weights: bad argument");
+    h->next_weights.assign(weights, weights + n);
+    return PDMPC_OK;
 }
 
 int pdmpc_launch_packed(pdmpc_handle* h) {

@@ -1,31 +1,39 @@
-// bulk_kernel.hip — the optimal graph search as bulk-synchronous passes over a round of open nodes.
+// bulk_search.hpp — the optimal graph search (GraphSearch.m:23-196) as bulk-synchronous passes over a round of open nodes; the helper
+// workgroups that share a search's large rounds; the kernel body.  Instantiated in bulk_kernel.hip (InterX, one successor-mask word:
+// every BASELINE road-network configuration), bulk_kernel_wide.hip (InterX, automata of more than 64 trims), bulk_kernel_sat.hip (the
+// separating-axis checker) and bulk_kernel_compact.hip (InterX, one word, fixed LDS regions sized for 8 wavefronts: two workgroups
+// per CU for launches of more searches than CUs).
 //
-// Same closed form of the reference's pop order as frontier_kernel.hip (GraphSearch.m:53-107; see the header of that file and
-// DESIGN.md section 3.2): any processing order gives the reference's result as long as every generated node that comes before
-// the goal G has been evaluated in the end; ids, n_popped and the tree size are counted afterwards (phase B).  What differs is
-// how a round is executed.  The frontier kernel hands one node to one wavefront, which walks the node's dependent chain of LDS
-// round trips alone (ticket, records, shape, three 64-segment passes with a ballot each, sincos, reservation, cost terms,
-// reductions, list appends: 8 000-16 000 cycles per node whatever the arithmetic).  Here a round is a handful of passes in which
-// every LANE has an item of its own and no lane talks to another one until the barrier that ends the pass:
+// The closed form the rounds rest on (tools/sigma_order.py checks it against the oracle's pop sequences): with
+// pairwise distinct keys the reference pops X before Y iff X is an ancestor of Y or the largest key on the path (LCA, X] is smaller
+// than the largest key on (LCA, Y].  With G the first collision-free node at the horizon in that order, the reference pops exactly the
+// nodes in front of G, so ANY processing order gives its result as long as every generated node in front of G has been evaluated in
+// the end; ids, n_popped and the tree size are counts of nodes in front of G's path nodes (phase B, frontier_common.hpp).
+//
+// A round is a handful of passes in which every LANE has an item of its own and talks to nobody until the barrier that ends the pass:
 //
 //   P1  check      item = (ready node, chunk of S obstacle segments): eval_edge_exact (GraphSearch.m:111-196) with InterX
-//                  (InterX.m:63-76, are_constraints_satisfied_interx.m:17-37) restricted to the chunk; a hit sets the node's flag;
-//                  chunk-major order, so later chunks of a node that already collides are skipped (the reference's early out).
-//                  S is chosen per round so that the items fill the workgroup: a young search spreads ONE node's ~130 segments
-//                  over 130 lanes, a round of a thousand nodes runs 16 segments per lane.
+//                  (InterX.m:63-76, are_constraints_satisfied_interx.m:17-37) restricted to the chunk — or, for the separating-axis
+//                  checker, a chunk of soup columns / boundary segments (are_constraints_satisfied_sat.m:15-53) —; a hit sets the
+//                  node's flag; chunk-major order, so later chunks of a node that already collides are skipped (the reference's early
+//                  out).  S is chosen per round so that the items fill the workgroup once.  A large round is shared with the helper
+//                  workgroups that have taken a seat at this search (bulk_helper_body): posted records, one assignment word per seat.
 //       + sincos   item = ready node: cos / sin of its yaw (expand_node.m:50-51) into its record, next to the checks
 //   P2  verdicts   item = ready node: validity byte, goal candidates (GraphSearch.m:81-90), children counts; one workgroup scan
 //                  hands out the children's node indices (Tree.m:61: the children of a node are consecutive, ascending trim)
-//   P3  expand     item = (collision-free node, successor slot): expand_node.m:18-90 — pose, cost-to-come, cost-to-go summed in the
+//   P3  expand     item = (collision-free node, successor): expand_node.m:18-90 — pose, cost-to-come, cost-to-go summed in the
 //                  reference's order by the lane itself —, record, key, link, open-list entry
-//   P4  boundary   goal candidates resolved, predecessors that finished meanwhile folded in (PrioritizedController.m:476-491),
-//                  termination test, phase B when done, else selection of the next round: the smallest keys of `near`
+//   P4  boundary   goal candidates resolved; predecessors that finished meanwhile copied in and verified
+//                  (PrioritizedController.m:476-491; expected areas until then); termination test; phase B or
+//                  the replay when done; else the next round: the smallest keys of `near` — picked by the first wavefront alone
+//                  while near is small (bisection on the key, ballots), by a 256-bin histogram over all wavefronts otherwise
 //
-// The open set: `near` lives in LDS (keys + nodes, unordered, up to BK_PER entries per thread so that a selection pass holds it
-// in registers), `far` in HBM takes what near cannot hold (frontier_kernel.hip's scheme, one level up the memory hierarchy).
-// Arithmetic, operation order and -ffp-contract=off are those of the other kernels: every record is bit-identical to the oracle's.
-// Equal keys where the order matters: the search ends with the internal status PDMPC_INTERNAL_TIE and the host plans the call
-// again with the kernel that carries the libstdc++-faithful heap (api.cpp) — no tie in any BASELINE road-network workload.
+// The open set: `near` lives in LDS (keys + nodes, unordered, BK_PER entries per thread so that a selection pass holds it in
+// registers), `far` in HBM takes what near cannot hold, a heavy search's far list feeds near through the `mid` list (section 3.3).
+// Arithmetic, operation order and -ffp-contract=off are the oracle's: every record is bit-identical to it.
+// Equal keys where the pop order decides (priority_queue_interface_mex.cpp:19-31: the layout of std::priority_queue's binary heap
+// decides, not the nodes): the search goes into tie mode, processes a superset of what any heap order can pop, and ends — in the same
+// launch — on bk_replay, which pops its tree once more through the libstdc++-faithful heap (heap_queue.hpp; section 3.6).
 #include <hip/hip_runtime.h>
 
 #include "search_common.hpp"
@@ -38,6 +46,7 @@
 #endif
 #define BK_P2 3                   // ready entries a thread handles in the verdict pass (the ready list holds at most BK_P2 * blockDim entries)
 #define BK_PER PDMPC_BK_PER       // near entries per thread a selection pass holds in registers (near capacity = BK_PER * blockDim)
+#define BK_FAST_PER 4             // ... and per lane of the first wavefront when it selects alone (a small open set: at most 256 entries)
 
 namespace {
 
@@ -1881,8 +1890,10 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
             if (!rec_valid && sh[BK_PUBLISHED] == 0u) {
                 if (wave == 0) bk_write_record(A, X, best, best ? PDMPC_OK : PDMPC_EXHAUSTED, false, R.n_popped, R.n_expanded, false, nullptr, rec_written, false, lane);
                 rec_written = true;
-                __syncthreads();  // (the path's areas in LDS: written by the first wave, which is also their reader; the barrier is for the bookkeeping below)
             }
+            // (bk_wait_done rewrites the pending set, the published flag, ...: every wavefront has made this boundary's decisions on
+            // them before the first one does — a wavefront can lag arbitrarily far behind the last barrier)
+            __syncthreads();
             if (wave == 0 && sh[BK_PUBLISHED] == 0u)
                 bk_wait_done(A.done_flag, P.pred, P.out, A.epoch, (uint32_t)slot, P.l_soup, P.l_soff, P.l_lit, (lds_d2*)(X.lsm + PDMPC_LK_PSHAPE), sh, Hp, P.n_pred, best != 0u,
                              ticking ? (lds_vu64*)(tk + tk_pub) : (lds_vu64*)nullptr, sh_load64(sh, BK_FD_LO), 0u, CHECKER == PDMPC_CHECK_SAT, lane);
@@ -1930,6 +1941,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                 vs_copied = true;
             }
             if (A.bk_fast_arrival && !dep_timeout) {
+                __syncthreads();  // (as above: everybody has read the pending set this wait is about to rewrite)
                 if (wave == 0)
                     bk_wait_done(A.done_flag, P.pred, P.out, A.epoch, (uint32_t)slot, P.l_soup, P.l_soff, P.l_lit, (lds_d2*)(X.lsm + PDMPC_LK_PSHAPE), sh, Hp, P.n_pred, best != 0u,
                                  ticking ? (lds_vu64*)(tk + tk_pub) : (lds_vu64*)nullptr, 0ull, 4096u, CHECKER == PDMPC_CHECK_SAT, lane);
@@ -2111,9 +2123,97 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         }
 
         BK_OPAQUE_TID
+        // ---- a SMALL open set (at most BK_PER entries per lane of one wavefront: every light search, and the young rounds of every
+        // other): the first wavefront picks the round by itself.  It holds all of near in registers, finds a key below which about a
+        // round's worth of entries lies by bisection (a ballot and a population count per step; any threshold will do: which open
+        // entries a round takes decides when they are processed, not what the search finds), classifies and compacts with ballots.
+        // No histogram, no workgroup scan, two barriers — the sixteen-wavefront selection below costs a light round 3.6-4.7 of its
+        // 13-17 us (profiles/r05_step_profile_passes.txt).
+        if (nn_near <= (uint32_t)(BK_FAST_PER * PDMPC_WAVE) && (A.bk_flags & 1)) {  // (uniform)
+            BK_TICK3(4)
+            // (the other wavefronts may be anywhere behind the last barrier, still reading the shared words the boundary's decisions
+            // rest on — near's count and key range, the flags —: they are through before the first wavefront rewrites them)
+            __syncthreads();
+            if (wave == 0) {
+                const double lo = sh_ld_d(sh, FR_NEAR_MIN), hi = sh_ld_d(sh, FR_NEAR_MAX);
+                double kk[BK_FAST_PER];
+                uint32_t ii[BK_FAST_PER];
+#pragma unroll
+                for (int j = 0; j < BK_FAST_PER; ++j) {
+                    const uint32_t e = (uint32_t)j * PDMPC_WAVE + (uint32_t)lane;
+                    kk[j] = e < nn_near ? near_key[e] : 0.0;
+                    ii[j] = e < nn_near ? near_id[e] : 0u;
+                }
+                double thr = hi;  // (near's keys do not exceed FR_NEAR_MAX: everything)
+                if (nn_near > round_target) {
+                    double a = lo, b = hi;
+                    for (int it = 0; it < 48; ++it) {  // (uniform: every quantity below is the same in all lanes)
+                        const double mid = a + (b - a) * 0.5;
+                        if (!(mid > a) || !(mid < b)) break;  // the interval has collapsed (equal keys): take what the last threshold took
+                        uint32_t c = 0;
+#pragma unroll
+                        for (int j = 0; j < BK_FAST_PER; ++j) c += (uint32_t)__builtin_popcountll(__ballot(ii[j] != 0u && kk[j] <= mid));
+                        if (c >= round_target) {
+                            thr = mid;
+                            b = mid;
+                            if (c <= 2u * round_target + 16u) break;
+                        } else {
+                            a = mid;
+                        }
+                    }
+                }
+                const bool have_goal = best != 0u;
+                const bool check_alive = sh[FR_EVER_INVAL] != 0u;
+                const uint32_t epoch_now = sh[BK_ARRIVALS] & 0xffffu;
+                ulonglong2* const wcache = (ulonglong2*)A.arena.walk + voff;
+                uint32_t pk = 0, pr = 0, n_dead = 0, n_drop = 0;
+#pragma unroll
+                for (int j = 0; j < BK_FAST_PER; ++j) {  // (as below: straight-line code around the wave-wide walk)
+                    const double k = kk[j];
+                    const uint32_t i = ii[j];
+                    const bool sel = i != 0u && k <= thr;
+                    const bool above = have_goal && k > bb;
+                    const bool walk = sel && !above && (have_goal || check_alive);
+                    if (sel && have_goal && k == bb) atomicOr((uint32_t*)&sh[FR_FLAGS], FRF_TIE);
+                    int r = 1;
+                    if (have_goal || check_alive) r = bk_classify_wave(F.glink, wcache, VS, F.gkey, gp_path, gp_mp, have_goal, check_alive, best, epoch_now, walk ? i : 0u, k, sh);  // (uniform condition)
+                    const int c = i == 0u ? -1 : (sel ? (above ? 3 : r) : 0);
+                    const unsigned long long bk = __ballot(c == 0), br = __ballot(c == 1);
+                    n_dead += (uint32_t)__builtin_popcountll(__ballot(c == 4));
+                    n_drop += (uint32_t)__builtin_popcountll(__ballot(c == 3));
+                    if (c == 0) {  // (every entry is in a register: the compacted list may overwrite the old one)
+                        const uint32_t pos = pk + lane_rank(bk, lane);
+                        near_key[pos] = k;
+                        near_id[pos] = i;
+                        near_mn = k < near_mn ? k : near_mn;  // (folded into the shared words at the end of the round)
+                        near_mx = k > near_mx ? k : near_mx;
+                    } else if (c == 1) {
+                        const uint32_t pos = pr + lane_rank(br, lane);  // (at most BK_FAST_PER * 64 entries: the ready list holds them)
+                        ready[pos] = i;
+                        r_flag[pos] = 0u;
+                    }
+                    pk += (uint32_t)__builtin_popcountll(bk);
+                    pr += (uint32_t)__builtin_popcountll(br);
+                }
+                if (lane == 0) {
+                    sh[FR_NEAR_N] = pk;
+                    sh_st_d(sh, FR_NEAR_MIN, inf);
+                    sh_st_d(sh, FR_NEAR_MAX, 0.0);
+                    sh[FR_SEL_BIN] = pr;  // (the refill's word, free here: the round's size for everybody)
+                    if (n_dead) sh[FR_DEAD] = sh[FR_DEAD] + n_dead;
+                    if (n_drop) sh[FR_DROPPED] = sh[FR_DROPPED] + n_drop;  // comes after the candidate: never popped
+                }
+            }
+            __syncthreads();  // the ready list and the compacted near are in place
+            Rn = sh[FR_SEL_BIN];
+            BK_TICK3(5)
+            BK_TICK(tk_select)
+            continue;
+        }
         // ---- this round's entries: the smallest keys of near.  Every thread holds BK_PER entries in registers.
         {
             BK_TICK3(4)
+            __syncthreads();  // (the classification below may raise FRF_TIE and the scan's thread 0 rewrites near's count: behind everybody's boundary decisions)
             const double lo = sh_ld_d(sh, FR_NEAR_MIN);
             double hi = sh_ld_d(sh, FR_NEAR_MAX);
             double kk[BK_PER];

@@ -528,6 +528,9 @@ __device__ PhaseB fr_phase_b(const KernelArgs& A, Ctx& X, const Frontier& F, con
     const int n = EE.n, nw = NW > 0 ? NW : EE.nw;
     lds_u32* pkw = cnt_ch + PDMPC_HP_MAX + 2;                              // [HP_MAX + 1] packed words of the path nodes
     ch_d[tid] = 0;
+#ifdef PDMPC_PB_INVALIDATE_L1
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (experiment: phase B reads nothing from this CU's L1 that was cached before)
+#endif
     // G's path: the selection's relevance tables hold it when G was the best candidate at the last round boundary (the usual
     // end of a search) — then its keys and packed words are one parallel load; else walked from G
     const bool have_path = goal && F.sh[FR_PATH_FOR] == goal;
@@ -622,13 +625,17 @@ __device__ PhaseB fr_phase_b(const KernelArgs& A, Ctx& X, const Frontier& F, con
                     ch_d[tid] = my_d | 0x80000000u;  // (after the value it announces: LDS keeps a wave's accesses in order)
                 }
             }
-            {  // all resolved?  (one shared word and two barriers; __syncthreads_and wants the linear thread index — y, z, the block's
+            {  // all resolved?  (a shared word and two barriers; __syncthreads_and wants the linear thread index — y, z, the block's
                // dimensions from the dispatch packet —, which then stay alive across the caller's round loop)
-                if (tid == 0) F.sh[FR_SLOWEST] = 1u;
+               // TWO words, taken in turn: thread 0 starts the next pass's word while slower wavefronts may not have read this pass's
+               // yet (with one word a wavefront that was held up behind the second barrier — two workgroups on a CU — read the 1 of
+               // the NEXT pass, left the loop alone and took the workgroup's barriers apart)
+                const int sw = FR_SLOWEST + (guard & 1);
+                if (tid == 0) F.sh[sw] = 1u;
                 __syncthreads();
-                if (!resolved) F.sh[FR_SLOWEST] = 0u;
+                if (!resolved) F.sh[sw] = 0u;
                 __syncthreads();
-                if (F.sh[FR_SLOWEST] != 0u) break;  // (uniform)
+                if (F.sh[sw] != 0u) break;  // (uniform)
             }
             if (++guard > PDMPC_HP_MAX + 4) {  // (cannot happen: a chain inside a chunk is at most Hp long)
                 if (tid == 0) atomicOr((uint32_t*)&F.sh[FR_FLAGS], FRF_BUG);

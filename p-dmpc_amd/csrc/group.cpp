@@ -221,12 +221,29 @@ int make_partition(int n, const int32_t* off, const int32_t* idx, const double* 
         for (int s : comp[(size_t)c]) P.parts[(size_t)r].push_back(s);
         load[(size_t)r] += weight(c);
     }
-    // a device's slots in LEVEL ORDER (ascending caller index within a level): the sub-problem handed to pdmpc_pack_step then has its
+    // a device's slots in a topological order of the coupling DAG: the sub-problem handed to pdmpc_pack_step then has its
     // predecessors in lower slots whatever order the caller's slots are in, so the handle does not permute it and the device-resident
-    // record path (pdmpc_export_results_async) applies; group_fetch scatters back through these lists
+    // record path (pdmpc_export_results_async) applies; group_fetch scatters back through these lists.  Without weights that is
+    // level order (ascending caller index within a level); with weights, PRIORITY order — the largest expected work among a vehicle
+    // and its descendants, descending, ties by level (api.cpp: pack_common does the same for a single handle, pdmpc_set_step_weights):
+    // a device with more searches than CUs starts its heavy searches with the launch, not behind the searches that wait.
+    std::vector<double> prio;
+    if (weights && off) {
+        prio.assign((size_t)n, 0.0);
+        for (int s = 0; s < n; ++s) prio[(size_t)s] = (weights[s] == weights[s] && weights[s] > 0) ? weights[s] : 0.0;
+        std::vector<int> by_level((size_t)n);
+        std::iota(by_level.begin(), by_level.end(), 0);
+        std::stable_sort(by_level.begin(), by_level.end(), [&](int a, int b) { return P.level_of[(size_t)a] > P.level_of[(size_t)b]; });
+        for (int s : by_level)  // (a vehicle after all its successors)
+            for (int q = off[s]; q < off[s + 1]; ++q)
+                if (idx[q] >= 0 && idx[q] < n) prio[(size_t)idx[q]] = std::max(prio[(size_t)idx[q]], prio[(size_t)s]);
+    }
     for (auto& p : P.parts) {
         std::sort(p.begin(), p.end());
-        std::stable_sort(p.begin(), p.end(), [&](int a, int b) { return P.level_of[(size_t)a] < P.level_of[(size_t)b]; });
+        std::stable_sort(p.begin(), p.end(), [&](int a, int b) {
+            if (!prio.empty() && prio[(size_t)a] != prio[(size_t)b]) return prio[(size_t)a] > prio[(size_t)b];
+            return P.level_of[(size_t)a] < P.level_of[(size_t)b];
+        });
     }
     // the shared component in level order (levels by longest path, ascending vehicle index within a level: find(levels == i))
     if (!P.shared.empty()) {

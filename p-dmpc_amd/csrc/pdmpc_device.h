@@ -91,8 +91,9 @@ struct LdsLayout {
 // same numbers; the automaton's tables, the soup, the validity bytes and the nodes follow at run-time offsets).
 #define PDMPC_LK_ALIGN16(x) (((x) + 15u) & ~15u)
 // (W = wavefronts the layout is sized for, RC = entries of its ready list.  The product kernels: PDMPC_MAX_WAVES and 2048 — one
-// workgroup per CU; bulk_kernel_compact.hip: 8 and 1024, which with the automaton's areas left in L2 fits 80 KB — TWO workgroups per CU.
-// A translation unit sets PDMPC_LK_WAVES / PDMPC_LK_READY_CAP before it includes this header; the host lays out with pdmpc_lk_fixed().)
+// workgroup per CU; bulk_kernel_compact.hip: 8 wavefronts, 512 ready entries and two near entries per thread, which with the automaton's
+// areas left in L2 fits 80 KB — TWO workgroups per CU.  A translation unit sets PDMPC_LK_WAVES / PDMPC_LK_READY_CAP / PDMPC_BK_PER
+// before it includes this header; the host lays out with pdmpc_lk_fixed().)
 #ifndef PDMPC_LK_WAVES
 #define PDMPC_LK_WAVES PDMPC_MAX_WAVES
 #endif
@@ -100,7 +101,8 @@ struct LdsLayout {
 #define PDMPC_LK_READY_CAP 2048u
 #endif
 #define PDMPC_LK_COMPACT_WAVES 8
-#define PDMPC_LK_COMPACT_READY_CAP 1024u
+#define PDMPC_LK_COMPACT_READY_CAP 512u
+#define PDMPC_LK_COMPACT_BK_PER 2
 #define PDMPC_LKX_THREADS(W) ((uint32_t)(W) * PDMPC_WAVE)
 #define PDMPC_LKX_REF 0u
 #define PDMPC_LKX_SHAPE (PDMPC_LKX_REF + 3u * PDMPC_HP_MAX * 8u)
@@ -108,12 +110,16 @@ struct LdsLayout {
 #define PDMPC_LKX_CAND(W) (PDMPC_LKX_PATH(W) + PDMPC_LK_ALIGN16((PDMPC_HP_MAX + 2u) * 4u + 2u * (PDMPC_HP_MAX + 1u) * 4u + PDMPC_SH_WORDS * 4u + PDMPC_HP_MAX * 4u))
 #define PDMPC_LKX_EXPAND(W) (PDMPC_LKX_CAND(W) + PDMPC_LK_ALIGN16(12u * PDMPC_LKX_THREADS(W)))
 #define PDMPC_LKX_NEAR_KEY(W) (PDMPC_LKX_EXPAND(W) + (2u * PDMPC_HP_MAX * PDMPC_HP_MAX) * 8u + 16u * 16u)
-#define PDMPC_LKX_NEAR_ID(W) (PDMPC_LKX_NEAR_KEY(W) + PDMPC_LK_ALIGN16(PDMPC_BK_PER * PDMPC_LKX_THREADS(W) * 8u))
-#define PDMPC_LKX_READY(W) (PDMPC_LKX_NEAR_ID(W) + PDMPC_LK_ALIGN16(PDMPC_BK_PER * PDMPC_LKX_THREADS(W) * 4u))
-#define PDMPC_LKX_HIST(W, RC) (PDMPC_LKX_READY(W) + (uint32_t)(RC) * 8u)
-#define PDMPC_LKX_MISC(W, RC) (PDMPC_LKX_HIST(W, RC) + 3072u * 4u)
-#define PDMPC_LKX_PSHAPE(W, RC) (PDMPC_LKX_MISC(W, RC) + 2048u)
-#define PDMPC_LKX_FIXED_END(W, RC) (PDMPC_LKX_PSHAPE(W, RC) + PDMPC_LK_ALIGN16(PDMPC_HP_MAX * PDMPC_VMAX * 16u + PDMPC_HP_MAX * 4u + PDMPC_HP_MAX * 8u))
+#define PDMPC_LKX_NEAR_ID(W, P) (PDMPC_LKX_NEAR_KEY(W) + PDMPC_LK_ALIGN16((uint32_t)(P) * PDMPC_LKX_THREADS(W) * 8u))
+#define PDMPC_LKX_READY(W, P) (PDMPC_LKX_NEAR_ID(W, P) + PDMPC_LK_ALIGN16((uint32_t)(P) * PDMPC_LKX_THREADS(W) * 4u))
+#define PDMPC_LKX_HIST(W, RC, P) (PDMPC_LKX_READY(W, P) + (uint32_t)(RC) * 8u)
+#define PDMPC_LKX_MISC(W, RC, P) (PDMPC_LKX_HIST(W, RC, P) + 3072u * 4u)
+#define PDMPC_LKX_PSHAPE(W, RC, P) (PDMPC_LKX_MISC(W, RC, P) + 2048u)
+#define PDMPC_LKX_FIXED_END(W, RC, P) (PDMPC_LKX_PSHAPE(W, RC, P) + PDMPC_LK_ALIGN16(PDMPC_HP_MAX * PDMPC_VMAX * 16u + PDMPC_HP_MAX * 4u + PDMPC_HP_MAX * 8u))
+#ifndef PDMPC_BK_PER
+#define PDMPC_BK_PER 4
+#endif
+/* entries of the LDS open list per thread (a selection pass holds them in registers) */
 #define PDMPC_LK_THREADS PDMPC_LKX_THREADS(PDMPC_LK_WAVES)
 #define PDMPC_LK_REF PDMPC_LKX_REF
 #define PDMPC_LK_SHAPE PDMPC_LKX_SHAPE
@@ -121,12 +127,12 @@ struct LdsLayout {
 #define PDMPC_LK_CAND PDMPC_LKX_CAND(PDMPC_LK_WAVES)
 #define PDMPC_LK_EXPAND PDMPC_LKX_EXPAND(PDMPC_LK_WAVES)
 #define PDMPC_LK_NEAR_KEY PDMPC_LKX_NEAR_KEY(PDMPC_LK_WAVES)
-#define PDMPC_LK_NEAR_ID PDMPC_LKX_NEAR_ID(PDMPC_LK_WAVES)
-#define PDMPC_LK_READY PDMPC_LKX_READY(PDMPC_LK_WAVES)
-#define PDMPC_LK_HIST PDMPC_LKX_HIST(PDMPC_LK_WAVES, PDMPC_LK_READY_CAP)
-#define PDMPC_LK_MISC PDMPC_LKX_MISC(PDMPC_LK_WAVES, PDMPC_LK_READY_CAP)
-#define PDMPC_LK_PSHAPE PDMPC_LKX_PSHAPE(PDMPC_LK_WAVES, PDMPC_LK_READY_CAP)
-#define PDMPC_LK_FIXED_END PDMPC_LKX_FIXED_END(PDMPC_LK_WAVES, PDMPC_LK_READY_CAP)
+#define PDMPC_LK_NEAR_ID PDMPC_LKX_NEAR_ID(PDMPC_LK_WAVES, PDMPC_BK_PER)
+#define PDMPC_LK_READY PDMPC_LKX_READY(PDMPC_LK_WAVES, PDMPC_BK_PER)
+#define PDMPC_LK_HIST PDMPC_LKX_HIST(PDMPC_LK_WAVES, PDMPC_LK_READY_CAP, PDMPC_BK_PER)
+#define PDMPC_LK_MISC PDMPC_LKX_MISC(PDMPC_LK_WAVES, PDMPC_LK_READY_CAP, PDMPC_BK_PER)
+#define PDMPC_LK_PSHAPE PDMPC_LKX_PSHAPE(PDMPC_LK_WAVES, PDMPC_LK_READY_CAP, PDMPC_BK_PER)
+#define PDMPC_LK_FIXED_END PDMPC_LKX_FIXED_END(PDMPC_LK_WAVES, PDMPC_LK_READY_CAP, PDMPC_BK_PER)
 
 struct NodeArena {  // HBM arrays, per-vehicle stride = max_nodes entries
     NodeRec* nodes;
@@ -143,26 +149,21 @@ struct NodeArena {  // HBM arrays, per-vehicle stride = max_nodes entries
     uint32_t* child0;  // 1-based arena index of a node's first child (its children are consecutive, ascending trim), 0 while it has none: what the replay of a tied search descends by
 };
 
-#ifndef PDMPC_BK_PER
-#define PDMPC_BK_PER 4
-#endif
-/* entries of the LDS open list per thread (a selection pass holds them in registers) */
-
 // the fixed part of the graph search's layout for (W wavefronts, ready list of RC entries): what the kernel built with those two
 // numbers addresses with immediates; returns the first free byte
-static inline uint32_t pdmpc_lk_fixed(uint32_t W, uint32_t RC, LdsLayout* L) {
+static inline uint32_t pdmpc_lk_fixed(uint32_t W, uint32_t RC, uint32_t P, LdsLayout* L) {
     L->ref = PDMPC_LKX_REF;
     L->shape = PDMPC_LKX_SHAPE;
     L->path = PDMPC_LKX_PATH(W);
     L->cand = PDMPC_LKX_CAND(W);
     L->expand = PDMPC_LKX_EXPAND(W);
     L->bk_near_key = PDMPC_LKX_NEAR_KEY(W);
-    L->bk_near_id = PDMPC_LKX_NEAR_ID(W);
-    L->bk_ready = PDMPC_LKX_READY(W);
-    L->bk_hist = PDMPC_LKX_HIST(W, RC);
-    L->bk_misc = PDMPC_LKX_MISC(W, RC);
-    L->bk_pshape = PDMPC_LKX_PSHAPE(W, RC);
-    return PDMPC_LKX_FIXED_END(W, RC);
+    L->bk_near_id = PDMPC_LKX_NEAR_ID(W, P);
+    L->bk_ready = PDMPC_LKX_READY(W, P);
+    L->bk_hist = PDMPC_LKX_HIST(W, RC, P);
+    L->bk_misc = PDMPC_LKX_MISC(W, RC, P);
+    L->bk_pshape = PDMPC_LKX_PSHAPE(W, RC, P);
+    return PDMPC_LKX_FIXED_END(W, RC, P);
 }
 
 #define PDMPC_HELP_CAP 2048 /* entries of a round that can be shared (= the ready list's capacity) */
@@ -212,7 +213,7 @@ struct KernelArgs {
     // helper workgroups (blockIdx >= n_searches): CUs the launch leaves idle check tiles of other workgroups' large rounds
     int32_t n_searches;              // workgroups of this launch that run a search (the first ones)
     int32_t n_helpers;               // helper workgroups behind them (0: none)
-    int32_t own_div;                 // the owner of a shared round starts on 1 / own_div of its tiles
+    int32_t bk_flags;                // bit 0: a small open set is selected by the first wavefront alone (PDMPC_TUNING=fast_select; bulk_search.hpp)
     unsigned long long* help_board;  // [slot][PDMPC_HB_WORDS]: see above
     uint32_t* help_verdict;          // [slot][PDMPC_HELP_CAP] 1 collision-free, 2 colliding, 3 crosses expected areas only (written by helpers)
     uint32_t* help_finished;         // searches that have published their result (runs on from launch to launch) ...

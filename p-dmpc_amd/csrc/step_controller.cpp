@@ -27,6 +27,7 @@
 #include <limits>
 #include <string>
 #include <utility>
+#include <map>
 #include <vector>
 
 #include "../../include/pdmpc.h"
@@ -72,6 +73,7 @@ struct pdmpc_controller {
     int k = 0;
     std::vector<double> mx, my, myaw, mspeed, msteer;  // measurements
     std::vector<Plan> info_old, infos;
+    std::vector<double> last_pops;  // per vehicle: nodes its search popped in the last step (the next step's expected work, pdmpc_set_step_weights)
     // per step
     std::vector<int32_t> trims;
     std::vector<Poly> occ_offset, occ_plain;
@@ -89,6 +91,10 @@ struct pdmpc_controller {
     // sets that do not depend on the prioritization are built once per time step and shared by the prioritizations of an explorative step
     std::vector<pdmpc_polygon_set> fb_of;
     std::vector<uint8_t> fb_done;
+    // obstacle sets of a vehicle by who contributes to them (a function of the vehicle and of those lists alone): the prioritizations
+    // of an explorative step differ in a few couplings, so most of their vehicles share their sets — one build, one pointer, and
+    // pdmpc_pack_step packs a set it has seen under the same pointer once (api.cpp: pack_common)
+    std::vector<std::map<std::vector<int>, pdmpc_polygon_set>> obst_memo, dyn_memo;
     pdmpc_polygon_set empty_set{};
     bool empty_done = false;
     // explorative step (PrioritizedExplorativeController): the prioritizations of the current traffic state, flattened
@@ -662,6 +668,8 @@ int pdmpc_controller_build_step(pdmpc_controller* c) {
     c->infos.assign(n, Plan());
     c->dpool.clear();
     c->ipool.clear();
+    c->obst_memo.assign((size_t)n, {});
+    c->dyn_memo.assign((size_t)n, {});
     c->fb_of.assign(n, pdmpc_polygon_set());
     c->fb_done.assign(n, 0);
     c->empty_done = false;
@@ -748,30 +756,46 @@ int assemble_step(pdmpc_controller* c, bool seq_given) {
         I.left_y = c->bnd_left[i].y.data();
         I.right_x = c->bnd_right[i].x.data();
         I.right_y = c->bnd_right[i].y.data();
-        SetBuilder obst, dyn;
         auto add_shifted = [](SetBuilder& b, const std::vector<Poly>& shapes) {  // del_first_rpt_last without the temporary
             for (size_t q = 1; q < shapes.size(); ++q) b.add(shapes[q]);
             b.add(shapes.back());
         };
-        for (const Poly& o : c->static_obstacles) obst.add(o);
-        // consider_predecessors (:449-506): sequential ones are handed over on the device; the others contribute their
-        // previous plan shifted by one step (parallel_coupling_previous_trajectory, :409-447)
+        // who contributes (in the order the sets are built in): consider_predecessors (:449-506) — sequential predecessors are handed
+        // over on the device; the others contribute their previous plan shifted by one step (parallel_coupling_previous_trajectory,
+        // :409-447) —, then consider_successors (:508-566)
+        std::vector<int> obst_key, dyn_key;
         for (int j = 0; j < n; ++j) {
             if (!at(c->directed, n, j, i)) continue;
             if (at(c->directed_seq, n, j, i)) continue;
-            if (c->info_old[j].present && c->k > 1) add_shifted(dyn, c->info_old[j].shapes);
+            if (c->info_old[j].present && c->k > 1) dyn_key.push_back(j);
         }
-        // consider_successors (:508-566)
+        dyn_key.push_back(-1);  // (predecessors | successors)
         for (int j = 0; j < n; ++j) {
             if (!at(c->directed, n, i, j)) continue;
             if (c->cfg.constraint_from_successor == PDMPC_SUCCESSOR_AREA_OF_STANDSTILL) {
-                if (std::fabs(c->mspeed[j]) < 0.01) obst.add(c->occ_offset[j]);  // :536-540
+                if (std::fabs(c->mspeed[j]) < 0.01) obst_key.push_back(j);  // :536-540
             } else if (c->cfg.constraint_from_successor == PDMPC_SUCCESSOR_AREA_OF_PREVIOUS_TRAJECTORY) {
-                if (c->info_old[j].present) add_shifted(dyn, c->info_old[j].shapes);
+                if (c->info_old[j].present) dyn_key.push_back(j);
             }
         }
-        I.obstacles = obst.finish(*c);
-        I.dynamic_obstacles = dyn.finish(*c);
+        auto& om = c->obst_memo[(size_t)i];
+        auto oit = om.find(obst_key);
+        if (oit == om.end()) {
+            SetBuilder obst;
+            for (const Poly& o : c->static_obstacles) obst.add(o);
+            for (int j : obst_key) obst.add(c->occ_offset[j]);
+            oit = om.emplace(obst_key, obst.finish(*c)).first;
+        }
+        auto& dm = c->dyn_memo[(size_t)i];
+        auto dit = dm.find(dyn_key);
+        if (dit == dm.end()) {
+            SetBuilder dyn;
+            for (int j : dyn_key)
+                if (j >= 0) add_shifted(dyn, c->info_old[j].shapes);
+            dit = dm.emplace(dyn_key, dyn.finish(*c)).first;
+        }
+        I.obstacles = oit->second;
+        I.dynamic_obstacles = dit->second;
         if (!c->empty_done) {
             SetBuilder none;
             c->empty_set = none.finish(*c);
@@ -830,6 +854,8 @@ int pdmpc_controller_apply(pdmpc_controller* c, const pdmpc_vehicle_out* recs) {
         Plan p;
         if (r.status != PDMPC_OK && r.status != PDMPC_EXHAUSTED) return cfail(c, PDMPC_ERR_HIP, "a result record carries an error status: not a planning result");
         p.n_expanded = r.n_expanded;
+        if (c->last_pops.size() != (size_t)n) c->last_pops.assign((size_t)n, 0.0);
+        c->last_pops[(size_t)i] = (double)r.n_popped;
         if (r.status == PDMPC_OK) {
             p.present = true;
             for (int q = 0; q < Hp; ++q) {
@@ -920,6 +946,11 @@ int pdmpc_controller_step(pdmpc_controller* c) {
     int rc = pdmpc_controller_build_step(c);
     if (rc) return rc;
     c->out.resize(c->n);
+    if (c->last_pops.size() == (size_t)c->n) {  // the work of the last step as the expected work of this one: heavy searches are dispatched first
+        std::vector<double> w((size_t)c->n);
+        for (int s = 0; s < c->n; ++s) w[(size_t)s] = c->last_pops[(size_t)c->order[(size_t)s]] + 1.0;
+        (void)pdmpc_set_step_weights(c->h, c->n, w.data());
+    }
     rc = pdmpc_plan_step(c->h, c->n, c->in.data(), c->pred_offset.data(), c->pred_index.data(), c->fb.data(), c->out.data());
     if (rc) return cfail(c, rc, pdmpc_last_error());
     return pdmpc_controller_apply(c, c->out.data());
@@ -1193,6 +1224,11 @@ int pdmpc_controller_explore_step(pdmpc_controller* c, int32_t n_perm) {
     if (rc) return rc;
     const int N = (int)c->x_in.size();
     c->x_out.resize((size_t)N);
+    if (c->last_pops.size() == (size_t)c->n) {
+        std::vector<double> w((size_t)N);
+        for (int i = 0; i < N; ++i) w[(size_t)i] = c->last_pops[(size_t)c->x_vehicle[(size_t)i]] + 1.0;
+        (void)pdmpc_set_step_weights(c->h, N, w.data());
+    }
     rc = pdmpc_plan_step(c->h, N, c->x_in.data(), c->x_pred_offset.data(), c->x_pred_index.data(), c->x_fb.data(), c->x_out.data());
     if (rc) return cfail(c, rc, pdmpc_last_error());
     rc = pdmpc_controller_explore_choose(c, c->x_out.data(), nullptr, nullptr, nullptr);

@@ -46,6 +46,7 @@ EXPORTS = [
     "pdmpc_get_last_stats",
     "pdmpc_group_create",
     "pdmpc_group_create_ex",
+    "pdmpc_set_step_weights",
     "pdmpc_group_collective",
     "pdmpc_group_destroy",
     "pdmpc_group_size",
@@ -358,10 +359,18 @@ class Handle:
         _check(self.L, self.L.pdmpc_pack_batch(self.h, len(iters), arr), "pdmpc_pack_batch")
         del keep
 
-    def pack_step(self, iters, predecessors, fallback_shapes=None):
+    def set_step_weights(self, weights):
+        """Expected work per vehicle of the next packed step (pdmpc_set_step_weights): its searches go out by priority, not slot order."""
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        self.L.pdmpc_set_step_weights.argtypes = [C.c_void_p, C.c_int32, abi.c_double_p]
+        _check(self.L, self.L.pdmpc_set_step_weights(self.h, len(w), w.ctypes.data_as(abi.c_double_p)), "pdmpc_set_step_weights")
+
+    def pack_step(self, iters, predecessors, fallback_shapes=None, weights=None):
         """predecessors: list (per vehicle) of lists of 0-based vehicle indices in this batch."""
         n = len(iters)
         arr, off, idx, fb, keep = self._step_args(iters, predecessors, fallback_shapes)
+        if weights is not None:
+            self.set_step_weights(weights)
         _check(
             self.L,
             self.L.pdmpc_pack_step(self.h, n, arr, off.ctypes.data_as(abi.c_int32_p), idx.ctypes.data_as(abi.c_int32_p), fb),
@@ -383,11 +392,13 @@ class Handle:
                 fb[i] = abi.pack_polygon_set(list(shapes), keep)
         return arr, off, idx, fb, keep
 
-    def plan_step(self, iters, predecessors, fallback_shapes=None):
+    def plan_step(self, iters, predecessors, fallback_shapes=None, weights=None):
         """A whole time step in one call (pdmpc_plan_step): pack + launch + fetch, arenas grow if a search needs it."""
         n = len(iters)
         arr, off, idx, fb, keep = self._step_args(iters, predecessors, fallback_shapes)
         out = abi.out_array(n)
+        if weights is not None:
+            self.set_step_weights(weights)
         _check(
             self.L,
             self.L.pdmpc_plan_step(self.h, n, arr, off.ctypes.data_as(abi.c_int32_p), idx.ctypes.data_as(abi.c_int32_p), fb, abi.out_ptr(out)),

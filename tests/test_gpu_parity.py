@@ -314,6 +314,10 @@ def test_random_road_problems_never_fall_back():
         "mid_min=100,mid_fill=1000,round0=300,tentative=0",
         "force_tie=1",  # every search ends on the replay through the libstdc++-faithful heap
         "force_tie=1,round0=300,share_min=64",
+        "compact=1",  # the kernel built for two workgroups per CU (8 wavefronts, 80 KB, near list of 1 024 entries: bulk_kernel_compact.hip)
+        "compact=1,share_min=64,round0=200,tile=64",
+        "compact=1,force_tie=1",
+        "compact=1,mid_min=0,mid_fill=256,round0=300",
     ],
 )
 def test_tuning_switches_do_not_change_results(tuning, monkeypatch):

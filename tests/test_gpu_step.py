@@ -488,6 +488,43 @@ def test_batch_not_in_level_order_is_reordered_by_the_library():
     opt.handle.close()
 
 
+def test_step_weights_fill_the_slots_by_priority_and_change_nothing():
+    """pdmpc_set_step_weights: with an expected work per vehicle the slots of the launch are filled by priority (the largest expected
+    work among a vehicle and its descendants in the coupling DAG, descending) — a topological order like the level order, so the
+    predecessors still sit in lower slots — and the records come back in the caller's order, equal to the oracle's bit for bit.
+    Weights that favour the LAST levels are the adversarial case: a late vehicle drags all its ancestors to the front."""
+    from oracle import oracle
+    from pdmpc.optimizer import GraphSearchHip
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    options = Config(scenario_type=ScenarioType.commonroad, amount=40, Hp=6, max_num_CLs=4, max_vehicles=64, max_nodes=1 << 16)
+    mpa = get_mpa(options)
+    sc = commonroad_scenario(options, seed=2, tiles=2)
+    opt = GraphSearchHip(options)
+    opt._ensure_mpa(mpa)
+    ctl = PrioritizedSequentialController(options, sc, mpa, None, coupling="distance", boundary_provider=boundary_provider(sc), priority_strategy="coloring")
+    rng = np.random.default_rng(7)
+
+    def plan_step(prob):
+        n = len(prob["iters"])
+        fb = [f if f is not None else [] for f in prob["fallback"]]
+        ref, _ = oracle.plan_step(options, mpa, prob, n_threads=os.cpu_count() or 1)
+        for weights in ([float(l) for l in prob["levels"]], list(rng.integers(1, 5000, n).astype(float)), [1.0] * n, [float("nan")] * n):
+            got = opt.handle.plan_step(prob["iters"], prob["preds"], fb, weights=weights)
+            assert_records_equal(got, ref, "slots by priority")
+        # ... and as a resident bank launched twice
+        opt.handle.pack_step(prob["iters"], prob["preds"], fb, weights=list(rng.integers(1, 5000, n).astype(float)))
+        for _ in range(2):
+            opt.handle.launch()
+            assert_records_equal(opt.handle.fetch(n), ref, "resident bank packed by priority")
+        return [info_from_record(ref[i], options.Hp) for i in range(n)]
+
+    for _ in range(4):
+        ctl.step(plan_step=plan_step)
+    assert opt.handle.stats()["safe_replans"] == 0
+    opt.handle.close()
+
+
 def test_starved_predecessors_are_replanned_in_resident_slices(monkeypatch):
     """Forward progress of oversubscribed launches.  PDMPC_TUNING=reverse_dispatch=1 hands the slots out in reverse workgroup order:
     the successors occupy the chip and spin for predecessors that have not been dispatched -- the adversarial order.  With a

@@ -21,7 +21,7 @@ opt = GraphSearchHip(options); opt._ensure_mpa(mpa); h = opt.handle
 probs = bench.record_steps(options, mpa, ctl, opt, 20 if args.workload in ("c2", "c5") else 4, 6 if args.workload not in ("c4", "c5") else 3, explore_instances=64 if args.workload == "c5" else 0)
 for b, prob in enumerate(probs):
     fb = [f if f is not None else [] for f in prob["fallback"]]
-    h.pack_step(prob["iters"], prob["preds"], fb)
+    h.pack_step(prob["iters"], prob["preds"], fb, weights=None if os.environ.get("PROFILE_NO_WEIGHTS") else prob.get("prev_pops"))  # (slots by priority on the work of the step before, as bench.py packs its banks)
     h.reset_stats()
     h.launch(); recs = h.fetch(len(prob["iters"])); st = h.stats()
     print("step", b, "kernel ms %.3f" % st["kernel_ms"], "levels", len(prob["level_sizes"]))
