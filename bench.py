@@ -500,15 +500,30 @@ def main():
         tiles = max(1, (args.vehicles + 19) // 20)
         nat = NativeController(options, commonroad_scenario(options, seed=args.seed + (rank if weak else 0), tiles=tiles), mpa, h, coupling="distance",
                                priority_strategy=args.priorities)
-        nat.run(args.skip)
-        ms = nat.run(args.steps)
+        # the SAME closed-loop steps the resident replay cycles through (skip + 1 .. skip + S), as often as the timed loop's step count
+        # asks for: a fresh controller per pass (the closed loop cannot be rewound)
+        reps = max(1, args.steps // max(S, 1))
+        ms_all, sums = [], None
+        for rep in range(reps):
+            if rep:
+                nat.close()
+                nat = NativeController(options, commonroad_scenario(options, seed=args.seed + (rank if weak else 0), tiles=tiles), mpa, h, coupling="distance",
+                                       priority_strategy=args.priorities)
+            nat.run(args.skip)
+            nat.timing_mean(reset=True)
+            ms_all.append(nat.run(S))
+            part = nat.timing_mean()
+            sums = part if sums is None else {k: sums[k] + part[k] for k in part}
+        ms = np.concatenate(ms_all)
+        breakdown = {k: v / reps for k, v in sums.items()}
         host_inclusive = {
             "value": 1e3 / float(np.mean(ms)),
             "unit": "MPC steps/s",
             "ms_per_step": float(np.mean(ms)),
             "p50_latency_ms": float(np.median(ms)),
             "p99_latency_ms": float(np.sort(ms)[min(len(ms) - 1, int(0.99 * len(ms)))]),
-            "what": "closed loop through the C ABI (pdmpc_controller_run): host step logic in C++ + pack + H2D + one launch + D2H + apply per step, closed-loop steps %d..%d" % (args.skip + 1, args.skip + args.steps),
+            "breakdown_ms": breakdown,
+            "what": "closed loop through the C ABI (pdmpc_controller_run): host step logic in C++ + pack + H2D + one launch + D2H + apply per step, closed-loop steps %d..%d (the resident replay's window), %d passes" % (args.skip + 1, args.skip + S, reps),
         }
         nat.close()
         # ---- the same recorded steps, one run_optimizer call per vehicle (what GraphSearchHip.m gives an unmodified controller)
@@ -541,18 +556,47 @@ def main():
 
         nat = NativeController(options, commonroad_scenario(options, seed=args.seed, tiles=max(1, (args.vehicles + 19) // 20)), mpa, h, coupling="distance",
                                priority_strategy=args.priorities)
-        nat.run(args.skip)
-        n_x = min(args.steps, 40)
-        nat.explore_run(args.instances, 2)
-        ms = nat.explore_run(args.instances, n_x)
+        n_x = S  # (exactly the recorded window: the steps the resident replay cycles through)
+        # (a) on the SAME steps as the resident replay: every step builds, plans and chooses among the prioritizations, and goes on with the
+        # controller's own one — the closed loop the recorded batches come from (pdmpc_controller_explore_follow_own); a fresh controller
+        # per pass over the window
+        reps = max(1, min(args.steps, 40) // max(S, 1))
+        ms_all, sums = [], None
+        for rep in range(reps):
+            if rep:
+                nat.close()
+                nat = NativeController(options, commonroad_scenario(options, seed=args.seed, tiles=max(1, (args.vehicles + 19) // 20)), mpa, h, coupling="distance",
+                                       priority_strategy=args.priorities)
+            nat.run(args.skip)
+            nat.explore_follow_own(True)
+            nat.timing_mean(reset=True)
+            ms_all.append(nat.explore_run(args.instances, n_x))
+            part = nat.timing_mean()
+            sums = part if sums is None else {k: sums[k] + part[k] for k in part}
+        ms = np.concatenate(ms_all)
+        breakdown = {k: v / reps for k, v in sums.items()}
         host_inclusive = {
             "value": 1e3 / float(np.mean(ms)),
             "unit": "MPC steps/s",
             "ms_per_step": float(np.mean(ms)),
             "p50_latency_ms": float(np.median(ms)),
             "p99_latency_ms": float(np.sort(ms)[min(len(ms) - 1, int(0.99 * len(ms)))]),
-            "what": "explorative closed loop through the C ABI (pdmpc_controller_explore_run): per step the %d prioritizations built and flattened in C++ + pack + H2D + "
-            "one launch + D2H + choice per sub-graph + apply of the chosen plans, closed-loop steps %d..%d" % (args.instances, args.skip + 3, args.skip + 2 + n_x),
+            "breakdown_ms": breakdown,
+            "what": "through the C ABI (pdmpc_controller_explore_run) on the steps of the resident replay: per step the %d prioritizations built and flattened in C++ + pack + H2D + "
+            "one launch + read-back of status / final cost of every plan + choice per sub-graph + the records of the applied plans; the loop goes on with the controller's own "
+            "prioritization, closed-loop steps %d..%d, %d passes" % (args.instances, args.skip + 1, args.skip + n_x, reps),
+        }
+        # (b) the explorative closed loop proper (the chosen plans are applied: other traffic, heavier steps among them)
+        nat.explore_follow_own(False)
+        nat.timing_mean(reset=True)
+        n_x2 = min(args.steps, 40)
+        ms2 = nat.explore_run(args.instances, n_x2)
+        host_inclusive["explorative_closed_loop"] = {
+            "value": 1e3 / float(np.mean(ms2)),
+            "ms_per_step": float(np.mean(ms2)),
+            "p50_latency_ms": float(np.median(ms2)),
+            "breakdown_ms": nat.timing_mean(),
+            "what": "the same call with the chosen plans applied, the %d steps that follow (other traffic; heavier steps among them)" % n_x2,
         }
         nat.close()
     scal_ref = None

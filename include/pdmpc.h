@@ -211,6 +211,17 @@ int pdmpc_plan_step_literal(pdmpc_handle* handle, int32_t n_vehicles, const pdmp
  * handle's stream); pdmpc_launch_packed runs the search kernel on whatever is packed (no copies);
  * pdmpc_fetch_results copies the result records back.  pdmpc_plan_batch == pack + launch + fetch. */
 int pdmpc_pack_batch(pdmpc_handle* handle, int32_t n_vehicles, const pdmpc_vehicle_in* in);
+/* pdmpc_plan_step for a caller that keeps only a few of the batch's plans (the explorative step: the choice among the prioritizations
+ * rests on the cost-to-come of every vehicle's final node, PrioritizedExplorativeController.m:94-112, and only the chosen plans are
+ * applied): plans the step like pdmpc_plan_step but copies back status[v] and final_cost[v] = path_nodes[Hp][4] only (12 bytes per
+ * vehicle instead of 2.9 KB); the records stay on the device until the next launch and pdmpc_fetch_records_at reads the ones wanted
+ * (vehicles: indices into the step as it was handed over). */
+int pdmpc_plan_step_lean(pdmpc_handle* handle, int32_t n_vehicles, const pdmpc_vehicle_in* in, const int32_t* pred_offset, const int32_t* pred_index,
+                         const pdmpc_polygon_set* fallback_shapes, int32_t* status, double* final_cost);
+int pdmpc_fetch_records_at(pdmpc_handle* handle, int32_t count, const int32_t* vehicles, pdmpc_vehicle_out* out);
+/* host wall-clock microseconds of the last pdmpc_plan_batch / pdmpc_plan_step on this handle: [0] pack (flatten + queue the
+ * host-to-device copy), [1] enqueue the launch, [2] wait for the kernel + copy the records back */
+int pdmpc_last_call_timing(pdmpc_handle* handle, double* us3);
 int pdmpc_launch_packed(pdmpc_handle* handle);
 /* launches only slots [first, first + count) of the packed batch: one computation level, or one GPU's shard of it */
 int pdmpc_launch_range(pdmpc_handle* handle, int32_t first, int32_t count);
@@ -405,7 +416,16 @@ int pdmpc_controller_explore_problem(pdmpc_controller* c, int32_t* n_slots, cons
 int pdmpc_controller_explore_choose(pdmpc_controller* c, const pdmpc_vehicle_out* records, int32_t* chosen, int32_t* n_graphs, double* cost);
 int pdmpc_controller_explore_step(pdmpc_controller* c, int32_t n_perm);
 int pdmpc_controller_explore_run(pdmpc_controller* c, int32_t n_perm, int32_t n_steps, double* ms);
+/* measurement only: on != 0 makes the explorative step build, plan and choose as always but APPLY the plans of the controller's own
+ * prioritization, so that the traffic follows pdmpc_controller_step's closed loop (bench.py: the host-inclusive rate on the same steps
+ * as the resident replay) */
+int pdmpc_controller_explore_follow_own(pdmpc_controller* c, int32_t on);
 int pdmpc_controller_explore_result(pdmpc_controller* c, int32_t* chosen, int32_t* n_graphs, const double** cost, const pdmpc_vehicle_out** records);
+/* host wall-clock milliseconds of the last pdmpc_controller_step / pdmpc_controller_explore_step, by part: [0] build the step problem(s)
+ * on the host, [1] pack, [2] enqueue, [3] wait + read-back, [4] choice among the prioritizations (explorative step), [5] apply */
+int pdmpc_controller_last_timing(pdmpc_controller* c, double* ms6);
+/* ... and summed over the steps since the last call with reset != 0 (n_steps: how many) */
+int pdmpc_controller_timing_sum(pdmpc_controller* c, double* ms6, int64_t* n_steps, int32_t reset);
 const char* pdmpc_controller_last_error(void);
 
 /* ---- several GPUs behind the same boundary (csrc/group.cpp) ----

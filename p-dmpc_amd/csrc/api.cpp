@@ -178,6 +178,7 @@ struct Tuning {
     int speculate = 1;      // 0: every search waits for all its predecessors before it starts
     int dispatch_order = 1; // 0: ignore pdmpc_set_step_weights (slots in level order, never by priority)
     int fast_select = 1;    // 0: every selection goes through the sixteen-wavefront histogram, also while the open set is small (A/B)
+    int lazy_verify = 0;    // 1: an arrival into a RUNNING search brings the parked nodes back at once but re-checks the collision-free nodes only when the search stalls or is done
     int compact = -1;       // 1: the kernel built for two workgroups per CU (8 wavefronts, <= 80 KB of LDS: bulk_kernel_compact.hip) where it applies (InterX, one mask word, the soup fits); 0: never; -1: for launches of more than two searches per CU; 2-5: layout experiments (one workgroup per CU with the compact kernel, slack behind the layout)
     int waves = -1;         // wavefronts per workgroup (4 .. PDMPC_MAX_WAVES; -1: 16 for the InterX kernels — 12 for a launch of more than two searches per CU —, 12 for the separating-axis kernel)
     uint32_t spin_limit = 1u << 22;  // the watchdog's limit of polls / rounds (debugging: fail fast)
@@ -196,7 +197,7 @@ bool parse_tuning(const char* text, Tuning& T, std::string& err) {
     int spin = (int)T.spin_limit;
     const Key keys[] = {{"round0", &T.round0}, {"round", &T.round}, {"ramp", &T.ramp}, {"ready", &T.ready}, {"share_min", &T.share_min}, {"own_div", &T.own_div},
                         {"tile", &T.tile}, {"mid_min", &T.mid_min}, {"mid_fill", &T.mid_fill}, {"tentative", &T.tentative}, {"fast_arrival", &T.fast_arrival}, {"helpers_first", &T.helpers_first}, {"seat_nodes", &T.seat_nodes},
-                        {"helpers", &T.helpers}, {"helpers_oversub", &T.helpers_oversub}, {"speculate", &T.speculate}, {"waves", &T.waves}, {"compact", &T.compact}, {"fast_select", &T.fast_select}, {"dispatch_order", &T.dispatch_order}, {"spin_limit", &spin},
+                        {"helpers", &T.helpers}, {"helpers_oversub", &T.helpers_oversub}, {"speculate", &T.speculate}, {"waves", &T.waves}, {"compact", &T.compact}, {"lazy_verify", &T.lazy_verify}, {"fast_select", &T.fast_select}, {"dispatch_order", &T.dispatch_order}, {"spin_limit", &spin},
                         {"force_tie", &T.force_tie}, {"reverse_dispatch", &T.reverse_dispatch}, {"debug_tail", &T.debug_tail}, {"debug_lds", &T.debug_lds},
                         {"debug_host", &T.debug_host}, {"debug_progress", &T.debug_progress}};
     std::string str(text ? text : "");
@@ -288,12 +289,15 @@ struct pdmpc_handle {
     bool boards_dirty = true;            // the helper boards / the finished counter need clearing before the helper workgroups may read them
     uint32_t help_fin_total = 0;         // value of the finished counter once every launch so far has ended
     uint32_t launch_serial = 0;          // launches of this handle so far (KernelArgs::launch_id)
+    double last_us[3] = {0, 0, 0};       // pdmpc_last_call_timing: pack, enqueue, wait + read-back of the last pdmpc_plan_batch / pdmpc_plan_step
     double dbg_us[4] = {0, 0, 0, 0};     // debug_host 2: pack, launch, fetch (host clock) and kernel (events) time of the plan_batch calls
     uint64_t sync_serial = 0;            // stream synchronisations through sync_stream so far (PackedStep::staged_serial)
     std::vector<double> pack_pts;        // pack_common's scratch (kept: a pack allocates nothing once warm)
     std::vector<int32_t> pack_pred;
     std::vector<double> next_weights;    // pdmpc_set_step_weights: expected work per vehicle of the NEXT packed step (the caller's order); consumed by that pack
     std::vector<DevVehicle> pack_veh;
+    PinnedBuf<double> h_lean;            // fetch_lean: (cost, status) per slot
+    DevBuf<double> d_lean;
     PinnedBuf<pdmpc_vehicle_out> h_out;  // pdmpc_fetch_results: the records land in pinned memory (a copy into the caller's pageable array goes through the runtime's staging otherwise)
     int bk_ready_launch = 2048;          // entries of the ready list of the last layout
     uint32_t* progress = nullptr;        // pinned, debug_progress
@@ -832,7 +836,7 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     a.bk_round0 = T.round0 > 0 ? T.round0 : 24;  // (C3's class: below, once the helpers are counted)
     a.bk_round = std::min(h->bk_ready_launch / 2 - 16, std::max(a.bk_round0, T.round > 0 ? T.round : (helped ? 1000 : 256)));
     a.bk_ramp = T.ramp > 0 ? T.ramp : (helped ? 2 : 4);
-    a.bk_flags = T.fast_select ? 1 : 0;
+    a.bk_flags = (T.fast_select ? 1 : 0) | (T.lazy_verify ? 2 : 0);
     a.bk_mid_min = T.mid_min;
     a.bk_mid_fill = T.mid_fill;
     a.bk_tile = T.tile > 0 ? T.tile : 256;
@@ -867,7 +871,7 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
             if (a.n_helpers < 2) a.n_helpers = 0;
         } else {
             a.n_helpers = 200;  // (seated helpers cost the searches nothing: measured on C4 96 -> 76.9 steps/s, 160-250 -> 77.7)
-            if (T.helpers_oversub >= 0) a.n_helpers = std::min(T.helpers_oversub, h->n_cu);
+            if (T.helpers_oversub >= 0) a.n_helpers = std::min(T.helpers_oversub, 3 * h->n_cu);
             if (T.helpers >= 0) a.n_helpers = std::min(a.n_helpers, T.helpers);
         }
     }
@@ -1055,6 +1059,8 @@ int pdmpc_destroy(pdmpc_handle* h) {
     h->achild0.release();
     h->d_out.release();
     h->h_out.release();
+    h->h_lean.release();
+    h->d_lean.release();
     h->d_flag.release();
     h->d_tree_size.release();
     h->d_tie_count.release();
@@ -1207,8 +1213,8 @@ int pdmpc_fetch_results(pdmpc_handle* h, int32_t n, pdmpc_vehicle_out* out) {
     if (h->h_out.ensure((size_t)std::max(n, 1))) return fail(PDMPC_ERR_HIP, "hipHostMalloc failed");
     if (n > 0) HIPCHK(hipMemcpyAsync(h->h_out.p, h->d_out.p, (size_t)n * sizeof(pdmpc_vehicle_out), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(sync_stream(h));
-    if (n > 0) std::memcpy(out, h->h_out.p, (size_t)n * sizeof(pdmpc_vehicle_out));
-    // counters + SURVEY.md 8(d) algorithmic bytes of one pass over the packed batch
+    // counters + SURVEY.md 8(d) algorithmic bytes of one pass over the packed batch (read where the records landed: pinned memory, slot order)
+    const pdmpc_vehicle_out* rec = h->h_out.p;
     pdmpc_stats& s = h->stats;
     const int Hp = h->cfg.Hp;
     const int m = std::min(n, B.n_packed);
@@ -1216,13 +1222,13 @@ int pdmpc_fetch_results(pdmpc_handle* h, int32_t n, pdmpc_vehicle_out* out) {
     s.nodes_popped = s.nodes_generated = s.obstacle_columns = 0;
     int64_t bytes = h->mpa_alg_bytes;
     for (int i = 0; i < m; ++i) {
-        const pdmpc_vehicle_out& o = out[i];
+        const pdmpc_vehicle_out& o = rec[i];
         const DevVehicle& d = B.h_veh[i];
         int64_t cols = B.lit_cols[i];
         for (int q = 0; q < d.n_pred; ++q) {
             const int ps = B.h_pred[d.pred_off + q];
             if (ps < n)
-                for (int k = 0; k < Hp; ++k) cols += out[ps].shape_cols[k] + 1;
+                for (int k = 0; k < Hp; ++k) cols += rec[ps].shape_cols[k] + 1;
         }
         const int64_t P = o.n_popped, C = std::max(o.n_expanded - 1, 0);
         s.nodes_popped += P;
@@ -1234,10 +1240,53 @@ int pdmpc_fetch_results(pdmpc_handle* h, int32_t n, pdmpc_vehicle_out* out) {
         bytes += 8 * (3 * Hp + Hp + (Hp + 1)) + 16 * PDMPC_VMAX * Hp;      // B_out
     }
     s.algorithmic_bytes = bytes;
-    if (permuted) {  // back into the caller's order (the tree_path ids are per search: nothing else refers to slots)
-        std::vector<pdmpc_vehicle_out> tmp(out, out + n);
-        for (int sl = 0; sl < n; ++sl) out[B.perm[(size_t)sl]] = tmp[(size_t)sl];
+    // ONE pass from pinned memory into the caller's array, in the caller's order (the tree_path ids are per search: nothing else refers to slots)
+    if (permuted) {
+        for (int sl = 0; sl < n; ++sl) out[B.perm[(size_t)sl]] = rec[sl];
+    } else if (n > 0) {
+        std::memcpy(out, rec, (size_t)n * sizeof(pdmpc_vehicle_out));
     }
+    return PDMPC_OK;
+}
+
+namespace {
+// What a caller that keeps only a few of a batch's plans needs of ALL of them (the explorative step: the choice among the
+// prioritizations rests on the cost-to-come of every vehicle's final node, PrioritizedExplorativeController.m:94-112): status and
+// path_nodes[Hp][4] per vehicle, as two strided copies — 12 bytes per record instead of 2.9 KB.  Caller's order.
+int fetch_lean(pdmpc_handle* h, int32_t n, int32_t* status, double* cost) {
+    PackedStep& B = h->banks[h->bank];
+    const bool permuted = !B.perm.empty();
+    if (permuted && n != B.n_packed) return fail(PDMPC_ERR_INVALID, "a batch that pdmpc_pack_step put into its own order is fetched as a whole");
+    if (h->h_lean.ensure((size_t)std::max(n, 1) * 2)) return fail(PDMPC_ERR_HIP, "hipHostMalloc failed");
+    if (h->d_lean.ensure((size_t)std::max(n, 1) * 2)) return fail(PDMPC_ERR_HIP, "hipMalloc failed");
+    if (n > 0) {
+        const int lrc = pdmpc_launch_gather_lean(h->d_out.p, n, h->cfg.Hp, h->d_lean.p, (void*)h->stream);
+        if (lrc) return fail(PDMPC_ERR_HIP, "gather kernel launch failed");
+        HIPCHK(hipMemcpyAsync(h->h_lean.p, h->d_lean.p, (size_t)n * 16, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(sync_stream(h));
+    for (int sl = 0; sl < n; ++sl) {
+        const int v = permuted ? B.perm[(size_t)sl] : sl;
+        cost[v] = h->h_lean.p[2 * (size_t)sl];
+        std::memcpy(&status[v], &h->h_lean.p[2 * (size_t)sl + 1], sizeof(int32_t));
+    }
+    return PDMPC_OK;
+}
+}  // namespace
+
+int pdmpc_fetch_records_at(pdmpc_handle* h, int32_t count, const int32_t* vehicles, pdmpc_vehicle_out* out) {
+    if (!h || count < 0 || (count > 0 && (!vehicles || !out))) return fail(PDMPC_ERR_INVALID, "null argument");
+    ON_DEVICE(h->cfg.device);
+    PackedStep& B = h->banks[h->bank];
+    if (h->h_out.ensure((size_t)std::max(count, 1))) return fail(PDMPC_ERR_HIP, "hipHostMalloc failed");
+    for (int i = 0; i < count; ++i) {
+        const int v = vehicles[i];
+        if (v < 0 || v >= B.n_packed) return fail(PDMPC_ERR_INVALID, "vehicle index outside the packed batch");
+        const int sl = B.perm.empty() ? v : B.inv[(size_t)v];
+        HIPCHK(hipMemcpyAsync(h->h_out.p + i, h->d_out.p + sl, sizeof(pdmpc_vehicle_out), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(sync_stream(h));
+    if (count > 0) std::memcpy(out, h->h_out.p, (size_t)count * sizeof(pdmpc_vehicle_out));
     return PDMPC_OK;
 }
 
@@ -1245,7 +1294,7 @@ namespace {
 // The reference's tree grows without bound (Tree.m:54-70); the arenas here are finite.  A call whose search outgrows them
 // is planned again from scratch with arenas twice as large (searches are deterministic, so the vehicles that did fit
 // produce the same records again) until it fits, the limit set with pdmpc_set_arena_limit is reached, or HBM runs out.
-int plan_packed_growing(pdmpc_handle* h, int32_t n, pdmpc_vehicle_out* out) {
+int plan_packed_growing(pdmpc_handle* h, int32_t n, pdmpc_vehicle_out* out, int32_t* lean_status = nullptr, double* lean_cost = nullptr) {
     bool safe = h->safe_launches;
     for (;;) {
         const bool dbg = h->tune.debug_host == 1;
@@ -1256,19 +1305,22 @@ int plan_packed_growing(pdmpc_handle* h, int32_t n, pdmpc_vehicle_out* out) {
         int rc = launch_range(h, 0, h->banks[h->bank].n_packed, safe);
         if (rc) return rc;
         const auto t1 = std::chrono::steady_clock::now();
-        rc = pdmpc_fetch_results(h, n, out);
+        rc = out ? pdmpc_fetch_results(h, n, out) : fetch_lean(h, n, lean_status, lean_cost);
         if (rc) return rc;
+        h->last_us[1] += std::chrono::duration<double, std::micro>(t1 - t0).count();
+        h->last_us[2] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
         if (h->tune.debug_host == 2) {  // (PDMPC_DEBUG_HOST=2: where a call's host time goes, printed by pdmpc_plan_step_literal)
             h->dbg_us[1] += std::chrono::duration<double, std::micro>(t1 - t0).count();
             h->dbg_us[2] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
             float ms = 0.f;
             if (h->events_used > 0 && hipEventElapsedTime(&ms, h->events[h->events_used - 1].first, h->events[h->events_used - 1].second) == hipSuccess) h->dbg_us[3] += 1e3 * ms;
         }
-        if (dbg) fprintf(stderr, "pdmpc: fetched, status[0] %d\n", n > 0 ? out[0].status : 0);
+        if (dbg) fprintf(stderr, "pdmpc: fetched, status[0] %d\n", n > 0 ? (out ? out[0].status : lean_status[0]) : 0);
         bool overflow = false, timed_out = false;
         for (int i = 0; i < n; ++i) {
-            overflow = overflow || out[i].status == PDMPC_ARENA_OVERFLOW;
-            timed_out = timed_out || out[i].status == PDMPC_ERR_HIP;
+            const int st = out ? out[i].status : lean_status[i];
+            overflow = overflow || st == PDMPC_ARENA_OVERFLOW;
+            timed_out = timed_out || st == PDMPC_ERR_HIP;
         }
         if (timed_out && safe)
             return fail(PDMPC_ERR_HIP, "a search gave up waiting for a predecessor although the call was planned in resident slices without helper workgroups (records carry PDMPC_ERR_HIP)");
@@ -1305,14 +1357,36 @@ int pdmpc_plan_batch(pdmpc_handle* h, int32_t n, const pdmpc_vehicle_in* in, pdm
     int rc = pdmpc_pack_batch(h, n, in);
     if (rc) return rc;
     if (dbg) h->dbg_us[0] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    h->last_us[0] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    h->last_us[1] = h->last_us[2] = 0;
     return plan_packed_growing(h, n, out);
 }
 
 int pdmpc_plan_step(pdmpc_handle* h, int32_t n, const pdmpc_vehicle_in* in, const int32_t* pred_offset, const int32_t* pred_index,
                     const pdmpc_polygon_set* fallback_shapes, pdmpc_vehicle_out* out) {
+    const auto t0 = std::chrono::steady_clock::now();
     int rc = pdmpc_pack_step(h, n, in, pred_offset, pred_index, fallback_shapes);
     if (rc) return rc;
+    h->last_us[0] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    h->last_us[1] = h->last_us[2] = 0;
     return plan_packed_growing(h, n, out);
+}
+
+int pdmpc_plan_step_lean(pdmpc_handle* h, int32_t n, const pdmpc_vehicle_in* in, const int32_t* pred_offset, const int32_t* pred_index, const pdmpc_polygon_set* fallback_shapes,
+                         int32_t* status, double* final_cost) {
+    if (!h || n < 0 || (n > 0 && (!status || !final_cost))) return fail(PDMPC_ERR_INVALID, "null argument");
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = pdmpc_pack_step(h, n, in, pred_offset, pred_index, fallback_shapes);
+    if (rc) return rc;
+    h->last_us[0] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    h->last_us[1] = h->last_us[2] = 0;
+    return plan_packed_growing(h, n, nullptr, status, final_cost);
+}
+
+int pdmpc_last_call_timing(pdmpc_handle* h, double* us3) {
+    if (!h || !us3) return fail(PDMPC_ERR_INVALID, "null argument");
+    for (int i = 0; i < 3; ++i) us3[i] = h->last_us[i];
+    return PDMPC_OK;
 }
 
 // The step as an UNMODIFIED reference controller drives this backend (GraphSearchHip.m behind OptimizerInterface): one

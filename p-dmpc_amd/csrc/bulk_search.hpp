@@ -1211,6 +1211,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
     bool rec_valid = false, rec_written = false;  // the result record in HBM is the one this search would publish now / some record has been written
     bool vs_copied = false;                       // the LDS validity bytes have been copied to HBM since the tree last changed
     bool tie_replayed = false;                    // the search ended on bk_replay (its pop sequence is in the arena: pdmpc_debug_pop_trace)
+    bool unpark_req = false;                      // (bk_flags bit 1) parked nodes come back at the next boundary; the re-check of the collision-free nodes waits
     bool verify_req = false;                      // the next round boundary verifies the tree against the areas that were copied since the last verification (BK_FD)
     // shared rounds (helper workgroups)
     unsigned long long* board = A.help_board + (size_t)slot * PDMPC_HB_WORDS;
@@ -1604,10 +1605,43 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
                     }
                 }
                 __syncthreads();
-                verify_req = true;  // (putting it off until the search stalls or is done: C2 1 382 -> 1 212, C3 1 100 -> 939, C4 82.8 -> 71.4 steps/s)
+                // (putting the whole verification off until the search stalls or is done: C2 1 382 -> 1 212, C3 1 100 -> 939, C4 82.8 -> 71.4
+                // steps/s — parked nodes stayed parked.  bk_flags bit 1, PDMPC_TUNING=lazy_verify=1: the parked nodes come back at once,
+                // only the re-check of the collision-free nodes — which can take edges away, never add any — waits)
+                if (A.bk_flags & 2)
+                    unpark_req = true;
+                else
+                    verify_req = true;
             }
         }
         BK_TICK2(0)
+        if (unpark_req && !verify_req) {  // (uniform) the arrival's cheap half: parked nodes are open again and meet the real areas in a round
+            const uint32_t n_parked = sh[BK_NTENT];
+            uint32_t nn = sh[FR_NNODES];
+            nn = nn < S.max_nodes ? nn : S.max_nodes;
+            if (n_parked) {  // (uniform)
+                const bool fits = sh[FR_NEAR_N] + n_parked <= OC;
+                const double l_far = sh_ld_d(sh, FR_L_FAR);
+                for (uint32_t base = 0; base < nn; base += (uint32_t)bd) {  // (uniform trip count: wave-wide appends inside)
+                    const uint32_t i0 = base + (uint32_t)tid;
+                    const bool tent = i0 < nn && vs_load(VS, i0 < nn ? i0 : 0u) == VS_TENT;
+                    const double k = tent ? F.gkey[i0] : 0.0;
+                    if (tent) vs_store(VS, i0, VS_UNKNOWN);
+                    to_near(tent && fits && !(k > l_far), k, i0 + 1u);
+                    to_far(tent && !(fits && !(k > l_far)), k, i0 + 1u);
+                }
+                flush_near();
+                flush_far();
+                vs_copied = false;
+                __syncthreads();
+                if (tid == 0) {
+                    sh[BK_NTENT] = 0;
+                    sh_st_d(sh, BK_TENT_MIN, inf);
+                }
+                __syncthreads();
+            }
+        }
+        unpark_req = false;
         if (verify_req) {  // (uniform)
             verify_req = false;
             const unsigned long long arr = sh_load64(sh, BK_FD_LO);  // everybody whose areas were copied since the last verification

@@ -250,6 +250,8 @@ int pdmpc_launch_bulk_wide(const KernelArgs* args, int count, void* stream, uint
 int pdmpc_launch_bulk_sat(const KernelArgs* args, int count, void* stream, uint32_t* lds_high_water);
 // bulk_kernel_compact.hip: the InterX / one-mask-word kernel built for 8 wavefronts and at most 80 KB of LDS: two workgroups per CU
 int pdmpc_launch_bulk_compact(const KernelArgs* args, int count, void* stream, uint32_t* lds_high_water);
+// util_kernels.hip: (cost-to-come of the final node, status) of n result records into lean[2 * n]
+int pdmpc_launch_gather_lean(const pdmpc_vehicle_out* out, int n, int Hp, double* lean, void* stream);
 // sampled_kernel.hip: the sampled optimizer (MonteCarloTreeSearch.m), `count` workgroups of one wavefront
 int pdmpc_launch_sampled(const KernelArgs* args, int count, void* stream);
 // debug_kernels.hip: the open-list command script on one wavefront, and the collision primitives on given polygons (one wavefront per case)

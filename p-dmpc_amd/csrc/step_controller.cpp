@@ -73,6 +73,13 @@ struct pdmpc_controller {
     int k = 0;
     std::vector<double> mx, my, myaw, mspeed, msteer;  // measurements
     std::vector<Plan> info_old, infos;
+    bool follow_own = false;                // the explorative step applies the plans of the controller's OWN prioritization (instance 0) whatever the choice: the traffic then follows pdmpc_controller_step's closed loop (measurement: the same steps as a recorded replay)
+    bool lean_explore = false;              // the explorative step reads back status + final cost of every plan and the chosen plans' records only
+    std::vector<int32_t> x_status;
+    std::vector<double> x_final_cost;
+    double timing[6] = {0, 0, 0, 0, 0, 0};  // pdmpc_controller_last_timing
+    double timing_sum[6] = {0, 0, 0, 0, 0, 0};  // ... summed over the steps since the last pdmpc_controller_timing_sum(reset)
+    int64_t timing_steps = 0;
     std::vector<double> last_pops;  // per vehicle: nodes its search popped in the last step (the next step's expected work, pdmpc_set_step_weights)
     // per step
     std::vector<int32_t> trims;
@@ -94,7 +101,11 @@ struct pdmpc_controller {
     // obstacle sets of a vehicle by who contributes to them (a function of the vehicle and of those lists alone): the prioritizations
     // of an explorative step differ in a few couplings, so most of their vehicles share their sets — one build, one pointer, and
     // pdmpc_pack_step packs a set it has seen under the same pointer once (api.cpp: pack_common)
-    std::vector<std::map<std::vector<int>, pdmpc_polygon_set>> obst_memo, dyn_memo;
+    struct MemoKey {  // who contributes, as bit masks over the vehicles (up to 512: larger scenarios build every set)
+        uint64_t w[16];
+        bool operator<(const MemoKey& o) const { return std::memcmp(w, o.w, sizeof w) < 0; }
+    };
+    std::vector<std::map<MemoKey, pdmpc_polygon_set>> obst_memo, dyn_memo;
     pdmpc_polygon_set empty_set{};
     bool empty_done = false;
     // explorative step (PrioritizedExplorativeController): the prioritizations of the current traffic state, flattened
@@ -542,6 +553,8 @@ std::vector<Poly> del_first_rpt_last(const std::vector<Poly>& s) {
     return r;
 }
 
+inline double ms_since(std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); }
+
 struct SetBuilder {  // builds a pdmpc_polygon_set whose arrays live in the controller's pools
     std::vector<int32_t> off{0};
     std::vector<double> x, y;
@@ -763,39 +776,66 @@ int assemble_step(pdmpc_controller* c, bool seq_given) {
         // who contributes (in the order the sets are built in): consider_predecessors (:449-506) — sequential predecessors are handed
         // over on the device; the others contribute their previous plan shifted by one step (parallel_coupling_previous_trajectory,
         // :409-447) —, then consider_successors (:508-566)
-        std::vector<int> obst_key, dyn_key;
+        const bool memo = n <= 512;
+        pdmpc_controller::MemoKey ok, dk;
+        std::memset(&ok, 0, sizeof ok);
+        std::memset(&dk, 0, sizeof dk);
+        int ol[512], dpl[512], dsl[512], no = 0, ndp = 0, nds = 0;  // (the contributors in the order the sets are built in)
+        std::vector<int> big;  // (n > 512: the lists on the heap)
+        int *olp = ol, *dplp = dpl, *dslp = dsl;
+        if (!memo) {
+            big.resize((size_t)3 * n);
+            olp = big.data();
+            dplp = big.data() + n;
+            dslp = big.data() + 2 * n;
+        }
         for (int j = 0; j < n; ++j) {
             if (!at(c->directed, n, j, i)) continue;
             if (at(c->directed_seq, n, j, i)) continue;
-            if (c->info_old[j].present && c->k > 1) dyn_key.push_back(j);
+            if (c->info_old[j].present && c->k > 1) {
+                dplp[ndp++] = j;
+                if (memo) dk.w[j >> 6] |= 1ull << (j & 63);
+            }
         }
-        dyn_key.push_back(-1);  // (predecessors | successors)
         for (int j = 0; j < n; ++j) {
             if (!at(c->directed, n, i, j)) continue;
             if (c->cfg.constraint_from_successor == PDMPC_SUCCESSOR_AREA_OF_STANDSTILL) {
-                if (std::fabs(c->mspeed[j]) < 0.01) obst_key.push_back(j);  // :536-540
+                if (std::fabs(c->mspeed[j]) < 0.01) {  // :536-540
+                    olp[no++] = j;
+                    if (memo) ok.w[j >> 6] |= 1ull << (j & 63);
+                }
             } else if (c->cfg.constraint_from_successor == PDMPC_SUCCESSOR_AREA_OF_PREVIOUS_TRAJECTORY) {
-                if (c->info_old[j].present) dyn_key.push_back(j);
+                if (c->info_old[j].present) {
+                    dslp[nds++] = j;
+                    if (memo) dk.w[8 + (j >> 6)] |= 1ull << (j & 63);
+                }
             }
         }
-        auto& om = c->obst_memo[(size_t)i];
-        auto oit = om.find(obst_key);
-        if (oit == om.end()) {
+        auto build_obst = [&]() {
             SetBuilder obst;
             for (const Poly& o : c->static_obstacles) obst.add(o);
-            for (int j : obst_key) obst.add(c->occ_offset[j]);
-            oit = om.emplace(obst_key, obst.finish(*c)).first;
-        }
-        auto& dm = c->dyn_memo[(size_t)i];
-        auto dit = dm.find(dyn_key);
-        if (dit == dm.end()) {
+            for (int q = 0; q < no; ++q) obst.add(c->occ_offset[olp[q]]);
+            return obst.finish(*c);
+        };
+        auto build_dyn = [&]() {
             SetBuilder dyn;
-            for (int j : dyn_key)
-                if (j >= 0) add_shifted(dyn, c->info_old[j].shapes);
-            dit = dm.emplace(dyn_key, dyn.finish(*c)).first;
+            for (int q = 0; q < ndp; ++q) add_shifted(dyn, c->info_old[dplp[q]].shapes);
+            for (int q = 0; q < nds; ++q) add_shifted(dyn, c->info_old[dslp[q]].shapes);
+            return dyn.finish(*c);
+        };
+        if (memo) {
+            auto& om = c->obst_memo[(size_t)i];
+            auto oit = om.find(ok);
+            if (oit == om.end()) oit = om.emplace(ok, build_obst()).first;
+            auto& dm = c->dyn_memo[(size_t)i];
+            auto dit = dm.find(dk);
+            if (dit == dm.end()) dit = dm.emplace(dk, build_dyn()).first;
+            I.obstacles = oit->second;
+            I.dynamic_obstacles = dit->second;
+        } else {
+            I.obstacles = build_obst();
+            I.dynamic_obstacles = build_dyn();
         }
-        I.obstacles = oit->second;
-        I.dynamic_obstacles = dit->second;
         if (!c->empty_done) {
             SetBuilder none;
             c->empty_set = none.finish(*c);
@@ -941,10 +981,40 @@ int pdmpc_controller_apply(pdmpc_controller* c, const pdmpc_vehicle_out* recs) {
 }
 
 // One pass of HighLevelController.main_control_loop (:334-373) in simulation: build, plan on the GPU (one launch), apply.
+namespace {
+// adds the parts of the step's one backend call (pdmpc_last_call_timing) to the controller's timing
+void add_call_timing(pdmpc_controller* c) {
+    double us[3] = {0, 0, 0};
+    if (pdmpc_last_call_timing(c->h, us) == PDMPC_OK)
+        for (int i = 0; i < 3; ++i) c->timing[1 + i] = us[i] * 1e-3;
+}
+}  // namespace
+
+int pdmpc_controller_last_timing(pdmpc_controller* c, double* ms6) {
+    if (!c || !ms6) return cfail(c, PDMPC_ERR_INVALID, "null argument");
+    for (int i = 0; i < 6; ++i) ms6[i] = c->timing[i];
+    return PDMPC_OK;
+}
+
+int pdmpc_controller_timing_sum(pdmpc_controller* c, double* ms6, int64_t* n_steps, int32_t reset) {
+    if (!c) return cfail(c, PDMPC_ERR_INVALID, "null argument");
+    if (ms6)
+        for (int i = 0; i < 6; ++i) ms6[i] = c->timing_sum[i];
+    if (n_steps) *n_steps = c->timing_steps;
+    if (reset) {
+        for (int i = 0; i < 6; ++i) c->timing_sum[i] = 0;
+        c->timing_steps = 0;
+    }
+    return PDMPC_OK;
+}
+
 int pdmpc_controller_step(pdmpc_controller* c) {
     if (!c || !c->h) return cfail(c, PDMPC_ERR_INVALID, "controller has no backend handle");
+    auto t = std::chrono::steady_clock::now();
     int rc = pdmpc_controller_build_step(c);
     if (rc) return rc;
+    c->timing[0] = ms_since(t);
+    c->timing[4] = 0;
     c->out.resize(c->n);
     if (c->last_pops.size() == (size_t)c->n) {  // the work of the last step as the expected work of this one: heavy searches are dispatched first
         std::vector<double> w((size_t)c->n);
@@ -953,7 +1023,13 @@ int pdmpc_controller_step(pdmpc_controller* c) {
     }
     rc = pdmpc_plan_step(c->h, c->n, c->in.data(), c->pred_offset.data(), c->pred_index.data(), c->fb.data(), c->out.data());
     if (rc) return cfail(c, rc, pdmpc_last_error());
-    return pdmpc_controller_apply(c, c->out.data());
+    add_call_timing(c);
+    t = std::chrono::steady_clock::now();
+    rc = pdmpc_controller_apply(c, c->out.data());
+    c->timing[5] = ms_since(t);
+    for (int i = 0; i < 6; ++i) c->timing_sum[i] += c->timing[i];
+    c->timing_steps += 1;
+    return rc;
 }
 
 // n_steps closed-loop time steps in one call; ms[i] (may be NULL) receives the wall time of step i: build + pack + launch +
@@ -1167,8 +1243,23 @@ int pdmpc_controller_explore_problem(pdmpc_controller* c, int32_t* n_slots, cons
 // smallest sum of the cost-to-come of the vehicles' final nodes after round(., 8); a vehicle whose search was exhausted makes its
 // instance infinitely expensive.  chosen[v] = instance of vehicle v's sub-graph; cost (may be NULL): n_perm x n_graphs, graphs
 // ordered by their smallest vehicle.  The chosen instances' couplings become the controller's (what apply's fallback handling sees).
+namespace {
+int explore_choose_on(pdmpc_controller* c, const int32_t* status, const double* final_cost, int32_t* chosen, int32_t* n_graphs, double* cost);
+}
 int pdmpc_controller_explore_choose(pdmpc_controller* c, const pdmpc_vehicle_out* recs, int32_t* chosen, int32_t* n_graphs, double* cost) {
     if (!c || !recs || c->inst.empty()) return cfail(c, PDMPC_ERR_INVALID, "no exploration batch has been built");
+    const int N = (int)c->inst.size() * c->n;
+    std::vector<int32_t> st((size_t)N);
+    std::vector<double> fc((size_t)N);
+    for (int s = 0; s < N; ++s) {
+        st[(size_t)s] = recs[s].status;
+        fc[(size_t)s] = recs[s].path_nodes[c->Hp][4];
+    }
+    return explore_choose_on(c, st.data(), fc.data(), chosen, n_graphs, cost);
+}
+namespace {
+// (status and cost-to-come of the final node per slot of the batch: all the choice looks at)
+int explore_choose_on(pdmpc_controller* c, const int32_t* status, const double* final_cost, int32_t* chosen, int32_t* n_graphs, double* cost) {
     const int n = c->n, Hp = c->Hp, K = (int)c->inst.size();
     std::vector<int> label((size_t)n);
     for (int i = 0; i < n; ++i) label[(size_t)i] = i;
@@ -1192,9 +1283,8 @@ int pdmpc_controller_explore_choose(pdmpc_controller* c, const pdmpc_vehicle_out
     c->x_cost.assign((size_t)K * G, 0.0);
     const int N = K * n;
     for (int s = 0; s < N; ++s) {  // (slot order: the order the twin adds in)
-        const pdmpc_vehicle_out& r = recs[s];
-        if (r.status != PDMPC_OK && r.status != PDMPC_EXHAUSTED) return cfail(c, PDMPC_ERR_HIP, "a result record carries an error status: not a planning result");
-        const double v = r.status == PDMPC_OK ? r.path_nodes[Hp][4] : std::numeric_limits<double>::infinity();
+        if (status[s] != PDMPC_OK && status[s] != PDMPC_EXHAUSTED) return cfail(c, PDMPC_ERR_HIP, "a result record carries an error status: not a planning result");
+        const double v = status[s] == PDMPC_OK ? final_cost[s] : std::numeric_limits<double>::infinity();
         c->x_cost[(size_t)c->x_instance[(size_t)s] * G + graph_of[(size_t)c->x_vehicle[(size_t)s]]] += v;
     }
     for (double& v : c->x_cost) v = std::nearbyint(v * 1e8) / 1e8;
@@ -1216,12 +1306,15 @@ int pdmpc_controller_explore_choose(pdmpc_controller* c, const pdmpc_vehicle_out
     if (cost) std::copy(c->x_cost.begin(), c->x_cost.end(), cost);
     return PDMPC_OK;
 }
+}  // namespace
 
 // One explorative time step: build the batch, plan all prioritizations with ONE launch, choose per sub-graph, apply the chosen plans.
 int pdmpc_controller_explore_step(pdmpc_controller* c, int32_t n_perm) {
     if (!c || !c->h) return cfail(c, PDMPC_ERR_INVALID, "controller has no backend handle");
+    auto t = std::chrono::steady_clock::now();
     int rc = pdmpc_controller_explore_build(c, n_perm, (uint32_t)(c->k + 1));  // RandStream("mt19937ar", Seed = obj.k) (:249)
     if (rc) return rc;
+    c->timing[0] = ms_since(t);
     const int N = (int)c->x_in.size();
     c->x_out.resize((size_t)N);
     if (c->last_pops.size() == (size_t)c->n) {
@@ -1229,19 +1322,66 @@ int pdmpc_controller_explore_step(pdmpc_controller* c, int32_t n_perm) {
         for (int i = 0; i < N; ++i) w[(size_t)i] = c->last_pops[(size_t)c->x_vehicle[(size_t)i]] + 1.0;
         (void)pdmpc_set_step_weights(c->h, N, w.data());
     }
-    rc = pdmpc_plan_step(c->h, N, c->x_in.data(), c->x_pred_offset.data(), c->x_pred_index.data(), c->x_fb.data(), c->x_out.data());
-    if (rc) return cfail(c, rc, pdmpc_last_error());
-    rc = pdmpc_controller_explore_choose(c, c->x_out.data(), nullptr, nullptr, nullptr);
-    if (rc) return rc;
-    c->out.resize((size_t)c->n);
-    for (int s = 0; s < c->n; ++s) {
-        const int v = c->order[(size_t)s];
-        c->out[(size_t)s] = c->x_out[(size_t)c->x_slot[(size_t)c->x_chosen[(size_t)v] * c->n + v]];
+    if (c->lean_explore) {
+        // the closed loop keeps the chosen plans only (obj.iter = obj.iter_array_tmp{chosen_solution}, :157-158): status and final
+        // cost of every plan come back for the choice, the chosen vehicles' records afterwards — not 2.9 KB for each of the N plans
+        c->x_out.clear();
+        c->x_status.resize((size_t)N);
+        c->x_final_cost.resize((size_t)N);
+        rc = pdmpc_plan_step_lean(c->h, N, c->x_in.data(), c->x_pred_offset.data(), c->x_pred_index.data(), c->x_fb.data(), c->x_status.data(), c->x_final_cost.data());
+        if (rc) return cfail(c, rc, pdmpc_last_error());
+        add_call_timing(c);
+        t = std::chrono::steady_clock::now();
+        rc = explore_choose_on(c, c->x_status.data(), c->x_final_cost.data(), nullptr, nullptr, nullptr);
+        if (rc) return rc;
+        std::vector<int32_t> want((size_t)c->n);
+        for (int s = 0; s < c->n; ++s) {
+            const int v = c->order[(size_t)s];
+            want[(size_t)s] = c->x_slot[(size_t)(c->follow_own ? 0 : c->x_chosen[(size_t)v]) * c->n + v];
+        }
+        c->out.resize((size_t)c->n);
+        rc = pdmpc_fetch_records_at(c->h, c->n, want.data(), c->out.data());
+        if (rc) return cfail(c, rc, pdmpc_last_error());
+    } else {
+        rc = pdmpc_plan_step(c->h, N, c->x_in.data(), c->x_pred_offset.data(), c->x_pred_index.data(), c->x_fb.data(), c->x_out.data());
+        if (rc) return cfail(c, rc, pdmpc_last_error());
+        add_call_timing(c);
+        t = std::chrono::steady_clock::now();
+        rc = pdmpc_controller_explore_choose(c, c->x_out.data(), nullptr, nullptr, nullptr);
+        if (rc) return rc;
+        c->out.resize((size_t)c->n);
+        for (int s = 0; s < c->n; ++s) {
+            const int v = c->order[(size_t)s];
+            c->out[(size_t)s] = c->x_out[(size_t)c->x_slot[(size_t)(c->follow_own ? 0 : c->x_chosen[(size_t)v]) * c->n + v]];
+        }
     }
-    return pdmpc_controller_apply(c, c->out.data());
+    if (c->follow_own) {  // (the couplings of instance 0 again: what apply's fallback handling sees)
+        c->directed = c->inst[0].directed;
+        c->directed_seq = c->inst[0].directed_seq;
+    }
+    c->timing[4] = ms_since(t);
+    t = std::chrono::steady_clock::now();
+    rc = pdmpc_controller_apply(c, c->out.data());
+    c->timing[5] = ms_since(t);
+    for (int i = 0; i < 6; ++i) c->timing_sum[i] += c->timing[i];
+    c->timing_steps += 1;
+    return rc;
+}
+
+int pdmpc_controller_explore_follow_own(pdmpc_controller* c, int32_t on) {
+    if (!c) return cfail(c, PDMPC_ERR_INVALID, "null argument");
+    c->follow_own = on != 0;
+    return PDMPC_OK;
 }
 
 int pdmpc_controller_explore_run(pdmpc_controller* c, int32_t n_perm, int32_t n_steps, double* ms) {
+    if (!c) return cfail(c, PDMPC_ERR_INVALID, "null argument");
+    struct Lean {  // (nobody looks at the plans that were not chosen: pdmpc_controller_explore_step keeps them all, this loop does not)
+        pdmpc_controller* c;
+        bool was;
+        ~Lean() { c->lean_explore = was; }
+    } lean{c, c->lean_explore};
+    c->lean_explore = true;
     for (int i = 0; i < n_steps; ++i) {
         const auto t0 = std::chrono::steady_clock::now();
         const int rc = pdmpc_controller_explore_step(c, n_perm);

@@ -47,6 +47,12 @@ EXPORTS = [
     "pdmpc_group_create",
     "pdmpc_group_create_ex",
     "pdmpc_set_step_weights",
+    "pdmpc_last_call_timing",
+    "pdmpc_plan_step_lean",
+    "pdmpc_fetch_records_at",
+    "pdmpc_controller_last_timing",
+    "pdmpc_controller_timing_sum",
+    "pdmpc_controller_explore_follow_own",
     "pdmpc_group_collective",
     "pdmpc_group_destroy",
     "pdmpc_group_size",

@@ -176,6 +176,21 @@ class NativeController:
         self._check(self.L.pdmpc_controller_run(self.c, n_steps, ms.ctypes.data_as(abi.c_double_p)), "pdmpc_controller_run")
         return ms[:n_steps]
 
+    def last_timing(self):
+        """Host milliseconds of the last step by part (pdmpc_controller_last_timing)."""
+        t = (C.c_double * 6)()
+        self.L.pdmpc_controller_last_timing.argtypes = [C.c_void_p, C.c_void_p]
+        self._check(self.L.pdmpc_controller_last_timing(self.c, t), "pdmpc_controller_last_timing")
+        return dict(zip(("build", "pack", "enqueue", "wait_and_read_back", "choose", "apply"), (float(x) for x in t)))
+
+    def timing_mean(self, reset=True):
+        """Mean host milliseconds per step by part over the steps since the last reset (pdmpc_controller_timing_sum)."""
+        t = (C.c_double * 6)()
+        k = C.c_int64(0)
+        self.L.pdmpc_controller_timing_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+        self._check(self.L.pdmpc_controller_timing_sum(self.c, t, C.byref(k), 1 if reset else 0), "pdmpc_controller_timing_sum")
+        return dict(zip(("build", "pack", "enqueue", "wait_and_read_back", "choose", "apply"), (float(x) / max(k.value, 1) for x in t)))
+
     def build_step(self):
         self._check(self.L.pdmpc_controller_build_step(self.c), "pdmpc_controller_build_step")
 
@@ -255,6 +270,10 @@ class NativeController:
         self._check(self.L.pdmpc_controller_explore_result(self.c, chosen.ctypes.data_as(abi.c_int32_p), None, None, C.byref(p)), "pdmpc_controller_explore_result")
         recs = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(self.n * n_perm * abi.VEHICLE_OUT_DTYPE.itemsize,)).view(abi.VEHICLE_OUT_DTYPE).copy()
         return recs, chosen
+
+    def explore_follow_own(self, on=True):
+        self.L.pdmpc_controller_explore_follow_own.argtypes = [C.c_void_p, C.c_int32]
+        self._check(self.L.pdmpc_controller_explore_follow_own(self.c, 1 if on else 0), "pdmpc_controller_explore_follow_own")
 
     def explore_run(self, n_perm, n_steps):
         ms = np.zeros(max(n_steps, 1))

@@ -424,8 +424,17 @@ def test_native_explorative_step_on_device():
         assert np.array_equal(st["x"], np.array([m.x for m in py.meas])) and np.array_equal(st["y"], np.array([m.y for m in py.meas])), k
         assert np.array_equal(st["yaw"], np.array([m.yaw for m in py.meas])) and np.array_equal(st["speed"], np.array([m.speed for m in py.meas])), k
     assert other > 0
-    ms = nat.explore_run(K, 3)
-    assert len(ms) == 3 and (ms > 0).all()
+    # pdmpc_controller_explore_run keeps the chosen plans only (status + final cost of every plan for the choice, then the chosen
+    # vehicles' records: pdmpc_plan_step_lean / pdmpc_fetch_records_at): the same closed loop, the same plant state
+    nat2 = NativeController(options, sc, mpa, opt.handle, coupling="distance")
+    ms = nat2.explore_run(K, 10)
+    assert len(ms) == 10 and (ms > 0).all()
+    a, b = nat.state(), nat2.state()
+    for key in ("x", "y", "yaw", "speed", "steering"):
+        assert np.array_equal(a[key], b[key]), key
+    tm = nat2.timing_mean()
+    assert tm["build"] > 0 and tm["wait_and_read_back"] > 0
+    nat2.close()
     nat.close()
     opt.handle.close()
 
