@@ -43,7 +43,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "p-dmpc_amd")]
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, MI355X_MICROARCH.md
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 
 def workload_defaults(args):
@@ -359,20 +359,38 @@ def main():
 
         ok = [0]
         if rank == 0:
-            try:
-                # (PDMPC_GROUP_LOGICAL=R on a 1-GPU box: R logical ranks on this GPU — the multi-rank protocol with peer copies for RCCL)
-                n_logical = int(os.environ.get("PDMPC_GROUP_LOGICAL", "0"))
-                grp = backend.Group(options, n_devices=n_logical, devices=[local_rank] * n_logical) if n_logical > 1 else backend.Group(options, n_devices=world)
-                grp.upload_mpa(mpa)
-                gmode = backend.SHARD_LEVELS if args.shard == "levels" else backend.SHARD_COMPONENTS
-                for b, prob in enumerate(problems):
-                    grp.pack_step(b, prob["iters"], prob["preds"], [f if f is not None else [] for f in prob["fallback"]],
-                                  weights=prob.get("prev_pops"), mode=gmode)  # (LPT and dispatch order on the work of the step BEFORE)
-                    grp.launch(b)
-                ok = [1]
-            except Exception as e:  # noqa: BLE001 (whatever went wrong: the other path is still there)
-                sys.stderr.write("bench.py: pdmpc_group path not available (%s): falling back to torch.distributed\n" % e)
-                grp = None
+            # (PDMPC_GROUP_LOGICAL=R on a 1-GPU box: R logical ranks on this GPU — the multi-rank protocol with peer copies for RCCL)
+            n_logical = int(os.environ.get("PDMPC_GROUP_LOGICAL", "0"))
+            gmode = backend.SHARD_LEVELS if args.shard == "levels" else backend.SHARD_COMPONENTS
+            fb0 = [f if f is not None else [] for f in problems[0]["fallback"]]
+            want0 = h.plan_step(problems[0]["iters"], problems[0]["preds"], fb0)  # (what the group must return for the first step)
+            # RCCL's all-gather first (ncclCommInitAll over the devices of this process); if the group cannot be created with it, fails, or
+            # returns other records than the single launch, the same exchange as peer copies ordered by events; then the twin
+            for coll in ((backend.COLLECTIVE_COPY,) if n_logical > 1 else (backend.COLLECTIVE_AUTO, backend.COLLECTIVE_COPY)):
+                try:
+                    grp = (backend.Group(options, n_devices=n_logical, devices=[local_rank] * n_logical, collective=coll) if n_logical > 1
+                           else backend.Group(options, n_devices=world, collective=coll))
+                    grp.upload_mpa(mpa)
+                    grp.grow_arena(h.arena_nodes()[0])
+                    for b, prob in enumerate(problems):
+                        grp.pack_step(b, prob["iters"], prob["preds"], [f if f is not None else [] for f in prob["fallback"]],
+                                      weights=prob.get("prev_pops"), mode=gmode)  # (LPT and dispatch order on the work of the step BEFORE)
+                    grp.launch(0)
+                    bad0 = count_record_mismatches(grp.fetch(0, len(problems[0]["iters"])), want0)
+                    if bad0:
+                        raise RuntimeError("%d records of the first step differ from the single launch's" % bad0)
+                    ok = [1]
+                    break
+                except Exception as e:  # noqa: BLE001 (whatever went wrong: the other path is still there)
+                    sys.stderr.write("bench.py: pdmpc_group with collective %d not usable (%s)\n" % (coll, e))
+                    try:
+                        if grp is not None:
+                            grp.close()
+                    except Exception:  # noqa: BLE001
+                        pass
+                    grp = None
+            if grp is None:
+                sys.stderr.write("bench.py: falling back to torch.distributed (one process per GPU)\n")
         # (the library leaves the current device as it found it; torch's collectives are bound to cuda:local_rank, so make sure anyway)
         torch.cuda.set_device(local_rank)
         if dist is not None:
