@@ -369,3 +369,38 @@ def test_arena_growth_with_shared_rounds(monkeypatch):
     assert regrows >= 3 and nodes >= int(ref["n_expanded"].max())
     assert h.stats()["shared_rounds"] > 0
     h.close()
+
+
+@pytest.mark.parametrize("tuning", ["compact=1", "compact=1,helpers=0", "compact=0"])
+def test_co_resident_copies_of_a_search_return_the_same_record(tuning, monkeypatch):
+    """600 copies of four independent searches in ONE launch: more searches than the chip holds at once, two workgroups per CU with
+    the compact kernel.  Every copy must return the record of the first — which is the oracle's.  (Round 6: with two workgroups on a
+    CU a wavefront that had been held up read phase B's vote word one pass late and took the workgroup's barriers apart — wrong
+    counts, error statuses, memory faults; DESIGN.md section 3.12.  This is the 8-second reproducer.)"""
+    monkeypatch.setenv("PDMPC_TUNING", tuning)
+    from oracle import oracle
+    from pdmpc.backend import Handle
+
+    distinct, copies = 4, 600
+    options, mpa, iters = problems.problem_set("interx", 11, distinct, Hp=8)
+    options.max_vehicles = copies
+    options.max_nodes = 1 << 15
+    unbounded = copy.copy(options)
+    unbounded.max_nodes = 1 << 30
+    _, ref, _ = oracle.plan_batch(unbounded, mpa, iters)
+    h = Handle(options)
+    h.upload_mpa(mpa)
+    batch = [iters[i % distinct] for i in range(copies)]
+    try:
+        for rep in range(2):
+            recs = h.plan_step(batch, [[] for _ in batch], None)
+            assert_records_equal(recs[:distinct], ref, "the originals, pass %d" % rep)
+            for name in ("status", "n_expanded", "n_popped", "tree_path", "predicted_trims", "y_predicted", "shapes"):
+                a = np.asarray(recs[name])
+                want = a[np.arange(copies) % distinct]
+                same = (a.view(np.uint64) == want.view(np.uint64)) if a.dtype.kind == "f" else (a == want)
+                bad = np.argwhere(~same.reshape(copies, -1).all(axis=1)).ravel()
+                assert bad.size == 0, "pass %d: field %s of the copies in slots %s differs from the original's" % (rep, name, bad[:8])
+        assert h.stats()["safe_replans"] == 0
+    finally:
+        h.close()
