@@ -178,6 +178,7 @@ struct Tuning {
     int speculate = 1;      // 0: every search waits for all its predecessors before it starts
     int dispatch_order = 1; // 0: ignore pdmpc_set_step_weights (slots in level order, never by priority)
     int fast_select = 1;    // 0: every selection goes through the sixteen-wavefront histogram, also while the open set is small (A/B)
+    int poll_every = 1;     // a search that has just run a round looks for arrived predecessors at every K-th round boundary only (1 .. 8)
     int lazy_verify = 0;    // 1: an arrival into a RUNNING search brings the parked nodes back at once but re-checks the collision-free nodes only when the search stalls or is done
     int compact = -1;       // 1: the kernel built for two workgroups per CU (8 wavefronts, <= 80 KB of LDS: bulk_kernel_compact.hip) where it applies (InterX, one mask word, the soup fits); 0: never; -1: for launches of more than two searches per CU; 2-5: layout experiments (one workgroup per CU with the compact kernel, slack behind the layout)
     int waves = -1;         // wavefronts per workgroup (4 .. PDMPC_MAX_WAVES; -1: 16 for the InterX kernels — 12 for a launch of more than two searches per CU —, 12 for the separating-axis kernel)
@@ -197,7 +198,7 @@ bool parse_tuning(const char* text, Tuning& T, std::string& err) {
     int spin = (int)T.spin_limit;
     const Key keys[] = {{"round0", &T.round0}, {"round", &T.round}, {"ramp", &T.ramp}, {"ready", &T.ready}, {"share_min", &T.share_min}, {"own_div", &T.own_div},
                         {"tile", &T.tile}, {"mid_min", &T.mid_min}, {"mid_fill", &T.mid_fill}, {"tentative", &T.tentative}, {"fast_arrival", &T.fast_arrival}, {"helpers_first", &T.helpers_first}, {"seat_nodes", &T.seat_nodes},
-                        {"helpers", &T.helpers}, {"helpers_oversub", &T.helpers_oversub}, {"speculate", &T.speculate}, {"waves", &T.waves}, {"compact", &T.compact}, {"lazy_verify", &T.lazy_verify}, {"fast_select", &T.fast_select}, {"dispatch_order", &T.dispatch_order}, {"spin_limit", &spin},
+                        {"helpers", &T.helpers}, {"helpers_oversub", &T.helpers_oversub}, {"speculate", &T.speculate}, {"waves", &T.waves}, {"compact", &T.compact}, {"lazy_verify", &T.lazy_verify}, {"poll_every", &T.poll_every}, {"fast_select", &T.fast_select}, {"dispatch_order", &T.dispatch_order}, {"spin_limit", &spin},
                         {"force_tie", &T.force_tie}, {"reverse_dispatch", &T.reverse_dispatch}, {"debug_tail", &T.debug_tail}, {"debug_lds", &T.debug_lds},
                         {"debug_host", &T.debug_host}, {"debug_progress", &T.debug_progress}};
     std::string str(text ? text : "");
@@ -836,7 +837,7 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     a.bk_round0 = T.round0 > 0 ? T.round0 : 24;  // (C3's class: below, once the helpers are counted)
     a.bk_round = std::min(h->bk_ready_launch / 2 - 16, std::max(a.bk_round0, T.round > 0 ? T.round : (helped ? 1000 : 256)));
     a.bk_ramp = T.ramp > 0 ? T.ramp : (helped ? 2 : 4);
-    a.bk_flags = (T.fast_select ? 1 : 0) | (T.lazy_verify ? 2 : 0);
+    a.bk_flags = (T.fast_select ? 1 : 0) | (T.lazy_verify ? 2 : 0) | ((std::min(8, std::max(1, T.poll_every)) - 1) << 2);
     a.bk_mid_min = T.mid_min;
     a.bk_mid_fill = T.mid_fill;
     a.bk_tile = T.tile > 0 ? T.tile : 256;

@@ -1233,6 +1233,7 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         lane = l__;                                        \
     }
         // ================= a round =================
+        const bool ran_round = Rn != 0u;
         if (Rn) {
             pb_valid = false;  // (the tree grows: phase B's result is stale)
             rec_valid = false;
@@ -1583,7 +1584,11 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         // for everybody who has arrived meanwhile; a running search verifies right behind the copy (measured: putting it off until
         // the search has nothing else to do leaves parked nodes parked and dead subtrees alive — C2's heavy steps 1.35 -> 1.75 ms).
         BK_MARK2
-        if (sh_load64(sh, SH_PEND_LO) != 0ull) {  // (uniform: written by thread 0 between barriers)
+        // (bk_flags bits 2-4, PDMPC_TUNING=poll_every=K: a search that has just run a round looks for arrivals at every K-th boundary
+        // only — an arrival event costs a running light search 15-25 us whatever it brings; a search that stalls or is done polls at once)
+        const uint32_t poll_k = ((uint32_t)A.bk_flags >> 2) & 7u;
+        const bool skip_poll = ran_round && poll_k != 0u && (sh[FR_ROUNDS] % (poll_k + 1u)) != 0u && sh[SH_STATE] != ST_ARRIVED;
+        if (!skip_poll && sh_load64(sh, SH_PEND_LO) != 0ull) {  // (uniform: written by thread 0 between barriers)
             if (wave == 0 && sh[SH_STATE] != ST_ARRIVED) (void)bk_poll_predecessors(A, P, sh, 0ull, lane);  // (a waiting search has polled already: bk_wait)
             __syncthreads();
             if (sh[SH_STATE] == ST_ARRIVED) {  // (uniform)
