@@ -1326,7 +1326,7 @@ int plan_packed_growing(pdmpc_handle* h, int32_t n, pdmpc_vehicle_out* out, int3
         if (timed_out && safe)
             return fail(PDMPC_ERR_HIP, "a search gave up waiting for a predecessor although the call was planned in resident slices without helper workgroups (records carry PDMPC_ERR_HIP)");
         if (timed_out && !safe) {
-            // A search gave up waiting for a predecessor of the same launch (the watchdog of frontier_kernel.hip): the launch was
+            // A search gave up waiting for a predecessor of the same launch (the kernel's watchdog): the launch was
             // oversubscribed and the dispatch order starved a predecessor, or a helper sat where a search should have run.  Plan
             // the call again in slices that are resident as a whole: forward progress then rests on nothing but slot order.
             safe = true;
@@ -1659,7 +1659,7 @@ namespace {
 // The frontier kernel processes open nodes in parallel, so its arena holds the reference's tree plus some nodes the
 // reference never creates, in another order.  This turns it back into the reference's tree and pop sequence, on the host
 // and independently of the kernel's phase B (it sorts the popped nodes instead of counting them), for the debug read-backs
-// the parity tests use.  Order (frontier_kernel.hip): X is popped before Y iff X is an ancestor of Y or the largest key on
+// the parity tests use.  Order (bulk_search.hpp): X is popped before Y iff X is an ancestor of Y or the largest key on
 // the path (LCA, X] is smaller than the largest key on (LCA, Y].
 struct RefTree {
     std::vector<NodeRec> rec;        // raw records

@@ -940,7 +940,7 @@ __device__ __forceinline__ void bk_replay(const KernelArgs& A, Ctx& X, const Fro
     }
 }
 
-// The search.  Returns true (to every thread) if a tie was met: the host plans the call again with the heap-carrying kernel.
+// The search (results in X).  The return value is unused (always false: equal keys are resolved inside the search, bk_replay).
 template <int NW, int CHECKER>
 __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32* ref_ids) {
     const int tid = X.tid, lane = X.lane, wave = X.wave, slot = X.slot, Hp = X.Hp;
@@ -955,7 +955,6 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
     const int n = X.n, nw = NW > 0 ? NW : X.nw;
     const uint32_t OC = (uint32_t)(BK_PER * bd), RC = (uint32_t)A.bk_ready_cap;
     const uint32_t VCAP = 1024u;  // expansion groups per tile (vlist / voffs)
-    const uint32_t TILE = (uint32_t)A.bk_tile;  // entries of a tile of a shared round (what a helper workgroup claims at a time)
 
     // ---- LDS carve of the bulk region
     lds_f64* near_key = (lds_f64*)(X.lsm + PDMPC_LK_NEAR_KEY);

@@ -1,7 +1,7 @@
-// frontier_common.hpp — device code shared by the round-based search kernels (frontier_kernel.hip: one node per wavefront;
-// bulk_kernel.hip: bulk-synchronous passes): shared-word indices, LDS counter helpers, the walks that decide whether an open
-// node comes before the goal candidate, goal-candidate resolution, the re-check of collision-free nodes against late
-// predecessor areas, and phase B (the reference's counts and ids).  Included after serial_search.hpp.
+// frontier_common.hpp — device code of the round-based search (bulk_search.hpp) that is not the round loop itself: shared-word
+// indices, LDS counter helpers, the list partition and histogram, the walks that decide whether an open node comes before the goal
+// candidate, goal-candidate resolution, and phase B (the reference's counts and ids).  Included after search_common.hpp.
+// (The name is history: rounds 2-3 had a "frontier kernel" — one node per wavefront — next to this code; docs/HISTORY.md.)
 #pragma once
 #include <type_traits>
 
