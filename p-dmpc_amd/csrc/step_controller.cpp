@@ -1260,7 +1260,7 @@ int pdmpc_controller_explore_choose(pdmpc_controller* c, const pdmpc_vehicle_out
 namespace {
 // (status and cost-to-come of the final node per slot of the batch: all the choice looks at)
 int explore_choose_on(pdmpc_controller* c, const int32_t* status, const double* final_cost, int32_t* chosen, int32_t* n_graphs, double* cost) {
-    const int n = c->n, Hp = c->Hp, K = (int)c->inst.size();
+    const int n = c->n, K = (int)c->inst.size();
     std::vector<int> label((size_t)n);
     for (int i = 0; i < n; ++i) label[(size_t)i] = i;
     auto find = [&](int a) {
