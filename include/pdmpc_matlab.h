@@ -83,6 +83,9 @@ int pdmpc_ml_step_problem(const pdmpc_ml_step* s, int32_t* n, const pdmpc_vehicl
 void pdmpc_ml_step_destroy(pdmpc_ml_step* s);
 /* plans the step with ONE launch (pdmpc_plan_step); out[v] = record of VEHICLE v (not of slot v) */
 int pdmpc_ml_plan_step(pdmpc_handle* handle, const pdmpc_ml_step* s, pdmpc_vehicle_out* out);
+/* ... with the expected work per VEHICLE (MATLAB's vehicle order; e.g. n_popped of each vehicle's last plan; NULL: none): the launch
+ * fills its slots by priority (pdmpc_set_step_weights).  Same records. */
+int pdmpc_ml_plan_step_weighted(pdmpc_handle* handle, const pdmpc_ml_step* step, const double* weights, pdmpc_vehicle_out* out);
 /* the same step over the GPUs of a group (pdmpc_group_*, include/pdmpc.h): weights[v] (may be NULL) = expected work of VEHICLE v,
  * mode = PDMPC_SHARD_*; out[v] = record of vehicle v.  What PredictionsCommunication.m:34-63 does between the vehicles' processes
  * happens between the devices: an RCCL all-gather of the solved areas. */

@@ -288,6 +288,20 @@ int pdmpc_ml_plan_step(pdmpc_handle* h, const pdmpc_ml_step* s, pdmpc_vehicle_ou
     return PDMPC_OK;
 }
 
+int pdmpc_ml_plan_step_weighted(pdmpc_handle* h, const pdmpc_ml_step* s, const double* weights, pdmpc_vehicle_out* out) {
+    if (!h || !s) return ml_fail(PDMPC_ERR_INVALID, "pdmpc_ml_plan_step_weighted: null argument");
+    if (weights && s->n > 0) {  // (per vehicle -> per slot of the step as it is handed to pdmpc_plan_step)
+        std::vector<double> w((size_t)s->n);
+        for (int sl = 0; sl < s->n; ++sl) w[(size_t)sl] = weights[(size_t)s->order[(size_t)sl] - 1];
+        const int rc = pdmpc_set_step_weights(h, s->n, w.data());
+        if (rc) {
+            g_ml_err = pdmpc_last_error();
+            return rc;
+        }
+    }
+    return pdmpc_ml_plan_step(h, s, out);
+}
+
 int pdmpc_ml_group_plan_step(pdmpc_group* g, const pdmpc_ml_step* s, const double* weights, int32_t mode, pdmpc_vehicle_out* out) {
     if (!g || !s || (s->n > 0 && !out)) return ml_fail(PDMPC_ERR_INVALID, "pdmpc_ml_group_plan_step: null argument");
     std::vector<pdmpc_vehicle_out> slots((size_t)std::max(s->n, 1));

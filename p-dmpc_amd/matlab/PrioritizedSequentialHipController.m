@@ -110,7 +110,10 @@ classdef PrioritizedSequentialHipController < PrioritizedSequentialController
                 outs = pdmpc_mex('group_plan_step', obj.handle, iters, double(directed_coupling_sequential), fallback_areas, obj.last_work, obj.shard_mode);
                 obj.last_work = double([outs.n_expanded]);
             else
-                outs = pdmpc_mex('plan_step', obj.handle, iters, double(directed_coupling_sequential), fallback_areas);
+                % (the work of every vehicle's last search as the expected work of this one: the launch hands its searches out by
+                % priority, heavy ones and their predecessors first — pdmpc_set_step_weights; results are the same bit for bit)
+                outs = pdmpc_mex('plan_step', obj.handle, iters, double(directed_coupling_sequential), fallback_areas, obj.last_work);
+                obj.last_work = double([outs.n_popped]);
             end
 
             % ---- results, in kahn order (publish_predictions sends the messages later readers expect in this order)

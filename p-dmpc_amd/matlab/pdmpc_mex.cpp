@@ -8,7 +8,7 @@
 //     out  = pdmpc_mex('plan', h, iter_struct)                     one run_optimizer call (GraphSearchHip.m)
 //     out  = pdmpc_mex('plan_sampled', h, iter_struct, seed)       the sampled optimizer (MonteCarloTreeSearchHip.m)
 //     outs = pdmpc_mex('plan_level', h, iter_structs)              one computation level: n vehicles, one launch
-//     outs = pdmpc_mex('plan_step', h, iter_structs, directed_coupling_sequential, fallback_areas)
+//     outs = pdmpc_mex('plan_step', h, iter_structs, directed_coupling_sequential, fallback_areas [, weights])
 //                                                                  ALL levels of a time step in one launch
 //                                                                  (PrioritizedSequentialHipController.m)
 //            pdmpc_mex('destroy', h)
@@ -88,13 +88,14 @@ class MexFunction : public matlab::mex::Function {
 
     // pdmpc_vehicle_out[n] -> 1 x n struct array in MATLAB's layout (pdmpc_ml_record_arrays)
     StructArray records(const std::vector<pdmpc_vehicle_out>& out, size_t Hp) {
-        StructArray s = f.createStructArray({1, out.size()}, {"status", "n_expanded", "predicted_trims", "shape_cols", "y_predicted", "shapes", "path_nodes", "tree_path"});
+        StructArray s = f.createStructArray({1, out.size()}, {"status", "n_expanded", "n_popped", "predicted_trims", "shape_cols", "y_predicted", "shapes", "path_nodes", "tree_path"});
         for (size_t i = 0; i < out.size(); ++i) {
             TypedArray<double> trims = f.createArray<double>({1, Hp}), cols = f.createArray<double>({1, Hp}), path = f.createArray<double>({1, Hp + 1});
             TypedArray<double> y = f.createArray<double>({Hp, 3}), nodes = f.createArray<double>({Hp + 1, 8}), shapes = f.createArray<double>({Hp, 2, PDMPC_VMAX});
             pdmpc_ml_record_arrays(&out[i], (int32_t)Hp, &*trims.begin(), &*cols.begin(), &*y.begin(), &*shapes.begin(), &*nodes.begin(), &*path.begin());
             s[i]["status"] = f.createScalar<double>(out[i].status);
             s[i]["n_expanded"] = f.createScalar<double>(out[i].n_expanded);
+            s[i]["n_popped"] = f.createScalar<double>(out[i].n_popped);
             s[i]["predicted_trims"] = trims;
             s[i]["shape_cols"] = cols;
             s[i]["y_predicted"] = y;
@@ -207,7 +208,11 @@ public:
                     const int32_t mode = inputs.size() > 6 ? (int32_t)inputs[6][0] : PDMPC_SHARD_AUTO;
                     rc = pdmpc_ml_group_plan_step(group, step, w.data, mode, out.data());
                 } else {
-                    rc = pdmpc_ml_plan_step(h, step, out.data());
+                    // optional 5th argument: 1 x n expected work per vehicle (e.g. the n_popped of its last plan), [] = none: the launch
+                    // fills its slots by priority (pdmpc_ml_plan_step_weighted -> pdmpc_set_step_weights)
+                    const pdmpc_ml_matrix w = inputs.size() > 5 && !inputs[5].isEmpty() ? pins.matrix(inputs[5]) : pdmpc_ml_matrix{nullptr, 0, 0};
+                    if (w.data != nullptr && (size_t)w.rows * (size_t)w.cols != n) fail("plan_step", "weights must hold one value per vehicle");
+                    rc = pdmpc_ml_plan_step_weighted(h, step, w.data, out.data());
                 }
                 pdmpc_ml_step_destroy(step);
                 if (rc != PDMPC_OK) fail(group ? "pdmpc_ml_group_plan_step" : "pdmpc_ml_plan_step", pdmpc_ml_last_error());

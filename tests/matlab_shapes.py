@@ -168,11 +168,16 @@ def step_problem(step):
     return n.value, vin, po, pi, fb, order, levels
 
 
-def plan_step(handle, step, n):
-    """pdmpc_ml_plan_step on a backend.Handle -> records in VEHICLE order."""
+def plan_step(handle, step, n, weights=None):
+    """pdmpc_ml_plan_step (weights: pdmpc_ml_plan_step_weighted, expected work per VEHICLE) on a backend.Handle -> records in VEHICLE order."""
     L = lib()
     out = abi.out_array(n)
-    rc = L.pdmpc_ml_plan_step(handle.h, step, abi.out_ptr(out))
+    if weights is None:
+        rc = L.pdmpc_ml_plan_step(handle.h, step, abi.out_ptr(out))
+    else:
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        L.pdmpc_ml_plan_step_weighted.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(abi.VehicleOut)]
+        rc = L.pdmpc_ml_plan_step_weighted(handle.h, step, w.ctypes.data_as(C.c_void_p), abi.out_ptr(out))
     if rc != 0:
         raise RuntimeError("pdmpc_ml_plan_step: %d %s" % (rc, L.pdmpc_ml_last_error().decode()))
     return out[:n]

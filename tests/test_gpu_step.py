@@ -590,12 +590,15 @@ def test_matlab_shaped_entry_points_plan_the_step_like_the_oracle():
     assert ms.lib().pdmpc_ml_upload_mpa(h.h, T, n_trims, Hp, man) == 0
     ctl = PrioritizedSequentialController(options, sc, mpa, None, coupling="distance", boundary_provider=boundary_provider(sc))
 
+    last = [None]  # n_popped per VEHICLE of the step before: what PrioritizedSequentialHipController.m hands over as weights
+
     def plan_step(prob):
         n = len(prob["iters"])
         keep = ms.Keep()
         step = ms.step_create(ms.vehicle_order_problem(prob), options.Hp, keep)
-        by_vehicle = ms.plan_step(h, step, n)
+        by_vehicle = ms.plan_step(h, step, n, weights=last[0])
         ms.lib().pdmpc_ml_step_destroy(step)
+        last[0] = np.asarray(by_vehicle["n_popped"], dtype=np.float64) + 1.0
         ref, _ = oracle.plan_step(options, mpa, prob)
         gpu = by_vehicle[np.asarray(prob["order"])]  # back into slot order
         assert_records_equal(gpu, ref, "matlab-shaped step")
