@@ -242,6 +242,11 @@ int pdmpc_synchronize(pdmpc_handle* handle);
  * pdmpc_set_safe_launch(on != 0) makes every launch of this handle, resident paths included, use the resident slices from the start.
  * Tested against the adversarial order with PDMPC_TUNING=reverse_dispatch=1 (tests/test_gpu_step.py). */
 int pdmpc_set_safe_launch(pdmpc_handle* handle, int32_t on);
+/* n_handles handles of this process launch on the handle's device side by side (pdmpc_group_create_ex sets it for logical ranks that
+ * share a GPU): the helper workgroups of a launch are sized for 1 / n_handles of the device's idle CUs and none of them is dispatched
+ * in front of the searches — four launches with half a chip's worth of helpers in front of each would fill the device with helpers
+ * that wait for searches which cannot start. */
+int pdmpc_set_device_share(pdmpc_handle* handle, int32_t n_handles);
 /* starts a new time step for launches issued with pdmpc_launch_range: results of earlier steps stop
  * satisfying predecessor waits (pdmpc_launch_packed does this implicitly) */
 int pdmpc_begin_step(pdmpc_handle* handle);

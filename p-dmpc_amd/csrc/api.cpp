@@ -287,6 +287,7 @@ struct pdmpc_handle {
     bool last_launch_search = false;     // the last launch ran the graph search (not the sampled optimizer)
     int last_first = 0, last_count = 0;  // slots of the last launch_range
     bool last_safe = false;              // ... and whether it went out in resident slices
+    int device_share = 1;                // handles of one process that launch on this device side by side (pdmpc_set_device_share: a group's logical ranks)
     bool boards_dirty = true;            // the helper boards / the finished counter need clearing before the helper workgroups may read them
     uint32_t help_fin_total = 0;         // value of the finished counter once every launch so far has ended
     uint32_t launch_serial = 0;          // launches of this handle so far (KernelArgs::launch_id)
@@ -881,8 +882,11 @@ int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     // start when the step is half over (C4: a helper lived 5-6 of the step's 11 ms, and the step's 10^5-node search ran most of its
     // rounds with fewer than eight seats).  Half the CUs' worth of helpers in front of the searches: C4 82.8 -> 90.2 steps/s (32: 84.2,
     // 64: 86.5, 128: 90.2, 160: 88.0, 200: 54.6).  A launch of independent searches keeps every CU for them.
+    // (handles that share a device — the logical ranks of a group — launch side by side: the idle CUs are the device's, not the
+    // launch's, and helper workgroups in FRONT of every launch's searches would fill the chip before any search starts)
+    if (h->device_share > 1) a.n_helpers = a.n_helpers / h->device_share >= 2 ? a.n_helpers / h->device_share : 0;
     a.bk_helpers_first = 0;
-    if (count > h->n_cu && a.n_helpers > 0) {
+    if (count > h->n_cu && a.n_helpers > 0 && h->device_share == 1) {
         int want = T.helpers_first;
         if (want < 0 && count > 2 * h->n_cu) want = 0;  // (five searches per CU, C5: the searches need every CU — 128 in front 331 steps/s, 32: 515, none: 560)
         if (want < 0) {
@@ -1157,6 +1161,12 @@ int pdmpc_launch_packed(pdmpc_handle* h) {
     ON_DEVICE(h->cfg.device);
     h->epoch += 1;  // a new step: results of earlier launches no longer satisfy predecessor waits
     return launch_range(h, 0, h->banks[h->bank].n_packed, h->safe_launches);
+}
+
+int pdmpc_set_device_share(pdmpc_handle* h, int32_t n_handles) {
+    if (!h || n_handles < 1) return fail(PDMPC_ERR_INVALID, "pdmpc_set_device_share: bad argument");
+    h->device_share = n_handles;
+    return PDMPC_OK;
 }
 
 int pdmpc_set_safe_launch(pdmpc_handle* h, int32_t on) {

@@ -2251,7 +2251,9 @@ __device__ __forceinline__ bool bulk_search(const KernelArgs& A, Ctx& X, lds_u32
         // ---- this round's entries: the smallest keys of near.  Every thread holds BK_PER entries in registers.
         {
             BK_TICK3(4)
-            __syncthreads();  // (the classification below may raise FRF_TIE and the scan's thread 0 rewrites near's count: behind everybody's boundary decisions)
+            // (the classification below may raise FRF_TIE: behind everybody's boundary decisions.  With a histogram its barrier is
+            // in front of the classification anyway; the scan's barrier is in front of thread 0's rewrite of near's count)
+            if (!(nn_near > round_target)) __syncthreads();
             const double lo = sh_ld_d(sh, FR_NEAR_MIN);
             double hi = sh_ld_d(sh, FR_NEAR_MAX);
             double kk[BK_PER];

@@ -633,6 +633,8 @@ int pdmpc_group_create_ex(const pdmpc_config* config, int32_t n_devices, const i
             return rc;
         }
         g->h.push_back(h);
+        const int share = (int)std::count(g->dev.begin(), g->dev.end(), g->dev[(size_t)r]);
+        if (share > 1) (void)pdmpc_set_device_share(h, share);  // (logical ranks: their launches run side by side on one GPU)
         void* st = nullptr;
         (void)pdmpc_stream(h, &st);
         g->stream.push_back((hipStream_t)st);

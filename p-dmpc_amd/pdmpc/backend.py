@@ -47,6 +47,7 @@ EXPORTS = [
     "pdmpc_group_create",
     "pdmpc_group_create_ex",
     "pdmpc_set_step_weights",
+    "pdmpc_set_device_share",
     "pdmpc_last_call_timing",
     "pdmpc_plan_step_lean",
     "pdmpc_fetch_records_at",
