@@ -28,6 +28,7 @@
 #include <string>
 #include <utility>
 #include <map>
+#include <memory>
 #include <vector>
 
 #include "../../include/pdmpc.h"
@@ -88,12 +89,40 @@ struct pdmpc_controller {
     std::vector<Poly> bnd_left, bnd_right;
     std::vector<uint8_t> adjacency, directed, directed_seq;  // n x n row-major
     std::vector<int32_t> levels, order, slot_of;
-    // the step problem in the C ABI's form (what pdmpc_plan_step takes); pools keep the pointed-to data alive
+    // the step problem in the C ABI's form (what pdmpc_plan_step takes); the arena keeps the pointed-to data alive
     std::vector<pdmpc_vehicle_in> in;
     std::vector<pdmpc_polygon_set> fb;
     std::vector<int32_t> pred_offset, pred_index;
-    std::vector<std::vector<double>> dpool;
-    std::vector<std::vector<int32_t>> ipool;
+    // the arrays of the step's polygon sets: chunks that are kept from step to step and handed out front to back (a set's arrays
+    // never move; build_step starts over at the first chunk)
+    struct Arena {
+        struct Chunk {
+            std::unique_ptr<double[]> mem;  // (doubles: 8-byte alignment for both kinds of arrays)
+            size_t cap = 0;
+        };
+        std::vector<Chunk> chunks;
+        size_t cur = 0, used = 0;
+        void reset() { cur = used = 0; }
+        void* take(size_t bytes) {
+            const size_t need = (bytes + 7) / 8;
+            while (cur < chunks.size() && used + need > chunks[cur].cap) {
+                ++cur;
+                used = 0;
+            }
+            if (cur == chunks.size()) {
+                Chunk ch;
+                ch.cap = std::max(need, (size_t)1 << 17);
+                ch.mem.reset(new double[ch.cap]);
+                chunks.push_back(std::move(ch));
+                used = 0;
+            }
+            void* p = chunks[cur].mem.get() + used;
+            used += need;
+            return p;
+        }
+    } arena;
+    std::vector<int32_t> sb_off;  // SetBuilder's scratch (one builder at a time)
+    std::vector<double> sb_x, sb_y;
     std::vector<pdmpc_vehicle_out> out;
     // sets that do not depend on the prioritization are built once per time step and shared by the prioritizations of an explorative step
     std::vector<pdmpc_polygon_set> fb_of;
@@ -108,6 +137,7 @@ struct pdmpc_controller {
     std::vector<std::map<MemoKey, pdmpc_polygon_set>> obst_memo, dyn_memo;
     pdmpc_polygon_set empty_set{};
     bool empty_done = false;
+    bool exploring = false;  // an explorative step is being built: its prioritizations share sets through the memos
     // explorative step (PrioritizedExplorativeController): the prioritizations of the current traffic state, flattened
     struct Instance {
         std::vector<uint8_t> directed, directed_seq;
@@ -131,14 +161,56 @@ thread_local std::string g_cerr;
 inline uint8_t& at(std::vector<uint8_t>& m, int n, int i, int j) { return m[(size_t)i * n + j]; }
 inline uint8_t at(const std::vector<uint8_t>& m, int n, int i, int j) { return m[(size_t)i * n + j]; }
 
+// f(j) for the non-zero entries j of a matrix row, ascending.  Rows of the coupling matrices are mostly zero (a vehicle is coupled with
+// the few around it): eight entries per test.
+template <class F>
+inline void for_each_set(const uint8_t* row, int n, F&& f) {
+    int j = 0;
+    for (; j + 8 <= n; j += 8) {
+        uint64_t w;
+        std::memcpy(&w, row + j, 8);
+        if (w == 0) continue;
+        for (int q = 0; q < 8; ++q)
+            if (row[j + q]) f(j + q);
+    }
+    for (; j < n; ++j)
+        if (row[j]) f(j);
+}
+
+// the non-zero entries of a matrix as lists: by row (idx[off[i] .. off[i + 1]) = the columns of row i) or by column (the rows of
+// column j), ascending in both forms
+struct Lists {
+    std::vector<int32_t> off, idx;
+    int size(int i) const { return off[i + 1] - off[i]; }
+    const int32_t* begin(int i) const { return idx.data() + off[i]; }
+    const int32_t* end(int i) const { return idx.data() + off[i + 1]; }
+};
+void lists_by_row(const std::vector<uint8_t>& M, int n, Lists& L) {
+    L.off.assign((size_t)n + 1, 0);
+    L.idx.clear();
+    for (int i = 0; i < n; ++i) {
+        for_each_set(M.data() + (size_t)i * n, n, [&](int j) { L.idx.push_back(j); });
+        L.off[i + 1] = (int32_t)L.idx.size();
+    }
+}
+void lists_by_column(const std::vector<uint8_t>& M, int n, const Lists& by_row, Lists& L) {
+    (void)M;
+    L.off.assign((size_t)n + 1, 0);
+    for (int32_t j : by_row.idx) ++L.off[j + 1];
+    for (int j = 0; j < n; ++j) L.off[j + 1] += L.off[j];
+    L.idx.resize(by_row.idx.size());
+    std::vector<int32_t> fill(L.off.begin(), L.off.end() - 1);
+    for (int i = 0; i < n; ++i)
+        for (const int32_t* q = by_row.begin(i); q != by_row.end(i); ++q) L.idx[fill[*q]++] = i;
+}
+
 // utility/kahn.m:1-24: computation level (1-based) of every vertex of the DAG A (A[i][j] = 1: i before j)
 bool kahn(const std::vector<uint8_t>& A, int n, std::vector<int32_t>& L) {
     // level = 1 + the longest path from a source (what removing all current sources, level by level, assigns); in-degrees are
     // counted once and decremented along the removed vertices' rows
     L.assign(n, 0);
     std::vector<int> indeg(n, 0), cur, next;
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) indeg[j] += A[(size_t)i * n + j] != 0;
+    for (int i = 0; i < n; ++i) for_each_set(A.data() + (size_t)i * n, n, [&](int j) { ++indeg[j]; });
     for (int j = 0; j < n; ++j)
         if (indeg[j] == 0) cur.push_back(j);
     int n_done = 0, level = 1;
@@ -150,8 +222,33 @@ bool kahn(const std::vector<uint8_t>& A, int n, std::vector<int32_t>& L) {
             ++n_done;
         }
         for (int v : cur)
-            for (int j = 0; j < n; ++j)
-                if (A[(size_t)v * n + j] && --indeg[j] == 0) next.push_back(j);
+            for_each_set(A.data() + (size_t)v * n, n, [&](int j) {
+                if (--indeg[j] == 0) next.push_back(j);
+            });
+        cur.swap(next);
+        ++level;
+    }
+    return true;
+}
+
+// kahn over the successor lists of the matrix
+bool kahn_lists(const Lists& succ, int n, std::vector<int32_t>& L) {
+    L.assign(n, 0);
+    std::vector<int> indeg(n, 0), cur, next;
+    for (int32_t j : succ.idx) ++indeg[j];
+    for (int j = 0; j < n; ++j)
+        if (indeg[j] == 0) cur.push_back(j);
+    int n_done = 0, level = 1;
+    while (n_done < n) {
+        if (cur.empty()) return false;  // a cycle
+        next.clear();
+        for (int v : cur) {
+            L[v] = level;
+            ++n_done;
+        }
+        for (int v : cur)
+            for (const int32_t* q = succ.begin(v); q != succ.end(v); ++q)
+                if (--indeg[*q] == 0) next.push_back(*q);
         cur.swap(next);
         ++level;
     }
@@ -238,11 +335,11 @@ void arc_projection(double px, double py, const std::vector<double>& cx, const s
     const int np = (int)cx.size();
     int ic = 0;
     double best = 0;
-    std::vector<double> sq(np);
+    auto sq_of = [&](int i) { return (cx[i] - px) * (cx[i] - px) + (cy[i] - py) * (cy[i] - py); };
     for (int i = 0; i < np; ++i) {
-        sq[i] = (cx[i] - px) * (cx[i] - px) + (cy[i] - py) * (cy[i] - py);
-        if (i == 0 || sq[i] < best) {
-            best = sq[i];
+        const double d = sq_of(i);
+        if (i == 0 || d < best) {
+            best = d;
             ic = i;
         }
     }
@@ -253,7 +350,7 @@ void arc_projection(double px, double py, const std::vector<double>& cx, const s
     } else if (ic == np - 1) {
         f = np - 2;
         s = np - 1;
-    } else if (sq[ic - 1] <= sq[ic + 1]) {
+    } else if (sq_of(ic - 1) <= sq_of(ic + 1)) {
         f = ic - 1;
         s = ic;
     } else {
@@ -325,39 +422,29 @@ void lanelet_boundary(const pdmpc_controller& c, int v, const std::vector<int32_
     right.y.clear();
     if (V.lanelets_index.empty()) return;
     const int n_total = (int)V.px.size(), n_lan = (int)V.lanelets_index.size();
-    std::vector<int> rpi(ref_points_index.begin(), ref_points_index.end());
-    int index_add = rpi.back() + 4;
+    int rpi[PDMPC_HP_MAX + 1], seen[PDMPC_HP_MAX + 2], predicted[PDMPC_HP_MAX + 2];
+    int n_rpi = 0, n_seen = 0, n_pred = 0;
+    for (int32_t p : ref_points_index) rpi[n_rpi++] = p;
+    int index_add = rpi[n_rpi - 1] + 4;
     if (index_add > n_total) index_add -= n_total;
-    rpi.push_back(index_add);
-    std::vector<int> seen;
-    for (int p : rpi) {
+    rpi[n_rpi++] = index_add;
+    for (int t = 0; t < n_rpi; ++t) {
+        const int p = rpi[t];
         int q = 1;
-        for (int t = 0; t < n_lan; ++t) q += p > V.points_index[t];
-        if (std::find(seen.begin(), seen.end(), q) == seen.end()) seen.push_back(q);  // unique(..., 'stable')
+        for (int u = 0; u < n_lan; ++u) q += p > V.points_index[u];
+        if (std::find(seen, seen + n_seen, q) == seen + n_seen) seen[n_seen++] = q;  // unique(..., 'stable')
     }
-    if (seen.size() == 1) {
+    if (n_seen == 1) {
         int nxt = seen[0] + 1;
         if (nxt > n_lan) nxt = 1;
-        seen.push_back(nxt);
+        seen[n_seen++] = nxt;
     }
     (void)current_point_index;
-    std::vector<int> predicted;
-    for (int q : seen) predicted.push_back(V.lanelets_index[std::min(q, n_lan) - 1]);
-    // boundaries of the predicted lanelets back to back, each without its last point but the final one   :26-32
+    for (int t = 0; t < n_seen; ++t) predicted[n_pred++] = V.lanelets_index[std::min(seen[t], n_lan) - 1];
     auto append = [](Poly& dst, const Poly& src, int from, int to) {
-        for (int i = from; i < to; ++i) {
-            dst.x.push_back(src.x[i]);
-            dst.y.push_back(src.y[i]);
-        }
+        dst.x.insert(dst.x.end(), src.x.begin() + from, src.x.begin() + to);
+        dst.y.insert(dst.y.end(), src.y.begin() + from, src.y.begin() + to);
     };
-    Poly L, R;
-    for (size_t q = 0; q < predicted.size(); ++q) {
-        const Poly& bl = c.bl_left[predicted[q] - 1];
-        const Poly& br = c.bl_right[predicted[q] - 1];
-        const bool final_one = q + 1 == predicted.size();
-        append(L, bl, 0, final_one ? bl.n() : bl.n() - 1);
-        append(R, br, 0, final_one ? br.n() : br.n() - 1);
-    }
     // up to four points of the predecessor lanelet in front   :39-65
     int pos = (int)(std::find(V.lanelets_index.begin(), V.lanelets_index.end(), predicted[0]) - V.lanelets_index.begin());
     int pred = -1;
@@ -372,8 +459,14 @@ void lanelet_boundary(const pdmpc_controller& c, int v, const std::vector<int32_
         append(left, pl, pl.n() - 1 - num_added, pl.n() - 1);
         append(right, pr, pr.n() - 1 - num_added, pr.n() - 1);
     }
-    append(left, L, 0, L.n());
-    append(right, R, 0, R.n());
+    // then the boundaries of the predicted lanelets back to back, each without its last point but the final one   :26-32
+    for (int q = 0; q < n_pred; ++q) {
+        const Poly& bl = c.bl_left[predicted[q] - 1];
+        const Poly& br = c.bl_right[predicted[q] - 1];
+        const bool final_one = q + 1 == n_pred;
+        append(left, bl, 0, final_one ? bl.n() : bl.n() - 1);
+        append(right, br, 0, final_one ? br.n() : br.n() - 1);
+    }
     for (int i = 0; i < left.n(); ++i) {
         left.x[i] = left.x[i] + V.tile_dx;
         left.y[i] = left.y[i] + V.tile_dy;
@@ -386,64 +479,86 @@ void lanelet_boundary(const pdmpc_controller& c, int v, const std::vector<int32_
 
 // ColoringPrioritizer.prioritize (:11-27): directed coupling from a colouring of the undirected graph
 void coloring_directed(const std::vector<uint8_t>& adjacency, int n, std::vector<uint8_t>& directed) {
-    std::vector<uint8_t> A = adjacency;
-    for (int i = 0; i < n; ++i) at(A, n, i, i) = 0;
+    // neighbour lists of the graph without self-loops; the degrees the selection compares are the matrix's column sums (:38-45)
+    Lists nb;
+    nb.off.assign((size_t)n + 1, 0);
+    nb.idx.clear();
     std::vector<int> degree(n, 0), color(n, 0);
-    for (int j = 0; j < n; ++j)
-        for (int i = 0; i < n; ++i) degree[j] += at(A, n, i, j);
+    std::vector<long> deg(n, 0);  // column counts of the matrix as given (order_topo, :93)
+    for (int i = 0; i < n; ++i) {
+        for_each_set(adjacency.data() + (size_t)i * n, n, [&](int j) {
+            ++deg[j];
+            if (j == i) return;
+            nb.idx.push_back(j);
+            degree[j] += adjacency[(size_t)i * n + j];
+        });
+        nb.off[i + 1] = (int32_t)nb.idx.size();
+    }
     for (int i = 0; i < n; ++i)
         if (degree[i] == 0) color[i] = 1;  // :45
-    // neighbour lists, and per vertex the distinct colours its neighbours carry (kept up to date as vertices are coloured: the
-    // selection below is then a scan of the vertices, not of the matrix — 512 vehicles: 63 ms -> well under 1 ms per step)
-    std::vector<std::vector<int>> nb(n);
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j)
-            if (at(A, n, i, j)) nb[i].push_back(j);
-    std::vector<int> ncol(n, 0);                              // distinct colours among the coloured neighbours
-    std::vector<uint8_t> has((size_t)n * (n + 2), 0);         // has[i][c]: a neighbour of i carries colour c
+    // per vertex the distinct colours its neighbours carry, as a bit set (kept up to date as vertices are coloured: the selection
+    // below is then a scan of the vertices, not of the matrix — 512 vehicles: 63 ms -> well under 1 ms per step)
+    const int cw = (n + 2 + 63) / 64;
+    std::vector<int> ncol(n, 0);                   // distinct colours among the coloured neighbours
+    std::vector<uint64_t> has((size_t)n * cw, 0);  // bit c of has[i]: a neighbour of i carries colour c
+    auto mark = [&](int j, int col) {
+        uint64_t& w = has[(size_t)j * cw + (col >> 6)];
+        const uint64_t bit = 1ull << (col & 63);
+        if (!(w & bit)) {
+            w |= bit;
+            ++ncol[j];
+        }
+    };
+    // vertex_sdo_ldo (:65-89) scans the uncoloured vertices for the most distinct neighbour colours and, among equals, moves on to
+    // a vertex only if its degree is strictly larger than the current pick's: the pick is the first uncoloured vertex with the
+    // largest (colours, degree) pair.  key = that pair for an uncoloured vertex, -1 for a coloured one.
+    // The largest key is found over blocks of 32 vertices whose maxima are kept up to date (keys of uncoloured vertices only grow;
+    // the picked vertex's block is rescanned).
+    constexpr int KB = 32;
+    const int nblk = (n + KB - 1) / KB;
+    std::vector<int64_t> key(n), bmax((size_t)nblk, -1);
+    auto key_of = [&](int i) { return color[i] != 0 ? (int64_t)-1 : ((int64_t)ncol[i] << 32) | (int64_t)(uint32_t)degree[i]; };
     int left = 0;
     for (int i = 0; i < n; ++i) left += color[i] == 0;
     for (int i = 0; i < n; ++i)
         if (color[i] != 0)
-            for (int j : nb[i])
-                if (!has[(size_t)j * (n + 2) + color[i]]) {
-                    has[(size_t)j * (n + 2) + color[i]] = 1;
-                    ++ncol[j];
-                }
+            for (const int32_t* q = nb.begin(i); q != nb.end(i); ++q) mark(*q, color[i]);
+    for (int i = 0; i < n; ++i) {
+        key[i] = key_of(i);
+        bmax[i / KB] = std::max(bmax[i / KB], key[i]);
+    }
     while (left > 0) {
-        // vertex_sdo_ldo (:65-89): most distinct neighbour colours; among equals the last one whose degree is strictly
-        // larger than the current pick's
-        int best = -1, idx = -1;
-        for (int i = 0; i < n; ++i) {
-            if (color[i] != 0) continue;
-            const int d = ncol[i];
-            if (d > best) {
-                best = d;
-                idx = i;
-            }
-            if (d == best && degree[i] > degree[idx]) idx = i;
-        }
+        int blk = 0;
+        for (int b = 1; b < nblk; ++b)
+            if (bmax[b] > bmax[blk]) blk = b;  // the first block that holds the largest key
+        int idx = blk * KB;
+        while (key[idx] != bmax[blk]) ++idx;
         int cpick = 1;
-        while (has[(size_t)idx * (n + 2) + cpick]) ++cpick;  // the smallest colour no neighbour carries
+        while (has[(size_t)idx * cw + (cpick >> 6)] >> (cpick & 63) & 1) ++cpick;  // the smallest colour no neighbour carries
         color[idx] = cpick;
         --left;
-        for (int j : nb[idx])
-            if (!has[(size_t)j * (n + 2) + cpick]) {
-                has[(size_t)j * (n + 2) + cpick] = 1;
-                ++ncol[j];
-            }
+        key[idx] = -1;
+        bmax[blk] = -1;
+        for (int i = blk * KB; i < std::min(n, blk * KB + KB); ++i) bmax[blk] = std::max(bmax[blk], key[i]);
+        for (const int32_t* q = nb.begin(idx); q != nb.end(idx); ++q) {
+            const int j = *q;
+            mark(j, cpick);
+            key[j] = key_of(j);
+            bmax[j / KB] = std::max(bmax[j / KB], key[j]);
+        }
     }
     // level matrix rows = colours in ascending order; order_topo (:91-131)
-    std::vector<int> colours;
-    for (int i = 0; i < n; ++i)
-        if (std::find(colours.begin(), colours.end(), color[i]) == colours.end()) colours.push_back(color[i]);
-    std::sort(colours.begin(), colours.end());
-    const int nl = (int)colours.size();
-    auto row_of = [&](int v) { return (int)(std::find(colours.begin(), colours.end(), color[v]) - colours.begin()); };
-    std::vector<long> deg(n, 0);
-    for (int j = 0; j < n; ++j)
-        for (int i = 0; i < n; ++i) deg[j] += adjacency[(size_t)i * n + j] != 0;
+    int cmax = 0;
+    for (int i = 0; i < n; ++i) cmax = std::max(cmax, color[i]);
+    std::vector<int> row_of_colour((size_t)cmax + 1, -1);
+    for (int i = 0; i < n; ++i) row_of_colour[color[i]] = 0;
+    int nl = 0;
+    for (int col = 0; col <= cmax; ++col)
+        if (row_of_colour[col] == 0) row_of_colour[col] = nl++;
+    std::vector<int> row(n);  // the level-matrix row a vertex stands in
+    for (int v = 0; v < n; ++v) row[v] = row_of_colour[color[v]];
     std::vector<int> order;
+    std::vector<int> place((size_t)nl, -1);  // position of a row in `order`
     long total = 0;
     for (long d : deg) total += d;
     if (total == 0) {
@@ -453,33 +568,39 @@ void coloring_directed(const std::vector<uint8_t>& adjacency, int n, std::vector
             int max_idx = 0;
             for (int i = 1; i < n; ++i)
                 if (deg[i] > deg[max_idx]) max_idx = i;  // first index of the maximum
-            const int lvl = row_of(max_idx);
+            const int lvl = row[max_idx];
             order.push_back(lvl);
             for (int i = 0; i < n; ++i)
-                if (row_of(i) == lvl) deg[i] = 0;
+                if (row[i] == lvl) deg[i] = 0;
             total = 0;
             for (long d : deg) total += d;
         }
         for (int g = 0; g < nl; ++g)
             if (std::find(order.begin(), order.end(), g) == order.end()) order.push_back(g);
     }
+    for (size_t q = 0; q < order.size(); ++q)
+        if (place[order[q]] < 0) place[order[q]] = (int)q;  // (find: the first position)
     std::vector<int> level(n, 0);
-    for (int v = 0; v < n; ++v) level[v] = (int)(std::find(order.begin(), order.end(), row_of(v)) - order.begin()) + 1;
+    for (int v = 0; v < n; ++v) level[v] = place[row[v]] + 1;
     directed.assign((size_t)n * n, 0);
     for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j)
-            if (i != j && adjacency[(size_t)i * n + j] && !(level[i] > level[j])) at(directed, n, i, j) = 1;  // Prioritizer.m:52-55
+        for_each_set(adjacency.data() + (size_t)i * n, n, [&](int j) {
+            if (i != j && !(level[i] > level[j])) at(directed, n, i, j) = 1;  // Prioritizer.m:52-55
+        });
 }
 
 // PrioritizedController.group (:375-389): weigh + GreedyCutter.cut (cut/GreedyCutter.m:5-86)
-bool group(pdmpc_controller& c, const std::vector<uint8_t>& directed, std::vector<uint8_t>& seq) {
+// (dir_succ / dir_pred: `directed` as lists by row / by column; uncut = nothing had to be cut: seq is `directed` and L its levels)
+bool group(pdmpc_controller& c, const std::vector<uint8_t>& directed, const Lists& dir_succ, const Lists& dir_pred, std::vector<uint8_t>& seq,
+           std::vector<int32_t>& L, bool& uncut) {
     const int n = c.n;
-    std::vector<int32_t> L;
-    if (!kahn(directed, n, L)) return false;
+    uncut = false;
+    if (!kahn_lists(dir_succ, n, L)) return false;
     int depth = 0;
     for (int v : L) depth = std::max(depth, v);
     if (depth <= c.cfg.max_num_CLs) {
         seq = directed;  // every sub-graph of the DAG is at most as deep: the cutter accepts every edge
+        uncut = true;
         return true;
     }
     seq.assign((size_t)n * n, 0);
@@ -490,8 +611,8 @@ bool group(pdmpc_controller& c, const std::vector<uint8_t>& directed, std::vecto
     const double vmax = *std::max_element(c.trim_speed.begin(), c.trim_speed.end());
     const double max_distance = 2 * vmax * c.cfg.dt_seconds * c.Hp;
     for (int b = 0; b < n; ++b)
-        for (int a = 0; a < n; ++a) {
-            if (!at(directed, n, a, b)) continue;
+        for (const int32_t* q = dir_pred.begin(b); q != dir_pred.end(b); ++q) {
+            const int a = *q;
             double w = 0.5;  // ConstantWeigher
             if (c.cfg.weight_strategy == PDMPC_WEIGHT_DISTANCE) {
                 const double dx = c.mx[a] - c.mx[b], dy = c.my[a] - c.my[b];
@@ -504,8 +625,7 @@ bool group(pdmpc_controller& c, const std::vector<uint8_t>& directed, std::vecto
     // longest-path layers (kahn), edges are only ever added, so the layers only grow: instead of a trial copy of the matrix and a
     // kahn pass per edge (128 vehicles: 6 ms per step), the new layers are relaxed from the edge's head through the accepted
     // successors; reaching the edge's tail again is a cycle, a layer beyond the limit a rejection (both undo the relaxation).
-    std::vector<int32_t> levels;
-    kahn(seq, n, levels);
+    std::vector<int32_t> levels((size_t)n, 1);  // (kahn of the graph without edges)
     std::vector<std::vector<int>> succ(n);
     std::vector<std::pair<int, int32_t>> undo;
     std::vector<int> work;
@@ -547,33 +667,36 @@ bool group(pdmpc_controller& c, const std::vector<uint8_t>& directed, std::vecto
     return true;
 }
 
-std::vector<Poly> del_first_rpt_last(const std::vector<Poly>& s) {
-    std::vector<Poly> r(s.begin() + 1, s.end());
-    r.push_back(s.back());
-    return r;
-}
-
 inline double ms_since(std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); }
 
-struct SetBuilder {  // builds a pdmpc_polygon_set whose arrays live in the controller's pools
-    std::vector<int32_t> off{0};
-    std::vector<double> x, y;
-    void add(const Poly& p) {
-        x.insert(x.end(), p.x.begin(), p.x.end());
-        y.insert(y.end(), p.y.begin(), p.y.end());
-        off.push_back((int32_t)x.size());
+struct SetBuilder {  // builds a pdmpc_polygon_set whose arrays live in the controller's arena; one builder at a time
+    pdmpc_controller& c;
+    explicit SetBuilder(pdmpc_controller& ctl) : c(ctl) {
+        c.sb_off.assign(1, 0);
+        c.sb_x.clear();
+        c.sb_y.clear();
     }
-    pdmpc_polygon_set finish(pdmpc_controller& c) {
+    void add(const Poly& p) {
+        c.sb_x.insert(c.sb_x.end(), p.x.begin(), p.x.end());
+        c.sb_y.insert(c.sb_y.end(), p.y.begin(), p.y.end());
+        c.sb_off.push_back((int32_t)c.sb_x.size());
+    }
+    pdmpc_polygon_set finish() {
         pdmpc_polygon_set s;
-        s.n_polygons = (int32_t)off.size() - 1;
-        x.push_back(0.0);
-        y.push_back(0.0);
-        c.ipool.push_back(std::move(off));
-        c.dpool.push_back(std::move(x));
-        c.dpool.push_back(std::move(y));
-        s.offset = c.ipool.back().data();
-        s.x = c.dpool[c.dpool.size() - 2].data();
-        s.y = c.dpool.back().data();
+        s.n_polygons = (int32_t)c.sb_off.size() - 1;
+        const size_t np = c.sb_x.size();
+        int32_t* off = (int32_t*)c.arena.take(c.sb_off.size() * sizeof(int32_t));
+        double* x = (double*)c.arena.take((np + 1) * sizeof(double));  // (one entry more: never an empty array)
+        double* y = (double*)c.arena.take((np + 1) * sizeof(double));
+        std::memcpy(off, c.sb_off.data(), c.sb_off.size() * sizeof(int32_t));
+        if (np) {
+            std::memcpy(x, c.sb_x.data(), np * sizeof(double));
+            std::memcpy(y, c.sb_y.data(), np * sizeof(double));
+        }
+        x[np] = y[np] = 0.0;
+        s.offset = off;
+        s.x = x;
+        s.y = y;
         return s;
     }
 };
@@ -678,34 +801,36 @@ int pdmpc_controller_build_step(pdmpc_controller* c) {
     if (!c) return cfail(nullptr, PDMPC_ERR_INVALID, "null controller");
     const int n = c->n, Hp = c->Hp;
     c->k += 1;
-    c->infos.assign(n, Plan());
-    c->dpool.clear();
-    c->ipool.clear();
-    c->obst_memo.assign((size_t)n, {});
-    c->dyn_memo.assign((size_t)n, {});
+    c->arena.reset();
+    if (c->exploring) {
+        c->obst_memo.assign((size_t)n, {});
+        c->dyn_memo.assign((size_t)n, {});
+    }
     c->fb_of.assign(n, pdmpc_polygon_set());
     c->fb_done.assign(n, 0);
     c->empty_done = false;
     // ---- traffic info
     c->trims.assign(n, 0);
-    c->occ_offset.assign(n, Poly());
-    c->occ_plain.assign(n, Poly());
-    c->ref_x.assign(n, {});
-    c->ref_y.assign(n, {});
-    c->v_ref.assign(n, {});
-    c->bnd_left.assign(n, Poly());
-    c->bnd_right.assign(n, Poly());
+    // (resized, not re-created: the per-vehicle vectors keep their capacity from step to step; every one of them is rewritten below)
+    c->occ_offset.resize(n);
+    c->occ_plain.resize(n);
+    c->ref_x.resize(n);
+    c->ref_y.resize(n);
+    c->v_ref.resize(n);
+    c->bnd_left.resize(n);
+    c->bnd_right.resize(n);
+    std::vector<double> step(Hp);
+    std::vector<int32_t> pidx;
     for (int v = 0; v < n; ++v) {
         c->trims[v] = trim_from_values(*c, c->mspeed[v], c->msteer[v]);
         occupied_areas(c->mx[v], c->my[v], c->myaw[v], c->cfg.vehicle_length, c->cfg.vehicle_width, c->cfg.offset, c->occ_offset[v], c->occ_plain[v]);
         // get_reference_trajectory.m:27-46
-        std::vector<double> vref(Hp, c->veh[v].reference_speed), step(Hp);
+        std::vector<double>& vref = c->v_ref[v];
+        vref.assign(Hp, c->veh[v].reference_speed);
         const double v_current = c->trim_speed[c->trims[v] - 1];
         for (int q = 0; q < Hp; ++q) step[q] = (((q == 0 ? v_current : vref[q - 1]) + vref[q]) / 2) * c->cfg.dt_seconds;
-        std::vector<int32_t> pidx;
         int cpi = 0;
         sample_reference(Hp, c->veh[v].px, c->veh[v].py, c->mx[v], c->my[v], step, c->ref_x[v], c->ref_y[v], pidx, cpi);
-        c->v_ref[v] = vref;
         lanelet_boundary(*c, v, pidx, cpi, c->bnd_left[v], c->bnd_right[v]);
     }
     // ---- coupling
@@ -716,11 +841,19 @@ int pdmpc_controller_build_step(pdmpc_controller* c) {
     } else if (c->cfg.coupling == PDMPC_COUPLING_DISTANCE) {
         const double vmax = *std::max_element(c->trim_speed.begin(), c->trim_speed.end());
         const double max_distance = 2 * vmax * c->cfg.dt_seconds * Hp;
-        for (int a = 0; a < n; ++a)
-            for (int b = a + 1; b < n; ++b) {
-                const bool near = std::hypot(c->mx[a] - c->mx[b], c->my[a] - c->my[b]) <= max_distance;
-                at(c->adjacency, n, a, b) = at(c->adjacency, n, b, a) = near;
-            }
+        // (hypot(dx, dy) >= max(|dx|, |dy|), also as rounded: a pair farther apart along one axis alone is not coupled — most pairs of
+        // a tiled network.  That test runs over the whole row, the distance itself over the survivors.)
+        for (int a = 0; a < n; ++a) {
+            uint8_t* row = c->adjacency.data() + (size_t)a * n;
+            const double xa = c->mx[a], ya = c->my[a];
+            const double *px = c->mx.data(), *py = c->my.data();
+            for (int b = a + 1; b < n; ++b) row[b] = (uint8_t)(!(std::fabs(xa - px[b]) > max_distance) & !(std::fabs(ya - py[b]) > max_distance));
+            for_each_set(row + a + 1, n - a - 1, [&](int q) {
+                const int b = a + 1 + q;
+                row[b] = std::hypot(xa - px[b], ya - py[b]) <= max_distance;
+                at(c->adjacency, n, b, a) = row[b];
+            });
+        }
     }
     // ---- priorities -> directed coupling
     if (c->cfg.priority_strategy == PDMPC_PRIORITY_COLORING) {
@@ -735,13 +868,23 @@ int pdmpc_controller_build_step(pdmpc_controller* c) {
 }
 
 namespace {
-// c->directed -> sequential couplings, levels, slot order and the per-slot inputs of pdmpc_plan_step (the pools are the caller's
+// c->directed -> sequential couplings, levels, slot order and the per-slot inputs of pdmpc_plan_step (the arena is the caller's
 // to clear: the explorative step keeps several problems alive side by side)
 int assemble_step(pdmpc_controller* c, bool seq_given) {
     const int n = c->n, Hp = c->Hp;
     // (seq_given: c->directed_seq is the caller's -- the explorative step swaps single couplings of the base prioritization)
-    if (!seq_given && !group(*c, c->directed, c->directed_seq)) return cfail(c, PDMPC_ERR_INVALID, "coupling graph has a cycle");
-    if (!kahn(c->directed_seq, n, c->levels)) return cfail(c, PDMPC_ERR_INVALID, "coupling graph has a cycle");
+    // who a vehicle is coupled with, as lists: the loops below visit a vehicle's few couplings, not rows and columns of the matrices
+    Lists dir_succ, dir_pred, seq_succ_own, seq_pred_own;
+    lists_by_row(c->directed, n, dir_succ);
+    lists_by_column(c->directed, n, dir_succ, dir_pred);
+    bool uncut = false;
+    if (!seq_given && !group(*c, c->directed, dir_succ, dir_pred, c->directed_seq, c->levels, uncut)) return cfail(c, PDMPC_ERR_INVALID, "coupling graph has a cycle");
+    if (!uncut) {  // (uncut: the sequential coupling is `directed` itself, levels and lists included)
+        lists_by_row(c->directed_seq, n, seq_succ_own);
+        lists_by_column(c->directed_seq, n, seq_succ_own, seq_pred_own);
+        if (!kahn_lists(seq_succ_own, n, c->levels)) return cfail(c, PDMPC_ERR_INVALID, "coupling graph has a cycle");
+    }
+    const Lists& seq_pred = uncut ? dir_pred : seq_pred_own;
     c->order.resize(n);
     for (int i = 0; i < n; ++i) c->order[i] = i;
     std::stable_sort(c->order.begin(), c->order.end(), [&](int a, int b) { return c->levels[a] < c->levels[b]; });
@@ -776,29 +919,31 @@ int assemble_step(pdmpc_controller* c, bool seq_given) {
         // who contributes (in the order the sets are built in): consider_predecessors (:449-506) — sequential predecessors are handed
         // over on the device; the others contribute their previous plan shifted by one step (parallel_coupling_previous_trajectory,
         // :409-447) —, then consider_successors (:508-566)
-        const bool memo = n <= 512;
+        const bool memo = c->exploring && n <= 512;  // (one prioritization: every set is built once anyway)
         pdmpc_controller::MemoKey ok, dk;
-        std::memset(&ok, 0, sizeof ok);
-        std::memset(&dk, 0, sizeof dk);
+        if (memo) {
+            std::memset(&ok, 0, sizeof ok);
+            std::memset(&dk, 0, sizeof dk);
+        }
         int ol[512], dpl[512], dsl[512], no = 0, ndp = 0, nds = 0;  // (the contributors in the order the sets are built in)
         std::vector<int> big;  // (n > 512: the lists on the heap)
         int *olp = ol, *dplp = dpl, *dslp = dsl;
-        if (!memo) {
+        if (n > 512) {
             big.resize((size_t)3 * n);
             olp = big.data();
             dplp = big.data() + n;
             dslp = big.data() + 2 * n;
         }
-        for (int j = 0; j < n; ++j) {
-            if (!at(c->directed, n, j, i)) continue;
+        for (const int32_t* q = dir_pred.begin(i); q != dir_pred.end(i); ++q) {
+            const int j = *q;
             if (at(c->directed_seq, n, j, i)) continue;
             if (c->info_old[j].present && c->k > 1) {
                 dplp[ndp++] = j;
                 if (memo) dk.w[j >> 6] |= 1ull << (j & 63);
             }
         }
-        for (int j = 0; j < n; ++j) {
-            if (!at(c->directed, n, i, j)) continue;
+        for (const int32_t* q = dir_succ.begin(i); q != dir_succ.end(i); ++q) {
+            const int j = *q;
             if (c->cfg.constraint_from_successor == PDMPC_SUCCESSOR_AREA_OF_STANDSTILL) {
                 if (std::fabs(c->mspeed[j]) < 0.01) {  // :536-540
                     olp[no++] = j;
@@ -812,16 +957,16 @@ int assemble_step(pdmpc_controller* c, bool seq_given) {
             }
         }
         auto build_obst = [&]() {
-            SetBuilder obst;
+            SetBuilder obst(*c);
             for (const Poly& o : c->static_obstacles) obst.add(o);
             for (int q = 0; q < no; ++q) obst.add(c->occ_offset[olp[q]]);
-            return obst.finish(*c);
+            return obst.finish();
         };
         auto build_dyn = [&]() {
-            SetBuilder dyn;
+            SetBuilder dyn(*c);
             for (int q = 0; q < ndp; ++q) add_shifted(dyn, c->info_old[dplp[q]].shapes);
             for (int q = 0; q < nds; ++q) add_shifted(dyn, c->info_old[dslp[q]].shapes);
-            return dyn.finish(*c);
+            return dyn.finish();
         };
         if (memo) {
             auto& om = c->obst_memo[(size_t)i];
@@ -837,26 +982,25 @@ int assemble_step(pdmpc_controller* c, bool seq_given) {
             I.dynamic_obstacles = build_dyn();
         }
         if (!c->empty_done) {
-            SetBuilder none;
-            c->empty_set = none.finish(*c);
+            SetBuilder none(*c);
+            c->empty_set = none.finish();
             c->empty_done = true;
         }
         I.hdv_reachable_sets = c->empty_set;
         // sequential predecessors as slots
-        for (int j = 0; j < n; ++j)
-            if (at(c->directed_seq, n, j, i)) c->pred_index.push_back(c->slot_of[j]);
+        for (const int32_t* q = seq_pred.begin(i); q != seq_pred.end(i); ++q) c->pred_index.push_back(c->slot_of[*q]);
         c->pred_offset[s + 1] = (int32_t)c->pred_index.size();
         // what the vehicle publishes if its search is exhausted: its standstill rectangle (:602-611) or the previous plan
         // shifted by one step (:678-718)
         if (!c->fb_done[i]) {  // (a function of the vehicle alone: shared by the prioritizations of an explorative step)
-            SetBuilder fbs;
+            SetBuilder fbs(*c);
             const bool standstill = c->trim_speed[c->trims[i] - 1] == 0;
             if (standstill && c->cfg.constraint_from_successor != PDMPC_SUCCESSOR_NONE) {
                 for (int q = 0; q < Hp; ++q) fbs.add(c->occ_plain[i]);
             } else if (c->info_old[i].present) {
                 add_shifted(fbs, c->info_old[i].shapes);
             }
-            c->fb_of[i] = fbs.finish(*c);
+            c->fb_of[i] = fbs.finish();
             c->fb_done[i] = 1;
         }
         c->fb[s] = c->fb_of[i];
@@ -870,62 +1014,71 @@ int assemble_step(pdmpc_controller* c, bool seq_given) {
 int pdmpc_controller_apply(pdmpc_controller* c, const pdmpc_vehicle_out* recs) {
     if (!c || !recs) return cfail(c, PDMPC_ERR_INVALID, "null argument");
     const int n = c->n, Hp = c->Hp;
-    auto fallback_plan = [&](int i, Plan& p) -> bool {  // plan_fallback (:678-718)
+    auto fallback_plan = [&](int i, Plan& p) -> bool {  // plan_fallback (:678-718): the previous plan shifted by one step
         const Plan& old = c->info_old[i];
         if (!old.present) return false;
         p.present = true;
-        p.shapes = del_first_rpt_last(old.shapes);
-        p.trims.assign(old.trims.begin() + 1, old.trims.end());
-        p.trims.push_back(old.trims.back());
-        p.yx.assign(old.yx.begin() + 1, old.yx.end());
-        p.yx.push_back(old.yx.back());
-        p.yy.assign(old.yy.begin() + 1, old.yy.end());
-        p.yy.push_back(old.yy.back());
-        p.yyaw.assign(old.yyaw.begin() + 1, old.yyaw.end());
-        p.yyaw.push_back(old.yyaw.back());
+        const size_t m = old.shapes.size();
+        p.shapes.resize(m);
+        p.trims.resize(m);
+        p.yx.resize(m);
+        p.yy.resize(m);
+        p.yyaw.resize(m);
+        for (size_t q = 0; q < m; ++q) {
+            const size_t from = std::min(q + 1, m - 1);
+            p.shapes[q] = old.shapes[from];
+            p.trims[q] = old.trims[from];
+            p.yx[q] = old.yx[from];
+            p.yy[q] = old.yy[from];
+            p.yyaw[q] = old.yyaw[from];
+        }
         return true;
     };
-    // (built on the side and committed at the end: an error status or a fallback in the first step leaves the controller's
-    // plans as they were)
-    std::vector<Plan> infos((size_t)n);
+    // The step's plans are built in c->infos — nothing else reads it — and swapped with c->info_old at the end: an error status or a
+    // fallback in the first step leaves the controller's plans as they were, and the vectors of a plan keep their capacity from
+    // step to step (they are overwritten entry by entry, not re-created).
+    std::vector<Plan>& infos = c->infos;
+    infos.resize((size_t)n);
+    if (c->last_pops.size() != (size_t)n) c->last_pops.assign((size_t)n, 0.0);
     for (int s = 0; s < n; ++s) {
         const int i = c->order[s];
         const pdmpc_vehicle_out& r = recs[s];
-        Plan p;
         if (r.status != PDMPC_OK && r.status != PDMPC_EXHAUSTED) return cfail(c, PDMPC_ERR_HIP, "a result record carries an error status: not a planning result");
+        Plan& p = infos[i];
+        p.present = p.needs_fallback = p.exhausted = false;
         p.n_expanded = r.n_expanded;
-        if (c->last_pops.size() != (size_t)n) c->last_pops.assign((size_t)n, 0.0);
         c->last_pops[(size_t)i] = (double)r.n_popped;
         if (r.status == PDMPC_OK) {
             p.present = true;
+            p.shapes.resize((size_t)Hp);
+            p.trims.resize((size_t)Hp);
+            p.yx.resize((size_t)Hp);
+            p.yy.resize((size_t)Hp);
+            p.yyaw.resize((size_t)Hp);
             for (int q = 0; q < Hp; ++q) {
-                Poly sh;
+                Poly& sh = p.shapes[q];
                 sh.x.assign(r.shapes[q][0], r.shapes[q][0] + r.shape_cols[q]);
                 sh.y.assign(r.shapes[q][1], r.shapes[q][1] + r.shape_cols[q]);
-                p.shapes.push_back(std::move(sh));
-                p.trims.push_back(r.predicted_trims[q]);
-                p.yx.push_back(r.y_predicted[q][0]);
-                p.yy.push_back(r.y_predicted[q][1]);
-                p.yyaw.push_back(r.y_predicted[q][2]);
+                p.trims[q] = r.predicted_trims[q];
+                p.yx[q] = r.y_predicted[q][0];
+                p.yy[q] = r.y_predicted[q][1];
+                p.yyaw[q] = r.y_predicted[q][2];
             }
         } else {  // PrioritizedController.m:344-352
             p.exhausted = true;
             const bool standstill = c->trim_speed[c->trims[i] - 1] == 0;
             if (standstill && c->cfg.constraint_from_successor != PDMPC_SUCCESSOR_NONE) {  // handle_graph_search_exhaustion (:568-616)
                 p.present = true;
-                for (int q = 0; q < Hp; ++q) {
-                    p.shapes.push_back(c->occ_plain[i]);
-                    p.trims.push_back(c->trims[i]);
-                    p.yx.push_back(c->mx[i]);
-                    p.yy.push_back(c->my[i]);
-                    p.yyaw.push_back(c->myaw[i]);
-                }
+                p.shapes.assign((size_t)Hp, c->occ_plain[i]);
+                p.trims.assign((size_t)Hp, c->trims[i]);
+                p.yx.assign((size_t)Hp, c->mx[i]);
+                p.yy.assign((size_t)Hp, c->my[i]);
+                p.yyaw.assign((size_t)Hp, c->myaw[i]);
             } else {
                 if (!fallback_plan(i, p)) return cfail(c, PDMPC_ERR_INVALID, "a vehicle needs a fallback in its first step");
                 p.needs_fallback = true;
             }
         }
-        infos[i] = std::move(p);
     }
     // handle_others_fallback / check_others_fallback
     bool any = false;
@@ -958,25 +1111,21 @@ int pdmpc_controller_apply(pdmpc_controller* c, const pdmpc_vehicle_out* recs) {
         }
         for (int i = 0; i < n; ++i)
             if (reached[i] && !infos[i].needs_fallback) {
-                Plan p;
-                p.n_expanded = infos[i].n_expanded;
-                p.exhausted = infos[i].exhausted;
+                Plan& p = infos[i];  // (keeps its search's n_expanded and exhausted)
                 if (!fallback_plan(i, p)) return cfail(c, PDMPC_ERR_INVALID, "a vehicle needs a fallback in its first step");
                 p.needs_fallback = false;  // plan_fallback(is_fallback_while_planning = false)
-                infos[i] = std::move(p);
             }
     }
-    c->infos = std::move(infos);
+    std::swap(c->info_old, c->infos);
     // Simulation.apply (Simulation.m:86-100)
     for (int i = 0; i < n; ++i) {
-        const Plan& p = c->infos[i];
+        const Plan& p = c->info_old[i];
         c->mx[i] = p.yx[0];
         c->my[i] = p.yy[0];
         c->myaw[i] = p.yyaw[0];
         c->mspeed[i] = c->trim_speed[p.trims[0] - 1];
         c->msteer[i] = c->trim_steering[p.trims[0] - 1];
     }
-    c->info_old = c->infos;
     return PDMPC_OK;
 }
 
@@ -1133,6 +1282,11 @@ int pdmpc_exploration_permutations(int32_t n_levels, int32_t n_perm, uint32_t se
 // of L in permutation p as its priority), slots ordered by (level, instance, slot).  Advances the time step like build_step.
 int pdmpc_controller_explore_build(pdmpc_controller* c, int32_t n_perm, uint32_t seed) {
     if (!c || n_perm < 1) return cfail(c, PDMPC_ERR_INVALID, "bad argument");
+    struct Exploring {  // (the memos of the obstacle sets are on while this step's prioritizations are assembled)
+        pdmpc_controller* c;
+        explicit Exploring(pdmpc_controller* ctl) : c(ctl) { c->exploring = true; }
+        ~Exploring() { c->exploring = false; }
+    } exploring(c);
     int rc = pdmpc_controller_build_step(c);  // instance 0: the controller's own prioritization
     if (rc) return rc;
     const int n = c->n;

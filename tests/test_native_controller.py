@@ -139,3 +139,14 @@ def test_explorative_step_native_twin(strategy, max_levels):
         assert st["needs_fallback"].tolist() == [bool(i.needs_fallback) for i in py.infos], k
     assert differing > 0, "the exploration never preferred another prioritization: the test would not notice a wrong choice"
     nat.close()
+
+
+def test_hundred_vehicles_colouring_cut_to_two_levels():
+    """A scenario large enough that the controller's sparse paths matter (coupling lists, the colouring's block maxima, the plans'
+    reused storage): 100 vehicles on five tiles — not a multiple of the 8-entry / 32-vertex strides those paths step by."""
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    options = Config(scenario_type=ScenarioType.commonroad, amount=100, Hp=6, max_num_CLs=2, max_nodes=1 << 20)
+    sc = commonroad_scenario(options, seed=3, tiles=5)
+    py = run_both(options, sc, 4, "distance", boundary_provider(sc), priority_strategy="coloring", weight_strategy="distance")
+    assert int(py.last_levels.max()) <= 2
