@@ -118,6 +118,19 @@ struct PinnedBuf {
         cap = want;
         return 0;
     }
+    int ensure_keep(size_t n, size_t keep) {  // as ensure, the first `keep` elements carried over
+        if (n <= cap) return 0;
+        size_t want = std::max(n, (size_t)64);
+        want += want / 2;
+        T* q = nullptr;
+        hipError_t e = hipHostMalloc((void**)&q, want * sizeof(T), hipHostMallocDefault);
+        if (e != hipSuccess) return (int)e;
+        if (p && keep) std::memcpy(q, p, std::min(keep, cap) * sizeof(T));
+        if (p) (void)hipHostFree(p);
+        p = q;
+        cap = want;
+        return 0;
+    }
     void release() {
         if (p) (void)hipHostFree(p);
         p = nullptr;
@@ -294,10 +307,7 @@ struct pdmpc_handle {
     double last_us[3] = {0, 0, 0};       // pdmpc_last_call_timing: pack, enqueue, wait + read-back of the last pdmpc_plan_batch / pdmpc_plan_step
     double dbg_us[4] = {0, 0, 0, 0};     // debug_host 2: pack, launch, fetch (host clock) and kernel (events) time of the plan_batch calls
     uint64_t sync_serial = 0;            // stream synchronisations through sync_stream so far (PackedStep::staged_serial)
-    std::vector<double> pack_pts;        // pack_common's scratch (kept: a pack allocates nothing once warm)
-    std::vector<int32_t> pack_pred;
     std::vector<double> next_weights;    // pdmpc_set_step_weights: expected work per vehicle of the NEXT packed step (the caller's order); consumed by that pack
-    std::vector<DevVehicle> pack_veh;
     PinnedBuf<double> h_lean;            // fetch_lean: (cost, status) per slot
     DevBuf<double> d_lean;
     PinnedBuf<pdmpc_vehicle_out> h_out;  // pdmpc_fetch_results: the records land in pinned memory (a copy into the caller's pageable array goes through the runtime's staging otherwise)
@@ -474,11 +484,6 @@ int compute_lds_sampled(pdmpc_handle* h, int soup_cap, int cand_cap) {
     return fail(PDMPC_ERR_CAPACITY, "obstacle soup + MPA tables do not fit into the LDS budget of the sampled optimizer");
 }
 
-inline void push_pt(std::vector<double>& pts, double x, double y) {
-    pts.push_back(x);
-    pts.push_back(y);
-}
-
 int check_set(const pdmpc_polygon_set& s, const char* what) {
     if (s.n_polygons < 0) return fail(PDMPC_ERR_INVALID, std::string(what) + ": negative polygon count");
     if (s.n_polygons > 0 && (!s.offset || !s.x || !s.y)) return fail(PDMPC_ERR_INVALID, std::string(what) + ": null pointer");
@@ -498,12 +503,31 @@ int pack_common(pdmpc_handle* h, int n, const pdmpc_vehicle_in* in, const int32_
     const double qnan = std::numeric_limits<double>::quiet_NaN();
     // the staging blob is reused: a copy out of it that may still be in flight (no stream synchronisation since it was queued) ends first
     if (B.staged_serial == h->sync_serial) HIPCHK(sync_stream(h));
-    std::vector<double>& pts = h->pack_pts;
-    std::vector<int32_t>& pred = h->pack_pred;
-    std::vector<DevVehicle>& veh = h->pack_veh;
-    pts.clear();
-    pred.clear();
-    veh.resize((size_t)std::max(n, 1));
+    // The packed batch is written where it is copied from, the bank's pinned blob: [vehicles | predecessor slots | points].  The
+    // points come last — their number is known once they are written — and the blob grows with its contents kept.
+    size_t total_pred = 0;
+    if (pred_offset)
+        for (int vi = 0; vi < n; ++vi) total_pred += (size_t)std::max(0, pred_offset[vi + 1] - pred_offset[vi]);
+    const size_t veh_bytes = ((size_t)std::max(n, 1) * sizeof(DevVehicle) + 15) & ~(size_t)15;
+    const size_t pred_bytes = ((total_pred + 1) * sizeof(int32_t) + 15) & ~(size_t)15;
+    const size_t pts_base = veh_bytes + pred_bytes;
+    B.n_packed = 0;  // (a pack that fails leaves the bank empty: the batch that was in it is being overwritten)
+    B.h_veh = nullptr;
+    B.h_pts = nullptr;
+    B.h_pred = nullptr;
+    if (B.h_blob.ensure_keep(pts_base + 4096, 0)) return fail(PDMPC_ERR_HIP, "hipHostMalloc failed");
+    DevVehicle* veh = (DevVehicle*)B.h_blob.p;
+    int32_t* pred = (int32_t*)(B.h_blob.p + veh_bytes);
+    double* pts = (double*)(B.h_blob.p + pts_base);
+    size_t n_pred_out = 0, n_pts = 0;  // entries of pred / POINTS (two doubles each) written
+    auto put = [&](double x, double y) {
+        pts[2 * n_pts] = x;
+        pts[2 * n_pts + 1] = y;
+        ++n_pts;
+    };
+    auto set_points = [](const pdmpc_polygon_set& s) -> size_t {  // points of a (checked) set + one separator per polygon
+        return s.n_polygons > 0 ? (size_t)(s.offset[s.n_polygons] - s.offset[0]) + (size_t)s.n_polygons : 0;
+    };
     B.lit_cols.assign((size_t)n, 0);
     int soup_cap = 0, cand_cap = 0;
     // Slot order.  A search spins for predecessors of the same launch, so every predecessor must sit in a lower slot than its
@@ -601,8 +625,6 @@ int pack_common(pdmpc_handle* h, int n, const pdmpc_vehicle_in* in, const int32_
         const int i = slot_i;  // (slot: index into the packed arrays)
         const int vi = permuted ? B.perm[(size_t)slot_i] : slot_i;  // (the caller's vehicle)
         const pdmpc_vehicle_in& v = in[vi];
-        DevVehicle& d = veh[(size_t)i];
-        std::memset(&d, 0, sizeof d);
         if (!v.ref_x || !v.ref_y || !v.v_ref) return fail(PDMPC_ERR_INVALID, "reference trajectory missing");
         if (v.trim0 < 1 || v.trim0 > h->n_trims) return fail(PDMPC_ERR_INVALID, "trim0 out of range");
         int rc;
@@ -613,6 +635,21 @@ int pack_common(pdmpc_handle* h, int n, const pdmpc_vehicle_in* in, const int32_
         if (v.hdv_reachable_sets.n_polygons % Hp) return fail(PDMPC_ERR_INVALID, "hdv_reachable_sets must hold n_h * Hp polygons");
         if (v.n_left < 0 || v.n_right < 0 || v.n_left == 1 || v.n_right == 1)
             return fail(PDMPC_ERR_INVALID, "lanelet boundary needs 0 or >= 2 points per side");
+        const bool has_fb = fallback && fallback[vi].n_polygons > 0;
+        if (has_fb) {
+            if (fallback[vi].n_polygons != Hp) return fail(PDMPC_ERR_INVALID, "fallback_shapes must hold Hp polygons per vehicle");
+            if ((rc = check_set(fallback[vi], "fallback_shapes"))) return rc;
+        }
+        {  // room for everything this vehicle can add (+ the batch's trailing pad)
+            const size_t most = (size_t)Hp * set_points(v.obstacles) + set_points(v.dynamic_obstacles) + set_points(v.hdv_reachable_sets) + (size_t)v.n_left + (size_t)v.n_right + 2 +
+                                (has_fb ? set_points(fallback[vi]) : 0) + 2;
+            if (B.h_blob.ensure_keep(pts_base + (n_pts + most) * 16, pts_base + n_pts * 16)) return fail(PDMPC_ERR_HIP, "hipHostMalloc failed");
+            veh = (DevVehicle*)B.h_blob.p;
+            pred = (int32_t*)(B.h_blob.p + veh_bytes);
+            pts = (double*)(B.h_blob.p + pts_base);
+        }
+        DevVehicle& d = veh[(size_t)i];
+        std::memset(&d, 0, sizeof d);
         d.x0 = v.x0;
         d.y0 = v.y0;
         d.yaw0 = v.yaw0;
@@ -624,16 +661,16 @@ int pack_common(pdmpc_handle* h, int n, const pdmpc_vehicle_in* in, const int32_
         }
         const int n_pred = pred_offset ? pred_offset[vi + 1] - pred_offset[vi] : 0;
         d.n_pred = n_pred;
-        d.pred_off = (int32_t)pred.size();
+        d.pred_off = (int32_t)n_pred_out;
         for (int q = 0; q < n_pred; ++q) {
             const int ps = pred_index[pred_offset[vi] + q];
             if (ps < 0 || ps >= h->max_vehicles) return fail(PDMPC_ERR_INVALID, "predecessor slot out of range");
-            pred.push_back(permuted && ps < n ? B.inv[(size_t)ps] : ps);
+            pred[n_pred_out++] = permuted && ps < n ? B.inv[(size_t)ps] : ps;
         }
         SoupKey key;
         std::memset(&key, 0, sizeof key);
         {
-            const pdmpc_polygon_set* fbv = (fallback && fallback[vi].n_polygons > 0) ? &fallback[vi] : nullptr;
+            const pdmpc_polygon_set* fbv = has_fb ? &fallback[vi] : nullptr;
             const void* ptrs[13] = {v.obstacles.offset, v.obstacles.x, v.obstacles.y, v.dynamic_obstacles.offset, v.dynamic_obstacles.x, v.dynamic_obstacles.y, v.hdv_reachable_sets.offset,
                                     v.hdv_reachable_sets.x, v.left_x, v.right_x, fbv ? fbv->offset : nullptr, fbv ? fbv->x : nullptr, fbv ? fbv->y : nullptr};
             for (int q = 0; q < 13; ++q) key.p[q] = ptrs[q];
@@ -664,45 +701,42 @@ int pack_common(pdmpc_handle* h, int n, const pdmpc_vehicle_in* in, const int32_
         const int n_dyn = v.dynamic_obstacles.n_polygons / Hp;
         const int n_hdv = v.hdv_reachable_sets.n_polygons / Hp;
         auto append_poly = [&](const pdmpc_polygon_set& s, int p, bool sep) {
-            for (int q = s.offset[p]; q < s.offset[p + 1]; ++q) push_pt(pts, s.x[q], s.y[q]);
-            if (sep) push_pt(pts, qnan, qnan);
+            for (int q = s.offset[p]; q < s.offset[p + 1]; ++q) put(s.x[q], s.y[q]);
+            if (sep) put(qnan, qnan);
         };
         int need = 0;
         // vehicle_obstacles{k} = [static..., dynamic(:, k)...], each followed by [NaN; NaN]   vectorize_all_obstacles.m:36-62
         for (int k = 0; k < Hp; ++k) {
-            d.lit_off[k] = (int32_t)(pts.size() / 2);
+            d.lit_off[k] = (int32_t)n_pts;
             for (int p = 0; p < v.obstacles.n_polygons; ++p) append_poly(v.obstacles, p, true);
             for (int r = 0; r < n_dyn; ++r) append_poly(v.dynamic_obstacles, r * Hp + k, true);
-            need += (int)(pts.size() / 2) - d.lit_off[k] + n_pred * PDMPC_VMAX;
+            need += (int)n_pts - d.lit_off[k] + n_pred * PDMPC_VMAX;
         }
-        d.lit_off[Hp] = (int32_t)(pts.size() / 2);
+        d.lit_off[Hp] = (int32_t)n_pts;
         B.lit_cols[i] = d.lit_off[Hp] - d.lit_off[0];
         for (int k = 0; k < Hp; ++k) {
-            d.hdv_off[k] = (int32_t)(pts.size() / 2);
+            d.hdv_off[k] = (int32_t)n_pts;
             for (int r = 0; r < n_hdv; ++r) append_poly(v.hdv_reachable_sets, r * Hp + k, true);
         }
-        d.hdv_off[Hp] = (int32_t)(pts.size() / 2);
+        d.hdv_off[Hp] = (int32_t)n_pts;
         need += d.hdv_off[Hp] - d.hdv_off[0];
         // lanelet_boundary = [left, NaN, right, NaN]                                          vectorize_all_obstacles.m:27-30
-        d.ll_off = (int32_t)(pts.size() / 2);
-        for (int q = 0; q < v.n_left; ++q) push_pt(pts, v.left_x[q], v.left_y[q]);
-        push_pt(pts, qnan, qnan);
-        for (int q = 0; q < v.n_right; ++q) push_pt(pts, v.right_x[q], v.right_y[q]);
-        push_pt(pts, qnan, qnan);
-        d.ll_len = (int32_t)(pts.size() / 2) - d.ll_off;
+        d.ll_off = (int32_t)n_pts;
+        for (int q = 0; q < v.n_left; ++q) put(v.left_x[q], v.left_y[q]);
+        put(qnan, qnan);
+        for (int q = 0; q < v.n_right; ++q) put(v.right_x[q], v.right_y[q]);
+        put(qnan, qnan);
+        d.ll_len = (int32_t)n_pts - d.ll_off;
         need += d.ll_len;
         B.lit_cols[i] += d.ll_len;
-        if (fallback && fallback[vi].n_polygons > 0) {
-            if (fallback[vi].n_polygons != Hp) return fail(PDMPC_ERR_INVALID, "fallback_shapes must hold Hp polygons per vehicle");
-            int rc2;
-            if ((rc2 = check_set(fallback[vi], "fallback_shapes"))) return rc2;
+        if (has_fb) {
             for (int k = 0; k < Hp; ++k) {
-                d.fb_off[k] = (int32_t)(pts.size() / 2);
+                d.fb_off[k] = (int32_t)n_pts;
                 if (fallback[vi].offset[k + 1] - fallback[vi].offset[k] > PDMPC_VMAX)
                     return fail(PDMPC_ERR_INVALID, "fallback area has more than PDMPC_VMAX columns");
                 append_poly(fallback[vi], k, false);
             }
-            d.fb_off[Hp] = (int32_t)(pts.size() / 2);
+            d.fb_off[Hp] = (int32_t)n_pts;
         } else {
             for (int k = 0; k <= Hp; ++k) d.fb_off[k] = -1;
         }
@@ -710,26 +744,20 @@ int pack_common(pdmpc_handle* h, int n, const pdmpc_vehicle_in* in, const int32_
         for (int k = 0; k < Hp; ++k)
             cand_cap = std::max(cand_cap, (d.lit_off[k + 1] - d.lit_off[k]) + n_pred * PDMPC_VMAX + (d.hdv_off[k + 1] - d.hdv_off[k]) + d.ll_len);
     }
-    // a trailing pad so 16-byte staged copies never run past the allocation
-    push_pt(pts, qnan, qnan);
-    pred.push_back(0);
+    // a trailing pad so 16-byte staged copies never run past the allocation (room: the blob's first 4096 bytes of points, or a vehicle's)
+    put(qnan, qnan);
+    pred[n_pred_out++] = 0;
     B.soup_cap = soup_cap + 2;
     B.cand_cap = (cand_cap + 4 + 3) & ~3;
-    const size_t veh_bytes = ((size_t)std::max(n, 1) * sizeof(DevVehicle) + 15) & ~(size_t)15;
-    const size_t pts_bytes = (pts.size() * sizeof(double) + 15) & ~(size_t)15;
-    const size_t pred_bytes = (pred.size() * sizeof(int32_t) + 15) & ~(size_t)15;
-    const size_t total = veh_bytes + pts_bytes + pred_bytes;
-    if (B.h_blob.ensure(total)) return fail(PDMPC_ERR_HIP, "hipHostMalloc failed");
+    const size_t pts_bytes = (n_pts * 16 + 15) & ~(size_t)15;
+    const size_t total = pts_base + pts_bytes;
     if (B.d_blob.ensure(total)) return fail(PDMPC_ERR_HIP, "hipMalloc failed for the batch blob");
-    B.h_veh = (DevVehicle*)B.h_blob.p;
-    B.h_pts = (double*)(B.h_blob.p + veh_bytes);
-    B.h_pred = (int32_t*)(B.h_blob.p + veh_bytes + pts_bytes);
+    B.h_veh = veh;
+    B.h_pred = pred;
+    B.h_pts = pts;
     B.d_veh = (DevVehicle*)B.d_blob.p;
-    B.d_pts = (double*)(B.d_blob.p + veh_bytes);
-    B.d_pred = (int32_t*)(B.d_blob.p + veh_bytes + pts_bytes);
-    std::memcpy(B.h_veh, veh.data(), (size_t)std::max(n, 1) * sizeof(DevVehicle));
-    std::memcpy(B.h_pts, pts.data(), pts.size() * sizeof(double));
-    std::memcpy(B.h_pred, pred.data(), pred.size() * sizeof(int32_t));
+    B.d_pred = (int32_t*)(B.d_blob.p + veh_bytes);
+    B.d_pts = (double*)(B.d_blob.p + pts_base);
     // one copy, not waited for: whatever the stream does next is ordered behind it, and the next pack into this bank waits (above)
     HIPCHK(hipMemcpyAsync(B.d_blob.p, B.h_blob.p, total, hipMemcpyHostToDevice, h->stream));
     B.staged_serial = h->sync_serial;
