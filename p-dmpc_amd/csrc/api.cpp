@@ -172,6 +172,12 @@ struct PackedStep {
 // Tuning knobs and A/B / test switches of the graph search.  The defaults are the measured optima quoted next to their use; every
 // setting leaves the results bit-identical.  ONE environment variable overrides them, read once in pdmpc_create (a launch makes no
 // getenv call):  PDMPC_TUNING="key=value,key=value,..."  with the keys below (include/pdmpc.h documents the variable).
+// what pack_common tells vehicles that hand over the same arrays by: the pointers and counts of a vehicle's polygon sets
+struct SoupKey {
+    const void* p[13];
+    int32_t c[6];
+};
+
 struct Tuning {
     int round0 = -1;        // nodes a round of a young search takes (-1: 24; 32 for a launch that leaves CUs idle but has fewer than four helpers per search, C3, and for one of more than two searches per CU, C5)
     int round = -1;         // the most a round takes (-1: 1000 with helper workgroups, else 256)
@@ -307,6 +313,8 @@ struct pdmpc_handle {
     double last_us[3] = {0, 0, 0};       // pdmpc_last_call_timing: pack, enqueue, wait + read-back of the last pdmpc_plan_batch / pdmpc_plan_step
     double dbg_us[4] = {0, 0, 0, 0};     // debug_host 2: pack, launch, fetch (host clock) and kernel (events) time of the plan_batch calls
     uint64_t sync_serial = 0;            // stream synchronisations through sync_stream so far (PackedStep::staged_serial)
+    std::vector<SoupKey> pack_soup_keys;  // pack_common's scratch: the distinct soup keys of the batch, the slots they were packed in, the hash table over them
+    std::vector<int32_t> pack_soup_slot, pack_soup_table;
     std::vector<double> next_weights;    // pdmpc_set_step_weights: expected work per vehicle of the NEXT packed step (the caller's order); consumed by that pack
     PinnedBuf<double> h_lean;            // fetch_lean: (cost, status) per slot
     DevBuf<double> d_lean;
@@ -615,32 +623,70 @@ int pack_common(pdmpc_handle* h, int n, const pdmpc_vehicle_in* in, const int32_
     // Vehicles that hand over THE SAME ARRAYS (same pointers, same counts: the prioritization instances of an explorative step share
     // every input but the predecessor lists, PrioritizedExplorativeController.m:25-91; step_controller.cpp builds one set per distinct
     // content) share one copy of their soups in the pool: a vehicle seen before takes over the offsets of the first one.
-    struct SoupKey {
-        const void* p[13];
-        int32_t c[6];
-        bool operator<(const SoupKey& o) const { return std::memcmp(this, &o, sizeof(SoupKey)) < 0; }
+    // (an open-addressing table over the slots that brought new arrays: a batch of 1 280 slots looks its key up 1 280 times)
+    std::vector<SoupKey>& soup_keys = h->pack_soup_keys;  // key of the q-th distinct vehicle, soup_slot[q] the slot it was packed in
+    std::vector<int32_t>& soup_slot = h->pack_soup_slot;
+    std::vector<int32_t>& soup_table = h->pack_soup_table;  // hash -> q + 1, 0 = empty
+    size_t table_size = 64;
+    while (table_size < (size_t)n * 2) table_size *= 2;
+    soup_keys.clear();
+    soup_slot.clear();
+    soup_table.assign(table_size, 0);
+    auto soup_hash = [](const SoupKey& k) {
+        uint64_t hsh = 1469598103934665603ull;
+        const uint64_t* w = (const uint64_t*)&k;
+        for (size_t q = 0; q < sizeof(SoupKey) / 8; ++q) hsh = (hsh ^ w[q]) * 1099511628211ull;
+        return hsh ^ (hsh >> 29);
     };
-    std::map<SoupKey, int> seen_soup;
+    static_assert(sizeof(SoupKey) % 8 == 0, "SoupKey is hashed by 64-bit words");
     for (int slot_i = 0; slot_i < n; ++slot_i) {
         const int i = slot_i;  // (slot: index into the packed arrays)
         const int vi = permuted ? B.perm[(size_t)slot_i] : slot_i;  // (the caller's vehicle)
         const pdmpc_vehicle_in& v = in[vi];
         if (!v.ref_x || !v.ref_y || !v.v_ref) return fail(PDMPC_ERR_INVALID, "reference trajectory missing");
         if (v.trim0 < 1 || v.trim0 > h->n_trims) return fail(PDMPC_ERR_INVALID, "trim0 out of range");
-        int rc;
-        if ((rc = check_set(v.obstacles, "obstacles"))) return rc;
-        if ((rc = check_set(v.dynamic_obstacles, "dynamic_obstacles"))) return rc;
-        if ((rc = check_set(v.hdv_reachable_sets, "hdv_reachable_sets"))) return rc;
-        if (v.dynamic_obstacles.n_polygons % Hp) return fail(PDMPC_ERR_INVALID, "dynamic_obstacles must hold n_d * Hp polygons");
-        if (v.hdv_reachable_sets.n_polygons % Hp) return fail(PDMPC_ERR_INVALID, "hdv_reachable_sets must hold n_h * Hp polygons");
-        if (v.n_left < 0 || v.n_right < 0 || v.n_left == 1 || v.n_right == 1)
-            return fail(PDMPC_ERR_INVALID, "lanelet boundary needs 0 or >= 2 points per side");
         const bool has_fb = fallback && fallback[vi].n_polygons > 0;
-        if (has_fb) {
-            if (fallback[vi].n_polygons != Hp) return fail(PDMPC_ERR_INVALID, "fallback_shapes must hold Hp polygons per vehicle");
-            if ((rc = check_set(fallback[vi], "fallback_shapes"))) return rc;
+        // seen before?  (looked up first: a vehicle that hands over arrays that are packed already needs neither their checks nor room)
+        SoupKey key;
+        std::memset(&key, 0, sizeof key);
+        {
+            const pdmpc_polygon_set* fbv = has_fb ? &fallback[vi] : nullptr;
+            const void* ptrs[13] = {v.obstacles.offset, v.obstacles.x, v.obstacles.y, v.dynamic_obstacles.offset, v.dynamic_obstacles.x, v.dynamic_obstacles.y, v.hdv_reachable_sets.offset,
+                                    v.hdv_reachable_sets.x, v.left_x, v.right_x, fbv ? fbv->offset : nullptr, fbv ? fbv->x : nullptr, fbv ? fbv->y : nullptr};
+            for (int q = 0; q < 13; ++q) key.p[q] = ptrs[q];
+            key.c[0] = v.obstacles.n_polygons;
+            key.c[1] = v.dynamic_obstacles.n_polygons;
+            key.c[2] = v.hdv_reachable_sets.n_polygons;
+            key.c[3] = v.n_left;
+            key.c[4] = v.n_right;
+            key.c[5] = fbv ? fbv->n_polygons : 0;
         }
-        {  // room for everything this vehicle can add (+ the batch's trailing pad)
+        size_t at_table = (size_t)soup_hash(key) & (table_size - 1);
+        int seen_slot = -1;
+        while (soup_table[at_table] != 0) {
+            const int q = soup_table[at_table] - 1;
+            if (std::memcmp(&soup_keys[(size_t)q], &key, sizeof key) == 0) {
+                seen_slot = soup_slot[(size_t)q];
+                break;
+            }
+            at_table = (at_table + 1) & (table_size - 1);
+        }
+        const pdmpc_vehicle_in* first_in = seen_slot >= 0 ? &in[permuted ? B.perm[(size_t)seen_slot] : seen_slot] : nullptr;
+        const bool shared = first_in && v.left_y == first_in->left_y && v.right_y == first_in->right_y && v.hdv_reachable_sets.y == first_in->hdv_reachable_sets.y;
+        if (!shared) {
+            int rc;
+            if ((rc = check_set(v.obstacles, "obstacles"))) return rc;
+            if ((rc = check_set(v.dynamic_obstacles, "dynamic_obstacles"))) return rc;
+            if ((rc = check_set(v.hdv_reachable_sets, "hdv_reachable_sets"))) return rc;
+            if (v.dynamic_obstacles.n_polygons % Hp) return fail(PDMPC_ERR_INVALID, "dynamic_obstacles must hold n_d * Hp polygons");
+            if (v.hdv_reachable_sets.n_polygons % Hp) return fail(PDMPC_ERR_INVALID, "hdv_reachable_sets must hold n_h * Hp polygons");
+            if (v.n_left < 0 || v.n_right < 0 || v.n_left == 1 || v.n_right == 1)
+                return fail(PDMPC_ERR_INVALID, "lanelet boundary needs 0 or >= 2 points per side");
+            if (has_fb) {
+                if (fallback[vi].n_polygons != Hp) return fail(PDMPC_ERR_INVALID, "fallback_shapes must hold Hp polygons per vehicle");
+                if ((rc = check_set(fallback[vi], "fallback_shapes"))) return rc;
+            }
+            // room for everything this vehicle can add (+ the batch's trailing pad)
             const size_t most = (size_t)Hp * set_points(v.obstacles) + set_points(v.dynamic_obstacles) + set_points(v.hdv_reachable_sets) + (size_t)v.n_left + (size_t)v.n_right + 2 +
                                 (has_fb ? set_points(fallback[vi]) : 0) + 2;
             if (B.h_blob.ensure_keep(pts_base + (n_pts + most) * 16, pts_base + n_pts * 16)) return fail(PDMPC_ERR_HIP, "hipHostMalloc failed");
@@ -667,37 +713,25 @@ int pack_common(pdmpc_handle* h, int n, const pdmpc_vehicle_in* in, const int32_
             if (ps < 0 || ps >= h->max_vehicles) return fail(PDMPC_ERR_INVALID, "predecessor slot out of range");
             pred[n_pred_out++] = permuted && ps < n ? B.inv[(size_t)ps] : ps;
         }
-        SoupKey key;
-        std::memset(&key, 0, sizeof key);
-        {
-            const pdmpc_polygon_set* fbv = has_fb ? &fallback[vi] : nullptr;
-            const void* ptrs[13] = {v.obstacles.offset, v.obstacles.x, v.obstacles.y, v.dynamic_obstacles.offset, v.dynamic_obstacles.x, v.dynamic_obstacles.y, v.hdv_reachable_sets.offset,
-                                    v.hdv_reachable_sets.x, v.left_x, v.right_x, fbv ? fbv->offset : nullptr, fbv ? fbv->x : nullptr, fbv ? fbv->y : nullptr};
-            for (int q = 0; q < 13; ++q) key.p[q] = ptrs[q];
-            key.c[0] = v.obstacles.n_polygons;
-            key.c[1] = v.dynamic_obstacles.n_polygons;
-            key.c[2] = v.hdv_reachable_sets.n_polygons;
-            key.c[3] = v.n_left;
-            key.c[4] = v.n_right;
-            key.c[5] = fbv ? fbv->n_polygons : 0;
-        }
-        const auto seen = seen_soup.find(key);
-        if (seen != seen_soup.end() && (v.left_y == in[permuted ? B.perm[(size_t)seen->second] : seen->second].left_y) && (v.right_y == in[permuted ? B.perm[(size_t)seen->second] : seen->second].right_y) &&
-            (v.hdv_reachable_sets.y == in[permuted ? B.perm[(size_t)seen->second] : seen->second].hdv_reachable_sets.y)) {
-            const DevVehicle& f = veh[(size_t)seen->second];  // (validated when it was packed)
+        if (shared) {
+            const DevVehicle& f = veh[(size_t)seen_slot];  // (validated when it was packed)
             std::memcpy(d.lit_off, f.lit_off, sizeof d.lit_off);
             std::memcpy(d.hdv_off, f.hdv_off, sizeof d.hdv_off);
             std::memcpy(d.fb_off, f.fb_off, sizeof d.fb_off);
             d.ll_off = f.ll_off;
             d.ll_len = f.ll_len;
-            B.lit_cols[i] = B.lit_cols[(size_t)seen->second];
+            B.lit_cols[i] = B.lit_cols[(size_t)seen_slot];
             const int need = (d.lit_off[Hp] - d.lit_off[0]) + Hp * n_pred * PDMPC_VMAX + (d.hdv_off[Hp] - d.hdv_off[0]) + d.ll_len;
             soup_cap = std::max(soup_cap, need);
             for (int k = 0; k < Hp; ++k)
                 cand_cap = std::max(cand_cap, (d.lit_off[k + 1] - d.lit_off[k]) + n_pred * PDMPC_VMAX + (d.hdv_off[k + 1] - d.hdv_off[k]) + d.ll_len);
             continue;
         }
-        seen_soup.emplace(key, i);
+        if (seen_slot < 0) {  // (a key met again with other y arrays keeps its first entry, as the map did)
+            soup_keys.push_back(key);
+            soup_slot.push_back(i);
+            soup_table[at_table] = (int32_t)soup_keys.size();
+        }
         const int n_dyn = v.dynamic_obstacles.n_polygons / Hp;
         const int n_hdv = v.hdv_reachable_sets.n_polygons / Hp;
         auto append_poly = [&](const pdmpc_polygon_set& s, int p, bool sep) {

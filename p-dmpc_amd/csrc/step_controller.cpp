@@ -27,7 +27,6 @@
 #include <limits>
 #include <string>
 #include <utility>
-#include <map>
 #include <memory>
 #include <vector>
 
@@ -39,6 +38,15 @@ namespace {
 struct Poly {  // 2 x V, MATLAB [x; y]
     std::vector<double> x, y;
     int n() const { return (int)x.size(); }
+};
+
+// the non-zero entries of a matrix as lists: by row (idx[off[i] .. off[i + 1]) = the columns of row i) or by column (the rows of
+// column j), ascending in both forms
+struct Lists {
+    std::vector<int32_t> off, idx, fill;  // (fill: scratch of lists_by_column)
+    int size(int i) const { return off[i + 1] - off[i]; }
+    const int32_t* begin(int i) const { return idx.data() + off[i]; }
+    const int32_t* end(int i) const { return idx.data() + off[i + 1]; }
 };
 
 struct Plan {  // what the controller keeps of a vehicle's ControlResultsInfo (ControlResultsInfo.m:5-17)
@@ -132,9 +140,23 @@ struct pdmpc_controller {
     // pdmpc_pack_step packs a set it has seen under the same pointer once (api.cpp: pack_common)
     struct MemoKey {  // who contributes, as bit masks over the vehicles (up to 512: larger scenarios build every set)
         uint64_t w[16];
-        bool operator<(const MemoKey& o) const { return std::memcmp(w, o.w, sizeof w) < 0; }
     };
-    std::vector<std::map<MemoKey, pdmpc_polygon_set>> obst_memo, dyn_memo;
+    struct Memo {  // a vehicle's sets built so far this step, by key (a handful: searched front to back)
+        std::vector<MemoKey> keys;
+        std::vector<pdmpc_polygon_set> sets;
+        const pdmpc_polygon_set* find(const MemoKey& k) const {
+            for (size_t q = 0; q < keys.size(); ++q)
+                if (std::memcmp(keys[q].w, k.w, sizeof k.w) == 0) return &sets[q];
+            return nullptr;
+        }
+        void clear() {
+            keys.clear();
+            sets.clear();
+        }
+    };
+    std::vector<Memo> obst_memo, dyn_memo;
+    Lists ls_dir_succ, ls_dir_pred, ls_seq_succ, ls_seq_pred;  // assemble_step's scratch (kept: no allocation per prioritization)
+    std::vector<int> kahn_indeg, kahn_cur, kahn_next;
     pdmpc_polygon_set empty_set{};
     bool empty_done = false;
     bool exploring = false;  // an explorative step is being built: its prioritizations share sets through the memos
@@ -144,6 +166,12 @@ struct pdmpc_controller {
         std::vector<int32_t> levels, order, slot_of;
     };
     std::vector<Instance> inst;
+    struct Part {  // an instance's step problem as assemble_step left it (explore_build's scratch, kept from step to step)
+        std::vector<pdmpc_vehicle_in> in;
+        std::vector<pdmpc_polygon_set> fb;
+        std::vector<int32_t> pred_offset, pred_index;
+    };
+    std::vector<Part> x_parts;
     std::vector<pdmpc_vehicle_in> x_in;
     std::vector<pdmpc_polygon_set> x_fb;
     std::vector<int32_t> x_pred_offset, x_pred_index, x_instance, x_vehicle, x_level, x_slot;  // x_slot[p * n + vehicle] = slot in the flattened batch
@@ -177,14 +205,6 @@ inline void for_each_set(const uint8_t* row, int n, F&& f) {
         if (row[j]) f(j);
 }
 
-// the non-zero entries of a matrix as lists: by row (idx[off[i] .. off[i + 1]) = the columns of row i) or by column (the rows of
-// column j), ascending in both forms
-struct Lists {
-    std::vector<int32_t> off, idx;
-    int size(int i) const { return off[i + 1] - off[i]; }
-    const int32_t* begin(int i) const { return idx.data() + off[i]; }
-    const int32_t* end(int i) const { return idx.data() + off[i + 1]; }
-};
 void lists_by_row(const std::vector<uint8_t>& M, int n, Lists& L) {
     L.off.assign((size_t)n + 1, 0);
     L.idx.clear();
@@ -199,9 +219,9 @@ void lists_by_column(const std::vector<uint8_t>& M, int n, const Lists& by_row, 
     for (int32_t j : by_row.idx) ++L.off[j + 1];
     for (int j = 0; j < n; ++j) L.off[j + 1] += L.off[j];
     L.idx.resize(by_row.idx.size());
-    std::vector<int32_t> fill(L.off.begin(), L.off.end() - 1);
+    L.fill.assign(L.off.begin(), L.off.end() - 1);
     for (int i = 0; i < n; ++i)
-        for (const int32_t* q = by_row.begin(i); q != by_row.end(i); ++q) L.idx[fill[*q]++] = i;
+        for (const int32_t* q = by_row.begin(i); q != by_row.end(i); ++q) L.idx[L.fill[*q]++] = i;
 }
 
 // utility/kahn.m:1-24: computation level (1-based) of every vertex of the DAG A (A[i][j] = 1: i before j)
@@ -232,9 +252,10 @@ bool kahn(const std::vector<uint8_t>& A, int n, std::vector<int32_t>& L) {
 }
 
 // kahn over the successor lists of the matrix
-bool kahn_lists(const Lists& succ, int n, std::vector<int32_t>& L) {
+bool kahn_lists(const Lists& succ, int n, std::vector<int32_t>& L, std::vector<int>& indeg, std::vector<int>& cur, std::vector<int>& next) {
     L.assign(n, 0);
-    std::vector<int> indeg(n, 0), cur, next;
+    indeg.assign(n, 0);
+    cur.clear();
     for (int32_t j : succ.idx) ++indeg[j];
     for (int j = 0; j < n; ++j)
         if (indeg[j] == 0) cur.push_back(j);
@@ -595,7 +616,7 @@ bool group(pdmpc_controller& c, const std::vector<uint8_t>& directed, const List
            std::vector<int32_t>& L, bool& uncut) {
     const int n = c.n;
     uncut = false;
-    if (!kahn_lists(dir_succ, n, L)) return false;
+    if (!kahn_lists(dir_succ, n, L, c.kahn_indeg, c.kahn_cur, c.kahn_next)) return false;
     int depth = 0;
     for (int v : L) depth = std::max(depth, v);
     if (depth <= c.cfg.max_num_CLs) {
@@ -803,8 +824,12 @@ int pdmpc_controller_build_step(pdmpc_controller* c) {
     c->k += 1;
     c->arena.reset();
     if (c->exploring) {
-        c->obst_memo.assign((size_t)n, {});
-        c->dyn_memo.assign((size_t)n, {});
+        c->obst_memo.resize((size_t)n);
+        c->dyn_memo.resize((size_t)n);
+        for (int v = 0; v < n; ++v) {
+            c->obst_memo[(size_t)v].clear();
+            c->dyn_memo[(size_t)v].clear();
+        }
     }
     c->fb_of.assign(n, pdmpc_polygon_set());
     c->fb_done.assign(n, 0);
@@ -874,7 +899,7 @@ int assemble_step(pdmpc_controller* c, bool seq_given) {
     const int n = c->n, Hp = c->Hp;
     // (seq_given: c->directed_seq is the caller's -- the explorative step swaps single couplings of the base prioritization)
     // who a vehicle is coupled with, as lists: the loops below visit a vehicle's few couplings, not rows and columns of the matrices
-    Lists dir_succ, dir_pred, seq_succ_own, seq_pred_own;
+    Lists &dir_succ = c->ls_dir_succ, &dir_pred = c->ls_dir_pred, &seq_succ_own = c->ls_seq_succ, &seq_pred_own = c->ls_seq_pred;
     lists_by_row(c->directed, n, dir_succ);
     lists_by_column(c->directed, n, dir_succ, dir_pred);
     bool uncut = false;
@@ -882,14 +907,23 @@ int assemble_step(pdmpc_controller* c, bool seq_given) {
     if (!uncut) {  // (uncut: the sequential coupling is `directed` itself, levels and lists included)
         lists_by_row(c->directed_seq, n, seq_succ_own);
         lists_by_column(c->directed_seq, n, seq_succ_own, seq_pred_own);
-        if (!kahn_lists(seq_succ_own, n, c->levels)) return cfail(c, PDMPC_ERR_INVALID, "coupling graph has a cycle");
+        if (!kahn_lists(seq_succ_own, n, c->levels, c->kahn_indeg, c->kahn_cur, c->kahn_next)) return cfail(c, PDMPC_ERR_INVALID, "coupling graph has a cycle");
     }
     const Lists& seq_pred = uncut ? dir_pred : seq_pred_own;
+    // slot order: by level, vehicles of a level in index order (a counting sort over the levels 1 .. n)
     c->order.resize(n);
-    for (int i = 0; i < n; ++i) c->order[i] = i;
-    std::stable_sort(c->order.begin(), c->order.end(), [&](int a, int b) { return c->levels[a] < c->levels[b]; });
     c->slot_of.assign(n, 0);
-    for (int s = 0; s < n; ++s) c->slot_of[c->order[s]] = s;
+    {
+        std::vector<int>& first = c->kahn_cur;  // (scratch) first[l] = slot of level l's first vehicle
+        first.assign((size_t)n + 2, 0);
+        for (int i = 0; i < n; ++i) ++first[(size_t)c->levels[i] + 1];
+        for (int l = 1; l <= n + 1; ++l) first[l] += first[l - 1];
+        for (int i = 0; i < n; ++i) {
+            const int s = first[(size_t)c->levels[i]]++;
+            c->order[s] = i;
+            c->slot_of[i] = s;
+        }
+    }
     // ---- per slot inputs
     c->in.assign(n, pdmpc_vehicle_in());
     c->fb.assign(n, pdmpc_polygon_set());
@@ -970,13 +1004,21 @@ int assemble_step(pdmpc_controller* c, bool seq_given) {
         };
         if (memo) {
             auto& om = c->obst_memo[(size_t)i];
-            auto oit = om.find(ok);
-            if (oit == om.end()) oit = om.emplace(ok, build_obst()).first;
+            if (const pdmpc_polygon_set* hit = om.find(ok)) {
+                I.obstacles = *hit;
+            } else {
+                I.obstacles = build_obst();
+                om.keys.push_back(ok);
+                om.sets.push_back(I.obstacles);
+            }
             auto& dm = c->dyn_memo[(size_t)i];
-            auto dit = dm.find(dk);
-            if (dit == dm.end()) dit = dm.emplace(dk, build_dyn()).first;
-            I.obstacles = oit->second;
-            I.dynamic_obstacles = dit->second;
+            if (const pdmpc_polygon_set* hit = dm.find(dk)) {
+                I.dynamic_obstacles = *hit;
+            } else {
+                I.dynamic_obstacles = build_dyn();
+                dm.keys.push_back(dk);
+                dm.sets.push_back(I.dynamic_obstacles);
+            }
         } else {
             I.obstacles = build_obst();
             I.dynamic_obstacles = build_dyn();
@@ -1298,20 +1340,28 @@ int pdmpc_controller_explore_build(pdmpc_controller* c, int32_t n_perm, uint32_t
     std::vector<int32_t> perms((size_t)n_perm * n_levels);
     rc = pdmpc_exploration_permutations(n_levels, n_perm, seed, perms.data());
     if (rc) return rc;
-    struct Part {
-        std::vector<pdmpc_vehicle_in> in;
-        std::vector<pdmpc_polygon_set> fb;
-        std::vector<int32_t> pred_offset, pred_index;
-    };
-    std::vector<Part> parts((size_t)n_perm);
-    c->inst.assign((size_t)n_perm, pdmpc_controller::Instance());
+    // (copies into vectors that are kept from step to step: no allocation once warm)
+    using Part = pdmpc_controller::Part;
+    std::vector<Part>& parts = c->x_parts;
+    if (parts.size() < (size_t)n_perm) parts.resize((size_t)n_perm);
+    if (c->inst.size() != (size_t)n_perm) c->inst.resize((size_t)n_perm);
     auto keep = [&](int p) {
-        parts[(size_t)p] = Part{c->in, c->fb, c->pred_offset, c->pred_index};
-        c->inst[(size_t)p] = pdmpc_controller::Instance{c->directed, c->directed_seq, c->levels, c->order, c->slot_of};
+        Part& P = parts[(size_t)p];
+        P.in = c->in;
+        P.fb = c->fb;
+        P.pred_offset = c->pred_offset;
+        P.pred_index = c->pred_index;
+        pdmpc_controller::Instance& I = c->inst[(size_t)p];
+        I.directed = c->directed;
+        I.directed_seq = c->directed_seq;
+        I.levels = c->levels;
+        I.order = c->order;
+        I.slot_of = c->slot_of;
     };
     keep(0);
+    std::vector<int32_t> where;
     for (int p = 1; p < n_perm; ++p) {
-        std::vector<int32_t> where((size_t)n_levels + 1, 0);
+        where.assign((size_t)n_levels + 1, 0);
         for (int j = 0; j < n_levels; ++j) where[(size_t)perms[(size_t)p * n_levels + j]] = j + 1;
         // prepare_permutation (:64-77): every coupling i -> j of the base prioritization whose permuted levels invert it is swapped
         // in ALL coupling matrices (swap_entries_all_coupling_matrices): a sequential coupling stays sequential, a parallel one

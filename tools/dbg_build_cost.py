@@ -13,15 +13,24 @@ from pdmpc.road_network import commonroad_scenario
 
 w = sys.argv[1] if len(sys.argv) > 1 else "c3"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-n, hp, cl = {"c3": (128, 8, 2), "c4": (512, 10, 99), "c2": (20, 6, 99)}[w]
+n, hp, cl = {"c3": (128, 8, 2), "c4": (512, 10, 99), "c2": (20, 8, 99), "c5": (20, 8, 99)}[w]
 options = Config(scenario_type=ScenarioType.commonroad, amount=n, Hp=hp, max_vehicles=max(n, 32), max_nodes=1 << 22, max_num_CLs=cl)
 mpa = get_mpa(options)
 nat = NativeController(options, commonroad_scenario(options, seed=1, tiles=max(1, (n + 19) // 20)), mpa, None, coupling="distance",
-                       priority_strategy="constant" if w == "c2" else "coloring")
+                       priority_strategy="constant" if w in ("c2", "c5") else "coloring")
 for k in range(steps):
     nat.build_step()
     recs, _ = oracle.plan_step(options, mpa, nat.problem())
     nat.apply(recs)
+if w == "c5":  # the explorative step's 64 prioritizations (the build advances the step counter only)
+    best = 1e9
+    for _ in range(8):
+        t0 = time.perf_counter()
+        for _ in range(50):
+            nat.explore_build(64, 7)
+        best = min(best, (time.perf_counter() - t0) / 50 * 1e3)
+    print("c5: explore_build(64) %.3f ms" % best)
+    sys.exit(0)
 reps, best = 100, 1e9
 for _ in range(8):
     t0 = time.perf_counter()
