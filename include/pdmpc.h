@@ -209,7 +209,9 @@ int pdmpc_plan_step_literal(pdmpc_handle* handle, int32_t n_vehicles, const pdmp
 /* ---- device-resident path used by the batched host driver and bench.py ----
  * pdmpc_pack_batch flattens host inputs into the handle's device blob (H2D copy, async on the
  * handle's stream); pdmpc_launch_packed runs the search kernel on whatever is packed (no copies);
- * pdmpc_fetch_results copies the result records back.  pdmpc_plan_batch == pack + launch + fetch. */
+ * pdmpc_fetch_results copies the result records back.  pdmpc_plan_batch == pack + launch + fetch.
+ * A pack writes the batch straight into the selected bank's staging memory: one that fails (invalid input, out of memory) leaves that
+ * bank EMPTY — the batch that was in it is gone, a launch on it returns PDMPC_ERR_INVALID until the next successful pack. */
 int pdmpc_pack_batch(pdmpc_handle* handle, int32_t n_vehicles, const pdmpc_vehicle_in* in);
 /* pdmpc_plan_step for a caller that keeps only a few of the batch's plans (the explorative step: the choice among the prioritizations
  * rests on the cost-to-come of every vehicle's final node, PrioritizedExplorativeController.m:94-112, and only the chosen plans are
