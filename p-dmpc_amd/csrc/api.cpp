@@ -155,6 +155,7 @@ struct PackedStep {
     int32_t* d_pred = nullptr;
     uint64_t staged_serial = ~0ull;  // the handle's sync_serial when the copy out of h_blob was queued (pack_common)
     int n_packed = 0;
+    bool pack_failed = false;  // the last pack into this bank did not finish: nothing to launch or fetch
     int soup_cap = 0;
     int cand_cap = 0;  // most segments any single edge check can see (one step's soups + the boundary)
     std::vector<int64_t> lit_cols;  // per slot: literal soup + boundary columns (for the bytes formula)
@@ -520,6 +521,7 @@ int pack_common(pdmpc_handle* h, int n, const pdmpc_vehicle_in* in, const int32_
     const size_t pred_bytes = ((total_pred + 1) * sizeof(int32_t) + 15) & ~(size_t)15;
     const size_t pts_base = veh_bytes + pred_bytes;
     B.n_packed = 0;  // (a pack that fails leaves the bank empty: the batch that was in it is being overwritten)
+    B.pack_failed = true;
     B.h_veh = nullptr;
     B.h_pts = nullptr;
     B.h_pred = nullptr;
@@ -796,6 +798,7 @@ int pack_common(pdmpc_handle* h, int n, const pdmpc_vehicle_in* in, const int32_
     HIPCHK(hipMemcpyAsync(B.d_blob.p, B.h_blob.p, total, hipMemcpyHostToDevice, h->stream));
     B.staged_serial = h->sync_serial;
     B.n_packed = n;
+    B.pack_failed = false;
     h->events_used = 0;
     h->folded_kernel_ms = 0.0;
     h->folded_launches = 0;
@@ -834,6 +837,7 @@ int alloc_arenas(pdmpc_handle* h, uint32_t nodes) {
 int launch_range(pdmpc_handle* h, int first, int count, bool safe = false) {
     if (!h) return fail(PDMPC_ERR_INVALID, "null handle");
     PackedStep& B = h->banks[h->bank];
+    if (B.pack_failed) return fail(PDMPC_ERR_INVALID, "the last pack into this bank failed: nothing is packed");
     if (first < 0 || count < 0 || first + count > B.n_packed) return fail(PDMPC_ERR_INVALID, "launch range outside the packed batch");
     if (!B.perm.empty() && (first != 0 || count != B.n_packed)) return fail(PDMPC_ERR_INVALID, "range launches need a batch packed in level order (predecessors in lower slots)");
     if (count == 0) return PDMPC_OK;

@@ -238,6 +238,29 @@ def test_empty_batch_and_errors():
     h.close()
 
 
+def test_a_failed_pack_leaves_its_bank_empty():
+    """pdmpc_pack_batch writes the batch straight into the bank's staging memory (include/pdmpc.h): a pack that fails half-way — the
+    second vehicle's trim is out of range — leaves no batch behind (a launch is refused, a fetch returns nothing of the old batch's),
+    and the next pack works as if nothing had happened."""
+    import copy
+
+    from pdmpc.backend import BackendError
+
+    options, mpa, iters = problems.problem_set("interx", 7, 6, Hp=6)
+    _, ref, _ = _oracle().plan_batch(options, mpa, iters)
+    h = Handle(options)
+    h.upload_mpa(mpa)
+    assert_records_equal(h.plan_batch(iters), ref, "before")
+    bad = [copy.copy(it) for it in iters]
+    bad[1].trim_index = 10 ** 6
+    with pytest.raises(BackendError):
+        h.pack_batch(bad)
+    with pytest.raises(BackendError):
+        h.launch()
+    assert_records_equal(h.plan_batch(iters), ref, "after")
+    h.close()
+
+
 def test_interx_with_hdv_reachable_sets():
     """are_constraints_satisfied_interx.m:23-31: the HDV soup is a third curve set checked with the normal-offset area."""
     options, mpa, iters = problems.problem_set("interx", 31, 16, Hp=6, n_hdv=2)
