@@ -150,3 +150,17 @@ def test_hundred_vehicles_colouring_cut_to_two_levels():
     sc = commonroad_scenario(options, seed=3, tiles=5)
     py = run_both(options, sc, 4, "distance", boundary_provider(sc), priority_strategy="coloring", weight_strategy="distance")
     assert int(py.last_levels.max()) <= 2
+
+
+@pytest.mark.parametrize("mode", ["none", "area_of_previous_trajectory"])
+def test_other_constraints_from_successors(mode):
+    """Config.m:37 constraint_from_successor: successors contribute nothing (none) or their previous plan shifted by one step
+    (area_of_previous_trajectory, PrioritizedController.m:541-553) instead of their standstill rectangle — the other branches of the
+    per-slot contributor loops, and of what an exhausted vehicle publishes."""
+    from pdmpc.config import ConstraintFromSuccessor
+    from pdmpc.road_network import boundary_provider, commonroad_scenario
+
+    options = Config(scenario_type=ScenarioType.commonroad, amount=30, Hp=5, max_num_CLs=2, max_nodes=1 << 20,
+                     constraint_from_successor=ConstraintFromSuccessor[mode])
+    sc = commonroad_scenario(options, seed=4, tiles=2)
+    run_both(options, sc, 6, "distance", boundary_provider(sc), priority_strategy="coloring", weight_strategy="distance")
